@@ -1,0 +1,346 @@
+// ORACLE / TEST INFRASTRUCTURE ONLY - never linked into libetx_hip.so.
+//
+// Headless driver around the reference's own host code, compiled read-only from /root/reference:
+//   SceneRepresentation::load_from_file  (sources/etx/render/host/scene_representation.cxx:679-838)
+//   Raytracing::commit_changes           (sources/etx/rt/rt.cxx:58-64; here: oracle/shims/raytracing_bvh.cxx)
+//   CPUPathTracing / CPUVCM ::run/update (sources/etx/rt/integrators/path_tracing.cxx:85-110, vcm_cpu.cxx:255-276)
+//   Film::layer                          (sources/etx/render/host/film.cxx:381-418)
+// It replaces the GUI pump of sources/raytracer/app.cxx:126-159 with a loop over Integrator::update() until
+// State::Stopped, then writes the film layers as raw float4 and (optionally) a byte-exact snapshot of the loaded
+// etx::Scene / etx::Camera (the input ABI of the HIP backend) so that GPU-side tests and bench.py
+// can run where /root/reference does not exist.
+//
+// Output formats (little endian):
+//   film  : "ETXFILM1" u32 width u32 height u32 layers u32 spp f64 seconds u32 threads u32 pad ; layers * (w*h float4)
+//           layer order: Film::CameraImage, Film::LightImage, Film::Result
+//   scene : see write_snapshot() below ("ETXSCENE1")
+#include <etx/core/core.hxx>
+#include <etx/core/environment.hxx>
+#include <etx/render/host/film.hxx>
+#include <etx/render/host/scene_representation.hxx>
+#include <etx/render/shared/ior_database.hxx>
+#include <etx/rt/integrators/path_tracing.hxx>
+#include <etx/rt/integrators/vcm_cpu.hxx>
+#include <etx/rt/integrators/bidirectional.hxx>
+#include <etx/rt/shared/vcm_shared.hxx>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace etx {
+extern std::atomic<uint64_t> g_oracle_rays_trace;
+extern std::atomic<uint64_t> g_oracle_rays_transmittance;
+extern std::atomic<uint64_t> g_oracle_rays_material;
+}  // namespace etx
+
+using namespace etx;
+
+namespace {
+
+struct Blob {
+  std::vector<uint8_t> bytes;
+
+  uint64_t append(const void* p, uint64_t size) {
+    uint64_t offset = (bytes.size() + 15u) & ~uint64_t(15);
+    bytes.resize(offset + size);
+    if (size > 0)
+      memcpy(bytes.data() + offset, p, size);
+    return offset;
+  }
+};
+
+// Snapshot layout:
+//   "ETXSCENE1" (16 bytes, zero padded) | u64 scene_offset | u64 camera_offset | u64 fixup_count | u64 total_size
+//   fixups[fixup_count] : u64 offset-of-pointer-field (the field holds a blob offset, 0 = null) |
+//   payload (16-byte aligned chunks: raw Scene bytes, raw Camera bytes, every array an ArrayView points to)
+// Loading = read file, add the base address to every listed pointer field.
+struct Snapshot {
+  Blob blob;
+  std::vector<uint64_t> fixups;
+
+  template <class T>
+  void patch(uint64_t struct_offset, const ArrayView<T>& view_in_struct, const void* struct_base, uint64_t data_offset) {
+    uint64_t field = struct_offset + uint64_t(reinterpret_cast<const uint8_t*>(&view_in_struct.a) - reinterpret_cast<const uint8_t*>(struct_base));
+    uint64_t value = view_in_struct.count ? data_offset : 0;
+    memcpy(blob.bytes.data() + field, &value, sizeof(uint64_t));
+    fixups.push_back(field);
+  }
+
+  template <class T>
+  uint64_t store_array(uint64_t struct_offset, const ArrayView<T>& view, const void* struct_base) {
+    uint64_t off = blob.append(view.a, view.count * sizeof(T));
+    patch(struct_offset, view, struct_base, off);
+    return off;
+  }
+
+  void store_distribution(uint64_t struct_offset, const Distribution& d, const void* struct_base) {
+    store_array(struct_offset, d.values, struct_base);
+  }
+};
+
+bool write_snapshot(const char* path, const Scene& scene, const Camera& camera) {
+  Snapshot s;
+  s.blob.bytes.reserve(1u << 20);
+  s.blob.bytes.resize(64);  // header placeholder
+
+  uint64_t scene_off = s.blob.append(&scene, sizeof(Scene));
+  uint64_t camera_off = s.blob.append(&camera, sizeof(Camera));
+
+  s.store_array(scene_off, scene.vertices, &scene);
+  s.store_array(scene_off, scene.triangles, &scene);
+  s.store_array(scene_off, scene.triangle_to_emitter, &scene);
+  s.store_array(scene_off, scene.materials, &scene);
+  s.store_array(scene_off, scene.emitter_profiles, &scene);
+  s.store_array(scene_off, scene.emitter_instances, &scene);
+  s.store_array(scene_off, scene.spectrums, &scene);
+  s.store_distribution(scene_off, scene.emitters_distribution, &scene);
+
+  uint64_t images_off = s.store_array(scene_off, scene.images, &scene);
+  for (uint64_t i = 0; i < scene.images.count; ++i) {
+    const Image& img = scene.images[i];
+    uint64_t img_off = images_off + i * sizeof(Image);
+    if (img.format == Image::Format::RGBA8) {
+      s.store_array(img_off, img.pixels.u8, &img);
+    } else {
+      s.store_array(img_off, img.pixels.f32, &img);
+    }
+    s.store_distribution(img_off, img.y_distribution, &img);
+    uint64_t xd_off = s.store_array(img_off, img.x_distributions, &img);
+    for (uint64_t j = 0; j < img.x_distributions.count; ++j) {
+      s.store_distribution(xd_off + j * sizeof(Distribution), img.x_distributions[j], &img.x_distributions[j]);
+    }
+  }
+
+  uint64_t mediums_off = s.store_array(scene_off, scene.mediums, &scene);
+  for (uint64_t i = 0; i < scene.mediums.count; ++i) {
+    const Medium& m = scene.mediums[i];
+    s.store_array(mediums_off + i * sizeof(Medium), m.density, &m);
+  }
+
+  uint64_t fix_off = s.blob.append(s.fixups.data(), s.fixups.size() * sizeof(uint64_t));
+  uint64_t total = s.blob.bytes.size();
+
+  uint8_t header[64] = {};
+  memcpy(header, "ETXSCENE1", 9);
+  uint64_t fields[6] = {scene_off, camera_off, uint64_t(s.fixups.size()), fix_off, total, (uint64_t(sizeof(Scene)) << 32) | uint64_t(sizeof(Camera))};
+  memcpy(header + 16, fields, sizeof(fields));
+  memcpy(s.blob.bytes.data(), header, sizeof(header));
+
+  FILE* f = fopen(path, "wb");
+  if (f == nullptr)
+    return false;
+  fwrite(s.blob.bytes.data(), 1, s.blob.bytes.size(), f);
+  fclose(f);
+  printf("snapshot: %s (%llu bytes, %llu pointer fixups)\n", path, (unsigned long long)total, (unsigned long long)s.fixups.size());
+  return true;
+}
+
+bool write_film(const char* path, Film& film, uint32_t spp, double seconds, uint32_t threads) {
+  FILE* f = fopen(path, "wb");
+  if (f == nullptr)
+    return false;
+  uint2 dim = film.size();
+  char magic[8] = {'E', 'T', 'X', 'F', 'I', 'L', 'M', '1'};
+  uint32_t head[4] = {dim.x, dim.y, 3u, spp};
+  uint32_t tail[2] = {threads, 0u};
+  fwrite(magic, 1, 8, f);
+  fwrite(head, sizeof(uint32_t), 4, f);
+  fwrite(&seconds, sizeof(double), 1, f);
+  fwrite(tail, sizeof(uint32_t), 2, f);
+  const uint32_t layers[3] = {Film::CameraImage, Film::LightImage, Film::Result};
+  for (uint32_t l : layers) {
+    const float4* data = film.layer(l);
+    fwrite(data, sizeof(float4), size_t(dim.x) * dim.y, f);
+  }
+  fclose(f);
+  return true;
+}
+
+// Inverse of write_snapshot: returns pointers into `storage`.
+bool load_snapshot(const char* path, std::vector<uint8_t>& storage, const Scene*& scene, const Camera*& camera) {
+  if (load_binary_file(path, storage) == false)
+    return false;
+  if ((storage.size() < 64) || (memcmp(storage.data(), "ETXSCENE1", 9) != 0))
+    return false;
+  uint64_t fields[6] = {};
+  memcpy(fields, storage.data() + 16, sizeof(fields));
+  if ((fields[4] != storage.size()) || (fields[5] != ((uint64_t(sizeof(Scene)) << 32) | uint64_t(sizeof(Camera)))))
+    return false;
+  uint64_t base = reinterpret_cast<uint64_t>(storage.data());
+  for (uint64_t i = 0; i < fields[2]; ++i) {
+    uint64_t field_offset = 0;
+    memcpy(&field_offset, storage.data() + fields[3] + i * sizeof(uint64_t), sizeof(uint64_t));
+    uint64_t value = 0;
+    memcpy(&value, storage.data() + field_offset, sizeof(uint64_t));
+    value = value ? value + base : 0;
+    memcpy(storage.data() + field_offset, &value, sizeof(uint64_t));
+  }
+  scene = reinterpret_cast<const Scene*>(storage.data() + fields[0]);
+  camera = reinterpret_cast<const Camera*>(storage.data() + fields[1]);
+  return true;
+}
+
+void usage() {
+  printf(
+    "etx_oracle --scene file.json | --load-snapshot scene.bin --integrator pt|vcm|bdpt [--spp N] [--out film.raw] [--snapshot scene.bin]\n"
+    "           [--data /root/reference/bin/] [--opt key=value]... [--max-iterations N]\n");
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::string load_snapshot_file;
+  std::string scene_file, integrator_name = "vcm", out_file, snapshot_file, data_folder = "/root/reference/bin/";
+  std::vector<std::pair<std::string, std::string>> opts;
+  int64_t spp = -1;
+  int64_t max_iterations = -1;
+  for (int i = 1; i < argc; ++i) {
+    auto next = [&]() -> const char* {
+      return (i + 1 < argc) ? argv[++i] : "";
+    };
+    if (strcmp(argv[i], "--scene") == 0)
+      scene_file = next();
+    else if (strcmp(argv[i], "--load-snapshot") == 0)
+      load_snapshot_file = next();
+    else if (strcmp(argv[i], "--integrator") == 0)
+      integrator_name = next();
+    else if (strcmp(argv[i], "--spp") == 0)
+      spp = atoll(next());
+    else if (strcmp(argv[i], "--max-iterations") == 0)
+      max_iterations = atoll(next());
+    else if (strcmp(argv[i], "--out") == 0)
+      out_file = next();
+    else if (strcmp(argv[i], "--snapshot") == 0)
+      snapshot_file = next();
+    else if (strcmp(argv[i], "--data") == 0)
+      data_folder = next();
+    else if (strcmp(argv[i], "--opt") == 0) {
+      std::string kv = next();
+      auto eq = kv.find('=');
+      if (eq != std::string::npos)
+        opts.emplace_back(kv.substr(0, eq), kv.substr(eq + 1));
+    } else {
+      usage();
+      return 1;
+    }
+  }
+  if (scene_file.empty() && load_snapshot_file.empty()) {
+    usage();
+    return 1;
+  }
+
+  init_platform();
+  env().setup(argv[0]);
+
+  IORDatabase ior_database;
+  Raytracing raytracing;
+  SceneRepresentation scene(raytracing.scheduler(), ior_database);
+  std::vector<uint8_t> snapshot_storage;
+  const Scene* scene_ptr = &scene.scene();
+  const Camera* camera_ptr = &scene.camera();
+
+  if (load_snapshot_file.empty()) {
+    ior_database.load((data_folder + "spectrum/").c_str());
+    if (scene.load_from_file(scene_file.c_str(), SceneRepresentation::LoadEverything) == false) {
+      printf("failed to load %s\n", scene_file.c_str());
+      return 2;
+    }
+    if (spp > 0) {
+      scene.mutable_scene().samples = uint32_t(spp);
+    }
+  } else {
+    if (load_snapshot(load_snapshot_file.c_str(), snapshot_storage, scene_ptr, camera_ptr) == false) {
+      printf("failed to load snapshot %s\n", load_snapshot_file.c_str());
+      return 2;
+    }
+    if (spp > 0) {
+      const_cast<Scene*>(scene_ptr)->samples = uint32_t(spp);
+    }
+  }
+  raytracing.link_scene(*scene_ptr);
+  raytracing.link_camera(*camera_ptr);
+  raytracing.commit_changes();
+
+  const Scene& sc = *scene_ptr;
+  const Camera& cam = *camera_ptr;
+  printf("scene: %llu vertices, %llu triangles, %llu materials, %llu emitters, %llu spectrums, %llu images, %llu mediums, radius %.4f, spectral %d\n",
+    (unsigned long long)sc.vertices.count, (unsigned long long)sc.triangles.count, (unsigned long long)sc.materials.count, (unsigned long long)sc.emitter_instances.count,
+    (unsigned long long)sc.spectrums.count, (unsigned long long)sc.images.count, (unsigned long long)sc.mediums.count, sc.bounding_sphere_radius, int(sc.spectral()));
+  printf("film: %u x %u, samples %u, max path %u, rr start %u\n", cam.film_size.x, cam.film_size.y, sc.samples, sc.max_path_length, sc.random_path_termination);
+
+  if (snapshot_file.empty() == false) {
+    if (write_snapshot(snapshot_file.c_str(), sc, cam) == false) {
+      printf("failed to write %s\n", snapshot_file.c_str());
+      return 3;
+    }
+  }
+
+  if (integrator_name == "none")
+    return 0;
+
+  CPUPathTracing pt(raytracing);
+  CPUVCM vcm(raytracing);
+  CPUBidirectional bdpt(raytracing);
+  Integrator* integrator = nullptr;
+  if (integrator_name == "pt")
+    integrator = &pt;
+  else if (integrator_name == "vcm")
+    integrator = &vcm;
+  else if (integrator_name == "bdpt")
+    integrator = &bdpt;
+  else {
+    usage();
+    return 1;
+  }
+
+  for (const auto& kv : opts) {
+    auto& o = integrator->options();
+    if ((kv.second == "true") || (kv.second == "false"))
+      o.set_bool(kv.first, kv.second == "true", kv.first);
+    else if (kv.second.find('.') != std::string::npos)
+      o.set_float(kv.first, float(atof(kv.second.c_str())), kv.first);
+    else
+      o.set_integral(kv.first, uint32_t(atoll(kv.second.c_str())), kv.first);
+  }
+
+  raytracing.film().clear(Film::ClearEverything);
+  auto t0 = std::chrono::steady_clock::now();
+  integrator->run();
+  while (integrator->state() != Integrator::State::Stopped) {
+    integrator->update();
+    if ((max_iterations > 0) && (int64_t(integrator->status().completed_iterations) >= max_iterations) && (integrator->state() == Integrator::State::Running)) {
+      integrator->stop(Integrator::Stop::WaitForCompletion);
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+  double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+  const auto& st = integrator->status();
+  uint32_t threads = raytracing.scheduler().max_thread_count() - 2u;
+  uint64_t pixels = uint64_t(cam.film_size.x) * cam.film_size.y;
+  double msamples = double(pixels) * double(st.completed_iterations) / st.total_time / 1.0e6;
+  printf("integrator %s: %u iterations, total_time %.4f s (wall %.4f s), %u threads, %.4f Msamples/s\n", integrator->name(), st.completed_iterations, st.total_time, wall, threads,
+    msamples);
+  uint64_t r0 = g_oracle_rays_trace.load(), r1 = g_oracle_rays_transmittance.load(), r2 = g_oracle_rays_material.load();
+  if (r0 + r1 + r2 > 0) {
+    double samples = double(pixels) * double(st.completed_iterations);
+    printf("rays: trace %llu transmittance %llu material %llu -> %.3f rays/sample\n", (unsigned long long)r0, (unsigned long long)r1, (unsigned long long)r2,
+      double(r0 + r1 + r2) / samples);
+  }
+  // machine readable line for bench.py / tests
+  printf("ORACLE_RESULT {\"integrator\": \"%s\", \"iterations\": %u, \"seconds\": %.6f, \"threads\": %u, \"msamples_per_s\": %.6f, \"width\": %u, \"height\": %u}\n",
+    integrator_name.c_str(), st.completed_iterations, st.total_time, threads, msamples, cam.film_size.x, cam.film_size.y);
+
+  if (out_file.empty() == false) {
+    if (write_film(out_file.c_str(), raytracing.film(), st.completed_iterations, st.total_time, threads) == false) {
+      printf("failed to write %s\n", out_file.c_str());
+      return 4;
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,65 @@
+// ORACLE / TEST INFRASTRUCTURE ONLY - never linked into libetx_hip.so.
+//
+// Linux stand-ins for the few host functions the reference only implements for Windows/macOS
+// (reference: sources/etx/core/platform.cxx:9-52 has no Linux branch; core/windows.cxx / core/macos.cxx
+// provide init_platform + log::set_console_color). Needed so that the reference's own integrator, film and
+// scene-loader sources can be compiled read-only from /root/reference into oracle/_ref/.
+#include <etx/core/core.hxx>
+#include <etx/core/log.hxx>
+
+#include <atomic>
+#include <cstring>
+#include <string>
+
+namespace etx {
+
+uint32_t atomic_inc(int32_t* ptr) {
+  // semantics of _InterlockedIncrement: returns the incremented value (platform.cxx:13-15)
+  return static_cast<uint32_t>(__atomic_add_fetch(ptr, 1, __ATOMIC_SEQ_CST));
+}
+
+uint64_t atomic_inc(int64_t* ptr) {
+  return static_cast<uint64_t>(__atomic_add_fetch(ptr, int64_t(1), __ATOMIC_SEQ_CST));
+}
+
+int64_t atomic_add_int64(int64_t* ptr, int64_t value) {
+  // _InterlockedExchangeAdd64 returns the previous value (platform.cxx:31-33)
+  return __atomic_fetch_add(ptr, value, __ATOMIC_SEQ_CST);
+}
+
+uint32_t atomic_compare_exchange(int32_t* ptr, int32_t old_value, int32_t new_value) {
+  int32_t expected = old_value;
+  __atomic_compare_exchange_n(ptr, &expected, new_value, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return static_cast<uint32_t>(expected);
+}
+
+void atomic_add_float(float* ptr, float value) {
+  // CAS loop on the bit pattern, as platform.cxx:36-52 does
+  auto iptr = reinterpret_cast<uint32_t*>(ptr);
+  uint32_t old_bits = __atomic_load_n(iptr, __ATOMIC_RELAXED);
+  for (;;) {
+    float old_value;
+    memcpy(&old_value, &old_bits, sizeof(float));
+    float new_value = old_value + value;
+    uint32_t new_bits;
+    memcpy(&new_bits, &new_value, sizeof(float));
+    if (__atomic_compare_exchange_n(iptr, &old_bits, new_bits, true, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED))
+      break;
+  }
+}
+
+std::string open_file(const char*) {
+  return {};
+}
+
+std::string save_file(const char*) {
+  return {};
+}
+
+void init_platform() {
+}
+
+void log::set_console_color(log::Color) {
+}
+
+}  // namespace etx

@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Authors the benchmark / parity scenes as OBJ + MTL + JSON files that the reference's own loader reads.
+
+The reference snapshot ships no geometry (`bin/assets/cornellbox/cornellbox.obj` is a missing blob, see
+/root/reference/.MISSING_LARGE_BLOBS); only the Cornell camera (`cornellbox.json:9-35`) and materials
+(`cornellbox.mtl`) survive. This script rebuilds the Cornell box for that camera (box x in [-1,1], y in [0,2],
+z in [-1,1], open towards +z, camera at (0,1,3.82) looking down -z, fov 39.5978 deg) with those material
+definitions, in two flavours:
+
+  cornell_classic : diffuse walls / short box, delta silver conductor tall box, blackbody area light
+  cornell_full    : + `et::env`, `et::dir`, and the `fog` boundary box with the `fog__vol` scattering medium
+                    (the full surviving cornellbox.mtl)
+
+and one JSON per configuration of BASELINE.json (resolution / spp), plus small variants for tests.
+Run: python3 scenes/make_scenes.py   (writes scenes/cornell/*)
+"""
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "cornell")
+
+
+def cornell_to_scene(X, Y, Z):
+    """Classic Cornell box data (x 0..556, y 0..548.8, z 0..559.2, camera at z=-800 looking +z) -> our frame."""
+    return (-(X - 278.0) / 278.0, Y / 274.4, 1.0 - Z / 279.6)
+
+
+class Mesh:
+    def __init__(self):
+        self.v = []
+        self.vn = []
+        self.groups = []  # (material, [(vi, ni) * 3])
+
+    def quad(self, mat, pts, normal_hint=None):
+        """pts: 4 points, counter-clockwise seen from the side the normal points to."""
+        base = len(self.v)
+        self.v.extend(pts)
+        ax = [pts[1][i] - pts[0][i] for i in range(3)]
+        bx = [pts[3][i] - pts[0][i] for i in range(3)]
+        n = [ax[1] * bx[2] - ax[2] * bx[1], ax[2] * bx[0] - ax[0] * bx[2], ax[0] * bx[1] - ax[1] * bx[0]]
+        ln = sum(c * c for c in n) ** 0.5
+        n = [c / ln for c in n]
+        if normal_hint is not None and sum(n[i] * normal_hint[i] for i in range(3)) < 0:
+            raise ValueError("winding does not match the requested normal for %s" % mat)
+        self.vn.append(n)
+        ni = len(self.vn)
+        self.groups.append((mat, [(base + 1, ni), (base + 2, ni), (base + 3, ni)]))
+        self.groups.append((mat, [(base + 1, ni), (base + 3, ni), (base + 4, ni)]))
+
+    def box(self, mat, top, height_y):
+        """top: 4 points of the top face (counter-clockwise seen from above); sides go down to y=0."""
+        bottom = [(p[0], 0.0, p[2]) for p in top]
+        top = [(p[0], height_y, p[2]) for p in top]
+        self.quad(mat, top, (0, 1, 0))
+        for i in range(4):
+            j = (i + 1) % 4
+            self.quad(mat, [top[j], top[i], bottom[i], bottom[j]])
+
+    def aabb(self, mat, lo, hi):
+        """closed axis aligned box with outward normals"""
+        x0, y0, z0 = lo
+        x1, y1, z1 = hi
+        self.quad(mat, [(x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1)], (0, -1, 0))
+        self.quad(mat, [(x0, y1, z0), (x0, y1, z1), (x1, y1, z1), (x1, y1, z0)], (0, 1, 0))
+        self.quad(mat, [(x0, y0, z0), (x0, y0, z1), (x0, y1, z1), (x0, y1, z0)], (-1, 0, 0))
+        self.quad(mat, [(x1, y0, z0), (x1, y1, z0), (x1, y1, z1), (x1, y0, z1)], (1, 0, 0))
+        self.quad(mat, [(x0, y0, z0), (x0, y1, z0), (x1, y1, z0), (x1, y0, z0)], (0, 0, -1))
+        self.quad(mat, [(x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)], (0, 0, 1))
+
+    def write(self, path, mtllib):
+        with open(path, "w") as f:
+            f.write("# Cornell box rebuilt for etx-tracer's surviving camera/materials (scenes/make_scenes.py)\n")
+            f.write("mtllib %s\n" % mtllib)
+            for p in self.v:
+                f.write("v %.6f %.6f %.6f\n" % tuple(p))
+            for n in self.vn:
+                f.write("vn %.6f %.6f %.6f\n" % tuple(n))
+            current = None
+            for mat, idx in self.groups:
+                if mat != current:
+                    f.write("usemtl %s\n" % mat)
+                    current = mat
+                f.write("f " + " ".join("%d//%d" % (vi, ni) for vi, ni in idx) + "\n")
+
+
+def build_mesh(with_fog):
+    m = Mesh()
+    # room, normals pointing inside
+    m.quad("floor", [(-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1)], (0, 1, 0))
+    m.quad("ceiling", [(-1, 2, -1), (1, 2, -1), (1, 2, 1), (-1, 2, 1)], (0, -1, 0))
+    m.quad("frontWall", [(-1, 0, -1), (1, 0, -1), (1, 2, -1), (-1, 2, -1)], (0, 0, 1))
+    m.quad("leftWall", [(-1, 0, 1), (-1, 0, -1), (-1, 2, -1), (-1, 2, 1)], (1, 0, 0))
+    m.quad("rightWall", [(1, 0, -1), (1, 0, 1), (1, 2, 1), (1, 2, -1)], (-1, 0, 0))
+    # light: classic 130 x 105 quad just below the ceiling, facing down
+    lx0, _, lz0 = cornell_to_scene(343.0, 0, 227.0)
+    lx1, _, lz1 = cornell_to_scene(213.0, 0, 332.0)
+    ly = 1.98
+    m.quad("light", [(lx0, ly, lz1), (lx1, ly, lz1), (lx1, ly, lz0), (lx0, ly, lz0)], (0, -1, 0))
+    # boxes
+    short_top = [cornell_to_scene(*p) for p in [(130.0, 165.0, 65.0), (82.0, 165.0, 225.0), (240.0, 165.0, 272.0), (290.0, 165.0, 114.0)]]
+    tall_top = [cornell_to_scene(*p) for p in [(423.0, 330.0, 247.0), (265.0, 330.0, 296.0), (314.0, 330.0, 456.0), (472.0, 330.0, 406.0)]]
+
+    def ccw_from_above(pts):
+        # signed area in the xz plane; counter-clockwise seen from +y means the face normal is +y
+        a = 0.0
+        for i in range(4):
+            j = (i + 1) % 4
+            a += pts[i][2] * pts[j][0] - pts[j][2] * pts[i][0]
+        return pts if a > 0 else list(reversed(pts))
+
+    m.box("shortBox", ccw_from_above(short_top), short_top[0][1])
+    m.box("tallBox", ccw_from_above(tall_top), tall_top[0][1])
+    if with_fog:
+        m.aabb("fog", (-0.99, 0.01, -0.99), (0.99, 1.99, 0.99))
+    return m
+
+
+MTL_COMMON = """newmtl ceiling
+material class diffuse
+Kd 1.000 1.000 1.000
+Pr 0.000
+two_sided 1
+
+newmtl floor
+material class diffuse
+Kd 1.000 1.000 1.000
+Pr 0.000
+two_sided 1
+
+newmtl frontWall
+material class diffuse
+Kd 0.906 0.906 0.906
+Pr 0.000
+two_sided 1
+
+newmtl leftWall
+material class diffuse
+Kd 1.000 0.000 0.000
+Pr 0.000
+two_sided 1
+
+newmtl rightWall
+material class diffuse
+Kd 0.000 1.000 0.000
+Pr 0.000
+two_sided 1
+
+newmtl shortBox
+material class diffuse
+Kd 0.906 0.906 0.906
+Pr 0.000
+two_sided 1
+
+newmtl tallBox
+material class conductor
+int_ior silver
+Ks 1.000 1.000 1.000
+Pr 0.000
+two_sided 1
+
+"""
+
+# A scene without any non-area emitter gets a default atmosphere (sun + sky images) from the loader
+# (scene_representation.cxx: "if (_private->data.emitter_profiles.empty())"); a zero-power directional emitter
+# keeps the classic variant at "area light only" (weight 0 => never sampled, not in environment_emitters).
+MTL_LIGHT_CLASSIC = """newmtl et::dir
+direction 0.0 1.0 0.0
+color 0.0 0.0 0.0
+angular_diameter 0.0000
+
+newmtl light
+material class diffuse
+Kd 0.000 0.000 0.000
+emitter nblackbody 2700 scale 5.0000
+two_sided 1
+
+"""
+
+MTL_LIGHT_FOG = """newmtl light
+material class diffuse
+Kd 0.000 0.000 0.000
+ext_medium fog__vol
+emitter nblackbody 2700 scale 5.0000
+two_sided 1
+
+"""
+
+MTL_FULL_EXTRA = """newmtl et::env
+color nblackbody 12000 scale 0.1000
+
+newmtl et::dir
+direction -0.0000 0.8660 0.5000
+color nblackbody 5800 scale 1.0000
+angular_diameter 0.0000
+
+newmtl et::medium
+id fog__vol
+scattering 0.8000 0.8000 0.8000
+
+newmtl fog
+material class boundary
+int_medium fog__vol
+
+"""
+
+CAMERA = {
+    "class": "perspective",
+    "origin": [0.0, 1.000000238418579, 3.819999933242798],
+    "target": [0.0, 1.000000238418579, -6.179999351501465],
+    "up": [0.0, 0.9999999403953552, -0.0],
+    "fov": 39.597755335771296,
+    "lens-radius": 0.0,
+    "focal-distance": 0.0,
+    "clip-near": 0.10000000149011612,
+    "clip-far": 100.0,
+}
+
+
+def write_json(name, geometry, materials, viewport, samples, max_path_length=1023, rr_start=6):
+    cam = dict(CAMERA)
+    cam["viewport"] = list(viewport)
+    doc = {
+        "geometry": geometry,
+        "materials": materials,
+        "samples": samples,
+        "max-path-length": max_path_length,
+        "random-termination-start": rr_start,
+        "spectral": False,
+        "force-tangents": False,
+        "camera": cam,
+    }
+    with open(os.path.join(OUT, name), "w") as f:
+        json.dump(doc, f, indent=2)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    build_mesh(False).write(os.path.join(OUT, "cornell_classic.obj"), "cornell_classic.mtl")
+    build_mesh(True).write(os.path.join(OUT, "cornell_full.obj"), "cornell_full.mtl")
+    with open(os.path.join(OUT, "cornell_classic.mtl"), "w") as f:
+        f.write(MTL_COMMON + MTL_LIGHT_CLASSIC)
+    with open(os.path.join(OUT, "cornell_full.mtl"), "w") as f:
+        f.write(MTL_FULL_EXTRA + MTL_COMMON + MTL_LIGHT_FOG)
+
+    for flavour in ("classic", "full"):
+        obj, mtl = "cornell_%s.obj" % flavour, "cornell_%s.mtl" % flavour
+        # BASELINE.json configs[0]: PT 512x512 16 spp ; configs[1]: VCM 1920x1080 64 spp
+        write_json("%s_c1_512.json" % flavour, obj, mtl, (512, 512), 16)
+        write_json("%s_c2_1080p.json" % flavour, obj, mtl, (1920, 1080), 64)
+        # test-sized variants (oracle finishes in seconds)
+        write_json("%s_test_128.json" % flavour, obj, mtl, (128, 128), 64)
+        write_json("%s_test_192x108.json" % flavour, obj, mtl, (192, 108), 64)
+        # short paths: isolates direct lighting + first connections
+        write_json("%s_test_128_len3.json" % flavour, obj, mtl, (128, 128), 64, max_path_length=3)
+
+
+if __name__ == "__main__":
+    main()
