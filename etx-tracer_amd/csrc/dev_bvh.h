@@ -1,0 +1,208 @@
+// dev_bvh.h - BVH2 traversal for gfx950: closest hit and transmittance ("shadow") queries.
+//
+// Replaces the reference's Embree calls (sources/etx/rt/rt.cxx:250-278 trace_with_function + the filter lambdas):
+//   closest hit   = Raytracing::trace               rt.cxx:428-466 (skip Void, stochastic alpha, keep closest)
+//   transmittance = Raytracing::trace_transmittance rt.cxx:468-579 (Boundary surfaces are transparent and switch
+//                   the medium by the side of geo_n; anything else occludes; media attenuate the segments)
+// Traversal state: a per-lane stack that lives in LDS, laid out [depth][lane] so a wavefront's pushes/pops hit 64
+// consecutive banks; nodes are 64-byte two-child packets (dev_scene.h). The node/triangle arrays are passed as
+// template-typed pointers so the same code runs from HBM/L2 or from an LDS-staged copy of the tree.
+#pragma once
+
+#include "dev_scene.h"
+
+namespace etxd {
+
+constexpr uint32_t kStackDepth = 32;
+
+struct LaneStack {
+  int32_t* base;    // LDS, this lane's slot of level 0
+  uint32_t stride;  // lanes per level (= block size)
+  ETX_DEV void push(uint32_t& sp, int32_t v) const {
+    base[sp * stride] = v;
+    sp += 1u;
+  }
+  ETX_DEV int32_t pop(uint32_t& sp) const {
+    sp -= 1u;
+    return base[sp * stride];
+  }
+};
+
+struct Hit {
+  float u, v, t;
+  uint32_t tri;  // kInvalid = miss
+};
+
+struct RayQ {
+  f3 o;
+  float tmin;
+  f3 d;
+  float tmax;
+};
+
+ETX_DEV float alpha_random(uint32_t& alpha_seed) {
+  // one uniform per alpha-tested candidate (scene_bsdf.hxx:143 draws smp.next() per candidate);
+  // the stream is private to the ray so the traversal kernels never write path state.
+  Sampler s;
+  s.seed = alpha_seed;
+  float r = s.next();
+  alpha_seed = s.seed;
+  return r;
+}
+
+// scene_bsdf.hxx:128-144 alpha_test_pass: true = the candidate is skipped
+ETX_DEV bool alpha_test_skips(const DScene& scene, uint32_t tri_index, uint32_t material_index, float u, float v, uint32_t& alpha_seed) {
+  const etx_abi_material& mat = scene.materials[material_index];
+  float alpha = mat.opacity;
+  if (mat.scattering.image_index != kInvalid) {
+    const DImage& img = scene.images[mat.scattering.image_index];
+    if (img.options & ETX_IMAGE_HAS_ALPHA) {
+      f2 uv = lerp_uv(scene, scene.triangles[tri_index], barycentrics(u, v));
+      ImageGather g = image_gather(img, uv);
+      alpha *= g.p00.w + g.p01.w + g.p10.w + g.p11.w;
+    }
+  }
+  return alpha <= alpha_random(alpha_seed);
+}
+
+// Slab test of one child box; returns entry distance or +inf when missed.
+ETX_DEV float slab(const f3& lo, const f3& hi, const f3& o, const f3& inv_d, float tmin, float tmax) {
+  float tx0 = (lo.x - o.x) * inv_d.x, tx1 = (hi.x - o.x) * inv_d.x;
+  float ty0 = (lo.y - o.y) * inv_d.y, ty1 = (hi.y - o.y) * inv_d.y;
+  float tz0 = (lo.z - o.z) * inv_d.z, tz1 = (hi.z - o.z) * inv_d.z;
+  float t_enter = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
+  float t_exit = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+  return (t_enter <= t_exit * 1.0000004f) ? t_enter : kMaxFloat;
+}
+
+enum : uint32_t {
+  kQueryClosest = 0,  // every non-void, alpha-passing triangle is a candidate
+  kQueryShadowAny = 1 // as closest, used by the transmittance walk (the caller inspects the material class)
+};
+
+// Closest accepted hit in [tmin, tmax]. `Nodes`/`Tris` are pointer types (global or LDS address space).
+template <class Nodes, class Tris>
+ETX_DEV Hit bvh_closest(const DScene& scene, Nodes nodes, Tris tris, int32_t root, const LaneStack& stack, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags) {
+  Hit best = {0.0f, 0.0f, ray.tmax, kInvalid};
+  uint32_t best_flags = 0u;
+  const f3 inv_d = {1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
+  uint32_t sp = 0;
+  int32_t cur = root;
+  const int32_t kDone = 0x7fffffff;
+  if (scene.bvh_tri_count == 0u)
+    cur = kDone;
+  while (cur != kDone) {
+    if (cur >= 0) {
+      const float4 a = nodes[cur].lo0_hi0x;
+      const float4 b = nodes[cur].hi0yz_lo1xy;
+      const float4 c = nodes[cur].lo1z_hi1;
+      const int32_t c0 = nodes[cur].child0, c1 = nodes[cur].child1;
+      float t0 = slab(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, ray.o, inv_d, ray.tmin, best.t);
+      float t1 = slab(f3{b.z, b.w, c.x}, f3{c.y, c.z, c.w}, ray.o, inv_d, ray.tmin, best.t);
+      bool h0 = t0 < kMaxFloat, h1 = t1 < kMaxFloat;
+      if (h0 && h1) {
+        bool first0 = t0 <= t1;
+        stack.push(sp, first0 ? c1 : c0);
+        cur = first0 ? c0 : c1;
+      } else if (h0) {
+        cur = c0;
+      } else if (h1) {
+        cur = c1;
+      } else {
+        cur = sp ? stack.pop(sp) : kDone;
+      }
+    } else {
+      uint32_t leaf = uint32_t(~cur);
+      uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+      for (uint32_t i = first; i < first + count; ++i) {
+        const float4 v0 = tris[i].v0_index;
+        const float4 e1 = tris[i].e1_flags;
+        const float4 e2 = tris[i].e2_mat;
+        // Moeller-Trumbore; u,v are the barycentrics of vertices 1 and 2 (Embree convention, rt.cxx:352-353)
+        f3 E1 = {e1.x, e1.y, e1.z}, E2 = {e2.x, e2.y, e2.z};
+        f3 p = cross(ray.d, E2);
+        float det = dot(E1, p);
+        if (det == 0.0f)
+          continue;
+        float inv_det = 1.0f / det;
+        f3 s = ray.o - f3{v0.x, v0.y, v0.z};
+        float u = dot(s, p) * inv_det;
+        if ((u < 0.0f) || (u > 1.0f))
+          continue;
+        f3 q = cross(s, E1);
+        float v = dot(ray.d, q) * inv_det;
+        if ((v < 0.0f) || (u + v > 1.0f))
+          continue;
+        float t = dot(E2, q) * inv_det;
+        if ((t < ray.tmin) || (t > best.t))
+          continue;
+        uint32_t flags = __float_as_uint(e1.w);
+        if (flags & kTriVoid)
+          continue;
+        uint32_t tri_index = __float_as_uint(v0.w);
+        if ((flags & kTriAlphaTested) && alpha_test_skips(scene, tri_index, __float_as_uint(e2.w), u, v, alpha_seed))
+          continue;
+        best = {u, v, t, tri_index};
+        best_flags = flags;
+      }
+      cur = sp ? stack.pop(sp) : kDone;
+    }
+  }
+  if (out_flags)
+    *out_flags = best_flags;
+  return best;
+}
+
+// scene_medium.hxx:187-193 (homogeneous branch): exp(-sigma_t * distance)
+ETX_DEV f3 medium_transmittance_homogeneous(const DMedium& m, float distance) {
+  f3 ext = m.absorption + m.scattering;
+  return {expf(-ext.x * distance), expf(-ext.y * distance), expf(-ext.z * distance)};
+}
+
+// Transmittance between p0 and p1 starting in `medium_index` (rt.cxx:468-579).
+// The reference collects up to 63 Boundary hits in one traversal and sorts them; here the boundaries are visited in
+// order by restarting the closest-hit search behind each one (same products, no per-lane hit buffer).
+// rays_traced counts the traversals (statistics).
+template <class Nodes, class Tris>
+ETX_DEV f3 bvh_transmittance(const DScene& scene, Nodes nodes, Tris tris, int32_t root, const LaneStack& stack, const f3& p0, const f3& p1, uint32_t medium_index,
+  uint32_t& alpha_seed) {
+  f3 direction = p1 - p0;
+  float t_max = dot(direction, direction);
+  if (t_max <= kRayEpsilon)
+    return mk3(1.0f);
+  t_max = sqrtf(t_max);
+  direction = direction / t_max;
+  t_max -= fmaxf(kRayEpsilon, t_max * kRayEpsilon);
+
+  f3 result = mk3(1.0f);
+  float current_t = 0.0f;
+  float t_min = kRayEpsilon;
+  uint32_t medium = medium_index;
+  for (uint32_t crossings = 0; crossings < 64u; ++crossings) {
+    uint32_t flags = 0u;
+    Hit h = bvh_closest(scene, nodes, tris, root, stack, RayQ{p0, t_min, direction, t_max}, alpha_seed, &flags);
+    bool found = h.tri != kInvalid;
+    if (found && ((flags & kTriBoundary) == 0u))
+      return mk3(0.0f);
+    float seg_end = found ? h.t : t_max;
+    if (medium != kInvalid) {
+      float dt = fmaxf(0.0f, seg_end - current_t);
+      const DMedium& m = scene.mediums[medium];
+      // heterogeneous media (ratio tracking, scene_medium.hxx:195-232) are rejected at upload for now
+      result *= medium_transmittance_homogeneous(m, dt);
+    }
+    if (found == false)
+      return result;
+    const etx_abi_triangle& tri = scene.triangles[h.tri];
+    const etx_abi_material& mat = scene.materials[tri.material_index];
+    bool entering = dot(ld3(tri.geo_n), direction) < 0.0f;
+    medium = entering ? mat.int_medium : mat.ext_medium;
+    current_t = h.t;
+    t_min = __uint_as_float(__float_as_uint(h.t) + 1u);  // strictly behind this boundary
+    if (t_min > t_max)
+      return result;
+  }
+  return mk3(0.0f);  // rt.cxx:503: more boundaries than the buffer holds counts as occlusion
+}
+
+}  // namespace etxd

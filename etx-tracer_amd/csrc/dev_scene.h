@@ -1,0 +1,312 @@
+// dev_scene.h - the scene as it lives in HBM, plus the geometry/texture accessors the kernels share.
+//
+// Geometry, materials, emitters stay in the reference's own POD layout (include/etx_scene_abi.h) so the host
+// upload is a deep copy with pointer patching (the author's own plan, sources/etx/rt/rt.cxx:141-238). What is
+// re-laid-out for the GPU: the BVH (dev_bvh.h), spectra (pre-resolved to one float4 RGB per spectrum in RGB mode),
+// images (always float4 + flat CDF tables) and media.
+#pragma once
+
+#include "dev_math.h"
+#include "../../include/etx_scene_abi.h"
+
+namespace etxd {
+
+// BVH2 node, Aila-Laine style: a node holds the boxes of BOTH children, so one 64-byte fetch decides both.
+// child >= 0: inner node index; child < 0: leaf, ~child = (first_triangle << 3) | (count - 1), count <= 8.
+struct __attribute__((aligned(16))) BvhNode {
+  float4 lo0_hi0x;    // c0.min.xyz, c0.max.x
+  float4 hi0yz_lo1xy; // c0.max.y, c0.max.z, c1.min.x, c1.min.y
+  float4 lo1z_hi1;    // c1.min.z, c1.max.xyz
+  int32_t child0, child1;
+  uint32_t pad0, pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be one 64-byte line");
+
+// Triangle in traversal order: v0 + two edges, original index, filter flags.
+struct __attribute__((aligned(16))) BvhTri {
+  float4 v0_index;  // v0.xyz, triangle index (u32 bits)
+  float4 e1_flags;  // e1.xyz, flags (u32 bits)
+  float4 e2_mat;    // e2.xyz, material index (u32 bits)
+};
+static_assert(sizeof(BvhTri) == 48, "BvhTri");
+
+enum : uint32_t {
+  kTriVoid = 1u << 0,        // Material::Class::Void: never reported (rt.cxx:441-444)
+  kTriAlphaTested = 1u << 1, // opacity < 1 or alpha texture: stochastic alpha test (scene_bsdf.hxx:128-144)
+  kTriBoundary = 1u << 2,    // Material::Class::Boundary: transparent to transmittance rays (rt.cxx:503)
+};
+
+struct DImage {
+  const float4* pixels;                  // isize.x * isize.y, RGBA8 sources are expanded at upload
+  const etx_abi_distribution_entry* x_entries;  // isize.y rows, x_stride entries each (sampling tables only)
+  const etx_abi_distribution_entry* y_entries;  // y_count entries
+  uint32_t x_stride, y_count;
+  f2 fsize, offset, scale;
+  uint32_t isize_x, isize_y;
+  float normalization;
+  uint32_t options;
+};
+
+struct DMedium {
+  const float* density;
+  f3 bounds_min, bounds_max;
+  f3 absorption, scattering;  // RGB-resolved (RGB mode)
+  uint32_t cls, explicit_connections;
+  float g, max_sigma;
+  uint32_t dim_x, dim_y, dim_z, pad;
+};
+
+struct DCamera {
+  float view_proj[16];
+  f3 position, side, up, direction;
+  float tan_half_fov, aspect, area, image_plane;
+  uint32_t film_w, film_h, cls;
+  float lens_radius, focal_distance, clip_near, clip_far;
+  uint32_t lens_image, medium_index;
+};
+
+struct DScene {
+  const etx_abi_vertex* vertices;
+  const etx_abi_triangle* triangles;
+  const uint32_t* triangle_to_emitter;
+  const etx_abi_material* materials;
+  const etx_abi_emitter_profile* emitter_profiles;
+  const etx_abi_emitter* emitters;
+  const etx_abi_distribution_entry* emitter_dist;
+  const float4* spectrum_rgb;  // RGB mode: SpectralDistribution::integrated_value per spectrum index
+  const DImage* images;
+  const DMedium* mediums;
+  const BvhNode* bvh_nodes;
+  const BvhTri* bvh_tris;
+  uint32_t vertex_count, triangle_count, material_count, emitter_count, emitter_dist_count, spectrum_count, image_count, medium_count;
+  uint32_t bvh_node_count, bvh_tri_count;
+  int32_t bvh_root;  // child encoding (a single leaf scene has a negative root)
+  float emitter_dist_total;
+  uint32_t env_emitters[ETX_ABI_MAX_ENVIRONMENT_EMITTERS];
+  uint32_t env_count;
+  f3 bounds_center;
+  float bounds_radius;
+  uint32_t min_path_length, max_path_length, samples, random_path_termination;
+  float radiance_clamp;
+  uint32_t flags;
+  uint32_t pixel_sampler_image;
+  float pixel_sampler_radius;
+  uint32_t subsurface_exit_material;
+  DCamera camera;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// small loaders (the ABI structs are 4-byte aligned AoS; these compile to dword loads served by L1/L2)
+ETX_DEV f3 ld3(const etx_abi_float3& v) {
+  return {v.x, v.y, v.z};
+}
+ETX_DEV f3 spectrum_rgb(const DScene& s, uint32_t index) {
+  float4 v = s.spectrum_rgb[index];
+  return {v.x, v.y, v.z};
+}
+
+struct Vtx {
+  f3 pos, nrm, tan, btn;
+  f2 tex;
+};
+
+struct Isect : public Vtx {
+  f3 bc;
+  uint32_t tri;
+  f3 w_i;
+  float t;
+  uint32_t material;
+  uint32_t emitter;
+};
+
+// scene.hxx:90-112 lerp_vertex: interpolate, re-orthogonalise (Gram-Schmidt), keep bitangent handedness
+ETX_DEV Vtx lerp_vertex(const DScene& s, const etx_abi_triangle& t, const f3& bc) {
+  const etx_abi_vertex& v0 = s.vertices[t.i[0]];
+  const etx_abi_vertex& v1 = s.vertices[t.i[1]];
+  const etx_abi_vertex& v2 = s.vertices[t.i[2]];
+  Vtx v;
+  v.pos = ld3(v0.pos) * bc.x + ld3(v1.pos) * bc.y + ld3(v2.pos) * bc.z;
+  v.nrm = ld3(v0.nrm) * bc.x + ld3(v1.nrm) * bc.y + ld3(v2.nrm) * bc.z;
+  v.tan = ld3(v0.tan) * bc.x + ld3(v1.tan) * bc.y + ld3(v2.tan) * bc.z;
+  f3 b = ld3(v0.btn) * bc.x + ld3(v1.btn) * bc.y + ld3(v2.btn) * bc.z;
+  v.tex = {v0.tex.x * bc.x + v1.tex.x * bc.y + v2.tex.x * bc.z, v0.tex.y * bc.x + v1.tex.y * bc.y + v2.tex.y * bc.z};
+  v.nrm = normalize(v.nrm);
+  v.tan = normalize(v.tan - dot(v.tan, v.nrm) * v.nrm);
+  f3 btn = cross(v.nrm, v.tan);
+  v.btn = normalize(btn * (dot(btn, b) > 0.0f ? 1.0f : -1.0f));
+  return v;
+}
+
+ETX_DEV f3 lerp_pos(const DScene& s, const etx_abi_triangle& t, const f3& bc) {  // scene.hxx:77-81
+  return ld3(s.vertices[t.i[0]].pos) * bc.x + ld3(s.vertices[t.i[1]].pos) * bc.y + ld3(s.vertices[t.i[2]].pos) * bc.z;
+}
+ETX_DEV f3 lerp_normal(const DScene& s, const etx_abi_triangle& t, const f3& bc) {  // scene.hxx:83-87
+  return normalize(ld3(s.vertices[t.i[0]].nrm) * bc.x + ld3(s.vertices[t.i[1]].nrm) * bc.y + ld3(s.vertices[t.i[2]].nrm) * bc.z);
+}
+ETX_DEV f2 lerp_uv(const DScene& s, const etx_abi_triangle& t, const f3& b) {  // scene.hxx:103-107
+  const etx_abi_float2& a = s.vertices[t.i[0]].tex;
+  const etx_abi_float2& bb = s.vertices[t.i[1]].tex;
+  const etx_abi_float2& c = s.vertices[t.i[2]].tex;
+  return {a.x * b.x + bb.x * b.y + c.x * b.z, a.y * b.x + bb.y * b.y + c.y * b.z};
+}
+
+// scene.hxx:172-186 shading_pos: Phong-tessellation style origin (avoids the shadow terminator), then offset_ray
+ETX_DEV f3 shading_pos(const DScene& s, const etx_abi_triangle& t, const f3& bc, const f3& w_o) {
+  f3 p0v = ld3(s.vertices[t.i[0]].pos), p1v = ld3(s.vertices[t.i[1]].pos), p2v = ld3(s.vertices[t.i[2]].pos);
+  f3 n0 = ld3(s.vertices[t.i[0]].nrm), n1 = ld3(s.vertices[t.i[1]].nrm), n2 = ld3(s.vertices[t.i[2]].nrm);
+  f3 geo_pos = p0v * bc.x + p1v * bc.y + p2v * bc.z;
+  f3 sh_normal = normalize(n0 * bc.x + n1 * bc.y + n2 * bc.z);
+  float direction = (dot(sh_normal, w_o) >= 0.0f) ? +1.0f : -1.0f;
+  f3 d0 = direction * n0, d1 = direction * n1, d2 = direction * n2;
+  f3 p0 = geo_pos - dot(geo_pos - p0v, d0) * d0;
+  f3 p1 = geo_pos - dot(geo_pos - p1v, d1) * d1;
+  f3 p2 = geo_pos - dot(geo_pos - p2v, d2) * d2;
+  f3 sh_pos = p0 * bc.x + p1 * bc.y + p2 * bc.z;
+  bool convex = dot(sh_pos - geo_pos, sh_normal) * direction > 0.0f;
+  return offset_ray(convex ? sh_pos : geo_pos, ld3(t.geo_n) * direction);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// images  sources/etx/render/shared/image.hxx
+
+ETX_DEV float tex_coord(float u, float size, bool repeat) {  // image.hxx:163-178
+  if (repeat) {
+    float x = fmodf(u, size);
+    return x < 0.0f ? (x + size) : x;
+  }
+  float hi = nextafterf(size, 0.0f);
+  return u < 0.0f ? 0.0f : (u > hi ? hi : u);
+}
+
+struct ImageGather {
+  float4 p00, p01, p10, p11;
+};
+
+ETX_DEV float4 scale4(const float4& a, float s) {
+  return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
+}
+ETX_DEV float4 add4(const float4& a, const float4& b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+ETX_DEV ImageGather image_gather(const DImage& img, const f2 in_uv) {  // image.hxx:55-80
+  float x0 = tex_coord(in_uv.x * img.fsize.x, img.fsize.x, (img.options & ETX_IMAGE_REPEAT_U) != 0);
+  float y0 = tex_coord(in_uv.y * img.fsize.y, img.fsize.y, (img.options & ETX_IMAGE_REPEAT_V) != 0);
+  float dx = x0 - floorf(x0);
+  float dy = y0 - floorf(y0);
+  uint32_t row_0 = min(static_cast<uint32_t>(y0), img.isize_y - 1u);
+  uint32_t row_1 = min(row_0 + 1u, img.isize_y - 1u);
+  uint32_t col_0 = min(static_cast<uint32_t>(x0), img.isize_x - 1u);
+  uint32_t col_1 = min(col_0 + 1u, img.isize_x - 1u);
+  uint32_t last = img.isize_x * img.isize_y - 1u;
+  ImageGather g;
+  g.p00 = scale4(img.pixels[min(col_0 + row_0 * img.isize_x, last)], (1.0f - dx) * (1.0f - dy));
+  g.p01 = scale4(img.pixels[min(col_1 + row_0 * img.isize_x, last)], dx * (1.0f - dy));
+  g.p10 = scale4(img.pixels[min(col_0 + row_1 * img.isize_x, last)], (1.0f - dx) * dy);
+  g.p11 = scale4(img.pixels[min(col_1 + row_1 * img.isize_x, last)], dx * dy);
+  return g;
+}
+
+ETX_DEV float4 image_evaluate(const DImage& img, const f2 uv, float* pdf) {  // image.hxx:82-96
+  ImageGather g = image_gather(img, uv);
+  if (pdf) {
+    bool uniform = (img.options & ETX_IMAGE_UNIFORM_SAMPLING_TABLE) || (img.fsize.y == 1.0f);
+    float s_t = uniform ? 1.0f : fmaxf(0.0f, sinf(kPi * saturate(uv.y + 0.0f / img.fsize.y)));
+    float t = luminance(mk3(add4(g.p00, g.p01))) * s_t;
+    float s_b = uniform ? 1.0f : fmaxf(0.0f, sinf(kPi * saturate(uv.y + 1.0f / img.fsize.y)));
+    float b = luminance(mk3(add4(g.p10, g.p11))) * s_b;
+    *pdf = (t + b) / img.normalization;
+  }
+  return add4(add4(g.p00, g.p01), add4(g.p10, g.p11));
+}
+
+// distribution.hxx:16-35 : binary search over the CDF
+ETX_DEV uint32_t distribution_sample(const etx_abi_distribution_entry* values, uint32_t count, float rnd) {
+  uint32_t b = 0, e = count;
+  do {
+    uint32_t m = b + (e - b) / 2;
+    if (values[m].cdf >= rnd) {
+      e = m;
+    } else {
+      b = m;
+    }
+  } while ((e - b) > 1);
+  return b;
+}
+
+// image.hxx:126-161 : importance sample a texel, returns uv + pdf + value
+ETX_DEV f2 image_sample(const DImage& img, const f2 rnd, float& image_pdf, float4& eval) {
+  uint32_t ly = distribution_sample(img.y_entries, img.y_count, rnd.y);
+  const etx_abi_distribution_entry* row = img.x_entries + size_t(ly) * img.x_stride;
+  uint32_t lx = distribution_sample(row, img.x_stride, rnd.x);
+  float x0c = row[lx].cdf, x1c = row[min(lx + 1u, img.x_stride - 1u)].cdf;
+  float dx = rnd.x - x0c;
+  if (x1c - x0c > 0.0f)
+    dx /= (x1c - x0c);
+  float y0c = img.y_entries[ly].cdf, y1c = img.y_entries[min(ly + 1u, img.y_count - 1u)].cdf;
+  float dy = rnd.y - y0c;
+  if (y1c - y0c > 0.0f)
+    dy /= (y1c - y0c);
+  f2 uv = {(float(lx) + dx) / img.fsize.x, (float(ly) + dy) / img.fsize.y};
+  eval = image_evaluate(img, uv, &image_pdf);
+  return uv;
+}
+
+// scene.hxx:250-320 : texture helpers (RGB mode: SpectralResponse = float3 `integrated`)
+ETX_DEV f3 apply_image(const DScene& s, const etx_abi_spectral_image& img, const f2 uv, float* image_pdf) {  // scene.hxx:295-309
+  if (image_pdf)
+    *image_pdf = 0.0f;
+  f3 result = spectrum_rgb(s, img.spectrum_index);
+  if (img.image_index == kInvalid)
+    return result;
+  float4 e = image_evaluate(s.images[img.image_index], uv, image_pdf);
+  return result * mk3(e);
+}
+ETX_DEV float evaluate_image(const DScene& s, const etx_abi_sampled_image& img, const f2 uv, float default_value) {  // scene.hxx:272-281
+  if ((img.image_index == kInvalid) || (img.channel >= 4u))
+    return default_value;
+  float4 e = image_evaluate(s.images[img.image_index], uv, nullptr);
+  return img.channel == 0 ? e.x : (img.channel == 1 ? e.y : (img.channel == 2 ? e.z : e.w));
+}
+ETX_DEV f2 evaluate_roughness(const DScene& s, const etx_abi_material& m, const f2 uv) {  // scene.hxx:287-289
+  float k = evaluate_image(s, m.roughness, uv, 1.0f);
+  return {m.roughness.value.x * k, m.roughness.value.y * k};
+}
+
+// scene.hxx:188-200 orient_normals_to_hemisphere (normal mapping helper)
+ETX_DEV f3 orient_normals_to_hemisphere(f3 n_s, const f3& n_g, const f3& v) {
+  const float i_dot_g = dot(v, n_g);
+  float i_dot_s = dot(v, n_s);
+  for (uint32_t i = 0; ((i_dot_s * i_dot_g) <= kEpsilon) && (i < 16u); ++i) {
+    n_s = normalize(8.0f * n_s + n_g);
+    i_dot_s = dot(v, n_s);
+  }
+  return n_s;
+}
+
+// scene.hxx:202-226 make_intersection: expand the 16-byte hit record (u, v, t, triangle) into a shading point
+ETX_DEV Isect make_intersection(const DScene& s, const f3& w_i, float u, float v, float t, uint32_t tri_index) {
+  f3 bc = barycentrics(u, v);
+  const etx_abi_triangle& tri = s.triangles[tri_index];
+  Isect r;
+  static_cast<Vtx&>(r) = lerp_vertex(s, tri, bc);
+  r.bc = bc;
+  r.tri = tri_index;
+  r.w_i = w_i;
+  r.t = t;
+  r.material = tri.material_index;
+  r.emitter = s.triangle_to_emitter[tri_index];
+  const etx_abi_material& mat = s.materials[r.material];
+  if ((mat.normal_image_index != kInvalid) && (mat.normal_scale > kEpsilon)) {
+    float4 value = image_evaluate(s.images[mat.normal_image_index], r.tex, nullptr);  // image.hxx:117-124 evaluate_normal
+    float sc = mat.normal_scale;
+    f3 sn = {sc * (value.x * 2.0f - 1.0f), sc * (value.y * 2.0f - 1.0f), sc * (value.z * 2.0f - 1.0f) + (1.0f - sc)};
+    r.nrm = normalize(r.tan * sn.x + r.btn * sn.y + r.nrm * sn.z);
+    r.nrm = orient_normals_to_hemisphere(r.nrm, ld3(tri.geo_n), w_i);
+    r.tan = normalize(r.tan - dot(r.tan, r.nrm) * r.nrm);
+    r.btn = normalize(cross(r.nrm, r.tan));
+  }
+  return r;
+}
+
+}  // namespace etxd

@@ -1,0 +1,405 @@
+// dev_vcm.h - per-path VCM logic (RGB mode), restated from sources/etx/rt/shared/vcm_shared.hxx for the wavefront
+// kernels in kernels_vcm.hip. One lane = one path; every function cites the reference lines it follows.
+#pragma once
+
+#include "dev_bvh.h"
+#include "dev_bsdf.h"
+#include "dev_emitters.h"
+#include "pipeline.h"
+
+namespace etxd {
+
+struct PathState {  // VCMPathState (vcm_shared.hxx:91-150) minus the per-pixel accumulators (they live in the film)
+  f3 ray_o;
+  float ray_tmin;
+  f3 ray_d;
+  float ray_tmax;
+  f3 throughput;
+  float eta;
+  float d_vcm, d_vc, d_vm, path_distance;
+  Sampler sampler;
+  uint32_t depth;   // total_path_depth
+  uint32_t medium;  // medium_index
+  uint32_t flags;
+  uint32_t id;      // global_index
+};
+
+ETX_DEV PathState load_path(const PathSet& set, uint32_t i) {
+  PathState s;
+  float4 a = set.ray_o_tmin[i], b = set.ray_d_tmax[i], c = set.thr_eta[i], d = set.mis[i];
+  uint4 m = set.meta[i];
+  s.ray_o = {a.x, a.y, a.z}, s.ray_tmin = a.w;
+  s.ray_d = {b.x, b.y, b.z}, s.ray_tmax = b.w;
+  s.throughput = {c.x, c.y, c.z}, s.eta = c.w;
+  s.d_vcm = d.x, s.d_vc = d.y, s.d_vm = d.z, s.path_distance = d.w;
+  s.sampler.seed = m.x, s.sampler.fixed_u = s.sampler.fixed_v = s.sampler.fixed_w = 0.0f;
+  s.depth = m.y, s.medium = m.z, s.flags = m.w;
+  s.id = set.path_id[i];
+  return s;
+}
+
+ETX_DEV void store_path(const PathSet& set, uint32_t i, const PathState& s) {
+  set.ray_o_tmin[i] = mk4(s.ray_o, s.ray_tmin);
+  set.ray_d_tmax[i] = mk4(s.ray_d, s.ray_tmax);
+  set.thr_eta[i] = mk4(s.throughput, s.eta);
+  set.mis[i] = make_float4(s.d_vcm, s.d_vc, s.d_vm, s.path_distance);
+  set.meta[i] = make_uint4(s.sampler.seed, s.depth, s.medium, s.flags);
+  set.path_id[i] = s.id;
+}
+
+// Dense slot for every lane with `alive` set; one atomic per wavefront (ballot + popcount prefix).
+// Must be called from wave-uniform control flow.
+ETX_DEV uint32_t wave_compact_slot(bool alive, uint32_t* counter) {
+  const uint64_t mask = __ballot(alive);
+  const uint32_t lane = __lane_id();
+  const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+  uint32_t base = 0;
+  if (lane == 0)
+    base = mask ? atomicAdd(counter, uint32_t(__popcll(mask))) : 0u;
+  base = __shfl(base, 0);
+  return base + prefix;
+}
+
+ETX_DEV void atomic_add_f3(float4* dst, const f3& v) {
+  atomicAdd(&dst->x, v.x);
+  atomicAdd(&dst->y, v.y);
+  atomicAdd(&dst->z, v.z);
+}
+
+ETX_DEV bool is_zero(const f3& v) {  // SpectralResponse::is_zero, spectrum.hxx:317-319
+  return (v.x <= kEpsilon) && (v.y <= kEpsilon) && (v.z <= kEpsilon);
+}
+
+// scene.hxx:228-248 random_continue (Russian roulette)
+ETX_DEV bool random_continue(uint32_t path_length, uint32_t start_path_length, float eta_scale, Sampler& smp, f3& throughput) {
+  float max_t = max_component(throughput);
+  if (max_t == 0.0f)
+    return false;
+  if (path_length < start_path_length)
+    return true;
+  max_t *= sqr(eta_scale);
+  if (valid_value(max_t) == false)
+    return false;
+  float q = fminf(0.95f, max_t);
+  if ((q > 0.0f) && (smp.next() < q)) {
+    throughput *= (1.0f / q);
+    return true;
+  }
+  return false;
+}
+
+struct TraceCtx {  // what an inline traversal needs
+  const DScene* scene;
+  LaneStack stack;
+  uint32_t alpha_seed;
+};
+
+ETX_DEV f3 trace_transmittance(TraceCtx& tc, const f3& p0, const f3& p1, uint32_t medium) {
+  const DScene& s = *tc.scene;
+  return bvh_transmittance(s, s.bvh_nodes, s.bvh_tris, s.bvh_root, tc.stack, p0, p1, medium, tc.alpha_seed);
+}
+
+// vcm_shared.hxx:218-283 vcm_next_ray
+ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& st, const VcmParams& it, const Isect& isect, const BsdfData& bsdf_data, const BsdfSample& bs) {
+  if (st.depth + 1 > scene.max_path_length)
+    return false;
+  if (bs.valid() == false)
+    return false;
+  const etx_abi_triangle& tri = scene.triangles[isect.tri];
+  const etx_abi_material& mat = scene.materials[isect.material];
+  st.throughput *= bs.weight;
+  if (path_source == kPathLight)
+    st.throughput *= fix_shading_normal(ld3(tri.geo_n), isect.nrm, isect.w_i, bs.w_o);
+  if (is_zero(st.throughput))
+    return false;
+  if (random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput) == false)
+    return false;
+  if (bs.properties & kSampleMediumChanged)
+    st.medium = bs.medium_index;
+  float cos_theta_bsdf = fabsf(dot(isect.nrm, bs.w_o));
+  if (bs.is_delta()) {
+    st.d_vc *= cos_theta_bsdf;
+    st.d_vm *= cos_theta_bsdf;
+    st.d_vcm = 0.0f;
+  } else {
+    float rev_pdf = bsdf_reverse_pdf(scene, bsdf_data, bs.w_o, mat);
+    st.d_vc = (cos_theta_bsdf / bs.pdf) * (st.d_vc * rev_pdf + st.d_vcm + it.vm_weight);
+    st.d_vm = (cos_theta_bsdf / bs.pdf) * (st.d_vm * rev_pdf + st.d_vcm * it.vc_weight + 1.0f);
+    st.d_vcm = 1.0f / bs.pdf;
+  }
+  st.ray_d = bs.w_o;
+  st.ray_o = shading_pos(scene, tri, isect.bc, bs.w_o);
+  st.ray_tmax = kMaxFloat;
+  st.ray_tmin = kRayEpsilon;
+  st.eta *= bs.eta;
+  st.depth += 1u;
+  return true;
+}
+
+// vcm_shared.hxx:436-449 vcm_handle_boundary_bsdf
+ETX_DEV bool vcm_handle_boundary(const DScene& scene, const Isect& isect, PathState& st) {
+  const etx_abi_material& mat = scene.materials[isect.material];
+  if (mat.cls != ETX_MAT_BOUNDARY)
+    return false;
+  const etx_abi_triangle& tri = scene.triangles[isect.tri];
+  uint32_t new_medium = (dot(ld3(tri.geo_n), st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
+  st.path_distance += isect.t;
+  st.medium = new_medium;
+  st.ray_o = shading_pos(scene, tri, isect.bc, st.ray_d);
+  st.ray_tmax = kMaxFloat;
+  st.ray_tmin = kRayEpsilon;
+  return true;
+}
+
+// vcm_shared.hxx:463-535 vcm_connect_to_camera. Returns the splat value, uv = film coordinates in NDC.
+ETX_DEV f3 vcm_connect_to_camera(TraceCtx& tc, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st, f2& uv) {
+  const DScene& scene = *tc.scene;
+  if ((opt_connect_to_camera(it) == false) || (st.depth + 2 > scene.max_path_length) || (st.depth + 2 < scene.min_path_length))
+    return mk3(0.0f);
+  f3 sample_pos = camera_at_medium ? medium_pos : isect->pos;
+  CameraSample cs = sample_film(scene, st.sampler, sample_pos);
+  if (cs.pdf_dir <= 0.0f)
+    return mk3(0.0f);
+  f3 direction = cs.position - sample_pos;
+  float dist2 = dot(direction, direction);
+  if (dist2 <= kEpsilon)
+    return mk3(0.0f);
+  f3 w_o = normalize(direction);
+  f3 scatter = mk3(0.0f);
+  float reverse_pdf = 0.0f;
+  f3 origin = sample_pos;
+  if (camera_at_medium == false) {
+    const etx_abi_material& mat = scene.materials[isect->material];
+    BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathLight);
+    BsdfEval eval = bsdf_evaluate(scene, data, w_o, mat, st.sampler);
+    if (eval.valid() == false)
+      return mk3(0.0f);
+    scatter = eval.bsdf;
+    reverse_pdf = bsdf_reverse_pdf(scene, data, w_o, mat);
+    origin = shading_pos(scene, scene.triangles[isect->tri], isect->bc, w_o);
+  } else {
+    const DMedium& medium = scene.mediums[st.medium];
+    float p = phase_function(st.ray_d, w_o, medium.g);
+    if (p <= 0.0f)
+      return mk3(0.0f);
+    scatter = mk3(p);
+    reverse_pdf = phase_function(w_o, st.ray_d, medium.g);
+  }
+  float len = length(cs.position - origin);
+  float cos_t = fabsf(dot(cs.direction, scene.camera.direction));
+  f3 clip_pos = origin + cs.direction * fmaxf(0.0f, len - scene.camera.clip_near / cos_t);
+  f3 tr = trace_transmittance(tc, origin, clip_pos, st.medium);
+  if (is_zero(tr))
+    return mk3(0.0f);
+  uv = cs.uv;
+  float camera_pdf = cs.pdf_dir_out * (camera_at_medium ? 1.0f : fabsf(dot(isect->nrm, w_o))) / dist2;
+  float vmW_cam = camera_at_medium ? 0.0f : it.vm_weight;
+  float w_light = camera_pdf * (vmW_cam + st.d_vcm + st.d_vc * reverse_pdf);
+  float weight = opt_enable_mis(it) ? (1.0f / (1.0f + w_light)) : 1.0f;
+  if (camera_at_medium == false)
+    weight *= fix_shading_normal(ld3(scene.triangles[isect->tri].geo_n), isect->nrm, isect->w_i, w_o);
+  return tr * scatter * st.throughput * (cs.weight * weight);
+}
+
+// vcm_shared.hxx:285-308 vcm_get_radiance (direct emitter hit from the camera sub path)
+ETX_DEV f3 vcm_get_radiance(const DScene& scene, const etx_abi_emitter& emitter, const PathState& st, const VcmParams& it, const Isect& isect) {
+  float pdf_area = 0.0f, pdf_dir = 0.0f, pdf_dir_out = 0.0f;
+  EmitterRadianceQuery q;
+  q.source_position = st.ray_o;
+  q.target_position = isect.pos;
+  q.direction = st.ray_d;
+  q.uv = isect.tex;
+  q.directly_visible = st.depth == 1;
+  f3 radiance = emitter_get_radiance(scene, emitter, q, pdf_area, pdf_dir, pdf_dir_out);
+  if (pdf_dir <= kEpsilon)
+    return mk3(0.0f);
+  float pdf_sample = emitter_discrete_pdf(scene, emitter);
+  float w_camera = st.d_vcm * pdf_area * pdf_sample + st.d_vc * (pdf_dir_out * pdf_sample);
+  float weight = (opt_enable_mis(it) && (st.depth > 1)) ? (1.0f / (1.0f + w_camera)) : 1.0f;
+  return weight * (st.throughput * radiance);
+}
+
+// vcm_shared.hxx:537-587 vcm_cam_handle_miss
+ETX_DEV f3 vcm_cam_handle_miss(const DScene& scene, const VcmParams& it, PathState& st) {
+  if (opt_direct_hit(it) == false)
+    return mk3(0.0f);
+  if (st.path_distance > 0.0f) {
+    st.d_vcm *= sqr(st.path_distance);
+    st.path_distance = 0.0f;
+  }
+  f3 accumulated = mk3(0.0f);
+  float sum_pdf_dir_out = 0.0f, sum_pdf_dir = 0.0f;
+  for (uint32_t ie = 0; ie < scene.env_count; ++ie) {
+    const etx_abi_emitter& em = scene.emitters[scene.env_emitters[ie]];
+    EmitterRadianceQuery q;
+    q.source_position = q.target_position = mk3(0.0f);
+    q.direction = st.ray_d;
+    q.uv = {0.0f, 0.0f};
+    q.directly_visible = st.depth <= 1;
+    float pdf_area = 0.0f, pdf_dir = 0.0f, pdf_dir_out = 0.0f;
+    f3 value = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out);
+    if (pdf_dir > kEpsilon) {
+      float pdf_discrete = emitter_discrete_pdf(scene, em);
+      sum_pdf_dir_out += pdf_dir_out * pdf_discrete;
+      sum_pdf_dir += pdf_dir * pdf_discrete;
+      accumulated += value;
+    }
+  }
+  if (max_component(accumulated) > kEpsilon) {
+    float inv_count = (scene.env_count > 0u) ? (1.0f / float(scene.env_count)) : 0.0f;
+    sum_pdf_dir *= inv_count;
+    sum_pdf_dir_out *= inv_count;
+    float w_camera_sum = st.d_vcm * sum_pdf_dir + st.d_vc * sum_pdf_dir_out;
+    float weight = (opt_enable_mis(it) && (st.depth > 1)) ? (1.0f / (1.0f + w_camera_sum)) : 1.0f;
+    return st.throughput * accumulated * weight;
+  }
+  return mk3(0.0f);
+}
+
+// vcm_shared.hxx:608-671 vcm_connect_to_light (NEE). sampler.fixed_* hold (rnd_connection.xy, rnd_support.y).
+ETX_DEV f3 vcm_connect_to_light(TraceCtx& tc, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st) {
+  const DScene& scene = *tc.scene;
+  if ((opt_connect_to_light(it) == false) || (st.depth + 1 > scene.max_path_length) || (st.depth + 1 < scene.min_path_length))
+    return mk3(0.0f);
+  f3 sample_pos = camera_at_medium ? medium_pos : isect->pos;
+  uint32_t emitter_index = sample_emitter_index(scene, st.sampler.fixed_w);
+  EmitterSample es = sample_emitter(scene, emitter_index, f2{st.sampler.fixed_u, st.sampler.fixed_v}, sample_pos);
+  if (es.pdf_dir <= 0.0f)
+    return mk3(0.0f);
+  f3 w_o = es.direction;
+  f3 scatter = mk3(0.0f);
+  float reverse_pdf = 0.0f;
+  f3 origin = sample_pos;
+  float camera_factor = 1.0f;
+  float conn_pdf = 0.0f;
+  if (camera_at_medium) {
+    const DMedium& medium = scene.mediums[st.medium];
+    float p = phase_function(st.ray_d, w_o, medium.g);
+    if (p <= 0.0f)
+      return mk3(0.0f);
+    scatter = mk3(p);
+    reverse_pdf = phase_function(w_o, st.ray_d, medium.g);
+  } else {
+    const etx_abi_material& mat = scene.materials[isect->material];
+    BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathCamera);
+    BsdfEval eval = bsdf_evaluate(scene, data, w_o, mat, st.sampler);
+    if (eval.valid() == false)
+      return mk3(0.0f);
+    scatter = eval.bsdf;
+    reverse_pdf = bsdf_reverse_pdf(scene, data, w_o, mat);
+    const etx_abi_triangle& tri = scene.triangles[isect->tri];
+    origin = shading_pos(scene, tri, isect->bc, normalize(es.origin - isect->pos));
+    camera_factor = fabsf(dot(w_o, ld3(tri.geo_n)));
+    conn_pdf = bsdf_pdf(scene, data, w_o, mat);
+  }
+  f3 tr = trace_transmittance(tc, origin, es.origin, st.medium);
+  if (is_zero(tr))
+    return mk3(0.0f);
+  float l_dot_e = fabsf(dot(es.direction, es.normal));
+  float w_light = 0.0f;
+  if (es.is_delta == false) {
+    // vcm_shared.hxx:655: the medium branch divides the scalar phase value (SpectralResponse::value)
+    w_light = (camera_at_medium ? scatter.x : conn_pdf) / (es.pdf_dir * es.pdf_sample);
+  }
+  float vmW_nee = camera_at_medium ? 0.0f : it.vm_weight;
+  float w_camera = (es.pdf_dir_out * camera_factor) / (es.pdf_dir * l_dot_e) * (vmW_nee + st.d_vcm + st.d_vc * reverse_pdf);
+  float weight = opt_enable_mis(it) ? 1.0f / (1.0f + w_light + w_camera) : 1.0f;
+  return tr * st.throughput * scatter * es.value * (weight / (es.pdf_dir * es.pdf_sample));
+}
+
+struct LightVertex {  // VCMLightVertex, vcm_shared.hxx:154-197
+  f3 pos, w_i, throughput, nrm;
+  float d_vcm, d_vc, d_vm;
+  float bc_u, bc_v;
+  uint32_t tri, path_length, index_in_path, medium;
+  ETX_DEV bool is_medium() const {
+    return tri == kInvalid;
+  }
+};
+
+ETX_DEV LightVertex load_light_vertex(const LightVertexPool& lv, uint32_t i) {
+  float4 a = lv.pos_dvcm[i], b = lv.wi_dvc[i], c = lv.thr_dvm[i], d = lv.nrm_tri[i], e = lv.bc_len_med[i];
+  LightVertex v;
+  v.pos = {a.x, a.y, a.z}, v.d_vcm = a.w;
+  v.w_i = {b.x, b.y, b.z}, v.d_vc = b.w;
+  v.throughput = {c.x, c.y, c.z}, v.d_vm = c.w;
+  v.nrm = {d.x, d.y, d.z}, v.tri = __float_as_uint(d.w);
+  v.bc_u = e.x, v.bc_v = e.y, v.path_length = __float_as_uint(e.z) & 0xffffu, v.index_in_path = __float_as_uint(e.z) >> 16u, v.medium = __float_as_uint(e.w);
+  return v;
+}
+
+// vcm_shared.hxx:673-763 vcm_connect_to_light_vertex (surface / medium on either side)
+ETX_DEV bool vcm_connect_to_light_vertex(const DScene& scene, const PathState& st, const LightVertex& lv, const VcmParams& it, bool camera_at_medium, const Isect* cam, const f3& medium_pos,
+  Sampler& smp, f3& target_position, f3& value) {
+  Vtx light_v;
+  if (lv.is_medium() == false)
+    light_v = lerp_vertex(scene, scene.triangles[lv.tri], barycentrics(lv.bc_u, lv.bc_v));
+  target_position = lv.is_medium() ? lv.pos : light_v.pos;
+  f3 w_o = target_position - (camera_at_medium ? medium_pos : cam->pos);
+  float distance_squared = dot(w_o, w_o);
+  if (distance_squared <= kEpsilon)
+    return false;
+  w_o = w_o / sqrtf(distance_squared);
+  float w_dot_l = lv.is_medium() ? 1.0f : -dot(light_v.nrm, w_o);
+
+  float camera_area_pdf = 0.0f, camera_rev_pdf = 0.0f;
+  f3 camera_scatter = mk3(0.0f);
+  if (camera_at_medium) {
+    const DMedium& medium = scene.mediums[st.medium];
+    float p = phase_function(st.ray_d, w_o, medium.g);
+    if (p <= 0.0f)
+      return false;
+    camera_area_pdf = p * fabsf(w_dot_l) / distance_squared;
+    camera_rev_pdf = phase_function(w_o, st.ray_d, medium.g);
+    camera_scatter = mk3(p);
+  } else {
+    const etx_abi_material& mat = scene.materials[cam->material];
+    BsdfData camera_data = make_bsdf_data(*cam, cam->w_i, st.medium, kPathCamera);
+    BsdfEval camera_bsdf = bsdf_evaluate(scene, camera_data, w_o, mat, smp);
+    if (camera_bsdf.valid() == false)
+      return false;
+    camera_area_pdf = camera_bsdf.pdf * fabsf(w_dot_l) / distance_squared;
+    camera_rev_pdf = bsdf_reverse_pdf(scene, camera_data, w_o, mat);
+    camera_scatter = camera_bsdf.bsdf;
+  }
+
+  float light_area_pdf = 0.0f, light_rev_pdf = 0.0f;
+  f3 light_scatter = mk3(0.0f);
+  if (lv.is_medium()) {
+    const DMedium& med = scene.mediums[lv.medium];
+    float p = phase_function(lv.w_i, -w_o, med.g);
+    if (p <= 0.0f)
+      return false;
+    light_area_pdf = p * (camera_at_medium ? 1.0f : fabsf(dot(cam->nrm, w_o))) / distance_squared;
+    light_rev_pdf = phase_function(-w_o, lv.w_i, med.g);
+    light_scatter = mk3(p);
+  } else {
+    const etx_abi_triangle& light_tri = scene.triangles[lv.tri];
+    const etx_abi_material& light_mat = scene.materials[light_tri.material_index];
+    BsdfData light_data = make_bsdf_data(light_v, lv.w_i, camera_at_medium ? lv.medium : st.medium, kPathLight);
+    BsdfEval light_bsdf = bsdf_evaluate(scene, light_data, -w_o, light_mat, smp);
+    if (light_bsdf.valid() == false)
+      return false;
+    light_area_pdf = camera_at_medium ? (light_bsdf.pdf / distance_squared) : (light_bsdf.pdf * fabsf(dot(cam->nrm, w_o)) / distance_squared);
+    light_rev_pdf = bsdf_reverse_pdf(scene, light_data, -w_o, light_mat);
+    light_scatter = light_bsdf.bsdf * fix_shading_normal(ld3(light_tri.geo_n), light_data.nrm, light_data.w_i, -w_o);
+  }
+
+  float vmW_pair = (camera_at_medium || lv.is_medium()) ? 0.0f : it.vm_weight;
+  float w_light = camera_area_pdf * (vmW_pair + lv.d_vcm + lv.d_vc * light_rev_pdf);
+  float w_camera = light_area_pdf * (vmW_pair + st.d_vcm + st.d_vc * camera_rev_pdf);
+  float weight = opt_enable_mis(it) ? 1.0f / (1.0f + w_light + w_camera) : 1.0f;
+  value = (camera_scatter * st.throughput) * (light_scatter * lv.throughput) * (weight / distance_squared);
+  return true;
+}
+
+ETX_DEV uint32_t grid_cell_index(int32_t x, int32_t y, int32_t z, uint32_t mask) {  // vcm_shared.hxx:820-822
+  return ((uint32_t(x) * 73856093u) ^ (uint32_t(y) * 19349663u) ^ (uint32_t(z) * 83492791u)) & mask;
+}
+
+ETX_DEV uint32_t grid_position_to_index(const GridParams& g, const f3& pos) {  // vcm_shared.hxx:824-827
+  f3 m = (pos - g.bbox_min) / g.cell_size;
+  return grid_cell_index(int32_t(floorf(m.x)), int32_t(floorf(m.y)), int32_t(floorf(m.z)), g.hash_mask);
+}
+
+}  // namespace etxd

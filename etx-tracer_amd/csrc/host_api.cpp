@@ -1,0 +1,731 @@
+// host_api.cpp - the C ABI of libetx_hip.so (include/etx_hip.h): context, device pools, the per-iteration launch
+// sequence that stands in for CPUVCMImpl::start_next_iteration / gather_* / complete_* (vcm_cpu.cxx:95-241).
+#include "../../include/etx_hip.h"
+
+#include "host_scene.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace etxd;
+
+#if defined(ETX_HIP_DEBUG_COUNTERS)
+namespace etxd { void launch_debug_lists(hipStream_t stream, const Pipeline& p); }
+static void launch_debug_lists_fwd(hipStream_t s, const etxd::Pipeline& p) { etxd::launch_debug_lists(s, p); }
+#endif
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum TimerId : uint32_t {
+  kTimerTraceClosest = 0,
+  kTimerShadeLight,
+  kTimerShadeCamera,
+  kTimerConnect,
+  kTimerMerge,
+  kTimerGridBuild,
+  kTimerGenerate,
+  kTimerCount,
+};
+
+struct TimedSpan {
+  hipEvent_t begin, end;
+  uint32_t id;
+};
+
+}  // namespace
+
+struct etx_hip_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+  etxh::DeviceScene scene;
+  Pipeline pipe = {};
+  std::vector<void*> allocations;
+  bool scene_ready = false;
+  bool armed = false;
+  int integrator = ETX_HIP_INTEGRATOR_VCM;
+  etx_abi_vcm_options vcm_options = {};
+  uint32_t first_iteration = 0, iteration_stride = 1;
+  uint32_t next_iteration = 0;       // iteration index to render next
+  uint32_t local_iterations = 0;     // iterations rendered by this context since begin
+  uint64_t global_iterations = 0;    // after etx_hip_reduce_film: iterations of all ranks
+  bool reduced = false;
+  uint32_t check_interval = 4;       // bounces enqueued between two reads of the active-path counter
+  uint32_t timer_mask = 1u << kTimerTraceClosest;
+  std::vector<hipEvent_t> event_pool;
+  size_t events_used = 0;
+  std::vector<TimedSpan> spans;
+  hipEvent_t iteration_begin = nullptr, iteration_end = nullptr;
+  uint32_t* host_counters = nullptr;  // pinned
+  etx_hip_stats_t stats = {};
+  float4* resolve_buffer = nullptr;
+  void* comm = nullptr;  // ncclComm_t (host_comm.cpp)
+  int rank = 0, world = 1;
+
+  bool fail(int, const std::string& msg) {
+    error = msg;
+    return false;
+  }
+};
+
+namespace {
+
+#define HIP_OK(ctx, call)                                                                 \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      (ctx)->error = std::string(#call) + " failed: " + hipGetErrorString(e_);           \
+      return ETX_HIP_ERROR_HIP;                                                           \
+    }                                                                                     \
+  } while (0)
+
+template <class T>
+int device_alloc(etx_hip_context* ctx, T*& ptr, size_t count) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    ctx->error = "hipMalloc(" + std::to_string(bytes) + ") failed: " + hipGetErrorString(e);
+    return ETX_HIP_ERROR_HIP;
+  }
+  ctx->allocations.push_back(p);
+  ptr = reinterpret_cast<T*>(p);
+  return 0;
+}
+
+void release_pipeline(etx_hip_context* ctx) {
+  for (void* p : ctx->allocations)
+    (void)hipFree(p);
+  ctx->allocations.clear();
+  ctx->pipe = {};
+  ctx->resolve_buffer = nullptr;
+}
+
+uint32_t next_pow2(uint32_t v) {
+  v--;
+  v |= v >> 1, v |= v >> 2, v |= v >> 4, v |= v >> 8, v |= v >> 16;
+  return v + 1;
+}
+
+int allocate_pipeline(etx_hip_context* ctx) {
+  release_pipeline(ctx);
+  Pipeline& p = ctx->pipe;
+  const uint32_t n = ctx->scene.film_w * ctx->scene.film_h;
+  p.scene = ctx->scene.device;
+  p.capacity = n;
+  int rc = 0;
+  for (int s = 0; s < 2; ++s) {
+    if ((rc = device_alloc(ctx, p.paths[s].ray_o_tmin, n)) || (rc = device_alloc(ctx, p.paths[s].ray_d_tmax, n)) || (rc = device_alloc(ctx, p.paths[s].thr_eta, n)) ||
+        (rc = device_alloc(ctx, p.paths[s].mis, n)) || (rc = device_alloc(ctx, p.paths[s].meta, n)) || (rc = device_alloc(ctx, p.paths[s].path_id, n)))
+      return rc;
+  }
+  if ((rc = device_alloc(ctx, p.hits, n)))
+    return rc;
+  // light vertex pool: the reference grows a std::vector (vcm_cpu.cxx:131-171); here a fixed pool sized for
+  // 16 stored vertices per path on average, overflow is detected and reported (never silently dropped).
+  uint32_t per_path = 16;
+  if (const char* e = getenv("ETX_HIP_LIGHT_VERTICES_PER_PATH"))
+    per_path = std::max(1, atoi(e));
+  uint64_t lv_cap64 = uint64_t(n) * per_path;
+  if (lv_cap64 > (1ull << 30))
+    lv_cap64 = 1ull << 30;
+  p.lv.capacity = uint32_t(lv_cap64);
+  if ((rc = device_alloc(ctx, p.lv.pos_dvcm, p.lv.capacity)) || (rc = device_alloc(ctx, p.lv.wi_dvc, p.lv.capacity)) || (rc = device_alloc(ctx, p.lv.thr_dvm, p.lv.capacity)) ||
+      (rc = device_alloc(ctx, p.lv.nrm_tri, p.lv.capacity)) || (rc = device_alloc(ctx, p.lv.bc_len_med, p.lv.capacity)) || (rc = device_alloc(ctx, p.lv.next, p.lv.capacity)))
+    return rc;
+  if ((rc = device_alloc(ctx, p.light_path_head, n)))
+    return rc;
+  p.grid.hash_capacity = next_pow2(p.lv.capacity);
+  if ((rc = device_alloc(ctx, p.grid.cell_ends, p.grid.hash_capacity)) || (rc = device_alloc(ctx, p.grid.pos_len, p.lv.capacity)) ||
+      (rc = device_alloc(ctx, p.grid.nrm_dvcm, p.lv.capacity)) || (rc = device_alloc(ctx, p.grid.win_dvm, p.lv.capacity)) || (rc = device_alloc(ctx, p.grid.thr, p.lv.capacity)) ||
+      (rc = device_alloc(ctx, p.grid.block_sums, p.grid.hash_capacity / 2048u + 1024u)))
+    return rc;
+  if ((rc = device_alloc(ctx, p.grid_params, 1)))
+    return rc;
+  if ((rc = device_alloc(ctx, p.cv.hit, n)) || (rc = device_alloc(ctx, p.cv.wi_medium, n)) || (rc = device_alloc(ctx, p.cv.thr_depth, n)) || (rc = device_alloc(ctx, p.cv.mis_pixel, n)) ||
+      (rc = device_alloc(ctx, p.cv.seed, n)))
+    return rc;
+  if ((rc = device_alloc(ctx, p.camera_sum, n)) || (rc = device_alloc(ctx, p.light_sum, n)) || (rc = device_alloc(ctx, ctx->resolve_buffer, n)))
+    return rc;
+  if ((rc = device_alloc(ctx, p.counters, kCounterCount)))
+    return rc;
+  HIP_OK(ctx, hipMemset(p.counters, 0, kCounterCount * sizeof(uint32_t)));
+  HIP_OK(ctx, hipMemset(p.grid_params, 0, sizeof(GridParams)));
+  HIP_OK(ctx, hipMemset(p.camera_sum, 0, size_t(n) * sizeof(float4)));
+  HIP_OK(ctx, hipMemset(p.light_sum, 0, size_t(n) * sizeof(float4)));
+  return 0;
+}
+
+hipEvent_t take_event(etx_hip_context* ctx) {
+  if (ctx->events_used == ctx->event_pool.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess)
+      return nullptr;
+    ctx->event_pool.push_back(e);
+  }
+  return ctx->event_pool[ctx->events_used++];
+}
+
+struct ScopedTimer {
+  etx_hip_context* ctx;
+  bool active;
+  TimedSpan span;
+  ScopedTimer(etx_hip_context* c, uint32_t id)
+    : ctx(c)
+    , active((c->timer_mask >> id) & 1u) {
+    if (active) {
+      span.id = id;
+      span.begin = take_event(ctx);
+      span.end = take_event(ctx);
+      active = span.begin && span.end;
+      if (active)
+        (void)hipEventRecord(span.begin, ctx->stream);
+    }
+  }
+  ~ScopedTimer() {
+    if (active) {
+      (void)hipEventRecord(span.end, ctx->stream);
+      ctx->spans.push_back(span);
+    }
+  }
+};
+
+int read_counters(etx_hip_context* ctx) {
+  HIP_OK(ctx, hipMemcpyAsync(ctx->host_counters, ctx->pipe.counters, kCounterCount * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// vcm_cpu.cxx:95-124 start_next_iteration: radius schedule and VC/VM weights
+VcmParams make_iteration_params(const etx_hip_context* ctx, uint32_t iteration) {
+  const auto& o = ctx->vcm_options;
+  const auto& sc = ctx->scene.host_copy;
+  VcmParams it = {};
+  it.options = o.options;
+  it.kernel = o.kernel;
+  it.iteration = iteration;
+  it.film_w = ctx->scene.film_w, it.film_h = ctx->scene.film_h;
+  it.path_count = it.film_w * it.film_h;
+  float used_radius = o.initial_radius;
+  if (used_radius == 0.0f) {
+    uint32_t max_dim = std::max(it.film_w, it.film_h);
+    used_radius = 5.0f * sc.bounds_radius / float(max_dim);
+  }
+  float radius_scale = 1.0f / (1.0f + float(iteration) / float(o.radius_decay));
+  it.current_radius = used_radius * radius_scale;
+  float eta_vcm = kPi * it.current_radius * it.current_radius * float(it.path_count);
+  it.vc_weight = 1.0f / eta_vcm;
+  it.vm_weight = (o.options & ETX_VCM_ENABLE_MERGING) ? eta_vcm : 0.0f;
+  it.vm_normalization = 1.0f / eta_vcm;
+  return it;
+}
+
+// One pass of the wavefront loop: trace + shade rounds until no path is alive. The active count lives on the device;
+// it is read back every `check_interval` rounds (a pass usually ends after a few dozen rounds).
+template <class ShadeFn>
+int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, uint64_t& rounds) {
+  uint32_t set = 0;
+  const uint32_t max_rounds = ctx->scene.host_copy.max_path_length * 2u + 16u;  // boundaries do not add depth
+  for (uint32_t round = 0; round < max_rounds;) {
+    for (uint32_t k = 0; k < ctx->check_interval; ++k, ++round) {
+      {
+        ScopedTimer t(ctx, kTimerTraceClosest);
+        launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB);
+      }
+      shade(set);
+      set ^= 1u;
+      rounds++;
+    }
+    int rc = read_counters(ctx);
+    if (rc)
+      return rc;
+    if (ctx->host_counters[set == 0 ? kCntActiveA : kCntActiveB] == 0u)
+      return 0;
+  }
+  return 0;
+}
+
+int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
+  const VcmParams it = make_iteration_params(ctx, iteration);
+  Pipeline& p = ctx->pipe;
+  hipStream_t s = ctx->stream;
+  uint64_t rounds = 0;
+
+  launch_iteration_reset(s, p);
+  {
+    ScopedTimer t(ctx, kTimerGenerate);
+    launch_light_generate(s, p, it);
+  }
+  int rc = run_bounce_loop(
+    ctx,
+    [&](uint32_t set) {
+      ScopedTimer t(ctx, kTimerShadeLight);
+      launch_light_shade(s, p, it, set);
+    },
+    rounds);
+  if (rc)
+    return rc;
+
+#if defined(ETX_HIP_DEBUG_COUNTERS)
+  launch_debug_lists_fwd(s, p);
+#endif
+  if (opt_merge_vertices(it)) {
+    ScopedTimer t(ctx, kTimerGridBuild);
+    launch_grid_build(s, p, it);
+  }
+
+  {
+    ScopedTimer t(ctx, kTimerGenerate);
+    launch_camera_generate(s, p, it);
+  }
+  rc = run_bounce_loop(
+    ctx,
+    [&](uint32_t set) {
+      {
+        ScopedTimer t(ctx, kTimerShadeCamera);
+        launch_camera_shade(s, p, it, set);
+      }
+      if (opt_connect_vertices(it)) {
+        ScopedTimer t(ctx, kTimerConnect);
+        launch_connect(s, p, it);
+      }
+      if (opt_merge_vertices(it)) {
+        ScopedTimer t(ctx, kTimerMerge);
+        launch_merge(s, p, it);
+      }
+    },
+    rounds);
+  if (rc)
+    return rc;
+  ctx->stats.wavefront_bounces = rounds;
+  return 0;
+}
+
+void collect_stats(etx_hip_context* ctx) {
+  auto& st = ctx->stats;
+  double ms[kTimerCount] = {};
+  uint64_t launches[kTimerCount] = {};
+  for (const auto& span : ctx->spans) {
+    float t = 0.0f;
+    if (hipEventElapsedTime(&t, span.begin, span.end) == hipSuccess) {
+      ms[span.id] += t;
+      launches[span.id]++;
+    }
+  }
+  st.ms_trace_closest = ms[kTimerTraceClosest];
+  st.launches_trace_closest = launches[kTimerTraceClosest];
+  st.ms_shade_light = ms[kTimerShadeLight];
+  st.ms_shade_camera = ms[kTimerShadeCamera];
+  st.ms_connect = ms[kTimerConnect];
+  st.ms_merge = ms[kTimerMerge];
+  st.ms_grid_build = ms[kTimerGridBuild];
+  st.ms_generate = ms[kTimerGenerate];
+  st.ms_trace_shadow = 0.0;
+  st.launches_trace_shadow = 0;
+  ctx->spans.clear();
+  ctx->events_used = 0;
+
+  const uint32_t* c = ctx->host_counters;
+  auto u64 = [&](uint32_t i) {
+    uint64_t v;
+    memcpy(&v, c + i, sizeof(v));
+    return v;
+  };
+  st.rays_extension = u64(kStatRaysExtension);
+  st.rays_shadow = u64(kStatRaysShadow);
+  st.light_vertices = c[kCntLightVertices];
+  st.camera_vertices = u64(kStatCameraVertices);
+  st.photons_examined = u64(kStatPhotonsExamined);
+  st.photons_merged = u64(kStatPhotonsMerged);
+  st.splats = u64(kStatSplats);
+  st.overflow_flags = c[kCntOverflow];
+#if defined(ETX_HIP_DEBUG_COUNTERS)
+  fprintf(stderr, "[dbg] it %u: lv %u cv %llu pairs %llu shadow %llu list_sum %llu list_max %u ext %llu\n", st.current_iteration, c[kCntLightVertices], (unsigned long long)u64(kStatCameraVertices),
+    (unsigned long long)u64(kDbgBase + 0), (unsigned long long)st.rays_shadow, (unsigned long long)u64(kDbgBase + 2), c[kDbgBase + 4], (unsigned long long)st.rays_extension);
+#endif
+}
+
+}  // namespace
+
+extern "C" {
+
+int etx_hip_abi_version(void) {
+  return ETX_HIP_ABI_VERSION;
+}
+
+const char* etx_hip_last_error(const etx_hip_context* context) {
+  return context ? context->error.c_str() : g_create_error.c_str();
+}
+
+int etx_hip_create(int device, etx_hip_context** out_context) {
+  if (out_context == nullptr) {
+    g_create_error = "out_context is null";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  *out_context = nullptr;
+  int count = 0;
+  if ((hipGetDeviceCount(&count) != hipSuccess) || (count == 0)) {
+    g_create_error = "no HIP device available (this backend has no CPU path)";
+    return ETX_HIP_ERROR_NO_DEVICE;
+  }
+  if ((device < 0) || (device >= count)) {
+    g_create_error = "device index out of range";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  hipDeviceProp_t props = {};
+  if (hipGetDeviceProperties(&props, device) != hipSuccess) {
+    g_create_error = "hipGetDeviceProperties failed";
+    return ETX_HIP_ERROR_HIP;
+  }
+  if (strncmp(props.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("device is ") + props.gcnArchName + ", this library is built for gfx950 only";
+    return ETX_HIP_ERROR_NO_DEVICE;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    g_create_error = "hipSetDevice failed";
+    return ETX_HIP_ERROR_HIP;
+  }
+  auto ctx = std::make_unique<etx_hip_context>();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    g_create_error = "hipStreamCreate failed";
+    return ETX_HIP_ERROR_HIP;
+  }
+  if ((hipEventCreate(&ctx->iteration_begin) != hipSuccess) || (hipEventCreate(&ctx->iteration_end) != hipSuccess)) {
+    g_create_error = "hipEventCreate failed";
+    return ETX_HIP_ERROR_HIP;
+  }
+  if (hipHostMalloc(reinterpret_cast<void**>(&ctx->host_counters), kCounterCount * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+    g_create_error = "hipHostMalloc failed";
+    return ETX_HIP_ERROR_HIP;
+  }
+  memset(ctx->host_counters, 0, kCounterCount * sizeof(uint32_t));
+  if (const char* e = getenv("ETX_HIP_CHECK_INTERVAL"))
+    ctx->check_interval = std::max(1, atoi(e));
+  if (const char* e = getenv("ETX_HIP_TIMERS"))
+    ctx->timer_mask = uint32_t(strtoul(e, nullptr, 0));
+  *out_context = ctx.release();
+  return ETX_HIP_OK;
+}
+
+void etx_hip_comm_destroy_internal(etx_hip_context* context);
+
+void etx_hip_destroy(etx_hip_context* context) {
+  if (context == nullptr)
+    return;
+  (void)hipSetDevice(context->device);
+  (void)hipStreamSynchronize(context->stream);
+  etx_hip_comm_destroy_internal(context);
+  release_pipeline(context);
+  context->scene.release();
+  for (hipEvent_t e : context->event_pool)
+    (void)hipEventDestroy(e);
+  if (context->iteration_begin)
+    (void)hipEventDestroy(context->iteration_begin);
+  if (context->iteration_end)
+    (void)hipEventDestroy(context->iteration_end);
+  if (context->host_counters)
+    (void)hipHostFree(context->host_counters);
+  if (context->stream)
+    (void)hipStreamDestroy(context->stream);
+  delete context;
+}
+
+int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, const etx_abi_camera* camera) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  HIP_OK(context, hipSetDevice(context->device));
+  HIP_OK(context, hipStreamSynchronize(context->stream));
+  context->scene_ready = false;
+  context->armed = false;
+  int rc = etxh::build_device_scene(scene, camera, context->scene, context->error);
+  if (rc)
+    return rc;
+  rc = allocate_pipeline(context);
+  if (rc)
+    return rc;
+  context->scene_ready = true;
+  return ETX_HIP_OK;
+}
+
+int etx_hip_upload_bluenoise(etx_hip_context* context, uint32_t, const int32_t*, const int32_t*, const int32_t*) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  context->error = "blue-noise tables are not consumed by the device path yet: run with options.blue_noise = 0";
+  return ETX_HIP_ERROR_UNSUPPORTED;
+}
+
+int etx_hip_begin(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  if (context->scene_ready == false) {
+    context->error = "etx_hip_begin: no scene uploaded";
+    return ETX_HIP_ERROR_STATE;
+  }
+  if (iteration_stride == 0) {
+    context->error = "iteration_stride must be >= 1";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  if (integrator == ETX_HIP_INTEGRATOR_VCM) {
+    if ((options == nullptr) || (options_size != sizeof(etx_abi_vcm_options))) {
+      context->error = "VCM expects etx_abi_vcm_options (32 bytes)";
+      return ETX_HIP_ERROR_INVALID_ARGUMENT;
+    }
+    memcpy(&context->vcm_options, options, sizeof(etx_abi_vcm_options));
+    if (context->vcm_options.blue_noise) {
+      context->error = "options.blue_noise needs the host's blue-noise tables (etx_hip_upload_bluenoise), which the device path does not consume yet; set vcm-blue_noise=false";
+      return ETX_HIP_ERROR_UNSUPPORTED;
+    }
+    if (context->vcm_options.radius_decay == 0) {
+      context->error = "radius_decay must be >= 1";
+      return ETX_HIP_ERROR_INVALID_ARGUMENT;
+    }
+  } else {
+    context->error = "integrator " + std::to_string(integrator) + " is not implemented by the device path";
+    return ETX_HIP_ERROR_UNSUPPORTED;
+  }
+  HIP_OK(context, hipSetDevice(context->device));
+  context->integrator = integrator;
+  context->first_iteration = first_iteration;
+  context->iteration_stride = iteration_stride;
+  context->next_iteration = first_iteration;
+  context->local_iterations = 0;
+  context->global_iterations = 0;
+  context->reduced = false;
+  context->stats = {};
+  const size_t n = size_t(context->pipe.capacity);
+  HIP_OK(context, hipMemsetAsync(context->pipe.camera_sum, 0, n * sizeof(float4), context->stream));
+  HIP_OK(context, hipMemsetAsync(context->pipe.light_sum, 0, n * sizeof(float4), context->stream));
+  context->armed = true;
+  return ETX_HIP_OK;
+}
+
+int etx_hip_render_iteration(etx_hip_context* context) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  if (context->armed == false) {
+    context->error = "etx_hip_render_iteration: call etx_hip_begin first";
+    return ETX_HIP_ERROR_STATE;
+  }
+  if (context->reduced) {
+    context->error = "etx_hip_render_iteration after etx_hip_reduce_film: call etx_hip_begin again";
+    return ETX_HIP_ERROR_STATE;
+  }
+  HIP_OK(context, hipSetDevice(context->device));
+  HIP_OK(context, hipEventRecord(context->iteration_begin, context->stream));
+  context->stats.current_iteration = context->next_iteration;
+  int rc = render_vcm_iteration(context, context->next_iteration);
+  if (rc)
+    return rc;
+  HIP_OK(context, hipEventRecord(context->iteration_end, context->stream));
+  // the bounce loop already synchronised on the counters; the tail (nothing after the last read) is empty
+  HIP_OK(context, hipEventSynchronize(context->iteration_end));
+  rc = read_counters(context);
+  if (rc)
+    return rc;
+  float ms = 0.0f;
+  (void)hipEventElapsedTime(&ms, context->iteration_begin, context->iteration_end);
+  collect_stats(context);
+  context->stats.last_iteration_time = double(ms) * 1.0e-3;
+  context->stats.total_time += context->stats.last_iteration_time;
+  context->stats.completed_iterations += 1;
+  context->local_iterations += 1;
+  context->next_iteration += context->iteration_stride;
+  if (context->stats.overflow_flags) {
+    context->error = "device pool overflow in iteration " + std::to_string(context->stats.current_iteration) + " (flags " + std::to_string(context->stats.overflow_flags) +
+                     "): raise ETX_HIP_LIGHT_VERTICES_PER_PATH";
+    return ETX_HIP_ERROR_OVERFLOW;
+  }
+  return ETX_HIP_OK;
+}
+
+int etx_hip_poll(etx_hip_context* context) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  hipError_t e = hipStreamQuery(context->stream);
+  if (e == hipSuccess)
+    return 1;
+  if (e == hipErrorNotReady)
+    return 0;
+  context->error = std::string("hipStreamQuery: ") + hipGetErrorString(e);
+  return ETX_HIP_ERROR_HIP;
+}
+
+int etx_hip_sync(etx_hip_context* context) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  HIP_OK(context, hipSetDevice(context->device));
+  HIP_OK(context, hipStreamSynchronize(context->stream));
+  return ETX_HIP_OK;
+}
+
+int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size_t dst_bytes) {
+  if ((context == nullptr) || (dst_rgba == nullptr))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  if (context->scene_ready == false) {
+    context->error = "etx_hip_read_film: no scene uploaded";
+    return ETX_HIP_ERROR_STATE;
+  }
+  const size_t n = context->pipe.capacity;
+  if (dst_bytes != n * sizeof(float4)) {
+    context->error = "etx_hip_read_film: dst_bytes must be width*height*16";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  if ((layer < ETX_HIP_LAYER_CAMERA) || (layer > ETX_HIP_LAYER_RESULT)) {
+    context->error = "etx_hip_read_film: unknown layer";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  HIP_OK(context, hipSetDevice(context->device));
+  uint64_t iterations = context->reduced ? context->global_iterations : context->local_iterations;
+  float scale = iterations ? float(1.0 / double(iterations)) : 0.0f;
+  launch_film_resolve(context->stream, context->pipe.camera_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, layer);
+  HIP_OK(context, hipMemcpyAsync(dst_rgba, context->resolve_buffer, dst_bytes, hipMemcpyDeviceToHost, context->stream));
+  HIP_OK(context, hipStreamSynchronize(context->stream));
+  return ETX_HIP_OK;
+}
+
+int etx_hip_stats(etx_hip_context* context, etx_hip_stats_t* out_stats, size_t stats_size) {
+  if ((context == nullptr) || (out_stats == nullptr) || (stats_size != sizeof(etx_hip_stats_t)))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  *out_stats = context->stats;
+  return ETX_HIP_OK;
+}
+
+int etx_hip_trace_rays(etx_hip_context* context, const float* rays_8f, uint64_t count, float* hits_4f) {
+  if ((context == nullptr) || ((count > 0) && ((rays_8f == nullptr) || (hits_4f == nullptr))))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  if (context->scene_ready == false) {
+    context->error = "etx_hip_trace_rays: no scene uploaded";
+    return ETX_HIP_ERROR_STATE;
+  }
+  if (count == 0)
+    return ETX_HIP_OK;
+  if (count > 0xffffffffull) {
+    context->error = "ray count exceeds 2^32";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  HIP_OK(context, hipSetDevice(context->device));
+  std::vector<float4> o(count), d(count);
+  for (uint64_t i = 0; i < count; ++i) {
+    o[i] = make_float4(rays_8f[8 * i + 0], rays_8f[8 * i + 1], rays_8f[8 * i + 2], rays_8f[8 * i + 3]);
+    d[i] = make_float4(rays_8f[8 * i + 4], rays_8f[8 * i + 5], rays_8f[8 * i + 6], rays_8f[8 * i + 7]);
+  }
+  float4 *d_o = nullptr, *d_d = nullptr, *d_h = nullptr;
+  HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&d_o), count * sizeof(float4)));
+  HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&d_d), count * sizeof(float4)));
+  HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&d_h), count * sizeof(float4)));
+  int rc = ETX_HIP_OK;
+  do {
+    if ((hipMemcpyAsync(d_o, o.data(), count * sizeof(float4), hipMemcpyHostToDevice, context->stream) != hipSuccess) ||
+        (hipMemcpyAsync(d_d, d.data(), count * sizeof(float4), hipMemcpyHostToDevice, context->stream) != hipSuccess)) {
+      context->error = "ray upload failed";
+      rc = ETX_HIP_ERROR_HIP;
+      break;
+    }
+    launch_trace_rays(context->stream, context->scene.device, d_o, d_d, d_h, uint32_t(count));
+    if ((hipMemcpyAsync(hits_4f, d_h, count * sizeof(float4), hipMemcpyDeviceToHost, context->stream) != hipSuccess) || (hipStreamSynchronize(context->stream) != hipSuccess)) {
+      context->error = std::string("trace kernel failed: ") + hipGetErrorString(hipGetLastError());
+      rc = ETX_HIP_ERROR_HIP;
+    }
+  } while (false);
+  (void)hipFree(d_o);
+  (void)hipFree(d_d);
+  (void)hipFree(d_h);
+  return rc;
+}
+
+int etx_hip_trace_rays_device(etx_hip_context* context, const void* d_rays_o_tmin, const void* d_rays_d_tmax, uint64_t count, void* d_hits, uint32_t repeat, double* out_avg_ms) {
+  if ((context == nullptr) || (d_rays_o_tmin == nullptr) || (d_rays_d_tmax == nullptr) || (d_hits == nullptr) || (count == 0) || (count > 0xffffffffull) || (repeat == 0))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  if (context->scene_ready == false) {
+    context->error = "etx_hip_trace_rays_device: no scene uploaded";
+    return ETX_HIP_ERROR_STATE;
+  }
+  HIP_OK(context, hipSetDevice(context->device));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_OK(context, hipEventCreate(&e0));
+  HIP_OK(context, hipEventCreate(&e1));
+  // one untimed launch (code object load, caches)
+  launch_trace_rays(context->stream, context->scene.device, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
+    reinterpret_cast<float4*>(d_hits), uint32_t(count));
+  HIP_OK(context, hipEventRecord(e0, context->stream));
+  for (uint32_t r = 0; r < repeat; ++r)
+    launch_trace_rays(context->stream, context->scene.device, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
+      reinterpret_cast<float4*>(d_hits), uint32_t(count));
+  HIP_OK(context, hipEventRecord(e1, context->stream));
+  HIP_OK(context, hipEventSynchronize(e1));
+  float ms = 0.0f;
+  HIP_OK(context, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (out_avg_ms)
+    *out_avg_ms = double(ms) / double(repeat);
+  return ETX_HIP_OK;
+}
+
+int etx_hip_kat(etx_hip_context* context, int which, const float* in, uint64_t count, float* out) {
+  static const uint32_t in_width[] = {2, 6, 3, 5, 4, 2};
+  static const uint32_t out_width[] = {4, 3, 6, 3, 1, 2};
+  if ((context == nullptr) || (which < 0) || (which > 5) || (in == nullptr) || (out == nullptr) || (count > (1u << 24)))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  if (count == 0)
+    return ETX_HIP_OK;
+  HIP_OK(context, hipSetDevice(context->device));
+  float *d_in = nullptr, *d_out = nullptr;
+  HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&d_in), count * in_width[which] * sizeof(float)));
+  HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&d_out), count * out_width[which] * sizeof(float)));
+  int rc = ETX_HIP_OK;
+  if (hipMemcpyAsync(d_in, in, count * in_width[which] * sizeof(float), hipMemcpyHostToDevice, context->stream) != hipSuccess)
+    rc = ETX_HIP_ERROR_HIP;
+  if (rc == ETX_HIP_OK) {
+    launch_kat(context->stream, which, d_in, uint32_t(count), d_out);
+    if ((hipMemcpyAsync(out, d_out, count * out_width[which] * sizeof(float), hipMemcpyDeviceToHost, context->stream) != hipSuccess) ||
+        (hipStreamSynchronize(context->stream) != hipSuccess))
+      rc = ETX_HIP_ERROR_HIP;
+  }
+  if (rc)
+    context->error = std::string("etx_hip_kat failed: ") + hipGetErrorString(hipGetLastError());
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return rc;
+}
+
+}  // extern "C"
+
+// accessors for host_comm.cpp (kept out of the public header)
+hipStream_t etx_hip_internal_stream(etx_hip_context* c) {
+  return c->stream;
+}
+void** etx_hip_internal_comm(etx_hip_context* c) {
+  return &c->comm;
+}
+void etx_hip_internal_film(etx_hip_context* c, float** camera, float** light, size_t* floats) {
+  *camera = reinterpret_cast<float*>(c->pipe.camera_sum);
+  *light = reinterpret_cast<float*>(c->pipe.light_sum);
+  *floats = size_t(c->pipe.capacity) * 4u;
+}
+void etx_hip_internal_set_error(etx_hip_context* c, const std::string& e) {
+  c->error = e;
+}
+void etx_hip_internal_rank(etx_hip_context* c, int** rank, int** world) {
+  *rank = &c->rank;
+  *world = &c->world;
+}
+void etx_hip_internal_iterations(etx_hip_context* c, uint32_t** local, uint64_t** global, bool** reduced) {
+  *local = &c->local_iterations;
+  *global = &c->global_iterations;
+  *reduced = &c->reduced;
+}
+int etx_hip_internal_device(etx_hip_context* c) {
+  return c->device;
+}

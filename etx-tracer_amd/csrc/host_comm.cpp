@@ -1,0 +1,123 @@
+// host_comm.cpp - multi-GPU film reduction over RCCL (xGMI).
+// The reference has no communication layer at all; iterations are sharded over ranks
+// (etx_hip_begin first/stride) and the ONLY exchange is one sum-reduce of the two float4 film accumulators plus the
+// iteration counter. Payload at 1080p: 2 x 33 MB fp32 - one ring all-reduce, per-link bound.
+#include "../../include/etx_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+
+static_assert(sizeof(ncclUniqueId) == ETX_HIP_UNIQUE_ID_BYTES, "ncclUniqueId size");
+
+hipStream_t etx_hip_internal_stream(etx_hip_context* c);
+void** etx_hip_internal_comm(etx_hip_context* c);
+void etx_hip_internal_film(etx_hip_context* c, float** camera, float** light, size_t* floats);
+void etx_hip_internal_set_error(etx_hip_context* c, const std::string& e);
+void etx_hip_internal_rank(etx_hip_context* c, int** rank, int** world);
+void etx_hip_internal_iterations(etx_hip_context* c, uint32_t** local, uint64_t** global, bool** reduced);
+int etx_hip_internal_device(etx_hip_context* c);
+
+extern "C" {
+
+void etx_hip_comm_destroy_internal(etx_hip_context* context) {
+  void** comm = etx_hip_internal_comm(context);
+  if (*comm) {
+    (void)ncclCommDestroy(reinterpret_cast<ncclComm_t>(*comm));
+    *comm = nullptr;
+  }
+}
+
+int etx_hip_comm_unique_id(void* out_id_128_bytes) {
+  if (out_id_128_bytes == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess)
+    return ETX_HIP_ERROR_COMM;
+  memcpy(out_id_128_bytes, &id, sizeof(id));
+  return ETX_HIP_OK;
+}
+
+int etx_hip_comm_init(etx_hip_context* context, int rank, int world_size, const void* id_128_bytes) {
+  if ((context == nullptr) || (id_128_bytes == nullptr) || (world_size < 1) || (rank < 0) || (rank >= world_size))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  etx_hip_comm_destroy_internal(context);
+  if (hipSetDevice(etx_hip_internal_device(context)) != hipSuccess) {
+    etx_hip_internal_set_error(context, "hipSetDevice failed");
+    return ETX_HIP_ERROR_HIP;
+  }
+  ncclUniqueId id;
+  memcpy(&id, id_128_bytes, sizeof(id));
+  ncclComm_t comm = nullptr;
+  ncclResult_t r = ncclCommInitRank(&comm, world_size, id, rank);
+  if (r != ncclSuccess) {
+    etx_hip_internal_set_error(context, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    return ETX_HIP_ERROR_COMM;
+  }
+  *etx_hip_internal_comm(context) = comm;
+  int *prank = nullptr, *pworld = nullptr;
+  etx_hip_internal_rank(context, &prank, &pworld);
+  *prank = rank;
+  *pworld = world_size;
+  return ETX_HIP_OK;
+}
+
+int etx_hip_reduce_film(etx_hip_context* context) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  uint32_t* local = nullptr;
+  uint64_t* global = nullptr;
+  bool* reduced = nullptr;
+  etx_hip_internal_iterations(context, &local, &global, &reduced);
+  ncclComm_t comm = reinterpret_cast<ncclComm_t>(*etx_hip_internal_comm(context));
+  if (comm == nullptr) {
+    // single rank: the reduce is the identity
+    *global = *local;
+    *reduced = true;
+    return ETX_HIP_OK;
+  }
+  if (hipSetDevice(etx_hip_internal_device(context)) != hipSuccess) {
+    etx_hip_internal_set_error(context, "hipSetDevice failed");
+    return ETX_HIP_ERROR_HIP;
+  }
+  hipStream_t stream = etx_hip_internal_stream(context);
+  float *camera = nullptr, *light = nullptr;
+  size_t floats = 0;
+  etx_hip_internal_film(context, &camera, &light, &floats);
+  unsigned long long* d_iterations = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d_iterations), sizeof(unsigned long long)) != hipSuccess) {
+    etx_hip_internal_set_error(context, "hipMalloc failed");
+    return ETX_HIP_ERROR_HIP;
+  }
+  unsigned long long h_iterations = *local;
+  (void)hipMemcpyAsync(d_iterations, &h_iterations, sizeof(h_iterations), hipMemcpyHostToDevice, stream);
+  ncclResult_t r = ncclGroupStart();
+  if (r == ncclSuccess)
+    r = ncclAllReduce(camera, camera, floats, ncclFloat, ncclSum, comm, stream);
+  if (r == ncclSuccess)
+    r = ncclAllReduce(light, light, floats, ncclFloat, ncclSum, comm, stream);
+  if (r == ncclSuccess)
+    r = ncclAllReduce(d_iterations, d_iterations, 1, ncclUint64, ncclSum, comm, stream);
+  ncclResult_t r2 = ncclGroupEnd();
+  if (r == ncclSuccess)
+    r = r2;
+  if (r != ncclSuccess) {
+    (void)hipFree(d_iterations);
+    etx_hip_internal_set_error(context, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    return ETX_HIP_ERROR_COMM;
+  }
+  (void)hipMemcpyAsync(&h_iterations, d_iterations, sizeof(h_iterations), hipMemcpyDeviceToHost, stream);
+  if (hipStreamSynchronize(stream) != hipSuccess) {
+    (void)hipFree(d_iterations);
+    etx_hip_internal_set_error(context, "stream synchronize failed after all-reduce");
+    return ETX_HIP_ERROR_HIP;
+  }
+  (void)hipFree(d_iterations);
+  *global = h_iterations;
+  *reduced = true;
+  return ETX_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,435 @@
+// host_scene.cpp - scene upload for the gfx950 backend (replaces Raytracing::commit_changes, sources/etx/rt/rt.cxx:58-88,
+// and follows the author's disabled device-upload sketch rt.cxx:141-238: deep copy + pointer patching).
+#include "host_scene.h"
+#include "dev_bsdf.h"
+#include "dev_bvh.h"
+#include "../../include/etx_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace etxh {
+
+using namespace etxd;
+
+DeviceScene::~DeviceScene() {
+  release();
+}
+
+void DeviceScene::release() {
+  for (void* p : allocations)
+    (void)hipFree(p);
+  allocations.clear();
+  device = nullptr;
+  host_copy = {};
+}
+
+namespace {
+
+struct Builder {
+  struct Prim {
+    f3 bmin, bmax, centroid;
+    uint32_t index;
+  };
+  struct TmpNode {
+    f3 bmin, bmax;
+    int32_t left = -1, right = -1;  // children (TmpNode index) or -1 for leaf
+    uint32_t first = 0, count = 0;
+  };
+  std::vector<Prim> prims;
+  std::vector<TmpNode> nodes;
+  uint32_t max_depth = 0;
+
+  static float half_area(const f3& mn, const f3& mx) {
+    f3 d = mx - mn;
+    return d.x * d.y + d.y * d.z + d.z * d.x;
+  }
+  static float axis(const f3& v, int a) {
+    return a == 0 ? v.x : (a == 1 ? v.y : v.z);
+  }
+
+  uint32_t subdivide(uint32_t first, uint32_t count, uint32_t depth) {
+    uint32_t index = uint32_t(nodes.size());
+    nodes.emplace_back();
+    max_depth = std::max(max_depth, depth);
+    f3 mn = mk3(kMaxFloat), mx = mk3(-kMaxFloat), cmn = mk3(kMaxFloat), cmx = mk3(-kMaxFloat);
+    for (uint32_t i = first; i < first + count; ++i) {
+      mn = fmin3(mn, prims[i].bmin), mx = fmax3(mx, prims[i].bmax);
+      cmn = fmin3(cmn, prims[i].centroid), cmx = fmax3(cmx, prims[i].centroid);
+    }
+    nodes[index].bmin = mn, nodes[index].bmax = mx, nodes[index].first = first, nodes[index].count = count;
+    constexpr uint32_t kMaxLeaf = 4;  // leaf encoding allows 8
+    if (count <= 1)
+      return index;
+
+    constexpr int kBins = 16;
+    float best_cost = kMaxFloat;
+    int best_axis = -1, best_split = 0;
+    for (int a = 0; a < 3; ++a) {
+      float lo = axis(cmn, a), hi = axis(cmx, a);
+      if (!(hi - lo > 0.0f))
+        continue;
+      struct Bin {
+        f3 mn = mk3(kMaxFloat), mx = mk3(-kMaxFloat);
+        uint32_t n = 0;
+      } bins[kBins];
+      float scale = float(kBins) / (hi - lo);
+      for (uint32_t i = first; i < first + count; ++i) {
+        int b = std::min(kBins - 1, int((axis(prims[i].centroid, a) - lo) * scale));
+        bins[b].n++, bins[b].mn = fmin3(bins[b].mn, prims[i].bmin), bins[b].mx = fmax3(bins[b].mx, prims[i].bmax);
+      }
+      float la[kBins - 1], ra[kBins - 1];
+      uint32_t ln[kBins - 1], rn[kBins - 1];
+      Bin l, r;
+      for (int i = 0; i < kBins - 1; ++i) {
+        l.n += bins[i].n, l.mn = fmin3(l.mn, bins[i].mn), l.mx = fmax3(l.mx, bins[i].mx);
+        ln[i] = l.n, la[i] = l.n ? half_area(l.mn, l.mx) : 0.0f;
+        int j = kBins - 1 - i;
+        r.n += bins[j].n, r.mn = fmin3(r.mn, bins[j].mn), r.mx = fmax3(r.mx, bins[j].mx);
+        rn[j - 1] = r.n, ra[j - 1] = r.n ? half_area(r.mn, r.mx) : 0.0f;
+      }
+      for (int i = 0; i < kBins - 1; ++i) {
+        if ((ln[i] == 0) || (rn[i] == 0))
+          continue;
+        float cost = la[i] * float(ln[i]) + ra[i] * float(rn[i]);
+        if (cost < best_cost)
+          best_cost = cost, best_axis = a, best_split = i;
+      }
+    }
+    uint32_t mid = first + count / 2;
+    if (best_axis >= 0) {
+      // SAH termination: traversal cost 1, intersection cost 1 (relative)
+      float leaf_cost = half_area(mn, mx) * float(count);
+      if ((count <= kMaxLeaf) && (best_cost + half_area(mn, mx) >= leaf_cost))
+        return index;
+      float lo = axis(cmn, best_axis), hi = axis(cmx, best_axis);
+      float scale = float(kBins) / (hi - lo);
+      auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim& p) {
+        return std::min(kBins - 1, int((axis(p.centroid, best_axis) - lo) * scale)) <= best_split;
+      });
+      mid = uint32_t(it - prims.begin());
+      if ((mid == first) || (mid == first + count))
+        mid = first + count / 2;
+    } else if (count <= kMaxLeaf) {
+      return index;
+    }
+    uint32_t l = subdivide(first, mid - first, depth + 1);
+    uint32_t r = subdivide(mid, first + count - mid, depth + 1);
+    nodes[index].left = int32_t(l), nodes[index].right = int32_t(r), nodes[index].count = 0;
+    return index;
+  }
+};
+
+template <class T>
+int upload(DeviceScene& out, const T* src, size_t count, const T*& dst, std::string& error) {
+  dst = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    error = "hipMalloc failed (" + std::to_string(bytes) + " bytes)";
+    return ETX_HIP_ERROR_HIP;
+  }
+  out.allocations.push_back(p);
+  if ((count > 0) && (hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)) {
+    error = "hipMemcpy failed";
+    return ETX_HIP_ERROR_HIP;
+  }
+  dst = reinterpret_cast<const T*>(p);
+  return 0;
+}
+
+f3 a3(const etx_abi_float3& v) {
+  return {v.x, v.y, v.z};
+}
+
+}  // namespace
+
+void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
+  const auto* vertices = reinterpret_cast<const etx_abi_vertex*>(scene->vertices.a);
+  const auto* triangles = reinterpret_cast<const etx_abi_triangle*>(scene->triangles.a);
+  const auto* materials = reinterpret_cast<const etx_abi_material*>(scene->materials.a);
+  const auto* images = reinterpret_cast<const etx_abi_image*>(scene->images.a);
+  uint32_t n = uint32_t(scene->triangles.count);
+  out = {};
+  if (n == 0) {
+    out.root = ~int32_t(0);
+    return;
+  }
+  Builder b;
+  b.prims.resize(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    f3 p0 = a3(vertices[triangles[i].i[0]].pos), p1 = a3(vertices[triangles[i].i[1]].pos), p2 = a3(vertices[triangles[i].i[2]].pos);
+    b.prims[i].bmin = fmin3(p0, fmin3(p1, p2));
+    b.prims[i].bmax = fmax3(p0, fmax3(p1, p2));
+    b.prims[i].centroid = (b.prims[i].bmin + b.prims[i].bmax) * 0.5f;
+    b.prims[i].index = i;
+  }
+  b.nodes.reserve(2 * n);
+  b.subdivide(0, n, 1);
+  out.depth = b.max_depth;
+
+  out.tris.resize(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t ti = b.prims[i].index;
+    const etx_abi_triangle& t = triangles[ti];
+    f3 p0 = a3(vertices[t.i[0]].pos), p1 = a3(vertices[t.i[1]].pos), p2 = a3(vertices[t.i[2]].pos);
+    uint32_t flags = 0;
+    if (t.material_index < scene->materials.count) {
+      const etx_abi_material& m = materials[t.material_index];
+      if (m.cls == ETX_MAT_VOID)
+        flags |= kTriVoid;
+      if (m.cls == ETX_MAT_BOUNDARY)
+        flags |= kTriBoundary;
+      bool alpha_image = (m.scattering.image_index != ETX_ABI_INVALID) && (m.scattering.image_index < scene->images.count) &&
+                         (images[m.scattering.image_index].options & ETX_IMAGE_HAS_ALPHA);
+      if ((m.opacity < 1.0f) || alpha_image)
+        flags |= kTriAlphaTested;
+    }
+    f3 e1 = p1 - p0, e2 = p2 - p0;
+    auto bits = [](uint32_t u) {
+      float f;
+      memcpy(&f, &u, 4);
+      return f;
+    };
+    out.tris[i].v0_index = make_float4(p0.x, p0.y, p0.z, bits(ti));
+    out.tris[i].e1_flags = make_float4(e1.x, e1.y, e1.z, bits(flags));
+    out.tris[i].e2_mat = make_float4(e2.x, e2.y, e2.z, bits(t.material_index));
+  }
+
+  // flatten: inner nodes only; a child reference is an inner index (>= 0) or ~((first << 3) | (count - 1))
+  std::vector<int32_t> remap(b.nodes.size(), -1);
+  uint32_t inner = 0;
+  for (size_t i = 0; i < b.nodes.size(); ++i)
+    if (b.nodes[i].count == 0)
+      remap[i] = int32_t(inner++);
+  auto encode = [&](int32_t tmp_index) -> int32_t {
+    const auto& tn = b.nodes[tmp_index];
+    if (tn.count == 0)
+      return remap[tmp_index];
+    return ~int32_t((tn.first << 3) | (tn.count - 1u));
+  };
+  out.nodes.resize(inner);
+  for (size_t i = 0; i < b.nodes.size(); ++i) {
+    const auto& tn = b.nodes[i];
+    if (tn.count != 0)
+      continue;
+    const auto& c0 = b.nodes[tn.left];
+    const auto& c1 = b.nodes[tn.right];
+    BvhNode& dn = out.nodes[remap[i]];
+    dn.lo0_hi0x = make_float4(c0.bmin.x, c0.bmin.y, c0.bmin.z, c0.bmax.x);
+    dn.hi0yz_lo1xy = make_float4(c0.bmax.y, c0.bmax.z, c1.bmin.x, c1.bmin.y);
+    dn.lo1z_hi1 = make_float4(c1.bmin.z, c1.bmax.x, c1.bmax.y, c1.bmax.z);
+    dn.child0 = encode(tn.left);
+    dn.child1 = encode(tn.right);
+    dn.pad0 = dn.pad1 = 0;
+  }
+  out.root = encode(0);
+}
+
+int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera, DeviceScene& out, std::string& error) {
+  out.release();
+  if ((scene == nullptr) || (camera == nullptr)) {
+    error = "scene / camera is null";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  if ((scene->flags & ETX_SCENE_COMMITTED) == 0) {
+    error = "scene is not committed (Integrator::can_run, integrator.hxx:85-87)";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  if (scene->flags & ETX_SCENE_SPECTRAL) {
+    error = "spectral scenes are not implemented by the device path yet (RGB mode only)";
+    return ETX_HIP_ERROR_UNSUPPORTED;
+  }
+  if ((camera->film_size.x == 0) || (camera->film_size.y == 0)) {
+    error = "camera film size is zero";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  if (scene->emitter_instances.count == 0) {
+    error = "scene has no emitters";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+
+  const auto* materials = reinterpret_cast<const etx_abi_material*>(scene->materials.a);
+  const auto* spectrums = reinterpret_cast<const etx_abi_spectrum*>(scene->spectrums.a);
+  const auto* images = reinterpret_cast<const etx_abi_image*>(scene->images.a);
+  const auto* mediums = reinterpret_cast<const etx_abi_medium*>(scene->mediums.a);
+  const auto* triangles = reinterpret_cast<const etx_abi_triangle*>(scene->triangles.a);
+
+  // only materials that geometry references need a device implementation
+  std::vector<bool> used(scene->materials.count, false);
+  for (uint64_t i = 0; i < scene->triangles.count; ++i)
+    if (triangles[i].material_index < scene->materials.count)
+      used[triangles[i].material_index] = true;
+  for (uint64_t i = 0; i < scene->materials.count; ++i) {
+    if (used[i] == false)
+      continue;
+    const etx_abi_material& m = materials[i];
+    if (bsdf_class_supported(m.cls) == false) {
+      error = "material class " + std::to_string(m.cls) + " (material " + std::to_string(i) + ") is not implemented by the device path";
+      return ETX_HIP_ERROR_UNSUPPORTED;
+    }
+    if ((m.cls == ETX_MAT_DIFFUSE) && (m.diffuse_variation != 0)) {
+      error = "diffuse_variation " + std::to_string(m.diffuse_variation) + " is not implemented by the device path";
+      return ETX_HIP_ERROR_UNSUPPORTED;
+    }
+    if (m.subsurface.cls != 0) {
+      error = "subsurface scattering is not implemented by the device path";
+      return ETX_HIP_ERROR_UNSUPPORTED;
+    }
+    if ((m.cls == ETX_MAT_CONDUCTOR) && (m.thinfilm.max_thickness * m.thinfilm.min_thickness > 0.0f)) {
+      error = "thin film interference is not implemented by the device path";
+      return ETX_HIP_ERROR_UNSUPPORTED;
+    }
+  }
+  for (uint64_t i = 0; i < scene->mediums.count; ++i) {
+    if (mediums[i].cls != 0) {
+      error = "heterogeneous media are not implemented by the device path";
+      return ETX_HIP_ERROR_UNSUPPORTED;
+    }
+  }
+
+  DScene d = {};
+  int rc = 0;
+  if ((rc = upload(out, reinterpret_cast<const etx_abi_vertex*>(scene->vertices.a), scene->vertices.count, d.vertices, error)))
+    return rc;
+  if ((rc = upload(out, triangles, scene->triangles.count, d.triangles, error)))
+    return rc;
+  if ((rc = upload(out, reinterpret_cast<const uint32_t*>(scene->triangle_to_emitter.a), scene->triangle_to_emitter.count, d.triangle_to_emitter, error)))
+    return rc;
+  if ((rc = upload(out, materials, scene->materials.count, d.materials, error)))
+    return rc;
+  if ((rc = upload(out, reinterpret_cast<const etx_abi_emitter_profile*>(scene->emitter_profiles.a), scene->emitter_profiles.count, d.emitter_profiles, error)))
+    return rc;
+  if ((rc = upload(out, reinterpret_cast<const etx_abi_emitter*>(scene->emitter_instances.a), scene->emitter_instances.count, d.emitters, error)))
+    return rc;
+  if ((rc = upload(out, reinterpret_cast<const etx_abi_distribution_entry*>(scene->emitters_distribution.values.a), scene->emitters_distribution.values.count, d.emitter_dist, error)))
+    return rc;
+
+  std::vector<float4> rgb(scene->spectrums.count);
+  for (uint64_t i = 0; i < scene->spectrums.count; ++i)
+    rgb[i] = make_float4(spectrums[i].integrated.x, spectrums[i].integrated.y, spectrums[i].integrated.z, 0.0f);
+  if ((rc = upload(out, rgb.data(), rgb.size(), d.spectrum_rgb, error)))
+    return rc;
+
+  std::vector<DImage> dimages(scene->images.count);
+  for (uint64_t i = 0; i < scene->images.count; ++i) {
+    const etx_abi_image& img = images[i];
+    DImage& di = dimages[i];
+    di = {};
+    size_t pixel_count = size_t(img.isize.x) * img.isize.y;
+    std::vector<float4> pixels(pixel_count);
+    if (img.format == ETX_IMAGE_FORMAT_RGBA8) {
+      const uint8_t* src = reinterpret_cast<const uint8_t*>(img.pixels.a);
+      for (size_t k = 0; k < pixel_count; ++k)  // math.hxx:689-691 to_float4(ubyte4)
+        pixels[k] = make_float4(src[4 * k] / 255.0f, src[4 * k + 1] / 255.0f, src[4 * k + 2] / 255.0f, src[4 * k + 3] / 255.0f);
+    } else if ((img.format == ETX_IMAGE_FORMAT_RGBA32F) && (pixel_count > 0)) {
+      memcpy(pixels.data(), img.pixels.a, pixel_count * sizeof(float4));
+    }
+    if ((rc = upload(out, pixels.data(), pixels.size(), di.pixels, error)))
+      return rc;
+    di.fsize = {img.fsize.x, img.fsize.y};
+    di.offset = {img.offset.x, img.offset.y};
+    di.scale = {img.scale.x, img.scale.y};
+    di.isize_x = img.isize.x, di.isize_y = img.isize.y;
+    di.normalization = img.normalization;
+    di.options = img.options;
+    di.y_count = uint32_t(img.y_distribution.values.count);
+    if ((rc = upload(out, reinterpret_cast<const etx_abi_distribution_entry*>(img.y_distribution.values.a), di.y_count, di.y_entries, error)))
+      return rc;
+    const auto* rows = reinterpret_cast<const etx_abi_distribution*>(img.x_distributions.a);
+    uint32_t stride = (img.x_distributions.count > 0) ? uint32_t(rows[0].values.count) : 0u;
+    std::vector<etx_abi_distribution_entry> flat(size_t(stride) * img.x_distributions.count);
+    for (uint64_t r = 0; r < img.x_distributions.count; ++r) {
+      if (rows[r].values.count != stride) {
+        error = "image sampling table rows differ in length";
+        return ETX_HIP_ERROR_UNSUPPORTED;
+      }
+      memcpy(flat.data() + r * stride, rows[r].values.a, stride * sizeof(etx_abi_distribution_entry));
+    }
+    di.x_stride = stride;
+    if ((rc = upload(out, flat.data(), flat.size(), di.x_entries, error)))
+      return rc;
+  }
+  if ((rc = upload(out, dimages.data(), dimages.size(), d.images, error)))
+    return rc;
+
+  std::vector<DMedium> dmediums(scene->mediums.count);
+  for (uint64_t i = 0; i < scene->mediums.count; ++i) {
+    const etx_abi_medium& m = mediums[i];
+    DMedium& dm = dmediums[i];
+    dm = {};
+    dm.bounds_min = a3(m.bounds_min), dm.bounds_max = a3(m.bounds_max);
+    auto resolve = [&](uint32_t idx) {  // scene_medium.hxx:146-158: invalid index => zero
+      return ((idx == ETX_ABI_INVALID) || (idx >= scene->spectrums.count)) ? mk3(0.0f) : a3(spectrums[idx].integrated);
+    };
+    dm.absorption = resolve(m.absorption_index);
+    dm.scattering = resolve(m.scattering_index);
+    dm.cls = m.cls;
+    dm.explicit_connections = m.enable_explicit_connections;
+    dm.g = m.phase_function_g;
+    dm.max_sigma = m.max_sigma;
+    dm.dim_x = m.dimensions.x, dm.dim_y = m.dimensions.y, dm.dim_z = m.dimensions.z;
+  }
+  if ((rc = upload(out, dmediums.data(), dmediums.size(), d.mediums, error)))
+    return rc;
+
+  HostBvh bvh;
+  build_bvh(scene, bvh);
+  if (bvh.depth + 2 > kStackDepth) {
+    error = "BVH depth " + std::to_string(bvh.depth) + " exceeds the traversal stack";
+    return ETX_HIP_ERROR_UNSUPPORTED;
+  }
+  if ((rc = upload(out, bvh.nodes.data(), bvh.nodes.size(), d.bvh_nodes, error)))
+    return rc;
+  if ((rc = upload(out, bvh.tris.data(), bvh.tris.size(), d.bvh_tris, error)))
+    return rc;
+  d.bvh_node_count = uint32_t(bvh.nodes.size());
+  d.bvh_tri_count = uint32_t(bvh.tris.size());
+  d.bvh_root = bvh.root;
+  out.bvh_depth = bvh.depth;
+  out.bvh_bytes = bvh.nodes.size() * sizeof(BvhNode) + bvh.tris.size() * sizeof(BvhTri);
+
+  d.vertex_count = uint32_t(scene->vertices.count);
+  d.triangle_count = uint32_t(scene->triangles.count);
+  d.material_count = uint32_t(scene->materials.count);
+  d.emitter_count = uint32_t(scene->emitter_instances.count);
+  d.emitter_dist_count = uint32_t(scene->emitters_distribution.values.count);
+  d.emitter_dist_total = scene->emitters_distribution.total_weight;
+  d.spectrum_count = uint32_t(scene->spectrums.count);
+  d.image_count = uint32_t(scene->images.count);
+  d.medium_count = uint32_t(scene->mediums.count);
+  d.env_count = scene->environment_emitters.count;
+  memcpy(d.env_emitters, scene->environment_emitters.emitters, sizeof(d.env_emitters));
+  d.bounds_center = a3(scene->bounding_sphere_center);
+  d.bounds_radius = scene->bounding_sphere_radius;
+  d.min_path_length = scene->min_path_length;
+  d.max_path_length = scene->max_path_length;
+  d.samples = scene->samples;
+  d.random_path_termination = scene->random_path_termination;
+  d.radiance_clamp = scene->radiance_clamp;
+  d.flags = scene->flags;
+  d.pixel_sampler_image = scene->pixel_sampler.image_index;
+  d.pixel_sampler_radius = scene->pixel_sampler.radius;
+  d.subsurface_exit_material = scene->subsurface_exit_material;
+
+  DCamera& c = d.camera;
+  memcpy(c.view_proj, camera->view_proj, sizeof(c.view_proj));
+  c.position = a3(camera->position), c.side = a3(camera->side), c.up = a3(camera->up), c.direction = a3(camera->direction);
+  c.tan_half_fov = camera->tan_half_fov, c.aspect = camera->aspect, c.area = camera->area, c.image_plane = camera->image_plane;
+  c.film_w = camera->film_size.x, c.film_h = camera->film_size.y, c.cls = camera->cls;
+  c.lens_radius = camera->lens_radius, c.focal_distance = camera->focal_distance;
+  c.clip_near = camera->clip_near, c.clip_far = camera->clip_far;
+  c.lens_image = camera->lens_image, c.medium_index = camera->medium_index;
+
+  out.host_copy = d;
+  const DScene* dev = nullptr;
+  if ((rc = upload(out, &d, 1, dev, error)))
+    return rc;
+  out.device = const_cast<DScene*>(dev);
+  out.film_w = camera->film_size.x;
+  out.film_h = camera->film_size.y;
+  return 0;
+}
+
+}  // namespace etxh

@@ -1,0 +1,42 @@
+// host_scene.h - host side of etx_hip_upload_scene: validates the borrowed etx::Scene, builds the BVH and the
+// device tables. Everything allocated here is owned by DeviceScene and released in its destructor.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+
+#include "dev_scene.h"
+
+namespace etxh {
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+};
+
+struct DeviceScene {
+  etxd::DScene host_copy = {};      // the struct as uploaded (device pointers inside)
+  etxd::DScene* device = nullptr;   // device copy of host_copy
+  std::vector<void*> allocations;
+  uint32_t film_w = 0, film_h = 0;
+  uint32_t bvh_depth = 0;
+  size_t bvh_bytes = 0;
+
+  ~DeviceScene();
+  void release();
+};
+
+// Returns 0 or an ETX_HIP_ERROR_* code with `error` set.
+int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera, DeviceScene& out, std::string& error);
+
+// BVH build exposed for tests of the host logic (no GPU needed)
+struct HostBvh {
+  std::vector<etxd::BvhNode> nodes;
+  std::vector<etxd::BvhTri> tris;
+  int32_t root = 0;
+  uint32_t depth = 0;
+};
+void build_bvh(const etx_abi_scene* scene, HostBvh& out);
+
+}  // namespace etxh

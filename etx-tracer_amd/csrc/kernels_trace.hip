@@ -1,0 +1,51 @@
+// kernels_trace.hip - the traversal kernel: ray queue -> hit queue.
+//
+// Roofline: HBM. Algorithmic traffic per ray = 32 B ray record in + 16 B hit record out = 48 B (the queues are
+// index-aligned with the path state, so no per-ray path index is moved); BVH bytes are not counted while the tree is
+// L2/LDS resident (Cornell: 3 KB). One lane = one ray; 256-thread blocks, persistent grid (256 CUs x 8 blocks),
+// wave-uniform grid-stride loop; per-lane traversal stack in LDS laid out [level][lane] (bank conflict free).
+#include "kernels.h"
+#include "dev_bvh.h"
+
+namespace etxd {
+
+template <bool kFromCounter>
+__global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene* __restrict__ scene_ptr, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
+  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count) {
+  __shared__ int32_t s_stack[kStackDepth * kBlockSize];
+  const DScene& scene = *scene_ptr;
+  const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
+  if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
+    // housekeeping for the shade kernel that follows: its output counter and the camera vertex pool start empty
+    counters[active_counter ^ 1u] = 0u;
+    counters[kCntCameraVertices] = 0u;
+    atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  LaneStack stack = {s_stack + threadIdx.x, kBlockSize};
+  for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {
+    const uint32_t i = base + lane;
+    if (i >= count)
+      continue;
+    const float4 a = ray_o_tmin[i];
+    const float4 b = ray_d_tmax[i];
+    uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ i;
+    Hit h = bvh_closest(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, RayQ{{a.x, a.y, a.z}, a.w, {b.x, b.y, b.z}, b.w}, alpha_seed, nullptr);
+    hits[i] = make_float4(h.u, h.v, h.t, __uint_as_float(h.tri));
+  }
+}
+
+void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter) {
+  uint32_t blocks = min(kPersistentBlocks, (p.capacity + kBlockSize - 1) / kBlockSize);
+  hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u);
+}
+
+void launch_trace_rays(hipStream_t stream, const DScene* scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count) {
+  uint32_t blocks = min(kPersistentBlocks, (count + kBlockSize - 1) / kBlockSize);
+  if (blocks == 0)
+    return;
+  hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks), dim3(kBlockSize), 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count);
+}
+
+}  // namespace etxd

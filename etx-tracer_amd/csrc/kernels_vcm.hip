@@ -1,0 +1,664 @@
+// kernels_vcm.hip - VCM wavefront kernels (light pass, camera pass, connections, photon merge) for gfx950.
+//
+// Kernel decomposition (one iteration, see host_api.cpp for the launch sequence):
+//   k_iteration_reset                       counters, light path heads
+//   k_light_generate                        vcm_generate_emitter_state          (vcm_shared.hxx:310-349)
+//   loop: k_trace_closest ; k_light_shade   vcm_light_step                      (vcm_shared.hxx:1090-1260)
+//   k_grid_* (kernels_grid.hip)             VCMSpatialGrid::construct           (vcm_shared.cxx:49-152)
+//   k_camera_generate                       vcm_generate_camera_state           (vcm_shared.hxx:351-377)
+//   loop: k_trace_closest ; k_camera_shade ; k_connect ; k_merge
+//                                           vcm_camera_step                     (vcm_shared.hxx:927-1079)
+// All kernels: 256-thread blocks, persistent grid, wave-uniform grid-stride loops, survivors compacted with a wave
+// ballot + one atomic per wavefront. Shading is fp32 VALU / divergence bound (no MFMA: there is no contraction).
+#include "kernels.h"
+#include "dev_vcm.h"
+
+namespace etxd {
+
+#define ETX_WAVE_LOOP(COUNT)                                                          \
+  const uint32_t lane_ = threadIdx.x & 63u;                                            \
+  const uint32_t stride_ = gridDim.x * blockDim.x;                                     \
+  for (uint32_t base_ = blockIdx.x * blockDim.x + threadIdx.x - lane_; base_ < (COUNT); base_ += stride_)
+
+static uint32_t grid_for(uint32_t capacity) {
+  return min(kPersistentBlocks, (capacity + kBlockSize - 1) / kBlockSize);
+}
+
+ETX_DEV uint32_t float_to_ordered(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockSize) void k_iteration_reset(Pipeline p) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t stride = gridDim.x * blockDim.x;
+  if (tid < kCounterCount) {
+    uint32_t v = 0u;
+    if ((tid >= kCntBboxMin) && (tid < kCntBboxMin + 3))
+      v = 0xffffffffu;
+    p.counters[tid] = v;
+  }
+  for (uint32_t i = tid; i < p.capacity; i += stride)
+    p.light_path_head[i] = kInvalid;
+}
+
+void launch_iteration_reset(hipStream_t stream, const Pipeline& p) {
+  hipLaunchKernelGGL(k_iteration_reset, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// vcm_generate_emitter_state, vcm_shared.hxx:310-349 (one light path per pixel index, vcm_cpu.cxx:139-140)
+__global__ __launch_bounds__(kBlockSize) void k_light_generate(Pipeline p, VcmParams it) {
+  const DScene& scene = *p.scene;
+  ETX_WAVE_LOOP(it.path_count) {
+    const uint32_t i = base_ + lane_;
+    bool valid = false;
+    PathState st;
+    if (i < it.path_count) {
+      st.sampler.init(i, it.iteration);
+      st.id = i;
+      EmitterSample es = sample_emission(scene, st.sampler);
+      if (es.pdf_dir > 0.0f) {
+        float cos_t = dot(es.direction, es.normal);
+        st.throughput = es.value * (cos_t / (es.pdf_dir * es.pdf_area * es.pdf_sample));
+        st.ray_o = es.origin;
+        st.ray_d = es.direction;
+        st.ray_tmin = kRayEpsilon;
+        st.ray_tmax = kMaxFloat;
+        if (es.triangle_index != kInvalid)
+          st.ray_o = shading_pos(scene, scene.triangles[es.triangle_index], es.barycentric, st.ray_d);
+        st.d_vcm = es.is_distant ? 1.0f / es.pdf_area : 1.0f / es.pdf_dir;
+        st.d_vc = es.is_delta ? 0.0f : (es.is_distant ? 1.0f : cos_t) / (es.pdf_dir * es.pdf_area * es.pdf_sample);
+        st.d_vm = st.d_vc * it.vc_weight;
+        st.path_distance = 0.0f;
+        st.eta = 1.0f;
+        st.medium = es.medium_index;
+        st.depth = 0u;
+        st.flags = (es.is_delta ? kPathDeltaEmitter : 0u) | (es.is_distant ? 0u : kPathLocalEmitter);
+        valid = true;
+      }
+    }
+    uint32_t slot = wave_compact_slot(valid, p.counters + kCntActiveA);
+    if (valid)
+      store_path(p.paths[0], slot, st);
+  }
+}
+
+void launch_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
+  hipLaunchKernelGGL(k_light_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
+}
+
+ETX_DEV void store_light_vertex(const Pipeline& p, const VcmParams& it, const PathState& st, const f3& pos, const f3& nrm, float bc_u, float bc_v, uint32_t tri, bool keep_bbox) {
+  uint32_t idx = atomicAdd(p.counters + kCntLightVertices, 1u);
+  if (idx >= p.lv.capacity) {
+    atomicOr(p.counters + kCntOverflow, kOverflowLightVertices);
+    return;
+  }
+  p.lv.pos_dvcm[idx] = mk4(pos, st.d_vcm);
+  p.lv.wi_dvc[idx] = mk4(st.ray_d, st.d_vc);
+  p.lv.thr_dvm[idx] = mk4(st.throughput, st.d_vm);
+  p.lv.nrm_tri[idx] = mk4(nrm, __uint_as_float(tri));
+  // vcm_connect_to_light_path (vcm_shared.hxx:773-778) derives the connection length from the vertex' INDEX in its
+  // light path (delta bounces advance the depth without storing a vertex), the merge uses path_length: keep both.
+  const uint32_t prev = p.light_path_head[st.id];
+  const uint32_t index_in_path = (prev == kInvalid) ? 0u : ((__float_as_uint(p.lv.bc_len_med[prev].z) >> 16u) + 1u);
+  p.lv.bc_len_med[idx] = make_float4(bc_u, bc_v, __uint_as_float((index_in_path << 16u) | (st.depth & 0xffffu)), __uint_as_float(st.medium));
+  p.lv.next[idx] = prev;
+  p.light_path_head[st.id] = idx;
+  if (keep_bbox) {
+    // bounding box of mergeable vertices (vcm_shared.cxx:66-80), ordered-int float atomics
+    atomicMin(p.counters + kCntBboxMin + 0, float_to_ordered(pos.x));
+    atomicMin(p.counters + kCntBboxMin + 1, float_to_ordered(pos.y));
+    atomicMin(p.counters + kCntBboxMin + 2, float_to_ordered(pos.z));
+    atomicMax(p.counters + kCntBboxMax + 0, float_to_ordered(pos.x));
+    atomicMax(p.counters + kCntBboxMax + 1, float_to_ordered(pos.y));
+    atomicMax(p.counters + kCntBboxMax + 2, float_to_ordered(pos.z));
+  }
+}
+
+// film.cxx:147-171 atomic_add_light_iteration (pixel_size == 1) after vcm_cpu.cxx:148-153
+ETX_DEV void splat_light(const Pipeline& p, const VcmParams& it, const f3& value, const f2 uv) {
+  if (max_component(value) <= kEpsilon)
+    return;
+  if (dot(value, value) <= kEpsilon)
+    return;
+  float u = uv.x * 0.5f + 0.5f, v = uv.y * 0.5f + 0.5f;
+  uint32_t x = static_cast<uint32_t>(u * float(it.film_w));
+  uint32_t y = static_cast<uint32_t>(v * float(it.film_h));
+  if ((x >= it.film_w) || (y >= it.film_h))
+    return;
+  uint32_t i = x + (it.film_h - 1u - y) * it.film_w;
+  atomic_add_f3(p.light_sum + i, value);
+}
+
+// vcm_light_step, vcm_shared.hxx:1090-1260 (everything after rt.trace)
+__global__ __launch_bounds__(kBlockSize) void k_light_shade(Pipeline p, VcmParams it, uint32_t in_set) {
+  __shared__ int32_t s_stack[kStackDepth * kBlockSize];
+  const DScene& scene = *p.scene;
+  const PathSet& in = p.paths[in_set];
+  const PathSet& out = p.paths[in_set ^ 1u];
+  const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
+  uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
+  TraceCtx tc = {&scene, {s_stack + threadIdx.x, kBlockSize}, 0u};
+  uint32_t splats = 0;
+  ETX_WAVE_LOOP(count) {
+    const uint32_t i = base_ + lane_;
+    bool alive = false;
+    PathState st;
+    if (i < count) {
+      st = load_path(in, i);
+      const float4 h = p.hits[i];
+      const uint32_t tri = __float_as_uint(h.w);
+      const bool found = tri != kInvalid;
+      tc.alpha_seed = st.sampler.seed ^ 0x85ebca6bu;
+      Isect isect;
+      if (found)
+        isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
+
+      // vcm_try_sampling_medium, vcm_shared.hxx:379-388
+      MediumSample ms;
+      ms.sampled_medium_t = 0.0f;
+      if (st.medium != kInvalid) {
+        ms = sample_medium_homogeneous(scene.mediums[st.medium], st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+        st.throughput *= ms.weight;
+      }
+
+      if (ms.sampled_medium()) {  // vcm_shared.hxx:1097-1170
+        f2 rnd_bsdf = st.sampler.next_2d();
+        f2 rnd_connection = st.sampler.next_2d();
+        f2 rnd_support = st.sampler.next_2d();
+        float seg = st.path_distance + ms.sampled_medium_t;
+        st.d_vcm *= sqr(seg);
+        st.path_distance = 0.0f;
+        const DMedium& med = scene.mediums[st.medium];
+        if (opt_connect_vertices(it) && (st.depth + 1 <= scene.max_path_length))
+          store_light_vertex(p, it, st, ms.pos, mk3(0.0f), 0.0f, 0.0f, kInvalid, false);
+        if (opt_connect_to_camera(it) && med.explicit_connections && (st.depth + 1 <= scene.max_path_length)) {
+          f2 uv = {0.0f, 0.0f};
+          st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+          f3 value = vcm_connect_to_camera(tc, it, true, nullptr, ms.pos, st, uv);
+          st.sampler.pop_fixed();
+          if (max_component(value) > kEpsilon) {
+            splat_light(p, it, value, uv);
+            splats++;
+          }
+        }
+        f3 w_i = st.ray_d;
+        f3 w_o = sample_phase_function(w_i, med.g, rnd_bsdf);
+        float pdf_fwd = phase_function(w_i, w_o, med.g);
+        float pdf_rev = phase_function(w_o, w_i, med.g);
+        st.d_vc = (1.0f / pdf_fwd) * (st.d_vc * pdf_rev + st.d_vcm);
+        st.d_vm = (1.0f / pdf_fwd) * (st.d_vm * pdf_rev + 0.0f);
+        st.d_vcm = 1.0f / pdf_fwd;
+        st.ray_o = ms.pos;
+        st.ray_d = w_o;
+        st.ray_tmax = kMaxFloat;
+        st.ray_tmin = kRayEpsilon;
+        st.depth += 1u;
+        alive = (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
+      } else if (found) {
+        if (vcm_handle_boundary(scene, isect, st)) {
+          alive = true;
+        } else {
+          const etx_abi_material& mat = scene.materials[isect.material];
+          BsdfData bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight);
+          f2 rnd_bsdf = st.sampler.next_2d();
+          f2 rnd_connection = st.sampler.next_2d();
+          f2 rnd_support = st.sampler.next_2d();
+          st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
+          BsdfSample bs = bsdf_sample(scene, bsdf_data, mat, st.sampler);
+          bool is_connectible = (bs.properties & kSampleDelta) == 0u;
+          st.sampler.pop_fixed();
+
+          // vcm_update_light_vcm, vcm_shared.hxx:451-461
+          if ((st.depth > 0u) || (st.flags & kPathLocalEmitter))
+            st.d_vcm *= sqr(st.path_distance + isect.t);
+          float cos_to_prev = fabsf(dot(isect.nrm, -st.ray_d));
+          st.d_vcm /= cos_to_prev;
+          st.d_vc /= cos_to_prev;
+          st.d_vm /= cos_to_prev;
+          st.path_distance = 0.0f;
+
+          if (is_connectible) {
+            store_light_vertex(p, it, st, isect.pos, isect.nrm, isect.bc.y, isect.bc.z, isect.tri, true);
+            if (opt_connect_to_camera(it) && (st.depth + 1 <= scene.max_path_length)) {
+              f2 uv = {0.0f, 0.0f};
+              st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+              f3 value = vcm_connect_to_camera(tc, it, false, &isect, mk3(0.0f), st, uv);
+              st.sampler.pop_fixed();
+              if (max_component(value) > kEpsilon) {
+                splat_light(p, it, value, uv);
+                splats++;
+              }
+            }
+          }
+          if (vcm_next_ray(scene, kPathLight, st, it, isect, bsdf_data, bs))
+            alive = st.depth + 1u < scene.max_path_length;
+        }
+      }
+    }
+    uint32_t slot = wave_compact_slot(alive, out_counter);
+    if (alive)
+      store_path(out, slot, st);
+  }
+  if (splats)
+    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatSplats), (unsigned long long)splats);
+}
+
+void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set) {
+  hipLaunchKernelGGL(k_light_shade, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it, in_set);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// vcm_generate_camera_state, vcm_shared.hxx:351-377 (all pixels active: Film::active_pixel with pixel_size 1)
+__global__ __launch_bounds__(kBlockSize) void k_camera_generate(Pipeline p, VcmParams it) {
+  const DScene& scene = *p.scene;
+  ETX_WAVE_LOOP(it.path_count) {
+    const uint32_t i = base_ + lane_;
+    if (i >= it.path_count)
+      continue;
+    PathState st;
+    st.id = i;
+    // The reference seeds camera path i exactly like light path i (vcm_shared.hxx:312,357). Its two streams drift
+    // apart only because alpha_test_pass draws one number per BVH candidate inside rt.trace (scene_bsdf.hxx:143);
+    // the device traversal draws none for opaque triangles, so with the same seed camera draw k+1 would equal
+    // light draw k forever and the (pixel i, light path i) vertex connections become correlated -> biased
+    // (measured: -7% in the connection-only image). The camera stream is therefore re-keyed.
+    st.sampler.init(i, it.iteration);
+    st.sampler.seed = Sampler::random_seed(st.sampler.seed, 0x43414d45u);
+    uint32_t px = i % it.film_w, py = i / it.film_w;
+    f2 uv = get_jittered_uv(st.sampler, px, py, it.film_w, it.film_h);
+    RayGen r = generate_ray(scene, uv, st.sampler.next_2d());
+    st.ray_o = r.o, st.ray_d = r.d, st.ray_tmin = r.tmin, st.ray_tmax = r.tmax;
+    st.throughput = mk3(1.0f);
+    st.d_vcm = 1.0f / film_evaluate_out_pdf_dir(scene, st.ray_d);
+    st.d_vc = 0.0f, st.d_vm = 0.0f;
+    st.medium = scene.camera.medium_index;
+    st.eta = 1.0f;
+    st.path_distance = 0.0f;
+    st.depth = 1u;
+    st.flags = 0u;
+    store_path(p.paths[0], i, st);
+  }
+  if ((blockIdx.x == 0) && (threadIdx.x == 0))
+    p.counters[kCntActiveA] = it.path_count;
+}
+
+void launch_camera_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
+  hipLaunchKernelGGL(k_camera_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
+}
+
+ETX_DEV uint32_t film_index(const VcmParams& it, uint32_t pixel_id) {  // film.cxx:189 y flip
+  uint32_t px = pixel_id % it.film_w, py = pixel_id / it.film_w;
+  return px + (it.film_h - 1u - py) * it.film_w;
+}
+
+ETX_DEV void store_camera_vertex(const Pipeline& p, const PathState& st, const float4& hit_or_pos, uint32_t seed) {
+  uint32_t idx = atomicAdd(p.counters + kCntCameraVertices, 1u);
+  p.cv.hit[idx] = hit_or_pos;
+  p.cv.wi_medium[idx] = mk4(st.ray_d, __uint_as_float(st.medium));
+  p.cv.thr_depth[idx] = mk4(st.throughput, __uint_as_float(st.depth));
+  p.cv.mis_pixel[idx] = make_float4(st.d_vcm, st.d_vc, st.d_vm, __uint_as_float(st.id));
+  p.cv.seed[idx] = seed;
+}
+
+// vcm_camera_step, vcm_shared.hxx:927-1079, without the vertex connections and the merge: connectible vertices are
+// written to the camera vertex pool and consumed by k_connect / k_merge of the same bounce.
+__global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmParams it, uint32_t in_set) {
+  __shared__ int32_t s_stack[kStackDepth * kBlockSize];
+  const DScene& scene = *p.scene;
+  const PathSet& in = p.paths[in_set];
+  const PathSet& out = p.paths[in_set ^ 1u];
+  const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
+  uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
+  TraceCtx tc = {&scene, {s_stack + threadIdx.x, kBlockSize}, 0u};
+  ETX_WAVE_LOOP(count) {
+    const uint32_t i = base_ + lane_;
+    bool alive = false;
+    PathState st;
+    if (i < count) {
+      st = load_path(in, i);
+      const float4 h = p.hits[i];
+      const uint32_t tri = __float_as_uint(h.w);
+      const bool found = tri != kInvalid;
+      tc.alpha_seed = st.sampler.seed ^ 0xc2b2ae35u;
+      f3 gathered = mk3(0.0f);
+      Isect isect;
+      if (found)
+        isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
+
+      MediumSample ms;
+      ms.sampled_medium_t = 0.0f;
+      if (st.medium != kInvalid) {
+        ms = sample_medium_homogeneous(scene.mediums[st.medium], st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+        st.throughput *= ms.weight;
+      }
+
+      if (ms.sampled_medium()) {  // vcm_shared.hxx:934-995
+        f2 rnd_bsdf = st.sampler.next_2d();
+        f2 rnd_connection = st.sampler.next_2d();
+        f2 rnd_support = st.sampler.next_2d();
+        float seg = st.path_distance + ms.sampled_medium_t;
+        st.d_vcm *= sqr(seg);
+        st.path_distance = 0.0f;
+        const DMedium& med = scene.mediums[st.medium];
+        f3 w_o_smp = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
+        float pdf_fwd = phase_function(st.ray_d, w_o_smp, med.g);
+        float pdf_rev = phase_function(w_o_smp, st.ray_d, med.g);
+        if (med.explicit_connections && (st.depth + 1 <= scene.max_path_length)) {
+          if (opt_connect_to_light(it)) {
+            st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+            gathered += vcm_connect_to_light(tc, it, true, nullptr, ms.pos, st);
+            st.sampler.pop_fixed();
+          }
+          if (opt_connect_vertices(it)) {
+            Sampler derived;
+            derived.init(st.sampler.seed, 0x51ed270bu);
+            store_camera_vertex(p, st, mk4(ms.pos, __uint_as_float(kInvalid)), derived.seed);
+          }
+        }
+        st.d_vc = (1.0f / pdf_fwd) * (st.d_vc * pdf_rev + st.d_vcm);
+        st.d_vm = (1.0f / pdf_fwd) * (st.d_vm * pdf_rev + 0.0f);
+        st.d_vcm = 1.0f / pdf_fwd;
+        st.ray_o = ms.pos;
+        st.ray_d = w_o_smp;
+        st.ray_tmax = kMaxFloat;
+        st.ray_tmin = kRayEpsilon;
+        st.depth += 1u;
+        alive = (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
+      } else if (found == false) {
+        gathered += vcm_cam_handle_miss(scene, it, st);
+      } else if (vcm_handle_boundary(scene, isect, st)) {
+        alive = true;
+      } else {
+        const etx_abi_material& mat = scene.materials[isect.material];
+        BsdfData bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera);
+        f2 rnd_bsdf = st.sampler.next_2d();
+        f2 rnd_connection = st.sampler.next_2d();
+        f2 rnd_support = st.sampler.next_2d();
+        // blue-noise override of the first vertex (vcm_shared.hxx:1018-1022) needs the host's tables:
+        // etx_hip_begin rejects options.blue_noise until etx_hip_upload_bluenoise provided them.
+        st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
+        BsdfSample bs = bsdf_sample(scene, bsdf_data, mat, st.sampler);
+        bool is_connectible = (bs.properties & kSampleDelta) == 0u;
+        st.sampler.pop_fixed();
+
+        // vcm_update_camera_vcm, vcm_shared.hxx:589-595
+        float cos_to_prev = fabsf(dot(isect.nrm, -st.ray_d));
+        st.d_vcm *= sqr(st.path_distance + isect.t) / cos_to_prev;
+        st.d_vc /= cos_to_prev;
+        st.d_vm /= cos_to_prev;
+        st.path_distance = 0.0f;
+
+        // vcm_handle_direct_hit, vcm_shared.hxx:597-606
+        if (opt_direct_hit(it) && (isect.emitter != kInvalid) && (st.depth <= scene.max_path_length) && (st.depth >= scene.min_path_length))
+          gathered += vcm_get_radiance(scene, scene.emitters[isect.emitter], st, it, isect);
+
+        if (is_connectible) {
+          if (opt_connect_vertices(it) || (opt_merge_vertices(it) && (st.depth + 1 <= scene.max_path_length))) {
+            Sampler derived;
+            derived.init(st.sampler.seed, 0x51ed270bu);
+            store_camera_vertex(p, st, h, derived.seed);
+          }
+          st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+          gathered += vcm_connect_to_light(tc, it, false, &isect, mk3(0.0f), st);
+          st.sampler.pop_fixed();
+        }
+        alive = vcm_next_ray(scene, kPathCamera, st, it, isect, bsdf_data, bs);
+      }
+      if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
+        atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered);
+    }
+    uint32_t slot = wave_compact_slot(alive, out_counter);
+    if (alive)
+      store_path(out, slot, st);
+  }
+}
+
+void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set) {
+  hipLaunchKernelGGL(k_camera_shade, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it, in_set);
+}
+
+struct CameraVertex {
+  PathState st;   // throughput, d_vcm/d_vc/d_vm, depth, medium, ray_d (= w_i), id (pixel)
+  Isect isect;
+  f3 medium_pos;
+  bool at_medium;
+};
+
+ETX_DEV CameraVertex load_camera_vertex(const Pipeline& p, const DScene& scene, uint32_t i) {
+  CameraVertex cv;
+  float4 h = p.cv.hit[i], w = p.cv.wi_medium[i], t = p.cv.thr_depth[i], m = p.cv.mis_pixel[i];
+  cv.st.ray_d = {w.x, w.y, w.z};
+  cv.st.medium = __float_as_uint(w.w);
+  cv.st.throughput = {t.x, t.y, t.z};
+  cv.st.depth = __float_as_uint(t.w);
+  cv.st.d_vcm = m.x, cv.st.d_vc = m.y, cv.st.d_vm = m.z;
+  cv.st.id = __float_as_uint(m.w);
+  cv.st.sampler.seed = p.cv.seed[i];
+  cv.st.sampler.fixed_u = cv.st.sampler.fixed_v = cv.st.sampler.fixed_w = 0.0f;
+  cv.st.eta = 1.0f, cv.st.path_distance = 0.0f, cv.st.flags = 0u;
+  cv.st.ray_o = mk3(0.0f), cv.st.ray_tmin = 0.0f, cv.st.ray_tmax = 0.0f;
+  uint32_t tri = __float_as_uint(h.w);
+  cv.at_medium = tri == kInvalid;
+  cv.medium_pos = {h.x, h.y, h.z};
+  if (cv.at_medium == false)
+    cv.isect = make_intersection(scene, cv.st.ray_d, h.x, h.y, h.z, tri);
+  return cv;
+}
+
+// vcm_connect_to_light_path, vcm_shared.hxx:765-803: camera vertex x every vertex of the SAME pixel's light path
+__global__ __launch_bounds__(kBlockSize) void k_connect(Pipeline p, VcmParams it) {
+  __shared__ int32_t s_stack[kStackDepth * kBlockSize];
+  const DScene& scene = *p.scene;
+  const uint32_t count = opt_connect_vertices(it) ? p.counters[kCntCameraVertices] : 0u;
+  TraceCtx tc = {&scene, {s_stack + threadIdx.x, kBlockSize}, 0u};
+  uint32_t shadow_rays = 0;
+  ETX_WAVE_LOOP(count) {
+    const uint32_t i = base_ + lane_;
+    if (i >= count)
+      continue;
+    CameraVertex cv = load_camera_vertex(p, scene, i);
+    tc.alpha_seed = cv.st.sampler.seed ^ 0x27d4eb2fu;
+    f3 result = mk3(0.0f);
+    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatCameraVertices), 1ull);
+    for (uint32_t vi = p.light_path_head[cv.st.id]; vi != kInvalid; vi = p.lv.next[vi]) {
+      LightVertex lv = load_light_vertex(p.lv, vi);
+#if defined(ETX_HIP_DEBUG_COUNTERS)
+      atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kDbgBase + 0), 1ull);
+#endif
+      const uint32_t target_path_length = cv.st.depth + lv.index_in_path + 2u;  // vcm_shared.hxx:774
+      if ((target_path_length < scene.min_path_length) || (target_path_length > scene.max_path_length))
+        continue;
+      f3 target_position, value;
+      if (vcm_connect_to_light_vertex(scene, cv.st, lv, it, cv.at_medium, &cv.isect, cv.medium_pos, cv.st.sampler, target_position, value) == false)
+        continue;
+      f3 p0 = cv.medium_pos;
+      if (cv.at_medium == false)
+        p0 = shading_pos(scene, scene.triangles[cv.isect.tri], cv.isect.bc, normalize(target_position - cv.isect.pos));
+      f3 tr = trace_transmittance(tc, p0, cv.at_medium ? lv.pos : target_position, cv.st.medium);
+      shadow_rays++;
+      if (is_zero(tr) == false)
+        result += tr * value;
+    }
+    if ((result.x != 0.0f) || (result.y != 0.0f) || (result.z != 0.0f))
+      atomic_add_f3(p.camera_sum + film_index(it, cv.st.id), result);
+  }
+  if (shadow_rays)
+    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatRaysShadow), (unsigned long long)shadow_rays);
+}
+
+void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
+  hipLaunchKernelGGL(k_connect, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
+}
+
+// VCMSpatialGridData::gather / gather_index, vcm_shared.hxx:829-924
+__global__ __launch_bounds__(kBlockSize) void k_merge(Pipeline p, VcmParams it) {
+  const DScene& scene = *p.scene;
+  const uint32_t count = p.counters[kCntCameraVertices];
+  const GridParams g = *p.grid_params;
+  if ((opt_merge_vertices(it) == false) || (g.valid == 0u) || (g.photon_count == 0u))
+    return;
+  unsigned long long examined = 0, merged_count = 0;
+  ETX_WAVE_LOOP(count) {
+    const uint32_t i = base_ + lane_;
+    if (i >= count)
+      continue;
+    CameraVertex cv = load_camera_vertex(p, scene, i);
+    if (cv.at_medium || (cv.st.depth + 1u > scene.max_path_length))
+      continue;
+    const Isect& isect = cv.isect;
+    if ((isect.pos.x < g.bbox_min.x) || (isect.pos.y < g.bbox_min.y) || (isect.pos.z < g.bbox_min.z) || (isect.pos.x > g.bbox_max.x) || (isect.pos.y > g.bbox_max.y) ||
+        (isect.pos.z > g.bbox_max.z))
+      continue;
+    f3 m = (isect.pos - g.bbox_min) / g.cell_size;
+    f3 mf = {floorf(m.x), floorf(m.y), floorf(m.z)};
+    f3 md = m - mf;
+    int32_t acx = int32_t(mf.x), acy = int32_t(mf.y), acz = int32_t(mf.z);
+    int32_t bcx = acx + ((md.x < 0.5f) ? -1 : +1);
+    int32_t bcy = acy + ((md.y < 0.5f) ? -1 : +1);
+    int32_t bcz = acz + ((md.z < 0.5f) ? -1 : +1);
+
+    const etx_abi_material& mat = scene.materials[isect.material];
+    BsdfData camera_data = make_bsdf_data(isect, isect.w_i, cv.st.medium, kPathCamera);
+    const f3 t_camera = cv.st.throughput;  // / sampling_pdf() == 1 in RGB mode
+    const float w_camera_base = cv.st.d_vcm * it.vc_weight;
+    const bool use_mis = opt_enable_mis(it);
+    const bool use_epan = it.kernel == ETX_VCM_KERNEL_EPANECHNIKOV;
+    f3 merged = mk3(0.0f);
+#pragma unroll 1
+    for (uint32_t c = 0; c < 8u; ++c) {
+      uint32_t cell = grid_cell_index((c & 1u) ? bcx : acx, (c & 2u) ? bcy : acy, (c & 4u) ? bcz : acz, g.hash_mask);
+      uint32_t range_begin = (cell == 0u) ? 0u : p.grid.cell_ends[cell - 1u];
+      uint32_t range_end = p.grid.cell_ends[cell];
+      for (uint32_t j = range_begin; j < range_end; ++j) {
+        examined++;
+        float4 pl = p.grid.pos_len[j];
+        f3 d = f3{pl.x, pl.y, pl.z} - isect.pos;
+        float distance_squared = dot(d, d);
+        if ((distance_squared > g.radius_squared) || (__float_as_uint(pl.w) + cv.st.depth + 1u > scene.max_path_length))
+          continue;
+        float4 nd = p.grid.nrm_dvcm[j];
+        if (dot(isect.nrm, f3{nd.x, nd.y, nd.z}) <= kEpsilon)
+          continue;
+        float4 wd = p.grid.win_dvm[j];
+        const f3 wi = {wd.x, wd.y, wd.z};
+        BsdfEval camera_bsdf = bsdf_evaluate(scene, camera_data, -wi, mat, cv.st.sampler);
+        if (camera_bsdf.valid() == false)
+          continue;
+        float camera_rev_pdf = bsdf_reverse_pdf(scene, camera_data, -wi, mat);
+        float w_light = nd.w * it.vc_weight + wd.w * camera_bsdf.pdf;
+        float w_camera = w_camera_base + cv.st.d_vm * camera_rev_pdf;
+        float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;
+        float kernel_weight = use_epan ? fmaxf(2.0f * (1.0f - distance_squared * g.inv_radius_squared), 0.0f) : 1.0f;
+        f3 c_value = camera_bsdf.func * t_camera;
+        float4 lt = p.grid.thr[j];
+        merged += (c_value * f3{lt.x, lt.y, lt.z}) * (kernel_weight * weight);
+        merged_count++;
+      }
+    }
+    merged *= it.vm_normalization;
+    if ((merged.x != 0.0f) || (merged.y != 0.0f) || (merged.z != 0.0f))
+      atomic_add_f3(p.camera_sum + film_index(it, cv.st.id), merged);
+  }
+  if (examined) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsExamined), examined);
+    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsMerged), merged_count);
+  }
+}
+
+void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
+  hipLaunchKernelGGL(k_merge, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
+}
+
+#if defined(ETX_HIP_DEBUG_COUNTERS)
+__global__ void k_debug_lists(Pipeline p) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.capacity)
+    return;
+  uint32_t len = 0;
+  for (uint32_t vi = p.light_path_head[i]; (vi != kInvalid) && (len < 100000u); vi = p.lv.next[vi])
+    len++;
+  atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kDbgBase + 2), (unsigned long long)len);
+  atomicMax(p.counters + kDbgBase + 4, len);
+}
+void launch_debug_lists(hipStream_t stream, const Pipeline& p) {
+  hipLaunchKernelGGL(k_debug_lists, dim3((p.capacity + 255u) / 256u), dim3(256), 0, stream, p);
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// Film::layer, film.cxx:381-418: float3 sums -> float4 (alpha 1); Result = max(0, camera + light)
+__global__ void k_film_resolve(const float4* __restrict__ camera_sum, const float4* __restrict__ light_sum, float4* __restrict__ out, uint32_t pixel_count, float scale, int layer) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pixel_count)
+    return;
+  float4 c = camera_sum[i], l = light_sum[i];
+  float4 r;
+  if (layer == 0)
+    r = make_float4(c.x * scale, c.y * scale, c.z * scale, 1.0f);
+  else if (layer == 1)
+    r = make_float4(l.x * scale, l.y * scale, l.z * scale, 1.0f);
+  else
+    r = make_float4(fmaxf(0.0f, (c.x + l.x) * scale), fmaxf(0.0f, (c.y + l.y) * scale), fmaxf(0.0f, (c.z + l.z) * scale), 1.0f);
+  out[i] = r;
+}
+
+void launch_film_resolve(hipStream_t stream, const float4* camera_sum, const float4* light_sum, float4* out, uint32_t pixel_count, float scale, int layer) {
+  hipLaunchKernelGGL(k_film_resolve, dim3((pixel_count + 255u) / 256u), dim3(256), 0, stream, camera_sum, light_sum, out, pixel_count, scale, layer);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// known-answer kernels (include/etx_hip.h: etx_hip_kat)
+__global__ void k_kat(int which, const float* __restrict__ in, uint32_t count, float* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count)
+    return;
+  switch (which) {
+    case 0: {
+      Sampler s;
+      s.init(__float_as_uint(in[2 * i + 0]), __float_as_uint(in[2 * i + 1]));
+      out[4 * i + 0] = __uint_as_float(s.seed);
+      out[4 * i + 1] = s.next();
+      out[4 * i + 2] = s.next();
+      out[4 * i + 3] = s.next();
+      break;
+    }
+    case 1: {
+      f3 r = offset_ray(f3{in[6 * i], in[6 * i + 1], in[6 * i + 2]}, f3{in[6 * i + 3], in[6 * i + 4], in[6 * i + 5]});
+      out[3 * i] = r.x, out[3 * i + 1] = r.y, out[3 * i + 2] = r.z;
+      break;
+    }
+    case 2: {
+      Basis b = orthonormal_basis(f3{in[3 * i], in[3 * i + 1], in[3 * i + 2]});
+      out[6 * i] = b.u.x, out[6 * i + 1] = b.u.y, out[6 * i + 2] = b.u.z, out[6 * i + 3] = b.v.x, out[6 * i + 4] = b.v.y, out[6 * i + 5] = b.v.z;
+      break;
+    }
+    case 3: {
+      f3 r = sample_cosine_distribution(f2{in[5 * i], in[5 * i + 1]}, f3{in[5 * i + 2], in[5 * i + 3], in[5 * i + 4]}, 1.0f);
+      out[3 * i] = r.x, out[3 * i + 1] = r.y, out[3 * i + 2] = r.z;
+      break;
+    }
+    case 4: {
+      uint32_t idx = grid_cell_index(__float_as_int(in[4 * i]), __float_as_int(in[4 * i + 1]), __float_as_int(in[4 * i + 2]), __float_as_uint(in[4 * i + 3]));
+      out[i] = __uint_as_float(idx);
+      break;
+    }
+    case 5: {
+      f2 r = sample_disk(f2{in[2 * i], in[2 * i + 1]});
+      out[2 * i] = r.x, out[2 * i + 1] = r.y;
+      break;
+    }
+    default:
+      break;
+  }
+}
+
+void launch_kat(hipStream_t stream, int which, const float* in, uint32_t count, float* out) {
+  if (count == 0)
+    return;
+  hipLaunchKernelGGL(k_kat, dim3((count + 255u) / 256u), dim3(256), 0, stream, which, in, count, out);
+}
+
+}  // namespace etxd

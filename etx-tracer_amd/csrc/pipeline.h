@@ -1,0 +1,133 @@
+// pipeline.h - HBM-resident wavefront state shared by the host (host_api.cpp) and the kernels.
+//
+// Data layout (re-derived for gfx950):
+//  * Path state is SoA and is re-compacted every bounce: the shade kernel reads slot i of the "in" set and writes the
+//    survivors densely into the "out" set (wave ballot + one atomic per wave), so every kernel streams contiguous
+//    16-byte lanes (1 KiB per wave instruction) and the ray / hit queues are index-aligned with the state
+//    (no indirection, no per-ray path index).
+//  * Ray queue : ray_o_tmin[i] = {o.xyz, tmin}, ray_d_tmax[i] = {d.xyz, tmax}      32 B / ray
+//  * Hit queue : hit[i] = {u, v, t, triangle index bits}                             16 B / ray
+//  * Light vertices: write-once SoA pool + per-path singly linked list (bounce order != path order).
+//  * Photon grid: counting sort by hash cell into a second SoA (reference: vcm_shared.cxx:49-152).
+//  * Film: float4 sums per pixel (camera, light), atomically accumulated; the host divides by the iteration count,
+//    which equals the reference's running-mean lerp (film.cxx:200-206, 332-343) and makes the multi-GPU reduce a sum.
+#pragma once
+
+#include "dev_scene.h"
+
+namespace etxd {
+
+struct PathSet {
+  float4* ray_o_tmin;
+  float4* ray_d_tmax;
+  float4* thr_eta;   // throughput rgb, eta
+  float4* mis;       // d_vcm, d_vc, d_vm, path_distance
+  uint4* meta;       // sampler seed, total_path_depth, medium index, flags
+  uint32_t* path_id; // global path index (light pass) / pixel index (camera pass)
+};
+
+enum : uint32_t {  // VCMPathState flags, vcm_shared.hxx:92-98
+  kPathDeltaEmitter = 1u << 0,
+  kPathLocalEmitter = 1u << 3,
+};
+
+struct LightVertexPool {   // VCMLightVertex (vcm_shared.hxx:154-197) as SoA
+  float4* pos_dvcm;        // pos.xyz, d_vcm
+  float4* wi_dvc;          // w_i.xyz, d_vc
+  float4* thr_dvm;         // throughput rgb, d_vm
+  float4* nrm_tri;         // nrm.xyz, triangle index bits (kInvalid = medium vertex)
+  float4* bc_len_med;      // bc.u, bc.v, path_length bits, medium index bits
+  uint32_t* next;          // previous vertex of the same light path (linked list), kInvalid = end
+  uint32_t capacity;
+};
+
+struct PhotonGrid {        // VCMSpatialGridData (vcm_shared.hxx:805-827) as SoA sorted by hash cell
+  uint32_t* cell_ends;     // size hash_capacity
+  float4* pos_len;         // pos.xyz, path_length bits
+  float4* nrm_dvcm;        // nrm.xyz, d_vcm
+  float4* win_dvm;         // w_in.xyz, d_vm
+  float4* thr;             // throughput_rgb / sampling_pdf
+  uint32_t* block_sums;    // scan scratch
+  uint32_t hash_capacity;
+};
+
+struct GridParams {        // written by k_grid_setup on the device each iteration
+  f3 bbox_min;
+  float cell_size;
+  f3 bbox_max;
+  float radius_squared;
+  float inv_radius_squared;
+  uint32_t hash_mask;
+  uint32_t photon_count;
+  uint32_t valid;
+};
+
+struct CameraVertexPool {  // connectible camera vertices of the current bounce (input of k_connect / k_merge)
+  float4* hit;             // u, v, t, triangle bits  (medium event: pos.xyz, kInvalid)
+  float4* wi_medium;       // ray direction (w_i), medium index bits
+  float4* thr_depth;       // throughput rgb, total_path_depth bits
+  float4* mis_pixel;       // d_vcm, d_vc, d_vm (already updated at the vertex), pixel index bits
+  uint32_t* seed;
+};
+
+enum : uint32_t {  // device counters (u32), cleared per iteration unless noted
+  kCntActiveA = 0,
+  kCntActiveB = 1,
+  kCntLightVertices = 2,
+  kCntCameraVertices = 3,   // cleared per bounce
+  kCntOverflow = 4,
+  kCntBboxMin = 5,          // 3 x ordered-int float min
+  kCntBboxMax = 8,          // 3 x ordered-int float max
+  kCntStatsBase = 16,
+  kStatRaysExtension = 16,
+  kStatRaysShadow = 18,
+  kStatCameraVertices = 20,
+  kStatPhotonsExamined = 22,
+  kStatPhotonsMerged = 24,
+  kStatSplats = 26,
+  kDbgBase = 32,           // u64 debug counters (ETX_HIP_DEBUG_COUNTERS builds)
+  kCounterCount = 64,
+};
+
+enum : uint32_t {
+  kOverflowLightVertices = 1u << 0,
+  kOverflowStack = 1u << 1,
+};
+
+struct VcmParams {  // VCMOptions + VCMIteration (vcm_shared.hxx:12-89), per iteration, by value
+  uint32_t options;
+  uint32_t kernel;
+  uint32_t iteration;
+  uint32_t path_count;   // W * H
+  float current_radius;
+  float vm_weight;
+  float vc_weight;
+  float vm_normalization;
+  uint32_t film_w, film_h;
+  uint32_t pad0, pad1;
+};
+
+ETX_HD bool opt_connect_to_camera(const VcmParams& p) { return p.options & ETX_VCM_CONNECT_TO_CAMERA; }
+ETX_HD bool opt_direct_hit(const VcmParams& p) { return p.options & ETX_VCM_DIRECT_HIT; }
+ETX_HD bool opt_connect_to_light(const VcmParams& p) { return p.options & ETX_VCM_CONNECT_TO_LIGHT; }
+ETX_HD bool opt_connect_vertices(const VcmParams& p) { return p.options & ETX_VCM_CONNECT_VERTICES; }
+ETX_HD bool opt_enable_mis(const VcmParams& p) { return p.options & ETX_VCM_ENABLE_MIS; }
+ETX_HD bool opt_enable_merging(const VcmParams& p) { return p.options & ETX_VCM_ENABLE_MERGING; }
+ETX_HD bool opt_merge_vertices(const VcmParams& p) { return opt_enable_merging(p) && (p.options & ETX_VCM_MERGE_VERTICES); }
+
+struct Pipeline {  // everything a kernel needs, passed by value (fits the kernarg segment)
+  const DScene* scene;   // device pointer
+  PathSet paths[2];
+  float4* hits;          // hit queue, aligned with the "in" path set
+  LightVertexPool lv;
+  uint32_t* light_path_head;   // per path: last stored vertex (kInvalid = none)
+  PhotonGrid grid;
+  GridParams* grid_params;
+  CameraVertexPool cv;
+  float4* camera_sum;
+  float4* light_sum;
+  uint32_t* counters;
+  uint32_t capacity;     // paths per set
+};
+
+}  // namespace etxd

@@ -1,0 +1,151 @@
+"""Host-side mirror of the reference's integrator plugin interface for the HIP backend.
+
+`Integrator` restates `struct Integrator` (sources/etx/rt/integrators/integrator.hxx:12-98): name / run / update /
+stop / status / options / state, same method names and call protocol as the C++ class a maintainer adds to the
+raytracer (INTEGRATION.md shows that class; both sit on the same C ABI). `HIPVCM` takes the place of `CPUVCM`
+(sources/etx/rt/integrators/vcm_cpu.cxx:243-310): run() arms the device pipeline, update() renders / polls one
+iteration per call and stops at scene.samples, stop() drains the device.
+"""
+import enum
+
+from . import api
+
+
+class State(enum.Enum):  # Integrator::State, integrator.hxx:13-17
+    Stopped = 0
+    Running = 1
+    WaitingForCompletion = 2
+
+
+class Stop(enum.Enum):  # Integrator::Stop, integrator.hxx:19-22
+    Immediate = 0
+    WaitForCompletion = 1
+
+
+class Integrator:
+    def __init__(self):
+        self.current_state = State.Stopped
+        self.integrator_options = {}
+
+    def name(self):
+        return "Basic Integrator"
+
+    def enabled(self):
+        return True
+
+    def options(self):
+        return self.integrator_options
+
+    def state(self):
+        return self.current_state
+
+    def run(self):
+        pass
+
+    def update(self):
+        pass
+
+    def stop(self, how=Stop.Immediate):
+        pass
+
+    def update_options(self):
+        if self.current_state == State.Running:
+            self.run()
+
+
+def vcm_options_from_dict(values):
+    """VCMOptions::load (sources/etx/rt/integrators/vcm_shared.cxx:15-31): same keys, same defaults."""
+    o = api.VCMOptions.default_values()
+    o.initial_radius = float(values.get("vcm-initial_radius", o.initial_radius))
+    o.radius_decay = int(values.get("vcm-radius_decay", o.radius_decay))
+    o.blue_noise = 1 if values.get("vcm-blue_noise", bool(o.blue_noise)) else 0
+    o.kernel = int(values.get("vcm-kernel", o.kernel))
+
+    def flag(key, bit):
+        nonlocal o
+        current = bool(o.options & bit)
+        if key == "vcm-merge_vertices":  # merge_vertices() = enable_merging() && MergeVertices (vcm_shared.hxx:58-60)
+            current = bool(o.options & api.VCM_ENABLE_MERGING) and current
+        enabled = bool(values.get(key, current))
+        o.options = (o.options | bit) if enabled else (o.options & ~bit)
+
+    flag("vcm-direct_hit", api.VCM_DIRECT_HIT)
+    flag("vcm-connect_to_light", api.VCM_CONNECT_TO_LIGHT)
+    flag("vcm-connect_to_camera", api.VCM_CONNECT_TO_CAMERA)
+    flag("vcm-connect_vertices", api.VCM_CONNECT_VERTICES)
+    flag("vcm-merge_vertices", api.VCM_MERGE_VERTICES)
+    flag("vcm-mis", api.VCM_ENABLE_MIS)
+    flag("vcm-merging", api.VCM_ENABLE_MERGING)
+    return o
+
+
+class HIPVCM(Integrator):
+    def __init__(self, snapshot, device=0, first_iteration=0, iteration_stride=1):
+        super().__init__()
+        self.snapshot = snapshot
+        self.context = api.Context(device)
+        self.first_iteration = first_iteration
+        self.iteration_stride = iteration_stride
+        self._uploaded = False
+        self._rendered = 0
+        self._have_camera_image = False
+        self._have_light_image = False
+
+    def name(self):
+        return "VCM (HIP gfx950)"
+
+    def _iterations_to_render(self):
+        # this rank renders first, first + stride, ... < scene.samples (vcm_cpu.cxx:234: stop at iteration + 1 >= samples)
+        total = self.snapshot.samples
+        if self.first_iteration >= total:
+            return 0
+        return (total - self.first_iteration + self.iteration_stride - 1) // self.iteration_stride
+
+    def run(self):
+        self.stop(Stop.Immediate)
+        if not self._uploaded:
+            self.context.upload_scene(self.snapshot)
+            self._uploaded = True
+        self.context.begin_vcm(vcm_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride)
+        self._rendered = 0
+        self.current_state = State.Running if self._iterations_to_render() > 0 else State.Stopped
+
+    def update(self):
+        if self.current_state == State.Stopped:
+            return
+        self.context.render_iteration()
+        self._rendered += 1
+        self._have_camera_image = True
+        self._have_light_image = True
+        if (self.current_state == State.WaitingForCompletion) or (self._rendered >= self._iterations_to_render()):
+            self.current_state = State.Stopped
+
+    def stop(self, how=Stop.Immediate):
+        if self.current_state == State.Stopped:
+            return
+        if how == Stop.Immediate:
+            self.context.sync()
+            self.current_state = State.Stopped
+        else:
+            self.current_state = State.WaitingForCompletion
+
+    def have_updated_camera_image(self):
+        r, self._have_camera_image = self._have_camera_image, False
+        return r
+
+    def have_updated_light_image(self):
+        r, self._have_light_image = self._have_light_image, False
+        return r
+
+    def status(self):
+        return self.context.stats()
+
+    def render(self):
+        """run() + update() until Stopped - what the headless driver does (oracle/driver/etx_oracle.cxx main loop)."""
+        self.run()
+        while self.state() != State.Stopped:
+            self.update()
+        return self
+
+    def film(self, layer=api.LAYER_RESULT):
+        return self.context.read_film(layer)

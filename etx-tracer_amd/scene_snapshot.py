@@ -1,0 +1,109 @@
+"""Scene snapshots: a byte-exact copy of the reference's `etx::Scene` / `etx::Camera` (the backend's input ABI,
+include/etx_scene_abi.h) plus every array they point to, written by oracle/_ref/etx_oracle --snapshot through the
+reference's own scene loader. Loading = relocating the listed pointer fields into this process' address space.
+
+File layout ("ETXSCENE1", see oracle/driver/etx_oracle.cxx write_snapshot):
+  bytes 0..15  magic, then u64 scene_offset, camera_offset, fixup_count, fixup_offset, total_size, (sizeof(Scene)<<32|sizeof(Camera))
+  fixups: u64 offsets of pointer fields; each field holds a payload offset (0 = null).
+"""
+import ctypes
+import struct
+
+import numpy as np
+
+SCENE_SIZE = 528   # sizeof(etx::Scene)  == sizeof(etx_abi_scene)
+CAMERA_SIZE = 176  # sizeof(etx::Camera) == sizeof(etx_abi_camera)
+
+# field offsets inside etx_abi_scene / etx_abi_camera used on the host side (include/etx_scene_abi.h)
+_SCENE_TRIANGLES = 16
+_SCENE_VERTICES = 0
+_SCENE_MATERIALS = 48
+_SCENE_EMITTERS = 80
+_SCENE_SAMPLES = 464
+_SCENE_MAX_PATH = 460
+_SCENE_MIN_PATH = 456
+_SCENE_RR_START = 468
+_SCENE_FLAGS = 520
+_SCENE_RADIUS = 444
+_CAMERA_FILM_SIZE = 144
+
+
+class SceneSnapshot:
+    def __init__(self, path):
+        with open(path, "rb") as f:
+            data = f.read()
+        if data[:9] != b"ETXSCENE1":
+            raise ValueError("%s: not an ETXSCENE1 snapshot" % path)
+        scene_off, camera_off, fix_count, fix_off, total, sizes = struct.unpack_from("<6Q", data, 16)
+        if total != len(data):
+            raise ValueError("%s: truncated snapshot" % path)
+        if sizes != ((SCENE_SIZE << 32) | CAMERA_SIZE):
+            raise ValueError("%s: snapshot was written for a different Scene/Camera layout" % path)
+        # 16-byte aligned, writable storage that outlives the upload call
+        self._raw = ctypes.create_string_buffer(len(data) + 16)
+        base = ctypes.addressof(self._raw)
+        aligned = (base + 15) & ~15
+        ctypes.memmove(aligned, data, len(data))
+        self.base = aligned
+        self.size = len(data)
+        fixups = struct.unpack_from("<%dQ" % fix_count, data, fix_off)
+        for field in fixups:
+            ptr = ctypes.c_uint64.from_address(aligned + field)
+            if ptr.value != 0:
+                ptr.value = ptr.value + aligned
+        self.scene_address = aligned + scene_off
+        self.camera_address = aligned + camera_off
+        self.path = path
+
+    def _u32(self, address):
+        return ctypes.c_uint32.from_address(address)
+
+    def _array(self, offset):
+        ptr = ctypes.c_uint64.from_address(self.scene_address + offset).value
+        count = ctypes.c_uint64.from_address(self.scene_address + offset + 8).value
+        return ptr, count
+
+    @property
+    def film_size(self):
+        return (self._u32(self.camera_address + _CAMERA_FILM_SIZE).value, self._u32(self.camera_address + _CAMERA_FILM_SIZE + 4).value)
+
+    @property
+    def samples(self):
+        return self._u32(self.scene_address + _SCENE_SAMPLES).value
+
+    @samples.setter
+    def samples(self, value):
+        self._u32(self.scene_address + _SCENE_SAMPLES).value = int(value)
+
+    @property
+    def max_path_length(self):
+        return self._u32(self.scene_address + _SCENE_MAX_PATH).value
+
+    @max_path_length.setter
+    def max_path_length(self, value):
+        self._u32(self.scene_address + _SCENE_MAX_PATH).value = int(value)
+
+    @property
+    def bounding_sphere_radius(self):
+        return ctypes.c_float.from_address(self.scene_address + _SCENE_RADIUS).value
+
+    @property
+    def triangle_count(self):
+        return self._array(_SCENE_TRIANGLES)[1]
+
+    def vertices(self):
+        """float32 view (count, 14): pos, nrm, tan, btn, tex"""
+        ptr, count = self._array(_SCENE_VERTICES)
+        buf = (ctypes.c_float * (count * 14)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.float32).reshape(count, 14)
+
+    def triangles(self):
+        """uint32 view (count, 8): i0, i1, i2, material, geo_n (float bits) x3, pad"""
+        ptr, count = self._array(_SCENE_TRIANGLES)
+        buf = (ctypes.c_uint32 * (count * 8)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.uint32).reshape(count, 8)
+
+    def material_classes(self):
+        ptr, count = self._array(_SCENE_MATERIALS)
+        buf = (ctypes.c_uint32 * (count * 50)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.uint32).reshape(count, 50)[:, 41].copy()  # offset 164 / 4

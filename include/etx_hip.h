@@ -1,0 +1,178 @@
+/*
+ * etx_hip.h - C ABI of libetx_hip.so, the MI355X (gfx950) wavefront light-transport backend for etx-tracer.
+ *
+ * Drop-in boundary: the reference's plugin interface is `struct Integrator`
+ * (sources/etx/rt/integrators/integrator.hxx:12-98). A host class `HIPVCM : Integrator` forwards
+ *   run()     -> etx_hip_upload_scene + etx_hip_begin + etx_hip_render_iteration   (replaces vcm_cpu.cxx:81-124:
+ *                Film::clear, VCMOptions::load, scheduler.schedule(pixel_count, &light_gather))
+ *   update()  -> etx_hip_poll / next etx_hip_render_iteration / etx_hip_read_film   (replaces vcm_cpu.cxx:264-276
+ *                + complete_light_vertices :209-225 + complete_camera_vertices :227-241)
+ *   stop()    -> etx_hip_sync                                                       (replaces vcm_cpu.cxx:278-288)
+ *   status()  -> etx_hip_stats                                                      (Integrator::Status, integrator.hxx:24-37)
+ * i.e. the device boundary sits exactly where the reference calls TaskScheduler::schedule for its per-pixel loops.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success, <0 on error (etx_hip_last_error
+ * gives the text), mirroring the reference's bool + log::error convention (sources/etx/gpu/gpu.hxx:74).
+ * The library never falls back to a CPU path: without a gfx950 device etx_hip_create fails.
+ */
+#ifndef ETX_HIP_H
+#define ETX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "etx_scene_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ETX_HIP_ABI_VERSION 1
+
+typedef struct etx_hip_context etx_hip_context; /* opaque */
+
+enum {
+  ETX_HIP_OK = 0,
+  ETX_HIP_ERROR_INVALID_ARGUMENT = -1,
+  ETX_HIP_ERROR_NO_DEVICE = -2,
+  ETX_HIP_ERROR_HIP = -3,            /* a HIP runtime call failed */
+  ETX_HIP_ERROR_UNSUPPORTED = -4,    /* scene feature not implemented by the device path (never silently ignored) */
+  ETX_HIP_ERROR_STATE = -5,          /* call order violated (e.g. render before begin) */
+  ETX_HIP_ERROR_OVERFLOW = -6,       /* a device queue/pool overflowed during the last iteration */
+  ETX_HIP_ERROR_COMM = -7            /* RCCL failure */
+};
+
+/* which integrator the device pipeline runs; names follow the reference classes it stands in for */
+enum {
+  ETX_HIP_INTEGRATOR_PT = 0,   /* CPUPathTracing  sources/etx/rt/integrators/path_tracing.cxx:50-110, options = etx_abi_pt_options */
+  ETX_HIP_INTEGRATOR_VCM = 1   /* CPUVCM          sources/etx/rt/integrators/vcm_cpu.cxx:95-241,     options = etx_abi_vcm_options */
+};
+
+/* film layers, subset of etx::Film layer ids (sources/etx/render/host/film.hxx:14-27) that the MC loop produces */
+enum {
+  ETX_HIP_LAYER_CAMERA = 0, /* Film::CameraImage : running mean of per-iteration camera estimates */
+  ETX_HIP_LAYER_LIGHT = 1,  /* Film::LightImage  : running mean of light-path splats */
+  ETX_HIP_LAYER_RESULT = 2  /* Film::Result      : max(0, camera + light), film.cxx:401-409 */
+};
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* lifetime */
+
+int etx_hip_abi_version(void);
+
+/* Opens HIP device `device` (must be gfx950) and creates the streams / queues. */
+int etx_hip_create(int device, etx_hip_context** out_context);
+void etx_hip_destroy(etx_hip_context* context);
+
+/* Text of the last error on this context (or of the last failed etx_hip_create when context == NULL). */
+const char* etx_hip_last_error(const etx_hip_context* context);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* scene: replaces Raytracing::commit_changes (sources/etx/rt/rt.cxx:58-88: film.allocate + Embree scene build)
+ * and the author's disabled build_device_scene sketch (rt.cxx:141-238). Borrows the host arrays during the call,
+ * owns device copies afterwards: geometry, BVH (built here), materials with spectra pre-resolved for the scene's
+ * RGB/spectral mode, emitters + distribution, images + sampling tables, media. Allocates the film for
+ * camera->film_size. */
+int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, const etx_abi_camera* camera);
+
+/* Optional: the Heitz/Belcour blue-noise tables the host links (thirdparty/bluenoise, used through
+ * sample_blue_noise, path_tracing.cxx:173-178). One table set per sample-count class 1,2,4,...,256 (9 sets);
+ * sobol: 256*256 ints, scrambling/ranking: 128*128*8 ints each. Without them options.blue_noise must be 0. */
+int etx_hip_upload_bluenoise(etx_hip_context* context, uint32_t set_index, const int32_t* sobol_256x256, const int32_t* scrambling_tile, const int32_t* ranking_tile);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* rendering */
+
+/* Clears the film (Film::clear(ClearCameraData|ClearLightData), vcm_cpu.cxx:86) and arms the pipeline.
+ * `options`: etx_abi_vcm_options or etx_abi_pt_options (by integrator). Scene scalars (samples, min/max path length,
+ * random_path_termination, radiance_clamp) come from the uploaded scene.
+ * This context renders iterations first_iteration, first_iteration + iteration_stride, ... (multi-GPU sharding by
+ * iteration; single GPU: 0, 1). */
+int etx_hip_begin(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride);
+
+/* Enqueues one full iteration (VCM: light pass, grid build, camera pass; PT: one sample per pixel) on the
+ * context's stream and returns without waiting. */
+int etx_hip_render_iteration(etx_hip_context* context);
+
+/* 1 = all enqueued iterations finished, 0 = still running, <0 = error. Never blocks (Integrator::update must not
+ * block: vcm_cpu.cxx:264-268). */
+int etx_hip_poll(etx_hip_context* context);
+
+/* Blocks until the device is idle (Integrator::stop(Immediate), vcm_cpu.cxx:278-288). */
+int etx_hip_sync(etx_hip_context* context);
+
+/* Copies a film layer as float4 RGBA (alpha = 1), row order and y-flip as etx::Film stores it
+ * (film.cxx:165,189: row (H-1-y)). Normalised by the number of iterations rendered so far on ALL ranks if
+ * etx_hip_reduce_film was called, else by this context's own iterations. Synchronises the stream. */
+int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size_t dst_bytes);
+
+typedef struct etx_hip_stats_t {
+  /* Integrator::Status (integrator.hxx:24-37) */
+  double last_iteration_time; /* seconds, device time of the last finished iteration (HIP events) */
+  double total_time;
+  uint32_t completed_iterations;
+  uint32_t current_iteration;
+  /* counters of the last finished iteration ("counters the oracle must emit") */
+  uint64_t rays_extension;       /* closest-hit rays (light + camera sub paths) */
+  uint64_t rays_shadow;          /* transmittance rays (camera connections, NEE, vertex connections) */
+  uint64_t light_vertices;       /* stored light vertices */
+  uint64_t camera_vertices;      /* connectible camera vertices */
+  uint64_t photons_examined;     /* photons visited by the merge */
+  uint64_t photons_merged;       /* photons accepted by the merge */
+  uint64_t splats;               /* light image splats */
+  uint64_t wavefront_bounces;    /* kernel rounds (light + camera) */
+  uint32_t overflow_flags;       /* != 0: a pool overflowed (result of that iteration is incomplete) */
+  uint32_t pad;
+  /* per-kernel device time of the last finished iteration, milliseconds (HIP events on the launch stream) */
+  double ms_trace_closest;
+  double ms_trace_shadow;
+  double ms_shade_light;
+  double ms_shade_camera;
+  double ms_connect;
+  double ms_merge;
+  double ms_grid_build;
+  double ms_generate;
+  uint64_t launches_trace_closest;
+  uint64_t launches_trace_shadow;
+} etx_hip_stats_t;
+
+int etx_hip_stats(etx_hip_context* context, etx_hip_stats_t* out_stats, size_t stats_size);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* multi GPU: iterations are sharded over ranks (etx_hip_begin first/stride); the only exchange is one RCCL
+ * sum-reduce of the two float4 film accumulators. The 128-byte ncclUniqueId is created by rank 0
+ * with etx_hip_comm_unique_id and distributed by the host (bench.py: torch.distributed). */
+#define ETX_HIP_UNIQUE_ID_BYTES 128
+int etx_hip_comm_unique_id(void* out_id_128_bytes);
+int etx_hip_comm_init(etx_hip_context* context, int rank, int world_size, const void* id_128_bytes);
+/* All ranks call it after their last etx_hip_render_iteration: ncclAllReduce(sum) of camera/light sums and of the
+ * iteration counter; afterwards etx_hip_read_film on any rank returns the whole-job image. */
+int etx_hip_reduce_film(etx_hip_context* context);
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* kernel-level entry points (used by tests/ and bench.py; the host integrator does not need them) */
+
+/* Closest-hit query over the uploaded scene = Raytracing::trace semantics (rt.cxx:428-466) without the Intersection
+ * expansion: rays = n * {ox,oy,oz,tmin,dx,dy,dz,tmax} (host), hits = n * {u, v, t, triangle_index as u32 bits},
+ * triangle_index 0xffffffff when nothing was hit. Runs the production traversal kernel. */
+int etx_hip_trace_rays(etx_hip_context* context, const float* rays_8f, uint64_t count, float* hits_4f);
+
+/* Same kernel on device-resident buffers (device pointers), `repeat` launches back to back; returns the average
+ * kernel time in ms measured with HIP events on the launch stream. Used by bench.py for the traversal roofline. */
+int etx_hip_trace_rays_device(etx_hip_context* context, const void* d_rays_o_tmin, const void* d_rays_d_tmax, uint64_t count, void* d_hits, uint32_t repeat, double* out_avg_ms);
+
+/* Runs a device-side known-answer kernel: `which` selects the function, in/out are host float arrays.
+ *   0: Sampler        in: n*{a,b} as u32 bits           out: n*{seed bits, next(), next(), next()}   (sampler.hxx:54-77)
+ *   1: offset_ray     in: n*{p.xyz, n.xyz}              out: n*{xyz}                                 (math.hxx:925-943)
+ *   2: orthonormal_basis in: n*{n.xyz}                  out: n*{u.xyz, v.xyz}                        (math.hxx:736-746)
+ *   3: sample_cosine_distribution(rnd, n, 1) in: n*{rx,ry,n.xyz} out: n*{xyz}                        (math.hxx:748-762)
+ *   4: grid cell_index in: n*{x,y,z as i32 bits, mask}  out: n*{index as u32 bits}                   (vcm_shared.hxx:820-822)
+ *   5: sample_disk    in: n*{rx,ry}                     out: n*{x,y}                                 (math.hxx:773-790)
+ */
+int etx_hip_kat(etx_hip_context* context, int which, const float* in, uint64_t count, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* ETX_HIP_H */

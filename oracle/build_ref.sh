@@ -14,7 +14,7 @@ if [ ! -d "$REF/sources/etx" ]; then
 fi
 CXX=/opt/rocm/lib/llvm/bin/clang++   # g++ 11 rejects sources/etx/util/options.hxx:78 (in-class explicit specialisation)
 CC=/opt/rocm/lib/llvm/bin/clang
-FLAGS="-std=c++23 -O2 -g0 -DNDEBUG -D_stricmp=strcasecmp -DETX_HAVE_OPENVDB=1 -D_USE_MATH_DEFINES=1 -DETX_LIBRARY=1 -march=native -w -fPIC"
+FLAGS="-Wno-invalid-offsetof -std=c++23 -O2 -g0 -DNDEBUG -D_stricmp=strcasecmp -DETX_HAVE_OPENVDB=1 -D_USE_MATH_DEFINES=1 -DETX_LIBRARY=1 -march=native -w -fPIC"
 T="$REF/thirdparty"
 INC="-I$REF/sources -I$T -I$T/enkits -I$T/bluenoise -I$T/json -I$T/tinyobjloader -I$T/tinygltf -I$T/mikktspace -I$T/stb_image -I$T/tinyexr -I$T/nanovdb"
 
@@ -34,6 +34,7 @@ compile "$HERE/shims/tasks_threads.cxx"   "$OBJ/tasks_threads.o" & pids+=($!)
 compile "$HERE/shims/denoiser_stub.cxx"   "$OBJ/denoiser_stub.o" & pids+=($!)
 compile "$HERE/shims/raytracing_bvh.cxx"  "$OBJ/raytracing_bvh.o" & pids+=($!)
 compile "$HERE/driver/etx_oracle.cxx"     "$OBJ/etx_oracle.o" & pids+=($!)
+compile "$HERE/ref/abi_check.cxx"         "$OBJ/abi_check.o" & pids+=($!)
 for f in bluenoise/bluenoise.cxx stb_image/stb_image.cxx tinyexr/tinyexr.cxx tinygltf/tiny_gltf.cxx tinyobjloader/tiny_obj_loader.cxx; do
   compile "$T/$f" "$OBJ/$(basename ${f%.cxx}).o" & pids+=($!)
 done
