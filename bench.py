@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the MI355X VCM backend (BASELINE.json: Msamples/s, 1080p Cornell VCM).
+
+One "step" = one full VCM iteration (light pass, photon grid, camera pass with connections + merge, film
+accumulation) over the whole 1920x1080 frame = 2 073 600 samples. N GPUs: every rank renders `steps` iterations of
+its own shard of the iteration sequence (rank r: r, r+N, ...; weak scaling), the timed region ends with the single
+RCCL all-reduce of the film. Scene upload / BVH build happen before the timed region (inputs resident
+in HBM).
+
+  python bench.py --gpus 1 --steps 8 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (traversal kernel, HBM) and
+`cpu_baseline` (the reference's CPUVCM compiled into oracle/_ref, timed on this box' host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+BYTES_PER_RAY = 48         # 32 B ray record in + 16 B hit record out (DESIGN.md "traversal kernel")
+
+
+def cpu_baseline(snapshot_path, width, height, seconds_budget=25.0):
+    """Times the reference's CPUVCM (oracle/_ref/etx_oracle = reference integrator + BVH shim, no Embree) on all host
+    cores, on a bounded number of iterations of the SAME workload."""
+    binary = os.path.join(ROOT, "oracle", "_ref", "etx_oracle")
+    if not os.path.exists(binary):
+        return None
+    # one probe iteration, then as many as fit the budget
+    def run(iterations):
+        out = subprocess.run([binary, "--load-snapshot", snapshot_path, "--integrator", "vcm", "--spp", str(iterations), "--opt", "vcm-blue_noise=false"],
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        m = re.search(r"ORACLE_RESULT (\{.*\})", out.stdout)
+        return json.loads(m.group(1)) if m else None
+
+    probe = run(1)
+    if probe is None:
+        return None
+    iterations = max(1, min(16, int(seconds_budget / max(probe["seconds"], 1e-3))))
+    result = run(iterations) if iterations > 1 else probe
+    if result is None:
+        return None
+    return {
+        "value": round(result["msamples_per_s"], 4),
+        "unit": "Msamples/s",
+        "cores": os.cpu_count(),
+        "threads": result["threads"],
+        "kind": "reference",
+        "sample": "%d VCM iterations of the same %dx%d snapshot (reference CPUVCM + oracle BVH shim instead of Embree), %.1f s" % (
+            result["iterations"], width, height, result["seconds"]),
+    }
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=8)
+    parser.add_argument("--warmup", type=int, default=2)
+    parser.add_argument("--workload", default="full", choices=["full", "classic"],
+                        help="full = surviving cornellbox.mtl (fog medium, env + dir emitters) = BASELINE.json configs[1]; classic = area light only")
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    args = parser.parse_args()
+
+    import numpy as np
+    import torch
+    import etx_tracer_amd as etx
+    from etx_tracer_amd import api, multi_gpu, integrator as integ_mod
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    snapshot_path = os.path.join(ROOT, "tests", "golden", "cornell_%s_1080p.etxscene" % args.workload)
+    snap = etx.SceneSnapshot(snapshot_path)
+    width, height = snap.film_size
+    ctx = api.Context(local_rank)
+    ctx.upload_scene(snap)
+    if distributed:
+        multi_gpu.init_context_comm(ctx, rank, world)
+
+    options = integ_mod.vcm_options_from_dict({"vcm-blue_noise": False})  # VCMOptions::default_values otherwise
+
+    def run_steps(count, first_offset):
+        ctx.begin_vcm(options, first_iteration=rank + first_offset * world, iteration_stride=world)
+        acc = {"rays": 0, "trace_ms": 0.0, "launches": 0, "shadow": 0, "lv": 0, "rounds": 0, "examined": 0}
+        for _ in range(count):
+            ctx.render_iteration()
+            s = ctx.stats()
+            acc["rays"] += s.rays_extension
+            acc["trace_ms"] += s.ms_trace_closest
+            acc["launches"] += s.launches_trace_closest
+            acc["shadow"] += s.rays_shadow
+            acc["lv"] += s.light_vertices
+            acc["rounds"] += s.wavefront_bounces
+            acc["examined"] += s.photons_examined
+        ctx.reduce_film()
+        return acc
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    if args.warmup > 0:
+        run_steps(args.warmup, 0)
+    barrier()
+    t0 = time.perf_counter()
+    acc = run_steps(args.steps, args.warmup)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = ctx.read_film(api.LAYER_RESULT)
+    finite = bool(np.isfinite(result).all())
+
+    if rank == 0:
+        samples = float(width) * height * args.steps * world
+        value = samples / elapsed / 1.0e6
+        achieved = (acc["rays"] * BYTES_PER_RAY / 1.0e9) / (acc["trace_ms"] * 1.0e-3) if acc["trace_ms"] > 0 else 0.0
+        line = {
+            "metric": "Msamples/s (pixels x spp / s), VCM",
+            "value": round(value, 4),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1.0e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "cornell_%s_vcm_1920x1080" % args.workload,
+                "scene": "Cornell box rebuilt for the reference's surviving camera/materials (scenes/make_scenes.py), loaded by the reference loader",
+                "integrator": "VCM, VCMOptions::default_values() except vcm-blue_noise=false, max-path-length 1023, rr start 6, RGB",
+                "samples_per_step": width * height,
+                "parallelism": "iteration-sharded x%d, one RCCL film all-reduce at the end" % world,
+            },
+            "roofline": {
+                "kernel": "k_trace_closest (ray queue -> hit queue)",
+                "bound": "hbm",
+                "achieved": round(achieved, 3),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6),
+                "traffic": None,
+                "bytes_per_ray": BYTES_PER_RAY,
+                "rays": acc["rays"],
+                "launches": acc["launches"],
+                "avg_launch_ms": round(acc["trace_ms"] / max(acc["launches"], 1), 6),
+                "note": "algorithmic bytes = rays x 48 B summed over the timed region / summed HIP-event time of the trace launches (rank 0)",
+            },
+            "counters": {
+                "rays_per_sample": round((acc["rays"] + acc["shadow"]) / (float(width) * height * args.steps), 3),
+                "light_vertices_per_path": round(acc["lv"] / (float(width) * height * args.steps), 3),
+                "wavefront_rounds_per_step": round(acc["rounds"] / args.steps, 2),
+                "photons_examined_per_sample": round(acc["examined"] / (float(width) * height * args.steps), 2),
+                "finite": finite,
+            },
+        }
+        line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(snapshot_path, width, height)
+        print(json.dumps(line))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

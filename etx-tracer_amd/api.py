@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene",
     "etx_hip_upload_bluenoise", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_poll", "etx_hip_sync",
     "etx_hip_read_film", "etx_hip_stats", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
-    "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat",
+    "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh",
 )
 
 
@@ -128,6 +128,7 @@ class Library:
         L.etx_hip_trace_rays.argtypes = [vp, vp, u64, vp]
         L.etx_hip_trace_rays_device.argtypes = [vp, vp, vp, u64, vp, u32, ctypes.POINTER(ctypes.c_double)]
         L.etx_hip_kat.argtypes = [vp, i32, vp, u64, vp]
+        L.etx_hip_host_check_bvh.argtypes = [vp, ctypes.POINTER(u32 * 4)]
 
     @classmethod
     def get(cls):
@@ -222,6 +223,14 @@ class Context:
 
     def reduce_film(self):
         self._check(self.library.lib.etx_hip_reduce_film(self.handle))
+
+
+def host_check_bvh(snapshot, library=None):
+    """(rc, {nodes, triangles, depth, bytes}) - host-only BVH build + invariant check, no GPU needed."""
+    library = library or Library.get()
+    info = (ctypes.c_uint32 * 4)()
+    rc = library.lib.etx_hip_host_check_bvh(snapshot.scene_address, ctypes.byref(info))
+    return rc, {"nodes": info[0], "triangles": info[1], "depth": info[2], "bytes": info[3]}
 
 
 def comm_unique_id(library=None):

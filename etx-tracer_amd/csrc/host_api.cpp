@@ -4,6 +4,7 @@
 
 #include "host_scene.h"
 #include "kernels.h"
+#include "dev_bvh.h"
 
 #include <hip/hip_runtime.h>
 
@@ -698,6 +699,70 @@ int etx_hip_kat(etx_hip_context* context, int which, const float* in, uint64_t c
   (void)hipFree(d_in);
   (void)hipFree(d_out);
   return rc;
+}
+
+int etx_hip_host_check_bvh(const etx_abi_scene* scene, uint32_t out_info[4]) {
+  if ((scene == nullptr) || (out_info == nullptr))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  etxh::HostBvh bvh;
+  etxh::build_bvh(scene, bvh);
+  const auto* vertices = reinterpret_cast<const etx_abi_vertex*>(scene->vertices.a);
+  const auto* triangles = reinterpret_cast<const etx_abi_triangle*>(scene->triangles.a);
+  const uint32_t n = uint32_t(scene->triangles.count);
+  std::vector<uint32_t> seen(n, 0u);
+  bool ok = bvh.tris.size() == n;
+  auto bits = [](float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+  };
+  // recursive descent with an explicit stack: (child reference, enclosing box)
+  struct Item {
+    int32_t ref;
+    f3 lo, hi;
+  };
+  std::vector<Item> stack;
+  if (n > 0)
+    stack.push_back({bvh.root, mk3(-kMaxFloat), mk3(kMaxFloat)});
+  while (ok && (stack.empty() == false)) {
+    Item it = stack.back();
+    stack.pop_back();
+    if (it.ref >= 0) {
+      if (size_t(it.ref) >= bvh.nodes.size()) {
+        ok = false;
+        break;
+      }
+      const BvhNode& nd = bvh.nodes[it.ref];
+      stack.push_back({nd.child0, {nd.lo0_hi0x.x, nd.lo0_hi0x.y, nd.lo0_hi0x.z}, {nd.lo0_hi0x.w, nd.hi0yz_lo1xy.x, nd.hi0yz_lo1xy.y}});
+      stack.push_back({nd.child1, {nd.hi0yz_lo1xy.z, nd.hi0yz_lo1xy.w, nd.lo1z_hi1.x}, {nd.lo1z_hi1.y, nd.lo1z_hi1.z, nd.lo1z_hi1.w}});
+    } else {
+      uint32_t leaf = uint32_t(~it.ref), first = leaf >> 3, count = (leaf & 7u) + 1u;
+      for (uint32_t i = first; ok && (i < first + count); ++i) {
+        if (i >= n) {
+          ok = false;
+          break;
+        }
+        uint32_t ti = bits(bvh.tris[i].v0_index.w);
+        if (ti >= n) {
+          ok = false;
+          break;
+        }
+        seen[ti]++;
+        for (int k = 0; k < 3; ++k) {
+          const etx_abi_float3& p = vertices[triangles[ti].i[k]].pos;
+          ok = ok && (p.x >= it.lo.x) && (p.y >= it.lo.y) && (p.z >= it.lo.z) && (p.x <= it.hi.x) && (p.y <= it.hi.y) && (p.z <= it.hi.z);
+        }
+      }
+    }
+  }
+  for (uint32_t i = 0; ok && (i < n); ++i)
+    ok = seen[i] == 1u;
+  ok = ok && (bvh.depth + 2 <= etxd::kStackDepth);
+  out_info[0] = uint32_t(bvh.nodes.size());
+  out_info[1] = uint32_t(bvh.tris.size());
+  out_info[2] = bvh.depth;
+  out_info[3] = uint32_t(bvh.nodes.size() * sizeof(BvhNode) + bvh.tris.size() * sizeof(BvhTri));
+  return ok ? ETX_HIP_OK : ETX_HIP_ERROR_INVALID_ARGUMENT;
 }
 
 }  // extern "C"

@@ -171,6 +171,11 @@ int etx_hip_trace_rays_device(etx_hip_context* context, const void* d_rays_o_tmi
  */
 int etx_hip_kat(etx_hip_context* context, int which, const float* in, uint64_t count, float* out);
 
+/* Host-only (no GPU, no context): builds the traversal BVH for `scene` exactly as etx_hip_upload_scene does and checks
+ * its invariants (every triangle referenced once, child boxes enclose their triangles, leaf size <= 8, depth within the
+ * device stack). out_info = {inner node count, triangle count, depth, bytes}. Returns 0 or ETX_HIP_ERROR_INVALID_ARGUMENT. */
+int etx_hip_host_check_bvh(const etx_abi_scene* scene, uint32_t out_info[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,6 +185,52 @@ bool load_snapshot(const char* path, std::vector<uint8_t>& storage, const Scene*
   return true;
 }
 
+// Known-answer vectors straight from the reference's headers (pins oracle/kat.c and the device KAT kernels).
+int print_kat() {
+  printf("{\n");
+  printf("  \"sampler\": [");
+  const uint32_t ab[][2] = {{1u, 2u}, {0u, 0u}, {12345u, 7u}, {2073599u, 63u}, {0xffffffffu, 1u}, {16383u, 1023u}};
+  for (uint32_t i = 0; i < 6; ++i) {
+    Sampler s(ab[i][0], ab[i][1]);
+    uint32_t seed = s.seed;
+    float a = s.next(), b = s.next(), c = s.next();
+    printf("%s[%u, %u, %u, %.9g, %.9g, %.9g]", i ? ", " : "", ab[i][0], ab[i][1], seed, a, b, c);
+  }
+  printf("],\n  \"offset_ray\": [");
+  const float pn[][6] = {{0.5f, 1.0f, -2.0f, 0.0f, 1.0f, 0.0f}, {0.01f, -0.02f, 0.03f, 0.57735f, 0.57735f, 0.57735f}, {-1.0f, 0.5f, 0.25f, 1.0f, 0.0f, 0.0f}, {100.0f, -50.0f, 0.001f, -0.6f, 0.0f, 0.8f}};
+  for (uint32_t i = 0; i < 4; ++i) {
+    float3 r = offset_ray({pn[i][0], pn[i][1], pn[i][2]}, {pn[i][3], pn[i][4], pn[i][5]});
+    printf("%s[%.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g]", i ? ", " : "", pn[i][0], pn[i][1], pn[i][2], pn[i][3], pn[i][4], pn[i][5], r.x, r.y, r.z);
+  }
+  printf("],\n  \"orthonormal_basis\": [");
+  const float nn[][3] = {{0.0f, 1.0f, 0.0f}, {0.57735026f, 0.57735026f, 0.57735026f}, {1.0f, 0.0f, 0.0f}, {-0.6f, 0.0f, 0.8f}, {0.0f, 0.0f, -1.0f}};
+  for (uint32_t i = 0; i < 5; ++i) {
+    auto b = orthonormal_basis({nn[i][0], nn[i][1], nn[i][2]});
+    printf("%s[%.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g]", i ? ", " : "", nn[i][0], nn[i][1], nn[i][2], b.u.x, b.u.y, b.u.z, b.v.x, b.v.y, b.v.z);
+  }
+  printf("],\n  \"sample_cosine\": [");
+  const float rc[][5] = {{0.25f, 0.5f, 0.0f, 1.0f, 0.0f}, {0.9f, 0.1f, 1.0f, 0.0f, 0.0f}, {0.01f, 0.77f, -0.6f, 0.0f, 0.8f}, {0.5f, 0.999f, 0.0f, 0.0f, -1.0f}};
+  for (uint32_t i = 0; i < 4; ++i) {
+    float3 r = sample_cosine_distribution(float2{rc[i][0], rc[i][1]}, float3{rc[i][2], rc[i][3], rc[i][4]}, 1.0f);
+    printf("%s[%.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g]", i ? ", " : "", rc[i][0], rc[i][1], rc[i][2], rc[i][3], rc[i][4], r.x, r.y, r.z);
+  }
+  printf("],\n  \"cell_index\": [");
+  const int32_t cells[][4] = {{0, 0, 0, 1023}, {1, 2, 3, 1023}, {-1, 5, 100, 65535}, {12345, -678, 9, 16777215}, {-2147483647, 2147483647, 1, 255}};
+  VCMSpatialGridData grid = {};
+  for (uint32_t i = 0; i < 5; ++i) {
+    grid.hash_table_mask = uint32_t(cells[i][3]);
+    printf("%s[%d, %d, %d, %u, %u]", i ? ", " : "", cells[i][0], cells[i][1], cells[i][2], uint32_t(cells[i][3]), grid.cell_index(cells[i][0], cells[i][1], cells[i][2]));
+  }
+  printf("],\n  \"sample_disk\": [");
+  const float rd[][2] = {{0.5f, 0.5f}, {0.1f, 0.9f}, {0.75f, 0.25f}, {0.0f, 1.0f}, {0.3f, 0.31f}};
+  for (uint32_t i = 0; i < 5; ++i) {
+    float2 r = sample_disk({rd[i][0], rd[i][1]});
+    printf("%s[%.9g, %.9g, %.9g, %.9g]", i ? ", " : "", rd[i][0], rd[i][1], r.x, r.y);
+  }
+  printf("]\n}\n");
+  return 0;
+}
+
 void usage() {
   printf(
     "etx_oracle --scene file.json | --load-snapshot scene.bin --integrator pt|vcm|bdpt [--spp N] [--out film.raw] [--snapshot scene.bin]\n"
@@ -207,6 +253,8 @@ int main(int argc, char** argv) {
       scene_file = next();
     else if (strcmp(argv[i], "--load-snapshot") == 0)
       load_snapshot_file = next();
+    else if (strcmp(argv[i], "--kat") == 0)
+      return print_kat();
     else if (strcmp(argv[i], "--integrator") == 0)
       integrator_name = next();
     else if (strcmp(argv[i], "--spp") == 0)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Regenerates the committed fixtures under tests/golden/ from the reference-based oracle (oracle/_ref/etx_oracle).
+Run in the build container (needs /root/reference): python3 oracle/gen_golden.py
+
+  scene snapshots  cornell_{classic,full}_{128,512,1080p}.etxscene   reference loader -> byte-exact etx::Scene
+  golden films     cornell_{classic,full}_128_vcm.npz                reference CPUVCM, 256 spp, vcm-blue_noise=false
+  KAT vectors      kat_reference.json                                reference header functions
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools import film_io  # noqa: E402
+
+ORACLE = os.path.join(ROOT, "oracle", "_ref", "etx_oracle")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SCENES = os.path.join(ROOT, "scenes", "cornell")
+GOLDEN_SPP = 256
+
+
+def run(*args):
+    print("+", " ".join(args))
+    subprocess.check_call([ORACLE] + list(args), stdout=subprocess.DEVNULL)
+
+
+def main():
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "scenes", "make_scenes.py")])
+    for flavour in ("classic", "full"):
+        for json_name, tag in (("test_128", "128"), ("c1_512", "512"), ("c2_1080p", "1080p")):
+            run("--scene", os.path.join(SCENES, "%s_%s.json" % (flavour, json_name)), "--integrator", "none", "--snapshot",
+                os.path.join(GOLDEN, "cornell_%s_%s.etxscene" % (flavour, tag)))
+        snapshot = os.path.join(GOLDEN, "cornell_%s_128.etxscene" % flavour)
+        film_path = "/tmp/golden_%s.raw" % flavour
+        run("--load-snapshot", snapshot, "--integrator", "vcm", "--spp", str(GOLDEN_SPP), "--opt", "vcm-blue_noise=false", "--out", film_path)
+        film = film_io.read_film(film_path)
+        np.savez_compressed(os.path.join(GOLDEN, "cornell_%s_128_vcm.npz" % flavour), camera=film["camera"][..., :3], light=film["light"][..., :3],
+                            spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]), threads=np.int32(film["threads"]))
+    with open(os.path.join(GOLDEN, "kat_reference.json"), "w") as f:
+        subprocess.check_call([ORACLE, "--kat"], stdout=f)
+
+
+if __name__ == "__main__":
+    main()

@@ -63,3 +63,41 @@ void log::set_console_color(log::Color) {
 }
 
 }  // namespace etx
+
+// ---------------------------------------------------------------------------------------------------------------
+// Heap slack for a latent overflow in the reference's photon grid.
+// VCMSpatialGrid::construct sizes its SoA arrays with `total = _cell_ends.back()` AFTER the exclusive scan
+// (sources/etx/rt/integrators/vcm_shared.cxx:109-123), i.e. without the photons of the LAST hash cell, and the
+// scatter pass then writes those photons past the end of every array (:133-141; AddressSanitizer: "heap-buffer-overflow
+// ... WRITE of size 12 ... vcm_shared.cxx:134"). With glibc this corrupts malloc metadata now and then
+// ("malloc(): invalid size (unsorted)"). The oracle must not patch reference sources, so every allocation simply
+// gets 4 KiB of tail slack: the few overflowing photons land in the slack (and are read back from there by
+// gather_index, exactly as in the reference). The device path sizes its arrays by capacity and has no such overflow.
+#include <cstdlib>
+#include <new>
+
+namespace {
+constexpr size_t kOracleHeapSlack = 4096;
+}
+
+void* operator new(size_t size) {
+  void* p = malloc(size + kOracleHeapSlack);
+  if (p == nullptr)
+    throw std::bad_alloc();
+  return p;
+}
+void* operator new[](size_t size) {
+  return operator new(size);
+}
+void operator delete(void* p) noexcept {
+  free(p);
+}
+void operator delete[](void* p) noexcept {
+  free(p);
+}
+void operator delete(void* p, size_t) noexcept {
+  free(p);
+}
+void operator delete[](void* p, size_t) noexcept {
+  free(p);
+}

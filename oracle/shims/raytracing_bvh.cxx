@@ -254,10 +254,12 @@ struct RaytracingImpl {
   const Camera* source_camera = nullptr;
   CpuBVH* bvh = nullptr;
   bool count_rays = false;
+  bool decorrelate = false;  // diagnostic only, see Raytracing::trace
 
   RaytracingImpl()
     : film(scheduler) {
     count_rays = getenv("ETX_ORACLE_COUNT_RAYS") != nullptr;
+    decorrelate = getenv("ETX_ORACLE_DECORRELATE") != nullptr;
   }
 
   ~RaytracingImpl() {
@@ -314,6 +316,15 @@ void Raytracing::commit_changes() {
 bool Raytracing::trace(const Scene& scene, const Ray& r, Intersection& result_intersection, Sampler& smp) const {
   if (_private->count_rays)
     g_oracle_rays_trace.fetch_add(1, std::memory_order_relaxed);
+  if (_private->decorrelate) {
+    // DIAGNOSTIC (ETX_ORACLE_DECORRELATE=1): the reference seeds light path i and camera path i identically
+    // (vcm_shared.hxx:312,357); how far the two streams drift apart depends on how many candidates the traversal
+    // hands to alpha_test_pass. Burning a ray-dependent number of extra draws removes any systematic alignment,
+    // which tells how much of an oracle-vs-device difference is this correlation and not the estimator.
+    uint32_t k = (to_uint(r.o.x) ^ (to_uint(r.d.y) >> 3u) ^ (to_uint(r.o.z) >> 5u)) % 5u;
+    for (uint32_t i = 0; i < k; ++i)
+      smp.next();
+  }
   IntersectionBase found = {{}, kInvalidIndex, 0.0f};
   _private->bvh->intersect(r, [&](uint32_t triangle_index, float u, float v, float t) {
     const auto& tri = scene.triangles[triangle_index];

@@ -1,0 +1,51 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an MI355X (gfx950) device; run with -m gpu on the GPU box")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def etx():
+    import etx_tracer_amd
+    return etx_tracer_amd
+
+
+@pytest.fixture(scope="session")
+def kat_reference():
+    import json
+    with open(os.path.join(GOLDEN, "kat_reference.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def kat_library():
+    """oracle/liboracle_kat.so: the plain-C restatement (checker only)."""
+    import ctypes
+    import subprocess
+    path = os.path.join(ROOT, "oracle", "liboracle_kat.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    return ctypes.CDLL(path)
+
+
+@pytest.fixture(scope="session")
+def gpu_context(etx):
+    from etx_tracer_amd import api
+    ctx = api.Context(0)
+    yield ctx
+    ctx.close()

@@ -1,0 +1,88 @@
+"""CPU: the C-ABI shared library loads, exports every symbol include/etx_hip.h declares, fails loudly without a GPU;
+host-side logic (snapshot relocation, BVH build, option mapping) works without a device."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    with open(os.path.join(ROOT, "include", "etx_hip.h")) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(etx_hip_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(etx):
+    lib = etx.Library.get()
+    symbols = declared_symbols()
+    assert len(symbols) >= 18
+    missing = [s for s in symbols if not lib.has_symbol(s)]
+    assert missing == []
+    assert set(etx.api.EXPORTED_SYMBOLS) == set(symbols)
+    assert lib.lib.etx_hip_abi_version() == 1
+
+
+def test_missing_library_is_an_error(etx, tmp_path):
+    with pytest.raises(FileNotFoundError):
+        etx.Library(str(tmp_path / "libetx_hip.so"))
+
+
+def test_abi_struct_sizes(etx):
+    import ctypes
+    assert ctypes.sizeof(etx.VCMOptions) == 32       # etx::VCMOptions, SURVEY.md 8
+    assert etx.scene_snapshot.SCENE_SIZE == 528 and etx.scene_snapshot.CAMERA_SIZE == 176
+    o = etx.VCMOptions.default_values()
+    assert (o.options, o.radius_decay, o.kernel, o.initial_radius) == (0x7F, 256, 1, 0.0)  # vcm_shared.cxx:6-13
+
+
+@pytest.mark.parametrize("name,triangles,size", [("cornell_classic_128", 32, (128, 128)), ("cornell_full_128", 44, (128, 128)),
+                                                 ("cornell_classic_1080p", 32, (1920, 1080)), ("cornell_full_512", 44, (512, 512))])
+def test_snapshot_relocation(etx, golden_dir, name, triangles, size):
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, name + ".etxscene"))
+    assert snap.film_size == size
+    assert snap.triangle_count == triangles
+    assert snap.max_path_length == 1023
+    assert abs(snap.bounding_sphere_radius - 3.0 ** 0.5) < 1e-5
+    v = snap.vertices()
+    t = snap.triangles()
+    assert v.shape[1] == 14 and t.shape == (triangles, 8)
+    assert t[:, 0:3].max() < v.shape[0]
+    # unit normals and the box extents of scenes/make_scenes.py
+    np.testing.assert_allclose(np.linalg.norm(v[:, 3:6], axis=1), 1.0, atol=1e-5)
+    assert v[:, 0].min() == -1.0 and v[:, 0].max() == 1.0 and v[:, 1].min() == 0.0 and v[:, 1].max() == 2.0
+
+
+def test_host_bvh_invariants(etx, golden_dir):
+    from etx_tracer_amd import api
+    for name in ("cornell_classic_128", "cornell_full_128"):
+        snap = etx.SceneSnapshot(os.path.join(golden_dir, name + ".etxscene"))
+        rc, info = api.host_check_bvh(snap)
+        assert rc == 0
+        assert info["triangles"] == snap.triangle_count
+        assert 1 <= info["nodes"] < snap.triangle_count
+        assert info["depth"] <= 12
+        assert info["bytes"] == info["nodes"] * 64 + info["triangles"] * 48
+
+
+def test_options_mapping_follows_vcmoptions_load(etx):
+    from etx_tracer_amd import api, integrator
+    o = integrator.vcm_options_from_dict({})
+    assert o.options == api.VCM_FULL_OPTIONS and o.blue_noise == 1
+    o = integrator.vcm_options_from_dict({"vcm-merging": False, "vcm-blue_noise": False, "vcm-radius_decay": 64})
+    assert (o.options & api.VCM_ENABLE_MERGING) == 0 and o.blue_noise == 0 and o.radius_decay == 64
+    o = integrator.vcm_options_from_dict({"vcm-connect_vertices": False, "vcm-mis": False})
+    assert (o.options & api.VCM_CONNECT_VERTICES) == 0 and (o.options & api.VCM_ENABLE_MIS) == 0
+    assert o.options & api.VCM_CONNECT_TO_LIGHT
+
+
+def test_create_without_gpu_fails_loudly(etx):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from etx_tracer_amd import api
+    with pytest.raises(api.EtxHipError) as e:
+        api.Context(0)
+    assert e.value.code == -2  # ETX_HIP_ERROR_NO_DEVICE: no CPU fallback exists
