@@ -14,6 +14,7 @@
 namespace etxd {
 
 constexpr uint32_t kStackDepth = 32;
+constexpr uint32_t kFlatSweepMaxTriangles = 64;  // scenes up to this size are swept linearly (all lanes, same triangle)
 
 struct LaneStack {
   int32_t* base;    // LDS, this lane's slot of level 0
@@ -80,12 +81,60 @@ enum : uint32_t {
   kQueryShadowAny = 1 // as closest, used by the transmittance walk (the caller inspects the material class)
 };
 
+// One Moeller-Trumbore test; u,v are the barycentrics of vertices 1 and 2 (Embree convention, rt.cxx:352-353).
+// Returns true when the triangle is a candidate closer than best.t (Void / alpha filter not applied yet).
+ETX_DEV bool triangle_test(const float4& v0, const float4& e1, const float4& e2, const RayQ& ray, float t_limit, float& out_u, float& out_v, float& out_t) {
+  const f3 E1 = {e1.x, e1.y, e1.z}, E2 = {e2.x, e2.y, e2.z};
+  const f3 p = cross(ray.d, E2);
+  const float det = dot(E1, p);
+  const float inv_det = __builtin_amdgcn_rcpf(det);  // v_rcp_f32 (1 ulp): t/u/v stay within 1e-6 relative of the IEEE division
+  const f3 s = ray.o - f3{v0.x, v0.y, v0.z};
+  const float u = dot(s, p) * inv_det;
+  const f3 q = cross(s, E1);
+  const float v = dot(ray.d, q) * inv_det;
+  const float t = dot(E2, q) * inv_det;
+  out_u = u, out_v = v, out_t = t;
+  // det == 0 gives inf/nan which fail the comparisons below
+  return (det != 0.0f) && (u >= 0.0f) && (u <= 1.0f) && (v >= 0.0f) && (u + v <= 1.0f) && (t >= ray.tmin) && (t <= t_limit);
+}
+
+// Linear sweep for tiny scenes (Cornell: 32-44 triangles): the loop index is wave uniform, so the triangle records
+// are fetched once per wave through the scalar cache and every lane runs the same instruction stream - no stack, no
+// divergence, no dependent node fetches. ~45 VALU per triangle and ray.
+template <class Tris>
+ETX_DEV Hit bvh_flat_closest(const DScene& scene, Tris tris, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags) {
+  Hit best = {0.0f, 0.0f, ray.tmax, kInvalid};
+  uint32_t best_flags = 0u;
+  const uint32_t count = scene.bvh_tri_count;
+  for (uint32_t i = 0; i < count; ++i) {
+    const float4 v0 = tris[i].v0_index;
+    const float4 e1 = tris[i].e1_flags;
+    const float4 e2 = tris[i].e2_mat;
+    float u, v, t;
+    if (triangle_test(v0, e1, e2, ray, best.t, u, v, t) == false)
+      continue;
+    const uint32_t flags = __float_as_uint(e1.w);
+    if (flags & kTriVoid)
+      continue;
+    const uint32_t tri_index = __float_as_uint(v0.w);
+    if ((flags & kTriAlphaTested) && alpha_test_skips(scene, tri_index, __float_as_uint(e2.w), u, v, alpha_seed))
+      continue;
+    best = {u, v, t, tri_index};
+    best_flags = flags;
+  }
+  if (out_flags)
+    *out_flags = best_flags;
+  return best;
+}
+
 // Closest accepted hit in [tmin, tmax]. `Nodes`/`Tris` are pointer types (global or LDS address space).
 template <class Nodes, class Tris>
 ETX_DEV Hit bvh_closest(const DScene& scene, Nodes nodes, Tris tris, int32_t root, const LaneStack& stack, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags) {
+  if (scene.bvh_flat)
+    return bvh_flat_closest(scene, tris, ray, alpha_seed, out_flags);
   Hit best = {0.0f, 0.0f, ray.tmax, kInvalid};
   uint32_t best_flags = 0u;
-  const f3 inv_d = {1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
+  const f3 inv_d = {__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)};
   uint32_t sp = 0;
   int32_t cur = root;
   const int32_t kDone = 0x7fffffff;
@@ -118,23 +167,8 @@ ETX_DEV Hit bvh_closest(const DScene& scene, Nodes nodes, Tris tris, int32_t roo
         const float4 v0 = tris[i].v0_index;
         const float4 e1 = tris[i].e1_flags;
         const float4 e2 = tris[i].e2_mat;
-        // Moeller-Trumbore; u,v are the barycentrics of vertices 1 and 2 (Embree convention, rt.cxx:352-353)
-        f3 E1 = {e1.x, e1.y, e1.z}, E2 = {e2.x, e2.y, e2.z};
-        f3 p = cross(ray.d, E2);
-        float det = dot(E1, p);
-        if (det == 0.0f)
-          continue;
-        float inv_det = 1.0f / det;
-        f3 s = ray.o - f3{v0.x, v0.y, v0.z};
-        float u = dot(s, p) * inv_det;
-        if ((u < 0.0f) || (u > 1.0f))
-          continue;
-        f3 q = cross(s, E1);
-        float v = dot(ray.d, q) * inv_det;
-        if ((v < 0.0f) || (u + v > 1.0f))
-          continue;
-        float t = dot(E2, q) * inv_det;
-        if ((t < ray.tmin) || (t > best.t))
+        float u, v, t;
+        if (triangle_test(v0, e1, e2, ray, best.t, u, v, t) == false)
           continue;
         uint32_t flags = __float_as_uint(e1.w);
         if (flags & kTriVoid)

@@ -81,6 +81,7 @@ struct DScene {
   uint32_t vertex_count, triangle_count, material_count, emitter_count, emitter_dist_count, spectrum_count, image_count, medium_count;
   uint32_t bvh_node_count, bvh_tri_count;
   int32_t bvh_root;  // child encoding (a single leaf scene has a negative root)
+  uint32_t bvh_flat; // != 0: so few triangles that the wave-uniform linear sweep beats the tree (dev_bvh.h)
   float emitter_dist_total;
   uint32_t env_emitters[ETX_ABI_MAX_ENVIRONMENT_EMITTERS];
   uint32_t env_count;

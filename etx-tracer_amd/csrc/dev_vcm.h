@@ -318,7 +318,7 @@ struct LightVertex {  // VCMLightVertex, vcm_shared.hxx:154-197
 };
 
 ETX_DEV LightVertex load_light_vertex(const LightVertexPool& lv, uint32_t i) {
-  float4 a = lv.pos_dvcm[i], b = lv.wi_dvc[i], c = lv.thr_dvm[i], d = lv.nrm_tri[i], e = lv.bc_len_med[i];
+  float4 a = lv.pos_dvcm(i), b = lv.wi_dvc(i), c = lv.thr_dvm(i), d = lv.nrm_tri(i), e = lv.bc_len_med(i);
   LightVertex v;
   v.pos = {a.x, a.y, a.z}, v.d_vcm = a.w;
   v.w_i = {b.x, b.y, b.z}, v.d_vc = b.w;
@@ -328,7 +328,27 @@ ETX_DEV LightVertex load_light_vertex(const LightVertexPool& lv, uint32_t i) {
   return v;
 }
 
+// Surface BSDF access for the connection / merge kernels: kDiffuseOnly instantiations are launched for vertices whose
+// materials are all Material::Class::Diffuse (the common case; keeps the Heitz random walk out of the register budget),
+// the generic instantiation dispatches over every implemented class.
+template <bool kDiffuseOnly>
+ETX_DEV BsdfEval bsdf_evaluate_t(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
+  if (kDiffuseOnly)
+    return diffuse_evaluate(s, d, w_o, m);
+  return bsdf_evaluate(s, d, w_o, m, smp);
+}
+template <bool kDiffuseOnly>
+ETX_DEV float bsdf_reverse_pdf_t(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m) {
+  if (kDiffuseOnly) {
+    BsdfData r = d;
+    r.w_i = -w_o;
+    return diffuse_pdf(r, -d.w_i);
+  }
+  return bsdf_reverse_pdf(s, d, w_o, m);
+}
+
 // vcm_shared.hxx:673-763 vcm_connect_to_light_vertex (surface / medium on either side)
+template <bool kDiffuseOnly>
 ETX_DEV bool vcm_connect_to_light_vertex(const DScene& scene, const PathState& st, const LightVertex& lv, const VcmParams& it, bool camera_at_medium, const Isect* cam, const f3& medium_pos,
   Sampler& smp, f3& target_position, f3& value) {
   Vtx light_v;
@@ -355,11 +375,11 @@ ETX_DEV bool vcm_connect_to_light_vertex(const DScene& scene, const PathState& s
   } else {
     const etx_abi_material& mat = scene.materials[cam->material];
     BsdfData camera_data = make_bsdf_data(*cam, cam->w_i, st.medium, kPathCamera);
-    BsdfEval camera_bsdf = bsdf_evaluate(scene, camera_data, w_o, mat, smp);
+    BsdfEval camera_bsdf = bsdf_evaluate_t<kDiffuseOnly>(scene, camera_data, w_o, mat, smp);
     if (camera_bsdf.valid() == false)
       return false;
     camera_area_pdf = camera_bsdf.pdf * fabsf(w_dot_l) / distance_squared;
-    camera_rev_pdf = bsdf_reverse_pdf(scene, camera_data, w_o, mat);
+    camera_rev_pdf = bsdf_reverse_pdf_t<kDiffuseOnly>(scene, camera_data, w_o, mat);
     camera_scatter = camera_bsdf.bsdf;
   }
 
@@ -377,11 +397,11 @@ ETX_DEV bool vcm_connect_to_light_vertex(const DScene& scene, const PathState& s
     const etx_abi_triangle& light_tri = scene.triangles[lv.tri];
     const etx_abi_material& light_mat = scene.materials[light_tri.material_index];
     BsdfData light_data = make_bsdf_data(light_v, lv.w_i, camera_at_medium ? lv.medium : st.medium, kPathLight);
-    BsdfEval light_bsdf = bsdf_evaluate(scene, light_data, -w_o, light_mat, smp);
+    BsdfEval light_bsdf = bsdf_evaluate_t<kDiffuseOnly>(scene, light_data, -w_o, light_mat, smp);
     if (light_bsdf.valid() == false)
       return false;
     light_area_pdf = camera_at_medium ? (light_bsdf.pdf / distance_squared) : (light_bsdf.pdf * fabsf(dot(cam->nrm, w_o)) / distance_squared);
-    light_rev_pdf = bsdf_reverse_pdf(scene, light_data, -w_o, light_mat);
+    light_rev_pdf = bsdf_reverse_pdf_t<kDiffuseOnly>(scene, light_data, -w_o, light_mat);
     light_scatter = light_bsdf.bsdf * fix_shading_normal(ld3(light_tri.geo_n), light_data.nrm, light_data.w_i, -w_o);
   }
 
@@ -400,6 +420,43 @@ ETX_DEV uint32_t grid_cell_index(int32_t x, int32_t y, int32_t z, uint32_t mask)
 ETX_DEV uint32_t grid_position_to_index(const GridParams& g, const f3& pos) {  // vcm_shared.hxx:824-827
   f3 m = (pos - g.bbox_min) / g.cell_size;
   return grid_cell_index(int32_t(floorf(m.x)), int32_t(floorf(m.y)), int32_t(floorf(m.z)), g.hash_mask);
+}
+
+
+// film.cxx:189: pixel (x, y) is stored in row (H - 1 - y)
+ETX_DEV uint32_t film_index(const VcmParams& it, uint32_t pixel_id) {
+  uint32_t px = pixel_id % it.film_w, py = pixel_id / it.film_w;
+  return px + (it.film_h - 1u - py) * it.film_w;
+}
+
+// A connectible camera vertex as k_camera_shade stored it (CameraVertexPool): the state BEFORE vcm_next_ray, after
+// vcm_update_camera_vcm.
+struct CameraVertex {
+  PathState st;   // throughput, d_vcm/d_vc/d_vm, depth, medium, ray_d (= w_i), id (pixel)
+  Isect isect;
+  f3 medium_pos;
+  bool at_medium;
+};
+
+ETX_DEV CameraVertex load_camera_vertex(const Pipeline& p, const DScene& scene, uint32_t i) {
+  CameraVertex cv;
+  float4 h = p.cv.hit[i], w = p.cv.wi_medium[i], t = p.cv.thr_depth[i], m = p.cv.mis_pixel[i];
+  cv.st.ray_d = {w.x, w.y, w.z};
+  cv.st.medium = __float_as_uint(w.w);
+  cv.st.throughput = {t.x, t.y, t.z};
+  cv.st.depth = __float_as_uint(t.w);
+  cv.st.d_vcm = m.x, cv.st.d_vc = m.y, cv.st.d_vm = m.z;
+  cv.st.id = __float_as_uint(m.w);
+  cv.st.sampler.seed = p.cv.seed[i];
+  cv.st.sampler.fixed_u = cv.st.sampler.fixed_v = cv.st.sampler.fixed_w = 0.0f;
+  cv.st.eta = 1.0f, cv.st.path_distance = 0.0f, cv.st.flags = 0u;
+  cv.st.ray_o = mk3(0.0f), cv.st.ray_tmin = 0.0f, cv.st.ray_tmax = 0.0f;
+  uint32_t tri = __float_as_uint(h.w);
+  cv.at_medium = tri == kInvalid;
+  cv.medium_pos = {h.x, h.y, h.z};
+  if (cv.at_medium == false)
+    cv.isect = make_intersection(scene, cv.st.ray_d, h.x, h.y, h.z, tri);
+  return cv;
 }
 
 }  // namespace etxd

@@ -61,7 +61,7 @@ struct etx_hip_context {
   uint32_t local_iterations = 0;     // iterations rendered by this context since begin
   uint64_t global_iterations = 0;    // after etx_hip_reduce_film: iterations of all ranks
   bool reduced = false;
-  uint32_t check_interval = 4;       // bounces enqueued between two reads of the active-path counter
+  uint32_t check_interval = 8;       // bounces enqueued between two reads of the active-path counter
   uint32_t timer_mask = 1u << kTimerTraceClosest;
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
@@ -141,20 +141,21 @@ int allocate_pipeline(etx_hip_context* ctx) {
   if (lv_cap64 > (1ull << 30))
     lv_cap64 = 1ull << 30;
   p.lv.capacity = uint32_t(lv_cap64);
-  if ((rc = device_alloc(ctx, p.lv.pos_dvcm, p.lv.capacity)) || (rc = device_alloc(ctx, p.lv.wi_dvc, p.lv.capacity)) || (rc = device_alloc(ctx, p.lv.thr_dvm, p.lv.capacity)) ||
-      (rc = device_alloc(ctx, p.lv.nrm_tri, p.lv.capacity)) || (rc = device_alloc(ctx, p.lv.bc_len_med, p.lv.capacity)) || (rc = device_alloc(ctx, p.lv.next, p.lv.capacity)))
+  if ((rc = device_alloc(ctx, p.lv.rec, size_t(p.lv.capacity) * LightVertexPool::kLvStride)))
     return rc;
   if ((rc = device_alloc(ctx, p.light_path_head, n)))
     return rc;
   p.grid.hash_capacity = next_pow2(p.lv.capacity);
   if ((rc = device_alloc(ctx, p.grid.cell_ends, p.grid.hash_capacity)) || (rc = device_alloc(ctx, p.grid.pos_len, p.lv.capacity)) ||
-      (rc = device_alloc(ctx, p.grid.nrm_dvcm, p.lv.capacity)) || (rc = device_alloc(ctx, p.grid.win_dvm, p.lv.capacity)) || (rc = device_alloc(ctx, p.grid.thr, p.lv.capacity)) ||
-      (rc = device_alloc(ctx, p.grid.block_sums, p.grid.hash_capacity / 2048u + 1024u)))
+      (rc = device_alloc(ctx, p.grid.rec, size_t(p.lv.capacity) * PhotonGrid::kPhotonStride)) || (rc = device_alloc(ctx, p.grid.block_sums, p.grid.hash_capacity / 2048u + 1024u)))
     return rc;
   if ((rc = device_alloc(ctx, p.grid_params, 1)))
     return rc;
   if ((rc = device_alloc(ctx, p.cv.hit, n)) || (rc = device_alloc(ctx, p.cv.wi_medium, n)) || (rc = device_alloc(ctx, p.cv.thr_depth, n)) || (rc = device_alloc(ctx, p.cv.mis_pixel, n)) ||
-      (rc = device_alloc(ctx, p.cv.seed, n)))
+      (rc = device_alloc(ctx, p.cv.seed, n)) || (rc = device_alloc(ctx, p.cv.pos_info, n)) || (rc = device_alloc(ctx, p.cv.nrm_dvm, n)) || (rc = device_alloc(ctx, p.cv.fthr_dvcm, n)))
+    return rc;
+  p.pair_capacity = uint32_t(std::min<uint64_t>(uint64_t(n) * 16u, 1ull << 30));
+  if ((rc = device_alloc(ctx, p.pairs, p.pair_capacity)))
     return rc;
   if ((rc = device_alloc(ctx, p.camera_sum, n)) || (rc = device_alloc(ctx, p.light_sum, n)) || (rc = device_alloc(ctx, ctx->resolve_buffer, n)))
     return rc;
@@ -236,21 +237,23 @@ VcmParams make_iteration_params(const etx_hip_context* ctx, uint32_t iteration) 
 template <class ShadeFn>
 int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, uint64_t& rounds) {
   uint32_t set = 0;
+  uint32_t known_count = ctx->pipe.capacity;  // upper bound of the active paths (the count never grows within a pass)
   const uint32_t max_rounds = ctx->scene.host_copy.max_path_length * 2u + 16u;  // boundaries do not add depth
   for (uint32_t round = 0; round < max_rounds;) {
     for (uint32_t k = 0; k < ctx->check_interval; ++k, ++round) {
       {
         ScopedTimer t(ctx, kTimerTraceClosest);
-        launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB);
+        launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB, known_count);
       }
-      shade(set);
+      shade(set, known_count);
       set ^= 1u;
       rounds++;
     }
     int rc = read_counters(ctx);
     if (rc)
       return rc;
-    if (ctx->host_counters[set == 0 ? kCntActiveA : kCntActiveB] == 0u)
+    known_count = ctx->host_counters[set == 0 ? kCntActiveA : kCntActiveB];
+    if (known_count == 0u)
       return 0;
   }
   return 0;
@@ -269,9 +272,9 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
   }
   int rc = run_bounce_loop(
     ctx,
-    [&](uint32_t set) {
+    [&](uint32_t set, uint32_t max_items) {
       ScopedTimer t(ctx, kTimerShadeLight);
-      launch_light_shade(s, p, it, set);
+      launch_light_shade(s, p, it, set, max_items);
     },
     rounds);
   if (rc)
@@ -291,18 +294,18 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
   }
   rc = run_bounce_loop(
     ctx,
-    [&](uint32_t set) {
+    [&](uint32_t set, uint32_t max_items) {
       {
         ScopedTimer t(ctx, kTimerShadeCamera);
-        launch_camera_shade(s, p, it, set);
+        launch_camera_shade(s, p, it, set, max_items);
       }
       if (opt_connect_vertices(it)) {
         ScopedTimer t(ctx, kTimerConnect);
-        launch_connect(s, p, it);
+        launch_connect(s, p, it, ctx->scene.generic_materials, max_items);
       }
       if (opt_merge_vertices(it)) {
         ScopedTimer t(ctx, kTimerMerge);
-        launch_merge(s, p, it);
+        launch_merge(s, p, it, ctx->scene.generic_materials, max_items);
       }
     },
     rounds);
@@ -544,7 +547,7 @@ int etx_hip_render_iteration(etx_hip_context* context) {
   context->next_iteration += context->iteration_stride;
   if (context->stats.overflow_flags) {
     context->error = "device pool overflow in iteration " + std::to_string(context->stats.current_iteration) + " (flags " + std::to_string(context->stats.overflow_flags) +
-                     "): raise ETX_HIP_LIGHT_VERTICES_PER_PATH";
+                     "): light vertex pool (1, raise ETX_HIP_LIGHT_VERTICES_PER_PATH) / connection pair buffer (4)";
     return ETX_HIP_ERROR_OVERFLOW;
   }
   return ETX_HIP_OK;

@@ -282,6 +282,17 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
       return ETX_HIP_ERROR_UNSUPPORTED;
     }
   }
+  out.generic_materials = false;
+  for (uint64_t i = 0; i < scene->materials.count; ++i) {
+    if (used[i] == false)
+      continue;
+    const etx_abi_material& m = materials[i];
+    // connectible = can return a non delta sample: Translucent always; Conductor unless its roughness is a constant <= kDeltaAlphaTreshold
+    bool delta_conductor = (m.cls == ETX_MAT_CONDUCTOR) && (m.roughness.image_index == ETX_ABI_INVALID) &&
+                           (std::max(m.roughness.value.x, m.roughness.value.y) <= kDeltaAlphaTreshold);
+    if ((m.cls == ETX_MAT_TRANSLUCENT) || ((m.cls == ETX_MAT_CONDUCTOR) && (delta_conductor == false)))
+      out.generic_materials = true;
+  }
   for (uint64_t i = 0; i < scene->mediums.count; ++i) {
     if (mediums[i].cls != 0) {
       error = "heterogeneous media are not implemented by the device path";
@@ -387,6 +398,9 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   d.bvh_node_count = uint32_t(bvh.nodes.size());
   d.bvh_tri_count = uint32_t(bvh.tris.size());
   d.bvh_root = bvh.root;
+  d.bvh_flat = (bvh.tris.size() <= kFlatSweepMaxTriangles) ? 1u : 0u;
+  if (const char* e = getenv("ETX_HIP_FORCE_BVH"))
+    d.bvh_flat = (atoi(e) != 0) ? 0u : d.bvh_flat;
   out.bvh_depth = bvh.depth;
   out.bvh_bytes = bvh.nodes.size() * sizeof(BvhNode) + bvh.tris.size() * sizeof(BvhTri);
 

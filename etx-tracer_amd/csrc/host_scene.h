@@ -21,6 +21,7 @@ struct DeviceScene {
   std::vector<void*> allocations;
   uint32_t film_w = 0, film_h = 0;
   uint32_t bvh_depth = 0;
+  bool generic_materials = false;  // a connectible (non delta) surface material other than Diffuse is in use
   size_t bvh_bytes = 0;
 
   ~DeviceScene();

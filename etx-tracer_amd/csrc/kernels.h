@@ -10,22 +10,23 @@ constexpr uint32_t kBlockSize = 256;
 constexpr uint32_t kPersistentBlocks = 256 * 8;  // 256 CUs x 8 blocks of 256 threads, grid-stride loops
 
 // traversal
-void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter);
+// `max_items`: host-side upper bound of the device-resident item count (sizes the grid; kernels grid-stride anyway)
+void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items);
 void launch_trace_rays(hipStream_t stream, const DScene* scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count);
 
 // VCM light pass
 void launch_iteration_reset(hipStream_t stream, const Pipeline& p);
 void launch_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
-void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set);
+void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items);
 
 // photon grid
 void launch_grid_build(hipStream_t stream, const Pipeline& p, const VcmParams& it);
 
 // VCM camera pass
 void launch_camera_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
-void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set);
-void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it);
-void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it);
+void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items);
+void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items);
+void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items);
 
 // film
 void launch_film_resolve(hipStream_t stream, const float4* camera_sum, const float4* light_sum, float4* out, uint32_t pixel_count, float scale, int layer);

@@ -1,0 +1,298 @@
+// kernels_connect.hip - the two variable-length expansions of the VCM camera pass, flattened for the GPU:
+//
+//   vertex connections  vcm_connect_to_light_path (vcm_shared.hxx:765-803): camera vertex x every vertex of the light
+//       path of the SAME pixel. k_expand_pairs turns (camera vertex, light path) into a dense list of
+//       (camera vertex, light vertex) pairs (wave prefix sum + one atomic per wave), k_connect_pairs evaluates one
+//       pair per lane (2 BSDF evaluations + 2 reverse pdfs + one transmittance ray), so lanes do equal work
+//       although light path lengths are geometric-ish (max over a wave ~5x the mean).
+//   photon merge        VCMSpatialGridData::gather (vcm_shared.hxx:886-924): camera vertex x 8 hash cells x photons.
+//       k_merge gives each (camera vertex, cell) its own lane: 8x more independent photon streams in flight per
+//       vertex, partial sums folded with three xor-shuffles.
+// Both accumulate straight into the film sums (float atomics). Roofline: HBM/L2 latency + fp32 VALU, no MFMA.
+#include "kernels.h"
+#include "dev_vcm.h"
+
+namespace etxd {
+
+#define ETX_WAVE_LOOP(COUNT)                                                          \
+  const uint32_t lane_ = threadIdx.x & 63u;                                            \
+  const uint32_t stride_ = gridDim.x * blockDim.x;                                     \
+  for (uint32_t base_ = blockIdx.x * blockDim.x + threadIdx.x - lane_; base_ < (COUNT); base_ += stride_)
+
+static uint32_t grid_for(uint32_t capacity) {
+  return min(kPersistentBlocks, (capacity + kBlockSize - 1) / kBlockSize);
+}
+
+ETX_DEV bool material_is_diffuse(const DScene& scene, uint32_t tri) {
+  return scene.materials[scene.triangles[tri].material_index].cls == ETX_MAT_DIFFUSE;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// (camera vertex, light path) -> pairs
+__global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmParams it) {
+  const uint32_t count = p.counters[kCntCameraVertices];
+  ETX_WAVE_LOOP(count) {
+    const uint32_t i = base_ + lane_;
+    uint32_t head = kInvalid, k = 0;
+    if (i < count) {
+      head = p.light_path_head[__float_as_uint(p.cv.mis_pixel[i].w)];
+      // the head vertex knows its index in the path (store_light_vertex), so the path length needs no extra table
+      k = (head == kInvalid) ? 0u : ((__float_as_uint(p.lv.bc_len_med(head).z) >> 16u) + 1u);
+    }
+    // wave exclusive prefix sum of k
+    uint32_t incl = k;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      uint32_t t = __shfl_up(incl, d);
+      if (lane_ >= d)
+        incl += t;
+    }
+    uint32_t total = __shfl(incl, 63);
+    uint32_t base = 0;
+    if (lane_ == 0)
+      base = total ? atomicAdd(p.counters + kCntPairs, total) : 0u;
+    base = __shfl(base, 0) + incl - k;
+    if (base + k > p.pair_capacity) {
+      if (k)
+        atomicOr(p.counters + kCntOverflow, kOverflowPairs);
+      continue;
+    }
+    for (uint32_t vi = head; vi != kInvalid; vi = p.lv.next(vi))
+      p.pairs[base++] = make_uint2(i, vi);
+  }
+}
+
+template <bool kDiffuseOnly>
+__global__ __launch_bounds__(kBlockSize) void k_connect_pairs(Pipeline p, VcmParams it) {
+  __shared__ int32_t s_stack[kStackDepth * kBlockSize];
+  const DScene& scene = *p.scene;
+  const uint32_t count = min(p.counters[kCntPairs], p.pair_capacity);
+  TraceCtx tc = {&scene, {s_stack + threadIdx.x, kBlockSize}, 0u};
+  uint32_t shadow_rays = 0;
+  ETX_WAVE_LOOP(count) {
+    const uint32_t i = base_ + lane_;
+    if (i >= count)
+      continue;
+    const uint2 pair = p.pairs[i];
+    LightVertex lv = load_light_vertex(p.lv, pair.y);
+    const uint32_t cam_tri = __float_as_uint(p.cv.hit[pair.x].w);
+    bool all_diffuse = ((cam_tri == kInvalid) || material_is_diffuse(scene, cam_tri)) && (lv.is_medium() || material_is_diffuse(scene, lv.tri));
+    if (all_diffuse != kDiffuseOnly)
+      continue;
+    CameraVertex cv = load_camera_vertex(p, scene, pair.x);
+    const uint32_t target_path_length = cv.st.depth + lv.index_in_path + 2u;  // vcm_shared.hxx:774
+    if ((target_path_length < scene.min_path_length) || (target_path_length > scene.max_path_length))
+      continue;
+    // the reference evaluates every connection of a vertex with the path's sampler; decorrelate per pair
+    cv.st.sampler.seed = Sampler::random_seed(cv.st.sampler.seed, pair.y);
+    tc.alpha_seed = cv.st.sampler.seed ^ 0x27d4eb2fu;
+    f3 target_position, value;
+    if (vcm_connect_to_light_vertex<kDiffuseOnly>(scene, cv.st, lv, it, cv.at_medium, &cv.isect, cv.medium_pos, cv.st.sampler, target_position, value) == false)
+      continue;
+    f3 p0 = cv.medium_pos;
+    if (cv.at_medium == false)
+      p0 = shading_pos(scene, scene.triangles[cv.isect.tri], cv.isect.bc, normalize(target_position - cv.isect.pos));
+    f3 tr = trace_transmittance(tc, p0, cv.at_medium ? lv.pos : target_position, cv.st.medium);
+    shadow_rays++;
+    if (is_zero(tr))
+      continue;
+    atomic_add_f3(p.camera_sum + film_index(it, cv.st.id), tr * value);
+  }
+  if (shadow_rays)
+    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatRaysShadow), (unsigned long long)shadow_rays);
+}
+
+void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items) {
+  max_items = min(max_items, p.capacity);
+  const uint32_t blocks = max(1u, grid_for(max_items));
+  const uint32_t pair_blocks = max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 8ull, uint64_t(p.pair_capacity)))));
+  hipLaunchKernelGGL(k_expand_pairs, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
+  hipLaunchKernelGGL(k_connect_pairs<true>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
+  if (generic_materials)
+    hipLaunchKernelGGL(k_connect_pairs<false>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// VCMSpatialGridData::gather / gather_index, vcm_shared.hxx:829-924 : one lane per (camera vertex, hash cell)
+ETX_DEV bool merge_cell_range(const Pipeline& p, const GridParams& g, const f3& pos, uint32_t c, uint32_t& range_begin, uint32_t& range_end) {
+  if ((pos.x < g.bbox_min.x) || (pos.y < g.bbox_min.y) || (pos.z < g.bbox_min.z) || (pos.x > g.bbox_max.x) || (pos.y > g.bbox_max.y) || (pos.z > g.bbox_max.z))
+    return false;  // BoundingBox::contains, vcm_shared.hxx:891-893
+  f3 m = (pos - g.bbox_min) / g.cell_size;
+  f3 mf = {floorf(m.x), floorf(m.y), floorf(m.z)};
+  f3 md = m - mf;
+  int32_t cx = int32_t(mf.x) + ((c & 1u) ? ((md.x < 0.5f) ? -1 : +1) : 0);
+  int32_t cy = int32_t(mf.y) + ((c & 2u) ? ((md.y < 0.5f) ? -1 : +1) : 0);
+  int32_t cz = int32_t(mf.z) + ((c & 4u) ? ((md.z < 0.5f) ? -1 : +1) : 0);
+  // two neighbour offsets can hash to the same cell: the reference then visits that cell twice, so does this kernel
+  const uint32_t cell = grid_cell_index(cx, cy, cz, g.hash_mask);
+  range_begin = (cell == 0u) ? 0u : p.grid.cell_ends[cell - 1u];
+  range_end = p.grid.cell_ends[cell];
+  return true;
+}
+
+// Diffuse camera vertices (the common case): everything the loop needs comes from five float4 of the vertex record.
+__global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmParams it) {
+  const DScene& scene = *p.scene;
+  const uint32_t count = p.counters[kCntCameraVertices];
+  const GridParams g = *p.grid_params;
+  if ((g.valid == 0u) || (g.photon_count == 0u))
+    return;
+  const uint32_t items = count * 8u;
+  const bool use_mis = opt_enable_mis(it);
+  const bool use_epan = it.kernel == ETX_VCM_KERNEL_EPANECHNIKOV;
+  const uint32_t max_path_length = scene.max_path_length;
+  unsigned long long examined = 0, merged_count = 0;
+  ETX_WAVE_LOOP(items) {
+    const uint32_t item = base_ + lane_;
+    const uint32_t vertex = item >> 3u, c = item & 7u;
+    f3 merged = mk3(0.0f);
+    uint32_t pixel = 0;
+    if (item < items) {
+      const float4 pi = p.cv.pos_info[vertex];
+      const uint32_t info = __float_as_uint(pi.w);
+      const uint32_t depth = info >> 8u;
+      uint32_t range_begin = 0, range_end = 0;
+      const f3 pos = {pi.x, pi.y, pi.z};
+      if ((info & kCvDiffuse) && (depth + 1u <= max_path_length) && merge_cell_range(p, g, pos, c, range_begin, range_end) && (range_begin < range_end)) {
+        const float4 nv = p.cv.nrm_dvm[vertex];
+        const float4 wv = p.cv.wi_medium[vertex];
+        const float4 fv = p.cv.fthr_dvcm[vertex];
+        pixel = __float_as_uint(p.cv.mis_pixel[vertex].w);
+        const f3 nrm = {nv.x, nv.y, nv.z}, w_i = {wv.x, wv.y, wv.z}, fthr = {fv.x, fv.y, fv.z};
+        const float d_vm = nv.w, w_camera_base = fv.w * it.vc_weight;
+        const f3 n_front = dot(nrm, w_i) < 0.0f ? nrm : -nrm;  // get_normal_frame, bsdf.hxx:37-40
+        const uint32_t max_photon_length = max_path_length - depth - 1u;
+        examined += range_end - range_begin;
+        for (uint32_t j0 = range_begin; j0 < range_end; j0 += 4u) {
+          // four independent position loads in flight per lane (the loop is latency bound)
+          float4 pl[4];
+#pragma unroll
+          for (uint32_t k = 0; k < 4u; ++k)
+            pl[k] = p.grid.pos_len[min(j0 + k, range_end - 1u)];
+#pragma unroll
+          for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t j = j0 + k;
+            const f3 d = f3{pl[k].x, pl[k].y, pl[k].z} - pos;
+            const float distance_squared = dot(d, d);
+            if ((j >= range_end) || (distance_squared > g.radius_squared) || (__float_as_uint(pl[k].w) > max_photon_length))
+              continue;
+            const float4 nd = p.grid.nrm_dvcm(j);
+            if (dot(nrm, f3{nd.x, nd.y, nd.z}) <= kEpsilon)
+              continue;
+            const float4 wd = p.grid.win_dvm(j);
+            const f3 wi = {wd.x, wd.y, wd.z};
+            const float cos_o = -dot(n_front, wi);  // DiffuseBSDF::evaluate(-wi), bsdf_various.hxx:97-106
+            if (cos_o <= kEpsilon)
+              continue;
+            const float pdf = kInvPi * cos_o;
+            // reverse_pdf: roles swapped, w_i' = wi, w_o' = -w_i (scene_bsdf.hxx:82-92 + bsdf_various.hxx:113-120)
+            const f3 n_rev = dot(nrm, wi) < 0.0f ? nrm : -nrm;
+            const float n_dot_o = -dot(n_rev, w_i);
+            const float rev_pdf = (n_dot_o <= kEpsilon) ? 0.0f : kInvPi * n_dot_o;
+            const float w_light = nd.w * it.vc_weight + wd.w * pdf;
+            const float w_camera = w_camera_base + d_vm * rev_pdf;
+            const float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;
+            const float kernel_weight = use_epan ? fmaxf(2.0f * (1.0f - distance_squared * g.inv_radius_squared), 0.0f) : 1.0f;
+            const float4 lt = p.grid.thr(j);
+            merged += (fthr * f3{lt.x, lt.y, lt.z}) * (kernel_weight * weight);
+            merged_count++;
+          }
+        }
+      }
+    }
+    // fold the 8 cells of a vertex (lanes 8k .. 8k+7); all lanes of the wave take part
+#pragma unroll
+    for (uint32_t d = 1; d < 8; d <<= 1) {
+      merged.x += __shfl_xor(merged.x, d);
+      merged.y += __shfl_xor(merged.y, d);
+      merged.z += __shfl_xor(merged.z, d);
+      pixel = max(pixel, uint32_t(__shfl_xor(int(pixel), d)));
+    }
+    if (((lane_ & 7u) == 0u) && ((merged.x != 0.0f) || (merged.y != 0.0f) || (merged.z != 0.0f)))
+      atomic_add_f3(p.camera_sum + film_index(it, pixel), merged * it.vm_normalization);
+  }
+  if (examined) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsExamined), examined);
+    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsMerged), merged_count);
+  }
+}
+
+// Every other connectible material: generic BSDF evaluation per accepted photon (stochastic for rough conductors).
+__global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmParams it) {
+  const DScene& scene = *p.scene;
+  const uint32_t count = p.counters[kCntCameraVertices];
+  const GridParams g = *p.grid_params;
+  if ((g.valid == 0u) || (g.photon_count == 0u))
+    return;
+  const uint32_t items = count * 8u;
+  const bool use_mis = opt_enable_mis(it);
+  const bool use_epan = it.kernel == ETX_VCM_KERNEL_EPANECHNIKOV;
+  unsigned long long examined = 0, merged_count = 0;
+  ETX_WAVE_LOOP(items) {
+    const uint32_t item = base_ + lane_;
+    const uint32_t vertex = item >> 3u, c = item & 7u;
+    f3 merged = mk3(0.0f);
+    uint32_t pixel = 0;
+    if (item < items) {
+      const uint32_t info = __float_as_uint(p.cv.pos_info[vertex].w);
+      if ((info & (kCvDiffuse | kCvMedium)) == 0u) {
+        CameraVertex cv = load_camera_vertex(p, scene, vertex);
+        const Isect& isect = cv.isect;
+        uint32_t range_begin = 0, range_end = 0;
+        if ((cv.st.depth + 1u <= scene.max_path_length) && merge_cell_range(p, g, isect.pos, c, range_begin, range_end)) {
+          pixel = cv.st.id;
+          const etx_abi_material& mat = scene.materials[isect.material];
+          const BsdfData camera_data = make_bsdf_data(isect, isect.w_i, cv.st.medium, kPathCamera);
+          const float w_camera_base = cv.st.d_vcm * it.vc_weight;
+          cv.st.sampler.seed = Sampler::random_seed(cv.st.sampler.seed, c);
+          for (uint32_t j = range_begin; j < range_end; ++j) {
+            examined++;
+            const float4 pl = p.grid.pos_len[j];
+            const f3 d = f3{pl.x, pl.y, pl.z} - isect.pos;
+            const float distance_squared = dot(d, d);
+            if ((distance_squared > g.radius_squared) || (__float_as_uint(pl.w) + cv.st.depth + 1u > scene.max_path_length))
+              continue;
+            const float4 nd = p.grid.nrm_dvcm(j);
+            if (dot(isect.nrm, f3{nd.x, nd.y, nd.z}) <= kEpsilon)
+              continue;
+            const float4 wd = p.grid.win_dvm(j);
+            const f3 wi = {wd.x, wd.y, wd.z};
+            BsdfEval camera_bsdf = bsdf_evaluate(scene, camera_data, -wi, mat, cv.st.sampler);
+            if (camera_bsdf.valid() == false)
+              continue;
+            const float rev_pdf = bsdf_reverse_pdf(scene, camera_data, -wi, mat);
+            const float w_light = nd.w * it.vc_weight + wd.w * camera_bsdf.pdf;
+            const float w_camera = w_camera_base + cv.st.d_vm * rev_pdf;
+            const float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;
+            const float kernel_weight = use_epan ? fmaxf(2.0f * (1.0f - distance_squared * g.inv_radius_squared), 0.0f) : 1.0f;
+            const float4 lt = p.grid.thr(j);
+            merged += (camera_bsdf.func * cv.st.throughput * f3{lt.x, lt.y, lt.z}) * (kernel_weight * weight);
+            merged_count++;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (uint32_t d = 1; d < 8; d <<= 1) {
+      merged.x += __shfl_xor(merged.x, d);
+      merged.y += __shfl_xor(merged.y, d);
+      merged.z += __shfl_xor(merged.z, d);
+      pixel = max(pixel, uint32_t(__shfl_xor(int(pixel), d)));
+    }
+    if (((lane_ & 7u) == 0u) && ((merged.x != 0.0f) || (merged.y != 0.0f) || (merged.z != 0.0f)))
+      atomic_add_f3(p.camera_sum + film_index(it, pixel), merged * it.vm_normalization);
+  }
+  if (examined) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsExamined), examined);
+    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsMerged), merged_count);
+  }
+}
+
+void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items) {
+  const uint32_t blocks = max(1u, grid_for(uint32_t(min(uint64_t(min(max_items, p.capacity)) * 8ull, 0xffffff00ull))));
+  hipLaunchKernelGGL(k_merge_diffuse, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
+  if (generic_materials)
+    hipLaunchKernelGGL(k_merge_generic, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
+}
+
+}  // namespace etxd

@@ -22,6 +22,37 @@ ETX_DEV uint32_t next_power_of_two(uint32_t v) {  // math.hxx:1012-1021
   return v + 1u;
 }
 
+ETX_DEV uint32_t float_to_ordered(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// bounding box of the mergeable light vertices (vcm_shared.cxx:66-80): wave shuffles, then 6 atomics per wave
+__global__ __launch_bounds__(kBlockSize) void k_grid_bbox(Pipeline p) {
+  const uint32_t n = min(p.counters[kCntLightVertices], p.lv.capacity);
+  f3 lo = mk3(kMaxFloat), hi = mk3(-kMaxFloat);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (__float_as_uint(p.lv.nrm_tri(i).w) == kInvalid)
+      continue;
+    float4 pd = p.lv.pos_dvcm(i);
+    lo = fmin3(lo, f3{pd.x, pd.y, pd.z});
+    hi = fmax3(hi, f3{pd.x, pd.y, pd.z});
+  }
+#pragma unroll
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    lo.x = fminf(lo.x, __shfl_xor(lo.x, d)), lo.y = fminf(lo.y, __shfl_xor(lo.y, d)), lo.z = fminf(lo.z, __shfl_xor(lo.z, d));
+    hi.x = fmaxf(hi.x, __shfl_xor(hi.x, d)), hi.y = fmaxf(hi.y, __shfl_xor(hi.y, d)), hi.z = fmaxf(hi.z, __shfl_xor(hi.z, d));
+  }
+  if (((threadIdx.x & 63u) == 0u) && (lo.x <= hi.x)) {
+    atomicMin(p.counters + kCntBboxMin + 0, float_to_ordered(lo.x));
+    atomicMin(p.counters + kCntBboxMin + 1, float_to_ordered(lo.y));
+    atomicMin(p.counters + kCntBboxMin + 2, float_to_ordered(lo.z));
+    atomicMax(p.counters + kCntBboxMax + 0, float_to_ordered(hi.x));
+    atomicMax(p.counters + kCntBboxMax + 1, float_to_ordered(hi.y));
+    atomicMax(p.counters + kCntBboxMax + 2, float_to_ordered(hi.z));
+  }
+}
+
 __global__ void k_grid_setup(Pipeline p, VcmParams it) {
   if ((blockIdx.x != 0) || (threadIdx.x != 0))
     return;
@@ -54,10 +85,10 @@ __global__ __launch_bounds__(kBlockSize) void k_grid_count(Pipeline p) {
     return;
   const uint32_t n = min(p.counters[kCntLightVertices], p.lv.capacity);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float4 nt = p.lv.nrm_tri[i];
+    float4 nt = p.lv.nrm_tri(i);
     if (__float_as_uint(nt.w) == kInvalid)
       continue;  // medium vertices are never merged (vcm_shared.cxx:100-102)
-    float4 pd = p.lv.pos_dvcm[i];
+    float4 pd = p.lv.pos_dvcm(i);
     atomicAdd(p.grid.cell_ends + grid_position_to_index(g, f3{pd.x, pd.y, pd.z}), 1u);
   }
 }
@@ -147,24 +178,25 @@ __global__ __launch_bounds__(kBlockSize) void k_grid_scatter(Pipeline p) {
     return;
   const uint32_t n = min(p.counters[kCntLightVertices], p.lv.capacity);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float4 nt = p.lv.nrm_tri[i];
+    float4 nt = p.lv.nrm_tri(i);
     if (__float_as_uint(nt.w) == kInvalid)
       continue;
-    float4 pd = p.lv.pos_dvcm[i];
-    float4 wd = p.lv.wi_dvc[i];
-    float4 td = p.lv.thr_dvm[i];
-    float4 bl = p.lv.bc_len_med[i];
+    float4 pd = p.lv.pos_dvcm(i);
+    float4 wd = p.lv.wi_dvc(i);
+    float4 td = p.lv.thr_dvm(i);
+    float4 bl = p.lv.bc_len_med(i);
     uint32_t cell = grid_position_to_index(g, f3{pd.x, pd.y, pd.z});
     uint32_t dst = atomicAdd(p.grid.cell_ends + cell, 1u);
     p.grid.pos_len[dst] = make_float4(pd.x, pd.y, pd.z, __uint_as_float(__float_as_uint(bl.z) & 0xffffu));
-    p.grid.nrm_dvcm[dst] = make_float4(nt.x, nt.y, nt.z, pd.w);
-    p.grid.win_dvm[dst] = make_float4(wd.x, wd.y, wd.z, td.w);
-    p.grid.thr[dst] = make_float4(td.x, td.y, td.z, 0.0f);  // throughput / sampling_pdf (= 1 in RGB mode)
+    p.grid.nrm_dvcm(dst) = make_float4(nt.x, nt.y, nt.z, pd.w);
+    p.grid.win_dvm(dst) = make_float4(wd.x, wd.y, wd.z, td.w);
+    p.grid.thr(dst) = make_float4(td.x, td.y, td.z, 0.0f);  // throughput / sampling_pdf (= 1 in RGB mode)
   }
 }
 
 void launch_grid_build(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
   const uint32_t blocks = min(kPersistentBlocks, (p.capacity + kBlockSize - 1) / kBlockSize);
+  hipLaunchKernelGGL(k_grid_bbox, dim3(kPersistentBlocks), dim3(kBlockSize), 0, stream, p);
   hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(64), 0, stream, p, it);
   hipLaunchKernelGGL(k_grid_clear, dim3(kPersistentBlocks), dim3(kBlockSize), 0, stream, p);
   hipLaunchKernelGGL(k_grid_count, dim3(kPersistentBlocks), dim3(kBlockSize), 0, stream, p);

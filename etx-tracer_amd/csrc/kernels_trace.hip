@@ -19,6 +19,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene* __re
     // housekeeping for the shade kernel that follows: its output counter and the camera vertex pool start empty
     counters[active_counter ^ 1u] = 0u;
     counters[kCntCameraVertices] = 0u;
+    counters[kCntPairs] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
   }
   const uint32_t lane = threadIdx.x & 63u;
@@ -36,8 +37,8 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene* __re
   }
 }
 
-void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter) {
-  uint32_t blocks = min(kPersistentBlocks, (p.capacity + kBlockSize - 1) / kBlockSize);
+void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items) {
+  uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.capacity, max_items) + kBlockSize - 1) / kBlockSize));
   hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u);
 }
 

@@ -95,26 +95,18 @@ ETX_DEV void store_light_vertex(const Pipeline& p, const VcmParams& it, const Pa
     atomicOr(p.counters + kCntOverflow, kOverflowLightVertices);
     return;
   }
-  p.lv.pos_dvcm[idx] = mk4(pos, st.d_vcm);
-  p.lv.wi_dvc[idx] = mk4(st.ray_d, st.d_vc);
-  p.lv.thr_dvm[idx] = mk4(st.throughput, st.d_vm);
-  p.lv.nrm_tri[idx] = mk4(nrm, __uint_as_float(tri));
+  p.lv.pos_dvcm(idx) = mk4(pos, st.d_vcm);
+  p.lv.wi_dvc(idx) = mk4(st.ray_d, st.d_vc);
+  p.lv.thr_dvm(idx) = mk4(st.throughput, st.d_vm);
+  p.lv.nrm_tri(idx) = mk4(nrm, __uint_as_float(tri));
   // vcm_connect_to_light_path (vcm_shared.hxx:773-778) derives the connection length from the vertex' INDEX in its
   // light path (delta bounces advance the depth without storing a vertex), the merge uses path_length: keep both.
   const uint32_t prev = p.light_path_head[st.id];
-  const uint32_t index_in_path = (prev == kInvalid) ? 0u : ((__float_as_uint(p.lv.bc_len_med[prev].z) >> 16u) + 1u);
-  p.lv.bc_len_med[idx] = make_float4(bc_u, bc_v, __uint_as_float((index_in_path << 16u) | (st.depth & 0xffffu)), __uint_as_float(st.medium));
-  p.lv.next[idx] = prev;
+  const uint32_t index_in_path = (prev == kInvalid) ? 0u : ((__float_as_uint(p.lv.bc_len_med(prev).z) >> 16u) + 1u);
+  p.lv.bc_len_med(idx) = make_float4(bc_u, bc_v, __uint_as_float((index_in_path << 16u) | (st.depth & 0xffffu)), __uint_as_float(st.medium));
+  p.lv.next(idx) = prev;
   p.light_path_head[st.id] = idx;
-  if (keep_bbox) {
-    // bounding box of mergeable vertices (vcm_shared.cxx:66-80), ordered-int float atomics
-    atomicMin(p.counters + kCntBboxMin + 0, float_to_ordered(pos.x));
-    atomicMin(p.counters + kCntBboxMin + 1, float_to_ordered(pos.y));
-    atomicMin(p.counters + kCntBboxMin + 2, float_to_ordered(pos.z));
-    atomicMax(p.counters + kCntBboxMax + 0, float_to_ordered(pos.x));
-    atomicMax(p.counters + kCntBboxMax + 1, float_to_ordered(pos.y));
-    atomicMax(p.counters + kCntBboxMax + 2, float_to_ordered(pos.z));
-  }
+  (void)keep_bbox;  // the photon bounding box is reduced by k_grid_bbox (kernels_grid.hip)
 }
 
 // film.cxx:147-171 atomic_add_light_iteration (pixel_size == 1) after vcm_cpu.cxx:148-153
@@ -246,8 +238,8 @@ __global__ __launch_bounds__(kBlockSize) void k_light_shade(Pipeline p, VcmParam
     atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatSplats), (unsigned long long)splats);
 }
 
-void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set) {
-  hipLaunchKernelGGL(k_light_shade, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it, in_set);
+void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
+  hipLaunchKernelGGL(k_light_shade, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -289,18 +281,26 @@ void launch_camera_generate(hipStream_t stream, const Pipeline& p, const VcmPara
   hipLaunchKernelGGL(k_camera_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
 }
 
-ETX_DEV uint32_t film_index(const VcmParams& it, uint32_t pixel_id) {  // film.cxx:189 y flip
-  uint32_t px = pixel_id % it.film_w, py = pixel_id / it.film_w;
-  return px + (it.film_h - 1u - py) * it.film_w;
-}
 
-ETX_DEV void store_camera_vertex(const Pipeline& p, const PathState& st, const float4& hit_or_pos, uint32_t seed) {
+ETX_DEV void store_camera_vertex(const Pipeline& p, const DScene& scene, const PathState& st, const float4& hit_or_pos, uint32_t seed, const Isect* isect) {
   uint32_t idx = atomicAdd(p.counters + kCntCameraVertices, 1u);
   p.cv.hit[idx] = hit_or_pos;
   p.cv.wi_medium[idx] = mk4(st.ray_d, __uint_as_float(st.medium));
   p.cv.thr_depth[idx] = mk4(st.throughput, __uint_as_float(st.depth));
   p.cv.mis_pixel[idx] = make_float4(st.d_vcm, st.d_vc, st.d_vm, __uint_as_float(st.id));
   p.cv.seed[idx] = seed;
+  if (isect == nullptr) {
+    p.cv.pos_info[idx] = make_float4(hit_or_pos.x, hit_or_pos.y, hit_or_pos.z, __uint_as_float((st.depth << 8u) | kCvMedium));
+    return;
+  }
+  const etx_abi_material& mat = scene.materials[isect->material];
+  const bool diffuse = mat.cls == ETX_MAT_DIFFUSE;
+  f3 fthr = st.throughput;
+  if (diffuse)
+    fthr = fthr * apply_image(scene, mat.scattering, isect->tex, nullptr) * kInvPi;  // DiffuseBSDF func (bsdf_various.hxx:60-64) x t_camera
+  p.cv.pos_info[idx] = mk4(isect->pos, __uint_as_float((st.depth << 8u) | (diffuse ? kCvDiffuse : 0u)));
+  p.cv.nrm_dvm[idx] = mk4(isect->nrm, st.d_vm);
+  p.cv.fthr_dvcm[idx] = mk4(fthr, st.d_vcm);
 }
 
 // vcm_camera_step, vcm_shared.hxx:927-1079, without the vertex connections and the merge: connectible vertices are
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmPara
           if (opt_connect_vertices(it)) {
             Sampler derived;
             derived.init(st.sampler.seed, 0x51ed270bu);
-            store_camera_vertex(p, st, mk4(ms.pos, __uint_as_float(kInvalid)), derived.seed);
+            store_camera_vertex(p, scene, st, mk4(ms.pos, __uint_as_float(kInvalid)), derived.seed, nullptr);
           }
         }
         st.d_vc = (1.0f / pdf_fwd) * (st.d_vc * pdf_rev + st.d_vcm);
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmPara
           if (opt_connect_vertices(it) || (opt_merge_vertices(it) && (st.depth + 1 <= scene.max_path_length))) {
             Sampler derived;
             derived.init(st.sampler.seed, 0x51ed270bu);
-            store_camera_vertex(p, st, h, derived.seed);
+            store_camera_vertex(p, scene, st, h, derived.seed, &isect);
           }
           st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
           gathered += vcm_connect_to_light(tc, it, false, &isect, mk3(0.0f), st);
@@ -416,160 +416,8 @@ __global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmPara
   }
 }
 
-void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set) {
-  hipLaunchKernelGGL(k_camera_shade, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it, in_set);
-}
-
-struct CameraVertex {
-  PathState st;   // throughput, d_vcm/d_vc/d_vm, depth, medium, ray_d (= w_i), id (pixel)
-  Isect isect;
-  f3 medium_pos;
-  bool at_medium;
-};
-
-ETX_DEV CameraVertex load_camera_vertex(const Pipeline& p, const DScene& scene, uint32_t i) {
-  CameraVertex cv;
-  float4 h = p.cv.hit[i], w = p.cv.wi_medium[i], t = p.cv.thr_depth[i], m = p.cv.mis_pixel[i];
-  cv.st.ray_d = {w.x, w.y, w.z};
-  cv.st.medium = __float_as_uint(w.w);
-  cv.st.throughput = {t.x, t.y, t.z};
-  cv.st.depth = __float_as_uint(t.w);
-  cv.st.d_vcm = m.x, cv.st.d_vc = m.y, cv.st.d_vm = m.z;
-  cv.st.id = __float_as_uint(m.w);
-  cv.st.sampler.seed = p.cv.seed[i];
-  cv.st.sampler.fixed_u = cv.st.sampler.fixed_v = cv.st.sampler.fixed_w = 0.0f;
-  cv.st.eta = 1.0f, cv.st.path_distance = 0.0f, cv.st.flags = 0u;
-  cv.st.ray_o = mk3(0.0f), cv.st.ray_tmin = 0.0f, cv.st.ray_tmax = 0.0f;
-  uint32_t tri = __float_as_uint(h.w);
-  cv.at_medium = tri == kInvalid;
-  cv.medium_pos = {h.x, h.y, h.z};
-  if (cv.at_medium == false)
-    cv.isect = make_intersection(scene, cv.st.ray_d, h.x, h.y, h.z, tri);
-  return cv;
-}
-
-// vcm_connect_to_light_path, vcm_shared.hxx:765-803: camera vertex x every vertex of the SAME pixel's light path
-__global__ __launch_bounds__(kBlockSize) void k_connect(Pipeline p, VcmParams it) {
-  __shared__ int32_t s_stack[kStackDepth * kBlockSize];
-  const DScene& scene = *p.scene;
-  const uint32_t count = opt_connect_vertices(it) ? p.counters[kCntCameraVertices] : 0u;
-  TraceCtx tc = {&scene, {s_stack + threadIdx.x, kBlockSize}, 0u};
-  uint32_t shadow_rays = 0;
-  ETX_WAVE_LOOP(count) {
-    const uint32_t i = base_ + lane_;
-    if (i >= count)
-      continue;
-    CameraVertex cv = load_camera_vertex(p, scene, i);
-    tc.alpha_seed = cv.st.sampler.seed ^ 0x27d4eb2fu;
-    f3 result = mk3(0.0f);
-    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatCameraVertices), 1ull);
-    for (uint32_t vi = p.light_path_head[cv.st.id]; vi != kInvalid; vi = p.lv.next[vi]) {
-      LightVertex lv = load_light_vertex(p.lv, vi);
-#if defined(ETX_HIP_DEBUG_COUNTERS)
-      atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kDbgBase + 0), 1ull);
-#endif
-      const uint32_t target_path_length = cv.st.depth + lv.index_in_path + 2u;  // vcm_shared.hxx:774
-      if ((target_path_length < scene.min_path_length) || (target_path_length > scene.max_path_length))
-        continue;
-      f3 target_position, value;
-      if (vcm_connect_to_light_vertex(scene, cv.st, lv, it, cv.at_medium, &cv.isect, cv.medium_pos, cv.st.sampler, target_position, value) == false)
-        continue;
-      f3 p0 = cv.medium_pos;
-      if (cv.at_medium == false)
-        p0 = shading_pos(scene, scene.triangles[cv.isect.tri], cv.isect.bc, normalize(target_position - cv.isect.pos));
-      f3 tr = trace_transmittance(tc, p0, cv.at_medium ? lv.pos : target_position, cv.st.medium);
-      shadow_rays++;
-      if (is_zero(tr) == false)
-        result += tr * value;
-    }
-    if ((result.x != 0.0f) || (result.y != 0.0f) || (result.z != 0.0f))
-      atomic_add_f3(p.camera_sum + film_index(it, cv.st.id), result);
-  }
-  if (shadow_rays)
-    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatRaysShadow), (unsigned long long)shadow_rays);
-}
-
-void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
-  hipLaunchKernelGGL(k_connect, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
-}
-
-// VCMSpatialGridData::gather / gather_index, vcm_shared.hxx:829-924
-__global__ __launch_bounds__(kBlockSize) void k_merge(Pipeline p, VcmParams it) {
-  const DScene& scene = *p.scene;
-  const uint32_t count = p.counters[kCntCameraVertices];
-  const GridParams g = *p.grid_params;
-  if ((opt_merge_vertices(it) == false) || (g.valid == 0u) || (g.photon_count == 0u))
-    return;
-  unsigned long long examined = 0, merged_count = 0;
-  ETX_WAVE_LOOP(count) {
-    const uint32_t i = base_ + lane_;
-    if (i >= count)
-      continue;
-    CameraVertex cv = load_camera_vertex(p, scene, i);
-    if (cv.at_medium || (cv.st.depth + 1u > scene.max_path_length))
-      continue;
-    const Isect& isect = cv.isect;
-    if ((isect.pos.x < g.bbox_min.x) || (isect.pos.y < g.bbox_min.y) || (isect.pos.z < g.bbox_min.z) || (isect.pos.x > g.bbox_max.x) || (isect.pos.y > g.bbox_max.y) ||
-        (isect.pos.z > g.bbox_max.z))
-      continue;
-    f3 m = (isect.pos - g.bbox_min) / g.cell_size;
-    f3 mf = {floorf(m.x), floorf(m.y), floorf(m.z)};
-    f3 md = m - mf;
-    int32_t acx = int32_t(mf.x), acy = int32_t(mf.y), acz = int32_t(mf.z);
-    int32_t bcx = acx + ((md.x < 0.5f) ? -1 : +1);
-    int32_t bcy = acy + ((md.y < 0.5f) ? -1 : +1);
-    int32_t bcz = acz + ((md.z < 0.5f) ? -1 : +1);
-
-    const etx_abi_material& mat = scene.materials[isect.material];
-    BsdfData camera_data = make_bsdf_data(isect, isect.w_i, cv.st.medium, kPathCamera);
-    const f3 t_camera = cv.st.throughput;  // / sampling_pdf() == 1 in RGB mode
-    const float w_camera_base = cv.st.d_vcm * it.vc_weight;
-    const bool use_mis = opt_enable_mis(it);
-    const bool use_epan = it.kernel == ETX_VCM_KERNEL_EPANECHNIKOV;
-    f3 merged = mk3(0.0f);
-#pragma unroll 1
-    for (uint32_t c = 0; c < 8u; ++c) {
-      uint32_t cell = grid_cell_index((c & 1u) ? bcx : acx, (c & 2u) ? bcy : acy, (c & 4u) ? bcz : acz, g.hash_mask);
-      uint32_t range_begin = (cell == 0u) ? 0u : p.grid.cell_ends[cell - 1u];
-      uint32_t range_end = p.grid.cell_ends[cell];
-      for (uint32_t j = range_begin; j < range_end; ++j) {
-        examined++;
-        float4 pl = p.grid.pos_len[j];
-        f3 d = f3{pl.x, pl.y, pl.z} - isect.pos;
-        float distance_squared = dot(d, d);
-        if ((distance_squared > g.radius_squared) || (__float_as_uint(pl.w) + cv.st.depth + 1u > scene.max_path_length))
-          continue;
-        float4 nd = p.grid.nrm_dvcm[j];
-        if (dot(isect.nrm, f3{nd.x, nd.y, nd.z}) <= kEpsilon)
-          continue;
-        float4 wd = p.grid.win_dvm[j];
-        const f3 wi = {wd.x, wd.y, wd.z};
-        BsdfEval camera_bsdf = bsdf_evaluate(scene, camera_data, -wi, mat, cv.st.sampler);
-        if (camera_bsdf.valid() == false)
-          continue;
-        float camera_rev_pdf = bsdf_reverse_pdf(scene, camera_data, -wi, mat);
-        float w_light = nd.w * it.vc_weight + wd.w * camera_bsdf.pdf;
-        float w_camera = w_camera_base + cv.st.d_vm * camera_rev_pdf;
-        float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;
-        float kernel_weight = use_epan ? fmaxf(2.0f * (1.0f - distance_squared * g.inv_radius_squared), 0.0f) : 1.0f;
-        f3 c_value = camera_bsdf.func * t_camera;
-        float4 lt = p.grid.thr[j];
-        merged += (c_value * f3{lt.x, lt.y, lt.z}) * (kernel_weight * weight);
-        merged_count++;
-      }
-    }
-    merged *= it.vm_normalization;
-    if ((merged.x != 0.0f) || (merged.y != 0.0f) || (merged.z != 0.0f))
-      atomic_add_f3(p.camera_sum + film_index(it, cv.st.id), merged);
-  }
-  if (examined) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsExamined), examined);
-    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsMerged), merged_count);
-  }
-}
-
-void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
-  hipLaunchKernelGGL(k_merge, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
+void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
+  hipLaunchKernelGGL(k_camera_shade, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
 }
 
 #if defined(ETX_HIP_DEBUG_COUNTERS)
@@ -578,7 +426,7 @@ __global__ void k_debug_lists(Pipeline p) {
   if (i >= p.capacity)
     return;
   uint32_t len = 0;
-  for (uint32_t vi = p.light_path_head[i]; (vi != kInvalid) && (len < 100000u); vi = p.lv.next[vi])
+  for (uint32_t vi = p.light_path_head[i]; (vi != kInvalid) && (len < 100000u); vi = p.lv.next(vi))
     len++;
   atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kDbgBase + 2), (unsigned long long)len);
   atomicMax(p.counters + kDbgBase + 4, len);

@@ -31,24 +31,29 @@ enum : uint32_t {  // VCMPathState flags, vcm_shared.hxx:92-98
   kPathLocalEmitter = 1u << 3,
 };
 
-struct LightVertexPool {   // VCMLightVertex (vcm_shared.hxx:154-197) as SoA
-  float4* pos_dvcm;        // pos.xyz, d_vcm
-  float4* wi_dvc;          // w_i.xyz, d_vc
-  float4* thr_dvm;         // throughput rgb, d_vm
-  float4* nrm_tri;         // nrm.xyz, triangle index bits (kInvalid = medium vertex)
-  float4* bc_len_med;      // bc.u, bc.v, path_length bits, medium index bits
-  uint32_t* next;          // previous vertex of the same light path (linked list), kInvalid = end
+struct LightVertexPool {   // VCMLightVertex (vcm_shared.hxx:154-197): one 96-byte record per vertex (write once; a
+                           // connection reads a whole vertex, so the record is interleaved: 1.5 cache lines, not 6)
+  float4* rec;             // kLvStride float4 per vertex
   uint32_t capacity;
+  static constexpr uint32_t kLvStride = 6;
+  ETX_HD float4& pos_dvcm(uint32_t i) const { return rec[i * kLvStride + 0]; }    // pos.xyz, d_vcm
+  ETX_HD float4& wi_dvc(uint32_t i) const { return rec[i * kLvStride + 1]; }      // w_i.xyz, d_vc
+  ETX_HD float4& thr_dvm(uint32_t i) const { return rec[i * kLvStride + 2]; }     // throughput rgb, d_vm
+  ETX_HD float4& nrm_tri(uint32_t i) const { return rec[i * kLvStride + 3]; }     // nrm.xyz, triangle index bits (kInvalid = medium vertex)
+  ETX_HD float4& bc_len_med(uint32_t i) const { return rec[i * kLvStride + 4]; }  // bc.u, bc.v, (index_in_path << 16 | path_length) bits, medium bits
+  ETX_HD uint32_t& next(uint32_t i) const { return reinterpret_cast<uint32_t*>(rec + i * kLvStride + 5)[0]; }  // previous vertex of the same path
 };
 
-struct PhotonGrid {        // VCMSpatialGridData (vcm_shared.hxx:805-827) as SoA sorted by hash cell
+struct PhotonGrid {        // VCMSpatialGridData (vcm_shared.hxx:805-827), photons sorted by hash cell
   uint32_t* cell_ends;     // size hash_capacity
-  float4* pos_len;         // pos.xyz, path_length bits
-  float4* nrm_dvcm;        // nrm.xyz, d_vcm
-  float4* win_dvm;         // w_in.xyz, d_vm
-  float4* thr;             // throughput_rgb / sampling_pdf
+  float4* pos_len;         // pos.xyz, path_length bits - dense: the distance filter touches nothing else
+  float4* rec;             // kPhotonStride float4 per photon, one 64-byte line for the ~20 % that pass the filter
   uint32_t* block_sums;    // scan scratch
   uint32_t hash_capacity;
+  static constexpr uint32_t kPhotonStride = 4;
+  ETX_HD float4& nrm_dvcm(uint32_t i) const { return rec[i * kPhotonStride + 0]; }  // nrm.xyz, d_vcm
+  ETX_HD float4& win_dvm(uint32_t i) const { return rec[i * kPhotonStride + 1]; }   // w_in.xyz, d_vm
+  ETX_HD float4& thr(uint32_t i) const { return rec[i * kPhotonStride + 2]; }       // throughput_rgb / sampling_pdf
 };
 
 struct GridParams {        // written by k_grid_setup on the device each iteration
@@ -68,7 +73,13 @@ struct CameraVertexPool {  // connectible camera vertices of the current bounce 
   float4* thr_depth;       // throughput rgb, total_path_depth bits
   float4* mis_pixel;       // d_vcm, d_vc, d_vm (already updated at the vertex), pixel index bits
   uint32_t* seed;
+  // merge-ready copy (k_merge reads these five float4 and nothing else): no dependent triangle/vertex/material loads
+  float4* pos_info;        // pos.xyz, (total_path_depth << 8) | flags   (kCvDiffuse, kCvMedium)
+  float4* nrm_dvm;         // shading normal, d_vm
+  float4* fthr_dvcm;       // diffuse: albedo/pi * throughput (= func * t_camera), else throughput; d_vcm
 };
+
+enum : uint32_t { kCvDiffuse = 1u << 0, kCvMedium = 1u << 1 };
 
 enum : uint32_t {  // device counters (u32), cleared per iteration unless noted
   kCntActiveA = 0,
@@ -78,6 +89,7 @@ enum : uint32_t {  // device counters (u32), cleared per iteration unless noted
   kCntOverflow = 4,
   kCntBboxMin = 5,          // 3 x ordered-int float min
   kCntBboxMax = 8,          // 3 x ordered-int float max
+  kCntPairs = 11,           // (camera vertex, light vertex) pairs of the current bounce, cleared per bounce
   kCntStatsBase = 16,
   kStatRaysExtension = 16,
   kStatRaysShadow = 18,
@@ -92,6 +104,7 @@ enum : uint32_t {  // device counters (u32), cleared per iteration unless noted
 enum : uint32_t {
   kOverflowLightVertices = 1u << 0,
   kOverflowStack = 1u << 1,
+  kOverflowPairs = 1u << 2,
 };
 
 struct VcmParams {  // VCMOptions + VCMIteration (vcm_shared.hxx:12-89), per iteration, by value
@@ -124,6 +137,8 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   PhotonGrid grid;
   GridParams* grid_params;
   CameraVertexPool cv;
+  uint2* pairs;          // (camera vertex slot, light vertex index) of the current bounce
+  uint32_t pair_capacity;
   float4* camera_sum;
   float4* light_sum;
   uint32_t* counters;

@@ -162,13 +162,16 @@ def test_vcm_classic_cornell_matches_reference(etx, golden_dir):
 def test_vcm_full_cornell_matches_reference(etx, golden_dir):
     # fog medium + environment + directional emitter (the complete surviving cornellbox.mtl)
     golden = np.load(os.path.join(golden_dir, "cornell_full_128_vcm.npz"))
-    spp = 64  # the golden holds 256 iterations; the radius schedule makes the first 64 slightly different -> looser bound
+    spp = int(golden["spp"])  # 64: same iteration set as the golden (the merge radius depends on the iteration index)
     cam, light, res, stats = render(etx, golden_dir, "cornell_full_128", spp)
     assert stats.overflow_flags == 0 and np.isfinite(res).all()
     ref_result = np.maximum(golden["camera"] + golden["light"], 0.0)
-    assert rmse(block_mean(res, 32), block_mean(ref_result, 32)) < 1.5e-2
+    assert rmse(block_mean(res, 32), block_mean(ref_result, 32)) < 5.0e-3
+    assert rmse(block_mean(light, 32), block_mean(golden["light"], 32)) < 1.0e-3
+    # the oracle's light and camera sub paths of a pixel share one random stream (partially correlated vertex
+    # connections, DESIGN.md "random streams"), the device re-keys the camera stream: allow 1.5 % in the means
     rel = (res[..., :3].mean(axis=(0, 1)) - ref_result.mean(axis=(0, 1))) / ref_result.mean(axis=(0, 1))
-    assert np.abs(rel).max() < 2e-2, rel
+    assert np.abs(rel).max() < 1.5e-2, rel
 
 
 def test_result_layer_is_camera_plus_light(etx, golden_dir):
