@@ -187,10 +187,75 @@ ETX_DEV Hit bvh_closest(const DScene& scene, Nodes nodes, Tris tris, int32_t roo
   return best;
 }
 
+
 // scene_medium.hxx:187-193 (homogeneous branch): exp(-sigma_t * distance)
 ETX_DEV f3 medium_transmittance_homogeneous(const DMedium& m, float distance) {
   f3 ext = m.absorption + m.scattering;
   return {expf(-ext.x * distance), expf(-ext.y * distance), expf(-ext.z * distance)};
+}
+
+// Flat-sweep transmittance for tiny scenes: ONE pass over all triangles finds (a) any occluder and (b) up to four
+// Boundary crossings kept sorted by t in registers (rt.cxx:488-516 collects up to 63 and sorts, :518-578 walks the
+// media); more than four crossings fall back to the restart walk below. Returns false when the fallback is needed.
+template <class Tris>
+ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, const f3& direction, float t_max, uint32_t medium_index, uint32_t& alpha_seed, f3& result) {
+  const RayQ ray = {p0, kRayEpsilon, direction, t_max};
+  float bt0 = kMaxFloat, bt1 = kMaxFloat, bt2 = kMaxFloat, bt3 = kMaxFloat;
+  uint32_t bi0 = kInvalid, bi1 = kInvalid, bi2 = kInvalid, bi3 = kInvalid;
+  uint32_t crossings = 0;
+  bool occluded = false;
+  const uint32_t count = scene.bvh_tri_count;
+  for (uint32_t i = 0; i < count; ++i) {
+    const float4 v0 = tris[i].v0_index;
+    const float4 e1 = tris[i].e1_flags;
+    const float4 e2 = tris[i].e2_mat;
+    float u, v, t;
+    if (triangle_test(v0, e1, e2, ray, t_max, u, v, t) == false)
+      continue;
+    const uint32_t flags = __float_as_uint(e1.w);
+    if (flags & kTriVoid)
+      continue;
+    const uint32_t tri_index = __float_as_uint(v0.w);
+    if ((flags & kTriAlphaTested) && alpha_test_skips(scene, tri_index, __float_as_uint(e2.w), u, v, alpha_seed))
+      continue;
+    if ((flags & kTriBoundary) == 0u) {
+      occluded = true;
+      continue;
+    }
+    crossings++;
+    // insertion into the sorted 4-slot list (compare-exchange chain, all in registers)
+    float ct = t;
+    uint32_t ci = tri_index;
+    if (ct < bt0) { float tt = bt0; uint32_t ti = bi0; bt0 = ct, bi0 = ci, ct = tt, ci = ti; }
+    if (ct < bt1) { float tt = bt1; uint32_t ti = bi1; bt1 = ct, bi1 = ci, ct = tt, ci = ti; }
+    if (ct < bt2) { float tt = bt2; uint32_t ti = bi2; bt2 = ct, bi2 = ci, ct = tt, ci = ti; }
+    if (ct < bt3) { bt3 = ct, bi3 = ci; }
+  }
+  if (occluded) {
+    result = mk3(0.0f);
+    return true;
+  }
+  if (crossings > 4u)
+    return false;
+  result = mk3(1.0f);
+  float current_t = 0.0f;
+  uint32_t medium = medium_index;
+  const float bts[4] = {bt0, bt1, bt2, bt3};
+  const uint32_t bis[4] = {bi0, bi1, bi2, bi3};
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) {
+    if (k < crossings) {
+      if (medium != kInvalid)
+        result *= medium_transmittance_homogeneous(scene.mediums[medium], fmaxf(0.0f, bts[k] - current_t));
+      const etx_abi_triangle& tri = scene.triangles[bis[k]];
+      const etx_abi_material& mat = scene.materials[tri.material_index];
+      medium = (dot(ld3(tri.geo_n), direction) < 0.0f) ? mat.int_medium : mat.ext_medium;
+      current_t = bts[k];
+    }
+  }
+  if (medium != kInvalid)
+    result *= medium_transmittance_homogeneous(scene.mediums[medium], fmaxf(0.0f, t_max - current_t));
+  return true;
 }
 
 // Transmittance between p0 and p1 starting in `medium_index` (rt.cxx:468-579).
@@ -209,6 +274,9 @@ ETX_DEV f3 bvh_transmittance(const DScene& scene, Nodes nodes, Tris tris, int32_
   t_max -= fmaxf(kRayEpsilon, t_max * kRayEpsilon);
 
   f3 result = mk3(1.0f);
+  if (scene.bvh_flat && flat_transmittance(scene, tris, p0, direction, t_max, medium_index, alpha_seed, result))
+    return result;
+  result = mk3(1.0f);
   float current_t = 0.0f;
   float t_min = kRayEpsilon;
   uint32_t medium = medium_index;

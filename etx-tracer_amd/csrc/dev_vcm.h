@@ -99,6 +99,20 @@ ETX_DEV f3 trace_transmittance(TraceCtx& tc, const f3& p0, const f3& p1, uint32_
   return bvh_transmittance(s, s.bvh_nodes, s.bvh_tris, s.bvh_root, tc.stack, p0, p1, medium, tc.alpha_seed);
 }
 
+// A connection whose visibility is still unknown: the shade / connect kernels evaluate everything but the
+// transmittance and queue the segment; k_trace_shadow (kernels_trace.hip) multiplies by the transmittance and adds
+// the result to the film. `target`: film pixel index, bit 31 set = light image (splat), clear = camera image.
+ETX_DEV void push_shadow(const Pipeline& p, const f3& p0, const f3& p1, uint32_t medium, uint32_t target, const f3& value) {
+  uint32_t idx = atomicAdd(p.counters + kCntShadow, 1u);
+  if (idx >= p.shadow.capacity) {
+    atomicOr(p.counters + kCntOverflow, kOverflowShadow);
+    return;
+  }
+  p.shadow.p0_medium[idx] = mk4(p0, __uint_as_float(medium));
+  p.shadow.p1_target[idx] = mk4(p1, __uint_as_float(target));
+  p.shadow.value[idx] = mk4(value, 0.0f);
+}
+
 // vcm_shared.hxx:218-283 vcm_next_ray
 ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& st, const VcmParams& it, const Isect& isect, const BsdfData& bsdf_data, const BsdfSample& bs) {
   if (st.depth + 1 > scene.max_path_length)
@@ -151,19 +165,19 @@ ETX_DEV bool vcm_handle_boundary(const DScene& scene, const Isect& isect, PathSt
   return true;
 }
 
-// vcm_shared.hxx:463-535 vcm_connect_to_camera. Returns the splat value, uv = film coordinates in NDC.
-ETX_DEV f3 vcm_connect_to_camera(TraceCtx& tc, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st, f2& uv) {
-  const DScene& scene = *tc.scene;
+// vcm_shared.hxx:463-535 vcm_connect_to_camera, minus the transmittance: queues the segment, the splat value
+// (vcm_cpu.cxx:148-153) is completed by k_trace_shadow.
+ETX_DEV void vcm_connect_to_camera(const Pipeline& p, const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st) {
   if ((opt_connect_to_camera(it) == false) || (st.depth + 2 > scene.max_path_length) || (st.depth + 2 < scene.min_path_length))
-    return mk3(0.0f);
+    return;
   f3 sample_pos = camera_at_medium ? medium_pos : isect->pos;
   CameraSample cs = sample_film(scene, st.sampler, sample_pos);
   if (cs.pdf_dir <= 0.0f)
-    return mk3(0.0f);
+    return;
   f3 direction = cs.position - sample_pos;
   float dist2 = dot(direction, direction);
   if (dist2 <= kEpsilon)
-    return mk3(0.0f);
+    return;
   f3 w_o = normalize(direction);
   f3 scatter = mk3(0.0f);
   float reverse_pdf = 0.0f;
@@ -173,7 +187,7 @@ ETX_DEV f3 vcm_connect_to_camera(TraceCtx& tc, const VcmParams& it, bool camera_
     BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathLight);
     BsdfEval eval = bsdf_evaluate(scene, data, w_o, mat, st.sampler);
     if (eval.valid() == false)
-      return mk3(0.0f);
+      return;
     scatter = eval.bsdf;
     reverse_pdf = bsdf_reverse_pdf(scene, data, w_o, mat);
     origin = shading_pos(scene, scene.triangles[isect->tri], isect->bc, w_o);
@@ -181,24 +195,25 @@ ETX_DEV f3 vcm_connect_to_camera(TraceCtx& tc, const VcmParams& it, bool camera_
     const DMedium& medium = scene.mediums[st.medium];
     float p = phase_function(st.ray_d, w_o, medium.g);
     if (p <= 0.0f)
-      return mk3(0.0f);
+      return;
     scatter = mk3(p);
     reverse_pdf = phase_function(w_o, st.ray_d, medium.g);
   }
   float len = length(cs.position - origin);
   float cos_t = fabsf(dot(cs.direction, scene.camera.direction));
   f3 clip_pos = origin + cs.direction * fmaxf(0.0f, len - scene.camera.clip_near / cos_t);
-  f3 tr = trace_transmittance(tc, origin, clip_pos, st.medium);
-  if (is_zero(tr))
-    return mk3(0.0f);
-  uv = cs.uv;
   float camera_pdf = cs.pdf_dir_out * (camera_at_medium ? 1.0f : fabsf(dot(isect->nrm, w_o))) / dist2;
   float vmW_cam = camera_at_medium ? 0.0f : it.vm_weight;
   float w_light = camera_pdf * (vmW_cam + st.d_vcm + st.d_vc * reverse_pdf);
   float weight = opt_enable_mis(it) ? (1.0f / (1.0f + w_light)) : 1.0f;
   if (camera_at_medium == false)
     weight *= fix_shading_normal(ld3(scene.triangles[isect->tri].geo_n), isect->nrm, isect->w_i, w_o);
-  return tr * scatter * st.throughput * (cs.weight * weight);
+  // film.cxx:147-171 atomic_add_light_iteration: NDC -> pixel, y flip
+  uint32_t x = static_cast<uint32_t>((cs.uv.x * 0.5f + 0.5f) * float(it.film_w));
+  uint32_t y = static_cast<uint32_t>((cs.uv.y * 0.5f + 0.5f) * float(it.film_h));
+  if ((x >= it.film_w) || (y >= it.film_h))
+    return;
+  push_shadow(p, origin, clip_pos, st.medium, kShadowTargetLight | (x + (it.film_h - 1u - y) * it.film_w), scatter * st.throughput * (cs.weight * weight));
 }
 
 // vcm_shared.hxx:285-308 vcm_get_radiance (direct emitter hit from the camera sub path)
@@ -256,16 +271,16 @@ ETX_DEV f3 vcm_cam_handle_miss(const DScene& scene, const VcmParams& it, PathSta
   return mk3(0.0f);
 }
 
-// vcm_shared.hxx:608-671 vcm_connect_to_light (NEE). sampler.fixed_* hold (rnd_connection.xy, rnd_support.y).
-ETX_DEV f3 vcm_connect_to_light(TraceCtx& tc, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st) {
-  const DScene& scene = *tc.scene;
+// vcm_shared.hxx:608-671 vcm_connect_to_light (NEE) minus the transmittance (queued for k_trace_shadow).
+// sampler.fixed_* hold (rnd_connection.xy, rnd_support.y). `film_target` = film index of the path's pixel.
+ETX_DEV void vcm_connect_to_light(const Pipeline& p, const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st, uint32_t film_target) {
   if ((opt_connect_to_light(it) == false) || (st.depth + 1 > scene.max_path_length) || (st.depth + 1 < scene.min_path_length))
-    return mk3(0.0f);
+    return;
   f3 sample_pos = camera_at_medium ? medium_pos : isect->pos;
   uint32_t emitter_index = sample_emitter_index(scene, st.sampler.fixed_w);
   EmitterSample es = sample_emitter(scene, emitter_index, f2{st.sampler.fixed_u, st.sampler.fixed_v}, sample_pos);
   if (es.pdf_dir <= 0.0f)
-    return mk3(0.0f);
+    return;
   f3 w_o = es.direction;
   f3 scatter = mk3(0.0f);
   float reverse_pdf = 0.0f;
@@ -276,7 +291,7 @@ ETX_DEV f3 vcm_connect_to_light(TraceCtx& tc, const VcmParams& it, bool camera_a
     const DMedium& medium = scene.mediums[st.medium];
     float p = phase_function(st.ray_d, w_o, medium.g);
     if (p <= 0.0f)
-      return mk3(0.0f);
+      return;
     scatter = mk3(p);
     reverse_pdf = phase_function(w_o, st.ray_d, medium.g);
   } else {
@@ -284,7 +299,7 @@ ETX_DEV f3 vcm_connect_to_light(TraceCtx& tc, const VcmParams& it, bool camera_a
     BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathCamera);
     BsdfEval eval = bsdf_evaluate(scene, data, w_o, mat, st.sampler);
     if (eval.valid() == false)
-      return mk3(0.0f);
+      return;
     scatter = eval.bsdf;
     reverse_pdf = bsdf_reverse_pdf(scene, data, w_o, mat);
     const etx_abi_triangle& tri = scene.triangles[isect->tri];
@@ -292,9 +307,6 @@ ETX_DEV f3 vcm_connect_to_light(TraceCtx& tc, const VcmParams& it, bool camera_a
     camera_factor = fabsf(dot(w_o, ld3(tri.geo_n)));
     conn_pdf = bsdf_pdf(scene, data, w_o, mat);
   }
-  f3 tr = trace_transmittance(tc, origin, es.origin, st.medium);
-  if (is_zero(tr))
-    return mk3(0.0f);
   float l_dot_e = fabsf(dot(es.direction, es.normal));
   float w_light = 0.0f;
   if (es.is_delta == false) {
@@ -304,7 +316,7 @@ ETX_DEV f3 vcm_connect_to_light(TraceCtx& tc, const VcmParams& it, bool camera_a
   float vmW_nee = camera_at_medium ? 0.0f : it.vm_weight;
   float w_camera = (es.pdf_dir_out * camera_factor) / (es.pdf_dir * l_dot_e) * (vmW_nee + st.d_vcm + st.d_vc * reverse_pdf);
   float weight = opt_enable_mis(it) ? 1.0f / (1.0f + w_light + w_camera) : 1.0f;
-  return tr * st.throughput * scatter * es.value * (weight / (es.pdf_dir * es.pdf_sample));
+  push_shadow(p, origin, es.origin, st.medium, film_target, st.throughput * scatter * es.value * (weight / (es.pdf_dir * es.pdf_sample)));
 }
 
 struct LightVertex {  // VCMLightVertex, vcm_shared.hxx:154-197

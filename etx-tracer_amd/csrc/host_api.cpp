@@ -29,6 +29,7 @@ thread_local std::string g_create_error;
 
 enum TimerId : uint32_t {
   kTimerTraceClosest = 0,
+  kTimerTraceShadow,
   kTimerShadeLight,
   kTimerShadeCamera,
   kTimerConnect,
@@ -61,8 +62,9 @@ struct etx_hip_context {
   uint32_t local_iterations = 0;     // iterations rendered by this context since begin
   uint64_t global_iterations = 0;    // after etx_hip_reduce_film: iterations of all ranks
   bool reduced = false;
+  uint32_t tail_divisor = 64;        // active paths <= capacity / tail_divisor: finish the pass in the tail kernel (0 = never)
   uint32_t check_interval = 8;       // bounces enqueued between two reads of the active-path counter
-  uint32_t timer_mask = 1u << kTimerTraceClosest;
+  uint32_t timer_mask = (1u << kTimerTraceClosest) | (1u << kTimerTraceShadow);
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
   std::vector<TimedSpan> spans;
@@ -157,6 +159,10 @@ int allocate_pipeline(etx_hip_context* ctx) {
   p.pair_capacity = uint32_t(std::min<uint64_t>(uint64_t(n) * 16u, 1ull << 30));
   if ((rc = device_alloc(ctx, p.pairs, p.pair_capacity)))
     return rc;
+  p.shadow.capacity = uint32_t(std::min<uint64_t>(uint64_t(p.pair_capacity) + 2ull * n, 0xfffffff0ull));
+  if ((rc = device_alloc(ctx, p.shadow.p0_medium, p.shadow.capacity)) || (rc = device_alloc(ctx, p.shadow.p1_target, p.shadow.capacity)) ||
+      (rc = device_alloc(ctx, p.shadow.value, p.shadow.capacity)))
+    return rc;
   if ((rc = device_alloc(ctx, p.camera_sum, n)) || (rc = device_alloc(ctx, p.light_sum, n)) || (rc = device_alloc(ctx, ctx->resolve_buffer, n)))
     return rc;
   if ((rc = device_alloc(ctx, p.counters, kCounterCount)))
@@ -234,10 +240,11 @@ VcmParams make_iteration_params(const etx_hip_context* ctx, uint32_t iteration) 
 
 // One pass of the wavefront loop: trace + shade rounds until no path is alive. The active count lives on the device;
 // it is read back every `check_interval` rounds (a pass usually ends after a few dozen rounds).
-template <class ShadeFn>
-int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, uint64_t& rounds) {
+template <class ShadeFn, class TailFn>
+int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64_t& rounds) {
   uint32_t set = 0;
   uint32_t known_count = ctx->pipe.capacity;  // upper bound of the active paths (the count never grows within a pass)
+  const uint32_t tail_threshold = ctx->tail_divisor ? std::max(64u, ctx->pipe.capacity / ctx->tail_divisor) : 0u;
   const uint32_t max_rounds = ctx->scene.host_copy.max_path_length * 2u + 16u;  // boundaries do not add depth
   for (uint32_t round = 0; round < max_rounds;) {
     for (uint32_t k = 0; k < ctx->check_interval; ++k, ++round) {
@@ -255,6 +262,11 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, uint64_t& rounds) {
     known_count = ctx->host_counters[set == 0 ? kCntActiveA : kCntActiveB];
     if (known_count == 0u)
       return 0;
+    if (known_count <= tail_threshold) {
+      tail(set, known_count);
+      rounds++;
+      return 0;
+    }
   }
   return 0;
 }
@@ -273,8 +285,24 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
   int rc = run_bounce_loop(
     ctx,
     [&](uint32_t set, uint32_t max_items) {
-      ScopedTimer t(ctx, kTimerShadeLight);
-      launch_light_shade(s, p, it, set, max_items);
+      {
+        ScopedTimer t(ctx, kTimerShadeLight);
+        launch_light_shade(s, p, it, set, max_items);
+      }
+      if (opt_connect_to_camera(it)) {
+        ScopedTimer t(ctx, kTimerTraceShadow);
+        launch_trace_shadow(s, p, max_items);
+      }
+    },
+    [&](uint32_t set, uint32_t max_items) {
+      {
+        ScopedTimer t(ctx, kTimerShadeLight);
+        launch_light_tail(s, p, it, set, max_items);
+      }
+      if (opt_connect_to_camera(it)) {
+        ScopedTimer t(ctx, kTimerTraceShadow);
+        launch_trace_shadow(s, p, p.shadow.capacity);
+      }
     },
     rounds);
   if (rc)
@@ -303,9 +331,32 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
         ScopedTimer t(ctx, kTimerConnect);
         launch_connect(s, p, it, ctx->scene.generic_materials, max_items);
       }
+      if (opt_connect_vertices(it) || opt_connect_to_light(it)) {
+        ScopedTimer t(ctx, kTimerTraceShadow);
+        launch_trace_shadow(s, p, uint32_t(std::min<uint64_t>(uint64_t(max_items) * 6ull, 0xffffffffull)));
+      }
       if (opt_merge_vertices(it)) {
         ScopedTimer t(ctx, kTimerMerge);
         launch_merge(s, p, it, ctx->scene.generic_materials, max_items);
+      }
+    },
+    [&](uint32_t set, uint32_t max_items) {
+      {
+        ScopedTimer t(ctx, kTimerShadeCamera);
+        launch_camera_tail(s, p, it, set, max_items);
+      }
+      // the tail leaves up to `capacity` camera vertices: drain them with one launch of each consumer
+      if (opt_connect_vertices(it)) {
+        ScopedTimer t(ctx, kTimerConnect);
+        launch_connect(s, p, it, ctx->scene.generic_materials, p.capacity);
+      }
+      if (opt_connect_vertices(it) || opt_connect_to_light(it)) {
+        ScopedTimer t(ctx, kTimerTraceShadow);
+        launch_trace_shadow(s, p, p.shadow.capacity);
+      }
+      if (opt_merge_vertices(it)) {
+        ScopedTimer t(ctx, kTimerMerge);
+        launch_merge(s, p, it, ctx->scene.generic_materials, p.capacity);
       }
     },
     rounds);
@@ -334,8 +385,8 @@ void collect_stats(etx_hip_context* ctx) {
   st.ms_merge = ms[kTimerMerge];
   st.ms_grid_build = ms[kTimerGridBuild];
   st.ms_generate = ms[kTimerGenerate];
-  st.ms_trace_shadow = 0.0;
-  st.launches_trace_shadow = 0;
+  st.ms_trace_shadow = ms[kTimerTraceShadow];
+  st.launches_trace_shadow = launches[kTimerTraceShadow];
   ctx->spans.clear();
   ctx->events_used = 0;
 
@@ -416,6 +467,8 @@ int etx_hip_create(int device, etx_hip_context** out_context) {
   memset(ctx->host_counters, 0, kCounterCount * sizeof(uint32_t));
   if (const char* e = getenv("ETX_HIP_CHECK_INTERVAL"))
     ctx->check_interval = std::max(1, atoi(e));
+  if (const char* e = getenv("ETX_HIP_TAIL_DIVISOR"))
+    ctx->tail_divisor = uint32_t(std::max(0, atoi(e)));
   if (const char* e = getenv("ETX_HIP_TIMERS"))
     ctx->timer_mask = uint32_t(strtoul(e, nullptr, 0));
   *out_context = ctx.release();
@@ -547,7 +600,7 @@ int etx_hip_render_iteration(etx_hip_context* context) {
   context->next_iteration += context->iteration_stride;
   if (context->stats.overflow_flags) {
     context->error = "device pool overflow in iteration " + std::to_string(context->stats.current_iteration) + " (flags " + std::to_string(context->stats.overflow_flags) +
-                     "): light vertex pool (1, raise ETX_HIP_LIGHT_VERTICES_PER_PATH) / connection pair buffer (4)";
+                     "): light vertex pool (1, raise ETX_HIP_LIGHT_VERTICES_PER_PATH) / connection pair buffer (4) / shadow queue (8) / camera vertex pool (16)";
     return ETX_HIP_ERROR_OVERFLOW;
   }
   return ETX_HIP_OK;

@@ -3,7 +3,7 @@
 //   vertex connections  vcm_connect_to_light_path (vcm_shared.hxx:765-803): camera vertex x every vertex of the light
 //       path of the SAME pixel. k_expand_pairs turns (camera vertex, light path) into a dense list of
 //       (camera vertex, light vertex) pairs (wave prefix sum + one atomic per wave), k_connect_pairs evaluates one
-//       pair per lane (2 BSDF evaluations + 2 reverse pdfs + one transmittance ray), so lanes do equal work
+//       pair per lane (2 BSDF evaluations + 2 reverse pdfs, the visibility segment goes to the shadow queue), so lanes do equal work
 //       although light path lengths are geometric-ish (max over a wave ~5x the mean).
 //   photon merge        VCMSpatialGridData::gather (vcm_shared.hxx:886-924): camera vertex x 8 hash cells x photons.
 //       k_merge gives each (camera vertex, cell) its own lane: 8x more independent photon streams in flight per
@@ -64,11 +64,8 @@ __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmPara
 
 template <bool kDiffuseOnly>
 __global__ __launch_bounds__(kBlockSize) void k_connect_pairs(Pipeline p, VcmParams it) {
-  __shared__ int32_t s_stack[kStackDepth * kBlockSize];
   const DScene& scene = *p.scene;
   const uint32_t count = min(p.counters[kCntPairs], p.pair_capacity);
-  TraceCtx tc = {&scene, {s_stack + threadIdx.x, kBlockSize}, 0u};
-  uint32_t shadow_rays = 0;
   ETX_WAVE_LOOP(count) {
     const uint32_t i = base_ + lane_;
     if (i >= count)
@@ -85,21 +82,14 @@ __global__ __launch_bounds__(kBlockSize) void k_connect_pairs(Pipeline p, VcmPar
       continue;
     // the reference evaluates every connection of a vertex with the path's sampler; decorrelate per pair
     cv.st.sampler.seed = Sampler::random_seed(cv.st.sampler.seed, pair.y);
-    tc.alpha_seed = cv.st.sampler.seed ^ 0x27d4eb2fu;
     f3 target_position, value;
     if (vcm_connect_to_light_vertex<kDiffuseOnly>(scene, cv.st, lv, it, cv.at_medium, &cv.isect, cv.medium_pos, cv.st.sampler, target_position, value) == false)
       continue;
     f3 p0 = cv.medium_pos;
     if (cv.at_medium == false)
       p0 = shading_pos(scene, scene.triangles[cv.isect.tri], cv.isect.bc, normalize(target_position - cv.isect.pos));
-    f3 tr = trace_transmittance(tc, p0, cv.at_medium ? lv.pos : target_position, cv.st.medium);
-    shadow_rays++;
-    if (is_zero(tr))
-      continue;
-    atomic_add_f3(p.camera_sum + film_index(it, cv.st.id), tr * value);
+    push_shadow(p, p0, cv.at_medium ? lv.pos : target_position, cv.st.medium, film_index(it, cv.st.id), value);
   }
-  if (shadow_rays)
-    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatRaysShadow), (unsigned long long)shadow_rays);
 }
 
 void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items) {

@@ -6,6 +6,7 @@
 // wave-uniform grid-stride loop; per-lane traversal stack in LDS laid out [level][lane] (bank conflict free).
 #include "kernels.h"
 #include "dev_bvh.h"
+#include "pipeline.h"
 
 namespace etxd {
 
@@ -20,6 +21,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene* __re
     counters[active_counter ^ 1u] = 0u;
     counters[kCntCameraVertices] = 0u;
     counters[kCntPairs] = 0u;
+    counters[kCntShadow] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
   }
   const uint32_t lane = threadIdx.x & 63u;
@@ -40,6 +42,54 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene* __re
 void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items) {
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.capacity, max_items) + kBlockSize - 1) / kBlockSize));
   hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Shadow kernel: segment queue -> transmittance -> film atomics (Raytracing::trace_transmittance, rt.cxx:468-579, plus
+// the accumulation the callers do: vcm_cpu.cxx:148-153 light splats, vcm_shared.hxx:1049-1053 camera gathers).
+// Algorithmic traffic: 48 B request in, 12 B of float atomics out for visible segments.
+__global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
+  __shared__ int32_t s_stack[kStackDepth * kBlockSize];
+  const DScene& scene = *p.scene;
+  const uint32_t count = min(p.counters[kCntShadow], p.shadow.capacity);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  LaneStack stack = {s_stack + threadIdx.x, kBlockSize};
+  uint32_t splats = 0;
+  for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {
+    const uint32_t i = base + lane;
+    if (i >= count)
+      continue;
+    const float4 a = p.shadow.p0_medium[i];
+    const float4 b = p.shadow.p1_target[i];
+    uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ i;
+    f3 tr = bvh_transmittance(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), alpha_seed);
+    if ((tr.x <= kEpsilon) && (tr.y <= kEpsilon) && (tr.z <= kEpsilon))
+      continue;  // SpectralResponse::is_zero
+    const float4 v = p.shadow.value[i];
+    const f3 value = tr * f3{v.x, v.y, v.z};
+    const uint32_t target = __float_as_uint(b.w);
+    if (target & kShadowTargetLight) {
+      // vcm_shared.hxx:1229 + vcm_cpu.cxx:148-153 + film.cxx:148: thresholds of the light splat
+      if ((max_component(value) <= kEpsilon) || (dot(value, value) <= kEpsilon))
+        continue;
+      float4* dst = p.light_sum + (target & ~kShadowTargetLight);
+      atomicAdd(&dst->x, value.x), atomicAdd(&dst->y, value.y), atomicAdd(&dst->z, value.z);
+      splats++;
+    } else {
+      float4* dst = p.camera_sum + target;
+      atomicAdd(&dst->x, value.x), atomicAdd(&dst->y, value.y), atomicAdd(&dst->z, value.z);
+    }
+  }
+  if ((blockIdx.x == 0) && (threadIdx.x == 0))
+    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatRaysShadow), (unsigned long long)count);
+  if (splats)
+    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatSplats), (unsigned long long)splats);
+}
+
+void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_items) {
+  uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.shadow.capacity, max_items) + kBlockSize - 1) / kBlockSize));
+  hipLaunchKernelGGL(k_trace_shadow, dim3(blocks), dim3(kBlockSize), 0, stream, p);
 }
 
 void launch_trace_rays(hipStream_t stream, const DScene* scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count) {

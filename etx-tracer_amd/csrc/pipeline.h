@@ -81,6 +81,15 @@ struct CameraVertexPool {  // connectible camera vertices of the current bounce 
 
 enum : uint32_t { kCvDiffuse = 1u << 0, kCvMedium = 1u << 1 };
 
+struct ShadowQueue {        // transmittance ("shadow") ray requests of the current bounce: 48 B in, film atomics out
+  float4* p0_medium;       // segment start, medium index bits at the start
+  float4* p1_target;       // segment end, film target bits: bit 31 = light layer, low bits = film pixel index
+  float4* value;           // contribution before transmittance (rgb)
+  uint32_t capacity;
+};
+
+constexpr uint32_t kShadowTargetLight = 0x80000000u;
+
 enum : uint32_t {  // device counters (u32), cleared per iteration unless noted
   kCntActiveA = 0,
   kCntActiveB = 1,
@@ -89,7 +98,8 @@ enum : uint32_t {  // device counters (u32), cleared per iteration unless noted
   kCntOverflow = 4,
   kCntBboxMin = 5,          // 3 x ordered-int float min
   kCntBboxMax = 8,          // 3 x ordered-int float max
-  kCntPairs = 11,           // (camera vertex, light vertex) pairs of the current bounce, cleared per bounce
+  kCntPairs = 11,
+  kCntShadow = 12,          // shadow requests of the current bounce, cleared per bounce           // (camera vertex, light vertex) pairs of the current bounce, cleared per bounce
   kCntStatsBase = 16,
   kStatRaysExtension = 16,
   kStatRaysShadow = 18,
@@ -105,6 +115,8 @@ enum : uint32_t {
   kOverflowLightVertices = 1u << 0,
   kOverflowStack = 1u << 1,
   kOverflowPairs = 1u << 2,
+  kOverflowShadow = 1u << 3,
+  kOverflowCameraVertices = 1u << 4,
 };
 
 struct VcmParams {  // VCMOptions + VCMIteration (vcm_shared.hxx:12-89), per iteration, by value
@@ -137,6 +149,7 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   PhotonGrid grid;
   GridParams* grid_params;
   CameraVertexPool cv;
+  ShadowQueue shadow;
   uint2* pairs;          // (camera vertex slot, light vertex index) of the current bounce
   uint32_t pair_capacity;
   float4* camera_sum;
