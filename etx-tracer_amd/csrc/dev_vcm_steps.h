@@ -54,10 +54,17 @@ ETX_DEV void store_camera_vertex(const Pipeline& p, const DScene& scene, const P
 }
 
 
+// What happened on a segment (the branches of vcm_light_step / vcm_camera_step)
+enum : uint32_t { kEventNone = 0, kEventMedium = 1, kEventSurface = 2, kEventBoundary = 3 };
+
 // vcm_light_step, vcm_shared.hxx:1090-1260: everything after rt.trace for one light sub path segment.
 // Returns whether the path continues (state updated in place).
+// The reference's medium branch (:1097-1170) and surface branch (:1181-1259) are restated as three phases so that the
+// expensive camera connection is a single call site that all lanes of a wave reach together:
+//   A  classify the event, draw the randoms, update the MIS quantities at the vertex, sample the BSDF
+//   B  store the light vertex, connect it to the camera (same code for medium and surface vertices)
+//   C  continue the path (phase function / vcm_next_ray, Russian roulette)
 ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h) {
-  bool alive = false;
   const uint32_t tri = __float_as_uint(h.w);
   const bool found = tri != kInvalid;
   Isect isect;
@@ -72,21 +79,64 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
     st.throughput *= ms.weight;
   }
 
-  if (ms.sampled_medium()) {  // vcm_shared.hxx:1097-1170
-    f2 rnd_bsdf = st.sampler.next_2d();
-    f2 rnd_connection = st.sampler.next_2d();
-    f2 rnd_support = st.sampler.next_2d();
-    float seg = st.path_distance + ms.sampled_medium_t;
-    st.d_vcm *= sqr(seg);
+  // ---- phase A
+  uint32_t event = kEventNone;
+  if (ms.sampled_medium())
+    event = kEventMedium;
+  else if (found)
+    event = vcm_handle_boundary(scene, isect, st) ? kEventBoundary : kEventSurface;
+  if (event == kEventNone)
+    return false;
+  if (event == kEventBoundary)
+    return true;
+
+  // both branches draw the same six numbers (vcm_shared.hxx:1099-1101, 1185-1187)
+  const f2 rnd_bsdf = st.sampler.next_2d();
+  const f2 rnd_connection = st.sampler.next_2d();
+  const f2 rnd_support = st.sampler.next_2d();
+  const bool at_medium = event == kEventMedium;
+  BsdfData bsdf_data;
+  BsdfSample bs;
+  bool store = false, connect = false;
+  if (at_medium) {
+    st.d_vcm *= sqr(st.path_distance + ms.sampled_medium_t);
     st.path_distance = 0.0f;
-    const DMedium& med = scene.mediums[st.medium];
-    if (opt_connect_vertices(it) && (st.depth + 1 <= scene.max_path_length))
+    store = opt_connect_vertices(it) && (st.depth + 1 <= scene.max_path_length);
+    connect = opt_connect_to_camera(it) && scene.mediums[st.medium].explicit_connections && (st.depth + 1 <= scene.max_path_length);
+  } else {
+    const etx_abi_material& mat = scene.materials[isect.material];
+    bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight);
+    st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
+    bs = bsdf_sample(scene, bsdf_data, mat, st.sampler);
+    st.sampler.pop_fixed();
+    // vcm_update_light_vcm, vcm_shared.hxx:451-461
+    if ((st.depth > 0u) || (st.flags & kPathLocalEmitter))
+      st.d_vcm *= sqr(st.path_distance + isect.t);
+    float cos_to_prev = fabsf(dot(isect.nrm, -st.ray_d));
+    st.d_vcm /= cos_to_prev;
+    st.d_vc /= cos_to_prev;
+    st.d_vm /= cos_to_prev;
+    st.path_distance = 0.0f;
+    store = (bs.properties & kSampleDelta) == 0u;  // is_connectible
+    connect = store && opt_connect_to_camera(it) && (st.depth + 1 <= scene.max_path_length);
+  }
+
+  // ---- phase B
+  if (store) {
+    if (at_medium)
       store_light_vertex(p, it, st, ms.pos, mk3(0.0f), 0.0f, 0.0f, kInvalid, false);
-    if (opt_connect_to_camera(it) && med.explicit_connections && (st.depth + 1 <= scene.max_path_length)) {
-      st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-      vcm_connect_to_camera(p, scene, it, true, nullptr, ms.pos, st);
-      st.sampler.pop_fixed();
-    }
+    else
+      store_light_vertex(p, it, st, isect.pos, isect.nrm, isect.bc.y, isect.bc.z, isect.tri, true);
+  }
+  if (connect) {
+    st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+    vcm_connect_to_camera(p, scene, it, at_medium, &isect, ms.pos, st);
+    st.sampler.pop_fixed();
+  }
+
+  // ---- phase C
+  if (at_medium) {  // vcm_shared.hxx:1143-1169
+    const DMedium& med = scene.mediums[st.medium];
     f3 w_i = st.ray_d;
     f3 w_o = sample_phase_function(w_i, med.g, rnd_bsdf);
     float pdf_fwd = phase_function(w_i, w_o, med.g);
@@ -99,53 +149,19 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
     st.ray_tmax = kMaxFloat;
     st.ray_tmin = kRayEpsilon;
     st.depth += 1u;
-    alive = (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
-  } else if (found) {
-    if (vcm_handle_boundary(scene, isect, st)) {
-      alive = true;
-    } else {
-      const etx_abi_material& mat = scene.materials[isect.material];
-      BsdfData bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight);
-      f2 rnd_bsdf = st.sampler.next_2d();
-      f2 rnd_connection = st.sampler.next_2d();
-      f2 rnd_support = st.sampler.next_2d();
-      st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
-      BsdfSample bs = bsdf_sample(scene, bsdf_data, mat, st.sampler);
-      bool is_connectible = (bs.properties & kSampleDelta) == 0u;
-      st.sampler.pop_fixed();
-
-      // vcm_update_light_vcm, vcm_shared.hxx:451-461
-      if ((st.depth > 0u) || (st.flags & kPathLocalEmitter))
-        st.d_vcm *= sqr(st.path_distance + isect.t);
-      float cos_to_prev = fabsf(dot(isect.nrm, -st.ray_d));
-      st.d_vcm /= cos_to_prev;
-      st.d_vc /= cos_to_prev;
-      st.d_vm /= cos_to_prev;
-      st.path_distance = 0.0f;
-
-      if (is_connectible) {
-        store_light_vertex(p, it, st, isect.pos, isect.nrm, isect.bc.y, isect.bc.z, isect.tri, true);
-        if (opt_connect_to_camera(it) && (st.depth + 1 <= scene.max_path_length)) {
-          st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-          vcm_connect_to_camera(p, scene, it, false, &isect, mk3(0.0f), st);
-          st.sampler.pop_fixed();
-        }
-      }
-      if (vcm_next_ray(scene, kPathLight, st, it, isect, bsdf_data, bs))
-        alive = st.depth + 1u < scene.max_path_length;
-    }
+    return (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
   }
-  return alive;
+  if (vcm_next_ray(scene, kPathLight, st, it, isect, bsdf_data, bs))
+    return st.depth + 1u < scene.max_path_length;
+  return false;
 }
 
 // vcm_camera_step, vcm_shared.hxx:927-1079 after rt.trace, without the vertex connections and the merge: connectible
-// vertices go to the camera vertex pool (k_expand_pairs / k_connect_pairs / k_merge consume them), NEE segments and the
-// direct / miss radiance go to the shadow queue / film.
+// vertices go to the camera vertex pool (k_expand_pairs / k_connect_pairs / k_merge consume them), NEE segments go to
+// the shadow queue, direct / miss radiance goes straight to the film. Same three-phase shape as light_step.
 ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h) {
-  bool alive = false;
   const uint32_t tri = __float_as_uint(h.w);
   const bool found = tri != kInvalid;
-  f3 gathered = mk3(0.0f);
   Isect isect;
   if (found)
     isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
@@ -157,54 +173,50 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
     st.throughput *= ms.weight;
   }
 
-  if (ms.sampled_medium()) {  // vcm_shared.hxx:934-995
-    f2 rnd_bsdf = st.sampler.next_2d();
-    f2 rnd_connection = st.sampler.next_2d();
-    f2 rnd_support = st.sampler.next_2d();
-    float seg = st.path_distance + ms.sampled_medium_t;
-    st.d_vcm *= sqr(seg);
+  // ---- phase A
+  uint32_t event = kEventNone;
+  if (ms.sampled_medium())
+    event = kEventMedium;
+  else if (found)
+    event = vcm_handle_boundary(scene, isect, st) ? kEventBoundary : kEventSurface;
+  if (event == kEventNone) {  // vcm_shared.hxx:997-1000
+    f3 gathered = vcm_cam_handle_miss(scene, it, st);
+    if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
+      atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered);
+    return false;
+  }
+  if (event == kEventBoundary)
+    return true;
+
+  // vcm_shared.hxx:936-938, 1013-1015. The blue-noise override of the first vertex (:941-945, 1018-1022) needs the
+  // host's tables: etx_hip_begin rejects options.blue_noise until etx_hip_upload_bluenoise provides them.
+  const f2 rnd_bsdf = st.sampler.next_2d();
+  const f2 rnd_connection = st.sampler.next_2d();
+  const f2 rnd_support = st.sampler.next_2d();
+  const bool at_medium = event == kEventMedium;
+  BsdfData bsdf_data;
+  BsdfSample bs;
+  f3 w_o_medium = mk3(0.0f);
+  float pdf_fwd = 0.0f, pdf_rev = 0.0f;
+  bool store = false, nee = false;
+  if (at_medium) {
+    st.d_vcm *= sqr(st.path_distance + ms.sampled_medium_t);
     st.path_distance = 0.0f;
     const DMedium& med = scene.mediums[st.medium];
-    f3 w_o_smp = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
-    float pdf_fwd = phase_function(st.ray_d, w_o_smp, med.g);
-    float pdf_rev = phase_function(w_o_smp, st.ray_d, med.g);
-    if (med.explicit_connections && (st.depth + 1 <= scene.max_path_length)) {
-      if (opt_connect_to_light(it)) {
-        st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-        vcm_connect_to_light(p, scene, it, true, nullptr, ms.pos, st, film_index(it, st.id));
-        st.sampler.pop_fixed();
-      }
-      if (opt_connect_vertices(it)) {
-        Sampler derived;
-        derived.init(st.sampler.seed, 0x51ed270bu);
-        store_camera_vertex(p, scene, st, mk4(ms.pos, __uint_as_float(kInvalid)), derived.seed, nullptr);
-      }
-    }
-    st.d_vc = (1.0f / pdf_fwd) * (st.d_vc * pdf_rev + st.d_vcm);
-    st.d_vm = (1.0f / pdf_fwd) * (st.d_vm * pdf_rev + 0.0f);
-    st.d_vcm = 1.0f / pdf_fwd;
-    st.ray_o = ms.pos;
-    st.ray_d = w_o_smp;
-    st.ray_tmax = kMaxFloat;
-    st.ray_tmin = kRayEpsilon;
-    st.depth += 1u;
-    alive = (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
-  } else if (found == false) {
-    gathered += vcm_cam_handle_miss(scene, it, st);
-  } else if (vcm_handle_boundary(scene, isect, st)) {
-    alive = true;
+    // phase sampling before the explicit connections (vcm_shared.hxx:954-959)
+    w_o_medium = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
+    pdf_fwd = phase_function(st.ray_d, w_o_medium, med.g);
+    pdf_rev = phase_function(w_o_medium, st.ray_d, med.g);
+    const bool explicit_connections = med.explicit_connections && (st.depth + 1 <= scene.max_path_length);
+    nee = explicit_connections && opt_connect_to_light(it);
+    store = explicit_connections && opt_connect_vertices(it);
   } else {
     const etx_abi_material& mat = scene.materials[isect.material];
-    BsdfData bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera);
-    f2 rnd_bsdf = st.sampler.next_2d();
-    f2 rnd_connection = st.sampler.next_2d();
-    f2 rnd_support = st.sampler.next_2d();
-    // blue-noise override of the first vertex (vcm_shared.hxx:1018-1022) needs the host's tables:
-    // etx_hip_begin rejects options.blue_noise until etx_hip_upload_bluenoise provided them.
+    bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera);
     st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
-    BsdfSample bs = bsdf_sample(scene, bsdf_data, mat, st.sampler);
-    bool is_connectible = (bs.properties & kSampleDelta) == 0u;
+    bs = bsdf_sample(scene, bsdf_data, mat, st.sampler);
     st.sampler.pop_fixed();
+    const bool is_connectible = (bs.properties & kSampleDelta) == 0u;
 
     // vcm_update_camera_vcm, vcm_shared.hxx:589-595
     float cos_to_prev = fabsf(dot(isect.nrm, -st.ray_d));
@@ -214,24 +226,43 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
     st.path_distance = 0.0f;
 
     // vcm_handle_direct_hit, vcm_shared.hxx:597-606
-    if (opt_direct_hit(it) && (isect.emitter != kInvalid) && (st.depth <= scene.max_path_length) && (st.depth >= scene.min_path_length))
-      gathered += vcm_get_radiance(scene, scene.emitters[isect.emitter], st, it, isect);
-
-    if (is_connectible) {
-      if (opt_connect_vertices(it) || (opt_merge_vertices(it) && (st.depth + 1 <= scene.max_path_length))) {
-        Sampler derived;
-        derived.init(st.sampler.seed, 0x51ed270bu);
-        store_camera_vertex(p, scene, st, h, derived.seed, &isect);
-      }
-      st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-      vcm_connect_to_light(p, scene, it, false, &isect, mk3(0.0f), st, film_index(it, st.id));
-      st.sampler.pop_fixed();
+    if (opt_direct_hit(it) && (isect.emitter != kInvalid) && (st.depth <= scene.max_path_length) && (st.depth >= scene.min_path_length)) {
+      f3 gathered = vcm_get_radiance(scene, scene.emitters[isect.emitter], st, it, isect);
+      if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
+        atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered);
     }
-    alive = vcm_next_ray(scene, kPathCamera, st, it, isect, bsdf_data, bs);
+    nee = is_connectible;
+    store = is_connectible && (opt_connect_vertices(it) || (opt_merge_vertices(it) && (st.depth + 1 <= scene.max_path_length)));
   }
-  if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
-    atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered);
-  return alive;
+
+  // ---- phase B
+  if (store) {
+    Sampler derived;
+    derived.init(st.sampler.seed, 0x51ed270bu);
+    if (at_medium)
+      store_camera_vertex(p, scene, st, mk4(ms.pos, __uint_as_float(kInvalid)), derived.seed, nullptr);
+    else
+      store_camera_vertex(p, scene, st, h, derived.seed, &isect);
+  }
+  if (nee) {
+    st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+    vcm_connect_to_light(p, scene, it, at_medium, &isect, ms.pos, st, film_index(it, st.id));
+    st.sampler.pop_fixed();
+  }
+
+  // ---- phase C
+  if (at_medium) {  // vcm_shared.hxx:973-994
+    st.d_vc = (1.0f / pdf_fwd) * (st.d_vc * pdf_rev + st.d_vcm);
+    st.d_vm = (1.0f / pdf_fwd) * (st.d_vm * pdf_rev + 0.0f);
+    st.d_vcm = 1.0f / pdf_fwd;
+    st.ray_o = ms.pos;
+    st.ray_d = w_o_medium;
+    st.ray_tmax = kMaxFloat;
+    st.ray_tmin = kRayEpsilon;
+    st.depth += 1u;
+    return (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
+  }
+  return vcm_next_ray(scene, kPathCamera, st, it, isect, bsdf_data, bs);
 }
 
 }  // namespace etxd

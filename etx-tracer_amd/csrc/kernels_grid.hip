@@ -43,7 +43,20 @@ __global__ __launch_bounds__(kBlockSize) void k_grid_bbox(Pipeline p) {
     lo.x = fminf(lo.x, __shfl_xor(lo.x, d)), lo.y = fminf(lo.y, __shfl_xor(lo.y, d)), lo.z = fminf(lo.z, __shfl_xor(lo.z, d));
     hi.x = fmaxf(hi.x, __shfl_xor(hi.x, d)), hi.y = fmaxf(hi.y, __shfl_xor(hi.y, d)), hi.z = fmaxf(hi.z, __shfl_xor(hi.z, d));
   }
-  if (((threadIdx.x & 63u) == 0u) && (lo.x <= hi.x)) {
+  // block level: the 4 waves meet in LDS, one lane per block issues the 6 atomics (they all hit the same 6 words)
+  __shared__ float s_box[kBlockSize / 64][6];
+  if ((threadIdx.x & 63u) == 0u) {
+    float* b = s_box[threadIdx.x >> 6];
+    b[0] = lo.x, b[1] = lo.y, b[2] = lo.z, b[3] = hi.x, b[4] = hi.y, b[5] = hi.z;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (uint32_t w = 1; w < kBlockSize / 64; ++w) {
+      lo = fmin3(lo, f3{s_box[w][0], s_box[w][1], s_box[w][2]});
+      hi = fmax3(hi, f3{s_box[w][3], s_box[w][4], s_box[w][5]});
+    }
+  }
+  if ((threadIdx.x == 0) && (lo.x <= hi.x)) {
     atomicMin(p.counters + kCntBboxMin + 0, float_to_ordered(lo.x));
     atomicMin(p.counters + kCntBboxMin + 1, float_to_ordered(lo.y));
     atomicMin(p.counters + kCntBboxMin + 2, float_to_ordered(lo.z));
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(kBlockSize) void k_grid_scatter(Pipeline p) {
 
 void launch_grid_build(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
   const uint32_t blocks = min(kPersistentBlocks, (p.capacity + kBlockSize - 1) / kBlockSize);
-  hipLaunchKernelGGL(k_grid_bbox, dim3(kPersistentBlocks), dim3(kBlockSize), 0, stream, p);
+  hipLaunchKernelGGL(k_grid_bbox, dim3(512), dim3(kBlockSize), 0, stream, p);
   hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(64), 0, stream, p, it);
   hipLaunchKernelGGL(k_grid_clear, dim3(kPersistentBlocks), dim3(kBlockSize), 0, stream, p);
   hipLaunchKernelGGL(k_grid_count, dim3(kPersistentBlocks), dim3(kBlockSize), 0, stream, p);
