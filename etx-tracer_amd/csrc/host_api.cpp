@@ -156,6 +156,8 @@ int allocate_pipeline(etx_hip_context* ctx) {
   if ((rc = device_alloc(ctx, p.cv.hit, n)) || (rc = device_alloc(ctx, p.cv.wi_medium, n)) || (rc = device_alloc(ctx, p.cv.thr_depth, n)) || (rc = device_alloc(ctx, p.cv.mis_pixel, n)) ||
       (rc = device_alloc(ctx, p.cv.seed, n)) || (rc = device_alloc(ctx, p.cv.pos_info, n)) || (rc = device_alloc(ctx, p.cv.nrm_dvm, n)) || (rc = device_alloc(ctx, p.cv.fthr_dvcm, n)))
     return rc;
+  if ((rc = device_alloc(ctx, p.merge_order, n)) || (rc = device_alloc(ctx, p.merge_buckets, kMergeBuckets + 1u)))
+    return rc;
   p.pair_capacity = uint32_t(std::min<uint64_t>(uint64_t(n) * 16u, 1ull << 30));
   if ((rc = device_alloc(ctx, p.pairs, p.pair_capacity)))
     return rc;
@@ -235,6 +237,8 @@ VcmParams make_iteration_params(const etx_hip_context* ctx, uint32_t iteration) 
   it.vc_weight = 1.0f / eta_vcm;
   it.vm_weight = (o.options & ETX_VCM_ENABLE_MERGING) ? eta_vcm : 0.0f;
   it.vm_normalization = 1.0f / eta_vcm;
+  if (const char* e = getenv("ETX_HIP_MERGE_DEBUG"))
+    it.pad0 = uint32_t(atoi(e));
   return it;
 }
 

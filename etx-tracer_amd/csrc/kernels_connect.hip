@@ -120,10 +120,133 @@ ETX_DEV bool merge_cell_range(const Pipeline& p, const GridParams& g, const f3& 
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cell-ordered merge. After the first bounce camera vertices are spatially random, so every (vertex, cell) lane pulled
+// its photons from HBM (PMC: 42 GB per iteration, 22 % L2 hits). The vertices of a bounce are therefore counting-sorted
+// by a coarse spatial bucket (64^3 Morton-ordered blocks) and the merge walks them in that order, each XCD owning one
+// contiguous eighth of the list so that its private L2 sees a compact working set (PMC after: 13 GB, 59 % L2 hits).
+// Only indices are sorted (4 B per vertex).
+ETX_DEV uint32_t spread_bits_6(uint32_t v) {  // 6 bits -> every third bit
+  v &= 0x3fu;
+  v = (v | (v << 8u)) & 0x300fu;
+  v = (v | (v << 4u)) & 0x30c3u;
+  v = (v | (v << 2u)) & 0x9249u;
+  return v;
+}
+
+ETX_DEV uint32_t merge_bucket(const GridParams& g, const f3& pos) {
+  // coarse block coordinates: the scene extent maps to 64 blocks per axis
+  f3 ext = g.bbox_max - g.bbox_min;
+  float scale = float(1u << kMergeBucketBits) / fmaxf(fmaxf(ext.x, ext.y), fmaxf(ext.z, g.cell_size));
+  f3 q = (pos - g.bbox_min) * scale;
+  uint32_t x = min(uint32_t(fmaxf(q.x, 0.0f)), (1u << kMergeBucketBits) - 1u);
+  uint32_t y = min(uint32_t(fmaxf(q.y, 0.0f)), (1u << kMergeBucketBits) - 1u);
+  uint32_t z = min(uint32_t(fmaxf(q.z, 0.0f)), (1u << kMergeBucketBits) - 1u);
+  return spread_bits_6(x) | (spread_bits_6(y) << 1u) | (spread_bits_6(z) << 2u);
+}
+
+ETX_DEV bool merge_candidate(const Pipeline& p, const GridParams& g, uint32_t max_path_length, uint32_t vertex, f3& pos) {
+  const float4 pi = p.cv.pos_info[vertex];
+  const uint32_t info = __float_as_uint(pi.w);
+  pos = {pi.x, pi.y, pi.z};
+  if ((info & kCvMedium) || ((info >> 8u) + 1u > max_path_length))
+    return false;
+  return (pos.x >= g.bbox_min.x) && (pos.y >= g.bbox_min.y) && (pos.z >= g.bbox_min.z) && (pos.x <= g.bbox_max.x) && (pos.y <= g.bbox_max.y) && (pos.z <= g.bbox_max.z);
+}
+
+__global__ __launch_bounds__(kBlockSize) void k_merge_clear(Pipeline p) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= kMergeBuckets; i += gridDim.x * blockDim.x)
+    p.merge_buckets[i] = 0u;
+}
+
+__global__ __launch_bounds__(kBlockSize) void k_merge_count(Pipeline p) {
+  const GridParams g = *p.grid_params;
+  if ((g.valid == 0u) || (g.photon_count == 0u))
+    return;
+  const uint32_t count = min(p.counters[kCntCameraVertices], p.capacity);
+  const uint32_t max_path_length = p.scene->max_path_length;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    f3 pos;
+    if (merge_candidate(p, g, max_path_length, i, pos))
+      atomicAdd(p.merge_buckets + merge_bucket(g, pos), 1u);
+  }
+}
+
+// exclusive scan of the 2^18 bucket counters by one block: every thread owns 256 consecutive counters, read and written
+// as 64 uint4 so that a wave instruction moves 1 KiB
+__global__ __launch_bounds__(1024) void k_merge_scan(Pipeline p) {
+  __shared__ uint32_t s_part[1024];
+  constexpr uint32_t kPerThread = kMergeBuckets / 1024u;
+  uint4* mine = reinterpret_cast<uint4*>(p.merge_buckets + threadIdx.x * kPerThread);
+  uint32_t sum = 0;
+  for (uint32_t k = 0; k < kPerThread / 4u; ++k) {
+    uint4 v = mine[k];
+    sum += v.x + v.y + v.z + v.w;
+  }
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024u; d <<= 1) {
+    uint32_t t = (threadIdx.x >= d) ? s_part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    s_part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t running = s_part[threadIdx.x] - sum;
+  for (uint32_t k = 0; k < kPerThread / 4u; ++k) {
+    uint4 v = mine[k];
+    uint4 o;
+    o.x = running, running += v.x;
+    o.y = running, running += v.y;
+    o.z = running, running += v.z;
+    o.w = running, running += v.w;
+    mine[k] = o;
+  }
+  if (threadIdx.x == 1023u)
+    p.counters[kCntMergeVertices] = s_part[1023];
+}
+
+__global__ __launch_bounds__(kBlockSize) void k_merge_scatter(Pipeline p) {
+  const GridParams g = *p.grid_params;
+  if ((g.valid == 0u) || (g.photon_count == 0u))
+    return;
+  const uint32_t count = min(p.counters[kCntCameraVertices], p.capacity);
+  const uint32_t max_path_length = p.scene->max_path_length;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    f3 pos;
+    if (merge_candidate(p, g, max_path_length, i, pos))
+      p.merge_order[atomicAdd(p.merge_buckets + merge_bucket(g, pos), 1u)] = i;
+  }
+}
+
+// XCD-aware item range: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only), so XCD x walks
+// the x-th eighth of the sorted item list. (Handing out chunks dynamically from one cursor was measured 40 % slower.)
+#define ETX_XCD_RANGE_LOOP(ITEMS)                                                                    \
+  const uint32_t lane_ = threadIdx.x & 63u;                                                          \
+  const uint32_t xcd_ = blockIdx.x & 7u, local_block_ = blockIdx.x >> 3u, blocks_per_xcd_ = gridDim.x >> 3u; \
+  const uint32_t seg_ = (((ITEMS) + 7u) / 8u + 63u) & ~63u;                                          \
+  const uint32_t seg_begin_ = xcd_ * seg_, seg_end_ = min((ITEMS), seg_begin_ + seg_);              \
+  for (uint32_t base_ = seg_begin_ + local_block_ * blockDim.x + threadIdx.x - lane_; base_ < seg_end_; base_ += blocks_per_xcd_ * blockDim.x)
+
 // Diffuse camera vertices (the common case): everything the loop needs comes from five float4 of the vertex record.
+//
+// Work distribution: a wave takes 8 vertices x 8 cells = 64 photon ranges. Range lengths vary wildly (0..100+), so
+// instead of one lane looping over "its" range (PMC: ~16 % of the lanes active per load instruction) the 64 ranges are
+// flattened: an exclusive wave scan of the lengths gives every photon of the batch a global element index, lane l
+// processes elements l, l+64, ... and finds its range by a 6-step binary search over the scanned offsets
+// (ds_bpermute), reads that range's vertex record from LDS, and adds accepted contributions to the vertex'
+// accumulator with LDS float atomics. Every load instruction then serves 64 photons.
+struct MergeSlot {   // per range, in LDS
+  float4 pos_depth;  // vertex position, total_path_depth bits
+  float4 nrm_dvm;    // shading normal, d_vm
+  float4 wi_wcam;    // w_i, d_vcm * vc_weight
+  float4 fthr;       // albedo/pi * throughput, unused
+};
+
 __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmParams it) {
+  __shared__ MergeSlot s_slot[kBlockSize];
+  __shared__ float s_acc[kBlockSize / 64][8][4];
   const DScene& scene = *p.scene;
-  const uint32_t count = p.counters[kCntCameraVertices];
+  const uint32_t count = min(p.counters[kCntMergeVertices], p.capacity);
   const GridParams g = *p.grid_params;
   if ((g.valid == 0u) || (g.photon_count == 0u))
     return;
@@ -131,77 +254,114 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
   const bool use_mis = opt_enable_mis(it);
   const bool use_epan = it.kernel == ETX_VCM_KERNEL_EPANECHNIKOV;
   const uint32_t max_path_length = scene.max_path_length;
+  const uint32_t wave = threadIdx.x >> 6u;
+  MergeSlot* slots = s_slot + wave * 64u;
   unsigned long long examined = 0, merged_count = 0;
-  ETX_WAVE_LOOP(items) {
+  ETX_XCD_RANGE_LOOP(items) {
     const uint32_t item = base_ + lane_;
-    const uint32_t vertex = item >> 3u, c = item & 7u;
-    f3 merged = mk3(0.0f);
-    uint32_t pixel = 0;
-    if (item < items) {
+    const uint32_t c = item & 7u;
+    uint32_t range_begin = 0, range_len = 0, pixel = 0;
+    if (item < seg_end_) {
+      const uint32_t vertex = p.merge_order[item >> 3u];
       const float4 pi = p.cv.pos_info[vertex];
       const uint32_t info = __float_as_uint(pi.w);
       const uint32_t depth = info >> 8u;
-      uint32_t range_begin = 0, range_end = 0;
       const f3 pos = {pi.x, pi.y, pi.z};
+      uint32_t range_end = 0;
       if ((info & kCvDiffuse) && (depth + 1u <= max_path_length) && merge_cell_range(p, g, pos, c, range_begin, range_end) && (range_begin < range_end)) {
+        range_len = range_end - range_begin;
         const float4 nv = p.cv.nrm_dvm[vertex];
         const float4 wv = p.cv.wi_medium[vertex];
         const float4 fv = p.cv.fthr_dvcm[vertex];
-        pixel = __float_as_uint(p.cv.mis_pixel[vertex].w);
-        const f3 nrm = {nv.x, nv.y, nv.z}, w_i = {wv.x, wv.y, wv.z}, fthr = {fv.x, fv.y, fv.z};
-        const float d_vm = nv.w, w_camera_base = fv.w * it.vc_weight;
-        const f3 n_front = dot(nrm, w_i) < 0.0f ? nrm : -nrm;  // get_normal_frame, bsdf.hxx:37-40
-        const uint32_t max_photon_length = max_path_length - depth - 1u;
-        examined += range_end - range_begin;
-        for (uint32_t j0 = range_begin; j0 < range_end; j0 += 4u) {
-          // four independent position loads in flight per lane (the loop is latency bound)
-          float4 pl[4];
-#pragma unroll
-          for (uint32_t k = 0; k < 4u; ++k)
-            pl[k] = p.grid.pos_len[min(j0 + k, range_end - 1u)];
-#pragma unroll
-          for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t j = j0 + k;
-            const f3 d = f3{pl[k].x, pl[k].y, pl[k].z} - pos;
-            const float distance_squared = dot(d, d);
-            if ((j >= range_end) || (distance_squared > g.radius_squared) || (__float_as_uint(pl[k].w) > max_photon_length))
-              continue;
-            const float4 nd = p.grid.nrm_dvcm(j);
-            if (dot(nrm, f3{nd.x, nd.y, nd.z}) <= kEpsilon)
-              continue;
-            const float4 wd = p.grid.win_dvm(j);
-            const f3 wi = {wd.x, wd.y, wd.z};
-            const float cos_o = -dot(n_front, wi);  // DiffuseBSDF::evaluate(-wi), bsdf_various.hxx:97-106
-            if (cos_o <= kEpsilon)
-              continue;
-            const float pdf = kInvPi * cos_o;
-            // reverse_pdf: roles swapped, w_i' = wi, w_o' = -w_i (scene_bsdf.hxx:82-92 + bsdf_various.hxx:113-120)
-            const f3 n_rev = dot(nrm, wi) < 0.0f ? nrm : -nrm;
-            const float n_dot_o = -dot(n_rev, w_i);
-            const float rev_pdf = (n_dot_o <= kEpsilon) ? 0.0f : kInvPi * n_dot_o;
-            const float w_light = nd.w * it.vc_weight + wd.w * pdf;
-            const float w_camera = w_camera_base + d_vm * rev_pdf;
-            const float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;
-            const float kernel_weight = use_epan ? fmaxf(2.0f * (1.0f - distance_squared * g.inv_radius_squared), 0.0f) : 1.0f;
-            const float4 lt = p.grid.thr(j);
-            merged += (fthr * f3{lt.x, lt.y, lt.z}) * (kernel_weight * weight);
-            merged_count++;
-          }
-        }
+        slots[lane_].pos_depth = make_float4(pi.x, pi.y, pi.z, __uint_as_float(depth));
+        slots[lane_].nrm_dvm = nv;
+        slots[lane_].wi_wcam = make_float4(wv.x, wv.y, wv.z, fv.w * it.vc_weight);
+        slots[lane_].fthr = fv;
       }
+      if (c == 0u)
+        pixel = __float_as_uint(p.cv.mis_pixel[vertex].w);
     }
-    // fold the 8 cells of a vertex (lanes 8k .. 8k+7); all lanes of the wave take part
+    if (lane_ < 32u)
+      (&s_acc[wave][0][0])[lane_] = 0.0f;
+    // exclusive scan of the range lengths
+    uint32_t incl = range_len;
 #pragma unroll
-    for (uint32_t d = 1; d < 8; d <<= 1) {
-      merged.x += __shfl_xor(merged.x, d);
-      merged.y += __shfl_xor(merged.y, d);
-      merged.z += __shfl_xor(merged.z, d);
-      pixel = max(pixel, uint32_t(__shfl_xor(int(pixel), d)));
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      uint32_t t = __shfl_up(incl, d);
+      if (lane_ >= d)
+        incl += t;
     }
-    if (((lane_ & 7u) == 0u) && ((merged.x != 0.0f) || (merged.y != 0.0f) || (merged.z != 0.0f)))
-      atomic_add_f3(p.camera_sum + film_index(it, pixel), merged * it.vm_normalization);
+    const uint32_t total = __shfl(incl, 63);
+    const uint32_t offset = incl - range_len;
+    __threadfence_block();  // slots / accumulators written before any lane of this wave reads them
+    if (lane_ == 0)
+      examined += total;
+    for (uint32_t e0 = 0; (e0 < total) && (it.pad0 != 1u); e0 += 64u) {
+      const uint32_t e = e0 + lane_;
+      // binary search: last range r with offset[r] <= e
+      uint32_t r = 0;
+#pragma unroll
+      for (uint32_t step = 32u; step > 0u; step >>= 1u) {
+        const uint32_t cand = r + step;
+        const uint32_t o = __shfl(offset, cand & 63u);
+        if (o <= e)
+          r = cand;
+      }
+      const uint32_t r_begin = __shfl(range_begin, r);
+      const uint32_t r_offset = __shfl(offset, r);
+      if (e >= total)
+        continue;
+      const uint32_t j = r_begin + (e - r_offset);
+      const float4 pl = p.grid.pos_len[j];
+      const MergeSlot& sl = slots[r];
+      const float4 sp = sl.pos_depth;
+      const f3 d = f3{pl.x, pl.y, pl.z} - f3{sp.x, sp.y, sp.z};
+      const float distance_squared = dot(d, d);
+      if ((distance_squared > g.radius_squared) || (__float_as_uint(pl.w) + __float_as_uint(sp.w) + 1u > max_path_length))
+        continue;
+      if (it.pad0 == 2u)
+        continue;
+      const float4 nv = sl.nrm_dvm;
+      const f3 nrm = {nv.x, nv.y, nv.z};
+      const float4 nd = p.grid.nrm_dvcm(j);
+      if (dot(nrm, f3{nd.x, nd.y, nd.z}) <= kEpsilon)
+        continue;
+      const float4 wv = sl.wi_wcam;
+      const f3 w_i = {wv.x, wv.y, wv.z};
+      const float4 wd = p.grid.win_dvm(j);
+      const f3 wi = {wd.x, wd.y, wd.z};
+      const f3 n_front = dot(nrm, w_i) < 0.0f ? nrm : -nrm;  // get_normal_frame, bsdf.hxx:37-40
+      const float cos_o = -dot(n_front, wi);                 // DiffuseBSDF::evaluate(-wi), bsdf_various.hxx:97-106
+      if (cos_o <= kEpsilon)
+        continue;
+      const float pdf = kInvPi * cos_o;
+      // reverse_pdf: roles swapped, w_i' = wi, w_o' = -w_i (scene_bsdf.hxx:82-92 + bsdf_various.hxx:113-120)
+      const f3 n_rev = dot(nrm, wi) < 0.0f ? nrm : -nrm;
+      const float n_dot_o = -dot(n_rev, w_i);
+      const float rev_pdf = (n_dot_o <= kEpsilon) ? 0.0f : kInvPi * n_dot_o;
+      const float w_light = nd.w * it.vc_weight + wd.w * pdf;
+      const float w_camera = wv.w + nv.w * rev_pdf;
+      const float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;
+      const float kernel_weight = use_epan ? fmaxf(2.0f * (1.0f - distance_squared * g.inv_radius_squared), 0.0f) : 1.0f;
+      const float4 lt = p.grid.thr(j);
+      const float4 fv = sl.fthr;
+      const float k = kernel_weight * weight;
+      float* acc = s_acc[wave][r >> 3u];
+      atomicAdd(acc + 0, fv.x * lt.x * k);
+      atomicAdd(acc + 1, fv.y * lt.y * k);
+      atomicAdd(acc + 2, fv.z * lt.z * k);
+      merged_count++;
+    }
+    __threadfence_block();
+    if (((lane_ & 7u) == 0u) && (item < seg_end_)) {
+      const float* acc = s_acc[wave][lane_ >> 3u];
+      const f3 merged = {acc[0], acc[1], acc[2]};
+      if ((merged.x != 0.0f) || (merged.y != 0.0f) || (merged.z != 0.0f))
+        atomic_add_f3(p.camera_sum + film_index(it, pixel), merged * it.vm_normalization);
+    }
+    __threadfence_block();  // accumulators are zeroed again at the top of the next batch
   }
-  if (examined) {
+  if (examined | merged_count) {
     atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsExamined), examined);
     atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsMerged), merged_count);
   }
@@ -210,7 +370,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
 // Every other connectible material: generic BSDF evaluation per accepted photon (stochastic for rough conductors).
 __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmParams it) {
   const DScene& scene = *p.scene;
-  const uint32_t count = p.counters[kCntCameraVertices];
+  const uint32_t count = min(p.counters[kCntMergeVertices], p.capacity);
   const GridParams g = *p.grid_params;
   if ((g.valid == 0u) || (g.photon_count == 0u))
     return;
@@ -218,12 +378,13 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
   const bool use_mis = opt_enable_mis(it);
   const bool use_epan = it.kernel == ETX_VCM_KERNEL_EPANECHNIKOV;
   unsigned long long examined = 0, merged_count = 0;
-  ETX_WAVE_LOOP(items) {
+  ETX_XCD_RANGE_LOOP(items) {
     const uint32_t item = base_ + lane_;
-    const uint32_t vertex = item >> 3u, c = item & 7u;
+    const uint32_t c = item & 7u;
     f3 merged = mk3(0.0f);
     uint32_t pixel = 0;
-    if (item < items) {
+    if (item < seg_end_) {
+      const uint32_t vertex = p.merge_order[item >> 3u];
       const uint32_t info = __float_as_uint(p.cv.pos_info[vertex].w);
       if ((info & (kCvDiffuse | kCvMedium)) == 0u) {
         CameraVertex cv = load_camera_vertex(p, scene, vertex);
@@ -279,7 +440,13 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
 }
 
 void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items) {
-  const uint32_t blocks = max(1u, grid_for(uint32_t(min(uint64_t(min(max_items, p.capacity)) * 8ull, 0xffffff00ull))));
+  const uint32_t vertex_blocks = max(1u, grid_for(min(max_items, p.capacity)));
+  hipLaunchKernelGGL(k_merge_clear, dim3(256), dim3(kBlockSize), 0, stream, p);
+  hipLaunchKernelGGL(k_merge_count, dim3(vertex_blocks), dim3(kBlockSize), 0, stream, p);
+  hipLaunchKernelGGL(k_merge_scan, dim3(1), dim3(1024), 0, stream, p);
+  hipLaunchKernelGGL(k_merge_scatter, dim3(vertex_blocks), dim3(kBlockSize), 0, stream, p);
+  // a multiple of 8 workgroups: one eighth of the sorted list per XCD
+  const uint32_t blocks = max(8u, (grid_for(uint32_t(min(uint64_t(min(max_items, p.capacity)) * 8ull, 0xffffff00ull))) + 7u) & ~7u);
   hipLaunchKernelGGL(k_merge_diffuse, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
   if (generic_materials)
     hipLaunchKernelGGL(k_merge_generic, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);

@@ -22,6 +22,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene* __re
     counters[kCntCameraVertices] = 0u;
     counters[kCntPairs] = 0u;
     counters[kCntShadow] = 0u;
+    counters[kCntMergeVertices] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
   }
   const uint32_t lane = threadIdx.x & 63u;

@@ -89,6 +89,8 @@ struct ShadowQueue {        // transmittance ("shadow") ray requests of the curr
 };
 
 constexpr uint32_t kShadowTargetLight = 0x80000000u;
+constexpr uint32_t kMergeBucketBits = 6;                                  // per axis
+constexpr uint32_t kMergeBuckets = 1u << (3u * kMergeBucketBits);         // 64^3 coarse buckets
 
 enum : uint32_t {  // device counters (u32), cleared per iteration unless noted
   kCntActiveA = 0,
@@ -99,7 +101,8 @@ enum : uint32_t {  // device counters (u32), cleared per iteration unless noted
   kCntBboxMin = 5,          // 3 x ordered-int float min
   kCntBboxMax = 8,          // 3 x ordered-int float max
   kCntPairs = 11,
-  kCntShadow = 12,          // shadow requests of the current bounce, cleared per bounce           // (camera vertex, light vertex) pairs of the current bounce, cleared per bounce
+  kCntShadow = 12,
+  kCntMergeVertices = 13,   // camera vertices of the current bounce that take part in the merge          // shadow requests of the current bounce, cleared per bounce           // (camera vertex, light vertex) pairs of the current bounce, cleared per bounce
   kCntStatsBase = 16,
   kStatRaysExtension = 16,
   kStatRaysShadow = 18,
@@ -150,6 +153,8 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   GridParams* grid_params;
   CameraVertexPool cv;
   ShadowQueue shadow;
+  uint32_t* merge_order;       // camera vertex slots of the current bounce sorted by coarse spatial bucket (k_merge_*)
+  uint32_t* merge_buckets;     // kMergeBuckets + 1 counters / offsets
   uint2* pairs;          // (camera vertex slot, light vertex index) of the current bounce
   uint32_t pair_capacity;
   float4* camera_sum;
