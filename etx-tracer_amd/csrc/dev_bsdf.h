@@ -634,6 +634,71 @@ ETX_DEV float bsdf_reverse_pdf(const DScene& s, const BsdfData& in_d, const f3& 
   return bsdf_pdf(s, d, w_o, m);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// "Simple material" instantiation of the dispatch. Scenes whose only non-diffuse surfaces are perfect mirrors
+// (Mirror, Conductor with roughness exactly 0) - Cornell is one - never need the Heitz random walk: with alpha = 0 the
+// walk of ConductorBSDF::sample (bsdf_conductor.hxx:13-70) deterministically reflects about the shading normal after one
+// microsurface interaction (height sample leaves the surface with probability 1, bsdf_external.hxx:76-104), the weight
+// is the Fresnel term of the macro normal and the "pdf" is the same D_ggx expression. Keeping the walk and the
+// stochastic evaluation out of the shade kernels halves their register count (2 -> 4 waves per SIMD).
+ETX_DEV BsdfSample conductor_sample_delta(const DScene& s, const BsdfData& d, const etx_abi_material& m) {
+  Frame frame = normal_frame(d);
+  f3 w_i = frame.to_local(-d.w_i);
+  Ior ext_ior = evaluate_refractive_index(s, m.ext_ior);
+  Ior int_ior = evaluate_refractive_index(s, m.int_ior);
+  BsdfSample r = sample_zero();
+  r.properties = kSampleReflection | kSampleDelta;
+  r.medium_index = d.medium;
+  r.eta = 1.0f;
+  f3 local_w_o = {-w_i.x, -w_i.y, w_i.z};  // -wi + 2 wm (wi . wm) with wm = (0, 0, 1)
+  r.weight = fresnel_calculate(w_i.z, ext_ior, int_ior) * apply_image(s, m.reflectance, d.tex, nullptr);
+  r.pdf = conductor_pdf_local(w_i, local_w_o, f2{0.0f, 0.0f});
+  r.w_o = normalize(frame.from_local(local_w_o));
+  return r;
+}
+
+template <bool kSimple>
+ETX_DEV BsdfSample bsdf_sample_s(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
+  if (kSimple && (m.cls == ETX_MAT_CONDUCTOR))
+    return conductor_sample_delta(s, d, m);
+  return bsdf_sample(s, d, m, smp);
+}
+template <bool kSimple>
+ETX_DEV BsdfEval bsdf_evaluate_s(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
+  if (kSimple) {  // delta conductors are never evaluated (only connectible vertices are)
+    switch (m.cls) {
+      case ETX_MAT_DIFFUSE:
+        return diffuse_evaluate(s, d, w_o, m);
+      case ETX_MAT_TRANSLUCENT:
+        return translucent_evaluate(s, d, w_o, m);
+      default:
+        return eval_zero();
+    }
+  }
+  return bsdf_evaluate(s, d, w_o, m, smp);
+}
+template <bool kSimple>
+ETX_DEV float bsdf_pdf_s(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m) {
+  if (kSimple) {
+    switch (m.cls) {
+      case ETX_MAT_DIFFUSE:
+        return diffuse_pdf(d, w_o);
+      case ETX_MAT_TRANSLUCENT:
+        return translucent_pdf(s, d, w_o, m);
+      default:
+        return 0.0f;
+    }
+  }
+  return bsdf_pdf(s, d, w_o, m);
+}
+template <bool kSimple>
+ETX_DEV float bsdf_reverse_pdf_s(const DScene& s, const BsdfData& in_d, const f3& in_w_o, const etx_abi_material& m) {
+  BsdfData d = in_d;
+  f3 w_o = -in_d.w_i;
+  d.w_i = -in_w_o;
+  return bsdf_pdf_s<kSimple>(s, d, w_o, m);
+}
+
 // classes the device path implements (checked by the host at upload)
 ETX_HD bool bsdf_class_supported(uint32_t cls) {
   return (cls == ETX_MAT_DIFFUSE) || (cls == ETX_MAT_TRANSLUCENT) || (cls == ETX_MAT_CONDUCTOR) || (cls == ETX_MAT_MIRROR) || (cls == ETX_MAT_BOUNDARY) || (cls == ETX_MAT_VOID);

@@ -114,6 +114,7 @@ ETX_DEV void push_shadow(const Pipeline& p, const f3& p0, const f3& p1, uint32_t
 }
 
 // vcm_shared.hxx:218-283 vcm_next_ray
+template <bool kSimple>
 ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& st, const VcmParams& it, const Isect& isect, const BsdfData& bsdf_data, const BsdfSample& bs) {
   if (st.depth + 1 > scene.max_path_length)
     return false;
@@ -136,7 +137,7 @@ ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& 
     st.d_vm *= cos_theta_bsdf;
     st.d_vcm = 0.0f;
   } else {
-    float rev_pdf = bsdf_reverse_pdf(scene, bsdf_data, bs.w_o, mat);
+    float rev_pdf = bsdf_reverse_pdf_s<kSimple>(scene, bsdf_data, bs.w_o, mat);
     st.d_vc = (cos_theta_bsdf / bs.pdf) * (st.d_vc * rev_pdf + st.d_vcm + it.vm_weight);
     st.d_vm = (cos_theta_bsdf / bs.pdf) * (st.d_vm * rev_pdf + st.d_vcm * it.vc_weight + 1.0f);
     st.d_vcm = 1.0f / bs.pdf;
@@ -167,6 +168,7 @@ ETX_DEV bool vcm_handle_boundary(const DScene& scene, const Isect& isect, PathSt
 
 // vcm_shared.hxx:463-535 vcm_connect_to_camera, minus the transmittance: queues the segment, the splat value
 // (vcm_cpu.cxx:148-153) is completed by k_trace_shadow.
+template <bool kSimple>
 ETX_DEV void vcm_connect_to_camera(const Pipeline& p, const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st) {
   if ((opt_connect_to_camera(it) == false) || (st.depth + 2 > scene.max_path_length) || (st.depth + 2 < scene.min_path_length))
     return;
@@ -185,11 +187,11 @@ ETX_DEV void vcm_connect_to_camera(const Pipeline& p, const DScene& scene, const
   if (camera_at_medium == false) {
     const etx_abi_material& mat = scene.materials[isect->material];
     BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathLight);
-    BsdfEval eval = bsdf_evaluate(scene, data, w_o, mat, st.sampler);
+    BsdfEval eval = bsdf_evaluate_s<kSimple>(scene, data, w_o, mat, st.sampler);
     if (eval.valid() == false)
       return;
     scatter = eval.bsdf;
-    reverse_pdf = bsdf_reverse_pdf(scene, data, w_o, mat);
+    reverse_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, w_o, mat);
     origin = shading_pos(scene, scene.triangles[isect->tri], isect->bc, w_o);
   } else {
     const DMedium& medium = scene.mediums[st.medium];
@@ -273,6 +275,7 @@ ETX_DEV f3 vcm_cam_handle_miss(const DScene& scene, const VcmParams& it, PathSta
 
 // vcm_shared.hxx:608-671 vcm_connect_to_light (NEE) minus the transmittance (queued for k_trace_shadow).
 // sampler.fixed_* hold (rnd_connection.xy, rnd_support.y). `film_target` = film index of the path's pixel.
+template <bool kSimple>
 ETX_DEV void vcm_connect_to_light(const Pipeline& p, const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st, uint32_t film_target) {
   if ((opt_connect_to_light(it) == false) || (st.depth + 1 > scene.max_path_length) || (st.depth + 1 < scene.min_path_length))
     return;
@@ -297,15 +300,15 @@ ETX_DEV void vcm_connect_to_light(const Pipeline& p, const DScene& scene, const 
   } else {
     const etx_abi_material& mat = scene.materials[isect->material];
     BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathCamera);
-    BsdfEval eval = bsdf_evaluate(scene, data, w_o, mat, st.sampler);
+    BsdfEval eval = bsdf_evaluate_s<kSimple>(scene, data, w_o, mat, st.sampler);
     if (eval.valid() == false)
       return;
     scatter = eval.bsdf;
-    reverse_pdf = bsdf_reverse_pdf(scene, data, w_o, mat);
+    reverse_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, w_o, mat);
     const etx_abi_triangle& tri = scene.triangles[isect->tri];
     origin = shading_pos(scene, tri, isect->bc, normalize(es.origin - isect->pos));
     camera_factor = fabsf(dot(w_o, ld3(tri.geo_n)));
-    conn_pdf = bsdf_pdf(scene, data, w_o, mat);
+    conn_pdf = bsdf_pdf_s<kSimple>(scene, data, w_o, mat);
   }
   float l_dot_e = fabsf(dot(es.direction, es.normal));
   float w_light = 0.0f;

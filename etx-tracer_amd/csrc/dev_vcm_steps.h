@@ -64,6 +64,7 @@ enum : uint32_t { kEventNone = 0, kEventMedium = 1, kEventSurface = 2, kEventBou
 //   A  classify the event, draw the randoms, update the MIS quantities at the vertex, sample the BSDF
 //   B  store the light vertex, connect it to the camera (same code for medium and surface vertices)
 //   C  continue the path (phase function / vcm_next_ray, Russian roulette)
+template <bool kSimple>
 ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h) {
   const uint32_t tri = __float_as_uint(h.w);
   const bool found = tri != kInvalid;
@@ -107,7 +108,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
     const etx_abi_material& mat = scene.materials[isect.material];
     bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight);
     st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
-    bs = bsdf_sample(scene, bsdf_data, mat, st.sampler);
+    bs = bsdf_sample_s<kSimple>(scene, bsdf_data, mat, st.sampler);
     st.sampler.pop_fixed();
     // vcm_update_light_vcm, vcm_shared.hxx:451-461
     if ((st.depth > 0u) || (st.flags & kPathLocalEmitter))
@@ -130,7 +131,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
   }
   if (connect) {
     st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-    vcm_connect_to_camera(p, scene, it, at_medium, &isect, ms.pos, st);
+    vcm_connect_to_camera<kSimple>(p, scene, it, at_medium, &isect, ms.pos, st);
     st.sampler.pop_fixed();
   }
 
@@ -151,7 +152,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
     st.depth += 1u;
     return (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
   }
-  if (vcm_next_ray(scene, kPathLight, st, it, isect, bsdf_data, bs))
+  if (vcm_next_ray<kSimple>(scene, kPathLight, st, it, isect, bsdf_data, bs))
     return st.depth + 1u < scene.max_path_length;
   return false;
 }
@@ -159,6 +160,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
 // vcm_camera_step, vcm_shared.hxx:927-1079 after rt.trace, without the vertex connections and the merge: connectible
 // vertices go to the camera vertex pool (k_expand_pairs / k_connect_pairs / k_merge consume them), NEE segments go to
 // the shadow queue, direct / miss radiance goes straight to the film. Same three-phase shape as light_step.
+template <bool kSimple>
 ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h) {
   const uint32_t tri = __float_as_uint(h.w);
   const bool found = tri != kInvalid;
@@ -214,7 +216,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
     const etx_abi_material& mat = scene.materials[isect.material];
     bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera);
     st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
-    bs = bsdf_sample(scene, bsdf_data, mat, st.sampler);
+    bs = bsdf_sample_s<kSimple>(scene, bsdf_data, mat, st.sampler);
     st.sampler.pop_fixed();
     const bool is_connectible = (bs.properties & kSampleDelta) == 0u;
 
@@ -246,7 +248,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
   }
   if (nee) {
     st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-    vcm_connect_to_light(p, scene, it, at_medium, &isect, ms.pos, st, film_index(it, st.id));
+    vcm_connect_to_light<kSimple>(p, scene, it, at_medium, &isect, ms.pos, st, film_index(it, st.id));
     st.sampler.pop_fixed();
   }
 
@@ -262,7 +264,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
     st.depth += 1u;
     return (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
   }
-  return vcm_next_ray(scene, kPathCamera, st, it, isect, bsdf_data, bs);
+  return vcm_next_ray<kSimple>(scene, kPathCamera, st, it, isect, bsdf_data, bs);
 }
 
 }  // namespace etxd

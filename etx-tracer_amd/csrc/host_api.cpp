@@ -156,7 +156,7 @@ int allocate_pipeline(etx_hip_context* ctx) {
   if ((rc = device_alloc(ctx, p.cv.hit, n)) || (rc = device_alloc(ctx, p.cv.wi_medium, n)) || (rc = device_alloc(ctx, p.cv.thr_depth, n)) || (rc = device_alloc(ctx, p.cv.mis_pixel, n)) ||
       (rc = device_alloc(ctx, p.cv.seed, n)) || (rc = device_alloc(ctx, p.cv.pos_info, n)) || (rc = device_alloc(ctx, p.cv.nrm_dvm, n)) || (rc = device_alloc(ctx, p.cv.fthr_dvcm, n)))
     return rc;
-  if ((rc = device_alloc(ctx, p.merge_order, n)) || (rc = device_alloc(ctx, p.merge_buckets, kMergeBuckets + 1u)))
+  if ((rc = device_alloc(ctx, p.merge_order, n)) || (rc = device_alloc(ctx, p.merge_buckets, kMergeBuckets + 1u + 256u)))
     return rc;
   p.pair_capacity = uint32_t(std::min<uint64_t>(uint64_t(n) * 16u, 1ull << 30));
   if ((rc = device_alloc(ctx, p.pairs, p.pair_capacity)))
@@ -237,8 +237,6 @@ VcmParams make_iteration_params(const etx_hip_context* ctx, uint32_t iteration) 
   it.vc_weight = 1.0f / eta_vcm;
   it.vm_weight = (o.options & ETX_VCM_ENABLE_MERGING) ? eta_vcm : 0.0f;
   it.vm_normalization = 1.0f / eta_vcm;
-  if (const char* e = getenv("ETX_HIP_MERGE_DEBUG"))
-    it.pad0 = uint32_t(atoi(e));
   return it;
 }
 
@@ -254,7 +252,7 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
     for (uint32_t k = 0; k < ctx->check_interval; ++k, ++round) {
       {
         ScopedTimer t(ctx, kTimerTraceClosest);
-        launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB, known_count);
+        launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB, known_count, ctx->scene.host_copy.bvh_flat != 0u);
       }
       shade(set, known_count);
       set ^= 1u;
@@ -291,21 +289,21 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
     [&](uint32_t set, uint32_t max_items) {
       {
         ScopedTimer t(ctx, kTimerShadeLight);
-        launch_light_shade(s, p, it, set, max_items);
+        launch_light_shade(s, p, it, set, max_items, ctx->scene.simple_materials);
       }
       if (opt_connect_to_camera(it)) {
         ScopedTimer t(ctx, kTimerTraceShadow);
-        launch_trace_shadow(s, p, max_items);
+        launch_trace_shadow(s, p, max_items, ctx->scene.host_copy.bvh_flat != 0u);
       }
     },
     [&](uint32_t set, uint32_t max_items) {
       {
         ScopedTimer t(ctx, kTimerShadeLight);
-        launch_light_tail(s, p, it, set, max_items);
+        launch_light_tail(s, p, it, set, max_items, ctx->scene.simple_materials);
       }
       if (opt_connect_to_camera(it)) {
         ScopedTimer t(ctx, kTimerTraceShadow);
-        launch_trace_shadow(s, p, p.shadow.capacity);
+        launch_trace_shadow(s, p, p.shadow.capacity, ctx->scene.host_copy.bvh_flat != 0u);
       }
     },
     rounds);
@@ -329,7 +327,7 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
     [&](uint32_t set, uint32_t max_items) {
       {
         ScopedTimer t(ctx, kTimerShadeCamera);
-        launch_camera_shade(s, p, it, set, max_items);
+        launch_camera_shade(s, p, it, set, max_items, ctx->scene.simple_materials);
       }
       if (opt_connect_vertices(it)) {
         ScopedTimer t(ctx, kTimerConnect);
@@ -337,7 +335,7 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
       }
       if (opt_connect_vertices(it) || opt_connect_to_light(it)) {
         ScopedTimer t(ctx, kTimerTraceShadow);
-        launch_trace_shadow(s, p, uint32_t(std::min<uint64_t>(uint64_t(max_items) * 6ull, 0xffffffffull)));
+        launch_trace_shadow(s, p, uint32_t(std::min<uint64_t>(uint64_t(max_items) * 6ull, 0xffffffffull)), ctx->scene.host_copy.bvh_flat != 0u);
       }
       if (opt_merge_vertices(it)) {
         ScopedTimer t(ctx, kTimerMerge);
@@ -347,7 +345,7 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
     [&](uint32_t set, uint32_t max_items) {
       {
         ScopedTimer t(ctx, kTimerShadeCamera);
-        launch_camera_tail(s, p, it, set, max_items);
+        launch_camera_tail(s, p, it, set, max_items, ctx->scene.simple_materials);
       }
       // the tail leaves up to `capacity` camera vertices: drain them with one launch of each consumer
       if (opt_connect_vertices(it)) {
@@ -356,7 +354,7 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
       }
       if (opt_connect_vertices(it) || opt_connect_to_light(it)) {
         ScopedTimer t(ctx, kTimerTraceShadow);
-        launch_trace_shadow(s, p, p.shadow.capacity);
+        launch_trace_shadow(s, p, p.shadow.capacity, ctx->scene.host_copy.bvh_flat != 0u);
       }
       if (opt_merge_vertices(it)) {
         ScopedTimer t(ctx, kTimerMerge);
@@ -693,7 +691,7 @@ int etx_hip_trace_rays(etx_hip_context* context, const float* rays_8f, uint64_t 
       rc = ETX_HIP_ERROR_HIP;
       break;
     }
-    launch_trace_rays(context->stream, context->scene.device, d_o, d_d, d_h, uint32_t(count));
+    launch_trace_rays(context->stream, context->scene.device, d_o, d_d, d_h, uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
     if ((hipMemcpyAsync(hits_4f, d_h, count * sizeof(float4), hipMemcpyDeviceToHost, context->stream) != hipSuccess) || (hipStreamSynchronize(context->stream) != hipSuccess)) {
       context->error = std::string("trace kernel failed: ") + hipGetErrorString(hipGetLastError());
       rc = ETX_HIP_ERROR_HIP;
@@ -718,11 +716,11 @@ int etx_hip_trace_rays_device(etx_hip_context* context, const void* d_rays_o_tmi
   HIP_OK(context, hipEventCreate(&e1));
   // one untimed launch (code object load, caches)
   launch_trace_rays(context->stream, context->scene.device, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
-    reinterpret_cast<float4*>(d_hits), uint32_t(count));
+    reinterpret_cast<float4*>(d_hits), uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
   HIP_OK(context, hipEventRecord(e0, context->stream));
   for (uint32_t r = 0; r < repeat; ++r)
     launch_trace_rays(context->stream, context->scene.device, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
-      reinterpret_cast<float4*>(d_hits), uint32_t(count));
+      reinterpret_cast<float4*>(d_hits), uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
   HIP_OK(context, hipEventRecord(e1, context->stream));
   HIP_OK(context, hipEventSynchronize(e1));
   float ms = 0.0f;

@@ -283,6 +283,7 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     }
   }
   out.generic_materials = false;
+  out.simple_materials = true;
   for (uint64_t i = 0; i < scene->materials.count; ++i) {
     if (used[i] == false)
       continue;
@@ -292,6 +293,9 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
                            (std::max(m.roughness.value.x, m.roughness.value.y) <= kDeltaAlphaTreshold);
     if ((m.cls == ETX_MAT_TRANSLUCENT) || ((m.cls == ETX_MAT_CONDUCTOR) && (delta_conductor == false)))
       out.generic_materials = true;
+    bool mirror_conductor = (m.cls == ETX_MAT_CONDUCTOR) && (m.roughness.image_index == ETX_ABI_INVALID) && (m.roughness.value.x == 0.0f) && (m.roughness.value.y == 0.0f);
+    if ((m.cls == ETX_MAT_CONDUCTOR) && (mirror_conductor == false))
+      out.simple_materials = false;
   }
   for (uint64_t i = 0; i < scene->mediums.count; ++i) {
     if (mediums[i].cls != 0) {
@@ -398,6 +402,8 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   d.bvh_node_count = uint32_t(bvh.nodes.size());
   d.bvh_tri_count = uint32_t(bvh.tris.size());
   d.bvh_root = bvh.root;
+  if (const char* e = getenv("ETX_HIP_FORCE_GENERIC_MATERIALS"))
+    out.simple_materials = (atoi(e) != 0) ? false : out.simple_materials;
   d.bvh_flat = (bvh.tris.size() <= kFlatSweepMaxTriangles) ? 1u : 0u;
   if (const char* e = getenv("ETX_HIP_FORCE_BVH"))
     d.bvh_flat = (atoi(e) != 0) ? 0u : d.bvh_flat;

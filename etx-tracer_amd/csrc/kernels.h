@@ -11,25 +11,25 @@ constexpr uint32_t kPersistentBlocks = 256 * 8;  // 256 CUs x 8 blocks of 256 th
 
 // traversal
 // `max_items`: host-side upper bound of the device-resident item count (sizes the grid; kernels grid-stride anyway)
-void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items);
-void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_items);
-void launch_trace_rays(hipStream_t stream, const DScene* scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count);
+void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat);
+void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_items, bool flat);
+void launch_trace_rays(hipStream_t stream, const DScene* scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count, bool flat);
 
 // VCM light pass
 void launch_iteration_reset(hipStream_t stream, const Pipeline& p);
 void launch_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
-void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items);
+void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);
 
 // tail: the few paths that are still alive after many bounces finish inside one launch (kernels_tail.hip)
-void launch_light_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items);
-void launch_camera_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items);
+void launch_light_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);
+void launch_camera_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);
 
 // photon grid
 void launch_grid_build(hipStream_t stream, const Pipeline& p, const VcmParams& it);
 
 // VCM camera pass
 void launch_camera_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
-void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items);
+void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);
 void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items);
 void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items);
 

@@ -172,37 +172,66 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_count(Pipeline p) {
   }
 }
 
-// exclusive scan of the 2^18 bucket counters by one block: every thread owns 256 consecutive counters, read and written
-// as 64 uint4 so that a wave instruction moves 1 KiB
-__global__ __launch_bounds__(1024) void k_merge_scan(Pipeline p) {
-  __shared__ uint32_t s_part[1024];
-  constexpr uint32_t kPerThread = kMergeBuckets / 1024u;
-  uint4* mine = reinterpret_cast<uint4*>(p.merge_buckets + threadIdx.x * kPerThread);
-  uint32_t sum = 0;
-  for (uint32_t k = 0; k < kPerThread / 4u; ++k) {
-    uint4 v = mine[k];
-    sum += v.x + v.y + v.z + v.w;
+// Exclusive scan of the 2^18 bucket counters in two small launches (one block over 1 MiB took 96 us per bounce):
+// kMergeScanBlocks workgroups of 256 threads, one uint4 per thread; the first launch leaves every workgroup's total
+// behind the counters, the second scans those totals in LDS (every workgroup redundantly) and then its own 1024 counters.
+constexpr uint32_t kMergeScanBlocks = kMergeBuckets / (4u * kBlockSize);
+static_assert(kMergeScanBlocks <= kBlockSize, "group totals are scanned by one workgroup-wide pass");
+
+ETX_DEV uint32_t block_exclusive_scan(uint32_t value, uint32_t* s_wave_sums, uint32_t& block_total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6u;
+  uint32_t incl = value;
+#pragma unroll
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(incl, d);
+    if (lane >= d)
+      incl += t;
   }
-  s_part[threadIdx.x] = sum;
+  if (lane == 63u)
+    s_wave_sums[wave] = incl;
   __syncthreads();
-  for (uint32_t d = 1; d < 1024u; d <<= 1) {
-    uint32_t t = (threadIdx.x >= d) ? s_part[threadIdx.x - d] : 0u;
-    __syncthreads();
-    s_part[threadIdx.x] += t;
-    __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kBlockSize / 64u; ++w) {
+    const uint32_t ws = s_wave_sums[w];
+    before += (w < wave) ? ws : 0u;
+    total += ws;
   }
-  uint32_t running = s_part[threadIdx.x] - sum;
-  for (uint32_t k = 0; k < kPerThread / 4u; ++k) {
-    uint4 v = mine[k];
-    uint4 o;
-    o.x = running, running += v.x;
-    o.y = running, running += v.y;
-    o.z = running, running += v.z;
-    o.w = running, running += v.w;
-    mine[k] = o;
-  }
-  if (threadIdx.x == 1023u)
-    p.counters[kCntMergeVertices] = s_part[1023];
+  __syncthreads();
+  block_total = total;
+  return before + incl - value;
+}
+
+__global__ __launch_bounds__(kBlockSize) void k_merge_scan_totals(Pipeline p) {
+  __shared__ uint32_t s_wave_sums[kBlockSize / 64u];
+  const uint4 v = reinterpret_cast<const uint4*>(p.merge_buckets)[blockIdx.x * kBlockSize + threadIdx.x];
+  uint32_t total = 0;
+  block_exclusive_scan(v.x + v.y + v.z + v.w, s_wave_sums, total);
+  if (threadIdx.x == 0)
+    p.merge_buckets[kMergeBuckets + 1u + blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kBlockSize) void k_merge_scan(Pipeline p) {
+  __shared__ uint32_t s_wave_sums[kBlockSize / 64u];
+  __shared__ uint32_t s_group_offset;
+  const uint32_t group_total = (threadIdx.x < kMergeScanBlocks) ? p.merge_buckets[kMergeBuckets + 1u + threadIdx.x] : 0u;
+  uint32_t all = 0;
+  const uint32_t group_before = block_exclusive_scan(group_total, s_wave_sums, all);
+  if (threadIdx.x == blockIdx.x)
+    s_group_offset = group_before;
+  uint4* mine = reinterpret_cast<uint4*>(p.merge_buckets) + blockIdx.x * kBlockSize + threadIdx.x;
+  const uint4 v = *mine;
+  uint32_t unused = 0;
+  uint32_t running = block_exclusive_scan(v.x + v.y + v.z + v.w, s_wave_sums, unused);  // contains the barrier for s_group_offset
+  running += s_group_offset;
+  uint4 o;
+  o.x = running, running += v.x;
+  o.y = running, running += v.y;
+  o.z = running, running += v.z;
+  o.w = running;
+  *mine = o;
+  if ((blockIdx.x == 0) && (threadIdx.x == 0))
+    p.counters[kCntMergeVertices] = all;
 }
 
 __global__ __launch_bounds__(kBlockSize) void k_merge_scatter(Pipeline p) {
@@ -245,6 +274,8 @@ struct MergeSlot {   // per range, in LDS
 __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmParams it) {
   __shared__ MergeSlot s_slot[kBlockSize];
   __shared__ float s_acc[kBlockSize / 64][8][4];
+  __shared__ uint2 s_ring[kBlockSize / 64][128];  // (photon, distance^2 bits)
+  __shared__ uint32_t s_ring_range[kBlockSize / 64][128];
   const DScene& scene = *p.scene;
   const uint32_t count = min(p.counters[kCntMergeVertices], p.capacity);
   const GridParams g = *p.grid_params;
@@ -256,6 +287,8 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
   const uint32_t max_path_length = scene.max_path_length;
   const uint32_t wave = threadIdx.x >> 6u;
   MergeSlot* slots = s_slot + wave * 64u;
+  uint2* ring = s_ring[wave];
+  uint32_t* ring_range = s_ring_range[wave];
   unsigned long long examined = 0, merged_count = 0;
   ETX_XCD_RANGE_LOOP(items) {
     const uint32_t item = base_ + lane_;
@@ -296,7 +329,48 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
     __threadfence_block();  // slots / accumulators written before any lane of this wave reads them
     if (lane_ == 0)
       examined += total;
-    for (uint32_t e0 = 0; (e0 < total) && (it.pad0 != 1u); e0 += 64u) {
+    // Two phases per batch. The distance / path-length filter accepts about one photon in five, so running the BSDF and
+    // MIS arithmetic right behind it would leave four lanes in five idle: accepted (range, photon) pairs go to a
+    // 128-entry LDS ring instead and are evaluated 64 at a time with every lane busy.
+    uint32_t ring_head = 0, ring_tail = 0;  // wave-uniform
+    auto evaluate = [&](uint32_t entries) {
+      if (lane_ < entries) {
+        const uint2 en = ring[(ring_head + lane_) & 127u];
+        const uint32_t r = ring_range[(ring_head + lane_) & 127u], j = en.x;
+        const float distance_squared = __uint_as_float(en.y);
+        const MergeSlot& sl = slots[r];
+        const float4 nv = sl.nrm_dvm;
+        const f3 nrm = {nv.x, nv.y, nv.z};
+        const float4 nd = p.grid.nrm_dvcm(j);
+        const float4 wv = sl.wi_wcam;
+        const f3 w_i = {wv.x, wv.y, wv.z};
+        const float4 wd = p.grid.win_dvm(j);
+        const f3 wi = {wd.x, wd.y, wd.z};
+        const f3 n_front = dot(nrm, w_i) < 0.0f ? nrm : -nrm;  // get_normal_frame, bsdf.hxx:37-40
+        const float cos_o = -dot(n_front, wi);                 // DiffuseBSDF::evaluate(-wi), bsdf_various.hxx:97-106
+        if ((dot(nrm, f3{nd.x, nd.y, nd.z}) > kEpsilon) && (cos_o > kEpsilon)) {
+          const float pdf = kInvPi * cos_o;
+          // reverse_pdf: roles swapped, w_i' = wi, w_o' = -w_i (scene_bsdf.hxx:82-92 + bsdf_various.hxx:113-120)
+          const f3 n_rev = dot(nrm, wi) < 0.0f ? nrm : -nrm;
+          const float n_dot_o = -dot(n_rev, w_i);
+          const float rev_pdf = (n_dot_o <= kEpsilon) ? 0.0f : kInvPi * n_dot_o;
+          const float w_light = nd.w * it.vc_weight + wd.w * pdf;
+          const float w_camera = wv.w + nv.w * rev_pdf;
+          const float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;
+          const float kernel_weight = use_epan ? fmaxf(2.0f * (1.0f - distance_squared * g.inv_radius_squared), 0.0f) : 1.0f;
+          const float4 lt = p.grid.thr(j);
+          const float4 fv = sl.fthr;
+          const float k = kernel_weight * weight;
+          float* acc = s_acc[wave][r >> 3u];
+          atomicAdd(acc + 0, fv.x * lt.x * k);
+          atomicAdd(acc + 1, fv.y * lt.y * k);
+          atomicAdd(acc + 2, fv.z * lt.z * k);
+          merged_count++;
+        }
+      }
+      ring_head += entries;
+    };
+    for (uint32_t e0 = 0; e0 < total; e0 += 64u) {
       const uint32_t e = e0 + lane_;
       // binary search: last range r with offset[r] <= e
       uint32_t r = 0;
@@ -309,49 +383,30 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
       }
       const uint32_t r_begin = __shfl(range_begin, r);
       const uint32_t r_offset = __shfl(offset, r);
-      if (e >= total)
-        continue;
-      const uint32_t j = r_begin + (e - r_offset);
-      const float4 pl = p.grid.pos_len[j];
-      const MergeSlot& sl = slots[r];
-      const float4 sp = sl.pos_depth;
-      const f3 d = f3{pl.x, pl.y, pl.z} - f3{sp.x, sp.y, sp.z};
-      const float distance_squared = dot(d, d);
-      if ((distance_squared > g.radius_squared) || (__float_as_uint(pl.w) + __float_as_uint(sp.w) + 1u > max_path_length))
-        continue;
-      if (it.pad0 == 2u)
-        continue;
-      const float4 nv = sl.nrm_dvm;
-      const f3 nrm = {nv.x, nv.y, nv.z};
-      const float4 nd = p.grid.nrm_dvcm(j);
-      if (dot(nrm, f3{nd.x, nd.y, nd.z}) <= kEpsilon)
-        continue;
-      const float4 wv = sl.wi_wcam;
-      const f3 w_i = {wv.x, wv.y, wv.z};
-      const float4 wd = p.grid.win_dvm(j);
-      const f3 wi = {wd.x, wd.y, wd.z};
-      const f3 n_front = dot(nrm, w_i) < 0.0f ? nrm : -nrm;  // get_normal_frame, bsdf.hxx:37-40
-      const float cos_o = -dot(n_front, wi);                 // DiffuseBSDF::evaluate(-wi), bsdf_various.hxx:97-106
-      if (cos_o <= kEpsilon)
-        continue;
-      const float pdf = kInvPi * cos_o;
-      // reverse_pdf: roles swapped, w_i' = wi, w_o' = -w_i (scene_bsdf.hxx:82-92 + bsdf_various.hxx:113-120)
-      const f3 n_rev = dot(nrm, wi) < 0.0f ? nrm : -nrm;
-      const float n_dot_o = -dot(n_rev, w_i);
-      const float rev_pdf = (n_dot_o <= kEpsilon) ? 0.0f : kInvPi * n_dot_o;
-      const float w_light = nd.w * it.vc_weight + wd.w * pdf;
-      const float w_camera = wv.w + nv.w * rev_pdf;
-      const float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;
-      const float kernel_weight = use_epan ? fmaxf(2.0f * (1.0f - distance_squared * g.inv_radius_squared), 0.0f) : 1.0f;
-      const float4 lt = p.grid.thr(j);
-      const float4 fv = sl.fthr;
-      const float k = kernel_weight * weight;
-      float* acc = s_acc[wave][r >> 3u];
-      atomicAdd(acc + 0, fv.x * lt.x * k);
-      atomicAdd(acc + 1, fv.y * lt.y * k);
-      atomicAdd(acc + 2, fv.z * lt.z * k);
-      merged_count++;
+      bool accept = false;
+      uint32_t j = 0;
+      float distance_squared = 0.0f;
+      if (e < total) {
+        j = r_begin + (e - r_offset);
+        const float4 pl = p.grid.pos_len[j];
+        const float4 sp = slots[r].pos_depth;
+        const f3 d = f3{pl.x, pl.y, pl.z} - f3{sp.x, sp.y, sp.z};
+        distance_squared = dot(d, d);
+        accept = (distance_squared <= g.radius_squared) && (__float_as_uint(pl.w) + __float_as_uint(sp.w) + 1u <= max_path_length);
+      }
+      const unsigned long long mask = __ballot(accept);
+      if (accept) {
+        const uint32_t at = (ring_tail + __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32u), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u))) & 127u;
+        ring[at] = make_uint2(j, __float_as_uint(distance_squared));
+        ring_range[at] = r;
+      }
+      ring_tail += uint32_t(__popcll(mask));
+      __threadfence_block();
+      if (ring_tail - ring_head >= 64u)
+        evaluate(64u);
     }
+    if (ring_tail != ring_head)
+      evaluate(ring_tail - ring_head);
     __threadfence_block();
     if (((lane_ & 7u) == 0u) && (item < seg_end_)) {
       const float* acc = s_acc[wave][lane_ >> 3u];
@@ -443,7 +498,8 @@ void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bo
   const uint32_t vertex_blocks = max(1u, grid_for(min(max_items, p.capacity)));
   hipLaunchKernelGGL(k_merge_clear, dim3(256), dim3(kBlockSize), 0, stream, p);
   hipLaunchKernelGGL(k_merge_count, dim3(vertex_blocks), dim3(kBlockSize), 0, stream, p);
-  hipLaunchKernelGGL(k_merge_scan, dim3(1), dim3(1024), 0, stream, p);
+  hipLaunchKernelGGL(k_merge_scan_totals, dim3(kMergeScanBlocks), dim3(kBlockSize), 0, stream, p);
+  hipLaunchKernelGGL(k_merge_scan, dim3(kMergeScanBlocks), dim3(kBlockSize), 0, stream, p);
   hipLaunchKernelGGL(k_merge_scatter, dim3(vertex_blocks), dim3(kBlockSize), 0, stream, p);
   // a multiple of 8 workgroups: one eighth of the sorted list per XCD
   const uint32_t blocks = max(8u, (grid_for(uint32_t(min(uint64_t(min(max_items, p.capacity)) * 8ull, 0xffffff00ull))) + 7u) & ~7u);

@@ -21,7 +21,7 @@ __global__ void k_reset_round_counters(Pipeline p) {
   }
 }
 
-template <bool kCamera>
+template <bool kCamera, bool kSimple>
 __global__ __launch_bounds__(kBlockSize) void k_path_tail(Pipeline p, VcmParams it, uint32_t in_set) {
   __shared__ int32_t s_stack[kStackDepth * kBlockSize];
   const DScene& scene = *p.scene;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kBlockSize) void k_path_tail(Pipeline p, VcmParams 
       Hit h = bvh_closest(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, RayQ{st.ray_o, st.ray_tmin, st.ray_d, st.ray_tmax}, alpha_seed, nullptr);
       rays++;
       const float4 hit = make_float4(h.u, h.v, h.t, __uint_as_float(h.tri));
-      alive = kCamera ? camera_step(p, scene, it, st, hit) : light_step(p, scene, it, st, hit);
+      alive = kCamera ? camera_step<kSimple>(p, scene, it, st, hit) : light_step<kSimple>(p, scene, it, st, hit);
     }
   }
   if (rays)
@@ -48,14 +48,20 @@ static uint32_t tail_blocks(uint32_t max_items) {
   return max(1u, min(kPersistentBlocks, (max_items + kBlockSize - 1) / kBlockSize));
 }
 
-void launch_light_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
+void launch_light_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials) {
   hipLaunchKernelGGL(k_reset_round_counters, dim3(1), dim3(64), 0, stream, p);
-  hipLaunchKernelGGL(k_path_tail<false>, dim3(tail_blocks(max_items)), dim3(kBlockSize), 0, stream, p, it, in_set);
+  if (simple_materials)
+    hipLaunchKernelGGL((k_path_tail<false, true>), dim3(tail_blocks(max_items)), dim3(kBlockSize), 0, stream, p, it, in_set);
+  else
+    hipLaunchKernelGGL((k_path_tail<false, false>), dim3(tail_blocks(max_items)), dim3(kBlockSize), 0, stream, p, it, in_set);
 }
 
-void launch_camera_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
+void launch_camera_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials) {
   hipLaunchKernelGGL(k_reset_round_counters, dim3(1), dim3(64), 0, stream, p);
-  hipLaunchKernelGGL(k_path_tail<true>, dim3(tail_blocks(max_items)), dim3(kBlockSize), 0, stream, p, it, in_set);
+  if (simple_materials)
+    hipLaunchKernelGGL((k_path_tail<true, true>), dim3(tail_blocks(max_items)), dim3(kBlockSize), 0, stream, p, it, in_set);
+  else
+    hipLaunchKernelGGL((k_path_tail<true, false>), dim3(tail_blocks(max_items)), dim3(kBlockSize), 0, stream, p, it, in_set);
 }
 
 }  // namespace etxd

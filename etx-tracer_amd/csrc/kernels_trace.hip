@@ -10,10 +10,11 @@
 
 namespace etxd {
 
-template <bool kFromCounter>
+template <bool kFromCounter, bool kFlat>
 __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene* __restrict__ scene_ptr, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
   float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count) {
-  __shared__ int32_t s_stack[kStackDepth * kBlockSize];
+  // the flat sweep needs no stack: without the 32 KB of LDS the kernel runs 8 waves per SIMD instead of 5
+  __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
   const DScene& scene = *scene_ptr;
   const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
   if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene* __re
   }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t stride = gridDim.x * blockDim.x;
-  LaneStack stack = {s_stack + threadIdx.x, kBlockSize};
+  LaneStack stack = {s_stack + (kFlat ? 0u : threadIdx.x), kBlockSize};
   for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {
     const uint32_t i = base + lane;
     if (i >= count)
@@ -35,27 +36,33 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene* __re
     const float4 a = ray_o_tmin[i];
     const float4 b = ray_d_tmax[i];
     uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ i;
-    Hit h = bvh_closest(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, RayQ{{a.x, a.y, a.z}, a.w, {b.x, b.y, b.z}, b.w}, alpha_seed, nullptr);
+    const RayQ ray = {{a.x, a.y, a.z}, a.w, {b.x, b.y, b.z}, b.w};
+    Hit h = kFlat ? bvh_flat_closest(scene, scene.bvh_tris, ray, alpha_seed, nullptr)
+                  : bvh_closest(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, ray, alpha_seed, nullptr);
     hits[i] = make_float4(h.u, h.v, h.t, __uint_as_float(h.tri));
   }
 }
 
-void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items) {
+void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat) {
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.capacity, max_items) + kBlockSize - 1) / kBlockSize));
-  hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u);
+  if (flat)
+    hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u);
+  else
+    hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Shadow kernel: segment queue -> transmittance -> film atomics (Raytracing::trace_transmittance, rt.cxx:468-579, plus
 // the accumulation the callers do: vcm_cpu.cxx:148-153 light splats, vcm_shared.hxx:1049-1053 camera gathers).
 // Algorithmic traffic: 48 B request in, 12 B of float atomics out for visible segments.
+template <bool kFlat>
 __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
-  __shared__ int32_t s_stack[kStackDepth * kBlockSize];
+  __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
   const DScene& scene = *p.scene;
   const uint32_t count = min(p.counters[kCntShadow], p.shadow.capacity);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t stride = gridDim.x * blockDim.x;
-  LaneStack stack = {s_stack + threadIdx.x, kBlockSize};
+  LaneStack stack = {s_stack + (kFlat ? 0u : threadIdx.x), kBlockSize};  // a flat scene only touches it when a segment crosses > 4 boundaries
   uint32_t splats = 0;
   for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {
     const uint32_t i = base + lane;
@@ -88,16 +95,22 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
     atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatSplats), (unsigned long long)splats);
 }
 
-void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_items) {
+void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_items, bool flat) {
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.shadow.capacity, max_items) + kBlockSize - 1) / kBlockSize));
-  hipLaunchKernelGGL(k_trace_shadow, dim3(blocks), dim3(kBlockSize), 0, stream, p);
+  if (flat)
+    hipLaunchKernelGGL(k_trace_shadow<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p);
+  else
+    hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p);
 }
 
-void launch_trace_rays(hipStream_t stream, const DScene* scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count) {
+void launch_trace_rays(hipStream_t stream, const DScene* scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count, bool flat) {
   uint32_t blocks = min(kPersistentBlocks, (count + kBlockSize - 1) / kBlockSize);
   if (blocks == 0)
     return;
-  hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks), dim3(kBlockSize), 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count);
+  if (flat)
+    hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count);
+  else
+    hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(blocks), dim3(kBlockSize), 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count);
 }
 
 }  // namespace etxd

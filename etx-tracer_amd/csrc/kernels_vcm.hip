@@ -90,6 +90,7 @@ void launch_light_generate(hipStream_t stream, const Pipeline& p, const VcmParam
 }
 
 // vcm_light_step, vcm_shared.hxx:1090-1260 (everything after rt.trace)
+template <bool kSimple>
 __global__ __launch_bounds__(kBlockSize) void k_light_shade(Pipeline p, VcmParams it, uint32_t in_set) {
   const DScene& scene = *p.scene;
   const PathSet& in = p.paths[in_set];
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(kBlockSize) void k_light_shade(Pipeline p, VcmParam
     if (i < count) {
       st = load_path(in, i);
       const float4 h = p.hits[i];
-      alive = light_step(p, scene, it, st, h);
+      alive = light_step<kSimple>(p, scene, it, st, h);
     }
     uint32_t slot = wave_compact_slot(alive, out_counter);
     if (alive)
@@ -111,8 +112,12 @@ __global__ __launch_bounds__(kBlockSize) void k_light_shade(Pipeline p, VcmParam
   }
 }
 
-void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
-  hipLaunchKernelGGL(k_light_shade, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
+void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials) {
+  const dim3 grid(max(1u, grid_for(min(p.capacity, max_items))));
+  if (simple_materials)
+    hipLaunchKernelGGL(k_light_shade<true>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+  else
+    hipLaunchKernelGGL(k_light_shade<false>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -157,6 +162,7 @@ void launch_camera_generate(hipStream_t stream, const Pipeline& p, const VcmPara
 
 // vcm_camera_step, vcm_shared.hxx:927-1079, without the vertex connections and the merge: connectible vertices are
 // written to the camera vertex pool and consumed by k_connect / k_merge of the same bounce.
+template <bool kSimple>
 __global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmParams it, uint32_t in_set) {
   const DScene& scene = *p.scene;
   const PathSet& in = p.paths[in_set];
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmPara
     if (i < count) {
       st = load_path(in, i);
       const float4 h = p.hits[i];
-      alive = camera_step(p, scene, it, st, h);
+      alive = camera_step<kSimple>(p, scene, it, st, h);
     }
     uint32_t slot = wave_compact_slot(alive, out_counter);
     if (alive)
@@ -178,8 +184,12 @@ __global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmPara
   }
 }
 
-void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
-  hipLaunchKernelGGL(k_camera_shade, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
+void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials) {
+  const dim3 grid(max(1u, grid_for(min(p.capacity, max_items))));
+  if (simple_materials)
+    hipLaunchKernelGGL(k_camera_shade<true>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+  else
+    hipLaunchKernelGGL(k_camera_shade<false>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
 }
 
 #if defined(ETX_HIP_DEBUG_COUNTERS)

@@ -154,7 +154,7 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   CameraVertexPool cv;
   ShadowQueue shadow;
   uint32_t* merge_order;       // camera vertex slots of the current bounce sorted by coarse spatial bucket (k_merge_*)
-  uint32_t* merge_buckets;     // kMergeBuckets + 1 counters / offsets
+  uint32_t* merge_buckets;     // kMergeBuckets + 1 counters / offsets, then 256 scan-group totals
   uint2* pairs;          // (camera vertex slot, light vertex index) of the current bounce
   uint32_t pair_capacity;
   float4* camera_sum;
