@@ -6,7 +6,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#if !defined(ETX_DEV)
 #define ETX_DEV __device__ __forceinline__
+#endif
 #define ETX_HD __host__ __device__ __forceinline__
 
 namespace etxd {

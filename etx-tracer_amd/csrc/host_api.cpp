@@ -124,7 +124,7 @@ int allocate_pipeline(etx_hip_context* ctx) {
   release_pipeline(ctx);
   Pipeline& p = ctx->pipe;
   const uint32_t n = ctx->scene.film_w * ctx->scene.film_h;
-  p.scene = ctx->scene.device;
+  p.scene = ctx->scene.host_copy;
   p.capacity = n;
   int rc = 0;
   for (int s = 0; s < 2; ++s) {
@@ -691,7 +691,7 @@ int etx_hip_trace_rays(etx_hip_context* context, const float* rays_8f, uint64_t 
       rc = ETX_HIP_ERROR_HIP;
       break;
     }
-    launch_trace_rays(context->stream, context->scene.device, d_o, d_d, d_h, uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
+    launch_trace_rays(context->stream, context->scene.host_copy, d_o, d_d, d_h, uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
     if ((hipMemcpyAsync(hits_4f, d_h, count * sizeof(float4), hipMemcpyDeviceToHost, context->stream) != hipSuccess) || (hipStreamSynchronize(context->stream) != hipSuccess)) {
       context->error = std::string("trace kernel failed: ") + hipGetErrorString(hipGetLastError());
       rc = ETX_HIP_ERROR_HIP;
@@ -715,11 +715,11 @@ int etx_hip_trace_rays_device(etx_hip_context* context, const void* d_rays_o_tmi
   HIP_OK(context, hipEventCreate(&e0));
   HIP_OK(context, hipEventCreate(&e1));
   // one untimed launch (code object load, caches)
-  launch_trace_rays(context->stream, context->scene.device, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
+  launch_trace_rays(context->stream, context->scene.host_copy, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
     reinterpret_cast<float4*>(d_hits), uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
   HIP_OK(context, hipEventRecord(e0, context->stream));
   for (uint32_t r = 0; r < repeat; ++r)
-    launch_trace_rays(context->stream, context->scene.device, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
+    launch_trace_rays(context->stream, context->scene.host_copy, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
       reinterpret_cast<float4*>(d_hits), uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
   HIP_OK(context, hipEventRecord(e1, context->stream));
   HIP_OK(context, hipEventSynchronize(e1));

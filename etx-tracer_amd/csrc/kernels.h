@@ -13,7 +13,7 @@ constexpr uint32_t kPersistentBlocks = 256 * 8;  // 256 CUs x 8 blocks of 256 th
 // `max_items`: host-side upper bound of the device-resident item count (sizes the grid; kernels grid-stride anyway)
 void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat);
 void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_items, bool flat);
-void launch_trace_rays(hipStream_t stream, const DScene* scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count, bool flat);
+void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count, bool flat);
 
 // VCM light pass
 void launch_iteration_reset(hipStream_t stream, const Pipeline& p);

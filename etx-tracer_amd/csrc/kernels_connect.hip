@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmPara
 
 template <bool kDiffuseOnly>
 __global__ __launch_bounds__(kBlockSize) void k_connect_pairs(Pipeline p, VcmParams it) {
-  const DScene& scene = *p.scene;
+  const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntPairs], p.pair_capacity);
   ETX_WAVE_LOOP(count) {
     const uint32_t i = base_ + lane_;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_count(Pipeline p) {
   if ((g.valid == 0u) || (g.photon_count == 0u))
     return;
   const uint32_t count = min(p.counters[kCntCameraVertices], p.capacity);
-  const uint32_t max_path_length = p.scene->max_path_length;
+  const uint32_t max_path_length = p.scene.max_path_length;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     f3 pos;
     if (merge_candidate(p, g, max_path_length, i, pos))
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_scatter(Pipeline p) {
   if ((g.valid == 0u) || (g.photon_count == 0u))
     return;
   const uint32_t count = min(p.counters[kCntCameraVertices], p.capacity);
-  const uint32_t max_path_length = p.scene->max_path_length;
+  const uint32_t max_path_length = p.scene.max_path_length;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     f3 pos;
     if (merge_candidate(p, g, max_path_length, i, pos))
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
   __shared__ float s_acc[kBlockSize / 64][8][4];
   __shared__ uint2 s_ring[kBlockSize / 64][128];  // (photon, distance^2 bits)
   __shared__ uint32_t s_ring_range[kBlockSize / 64][128];
-  const DScene& scene = *p.scene;
+  const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntMergeVertices], p.capacity);
   const GridParams g = *p.grid_params;
   if ((g.valid == 0u) || (g.photon_count == 0u))
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
 
 // Every other connectible material: generic BSDF evaluation per accepted photon (stochastic for rough conductors).
 __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmParams it) {
-  const DScene& scene = *p.scene;
+  const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntMergeVertices], p.capacity);
   const GridParams g = *p.grid_params;
   if ((g.valid == 0u) || (g.photon_count == 0u))

@@ -24,7 +24,7 @@ __global__ void k_reset_round_counters(Pipeline p) {
 template <bool kCamera, bool kSimple>
 __global__ __launch_bounds__(kBlockSize) void k_path_tail(Pipeline p, VcmParams it, uint32_t in_set) {
   __shared__ int32_t s_stack[kStackDepth * kBlockSize];
-  const DScene& scene = *p.scene;
+  const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
   LaneStack stack = {s_stack + threadIdx.x, kBlockSize};

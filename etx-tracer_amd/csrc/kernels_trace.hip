@@ -11,11 +11,11 @@
 namespace etxd {
 
 template <bool kFromCounter, bool kFlat>
-__global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene* __restrict__ scene_ptr, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
+__global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
   float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count) {
   // the flat sweep needs no stack: without the 32 KB of LDS the kernel runs 8 waves per SIMD instead of 5
   __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
-  const DScene& scene = *scene_ptr;
+  const DScene& scene = scene_arg;  // by value: kernarg (scalar) loads, table pointers known to be global
   const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
   if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
     // housekeeping for the shade kernel that follows: its output counter and the camera vertex pool start empty
@@ -58,7 +58,7 @@ void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, u
 template <bool kFlat>
 __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
   __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
-  const DScene& scene = *p.scene;
+  const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntShadow], p.shadow.capacity);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -103,7 +103,7 @@ void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_ite
     hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p);
 }
 
-void launch_trace_rays(hipStream_t stream, const DScene* scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count, bool flat) {
+void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count, bool flat) {
   uint32_t blocks = min(kPersistentBlocks, (count + kBlockSize - 1) / kBlockSize);
   if (blocks == 0)
     return;

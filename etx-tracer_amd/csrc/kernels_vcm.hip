@@ -13,6 +13,13 @@
 #include "kernels.h"
 #include "dev_vcm_steps.h"
 
+#if !defined(ETX_CAM_ATTR)
+#define ETX_CAM_ATTR
+#endif
+#if !defined(ETX_LIGHT_ATTR)
+#define ETX_LIGHT_ATTR
+#endif
+
 namespace etxd {
 
 #define ETX_WAVE_LOOP(COUNT)                                                          \
@@ -50,7 +57,7 @@ void launch_iteration_reset(hipStream_t stream, const Pipeline& p) {
 // ---------------------------------------------------------------------------------------------------------------
 // vcm_generate_emitter_state, vcm_shared.hxx:310-349 (one light path per pixel index, vcm_cpu.cxx:139-140)
 __global__ __launch_bounds__(kBlockSize) void k_light_generate(Pipeline p, VcmParams it) {
-  const DScene& scene = *p.scene;
+  const DScene& scene = p.scene;
   ETX_WAVE_LOOP(it.path_count) {
     const uint32_t i = base_ + lane_;
     bool valid = false;
@@ -91,8 +98,8 @@ void launch_light_generate(hipStream_t stream, const Pipeline& p, const VcmParam
 
 // vcm_light_step, vcm_shared.hxx:1090-1260 (everything after rt.trace)
 template <bool kSimple>
-__global__ __launch_bounds__(kBlockSize) void k_light_shade(Pipeline p, VcmParams it, uint32_t in_set) {
-  const DScene& scene = *p.scene;
+__global__ __launch_bounds__(kBlockSize) ETX_LIGHT_ATTR void k_light_shade(Pipeline p, VcmParams it, uint32_t in_set) {
+  const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const PathSet& out = p.paths[in_set ^ 1u];
   const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
@@ -123,7 +130,7 @@ void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& 
 // ---------------------------------------------------------------------------------------------------------------
 // vcm_generate_camera_state, vcm_shared.hxx:351-377 (all pixels active: Film::active_pixel with pixel_size 1)
 __global__ __launch_bounds__(kBlockSize) void k_camera_generate(Pipeline p, VcmParams it) {
-  const DScene& scene = *p.scene;
+  const DScene& scene = p.scene;
   ETX_WAVE_LOOP(it.path_count) {
     const uint32_t i = base_ + lane_;
     if (i >= it.path_count)
@@ -163,8 +170,8 @@ void launch_camera_generate(hipStream_t stream, const Pipeline& p, const VcmPara
 // vcm_camera_step, vcm_shared.hxx:927-1079, without the vertex connections and the merge: connectible vertices are
 // written to the camera vertex pool and consumed by k_connect / k_merge of the same bounce.
 template <bool kSimple>
-__global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmParams it, uint32_t in_set) {
-  const DScene& scene = *p.scene;
+__global__ __launch_bounds__(kBlockSize) ETX_CAM_ATTR void k_camera_shade(Pipeline p, VcmParams it, uint32_t in_set) {
+  const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const PathSet& out = p.paths[in_set ^ 1u];
   const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];

@@ -144,7 +144,8 @@ ETX_HD bool opt_enable_merging(const VcmParams& p) { return p.options & ETX_VCM_
 ETX_HD bool opt_merge_vertices(const VcmParams& p) { return opt_enable_merging(p) && (p.options & ETX_VCM_MERGE_VERTICES); }
 
 struct Pipeline {  // everything a kernel needs, passed by value (fits the kernarg segment)
-  const DScene* scene;   // device pointer
+  DScene scene;          // by value: travels in the kernel argument segment, so its fields are scalar loads and its
+                         // table pointers are known global pointers (not flat) to the compiler
   PathSet paths[2];
   float4* hits;          // hit queue, aligned with the "in" path set
   LightVertexPool lv;
