@@ -60,6 +60,74 @@ ETX_DEV uint32_t wave_compact_slot(bool alive, uint32_t* counter) {
   return base + prefix;
 }
 
+// The same for a whole workgroup: ONE atomic per 256 threads. All atomics on a counter are serialised by its L2
+// channel at ~11 ns each (pipeline.h), and a 1080p iteration used to issue ~1 M of them per counter from the shade
+// kernels alone - more time than the shading itself. Must be called from workgroup-uniform control flow
+// (ETX_BLOCK_LOOP); three barriers, the last one makes the scratch reusable by the next call.
+struct BlockScratch {  // in LDS
+  uint32_t wave_total[kBlockSize / 64u];
+  uint32_t base;
+};
+
+ETX_DEV uint32_t block_compact_slot(bool alive, uint32_t* counter, BlockScratch& scratch) {
+  const uint64_t mask = __ballot(alive);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6u;
+  const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32u), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+  if (lane == 0u)
+    scratch.wave_total[wave] = uint32_t(__popcll(mask));
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlockSize / 64u; ++w)
+      total += scratch.wave_total[w];
+    scratch.base = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  uint32_t slot = scratch.base + prefix;
+#pragma unroll
+  for (uint32_t w = 0; w < kBlockSize / 64u; ++w)
+    slot += (w < wave) ? scratch.wave_total[w] : 0u;
+  __syncthreads();
+  return slot;
+}
+
+// Slot reservation policy of the step functions (dev_vcm_steps.h). The wavefront kernels reserve per workgroup; the
+// tail kernels, whose lanes loop independently over the few surviving paths, reserve per lane.
+struct BlockSlots {
+  BlockScratch* scratch;
+  ETX_DEV uint32_t get(bool wanted, uint32_t* counter) const {
+    return block_compact_slot(wanted, counter, *scratch);
+  }
+};
+struct LaneSlots {
+  ETX_DEV uint32_t get(bool wanted, uint32_t* counter) const {
+    return wanted ? atomicAdd(counter, 1u) : 0u;
+  }
+};
+
+// Workgroup-uniform grid-stride loop: every thread of a workgroup runs the same number of iterations, threads beyond
+// COUNT take part in the barriers of block_compact_slot with their predicate false.
+#define ETX_BLOCK_LOOP(COUNT, INDEX)                                                                        \
+  for (uint32_t block_base_ = blockIdx.x * blockDim.x, INDEX = block_base_ + threadIdx.x; block_base_ < (COUNT); \
+       block_base_ += gridDim.x * blockDim.x, INDEX = block_base_ + threadIdx.x)
+
+// Workgroup sum of a per-lane statistic into this workgroup's row of p.block_stats (no atomics).
+ETX_DEV void block_stat_add(const Pipeline& p, uint32_t which, unsigned long long value, unsigned long long* scratch /* LDS, one word */) {
+#pragma unroll
+  for (uint32_t d = 1; d < 64; d <<= 1)
+    value += __shfl_xor(value, d);
+  if (threadIdx.x == 0u)
+    *scratch = 0ull;
+  __syncthreads();
+  if (((threadIdx.x & 63u) == 0u) && (value != 0ull))
+    atomicAdd(scratch, value);
+  __syncthreads();
+  if ((threadIdx.x == 0u) && (*scratch != 0ull))
+    p.block_stats[min(blockIdx.x, kBlockStatRows - 1u) * kBlockStatCount + which] += *scratch;
+  __syncthreads();
+}
+
 ETX_DEV void atomic_add_f3(float4* dst, const f3& v) {
   atomicAdd(&dst->x, v.x);
   atomicAdd(&dst->y, v.y);
@@ -102,15 +170,19 @@ ETX_DEV f3 trace_transmittance(TraceCtx& tc, const f3& p0, const f3& p1, uint32_
 // A connection whose visibility is still unknown: the shade / connect kernels evaluate everything but the
 // transmittance and queue the segment; k_trace_shadow (kernels_trace.hip) multiplies by the transmittance and adds
 // the result to the film. `target`: film pixel index, bit 31 set = light image (splat), clear = camera image.
-ETX_DEV void push_shadow(const Pipeline& p, const f3& p0, const f3& p1, uint32_t medium, uint32_t target, const f3& value) {
-  uint32_t idx = atomicAdd(p.counters + kCntShadow, 1u);
+struct ShadowRequest {
+  f3 p0, p1, value;
+  uint32_t medium, target;
+};
+
+ETX_DEV void write_shadow(const Pipeline& p, uint32_t idx, const ShadowRequest& r) {
   if (idx >= p.shadow.capacity) {
     atomicOr(p.counters + kCntOverflow, kOverflowShadow);
     return;
   }
-  p.shadow.p0_medium[idx] = mk4(p0, __uint_as_float(medium));
-  p.shadow.p1_target[idx] = mk4(p1, __uint_as_float(target));
-  p.shadow.value[idx] = mk4(value, 0.0f);
+  p.shadow.p0_medium[idx] = mk4(r.p0, __uint_as_float(r.medium));
+  p.shadow.p1_target[idx] = mk4(r.p1, __uint_as_float(r.target));
+  p.shadow.value[idx] = mk4(r.value, 0.0f);
 }
 
 // vcm_shared.hxx:218-283 vcm_next_ray
@@ -168,18 +240,19 @@ ETX_DEV bool vcm_handle_boundary(const DScene& scene, const Isect& isect, PathSt
 
 // vcm_shared.hxx:463-535 vcm_connect_to_camera, minus the transmittance: queues the segment, the splat value
 // (vcm_cpu.cxx:148-153) is completed by k_trace_shadow.
+// Returns true when `out` holds a request for the shadow queue.
 template <bool kSimple>
-ETX_DEV void vcm_connect_to_camera(const Pipeline& p, const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st) {
+ETX_DEV bool vcm_connect_to_camera(const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st, ShadowRequest& out) {
   if ((opt_connect_to_camera(it) == false) || (st.depth + 2 > scene.max_path_length) || (st.depth + 2 < scene.min_path_length))
-    return;
+    return false;
   f3 sample_pos = camera_at_medium ? medium_pos : isect->pos;
   CameraSample cs = sample_film(scene, st.sampler, sample_pos);
   if (cs.pdf_dir <= 0.0f)
-    return;
+    return false;
   f3 direction = cs.position - sample_pos;
   float dist2 = dot(direction, direction);
   if (dist2 <= kEpsilon)
-    return;
+    return false;
   f3 w_o = normalize(direction);
   f3 scatter = mk3(0.0f);
   float reverse_pdf = 0.0f;
@@ -189,7 +262,7 @@ ETX_DEV void vcm_connect_to_camera(const Pipeline& p, const DScene& scene, const
     BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathLight);
     BsdfEval eval = bsdf_evaluate_s<kSimple>(scene, data, w_o, mat, st.sampler);
     if (eval.valid() == false)
-      return;
+      return false;
     scatter = eval.bsdf;
     reverse_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, w_o, mat);
     origin = shading_pos(scene, scene.triangles[isect->tri], isect->bc, w_o);
@@ -197,7 +270,7 @@ ETX_DEV void vcm_connect_to_camera(const Pipeline& p, const DScene& scene, const
     const DMedium& medium = scene.mediums[st.medium];
     float p = phase_function(st.ray_d, w_o, medium.g);
     if (p <= 0.0f)
-      return;
+      return false;
     scatter = mk3(p);
     reverse_pdf = phase_function(w_o, st.ray_d, medium.g);
   }
@@ -214,8 +287,9 @@ ETX_DEV void vcm_connect_to_camera(const Pipeline& p, const DScene& scene, const
   uint32_t x = static_cast<uint32_t>((cs.uv.x * 0.5f + 0.5f) * float(it.film_w));
   uint32_t y = static_cast<uint32_t>((cs.uv.y * 0.5f + 0.5f) * float(it.film_h));
   if ((x >= it.film_w) || (y >= it.film_h))
-    return;
-  push_shadow(p, origin, clip_pos, st.medium, kShadowTargetLight | (x + (it.film_h - 1u - y) * it.film_w), scatter * st.throughput * (cs.weight * weight));
+    return false;
+  out = {origin, clip_pos, scatter * st.throughput * (cs.weight * weight), st.medium, kShadowTargetLight | (x + (it.film_h - 1u - y) * it.film_w)};
+  return true;
 }
 
 // vcm_shared.hxx:285-308 vcm_get_radiance (direct emitter hit from the camera sub path)
@@ -275,15 +349,16 @@ ETX_DEV f3 vcm_cam_handle_miss(const DScene& scene, const VcmParams& it, PathSta
 
 // vcm_shared.hxx:608-671 vcm_connect_to_light (NEE) minus the transmittance (queued for k_trace_shadow).
 // sampler.fixed_* hold (rnd_connection.xy, rnd_support.y). `film_target` = film index of the path's pixel.
+// Returns true when `out` holds a request for the shadow queue.
 template <bool kSimple>
-ETX_DEV void vcm_connect_to_light(const Pipeline& p, const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st, uint32_t film_target) {
+ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st, uint32_t film_target, ShadowRequest& out) {
   if ((opt_connect_to_light(it) == false) || (st.depth + 1 > scene.max_path_length) || (st.depth + 1 < scene.min_path_length))
-    return;
+    return false;
   f3 sample_pos = camera_at_medium ? medium_pos : isect->pos;
   uint32_t emitter_index = sample_emitter_index(scene, st.sampler.fixed_w);
   EmitterSample es = sample_emitter(scene, emitter_index, f2{st.sampler.fixed_u, st.sampler.fixed_v}, sample_pos);
   if (es.pdf_dir <= 0.0f)
-    return;
+    return false;
   f3 w_o = es.direction;
   f3 scatter = mk3(0.0f);
   float reverse_pdf = 0.0f;
@@ -294,7 +369,7 @@ ETX_DEV void vcm_connect_to_light(const Pipeline& p, const DScene& scene, const 
     const DMedium& medium = scene.mediums[st.medium];
     float p = phase_function(st.ray_d, w_o, medium.g);
     if (p <= 0.0f)
-      return;
+      return false;
     scatter = mk3(p);
     reverse_pdf = phase_function(w_o, st.ray_d, medium.g);
   } else {
@@ -302,7 +377,7 @@ ETX_DEV void vcm_connect_to_light(const Pipeline& p, const DScene& scene, const 
     BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathCamera);
     BsdfEval eval = bsdf_evaluate_s<kSimple>(scene, data, w_o, mat, st.sampler);
     if (eval.valid() == false)
-      return;
+      return false;
     scatter = eval.bsdf;
     reverse_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, w_o, mat);
     const etx_abi_triangle& tri = scene.triangles[isect->tri];
@@ -319,7 +394,8 @@ ETX_DEV void vcm_connect_to_light(const Pipeline& p, const DScene& scene, const 
   float vmW_nee = camera_at_medium ? 0.0f : it.vm_weight;
   float w_camera = (es.pdf_dir_out * camera_factor) / (es.pdf_dir * l_dot_e) * (vmW_nee + st.d_vcm + st.d_vc * reverse_pdf);
   float weight = opt_enable_mis(it) ? 1.0f / (1.0f + w_light + w_camera) : 1.0f;
-  push_shadow(p, origin, es.origin, st.medium, film_target, st.throughput * scatter * es.value * (weight / (es.pdf_dir * es.pdf_sample)));
+  out = {origin, es.origin, st.throughput * scatter * es.value * (weight / (es.pdf_dir * es.pdf_sample)), st.medium, film_target};
+  return true;
 }
 
 struct LightVertex {  // VCMLightVertex, vcm_shared.hxx:154-197

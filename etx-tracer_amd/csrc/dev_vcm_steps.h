@@ -7,8 +7,7 @@
 
 namespace etxd {
 
-ETX_DEV void store_light_vertex(const Pipeline& p, const VcmParams& it, const PathState& st, const f3& pos, const f3& nrm, float bc_u, float bc_v, uint32_t tri, bool keep_bbox) {
-  uint32_t idx = atomicAdd(p.counters + kCntLightVertices, 1u);
+ETX_DEV void store_light_vertex(const Pipeline& p, uint32_t idx, const PathState& st, const f3& pos, const f3& nrm, float bc_u, float bc_v, uint32_t tri) {
   if (idx >= p.lv.capacity) {
     atomicOr(p.counters + kCntOverflow, kOverflowLightVertices);
     return;
@@ -23,13 +22,11 @@ ETX_DEV void store_light_vertex(const Pipeline& p, const VcmParams& it, const Pa
   const uint32_t index_in_path = (prev == kInvalid) ? 0u : ((__float_as_uint(p.lv.bc_len_med(prev).z) >> 16u) + 1u);
   p.lv.bc_len_med(idx) = make_float4(bc_u, bc_v, __uint_as_float((index_in_path << 16u) | (st.depth & 0xffffu)), __uint_as_float(st.medium));
   p.lv.next(idx) = prev;
-  p.light_path_head[st.id] = idx;
-  (void)keep_bbox;  // the photon bounding box is reduced by k_grid_bbox (kernels_grid.hip)
+  p.light_path_head[st.id] = idx;  // the photon bounding box is reduced by k_grid_bbox (kernels_grid.hip)
 }
 
 
-ETX_DEV void store_camera_vertex(const Pipeline& p, const DScene& scene, const PathState& st, const float4& hit_or_pos, uint32_t seed, const Isect* isect) {
-  uint32_t idx = atomicAdd(p.counters + kCntCameraVertices, 1u);
+ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& scene, const PathState& st, const float4& hit_or_pos, uint32_t seed, const Isect* isect) {
   if (idx >= p.capacity) {  // only the tail kernel can exceed one vertex per path slot
     atomicOr(p.counters + kCntOverflow, kOverflowCameraVertices);
     return;
@@ -64,78 +61,90 @@ enum : uint32_t { kEventNone = 0, kEventMedium = 1, kEventSurface = 2, kEventBou
 //   A  classify the event, draw the randoms, update the MIS quantities at the vertex, sample the BSDF
 //   B  store the light vertex, connect it to the camera (same code for medium and surface vertices)
 //   C  continue the path (phase function / vcm_next_ray, Russian roulette)
-template <bool kSimple>
-ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h) {
+// `slots.get(wanted, counter)` reserves queue / pool slots: the wavefront kernels call this function from
+// workgroup-uniform control flow (lanes without a path pass valid = false) and reserve once per workgroup, so the
+// reservation points sit outside every data-dependent branch.
+template <bool kSimple, class Slots>
+ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots) {
   const uint32_t tri = __float_as_uint(h.w);
-  const bool found = tri != kInvalid;
+  const bool found = valid && (tri != kInvalid);
   Isect isect;
-  if (found)
-    isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
-
-  // vcm_try_sampling_medium, vcm_shared.hxx:379-388
   MediumSample ms;
   ms.sampled_medium_t = 0.0f;
-  if (st.medium != kInvalid) {
-    ms = sample_medium_homogeneous(scene.mediums[st.medium], st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
-    st.throughput *= ms.weight;
-  }
-
-  // ---- phase A
   uint32_t event = kEventNone;
-  if (ms.sampled_medium())
-    event = kEventMedium;
-  else if (found)
-    event = vcm_handle_boundary(scene, isect, st) ? kEventBoundary : kEventSurface;
-  if (event == kEventNone)
-    return false;
-  if (event == kEventBoundary)
-    return true;
-
-  // both branches draw the same six numbers (vcm_shared.hxx:1099-1101, 1185-1187)
-  const f2 rnd_bsdf = st.sampler.next_2d();
-  const f2 rnd_connection = st.sampler.next_2d();
-  const f2 rnd_support = st.sampler.next_2d();
+  if (valid) {
+    if (found)
+      isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
+    // vcm_try_sampling_medium, vcm_shared.hxx:379-388
+    if (st.medium != kInvalid) {
+      ms = sample_medium_homogeneous(scene.mediums[st.medium], st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+      st.throughput *= ms.weight;
+    }
+    // ---- phase A
+    if (ms.sampled_medium())
+      event = kEventMedium;
+    else if (found)
+      event = vcm_handle_boundary(scene, isect, st) ? kEventBoundary : kEventSurface;
+  }
+  const bool scatter_event = (event == kEventMedium) || (event == kEventSurface);  // None: path ends, Boundary: continues as is
   const bool at_medium = event == kEventMedium;
+  f2 rnd_bsdf = {0.0f, 0.0f}, rnd_connection = {0.0f, 0.0f}, rnd_support = {0.0f, 0.0f};
   BsdfData bsdf_data;
   BsdfSample bs;
   bool store = false, connect = false;
-  if (at_medium) {
-    st.d_vcm *= sqr(st.path_distance + ms.sampled_medium_t);
-    st.path_distance = 0.0f;
-    store = opt_connect_vertices(it) && (st.depth + 1 <= scene.max_path_length);
-    connect = opt_connect_to_camera(it) && scene.mediums[st.medium].explicit_connections && (st.depth + 1 <= scene.max_path_length);
-  } else {
-    const etx_abi_material& mat = scene.materials[isect.material];
-    bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight);
-    st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
-    bs = bsdf_sample_s<kSimple>(scene, bsdf_data, mat, st.sampler);
-    st.sampler.pop_fixed();
-    // vcm_update_light_vcm, vcm_shared.hxx:451-461
-    if ((st.depth > 0u) || (st.flags & kPathLocalEmitter))
-      st.d_vcm *= sqr(st.path_distance + isect.t);
-    float cos_to_prev = fabsf(dot(isect.nrm, -st.ray_d));
-    st.d_vcm /= cos_to_prev;
-    st.d_vc /= cos_to_prev;
-    st.d_vm /= cos_to_prev;
-    st.path_distance = 0.0f;
-    store = (bs.properties & kSampleDelta) == 0u;  // is_connectible
-    connect = store && opt_connect_to_camera(it) && (st.depth + 1 <= scene.max_path_length);
+  if (scatter_event) {
+    // both branches draw the same six numbers (vcm_shared.hxx:1099-1101, 1185-1187)
+    rnd_bsdf = st.sampler.next_2d();
+    rnd_connection = st.sampler.next_2d();
+    rnd_support = st.sampler.next_2d();
+    if (at_medium) {
+      st.d_vcm *= sqr(st.path_distance + ms.sampled_medium_t);
+      st.path_distance = 0.0f;
+      store = opt_connect_vertices(it) && (st.depth + 1 <= scene.max_path_length);
+      connect = opt_connect_to_camera(it) && scene.mediums[st.medium].explicit_connections && (st.depth + 1 <= scene.max_path_length);
+    } else {
+      const etx_abi_material& mat = scene.materials[isect.material];
+      bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight);
+      st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
+      bs = bsdf_sample_s<kSimple>(scene, bsdf_data, mat, st.sampler);
+      st.sampler.pop_fixed();
+      // vcm_update_light_vcm, vcm_shared.hxx:451-461
+      if ((st.depth > 0u) || (st.flags & kPathLocalEmitter))
+        st.d_vcm *= sqr(st.path_distance + isect.t);
+      float cos_to_prev = fabsf(dot(isect.nrm, -st.ray_d));
+      st.d_vcm /= cos_to_prev;
+      st.d_vc /= cos_to_prev;
+      st.d_vm /= cos_to_prev;
+      st.path_distance = 0.0f;
+      store = (bs.properties & kSampleDelta) == 0u;  // is_connectible
+      connect = store && opt_connect_to_camera(it) && (st.depth + 1 <= scene.max_path_length);
+    }
   }
 
   // ---- phase B
+  const uint32_t vertex_slot = slots.get(store, p.counters + kCntLightVertices);
   if (store) {
     if (at_medium)
-      store_light_vertex(p, it, st, ms.pos, mk3(0.0f), 0.0f, 0.0f, kInvalid, false);
+      store_light_vertex(p, vertex_slot, st, ms.pos, mk3(0.0f), 0.0f, 0.0f, kInvalid);
     else
-      store_light_vertex(p, it, st, isect.pos, isect.nrm, isect.bc.y, isect.bc.z, isect.tri, true);
+      store_light_vertex(p, vertex_slot, st, isect.pos, isect.nrm, isect.bc.y, isect.bc.z, isect.tri);
   }
+  ShadowRequest request;
+  bool queue = false;
   if (connect) {
     st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-    vcm_connect_to_camera<kSimple>(p, scene, it, at_medium, &isect, ms.pos, st);
+    queue = vcm_connect_to_camera<kSimple>(scene, it, at_medium, &isect, ms.pos, st, request);
     st.sampler.pop_fixed();
   }
+  const uint32_t shadow_slot = slots.get(queue, p.counters + kCntShadow);
+  if (queue)
+    write_shadow(p, shadow_slot, request);
 
   // ---- phase C
+  if (event == kEventBoundary)
+    return true;
+  if (scatter_event == false)
+    return false;
   if (at_medium) {  // vcm_shared.hxx:1143-1169
     const DMedium& med = scene.mediums[st.medium];
     f3 w_i = st.ray_d;
@@ -160,99 +169,110 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
 // vcm_camera_step, vcm_shared.hxx:927-1079 after rt.trace, without the vertex connections and the merge: connectible
 // vertices go to the camera vertex pool (k_expand_pairs / k_connect_pairs / k_merge consume them), NEE segments go to
 // the shadow queue, direct / miss radiance goes straight to the film. Same three-phase shape as light_step.
-template <bool kSimple>
-ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h) {
+template <bool kSimple, class Slots>
+ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots) {
   const uint32_t tri = __float_as_uint(h.w);
-  const bool found = tri != kInvalid;
+  const bool found = valid && (tri != kInvalid);
   Isect isect;
-  if (found)
-    isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
-
   MediumSample ms;
   ms.sampled_medium_t = 0.0f;
-  if (st.medium != kInvalid) {
-    ms = sample_medium_homogeneous(scene.mediums[st.medium], st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
-    st.throughput *= ms.weight;
-  }
-
-  // ---- phase A
   uint32_t event = kEventNone;
-  if (ms.sampled_medium())
-    event = kEventMedium;
-  else if (found)
-    event = vcm_handle_boundary(scene, isect, st) ? kEventBoundary : kEventSurface;
-  if (event == kEventNone) {  // vcm_shared.hxx:997-1000
-    f3 gathered = vcm_cam_handle_miss(scene, it, st);
-    if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
-      atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered);
-    return false;
+  if (valid) {
+    if (found)
+      isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
+    if (st.medium != kInvalid) {
+      ms = sample_medium_homogeneous(scene.mediums[st.medium], st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+      st.throughput *= ms.weight;
+    }
+    // ---- phase A
+    if (ms.sampled_medium())
+      event = kEventMedium;
+    else if (found)
+      event = vcm_handle_boundary(scene, isect, st) ? kEventBoundary : kEventSurface;
+    if (event == kEventNone) {  // vcm_shared.hxx:997-1000
+      f3 gathered = vcm_cam_handle_miss(scene, it, st);
+      if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
+        atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered);
+    }
   }
-  if (event == kEventBoundary)
-    return true;
+  const bool scatter_event = (event == kEventMedium) || (event == kEventSurface);
+  const bool at_medium = event == kEventMedium;
 
   // vcm_shared.hxx:936-938, 1013-1015. The blue-noise override of the first vertex (:941-945, 1018-1022) needs the
   // host's tables: etx_hip_begin rejects options.blue_noise until etx_hip_upload_bluenoise provides them.
-  const f2 rnd_bsdf = st.sampler.next_2d();
-  const f2 rnd_connection = st.sampler.next_2d();
-  const f2 rnd_support = st.sampler.next_2d();
-  const bool at_medium = event == kEventMedium;
+  f2 rnd_bsdf = {0.0f, 0.0f}, rnd_connection = {0.0f, 0.0f}, rnd_support = {0.0f, 0.0f};
   BsdfData bsdf_data;
   BsdfSample bs;
   f3 w_o_medium = mk3(0.0f);
   float pdf_fwd = 0.0f, pdf_rev = 0.0f;
   bool store = false, nee = false;
-  if (at_medium) {
-    st.d_vcm *= sqr(st.path_distance + ms.sampled_medium_t);
-    st.path_distance = 0.0f;
-    const DMedium& med = scene.mediums[st.medium];
-    // phase sampling before the explicit connections (vcm_shared.hxx:954-959)
-    w_o_medium = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
-    pdf_fwd = phase_function(st.ray_d, w_o_medium, med.g);
-    pdf_rev = phase_function(w_o_medium, st.ray_d, med.g);
-    const bool explicit_connections = med.explicit_connections && (st.depth + 1 <= scene.max_path_length);
-    nee = explicit_connections && opt_connect_to_light(it);
-    store = explicit_connections && opt_connect_vertices(it);
-  } else {
-    const etx_abi_material& mat = scene.materials[isect.material];
-    bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera);
-    st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
-    bs = bsdf_sample_s<kSimple>(scene, bsdf_data, mat, st.sampler);
-    st.sampler.pop_fixed();
-    const bool is_connectible = (bs.properties & kSampleDelta) == 0u;
+  if (scatter_event) {
+    rnd_bsdf = st.sampler.next_2d();
+    rnd_connection = st.sampler.next_2d();
+    rnd_support = st.sampler.next_2d();
+    if (at_medium) {
+      st.d_vcm *= sqr(st.path_distance + ms.sampled_medium_t);
+      st.path_distance = 0.0f;
+      const DMedium& med = scene.mediums[st.medium];
+      // phase sampling before the explicit connections (vcm_shared.hxx:954-959)
+      w_o_medium = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
+      pdf_fwd = phase_function(st.ray_d, w_o_medium, med.g);
+      pdf_rev = phase_function(w_o_medium, st.ray_d, med.g);
+      const bool explicit_connections = med.explicit_connections && (st.depth + 1 <= scene.max_path_length);
+      nee = explicit_connections && opt_connect_to_light(it);
+      store = explicit_connections && opt_connect_vertices(it);
+    } else {
+      const etx_abi_material& mat = scene.materials[isect.material];
+      bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera);
+      st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
+      bs = bsdf_sample_s<kSimple>(scene, bsdf_data, mat, st.sampler);
+      st.sampler.pop_fixed();
+      const bool is_connectible = (bs.properties & kSampleDelta) == 0u;
 
-    // vcm_update_camera_vcm, vcm_shared.hxx:589-595
-    float cos_to_prev = fabsf(dot(isect.nrm, -st.ray_d));
-    st.d_vcm *= sqr(st.path_distance + isect.t) / cos_to_prev;
-    st.d_vc /= cos_to_prev;
-    st.d_vm /= cos_to_prev;
-    st.path_distance = 0.0f;
+      // vcm_update_camera_vcm, vcm_shared.hxx:589-595
+      float cos_to_prev = fabsf(dot(isect.nrm, -st.ray_d));
+      st.d_vcm *= sqr(st.path_distance + isect.t) / cos_to_prev;
+      st.d_vc /= cos_to_prev;
+      st.d_vm /= cos_to_prev;
+      st.path_distance = 0.0f;
 
-    // vcm_handle_direct_hit, vcm_shared.hxx:597-606
-    if (opt_direct_hit(it) && (isect.emitter != kInvalid) && (st.depth <= scene.max_path_length) && (st.depth >= scene.min_path_length)) {
-      f3 gathered = vcm_get_radiance(scene, scene.emitters[isect.emitter], st, it, isect);
-      if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
-        atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered);
+      // vcm_handle_direct_hit, vcm_shared.hxx:597-606
+      if (opt_direct_hit(it) && (isect.emitter != kInvalid) && (st.depth <= scene.max_path_length) && (st.depth >= scene.min_path_length)) {
+        f3 gathered = vcm_get_radiance(scene, scene.emitters[isect.emitter], st, it, isect);
+        if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
+          atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered);
+      }
+      nee = is_connectible;
+      store = is_connectible && (opt_connect_vertices(it) || (opt_merge_vertices(it) && (st.depth + 1 <= scene.max_path_length)));
     }
-    nee = is_connectible;
-    store = is_connectible && (opt_connect_vertices(it) || (opt_merge_vertices(it) && (st.depth + 1 <= scene.max_path_length)));
   }
 
   // ---- phase B
+  const uint32_t vertex_slot = slots.get(store, p.counters + kCntCameraVertices);
   if (store) {
     Sampler derived;
     derived.init(st.sampler.seed, 0x51ed270bu);
     if (at_medium)
-      store_camera_vertex(p, scene, st, mk4(ms.pos, __uint_as_float(kInvalid)), derived.seed, nullptr);
+      store_camera_vertex(p, vertex_slot, scene, st, mk4(ms.pos, __uint_as_float(kInvalid)), derived.seed, nullptr);
     else
-      store_camera_vertex(p, scene, st, h, derived.seed, &isect);
+      store_camera_vertex(p, vertex_slot, scene, st, h, derived.seed, &isect);
   }
+  ShadowRequest request;
+  bool queue = false;
   if (nee) {
     st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-    vcm_connect_to_light<kSimple>(p, scene, it, at_medium, &isect, ms.pos, st, film_index(it, st.id));
+    queue = vcm_connect_to_light<kSimple>(scene, it, at_medium, &isect, ms.pos, st, film_index(it, st.id), request);
     st.sampler.pop_fixed();
   }
+  const uint32_t shadow_slot = slots.get(queue, p.counters + kCntShadow);
+  if (queue)
+    write_shadow(p, shadow_slot, request);
 
   // ---- phase C
+  if (event == kEventBoundary)
+    return true;
+  if (scatter_event == false)
+    return false;
   if (at_medium) {  // vcm_shared.hxx:973-994
     st.d_vc = (1.0f / pdf_fwd) * (st.d_vc * pdf_rev + st.d_vcm);
     st.d_vm = (1.0f / pdf_fwd) * (st.d_vm * pdf_rev + 0.0f);

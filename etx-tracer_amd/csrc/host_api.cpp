@@ -167,6 +167,8 @@ int allocate_pipeline(etx_hip_context* ctx) {
     return rc;
   if ((rc = device_alloc(ctx, p.camera_sum, n)) || (rc = device_alloc(ctx, p.light_sum, n)) || (rc = device_alloc(ctx, ctx->resolve_buffer, n)))
     return rc;
+  if ((rc = device_alloc(ctx, p.block_stats, kBlockStatRows * kBlockStatCount)))
+    return rc;
   if ((rc = device_alloc(ctx, p.counters, kCounterCount)))
     return rc;
   HIP_OK(ctx, hipMemset(p.counters, 0, kCounterCount * sizeof(uint32_t)));
@@ -364,6 +366,7 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
     rounds);
   if (rc)
     return rc;
+  launch_stats_finalize(s, p);
   ctx->stats.wavefront_bounces = rounds;
   return 0;
 }

@@ -16,6 +16,7 @@ void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_ite
 void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count, bool flat);
 
 // VCM light pass
+void launch_stats_finalize(hipStream_t stream, const Pipeline& p);
 void launch_iteration_reset(hipStream_t stream, const Pipeline& p);
 void launch_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
 void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);

@@ -30,28 +30,41 @@ ETX_DEV bool material_is_diffuse(const DScene& scene, uint32_t tri) {
 // ---------------------------------------------------------------------------------------------------------------
 // (camera vertex, light path) -> pairs
 __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmParams it) {
+  __shared__ uint32_t s_wave_total[kBlockSize / 64u];
+  __shared__ uint32_t s_base;
   const uint32_t count = p.counters[kCntCameraVertices];
-  ETX_WAVE_LOOP(count) {
-    const uint32_t i = base_ + lane_;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6u;
+  ETX_BLOCK_LOOP(count, i) {
     uint32_t head = kInvalid, k = 0;
     if (i < count) {
       head = p.light_path_head[__float_as_uint(p.cv.mis_pixel[i].w)];
       // the head vertex knows its index in the path (store_light_vertex), so the path length needs no extra table
       k = (head == kInvalid) ? 0u : ((__float_as_uint(p.lv.bc_len_med(head).z) >> 16u) + 1u);
     }
-    // wave exclusive prefix sum of k
+    // workgroup exclusive prefix sum of k: wave scan, then one reservation for all four waves
     uint32_t incl = k;
 #pragma unroll
     for (uint32_t d = 1; d < 64; d <<= 1) {
       uint32_t t = __shfl_up(incl, d);
-      if (lane_ >= d)
+      if (lane >= d)
         incl += t;
     }
-    uint32_t total = __shfl(incl, 63);
-    uint32_t base = 0;
-    if (lane_ == 0)
-      base = total ? atomicAdd(p.counters + kCntPairs, total) : 0u;
-    base = __shfl(base, 0) + incl - k;
+    if (lane == 63u)
+      s_wave_total[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+      uint32_t total = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < kBlockSize / 64u; ++w)
+        total += s_wave_total[w];
+      s_base = total ? atomicAdd(p.counters + kCntPairs, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_base + incl - k;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlockSize / 64u; ++w)
+      base += (w < wave) ? s_wave_total[w] : 0u;
+    __syncthreads();
     if (base + k > p.pair_capacity) {
       if (k)
         atomicOr(p.counters + kCntOverflow, kOverflowPairs);
@@ -64,31 +77,37 @@ __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmPara
 
 template <bool kDiffuseOnly>
 __global__ __launch_bounds__(kBlockSize) void k_connect_pairs(Pipeline p, VcmParams it) {
+  __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntPairs], p.pair_capacity);
-  ETX_WAVE_LOOP(count) {
-    const uint32_t i = base_ + lane_;
-    if (i >= count)
-      continue;
-    const uint2 pair = p.pairs[i];
-    LightVertex lv = load_light_vertex(p.lv, pair.y);
-    const uint32_t cam_tri = __float_as_uint(p.cv.hit[pair.x].w);
-    bool all_diffuse = ((cam_tri == kInvalid) || material_is_diffuse(scene, cam_tri)) && (lv.is_medium() || material_is_diffuse(scene, lv.tri));
-    if (all_diffuse != kDiffuseOnly)
-      continue;
-    CameraVertex cv = load_camera_vertex(p, scene, pair.x);
-    const uint32_t target_path_length = cv.st.depth + lv.index_in_path + 2u;  // vcm_shared.hxx:774
-    if ((target_path_length < scene.min_path_length) || (target_path_length > scene.max_path_length))
-      continue;
-    // the reference evaluates every connection of a vertex with the path's sampler; decorrelate per pair
-    cv.st.sampler.seed = Sampler::random_seed(cv.st.sampler.seed, pair.y);
-    f3 target_position, value;
-    if (vcm_connect_to_light_vertex<kDiffuseOnly>(scene, cv.st, lv, it, cv.at_medium, &cv.isect, cv.medium_pos, cv.st.sampler, target_position, value) == false)
-      continue;
-    f3 p0 = cv.medium_pos;
-    if (cv.at_medium == false)
-      p0 = shading_pos(scene, scene.triangles[cv.isect.tri], cv.isect.bc, normalize(target_position - cv.isect.pos));
-    push_shadow(p, p0, cv.at_medium ? lv.pos : target_position, cv.st.medium, film_index(it, cv.st.id), value);
+  ETX_BLOCK_LOOP(count, i) {
+    ShadowRequest request;
+    bool queue = false;
+    if (i < count) {
+      const uint2 pair = p.pairs[i];
+      LightVertex lv = load_light_vertex(p.lv, pair.y);
+      const uint32_t cam_tri = __float_as_uint(p.cv.hit[pair.x].w);
+      bool all_diffuse = ((cam_tri == kInvalid) || material_is_diffuse(scene, cam_tri)) && (lv.is_medium() || material_is_diffuse(scene, lv.tri));
+      if (all_diffuse == kDiffuseOnly) {
+        CameraVertex cv = load_camera_vertex(p, scene, pair.x);
+        const uint32_t target_path_length = cv.st.depth + lv.index_in_path + 2u;  // vcm_shared.hxx:774
+        if ((target_path_length >= scene.min_path_length) && (target_path_length <= scene.max_path_length)) {
+          // the reference evaluates every connection of a vertex with the path's sampler; decorrelate per pair
+          cv.st.sampler.seed = Sampler::random_seed(cv.st.sampler.seed, pair.y);
+          f3 target_position, value;
+          if (vcm_connect_to_light_vertex<kDiffuseOnly>(scene, cv.st, lv, it, cv.at_medium, &cv.isect, cv.medium_pos, cv.st.sampler, target_position, value)) {
+            f3 p0 = cv.medium_pos;
+            if (cv.at_medium == false)
+              p0 = shading_pos(scene, scene.triangles[cv.isect.tri], cv.isect.bc, normalize(target_position - cv.isect.pos));
+            request = {p0, cv.at_medium ? lv.pos : target_position, value, cv.st.medium, film_index(it, cv.st.id)};
+            queue = true;
+          }
+        }
+      }
+    }
+    const uint32_t slot = block_compact_slot(queue, p.counters + kCntShadow, s_scratch);
+    if (queue)
+      write_shadow(p, slot, request);
   }
 }
 
@@ -416,10 +435,9 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
     }
     __threadfence_block();  // accumulators are zeroed again at the top of the next batch
   }
-  if (examined | merged_count) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsExamined), examined);
-    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsMerged), merged_count);
-  }
+  __shared__ unsigned long long s_stat;
+  block_stat_add(p, kBlockStatExamined, examined, &s_stat);
+  block_stat_add(p, kBlockStatMerged, merged_count, &s_stat);
 }
 
 // Every other connectible material: generic BSDF evaluation per accepted photon (stochastic for rough conductors).
@@ -488,10 +506,9 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
     if (((lane_ & 7u) == 0u) && ((merged.x != 0.0f) || (merged.y != 0.0f) || (merged.z != 0.0f)))
       atomic_add_f3(p.camera_sum + film_index(it, pixel), merged * it.vm_normalization);
   }
-  if (examined) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsExamined), examined);
-    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsMerged), merged_count);
-  }
+  __shared__ unsigned long long s_stat;
+  block_stat_add(p, kBlockStatExamined, examined, &s_stat);
+  block_stat_add(p, kBlockStatMerged, merged_count, &s_stat);
 }
 
 void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items) {

@@ -6,6 +6,7 @@
 // wave-uniform grid-stride loop; per-lane traversal stack in LDS laid out [level][lane] (bank conflict free).
 #include "kernels.h"
 #include "dev_bvh.h"
+#include "dev_vcm.h"
 #include "pipeline.h"
 
 namespace etxd {
@@ -19,7 +20,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
   const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
   if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
     // housekeeping for the shade kernel that follows: its output counter and the camera vertex pool start empty
-    counters[active_counter ^ 1u] = 0u;
+    counters[kCntActiveA + kCntActiveB - active_counter] = 0u;
     counters[kCntCameraVertices] = 0u;
     counters[kCntPairs] = 0u;
     counters[kCntShadow] = 0u;
@@ -91,8 +92,8 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
   }
   if ((blockIdx.x == 0) && (threadIdx.x == 0))
     atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatRaysShadow), (unsigned long long)count);
-  if (splats)
-    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatSplats), (unsigned long long)splats);
+  __shared__ unsigned long long s_stat;
+  block_stat_add(p, kBlockStatSplats, splats, &s_stat);
 }
 
 void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_items, bool flat) {

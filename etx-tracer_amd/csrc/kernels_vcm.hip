@@ -46,6 +46,8 @@ __global__ __launch_bounds__(kBlockSize) void k_iteration_reset(Pipeline p) {
       v = 0xffffffffu;
     p.counters[tid] = v;
   }
+  if (tid < kBlockStatRows * kBlockStatCount)
+    p.block_stats[tid] = 0ull;
   for (uint32_t i = tid; i < p.capacity; i += stride)
     p.light_path_head[i] = kInvalid;
 }
@@ -57,9 +59,9 @@ void launch_iteration_reset(hipStream_t stream, const Pipeline& p) {
 // ---------------------------------------------------------------------------------------------------------------
 // vcm_generate_emitter_state, vcm_shared.hxx:310-349 (one light path per pixel index, vcm_cpu.cxx:139-140)
 __global__ __launch_bounds__(kBlockSize) void k_light_generate(Pipeline p, VcmParams it) {
+  __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
-  ETX_WAVE_LOOP(it.path_count) {
-    const uint32_t i = base_ + lane_;
+  ETX_BLOCK_LOOP(it.path_count, i) {
     bool valid = false;
     PathState st;
     if (i < it.path_count) {
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(kBlockSize) void k_light_generate(Pipeline p, VcmPa
         valid = true;
       }
     }
-    uint32_t slot = wave_compact_slot(valid, p.counters + kCntActiveA);
+    uint32_t slot = block_compact_slot(valid, p.counters + kCntActiveA, s_scratch);
     if (valid)
       store_path(p.paths[0], slot, st);
   }
@@ -104,16 +106,18 @@ __global__ __launch_bounds__(kBlockSize) ETX_LIGHT_ATTR void k_light_shade(Pipel
   const PathSet& out = p.paths[in_set ^ 1u];
   const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
   uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
-  ETX_WAVE_LOOP(count) {
-    const uint32_t i = base_ + lane_;
-    bool alive = false;
+  __shared__ BlockScratch s_scratch;
+  const BlockSlots slots = {&s_scratch};
+  ETX_BLOCK_LOOP(count, i) {
+    const bool valid = i < count;
     PathState st;
-    if (i < count) {
+    float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
+    if (valid) {
       st = load_path(in, i);
-      const float4 h = p.hits[i];
-      alive = light_step<kSimple>(p, scene, it, st, h);
+      h = p.hits[i];
     }
-    uint32_t slot = wave_compact_slot(alive, out_counter);
+    const bool alive = light_step<kSimple>(p, scene, it, st, h, valid, slots);
+    const uint32_t slot = slots.get(alive, out_counter);
     if (alive)
       store_path(out, slot, st);
   }
@@ -176,16 +180,18 @@ __global__ __launch_bounds__(kBlockSize) ETX_CAM_ATTR void k_camera_shade(Pipeli
   const PathSet& out = p.paths[in_set ^ 1u];
   const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
   uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
-  ETX_WAVE_LOOP(count) {
-    const uint32_t i = base_ + lane_;
-    bool alive = false;
+  __shared__ BlockScratch s_scratch;
+  const BlockSlots slots = {&s_scratch};
+  ETX_BLOCK_LOOP(count, i) {
+    const bool valid = i < count;
     PathState st;
-    if (i < count) {
+    float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
+    if (valid) {
       st = load_path(in, i);
-      const float4 h = p.hits[i];
-      alive = camera_step<kSimple>(p, scene, it, st, h);
+      h = p.hits[i];
     }
-    uint32_t slot = wave_compact_slot(alive, out_counter);
+    const bool alive = camera_step<kSimple>(p, scene, it, st, h, valid, slots);
+    const uint32_t slot = slots.get(alive, out_counter);
     if (alive)
       store_path(out, slot, st);
   }
@@ -214,6 +220,34 @@ void launch_debug_lists(hipStream_t stream, const Pipeline& p) {
   hipLaunchKernelGGL(k_debug_lists, dim3((p.capacity + 255u) / 256u), dim3(256), 0, stream, p);
 }
 #endif
+
+// Folds the per-workgroup statistics rows into the u64 counters the host reads (once per iteration).
+__global__ __launch_bounds__(kBlockSize) void k_stats_finalize(Pipeline p) {
+  __shared__ unsigned long long s_sum[kBlockStatCount];
+  if (threadIdx.x < kBlockStatCount)
+    s_sum[threadIdx.x] = 0ull;
+  __syncthreads();
+  for (uint32_t k = 0; k < kBlockStatCount; ++k) {
+    unsigned long long v = 0ull;
+    for (uint32_t row = threadIdx.x; row < kBlockStatRows; row += blockDim.x)
+      v += p.block_stats[row * kBlockStatCount + k];
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1)
+      v += __shfl_xor(v, d);
+    if (((threadIdx.x & 63u) == 0u) && (v != 0ull))
+      atomicAdd(&s_sum[k], v);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsExamined) = s_sum[kBlockStatExamined];
+    *reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsMerged) = s_sum[kBlockStatMerged];
+    *reinterpret_cast<unsigned long long*>(p.counters + kStatSplats) = s_sum[kBlockStatSplats];
+  }
+}
+
+void launch_stats_finalize(hipStream_t stream, const Pipeline& p) {
+  hipLaunchKernelGGL(k_stats_finalize, dim3(1), dim3(kBlockSize), 0, stream, p);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Film::layer, film.cxx:381-418: float3 sums -> float4 (alpha 1); Result = max(0, camera + light)

@@ -92,27 +92,35 @@ constexpr uint32_t kShadowTargetLight = 0x80000000u;
 constexpr uint32_t kMergeBucketBits = 6;                                  // per axis
 constexpr uint32_t kMergeBuckets = 1u << (3u * kMergeBucketBits);         // 64^3 coarse buckets
 
-enum : uint32_t {  // device counters (u32), cleared per iteration unless noted
+// Device counters (u32), cleared per iteration unless noted. Atomics on one 128-byte line are serialised by the L2
+// channel that owns it - measured 88 M atomics/s chip-wide (11.3 ns each) no matter how many different words of the
+// line are hit, 3x that for three lines - so every hot counter lives on a line of its own (index stride 32) and the
+// queue producers reserve slots once per workgroup, not once per wavefront (dev_vcm.h block_compact_slot).
+enum : uint32_t {
   kCntActiveA = 0,
-  kCntActiveB = 1,
-  kCntLightVertices = 2,
-  kCntCameraVertices = 3,   // cleared per bounce
-  kCntOverflow = 4,
-  kCntBboxMin = 5,          // 3 x ordered-int float min
-  kCntBboxMax = 8,          // 3 x ordered-int float max
-  kCntPairs = 11,
-  kCntShadow = 12,
-  kCntMergeVertices = 13,   // camera vertices of the current bounce that take part in the merge          // shadow requests of the current bounce, cleared per bounce           // (camera vertex, light vertex) pairs of the current bounce, cleared per bounce
-  kCntStatsBase = 16,
-  kStatRaysExtension = 16,
-  kStatRaysShadow = 18,
-  kStatCameraVertices = 20,
-  kStatPhotonsExamined = 22,
-  kStatPhotonsMerged = 24,
-  kStatSplats = 26,
-  kDbgBase = 32,           // u64 debug counters (ETX_HIP_DEBUG_COUNTERS builds)
-  kCounterCount = 64,
+  kCntActiveB = 32,
+  kCntLightVertices = 64,
+  kCntCameraVertices = 96,   // cleared per bounce
+  kCntOverflow = 128,
+  kCntBboxMin = 160,         // 3 x ordered-int float min
+  kCntBboxMax = 192,         // 3 x ordered-int float max
+  kCntPairs = 224,           // (camera vertex, light vertex) pairs of the current bounce, cleared per bounce
+  kCntShadow = 256,          // shadow requests of the current bounce, cleared per bounce
+  kCntMergeVertices = 288,   // camera vertices of the current bounce that take part in the merge
+  kStatRaysExtension = 320,  // u64 statistics
+  kStatRaysShadow = 352,
+  kStatCameraVertices = 384,
+  kStatPhotonsExamined = 416,
+  kStatPhotonsMerged = 448,
+  kStatSplats = 480,
+  kDbgBase = 512,            // u64 debug counters (ETX_HIP_DEBUG_COUNTERS builds)
+  kCounterCount = 544,
 };
+
+// Per-workgroup statistics (u64): workgroup b of any launch adds to row b without atomics (launches on one stream do
+// not overlap); k_stats_finalize folds the rows into the counters above once per iteration.
+enum : uint32_t { kBlockStatExamined = 0, kBlockStatMerged = 1, kBlockStatSplats = 2, kBlockStatCount = 4 };
+constexpr uint32_t kBlockStatRows = 2048 + 8;
 
 enum : uint32_t {
   kOverflowLightVertices = 1u << 0,
@@ -161,6 +169,7 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   float4* camera_sum;
   float4* light_sum;
   uint32_t* counters;
+  unsigned long long* block_stats;  // kBlockStatRows x kBlockStatCount
   uint32_t capacity;     // paths per set
 };
 
