@@ -116,31 +116,59 @@ ETX_DEV FlatTri load_flat_triangle(ConstantFloats table, uint32_t i) {
   return {make_float4(t[0], t[1], t[2], t[3]), make_float4(t[4], t[5], t[6], t[7]), make_float4(t[8], t[9], t[10], t[11])};
 }
 
+// Test of one flat primitive: Moeller-Trumbore, the parallelogram drops the a + b <= 1 condition.
+ETX_DEV bool flat_prim_test(const FlatTri& prim, uint32_t flags, const RayQ& ray, float t_limit, float& out_a, float& out_b, float& out_t) {
+  const f3 E1 = {prim.e1.x, prim.e1.y, prim.e1.z}, E2 = {prim.e2.x, prim.e2.y, prim.e2.z};
+  const f3 pv = cross(ray.d, E2);
+  const float det = dot(E1, pv);
+  const float inv_det = __builtin_amdgcn_rcpf(det);
+  const f3 s = ray.o - f3{prim.v0.x, prim.v0.y, prim.v0.z};
+  const float a = dot(s, pv) * inv_det;
+  const f3 q = cross(s, E1);
+  const float b = dot(ray.d, q) * inv_det;
+  const float t = dot(E2, q) * inv_det;
+  out_a = a, out_b = b, out_t = t;
+  const float diagonal = (flags & kTriQuad) ? 2.0f : 1.0f;
+  return (det != 0.0f) && (a >= 0.0f) && (a <= 1.0f) && (b >= 0.0f) && (b <= 1.0f) && (a + b <= diagonal) && (t >= ray.tmin) && (t <= t_limit);
+}
+
+// (primitive, a, b) -> (triangle, u, v)
+ETX_DEV Hit flat_resolve(const DScene& scene, uint32_t prim, float a, float b, float t) {
+  const FlatPrimInfo& info = scene.flat_info[prim];
+  const bool second = (info.tri_b != kInvalid) && (a + b > 1.0f);
+  const float* cu = second ? info.ub : info.ua;
+  const float* cv = second ? info.vb : info.va;
+  return {cu[0] + cu[1] * a + cu[2] * b, cv[0] + cv[1] * a + cv[2] * b, t, second ? info.tri_b : info.tri_a};
+}
+
 template <class Tris>
-ETX_DEV Hit bvh_flat_closest(const DScene& scene, Tris tris, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags) {
-  static_assert(sizeof(BvhTri) == 48, "12 floats per triangle");
-  Hit best = {0.0f, 0.0f, ray.tmax, kInvalid};
+ETX_DEV Hit bvh_flat_closest(const DScene& scene, Tris, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags) {
+  static_assert(sizeof(BvhTri) == 48, "12 floats per primitive");
+  float best_a = 0.0f, best_b = 0.0f, best_t = ray.tmax;
+  uint32_t best_prim = kInvalid;
   uint32_t best_flags = 0u;
-  const uint32_t count = scene.bvh_tri_count;
-  ConstantFloats table = (ConstantFloats)(const void*)(scene.bvh_tris);
+  const uint32_t count = scene.flat_prim_count;
+  ConstantFloats table = (ConstantFloats)(const void*)(scene.flat_prims);
 #pragma unroll 4
   for (uint32_t i = 0; i < count; ++i) {
-    const FlatTri tri = load_flat_triangle(table, i);
-    float u, v, t;
-    if (triangle_test(tri.v0, tri.e1, tri.e2, ray, best.t, u, v, t) == false)
+    const FlatTri prim = load_flat_triangle(table, i);
+    const uint32_t flags = __float_as_uint(prim.e1.w);
+    float a, b, t;
+    if (flat_prim_test(prim, flags, ray, best_t, a, b, t) == false)
       continue;
-    const uint32_t flags = __float_as_uint(tri.e1.w);
     if (flags & kTriVoid)
       continue;
-    const uint32_t tri_index = __float_as_uint(tri.v0.w);
-    if ((flags & kTriAlphaTested) && alpha_test_skips(scene, tri_index, __float_as_uint(tri.e2.w), u, v, alpha_seed))
+    // alpha-tested triangles are never merged into parallelograms: (a, b) are the triangle's own barycentrics
+    if ((flags & kTriAlphaTested) && alpha_test_skips(scene, scene.flat_info[i].tri_a, __float_as_uint(prim.e2.w), a, b, alpha_seed))
       continue;
-    best = {u, v, t, tri_index};
+    best_a = a, best_b = b, best_t = t, best_prim = i;
     best_flags = flags;
   }
   if (out_flags)
     *out_flags = best_flags;
-  return best;
+  if (best_prim == kInvalid)
+    return {0.0f, 0.0f, ray.tmax, kInvalid};
+  return flat_resolve(scene, best_prim, best_a, best_b, best_t);
 }
 
 // Closest accepted hit in [tmin, tmax]. `Nodes`/`Tris` are pointer types (global or LDS address space).
@@ -220,19 +248,19 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
   uint32_t bi0 = kInvalid, bi1 = kInvalid, bi2 = kInvalid, bi3 = kInvalid;
   uint32_t crossings = 0;
   bool occluded = false;
-  const uint32_t count = scene.bvh_tri_count;
-  ConstantFloats table = (ConstantFloats)(const void*)(scene.bvh_tris);
+  const uint32_t count = scene.flat_prim_count;
+  ConstantFloats table = (ConstantFloats)(const void*)(scene.flat_prims);
 #pragma unroll 4
   for (uint32_t i = 0; i < count; ++i) {
     const FlatTri tri = load_flat_triangle(table, i);
-    float u, v, t;
-    if (triangle_test(tri.v0, tri.e1, tri.e2, ray, t_max, u, v, t) == false)
-      continue;
     const uint32_t flags = __float_as_uint(tri.e1.w);
+    float u, v, t;
+    if (flat_prim_test(tri, flags, ray, t_max, u, v, t) == false)
+      continue;
     if (flags & kTriVoid)
       continue;
-    const uint32_t tri_index = __float_as_uint(tri.v0.w);
-    if ((flags & kTriAlphaTested) && alpha_test_skips(scene, tri_index, __float_as_uint(tri.e2.w), u, v, alpha_seed))
+    const uint32_t tri_index = i;  // primitive index; both halves of a parallelogram share plane, winding and material
+    if ((flags & kTriAlphaTested) && alpha_test_skips(scene, scene.flat_info[i].tri_a, __float_as_uint(tri.e2.w), u, v, alpha_seed))
       continue;
     if ((flags & kTriBoundary) == 0u) {
       occluded = true;
@@ -263,7 +291,7 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
     if (k < crossings) {
       if (medium != kInvalid)
         result *= medium_transmittance_homogeneous(scene.mediums[medium], fmaxf(0.0f, bts[k] - current_t));
-      const etx_abi_triangle& tri = scene.triangles[bis[k]];
+      const etx_abi_triangle& tri = scene.triangles[scene.flat_info[bis[k]].tri_a];
       const etx_abi_material& mat = scene.materials[tri.material_index];
       medium = (dot(ld3(tri.geo_n), direction) < 0.0f) ? mat.int_medium : mat.ext_medium;
       current_t = bts[k];

@@ -34,7 +34,20 @@ enum : uint32_t {
   kTriVoid = 1u << 0,        // Material::Class::Void: never reported (rt.cxx:441-444)
   kTriAlphaTested = 1u << 1, // opacity < 1 or alpha texture: stochastic alpha test (scene_bsdf.hxx:128-144)
   kTriBoundary = 1u << 2,    // Material::Class::Boundary: transparent to transmittance rays (rt.cxx:503)
+  kTriQuad = 1u << 3,        // flat-sweep primitive that covers a parallelogram = two triangles (FlatPrimInfo)
 };
+
+// Flat sweep (dev_bvh.h): the primitives are the scene's triangles, except that two coplanar triangles which form a
+// parallelogram (same material, same filter flags, same winding - every wall of a Cornell box) are tested once as
+// P = v0 + a e1 + b e2 with a, b in [0, 1]. After the sweep the hit is handed back as (triangle, u, v) of the
+// reference's convention: u and v of the triangle on either side of the diagonal are affine in (a, b).
+struct __attribute__((aligned(16))) FlatPrimInfo {
+  uint32_t tri_a, tri_b;  // tri_b == kInvalid: a single triangle
+  float ua[3], va[3];     // a + b <= 1: u = ua[0] + ua[1] a + ua[2] b, v likewise
+  float ub[3], vb[3];     // a + b >  1: barycentrics in tri_b
+  uint32_t pad[2];
+};
+static_assert(sizeof(FlatPrimInfo) == 64, "FlatPrimInfo");
 
 struct DImage {
   const float4* pixels;                  // isize.x * isize.y, RGBA8 sources are expanded at upload
@@ -78,8 +91,10 @@ struct DScene {
   const DMedium* mediums;
   const BvhNode* bvh_nodes;
   const BvhTri* bvh_tris;
+  const BvhTri* flat_prims;        // bvh_flat scenes: v0.w = primitive index, e1.w = flags, e2.w = material
+  const FlatPrimInfo* flat_info;   // per primitive
   uint32_t vertex_count, triangle_count, material_count, emitter_count, emitter_dist_count, spectrum_count, image_count, medium_count;
-  uint32_t bvh_node_count, bvh_tri_count;
+  uint32_t bvh_node_count, bvh_tri_count, flat_prim_count, pad_flat;
   int32_t bvh_root;  // child encoding (a single leaf scene has a negative root)
   uint32_t bvh_flat; // != 0: so few triangles that the wave-uniform linear sweep beats the tree (dev_bvh.h)
   float emitter_dist_total;

@@ -125,6 +125,9 @@ int allocate_pipeline(etx_hip_context* ctx) {
   Pipeline& p = ctx->pipe;
   const uint32_t n = ctx->scene.film_w * ctx->scene.film_h;
   p.scene = ctx->scene.host_copy;
+  p.debug_flags = 0u;
+  if (const char* e = getenv("ETX_HIP_DEBUG_FLAGS"))
+    p.debug_flags = uint32_t(strtoul(e, nullptr, 0));
   p.capacity = n;
   int rc = 0;
   for (int s = 0; s < 2; ++s) {

@@ -5,6 +5,7 @@
 #include "dev_bvh.h"
 #include "../../include/etx_hip.h"
 
+#include <cstdio>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -144,6 +145,104 @@ f3 a3(const etx_abi_float3& v) {
 }
 
 }  // namespace
+
+// Flat-sweep primitives (dev_scene.h FlatPrimInfo): the triangles in traversal order, with every pair that forms a
+// parallelogram (two shared corners, fourth corner = a_i + a_j - a_k, same material / flags / winding, no alpha test)
+// merged into one primitive based at the corner opposite the shared edge.
+void build_flat_prims(const etx_abi_scene* scene, const HostBvh& bvh, std::vector<etxd::BvhTri>& prims, std::vector<etxd::FlatPrimInfo>& infos) {
+  using namespace etxd;
+  const auto* vertices = reinterpret_cast<const etx_abi_vertex*>(scene->vertices.a);
+  const auto* triangles = reinterpret_cast<const etx_abi_triangle*>(scene->triangles.a);
+  auto ubits = [](float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+  };
+  auto fbits = [](uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
+  const size_t n = bvh.tris.size();
+  std::vector<bool> used(n, false);
+  auto corner = [&](uint32_t tri, uint32_t k) { return a3(vertices[triangles[tri].i[k]].pos); };
+  auto close = [](const f3& a, const f3& b, float tol) { return (fabsf(a.x - b.x) <= tol) && (fabsf(a.y - b.y) <= tol) && (fabsf(a.z - b.z) <= tol); };
+  // weights of the three roles as affine functions (c0, c1 a, c2 b) of the parallelogram coordinates
+  const float kFirst[3][3] = {{1.0f, -1.0f, -1.0f}, {0.0f, 1.0f, 0.0f}, {0.0f, 0.0f, 1.0f}};   // a + b <= 1: base corner, corner at a = 1, corner at b = 1
+  const float kSecond[3][3] = {{-1.0f, 1.0f, 1.0f}, {1.0f, 0.0f, -1.0f}, {1.0f, -1.0f, 0.0f}}; // a + b > 1: far corner, corner at a = 1, corner at b = 1
+  for (size_t ia = 0; ia < n; ++ia) {
+    if (used[ia])
+      continue;
+    used[ia] = true;
+    const uint32_t ta = ubits(bvh.tris[ia].v0_index.w);
+    const uint32_t flags = ubits(bvh.tris[ia].e1_flags.w);
+    const uint32_t material = ubits(bvh.tris[ia].e2_mat.w);
+    FlatPrimInfo info = {};
+    info.tri_a = ta;
+    info.tri_b = kInvalid;
+    BvhTri prim = bvh.tris[ia];
+    // single triangle: (a, b) are its own barycentrics
+    info.ua[1] = 1.0f, info.va[2] = 1.0f;
+    if ((flags & kTriAlphaTested) == 0u) {
+      const f3 a[3] = {corner(ta, 0), corner(ta, 1), corner(ta, 2)};
+      const f3 na = a3(triangles[ta].geo_n);
+      float extent = 0.0f;
+      for (int k = 0; k < 3; ++k)
+        extent = std::max(extent, std::max(fabsf(a[k].x), std::max(fabsf(a[k].y), fabsf(a[k].z))));
+      const float tol = 1.0e-6f * std::max(1.0f, extent);
+      for (size_t ib = ia + 1; (ib < n) && (info.tri_b == kInvalid); ++ib) {
+        if (used[ib] || (ubits(bvh.tris[ib].e1_flags.w) != flags) || (ubits(bvh.tris[ib].e2_mat.w) != material))
+          continue;
+        const uint32_t tb = ubits(bvh.tris[ib].v0_index.w);
+        const f3 nb = a3(triangles[tb].geo_n);
+        if (na.x * nb.x + na.y * nb.y + na.z * nb.z < 0.9999f)
+          continue;
+        const f3 b[3] = {corner(tb, 0), corner(tb, 1), corner(tb, 2)};
+        // role of every corner of B: index of the equal corner of A, or -1
+        int match[3] = {-1, -1, -1};
+        int shared = 0;
+        for (int m = 0; m < 3; ++m)
+          for (int k = 0; k < 3; ++k)
+            if ((match[m] < 0) && close(b[m], a[k], tol)) {
+              match[m] = k;
+              shared++;
+            }
+        if (shared != 2)
+          continue;
+        int far_b = (match[0] < 0) ? 0 : ((match[1] < 0) ? 1 : 2);
+        int base_k = 3 - match[(far_b + 1) % 3] - match[(far_b + 2) % 3];  // the corner of A that B does not share
+        if ((base_k < 0) || (base_k > 2) || (match[(far_b + 1) % 3] == match[(far_b + 2) % 3]))
+          continue;
+        const int ki = (base_k + 1) % 3, kj = (base_k + 2) % 3;
+        const f3 fourth = {a[ki].x + a[kj].x - a[base_k].x, a[ki].y + a[kj].y - a[base_k].y, a[ki].z + a[kj].z - a[base_k].z};
+        if (close(b[far_b], fourth, 4.0f * tol) == false)
+          continue;
+        // parallelogram: base corner a[base_k], a-axis towards a[ki], b-axis towards a[kj]
+        used[ib] = true;
+        info.tri_b = tb;
+        const f3 e1 = {a[ki].x - a[base_k].x, a[ki].y - a[base_k].y, a[ki].z - a[base_k].z};
+        const f3 e2 = {a[kj].x - a[base_k].x, a[kj].y - a[base_k].y, a[kj].z - a[base_k].z};
+        prim.v0_index = make_float4(a[base_k].x, a[base_k].y, a[base_k].z, 0.0f);
+        prim.e1_flags = make_float4(e1.x, e1.y, e1.z, fbits(flags | kTriQuad));
+        prim.e2_mat = make_float4(e2.x, e2.y, e2.z, fbits(material));
+        // u = weight of corner 1, v = weight of corner 2 (Embree convention, rt.cxx:352-353)
+        auto role_a = [&](int corner_index) { return (corner_index == base_k) ? 0 : ((corner_index == ki) ? 1 : 2); };
+        for (int c = 0; c < 3; ++c) {
+          info.ua[c] = kFirst[role_a(1)][c];
+          info.va[c] = kFirst[role_a(2)][c];
+        }
+        auto role_b = [&](int corner_index) { return (corner_index == far_b) ? 0 : ((match[corner_index] == ki) ? 1 : 2); };
+        for (int c = 0; c < 3; ++c) {
+          info.ub[c] = kSecond[role_b(1)][c];
+          info.vb[c] = kSecond[role_b(2)][c];
+        }
+      }
+    }
+    prim.v0_index.w = fbits(uint32_t(prims.size()));
+    prims.push_back(prim);
+    infos.push_back(info);
+  }
+}
 
 void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
   const auto* vertices = reinterpret_cast<const etx_abi_vertex*>(scene->vertices.a);
@@ -401,6 +500,17 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     return rc;
   d.bvh_node_count = uint32_t(bvh.nodes.size());
   d.bvh_tri_count = uint32_t(bvh.tris.size());
+  if (bvh.tris.size() <= kFlatSweepMaxTriangles) {
+    std::vector<BvhTri> prims;
+    std::vector<FlatPrimInfo> infos;
+    build_flat_prims(scene, bvh, prims, infos);
+    if ((rc = upload(out, prims.data(), prims.size(), d.flat_prims, error)) || (rc = upload(out, infos.data(), infos.size(), d.flat_info, error)))
+      return rc;
+    d.flat_prim_count = uint32_t(prims.size());
+    out.flat_prims = uint32_t(prims.size());
+    if (getenv("ETX_HIP_VERBOSE"))
+      fprintf(stderr, "[etx_hip] flat sweep: %zu triangles -> %zu primitives\n", bvh.tris.size(), prims.size());
+  }
   d.bvh_root = bvh.root;
   if (const char* e = getenv("ETX_HIP_FORCE_GENERIC_MATERIALS"))
     out.simple_materials = (atoi(e) != 0) ? false : out.simple_materials;

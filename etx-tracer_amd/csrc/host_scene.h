@@ -16,6 +16,7 @@ struct DeviceBuffer {
 };
 
 struct DeviceScene {
+  uint32_t flat_prims = 0;          // primitives of the flat sweep (parallelograms count once), 0 = BVH traversal
   etxd::DScene host_copy = {};      // the struct as uploaded (device pointers inside)
   etxd::DScene* device = nullptr;   // device copy of host_copy
   std::vector<void*> allocations;

@@ -67,26 +67,45 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
   uint32_t splats = 0;
   for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {
     const uint32_t i = base + lane;
-    if (i >= count)
+    f3 value = mk3(0.0f);
+    uint32_t target = 0xffffffffu - lane;  // idle lanes: a target nobody shares
+    if (i < count) {
+      const float4 a = p.shadow.p0_medium[i];
+      const float4 b = p.shadow.p1_target[i];
+      uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ i;
+      f3 tr = mk3(1.0f);
+      if ((p.debug_flags & 4u) == 0u)
+        tr = bvh_transmittance(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), alpha_seed);
+      target = __float_as_uint(b.w);
+      if ((tr.x > kEpsilon) || (tr.y > kEpsilon) || (tr.z > kEpsilon)) {  // SpectralResponse::is_zero
+        const float4 v = p.shadow.value[i];
+        value = tr * f3{v.x, v.y, v.z};
+        if (target & kShadowTargetLight) {
+          // vcm_shared.hxx:1229 + vcm_cpu.cxx:148-153 + film.cxx:148: thresholds of the light splat
+          if ((max_component(value) <= kEpsilon) || (dot(value, value) <= kEpsilon))
+            value = mk3(0.0f);
+          else
+            splats++;
+        }
+      }
+    }
+    if (p.debug_flags & 1u)
       continue;
-    const float4 a = p.shadow.p0_medium[i];
-    const float4 b = p.shadow.p1_target[i];
-    uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ i;
-    f3 tr = bvh_transmittance(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), alpha_seed);
-    if ((tr.x <= kEpsilon) && (tr.y <= kEpsilon) && (tr.z <= kEpsilon))
-      continue;  // SpectralResponse::is_zero
-    const float4 v = p.shadow.value[i];
-    const f3 value = tr * f3{v.x, v.y, v.z};
-    const uint32_t target = __float_as_uint(b.w);
-    if (target & kShadowTargetLight) {
-      // vcm_shared.hxx:1229 + vcm_cpu.cxx:148-153 + film.cxx:148: thresholds of the light splat
-      if ((max_component(value) <= kEpsilon) || (dot(value, value) <= kEpsilon))
-        continue;
-      float4* dst = p.light_sum + (target & ~kShadowTargetLight);
-      atomicAdd(&dst->x, value.x), atomicAdd(&dst->y, value.y), atomicAdd(&dst->z, value.z);
-      splats++;
-    } else {
-      float4* dst = p.camera_sum + target;
+    // The film atomics are the expensive part of this kernel (measured: 5 of 9 ms). The K connections of one camera
+    // vertex sit next to each other in the queue and hit the same pixel, so runs of equal targets are summed across
+    // lanes first (segmented inclusive scan) and only the last lane of a run touches the film.
+    const uint32_t previous_target = __shfl_up(target, 1);
+    const unsigned long long heads = __ballot((lane == 0u) || (previous_target != target));
+    const uint32_t run_start = 63u - uint32_t(__clzll(heads & (~0ull >> (63u - lane))));
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const float ox = __shfl_up(value.x, d), oy = __shfl_up(value.y, d), oz = __shfl_up(value.z, d);
+      if (lane >= run_start + d)
+        value.x += ox, value.y += oy, value.z += oz;
+    }
+    const bool run_end = (lane == 63u) || (((heads >> (lane + 1u)) & 1ull) != 0ull);
+    if (run_end && ((value.x != 0.0f) || (value.y != 0.0f) || (value.z != 0.0f))) {
+      float4* dst = (target & kShadowTargetLight) ? (p.light_sum + (target & ~kShadowTargetLight)) : (p.camera_sum + target);
       atomicAdd(&dst->x, value.x), atomicAdd(&dst->y, value.y), atomicAdd(&dst->z, value.z);
     }
   }

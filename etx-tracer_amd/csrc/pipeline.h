@@ -170,6 +170,7 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   float4* light_sum;
   uint32_t* counters;
   unsigned long long* block_stats;  // kBlockStatRows x kBlockStatCount
+  uint32_t debug_flags;             // ETX_HIP_DEBUG_FLAGS: ablation switches for kernel timing experiments (0 in production)
   uint32_t capacity;     // paths per set
 };
 
