@@ -22,6 +22,8 @@ ETX_DEV void store_light_vertex(const Pipeline& p, uint32_t idx, const PathState
   const uint32_t index_in_path = (prev == kInvalid) ? 0u : ((__float_as_uint(p.lv.bc_len_med(prev).z) >> 16u) + 1u);
   p.lv.bc_len_med(idx) = make_float4(bc_u, bc_v, __uint_as_float((index_in_path << 16u) | (st.depth & 0xffffu)), __uint_as_float(st.medium));
   p.lv.next(idx) = prev;
+  if (index_in_path < kPathTableEntries)
+    reinterpret_cast<uint32_t*>(p.light_path_table)[st.id * kPathTableEntries + index_in_path] = idx;
   p.light_path_head[st.id] = idx;  // the photon bounding box is reduced by k_grid_bbox (kernels_grid.hip)
 }
 

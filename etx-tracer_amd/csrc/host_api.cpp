@@ -148,7 +148,7 @@ int allocate_pipeline(etx_hip_context* ctx) {
   p.lv.capacity = uint32_t(lv_cap64);
   if ((rc = device_alloc(ctx, p.lv.rec, size_t(p.lv.capacity) * LightVertexPool::kLvStride)))
     return rc;
-  if ((rc = device_alloc(ctx, p.light_path_head, n)))
+  if ((rc = device_alloc(ctx, p.light_path_head, n)) || (rc = device_alloc(ctx, p.light_path_table, size_t(n) * (kPathTableEntries / 4u))))
     return rc;
   p.grid.hash_capacity = next_pow2(p.lv.capacity);
   if ((rc = device_alloc(ctx, p.grid.cell_ends, p.grid.hash_capacity)) || (rc = device_alloc(ctx, p.grid.pos_len, p.lv.capacity)) ||

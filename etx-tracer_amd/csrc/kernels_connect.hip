@@ -35,9 +35,10 @@ __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmPara
   const uint32_t count = p.counters[kCntCameraVertices];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6u;
   ETX_BLOCK_LOOP(count, i) {
-    uint32_t head = kInvalid, k = 0;
+    uint32_t head = kInvalid, k = 0, path = 0;
     if (i < count) {
-      head = p.light_path_head[__float_as_uint(p.cv.mis_pixel[i].w)];
+      path = __float_as_uint(p.cv.mis_pixel[i].w);
+      head = p.light_path_head[path];
       // the head vertex knows its index in the path (store_light_vertex), so the path length needs no extra table
       k = (head == kInvalid) ? 0u : ((__float_as_uint(p.lv.bc_len_med(head).z) >> 16u) + 1u);
     }
@@ -70,8 +71,22 @@ __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmPara
         atomicOr(p.counters + kCntOverflow, kOverflowPairs);
       continue;
     }
-    for (uint32_t vi = head; vi != kInvalid; vi = p.lv.next(vi))
-      p.pairs[base++] = make_uint2(i, vi);
+    if (k == 0u)
+      continue;
+    // the first kPathTableEntries vertices come from the path table (two independent 16-byte loads), only longer
+    // paths walk the list from the head down to that index
+    const uint4 t0 = p.light_path_table[path * 2u + 0u];
+    const uint4 t1 = (k > 4u) ? p.light_path_table[path * 2u + 1u] : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t table[kPathTableEntries] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+    for (uint32_t j = 0; j < kPathTableEntries; ++j)
+      if (j < k)
+        p.pairs[base + j] = make_uint2(i, table[j]);
+    uint32_t vi = head;
+    for (uint32_t j = k; j > kPathTableEntries; --j) {
+      p.pairs[base + j - 1u] = make_uint2(i, vi);
+      vi = p.lv.next(vi);
+    }
   }
 }
 

@@ -89,6 +89,7 @@ struct ShadowQueue {        // transmittance ("shadow") ray requests of the curr
 };
 
 constexpr uint32_t kShadowTargetLight = 0x80000000u;
+constexpr uint32_t kPathTableEntries = 8;
 constexpr uint32_t kMergeBucketBits = 6;                                  // per axis
 constexpr uint32_t kMergeBuckets = 1u << (3u * kMergeBucketBits);         // 64^3 coarse buckets
 
@@ -158,6 +159,8 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   float4* hits;          // hit queue, aligned with the "in" path set
   LightVertexPool lv;
   uint32_t* light_path_head;   // per path: last stored vertex (kInvalid = none)
+  uint4* light_path_table;     // per path: its first kPathTableEntries vertices by index in path (expand_pairs reads them
+                               // with two independent loads instead of walking the list from the head)
   PhotonGrid grid;
   GridParams* grid_params;
   CameraVertexPool cv;
