@@ -36,7 +36,9 @@ def cpu_baseline(snapshot_path, width, height, seconds_budget=25.0):
         return None
     # one probe iteration, then as many as fit the budget
     def run(iterations):
-        out = subprocess.run([binary, "--load-snapshot", snapshot_path, "--integrator", "vcm", "--spp", str(iterations), "--opt", "vcm-blue_noise=false"],
+        # VCMOptions::default_values() (blue noise on), like the device run; --max-iterations bounds the sample, --spp keeps
+        # scene.samples (and with it the blue-noise class) at the workload's 64
+        out = subprocess.run([binary, "--load-snapshot", snapshot_path, "--integrator", "vcm", "--spp", "64", "--max-iterations", str(iterations)],
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         m = re.search(r"ORACLE_RESULT (\{.*\})", out.stdout)
         return json.loads(m.group(1)) if m else None
@@ -94,7 +96,14 @@ def main():
     if distributed:
         multi_gpu.init_context_comm(ctx, rank, world)
 
-    options = integ_mod.vcm_options_from_dict({"vcm-blue_noise": False})  # VCMOptions::default_values otherwise
+    # VCMOptions::default_values(): blue noise on. The C++ host tabulates its BNSampler for the class of scene.samples
+    # (64 -> set 6, include/etx_hip.h); here the same table comes from the committed fixture of the reference's sampler.
+    from tools import bluenoise_tables
+    snap_samples = snap.samples
+    if bluenoise_tables.set_index(snap_samples) != 6:
+        raise SystemExit("bench workload expects scene.samples = 64 (blue-noise class 6), snapshot has %d" % snap_samples)
+    ctx.upload_bluenoise(6, bluenoise_tables.load(os.path.join(ROOT, "tests", "golden", "bluenoise_64spp.npz")))
+    options = integ_mod.vcm_options_from_dict({})
 
     def run_steps(count, first_offset):
         ctx.begin_vcm(options, first_iteration=rank + first_offset * world, iteration_stride=world)
@@ -153,7 +162,7 @@ def main():
             "config": {
                 "workload": "cornell_%s_vcm_1920x1080" % args.workload,
                 "scene": "Cornell box rebuilt for the reference's surviving camera/materials (scenes/make_scenes.py), loaded by the reference loader",
-                "integrator": "VCM, VCMOptions::default_values() except vcm-blue_noise=false, max-path-length 1023, rr start 6, RGB",
+                "integrator": "VCM, VCMOptions::default_values() (blue noise on), scene.samples 64, max-path-length 1023, rr start 6, RGB",
                 "samples_per_step": width * height,
                 "parallelism": "iteration-sharded x%d, one RCCL film all-reduce at the end" % world,
             },

@@ -115,7 +115,7 @@ class Library:
         L.etx_hip_last_error.argtypes = [vp]
         L.etx_hip_last_error.restype = ctypes.c_char_p
         L.etx_hip_upload_scene.argtypes = [vp, vp, vp]
-        L.etx_hip_upload_bluenoise.argtypes = [vp, u32, vp, vp, vp]
+        L.etx_hip_upload_bluenoise.argtypes = [vp, u32, vp, sz]
         L.etx_hip_begin.argtypes = [vp, i32, vp, sz, u32, u32]
         L.etx_hip_render_iteration.argtypes = [vp]
         L.etx_hip_poll.argtypes = [vp]
@@ -175,6 +175,12 @@ class Context:
         self._check(self.library.lib.etx_hip_upload_scene(self.handle, snapshot.scene_address, snapshot.camera_address))
         self.film_size = snapshot.film_size
         self._scene_keepalive = snapshot
+
+    def upload_bluenoise(self, set_index, values):
+        """values: uint8 array [128,128,256,8] - the host's sample_blue_noise outputs for one sample-count class."""
+        import numpy as np
+        table = np.ascontiguousarray(values, dtype=np.uint8)
+        self._check(self.library.lib.etx_hip_upload_bluenoise(self.handle, int(set_index), table.ctypes.data, table.nbytes))
 
     def begin_vcm(self, options, first_iteration=0, iteration_stride=1):
         self._check(self.library.lib.etx_hip_begin(self.handle, INTEGRATOR_VCM, ctypes.byref(options), ctypes.sizeof(options), first_iteration, iteration_stride))

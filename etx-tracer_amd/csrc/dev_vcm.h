@@ -170,6 +170,16 @@ ETX_DEV f3 trace_transmittance(TraceCtx& tc, const f3& p0, const f3& p1, uint32_
 // A connection whose visibility is still unknown: the shade / connect kernels evaluate everything but the
 // transmittance and queue the segment; k_trace_shadow (kernels_trace.hip) multiplies by the transmittance and adds
 // the result to the film. `target`: film pixel index, bit 31 set = light image (splat), clear = camera image.
+// The host's sample_blue_noise(pixel, scene.samples, sample, dimension 0..5) from the table of etx_hip_upload_bluenoise:
+// 8 bytes per (pixel of the 128 x 128 tile, sample), float = (0.5 + byte) / 256 (thirdparty/bluenoise, wrap as there)
+ETX_DEV void bluenoise_samples(const uint2* table, uint32_t px, uint32_t py, uint32_t sample, f2& d01, f2& d23, f2& d45) {
+  const uint2 v = table[((py & 127u) * 128u + (px & 127u)) * 256u + (sample & 255u)];
+  auto unpack = [](uint32_t word, uint32_t byte) { return (0.5f + float((word >> (8u * byte)) & 0xffu)) / 256.0f; };
+  d01 = {unpack(v.x, 0), unpack(v.x, 1)};
+  d23 = {unpack(v.x, 2), unpack(v.x, 3)};
+  d45 = {unpack(v.y, 0), unpack(v.y, 1)};
+}
+
 struct ShadowRequest {
   f3 p0, p1, value;
   uint32_t medium, target;

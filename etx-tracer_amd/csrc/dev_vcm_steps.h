@@ -200,8 +200,6 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
   const bool scatter_event = (event == kEventMedium) || (event == kEventSurface);
   const bool at_medium = event == kEventMedium;
 
-  // vcm_shared.hxx:936-938, 1013-1015. The blue-noise override of the first vertex (:941-945, 1018-1022) needs the
-  // host's tables: etx_hip_begin rejects options.blue_noise until etx_hip_upload_bluenoise provides them.
   f2 rnd_bsdf = {0.0f, 0.0f}, rnd_connection = {0.0f, 0.0f}, rnd_support = {0.0f, 0.0f};
   BsdfData bsdf_data;
   BsdfSample bs;
@@ -209,9 +207,14 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
   float pdf_fwd = 0.0f, pdf_rev = 0.0f;
   bool store = false, nee = false;
   if (scatter_event) {
+    // vcm_shared.hxx:936-938, 1013-1015: six numbers from the path's sampler ...
     rnd_bsdf = st.sampler.next_2d();
     rnd_connection = st.sampler.next_2d();
     rnd_support = st.sampler.next_2d();
+    // ... replaced by the host's blue-noise samples at the first camera vertex (:941-945, 1018-1022; the sampler has
+    // still advanced). pixel_coord = (index % W, index / W) (film.cxx:452-455), sample = iteration, dimensions 0..5
+    if ((it.bluenoise != nullptr) && (st.depth == 1u) && (it.iteration < 256u))
+      bluenoise_samples(it.bluenoise, st.id % it.film_w, st.id / it.film_w, it.iteration, rnd_bsdf, rnd_connection, rnd_support);
     if (at_medium) {
       st.d_vcm *= sqr(st.path_distance + ms.sampled_medium_t);
       st.path_distance = 0.0f;

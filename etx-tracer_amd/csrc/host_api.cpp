@@ -46,6 +46,8 @@ struct TimedSpan {
 
 }  // namespace
 
+constexpr uint32_t kBlueNoiseSets = 9;  // sample-count classes 1, 2, 4, ... 256 of the host's blue-noise sampler
+
 struct etx_hip_context {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -70,6 +72,8 @@ struct etx_hip_context {
   std::vector<TimedSpan> spans;
   hipEvent_t iteration_begin = nullptr, iteration_end = nullptr;
   uint32_t* host_counters = nullptr;  // pinned
+  uint8_t* bluenoise[kBlueNoiseSets] = {};  // device tables by sample-count class (etx_hip_upload_bluenoise)
+  const uint8_t* active_bluenoise = nullptr;
   etx_hip_stats_t stats = {};
   float4* resolve_buffer = nullptr;
   void* comm = nullptr;  // ncclComm_t (host_comm.cpp)
@@ -242,6 +246,7 @@ VcmParams make_iteration_params(const etx_hip_context* ctx, uint32_t iteration) 
   it.vc_weight = 1.0f / eta_vcm;
   it.vm_weight = (o.options & ETX_VCM_ENABLE_MERGING) ? eta_vcm : 0.0f;
   it.vm_normalization = 1.0f / eta_vcm;
+  it.bluenoise = reinterpret_cast<const uint2*>(ctx->active_bluenoise);
   return it;
 }
 
@@ -501,6 +506,9 @@ void etx_hip_destroy(etx_hip_context* context) {
     (void)hipEventDestroy(context->iteration_end);
   if (context->host_counters)
     (void)hipHostFree(context->host_counters);
+  for (uint8_t* table : context->bluenoise)
+    if (table)
+      (void)hipFree(table);
   if (context->stream)
     (void)hipStreamDestroy(context->stream);
   delete context;
@@ -523,11 +531,19 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
   return ETX_HIP_OK;
 }
 
-int etx_hip_upload_bluenoise(etx_hip_context* context, uint32_t, const int32_t*, const int32_t*, const int32_t*) {
+int etx_hip_upload_bluenoise(etx_hip_context* context, uint32_t set_index, const uint8_t* values, size_t bytes) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
-  context->error = "blue-noise tables are not consumed by the device path yet: run with options.blue_noise = 0";
-  return ETX_HIP_ERROR_UNSUPPORTED;
+  constexpr size_t kTableBytes = size_t(128) * 128 * 256 * 8;
+  if ((set_index >= kBlueNoiseSets) || (values == nullptr) || (bytes != kTableBytes)) {
+    context->error = "etx_hip_upload_bluenoise: set_index must be 0..8 and the table 128*128*256*8 bytes";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  HIP_OK(context, hipSetDevice(context->device));
+  if (context->bluenoise[set_index] == nullptr)
+    HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&context->bluenoise[set_index]), kTableBytes));
+  HIP_OK(context, hipMemcpy(context->bluenoise[set_index], values, kTableBytes, hipMemcpyHostToDevice));
+  return ETX_HIP_OK;
 }
 
 int etx_hip_begin(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride) {
@@ -547,9 +563,18 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
       return ETX_HIP_ERROR_INVALID_ARGUMENT;
     }
     memcpy(&context->vcm_options, options, sizeof(etx_abi_vcm_options));
+    context->active_bluenoise = nullptr;
     if (context->vcm_options.blue_noise) {
-      context->error = "options.blue_noise needs the host's blue-noise tables (etx_hip_upload_bluenoise), which the device path does not consume yet; set vcm-blue_noise=false";
-      return ETX_HIP_ERROR_UNSUPPORTED;
+      // BNSampler's class for scene.samples (thirdparty/bluenoise/bluenoise.cxx:78-92)
+      uint32_t samples = context->scene.host_copy.samples;
+      samples = (samples == 0u) ? 1u : std::min(samples, 256u);
+      const uint32_t set_index = 31u - uint32_t(__builtin_clz(next_pow2(samples)));
+      if (context->bluenoise[set_index] == nullptr) {
+        context->error = "options.blue_noise: the blue-noise samples of class " + std::to_string(1u << set_index) + " spp (set " + std::to_string(set_index) +
+                         ") have not been uploaded (etx_hip_upload_bluenoise); upload them or set vcm-blue_noise=false";
+        return ETX_HIP_ERROR_UNSUPPORTED;
+      }
+      context->active_bluenoise = context->bluenoise[set_index];
     }
     if (context->vcm_options.radius_decay == 0) {
       context->error = "radius_decay must be >= 1";
@@ -739,9 +764,21 @@ int etx_hip_trace_rays_device(etx_hip_context* context, const void* d_rays_o_tmi
 }
 
 int etx_hip_kat(etx_hip_context* context, int which, const float* in, uint64_t count, float* out) {
-  static const uint32_t in_width[] = {2, 6, 3, 5, 4, 2};
-  static const uint32_t out_width[] = {4, 3, 6, 3, 1, 2};
-  if ((context == nullptr) || (which < 0) || (which > 5) || (in == nullptr) || (out == nullptr) || (count > (1u << 24)))
+  static const uint32_t in_width[] = {2, 6, 3, 5, 4, 2, 3};
+  static const uint32_t out_width[] = {4, 3, 6, 3, 1, 2, 6};
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  // 6 + 16 * set_index: blue-noise lookups in the uploaded table of that sample-count class
+  const uint2* bluenoise = nullptr;
+  if ((which >= 6) && ((which & 15) == 6) && ((which >> 4) < int(kBlueNoiseSets))) {
+    bluenoise = reinterpret_cast<const uint2*>(context->bluenoise[which >> 4]);
+    which = 6;
+    if (bluenoise == nullptr) {
+      context->error = "etx_hip_kat: that blue-noise set has not been uploaded";
+      return ETX_HIP_ERROR_STATE;
+    }
+  }
+  if ((which < 0) || (which > 6) || ((which == 6) && (bluenoise == nullptr)) || (in == nullptr) || (out == nullptr) || (count > (1u << 24)))
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   if (count == 0)
     return ETX_HIP_OK;
@@ -753,7 +790,7 @@ int etx_hip_kat(etx_hip_context* context, int which, const float* in, uint64_t c
   if (hipMemcpyAsync(d_in, in, count * in_width[which] * sizeof(float), hipMemcpyHostToDevice, context->stream) != hipSuccess)
     rc = ETX_HIP_ERROR_HIP;
   if (rc == ETX_HIP_OK) {
-    launch_kat(context->stream, which, d_in, uint32_t(count), d_out);
+    launch_kat(context->stream, which, d_in, uint32_t(count), d_out, bluenoise);
     if ((hipMemcpyAsync(out, d_out, count * out_width[which] * sizeof(float), hipMemcpyDeviceToHost, context->stream) != hipSuccess) ||
         (hipStreamSynchronize(context->stream) != hipSuccess))
       rc = ETX_HIP_ERROR_HIP;

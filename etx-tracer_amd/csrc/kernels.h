@@ -38,6 +38,6 @@ void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bo
 void launch_film_resolve(hipStream_t stream, const float4* camera_sum, const float4* light_sum, float4* out, uint32_t pixel_count, float scale, int layer);
 
 // known-answer kernels
-void launch_kat(hipStream_t stream, int which, const float* in, uint32_t count, float* out);
+void launch_kat(hipStream_t stream, int which, const float* in, uint32_t count, float* out, const uint2* bluenoise);
 
 }  // namespace etxd

@@ -272,7 +272,7 @@ void launch_film_resolve(hipStream_t stream, const float4* camera_sum, const flo
 
 // ---------------------------------------------------------------------------------------------------------------
 // known-answer kernels (include/etx_hip.h: etx_hip_kat)
-__global__ void k_kat(int which, const float* __restrict__ in, uint32_t count, float* __restrict__ out) {
+__global__ void k_kat(int which, const float* __restrict__ in, uint32_t count, float* __restrict__ out, const uint2* __restrict__ bluenoise) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count)
     return;
@@ -311,15 +311,21 @@ __global__ void k_kat(int which, const float* __restrict__ in, uint32_t count, f
       out[2 * i] = r.x, out[2 * i + 1] = r.y;
       break;
     }
+    case 6: {  // in: pixel x, pixel y, sample (u32 bits) -> the six blue-noise numbers of vcm_camera_step
+      f2 a, b, c;
+      bluenoise_samples(bluenoise, __float_as_uint(in[3 * i]), __float_as_uint(in[3 * i + 1]), __float_as_uint(in[3 * i + 2]), a, b, c);
+      out[6 * i] = a.x, out[6 * i + 1] = a.y, out[6 * i + 2] = b.x, out[6 * i + 3] = b.y, out[6 * i + 4] = c.x, out[6 * i + 5] = c.y;
+      break;
+    }
     default:
       break;
   }
 }
 
-void launch_kat(hipStream_t stream, int which, const float* in, uint32_t count, float* out) {
+void launch_kat(hipStream_t stream, int which, const float* in, uint32_t count, float* out, const uint2* bluenoise) {
   if (count == 0)
     return;
-  hipLaunchKernelGGL(k_kat, dim3((count + 255u) / 256u), dim3(256), 0, stream, which, in, count, out);
+  hipLaunchKernelGGL(k_kat, dim3((count + 255u) / 256u), dim3(256), 0, stream, which, in, count, out, bluenoise);
 }
 
 }  // namespace etxd

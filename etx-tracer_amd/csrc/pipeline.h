@@ -141,7 +141,7 @@ struct VcmParams {  // VCMOptions + VCMIteration (vcm_shared.hxx:12-89), per ite
   float vc_weight;
   float vm_normalization;
   uint32_t film_w, film_h;
-  uint32_t pad0, pad1;
+  const uint2* bluenoise;  // [128*128][256] x 8 bytes (etx_hip_upload_bluenoise), nullptr = options.blue_noise off
 };
 
 ETX_HD bool opt_connect_to_camera(const VcmParams& p) { return p.options & ETX_VCM_CONNECT_TO_CAMERA; }

@@ -90,6 +90,9 @@ class HIPVCM(Integrator):
         self._rendered = 0
         self._have_camera_image = False
         self._have_light_image = False
+        # what the C++ host tabulates from its BNSampler (include/etx_hip.h): {set_index: uint8 [128,128,256,8]}
+        self.bluenoise_tables = {}
+        self._bluenoise_uploaded = set()
 
     def name(self):
         return "VCM (HIP gfx950)"
@@ -106,6 +109,10 @@ class HIPVCM(Integrator):
         if not self._uploaded:
             self.context.upload_scene(self.snapshot)
             self._uploaded = True
+        for set_index, table in self.bluenoise_tables.items():
+            if set_index not in self._bluenoise_uploaded:
+                self.context.upload_bluenoise(set_index, table)
+                self._bluenoise_uploaded.add(set_index)
         self.context.begin_vcm(vcm_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride)
         self._rendered = 0
         self.current_state = State.Running if self._iterations_to_render() > 0 else State.Stopped

@@ -75,10 +75,16 @@ const char* etx_hip_last_error(const etx_hip_context* context);
  * camera->film_size. */
 int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, const etx_abi_camera* camera);
 
-/* Optional: the Heitz/Belcour blue-noise tables the host links (thirdparty/bluenoise, used through
- * sample_blue_noise, path_tracing.cxx:173-178). One table set per sample-count class 1,2,4,...,256 (9 sets);
- * sobol: 256*256 ints, scrambling/ranking: 128*128*8 ints each. Without them options.blue_noise must be 0. */
-int etx_hip_upload_bluenoise(etx_hip_context* context, uint32_t set_index, const int32_t* sobol_256x256, const int32_t* scrambling_tile, const int32_t* ranking_tile);
+/* The blue-noise samples options.blue_noise needs (vcm_shared.hxx:941-945, 1018-1022). The host's sampler is
+ * sample_blue_noise(pixel, scene.samples, iteration, dimension) (path_tracing.cxx:173-178 -> thirdparty/bluenoise
+ * BNSampler), whose tables are private to that library; the ABI therefore takes the sampler's OUTPUT for one
+ * sample-count class, tabulated by the host:
+ *   values[(((py * 128 + px) * 256) + sample) * 8 + dimension] = (uint8_t)(BNSampler(px, py, samples, sample).get(dimension) * 256)
+ * for px, py < 128, sample < 256, dimension < 8 (the sampler wraps exactly these ranges; its floats are
+ * (0.5 + value) / 256). `set_index` = log2 of the class (0..8: 1, 2, 4, ... 256 samples; BNSampler picks
+ * next_pow2(clamp(scene.samples, 1, 256))). `bytes` must be 128*128*256*8. etx_hip_begin fails with
+ * ETX_HIP_ERROR_UNSUPPORTED when options.blue_noise is set and the class of scene.samples has not been uploaded. */
+int etx_hip_upload_bluenoise(etx_hip_context* context, uint32_t set_index, const uint8_t* values, size_t bytes);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* rendering */
@@ -168,6 +174,8 @@ int etx_hip_trace_rays_device(etx_hip_context* context, const void* d_rays_o_tmi
  *   3: sample_cosine_distribution(rnd, n, 1) in: n*{rx,ry,n.xyz} out: n*{xyz}                        (math.hxx:748-762)
  *   4: grid cell_index in: n*{x,y,z as i32 bits, mask}  out: n*{index as u32 bits}                   (vcm_shared.hxx:820-822)
  *   5: sample_disk    in: n*{rx,ry}                     out: n*{x,y}                                 (math.hxx:773-790)
+ *   6 + 16*set: sample_blue_noise from the uploaded table of that set: in: n*{px,py,sample as u32 bits}
+ *                     out: n*{dimensions 0..5}                                                     (path_tracing.cxx:173-178)
  */
 int etx_hip_kat(etx_hip_context* context, int which, const float* in, uint64_t count, float* out);
 

@@ -23,6 +23,7 @@
 #include <etx/rt/integrators/vcm_cpu.hxx>
 #include <etx/rt/integrators/bidirectional.hxx>
 #include <etx/rt/shared/vcm_shared.hxx>
+#include <bluenoise.hxx>
 
 #include <atomic>
 #include <chrono>
@@ -227,6 +228,15 @@ int print_kat() {
     float2 r = sample_disk({rd[i][0], rd[i][1]});
     printf("%s[%.9g, %.9g, %.9g, %.9g]", i ? ", " : "", rd[i][0], rd[i][1], r.x, r.y);
   }
+  // sample_blue_noise(pixel, total_samples = 64, current_sample, dimension 0 / 2 / 4) as vcm_camera_step calls it
+  printf("],\n  \"blue_noise_64spp\": [");
+  const uint32_t bn[][3] = {{0u, 0u, 0u}, {1u, 0u, 0u}, {0u, 1u, 0u}, {5u, 7u, 3u}, {127u, 127u, 63u}, {128u, 130u, 1u}, {1919u, 1079u, 17u}, {777u, 345u, 255u}, {64u, 64u, 200u}};
+  for (uint32_t i = 0; i < 9; ++i) {
+    float2 a = sample_blue_noise({bn[i][0], bn[i][1]}, 64u, bn[i][2], 0u);
+    float2 b = sample_blue_noise({bn[i][0], bn[i][1]}, 64u, bn[i][2], 2u);
+    float2 c = sample_blue_noise({bn[i][0], bn[i][1]}, 64u, bn[i][2], 4u);
+    printf("%s[%u, %u, %u, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g]", i ? ", " : "", bn[i][0], bn[i][1], bn[i][2], a.x, a.y, b.x, b.y, c.x, c.y);
+  }
   printf("]\n}\n");
   return 0;
 }
@@ -255,6 +265,26 @@ int main(int argc, char** argv) {
       load_snapshot_file = next();
     else if (strcmp(argv[i], "--kat") == 0)
       return print_kat();
+    else if (strcmp(argv[i], "--dump-bluenoise") == 0) {
+      // --dump-bluenoise <samples> <file>: what sample_blue_noise (path_tracing.cxx:173-178) returns for this sample-count
+      // class, as bytes: value[(((py * 128 + px) * 256) + sample) * 8 + dimension], float = (0.5 + value) / 256
+      const uint32_t samples = uint32_t(atoll(next()));
+      const char* file = next();
+      std::vector<uint8_t> table(size_t(128) * 128 * 256 * 8);
+      for (uint32_t py = 0; py < 128; ++py)
+        for (uint32_t px = 0; px < 128; ++px)
+          for (uint32_t sample = 0; sample < 256; ++sample) {
+            BNSampler smp(px, py, samples, sample);
+            for (uint32_t d = 0; d < 8; ++d)
+              table[(((size_t(py) * 128 + px) * 256) + sample) * 8 + d] = uint8_t(smp.get(d) * 256.0f);
+          }
+      FILE* f = fopen(file, "wb");
+      if (f == nullptr)
+        return 2;
+      fwrite(table.data(), 1, table.size(), f);
+      fclose(f);
+      return 0;
+    }
     else if (strcmp(argv[i], "--integrator") == 0)
       integrator_name = next();
     else if (strcmp(argv[i], "--spp") == 0)

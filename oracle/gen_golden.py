@@ -4,6 +4,9 @@ Run in the build container (needs /root/reference): python3 oracle/gen_golden.py
 
   scene snapshots  cornell_{classic,full}_{128,512,1080p}.etxscene   reference loader -> byte-exact etx::Scene
   golden films     cornell_{classic,full}_128_vcm.npz                reference CPUVCM, 256 / 64 spp, vcm-blue_noise=false
+                   cornell_full_128_vcm_bluenoise.npz                reference CPUVCM, 64 spp, VCMOptions defaults (blue noise on)
+  blue noise       bluenoise_64spp.npz                               the reference's sample_blue_noise for the 64-spp class,
+                                                                     factorised by tools/bluenoise_tables.py (258 KiB instead of 32 MiB)
   KAT vectors      kat_reference.json                                reference header functions
 """
 import os
@@ -27,6 +30,21 @@ def run(*args):
     subprocess.check_call([ORACLE] + list(args), stdout=subprocess.DEVNULL)
 
 
+def bluenoise_golden():
+    from tools import bluenoise_tables
+    raw_path = "/tmp/bluenoise_64.raw"
+    run("--dump-bluenoise", "64", raw_path)
+    raw = np.fromfile(raw_path, dtype=np.uint8)
+    base, index_xor, value_xor = bluenoise_tables.factor(raw)
+    assert np.array_equal(bluenoise_tables.expand(base, index_xor, value_xor).reshape(-1), raw)
+    np.savez_compressed(os.path.join(GOLDEN, "bluenoise_64spp.npz"), base=base, index_xor=index_xor, value_xor=value_xor)
+    film_path = "/tmp/golden_full_bluenoise.raw"
+    run("--load-snapshot", os.path.join(GOLDEN, "cornell_full_128.etxscene"), "--integrator", "vcm", "--spp", "64", "--out", film_path)
+    film = film_io.read_film(film_path)
+    np.savez_compressed(os.path.join(GOLDEN, "cornell_full_128_vcm_bluenoise.npz"), camera=film["camera"][..., :3], light=film["light"][..., :3],
+                        spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]), threads=np.int32(film["threads"]))
+
+
 def main():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "scenes", "make_scenes.py")])
     for flavour in ("classic", "full"):
@@ -39,9 +57,13 @@ def main():
         film = film_io.read_film(film_path)
         np.savez_compressed(os.path.join(GOLDEN, "cornell_%s_128_vcm.npz" % flavour), camera=film["camera"][..., :3], light=film["light"][..., :3],
                             spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]), threads=np.int32(film["threads"]))
+    bluenoise_golden()
     with open(os.path.join(GOLDEN, "kat_reference.json"), "w") as f:
         subprocess.check_call([ORACLE, "--kat"], stdout=f)
 
 
 if __name__ == "__main__":
-    main()
+    if (len(sys.argv) > 1) and (sys.argv[1] == "bluenoise"):
+        bluenoise_golden()
+    else:
+        main()

@@ -49,3 +49,10 @@ def gpu_context(etx):
     ctx = api.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def bluenoise_64spp():
+    """The reference's sample_blue_noise outputs for the 64-spp class, uint8 [128,128,256,8] (oracle/gen_golden.py)."""
+    from tools import bluenoise_tables
+    return bluenoise_tables.load(os.path.join(GOLDEN, "bluenoise_64spp.npz"))

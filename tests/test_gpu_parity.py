@@ -125,14 +125,29 @@ def test_traversal_empty_and_ragged(etx, gpu_context, golden_dir):
     assert gpu_context.trace_rays(miss)[0, 3].view(np.uint32) == 0xFFFFFFFF
 
 
+def test_device_bluenoise_lookup_matches_reference(etx, kat_reference, bluenoise_64spp):
+    from etx_tracer_amd import api
+    ctx = api.Context(0)
+    ctx.upload_bluenoise(6, bluenoise_64spp)
+    rows = kat_reference["blue_noise_64spp"]
+    query = np.array([[r[0], r[1], r[2]] for r in rows], dtype=np.uint32).view(np.float32)
+    out = ctx.kat(6 + 16 * 6, query, 6)
+    assert np.array_equal(out, np.array([r[3:9] for r in rows], dtype=np.float32))  # bytes -> (0.5 + v) / 256: exact
+    with pytest.raises(api.EtxHipError):
+        ctx.kat(6 + 16 * 3, query, 6)  # that set was never uploaded
+    ctx.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # VCM images against the reference's golden films
 
-def render(etx, golden_dir, scene, spp, options=None, first=0, stride=1, size_override=None):
+def render(etx, golden_dir, scene, spp, options=None, first=0, stride=1, size_override=None, bluenoise=None):
     snap = etx.SceneSnapshot(os.path.join(golden_dir, scene + ".etxscene"))
     snap.samples = spp
     integ = etx.HIPVCM(snap, first_iteration=first, iteration_stride=stride)
-    integ.options()["vcm-blue_noise"] = False
+    integ.options()["vcm-blue_noise"] = bluenoise is not None
+    if bluenoise is not None:
+        integ.bluenoise_tables = dict(bluenoise)
     integ.options().update(options or {})
     integ.render()
     cam = integ.film(etx.api.LAYER_CAMERA)
@@ -172,6 +187,24 @@ def test_vcm_full_cornell_matches_reference(etx, golden_dir):
     # connections, DESIGN.md "random streams"), the device re-keys the camera stream: allow 1.5 % in the means
     rel = (res[..., :3].mean(axis=(0, 1)) - ref_result.mean(axis=(0, 1))) / ref_result.mean(axis=(0, 1))
     assert np.abs(rel).max() < 1.5e-2, rel
+
+
+def test_vcm_default_options_with_blue_noise_match_reference(etx, golden_dir, bluenoise_64spp):
+    # VCMOptions::default_values(): blue noise on. The host tabulates its sampler for the 64-spp class (set 6).
+    golden = np.load(os.path.join(golden_dir, "cornell_full_128_vcm_bluenoise.npz"))
+    spp = int(golden["spp"])
+    assert spp == 64
+    cam, light, res, stats = render(etx, golden_dir, "cornell_full_128", spp, bluenoise={6: bluenoise_64spp})
+    assert stats.overflow_flags == 0 and np.isfinite(res).all()
+    ref_result = np.maximum(golden["camera"] + golden["light"], 0.0)
+    assert rmse(block_mean(res, 32), block_mean(ref_result, 32)) < 5.0e-3
+    assert rmse(block_mean(light, 32), block_mean(golden["light"], 32)) < 1.0e-3
+    rel = (res[..., :3].mean(axis=(0, 1)) - ref_result.mean(axis=(0, 1))) / ref_result.mean(axis=(0, 1))
+    assert np.abs(rel).max() < 1.5e-2, rel
+    # the override changes only the first camera vertex: same image as without it, up to noise
+    _, _, plain, _ = render(etx, golden_dir, "cornell_full_128", spp)
+    assert rmse(block_mean(res, 32), block_mean(plain, 32)) < 5.0e-3
+    assert not np.array_equal(res, plain)
 
 
 def test_result_layer_is_camera_plus_light(etx, golden_dir):
@@ -220,7 +253,7 @@ def test_unsupported_options_are_rejected(etx, golden_dir):
     from etx_tracer_amd import api
     snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_classic_128.etxscene"))
     integ = etx.HIPVCM(snap)
-    integ.options()["vcm-blue_noise"] = True  # needs the host's blue-noise tables: must fail loudly, not fall back
+    integ.options()["vcm-blue_noise"] = True  # without the host's blue-noise samples for this class: fail loudly
     with pytest.raises(api.EtxHipError) as e:
         integ.run()
     assert e.value.code == -4

@@ -31,6 +31,9 @@ def main():
     snap.samples = spp
     integ = etx.HIPVCM(snap)
     integ.options().update(options)
+    if options.get("vcm-blue_noise"):
+        from tools import bluenoise_tables  # the committed table of the 64-spp class (scene.samples 33..64)
+        integ.bluenoise_tables = {6: bluenoise_tables.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "bluenoise_64spp.npz"))}
     t0 = time.time()
     integ.render()
     wall = time.time() - t0
