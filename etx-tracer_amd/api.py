@@ -6,7 +6,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-LAYER_CAMERA, LAYER_LIGHT, LAYER_RESULT = 0, 1, 2
+LAYER_CAMERA, LAYER_LIGHT, LAYER_RESULT, LAYER_NORMAL, LAYER_ALBEDO = 0, 1, 2, 3, 4
 INTEGRATOR_PT, INTEGRATOR_VCM = 0, 1
 
 # etx::VCMOptions bits (sources/etx/rt/shared/vcm_shared.hxx:24-37)
@@ -53,6 +53,25 @@ class VCMOptions(ctypes.Structure):
         o.kernel = 1  # Epanechnikov
         o.initial_radius = 0.0
         o.blue_noise = 1
+        return o
+
+
+class PTOptions(ctypes.Structure):
+    """etx_abi_pt_options == etx::PTOptions (path_tracing_shared.hxx:8-14), 16 bytes."""
+    _fields_ = [
+        ("path_per_iteration", ctypes.c_uint32),
+        ("nee", ctypes.c_uint8),
+        ("direct", ctypes.c_uint8),
+        ("mis", ctypes.c_uint8),
+        ("blue_noise", ctypes.c_uint8),
+        ("_pad", ctypes.c_uint8 * 8),
+    ]
+
+    @staticmethod
+    def default_values():
+        o = PTOptions()
+        o.path_per_iteration = 1
+        o.nee = o.direct = o.mis = o.blue_noise = 1
         return o
 
 
@@ -184,6 +203,9 @@ class Context:
 
     def begin_vcm(self, options, first_iteration=0, iteration_stride=1):
         self._check(self.library.lib.etx_hip_begin(self.handle, INTEGRATOR_VCM, ctypes.byref(options), ctypes.sizeof(options), first_iteration, iteration_stride))
+
+    def begin_pt(self, options, first_iteration=0, iteration_stride=1):
+        self._check(self.library.lib.etx_hip_begin(self.handle, INTEGRATOR_PT, ctypes.byref(options), ctypes.sizeof(options), first_iteration, iteration_stride))
 
     def render_iteration(self):
         self._check(self.library.lib.etx_hip_render_iteration(self.handle))

@@ -46,6 +46,7 @@ struct TimedSpan {
 
 }  // namespace
 
+constexpr uint32_t kFilmLayers = 4;     // camera, light, normal, albedo sums (pipeline.h)
 constexpr uint32_t kBlueNoiseSets = 9;  // sample-count classes 1, 2, 4, ... 256 of the host's blue-noise sampler
 
 struct etx_hip_context {
@@ -59,6 +60,8 @@ struct etx_hip_context {
   bool armed = false;
   int integrator = ETX_HIP_INTEGRATOR_VCM;
   etx_abi_vcm_options vcm_options = {};
+  etx_abi_pt_options pt_options = {};
+  float4* pt_iteration_image = nullptr;  // PT: sum of the current iteration's contributions per pixel (radiance clamp at commit)
   uint32_t first_iteration = 0, iteration_stride = 1;
   uint32_t next_iteration = 0;       // iteration index to render next
   uint32_t local_iterations = 0;     // iterations rendered by this context since begin
@@ -116,6 +119,7 @@ void release_pipeline(etx_hip_context* ctx) {
   ctx->allocations.clear();
   ctx->pipe = {};
   ctx->resolve_buffer = nullptr;
+  ctx->pt_iteration_image = nullptr;
 }
 
 uint32_t next_pow2(uint32_t v) {
@@ -172,7 +176,7 @@ int allocate_pipeline(etx_hip_context* ctx) {
   if ((rc = device_alloc(ctx, p.shadow.p0_medium, p.shadow.capacity)) || (rc = device_alloc(ctx, p.shadow.p1_target, p.shadow.capacity)) ||
       (rc = device_alloc(ctx, p.shadow.value, p.shadow.capacity)))
     return rc;
-  if ((rc = device_alloc(ctx, p.camera_sum, n)) || (rc = device_alloc(ctx, p.light_sum, n)) || (rc = device_alloc(ctx, ctx->resolve_buffer, n)))
+  if ((rc = device_alloc(ctx, p.camera_sum, size_t(n) * kFilmLayers)) || (rc = device_alloc(ctx, ctx->pt_iteration_image, n)) || (rc = device_alloc(ctx, ctx->resolve_buffer, n)))
     return rc;
   if ((rc = device_alloc(ctx, p.block_stats, kBlockStatRows * kBlockStatCount)))
     return rc;
@@ -180,8 +184,11 @@ int allocate_pipeline(etx_hip_context* ctx) {
     return rc;
   HIP_OK(ctx, hipMemset(p.counters, 0, kCounterCount * sizeof(uint32_t)));
   HIP_OK(ctx, hipMemset(p.grid_params, 0, sizeof(GridParams)));
-  HIP_OK(ctx, hipMemset(p.camera_sum, 0, size_t(n) * sizeof(float4)));
-  HIP_OK(ctx, hipMemset(p.light_sum, 0, size_t(n) * sizeof(float4)));
+  p.light_sum = p.camera_sum + n;
+  p.normal_sum = p.camera_sum + 2u * size_t(n);
+  p.albedo_sum = p.camera_sum + 3u * size_t(n);
+  HIP_OK(ctx, hipMemset(p.camera_sum, 0, size_t(n) * kFilmLayers * sizeof(float4)));
+  HIP_OK(ctx, hipMemset(ctx->pt_iteration_image, 0, size_t(n) * sizeof(float4)));
   return 0;
 }
 
@@ -253,10 +260,10 @@ VcmParams make_iteration_params(const etx_hip_context* ctx, uint32_t iteration) 
 // One pass of the wavefront loop: trace + shade rounds until no path is alive. The active count lives on the device;
 // it is read back every `check_interval` rounds (a pass usually ends after a few dozen rounds).
 template <class ShadeFn, class TailFn>
-int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64_t& rounds) {
+int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64_t& rounds, bool allow_tail = true) {
   uint32_t set = 0;
   uint32_t known_count = ctx->pipe.capacity;  // upper bound of the active paths (the count never grows within a pass)
-  const uint32_t tail_threshold = ctx->tail_divisor ? std::max(64u, ctx->pipe.capacity / ctx->tail_divisor) : 0u;
+  const uint32_t tail_threshold = (allow_tail && ctx->tail_divisor) ? std::max(64u, ctx->pipe.capacity / ctx->tail_divisor) : 0u;
   const uint32_t max_rounds = ctx->scene.host_copy.max_path_length * 2u + 16u;  // boundaries do not add depth
   for (uint32_t round = 0; round < max_rounds;) {
     for (uint32_t k = 0; k < ctx->check_interval; ++k, ++round) {
@@ -375,6 +382,47 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
   if (rc)
     return rc;
   launch_stats_finalize(s, p);
+  ctx->stats.wavefront_bounces = rounds;
+  return 0;
+}
+
+// One path-tracing iteration (CPUPathTracingImpl::execute_range over all pixels, path_tracing.cxx:50-83).
+int render_pt_iteration(etx_hip_context* ctx, uint32_t iteration) {
+  const auto& o = ctx->pt_options;
+  VcmParams it = {};
+  it.options = (o.direct ? ETX_PT_DIRECT : 0u) | (o.nee ? ETX_PT_NEE : 0u) | (o.mis ? ETX_PT_MIS : 0u);
+  it.iteration = iteration;
+  it.film_w = ctx->scene.film_w, it.film_h = ctx->scene.film_h;
+  it.path_count = it.film_w * it.film_h;
+  it.bluenoise = reinterpret_cast<const uint2*>(ctx->active_bluenoise);
+  hipStream_t s = ctx->stream;
+  // the shade and shadow kernels add into the ITERATION image (radiance clamp applies to the iteration's pixel value)
+  Pipeline p = ctx->pipe;
+  p.camera_sum = ctx->pt_iteration_image;
+  uint64_t rounds = 0;
+  launch_iteration_reset(s, p);
+  {
+    ScopedTimer t(ctx, kTimerGenerate);
+    launch_pt_generate(s, p, it);
+  }
+  const bool flat = ctx->scene.host_copy.bvh_flat != 0u;
+  int rc = run_bounce_loop(
+    ctx,
+    [&](uint32_t set, uint32_t max_items) {
+      {
+        ScopedTimer t(ctx, kTimerShadeCamera);
+        launch_pt_shade(s, p, it, set, max_items, ctx->scene.simple_materials);
+      }
+      if (o.direct || o.nee) {
+        ScopedTimer t(ctx, kTimerTraceShadow);
+        launch_trace_shadow(s, p, uint32_t(std::min<uint64_t>(uint64_t(max_items) * 2ull, p.shadow.capacity)), flat);
+      }
+    },
+    [&](uint32_t, uint32_t) {}, rounds, false);
+  if (rc)
+    return rc;
+  launch_pt_commit(s, ctx->pt_iteration_image, ctx->pipe.camera_sum, it.path_count, ctx->scene.host_copy.radiance_clamp);
+  launch_stats_finalize(s, ctx->pipe);
   ctx->stats.wavefront_bounces = rounds;
   return 0;
 }
@@ -546,6 +594,22 @@ int etx_hip_upload_bluenoise(etx_hip_context* context, uint32_t set_index, const
   return ETX_HIP_OK;
 }
 
+namespace {
+// BNSampler's class for scene.samples (thirdparty/bluenoise/bluenoise.cxx:78-92)
+int select_bluenoise(etx_hip_context* context, const char* option_name) {
+  uint32_t samples = context->scene.host_copy.samples;
+  samples = (samples == 0u) ? 1u : std::min(samples, 256u);
+  const uint32_t set_index = 31u - uint32_t(__builtin_clz(next_pow2(samples)));
+  if (context->bluenoise[set_index] == nullptr) {
+    context->error = std::string("options.blue_noise: the blue-noise samples of class ") + std::to_string(1u << set_index) + " spp (set " + std::to_string(set_index) +
+                     ") have not been uploaded (etx_hip_upload_bluenoise); upload them or set " + option_name + "=false";
+    return ETX_HIP_ERROR_UNSUPPORTED;
+  }
+  context->active_bluenoise = context->bluenoise[set_index];
+  return ETX_HIP_OK;
+}
+}  // namespace
+
 int etx_hip_begin(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
@@ -565,20 +629,25 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
     memcpy(&context->vcm_options, options, sizeof(etx_abi_vcm_options));
     context->active_bluenoise = nullptr;
     if (context->vcm_options.blue_noise) {
-      // BNSampler's class for scene.samples (thirdparty/bluenoise/bluenoise.cxx:78-92)
-      uint32_t samples = context->scene.host_copy.samples;
-      samples = (samples == 0u) ? 1u : std::min(samples, 256u);
-      const uint32_t set_index = 31u - uint32_t(__builtin_clz(next_pow2(samples)));
-      if (context->bluenoise[set_index] == nullptr) {
-        context->error = "options.blue_noise: the blue-noise samples of class " + std::to_string(1u << set_index) + " spp (set " + std::to_string(set_index) +
-                         ") have not been uploaded (etx_hip_upload_bluenoise); upload them or set vcm-blue_noise=false";
-        return ETX_HIP_ERROR_UNSUPPORTED;
-      }
-      context->active_bluenoise = context->bluenoise[set_index];
+      int rc = select_bluenoise(context, "vcm-blue_noise");
+      if (rc)
+        return rc;
     }
     if (context->vcm_options.radius_decay == 0) {
       context->error = "radius_decay must be >= 1";
       return ETX_HIP_ERROR_INVALID_ARGUMENT;
+    }
+  } else if (integrator == ETX_HIP_INTEGRATOR_PT) {
+    if ((options == nullptr) || (options_size != sizeof(etx_abi_pt_options))) {
+      context->error = "PT expects etx_abi_pt_options (16 bytes)";
+      return ETX_HIP_ERROR_INVALID_ARGUMENT;
+    }
+    memcpy(&context->pt_options, options, sizeof(etx_abi_pt_options));
+    context->active_bluenoise = nullptr;
+    if (context->pt_options.blue_noise) {
+      int rc = select_bluenoise(context, "bn");
+      if (rc)
+        return rc;
     }
   } else {
     context->error = "integrator " + std::to_string(integrator) + " is not implemented by the device path";
@@ -594,8 +663,8 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
   context->reduced = false;
   context->stats = {};
   const size_t n = size_t(context->pipe.capacity);
-  HIP_OK(context, hipMemsetAsync(context->pipe.camera_sum, 0, n * sizeof(float4), context->stream));
-  HIP_OK(context, hipMemsetAsync(context->pipe.light_sum, 0, n * sizeof(float4), context->stream));
+  HIP_OK(context, hipMemsetAsync(context->pipe.camera_sum, 0, n * kFilmLayers * sizeof(float4), context->stream));
+  HIP_OK(context, hipMemsetAsync(context->pt_iteration_image, 0, n * sizeof(float4), context->stream));
   context->armed = true;
   return ETX_HIP_OK;
 }
@@ -614,7 +683,7 @@ int etx_hip_render_iteration(etx_hip_context* context) {
   HIP_OK(context, hipSetDevice(context->device));
   HIP_OK(context, hipEventRecord(context->iteration_begin, context->stream));
   context->stats.current_iteration = context->next_iteration;
-  int rc = render_vcm_iteration(context, context->next_iteration);
+  int rc = (context->integrator == ETX_HIP_INTEGRATOR_PT) ? render_pt_iteration(context, context->next_iteration) : render_vcm_iteration(context, context->next_iteration);
   if (rc)
     return rc;
   HIP_OK(context, hipEventRecord(context->iteration_end, context->stream));
@@ -671,14 +740,19 @@ int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size
     context->error = "etx_hip_read_film: dst_bytes must be width*height*16";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
-  if ((layer < ETX_HIP_LAYER_CAMERA) || (layer > ETX_HIP_LAYER_RESULT)) {
+  if ((layer < ETX_HIP_LAYER_CAMERA) || (layer > ETX_HIP_LAYER_ALBEDO)) {
     context->error = "etx_hip_read_film: unknown layer";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
   HIP_OK(context, hipSetDevice(context->device));
   uint64_t iterations = context->reduced ? context->global_iterations : context->local_iterations;
   float scale = iterations ? float(1.0 / double(iterations)) : 0.0f;
-  launch_film_resolve(context->stream, context->pipe.camera_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, layer);
+  if (layer == ETX_HIP_LAYER_NORMAL)
+    launch_film_resolve(context->stream, context->pipe.normal_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, 3);
+  else if (layer == ETX_HIP_LAYER_ALBEDO)
+    launch_film_resolve(context->stream, context->pipe.albedo_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, 0);
+  else
+    launch_film_resolve(context->stream, context->pipe.camera_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, layer);
   HIP_OK(context, hipMemcpyAsync(dst_rgba, context->resolve_buffer, dst_bytes, hipMemcpyDeviceToHost, context->stream));
   HIP_OK(context, hipStreamSynchronize(context->stream));
   return ETX_HIP_OK;
@@ -878,7 +952,7 @@ void** etx_hip_internal_comm(etx_hip_context* c) {
 void etx_hip_internal_film(etx_hip_context* c, float** camera, float** light, size_t* floats) {
   *camera = reinterpret_cast<float*>(c->pipe.camera_sum);
   *light = reinterpret_cast<float*>(c->pipe.light_sum);
-  *floats = size_t(c->pipe.capacity) * 4u;
+  *floats = size_t(c->pipe.capacity) * 4u * kFilmLayers;  // camera, light, normal, albedo are one allocation
 }
 void etx_hip_internal_set_error(etx_hip_context* c, const std::string& e) {
   c->error = e;

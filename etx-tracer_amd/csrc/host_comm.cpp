@@ -95,9 +95,7 @@ int etx_hip_reduce_film(etx_hip_context* context) {
   (void)hipMemcpyAsync(d_iterations, &h_iterations, sizeof(h_iterations), hipMemcpyHostToDevice, stream);
   ncclResult_t r = ncclGroupStart();
   if (r == ncclSuccess)
-    r = ncclAllReduce(camera, camera, floats, ncclFloat, ncclSum, comm, stream);
-  if (r == ncclSuccess)
-    r = ncclAllReduce(light, light, floats, ncclFloat, ncclSum, comm, stream);
+    r = ncclAllReduce(camera, camera, floats, ncclFloat, ncclSum, comm, stream);  // all film layers, one buffer
   if (r == ncclSuccess)
     r = ncclAllReduce(d_iterations, d_iterations, 1, ncclUint64, ncclSum, comm, stream);
   ncclResult_t r2 = ncclGroupEnd();

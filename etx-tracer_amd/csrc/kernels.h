@@ -21,6 +21,11 @@ void launch_iteration_reset(hipStream_t stream, const Pipeline& p);
 void launch_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
 void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);
 
+// path tracer (kernels_pt.hip)
+void launch_pt_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
+void launch_pt_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);
+void launch_pt_commit(hipStream_t stream, float4* iteration_image, float4* camera_sum, uint32_t pixels, float radiance_clamp);
+
 // tail: the few paths that are still alive after many bounces finish inside one launch (kernels_tail.hip)
 void launch_light_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);
 void launch_camera_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);

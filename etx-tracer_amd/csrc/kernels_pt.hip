@@ -1,0 +1,307 @@
+// kernels_pt.hip - unidirectional path tracer (BASELINE configs[0]) on the same wavefront pipeline as VCM.
+//
+// Restates CPUPathTracingImpl::execute_range (sources/etx/rt/integrators/path_tracing.cxx:50-83) and
+// run_path_iteration / handle_hit_ray / handle_sampled_medium / handle_missed_ray
+// (sources/etx/rt/shared/path_tracing_shared.hxx:238-510):
+//   k_pt_generate   make_ray_payload (:238-259): one payload per pixel, pixel filter + lens sample
+//   k_trace_closest (kernels_trace.hip) = rt.trace
+//   k_pt_shade      everything after rt.trace; the two transmittance queries of a segment (direct emitter hit :343-349,
+//                   next event estimation :287-312 / :274-283) become shadow-queue requests against the pixel
+//   k_trace_shadow  (kernels_trace.hip) multiplies by the transmittance and adds to the iteration image
+//   k_pt_commit     path_tracing.cxx:67-82: radiance clamp of the iteration's pixel value (paths longer than one
+//                   segment), accumulation into the camera image; normal / albedo AOVs are added by k_pt_shade
+// PathState reuse: depth = path_length, d_vcm = sampled_bsdf_pdf, flags bit kPtMisWeight = payload.mis_weight.
+// Not implemented (etx_hip_upload_scene / etx_hip_begin reject them): subsurface scattering, spectral mode.
+#include "kernels.h"
+#include "dev_vcm.h"
+
+namespace etxd {
+
+static uint32_t grid_for(uint32_t capacity) {
+  return min(kPersistentBlocks, (capacity + kBlockSize - 1) / kBlockSize);
+}
+
+enum : uint32_t { kPtMisWeight = 1u << 8 };
+
+// bsdf::albedo, scene_bsdf.hxx:95-107 + bsdf_various.hxx:28,127,214,259,291 + bsdf_conductor.hxx:133
+ETX_DEV f3 bsdf_albedo(const DScene& scene, const etx_abi_material& mat, const f2 tex) {
+  switch (mat.cls) {
+    case ETX_MAT_DIFFUSE:
+    case ETX_MAT_TRANSLUCENT:
+      return apply_image(scene, mat.scattering, tex, nullptr);
+    case ETX_MAT_CONDUCTOR:
+      return apply_image(scene, mat.reflectance, tex, nullptr);
+    case ETX_MAT_MIRROR:
+    case ETX_MAT_BOUNDARY:
+      return mk3(1.0f);
+    default:
+      return mk3(0.0f);
+  }
+}
+
+// Film::sample, film.cxx:137-145
+ETX_DEV f2 film_sample(const DScene& scene, bool filtered, uint32_t px, uint32_t py, const VcmParams& it, const f2 rnd) {
+  f2 jitter = {rnd.x * 2.0f - 1.0f, rnd.y * 2.0f - 1.0f};
+  float radius = 0.0f;  // PixelFilter::empty() for the first iteration (path_tracing_shared.hxx:245)
+  if (filtered) {
+    radius = scene.pixel_sampler_radius;
+    if (scene.pixel_sampler_image != kInvalid) {
+      float pdf = 0.0f;
+      float4 eval;
+      f2 uv = image_sample(scene.images[scene.pixel_sampler_image], rnd, pdf, eval);
+      jitter = {uv.x * 2.0f - 1.0f, uv.y * 2.0f - 1.0f};
+    }
+  }
+  return {(float(px) + 0.5f + radius * jitter.x) / float(it.film_w) * 2.0f - 1.0f, (float(py) + 0.5f + radius * jitter.y) / float(it.film_h) * 2.0f - 1.0f};
+}
+
+// make_ray_payload, path_tracing_shared.hxx:238-259 (RGB mode)
+__global__ __launch_bounds__(kBlockSize) void k_pt_generate(Pipeline p, VcmParams it) {
+  const DScene& scene = p.scene;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((i == 0u))
+    p.counters[kCntActiveA] = it.path_count;
+  for (uint32_t id = i; id < it.path_count; id += gridDim.x * blockDim.x) {
+    PathState st;
+    st.id = id;
+    st.sampler.init(id, it.iteration);
+    const uint32_t px = id % it.film_w, py = id / it.film_w;
+    const f2 uv = film_sample(scene, it.iteration != 0u, px, py, it, st.sampler.next_2d());
+    RayGen r = generate_ray(scene, uv, st.sampler.next_2d());
+    st.ray_o = r.o, st.ray_d = r.d, st.ray_tmin = r.tmin, st.ray_tmax = r.tmax;
+    st.throughput = mk3(1.0f);
+    st.medium = scene.camera.medium_index;
+    st.depth = 1u;
+    st.eta = 1.0f;
+    st.d_vcm = 0.0f;  // sampled_bsdf_pdf
+    st.d_vc = st.d_vm = st.path_distance = 0.0f;
+    st.flags = kPtMisWeight;
+    store_path(p.paths[0], id, st);
+  }
+}
+
+struct PtRequests {
+  ShadowRequest direct, nee;
+  bool has_direct, has_nee;
+};
+
+// run_path_iteration after rt.trace, path_tracing_shared.hxx:479-508
+template <bool kSimple>
+ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, PtRequests& out) {
+  const bool opt_direct = (it.options & ETX_PT_DIRECT) != 0u, opt_nee = (it.options & ETX_PT_NEE) != 0u, opt_mis = (it.options & ETX_PT_MIS) != 0u;
+  if (st.depth > scene.max_path_length)
+    return false;
+  const uint32_t film_target = film_index(it, st.id);
+  const uint32_t tri_index = __float_as_uint(h.w);
+  const bool found = tri_index != kInvalid;
+  Isect isect;
+  if (found)
+    isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri_index);
+
+  // try_sampling_medium, :261-270
+  MediumSample ms;
+  ms.sampled_medium_t = 0.0f;
+  if (st.medium != kInvalid) {
+    ms = sample_medium_homogeneous(scene.mediums[st.medium], st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+    st.throughput *= ms.weight;
+  }
+
+  if (ms.sampled_medium()) {  // handle_sampled_medium, :272-298
+    const DMedium& medium = scene.mediums[st.medium];
+    if (opt_nee && (st.depth + 1u <= scene.max_path_length) && medium.explicit_connections) {
+      const uint32_t emitter_index = sample_emitter_index(scene, st.sampler.next());
+      const EmitterSample es = sample_emitter(scene, emitter_index, st.sampler.next_2d(), ms.pos);
+      if (es.pdf_dir > 0.0f) {
+        const float phase = phase_function(st.ray_d, es.direction, medium.g);
+        const float weight = es.is_delta ? 1.0f : power_heuristic(es.pdf_dir * es.pdf_sample, phase);
+        out.nee = {ms.pos, es.origin, st.throughput * es.value * (phase * weight / (es.pdf_dir * es.pdf_sample)), st.medium, film_target};
+        out.has_nee = true;
+      }
+    }
+    const f3 w_o = sample_phase_function(st.ray_d, medium.g, st.sampler.next_2d());
+    st.d_vcm = phase_function(st.ray_d, w_o, medium.g);
+    st.flags |= kPtMisWeight;
+    st.ray_o = ms.pos;
+    st.ray_d = w_o;
+    st.ray_tmax = kMaxFloat;
+    st.ray_tmin = kRayEpsilon;
+    st.depth += 1u;
+    p.camera_sum[film_target].w = 1.0f;  // the path is longer than one segment (radiance clamp, path_tracing.cxx:74)
+    return random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
+  }
+
+  if (found == false) {  // handle_missed_ray, :458-477
+    if (opt_direct) {
+      f3 accumulated = mk3(0.0f);
+      for (uint32_t ie = 0; ie < scene.env_count; ++ie) {
+        const etx_abi_emitter& em = scene.emitters[scene.env_emitters[ie]];
+        EmitterRadianceQuery q;
+        q.source_position = q.target_position = mk3(0.0f);
+        q.direction = st.ray_d;
+        q.uv = {0.0f, 0.0f};
+        q.directly_visible = st.depth == 1u;
+        float pdf_area = 0.0f, pdf_dir = 0.0f, pdf_dir_out = 0.0f;
+        const f3 e = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out);
+        if ((pdf_dir > 0.0f) && (is_zero(e) == false)) {
+          const float pdf_discrete = emitter_discrete_pdf(scene, em);
+          const float weight = (((st.flags & kPtMisWeight) == 0u) || q.directly_visible) ? 1.0f : power_heuristic(st.d_vcm, pdf_discrete * pdf_dir);
+          accumulated += st.throughput * e * weight;
+        }
+      }
+      if ((accumulated.x != 0.0f) || (accumulated.y != 0.0f) || (accumulated.z != 0.0f))
+        atomic_add_f3(p.camera_sum + film_target, accumulated);
+    }
+    return false;
+  }
+
+  // handle_hit_ray, :352-456
+  const etx_abi_triangle& tri = scene.triangles[isect.tri];
+  const etx_abi_material& mat = scene.materials[isect.material];
+  if (mat.cls == ETX_MAT_BOUNDARY) {
+    st.medium = (dot(isect.nrm, st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
+    st.ray_o = shading_pos(scene, tri, isect.bc, st.ray_d);
+    st.ray_tmax = kMaxFloat;
+    st.ray_tmin = kRayEpsilon;
+    return true;
+  }
+
+  // handle_direct_emitter, :323-350
+  if (opt_direct && (isect.emitter != kInvalid)) {
+    const etx_abi_emitter& em = scene.emitters[isect.emitter];
+    EmitterRadianceQuery q;
+    q.source_position = st.ray_o;
+    q.target_position = isect.pos;
+    q.direction = mk3(0.0f);
+    q.uv = isect.tex;
+    q.directly_visible = st.depth == 1u;
+    float pdf_area = 0.0f, pdf_dir = 0.0f, pdf_dir_out = 0.0f;
+    const f3 e = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out);
+    if (pdf_dir > 0.0f) {
+      const float pdf_discrete = emitter_discrete_pdf(scene, em);
+      const bool no_weight = (opt_mis == false) || q.directly_visible || ((st.flags & kPtMisWeight) == 0u);
+      const float weight = no_weight ? 1.0f : power_heuristic(st.d_vcm, pdf_discrete * pdf_dir);
+      out.direct = {st.ray_o, isect.pos, st.throughput * e * weight, st.medium, film_target};
+      out.has_direct = true;
+    }
+  }
+
+  BsdfData bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera);
+  if (st.depth == 1u) {  // view_normal / view_albedo -> Film::accumulate_camera_image(pixel, color, normal, albedo)
+    const f3 albedo = bsdf_albedo(scene, mat, isect.tex);
+    float4& n = p.normal_sum[film_target];
+    float4& a = p.albedo_sum[film_target];
+    n = make_float4(n.x + isect.nrm.x, n.y + isect.nrm.y, n.z + isect.nrm.z, 1.0f);
+    a = make_float4(a.x + albedo.x, a.y + albedo.y, a.z + albedo.z, 1.0f);
+  }
+
+  f2 rnd_bsdf = st.sampler.next_2d();
+  f2 rnd_em_sample = st.sampler.next_2d();
+  f2 rnd_support = st.sampler.next_2d();
+  if ((it.bluenoise != nullptr) && (st.depth == 1u))  // :380-384 (no iteration limit here, the sampler wraps at 256)
+    bluenoise_samples(it.bluenoise, st.id % it.film_w, st.id / it.film_w, it.iteration, rnd_bsdf, rnd_em_sample, rnd_support);
+
+  st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
+  const BsdfSample bs = bsdf_sample_s<kSimple>(scene, bsdf_data, mat, st.sampler);
+  st.sampler.pop_fixed();
+  if (bs.valid() == false)
+    return false;
+  if (bs.properties & kSampleMediumChanged)
+    st.medium = bs.medium_index;
+
+  if (opt_nee && (st.depth + 1u <= scene.max_path_length)) {  // :409-431 + evaluate_light :300-321
+    st.sampler.push_fixed(rnd_em_sample.x, rnd_em_sample.y, rnd_support.x);
+    const uint32_t emitter_index = sample_emitter_index(scene, rnd_support.y);
+    const EmitterSample es = sample_emitter(scene, emitter_index, rnd_em_sample, isect.pos);
+    if (es.pdf_dir != 0.0f) {
+      bsdf_data.medium = st.medium;
+      const BsdfEval eval = bsdf_evaluate_s<kSimple>(scene, bsdf_data, es.direction, mat, st.sampler);
+      if (eval.valid()) {
+        const f3 pos = shading_pos(scene, tri, isect.bc, es.direction);
+        const bool no_weight = (opt_mis == false) || es.is_delta;
+        const float weight = no_weight ? 1.0f : power_heuristic(es.pdf_dir * es.pdf_sample, eval.pdf);
+        out.nee = {pos, es.origin, st.throughput * eval.bsdf * es.value * (weight / (es.pdf_dir * es.pdf_sample)), st.medium, film_target};
+        out.has_nee = true;
+      }
+    }
+    st.sampler.pop_fixed();
+  }
+
+  st.throughput *= bs.weight;
+  st.d_vcm = bs.pdf;
+  st.flags = bs.is_delta() ? (st.flags & ~kPtMisWeight) : (st.flags | kPtMisWeight);
+  st.eta *= bs.eta;
+  st.ray_d = bs.w_o;
+  st.ray_o = shading_pos(scene, tri, isect.bc, st.ray_d);
+  if (is_zero(st.throughput))
+    return false;
+  st.ray_tmax = kMaxFloat;
+  st.ray_tmin = kRayEpsilon;
+  st.depth += 1u;
+  p.camera_sum[film_target].w = 1.0f;
+  return random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
+}
+
+template <bool kSimple>
+__global__ __launch_bounds__(kBlockSize) void k_pt_shade(Pipeline p, VcmParams it, uint32_t in_set) {
+  __shared__ BlockScratch s_scratch;
+  const DScene& scene = p.scene;
+  const PathSet& in = p.paths[in_set];
+  const PathSet& out = p.paths[in_set ^ 1u];
+  const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
+  uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
+  const BlockSlots slots = {&s_scratch};
+  ETX_BLOCK_LOOP(count, i) {
+    PathState st;
+    PtRequests requests;
+    requests.has_direct = requests.has_nee = false;
+    bool alive = false;
+    if (i < count) {
+      st = load_path(in, i);
+      alive = pt_step<kSimple>(p, scene, it, st, p.hits[i], requests);
+    }
+    const uint32_t direct_slot = slots.get(requests.has_direct, p.counters + kCntShadow);
+    if (requests.has_direct)
+      write_shadow(p, direct_slot, requests.direct);
+    const uint32_t nee_slot = slots.get(requests.has_nee, p.counters + kCntShadow);
+    if (requests.has_nee)
+      write_shadow(p, nee_slot, requests.nee);
+    const uint32_t slot = slots.get(alive, out_counter);
+    if (alive)
+      store_path(out, slot, st);
+  }
+}
+
+// path_tracing.cxx:67-82: clamp the iteration's pixel value, add it to the camera image. `iteration_image` holds the
+// sum of the iteration's contributions in xyz and "path continued past its first vertex" in w.
+__global__ __launch_bounds__(kBlockSize) void k_pt_commit(float4* __restrict__ iteration_image, float4* __restrict__ camera_sum, uint32_t pixels, float radiance_clamp) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += gridDim.x * blockDim.x) {
+    const float4 v = iteration_image[i];
+    f3 color = {v.x, v.y, v.z};
+    if ((radiance_clamp > 0.0f) && (v.w != 0.0f)) {
+      const float lum = luminance(color);
+      if (lum > radiance_clamp)
+        color *= radiance_clamp / lum;
+    }
+    float4 c = camera_sum[i];
+    camera_sum[i] = make_float4(c.x + color.x, c.y + color.y, c.z + color.z, 1.0f);
+    iteration_image[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+}
+
+void launch_pt_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
+  hipLaunchKernelGGL(k_pt_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
+}
+
+void launch_pt_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials) {
+  const dim3 grid(max(1u, grid_for(min(p.capacity, max_items))));
+  if (simple_materials)
+    hipLaunchKernelGGL(k_pt_shade<true>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+  else
+    hipLaunchKernelGGL(k_pt_shade<false>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+}
+
+void launch_pt_commit(hipStream_t stream, float4* iteration_image, float4* camera_sum, uint32_t pixels, float radiance_clamp) {
+  hipLaunchKernelGGL(k_pt_commit, dim3(grid_for(pixels)), dim3(kBlockSize), 0, stream, iteration_image, camera_sum, pixels, radiance_clamp);
+}
+
+}  // namespace etxd

@@ -261,6 +261,8 @@ __global__ void k_film_resolve(const float4* __restrict__ camera_sum, const floa
     r = make_float4(c.x * scale, c.y * scale, c.z * scale, 1.0f);
   else if (layer == 1)
     r = make_float4(l.x * scale, l.y * scale, l.z * scale, 1.0f);
+  else if (layer == 3)  // Film::layer(Normals) = buf * 0.5 + 0.5 (film.cxx:411)
+    r = make_float4(c.x * scale * 0.5f + 0.5f, c.y * scale * 0.5f + 0.5f, c.z * scale * 0.5f + 0.5f, 1.0f);
   else
     r = make_float4(fmaxf(0.0f, (c.x + l.x) * scale), fmaxf(0.0f, (c.y + l.y) * scale), fmaxf(0.0f, (c.z + l.z) * scale), 1.0f);
   out[i] = r;

@@ -144,6 +144,9 @@ struct VcmParams {  // VCMOptions + VCMIteration (vcm_shared.hxx:12-89), per ite
   const uint2* bluenoise;  // [128*128][256] x 8 bytes (etx_hip_upload_bluenoise), nullptr = options.blue_noise off
 };
 
+// PT: VcmParams::options carries PTOptions (path_tracing_shared.hxx:8-14)
+enum : uint32_t { ETX_PT_DIRECT = 1u << 0, ETX_PT_NEE = 1u << 1, ETX_PT_MIS = 1u << 2 };
+
 ETX_HD bool opt_connect_to_camera(const VcmParams& p) { return p.options & ETX_VCM_CONNECT_TO_CAMERA; }
 ETX_HD bool opt_direct_hit(const VcmParams& p) { return p.options & ETX_VCM_DIRECT_HIT; }
 ETX_HD bool opt_connect_to_light(const VcmParams& p) { return p.options & ETX_VCM_CONNECT_TO_LIGHT; }
@@ -169,8 +172,12 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   uint32_t* merge_buckets;     // kMergeBuckets + 1 counters / offsets, then 256 scan-group totals
   uint2* pairs;          // (camera vertex slot, light vertex index) of the current bounce
   uint32_t pair_capacity;
-  float4* camera_sum;
-  float4* light_sum;
+  // film: per-pixel sums over this rank's iterations, four layers in ONE allocation (camera, light, normal, albedo)
+  // so that the multi-GPU film reduce is a single RCCL all-reduce
+  float4* camera_sum;    // Film::CameraImage x iterations (PT kernels get the iteration image here, host_api.cpp)
+  float4* light_sum;     // Film::LightImage x iterations
+  float4* normal_sum;    // Film::Normals x iterations (PT)
+  float4* albedo_sum;    // Film::Albedo x iterations (PT)
   uint32_t* counters;
   unsigned long long* block_stats;  // kBlockStatRows x kBlockStatCount
   uint32_t debug_flags;             // ETX_HIP_DEBUG_FLAGS: ablation switches for kernel timing experiments (0 in production)

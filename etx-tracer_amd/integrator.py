@@ -79,7 +79,19 @@ def vcm_options_from_dict(values):
     return o
 
 
-class HIPVCM(Integrator):
+def pt_options_from_dict(values):
+    """CPUPathTracingImpl::start (sources/etx/rt/integrators/path_tracing.cxx:36-40): keys direct / nee / mis / bn."""
+    o = api.PTOptions.default_values()
+    o.direct = 1 if values.get("direct", bool(o.direct)) else 0
+    o.nee = 1 if values.get("nee", bool(o.nee)) else 0
+    o.mis = 1 if values.get("mis", bool(o.mis)) else 0
+    o.blue_noise = 1 if values.get("bn", bool(o.blue_noise)) else 0
+    return o
+
+
+class HIPIntegrator(Integrator):
+    """run / update / stop protocol shared by the device integrators (one iteration per update())."""
+
     def __init__(self, snapshot, device=0, first_iteration=0, iteration_stride=1):
         super().__init__()
         self.snapshot = snapshot
@@ -94,8 +106,8 @@ class HIPVCM(Integrator):
         self.bluenoise_tables = {}
         self._bluenoise_uploaded = set()
 
-    def name(self):
-        return "VCM (HIP gfx950)"
+    def _begin(self):
+        raise NotImplementedError
 
     def _iterations_to_render(self):
         # this rank renders first, first + stride, ... < scene.samples (vcm_cpu.cxx:234: stop at iteration + 1 >= samples)
@@ -113,7 +125,7 @@ class HIPVCM(Integrator):
             if set_index not in self._bluenoise_uploaded:
                 self.context.upload_bluenoise(set_index, table)
                 self._bluenoise_uploaded.add(set_index)
-        self.context.begin_vcm(vcm_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride)
+        self._begin()
         self._rendered = 0
         self.current_state = State.Running if self._iterations_to_render() > 0 else State.Stopped
 
@@ -156,3 +168,24 @@ class HIPVCM(Integrator):
 
     def film(self, layer=api.LAYER_RESULT):
         return self.context.read_film(layer)
+
+
+class HIPVCM(HIPIntegrator):
+    """CPUVCM (sources/etx/rt/integrators/vcm_cpu.cxx:243-310) on the device."""
+
+    def name(self):
+        return "VCM (HIP gfx950)"
+
+    def _begin(self):
+        self.context.begin_vcm(vcm_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride)
+
+
+class HIPPathTracing(HIPIntegrator):
+    """CPUPathTracing (sources/etx/rt/integrators/path_tracing.cxx:112-172) on the device. film(LAYER_NORMAL / LAYER_ALBEDO)
+    are the AOVs Film::accumulate_camera_image receives."""
+
+    def name(self):
+        return "Path Tracing (HIP gfx950)"
+
+    def _begin(self):
+        self.context.begin_pt(pt_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride)

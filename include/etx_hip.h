@@ -52,7 +52,9 @@ enum {
 enum {
   ETX_HIP_LAYER_CAMERA = 0, /* Film::CameraImage : running mean of per-iteration camera estimates */
   ETX_HIP_LAYER_LIGHT = 1,  /* Film::LightImage  : running mean of light-path splats */
-  ETX_HIP_LAYER_RESULT = 2  /* Film::Result      : max(0, camera + light), film.cxx:401-409 */
+  ETX_HIP_LAYER_RESULT = 2, /* Film::Result      : max(0, camera + light), film.cxx:401-409 */
+  ETX_HIP_LAYER_NORMAL = 3, /* Film::Normals     : running mean of the first-hit shading normal, as Film::layer returns it: n * 0.5 + 0.5 (PT), film.cxx:207-211,411 */
+  ETX_HIP_LAYER_ALBEDO = 4  /* Film::Albedo      : running mean of the first-hit bsdf::albedo (PT), film.cxx:212-216 */
 };
 
 /* ------------------------------------------------------------------------------------------------------------ */

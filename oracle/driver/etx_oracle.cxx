@@ -147,13 +147,13 @@ bool write_film(const char* path, Film& film, uint32_t spp, double seconds, uint
     return false;
   uint2 dim = film.size();
   char magic[8] = {'E', 'T', 'X', 'F', 'I', 'L', 'M', '1'};
-  uint32_t head[4] = {dim.x, dim.y, 3u, spp};
+  uint32_t head[4] = {dim.x, dim.y, 5u, spp};
   uint32_t tail[2] = {threads, 0u};
   fwrite(magic, 1, 8, f);
   fwrite(head, sizeof(uint32_t), 4, f);
   fwrite(&seconds, sizeof(double), 1, f);
   fwrite(tail, sizeof(uint32_t), 2, f);
-  const uint32_t layers[3] = {Film::CameraImage, Film::LightImage, Film::Result};
+  const uint32_t layers[5] = {Film::CameraImage, Film::LightImage, Film::Result, Film::Normals, Film::Albedo};
   for (uint32_t l : layers) {
     const float4* data = film.layer(l);
     fwrite(data, sizeof(float4), size_t(dim.x) * dim.y, f);

@@ -5,6 +5,8 @@ Run in the build container (needs /root/reference): python3 oracle/gen_golden.py
   scene snapshots  cornell_{classic,full}_{128,512,1080p}.etxscene   reference loader -> byte-exact etx::Scene
   golden films     cornell_{classic,full}_128_vcm.npz                reference CPUVCM, 256 / 64 spp, vcm-blue_noise=false
                    cornell_full_128_vcm_bluenoise.npz                reference CPUVCM, 64 spp, VCMOptions defaults (blue noise on)
+                   cornell_classic_128_pt.npz                        reference CPUPathTracing, 256 spp, bn=false (+ normal / albedo AOVs)
+                   cornell_full_128_pt_bluenoise.npz                 reference CPUPathTracing, 64 spp, PTOptions defaults
   blue noise       bluenoise_64spp.npz                               the reference's sample_blue_noise for the 64-spp class,
                                                                      factorised by tools/bluenoise_tables.py (258 KiB instead of 32 MiB)
   KAT vectors      kat_reference.json                                reference header functions
@@ -45,6 +47,17 @@ def bluenoise_golden():
                         spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]), threads=np.int32(film["threads"]))
 
 
+def pt_golden():
+    # CPUPathTracing (configs[0] family): classic box, 256 spp, bn=false; fog box, 64 spp, PTOptions defaults (blue noise)
+    for name, snapshot, spp, extra in (("cornell_classic_128_pt", "cornell_classic_128", 256, ["--opt", "bn=false"]),
+                                       ("cornell_full_128_pt_bluenoise", "cornell_full_128", 64, [])):
+        film_path = "/tmp/golden_%s.raw" % name
+        run("--load-snapshot", os.path.join(GOLDEN, snapshot + ".etxscene"), "--integrator", "pt", "--spp", str(spp), "--out", film_path, *extra)
+        film = film_io.read_film(film_path)
+        np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), camera=film["camera"][..., :3], normal=film["normal"][..., :3], albedo=film["albedo"][..., :3],
+                            spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]), threads=np.int32(film["threads"]))
+
+
 def main():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "scenes", "make_scenes.py")])
     for flavour in ("classic", "full"):
@@ -58,6 +71,7 @@ def main():
         np.savez_compressed(os.path.join(GOLDEN, "cornell_%s_128_vcm.npz" % flavour), camera=film["camera"][..., :3], light=film["light"][..., :3],
                             spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]), threads=np.int32(film["threads"]))
     bluenoise_golden()
+    pt_golden()
     with open(os.path.join(GOLDEN, "kat_reference.json"), "w") as f:
         subprocess.check_call([ORACLE, "--kat"], stdout=f)
 
@@ -65,5 +79,7 @@ def main():
 if __name__ == "__main__":
     if (len(sys.argv) > 1) and (sys.argv[1] == "bluenoise"):
         bluenoise_golden()
+    elif (len(sys.argv) > 1) and (sys.argv[1] == "pt"):
+        pt_golden()
     else:
         main()

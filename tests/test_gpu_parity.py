@@ -207,6 +207,75 @@ def test_vcm_default_options_with_blue_noise_match_reference(etx, golden_dir, bl
     assert not np.array_equal(res, plain)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# unidirectional path tracer (BASELINE configs[0]) against the reference's CPUPathTracing
+
+def render_pt(etx, golden_dir, scene, spp, options=None, bluenoise=None, first=0, stride=1):
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, scene + ".etxscene"))
+    snap.samples = spp
+    integ = etx.HIPPathTracing(snap, first_iteration=first, iteration_stride=stride)
+    integ.options()["bn"] = bluenoise is not None
+    if bluenoise is not None:
+        integ.bluenoise_tables = dict(bluenoise)
+    integ.options().update(options or {})
+    integ.render()
+    layers = {name: integ.film(getattr(etx.api, "LAYER_" + name.upper())) for name in ("camera", "light", "result", "normal", "albedo")}
+    stats = integ.status()
+    integ.context.close()
+    return layers, stats
+
+
+def compare_pt(layers, golden, rmse_limit, mean_limit):
+    ok = np.isfinite(golden["camera"]).all(axis=2)  # the reference's release build lets an occasional NaN sample through
+    assert ok.mean() > 0.999
+    ref = np.where(ok[..., None], golden["camera"], 0.0)
+    cam = np.where(ok[..., None], layers["camera"][..., :3], 0.0)
+    assert np.isfinite(layers["camera"]).all() and (layers["camera"][..., :3] >= 0).all()
+    assert np.abs(layers["light"][..., :3]).max() == 0.0  # PT never touches the light image
+    assert rmse(block_mean(cam, 32), block_mean(ref, 32)) < rmse_limit
+    rel = (cam.mean(axis=(0, 1)) - ref.mean(axis=(0, 1))) / ref.mean(axis=(0, 1))
+    assert np.abs(rel).max() < mean_limit, rel
+    # AOVs of the first hit (Film::accumulate_camera_image normal / albedo): only the pixel jitter differs
+    assert rmse(block_mean(layers["normal"], 8), block_mean(golden["normal"], 8)) < 1.0e-2
+    assert rmse(block_mean(layers["albedo"], 8), block_mean(golden["albedo"], 8)) < 1.0e-2
+
+
+def test_pt_classic_cornell_matches_reference(etx, golden_dir):
+    golden = np.load(os.path.join(golden_dir, "cornell_classic_128_pt.npz"))
+    layers, stats = render_pt(etx, golden_dir, "cornell_classic_128", int(golden["spp"]))
+    assert stats.completed_iterations == int(golden["spp"]) and stats.overflow_flags == 0
+    compare_pt(layers, golden, 4.0e-3, 1.0e-2)
+
+
+def test_pt_fog_cornell_with_blue_noise_matches_reference(etx, golden_dir, bluenoise_64spp):
+    golden = np.load(os.path.join(golden_dir, "cornell_full_128_pt_bluenoise.npz"))
+    layers, stats = render_pt(etx, golden_dir, "cornell_full_128", int(golden["spp"]), bluenoise={6: bluenoise_64spp})
+    assert stats.overflow_flags == 0
+    compare_pt(layers, golden, 8.0e-3, 1.5e-2)
+
+
+def test_pt_options_and_config1_size(etx, golden_dir):
+    # configs[0]: 512 x 512, 16 spp. Size-independent properties + the option switches of CPUPathTracingImpl::start
+    full, stats = render_pt(etx, golden_dir, "cornell_classic_512", 16)
+    res = full["result"]
+    assert res.shape == (512, 512, 4) and np.isfinite(res).all() and stats.completed_iterations == 16
+    assert res[..., :3].mean() > 0.02
+    no_nee, _ = render_pt(etx, golden_dir, "cornell_classic_512", 16, options={"nee": False, "mis": False})
+    only_nee, _ = render_pt(etx, golden_dir, "cornell_classic_512", 16, options={"direct": False})
+    no_mis, _ = render_pt(etx, golden_dir, "cornell_classic_512", 16, options={"mis": False})
+    m = lambda layers: layers["camera"][..., :3].mean()
+    # BSDF sampling alone (no NEE, no MIS weights) estimates the same image as the MIS combination, with more noise;
+    # direct=false drops the emitter hits; nee + direct without MIS weights count the emitter twice
+    assert abs(m(no_nee) - m(full)) / m(full) < 0.08
+    assert m(only_nee) < m(full)
+    assert m(no_mis) > 1.2 * m(full)  # without MIS the emitter is counted by both strategies
+    # iteration sharding is exact for PT as well (independent samples): two halves average to the whole
+    even, _ = render_pt(etx, golden_dir, "cornell_classic_128", 8, first=0, stride=2)
+    odd, _ = render_pt(etx, golden_dir, "cornell_classic_128", 8, first=1, stride=2)
+    whole, _ = render_pt(etx, golden_dir, "cornell_classic_128", 8)
+    np.testing.assert_allclose(0.5 * (even["camera"][..., :3] + odd["camera"][..., :3]), whole["camera"][..., :3], rtol=2e-4, atol=2e-5)
+
+
 def test_result_layer_is_camera_plus_light(etx, golden_dir):
     cam, light, res, _ = render(etx, golden_dir, "cornell_classic_128", 4)
     np.testing.assert_allclose(res[..., :3], np.maximum(cam[..., :3] + light[..., :3], 0.0), rtol=1e-6, atol=1e-7)

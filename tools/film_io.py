@@ -2,7 +2,7 @@
 import struct
 import numpy as np
 
-LAYER_NAMES = ("camera", "light", "result")
+LAYER_NAMES = ("camera", "light", "result", "normal", "albedo")
 
 
 def read_film(path):
