@@ -107,17 +107,12 @@ def main():
 
     def run_steps(count, first_offset):
         ctx.begin_vcm(options, first_iteration=rank + first_offset * world, iteration_stride=world)
-        acc = {"rays": 0, "trace_ms": 0.0, "launches": 0, "shadow": 0, "lv": 0, "rounds": 0, "examined": 0}
         for _ in range(count):
-            ctx.render_iteration()
-            s = ctx.stats()
-            acc["rays"] += s.rays_extension
-            acc["trace_ms"] += s.ms_trace_closest
-            acc["launches"] += s.launches_trace_closest
-            acc["shadow"] += s.rays_shadow
-            acc["lv"] += s.light_vertices
-            acc["rounds"] += s.wavefront_bounces
-            acc["examined"] += s.photons_examined
+            ctx.render_iteration()  # asynchronous: iterations overlap on the device lanes
+        ctx.sync()
+        s = ctx.stats()             # totals since begin
+        acc = {"rays": s.rays_extension, "trace_ms": s.ms_trace_closest, "launches": s.launches_trace_closest, "shadow": s.rays_shadow, "lv": s.light_vertices,
+               "rounds": s.wavefront_bounces, "examined": s.photons_examined}
         ctx.reduce_film()
         return acc
 

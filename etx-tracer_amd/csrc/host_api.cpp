@@ -10,10 +10,14 @@
 
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace etxd;
@@ -81,6 +85,28 @@ struct etx_hip_context {
   float4* resolve_buffer = nullptr;
   void* comm = nullptr;  // ncclComm_t (host_comm.cpp)
   int rank = 0, world = 1;
+
+  // Asynchronous execution. A context is a set of LANES: the public context itself plus helper contexts, each with its
+  // own stream, per-iteration pools, counters and worker thread; all lanes add into the film of the public context
+  // (float atomics). etx_hip_render_iteration hands the next iteration to a free lane and returns, so consecutive
+  // iterations overlap on the device: while one is in its thin tail (a few thousand long paths, launch-latency bound)
+  // the wide first bounces of the next one fill the CUs.
+  etx_hip_context* owner = nullptr;       // helper lanes: the public context
+  std::vector<etx_hip_context*> helpers;  // public context: its helper lanes (owned)
+  std::thread worker;
+  std::mutex lane_mutex;                  // jobs / quit of this lane
+  std::condition_variable lane_cv;
+  std::deque<uint32_t> jobs;              // iteration indices handed to this lane
+  bool lane_busy = false;                 // guarded by the owner's shared_mutex
+  bool quit = false;
+  // public context only
+  std::mutex shared_mutex;
+  std::condition_variable idle_cv;
+  uint32_t jobs_in_flight = 0;
+  int sticky_error = 0;
+  std::string sticky_error_text;
+  etx_hip_stats_t totals = {};            // since etx_hip_begin
+  std::chrono::steady_clock::time_point busy_since;
 
   bool fail(int, const std::string& msg) {
     error = msg;
@@ -176,8 +202,14 @@ int allocate_pipeline(etx_hip_context* ctx) {
   if ((rc = device_alloc(ctx, p.shadow.p0_medium, p.shadow.capacity)) || (rc = device_alloc(ctx, p.shadow.p1_target, p.shadow.capacity)) ||
       (rc = device_alloc(ctx, p.shadow.value, p.shadow.capacity)))
     return rc;
-  if ((rc = device_alloc(ctx, p.camera_sum, size_t(n) * kFilmLayers)) || (rc = device_alloc(ctx, ctx->pt_iteration_image, n)) || (rc = device_alloc(ctx, ctx->resolve_buffer, n)))
+  if ((rc = device_alloc(ctx, ctx->pt_iteration_image, n)))
     return rc;
+  if (ctx->owner == nullptr) {
+    if ((rc = device_alloc(ctx, p.camera_sum, size_t(n) * kFilmLayers)) || (rc = device_alloc(ctx, ctx->resolve_buffer, n)))
+      return rc;
+  } else {
+    p.camera_sum = ctx->owner->pipe.camera_sum;  // every lane adds into the public context's film
+  }
   if ((rc = device_alloc(ctx, p.block_stats, kBlockStatRows * kBlockStatCount)))
     return rc;
   if ((rc = device_alloc(ctx, p.counters, kCounterCount)))
@@ -187,7 +219,8 @@ int allocate_pipeline(etx_hip_context* ctx) {
   p.light_sum = p.camera_sum + n;
   p.normal_sum = p.camera_sum + 2u * size_t(n);
   p.albedo_sum = p.camera_sum + 3u * size_t(n);
-  HIP_OK(ctx, hipMemset(p.camera_sum, 0, size_t(n) * kFilmLayers * sizeof(float4)));
+  if (ctx->owner == nullptr)
+    HIP_OK(ctx, hipMemset(p.camera_sum, 0, size_t(n) * kFilmLayers * sizeof(float4)));
   HIP_OK(ctx, hipMemset(ctx->pt_iteration_image, 0, size_t(n) * sizeof(float4)));
   return 0;
 }
@@ -471,9 +504,146 @@ void collect_stats(etx_hip_context* ctx) {
 #endif
 }
 
+// Renders one iteration on `lane` (worker thread of that lane) and folds its statistics into the public context.
+int execute_iteration(etx_hip_context* lane, uint32_t iteration) {
+  HIP_OK(lane, hipEventRecord(lane->iteration_begin, lane->stream));
+  lane->stats = {};
+  lane->stats.current_iteration = iteration;
+  int rc = (lane->integrator == ETX_HIP_INTEGRATOR_PT) ? render_pt_iteration(lane, iteration) : render_vcm_iteration(lane, iteration);
+  if (rc)
+    return rc;
+  HIP_OK(lane, hipEventRecord(lane->iteration_end, lane->stream));
+  // the bounce loop already synchronised on the counters; the tail (nothing after the last read) is short
+  HIP_OK(lane, hipEventSynchronize(lane->iteration_end));
+  rc = read_counters(lane);
+  if (rc)
+    return rc;
+  float ms = 0.0f;
+  (void)hipEventElapsedTime(&ms, lane->iteration_begin, lane->iteration_end);
+  collect_stats(lane);
+  lane->stats.last_iteration_time = double(ms) * 1.0e-3;
+  if (lane->stats.overflow_flags) {
+    lane->error = "device pool overflow in iteration " + std::to_string(iteration) + " (flags " + std::to_string(lane->stats.overflow_flags) +
+                  "): light vertex pool (1, raise ETX_HIP_LIGHT_VERTICES_PER_PATH) / connection pair buffer (4) / shadow queue (8) / camera vertex pool (16)";
+    return ETX_HIP_ERROR_OVERFLOW;
+  }
+  return ETX_HIP_OK;
+}
+
+etx_hip_context* public_context(etx_hip_context* lane) {
+  return lane->owner ? lane->owner : lane;
+}
+
+void lane_worker(etx_hip_context* lane) {
+  (void)hipSetDevice(lane->device);
+  etx_hip_context* pub = public_context(lane);
+  for (;;) {
+    uint32_t iteration = 0;
+    {
+      std::unique_lock<std::mutex> lock(lane->lane_mutex);
+      lane->lane_cv.wait(lock, [&] { return lane->quit || (lane->jobs.empty() == false); });
+      if (lane->quit && lane->jobs.empty())
+        return;
+      iteration = lane->jobs.front();
+      lane->jobs.pop_front();
+    }
+    int rc = execute_iteration(lane, iteration);
+    {
+      std::lock_guard<std::mutex> lock(pub->shared_mutex);
+      auto& t = pub->totals;
+      const auto& s = lane->stats;
+      if (rc == ETX_HIP_OK) {
+        t.completed_iterations += 1;
+        t.last_iteration_time = s.last_iteration_time;
+        t.rays_extension += s.rays_extension, t.rays_shadow += s.rays_shadow;
+        t.light_vertices += s.light_vertices, t.camera_vertices += s.camera_vertices;
+        t.photons_examined += s.photons_examined, t.photons_merged += s.photons_merged, t.splats += s.splats;
+        t.wavefront_bounces += s.wavefront_bounces;
+        t.ms_trace_closest += s.ms_trace_closest, t.ms_trace_shadow += s.ms_trace_shadow;
+        t.ms_shade_light += s.ms_shade_light, t.ms_shade_camera += s.ms_shade_camera;
+        t.ms_connect += s.ms_connect, t.ms_merge += s.ms_merge, t.ms_grid_build += s.ms_grid_build, t.ms_generate += s.ms_generate;
+        t.launches_trace_closest += s.launches_trace_closest, t.launches_trace_shadow += s.launches_trace_shadow;
+        pub->local_iterations += 1;
+      } else if (pub->sticky_error == 0) {
+        pub->sticky_error = rc;
+        pub->sticky_error_text = lane->error;
+      }
+      t.overflow_flags |= s.overflow_flags;
+      lane->lane_busy = false;
+      pub->jobs_in_flight -= 1;
+      if (pub->jobs_in_flight == 0u)
+        t.total_time += std::chrono::duration<double>(std::chrono::steady_clock::now() - pub->busy_since).count();
+    }
+    pub->idle_cv.notify_all();
+  }
+}
+
+// Waits until no iteration is queued or running; returns the sticky error of a failed iteration, if any.
+int wait_idle(etx_hip_context* pub) {
+  std::unique_lock<std::mutex> lock(pub->shared_mutex);
+  pub->idle_cv.wait(lock, [&] { return pub->jobs_in_flight == 0u; });
+  if (pub->sticky_error) {
+    pub->error = pub->sticky_error_text;
+    return pub->sticky_error;
+  }
+  return ETX_HIP_OK;
+}
+
+int init_lane(etx_hip_context* lane, int device, std::string& error) {
+  lane->device = device;
+  if (hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess) {
+    error = "hipStreamCreate failed";
+    return ETX_HIP_ERROR_HIP;
+  }
+  if ((hipEventCreate(&lane->iteration_begin) != hipSuccess) || (hipEventCreate(&lane->iteration_end) != hipSuccess)) {
+    error = "hipEventCreate failed";
+    return ETX_HIP_ERROR_HIP;
+  }
+  if (hipHostMalloc(reinterpret_cast<void**>(&lane->host_counters), kCounterCount * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+    error = "hipHostMalloc failed";
+    return ETX_HIP_ERROR_HIP;
+  }
+  memset(lane->host_counters, 0, kCounterCount * sizeof(uint32_t));
+  if (const char* e = getenv("ETX_HIP_CHECK_INTERVAL"))
+    lane->check_interval = std::max(1, atoi(e));
+  if (const char* e = getenv("ETX_HIP_TAIL_DIVISOR"))
+    lane->tail_divisor = uint32_t(std::max(0, atoi(e)));
+  if (const char* e = getenv("ETX_HIP_TIMERS"))
+    lane->timer_mask = uint32_t(strtoul(e, nullptr, 0));
+  lane->worker = std::thread(lane_worker, lane);
+  return ETX_HIP_OK;
+}
+
+void destroy_lane(etx_hip_context* lane) {
+  if (lane->worker.joinable()) {
+    {
+      std::lock_guard<std::mutex> lock(lane->lane_mutex);
+      lane->quit = true;
+    }
+    lane->lane_cv.notify_all();
+    lane->worker.join();
+  }
+  if (lane->stream)
+    (void)hipStreamSynchronize(lane->stream);
+  release_pipeline(lane);
+  lane->scene.release();
+  for (hipEvent_t e : lane->event_pool)
+    (void)hipEventDestroy(e);
+  if (lane->iteration_begin)
+    (void)hipEventDestroy(lane->iteration_begin);
+  if (lane->iteration_end)
+    (void)hipEventDestroy(lane->iteration_end);
+  if (lane->host_counters)
+    (void)hipHostFree(lane->host_counters);
+  if (lane->stream)
+    (void)hipStreamDestroy(lane->stream);
+}
+
 }  // namespace
 
 extern "C" {
+
+void etx_hip_destroy(etx_hip_context* context);
 
 int etx_hip_abi_version(void) {
   return ETX_HIP_ABI_VERSION;
@@ -512,26 +682,21 @@ int etx_hip_create(int device, etx_hip_context** out_context) {
     return ETX_HIP_ERROR_HIP;
   }
   auto ctx = std::make_unique<etx_hip_context>();
-  ctx->device = device;
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-    g_create_error = "hipStreamCreate failed";
-    return ETX_HIP_ERROR_HIP;
+  int rc = init_lane(ctx.get(), device, g_create_error);
+  // ETX_HIP_LANES: iterations in flight (default 2: the tail of one iteration overlaps the wide start of the next)
+  int lanes = 2;
+  if (const char* e = getenv("ETX_HIP_LANES"))
+    lanes = std::min(8, std::max(1, atoi(e)));
+  for (int l = 1; (rc == ETX_HIP_OK) && (l < lanes); ++l) {
+    auto* helper = new etx_hip_context();
+    helper->owner = ctx.get();
+    ctx->helpers.push_back(helper);
+    rc = init_lane(helper, device, g_create_error);
   }
-  if ((hipEventCreate(&ctx->iteration_begin) != hipSuccess) || (hipEventCreate(&ctx->iteration_end) != hipSuccess)) {
-    g_create_error = "hipEventCreate failed";
-    return ETX_HIP_ERROR_HIP;
+  if (rc != ETX_HIP_OK) {
+    etx_hip_destroy(ctx.release());
+    return rc;
   }
-  if (hipHostMalloc(reinterpret_cast<void**>(&ctx->host_counters), kCounterCount * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
-    g_create_error = "hipHostMalloc failed";
-    return ETX_HIP_ERROR_HIP;
-  }
-  memset(ctx->host_counters, 0, kCounterCount * sizeof(uint32_t));
-  if (const char* e = getenv("ETX_HIP_CHECK_INTERVAL"))
-    ctx->check_interval = std::max(1, atoi(e));
-  if (const char* e = getenv("ETX_HIP_TAIL_DIVISOR"))
-    ctx->tail_divisor = uint32_t(std::max(0, atoi(e)));
-  if (const char* e = getenv("ETX_HIP_TIMERS"))
-    ctx->timer_mask = uint32_t(strtoul(e, nullptr, 0));
   *out_context = ctx.release();
   return ETX_HIP_OK;
 }
@@ -542,23 +707,16 @@ void etx_hip_destroy(etx_hip_context* context) {
   if (context == nullptr)
     return;
   (void)hipSetDevice(context->device);
-  (void)hipStreamSynchronize(context->stream);
+  for (etx_hip_context* helper : context->helpers) {
+    destroy_lane(helper);
+    delete helper;
+  }
+  context->helpers.clear();
   etx_hip_comm_destroy_internal(context);
-  release_pipeline(context);
-  context->scene.release();
-  for (hipEvent_t e : context->event_pool)
-    (void)hipEventDestroy(e);
-  if (context->iteration_begin)
-    (void)hipEventDestroy(context->iteration_begin);
-  if (context->iteration_end)
-    (void)hipEventDestroy(context->iteration_end);
-  if (context->host_counters)
-    (void)hipHostFree(context->host_counters);
+  destroy_lane(context);
   for (uint8_t* table : context->bluenoise)
     if (table)
       (void)hipFree(table);
-  if (context->stream)
-    (void)hipStreamDestroy(context->stream);
   delete context;
 }
 
@@ -566,15 +724,27 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   HIP_OK(context, hipSetDevice(context->device));
+  (void)wait_idle(context);
   HIP_OK(context, hipStreamSynchronize(context->stream));
   context->scene_ready = false;
   context->armed = false;
+  for (etx_hip_context* helper : context->helpers)
+    release_pipeline(helper);
   int rc = etxh::build_device_scene(scene, camera, context->scene, context->error);
   if (rc)
     return rc;
   rc = allocate_pipeline(context);
   if (rc)
     return rc;
+  for (etx_hip_context* helper : context->helpers) {
+    helper->scene.borrow(context->scene);
+    rc = allocate_pipeline(helper);
+    if (rc) {
+      context->error = helper->error;
+      return rc;
+    }
+  }
+  HIP_OK(context, hipDeviceSynchronize());
   context->scene_ready = true;
   return ETX_HIP_OK;
 }
@@ -621,6 +791,7 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
     context->error = "iteration_stride must be >= 1";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
+  (void)wait_idle(context);  // iterations of the previous run
   if (integrator == ETX_HIP_INTEGRATOR_VCM) {
     if ((options == nullptr) || (options_size != sizeof(etx_abi_vcm_options))) {
       context->error = "VCM expects etx_abi_vcm_options (32 bytes)";
@@ -662,9 +833,24 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
   context->global_iterations = 0;
   context->reduced = false;
   context->stats = {};
+  {
+    std::lock_guard<std::mutex> lock(context->shared_mutex);
+    context->totals = {};
+    context->sticky_error = 0;
+    context->sticky_error_text.clear();
+  }
+  for (etx_hip_context* helper : context->helpers) {
+    helper->integrator = integrator;
+    helper->vcm_options = context->vcm_options;
+    helper->pt_options = context->pt_options;
+    helper->active_bluenoise = context->active_bluenoise;
+  }
   const size_t n = size_t(context->pipe.capacity);
   HIP_OK(context, hipMemsetAsync(context->pipe.camera_sum, 0, n * kFilmLayers * sizeof(float4), context->stream));
   HIP_OK(context, hipMemsetAsync(context->pt_iteration_image, 0, n * sizeof(float4), context->stream));
+  for (etx_hip_context* helper : context->helpers)
+    HIP_OK(context, hipMemsetAsync(helper->pt_iteration_image, 0, n * sizeof(float4), context->stream));
+  HIP_OK(context, hipStreamSynchronize(context->stream));  // the lanes run on their own streams
   context->armed = true;
   return ETX_HIP_OK;
 }
@@ -680,49 +866,55 @@ int etx_hip_render_iteration(etx_hip_context* context) {
     context->error = "etx_hip_render_iteration after etx_hip_reduce_film: call etx_hip_begin again";
     return ETX_HIP_ERROR_STATE;
   }
-  HIP_OK(context, hipSetDevice(context->device));
-  HIP_OK(context, hipEventRecord(context->iteration_begin, context->stream));
-  context->stats.current_iteration = context->next_iteration;
-  int rc = (context->integrator == ETX_HIP_INTEGRATOR_PT) ? render_pt_iteration(context, context->next_iteration) : render_vcm_iteration(context, context->next_iteration);
-  if (rc)
-    return rc;
-  HIP_OK(context, hipEventRecord(context->iteration_end, context->stream));
-  // the bounce loop already synchronised on the counters; the tail (nothing after the last read) is empty
-  HIP_OK(context, hipEventSynchronize(context->iteration_end));
-  rc = read_counters(context);
-  if (rc)
-    return rc;
-  float ms = 0.0f;
-  (void)hipEventElapsedTime(&ms, context->iteration_begin, context->iteration_end);
-  collect_stats(context);
-  context->stats.last_iteration_time = double(ms) * 1.0e-3;
-  context->stats.total_time += context->stats.last_iteration_time;
-  context->stats.completed_iterations += 1;
-  context->local_iterations += 1;
-  context->next_iteration += context->iteration_stride;
-  if (context->stats.overflow_flags) {
-    context->error = "device pool overflow in iteration " + std::to_string(context->stats.current_iteration) + " (flags " + std::to_string(context->stats.overflow_flags) +
-                     "): light vertex pool (1, raise ETX_HIP_LIGHT_VERTICES_PER_PATH) / connection pair buffer (4) / shadow queue (8) / camera vertex pool (16)";
-    return ETX_HIP_ERROR_OVERFLOW;
+  // hand the iteration to a free lane; blocks only while every lane is busy
+  const uint32_t lane_count = uint32_t(context->helpers.size()) + 1u;
+  etx_hip_context* lane = nullptr;
+  {
+    std::unique_lock<std::mutex> lock(context->shared_mutex);
+    context->idle_cv.wait(lock, [&] { return (context->jobs_in_flight < lane_count) || (context->sticky_error != 0); });
+    if (context->sticky_error) {
+      context->error = context->sticky_error_text;
+      return context->sticky_error;
+    }
+    lane = context->lane_busy ? nullptr : context;
+    for (size_t i = 0; (lane == nullptr) && (i < context->helpers.size()); ++i)
+      lane = context->helpers[i]->lane_busy ? nullptr : context->helpers[i];
+    if (lane == nullptr) {
+      context->error = "internal: no free lane";
+      return ETX_HIP_ERROR_STATE;
+    }
+    lane->lane_busy = true;
+    if (context->jobs_in_flight == 0u)
+      context->busy_since = std::chrono::steady_clock::now();
+    context->jobs_in_flight += 1;
+    context->totals.current_iteration = context->next_iteration;
   }
+  {
+    std::lock_guard<std::mutex> lock(lane->lane_mutex);
+    lane->jobs.push_back(context->next_iteration);
+  }
+  lane->lane_cv.notify_one();
+  context->next_iteration += context->iteration_stride;
   return ETX_HIP_OK;
 }
 
 int etx_hip_poll(etx_hip_context* context) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
-  hipError_t e = hipStreamQuery(context->stream);
-  if (e == hipSuccess)
-    return 1;
-  if (e == hipErrorNotReady)
-    return 0;
-  context->error = std::string("hipStreamQuery: ") + hipGetErrorString(e);
-  return ETX_HIP_ERROR_HIP;
+  std::lock_guard<std::mutex> lock(context->shared_mutex);
+  if (context->sticky_error) {
+    context->error = context->sticky_error_text;
+    return context->sticky_error;
+  }
+  return (context->jobs_in_flight == 0u) ? 1 : 0;
 }
 
 int etx_hip_sync(etx_hip_context* context) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  int rc = wait_idle(context);
+  if (rc)
+    return rc;
   HIP_OK(context, hipSetDevice(context->device));
   HIP_OK(context, hipStreamSynchronize(context->stream));
   return ETX_HIP_OK;
@@ -744,6 +936,9 @@ int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size
     context->error = "etx_hip_read_film: unknown layer";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
+  int sync_rc = wait_idle(context);
+  if (sync_rc)
+    return sync_rc;
   HIP_OK(context, hipSetDevice(context->device));
   uint64_t iterations = context->reduced ? context->global_iterations : context->local_iterations;
   float scale = iterations ? float(1.0 / double(iterations)) : 0.0f;
@@ -761,7 +956,8 @@ int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size
 int etx_hip_stats(etx_hip_context* context, etx_hip_stats_t* out_stats, size_t stats_size) {
   if ((context == nullptr) || (out_stats == nullptr) || (stats_size != sizeof(etx_hip_stats_t)))
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
-  *out_stats = context->stats;
+  std::lock_guard<std::mutex> lock(context->shared_mutex);
+  *out_stats = context->totals;
   return ETX_HIP_OK;
 }
 

@@ -67,6 +67,9 @@ int etx_hip_comm_init(etx_hip_context* context, int rank, int world_size, const 
 int etx_hip_reduce_film(etx_hip_context* context) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  int sync_rc = etx_hip_sync(context);  // every iteration handed to a lane has reached the film
+  if (sync_rc)
+    return sync_rc;
   uint32_t* local = nullptr;
   uint64_t* global = nullptr;
   bool* reduced = nullptr;

@@ -26,6 +26,18 @@ void DeviceScene::release() {
   host_copy = {};
 }
 
+void DeviceScene::borrow(const DeviceScene& owner) {
+  release();
+  flat_prims = owner.flat_prims;
+  host_copy = owner.host_copy;
+  device = owner.device;
+  film_w = owner.film_w, film_h = owner.film_h;
+  bvh_depth = owner.bvh_depth;
+  simple_materials = owner.simple_materials;
+  generic_materials = owner.generic_materials;
+  bvh_bytes = owner.bvh_bytes;
+}
+
 namespace {
 
 struct Builder {

@@ -28,6 +28,7 @@ struct DeviceScene {
 
   ~DeviceScene();
   void release();
+  void borrow(const DeviceScene& owner);  // non-owning view of the owner's device tables (helper lanes, host_api.cpp)
 };
 
 // Returns 0 or an ETX_HIP_ERROR_* code with `error` set.

@@ -188,10 +188,8 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
   BsdfData bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera);
   if (st.depth == 1u) {  // view_normal / view_albedo -> Film::accumulate_camera_image(pixel, color, normal, albedo)
     const f3 albedo = bsdf_albedo(scene, mat, isect.tex);
-    float4& n = p.normal_sum[film_target];
-    float4& a = p.albedo_sum[film_target];
-    n = make_float4(n.x + isect.nrm.x, n.y + isect.nrm.y, n.z + isect.nrm.z, 1.0f);
-    a = make_float4(a.x + albedo.x, a.y + albedo.y, a.z + albedo.z, 1.0f);
+    atomic_add_f3(p.normal_sum + film_target, isect.nrm);  // atomics: another lane may add the same pixel of another iteration
+    atomic_add_f3(p.albedo_sum + film_target, albedo);
   }
 
   f2 rnd_bsdf = st.sampler.next_2d();
@@ -282,8 +280,7 @@ __global__ __launch_bounds__(kBlockSize) void k_pt_commit(float4* __restrict__ i
       if (lum > radiance_clamp)
         color *= radiance_clamp / lum;
     }
-    float4 c = camera_sum[i];
-    camera_sum[i] = make_float4(c.x + color.x, c.y + color.y, c.z + color.z, 1.0f);
+    atomic_add_f3(camera_sum + i, color);  // the film is shared by the lanes (host_api.cpp)
     iteration_image[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
 }

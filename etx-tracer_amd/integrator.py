@@ -132,11 +132,14 @@ class HIPIntegrator(Integrator):
     def update(self):
         if self.current_state == State.Stopped:
             return
+        # asynchronous: hands the iteration to a free device lane (two iterations overlap on the GPU), blocks only
+        # while every lane is busy; the film is complete after sync()
         self.context.render_iteration()
         self._rendered += 1
         self._have_camera_image = True
         self._have_light_image = True
         if (self.current_state == State.WaitingForCompletion) or (self._rendered >= self._iterations_to_render()):
+            self.context.sync()
             self.current_state = State.Stopped
 
     def stop(self, how=Stop.Immediate):

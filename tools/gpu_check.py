@@ -40,7 +40,9 @@ def main():
     st = integ.status()
     w, h = snap.film_size
     print("rendered %dx%d x %d spp in %.3f s wall, device total %.3f s -> %.3f Msamples/s" % (w, h, spp, wall, st.total_time, w * h * spp / st.total_time / 1e6))
-    print({k: v for k, v in st.as_dict().items()})
+    per_iteration = {k: (v / max(1, st.completed_iterations) if (k.startswith("ms_") or k.startswith("rays_") or k in ("light_vertices", "photons_examined", "photons_merged", "splats", "wavefront_bounces", "launches_trace_closest", "launches_trace_shadow")) else v)
+                     for k, v in st.as_dict().items()}
+    print(per_iteration)  # totals since begin, divided by the iteration count
     cam = integ.film(etx.api.LAYER_CAMERA)
     light = integ.film(etx.api.LAYER_LIGHT)
     res = integ.film(etx.api.LAYER_RESULT)
