@@ -250,6 +250,10 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       nee = is_connectible;
       store = is_connectible && (opt_connect_vertices(it) || (opt_merge_vertices(it) && (st.depth + 1 <= scene.max_path_length)));
     }
+    if (p.debug_flags & 0x100u)  // timing experiments (ETX_HIP_DEBUG_FLAGS)
+      nee = false;
+    if (p.debug_flags & 0x200u)
+      store = false;
   }
 
   // ---- phase B
