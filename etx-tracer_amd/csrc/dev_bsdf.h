@@ -145,24 +145,131 @@ ETX_DEV Ior evaluate_refractive_index(const DScene& s, const etx_abi_refractive_
 }
 
 constexpr uint32_t kSpectrumClassConductor = 2u;  // SpectralDistribution::Class::Conductor, spectrum.hxx:450-456
+constexpr uint32_t kSpectrumClassDielectric = 3u;
 
-// bsdf.hxx:337-375 fresnel::calculate, RGB branch without thin film
-ETX_DEV f3 fresnel_calculate(float cos_theta, const Ior& ext_ior, const Ior& int_ior) {
+ETX_DEV bool is_zero_rgb(const f3& v) {  // SpectralResponse::is_zero, spectrum.hxx:317-319
+  return (v.x <= kEpsilon) && (v.y <= kEpsilon) && (v.z <= kEpsilon);
+}
+
+// Thinfilm::Eval (material.hxx:23-27) from evaluate_thinfilm (scene_bsdf.hxx:110-126). In RGB mode the three film
+// wavelengths are jittered around 610 / 537 / 450 nm with three draws of the path's sampler.
+struct ThinfilmEval {
+  Ior ior;
+  f3 rgb_wavelengths;
+  float thickness;
+};
+
+ETX_DEV ThinfilmEval evaluate_thinfilm(const DScene& s, const etx_abi_thinfilm& film, const f2 uv, Sampler& smp) {
+  ThinfilmEval r;
+  r.ior.cls = 0u, r.ior.eta = mk3(0.0f), r.ior.k = mk3(0.0f);
+  r.rgb_wavelengths = {610.0f, 537.0f, 450.0f};
+  r.thickness = 0.0f;
+  if (film.max_thickness * film.min_thickness <= 0.0f)
+    return r;
+  const float t = (film.thickness_image == kInvalid) ? 1.0f : image_evaluate(s.images[film.thickness_image], uv, nullptr).x;
+  r.thickness = film.min_thickness + (film.max_thickness - film.min_thickness) * t;  // lerp(min, max, t)
+  r.rgb_wavelengths.x = 610.0f + 45.0f * (2.0f * smp.next() - 1.0f);
+  r.rgb_wavelengths.y = 537.0f + 47.0f * (2.0f * smp.next() - 1.0f);
+  r.rgb_wavelengths.z = 450.0f + 23.5f * (2.0f * smp.next() - 1.0f);
+  r.ior = evaluate_refractive_index(s, film.ior);
+  return r;
+}
+
+ETX_DEV cplx cscale(cplx a, float k) {
+  return {a.re * k, a.im * k};
+}
+ETX_DEV cplx cexp(cplx z) {  // complex_exp
+  const float e = expf(z.re);
+  float sn, cs;
+  sincosf(z.im, &sn, &cs);
+  return {e * cs, e * sn};
+}
+struct FresnelPair {
+  cplx s, p;
+};
+// bsdf.hxx:249-266 reflectance, :268-285 transmittance
+ETX_DEV FresnelPair fresnel_reflectance(cplx ni, cplx cos_i, cplx nj, cplx cos_j) {
+  if ((cos_i.re == 0.0f) && (cos_j.re == 0.0f) && (cos_i.im == 0.0f) && (cos_j.im == 0.0f))
+    return {cplx{1.0f, 0.0f}, cplx{1.0f, 0.0f}};
+  if ((ni.re == nj.re) && (ni.im == nj.im))
+    return {cplx{0.0f, 0.0f}, cplx{0.0f, 0.0f}};
+  const cplx ni_ci = cmul(ni, cos_i), nj_cj = cmul(nj, cos_j), nj_ci = cmul(nj, cos_i), ni_cj = cmul(ni, cos_j);
+  return {cdiv(csub(ni_ci, nj_cj), cadd(ni_ci, nj_cj)), cdiv(csub(nj_ci, ni_cj), cadd(nj_ci, ni_cj))};
+}
+ETX_DEV FresnelPair fresnel_transmittance(cplx ni, cplx cos_i, cplx nj, cplx cos_j) {
+  if ((cos_i.re == 0.0f) && (cos_j.re == 0.0f) && (cos_i.im == 0.0f) && (cos_j.im == 0.0f))
+    return {cplx{0.0f, 0.0f}, cplx{0.0f, 0.0f}};
+  if ((ni.re == nj.re) && (ni.im == nj.im))
+    return {cplx{1.0f, 0.0f}, cplx{1.0f, 0.0f}};
+  const cplx two_ni_ci = cscale(cmul(ni, cos_i), 2.0f);
+  return {cdiv(two_ni_ci, cadd(cmul(ni, cos_i), cmul(nj, cos_j))), cdiv(two_ni_ci, cadd(cmul(ni, cos_j), cmul(nj, cos_i)))};
+}
+
+// bsdf.hxx:299-337 fresnel_thinfilm
+ETX_DEV float fresnel_thinfilm(float wavelength, float cos_theta_0, cplx ext_ior, cplx film_ior, cplx int_ior, float thickness) {
+  if (cos_theta_0 == 0.0f)
+    return 0.0f;
+  const cplx one = {1.0f, 0.0f};
+  cplx ratio_01 = cdiv(ext_ior, film_ior);
+  const cplx sin_theta_1_squared = cscale(cmul(ratio_01, ratio_01), 1.0f - cos_theta_0 * cos_theta_0);
+  if (sin_theta_1_squared.re >= 1.0f)
+    return 1.0f;
+  const cplx cos_theta_1 = csqrt(csub(one, sin_theta_1_squared));
+  cplx ratio_12 = cdiv(film_ior, int_ior);
+  const cplx sin_theta_2_squared = cmul(cmul(ratio_12, ratio_12), csub(one, cmul(cos_theta_1, cos_theta_1)));
+  if (sin_theta_2_squared.re >= 1.0f)
+    return 1.0f;
+  const cplx cos_theta_2 = csqrt(csub(one, sin_theta_2_squared));
+  const cplx cos_0 = {cos_theta_0, 0.0f};
+  const cplx ratio = cdiv(cmul(int_ior, cos_theta_2), cmul(ext_ior, cos_0));
+  const float delta_10 = ext_ior.re < film_ior.re ? kPi : 0.0f;
+  const float delta_21 = film_ior.re < int_ior.re ? kPi : 0.0f;
+  const float phase_shift = delta_10 + delta_21;
+  const FresnelPair r01 = fresnel_reflectance(ext_ior, cos_0, film_ior, cos_theta_1);
+  const FresnelPair t01 = fresnel_transmittance(ext_ior, cos_0, film_ior, cos_theta_1);
+  const FresnelPair r12 = fresnel_reflectance(film_ior, cos_theta_1, int_ior, cos_theta_2);
+  const FresnelPair t12 = fresnel_transmittance(film_ior, cos_theta_1, int_ior, cos_theta_2);
+  const cplx phi = cscale(cadd(cscale(cos_theta_1, kDoublePi * 2.0f * thickness), cscale(film_ior, phase_shift)), 1.0f / wavelength);
+  const cplx exp_i_phi = cexp(cplx{-phi.im, phi.re});  // exp(i * phi)
+  cplx tp = cdiv(cmul(t01.p, t12.p), csub(one, cmul(cmul(r01.p, r12.p), exp_i_phi)));
+  tp = cmul(tp, tp);
+  cplx ts = cdiv(cmul(t01.s, t12.s), csub(one, cmul(cmul(r01.s, r12.s), exp_i_phi)));
+  ts = cmul(ts, ts);
+  const cplx v = csub(one, cscale(cmul(ratio, cadd(tp, ts)), 0.5f));
+  return sqrtf(v.re * v.re + v.im * v.im);  // complex_abs
+}
+
+// bsdf.hxx:337-375 fresnel::calculate, RGB branch
+ETX_DEV f3 fresnel_calculate(float cos_theta, const Ior& ext_ior, const Ior& int_ior, const ThinfilmEval& tf) {
   cos_theta = fabsf(cos_theta);
   f3 values;
-  values.x = fresnel_generic(cos_theta, cplx{ext_ior.eta.x, ext_ior.k.x}, cplx{int_ior.eta.x, int_ior.k.x});
-  values.y = fresnel_generic(cos_theta, cplx{ext_ior.eta.y, ext_ior.k.y}, cplx{int_ior.eta.y, int_ior.k.y});
-  values.z = fresnel_generic(cos_theta, cplx{ext_ior.eta.z, ext_ior.k.z}, cplx{int_ior.eta.z, int_ior.k.z});
-  if (int_ior.cls == kSpectrumClassConductor) {
-    // conductor IORs are stored as XYZ (spectrum.cxx:390-391); spectrum.hxx:142-148 xyz_to_rgb, :449 kRGBLuminanceScale
-    f3 rgb = {
-      3.24045420f * values.x - 1.5371385f * values.y - 0.4985314f * values.z,
-      -0.9692660f * values.x + 1.8760108f * values.y + 0.0415560f * values.z,
-      0.05564340f * values.x - 0.2040259f * values.y + 1.0572252f * values.z,
-    };
-    values = rgb * f3{0.817660332f, 1.05418909f, 1.09945524f};
+  if ((tf.thickness == 0.0f) || is_zero_rgb(tf.ior.eta)) {
+    values.x = fresnel_generic(cos_theta, cplx{ext_ior.eta.x, ext_ior.k.x}, cplx{int_ior.eta.x, int_ior.k.x});
+    values.y = fresnel_generic(cos_theta, cplx{ext_ior.eta.y, ext_ior.k.y}, cplx{int_ior.eta.y, int_ior.k.y});
+    values.z = fresnel_generic(cos_theta, cplx{ext_ior.eta.z, ext_ior.k.z}, cplx{int_ior.eta.z, int_ior.k.z});
+    if (int_ior.cls == kSpectrumClassConductor) {
+      // conductor IORs are stored as XYZ (spectrum.cxx:390-391); spectrum.hxx:142-148 xyz_to_rgb, :449 kRGBLuminanceScale
+      f3 rgb = {
+        3.24045420f * values.x - 1.5371385f * values.y - 0.4985314f * values.z,
+        -0.9692660f * values.x + 1.8760108f * values.y + 0.0415560f * values.z,
+        0.05564340f * values.x - 0.2040259f * values.y + 1.0572252f * values.z,
+      };
+      values = rgb * f3{0.817660332f, 1.05418909f, 1.09945524f};
+    }
+  } else {
+    values.x = fresnel_thinfilm(tf.rgb_wavelengths.x, cos_theta, cplx{ext_ior.eta.x, ext_ior.k.x}, cplx{tf.ior.eta.x, tf.ior.k.x}, cplx{int_ior.eta.x, int_ior.k.x}, tf.thickness);
+    values.y = fresnel_thinfilm(tf.rgb_wavelengths.y, cos_theta, cplx{ext_ior.eta.y, ext_ior.k.y}, cplx{tf.ior.eta.y, tf.ior.k.y}, cplx{int_ior.eta.y, int_ior.k.y}, tf.thickness);
+    values.z = fresnel_thinfilm(tf.rgb_wavelengths.z, cos_theta, cplx{ext_ior.eta.z, ext_ior.k.z}, cplx{tf.ior.eta.z, tf.ior.k.z}, cplx{int_ior.eta.z, int_ior.k.z}, tf.thickness);
   }
   return {saturate(values.x), saturate(values.y), saturate(values.z)};
+}
+
+ETX_DEV ThinfilmEval thinfilm_none() {
+  ThinfilmEval r;
+  r.ior.cls = 0u, r.ior.eta = mk3(0.0f), r.ior.k = mk3(0.0f);
+  r.rgb_wavelengths = {610.0f, 537.0f, 450.0f};
+  r.thickness = 0.0f;
+  return r;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -273,7 +380,7 @@ ETX_DEV f2 ms_sample_p22_11(float theta_i, const f2 rnd) {  // bsdf_external.hxx
 }
 
 // bsdf_external.hxx:248-279 samplePhaseFunction_conductor
-ETX_DEV f3 ms_sample_phase_conductor(const f2 slope_rnd, const f3& wi, const f2 alpha, const Ior& ext_ior, const Ior& int_ior, f3& weight) {
+ETX_DEV f3 ms_sample_phase_conductor(const f2 slope_rnd, const f3& wi, const f2 alpha, const Ior& ext_ior, const Ior& int_ior, const ThinfilmEval& tf, f3& weight) {
   const f3 wi_11 = normalize(f3{alpha.x * wi.x, alpha.y * wi.y, wi.z});
   f2 slope_11 = ms_sample_p22_11(acosf(wi_11.z), slope_rnd);
   const float phi = atan2f(wi_11.y, wi_11.x);
@@ -289,12 +396,12 @@ ETX_DEV f3 ms_sample_phase_conductor(const f2 slope_rnd, const f3& wi, const f2 
     wm = normalize(f3{-slope.x, -slope.y, 1.0f});
   }
   float i_dot_m = dot(wi, wm);
-  weight = fresnel_calculate(i_dot_m, ext_ior, int_ior);
+  weight = fresnel_calculate(i_dot_m, ext_ior, int_ior, tf);
   return -wi + 2.0f * wm * i_dot_m;
 }
 
 // bsdf_external.hxx:211-246 phase_function_reflection
-ETX_DEV f3 ms_phase_function_reflection(const MsRay& ray, const f3& wo, const f2 alpha, const Ior& ext_ior, const Ior& int_ior) {
+ETX_DEV f3 ms_phase_function_reflection(const MsRay& ray, const f3& wo, const f2 alpha, const Ior& ext_ior, const Ior& int_ior, const ThinfilmEval& tf) {
   if (ray.w.z > 0.9999f)
     return mk3(0.0f);
   float projected_area = (ray.w.z < -0.9999f) ? 1.0f : ray.Lambda * ray.w.z;
@@ -306,7 +413,7 @@ ETX_DEV f3 ms_phase_function_reflection(const MsRay& ray, const f3& wo, const f2
   float w_dot_h = dot(-ray.w, wh);
   if (w_dot_h < kEpsilon)
     return mk3(0.0f);
-  const f3 f = fresnel_calculate(w_dot_h, ext_ior, int_ior);
+  const f3 f = fresnel_calculate(w_dot_h, ext_ior, int_ior, tf);
   return f * (D_ggx(wh, alpha) / (4.0f * projected_area));
 }
 
@@ -318,7 +425,7 @@ ETX_DEV float ms_mis_weight_conductor(const f3& wi, const f3& wo, const f2 alpha
 }
 
 // bsdf_external.hxx:289-353 eval_conductor (stochastic: consumes a variable number of randoms)
-ETX_DEV f3 ms_eval_conductor(Sampler& smp, const f3& wi, const f3& wo, const f2 alpha, const Ior& ext_ior, const Ior& int_ior) {
+ETX_DEV f3 ms_eval_conductor(Sampler& smp, const f3& wi, const f3& wo, const f2 alpha, const Ior& ext_ior, const Ior& int_ior, const ThinfilmEval& tf) {
   if (wi.z <= 0 || wo.z <= 0)
     return mk3(0.0f);
   MsRay ray = ms_ray(-wi, alpha);
@@ -328,7 +435,7 @@ ETX_DEV f3 ms_eval_conductor(Sampler& smp, const f3& wi, const f3& wo, const f2 
   const f3 wh = normalize(wi + wo);
   const float D = D_ggx(wh, alpha);
   const float G2 = 1.0f / (1.0f + (-ray.Lambda - 1.0f) + ray_shadowing.Lambda);
-  f3 single_scattering = fresnel_calculate(dot(ray.w, wh), ext_ior, int_ior) * (D * G2 / (4.0f * wi.z));
+  f3 single_scattering = fresnel_calculate(dot(ray.w, wh), ext_ior, int_ior, tf) * (D * G2 / (4.0f * wi.z));
   float wi_mis_weight = 0.0f;
   f3 multiple_scattering = mk3(0.0f);
   uint32_t order = 0;
@@ -338,7 +445,7 @@ ETX_DEV f3 ms_eval_conductor(Sampler& smp, const f3& wi, const f3& wo, const f2 
       break;
     order++;
     if (order > 1) {
-      f3 phase = ms_phase_function_reflection(ray, wo, alpha, ext_ior, int_ior);
+      f3 phase = ms_phase_function_reflection(ray, wo, alpha, ext_ior, int_ior, tf);
       ray_shadowing.update_height(ray.h);
       f3 I = energy * phase * ray_shadowing.G1;
       const float mis = wi_mis_weight / (wi_mis_weight + ms_mis_weight_conductor(-ray.w, wo, alpha));
@@ -346,7 +453,7 @@ ETX_DEV f3 ms_eval_conductor(Sampler& smp, const f3& wi, const f3& wo, const f2 
     }
     f2 slope_rnd = ((order == 1) && smp.has_fixed()) ? f2{smp.fixed_u, smp.fixed_v} : smp.next_2d();
     f3 weight;
-    ray.update_direction(ms_sample_phase_conductor(slope_rnd, -ray.w, alpha, ext_ior, int_ior, weight), alpha);
+    ray.update_direction(ms_sample_phase_conductor(slope_rnd, -ray.w, alpha, ext_ior, int_ior, tf, weight), alpha);
     energy = energy * weight;
     ray.update_height(ray.h);
     if (order == 1)
@@ -357,10 +464,37 @@ ETX_DEV f3 ms_eval_conductor(Sampler& smp, const f3& wi, const f3& wo, const f2 
   return 0.5f * single_scattering + multiple_scattering;
 }
 
+}  // namespace etxd
+
+#include "dev_bsdf_ext.h"
+
+namespace etxd {
+
 // ---------------------------------------------------------------------------------------------------------------
 // per-class implementations
 
-// bsdf_various.hxx:38-134 DiffuseBSDF (diffuse_variation 0: Lambert)
+// bsdf_various.hxx:36-134 DiffuseBSDF: diffuse_variation 0 Lambert, 1 microfacet random walk, 2 vMF diffuse
+ETX_DEV BsdfEval diffuse_layer_v(const DScene& s, const BsdfData& d, const f3& local_w_i, const f3& local_w_o, const etx_abi_material& m, Sampler& smp) {
+  if (local_w_o.z <= 0.0f)
+    return eval_zero();
+  f3 diffuse = apply_image(s, m.scattering, d.tex, nullptr);
+  BsdfEval e;
+  e.eta = 1.0f;
+  if (m.diffuse_variation == 1u) {
+    e.bsdf = ms_eval_diffuse(smp, local_w_i, local_w_o, evaluate_roughness(s, m, d.tex), diffuse);
+    e.func = e.bsdf / local_w_o.z;
+  } else if (m.diffuse_variation == 2u) {
+    e.func = vmf_diffuse_brdf(local_w_i, local_w_o, evaluate_roughness(s, m, d.tex), diffuse);
+    e.bsdf = e.func * local_w_o.z;
+  } else {
+    e.func = diffuse / kPi;
+    e.bsdf = e.func * local_w_o.z;
+  }
+  e.pdf = kInvPi * local_w_o.z;
+  return e;
+}
+
+// the Lambert case without a sampler (simple-material kernels, merge-ready camera vertices)
 ETX_DEV BsdfEval diffuse_layer(const DScene& s, const BsdfData& d, const f3& local_w_o, const etx_abi_material& m) {
   if (local_w_o.z <= 0.0f)
     return eval_zero();
@@ -375,16 +509,32 @@ ETX_DEV BsdfEval diffuse_layer(const DScene& s, const BsdfData& d, const f3& loc
 
 ETX_DEV BsdfSample diffuse_sample(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
   Frame frame = normal_frame(d);
+  f3 local_w_i = frame.to_local(-d.w_i);
   BsdfSample r = sample_zero();
   r.eta = 1.0f;
   r.properties = kSampleReflection | kSampleDiffuse;
-  f2 cos_rnd = smp.has_fixed() ? f2{smp.fixed_u, smp.fixed_v} : smp.next_2d();
-  f3 local_w_o = sample_cosine_distribution(cos_rnd, 1.0f);
-  BsdfEval dl = diffuse_layer(s, d, local_w_o, m);
-  r.weight = (dl.pdf == 0.0f) ? mk3(0.0f) : dl.bsdf / dl.pdf;
-  r.pdf = dl.pdf;
+  f3 local_w_o;
+  if (m.diffuse_variation == 1u) {
+    f3 diffuse = apply_image(s, m.scattering, d.tex, nullptr);
+    local_w_o = ms_sample_diffuse(smp, local_w_i, evaluate_roughness(s, m, d.tex), diffuse, r.weight);
+    r.pdf = kInvPi * local_w_o.z;
+  } else {
+    f2 cos_rnd = smp.has_fixed() ? f2{smp.fixed_u, smp.fixed_v} : smp.next_2d();
+    local_w_o = sample_cosine_distribution(cos_rnd, 1.0f);
+    BsdfEval dl = diffuse_layer_v(s, d, local_w_i, local_w_o, m, smp);
+    r.weight = (dl.pdf == 0.0f) ? mk3(0.0f) : dl.bsdf / dl.pdf;
+    r.pdf = dl.pdf;
+  }
   r.w_o = frame.from_local(local_w_o);
   return r;
+}
+
+ETX_DEV BsdfEval diffuse_evaluate_v(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
+  Frame frame = normal_frame(d);
+  f3 local_w_o = frame.to_local(w_o);
+  if (local_w_o.z <= kEpsilon)
+    return eval_zero();
+  return diffuse_layer_v(s, d, frame.to_local(-d.w_i), local_w_o, m, smp);
 }
 
 ETX_DEV BsdfEval diffuse_evaluate(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m) {
@@ -418,6 +568,7 @@ ETX_DEV BsdfSample conductor_sample(const DScene& s, const BsdfData& d, const et
   f3 w_i = frame.to_local(-d.w_i);
   Ior ext_ior = evaluate_refractive_index(s, m.ext_ior);
   Ior int_ior = evaluate_refractive_index(s, m.int_ior);
+  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp);
   BsdfSample r = sample_zero();
   r.properties = kSampleReflection | (conductor_is_delta(s, m, d.tex) ? kSampleDelta : 0u);
   r.medium_index = d.medium;
@@ -433,7 +584,7 @@ ETX_DEV BsdfSample conductor_sample(const DScene& s, const BsdfData& d, const et
       break;
     f2 slope_rnd = ((order == 0) && smp.has_fixed()) ? f2{smp.fixed_u, smp.fixed_v} : smp.next_2d();
     f3 weight;
-    ray.update_direction(ms_sample_phase_conductor(slope_rnd, -ray.w, roughness, ext_ior, int_ior, weight), roughness);
+    ray.update_direction(ms_sample_phase_conductor(slope_rnd, -ray.w, roughness, ext_ior, int_ior, tf, weight), roughness);
     ray.update_height(ray.h);
     r.weight *= weight;
     if ((order++ > kScatteringOrderMax) || (ray.h != ray.h) || (ray.w.x != ray.w.x)) {
@@ -460,7 +611,8 @@ ETX_DEV BsdfEval conductor_evaluate(const DScene& s, const BsdfData& d, const f3
   f2 roughness = evaluate_roughness(s, m, d.tex);
   Ior ext_ior = evaluate_refractive_index(s, m.ext_ior);
   Ior int_ior = evaluate_refractive_index(s, m.int_ior);
-  f3 value = ms_eval_conductor(smp, w_i, w_o, roughness, ext_ior, int_ior);
+  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp);
+  f3 value = ms_eval_conductor(smp, w_i, w_o, roughness, ext_ior, int_ior, tf);
   BsdfEval e;
   e.eta = 1.0f;
   e.bsdf = value * apply_image(s, m.reflectance, d.tex, nullptr);
@@ -549,7 +701,7 @@ ETX_DEV float translucent_pdf(const DScene& s, const BsdfData& d, const f3& w_o,
 // ---------------------------------------------------------------------------------------------------------------
 // dispatch  scene_bsdf.hxx:56-107
 
-ETX_DEV BsdfSample bsdf_sample(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
+ETX_DEV BsdfSample bsdf_sample_core(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
   switch (m.cls) {
     case ETX_MAT_DIFFUSE:
       return diffuse_sample(s, d, m, smp);
@@ -557,6 +709,14 @@ ETX_DEV BsdfSample bsdf_sample(const DScene& s, const BsdfData& d, const etx_abi
       return translucent_sample(s, d, m, smp);
     case ETX_MAT_CONDUCTOR:
       return conductor_sample(s, d, m, smp);
+    case ETX_MAT_DIELECTRIC:
+      return dielectric_sample(s, d, m, smp);
+    case ETX_MAT_THINFILM:
+      return thinfilm_sample(s, d, m, smp);
+    case ETX_MAT_PLASTIC:
+      return plastic_sample(s, d, m, smp);
+    case ETX_MAT_VELVET:
+      return velvet_sample(s, d, m, smp);
     case ETX_MAT_MIRROR: {  // bsdf_various.hxx:215-224
       Frame frame = normal_frame(d);
       BsdfSample r = sample_zero();
@@ -586,14 +746,20 @@ ETX_DEV BsdfSample bsdf_sample(const DScene& s, const BsdfData& d, const etx_abi
   }
 }
 
-ETX_DEV BsdfEval bsdf_evaluate(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
+ETX_DEV BsdfEval bsdf_evaluate_core(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
   switch (m.cls) {
     case ETX_MAT_DIFFUSE:
-      return diffuse_evaluate(s, d, w_o, m);
+      return diffuse_evaluate_v(s, d, w_o, m, smp);
     case ETX_MAT_TRANSLUCENT:
       return translucent_evaluate(s, d, w_o, m);
     case ETX_MAT_CONDUCTOR:
       return conductor_evaluate(s, d, w_o, m, smp);
+    case ETX_MAT_DIELECTRIC:
+      return dielectric_evaluate(s, d, w_o, m, smp);
+    case ETX_MAT_PLASTIC:
+      return plastic_evaluate(s, d, w_o, m, smp);
+    case ETX_MAT_VELVET:
+      return velvet_evaluate(s, d, w_o, m);
     case ETX_MAT_MIRROR: {  // bsdf_various.hxx:226-240
       BsdfEval e = eval_zero();
       Frame frame = normal_frame(d);
@@ -604,12 +770,12 @@ ETX_DEV BsdfEval bsdf_evaluate(const DScene& s, const BsdfData& d, const f3& w_o
       }
       return e;
     }
-    default:  // Boundary, Void: bsdf_various.hxx:272-274, 17-19
+    default:  // Boundary, Void, Thinfilm: bsdf_various.hxx:272-274, 17-19, bsdf_dielectric.hxx:43-45
       return eval_zero();
   }
 }
 
-ETX_DEV float bsdf_pdf(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m) {
+ETX_DEV float bsdf_pdf_core(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
   switch (m.cls) {
     case ETX_MAT_DIFFUSE:
       return diffuse_pdf(d, w_o);
@@ -617,6 +783,12 @@ ETX_DEV float bsdf_pdf(const DScene& s, const BsdfData& d, const f3& w_o, const 
       return translucent_pdf(s, d, w_o, m);
     case ETX_MAT_CONDUCTOR:
       return conductor_pdf(s, d, w_o, m);
+    case ETX_MAT_DIELECTRIC:
+      return dielectric_pdf(s, d, w_o, m, smp);
+    case ETX_MAT_PLASTIC:
+      return plastic_pdf(s, d, w_o, m, smp);
+    case ETX_MAT_VELVET:
+      return velvet_pdf(d);
     case ETX_MAT_MIRROR: {
       Frame frame = normal_frame(d);
       return direction_matches(normalize(reflect(d.w_i, frame.nrm)), normalize(w_o)) ? 1.0f : 0.0f;
@@ -626,12 +798,65 @@ ETX_DEV float bsdf_pdf(const DScene& s, const BsdfData& d, const f3& w_o, const 
   }
 }
 
+// PrincipledBSDF, bsdf_principled.hxx:16-114: one of Conductor / Dielectric / Plastic is picked per call with the
+// path's sampler (metalness, transmission) and evaluated on a modified copy of the material.
+enum : uint32_t { kPrincipledConductor = 0, kPrincipledDielectric = 1, kPrincipledPlastic = 2 };
+ETX_DEV uint32_t principled_pick(const DScene& s, const BsdfData& d, const etx_abi_material& in_m, Sampler& smp, etx_abi_material& m_local) {
+  m_local = in_m;
+  const float metalness = in_m.metalness.value.x * evaluate_image(s, in_m.metalness, d.tex, 1.0f);  // evaluate_metalness, scene.hxx:283-285
+  if (smp.next() < metalness) {
+    m_local.int_ior.cls = kSpectrumClassConductor;
+    m_local.int_ior.eta_index = s.default_conductor_eta;
+    m_local.int_ior.k_index = s.default_conductor_k;
+    m_local.scattering.image_index = kInvalid;
+    m_local.cls = ETX_MAT_CONDUCTOR;
+    return kPrincipledConductor;
+  }
+  m_local.int_ior.cls = kSpectrumClassDielectric;
+  m_local.int_ior.eta_index = s.default_dielectric_eta;
+  m_local.int_ior.k_index = kInvalid;
+  m_local.reflectance.image_index = kInvalid;
+  if (smp.next() < m_local.transmission.value.x) {
+    m_local.cls = ETX_MAT_DIELECTRIC;
+    return kPrincipledDielectric;
+  }
+  m_local.cls = ETX_MAT_PLASTIC;
+  return kPrincipledPlastic;
+}
+
+ETX_DEV float bsdf_pdf(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
+  if (m.cls == ETX_MAT_PRINCIPLED) {
+    etx_abi_material m_local;
+    principled_pick(s, d, m, smp, m_local);
+    return bsdf_pdf_core(s, d, w_o, m_local, smp);
+  }
+  return bsdf_pdf_core(s, d, w_o, m, smp);
+}
+
+ETX_DEV BsdfSample bsdf_sample(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
+  if (m.cls == ETX_MAT_PRINCIPLED) {
+    etx_abi_material m_local;
+    principled_pick(s, d, m, smp, m_local);
+    return bsdf_sample_core(s, d, m_local, smp);
+  }
+  return bsdf_sample_core(s, d, m, smp);
+}
+
+ETX_DEV BsdfEval bsdf_evaluate(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
+  if (m.cls == ETX_MAT_PRINCIPLED) {
+    etx_abi_material m_local;
+    principled_pick(s, d, m, smp, m_local);
+    return bsdf_evaluate_core(s, d, w_o, m_local, smp);
+  }
+  return bsdf_evaluate_core(s, d, w_o, m, smp);
+}
+
 // scene_bsdf.hxx:82-92 reverse_pdf: swap the roles of w_i and w_o
-ETX_DEV float bsdf_reverse_pdf(const DScene& s, const BsdfData& in_d, const f3& in_w_o, const etx_abi_material& m) {
+ETX_DEV float bsdf_reverse_pdf(const DScene& s, const BsdfData& in_d, const f3& in_w_o, const etx_abi_material& m, Sampler& smp) {
   BsdfData d = in_d;
   f3 w_o = -in_d.w_i;
   d.w_i = -in_w_o;
-  return bsdf_pdf(s, d, w_o, m);
+  return bsdf_pdf(s, d, w_o, m, smp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -651,7 +876,7 @@ ETX_DEV BsdfSample conductor_sample_delta(const DScene& s, const BsdfData& d, co
   r.medium_index = d.medium;
   r.eta = 1.0f;
   f3 local_w_o = {-w_i.x, -w_i.y, w_i.z};  // -wi + 2 wm (wi . wm) with wm = (0, 0, 1)
-  r.weight = fresnel_calculate(w_i.z, ext_ior, int_ior) * apply_image(s, m.reflectance, d.tex, nullptr);
+  r.weight = fresnel_calculate(w_i.z, ext_ior, int_ior, thinfilm_none()) * apply_image(s, m.reflectance, d.tex, nullptr);
   r.pdf = conductor_pdf_local(w_i, local_w_o, f2{0.0f, 0.0f});
   r.w_o = normalize(frame.from_local(local_w_o));
   return r;
@@ -678,7 +903,7 @@ ETX_DEV BsdfEval bsdf_evaluate_s(const DScene& s, const BsdfData& d, const f3& w
   return bsdf_evaluate(s, d, w_o, m, smp);
 }
 template <bool kSimple>
-ETX_DEV float bsdf_pdf_s(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m) {
+ETX_DEV float bsdf_pdf_s(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
   if (kSimple) {
     switch (m.cls) {
       case ETX_MAT_DIFFUSE:
@@ -689,19 +914,24 @@ ETX_DEV float bsdf_pdf_s(const DScene& s, const BsdfData& d, const f3& w_o, cons
         return 0.0f;
     }
   }
-  return bsdf_pdf(s, d, w_o, m);
+  return bsdf_pdf(s, d, w_o, m, smp);
 }
 template <bool kSimple>
-ETX_DEV float bsdf_reverse_pdf_s(const DScene& s, const BsdfData& in_d, const f3& in_w_o, const etx_abi_material& m) {
+ETX_DEV float bsdf_reverse_pdf_s(const DScene& s, const BsdfData& in_d, const f3& in_w_o, const etx_abi_material& m, Sampler& smp) {
   BsdfData d = in_d;
   f3 w_o = -in_d.w_i;
   d.w_i = -in_w_o;
-  return bsdf_pdf_s<kSimple>(s, d, w_o, m);
+  return bsdf_pdf_s<kSimple>(s, d, w_o, m, smp);
+}
+
+// Lambert surfaces take the sampler-free fast paths of the connect / merge kernels
+ETX_HD bool material_is_lambert(const etx_abi_material& m) {
+  return (m.cls == ETX_MAT_DIFFUSE) && (m.diffuse_variation == 0u);
 }
 
 // classes the device path implements (checked by the host at upload)
 ETX_HD bool bsdf_class_supported(uint32_t cls) {
-  return (cls == ETX_MAT_DIFFUSE) || (cls == ETX_MAT_TRANSLUCENT) || (cls == ETX_MAT_CONDUCTOR) || (cls == ETX_MAT_MIRROR) || (cls == ETX_MAT_BOUNDARY) || (cls == ETX_MAT_VOID);
+  return cls < ETX_MAT_COUNT;  // all eleven classes of scene_bsdf.hxx:56-107
 }
 
 }  // namespace etxd

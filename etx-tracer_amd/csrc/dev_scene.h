@@ -108,6 +108,7 @@ struct DScene {
   uint32_t pixel_sampler_image;
   float pixel_sampler_radius;
   uint32_t subsurface_exit_material;
+  uint32_t default_dielectric_eta, default_conductor_eta, default_conductor_k;  // spectrum indices (PrincipledBSDF)
   DCamera camera;
 };
 

@@ -219,7 +219,7 @@ ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& 
     st.d_vm *= cos_theta_bsdf;
     st.d_vcm = 0.0f;
   } else {
-    float rev_pdf = bsdf_reverse_pdf_s<kSimple>(scene, bsdf_data, bs.w_o, mat);
+    float rev_pdf = bsdf_reverse_pdf_s<kSimple>(scene, bsdf_data, bs.w_o, mat, st.sampler);
     st.d_vc = (cos_theta_bsdf / bs.pdf) * (st.d_vc * rev_pdf + st.d_vcm + it.vm_weight);
     st.d_vm = (cos_theta_bsdf / bs.pdf) * (st.d_vm * rev_pdf + st.d_vcm * it.vc_weight + 1.0f);
     st.d_vcm = 1.0f / bs.pdf;
@@ -274,7 +274,7 @@ ETX_DEV bool vcm_connect_to_camera(const DScene& scene, const VcmParams& it, boo
     if (eval.valid() == false)
       return false;
     scatter = eval.bsdf;
-    reverse_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, w_o, mat);
+    reverse_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, w_o, mat, st.sampler);
     origin = shading_pos(scene, scene.triangles[isect->tri], isect->bc, w_o);
   } else {
     const DMedium& medium = scene.mediums[st.medium];
@@ -389,11 +389,11 @@ ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool
     if (eval.valid() == false)
       return false;
     scatter = eval.bsdf;
-    reverse_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, w_o, mat);
+    reverse_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, w_o, mat, st.sampler);
     const etx_abi_triangle& tri = scene.triangles[isect->tri];
     origin = shading_pos(scene, tri, isect->bc, normalize(es.origin - isect->pos));
     camera_factor = fabsf(dot(w_o, ld3(tri.geo_n)));
-    conn_pdf = bsdf_pdf_s<kSimple>(scene, data, w_o, mat);
+    conn_pdf = bsdf_pdf_s<kSimple>(scene, data, w_o, mat, st.sampler);
   }
   float l_dot_e = fabsf(dot(es.direction, es.normal));
   float w_light = 0.0f;
@@ -439,13 +439,13 @@ ETX_DEV BsdfEval bsdf_evaluate_t(const DScene& s, const BsdfData& d, const f3& w
   return bsdf_evaluate(s, d, w_o, m, smp);
 }
 template <bool kDiffuseOnly>
-ETX_DEV float bsdf_reverse_pdf_t(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m) {
+ETX_DEV float bsdf_reverse_pdf_t(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
   if (kDiffuseOnly) {
     BsdfData r = d;
     r.w_i = -w_o;
     return diffuse_pdf(r, -d.w_i);
   }
-  return bsdf_reverse_pdf(s, d, w_o, m);
+  return bsdf_reverse_pdf(s, d, w_o, m, smp);
 }
 
 // vcm_shared.hxx:673-763 vcm_connect_to_light_vertex (surface / medium on either side)
@@ -480,7 +480,7 @@ ETX_DEV bool vcm_connect_to_light_vertex(const DScene& scene, const PathState& s
     if (camera_bsdf.valid() == false)
       return false;
     camera_area_pdf = camera_bsdf.pdf * fabsf(w_dot_l) / distance_squared;
-    camera_rev_pdf = bsdf_reverse_pdf_t<kDiffuseOnly>(scene, camera_data, w_o, mat);
+    camera_rev_pdf = bsdf_reverse_pdf_t<kDiffuseOnly>(scene, camera_data, w_o, mat, smp);
     camera_scatter = camera_bsdf.bsdf;
   }
 
@@ -502,7 +502,7 @@ ETX_DEV bool vcm_connect_to_light_vertex(const DScene& scene, const PathState& s
     if (light_bsdf.valid() == false)
       return false;
     light_area_pdf = camera_at_medium ? (light_bsdf.pdf / distance_squared) : (light_bsdf.pdf * fabsf(dot(cam->nrm, w_o)) / distance_squared);
-    light_rev_pdf = bsdf_reverse_pdf_t<kDiffuseOnly>(scene, light_data, -w_o, light_mat);
+    light_rev_pdf = bsdf_reverse_pdf_t<kDiffuseOnly>(scene, light_data, -w_o, light_mat, smp);
     light_scatter = light_bsdf.bsdf * fix_shading_normal(ld3(light_tri.geo_n), light_data.nrm, light_data.w_i, -w_o);
   }
 

@@ -43,7 +43,7 @@ ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& 
     return;
   }
   const etx_abi_material& mat = scene.materials[isect->material];
-  const bool diffuse = mat.cls == ETX_MAT_DIFFUSE;
+  const bool diffuse = material_is_lambert(mat);
   f3 fthr = st.throughput;
   if (diffuse)
     fthr = fthr * apply_image(scene, mat.scattering, isect->tex, nullptr) * kInvPi;  // DiffuseBSDF func (bsdf_various.hxx:60-64) x t_camera

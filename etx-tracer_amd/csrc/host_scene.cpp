@@ -380,16 +380,12 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
       error = "material class " + std::to_string(m.cls) + " (material " + std::to_string(i) + ") is not implemented by the device path";
       return ETX_HIP_ERROR_UNSUPPORTED;
     }
-    if ((m.cls == ETX_MAT_DIFFUSE) && (m.diffuse_variation != 0)) {
-      error = "diffuse_variation " + std::to_string(m.diffuse_variation) + " is not implemented by the device path";
+    if ((m.cls == ETX_MAT_DIFFUSE) && (m.diffuse_variation > 2u)) {
+      error = "diffuse_variation " + std::to_string(m.diffuse_variation) + " is unknown (0 Lambert, 1 microfacet, 2 vMF: bsdf_various.hxx:47-69)";
       return ETX_HIP_ERROR_UNSUPPORTED;
     }
     if (m.subsurface.cls != 0) {
       error = "subsurface scattering is not implemented by the device path";
-      return ETX_HIP_ERROR_UNSUPPORTED;
-    }
-    if ((m.cls == ETX_MAT_CONDUCTOR) && (m.thinfilm.max_thickness * m.thinfilm.min_thickness > 0.0f)) {
-      error = "thin film interference is not implemented by the device path";
       return ETX_HIP_ERROR_UNSUPPORTED;
     }
   }
@@ -399,13 +395,20 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     if (used[i] == false)
       continue;
     const etx_abi_material& m = materials[i];
-    // connectible = can return a non delta sample: Translucent always; Conductor unless its roughness is a constant <= kDeltaAlphaTreshold
-    bool delta_conductor = (m.cls == ETX_MAT_CONDUCTOR) && (m.roughness.image_index == ETX_ABI_INVALID) &&
-                           (std::max(m.roughness.value.x, m.roughness.value.y) <= kDeltaAlphaTreshold);
-    if ((m.cls == ETX_MAT_TRANSLUCENT) || ((m.cls == ETX_MAT_CONDUCTOR) && (delta_conductor == false)))
+    const bool constant_roughness = m.roughness.image_index == ETX_ABI_INVALID;
+    const float max_roughness = std::max(m.roughness.value.x, m.roughness.value.y);
+    const bool thin_film = m.thinfilm.max_thickness * m.thinfilm.min_thickness > 0.0f;
+    // "generic" = a connectible (non delta) surface that is not a plain Lambert diffuse one: its connections and merges
+    // go through the general BSDF kernels. Delta-only: Mirror, Thinfilm, Boundary, Void, roughness-0 Conductor / Dielectric.
+    const bool lambert = (m.cls == ETX_MAT_DIFFUSE) && (m.diffuse_variation == 0u);
+    const bool always_delta = (m.cls == ETX_MAT_MIRROR) || (m.cls == ETX_MAT_THINFILM) || (m.cls == ETX_MAT_BOUNDARY) || (m.cls == ETX_MAT_VOID) ||
+                              (((m.cls == ETX_MAT_CONDUCTOR) || (m.cls == ETX_MAT_DIELECTRIC)) && constant_roughness && (max_roughness <= kDeltaAlphaTreshold));
+    if ((lambert == false) && (always_delta == false))
       out.generic_materials = true;
-    bool mirror_conductor = (m.cls == ETX_MAT_CONDUCTOR) && (m.roughness.image_index == ETX_ABI_INVALID) && (m.roughness.value.x == 0.0f) && (m.roughness.value.y == 0.0f);
-    if ((m.cls == ETX_MAT_CONDUCTOR) && (mirror_conductor == false))
+    // "simple" = the shade kernels need neither the Heitz walk nor a sampler-dependent evaluation (dev_bsdf.h)
+    const bool mirror_conductor = (m.cls == ETX_MAT_CONDUCTOR) && constant_roughness && (m.roughness.value.x == 0.0f) && (m.roughness.value.y == 0.0f) && (thin_film == false);
+    const bool simple = lambert || (m.cls == ETX_MAT_TRANSLUCENT) || (m.cls == ETX_MAT_MIRROR) || (m.cls == ETX_MAT_BOUNDARY) || (m.cls == ETX_MAT_VOID) || mirror_conductor;
+    if (simple == false)
       out.simple_materials = false;
   }
   for (uint64_t i = 0; i < scene->mediums.count; ++i) {
@@ -554,6 +557,9 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   d.pixel_sampler_image = scene->pixel_sampler.image_index;
   d.pixel_sampler_radius = scene->pixel_sampler.radius;
   d.subsurface_exit_material = scene->subsurface_exit_material;
+  d.default_dielectric_eta = scene->default_dielectric_eta;
+  d.default_conductor_eta = scene->default_conductor_eta;
+  d.default_conductor_k = scene->default_conductor_k;
 
   DCamera& c = d.camera;
   memcpy(c.view_proj, camera->view_proj, sizeof(c.view_proj));

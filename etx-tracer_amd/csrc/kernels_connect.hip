@@ -24,7 +24,7 @@ static uint32_t grid_for(uint32_t capacity) {
 }
 
 ETX_DEV bool material_is_diffuse(const DScene& scene, uint32_t tri) {
-  return scene.materials[scene.triangles[tri].material_index].cls == ETX_MAT_DIFFUSE;
+  return material_is_lambert(scene.materials[scene.triangles[tri].material_index]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
             BsdfEval camera_bsdf = bsdf_evaluate(scene, camera_data, -wi, mat, cv.st.sampler);
             if (camera_bsdf.valid() == false)
               continue;
-            const float rev_pdf = bsdf_reverse_pdf(scene, camera_data, -wi, mat);
+            const float rev_pdf = bsdf_reverse_pdf(scene, camera_data, -wi, mat, cv.st.sampler);
             const float w_light = nd.w * it.vc_weight + wd.w * camera_bsdf.pdf;
             const float w_camera = w_camera_base + cv.st.d_vm * rev_pdf;
             const float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;

@@ -28,6 +28,11 @@ ETX_DEV f3 bsdf_albedo(const DScene& scene, const etx_abi_material& mat, const f
   switch (mat.cls) {
     case ETX_MAT_DIFFUSE:
     case ETX_MAT_TRANSLUCENT:
+    case ETX_MAT_PLASTIC:     // bsdf_plastic.hxx:182
+    case ETX_MAT_DIELECTRIC:  // bsdf_dielectric.hxx:256
+    case ETX_MAT_THINFILM:    // bsdf_dielectric.hxx:55
+    case ETX_MAT_VELVET:      // bsdf_velvet.hxx:122
+    case ETX_MAT_PRINCIPLED:  // bsdf_principled.hxx:120
       return apply_image(scene, mat.scattering, tex, nullptr);
     case ETX_MAT_CONDUCTOR:
       return apply_image(scene, mat.reflectance, tex, nullptr);

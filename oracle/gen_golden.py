@@ -7,6 +7,7 @@ Run in the build container (needs /root/reference): python3 oracle/gen_golden.py
                    cornell_full_128_vcm_bluenoise.npz                reference CPUVCM, 64 spp, VCMOptions defaults (blue noise on)
                    cornell_classic_128_pt.npz                        reference CPUPathTracing, 256 spp, bn=false (+ normal / albedo AOVs)
                    cornell_full_128_pt_bluenoise.npz                 reference CPUPathTracing, 64 spp, PTOptions defaults
+                   cornell_{rough,glass}_128_{vcm,pt}.npz            all BSDF classes: reference CPUVCM 64 spp / CPUPathTracing 256 spp
   blue noise       bluenoise_64spp.npz                               the reference's sample_blue_noise for the 64-spp class,
                                                                      factorised by tools/bluenoise_tables.py (258 KiB instead of 32 MiB)
   KAT vectors      kat_reference.json                                reference header functions
@@ -58,6 +59,21 @@ def pt_golden():
                             spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]), threads=np.int32(film["threads"]))
 
 
+def materials_golden():
+    # every BSDF class once: "rough" (diffuse variations 1 / 2, principled, velvet, plastic, rough dielectric, rough gold
+    # with a thin film) and "glass" (delta dielectric, thinfilm class); scenes/make_scenes.py
+    for flavour in ("rough", "glass"):
+        snapshot = os.path.join(GOLDEN, "cornell_%s_128.etxscene" % flavour)
+        run("--scene", os.path.join(SCENES, "%s_test_128.json" % flavour), "--integrator", "none", "--snapshot", snapshot)
+        for integrator, spp, extra in (("vcm", 64, ["--opt", "vcm-blue_noise=false"]), ("pt", 256, ["--opt", "bn=false"])):
+            film_path = "/tmp/golden_%s_%s.raw" % (flavour, integrator)
+            run("--load-snapshot", snapshot, "--integrator", integrator, "--spp", str(spp), "--out", film_path, *extra)
+            film = film_io.read_film(film_path)
+            np.savez_compressed(os.path.join(GOLDEN, "cornell_%s_128_%s.npz" % (flavour, integrator)), camera=film["camera"][..., :3], light=film["light"][..., :3],
+                                normal=film["normal"][..., :3], albedo=film["albedo"][..., :3], spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]),
+                                threads=np.int32(film["threads"]))
+
+
 def main():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "scenes", "make_scenes.py")])
     for flavour in ("classic", "full"):
@@ -72,6 +88,7 @@ def main():
                             spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]), threads=np.int32(film["threads"]))
     bluenoise_golden()
     pt_golden()
+    materials_golden()
     with open(os.path.join(GOLDEN, "kat_reference.json"), "w") as f:
         subprocess.check_call([ORACLE, "--kat"], stdout=f)
 
@@ -81,5 +98,7 @@ if __name__ == "__main__":
         bluenoise_golden()
     elif (len(sys.argv) > 1) and (sys.argv[1] == "pt"):
         pt_golden()
+    elif (len(sys.argv) > 1) and (sys.argv[1] == "materials"):
+        materials_golden()
     else:
         main()

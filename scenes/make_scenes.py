@@ -161,6 +161,107 @@ two_sided 1
 
 """
 
+# Material coverage scenes (same geometry as the classic box): every BSDF class of scene_bsdf.hxx:56-107 appears once.
+# "Pr r" sets alpha = r^2 (scene_representation.cxx:1731-1737).
+MTL_MATERIALS_ROUGH = """newmtl ceiling
+material class diffuse
+diffuse 1
+Kd 0.900 0.900 0.900
+Pr 0.600
+two_sided 1
+
+newmtl floor
+material class diffuse
+diffuse 2
+Kd 0.900 0.900 0.900
+Pr 0.700
+two_sided 1
+
+newmtl frontWall
+material class principled
+Kd 0.800 0.800 0.700
+Ks 1.000 1.000 1.000
+metalness 0.500
+transmission 0.000
+Pr 0.600
+two_sided 1
+
+newmtl leftWall
+material class velvet
+Kd 0.800 0.050 0.050
+Ks 0.600 0.600 0.600
+Pr 0.700
+two_sided 1
+
+newmtl rightWall
+material class plastic
+Kd 0.050 0.800 0.050
+Ks 1.000 1.000 1.000
+int_ior 1.5
+Pr 0.500
+two_sided 1
+
+newmtl shortBox
+material class dielectric
+Ks 1.000 1.000 1.000
+Kt 0.950 0.950 1.000
+int_ior 1.5
+Pr 0.450
+two_sided 1
+
+newmtl tallBox
+material class conductor
+int_ior gold
+Ks 1.000 1.000 1.000
+Pr 0.500
+thinfilm range 250 450 ior 1.33
+two_sided 1
+
+"""
+
+MTL_MATERIALS_DELTA = """newmtl ceiling
+material class diffuse
+Kd 1.000 1.000 1.000
+two_sided 1
+
+newmtl floor
+material class diffuse
+Kd 1.000 1.000 1.000
+two_sided 1
+
+newmtl frontWall
+material class diffuse
+Kd 0.906 0.906 0.906
+two_sided 1
+
+newmtl leftWall
+material class diffuse
+Kd 1.000 0.000 0.000
+two_sided 1
+
+newmtl rightWall
+material class diffuse
+Kd 0.000 1.000 0.000
+two_sided 1
+
+newmtl shortBox
+material class dielectric
+Ks 1.000 1.000 1.000
+Kt 1.000 1.000 1.000
+int_ior 1.5
+Pr 0.000
+two_sided 1
+
+newmtl tallBox
+material class thinfilm
+Ks 1.000 1.000 1.000
+Kt 1.000 1.000 1.000
+int_ior 1.5
+thinfilm range 300 600 ior 1.33
+two_sided 1
+
+"""
+
 # A scene without any non-area emitter gets a default atmosphere (sun + sky images) from the loader
 # (scene_representation.cxx: "if (_private->data.emitter_profiles.empty())"); a zero-power directional emitter
 # keeps the classic variant at "area light only" (weight 0 => never sampled, not in environment_emitters).
@@ -242,6 +343,13 @@ def main():
         f.write(MTL_COMMON + MTL_LIGHT_CLASSIC)
     with open(os.path.join(OUT, "cornell_full.mtl"), "w") as f:
         f.write(MTL_FULL_EXTRA + MTL_COMMON + MTL_LIGHT_FOG)
+
+    with open(os.path.join(OUT, "cornell_rough.mtl"), "w") as f:
+        f.write(MTL_MATERIALS_ROUGH + MTL_LIGHT_CLASSIC)
+    with open(os.path.join(OUT, "cornell_glass.mtl"), "w") as f:
+        f.write(MTL_MATERIALS_DELTA + MTL_LIGHT_CLASSIC)
+    write_json("rough_test_128.json", "cornell_classic.obj", "cornell_rough.mtl", (128, 128), 64)
+    write_json("glass_test_128.json", "cornell_classic.obj", "cornell_glass.mtl", (128, 128), 64)
 
     for flavour in ("classic", "full"):
         obj, mtl = "cornell_%s.obj" % flavour, "cornell_%s.mtl" % flavour

@@ -254,6 +254,27 @@ def test_pt_fog_cornell_with_blue_noise_matches_reference(etx, golden_dir, bluen
     compare_pt(layers, golden, 8.0e-3, 1.5e-2)
 
 
+@pytest.mark.parametrize("flavour", ["rough", "glass"])
+def test_all_bsdf_classes_match_reference(etx, golden_dir, flavour):
+    """rough: diffuse variations 1 / 2, principled, velvet, plastic, rough dielectric, rough gold under a thin film;
+    glass: delta dielectric, thinfilm class (scenes/make_scenes.py). PT and VCM against the reference's films."""
+    golden = np.load(os.path.join(golden_dir, "cornell_%s_128_pt.npz" % flavour))
+    layers, stats = render_pt(etx, golden_dir, "cornell_%s_128" % flavour, int(golden["spp"]))
+    assert stats.overflow_flags == 0
+    compare_pt(layers, golden, 6.0e-3, 2.0e-2)
+    golden = np.load(os.path.join(golden_dir, "cornell_%s_128_vcm.npz" % flavour))
+    cam, light, res, stats = render(etx, golden_dir, "cornell_%s_128" % flavour, int(golden["spp"]))
+    assert stats.overflow_flags == 0 and np.isfinite(res).all()
+    ref_result = np.maximum(golden["camera"] + golden["light"], 0.0)
+    ok = np.isfinite(ref_result).all(axis=2)  # the reference's release build lets an occasional NaN sample through
+    assert ok.mean() > 0.999
+    ref_result = np.where(ok[..., None], ref_result, 0.0)
+    res = np.where(ok[..., None], res[..., :3], 0.0)
+    assert rmse(block_mean(res, 32), block_mean(ref_result, 32)) < 6.0e-3
+    rel = (res.mean(axis=(0, 1)) - ref_result.mean(axis=(0, 1))) / ref_result.mean(axis=(0, 1))
+    assert np.abs(rel).max() < 2.0e-2, rel
+
+
 def test_pt_options_and_config1_size(etx, golden_dir):
     # configs[0]: 512 x 512, 16 spp. Size-independent properties + the option switches of CPUPathTracingImpl::start
     full, stats = render_pt(etx, golden_dir, "cornell_classic_512", 16)
