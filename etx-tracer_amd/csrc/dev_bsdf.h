@@ -17,10 +17,11 @@ struct BsdfData {  // bsdf.hxx:22-48 BSDFData (spectrum query dropped: RGB mode)
   f3 w_i;
   uint32_t medium;
   uint32_t path_source;
+  float wavelength;  // spectrum_sample: the path's wavelength in spectral mode (ignored in RGB mode)
 };
 
-ETX_DEV BsdfData make_bsdf_data(const Vtx& v, const f3& w_i, uint32_t medium, uint32_t path_source) {
-  return BsdfData{v.nrm, v.tan, v.btn, v.tex, w_i, medium, path_source};
+ETX_DEV BsdfData make_bsdf_data(const Vtx& v, const f3& w_i, uint32_t medium, uint32_t path_source, float wavelength) {
+  return BsdfData{v.nrm, v.tan, v.btn, v.tex, w_i, medium, path_source, wavelength};
 }
 
 struct Frame {  // math.hxx:614-646 LocalFrame
@@ -131,16 +132,18 @@ ETX_DEV float fresnel_generic(float cos_theta_i, cplx ext_ior, cplx int_ior) {
   return 0.5f * (cnorm(rs) + cnorm(rp));
 }
 
-struct Ior {  // RefractiveIndex::Sample, RGB mode (spectrum.hxx:553-590)
+struct Ior {  // RefractiveIndex::Sample (spectrum.hxx:553-590)
   f3 eta, k;
   uint32_t cls;
+  uint32_t spectral;  // values are single-wavelength samples (replicated), not RGB / XYZ integrals
 };
 
-ETX_DEV Ior evaluate_refractive_index(const DScene& s, const etx_abi_refractive_index& ri) {  // scene.hxx:311-317
+ETX_DEV Ior evaluate_refractive_index(const DScene& s, const etx_abi_refractive_index& ri, float wavelength) {  // scene.hxx:311-317
   Ior r;
   r.cls = ri.cls;
-  r.eta = (ri.eta_index == kInvalid) ? mk3(1.0f) : spectrum_rgb(s, ri.eta_index);
-  r.k = (ri.k_index == kInvalid) ? mk3(0.0f) : spectrum_rgb(s, ri.k_index);
+  r.spectral = s.spectral;
+  r.eta = (ri.eta_index == kInvalid) ? mk3(1.0f) : spectrum_eval(s, ri.eta_index, wavelength);
+  r.k = (ri.k_index == kInvalid) ? mk3(0.0f) : spectrum_eval(s, ri.k_index, wavelength);
   return r;
 }
 
@@ -159,19 +162,23 @@ struct ThinfilmEval {
   float thickness;
 };
 
-ETX_DEV ThinfilmEval evaluate_thinfilm(const DScene& s, const etx_abi_thinfilm& film, const f2 uv, Sampler& smp) {
+ETX_DEV ThinfilmEval evaluate_thinfilm(const DScene& s, const etx_abi_thinfilm& film, const f2 uv, Sampler& smp, float wavelength) {
   ThinfilmEval r;
-  r.ior.cls = 0u, r.ior.eta = mk3(0.0f), r.ior.k = mk3(0.0f);
+  r.ior.cls = 0u, r.ior.spectral = s.spectral, r.ior.eta = mk3(0.0f), r.ior.k = mk3(0.0f);
   r.rgb_wavelengths = {610.0f, 537.0f, 450.0f};
   r.thickness = 0.0f;
   if (film.max_thickness * film.min_thickness <= 0.0f)
     return r;
   const float t = (film.thickness_image == kInvalid) ? 1.0f : image_evaluate(s.images[film.thickness_image], uv, nullptr).x;
   r.thickness = film.min_thickness + (film.max_thickness - film.min_thickness) * t;  // lerp(min, max, t)
-  r.rgb_wavelengths.x = 610.0f + 45.0f * (2.0f * smp.next() - 1.0f);
-  r.rgb_wavelengths.y = 537.0f + 47.0f * (2.0f * smp.next() - 1.0f);
-  r.rgb_wavelengths.z = 450.0f + 23.5f * (2.0f * smp.next() - 1.0f);
-  r.ior = evaluate_refractive_index(s, film.ior);
+  if (s.spectral) {  // scene_bsdf.hxx:118: the film sees the path's wavelength, no draws
+    r.rgb_wavelengths = mk3(wavelength);
+  } else {
+    r.rgb_wavelengths.x = 610.0f + 45.0f * (2.0f * smp.next() - 1.0f);
+    r.rgb_wavelengths.y = 537.0f + 47.0f * (2.0f * smp.next() - 1.0f);
+    r.rgb_wavelengths.z = 450.0f + 23.5f * (2.0f * smp.next() - 1.0f);
+  }
+  r.ior = evaluate_refractive_index(s, film.ior, wavelength);
   return r;
 }
 
@@ -247,7 +254,7 @@ ETX_DEV f3 fresnel_calculate(float cos_theta, const Ior& ext_ior, const Ior& int
     values.x = fresnel_generic(cos_theta, cplx{ext_ior.eta.x, ext_ior.k.x}, cplx{int_ior.eta.x, int_ior.k.x});
     values.y = fresnel_generic(cos_theta, cplx{ext_ior.eta.y, ext_ior.k.y}, cplx{int_ior.eta.y, int_ior.k.y});
     values.z = fresnel_generic(cos_theta, cplx{ext_ior.eta.z, ext_ior.k.z}, cplx{int_ior.eta.z, int_ior.k.z});
-    if (int_ior.cls == kSpectrumClassConductor) {
+    if ((int_ior.cls == kSpectrumClassConductor) && (int_ior.spectral == 0u)) {
       // conductor IORs are stored as XYZ (spectrum.cxx:390-391); spectrum.hxx:142-148 xyz_to_rgb, :449 kRGBLuminanceScale
       f3 rgb = {
         3.24045420f * values.x - 1.5371385f * values.y - 0.4985314f * values.z,
@@ -266,7 +273,7 @@ ETX_DEV f3 fresnel_calculate(float cos_theta, const Ior& ext_ior, const Ior& int
 
 ETX_DEV ThinfilmEval thinfilm_none() {
   ThinfilmEval r;
-  r.ior.cls = 0u, r.ior.eta = mk3(0.0f), r.ior.k = mk3(0.0f);
+  r.ior.cls = 0u, r.ior.spectral = 0u, r.ior.eta = mk3(0.0f), r.ior.k = mk3(0.0f);
   r.rgb_wavelengths = {610.0f, 537.0f, 450.0f};
   r.thickness = 0.0f;
   return r;
@@ -477,7 +484,7 @@ namespace etxd {
 ETX_DEV BsdfEval diffuse_layer_v(const DScene& s, const BsdfData& d, const f3& local_w_i, const f3& local_w_o, const etx_abi_material& m, Sampler& smp) {
   if (local_w_o.z <= 0.0f)
     return eval_zero();
-  f3 diffuse = apply_image(s, m.scattering, d.tex, nullptr);
+  f3 diffuse = apply_image(s, m.scattering, d.tex, nullptr, d.wavelength);
   BsdfEval e;
   e.eta = 1.0f;
   if (m.diffuse_variation == 1u) {
@@ -498,7 +505,7 @@ ETX_DEV BsdfEval diffuse_layer_v(const DScene& s, const BsdfData& d, const f3& l
 ETX_DEV BsdfEval diffuse_layer(const DScene& s, const BsdfData& d, const f3& local_w_o, const etx_abi_material& m) {
   if (local_w_o.z <= 0.0f)
     return eval_zero();
-  f3 diffuse = apply_image(s, m.scattering, d.tex, nullptr);
+  f3 diffuse = apply_image(s, m.scattering, d.tex, nullptr, d.wavelength);
   BsdfEval e;
   e.eta = 1.0f;
   e.func = diffuse / kPi;
@@ -515,7 +522,7 @@ ETX_DEV BsdfSample diffuse_sample(const DScene& s, const BsdfData& d, const etx_
   r.properties = kSampleReflection | kSampleDiffuse;
   f3 local_w_o;
   if (m.diffuse_variation == 1u) {
-    f3 diffuse = apply_image(s, m.scattering, d.tex, nullptr);
+    f3 diffuse = apply_image(s, m.scattering, d.tex, nullptr, d.wavelength);
     local_w_o = ms_sample_diffuse(smp, local_w_i, evaluate_roughness(s, m, d.tex), diffuse, r.weight);
     r.pdf = kInvPi * local_w_o.z;
   } else {
@@ -566,9 +573,9 @@ ETX_DEV bool conductor_is_delta(const DScene& s, const etx_abi_material& m, cons
 ETX_DEV BsdfSample conductor_sample(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
   Frame frame = normal_frame(d);
   f3 w_i = frame.to_local(-d.w_i);
-  Ior ext_ior = evaluate_refractive_index(s, m.ext_ior);
-  Ior int_ior = evaluate_refractive_index(s, m.int_ior);
-  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp);
+  Ior ext_ior = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
+  Ior int_ior = evaluate_refractive_index(s, m.int_ior, d.wavelength);
+  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
   BsdfSample r = sample_zero();
   r.properties = kSampleReflection | (conductor_is_delta(s, m, d.tex) ? kSampleDelta : 0u);
   r.medium_index = d.medium;
@@ -594,7 +601,7 @@ ETX_DEV BsdfSample conductor_sample(const DScene& s, const BsdfData& d, const et
     }
   }
   f3 local_w_o = ray.w;
-  r.weight *= apply_image(s, m.reflectance, d.tex, nullptr);
+  r.weight *= apply_image(s, m.reflectance, d.tex, nullptr, d.wavelength);
   r.pdf = conductor_pdf_local(w_i, local_w_o, roughness);
   r.w_o = normalize(frame.from_local(local_w_o));
   return r;
@@ -609,13 +616,13 @@ ETX_DEV BsdfEval conductor_evaluate(const DScene& s, const BsdfData& d, const f3
   if (w_i.z <= kEpsilon)
     return eval_zero();
   f2 roughness = evaluate_roughness(s, m, d.tex);
-  Ior ext_ior = evaluate_refractive_index(s, m.ext_ior);
-  Ior int_ior = evaluate_refractive_index(s, m.int_ior);
-  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp);
+  Ior ext_ior = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
+  Ior int_ior = evaluate_refractive_index(s, m.int_ior, d.wavelength);
+  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
   f3 value = ms_eval_conductor(smp, w_i, w_o, roughness, ext_ior, int_ior, tf);
   BsdfEval e;
   e.eta = 1.0f;
-  e.bsdf = value * apply_image(s, m.reflectance, d.tex, nullptr);
+  e.bsdf = value * apply_image(s, m.reflectance, d.tex, nullptr, d.wavelength);
   e.func = e.bsdf / w_o.z;
   e.pdf = conductor_pdf_local(w_i, w_o, roughness);
   return e;
@@ -640,8 +647,8 @@ ETX_DEV bool direction_matches(const f3& ideal, const f3& actual) {  // math.hxx
 // bsdf_various.hxx:136-211 TranslucentBSDF
 ETX_DEV BsdfSample translucent_sample(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
   Frame frame = normal_frame(d);
-  f3 tr = apply_image(s, m.scattering, d.tex, nullptr);
-  f3 rf = apply_image(s, m.reflectance, d.tex, nullptr);
+  f3 tr = apply_image(s, m.scattering, d.tex, nullptr, d.wavelength);
+  f3 rf = apply_image(s, m.reflectance, d.tex, nullptr, d.wavelength);
   float tr_value = luminance(tr), rf_value = luminance(rf);
   float total = tr_value + rf_value;
   if (total == 0.0f)
@@ -671,8 +678,8 @@ ETX_DEV BsdfEval translucent_evaluate(const DScene& s, const BsdfData& d, const 
   float n_dot_i = -dot(frame.nrm, d.w_i);
   float n_dot_o = dot(frame.nrm, w_o);
   bool reflection = n_dot_o * n_dot_i > 0.0f;
-  f3 tr = apply_image(s, m.scattering, d.tex, nullptr);
-  f3 rf = apply_image(s, m.reflectance, d.tex, nullptr);
+  f3 tr = apply_image(s, m.scattering, d.tex, nullptr, d.wavelength);
+  f3 rf = apply_image(s, m.reflectance, d.tex, nullptr, d.wavelength);
   float tr_value = luminance(tr), rf_value = luminance(rf);
   float total = tr_value + rf_value;
   if (total == 0.0f)
@@ -691,8 +698,8 @@ ETX_DEV float translucent_pdf(const DScene& s, const BsdfData& d, const f3& w_o,
   Frame frame = normal_frame(d);
   float n_dot_i = -dot(frame.nrm, d.w_i);
   float n_dot_o = dot(frame.nrm, w_o);
-  float tr_value = luminance(apply_image(s, m.scattering, d.tex, nullptr));
-  float rf_value = luminance(apply_image(s, m.reflectance, d.tex, nullptr));
+  float tr_value = luminance(apply_image(s, m.scattering, d.tex, nullptr, d.wavelength));
+  float rf_value = luminance(apply_image(s, m.reflectance, d.tex, nullptr, d.wavelength));
   float total = tr_value + rf_value;
   bool reflection = n_dot_o * n_dot_i > 0.0f;
   return (total == 0.0f) ? 0.0f : kInvPi * fabsf(n_dot_o) * (reflection ? rf_value / total : tr_value / total);
@@ -700,6 +707,26 @@ ETX_DEV float translucent_pdf(const DScene& s, const BsdfData& d, const f3& w_o,
 
 // ---------------------------------------------------------------------------------------------------------------
 // dispatch  scene_bsdf.hxx:56-107
+
+// Mirror (bsdf_various.hxx:215-224) and Boundary (:260-270)
+ETX_DEV BsdfSample bsdf_sample_delta_classes(const DScene& s, const BsdfData& d, const etx_abi_material& m) {
+  BsdfSample r = sample_zero();
+  if (m.cls == ETX_MAT_MIRROR) {
+    Frame frame = normal_frame(d);
+    r.w_o = normalize(reflect(d.w_i, frame.nrm));
+    r.weight = apply_image(s, m.scattering, d.tex, nullptr, d.wavelength);
+    r.pdf = 1.0f;
+    r.properties = kSampleDelta | kSampleReflection;
+    return r;
+  }
+  bool entering = dot(d.nrm, d.w_i) < 0.0f;
+  r.w_o = d.w_i;
+  r.pdf = 1.0f;
+  r.weight = mk3(1.0f);
+  r.properties = kSampleTransmission | kSampleMediumChanged;
+  r.medium_index = entering ? m.int_medium : m.ext_medium;
+  return r;
+}
 
 ETX_DEV BsdfSample bsdf_sample_core(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
   switch (m.cls) {
@@ -717,25 +744,9 @@ ETX_DEV BsdfSample bsdf_sample_core(const DScene& s, const BsdfData& d, const et
       return plastic_sample(s, d, m, smp);
     case ETX_MAT_VELVET:
       return velvet_sample(s, d, m, smp);
-    case ETX_MAT_MIRROR: {  // bsdf_various.hxx:215-224
-      Frame frame = normal_frame(d);
-      BsdfSample r = sample_zero();
-      r.w_o = normalize(reflect(d.w_i, frame.nrm));
-      r.weight = apply_image(s, m.scattering, d.tex, nullptr);
-      r.pdf = 1.0f;
-      r.properties = kSampleDelta | kSampleReflection;
-      return r;
-    }
-    case ETX_MAT_BOUNDARY: {  // bsdf_various.hxx:260-270
-      bool entering = dot(d.nrm, d.w_i) < 0.0f;
-      BsdfSample r = sample_zero();
-      r.w_o = d.w_i;
-      r.pdf = 1.0f;
-      r.weight = mk3(1.0f);
-      r.properties = kSampleTransmission | kSampleMediumChanged;
-      r.medium_index = entering ? m.int_medium : m.ext_medium;
-      return r;
-    }
+    case ETX_MAT_MIRROR:
+    case ETX_MAT_BOUNDARY:
+      return bsdf_sample_delta_classes(s, d, m);
     default: {  // Void, bsdf_various.hxx:5-15
       BsdfSample r = sample_zero();
       r.w_o = d.w_i;
@@ -764,7 +775,7 @@ ETX_DEV BsdfEval bsdf_evaluate_core(const DScene& s, const BsdfData& d, const f3
       BsdfEval e = eval_zero();
       Frame frame = normal_frame(d);
       if (direction_matches(normalize(reflect(d.w_i, frame.nrm)), normalize(w_o))) {
-        e.func = apply_image(s, m.scattering, d.tex, nullptr);
+        e.func = apply_image(s, m.scattering, d.tex, nullptr, d.wavelength);
         e.bsdf = e.func;
         e.pdf = 1.0f;
       }
@@ -869,23 +880,56 @@ ETX_DEV float bsdf_reverse_pdf(const DScene& s, const BsdfData& in_d, const f3& 
 ETX_DEV BsdfSample conductor_sample_delta(const DScene& s, const BsdfData& d, const etx_abi_material& m) {
   Frame frame = normal_frame(d);
   f3 w_i = frame.to_local(-d.w_i);
-  Ior ext_ior = evaluate_refractive_index(s, m.ext_ior);
-  Ior int_ior = evaluate_refractive_index(s, m.int_ior);
+  Ior ext_ior = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
+  Ior int_ior = evaluate_refractive_index(s, m.int_ior, d.wavelength);
   BsdfSample r = sample_zero();
   r.properties = kSampleReflection | kSampleDelta;
   r.medium_index = d.medium;
   r.eta = 1.0f;
   f3 local_w_o = {-w_i.x, -w_i.y, w_i.z};  // -wi + 2 wm (wi . wm) with wm = (0, 0, 1)
-  r.weight = fresnel_calculate(w_i.z, ext_ior, int_ior, thinfilm_none()) * apply_image(s, m.reflectance, d.tex, nullptr);
+  r.weight = fresnel_calculate(w_i.z, ext_ior, int_ior, thinfilm_none()) * apply_image(s, m.reflectance, d.tex, nullptr, d.wavelength);
   r.pdf = conductor_pdf_local(w_i, local_w_o, f2{0.0f, 0.0f});
   r.w_o = normalize(frame.from_local(local_w_o));
   return r;
 }
 
+// Lambert DiffuseBSDF::sample without the rough-diffuse variations (bsdf_various.hxx:88-110, default branch)
+ETX_DEV BsdfSample diffuse_sample_lambert(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
+  Frame frame = normal_frame(d);
+  BsdfSample r = sample_zero();
+  r.eta = 1.0f;
+  r.properties = kSampleReflection | kSampleDiffuse;
+  f2 cos_rnd = smp.has_fixed() ? f2{smp.fixed_u, smp.fixed_v} : smp.next_2d();
+  f3 local_w_o = sample_cosine_distribution(cos_rnd, 1.0f);
+  BsdfEval dl = diffuse_layer(s, d, local_w_o, m);
+  r.weight = (dl.pdf == 0.0f) ? mk3(0.0f) : dl.bsdf / dl.pdf;
+  r.pdf = dl.pdf;
+  r.w_o = frame.from_local(local_w_o);
+  return r;
+}
+
 template <bool kSimple>
 ETX_DEV BsdfSample bsdf_sample_s(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
-  if (kSimple && (m.cls == ETX_MAT_CONDUCTOR))
-    return conductor_sample_delta(s, d, m);
+  if (kSimple) {  // the classes host_scene.cpp admits to "simple" scenes; the others are compiled out of these kernels
+    switch (m.cls) {
+      case ETX_MAT_DIFFUSE:
+        return diffuse_sample_lambert(s, d, m, smp);
+      case ETX_MAT_TRANSLUCENT:
+        return translucent_sample(s, d, m, smp);
+      case ETX_MAT_CONDUCTOR:
+        return conductor_sample_delta(s, d, m);
+      case ETX_MAT_MIRROR:
+      case ETX_MAT_BOUNDARY:
+        return bsdf_sample_delta_classes(s, d, m);
+      default: {  // Void
+        BsdfSample r = sample_zero();
+        r.w_o = d.w_i;
+        r.properties = kSampleDelta;
+        r.medium_index = d.medium;
+        return r;
+      }
+    }
+  }
   return bsdf_sample(s, d, m, smp);
 }
 template <bool kSimple>

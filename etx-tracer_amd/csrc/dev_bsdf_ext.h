@@ -169,9 +169,9 @@ ETX_DEV float dielectric_pdf(const DScene& s, const BsdfData& d, const f3& in_w_
   if (fabsf(w_o.z) <= kEpsilon)
     return 0.0f;
   const f2 roughness = evaluate_roughness(s, m, d.tex);
-  const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior);
-  const Ior int_ior = evaluate_refractive_index(s, m.int_ior);
-  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp);
+  const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
+  const Ior int_ior = evaluate_refractive_index(s, m.int_ior, d.wavelength);
+  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
   const bool outside = w_i.z > 0.0f;
   const bool reflection = w_i.z * w_o.z > 0.0f;
   f3 wh;
@@ -199,9 +199,9 @@ ETX_DEV BsdfSample dielectric_sample(const DScene& s, const BsdfData& d, const e
   const f3 w_i = frame.to_local(-d.w_i);
   const bool in_outside = w_i.z > 0.0f;
   const float direction_scale = in_outside ? 1.0f : -1.0f;
-  const Ior ext_ior = in_outside ? evaluate_refractive_index(s, m.ext_ior) : evaluate_refractive_index(s, m.int_ior);
-  const Ior int_ior = in_outside ? evaluate_refractive_index(s, m.int_ior) : evaluate_refractive_index(s, m.ext_ior);
-  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp);
+  const Ior ext_ior = in_outside ? evaluate_refractive_index(s, m.ext_ior, d.wavelength) : evaluate_refractive_index(s, m.int_ior, d.wavelength);
+  const Ior int_ior = in_outside ? evaluate_refractive_index(s, m.int_ior, d.wavelength) : evaluate_refractive_index(s, m.ext_ior, d.wavelength);
+  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
   BsdfSample r = sample_zero();
   r.weight = mk3(1.0f);
   const f2 roughness = evaluate_roughness(s, m, d.tex);
@@ -233,13 +233,13 @@ ETX_DEV BsdfSample dielectric_sample(const DScene& s, const BsdfData& d, const e
   const uint32_t delta_sample = dielectric_is_delta(s, m, d.tex) ? kSampleDelta : 0u;
   if (w_i.z * local_w_o.z > 0.0f) {
     r.eta = 1.0f;
-    r.weight = (r.weight / luminance(r.weight)) * apply_image(s, m.reflectance, d.tex, nullptr);
+    r.weight = (r.weight / luminance(r.weight)) * apply_image(s, m.reflectance, d.tex, nullptr, d.wavelength);
     r.properties = kSampleReflection | delta_sample;
     r.medium_index = d.medium;
   } else {
     const float eta = ior_eta_ratio(int_ior, ext_ior);
     r.eta = eta;
-    r.weight = (r.weight / luminance(r.weight)) * apply_image(s, m.scattering, d.tex, nullptr) * sqr(1.0f / eta);
+    r.weight = (r.weight / luminance(r.weight)) * apply_image(s, m.scattering, d.tex, nullptr, d.wavelength) * sqr(1.0f / eta);
     r.properties = kSampleTransmission | kSampleMediumChanged | delta_sample;
     r.medium_index = in_outside ? m.int_medium : m.ext_medium;
   }
@@ -257,9 +257,9 @@ ETX_DEV BsdfEval dielectric_evaluate(const DScene& s, const BsdfData& d, const f
   if (fabsf(w_o.z) <= kEpsilon)
     return eval_zero();
   const f2 roughness = evaluate_roughness(s, m, d.tex);
-  const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior);
-  const Ior int_ior = evaluate_refractive_index(s, m.int_ior);
-  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp);
+  const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
+  const Ior int_ior = evaluate_refractive_index(s, m.int_ior, d.wavelength);
+  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
   const bool forward_path = d.path_source == kPathCamera;
   const float backward_scale = fabsf(1.0f / w_i.z);
   f3 value;
@@ -278,7 +278,7 @@ ETX_DEV BsdfEval dielectric_evaluate(const DScene& s, const BsdfData& d, const f
   const bool reflection = w_i.z * w_o.z > 0.0f;
   BsdfEval e;
   e.eta = 1.0f;
-  e.func = (2.0f * value) * apply_image(s, reflection ? m.reflectance : m.scattering, d.tex, nullptr);
+  e.func = (2.0f * value) * apply_image(s, reflection ? m.reflectance : m.scattering, d.tex, nullptr, d.wavelength);
   e.bsdf = e.func * fabsf(w_o.z);
   e.pdf = dielectric_pdf(s, d, in_w_o, m, smp);
   return e;
@@ -288,22 +288,22 @@ ETX_DEV BsdfEval dielectric_evaluate(const DScene& s, const BsdfData& d, const f
 // ThinfilmBSDF, bsdf_dielectric.hxx:3-59 (always delta: evaluate / pdf are zero)
 ETX_DEV BsdfSample thinfilm_sample(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
   const Frame frame = normal_frame(d);
-  const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior);
-  const Ior int_ior = evaluate_refractive_index(s, m.int_ior);
-  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp);
+  const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
+  const Ior int_ior = evaluate_refractive_index(s, m.int_ior, d.wavelength);
+  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
   const f3 fr = fresnel_calculate(dot(d.w_i, d.nrm), ext_ior, int_ior, tf);
   const float f = luminance(fr);
   BsdfSample r = sample_zero();
   if (smp.next() <= f) {
     r.w_o = normalize(reflect(d.w_i, frame.nrm));
     r.pdf = f;
-    r.weight = apply_image(s, m.reflectance, d.tex, nullptr) * (fr / f);
+    r.weight = apply_image(s, m.reflectance, d.tex, nullptr, d.wavelength) * (fr / f);
     r.properties = kSampleDelta | kSampleReflection;
     r.medium_index = d.medium;
   } else {
     r.w_o = d.w_i;
     r.pdf = 1.0f - f;
-    r.weight = apply_image(s, m.scattering, d.tex, nullptr) * ((mk3(1.0f) - fr) / (1.0f - f));
+    r.weight = apply_image(s, m.scattering, d.tex, nullptr, d.wavelength) * ((mk3(1.0f) - fr) / (1.0f - f));
     r.properties = kSampleDelta | kSampleTransmission | kSampleMediumChanged;
     r.medium_index = frame.entering ? m.int_medium : m.ext_medium;
   }
@@ -532,11 +532,11 @@ ETX_DEV f3 plastic_specular_func(const DScene& s, const BsdfData& d, const f3& i
   if (w_o.z <= kEpsilon)
     return mk3(0.0f);
   const f2 roughness = evaluate_roughness(s, m, d.tex);
-  const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior);
-  const Ior int_ior = evaluate_refractive_index(s, m.int_ior);
-  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp);
+  const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
+  const Ior int_ior = evaluate_refractive_index(s, m.int_ior, d.wavelength);
+  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
   const f3 value = ms_eval_dielectric(smp, w_i, w_o, true, roughness, ext_ior, int_ior, tf);
-  return 2.0f * value * apply_image(s, m.reflectance, d.tex, nullptr);
+  return 2.0f * value * apply_image(s, m.reflectance, d.tex, nullptr, d.wavelength);
 }
 
 ETX_DEV float plastic_specular_pdf(const DScene& s, const BsdfData& d, const f3& in_w_o, const etx_abi_material& m, Sampler& smp) {  // :37-74
@@ -547,10 +547,10 @@ ETX_DEV float plastic_specular_pdf(const DScene& s, const BsdfData& d, const f3&
   const f3 w_o = frame.to_local(in_w_o);
   if (w_o.z <= kEpsilon)
     return 0.0f;
-  const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior);
-  const Ior int_ior = evaluate_refractive_index(s, m.int_ior);
+  const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
+  const Ior int_ior = evaluate_refractive_index(s, m.int_ior, d.wavelength);
   const f2 roughness = evaluate_roughness(s, m, d.tex);
-  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp);
+  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
   const f3 wh = normalize(w_o + w_i);
   const float dwh_dwo = 1.0f / (4.0f * dot(w_o, wh));
   const MsRay ray = ms_ray(w_i, roughness);
@@ -569,9 +569,9 @@ ETX_DEV BsdfEval plastic_evaluate(const DScene& s, const BsdfData& d, const f3& 
   const float m_dot_o = dot(mh, w_o);
   if ((n_dot_o <= kEpsilon) || (m_dot_o <= kEpsilon))
     return eval_zero();
-  const Ior eta_e = evaluate_refractive_index(s, m.ext_ior);
-  const Ior eta_i = evaluate_refractive_index(s, m.int_ior);
-  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp);
+  const Ior eta_e = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
+  const Ior eta_i = evaluate_refractive_index(s, m.int_ior, d.wavelength);
+  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
   const f3 fr = fresnel_calculate(dot(d.w_i, mh), eta_e, eta_i, tf);
   const f3 local_w_i = frame.to_local(-d.w_i);
   const f3 local_w_o = frame.to_local(w_o);
@@ -593,9 +593,9 @@ ETX_DEV float plastic_pdf(const DScene& s, const BsdfData& d, const f3& w_o, con
   const float n_dot_o = dot(frame.nrm, w_o);
   if ((n_dot_o <= kEpsilon) || (m_dot_o <= kEpsilon))
     return 0.0f;
-  const Ior eta_e = evaluate_refractive_index(s, m.ext_ior);
-  const Ior eta_i = evaluate_refractive_index(s, m.int_ior);
-  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp);
+  const Ior eta_e = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
+  const Ior eta_i = evaluate_refractive_index(s, m.int_ior, d.wavelength);
+  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
   const f3 fr = fresnel_calculate(dot(d.w_i, mh), eta_e, eta_i, tf);
   const float diff_pdf = kInvPi * n_dot_o;
   const float spec_pdf = plastic_specular_pdf(s, d, w_o, m, smp);
@@ -606,9 +606,9 @@ ETX_DEV BsdfSample plastic_sample(const DScene& s, const BsdfData& d, const etx_
   const Frame frame = normal_frame(d);
   const f2 roughness = evaluate_roughness(s, m, d.tex);
   const f3 mh = ggx_sample_normal(frame, roughness, smp, d.w_i);
-  const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior);
-  const Ior int_ior = evaluate_refractive_index(s, m.int_ior);
-  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp);
+  const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
+  const Ior int_ior = evaluate_refractive_index(s, m.int_ior, d.wavelength);
+  const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
   const f3 f = fresnel_calculate(dot(d.w_i, mh), ext_ior, int_ior, tf);
   const f3 w_i = frame.to_local(-d.w_i);
   if (w_i.z <= kEpsilon)
@@ -674,8 +674,8 @@ ETX_DEV BsdfEval velvet_evaluate(const DScene& s, const BsdfData& d, const f3& w
     const float g = 1.0f / (1.0f + l_i + l_o);
     specular_scale_base = 0.25f * dd * g / n_dot_i;
   }
-  const f3 diffuse = apply_image(s, m.scattering, d.tex, nullptr);
-  const f3 specular = apply_image(s, m.reflectance, d.tex, nullptr);
+  const f3 diffuse = apply_image(s, m.scattering, d.tex, nullptr, d.wavelength);
+  const f3 specular = apply_image(s, m.reflectance, d.tex, nullptr, d.wavelength);
   // diffuse_burley, :55-60
   const float f90 = 0.5f + 2.0f * alpha * m_dot_o * m_dot_o;
   const float diffuse_scale = velvet_fresnel_approximate(1.0f, f90, n_dot_o) * velvet_fresnel_approximate(1.0f, f90, n_dot_i) * kInvPi;

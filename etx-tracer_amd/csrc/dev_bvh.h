@@ -233,8 +233,10 @@ ETX_DEV Hit bvh_closest(const DScene& scene, Nodes nodes, Tris tris, int32_t roo
 
 
 // scene_medium.hxx:187-193 (homogeneous branch): exp(-sigma_t * distance)
-ETX_DEV f3 medium_transmittance_homogeneous(const DMedium& m, float distance) {
-  f3 ext = m.absorption + m.scattering;
+ETX_DEV f3 medium_transmittance_homogeneous(const DScene& scene, const DMedium& m, float wavelength, float distance) {
+  f3 absorption, scattering;
+  medium_coefficients(scene, m, wavelength, absorption, scattering);
+  f3 ext = absorption + scattering;
   return {expf(-ext.x * distance), expf(-ext.y * distance), expf(-ext.z * distance)};
 }
 
@@ -242,7 +244,7 @@ ETX_DEV f3 medium_transmittance_homogeneous(const DMedium& m, float distance) {
 // Boundary crossings kept sorted by t in registers (rt.cxx:488-516 collects up to 63 and sorts, :518-578 walks the
 // media); more than four crossings fall back to the restart walk below. Returns false when the fallback is needed.
 template <class Tris>
-ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, const f3& direction, float t_max, uint32_t medium_index, uint32_t& alpha_seed, f3& result) {
+ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, const f3& direction, float t_max, uint32_t medium_index, float wavelength, uint32_t& alpha_seed, f3& result) {
   const RayQ ray = {p0, kRayEpsilon, direction, t_max};
   float bt0 = kMaxFloat, bt1 = kMaxFloat, bt2 = kMaxFloat, bt3 = kMaxFloat;
   uint32_t bi0 = kInvalid, bi1 = kInvalid, bi2 = kInvalid, bi3 = kInvalid;
@@ -290,7 +292,7 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
   for (uint32_t k = 0; k < 4u; ++k) {
     if (k < crossings) {
       if (medium != kInvalid)
-        result *= medium_transmittance_homogeneous(scene.mediums[medium], fmaxf(0.0f, bts[k] - current_t));
+        result *= medium_transmittance_homogeneous(scene, scene.mediums[medium], wavelength, fmaxf(0.0f, bts[k] - current_t));
       const etx_abi_triangle& tri = scene.triangles[scene.flat_info[bis[k]].tri_a];
       const etx_abi_material& mat = scene.materials[tri.material_index];
       medium = (dot(ld3(tri.geo_n), direction) < 0.0f) ? mat.int_medium : mat.ext_medium;
@@ -298,7 +300,7 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
     }
   }
   if (medium != kInvalid)
-    result *= medium_transmittance_homogeneous(scene.mediums[medium], fmaxf(0.0f, t_max - current_t));
+    result *= medium_transmittance_homogeneous(scene, scene.mediums[medium], wavelength, fmaxf(0.0f, t_max - current_t));
   return true;
 }
 
@@ -308,7 +310,7 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
 // rays_traced counts the traversals (statistics).
 template <class Nodes, class Tris>
 ETX_DEV f3 bvh_transmittance(const DScene& scene, Nodes nodes, Tris tris, int32_t root, const LaneStack& stack, const f3& p0, const f3& p1, uint32_t medium_index,
-  uint32_t& alpha_seed) {
+  float wavelength, uint32_t& alpha_seed) {
   f3 direction = p1 - p0;
   float t_max = dot(direction, direction);
   if (t_max <= kRayEpsilon)
@@ -318,7 +320,7 @@ ETX_DEV f3 bvh_transmittance(const DScene& scene, Nodes nodes, Tris tris, int32_
   t_max -= fmaxf(kRayEpsilon, t_max * kRayEpsilon);
 
   f3 result = mk3(1.0f);
-  if (scene.bvh_flat && flat_transmittance(scene, tris, p0, direction, t_max, medium_index, alpha_seed, result))
+  if (scene.bvh_flat && flat_transmittance(scene, tris, p0, direction, t_max, medium_index, wavelength, alpha_seed, result))
     return result;
   result = mk3(1.0f);
   float current_t = 0.0f;
@@ -335,7 +337,7 @@ ETX_DEV f3 bvh_transmittance(const DScene& scene, Nodes nodes, Tris tris, int32_
       float dt = fmaxf(0.0f, seg_end - current_t);
       const DMedium& m = scene.mediums[medium];
       // heterogeneous media (ratio tracking, scene_medium.hxx:195-232) are rejected at upload for now
-      result *= medium_transmittance_homogeneous(m, dt);
+      result *= medium_transmittance_homogeneous(scene, m, wavelength, dt);
     }
     if (found == false)
       return result;

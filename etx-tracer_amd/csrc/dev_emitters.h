@@ -62,7 +62,7 @@ ETX_DEV float env_pdf_area(const DScene& s) {
 }
 
 // scene_emitters.hxx:40-105 emitter_get_radiance
-ETX_DEV f3 emitter_get_radiance(const DScene& s, const etx_abi_emitter& em_inst, const EmitterRadianceQuery& q, float& pdf_area, float& pdf_dir, float& pdf_dir_out) {
+ETX_DEV f3 emitter_get_radiance(const DScene& s, const etx_abi_emitter& em_inst, const EmitterRadianceQuery& q, float& pdf_area, float& pdf_dir, float& pdf_dir_out, float wavelength) {
   const etx_abi_emitter_profile& em = s.emitter_profiles[em_inst.profile];
   pdf_dir = 0.0f, pdf_area = 0.0f, pdf_dir_out = 0.0f;
   switch (em_inst.cls) {
@@ -74,15 +74,15 @@ ETX_DEV f3 emitter_get_radiance(const DScene& s, const etx_abi_emitter& em_inst,
       pdf_area = env_pdf_area(s);
       pdf_dir_out = pdf_dir * pdf_area;
       f2 uv = disk_uv(em_dir, q.direction, em.equivalent_disk_size, em.angular_size_cosine);
-      f3 direct_scale = mk3(1.0f) / (spectrum_rgb(s, em.emission.spectrum_index) * (kDoublePi * (1.0f - em.angular_size_cosine)));
-      return apply_image(s, em.emission, uv, nullptr) * direct_scale;
+      f3 direct_scale = mk3(1.0f) / (spectrum_eval(s, em.emission.spectrum_index, wavelength) * (kDoublePi * (1.0f - em.angular_size_cosine)));
+      return apply_image(s, em.emission, uv, nullptr, wavelength) * direct_scale;
     }
     case ETX_EMITTER_ENVIRONMENT: {
       const DImage& img = s.images[em.emission.image_index];
       f2 uv = direction_to_uv(q.direction, img.offset, img.scale.x);
       float sin_t = fmaxf(kEpsilon, sinf(uv.y * kPi));
       float image_pdf = 0.0f;
-      f3 eval = apply_image(s, em.emission, uv, &image_pdf);
+      f3 eval = apply_image(s, em.emission, uv, &image_pdf, wavelength);
       pdf_area = env_pdf_area(s);
       pdf_dir = image_pdf / (2.0f * kPi * kPi * sin_t);
       pdf_dir_out = pdf_area * pdf_dir;
@@ -106,13 +106,13 @@ ETX_DEV f3 emitter_get_radiance(const DScene& s, const etx_abi_emitter& em_inst,
           pdf_dir_out = pdf_area * cos_tx * kInvPi;
         }
       }
-      return apply_image(s, em.emission, q.uv, nullptr);
+      return apply_image(s, em.emission, q.uv, nullptr, wavelength);
     }
   }
 }
 
 // scene_emitters.hxx:139-203 emitter_sample_in + :216-224 sample_emitter
-ETX_DEV EmitterSample sample_emitter(const DScene& s, uint32_t emitter_index, const f2 smp, const f3& from_point) {
+ETX_DEV EmitterSample sample_emitter(const DScene& s, uint32_t emitter_index, const f2 smp, const f3& from_point, float wavelength) {
   const etx_abi_emitter& em_inst = s.emitters[emitter_index];
   const etx_abi_emitter_profile& em = s.emitter_profiles[em_inst.profile];
   EmitterSample r = emitter_sample_zero();
@@ -129,7 +129,7 @@ ETX_DEV EmitterSample sample_emitter(const DScene& s, uint32_t emitter_index, co
       q.direction = mk3(0.0f);
       q.uv = lerp_uv(s, tri, r.barycentric);
       q.directly_visible = false;
-      r.value = emitter_get_radiance(s, em_inst, q, r.pdf_area, r.pdf_dir, r.pdf_dir_out);
+      r.value = emitter_get_radiance(s, em_inst, q, r.pdf_area, r.pdf_dir, r.pdf_dir_out, wavelength);
       break;
     }
     case ETX_EMITTER_DIRECTIONAL: {
@@ -147,7 +147,7 @@ ETX_DEV EmitterSample sample_emitter(const DScene& s, uint32_t emitter_index, co
       r.pdf_dir_out = r.pdf_dir * r.pdf_area;
       r.origin = from_point + r.direction * distance_to_sphere(from_point, r.direction, s.bounds_center, s.bounds_radius);
       r.normal = em_dir * (-1.0f);
-      r.value = apply_image(s, em.emission, disk_sample * 0.5f + f2{0.5f, 0.5f}, nullptr);
+      r.value = apply_image(s, em.emission, disk_sample * 0.5f + f2{0.5f, 0.5f}, nullptr, wavelength);
       break;
     }
     default: {  // Environment
@@ -162,7 +162,7 @@ ETX_DEV EmitterSample sample_emitter(const DScene& s, uint32_t emitter_index, co
       r.pdf_dir = pdf_image / (2.0f * kPi * kPi * sin_t);
       r.pdf_area = env_pdf_area(s);
       r.pdf_dir_out = r.pdf_area * r.pdf_dir;
-      r.value = spectrum_rgb(s, em.emission.spectrum_index) * mk3(image_value);
+      r.value = spectrum_eval(s, em.emission.spectrum_index, wavelength) * mk3(image_value);
       break;
     }
   }
@@ -179,7 +179,7 @@ ETX_DEV uint32_t sample_emitter_index(const DScene& s, float rnd) {  // scene_em
 }
 
 // scene_emitters.hxx:226-306 sample_emission : start of a light sub path
-ETX_DEV EmitterSample sample_emission(const DScene& s, Sampler& smp) {
+ETX_DEV EmitterSample sample_emission(const DScene& s, Sampler& smp, float wavelength) {
   EmitterSample r = emitter_sample_zero();
   r.emitter_index = distribution_sample(s.emitter_dist, s.emitter_dist_count, smp.next());
   r.pdf_sample = s.emitter_dist[r.emitter_index].pdf;
@@ -201,7 +201,7 @@ ETX_DEV EmitterSample sample_emission(const DScene& s, Sampler& smp) {
       } else {
         r.pdf_area = 1.0f / em_inst.triangle_area;
         r.pdf_dir_out = r.pdf_dir * r.pdf_area;
-        r.value = apply_image(s, em.emission, vertex.tex, nullptr);
+        r.value = apply_image(s, em.emission, vertex.tex, nullptr, wavelength);
       }
       break;
     }
@@ -217,7 +217,7 @@ ETX_DEV EmitterSample sample_emission(const DScene& s, Sampler& smp) {
       r.normal = direction_to_scene;
       r.origin = s.bounds_center + s.bounds_radius * (pos_sample.x * basis.u + pos_sample.y * basis.v - direction_to_scene);
       r.origin += r.direction * distance_to_sphere(r.origin, r.direction, s.bounds_center, s.bounds_radius);
-      r.value = apply_image(s, em.emission, dir_sample * 0.5f + f2{0.5f, 0.5f}, nullptr);
+      r.value = apply_image(s, em.emission, dir_sample * 0.5f + f2{0.5f, 0.5f}, nullptr, wavelength);
       break;
     }
     default: {  // Environment
@@ -235,7 +235,7 @@ ETX_DEV EmitterSample sample_emission(const DScene& s, Sampler& smp) {
       r.normal = d;
       r.origin = s.bounds_center + s.bounds_radius * (disk_sample.x * basis.u + disk_sample.y * basis.v - d);
       r.origin += r.direction * distance_to_sphere(r.origin, r.direction, s.bounds_center, s.bounds_radius);
-      r.value = spectrum_rgb(s, em.emission.spectrum_index) * mk3(image_value);
+      r.value = spectrum_eval(s, em.emission.spectrum_index, wavelength) * mk3(image_value);
       r.pdf_area = env_pdf_area(s);
       r.pdf_dir = pdf_image / (2.0f * kPi * kPi * sin_t);
       r.pdf_dir_out = r.pdf_area * r.pdf_dir;
@@ -403,9 +403,10 @@ ETX_DEV uint32_t sample_spectrum_component(const f3& albedo, const f3& throughpu
 }
 
 // scene_medium.hxx:241-288 sample_medium, homogeneous branch (channel-selected exponential free flight)
-ETX_DEV MediumSample sample_medium_homogeneous(const DMedium& m, const f3& throughput, Sampler& smp, const f3& pos, const f3& w_i, float max_t) {
-  f3 scattering = m.scattering;
-  f3 extinction = m.scattering + m.absorption;
+ETX_DEV MediumSample sample_medium_homogeneous(const DScene& s, const DMedium& m, float wavelength, const f3& throughput, Sampler& smp, const f3& pos, const f3& w_i, float max_t) {
+  f3 absorption, scattering;
+  medium_coefficients(s, m, wavelength, absorption, scattering);
+  f3 extinction = scattering + absorption;
   f3 albedo = {extinction.x > 0.0f ? scattering.x / extinction.x : 0.0f, extinction.y > 0.0f ? scattering.y / extinction.y : 0.0f,
     extinction.z > 0.0f ? scattering.z / extinction.z : 0.0f};
   float t = 0.0f;

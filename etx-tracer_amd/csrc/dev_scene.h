@@ -64,10 +64,12 @@ struct DMedium {
   const float* density;
   f3 bounds_min, bounds_max;
   f3 absorption, scattering;  // RGB-resolved (RGB mode)
+  uint32_t absorption_index, scattering_index;  // spectra (spectral mode), kInvalid = zero
   uint32_t cls, explicit_connections;
   float g, max_sigma;
   uint32_t dim_x, dim_y, dim_z, pad;
 };
+
 
 struct DCamera {
   float view_proj[16];
@@ -87,6 +89,10 @@ struct DScene {
   const etx_abi_emitter* emitters;
   const etx_abi_distribution_entry* emitter_dist;
   const float4* spectrum_rgb;  // RGB mode: SpectralDistribution::integrated_value per spectrum index
+  // spectral mode (scene.spectral()): every spectrum as (wavelength, power) pairs, the CIE observer for the film
+  const float2* spectrum_entries;
+  const uint2* spectrum_ranges;  // per spectrum: first entry, entry count
+  const float4* cie_xyz;         // spectrum::spectral_xyz(i), i = wavelength - cie_first (etx_hip_upload_cie_table)
   const DImage* images;
   const DMedium* mediums;
   const BvhNode* bvh_nodes;
@@ -109,6 +115,9 @@ struct DScene {
   float pixel_sampler_radius;
   uint32_t subsurface_exit_material;
   uint32_t default_dielectric_eta, default_conductor_eta, default_conductor_k;  // spectrum indices (PrincipledBSDF)
+  uint32_t spectral;    // Scene::spectral(): one wavelength per path, SpectralResponse = one float (kept replicated in xyz here)
+  uint32_t cie_count;
+  float cie_first, cie_y_scale;  // spectrum::kShortestWavelength, 1 / kYIntegral
   DCamera camera;
 };
 
@@ -120,6 +129,78 @@ ETX_DEV f3 ld3(const etx_abi_float3& v) {
 ETX_DEV f3 spectrum_rgb(const DScene& s, uint32_t index) {
   float4 v = s.spectrum_rgb[index];
   return {v.x, v.y, v.z};
+}
+
+// scene.spectrums[index](spect), spectrum.hxx:462-504. RGB mode: the integrated value. Spectral mode: the power at the
+// path's wavelength (binary search + lerp), replicated into the three components - every SpectralResponse operation of
+// the hot path (products, luminance = monochromatic(), maxima, the per-channel medium sampling) then yields the
+// scalar result of the reference's spectral branch, and RGB and spectral paths share one instruction stream.
+ETX_DEV f3 spectrum_eval(const DScene& s, uint32_t index, float wavelength) {
+  if (s.spectral == 0u)
+    return spectrum_rgb(s, index);
+  const uint2 range = s.spectrum_ranges[index];
+  const uint32_t count = range.y;
+  if (count == 0u)
+    return f3{0.0f, 0.0f, 0.0f};
+  const float2* entries = s.spectrum_entries + range.x;
+  uint32_t b = 0, e = count;
+  do {
+    uint32_t m = b + (e - b) / 2;
+    if (entries[m].x > wavelength)
+      e = m;
+    else
+      b = m;
+  } while ((e - b) > 1);
+  const uint32_t i = b;
+  const float2 ei = entries[i];
+  if ((i == 0u) && (wavelength < ei.x))
+    return f3{0.0f, 0.0f, 0.0f};
+  if ((i + 1u == count) && (wavelength > ei.x))
+    return f3{0.0f, 0.0f, 0.0f};
+  const uint32_t j = min(i + 1u, count - 1u);
+  const float2 ej = entries[j];
+  const float t = (i == j) ? 0.0f : (wavelength - ei.x) / (ej.x - ei.x);
+  const float power = ei.y + (ej.y - ei.y) * t;
+  return f3{power, power, power};
+}
+
+// What a scalar contribution at `wavelength` adds to the RGB film: (value / sampling_pdf).to_rgb(), spectrum.hxx:221-223,
+// 268-289 (CIE observer, xyz -> rgb). RGB mode: 1.
+ETX_DEV f3 spectral_film_weight(const DScene& s, float wavelength) {
+  if (s.spectral == 0u)
+    return f3{1.0f, 1.0f, 1.0f};
+  const float last = s.cie_first + float(s.cie_count - 1u);
+  if ((wavelength < s.cie_first) || (wavelength > last))
+    return f3{0.0f, 0.0f, 0.0f};
+  const float w = floorf(wavelength);
+  const float dw = wavelength - w;
+  const uint32_t i = uint32_t(w - s.cie_first);
+  const uint32_t j = min(i + 1u, s.cie_count - 1u);
+  const float4 a = s.cie_xyz[i], b = s.cie_xyz[j];
+  const f3 xyz = f3{a.x + (b.x - a.x) * dw, a.y + (b.y - a.y) * dw, a.z + (b.z - a.z) * dw} * s.cie_y_scale;
+  const f3 rgb = {3.24045420f * xyz.x - 1.5371385f * xyz.y - 0.4985314f * xyz.z, -0.9692660f * xyz.x + 1.8760108f * xyz.y + 0.0415560f * xyz.z,
+    0.05564340f * xyz.x - 0.2040259f * xyz.y + 1.0572252f * xyz.z};
+  const float c = coshf(0.0072f * (wavelength - 538.0f));
+  const float sampling_pdf = 0.0039398042f / (c * c);
+  return rgb / sampling_pdf;
+}
+
+// absorption / scattering coefficients of a medium at the path's wavelength (RGB mode: the resolved RGB values)
+ETX_DEV void medium_coefficients(const DScene& s, const DMedium& m, float wavelength, f3& absorption, f3& scattering) {
+  if (s.spectral == 0u) {
+    absorption = m.absorption;
+    scattering = m.scattering;
+    return;
+  }
+  absorption = (m.absorption_index == kInvalid) ? f3{0.0f, 0.0f, 0.0f} : spectrum_eval(s, m.absorption_index, wavelength);
+  scattering = (m.scattering_index == kInvalid) ? f3{0.0f, 0.0f, 0.0f} : spectrum_eval(s, m.scattering_index, wavelength);
+}
+
+// SpectralQuery::spectral_sample, spectrum.hxx:234-239
+ETX_DEV float spectral_sample_wavelength(float rnd) {
+  const float offset = 0x1.35ce7a0000000p-5f;
+  const float scale = 1.0f - offset;
+  return 538.0f - 138.888889f * atanhf(0.85691062f - 1.82750197f * (rnd * scale + offset));
 }
 
 struct Vtx {
@@ -270,10 +351,10 @@ ETX_DEV f2 image_sample(const DImage& img, const f2 rnd, float& image_pdf, float
 }
 
 // scene.hxx:250-320 : texture helpers (RGB mode: SpectralResponse = float3 `integrated`)
-ETX_DEV f3 apply_image(const DScene& s, const etx_abi_spectral_image& img, const f2 uv, float* image_pdf) {  // scene.hxx:295-309
+ETX_DEV f3 apply_image(const DScene& s, const etx_abi_spectral_image& img, const f2 uv, float* image_pdf, float wavelength) {  // scene.hxx:295-309
   if (image_pdf)
     *image_pdf = 0.0f;
-  f3 result = spectrum_rgb(s, img.spectrum_index);
+  f3 result = spectrum_eval(s, img.spectrum_index, wavelength);
   if (img.image_index == kInvalid)
     return result;
   float4 e = image_evaluate(s.images[img.image_index], uv, image_pdf);

@@ -22,6 +22,7 @@ struct PathState {  // VCMPathState (vcm_shared.hxx:91-150) minus the per-pixel 
   uint32_t medium;  // medium_index
   uint32_t flags;
   uint32_t id;      // global_index
+  float wavelength; // spect.wavelength (spectral mode)
 };
 
 ETX_DEV PathState load_path(const PathSet& set, uint32_t i) {
@@ -35,6 +36,7 @@ ETX_DEV PathState load_path(const PathSet& set, uint32_t i) {
   s.sampler.seed = m.x, s.sampler.fixed_u = s.sampler.fixed_v = s.sampler.fixed_w = 0.0f;
   s.depth = m.y, s.medium = m.z, s.flags = m.w;
   s.id = set.path_id[i];
+  s.wavelength = set.wavelength[i];
   return s;
 }
 
@@ -45,6 +47,7 @@ ETX_DEV void store_path(const PathSet& set, uint32_t i, const PathState& s) {
   set.mis[i] = make_float4(s.d_vcm, s.d_vc, s.d_vm, s.path_distance);
   set.meta[i] = make_uint4(s.sampler.seed, s.depth, s.medium, s.flags);
   set.path_id[i] = s.id;
+  set.wavelength[i] = s.wavelength;
 }
 
 // Dense slot for every lane with `alive` set; one atomic per wavefront (ballot + popcount prefix).
@@ -162,9 +165,9 @@ struct TraceCtx {  // what an inline traversal needs
   uint32_t alpha_seed;
 };
 
-ETX_DEV f3 trace_transmittance(TraceCtx& tc, const f3& p0, const f3& p1, uint32_t medium) {
+ETX_DEV f3 trace_transmittance(TraceCtx& tc, const f3& p0, const f3& p1, uint32_t medium, float wavelength) {
   const DScene& s = *tc.scene;
-  return bvh_transmittance(s, s.bvh_nodes, s.bvh_tris, s.bvh_root, tc.stack, p0, p1, medium, tc.alpha_seed);
+  return bvh_transmittance(s, s.bvh_nodes, s.bvh_tris, s.bvh_root, tc.stack, p0, p1, medium, wavelength, tc.alpha_seed);
 }
 
 // A connection whose visibility is still unknown: the shade / connect kernels evaluate everything but the
@@ -181,8 +184,9 @@ ETX_DEV void bluenoise_samples(const uint2* table, uint32_t px, uint32_t py, uin
 }
 
 struct ShadowRequest {
-  f3 p0, p1, value;
+  f3 p0, p1, value;  // value: contribution as the film sees it (x spectral_film_weight in spectral mode)
   uint32_t medium, target;
+  float wavelength;  // for the media along the segment
 };
 
 ETX_DEV void write_shadow(const Pipeline& p, uint32_t idx, const ShadowRequest& r) {
@@ -192,7 +196,7 @@ ETX_DEV void write_shadow(const Pipeline& p, uint32_t idx, const ShadowRequest& 
   }
   p.shadow.p0_medium[idx] = mk4(r.p0, __uint_as_float(r.medium));
   p.shadow.p1_target[idx] = mk4(r.p1, __uint_as_float(r.target));
-  p.shadow.value[idx] = mk4(r.value, 0.0f);
+  p.shadow.value[idx] = mk4(r.value, r.wavelength);
 }
 
 // vcm_shared.hxx:218-283 vcm_next_ray
@@ -269,7 +273,7 @@ ETX_DEV bool vcm_connect_to_camera(const DScene& scene, const VcmParams& it, boo
   f3 origin = sample_pos;
   if (camera_at_medium == false) {
     const etx_abi_material& mat = scene.materials[isect->material];
-    BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathLight);
+    BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathLight, st.wavelength);
     BsdfEval eval = bsdf_evaluate_s<kSimple>(scene, data, w_o, mat, st.sampler);
     if (eval.valid() == false)
       return false;
@@ -298,7 +302,8 @@ ETX_DEV bool vcm_connect_to_camera(const DScene& scene, const VcmParams& it, boo
   uint32_t y = static_cast<uint32_t>((cs.uv.y * 0.5f + 0.5f) * float(it.film_h));
   if ((x >= it.film_w) || (y >= it.film_h))
     return false;
-  out = {origin, clip_pos, scatter * st.throughput * (cs.weight * weight), st.medium, kShadowTargetLight | (x + (it.film_h - 1u - y) * it.film_w)};
+  out = {origin, clip_pos, scatter * st.throughput * (cs.weight * weight) * spectral_film_weight(scene, st.wavelength), st.medium,
+    kShadowTargetLight | (x + (it.film_h - 1u - y) * it.film_w), st.wavelength};
   return true;
 }
 
@@ -311,7 +316,7 @@ ETX_DEV f3 vcm_get_radiance(const DScene& scene, const etx_abi_emitter& emitter,
   q.direction = st.ray_d;
   q.uv = isect.tex;
   q.directly_visible = st.depth == 1;
-  f3 radiance = emitter_get_radiance(scene, emitter, q, pdf_area, pdf_dir, pdf_dir_out);
+  f3 radiance = emitter_get_radiance(scene, emitter, q, pdf_area, pdf_dir, pdf_dir_out, st.wavelength);
   if (pdf_dir <= kEpsilon)
     return mk3(0.0f);
   float pdf_sample = emitter_discrete_pdf(scene, emitter);
@@ -338,7 +343,7 @@ ETX_DEV f3 vcm_cam_handle_miss(const DScene& scene, const VcmParams& it, PathSta
     q.uv = {0.0f, 0.0f};
     q.directly_visible = st.depth <= 1;
     float pdf_area = 0.0f, pdf_dir = 0.0f, pdf_dir_out = 0.0f;
-    f3 value = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out);
+    f3 value = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out, st.wavelength);
     if (pdf_dir > kEpsilon) {
       float pdf_discrete = emitter_discrete_pdf(scene, em);
       sum_pdf_dir_out += pdf_dir_out * pdf_discrete;
@@ -366,7 +371,7 @@ ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool
     return false;
   f3 sample_pos = camera_at_medium ? medium_pos : isect->pos;
   uint32_t emitter_index = sample_emitter_index(scene, st.sampler.fixed_w);
-  EmitterSample es = sample_emitter(scene, emitter_index, f2{st.sampler.fixed_u, st.sampler.fixed_v}, sample_pos);
+  EmitterSample es = sample_emitter(scene, emitter_index, f2{st.sampler.fixed_u, st.sampler.fixed_v}, sample_pos, st.wavelength);
   if (es.pdf_dir <= 0.0f)
     return false;
   f3 w_o = es.direction;
@@ -384,7 +389,7 @@ ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool
     reverse_pdf = phase_function(w_o, st.ray_d, medium.g);
   } else {
     const etx_abi_material& mat = scene.materials[isect->material];
-    BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathCamera);
+    BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathCamera, st.wavelength);
     BsdfEval eval = bsdf_evaluate_s<kSimple>(scene, data, w_o, mat, st.sampler);
     if (eval.valid() == false)
       return false;
@@ -404,7 +409,8 @@ ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool
   float vmW_nee = camera_at_medium ? 0.0f : it.vm_weight;
   float w_camera = (es.pdf_dir_out * camera_factor) / (es.pdf_dir * l_dot_e) * (vmW_nee + st.d_vcm + st.d_vc * reverse_pdf);
   float weight = opt_enable_mis(it) ? 1.0f / (1.0f + w_light + w_camera) : 1.0f;
-  out = {origin, es.origin, st.throughput * scatter * es.value * (weight / (es.pdf_dir * es.pdf_sample)), st.medium, film_target};
+  out = {origin, es.origin, st.throughput * scatter * es.value * (weight / (es.pdf_dir * es.pdf_sample)) * spectral_film_weight(scene, st.wavelength), st.medium, film_target,
+    st.wavelength};
   return true;
 }
 
@@ -475,7 +481,7 @@ ETX_DEV bool vcm_connect_to_light_vertex(const DScene& scene, const PathState& s
     camera_scatter = mk3(p);
   } else {
     const etx_abi_material& mat = scene.materials[cam->material];
-    BsdfData camera_data = make_bsdf_data(*cam, cam->w_i, st.medium, kPathCamera);
+    BsdfData camera_data = make_bsdf_data(*cam, cam->w_i, st.medium, kPathCamera, st.wavelength);
     BsdfEval camera_bsdf = bsdf_evaluate_t<kDiffuseOnly>(scene, camera_data, w_o, mat, smp);
     if (camera_bsdf.valid() == false)
       return false;
@@ -497,7 +503,7 @@ ETX_DEV bool vcm_connect_to_light_vertex(const DScene& scene, const PathState& s
   } else {
     const etx_abi_triangle& light_tri = scene.triangles[lv.tri];
     const etx_abi_material& light_mat = scene.materials[light_tri.material_index];
-    BsdfData light_data = make_bsdf_data(light_v, lv.w_i, camera_at_medium ? lv.medium : st.medium, kPathLight);
+    BsdfData light_data = make_bsdf_data(light_v, lv.w_i, camera_at_medium ? lv.medium : st.medium, kPathLight, st.wavelength);
     BsdfEval light_bsdf = bsdf_evaluate_t<kDiffuseOnly>(scene, light_data, -w_o, light_mat, smp);
     if (light_bsdf.valid() == false)
       return false;
@@ -549,6 +555,7 @@ ETX_DEV CameraVertex load_camera_vertex(const Pipeline& p, const DScene& scene, 
   cv.st.d_vcm = m.x, cv.st.d_vc = m.y, cv.st.d_vm = m.z;
   cv.st.id = __float_as_uint(m.w);
   cv.st.sampler.seed = p.cv.seed[i];
+  cv.st.wavelength = p.cv.wavelength[i];
   cv.st.sampler.fixed_u = cv.st.sampler.fixed_v = cv.st.sampler.fixed_w = 0.0f;
   cv.st.eta = 1.0f, cv.st.path_distance = 0.0f, cv.st.flags = 0u;
   cv.st.ray_o = mk3(0.0f), cv.st.ray_tmin = 0.0f, cv.st.ray_tmax = 0.0f;

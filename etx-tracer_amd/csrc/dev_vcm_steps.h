@@ -22,6 +22,7 @@ ETX_DEV void store_light_vertex(const Pipeline& p, uint32_t idx, const PathState
   const uint32_t index_in_path = (prev == kInvalid) ? 0u : ((__float_as_uint(p.lv.bc_len_med(prev).z) >> 16u) + 1u);
   p.lv.bc_len_med(idx) = make_float4(bc_u, bc_v, __uint_as_float((index_in_path << 16u) | (st.depth & 0xffffu)), __uint_as_float(st.medium));
   p.lv.next(idx) = prev;
+  p.lv.wavelength(idx) = st.wavelength;
   if (index_in_path < kPathTableEntries)
     reinterpret_cast<uint32_t*>(p.light_path_table)[st.id * kPathTableEntries + index_in_path] = idx;
   p.light_path_head[st.id] = idx;  // the photon bounding box is reduced by k_grid_bbox (kernels_grid.hip)
@@ -38,6 +39,7 @@ ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& 
   p.cv.thr_depth[idx] = mk4(st.throughput, __uint_as_float(st.depth));
   p.cv.mis_pixel[idx] = make_float4(st.d_vcm, st.d_vc, st.d_vm, __uint_as_float(st.id));
   p.cv.seed[idx] = seed;
+  p.cv.wavelength[idx] = st.wavelength;
   if (isect == nullptr) {
     p.cv.pos_info[idx] = make_float4(hit_or_pos.x, hit_or_pos.y, hit_or_pos.z, __uint_as_float((st.depth << 8u) | kCvMedium));
     return;
@@ -46,7 +48,7 @@ ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& 
   const bool diffuse = material_is_lambert(mat);
   f3 fthr = st.throughput;
   if (diffuse)
-    fthr = fthr * apply_image(scene, mat.scattering, isect->tex, nullptr) * kInvPi;  // DiffuseBSDF func (bsdf_various.hxx:60-64) x t_camera
+    fthr = fthr * apply_image(scene, mat.scattering, isect->tex, nullptr, st.wavelength) * kInvPi;  // DiffuseBSDF func (bsdf_various.hxx:60-64) x t_camera
   p.cv.pos_info[idx] = mk4(isect->pos, __uint_as_float((st.depth << 8u) | (diffuse ? kCvDiffuse : 0u)));
   p.cv.nrm_dvm[idx] = mk4(isect->nrm, st.d_vm);
   p.cv.fthr_dvcm[idx] = mk4(fthr, st.d_vcm);
@@ -79,7 +81,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
       isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
     // vcm_try_sampling_medium, vcm_shared.hxx:379-388
     if (st.medium != kInvalid) {
-      ms = sample_medium_homogeneous(scene.mediums[st.medium], st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+      ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
       st.throughput *= ms.weight;
     }
     // ---- phase A
@@ -106,7 +108,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
       connect = opt_connect_to_camera(it) && scene.mediums[st.medium].explicit_connections && (st.depth + 1 <= scene.max_path_length);
     } else {
       const etx_abi_material& mat = scene.materials[isect.material];
-      bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight);
+      bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight, st.wavelength);
       st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
       bs = bsdf_sample_s<kSimple>(scene, bsdf_data, mat, st.sampler);
       st.sampler.pop_fixed();
@@ -183,7 +185,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
     if (found)
       isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
     if (st.medium != kInvalid) {
-      ms = sample_medium_homogeneous(scene.mediums[st.medium], st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+      ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
       st.throughput *= ms.weight;
     }
     // ---- phase A
@@ -194,7 +196,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
     if (event == kEventNone) {  // vcm_shared.hxx:997-1000
       f3 gathered = vcm_cam_handle_miss(scene, it, st);
       if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
-        atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered);
+        atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered * spectral_film_weight(scene, st.wavelength));
     }
   }
   const bool scatter_event = (event == kEventMedium) || (event == kEventSurface);
@@ -228,7 +230,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       store = explicit_connections && opt_connect_vertices(it);
     } else {
       const etx_abi_material& mat = scene.materials[isect.material];
-      bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera);
+      bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera, st.wavelength);
       st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
       bs = bsdf_sample_s<kSimple>(scene, bsdf_data, mat, st.sampler);
       st.sampler.pop_fixed();
@@ -245,7 +247,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       if (opt_direct_hit(it) && (isect.emitter != kInvalid) && (st.depth <= scene.max_path_length) && (st.depth >= scene.min_path_length)) {
         f3 gathered = vcm_get_radiance(scene, scene.emitters[isect.emitter], st, it, isect);
         if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
-          atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered);
+          atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered * spectral_film_weight(scene, st.wavelength));
       }
       nee = is_connectible;
       store = is_connectible && (opt_connect_vertices(it) || (opt_merge_vertices(it) && (st.depth + 1 <= scene.max_path_length)));

@@ -81,6 +81,9 @@ struct etx_hip_context {
   uint32_t* host_counters = nullptr;  // pinned
   uint8_t* bluenoise[kBlueNoiseSets] = {};  // device tables by sample-count class (etx_hip_upload_bluenoise)
   const uint8_t* active_bluenoise = nullptr;
+  float4* cie_table = nullptr;      // spectrum::spectral_xyz (etx_hip_upload_cie_table), spectral scenes only
+  uint32_t cie_count = 0;
+  float cie_first = 0.0f, cie_y_scale = 0.0f;
   etx_hip_stats_t stats = {};
   float4* resolve_buffer = nullptr;
   void* comm = nullptr;  // ncclComm_t (host_comm.cpp)
@@ -166,7 +169,7 @@ int allocate_pipeline(etx_hip_context* ctx) {
   int rc = 0;
   for (int s = 0; s < 2; ++s) {
     if ((rc = device_alloc(ctx, p.paths[s].ray_o_tmin, n)) || (rc = device_alloc(ctx, p.paths[s].ray_d_tmax, n)) || (rc = device_alloc(ctx, p.paths[s].thr_eta, n)) ||
-        (rc = device_alloc(ctx, p.paths[s].mis, n)) || (rc = device_alloc(ctx, p.paths[s].meta, n)) || (rc = device_alloc(ctx, p.paths[s].path_id, n)))
+        (rc = device_alloc(ctx, p.paths[s].mis, n)) || (rc = device_alloc(ctx, p.paths[s].meta, n)) || (rc = device_alloc(ctx, p.paths[s].path_id, n)) || (rc = device_alloc(ctx, p.paths[s].wavelength, n)))
       return rc;
   }
   if ((rc = device_alloc(ctx, p.hits, n)))
@@ -181,6 +184,8 @@ int allocate_pipeline(etx_hip_context* ctx) {
     lv_cap64 = 1ull << 30;
   p.lv.capacity = uint32_t(lv_cap64);
   if ((rc = device_alloc(ctx, p.lv.rec, size_t(p.lv.capacity) * LightVertexPool::kLvStride)))
+    return rc;
+  if ((rc = device_alloc(ctx, p.path_wavelength, n)) || (rc = device_alloc(ctx, p.cv.wavelength, n)))
     return rc;
   if ((rc = device_alloc(ctx, p.light_path_head, n)) || (rc = device_alloc(ctx, p.light_path_table, size_t(n) * (kPathTableEntries / 4u))))
     return rc;
@@ -718,6 +723,8 @@ void etx_hip_destroy(etx_hip_context* context) {
   for (uint8_t* table : context->bluenoise)
     if (table)
       (void)hipFree(table);
+  if (context->cie_table)
+    (void)hipFree(context->cie_table);
   delete context;
 }
 
@@ -781,6 +788,33 @@ int select_bluenoise(etx_hip_context* context, const char* option_name) {
 }
 }  // namespace
 
+int etx_hip_upload_cie_table(etx_hip_context* context, const float* xyz, uint32_t count, float first_wavelength) {
+  if ((context == nullptr) || (xyz == nullptr) || (count < 2u) || (count > 4096u))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  (void)wait_idle(context);
+  HIP_OK(context, hipSetDevice(context->device));
+  std::vector<float4> table(count);
+  double y_integral = 0.0;
+  for (uint32_t i = 0; i < count; ++i) {
+    table[i] = make_float4(xyz[3 * i + 0], xyz[3 * i + 1], xyz[3 * i + 2], 0.0f);
+    y_integral += double(xyz[3 * i + 1]);
+  }
+  // kYIntegral() accumulates in float (spectrum.hxx:188-194)
+  float y_sum = 0.0f;
+  for (uint32_t i = 0; i < count; ++i)
+    y_sum += xyz[3 * i + 1];
+  if (context->cie_table)
+    (void)hipFree(context->cie_table);
+  context->cie_table = nullptr;
+  HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&context->cie_table), count * sizeof(float4)));
+  HIP_OK(context, hipMemcpy(context->cie_table, table.data(), count * sizeof(float4), hipMemcpyHostToDevice));
+  context->cie_count = count;
+  context->cie_first = first_wavelength;
+  context->cie_y_scale = (y_sum > 0.0f) ? 1.0f / y_sum : 0.0f;
+  (void)y_integral;
+  return ETX_HIP_OK;
+}
+
 int etx_hip_begin(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
@@ -824,6 +858,23 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
   } else {
     context->error = "integrator " + std::to_string(integrator) + " is not implemented by the device path";
     return ETX_HIP_ERROR_UNSUPPORTED;
+  }
+  if (context->scene.host_copy.spectral) {
+    if (context->cie_table == nullptr) {
+      context->error = "spectral scene: the CIE observer table has not been uploaded (etx_hip_upload_cie_table)";
+      return ETX_HIP_ERROR_UNSUPPORTED;
+    }
+    auto patch = [&](etx_hip_context* lane) {
+      for (DScene* d : {&lane->scene.host_copy, &lane->pipe.scene}) {
+        d->cie_xyz = context->cie_table;
+        d->cie_count = context->cie_count;
+        d->cie_first = context->cie_first;
+        d->cie_y_scale = context->cie_y_scale;
+      }
+    };
+    patch(context);
+    for (etx_hip_context* helper : context->helpers)
+      patch(helper);
   }
   HIP_OK(context, hipSetDevice(context->device));
   context->integrator = integrator;

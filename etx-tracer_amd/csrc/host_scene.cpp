@@ -348,10 +348,7 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     error = "scene is not committed (Integrator::can_run, integrator.hxx:85-87)";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
-  if (scene->flags & ETX_SCENE_SPECTRAL) {
-    error = "spectral scenes are not implemented by the device path yet (RGB mode only)";
-    return ETX_HIP_ERROR_UNSUPPORTED;
-  }
+  const bool spectral = (scene->flags & ETX_SCENE_SPECTRAL) != 0;
   if ((camera->film_size.x == 0) || (camera->film_size.y == 0)) {
     error = "camera film size is zero";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
@@ -382,6 +379,10 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     }
     if ((m.cls == ETX_MAT_DIFFUSE) && (m.diffuse_variation > 2u)) {
       error = "diffuse_variation " + std::to_string(m.diffuse_variation) + " is unknown (0 Lambert, 1 microfacet, 2 vMF: bsdf_various.hxx:47-69)";
+      return ETX_HIP_ERROR_UNSUPPORTED;
+    }
+    if (spectral && ((m.scattering.image_index != ETX_ABI_INVALID) || (m.reflectance.image_index != ETX_ABI_INVALID) || (m.emission.image_index != ETX_ABI_INVALID))) {
+      error = "spectral mode with RGB textures (apply_rgb upsampling, scene.hxx:250-270) is not implemented by the device path";
       return ETX_HIP_ERROR_UNSUPPORTED;
     }
     if (m.subsurface.cls != 0) {
@@ -440,6 +441,20 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     rgb[i] = make_float4(spectrums[i].integrated.x, spectrums[i].integrated.y, spectrums[i].integrated.z, 0.0f);
   if ((rc = upload(out, rgb.data(), rgb.size(), d.spectrum_rgb, error)))
     return rc;
+  // spectral mode: the (wavelength, power) tables of every spectrum, flattened (SpectralDistribution::spectral_entries)
+  d.spectral = spectral ? 1u : 0u;
+  if (spectral) {
+    std::vector<float2> entries;
+    std::vector<uint2> ranges(scene->spectrums.count);
+    for (uint64_t i = 0; i < scene->spectrums.count; ++i) {
+      const uint32_t count = std::min<uint32_t>(spectrums[i].entry_count, ETX_ABI_SPECTRUM_MAX_ENTRIES);
+      ranges[i] = make_uint2(uint32_t(entries.size()), count);
+      for (uint32_t k = 0; k < count; ++k)
+        entries.push_back(make_float2(spectrums[i].entries[k].wavelength, spectrums[i].entries[k].power));
+    }
+    if ((rc = upload(out, entries.data(), entries.size(), d.spectrum_entries, error)) || (rc = upload(out, ranges.data(), ranges.size(), d.spectrum_ranges, error)))
+      return rc;
+  }
 
   std::vector<DImage> dimages(scene->images.count);
   for (uint64_t i = 0; i < scene->images.count; ++i) {
@@ -494,6 +509,8 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     };
     dm.absorption = resolve(m.absorption_index);
     dm.scattering = resolve(m.scattering_index);
+    dm.absorption_index = (m.absorption_index < scene->spectrums.count) ? m.absorption_index : kInvalid;
+    dm.scattering_index = (m.scattering_index < scene->spectrums.count) ? m.scattering_index : kInvalid;
     dm.cls = m.cls;
     dm.explicit_connections = m.enable_explicit_connections;
     dm.g = m.phase_function_g;

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlockSize) void k_connect_pairs(Pipeline p, VcmPar
             f3 p0 = cv.medium_pos;
             if (cv.at_medium == false)
               p0 = shading_pos(scene, scene.triangles[cv.isect.tri], cv.isect.bc, normalize(target_position - cv.isect.pos));
-            request = {p0, cv.at_medium ? lv.pos : target_position, value, cv.st.medium, film_index(it, cv.st.id)};
+            request = {p0, cv.at_medium ? lv.pos : target_position, value * spectral_film_weight(scene, cv.st.wavelength), cv.st.medium, film_index(it, cv.st.id), cv.st.wavelength};
             queue = true;
           }
         }
@@ -328,6 +328,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
     const uint32_t item = base_ + lane_;
     const uint32_t c = item & 7u;
     uint32_t range_begin = 0, range_len = 0, pixel = 0;
+    float wavelength = 0.0f;
     if (item < seg_end_) {
       const uint32_t vertex = p.merge_order[item >> 3u];
       const float4 pi = p.cv.pos_info[vertex];
@@ -343,10 +344,12 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
         slots[lane_].pos_depth = make_float4(pi.x, pi.y, pi.z, __uint_as_float(depth));
         slots[lane_].nrm_dvm = nv;
         slots[lane_].wi_wcam = make_float4(wv.x, wv.y, wv.z, fv.w * it.vc_weight);
-        slots[lane_].fthr = fv;
+        // spectral mode: c_value = (func x throughput / sampling_pdf).to_rgb() (vcm_shared.hxx:869), channel-wise product with the photon's RGB
+        const f3 cw = f3{fv.x, fv.y, fv.z} * spectral_film_weight(scene, p.cv.wavelength[vertex]);
+        slots[lane_].fthr = make_float4(cw.x, cw.y, cw.z, fv.w);
       }
       if (c == 0u)
-        pixel = __float_as_uint(p.cv.mis_pixel[vertex].w);
+        pixel = __float_as_uint(p.cv.mis_pixel[vertex].w), wavelength = p.cv.wavelength[vertex];
     }
     if (lane_ < 32u)
       (&s_acc[wave][0][0])[lane_] = 0.0f;
@@ -471,6 +474,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
     const uint32_t c = item & 7u;
     f3 merged = mk3(0.0f);
     uint32_t pixel = 0;
+    float wavelength = 0.0f;
     if (item < seg_end_) {
       const uint32_t vertex = p.merge_order[item >> 3u];
       const uint32_t info = __float_as_uint(p.cv.pos_info[vertex].w);
@@ -479,10 +483,11 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
         const Isect& isect = cv.isect;
         uint32_t range_begin = 0, range_end = 0;
         if ((cv.st.depth + 1u <= scene.max_path_length) && merge_cell_range(p, g, isect.pos, c, range_begin, range_end)) {
-          pixel = cv.st.id;
+          pixel = cv.st.id, wavelength = cv.st.wavelength;
           const etx_abi_material& mat = scene.materials[isect.material];
-          const BsdfData camera_data = make_bsdf_data(isect, isect.w_i, cv.st.medium, kPathCamera);
+          const BsdfData camera_data = make_bsdf_data(isect, isect.w_i, cv.st.medium, kPathCamera, cv.st.wavelength);
           const float w_camera_base = cv.st.d_vcm * it.vc_weight;
+          const f3 camera_film_weight = spectral_film_weight(scene, cv.st.wavelength);
           cv.st.sampler.seed = Sampler::random_seed(cv.st.sampler.seed, c);
           for (uint32_t j = range_begin; j < range_end; ++j) {
             examined++;
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
             const float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;
             const float kernel_weight = use_epan ? fmaxf(2.0f * (1.0f - distance_squared * g.inv_radius_squared), 0.0f) : 1.0f;
             const float4 lt = p.grid.thr(j);
-            merged += (camera_bsdf.func * cv.st.throughput * f3{lt.x, lt.y, lt.z}) * (kernel_weight * weight);
+            merged += (camera_bsdf.func * cv.st.throughput * camera_film_weight * f3{lt.x, lt.y, lt.z}) * (kernel_weight * weight);
             merged_count++;
           }
         }
@@ -517,6 +522,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
       merged.y += __shfl_xor(merged.y, d);
       merged.z += __shfl_xor(merged.z, d);
       pixel = max(pixel, uint32_t(__shfl_xor(int(pixel), d)));
+      wavelength = fmaxf(wavelength, __shfl_xor(wavelength, d));
     }
     if (((lane_ & 7u) == 0u) && ((merged.x != 0.0f) || (merged.y != 0.0f) || (merged.z != 0.0f)))
       atomic_add_f3(p.camera_sum + film_index(it, pixel), merged * it.vm_normalization);

@@ -203,7 +203,12 @@ __global__ __launch_bounds__(kBlockSize) void k_grid_scatter(Pipeline p) {
     p.grid.pos_len[dst] = make_float4(pd.x, pd.y, pd.z, __uint_as_float(__float_as_uint(bl.z) & 0xffffu));
     p.grid.nrm_dvcm(dst) = make_float4(nt.x, nt.y, nt.z, pd.w);
     p.grid.win_dvm(dst) = make_float4(wd.x, wd.y, wd.z, td.w);
-    p.grid.thr(dst) = make_float4(td.x, td.y, td.z, 0.0f);  // throughput / sampling_pdf (= 1 in RGB mode)
+    // vcm_shared.cxx:140 + vcm_shared.hxx:873-877: (throughput / sampling_pdf).to_rgb(), in spectral mode scaled by
+    // SpectralDistribution::kRGBLuminanceScale; the merge multiplies it channel-wise with the camera side's RGB
+    f3 thr = {td.x, td.y, td.z};
+    if (p.scene.spectral)
+      thr = thr * spectral_film_weight(p.scene, p.lv.wavelength(i)) * f3{0.817660332f, 1.05418909f, 1.09945524f};
+    p.grid.thr(dst) = make_float4(thr.x, thr.y, thr.z, 0.0f);
   }
 }
 

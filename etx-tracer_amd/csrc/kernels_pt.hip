@@ -24,7 +24,7 @@ static uint32_t grid_for(uint32_t capacity) {
 enum : uint32_t { kPtMisWeight = 1u << 8 };
 
 // bsdf::albedo, scene_bsdf.hxx:95-107 + bsdf_various.hxx:28,127,214,259,291 + bsdf_conductor.hxx:133
-ETX_DEV f3 bsdf_albedo(const DScene& scene, const etx_abi_material& mat, const f2 tex) {
+ETX_DEV f3 bsdf_albedo(const DScene& scene, const etx_abi_material& mat, const f2 tex, float wavelength) {
   switch (mat.cls) {
     case ETX_MAT_DIFFUSE:
     case ETX_MAT_TRANSLUCENT:
@@ -33,9 +33,9 @@ ETX_DEV f3 bsdf_albedo(const DScene& scene, const etx_abi_material& mat, const f
     case ETX_MAT_THINFILM:    // bsdf_dielectric.hxx:55
     case ETX_MAT_VELVET:      // bsdf_velvet.hxx:122
     case ETX_MAT_PRINCIPLED:  // bsdf_principled.hxx:120
-      return apply_image(scene, mat.scattering, tex, nullptr);
+      return apply_image(scene, mat.scattering, tex, nullptr, wavelength);
     case ETX_MAT_CONDUCTOR:
-      return apply_image(scene, mat.reflectance, tex, nullptr);
+      return apply_image(scene, mat.reflectance, tex, nullptr, wavelength);
     case ETX_MAT_MIRROR:
     case ETX_MAT_BOUNDARY:
       return mk3(1.0f);
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(kBlockSize) void k_pt_generate(Pipeline p, VcmParam
     PathState st;
     st.id = id;
     st.sampler.init(id, it.iteration);
+    st.wavelength = scene.spectral ? spectral_sample_wavelength(st.sampler.next()) : 0.0f;  // path_tracing_shared.hxx:243
     const uint32_t px = id % it.film_w, py = id / it.film_w;
     const f2 uv = film_sample(scene, it.iteration != 0u, px, py, it, st.sampler.next_2d());
     RayGen r = generate_ray(scene, uv, st.sampler.next_2d());
@@ -97,6 +98,7 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
   if (st.depth > scene.max_path_length)
     return false;
   const uint32_t film_target = film_index(it, st.id);
+  const f3 film_weight = spectral_film_weight(scene, st.wavelength);  // (value / sampling_pdf).to_rgb(), path_tracing.cxx:67-72
   const uint32_t tri_index = __float_as_uint(h.w);
   const bool found = tri_index != kInvalid;
   Isect isect;
@@ -107,7 +109,7 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
   MediumSample ms;
   ms.sampled_medium_t = 0.0f;
   if (st.medium != kInvalid) {
-    ms = sample_medium_homogeneous(scene.mediums[st.medium], st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+    ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
     st.throughput *= ms.weight;
   }
 
@@ -115,11 +117,11 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
     const DMedium& medium = scene.mediums[st.medium];
     if (opt_nee && (st.depth + 1u <= scene.max_path_length) && medium.explicit_connections) {
       const uint32_t emitter_index = sample_emitter_index(scene, st.sampler.next());
-      const EmitterSample es = sample_emitter(scene, emitter_index, st.sampler.next_2d(), ms.pos);
+      const EmitterSample es = sample_emitter(scene, emitter_index, st.sampler.next_2d(), ms.pos, st.wavelength);
       if (es.pdf_dir > 0.0f) {
         const float phase = phase_function(st.ray_d, es.direction, medium.g);
         const float weight = es.is_delta ? 1.0f : power_heuristic(es.pdf_dir * es.pdf_sample, phase);
-        out.nee = {ms.pos, es.origin, st.throughput * es.value * (phase * weight / (es.pdf_dir * es.pdf_sample)), st.medium, film_target};
+        out.nee = {ms.pos, es.origin, st.throughput * es.value * (phase * weight / (es.pdf_dir * es.pdf_sample)) * film_weight, st.medium, film_target, st.wavelength};
         out.has_nee = true;
       }
     }
@@ -146,7 +148,7 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
         q.uv = {0.0f, 0.0f};
         q.directly_visible = st.depth == 1u;
         float pdf_area = 0.0f, pdf_dir = 0.0f, pdf_dir_out = 0.0f;
-        const f3 e = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out);
+        const f3 e = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out, st.wavelength);
         if ((pdf_dir > 0.0f) && (is_zero(e) == false)) {
           const float pdf_discrete = emitter_discrete_pdf(scene, em);
           const float weight = (((st.flags & kPtMisWeight) == 0u) || q.directly_visible) ? 1.0f : power_heuristic(st.d_vcm, pdf_discrete * pdf_dir);
@@ -154,7 +156,7 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
         }
       }
       if ((accumulated.x != 0.0f) || (accumulated.y != 0.0f) || (accumulated.z != 0.0f))
-        atomic_add_f3(p.camera_sum + film_target, accumulated);
+        atomic_add_f3(p.camera_sum + film_target, accumulated * film_weight);
     }
     return false;
   }
@@ -180,19 +182,19 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
     q.uv = isect.tex;
     q.directly_visible = st.depth == 1u;
     float pdf_area = 0.0f, pdf_dir = 0.0f, pdf_dir_out = 0.0f;
-    const f3 e = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out);
+    const f3 e = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out, st.wavelength);
     if (pdf_dir > 0.0f) {
       const float pdf_discrete = emitter_discrete_pdf(scene, em);
       const bool no_weight = (opt_mis == false) || q.directly_visible || ((st.flags & kPtMisWeight) == 0u);
       const float weight = no_weight ? 1.0f : power_heuristic(st.d_vcm, pdf_discrete * pdf_dir);
-      out.direct = {st.ray_o, isect.pos, st.throughput * e * weight, st.medium, film_target};
+      out.direct = {st.ray_o, isect.pos, st.throughput * e * weight * film_weight, st.medium, film_target, st.wavelength};
       out.has_direct = true;
     }
   }
 
-  BsdfData bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera);
+  BsdfData bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera, st.wavelength);
   if (st.depth == 1u) {  // view_normal / view_albedo -> Film::accumulate_camera_image(pixel, color, normal, albedo)
-    const f3 albedo = bsdf_albedo(scene, mat, isect.tex);
+    const f3 albedo = bsdf_albedo(scene, mat, isect.tex, st.wavelength) * film_weight;
     atomic_add_f3(p.normal_sum + film_target, isect.nrm);  // atomics: another lane may add the same pixel of another iteration
     atomic_add_f3(p.albedo_sum + film_target, albedo);
   }
@@ -214,7 +216,7 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
   if (opt_nee && (st.depth + 1u <= scene.max_path_length)) {  // :409-431 + evaluate_light :300-321
     st.sampler.push_fixed(rnd_em_sample.x, rnd_em_sample.y, rnd_support.x);
     const uint32_t emitter_index = sample_emitter_index(scene, rnd_support.y);
-    const EmitterSample es = sample_emitter(scene, emitter_index, rnd_em_sample, isect.pos);
+    const EmitterSample es = sample_emitter(scene, emitter_index, rnd_em_sample, isect.pos, st.wavelength);
     if (es.pdf_dir != 0.0f) {
       bsdf_data.medium = st.medium;
       const BsdfEval eval = bsdf_evaluate_s<kSimple>(scene, bsdf_data, es.direction, mat, st.sampler);
@@ -222,7 +224,7 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
         const f3 pos = shading_pos(scene, tri, isect.bc, es.direction);
         const bool no_weight = (opt_mis == false) || es.is_delta;
         const float weight = no_weight ? 1.0f : power_heuristic(es.pdf_dir * es.pdf_sample, eval.pdf);
-        out.nee = {pos, es.origin, st.throughput * eval.bsdf * es.value * (weight / (es.pdf_dir * es.pdf_sample)), st.medium, film_target};
+        out.nee = {pos, es.origin, st.throughput * eval.bsdf * es.value * (weight / (es.pdf_dir * es.pdf_sample)) * film_weight, st.medium, film_target, st.wavelength};
         out.has_nee = true;
       }
     }

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
       uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ i;
       f3 tr = mk3(1.0f);
       if ((p.debug_flags & 4u) == 0u)
-        tr = bvh_transmittance(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), alpha_seed);
+        tr = bvh_transmittance(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), p.shadow.value[i].w, alpha_seed);
       target = __float_as_uint(b.w);
       if ((tr.x > kEpsilon) || (tr.y > kEpsilon) || (tr.z > kEpsilon)) {  // SpectralResponse::is_zero
         const float4 v = p.shadow.value[i];

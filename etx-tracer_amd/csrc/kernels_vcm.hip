@@ -67,7 +67,10 @@ __global__ __launch_bounds__(kBlockSize) void k_light_generate(Pipeline p, VcmPa
     if (i < it.path_count) {
       st.sampler.init(i, it.iteration);
       st.id = i;
-      EmitterSample es = sample_emission(scene, st.sampler);
+      // vcm_shared.hxx:313: spectral scenes draw the wavelength first
+      st.wavelength = scene.spectral ? spectral_sample_wavelength(st.sampler.next()) : 0.0f;
+      p.path_wavelength[i] = st.wavelength;
+      EmitterSample es = sample_emission(scene, st.sampler, st.wavelength);
       if (es.pdf_dir > 0.0f) {
         float cos_t = dot(es.direction, es.normal);
         st.throughput = es.value * (cos_t / (es.pdf_dir * es.pdf_area * es.pdf_sample));
@@ -148,6 +151,12 @@ __global__ __launch_bounds__(kBlockSize) void k_camera_generate(Pipeline p, VcmP
     // (measured: -7% in the connection-only image). The camera stream is therefore re-keyed.
     st.sampler.init(i, it.iteration);
     st.sampler.seed = Sampler::random_seed(st.sampler.seed, 0x43414d45u);
+    // vcm_shared.hxx:358-359: one draw is consumed, the wavelength is the one of light path i (vcm_cpu.cxx:186)
+    st.wavelength = 0.0f;
+    if (scene.spectral) {
+      (void)st.sampler.next();
+      st.wavelength = p.path_wavelength[i];
+    }
     uint32_t px = i % it.film_w, py = i / it.film_w;
     f2 uv = get_jittered_uv(st.sampler, px, py, it.film_w, it.film_h);
     RayGen r = generate_ray(scene, uv, st.sampler.next_2d());

@@ -24,6 +24,7 @@ struct PathSet {
   float4* mis;       // d_vcm, d_vc, d_vm, path_distance
   uint4* meta;       // sampler seed, total_path_depth, medium index, flags
   uint32_t* path_id; // global path index (light pass) / pixel index (camera pass)
+  float* wavelength; // spectral mode: the path's wavelength (VCMPathState::spect)
 };
 
 enum : uint32_t {  // VCMPathState flags, vcm_shared.hxx:92-98
@@ -42,6 +43,7 @@ struct LightVertexPool {   // VCMLightVertex (vcm_shared.hxx:154-197): one 96-by
   ETX_HD float4& nrm_tri(uint32_t i) const { return rec[i * kLvStride + 3]; }     // nrm.xyz, triangle index bits (kInvalid = medium vertex)
   ETX_HD float4& bc_len_med(uint32_t i) const { return rec[i * kLvStride + 4]; }  // bc.u, bc.v, (index_in_path << 16 | path_length) bits, medium bits
   ETX_HD uint32_t& next(uint32_t i) const { return reinterpret_cast<uint32_t*>(rec + i * kLvStride + 5)[0]; }  // previous vertex of the same path
+  ETX_HD float& wavelength(uint32_t i) const { return reinterpret_cast<float*>(rec + i * kLvStride + 5)[1]; }  // spectral mode: the light path's wavelength
 };
 
 struct PhotonGrid {        // VCMSpatialGridData (vcm_shared.hxx:805-827), photons sorted by hash cell
@@ -73,6 +75,7 @@ struct CameraVertexPool {  // connectible camera vertices of the current bounce 
   float4* thr_depth;       // throughput rgb, total_path_depth bits
   float4* mis_pixel;       // d_vcm, d_vc, d_vm (already updated at the vertex), pixel index bits
   uint32_t* seed;
+  float* wavelength;       // spectral mode: wavelength of the camera path
   // merge-ready copy (k_merge reads these five float4 and nothing else): no dependent triangle/vertex/material loads
   float4* pos_info;        // pos.xyz, (total_path_depth << 8) | flags   (kCvDiffuse, kCvMedium)
   float4* nrm_dvm;         // shading normal, d_vm
@@ -84,7 +87,7 @@ enum : uint32_t { kCvDiffuse = 1u << 0, kCvMedium = 1u << 1 };
 struct ShadowQueue {        // transmittance ("shadow") ray requests of the current bounce: 48 B in, film atomics out
   float4* p0_medium;       // segment start, medium index bits at the start
   float4* p1_target;       // segment end, film target bits: bit 31 = light layer, low bits = film pixel index
-  float4* value;           // contribution before transmittance (rgb)
+  float4* value;           // contribution before transmittance (rgb, already weighted for the film), w = wavelength (media)
   uint32_t capacity;
 };
 
@@ -162,6 +165,7 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   float4* hits;          // hit queue, aligned with the "in" path set
   LightVertexPool lv;
   uint32_t* light_path_head;   // per path: last stored vertex (kInvalid = none)
+  float* path_wavelength;      // spectral mode: wavelength of light path i, reused by camera path i (vcm_cpu.cxx:186)
   uint4* light_path_table;     // per path: its first kPathTableEntries vertices by index in path (expand_pairs reads them
                                // with two independent loads instead of walking the list from the head)
   PhotonGrid grid;

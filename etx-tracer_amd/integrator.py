@@ -104,6 +104,7 @@ class HIPIntegrator(Integrator):
         self._have_light_image = False
         # what the C++ host tabulates from its BNSampler (include/etx_hip.h): {set_index: uint8 [128,128,256,8]}
         self.bluenoise_tables = {}
+        self.cie_table = None  # spectral scenes: (float32 [count, 3] spectrum::spectral_xyz, first wavelength) of the host
         self._bluenoise_uploaded = set()
 
     def _begin(self):
@@ -121,6 +122,8 @@ class HIPIntegrator(Integrator):
         if not self._uploaded:
             self.context.upload_scene(self.snapshot)
             self._uploaded = True
+        if self.cie_table is not None:
+            self.context.upload_cie_table(*self.cie_table)
         for set_index, table in self.bluenoise_tables.items():
             if set_index not in self._bluenoise_uploaded:
                 self.context.upload_bluenoise(set_index, table)

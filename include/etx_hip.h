@@ -88,6 +88,12 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
  * ETX_HIP_ERROR_UNSUPPORTED when options.blue_noise is set and the class of scene.samples has not been uploaded. */
 int etx_hip_upload_bluenoise(etx_hip_context* context, uint32_t set_index, const uint8_t* values, size_t bytes);
 
+/* Spectral scenes (Scene::spectral()): the film conversion (value / sampling_pdf).to_rgb() needs the CIE observer the
+ * host compiles in, spectrum::spectral_xyz(i) for i < spectrum::WavelengthCount at 1 nm from spectrum::kShortestWavelength
+ * (sources/etx/render/shared/spectrum.hxx:17-21, 24-186). xyz = count * 3 floats. etx_hip_begin fails with
+ * ETX_HIP_ERROR_UNSUPPORTED on a spectral scene until the table is uploaded. */
+int etx_hip_upload_cie_table(etx_hip_context* context, const float* xyz, uint32_t count, float first_wavelength);
+
 /* ------------------------------------------------------------------------------------------------------------ */
 /* rendering */
 

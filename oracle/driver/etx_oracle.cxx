@@ -265,6 +265,21 @@ int main(int argc, char** argv) {
       load_snapshot_file = next();
     else if (strcmp(argv[i], "--kat") == 0)
       return print_kat();
+    else if (strcmp(argv[i], "--dump-cie") == 0) {
+      // --dump-cie <file>: first wavelength, count, then spectrum::spectral_xyz(i) (the observer behind SpectralResponse::to_xyz)
+      const char* file = next();
+      FILE* f = fopen(file, "wb");
+      if (f == nullptr)
+        return 2;
+      float head[2] = {spectrum::kShortestWavelength, float(spectrum::WavelengthCount)};
+      fwrite(head, sizeof(float), 2, f);
+      for (uint32_t k = 0; k < spectrum::WavelengthCount; ++k) {
+        float3 v = spectrum::spectral_xyz(k);
+        fwrite(&v.x, sizeof(float), 3, f);
+      }
+      fclose(f);
+      return 0;
+    }
     else if (strcmp(argv[i], "--dump-bluenoise") == 0) {
       // --dump-bluenoise <samples> <file>: what sample_blue_noise (path_tracing.cxx:173-178) returns for this sample-count
       // class, as bytes: value[(((py * 128 + px) * 256) + sample) * 8 + dimension], float = (0.5 + value) / 256

@@ -8,6 +8,8 @@ Run in the build container (needs /root/reference): python3 oracle/gen_golden.py
                    cornell_classic_128_pt.npz                        reference CPUPathTracing, 256 spp, bn=false (+ normal / albedo AOVs)
                    cornell_full_128_pt_bluenoise.npz                 reference CPUPathTracing, 64 spp, PTOptions defaults
                    cornell_{rough,glass}_128_{vcm,pt}.npz            all BSDF classes: reference CPUVCM 64 spp / CPUPathTracing 256 spp
+                   cornell_{spectral,diamond}_128_{vcm,pt}.npz       spectral mode: classic box / dispersive diamond + thinfilm, VCM 64 spp, PT 256 spp
+  spectral         cie_observer.npz                                  spectrum::spectral_xyz of the reference (etx_hip_upload_cie_table)
   blue noise       bluenoise_64spp.npz                               the reference's sample_blue_noise for the 64-spp class,
                                                                      factorised by tools/bluenoise_tables.py (258 KiB instead of 32 MiB)
   KAT vectors      kat_reference.json                                reference header functions
@@ -74,6 +76,25 @@ def materials_golden():
                                 threads=np.int32(film["threads"]))
 
 
+def spectral_golden():
+    # Scene::spectral(): the classic box and the box with a dispersive diamond + thinfilm class (configs[2] family);
+    # the CIE observer of the reference for etx_hip_upload_cie_table
+    raw_path = "/tmp/cie.raw"
+    run("--dump-cie", raw_path)
+    raw = np.fromfile(raw_path, dtype=np.float32)
+    np.savez_compressed(os.path.join(GOLDEN, "cie_observer.npz"), first_wavelength=np.float32(raw[0]), xyz=raw[2:].reshape(int(raw[1]), 3))
+    for flavour in ("spectral", "diamond"):
+        snapshot = os.path.join(GOLDEN, "cornell_%s_128.etxscene" % flavour)
+        run("--scene", os.path.join(SCENES, "%s_test_128.json" % flavour), "--integrator", "none", "--snapshot", snapshot)
+        for integrator, spp, extra in (("vcm", 64, ["--opt", "vcm-blue_noise=false"]), ("pt", 256, ["--opt", "bn=false"])):
+            film_path = "/tmp/golden_%s_%s.raw" % (flavour, integrator)
+            run("--load-snapshot", snapshot, "--integrator", integrator, "--spp", str(spp), "--out", film_path, *extra)
+            film = film_io.read_film(film_path)
+            np.savez_compressed(os.path.join(GOLDEN, "cornell_%s_128_%s.npz" % (flavour, integrator)), camera=film["camera"][..., :3], light=film["light"][..., :3],
+                                normal=film["normal"][..., :3], albedo=film["albedo"][..., :3], spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]),
+                                threads=np.int32(film["threads"]))
+
+
 def main():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "scenes", "make_scenes.py")])
     for flavour in ("classic", "full"):
@@ -89,6 +110,7 @@ def main():
     bluenoise_golden()
     pt_golden()
     materials_golden()
+    spectral_golden()
     with open(os.path.join(GOLDEN, "kat_reference.json"), "w") as f:
         subprocess.check_call([ORACLE, "--kat"], stdout=f)
 
@@ -100,5 +122,7 @@ if __name__ == "__main__":
         pt_golden()
     elif (len(sys.argv) > 1) and (sys.argv[1] == "materials"):
         materials_golden()
+    elif (len(sys.argv) > 1) and (sys.argv[1] == "spectral"):
+        spectral_golden()
     else:
         main()

@@ -318,7 +318,7 @@ CAMERA = {
 }
 
 
-def write_json(name, geometry, materials, viewport, samples, max_path_length=1023, rr_start=6):
+def write_json(name, geometry, materials, viewport, samples, max_path_length=1023, rr_start=6, spectral=False):
     cam = dict(CAMERA)
     cam["viewport"] = list(viewport)
     doc = {
@@ -327,7 +327,7 @@ def write_json(name, geometry, materials, viewport, samples, max_path_length=102
         "samples": samples,
         "max-path-length": max_path_length,
         "random-termination-start": rr_start,
-        "spectral": False,
+        "spectral": spectral,
         "force-tangents": False,
         "camera": cam,
     }
@@ -350,6 +350,13 @@ def main():
         f.write(MTL_MATERIALS_DELTA + MTL_LIGHT_CLASSIC)
     write_json("rough_test_128.json", "cornell_classic.obj", "cornell_rough.mtl", (128, 128), 64)
     write_json("glass_test_128.json", "cornell_classic.obj", "cornell_glass.mtl", (128, 128), 64)
+    # spectral mode (one wavelength per path): the classic box, and the delta-glass box with a dispersive diamond
+    # (BASELINE configs[2] family: dielectric-heavy SDS paths, spectral)
+    with open(os.path.join(OUT, "cornell_diamond.mtl"), "w") as f:
+        f.write(MTL_MATERIALS_DELTA.replace("newmtl shortBox\nmaterial class dielectric\nKs 1.000 1.000 1.000\nKt 1.000 1.000 1.000\nint_ior 1.5",
+                                            "newmtl shortBox\nmaterial class dielectric\nKs 1.000 1.000 1.000\nKt 1.000 1.000 1.000\nint_ior diamond") + MTL_LIGHT_CLASSIC)
+    write_json("spectral_test_128.json", "cornell_classic.obj", "cornell_classic.mtl", (128, 128), 64, spectral=True)
+    write_json("diamond_test_128.json", "cornell_classic.obj", "cornell_diamond.mtl", (128, 128), 64, spectral=True)
 
     for flavour in ("classic", "full"):
         obj, mtl = "cornell_%s.obj" % flavour, "cornell_%s.mtl" % flavour

@@ -56,3 +56,11 @@ def bluenoise_64spp():
     """The reference's sample_blue_noise outputs for the 64-spp class, uint8 [128,128,256,8] (oracle/gen_golden.py)."""
     from tools import bluenoise_tables
     return bluenoise_tables.load(os.path.join(GOLDEN, "bluenoise_64spp.npz"))
+
+
+@pytest.fixture(scope="session")
+def cie_observer():
+    """(xyz float32 [441, 3], first wavelength): spectrum::spectral_xyz of the reference (oracle/gen_golden.py)."""
+    import numpy as np
+    z = np.load(os.path.join(GOLDEN, "cie_observer.npz"))
+    return z["xyz"], float(z["first_wavelength"])

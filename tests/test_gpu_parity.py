@@ -141,10 +141,11 @@ def test_device_bluenoise_lookup_matches_reference(etx, kat_reference, bluenoise
 # ---------------------------------------------------------------------------------------------------------------
 # VCM images against the reference's golden films
 
-def render(etx, golden_dir, scene, spp, options=None, first=0, stride=1, size_override=None, bluenoise=None):
+def render(etx, golden_dir, scene, spp, options=None, first=0, stride=1, size_override=None, bluenoise=None, cie=None):
     snap = etx.SceneSnapshot(os.path.join(golden_dir, scene + ".etxscene"))
     snap.samples = spp
     integ = etx.HIPVCM(snap, first_iteration=first, iteration_stride=stride)
+    integ.cie_table = cie
     integ.options()["vcm-blue_noise"] = bluenoise is not None
     if bluenoise is not None:
         integ.bluenoise_tables = dict(bluenoise)
@@ -210,10 +211,11 @@ def test_vcm_default_options_with_blue_noise_match_reference(etx, golden_dir, bl
 # ---------------------------------------------------------------------------------------------------------------
 # unidirectional path tracer (BASELINE configs[0]) against the reference's CPUPathTracing
 
-def render_pt(etx, golden_dir, scene, spp, options=None, bluenoise=None, first=0, stride=1):
+def render_pt(etx, golden_dir, scene, spp, options=None, bluenoise=None, first=0, stride=1, cie=None):
     snap = etx.SceneSnapshot(os.path.join(golden_dir, scene + ".etxscene"))
     snap.samples = spp
     integ = etx.HIPPathTracing(snap, first_iteration=first, iteration_stride=stride)
+    integ.cie_table = cie
     integ.options()["bn"] = bluenoise is not None
     if bluenoise is not None:
         integ.bluenoise_tables = dict(bluenoise)
@@ -273,6 +275,40 @@ def test_all_bsdf_classes_match_reference(etx, golden_dir, flavour):
     assert rmse(block_mean(res, 32), block_mean(ref_result, 32)) < 6.0e-3
     rel = (res.mean(axis=(0, 1)) - ref_result.mean(axis=(0, 1))) / ref_result.mean(axis=(0, 1))
     assert np.abs(rel).max() < 2.0e-2, rel
+
+
+@pytest.mark.parametrize("flavour", ["spectral", "diamond"])
+def test_spectral_mode_matches_reference(etx, golden_dir, flavour, cie_observer):
+    """Scene::spectral(): one wavelength per path, CIE observer on the film. `diamond`: dispersive dielectric
+    (int_ior diamond.spd) + thinfilm class - the material family of BASELINE configs[2]."""
+    golden = np.load(os.path.join(golden_dir, "cornell_%s_128_pt.npz" % flavour))
+    layers, stats = render_pt(etx, golden_dir, "cornell_%s_128" % flavour, int(golden["spp"]), cie=cie_observer)
+    assert stats.overflow_flags == 0
+    ok = np.isfinite(golden["camera"]).all(axis=2)
+    ref = np.where(ok[..., None], golden["camera"], 0.0)
+    cam = np.where(ok[..., None], layers["camera"][..., :3], 0.0)
+    assert np.isfinite(layers["camera"]).all()
+    assert rmse(block_mean(cam, 32), block_mean(ref, 32)) < 8.0e-3
+    rel = (cam.mean(axis=(0, 1)) - ref.mean(axis=(0, 1))) / ref.mean(axis=(0, 1))
+    assert np.abs(rel).max() < 3.0e-2, rel
+    golden = np.load(os.path.join(golden_dir, "cornell_%s_128_vcm.npz" % flavour))
+    cam, light, res, stats = render(etx, golden_dir, "cornell_%s_128" % flavour, int(golden["spp"]), cie=cie_observer)
+    assert stats.overflow_flags == 0 and np.isfinite(res).all()
+    ref_result = golden["camera"] + golden["light"]  # single-wavelength samples: channels can be negative before clamping
+    ok = np.isfinite(ref_result).all(axis=2)
+    ref_result = np.where(ok[..., None], ref_result, 0.0)
+    got = np.where(ok[..., None], cam[..., :3] + light[..., :3], 0.0)
+    assert rmse(block_mean(got, 32), block_mean(ref_result, 32)) < 8.0e-3
+    rel = (got.mean(axis=(0, 1)) - ref_result.mean(axis=(0, 1))) / ref_result.mean(axis=(0, 1))
+    assert np.abs(rel).max() < 3.0e-2, rel
+    # without the observer table a spectral scene is rejected, not rendered in RGB
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_%s_128.etxscene" % flavour))
+    integ = etx.HIPVCM(snap)
+    integ.options()["vcm-blue_noise"] = False
+    with pytest.raises(etx.EtxHipError) as e:
+        integ.run()
+    assert e.value.code == -4
+    integ.context.close()
 
 
 def test_pt_options_and_config1_size(etx, golden_dir):
