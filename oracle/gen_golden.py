@@ -8,7 +8,7 @@ Run in the build container (needs /root/reference): python3 oracle/gen_golden.py
                    cornell_classic_128_pt.npz                        reference CPUPathTracing, 256 spp, bn=false (+ normal / albedo AOVs)
                    cornell_full_128_pt_bluenoise.npz                 reference CPUPathTracing, 64 spp, PTOptions defaults
                    cornell_{rough,glass}_128_{vcm,pt}.npz            all BSDF classes: reference CPUVCM 64 spp / CPUPathTracing 256 spp
-                   cornell_{spectral,diamond}_128_{vcm,pt}.npz       spectral mode: classic box / dispersive diamond + thinfilm, VCM 64 spp, PT 256 spp
+                   cornell_{spectral,diamond,gems}_128_{vcm,pt}.npz  spectral mode: classic box / dispersive diamond + thinfilm / 2 892-triangle gems, VCM 64 spp, PT 256 spp
   spectral         cie_observer.npz                                  spectrum::spectral_xyz of the reference (etx_hip_upload_cie_table)
   blue noise       bluenoise_64spp.npz                               the reference's sample_blue_noise for the 64-spp class,
                                                                      factorised by tools/bluenoise_tables.py (258 KiB instead of 32 MiB)
@@ -83,7 +83,7 @@ def spectral_golden():
     run("--dump-cie", raw_path)
     raw = np.fromfile(raw_path, dtype=np.float32)
     np.savez_compressed(os.path.join(GOLDEN, "cie_observer.npz"), first_wavelength=np.float32(raw[0]), xyz=raw[2:].reshape(int(raw[1]), 3))
-    for flavour in ("spectral", "diamond"):
+    for flavour in ("spectral", "diamond", "gems"):  # gems: 2 892 triangles -> BVH traversal
         snapshot = os.path.join(GOLDEN, "cornell_%s_128.etxscene" % flavour)
         run("--scene", os.path.join(SCENES, "%s_test_128.json" % flavour), "--integrator", "none", "--snapshot", snapshot)
         for integrator, spp, extra in (("vcm", 64, ["--opt", "vcm-blue_noise=false"]), ("pt", 256, ["--opt", "bn=false"])):

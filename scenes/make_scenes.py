@@ -68,6 +68,46 @@ class Mesh:
         self.quad(mat, [(x0, y0, z0), (x0, y1, z0), (x1, y1, z0), (x1, y0, z0)], (0, 0, -1))
         self.quad(mat, [(x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)], (0, 0, 1))
 
+    def icosphere(self, mat, center, radius, subdivisions, flat=False):
+        """Triangle mesh of a sphere (20 * 4^subdivisions faces), smooth vertex normals unless `flat`."""
+        t = (1.0 + 5.0 ** 0.5) / 2.0
+        verts = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+        faces = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+                 (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+
+        def unit(v):
+            ln = sum(c * c for c in v) ** 0.5
+            return tuple(c / ln for c in v)
+
+        verts = [unit(v) for v in verts]
+        for _ in range(subdivisions):
+            cache, new_faces = {}, []
+
+            def mid(a, b):
+                key = (min(a, b), max(a, b))
+                if key not in cache:
+                    verts.append(unit(tuple((verts[a][i] + verts[b][i]) * 0.5 for i in range(3))))
+                    cache[key] = len(verts) - 1
+                return cache[key]
+
+            for a, b, c in faces:
+                ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+                new_faces += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+            faces = new_faces
+        vbase, nbase = len(self.v), len(self.vn)
+        for v in verts:
+            self.v.append(tuple(center[i] + radius * v[i] for i in range(3)))
+            if not flat:
+                self.vn.append(v)
+        for a, b, c in faces:
+            if flat:
+                n = unit(tuple(verts[a][i] + verts[b][i] + verts[c][i] for i in range(3)))
+                self.vn.append(n)
+                ni = len(self.vn)
+                self.groups.append((mat, [(vbase + a + 1, ni), (vbase + b + 1, ni), (vbase + c + 1, ni)]))
+            else:
+                self.groups.append((mat, [(vbase + a + 1, nbase + a + 1), (vbase + b + 1, nbase + b + 1), (vbase + c + 1, nbase + c + 1)]))
+
     def write(self, path, mtllib):
         with open(path, "w") as f:
             f.write("# Cornell box rebuilt for etx-tracer's surviving camera/materials (scenes/make_scenes.py)\n")
@@ -84,7 +124,7 @@ class Mesh:
                 f.write("f " + " ".join("%d//%d" % (vi, ni) for vi, ni in idx) + "\n")
 
 
-def build_mesh(with_fog):
+def build_mesh(with_fog, spheres=False):
     m = Mesh()
     # room, normals pointing inside
     m.quad("floor", [(-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1)], (0, 1, 0))
@@ -109,8 +149,14 @@ def build_mesh(with_fog):
             a += pts[i][2] * pts[j][0] - pts[j][2] * pts[i][0]
         return pts if a > 0 else list(reversed(pts))
 
-    m.box("shortBox", ccw_from_above(short_top), short_top[0][1])
-    m.box("tallBox", ccw_from_above(tall_top), tall_top[0][1])
+    if spheres:
+        # BVH-sized geometry (2 x 1280 + 320 triangles): a faceted "gem" and two smooth spheres instead of the boxes
+        m.icosphere("shortBox", (0.35, 0.33, 0.45), 0.33, 3, flat=True)
+        m.icosphere("tallBox", (-0.40, 0.45, -0.30), 0.45, 3)
+        m.icosphere("gem", (-0.45, 0.22, 0.55), 0.22, 2, flat=True)
+    else:
+        m.box("shortBox", ccw_from_above(short_top), short_top[0][1])
+        m.box("tallBox", ccw_from_above(tall_top), tall_top[0][1])
     if with_fog:
         m.aabb("fog", (-0.99, 0.01, -0.99), (0.99, 1.99, 0.99))
     return m
@@ -355,6 +401,36 @@ def main():
     with open(os.path.join(OUT, "cornell_diamond.mtl"), "w") as f:
         f.write(MTL_MATERIALS_DELTA.replace("newmtl shortBox\nmaterial class dielectric\nKs 1.000 1.000 1.000\nKt 1.000 1.000 1.000\nint_ior 1.5",
                                             "newmtl shortBox\nmaterial class dielectric\nKs 1.000 1.000 1.000\nKt 1.000 1.000 1.000\nint_ior diamond") + MTL_LIGHT_CLASSIC)
+    # "gems": 2 900 triangles (BVH traversal instead of the flat sweep), dispersive diamond + glass + rough gold, spectral:
+    # the shape of BASELINE configs[2] at test size
+    build_mesh(False, spheres=True).write(os.path.join(OUT, "cornell_gems.obj"), "cornell_gems.mtl")
+    with open(os.path.join(OUT, "cornell_gems.mtl"), "w") as f:
+        f.write(MTL_COMMON.split("newmtl shortBox")[0] + """newmtl shortBox
+material class dielectric
+Ks 1.000 1.000 1.000
+Kt 1.000 1.000 1.000
+int_ior diamond
+Pr 0.000
+two_sided 1
+
+newmtl tallBox
+material class conductor
+int_ior gold
+Ks 1.000 1.000 1.000
+Pr 0.350
+two_sided 1
+
+newmtl gem
+material class dielectric
+Ks 1.000 1.000 1.000
+Kt 0.950 1.000 0.950
+int_ior 1.5
+Pr 0.000
+two_sided 1
+
+""" + MTL_LIGHT_CLASSIC)
+    write_json("gems_test_128.json", "cornell_gems.obj", "cornell_gems.mtl", (128, 128), 64, spectral=True)
+    write_json("gems_c3_1080p.json", "cornell_gems.obj", "cornell_gems.mtl", (1920, 1080), 64, spectral=True)
     write_json("spectral_test_128.json", "cornell_classic.obj", "cornell_classic.mtl", (128, 128), 64, spectral=True)
     write_json("diamond_test_128.json", "cornell_classic.obj", "cornell_diamond.mtl", (128, 128), 64, spectral=True)
 

@@ -91,7 +91,7 @@ def make_rays(n, seed):
     return rays
 
 
-@pytest.mark.parametrize("scene", ["cornell_classic_128", "cornell_full_128"])
+@pytest.mark.parametrize("scene", ["cornell_classic_128", "cornell_full_128", "cornell_gems_128"])  # flat sweep, flat sweep, BVH2
 def test_traversal_matches_bruteforce(etx, gpu_context, golden_dir, scene):
     from oracle import ray_oracle
     snap = etx.SceneSnapshot(os.path.join(golden_dir, scene + ".etxscene"))
@@ -277,10 +277,11 @@ def test_all_bsdf_classes_match_reference(etx, golden_dir, flavour):
     assert np.abs(rel).max() < 2.0e-2, rel
 
 
-@pytest.mark.parametrize("flavour", ["spectral", "diamond"])
+@pytest.mark.parametrize("flavour", ["spectral", "diamond", "gems"])
 def test_spectral_mode_matches_reference(etx, golden_dir, flavour, cie_observer):
     """Scene::spectral(): one wavelength per path, CIE observer on the film. `diamond`: dispersive dielectric
-    (int_ior diamond.spd) + thinfilm class - the material family of BASELINE configs[2]."""
+    (int_ior diamond.spd) + thinfilm class; `gems`: 2 892 triangles (BVH traversal), diamond + glass gems and a rough gold
+    sphere - the shape of BASELINE configs[2] at test size."""
     golden = np.load(os.path.join(golden_dir, "cornell_%s_128_pt.npz" % flavour))
     layers, stats = render_pt(etx, golden_dir, "cornell_%s_128" % flavour, int(golden["spp"]), cie=cie_observer)
     assert stats.overflow_flags == 0

@@ -31,6 +31,9 @@ def main():
     snap.samples = spp
     integ = etx.HIPVCM(snap)
     integ.options().update(options)
+    golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    cie = np.load(os.path.join(golden, "cie_observer.npz"))  # only consulted by spectral scenes
+    integ.cie_table = (cie["xyz"], float(cie["first_wavelength"]))
     if options.get("vcm-blue_noise"):
         from tools import bluenoise_tables  # the committed table of the 64-spp class (scene.samples 33..64)
         integ.bluenoise_tables = {6: bluenoise_tables.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "bluenoise_64spp.npz"))}
