@@ -458,8 +458,24 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
   block_stat_add(p, kBlockStatMerged, merged_count, &s_stat);
 }
 
-// Every other connectible material: generic BSDF evaluation per accepted photon (stochastic for rough conductors).
+// Every other connectible material: generic BSDF evaluation per accepted photon (stochastic for the Heitz models).
+// Same shape as k_merge_diffuse - 8 vertices x 8 cells per wave, ranges flattened, accepted photons through the LDS
+// ring, evaluated 64 at a time - with one LDS record per VERTEX (rebuilt intersection, BSDF inputs) written by the
+// first of its eight lanes. A lane-per-range loop left 1 lane in 30 busy inside the conductor random walk
+// (380 ms per iteration on the 1080p gems scene).
+struct MergeVertex {  // per camera vertex, in LDS
+  f3 pos, nrm, tan, btn, w_i, thr_film;
+  f2 tex;
+  float wavelength, w_camera_base, d_vm;
+  uint32_t medium, material, depth, seed;
+};
+
 __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmParams it) {
+  __shared__ MergeVertex s_vertex[kBlockSize / 64][8];
+  __shared__ float s_acc[kBlockSize / 64][8][4];
+  __shared__ uint2 s_ring[kBlockSize / 64][128];  // (photon, distance^2 bits)
+  __shared__ uint32_t s_ring_range[kBlockSize / 64][128];
+  __shared__ unsigned long long s_stat;
   const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntMergeVertices], p.capacity);
   const GridParams g = *p.grid_params;
@@ -468,66 +484,136 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
   const uint32_t items = count * 8u;
   const bool use_mis = opt_enable_mis(it);
   const bool use_epan = it.kernel == ETX_VCM_KERNEL_EPANECHNIKOV;
+  const uint32_t max_path_length = scene.max_path_length;
+  const uint32_t wave = threadIdx.x >> 6u;
+  MergeVertex* verts = s_vertex[wave];
+  uint2* ring = s_ring[wave];
+  uint32_t* ring_range = s_ring_range[wave];
   unsigned long long examined = 0, merged_count = 0;
   ETX_XCD_RANGE_LOOP(items) {
     const uint32_t item = base_ + lane_;
     const uint32_t c = item & 7u;
-    f3 merged = mk3(0.0f);
-    uint32_t pixel = 0;
-    float wavelength = 0.0f;
+    uint32_t range_begin = 0, range_len = 0, pixel = 0;
+    bool generic = false;
     if (item < seg_end_) {
       const uint32_t vertex = p.merge_order[item >> 3u];
-      const uint32_t info = __float_as_uint(p.cv.pos_info[vertex].w);
-      if ((info & (kCvDiffuse | kCvMedium)) == 0u) {
+      const float4 pi = p.cv.pos_info[vertex];
+      const uint32_t info = __float_as_uint(pi.w);
+      const uint32_t depth = info >> 8u;
+      generic = ((info & (kCvDiffuse | kCvMedium)) == 0u) && (depth + 1u <= max_path_length);
+      uint32_t range_end = 0;
+      if (generic && merge_cell_range(p, g, f3{pi.x, pi.y, pi.z}, c, range_begin, range_end) && (range_begin < range_end))
+        range_len = range_end - range_begin;
+      if (c == 0u)
+        pixel = __float_as_uint(p.cv.mis_pixel[vertex].w);
+      if (generic && (c == 0u)) {  // one lane rebuilds the vertex for its eight ranges
         CameraVertex cv = load_camera_vertex(p, scene, vertex);
-        const Isect& isect = cv.isect;
-        uint32_t range_begin = 0, range_end = 0;
-        if ((cv.st.depth + 1u <= scene.max_path_length) && merge_cell_range(p, g, isect.pos, c, range_begin, range_end)) {
-          pixel = cv.st.id, wavelength = cv.st.wavelength;
-          const etx_abi_material& mat = scene.materials[isect.material];
-          const BsdfData camera_data = make_bsdf_data(isect, isect.w_i, cv.st.medium, kPathCamera, cv.st.wavelength);
-          const float w_camera_base = cv.st.d_vcm * it.vc_weight;
-          const f3 camera_film_weight = spectral_film_weight(scene, cv.st.wavelength);
-          cv.st.sampler.seed = Sampler::random_seed(cv.st.sampler.seed, c);
-          for (uint32_t j = range_begin; j < range_end; ++j) {
-            examined++;
-            const float4 pl = p.grid.pos_len[j];
-            const f3 d = f3{pl.x, pl.y, pl.z} - isect.pos;
-            const float distance_squared = dot(d, d);
-            if ((distance_squared > g.radius_squared) || (__float_as_uint(pl.w) + cv.st.depth + 1u > scene.max_path_length))
-              continue;
-            const float4 nd = p.grid.nrm_dvcm(j);
-            if (dot(isect.nrm, f3{nd.x, nd.y, nd.z}) <= kEpsilon)
-              continue;
-            const float4 wd = p.grid.win_dvm(j);
-            const f3 wi = {wd.x, wd.y, wd.z};
-            BsdfEval camera_bsdf = bsdf_evaluate(scene, camera_data, -wi, mat, cv.st.sampler);
-            if (camera_bsdf.valid() == false)
-              continue;
-            const float rev_pdf = bsdf_reverse_pdf(scene, camera_data, -wi, mat, cv.st.sampler);
+        MergeVertex& v = verts[lane_ >> 3u];
+        v.pos = cv.isect.pos, v.nrm = cv.isect.nrm, v.tan = cv.isect.tan, v.btn = cv.isect.btn, v.w_i = cv.isect.w_i, v.tex = cv.isect.tex;
+        // c_value = (func x throughput / sampling_pdf).to_rgb(), vcm_shared.hxx:869
+        v.thr_film = cv.st.throughput * spectral_film_weight(scene, cv.st.wavelength);
+        v.wavelength = cv.st.wavelength;
+        v.w_camera_base = cv.st.d_vcm * it.vc_weight;
+        v.d_vm = cv.st.d_vm;
+        v.medium = cv.st.medium, v.material = cv.isect.material, v.depth = cv.st.depth, v.seed = cv.st.sampler.seed;
+      }
+    }
+    if (__ballot(range_len != 0u) == 0ull)
+      continue;  // no generic vertex with photons in this batch (the common case: the list is sorted in space)
+    if (lane_ < 32u)
+      (&s_acc[wave][0][0])[lane_] = 0.0f;
+    uint32_t incl = range_len;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      uint32_t t = __shfl_up(incl, d);
+      if (lane_ >= d)
+        incl += t;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    const uint32_t offset = incl - range_len;
+    __threadfence_block();
+    if (lane_ == 0)
+      examined += total;
+    uint32_t ring_head = 0, ring_tail = 0;
+    auto evaluate = [&](uint32_t entries) {
+      if (lane_ < entries) {
+        const uint2 en = ring[(ring_head + lane_) & 127u];
+        const uint32_t r = ring_range[(ring_head + lane_) & 127u], j = en.x;
+        const float distance_squared = __uint_as_float(en.y);
+        const MergeVertex& v = verts[r >> 3u];
+        const float4 nd = p.grid.nrm_dvcm(j);
+        if (dot(v.nrm, f3{nd.x, nd.y, nd.z}) > kEpsilon) {
+          const float4 wd = p.grid.win_dvm(j);
+          const f3 wi = {wd.x, wd.y, wd.z};
+          const etx_abi_material& mat = scene.materials[v.material];
+          const BsdfData camera_data = {v.nrm, v.tan, v.btn, v.tex, v.w_i, v.medium, kPathCamera, v.wavelength};
+          Sampler smp;  // the reference continues the path's stream through all photons; here one stream per (vertex, photon)
+          smp.seed = Sampler::random_seed(v.seed, j);
+          smp.fixed_u = smp.fixed_v = smp.fixed_w = 0.0f;
+          const BsdfEval camera_bsdf = bsdf_evaluate(scene, camera_data, -wi, mat, smp);
+          if (camera_bsdf.valid()) {
+            const float rev_pdf = bsdf_reverse_pdf(scene, camera_data, -wi, mat, smp);
             const float w_light = nd.w * it.vc_weight + wd.w * camera_bsdf.pdf;
-            const float w_camera = w_camera_base + cv.st.d_vm * rev_pdf;
+            const float w_camera = v.w_camera_base + v.d_vm * rev_pdf;
             const float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;
             const float kernel_weight = use_epan ? fmaxf(2.0f * (1.0f - distance_squared * g.inv_radius_squared), 0.0f) : 1.0f;
             const float4 lt = p.grid.thr(j);
-            merged += (camera_bsdf.func * cv.st.throughput * camera_film_weight * f3{lt.x, lt.y, lt.z}) * (kernel_weight * weight);
+            const f3 value = camera_bsdf.func * v.thr_film * f3{lt.x, lt.y, lt.z} * (kernel_weight * weight);
+            float* acc = s_acc[wave][r >> 3u];
+            atomicAdd(acc + 0, value.x);
+            atomicAdd(acc + 1, value.y);
+            atomicAdd(acc + 2, value.z);
             merged_count++;
           }
         }
       }
-    }
+      ring_head += entries;
+    };
+    for (uint32_t e0 = 0; e0 < total; e0 += 64u) {
+      const uint32_t e = e0 + lane_;
+      uint32_t r = 0;
 #pragma unroll
-    for (uint32_t d = 1; d < 8; d <<= 1) {
-      merged.x += __shfl_xor(merged.x, d);
-      merged.y += __shfl_xor(merged.y, d);
-      merged.z += __shfl_xor(merged.z, d);
-      pixel = max(pixel, uint32_t(__shfl_xor(int(pixel), d)));
-      wavelength = fmaxf(wavelength, __shfl_xor(wavelength, d));
+      for (uint32_t step = 32u; step > 0u; step >>= 1u) {
+        const uint32_t cand = r + step;
+        const uint32_t o = __shfl(offset, cand & 63u);
+        if (o <= e)
+          r = cand;
+      }
+      const uint32_t r_begin = __shfl(range_begin, r);
+      const uint32_t r_offset = __shfl(offset, r);
+      bool accept = false;
+      uint32_t j = 0;
+      float distance_squared = 0.0f;
+      if (e < total) {
+        j = r_begin + (e - r_offset);
+        const float4 pl = p.grid.pos_len[j];
+        const MergeVertex& v = verts[r >> 3u];
+        const f3 d = f3{pl.x, pl.y, pl.z} - v.pos;
+        distance_squared = dot(d, d);
+        accept = (distance_squared <= g.radius_squared) && (__float_as_uint(pl.w) + v.depth + 1u <= max_path_length);
+      }
+      const unsigned long long mask = __ballot(accept);
+      if (accept) {
+        const uint32_t at = (ring_tail + __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32u), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u))) & 127u;
+        ring[at] = make_uint2(j, __float_as_uint(distance_squared));
+        ring_range[at] = r;
+      }
+      ring_tail += uint32_t(__popcll(mask));
+      __threadfence_block();
+      if (ring_tail - ring_head >= 64u)
+        evaluate(64u);
     }
-    if (((lane_ & 7u) == 0u) && ((merged.x != 0.0f) || (merged.y != 0.0f) || (merged.z != 0.0f)))
-      atomic_add_f3(p.camera_sum + film_index(it, pixel), merged * it.vm_normalization);
+    if (ring_tail != ring_head)
+      evaluate(ring_tail - ring_head);
+    __threadfence_block();
+    if (((lane_ & 7u) == 0u) && (item < seg_end_)) {
+      const float* acc = s_acc[wave][lane_ >> 3u];
+      const f3 merged = {acc[0], acc[1], acc[2]};
+      if ((merged.x != 0.0f) || (merged.y != 0.0f) || (merged.z != 0.0f))
+        atomic_add_f3(p.camera_sum + film_index(it, pixel), merged * it.vm_normalization);
+    }
+    __threadfence_block();
   }
-  __shared__ unsigned long long s_stat;
   block_stat_add(p, kBlockStatExamined, examined, &s_stat);
   block_stat_add(p, kBlockStatMerged, merged_count, &s_stat);
 }
