@@ -233,11 +233,38 @@ ETX_DEV Hit bvh_closest(const DScene& scene, Nodes nodes, Tris tris, int32_t roo
 
 
 // scene_medium.hxx:187-193 (homogeneous branch): exp(-sigma_t * distance)
-ETX_DEV f3 medium_transmittance_homogeneous(const DScene& scene, const DMedium& m, float wavelength, float distance) {
-  f3 absorption, scattering;
-  medium_coefficients(scene, m, wavelength, absorption, scattering);
-  f3 ext = absorption + scattering;
-  return {expf(-ext.x * distance), expf(-ext.y * distance), expf(-ext.z * distance)};
+// medium_transmittance, scene_medium.hxx:191-239: homogeneous exp(-sigma_t d); heterogeneous ratio tracking against the
+// majorant with Russian roulette below 0.1 (draws from `smp`: the per-request stream of the shadow kernel).
+ETX_DEV f3 medium_transmittance(const DScene& scene, const DMedium& m, float wavelength, Sampler& smp, const f3& pos, const f3& direction, float distance) {
+  if (m.cls == 0u) {
+    f3 absorption, scattering;
+    medium_coefficients(scene, m, wavelength, absorption, scattering);
+    f3 ext = absorption + scattering;
+    return {expf(-ext.x * distance), expf(-ext.y * distance), expf(-ext.z * distance)};
+  }
+  if (m.max_sigma <= 0.0f)
+    return mk3(1.0f);
+  f3 medium_pos, medium_dir;
+  float t_min = 0.0f, t_max = 0.0f;
+  if (medium_intersects_bounds(m, pos, direction, distance, medium_pos, medium_dir, t_min, t_max) == false)
+    return mk3(1.0f);
+  const float rr_threshold = 0.1f;
+  float transmittance = 1.0f;
+  float t = t_min;
+  while (true) {
+    t -= logf(1.0f - smp.next()) / m.max_sigma;
+    if (t >= t_max)
+      break;
+    const float density_value = medium_sample_density(m, medium_pos + medium_dir * t);
+    transmittance *= fmaxf(0.0f, 1.0f - density_value);
+    if (transmittance < rr_threshold) {
+      const float q = fmaxf(0.05f, 1.0f - transmittance);
+      if (smp.next() < q)
+        return mk3(0.0f);
+      transmittance /= (1.0f - q);
+    }
+  }
+  return mk3(transmittance);
 }
 
 // Flat-sweep transmittance for tiny scenes: ONE pass over all triangles finds (a) any occluder and (b) up to four
@@ -285,6 +312,8 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
     return false;
   result = mk3(1.0f);
   float current_t = 0.0f;
+  Sampler medium_rng;  // heterogeneous media draw from the segment's own stream
+  medium_rng.seed = alpha_seed ^ 0x6d656469u, medium_rng.fixed_u = medium_rng.fixed_v = medium_rng.fixed_w = 0.0f;
   uint32_t medium = medium_index;
   const float bts[4] = {bt0, bt1, bt2, bt3};
   const uint32_t bis[4] = {bi0, bi1, bi2, bi3};
@@ -292,7 +321,7 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
   for (uint32_t k = 0; k < 4u; ++k) {
     if (k < crossings) {
       if (medium != kInvalid)
-        result *= medium_transmittance_homogeneous(scene, scene.mediums[medium], wavelength, fmaxf(0.0f, bts[k] - current_t));
+        result *= medium_transmittance(scene, scene.mediums[medium], wavelength, medium_rng, p0 + direction * current_t, direction, fmaxf(0.0f, bts[k] - current_t));
       const etx_abi_triangle& tri = scene.triangles[scene.flat_info[bis[k]].tri_a];
       const etx_abi_material& mat = scene.materials[tri.material_index];
       medium = (dot(ld3(tri.geo_n), direction) < 0.0f) ? mat.int_medium : mat.ext_medium;
@@ -300,7 +329,7 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
     }
   }
   if (medium != kInvalid)
-    result *= medium_transmittance_homogeneous(scene, scene.mediums[medium], wavelength, fmaxf(0.0f, t_max - current_t));
+    result *= medium_transmittance(scene, scene.mediums[medium], wavelength, medium_rng, p0 + direction * current_t, direction, fmaxf(0.0f, t_max - current_t));
   return true;
 }
 
@@ -324,6 +353,8 @@ ETX_DEV f3 bvh_transmittance(const DScene& scene, Nodes nodes, Tris tris, int32_
     return result;
   result = mk3(1.0f);
   float current_t = 0.0f;
+  Sampler medium_rng;  // heterogeneous media draw from the segment's own stream
+  medium_rng.seed = alpha_seed ^ 0x6d656469u, medium_rng.fixed_u = medium_rng.fixed_v = medium_rng.fixed_w = 0.0f;
   float t_min = kRayEpsilon;
   uint32_t medium = medium_index;
   for (uint32_t crossings = 0; crossings < 64u; ++crossings) {
@@ -337,7 +368,7 @@ ETX_DEV f3 bvh_transmittance(const DScene& scene, Nodes nodes, Tris tris, int32_
       float dt = fmaxf(0.0f, seg_end - current_t);
       const DMedium& m = scene.mediums[medium];
       // heterogeneous media (ratio tracking, scene_medium.hxx:195-232) are rejected at upload for now
-      result *= medium_transmittance_homogeneous(scene, m, wavelength, dt);
+      result *= medium_transmittance(scene, m, wavelength, medium_rng, p0 + direction * current_t, direction, dt);
     }
     if (found == false)
       return result;

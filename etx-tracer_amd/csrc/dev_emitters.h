@@ -403,7 +403,56 @@ ETX_DEV uint32_t sample_spectrum_component(const f3& albedo, const f3& throughpu
 }
 
 // scene_medium.hxx:241-288 sample_medium, homogeneous branch (channel-selected exponential free flight)
+// sample_medium heterogeneous branch, scene_medium.hxx:284-349: delta tracking against the majorant max_sigma in the
+// medium's local frame. NOTE: like the reference, `pos` and `sampled_medium_t` of the result are in that LOCAL frame
+// ((p - bounds.min) / extent): the reference hands result.pos to the integrators as the new ray origin unchanged.
+ETX_DEV MediumSample sample_medium_heterogeneous(const DScene& s, const DMedium& m, float wavelength, Sampler& smp, const f3& pos, const f3& w_i, float max_t) {
+  MediumSample r;
+  r.weight = mk3(0.0f), r.pos = mk3(0.0f), r.sampled_medium_t = 0.0f;
+  if (m.max_sigma <= 0.0f)
+    return r;
+  f3 medium_pos, medium_dir;
+  float t_min = 0.0f, t_max = 0.0f;
+  if (medium_intersects_bounds(m, pos, w_i, max_t, medium_pos, medium_dir, t_min, t_max) == false)
+    return r;
+  f3 absorption, scattering;
+  medium_coefficients(s, m, wavelength, absorption, scattering);
+  const f3 extinction = scattering + absorption;
+  const f3 albedo = {extinction.x > 0.0f ? scattering.x / extinction.x : 0.0f, extinction.y > 0.0f ? scattering.y / extinction.y : 0.0f,
+    extinction.z > 0.0f ? scattering.z / extinction.z : 0.0f};
+  float t = t_min, previous_t = t_min;
+  f3 accumulated = mk3(1.0f);
+  while (true) {
+    t -= logf(1.0f - smp.next()) / m.max_sigma;
+    if (t >= t_max)
+      break;
+    const float distance = fmaxf(0.0f, t - previous_t);
+    accumulated *= f3{expf(-extinction.x * distance), expf(-extinction.y * distance), expf(-extinction.z * distance)};
+    previous_t = t;
+    const float density_value = medium_sample_density(m, medium_pos + medium_dir * t);
+    if (density_value * m.max_sigma == 0.0f)
+      continue;
+    f3 pdf;
+    const uint32_t channel = sample_spectrum_component(albedo, scattering, smp.next(), pdf);
+    const float sigma_t = channel == 0 ? extinction.x : (channel == 1 ? extinction.y : extinction.z);
+    const float random = smp.next();
+    if ((sigma_t > 0.0f) && (random < density_value)) {
+      const float pdf_sum = pdf.x + pdf.y + pdf.z;
+      r.weight = (pdf_sum > 0.0f) ? (scattering * accumulated) / pdf_sum : scattering * accumulated;
+      r.pos = medium_pos + medium_dir * t;
+      r.sampled_medium_t = t - t_min;
+      return r;
+    }
+  }
+  const float remaining = fmaxf(0.0f, t_max - previous_t);
+  accumulated *= f3{expf(-extinction.x * remaining), expf(-extinction.y * remaining), expf(-extinction.z * remaining)};
+  r.weight = accumulated;
+  return r;
+}
+
 ETX_DEV MediumSample sample_medium_homogeneous(const DScene& s, const DMedium& m, float wavelength, const f3& throughput, Sampler& smp, const f3& pos, const f3& w_i, float max_t) {
+  if (m.cls != 0u)  // Medium::Class::Heterogeneous
+    return sample_medium_heterogeneous(s, m, wavelength, smp, pos, w_i, max_t);
   f3 absorption, scattering;
   medium_coefficients(s, m, wavelength, absorption, scattering);
   f3 extinction = scattering + absorption;

@@ -196,6 +196,66 @@ ETX_DEV void medium_coefficients(const DScene& s, const DMedium& m, float wavele
   scattering = (m.scattering_index == kInvalid) ? f3{0.0f, 0.0f, 0.0f} : spectrum_eval(s, m.scattering_index, wavelength);
 }
 
+// ---- heterogeneous media: scene_medium.hxx:7-97 (bounds in the medium's local [0,1]^3 frame, trilinear density) ----
+ETX_DEV bool medium_bounds(const f3& in_pos, const f3& in_dir, float max_t, float& t_min, float& t_max) {  // :12-40
+  const float e = kEpsilon * 0.5f;
+  const float g3 = 1.0f + 2.0f * ((3.0f * e) / (1.0f - 3.0f * e));
+  const float pos[3] = {in_pos.x, in_pos.y, in_pos.z};
+  const float dir[3] = {in_dir.x, in_dir.y, in_dir.z};
+  t_min = 0.0f;
+  t_max = max_t;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float t_near = (0.0f - pos[i]) / dir[i];
+    float t_far = (1.0f - pos[i]) / dir[i];
+    if (t_near > t_far) {
+      float t = t_far;
+      t_far = t_near;
+      t_near = t;
+    }
+    t_far *= g3;
+    t_min = t_near > t_min ? t_near : t_min;
+    t_max = t_far < t_max ? t_far : t_max;
+    if (t_min > t_max)
+      return false;
+  }
+  return true;
+}
+
+ETX_DEV bool medium_intersects_bounds(const DMedium& m, const f3& in_pos, const f3& in_direction, float in_max_t, f3& medium_pos, f3& medium_dir, float& t_min, float& t_max) {  // :42-57
+  if (in_max_t >= kMaxFloat)
+    return false;
+  const f3 extent = m.bounds_max - m.bounds_min;
+  const f3 end_pos = in_pos + in_direction * in_max_t;
+  const f3 medium_end_pos = (end_pos - m.bounds_min) / extent;  // BoundingBox::to_local, math.hxx:581-583
+  medium_pos = (in_pos - m.bounds_min) / extent;
+  const f3 delta = medium_end_pos - medium_pos;
+  const float segment = length(delta);
+  medium_dir = delta / segment;
+  return medium_bounds(medium_pos, medium_dir, segment, t_min, t_max);
+}
+
+ETX_DEV float medium_sample_density(const DMedium& m, const f3& coord) {  // medium_sample_density_internal, :59-95
+  if ((coord.x < 0.0f) || (coord.y < 0.0f) || (coord.z < 0.0f) || (coord.x >= 1.0f) || (coord.y >= 1.0f) || (coord.z >= 1.0f))
+    return 0.0f;
+  const float px = fminf(fmaxf(coord.x * float(m.dim_x) - 0.5f, 0.0f), float(m.dim_x) - 1.0f);
+  const float py = fminf(fmaxf(coord.y * float(m.dim_y) - 0.5f, 0.0f), float(m.dim_y) - 1.0f);
+  const float pz = fminf(fmaxf(coord.z * float(m.dim_z) - 0.5f, 0.0f), float(m.dim_z) - 1.0f);
+  const uint32_t ix = min(m.dim_x - 1u, uint32_t(px)), nx = min(m.dim_x - 1u, ix + 1u);
+  const uint32_t iy = min(m.dim_y - 1u, uint32_t(py)), ny = min(m.dim_y - 1u, iy + 1u);
+  const uint32_t iz = min(m.dim_z - 1u, uint32_t(pz)), nz = min(m.dim_z - 1u, iz + 1u);
+  const uint32_t sy = m.dim_x, sz = m.dim_x * m.dim_y;
+  const float* density = m.density;
+  const float d000 = density[ix + iy * sy + iz * sz], d001 = density[nx + iy * sy + iz * sz];
+  const float d010 = density[ix + ny * sy + iz * sz], d011 = density[nx + ny * sy + iz * sz];
+  const float d100 = density[ix + iy * sy + nz * sz], d101 = density[nx + iy * sy + nz * sz];
+  const float d110 = density[ix + ny * sy + nz * sz], d111 = density[nx + ny * sy + nz * sz];
+  const float dx = px - floorf(px), dy = py - floorf(py), dz = pz - floorf(pz);
+  const float bottom = (d000 + (d001 - d000) * dx) + ((d010 + (d011 - d010) * dx) - (d000 + (d001 - d000) * dx)) * dy;
+  const float top = (d100 + (d101 - d100) * dx) + ((d110 + (d111 - d110) * dx) - (d100 + (d101 - d100) * dx)) * dy;
+  return bottom + (top - bottom) * dz;
+}
+
 // SpectralQuery::spectral_sample, spectrum.hxx:234-239
 ETX_DEV float spectral_sample_wavelength(float rnd) {
   const float offset = 0x1.35ce7a0000000p-5f;

@@ -412,13 +412,6 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     if (simple == false)
       out.simple_materials = false;
   }
-  for (uint64_t i = 0; i < scene->mediums.count; ++i) {
-    if (mediums[i].cls != 0) {
-      error = "heterogeneous media are not implemented by the device path";
-      return ETX_HIP_ERROR_UNSUPPORTED;
-    }
-  }
-
   DScene d = {};
   int rc = 0;
   if ((rc = upload(out, reinterpret_cast<const etx_abi_vertex*>(scene->vertices.a), scene->vertices.count, d.vertices, error)))
@@ -516,6 +509,15 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     dm.g = m.phase_function_g;
     dm.max_sigma = m.max_sigma;
     dm.dim_x = m.dimensions.x, dm.dim_y = m.dimensions.y, dm.dim_z = m.dimensions.z;
+    if (m.cls != 0) {  // heterogeneous: the density grid, normalised to [0, 1] by the host's MediumPool
+      const uint64_t cells = uint64_t(m.dimensions.x) * m.dimensions.y * m.dimensions.z;
+      if ((m.density.a == nullptr) || (m.density.count < cells) || (cells == 0)) {
+        error = "heterogeneous medium " + std::to_string(i) + " has no density grid";
+        return ETX_HIP_ERROR_INVALID_ARGUMENT;
+      }
+      if ((rc = upload(out, reinterpret_cast<const float*>(m.density.a), cells, dm.density, error)))
+        return rc;
+    }
   }
   if ((rc = upload(out, dmediums.data(), dmediums.size(), d.mediums, error)))
     return rc;

@@ -9,6 +9,7 @@ Run in the build container (needs /root/reference): python3 oracle/gen_golden.py
                    cornell_full_128_pt_bluenoise.npz                 reference CPUPathTracing, 64 spp, PTOptions defaults
                    cornell_{rough,glass}_128_{vcm,pt}.npz            all BSDF classes: reference CPUVCM 64 spp / CPUPathTracing 256 spp
                    cornell_{spectral,diamond,gems}_128_{vcm,pt}.npz  spectral mode: classic box / dispersive diamond + thinfilm / 2 892-triangle gems, VCM 64 spp, PT 256 spp
+                   cornell_cloud_128_{vcm,pt}.npz                    heterogeneous medium (procedural 32^3 density in the fog box)
   spectral         cie_observer.npz                                  spectrum::spectral_xyz of the reference (etx_hip_upload_cie_table)
   blue noise       bluenoise_64spp.npz                               the reference's sample_blue_noise for the 64-spp class,
                                                                      factorised by tools/bluenoise_tables.py (258 KiB instead of 32 MiB)
@@ -95,6 +96,20 @@ def spectral_golden():
                                 threads=np.int32(film["threads"]))
 
 
+def cloud_golden():
+    # heterogeneous medium (delta tracking / ratio tracking, scene_medium.hxx:191-239, 284-349): the fog box with a
+    # procedural 32^3 density grid injected by the oracle driver (the loader only reads .nvdb files and the tree has none)
+    snapshot = os.path.join(GOLDEN, "cornell_cloud_128.etxscene")
+    run("--scene", os.path.join(SCENES, "full_test_128.json"), "--inject-density", "32", "--integrator", "none", "--snapshot", snapshot)
+    for integrator, spp, extra in (("vcm", 64, ["--opt", "vcm-blue_noise=false"]), ("pt", 256, ["--opt", "bn=false"])):
+        film_path = "/tmp/golden_cloud_%s.raw" % integrator
+        run("--load-snapshot", snapshot, "--integrator", integrator, "--spp", str(spp), "--out", film_path, *extra)
+        film = film_io.read_film(film_path)
+        np.savez_compressed(os.path.join(GOLDEN, "cornell_cloud_128_%s.npz" % integrator), camera=film["camera"][..., :3], light=film["light"][..., :3],
+                            normal=film["normal"][..., :3], albedo=film["albedo"][..., :3], spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]),
+                            threads=np.int32(film["threads"]))
+
+
 def main():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "scenes", "make_scenes.py")])
     for flavour in ("classic", "full"):
@@ -111,6 +126,7 @@ def main():
     pt_golden()
     materials_golden()
     spectral_golden()
+    cloud_golden()
     with open(os.path.join(GOLDEN, "kat_reference.json"), "w") as f:
         subprocess.check_call([ORACLE, "--kat"], stdout=f)
 
@@ -124,5 +140,7 @@ if __name__ == "__main__":
         materials_golden()
     elif (len(sys.argv) > 1) and (sys.argv[1] == "spectral"):
         spectral_golden()
+    elif (len(sys.argv) > 1) and (sys.argv[1] == "cloud"):
+        cloud_golden()
     else:
         main()

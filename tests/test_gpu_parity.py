@@ -312,6 +312,25 @@ def test_spectral_mode_matches_reference(etx, golden_dir, flavour, cie_observer)
     integ.context.close()
 
 
+def test_heterogeneous_medium_matches_reference(etx, golden_dir):
+    """Fog box whose medium carries a 32^3 density grid: delta tracking in the shade kernels, ratio tracking in the
+    shadow kernel (scene_medium.hxx:191-239, 284-349) - the mechanism of BASELINE configs[4]."""
+    golden = np.load(os.path.join(golden_dir, "cornell_cloud_128_pt.npz"))
+    layers, stats = render_pt(etx, golden_dir, "cornell_cloud_128", int(golden["spp"]))
+    assert stats.overflow_flags == 0
+    compare_pt(layers, golden, 8.0e-3, 2.0e-2)
+    golden = np.load(os.path.join(golden_dir, "cornell_cloud_128_vcm.npz"))
+    cam, light, res, stats = render(etx, golden_dir, "cornell_cloud_128", int(golden["spp"]))
+    assert stats.overflow_flags == 0 and np.isfinite(res).all()
+    ref_result = np.maximum(golden["camera"] + golden["light"], 0.0)
+    ok = np.isfinite(ref_result).all(axis=2)
+    ref_result = np.where(ok[..., None], ref_result, 0.0)
+    res = np.where(ok[..., None], res[..., :3], 0.0)
+    assert rmse(block_mean(res, 32), block_mean(ref_result, 32)) < 8.0e-3
+    rel = (res.mean(axis=(0, 1)) - ref_result.mean(axis=(0, 1))) / ref_result.mean(axis=(0, 1))
+    assert np.abs(rel).max() < 2.0e-2, rel
+
+
 def test_pt_options_and_config1_size(etx, golden_dir):
     # configs[0]: 512 x 512, 16 spp. Size-independent properties + the option switches of CPUPathTracingImpl::start
     full, stats = render_pt(etx, golden_dir, "cornell_classic_512", 16)
