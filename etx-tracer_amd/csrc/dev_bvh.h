@@ -107,29 +107,33 @@ ETX_DEV bool triangle_test(const float4& v0, const float4& e1, const float4& e2,
 // wave-uniform address become s_load_dwordx4 into SGPRs, can be issued several triangles ahead and cost no VGPRs.
 typedef const __attribute__((address_space(4))) float* ConstantFloats;
 
-struct FlatTri {
-  float4 v0, e1, e2;
+struct FlatRow {  // one FlatPrim as it sits in SGPRs
+  float4 plane, row_a, row_b;
+  uint32_t flags, material;
 };
 
-ETX_DEV FlatTri load_flat_triangle(ConstantFloats table, uint32_t i) {
-  ConstantFloats t = table + i * 12u;
-  return {make_float4(t[0], t[1], t[2], t[3]), make_float4(t[4], t[5], t[6], t[7]), make_float4(t[8], t[9], t[10], t[11])};
+ETX_DEV FlatRow load_flat_prim(ConstantFloats table, uint32_t i) {
+  ConstantFloats t = table + i * 16u;
+  return {make_float4(t[0], t[1], t[2], t[3]), make_float4(t[4], t[5], t[6], t[7]), make_float4(t[8], t[9], t[10], t[11]), __float_as_uint(t[12]), __float_as_uint(t[13])};
 }
 
-// Test of one flat primitive: Moeller-Trumbore, the parallelogram drops the a + b <= 1 condition.
-ETX_DEV bool flat_prim_test(const FlatTri& prim, uint32_t flags, const RayQ& ray, float t_limit, float& out_a, float& out_b, float& out_t) {
-  const f3 E1 = {prim.e1.x, prim.e1.y, prim.e1.z}, E2 = {prim.e2.x, prim.e2.y, prim.e2.z};
-  const f3 pv = cross(ray.d, E2);
-  const float det = dot(E1, pv);
-  const float inv_det = __builtin_amdgcn_rcpf(det);
-  const f3 s = ray.o - f3{prim.v0.x, prim.v0.y, prim.v0.z};
-  const float a = dot(s, pv) * inv_det;
-  const f3 q = cross(s, E1);
-  const float b = dot(ray.d, q) * inv_det;
-  const float t = dot(E2, q) * inv_det;
+// Plane hit, then parallelogram coordinates of the hit point. A triangle needs a + b <= 1, a parallelogram a <= 1 and
+// b <= 1; the primitive kind is wave-uniform, so the two upper bounds become e = 1 - b - (quad ? 0 : a) >= 0 and
+// f = 1 - (quad ? a : 0) >= 0 and the four lower bounds fold into one v_min3 + v_min. A ray parallel to the plane gives
+// t = inf / nan, which fails the two explicit comparisons on t before the (NaN-dropping) minima matter.
+ETX_DEV bool flat_prim_test(const FlatRow& prim, const RayQ& ray, float t_limit, float& out_a, float& out_b, float& out_t) {
+  const float den = prim.plane.x * ray.d.x + prim.plane.y * ray.d.y + prim.plane.z * ray.d.z;
+  const float num = prim.plane.x * ray.o.x + prim.plane.y * ray.o.y + prim.plane.z * ray.o.z + prim.plane.w;
+  const float t = -num * __builtin_amdgcn_rcpf(den);
+  const f3 x = ray.o + ray.d * t;
+  const float a = prim.row_a.x * x.x + prim.row_a.y * x.y + prim.row_a.z * x.z + prim.row_a.w;
+  const float b = prim.row_b.x * x.x + prim.row_b.y * x.y + prim.row_b.z * x.z + prim.row_b.w;
+  const float quad = (prim.flags & kTriQuad) ? 1.0f : 0.0f;  // scalar
+  const float e = (1.0f - b) - (1.0f - quad) * a;
+  const float f = 1.0f - quad * a;
+  const float inside = fminf(fminf(fminf(a, b), e), f);
   out_a = a, out_b = b, out_t = t;
-  const float diagonal = (flags & kTriQuad) ? 2.0f : 1.0f;
-  return (det != 0.0f) && (a >= 0.0f) && (a <= 1.0f) && (b >= 0.0f) && (b <= 1.0f) && (a + b <= diagonal) && (t >= ray.tmin) && (t <= t_limit);
+  return (t >= ray.tmin) && (t <= t_limit) && (inside >= 0.0f);
 }
 
 // (primitive, a, b) -> (triangle, u, v)
@@ -143,7 +147,6 @@ ETX_DEV Hit flat_resolve(const DScene& scene, uint32_t prim, float a, float b, f
 
 template <class Tris>
 ETX_DEV Hit bvh_flat_closest(const DScene& scene, Tris, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags) {
-  static_assert(sizeof(BvhTri) == 48, "12 floats per primitive");
   float best_a = 0.0f, best_b = 0.0f, best_t = ray.tmax;
   uint32_t best_prim = kInvalid;
   uint32_t best_flags = 0u;
@@ -151,15 +154,15 @@ ETX_DEV Hit bvh_flat_closest(const DScene& scene, Tris, const RayQ& ray, uint32_
   ConstantFloats table = (ConstantFloats)(const void*)(scene.flat_prims);
 #pragma unroll 4
   for (uint32_t i = 0; i < count; ++i) {
-    const FlatTri prim = load_flat_triangle(table, i);
-    const uint32_t flags = __float_as_uint(prim.e1.w);
+    const FlatRow prim = load_flat_prim(table, i);
+    const uint32_t flags = prim.flags;
     float a, b, t;
-    if (flat_prim_test(prim, flags, ray, best_t, a, b, t) == false)
+    if (flat_prim_test(prim, ray, best_t, a, b, t) == false)
       continue;
     if (flags & kTriVoid)
       continue;
     // alpha-tested triangles are never merged into parallelograms: (a, b) are the triangle's own barycentrics
-    if ((flags & kTriAlphaTested) && alpha_test_skips(scene, scene.flat_info[i].tri_a, __float_as_uint(prim.e2.w), a, b, alpha_seed))
+    if ((flags & kTriAlphaTested) && alpha_test_skips(scene, scene.flat_info[i].tri_a, prim.material, a, b, alpha_seed))
       continue;
     best_a = a, best_b = b, best_t = t, best_prim = i;
     best_flags = flags;
@@ -281,15 +284,15 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
   ConstantFloats table = (ConstantFloats)(const void*)(scene.flat_prims);
 #pragma unroll 4
   for (uint32_t i = 0; i < count; ++i) {
-    const FlatTri tri = load_flat_triangle(table, i);
-    const uint32_t flags = __float_as_uint(tri.e1.w);
+    const FlatRow tri = load_flat_prim(table, i);
+    const uint32_t flags = tri.flags;
     float u, v, t;
-    if (flat_prim_test(tri, flags, ray, t_max, u, v, t) == false)
+    if (flat_prim_test(tri, ray, t_max, u, v, t) == false)
       continue;
     if (flags & kTriVoid)
       continue;
     const uint32_t tri_index = i;  // primitive index; both halves of a parallelogram share plane, winding and material
-    if ((flags & kTriAlphaTested) && alpha_test_skips(scene, scene.flat_info[i].tri_a, __float_as_uint(tri.e2.w), u, v, alpha_seed))
+    if ((flags & kTriAlphaTested) && alpha_test_skips(scene, scene.flat_info[i].tri_a, tri.material, u, v, alpha_seed))
       continue;
     if ((flags & kTriBoundary) == 0u) {
       occluded = true;

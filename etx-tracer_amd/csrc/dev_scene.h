@@ -41,6 +41,17 @@ enum : uint32_t {
 // parallelogram (same material, same filter flags, same winding - every wall of a Cornell box) are tested once as
 // P = v0 + a e1 + b e2 with a, b in [0, 1]. After the sweep the hit is handed back as (triangle, u, v) of the
 // reference's convention: u and v of the triangle on either side of the diagonal are affine in (a, b).
+// One primitive of the sweep, pre-transformed on the host: the plane (N . X + nd = 0) and the two rows that map a point
+// of the plane to the parallelogram coordinates (a = U . X + ud, b = V . X + vd). The per-ray test is 17 FMAs and one
+// reciprocal instead of the 31 of Moeller-Trumbore on (v0, e1, e2).
+struct __attribute__((aligned(16))) FlatPrim {
+  float4 plane;   // N.xyz (= e1 x e2), nd = -N . v0
+  float4 row_a;   // U.xyz = (e2 x N) / |N|^2, ud = -U . v0
+  float4 row_b;   // V.xyz = (N x e1) / |N|^2, vd = -V . v0
+  uint32_t flags, material, pad0, pad1;
+};
+static_assert(sizeof(FlatPrim) == 64, "FlatPrim");
+
 struct __attribute__((aligned(16))) FlatPrimInfo {
   uint32_t tri_a, tri_b;  // tri_b == kInvalid: a single triangle
   float ua[3], va[3];     // a + b <= 1: u = ua[0] + ua[1] a + ua[2] b, v likewise
@@ -97,7 +108,7 @@ struct DScene {
   const DMedium* mediums;
   const BvhNode* bvh_nodes;
   const BvhTri* bvh_tris;
-  const BvhTri* flat_prims;        // bvh_flat scenes: v0.w = primitive index, e1.w = flags, e2.w = material
+  const FlatPrim* flat_prims;      // bvh_flat scenes: pre-transformed primitives of the sweep
   const FlatPrimInfo* flat_info;   // per primitive
   uint32_t vertex_count, triangle_count, material_count, emitter_count, emitter_dist_count, spectrum_count, image_count, medium_count;
   uint32_t bvh_node_count, bvh_tri_count, flat_prim_count, pad_flat;

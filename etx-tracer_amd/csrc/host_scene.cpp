@@ -535,9 +535,33 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   d.bvh_node_count = uint32_t(bvh.nodes.size());
   d.bvh_tri_count = uint32_t(bvh.tris.size());
   if (bvh.tris.size() <= kFlatSweepMaxTriangles) {
-    std::vector<BvhTri> prims;
+    std::vector<BvhTri> edge_prims;
     std::vector<FlatPrimInfo> infos;
-    build_flat_prims(scene, bvh, prims, infos);
+    build_flat_prims(scene, bvh, edge_prims, infos);
+    // (v0, e1, e2) -> plane + the two coordinate rows, in double
+    std::vector<FlatPrim> prims(edge_prims.size());
+    for (size_t i = 0; i < edge_prims.size(); ++i) {
+      const BvhTri& t = edge_prims[i];
+      const double v0[3] = {t.v0_index.x, t.v0_index.y, t.v0_index.z}, e1[3] = {t.e1_flags.x, t.e1_flags.y, t.e1_flags.z}, e2[3] = {t.e2_mat.x, t.e2_mat.y, t.e2_mat.z};
+      auto cross3 = [](const double a[3], const double b[3], double r[3]) {
+        r[0] = a[1] * b[2] - a[2] * b[1], r[1] = a[2] * b[0] - a[0] * b[2], r[2] = a[0] * b[1] - a[1] * b[0];
+      };
+      auto dot3 = [](const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+      double n[3], u[3], v[3];
+      cross3(e1, e2, n);
+      const double nn = dot3(n, n);
+      cross3(e2, n, u);
+      cross3(n, e1, v);
+      FlatPrim& p = prims[i];
+      p = {};
+      if (nn > 0.0) {
+        p.plane = make_float4(float(n[0]), float(n[1]), float(n[2]), float(-dot3(n, v0)));
+        p.row_a = make_float4(float(u[0] / nn), float(u[1] / nn), float(u[2] / nn), float(-dot3(u, v0) / nn));
+        p.row_b = make_float4(float(v[0] / nn), float(v[1] / nn), float(v[2] / nn), float(-dot3(v, v0) / nn));
+      }  // a degenerate primitive keeps a zero plane: den = 0 -> never hit
+      memcpy(&p.flags, &t.e1_flags.w, 4);
+      memcpy(&p.material, &t.e2_mat.w, 4);
+    }
     if ((rc = upload(out, prims.data(), prims.size(), d.flat_prims, error)) || (rc = upload(out, infos.data(), infos.size(), d.flat_info, error)))
       return rc;
     d.flat_prim_count = uint32_t(prims.size());
