@@ -146,7 +146,7 @@ ETX_DEV Hit flat_resolve(const DScene& scene, uint32_t prim, float a, float b, f
 }
 
 template <class Tris>
-ETX_DEV Hit bvh_flat_closest(const DScene& scene, Tris, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags) {
+ETX_DEV Hit bvh_flat_closest(const DScene& scene, Tris, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags, uint32_t material_filter = kInvalid) {
   float best_a = 0.0f, best_b = 0.0f, best_t = ray.tmax;
   uint32_t best_prim = kInvalid;
   uint32_t best_flags = 0u;
@@ -160,6 +160,8 @@ ETX_DEV Hit bvh_flat_closest(const DScene& scene, Tris, const RayQ& ray, uint32_
     if (flat_prim_test(prim, ray, best_t, a, b, t) == false)
       continue;
     if (flags & kTriVoid)
+      continue;
+    if ((material_filter != kInvalid) && (prim.material != material_filter))  // trace_material, rt.cxx:342-345
       continue;
     // alpha-tested triangles are never merged into parallelograms: (a, b) are the triangle's own barycentrics
     if ((flags & kTriAlphaTested) && alpha_test_skips(scene, scene.flat_info[i].tri_a, prim.material, a, b, alpha_seed))
@@ -176,9 +178,10 @@ ETX_DEV Hit bvh_flat_closest(const DScene& scene, Tris, const RayQ& ray, uint32_
 
 // Closest accepted hit in [tmin, tmax]. `Nodes`/`Tris` are pointer types (global or LDS address space).
 template <class Nodes, class Tris>
-ETX_DEV Hit bvh_closest(const DScene& scene, Nodes nodes, Tris tris, int32_t root, const LaneStack& stack, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags) {
+ETX_DEV Hit bvh_closest(const DScene& scene, Nodes nodes, Tris tris, int32_t root, const LaneStack& stack, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags,
+  uint32_t material_filter = kInvalid) {
   if (scene.bvh_flat)
-    return bvh_flat_closest(scene, tris, ray, alpha_seed, out_flags);
+    return bvh_flat_closest(scene, tris, ray, alpha_seed, out_flags, material_filter);
   Hit best = {0.0f, 0.0f, ray.tmax, kInvalid};
   uint32_t best_flags = 0u;
   const f3 inv_d = {__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)};
@@ -219,6 +222,8 @@ ETX_DEV Hit bvh_closest(const DScene& scene, Nodes nodes, Tris tris, int32_t roo
           continue;
         uint32_t flags = __float_as_uint(e1.w);
         if (flags & kTriVoid)
+          continue;
+        if ((material_filter != kInvalid) && (__float_as_uint(e2.w) != material_filter))
           continue;
         uint32_t tri_index = __float_as_uint(v0.w);
         if ((flags & kTriAlphaTested) && alpha_test_skips(scene, tri_index, __float_as_uint(e2.w), u, v, alpha_seed))

@@ -34,6 +34,7 @@ void DeviceScene::borrow(const DeviceScene& owner) {
   film_w = owner.film_w, film_h = owner.film_h;
   bvh_depth = owner.bvh_depth;
   simple_materials = owner.simple_materials;
+  has_subsurface = owner.has_subsurface;
   generic_materials = owner.generic_materials;
   bvh_bytes = owner.bvh_bytes;
 }
@@ -364,6 +365,7 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   const auto* mediums = reinterpret_cast<const etx_abi_medium*>(scene->mediums.a);
   const auto* triangles = reinterpret_cast<const etx_abi_triangle*>(scene->triangles.a);
 
+  out.has_subsurface = false;
   // only materials that geometry references need a device implementation
   std::vector<bool> used(scene->materials.count, false);
   for (uint64_t i = 0; i < scene->triangles.count; ++i)
@@ -385,10 +387,12 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
       error = "spectral mode with RGB textures (apply_rgb upsampling, scene.hxx:250-270) is not implemented by the device path";
       return ETX_HIP_ERROR_UNSUPPORTED;
     }
-    if (m.subsurface.cls != 0) {
-      error = "subsurface scattering is not implemented by the device path";
+    if (m.subsurface.cls == 2u) {
+      error = "Christensen-Burley subsurface scattering (gather_cb, path_tracing_shared.hxx:161-232) is not implemented by the device path (random walk is)";
       return ETX_HIP_ERROR_UNSUPPORTED;
     }
+    if (m.subsurface.cls != 0u)
+      out.has_subsurface = true;
   }
   out.generic_materials = false;
   out.simple_materials = true;
@@ -409,7 +413,7 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     // "simple" = the shade kernels need neither the Heitz walk nor a sampler-dependent evaluation (dev_bsdf.h)
     const bool mirror_conductor = (m.cls == ETX_MAT_CONDUCTOR) && constant_roughness && (m.roughness.value.x == 0.0f) && (m.roughness.value.y == 0.0f) && (thin_film == false);
     const bool simple = lambert || (m.cls == ETX_MAT_TRANSLUCENT) || (m.cls == ETX_MAT_MIRROR) || (m.cls == ETX_MAT_BOUNDARY) || (m.cls == ETX_MAT_VOID) || mirror_conductor;
-    if (simple == false)
+    if ((simple == false) || (m.subsurface.cls != 0u))
       out.simple_materials = false;
   }
   DScene d = {};

@@ -23,6 +23,7 @@ struct DeviceScene {
   uint32_t film_w = 0, film_h = 0;
   uint32_t bvh_depth = 0;
   bool simple_materials = false;   // only Diffuse / Translucent / Mirror / Boundary / Void / roughness-0 Conductor in use (dev_bsdf.h)
+  bool has_subsurface = false;     // a random-walk subsurface material is in use (PT only so far)
   bool generic_materials = false;  // a connectible (non delta) surface material other than Diffuse is in use
   size_t bvh_bytes = 0;
 

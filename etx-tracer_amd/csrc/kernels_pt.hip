@@ -86,6 +86,83 @@ __global__ __launch_bounds__(kBlockSize) void k_pt_generate(Pipeline p, VcmParam
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Random-walk subsurface scattering: subsurface::remap_channel (scene_bssrdf_subsurface.hxx:17-44) and
+// subsurface::gather_rw (path_tracing_shared.hxx:64-159). The walk runs inside the shade kernel with an inline
+// material-filtered closest-hit query (Raytracing::trace_material, rt.cxx:327-371) until it leaves the object.
+ETX_DEV void sss_remap_channel(float color, float scattering_distance, float& albedo, float& extinction, float& scattering) {
+  const float a = 1.826052378200f, b = 4.985111943850f + 0.12735595943800f, c = 1.096861024240f;
+  const float d = 0.496310210422f, e = 4.231902997010f + 0.00310603949088f, f = 2.406029994080f;
+  const float kMinScattering = 1.0f / 1024.0f;
+  color = fmaxf(0.0f, color);
+  const float blend = powf(color, 0.25f);
+  albedo = (1.0f - blend) * a * powf(atanf(b * color), c) + blend * d * powf(atanf(e * color), f);
+  albedo = fminf(fmaxf(albedo, 0.0f), 1.0f - kEpsilon);
+  extinction = 1.0f / fmaxf(scattering_distance, kMinScattering);
+  scattering = extinction * albedo;
+}
+
+ETX_DEV float sss_safe_mul(float a, float b) {  // path_tracing_shared.hxx:51-53
+  return ((a == 0.0f) || (b == 0.0f)) ? 0.0f : a * b;
+}
+
+ETX_DEV bool sss_gather_rw(const DScene& scene, const LaneStack& stack, const Isect& in, Sampler& smp, float wavelength, Isect& out, f3& out_weight) {
+  const uint32_t kMaxIterations = 1024u;
+  const etx_abi_material& mat = scene.materials[in.material];
+  float anisotropy = 0.0f;
+  f3 extinction, scattering, albedo;
+  if (mat.int_medium == kInvalid) {
+    const f3 color = apply_image(scene, mat.scattering, in.tex, nullptr, wavelength);
+    const etx_abi_spectral_image distances_image = {mat.subsurface.spectrum_index, mat.subsurface.image_index};
+    const f3 distances = apply_image(scene, distances_image, in.tex, nullptr, wavelength);
+    sss_remap_channel(color.x, distances.x, albedo.x, extinction.x, scattering.x);
+    sss_remap_channel(color.y, distances.y, albedo.y, extinction.y, scattering.y);
+    sss_remap_channel(color.z, distances.z, albedo.z, extinction.z, scattering.z);
+  } else {
+    const DMedium& medium = scene.mediums[mat.int_medium];
+    anisotropy = medium.g;
+    f3 absorption;
+    medium_coefficients(scene, medium, wavelength, absorption, scattering);
+    extinction = scattering + absorption;
+    albedo = {extinction.x > 0.0f ? scattering.x / extinction.x : 0.0f, extinction.y > 0.0f ? scattering.y / extinction.y : 0.0f, extinction.z > 0.0f ? scattering.z / extinction.z : 0.0f};
+  }
+  f3 ray_d = (mat.subsurface.path == 0u) ? sample_cosine_distribution(smp.next_2d(), -in.nrm, 1.0f) : in.w_i;  // Path::Diffuse
+  f3 ray_o = shading_pos(scene, scene.triangles[in.tri], in.bc, ray_d);
+  f3 throughput = mk3(1.0f);
+  uint32_t alpha_seed = smp.seed ^ 0x73737321u;
+  for (uint32_t i = 0; i < kMaxIterations; ++i) {
+    f3 pdf;
+    const uint32_t channel = sample_spectrum_component(albedo, throughput, smp.next(), pdf);
+    const float scattering_distance = channel == 0 ? extinction.x : (channel == 1 ? extinction.y : extinction.z);
+    float max_t = scattering_distance > 0.0f ? (-logf(1.0f - smp.next()) / scattering_distance) : kMaxFloat;
+    if ((i == 0u) && (max_t <= kRayEpsilon))
+      return false;
+    const Hit h = bvh_closest(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, RayQ{ray_o, kRayEpsilon, ray_d, max_t}, alpha_seed, nullptr, in.material);
+    const bool found = h.tri != kInvalid;
+    if (found)
+      max_t = h.t;
+    const f3 tr = {expf(-max_t * extinction.x), expf(-max_t * extinction.y), expf(-max_t * extinction.z)};
+    pdf = found ? pdf * tr : pdf * f3{sss_safe_mul(tr.x, extinction.x), sss_safe_mul(tr.y, extinction.y), sss_safe_mul(tr.z, extinction.z)};
+    if (is_zero(pdf))
+      return false;
+    const f3 weight = found ? tr : f3{sss_safe_mul(tr.x, scattering.x), sss_safe_mul(tr.y, scattering.y), sss_safe_mul(tr.z, scattering.z)};
+    throughput *= weight / (pdf.x + pdf.y + pdf.z);
+    if (max_component(throughput) <= kEpsilon)
+      return false;
+    if (found) {
+      out = make_intersection(scene, ray_d, h.u, h.v, h.t, h.tri);
+      const bool w_i_in = dot(out.w_i, out.nrm) > 0.0f;
+      out.w_i = out.w_i * (w_i_in ? -1.0f : 1.0f);
+      out_weight = throughput;
+      return true;
+    }
+    const f3 prev_dir = ray_d;
+    ray_o = ray_o + ray_d * max_t;
+    ray_d = sample_phase_function(prev_dir, anisotropy, smp.next_2d());
+  }
+  return false;
+}
+
 struct PtRequests {
   ShadowRequest direct, nee;
   bool has_direct, has_nee;
@@ -93,7 +170,7 @@ struct PtRequests {
 
 // run_path_iteration after rt.trace, path_tracing_shared.hxx:479-508
 template <bool kSimple>
-ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, PtRequests& out) {
+ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, PtRequests& out, const LaneStack& stack) {
   const bool opt_direct = (it.options & ETX_PT_DIRECT) != 0u, opt_nee = (it.options & ETX_PT_NEE) != 0u, opt_mis = (it.options & ETX_PT_MIS) != 0u;
   if (st.depth > scene.max_path_length)
     return false;
@@ -208,6 +285,15 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
   st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
   const BsdfSample bs = bsdf_sample_s<kSimple>(scene, bsdf_data, mat, st.sampler);
   st.sampler.pop_fixed();
+  // path_tracing_shared.hxx:391-408: a diffuse reflection off a subsurface material enters the object instead
+  bool subsurface_sampled = false;
+  Isect ss_isect;
+  f3 ss_weight = mk3(0.0f);
+  if ((kSimple == false) && (mat.subsurface.cls != 0u) && (bs.properties & kSampleReflection) && (bs.properties & kSampleDiffuse)) {
+    subsurface_sampled = sss_gather_rw(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight);
+    if (subsurface_sampled == false)
+      return false;
+  }
   if (bs.valid() == false)
     return false;
   if (bs.properties & kSampleMediumChanged)
@@ -216,27 +302,39 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
   if (opt_nee && (st.depth + 1u <= scene.max_path_length)) {  // :409-431 + evaluate_light :300-321
     st.sampler.push_fixed(rnd_em_sample.x, rnd_em_sample.y, rnd_support.x);
     const uint32_t emitter_index = sample_emitter_index(scene, rnd_support.y);
-    const EmitterSample es = sample_emitter(scene, emitter_index, rnd_em_sample, isect.pos, st.wavelength);
+    // :414-421: after a subsurface walk the light is gathered at the exit point through scene.subsurface_exit_material
+    const Isect& nee_isect = subsurface_sampled ? ss_isect : isect;
+    const etx_abi_material& nee_mat = subsurface_sampled ? scene.materials[scene.subsurface_exit_material] : mat;
+    const f3 nee_scale = subsurface_sampled ? ss_weight : mk3(1.0f);
+    const EmitterSample es = sample_emitter(scene, emitter_index, rnd_em_sample, nee_isect.pos, st.wavelength);
     if (es.pdf_dir != 0.0f) {
-      bsdf_data.medium = st.medium;
-      const BsdfEval eval = bsdf_evaluate_s<kSimple>(scene, bsdf_data, es.direction, mat, st.sampler);
+      BsdfData nee_data = make_bsdf_data(nee_isect, nee_isect.w_i, st.medium, kPathCamera, st.wavelength);
+      const BsdfEval eval = bsdf_evaluate_s<kSimple>(scene, nee_data, es.direction, nee_mat, st.sampler);
       if (eval.valid()) {
-        const f3 pos = shading_pos(scene, tri, isect.bc, es.direction);
+        const f3 pos = shading_pos(scene, scene.triangles[nee_isect.tri], nee_isect.bc, es.direction);
         const bool no_weight = (opt_mis == false) || es.is_delta;
         const float weight = no_weight ? 1.0f : power_heuristic(es.pdf_dir * es.pdf_sample, eval.pdf);
-        out.nee = {pos, es.origin, st.throughput * eval.bsdf * es.value * (weight / (es.pdf_dir * es.pdf_sample)) * film_weight, st.medium, film_target, st.wavelength};
+        out.nee = {pos, es.origin, st.throughput * nee_scale * eval.bsdf * es.value * (weight / (es.pdf_dir * es.pdf_sample)) * film_weight, st.medium, film_target, st.wavelength};
         out.has_nee = true;
       }
     }
     st.sampler.pop_fixed();
   }
 
-  st.throughput *= bs.weight;
-  st.d_vcm = bs.pdf;
-  st.flags = bs.is_delta() ? (st.flags & ~kPtMisWeight) : (st.flags | kPtMisWeight);
-  st.eta *= bs.eta;
-  st.ray_d = bs.w_o;
-  st.ray_o = shading_pos(scene, tri, isect.bc, st.ray_d);
+  if (subsurface_sampled) {  // :433-439
+    st.ray_d = sample_cosine_distribution(rnd_bsdf, ss_isect.nrm, 1.0f);
+    st.throughput *= ss_weight;  // weights[selected] * selected_sample_weight (= 1 for the random walk)
+    st.d_vcm = fabsf(dot(st.ray_d, ss_isect.nrm)) / kPi;
+    st.flags |= kPtMisWeight;
+    st.ray_o = shading_pos(scene, scene.triangles[ss_isect.tri], ss_isect.bc, st.ray_d);
+  } else {
+    st.throughput *= bs.weight;
+    st.d_vcm = bs.pdf;
+    st.flags = bs.is_delta() ? (st.flags & ~kPtMisWeight) : (st.flags | kPtMisWeight);
+    st.eta *= bs.eta;
+    st.ray_d = bs.w_o;
+    st.ray_o = shading_pos(scene, tri, isect.bc, st.ray_d);
+  }
   if (is_zero(st.throughput))
     return false;
   st.ray_tmax = kMaxFloat;
@@ -249,6 +347,8 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
 template <bool kSimple>
 __global__ __launch_bounds__(kBlockSize) void k_pt_shade(Pipeline p, VcmParams it, uint32_t in_set) {
   __shared__ BlockScratch s_scratch;
+  __shared__ int32_t s_stack[kSimple ? 1 : kStackDepth * kBlockSize];  // the subsurface walk traverses inline (general materials only)
+  const LaneStack stack = {s_stack + (kSimple ? 0u : threadIdx.x), kBlockSize};
   const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const PathSet& out = p.paths[in_set ^ 1u];
@@ -262,7 +362,7 @@ __global__ __launch_bounds__(kBlockSize) void k_pt_shade(Pipeline p, VcmParams i
     bool alive = false;
     if (i < count) {
       st = load_path(in, i);
-      alive = pt_step<kSimple>(p, scene, it, st, p.hits[i], requests);
+      alive = pt_step<kSimple>(p, scene, it, st, p.hits[i], requests, stack);
     }
     const uint32_t direct_slot = slots.get(requests.has_direct, p.counters + kCntShadow);
     if (requests.has_direct)

@@ -431,6 +431,26 @@ two_sided 1
 """ + MTL_LIGHT_CLASSIC)
     write_json("gems_test_128.json", "cornell_gems.obj", "cornell_gems.mtl", (128, 128), 64, spectral=True)
     write_json("gems_c3_1080p.json", "cornell_gems.obj", "cornell_gems.mtl", (1920, 1080), 64, spectral=True)
+    # random-walk subsurface scattering (the material family of BASELINE configs[3]): a waxy short box, a tall box whose walk
+    # starts along the refracted direction of a plastic coat
+    with open(os.path.join(OUT, "cornell_sss.mtl"), "w") as f:
+        f.write(MTL_COMMON.split("newmtl shortBox")[0] + """newmtl shortBox
+material class diffuse
+Kd 0.900 0.750 0.550
+subsurface distances 0.30 0.15 0.08 scale 0.5
+two_sided 1
+
+newmtl tallBox
+material class plastic
+Kd 0.550 0.750 0.900
+Ks 1.000 1.000 1.000
+int_ior 1.5
+Pr 0.300
+subsurface path refracted distances 0.10 0.20 0.40 scale 0.5
+two_sided 1
+
+""" + MTL_LIGHT_CLASSIC)
+    write_json("sss_test_128.json", "cornell_classic.obj", "cornell_sss.mtl", (128, 128), 64)
     write_json("spectral_test_128.json", "cornell_classic.obj", "cornell_classic.mtl", (128, 128), 64, spectral=True)
     write_json("diamond_test_128.json", "cornell_classic.obj", "cornell_diamond.mtl", (128, 128), 64, spectral=True)
 
