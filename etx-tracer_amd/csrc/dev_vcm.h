@@ -5,6 +5,7 @@
 #include "dev_bvh.h"
 #include "dev_bsdf.h"
 #include "dev_emitters.h"
+#include "dev_sss.h"
 #include "pipeline.h"
 
 namespace etxd {
@@ -201,7 +202,8 @@ ETX_DEV void write_shadow(const Pipeline& p, uint32_t idx, const ShadowRequest& 
 
 // vcm_shared.hxx:218-283 vcm_next_ray
 template <bool kSimple>
-ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& st, const VcmParams& it, const Isect& isect, const BsdfData& bsdf_data, const BsdfSample& bs) {
+ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& st, const VcmParams& it, const Isect& isect, const BsdfData& bsdf_data, const BsdfSample& bs,
+  bool subsurface_sample = false) {
   if (st.depth + 1 > scene.max_path_length)
     return false;
   if (bs.valid() == false)
@@ -223,7 +225,8 @@ ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& 
     st.d_vm *= cos_theta_bsdf;
     st.d_vcm = 0.0f;
   } else {
-    float rev_pdf = bsdf_reverse_pdf_s<kSimple>(scene, bsdf_data, bs.w_o, mat, st.sampler);
+    // vcm_shared.hxx:259-261: after a subsurface walk the reverse pdf is the cosine lobe of the exit point
+    float rev_pdf = subsurface_sample ? (fabsf(dot(bsdf_data.w_i, isect.nrm)) / kPi) : bsdf_reverse_pdf_s<kSimple>(scene, bsdf_data, bs.w_o, mat, st.sampler);
     st.d_vc = (cos_theta_bsdf / bs.pdf) * (st.d_vc * rev_pdf + st.d_vcm + it.vm_weight);
     st.d_vm = (cos_theta_bsdf / bs.pdf) * (st.d_vm * rev_pdf + st.d_vcm * it.vc_weight + 1.0f);
     st.d_vcm = 1.0f / bs.pdf;
@@ -551,7 +554,8 @@ ETX_DEV CameraVertex load_camera_vertex(const Pipeline& p, const DScene& scene, 
   cv.st.ray_d = {w.x, w.y, w.z};
   cv.st.medium = __float_as_uint(w.w);
   cv.st.throughput = {t.x, t.y, t.z};
-  cv.st.depth = __float_as_uint(t.w);
+  const uint32_t depth_bits = __float_as_uint(t.w);
+  cv.st.depth = depth_bits & 0x7fffffffu;
   cv.st.d_vcm = m.x, cv.st.d_vc = m.y, cv.st.d_vm = m.z;
   cv.st.id = __float_as_uint(m.w);
   cv.st.sampler.seed = p.cv.seed[i];
@@ -564,6 +568,8 @@ ETX_DEV CameraVertex load_camera_vertex(const Pipeline& p, const DScene& scene, 
   cv.medium_pos = {h.x, h.y, h.z};
   if (cv.at_medium == false)
     cv.isect = make_intersection(scene, cv.st.ray_d, h.x, h.y, h.z, tri);
+  if ((cv.at_medium == false) && (depth_bits & kCvExitMaterialBit))
+    cv.isect.material = scene.subsurface_exit_material;  // exit point of a subsurface walk (vcm_shared.hxx:1037-1038)
   return cv;
 }
 

@@ -29,14 +29,15 @@ ETX_DEV void store_light_vertex(const Pipeline& p, uint32_t idx, const PathState
 }
 
 
-ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& scene, const PathState& st, const float4& hit_or_pos, uint32_t seed, const Isect* isect) {
+ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& scene, const PathState& st, const float4& hit_or_pos, uint32_t seed, const Isect* isect,
+  bool exit_material = false) {
   if (idx >= p.capacity) {  // only the tail kernel can exceed one vertex per path slot
     atomicOr(p.counters + kCntOverflow, kOverflowCameraVertices);
     return;
   }
   p.cv.hit[idx] = hit_or_pos;
   p.cv.wi_medium[idx] = mk4(st.ray_d, __uint_as_float(st.medium));
-  p.cv.thr_depth[idx] = mk4(st.throughput, __uint_as_float(st.depth));
+  p.cv.thr_depth[idx] = mk4(st.throughput, __uint_as_float(st.depth | (exit_material ? kCvExitMaterialBit : 0u)));
   p.cv.mis_pixel[idx] = make_float4(st.d_vcm, st.d_vc, st.d_vm, __uint_as_float(st.id));
   p.cv.seed[idx] = seed;
   p.cv.wavelength[idx] = st.wavelength;
@@ -69,7 +70,7 @@ enum : uint32_t { kEventNone = 0, kEventMedium = 1, kEventSurface = 2, kEventBou
 // workgroup-uniform control flow (lanes without a path pass valid = false) and reserve once per workgroup, so the
 // reservation points sit outside every data-dependent branch.
 template <bool kSimple, class Slots>
-ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots) {
+ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots, const LaneStack& stack) {
   const uint32_t tri = __float_as_uint(h.w);
   const bool found = valid && (tri != kInvalid);
   Isect isect;
@@ -96,6 +97,9 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
   BsdfData bsdf_data;
   BsdfSample bs;
   bool store = false, connect = false;
+  bool subsurface_path = false, subsurface_sampled = false;
+  Isect ss_isect;
+  f3 ss_weight = mk3(0.0f);
   if (scatter_event) {
     // both branches draw the same six numbers (vcm_shared.hxx:1099-1101, 1185-1187)
     rnd_bsdf = st.sampler.next_2d();
@@ -122,6 +126,12 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
       st.path_distance = 0.0f;
       store = (bs.properties & kSampleDelta) == 0u;  // is_connectible
       connect = store && opt_connect_to_camera(it) && (st.depth + 1 <= scene.max_path_length);
+      // vcm_shared.hxx:1198-1200: a diffuse sample on a subsurface material walks through the object
+      if ((kSimple == false) && (bs.properties & kSampleDiffuse) && (mat.subsurface.cls != 0u)) {
+        subsurface_path = true;
+        subsurface_sampled = sss_gather_rw(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight);
+        ss_isect.material = scene.subsurface_exit_material;
+      }
     }
   }
 
@@ -137,7 +147,14 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
   bool queue = false;
   if (connect) {
     st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-    queue = vcm_connect_to_camera<kSimple>(scene, it, at_medium, &isect, ms.pos, st, request);
+    if (subsurface_sampled) {  // vcm_shared.hxx:1208-1222: from the exit point, through the exit material, scaled by the walk
+      PathState scaled = st;
+      scaled.throughput = st.throughput * ss_weight;
+      queue = vcm_connect_to_camera<kSimple>(scene, it, false, &ss_isect, ms.pos, scaled, request);
+      st.sampler = scaled.sampler;
+    } else {  // also when the walk failed: the reference connects the entry vertex, then ends the path (:1223-1231, 1249-1251)
+      queue = vcm_connect_to_camera<kSimple>(scene, it, at_medium, &isect, ms.pos, st, request);
+    }
     st.sampler.pop_fixed();
   }
   const uint32_t shadow_slot = slots.get(queue, p.counters + kCntShadow);
@@ -165,6 +182,18 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
     st.depth += 1u;
     return (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
   }
+  if (subsurface_path && (subsurface_sampled == false))
+    return false;
+  if (subsurface_sampled) {  // vcm_shared.hxx:1237-1247
+    st.throughput *= ss_weight;
+    bs.w_o = sample_cosine_distribution(rnd_bsdf, ss_isect.nrm, 1.0f);
+    bs.pdf = fabsf(dot(bs.w_o, ss_isect.nrm)) / kPi;
+    bs.eta = 1.0f;
+    bsdf_data = make_bsdf_data(ss_isect, ss_isect.w_i, st.medium, kPathLight, st.wavelength);
+    if (vcm_next_ray<kSimple>(scene, kPathLight, st, it, ss_isect, bsdf_data, bs, true))
+      return st.depth + 1u < scene.max_path_length;
+    return false;
+  }
   if (vcm_next_ray<kSimple>(scene, kPathLight, st, it, isect, bsdf_data, bs))
     return st.depth + 1u < scene.max_path_length;
   return false;
@@ -174,7 +203,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
 // vertices go to the camera vertex pool (k_expand_pairs / k_connect_pairs / k_merge consume them), NEE segments go to
 // the shadow queue, direct / miss radiance goes straight to the film. Same three-phase shape as light_step.
 template <bool kSimple, class Slots>
-ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots) {
+ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots, const LaneStack& stack) {
   const uint32_t tri = __float_as_uint(h.w);
   const bool found = valid && (tri != kInvalid);
   Isect isect;
@@ -208,6 +237,9 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
   f3 w_o_medium = mk3(0.0f);
   float pdf_fwd = 0.0f, pdf_rev = 0.0f;
   bool store = false, nee = false;
+  bool subsurface_path = false, subsurface_sampled = false;
+  Isect ss_isect;
+  f3 ss_weight = mk3(0.0f);
   if (scatter_event) {
     // vcm_shared.hxx:936-938, 1013-1015: six numbers from the path's sampler ...
     rnd_bsdf = st.sampler.next_2d();
@@ -251,6 +283,12 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       }
       nee = is_connectible;
       store = is_connectible && (opt_connect_vertices(it) || (opt_merge_vertices(it) && (st.depth + 1 <= scene.max_path_length)));
+      // vcm_shared.hxx:1032-1034
+      if ((kSimple == false) && (bs.properties & kSampleDiffuse) && (mat.subsurface.cls != 0u)) {
+        subsurface_path = true;
+        subsurface_sampled = sss_gather_rw(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight);
+        ss_isect.material = scene.subsurface_exit_material;
+      }
     }
     if (p.debug_flags & 0x100u)  // timing experiments (ETX_HIP_DEBUG_FLAGS)
       nee = false;
@@ -263,16 +301,31 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
   if (store) {
     Sampler derived;
     derived.init(st.sampler.seed, 0x51ed270bu);
-    if (at_medium)
+    if (at_medium) {
       store_camera_vertex(p, vertex_slot, scene, st, mk4(ms.pos, __uint_as_float(kInvalid)), derived.seed, nullptr);
-    else
+    } else if (subsurface_sampled) {
+      // vcm_shared.hxx:1036-1046: connections and the merge happen at the exit point, through the exit material, with the
+      // walk's weight folded into the throughput
+      PathState scaled = st;
+      scaled.throughput = st.throughput * ss_weight;
+      scaled.ray_d = ss_isect.w_i;
+      store_camera_vertex(p, vertex_slot, scene, scaled, make_float4(ss_isect.bc.y, ss_isect.bc.z, ss_isect.t, __uint_as_float(ss_isect.tri)), derived.seed, &ss_isect, true);
+    } else {
       store_camera_vertex(p, vertex_slot, scene, st, h, derived.seed, &isect);
+    }
   }
   ShadowRequest request;
   bool queue = false;
   if (nee) {
     st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-    queue = vcm_connect_to_light<kSimple>(scene, it, at_medium, &isect, ms.pos, st, film_index(it, st.id), request);
+    if (subsurface_sampled) {
+      PathState scaled = st;
+      scaled.throughput = st.throughput * ss_weight;
+      queue = vcm_connect_to_light<kSimple>(scene, it, false, &ss_isect, ms.pos, scaled, film_index(it, st.id), request);
+      st.sampler = scaled.sampler;
+    } else {
+      queue = vcm_connect_to_light<kSimple>(scene, it, at_medium, &isect, ms.pos, st, film_index(it, st.id), request);
+    }
     st.sampler.pop_fixed();
   }
   const uint32_t shadow_slot = slots.get(queue, p.counters + kCntShadow);
@@ -294,6 +347,16 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
     st.ray_tmin = kRayEpsilon;
     st.depth += 1u;
     return (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
+  }
+  if (subsurface_path && (subsurface_sampled == false))
+    return false;
+  if (subsurface_sampled) {  // vcm_shared.hxx:1049-1061
+    st.throughput *= ss_weight;
+    bs.w_o = sample_cosine_distribution(rnd_bsdf, ss_isect.nrm, 1.0f);
+    bs.pdf = fabsf(dot(bs.w_o, ss_isect.nrm)) / kPi;
+    bs.eta = 1.0f;
+    bsdf_data = make_bsdf_data(ss_isect, ss_isect.w_i, st.medium, kPathCamera, st.wavelength);
+    return vcm_next_ray<kSimple>(scene, kPathCamera, st, it, ss_isect, bsdf_data, bs, true);
   }
   return vcm_next_ray<kSimple>(scene, kPathCamera, st, it, isect, bsdf_data, bs);
 }

@@ -832,10 +832,6 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
       context->error = "VCM expects etx_abi_vcm_options (32 bytes)";
       return ETX_HIP_ERROR_INVALID_ARGUMENT;
     }
-    if (context->scene.has_subsurface) {
-      context->error = "subsurface scattering in VCM (vcm_shared.hxx:1024-1070, 1198-1240) is not implemented by the device path yet; the path tracer supports the random walk";
-      return ETX_HIP_ERROR_UNSUPPORTED;
-    }
     memcpy(&context->vcm_options, options, sizeof(etx_abi_vcm_options));
     context->active_bluenoise = nullptr;
     if (context->vcm_options.blue_noise) {

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(kBlockSize) void k_connect_pairs(Pipeline p, VcmPar
       const uint2 pair = p.pairs[i];
       LightVertex lv = load_light_vertex(p.lv, pair.y);
       const uint32_t cam_tri = __float_as_uint(p.cv.hit[pair.x].w);
-      bool all_diffuse = ((cam_tri == kInvalid) || material_is_diffuse(scene, cam_tri)) && (lv.is_medium() || material_is_diffuse(scene, lv.tri));
+      const bool cam_exit = (__float_as_uint(p.cv.thr_depth[pair.x].w) & kCvExitMaterialBit) != 0u;  // subsurface exit point: white Lambert
+      bool all_diffuse = ((cam_tri == kInvalid) || cam_exit || material_is_diffuse(scene, cam_tri)) && (lv.is_medium() || material_is_diffuse(scene, lv.tri));
       if (all_diffuse == kDiffuseOnly) {
         CameraVertex cv = load_camera_vertex(p, scene, pair.x);
         const uint32_t target_path_length = cv.st.depth + lv.index_in_path + 2u;  // vcm_shared.hxx:774

@@ -110,6 +110,8 @@ __global__ __launch_bounds__(kBlockSize) ETX_LIGHT_ATTR void k_light_shade(Pipel
   const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
   uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
   __shared__ BlockScratch s_scratch;
+  __shared__ int32_t s_stack[kSimple ? 1 : kStackDepth * kBlockSize];  // inline traversal of the subsurface walk (general materials only)
+  const LaneStack stack = {s_stack + (kSimple ? 0u : threadIdx.x), kBlockSize};
   const BlockSlots slots = {&s_scratch};
   ETX_BLOCK_LOOP(count, i) {
     const bool valid = i < count;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(kBlockSize) ETX_LIGHT_ATTR void k_light_shade(Pipel
       st = load_path(in, i);
       h = p.hits[i];
     }
-    const bool alive = light_step<kSimple>(p, scene, it, st, h, valid, slots);
+    const bool alive = light_step<kSimple>(p, scene, it, st, h, valid, slots, stack);
     const uint32_t slot = slots.get(alive, out_counter);
     if (alive)
       store_path(out, slot, st);
@@ -190,6 +192,8 @@ __global__ __launch_bounds__(kBlockSize) ETX_CAM_ATTR void k_camera_shade(Pipeli
   const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
   uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
   __shared__ BlockScratch s_scratch;
+  __shared__ int32_t s_stack[kSimple ? 1 : kStackDepth * kBlockSize];  // inline traversal of the subsurface walk (general materials only)
+  const LaneStack stack = {s_stack + (kSimple ? 0u : threadIdx.x), kBlockSize};
   const BlockSlots slots = {&s_scratch};
   ETX_BLOCK_LOOP(count, i) {
     const bool valid = i < count;
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(kBlockSize) ETX_CAM_ATTR void k_camera_shade(Pipeli
       st = load_path(in, i);
       h = p.hits[i];
     }
-    const bool alive = camera_step<kSimple>(p, scene, it, st, h, valid, slots);
+    const bool alive = camera_step<kSimple>(p, scene, it, st, h, valid, slots, stack);
     const uint32_t slot = slots.get(alive, out_counter);
     if (alive)
       store_path(out, slot, st);

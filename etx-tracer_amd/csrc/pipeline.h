@@ -83,6 +83,7 @@ struct CameraVertexPool {  // connectible camera vertices of the current bounce 
 };
 
 enum : uint32_t { kCvDiffuse = 1u << 0, kCvMedium = 1u << 1 };
+constexpr uint32_t kCvExitMaterialBit = 0x80000000u;  // in thr_depth.w: the vertex is the exit point of a subsurface walk, material = scene.subsurface_exit_material
 
 struct ShadowQueue {        // transmittance ("shadow") ray requests of the current bounce: 48 B in, film atomics out
   float4* p0_medium;       // segment start, medium index bits at the start

@@ -10,7 +10,7 @@ Run in the build container (needs /root/reference): python3 oracle/gen_golden.py
                    cornell_{rough,glass}_128_{vcm,pt}.npz            all BSDF classes: reference CPUVCM 64 spp / CPUPathTracing 256 spp
                    cornell_{spectral,diamond,gems}_128_{vcm,pt}.npz  spectral mode: classic box / dispersive diamond + thinfilm / 2 892-triangle gems, VCM 64 spp, PT 256 spp
                    cornell_cloud_128_{vcm,pt}.npz                    heterogeneous medium (procedural 32^3 density in the fog box)
-                   cornell_sss_128_pt.npz                            random-walk subsurface scattering, CPUPathTracing 256 spp
+                   cornell_sss_128_{vcm,pt}.npz                      random-walk subsurface scattering, CPUVCM 64 spp / CPUPathTracing 256 spp
   spectral         cie_observer.npz                                  spectrum::spectral_xyz of the reference (etx_hip_upload_cie_table)
   blue noise       bluenoise_64spp.npz                               the reference's sample_blue_noise for the 64-spp class,
                                                                      factorised by tools/bluenoise_tables.py (258 KiB instead of 32 MiB)
@@ -115,11 +115,13 @@ def sss_golden():
     # random-walk subsurface scattering in the path tracer (path_tracing_shared.hxx:64-159, 391-439)
     snapshot = os.path.join(GOLDEN, "cornell_sss_128.etxscene")
     run("--scene", os.path.join(SCENES, "sss_test_128.json"), "--integrator", "none", "--snapshot", snapshot)
-    film_path = "/tmp/golden_sss_pt.raw"
-    run("--load-snapshot", snapshot, "--integrator", "pt", "--spp", "256", "--out", film_path, "--opt", "bn=false")
-    film = film_io.read_film(film_path)
-    np.savez_compressed(os.path.join(GOLDEN, "cornell_sss_128_pt.npz"), camera=film["camera"][..., :3], light=film["light"][..., :3], normal=film["normal"][..., :3],
-                        albedo=film["albedo"][..., :3], spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]), threads=np.int32(film["threads"]))
+    for integrator, spp, extra in (("vcm", 64, ["--opt", "vcm-blue_noise=false"]), ("pt", 256, ["--opt", "bn=false"])):
+        film_path = "/tmp/golden_sss_%s.raw" % integrator
+        run("--load-snapshot", snapshot, "--integrator", integrator, "--spp", str(spp), "--out", film_path, *extra)
+        film = film_io.read_film(film_path)
+        np.savez_compressed(os.path.join(GOLDEN, "cornell_sss_128_%s.npz" % integrator), camera=film["camera"][..., :3], light=film["light"][..., :3],
+                            normal=film["normal"][..., :3], albedo=film["albedo"][..., :3], spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]),
+                            threads=np.int32(film["threads"]))
 
 
 def main():

@@ -332,20 +332,22 @@ def test_heterogeneous_medium_matches_reference(etx, golden_dir):
 
 
 def test_subsurface_random_walk_matches_reference(etx, golden_dir):
-    """Random-walk subsurface scattering in the path tracer (diffuse entry and refracted entry under a plastic coat):
+    """Random-walk subsurface scattering in the path tracer and in VCM (diffuse entry and refracted entry under a plastic coat):
     the walk runs inside the shade kernel on an inline material-filtered traversal (Raytracing::trace_material)."""
     golden = np.load(os.path.join(golden_dir, "cornell_sss_128_pt.npz"))
     layers, stats = render_pt(etx, golden_dir, "cornell_sss_128", int(golden["spp"]))
     assert stats.overflow_flags == 0
     compare_pt(layers, golden, 6.0e-3, 2.0e-2)
-    # VCM with subsurface materials is not implemented yet: rejected, not rendered without the walk
-    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_sss_128.etxscene"))
-    integ = etx.HIPVCM(snap)
-    integ.options()["vcm-blue_noise"] = False
-    with pytest.raises(etx.EtxHipError) as e:
-        integ.run()
-    assert e.value.code == -4
-    integ.context.close()
+    golden = np.load(os.path.join(golden_dir, "cornell_sss_128_vcm.npz"))
+    cam, light, res, stats = render(etx, golden_dir, "cornell_sss_128", int(golden["spp"]))
+    assert stats.overflow_flags == 0 and np.isfinite(res).all()
+    ref_result = np.maximum(golden["camera"] + golden["light"], 0.0)
+    ok = np.isfinite(ref_result).all(axis=2)
+    ref_result = np.where(ok[..., None], ref_result, 0.0)
+    res = np.where(ok[..., None], res[..., :3], 0.0)
+    assert rmse(block_mean(res, 32), block_mean(ref_result, 32)) < 6.0e-3
+    rel = (res.mean(axis=(0, 1)) - ref_result.mean(axis=(0, 1))) / ref_result.mean(axis=(0, 1))
+    assert np.abs(rel).max() < 2.0e-2, rel
 
 
 def test_pt_options_and_config1_size(etx, golden_dir):
