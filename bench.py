@@ -155,7 +155,7 @@ def main():
         torch.cuda.synchronize()
         gbs = n_rays * BYTES_PER_RAY / ms / 1.0e6
         isolated = {"rays_per_launch": n_rays, "avg_launch_ms": round(ms, 6), "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6),
-                    "note": "k_trace_closest alone on the device, 20 launches over one queue of incoherent rays"}
+                    "note": "the same kernel alone on the device, 20 launches over one queue of incoherent rays"}
 
     if rank == 0:
         samples = float(width) * height * args.steps * world

@@ -372,6 +372,7 @@ template <bool kSimple>
 ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st, uint32_t film_target, ShadowRequest& out) {
   if ((opt_connect_to_light(it) == false) || (st.depth + 1 > scene.max_path_length) || (st.depth + 1 < scene.min_path_length))
     return false;
+  const Sampler trap_sampler = st.sampler;  // NaN trap only (dead otherwise)
   f3 sample_pos = camera_at_medium ? medium_pos : isect->pos;
   uint32_t emitter_index = sample_emitter_index(scene, st.sampler.fixed_w);
   EmitterSample es = sample_emitter(scene, emitter_index, f2{st.sampler.fixed_u, st.sampler.fixed_v}, sample_pos, st.wavelength);
@@ -414,6 +415,47 @@ ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool
   float weight = opt_enable_mis(it) ? 1.0f / (1.0f + w_light + w_camera) : 1.0f;
   out = {origin, es.origin, st.throughput * scatter * es.value * (weight / (es.pdf_dir * es.pdf_sample)) * spectral_film_weight(scene, st.wavelength), st.medium, film_target,
     st.wavelength};
+  if ((kSimple == false) && (it.options & 0x80000000u) && (camera_at_medium == false)) {  // NaN trap (ETX_HIP_TRAP), debugging only
+    const bool bad = (out.value.x != out.value.x) || (out.value.y != out.value.y) || (out.value.z != out.value.z);
+    if (bad) {
+      const float scale = weight / (es.pdf_dir * es.pdf_sample);
+      const uint32_t code = ((st.throughput.z != st.throughput.z) ? 1u : 0u) | ((scatter.z != scatter.z) ? 2u : 0u) | ((es.value.z != es.value.z) ? 4u : 0u) |
+                            (((scale != scale) || isinf(scale)) ? 8u : 0u) | (((scatter.x != scatter.x) || (scatter.y != scatter.y)) ? 16u : 0u);
+      const uint32_t mode = (it.options >> 24u) & 15u;
+      const etx_abi_material& mat = scene.materials[isect->material];
+      BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathCamera, st.wavelength);
+      Frame frame = normal_frame(data);
+      const f3 lwo = frame.to_local(w_o), lwi = frame.to_local(-data.w_i);
+      Sampler probe = trap_sampler;
+      Ior ext_ior = evaluate_refractive_index(scene, mat.ext_ior, data.wavelength);
+      Ior int_ior = evaluate_refractive_index(scene, mat.int_ior, data.wavelength);
+      const ThinfilmEval tf = evaluate_thinfilm(scene, mat.thinfilm, data.tex, probe, data.wavelength);
+      const f2 roughness = evaluate_roughness(scene, mat, data.tex);
+      float g = 0.0f, b = 0.0f;
+      switch (mode) {
+        case 0: g = lwi.z, b = lwo.z; break;
+        case 1: g = int_ior.eta.z, b = int_ior.k.z; break;
+        case 2: g = tf.ior.eta.z, b = tf.thickness; break;
+        case 3: g = tf.rgb_wavelengths.z, b = ext_ior.eta.z; break;
+        case 4: g = roughness.x, b = trap_sampler.fixed_u; break;
+        case 5: g = float(mat.cls), b = float(isect->material); break;
+        case 6: {
+          Sampler again = trap_sampler;
+          BsdfEval e2 = bsdf_evaluate_s<kSimple>(scene, data, w_o, mat, again);
+          g = (e2.bsdf.z != e2.bsdf.z) ? 1.0f : 2.0f;
+          const f3 wh = normalize(lwi + lwo);
+          const f3 fr = fresnel_calculate(dot(lwi, wh), ext_ior, int_ior, tf);
+          b = (fr.z != fr.z) ? 1.0f : 2.0f;
+          break;
+        }
+        case 7: g = tf.ior.k.z, b = ext_ior.k.z; break;
+        case 8: g = es.value.z, b = float(emitter_index); break;
+        case 9: g = trap_sampler.fixed_v, b = trap_sampler.fixed_w; break;
+        default: g = scatter.x, b = scatter.y; break;
+      }
+      out.value = f3{1000.0f + float(code), g, b};
+    }
+  }
   return true;
 }
 

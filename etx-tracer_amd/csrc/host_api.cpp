@@ -276,6 +276,8 @@ VcmParams make_iteration_params(const etx_hip_context* ctx, uint32_t iteration) 
   const auto& sc = ctx->scene.host_copy;
   VcmParams it = {};
   it.options = o.options;
+  if (const char* e = getenv("ETX_HIP_TRAP"))  // NaN trap of vcm_connect_to_light (debugging): mode in bits 24..27
+    it.options |= 0x80000000u | ((uint32_t(strtoul(e, nullptr, 0)) & 15u) << 24u);
   it.kernel = o.kernel;
   it.iteration = iteration;
   it.film_w = ctx->scene.film_w, it.film_h = ctx->scene.film_h;

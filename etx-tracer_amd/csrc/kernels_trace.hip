@@ -4,6 +4,7 @@
 // index-aligned with the path state, so no per-ray path index is moved); BVH bytes are not counted while the tree is
 // L2/LDS resident (Cornell: 3 KB). One lane = one ray; 256-thread blocks, persistent grid (256 CUs x 8 blocks),
 // wave-uniform grid-stride loop; per-lane traversal stack in LDS laid out [level][lane] (bank conflict free).
+#include <cstdlib>
 #include "kernels.h"
 #include "dev_bvh.h"
 #include "dev_vcm.h"
@@ -44,9 +45,143 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Flat sweep, two rays per lane on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32). The one-ray sweep is VALU bound (about 30
+// VALU per primitive and ray); here a lane carries rays i and i + 64 of a 128-ray chunk in the two halves of 64-bit
+// register pairs, the primitive rows stay wave-uniform in SGPRs and are broadcast to both halves, so the affine part of
+// the test (plane distance, hit point, the two parallelogram coordinates: 18 multiply-adds) costs 9 instructions per
+// ray. The inside test is folded differently from flat_prim_test: a parallelogram needs |a - 1/2| <= 1/2 and
+// |b - 1/2| <= 1/2 (one v_max3 with |.| modifiers, the -1/2 is a scalar subtraction on the row's constant), a triangle
+// min3(a, b, 1 - a - b) >= 0. Only (t, primitive) are tracked in the loop; the coordinates of the winner are recomputed
+// once after the sweep. Alpha-tested primitives (per-candidate random draws, scene_bsdf.hxx:128-144) take the one-ray
+// code for each half so their draw order is the one of bvh_flat_closest.
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr uint32_t kFlat2Blocks = 2048u;  // 256 CUs x 8 blocks: more waves per SIMD overlap the queue traffic of one wave with the sweep of the others (measured 1024: 35.7, 2048: 39.3 Grays/s)
+
+ETX_DEV v2f splat2(float v) {
+  return v2f{v, v};
+}
+
+template <bool kFromCounter>
+__global__ __launch_bounds__(kBlockSize) void k_trace_closest_flat2(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
+  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count) {
+  const DScene& scene = scene_arg;
+  const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
+  if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
+    counters[kCntActiveA + kCntActiveB - active_counter] = 0u;
+    counters[kCntCameraVertices] = 0u;
+    counters[kCntPairs] = 0u;
+    counters[kCntShadow] = 0u;
+    counters[kCntMergeVertices] = 0u;
+    atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6u;
+  const uint32_t wave_count = (gridDim.x * blockDim.x) >> 6u;
+  const uint32_t prim_count = scene.flat_prim_count;
+  ConstantFloats table = (ConstantFloats)(const void*)(scene.flat_prims);
+  // software pipeline: the rays of the wave's next chunk are requested before the current chunk is swept, so the
+  // queue traffic overlaps the VALU work (without it every wave alternates load / sweep / store phases and, with all
+  // waves of the persistent grid in step, the memory pipe idles while the VALU works and vice versa)
+  const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  uint32_t base = wave * 128u;
+  float4 na0 = zero, nb0 = zero, na1 = zero, nb1 = zero;
+  if (base + lane < count)
+    na0 = ray_o_tmin[base + lane], nb0 = ray_d_tmax[base + lane];
+  if (base + 64u + lane < count)
+    na1 = ray_o_tmin[base + 64u + lane], nb1 = ray_d_tmax[base + 64u + lane];
+  for (; base < count; base += wave_count * 128u) {
+    const uint32_t i0 = base + lane, i1 = base + 64u + lane;
+    const bool live0 = i0 < count, live1 = i1 < count;
+    const float4 a0 = na0, b0 = nb0, a1 = na1, b1 = nb1;
+    {
+      const uint32_t n0 = i0 + wave_count * 128u, n1 = i1 + wave_count * 128u;
+      if (n0 < count)
+        na0 = ray_o_tmin[n0], nb0 = ray_d_tmax[n0];
+      if (n1 < count)
+        na1 = ray_o_tmin[n1], nb1 = ray_d_tmax[n1];
+    }
+    const v2f ox = {a0.x, a1.x}, oy = {a0.y, a1.y}, oz = {a0.z, a1.z};
+    const v2f dx = {b0.x, b1.x}, dy = {b0.y, b1.y}, dz = {b0.z, b1.z};
+    const float tmin0 = a0.w, tmin1 = a1.w;
+    // a dead half gets an empty interval
+    float best_t0 = live0 ? b0.w : -1.0f, best_t1 = live1 ? b1.w : -1.0f;
+    uint32_t best_p0 = kInvalid, best_p1 = kInvalid;
+    uint32_t seed0 = __float_as_uint(a0.x) ^ (__float_as_uint(b0.y) * 0x9e3779b9u) ^ i0;
+    uint32_t seed1 = __float_as_uint(a1.x) ^ (__float_as_uint(b1.y) * 0x9e3779b9u) ^ i1;
+#pragma unroll 2
+    for (uint32_t k = 0; k < prim_count; ++k) {
+      const FlatRow prim = load_flat_prim(table, k);
+      const uint32_t flags = prim.flags;
+      if (flags & kTriVoid)  // scalar branch
+        continue;
+      if (flags & kTriAlphaTested) {  // scalar branch; rare
+        float a, b, t;
+        const RayQ r0 = {{a0.x, a0.y, a0.z}, tmin0, {b0.x, b0.y, b0.z}, best_t0};
+        if (flat_prim_test(prim, r0, best_t0, a, b, t) && (alpha_test_skips(scene, scene.flat_info[k].tri_a, prim.material, a, b, seed0) == false))
+          best_t0 = t, best_p0 = k;
+        const RayQ r1 = {{a1.x, a1.y, a1.z}, tmin1, {b1.x, b1.y, b1.z}, best_t1};
+        if (flat_prim_test(prim, r1, best_t1, a, b, t) && (alpha_test_skips(scene, scene.flat_info[k].tri_a, prim.material, a, b, seed1) == false))
+          best_t1 = t, best_p1 = k;
+        continue;
+      }
+      const v2f den = splat2(prim.plane.x) * dx + splat2(prim.plane.y) * dy + splat2(prim.plane.z) * dz;
+      const v2f num = splat2(prim.plane.x) * ox + splat2(prim.plane.y) * oy + splat2(prim.plane.z) * oz + splat2(prim.plane.w);
+      const v2f inv = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+      const v2f t = -num * inv;
+      const v2f px = ox + dx * t, py = oy + dy * t, pz = oz + dz * t;
+      bool in0, in1;
+      if (flags & kTriQuad) {  // scalar branch
+        const float wa = prim.row_a.w - 0.5f, wb = prim.row_b.w - 0.5f;  // SALU
+        const v2f a = splat2(prim.row_a.x) * px + splat2(prim.row_a.y) * py + splat2(prim.row_a.z) * pz + splat2(wa);
+        const v2f b = splat2(prim.row_b.x) * px + splat2(prim.row_b.y) * py + splat2(prim.row_b.z) * pz + splat2(wb);
+        in0 = fmaxf(fabsf(a.x), fabsf(b.x)) <= 0.5f;
+        in1 = fmaxf(fabsf(a.y), fabsf(b.y)) <= 0.5f;
+      } else {
+        const v2f a = splat2(prim.row_a.x) * px + splat2(prim.row_a.y) * py + splat2(prim.row_a.z) * pz + splat2(prim.row_a.w);
+        const v2f b = splat2(prim.row_b.x) * px + splat2(prim.row_b.y) * py + splat2(prim.row_b.z) * pz + splat2(prim.row_b.w);
+        const v2f e = (splat2(1.0f) - a) - b;
+        in0 = fminf(fminf(a.x, b.x), e.x) >= 0.0f;
+        in1 = fminf(fminf(a.y, b.y), e.y) >= 0.0f;
+      }
+      // a ray parallel to the plane gives t = inf / nan: both fail the explicit comparisons on t
+      if ((t.x >= tmin0) && (t.x <= best_t0) && in0)
+        best_t0 = t.x, best_p0 = k;
+      if ((t.y >= tmin1) && (t.y <= best_t1) && in1)
+        best_t1 = t.y, best_p1 = k;
+    }
+    // coordinates of the winners (per-lane primitive index: ordinary loads, once per ray)
+    auto resolve = [&](uint32_t prim_index, const float4& ro, const float4& rd, float t, float t_max) -> float4 {
+      if (prim_index == kInvalid)
+        return make_float4(0.0f, 0.0f, t_max, __uint_as_float(kInvalid));
+      const FlatPrim& pr = scene.flat_prims[prim_index];
+      const float4 ra = pr.row_a, rb = pr.row_b;
+      const f3 x = f3{ro.x, ro.y, ro.z} + f3{rd.x, rd.y, rd.z} * t;
+      const float a = ra.x * x.x + ra.y * x.y + ra.z * x.z + ra.w;
+      const float b = rb.x * x.x + rb.y * x.y + rb.z * x.z + rb.w;
+      const Hit h = flat_resolve(scene, prim_index, a, b, t);
+      return make_float4(h.u, h.v, h.t, __uint_as_float(h.tri));
+    };
+    if (live0)
+      hits[i0] = resolve(best_p0, a0, b0, best_t0, b0.w);
+    if (live1)
+      hits[i1] = resolve(best_p1, a1, b1, best_t1, b1.w);
+  }
+}
+
+static uint32_t flat2_blocks(uint32_t items) {  // 512 rays per 256-thread block and loop iteration
+  const uint32_t limit = getenv("ETX_HIP_DEBUG_BLOCKS") ? uint32_t(strtoul(getenv("ETX_HIP_DEBUG_BLOCKS"), nullptr, 0)) : kFlat2Blocks;
+  return max(1u, min(limit, (items + 2u * kBlockSize - 1u) / (2u * kBlockSize)));
+}
+
 void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat) {
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.capacity, max_items) + kBlockSize - 1) / kBlockSize));
-  if (flat)
+  // opt-in (ETX_HIP_DEBUG_FLAGS bit 64): alone on the device the two-ray sweep is 10 % faster (39.3 vs 35.7 Grays/s on 2 M incoherent
+  // rays), inside the 4-lane pipeline its fatter waves lose against the co-running kernels (51.5 vs 46.6 us per launch) - DESIGN.md 3
+  if (flat && (p.debug_flags & 64u))
+    hipLaunchKernelGGL((k_trace_closest_flat2<true>), dim3(flat2_blocks(min(p.capacity, max_items))), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits,
+      p.counters, active_counter, 0u);
+  else if (flat)
     hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u);
   else
     hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u);
@@ -80,6 +215,13 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
       if ((tr.x > kEpsilon) || (tr.y > kEpsilon) || (tr.z > kEpsilon)) {  // SpectralResponse::is_zero
         const float4 v = p.shadow.value[i];
         value = tr * f3{v.x, v.y, v.z};
+        if ((p.debug_flags & 16u) && ((v.x >= 999.5f) == false))  // ETX_HIP_TRAP decoding: keep only the trap records
+          value = mk3(0.0f);
+        if (p.debug_flags & 8u) {  // NaN provenance: red marker = request value, green marker = transmittance
+          const bool bad_v = (v.z != v.z), bad_t = (tr.z != tr.z);
+          if (bad_v || bad_t)
+            value = f3{bad_v ? 1000.0f : 0.0f, bad_t ? 1000.0f : 0.0f, 0.0f};
+        }
         if (target & kShadowTargetLight) {
           // vcm_shared.hxx:1229 + vcm_cpu.cxx:148-153 + film.cxx:148: thresholds of the light splat
           if ((max_component(value) <= kEpsilon) || (dot(value, value) <= kEpsilon))
@@ -127,10 +269,16 @@ void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ra
   uint32_t blocks = min(kPersistentBlocks, (count + kBlockSize - 1) / kBlockSize);
   if (blocks == 0)
     return;
-  if (flat)
-    hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count);
+  DScene limited = scene;  // experiments: ETX_HIP_DEBUG_PRIMS caps the primitive count of the flat sweep (cost per primitive vs memory floor)
+  if (const char* e = getenv("ETX_HIP_DEBUG_PRIMS"))
+    limited.flat_prim_count = min(limited.flat_prim_count, uint32_t(strtoul(e, nullptr, 0)));
+  const bool two_ray_sweep = (getenv("ETX_HIP_DEBUG_FLAGS") != nullptr) && ((strtoul(getenv("ETX_HIP_DEBUG_FLAGS"), nullptr, 0) & 64u) != 0u);
+  if (flat && two_ray_sweep)
+    hipLaunchKernelGGL((k_trace_closest_flat2<false>), dim3(flat2_blocks(count)), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count);
+  else if (flat)
+    hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count);
   else
-    hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(blocks), dim3(kBlockSize), 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count);
+    hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(blocks), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count);
 }
 
 }  // namespace etxd

@@ -10,15 +10,7 @@
 //                                           vcm_camera_step                     (vcm_shared.hxx:927-1079)
 // All kernels: 256-thread blocks, persistent grid, wave-uniform grid-stride loops, survivors compacted with a wave
 // ballot + one atomic per wavefront. Shading is fp32 VALU / divergence bound (no MFMA: there is no contraction).
-#include "kernels.h"
-#include "dev_vcm_steps.h"
-
-#if !defined(ETX_CAM_ATTR)
-#define ETX_CAM_ATTR
-#endif
-#if !defined(ETX_LIGHT_ATTR)
-#define ETX_LIGHT_ATTR
-#endif
+#include "kernels_shade.inl"  // k_light_shade / k_camera_shade templates; the <false> instantiations are separate translation units
 
 namespace etxd {
 
@@ -101,39 +93,12 @@ void launch_light_generate(hipStream_t stream, const Pipeline& p, const VcmParam
   hipLaunchKernelGGL(k_light_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
 }
 
-// vcm_light_step, vcm_shared.hxx:1090-1260 (everything after rt.trace)
-template <bool kSimple>
-__global__ __launch_bounds__(kBlockSize) ETX_LIGHT_ATTR void k_light_shade(Pipeline p, VcmParams it, uint32_t in_set) {
-  const DScene& scene = p.scene;
-  const PathSet& in = p.paths[in_set];
-  const PathSet& out = p.paths[in_set ^ 1u];
-  const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
-  uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
-  __shared__ BlockScratch s_scratch;
-  __shared__ int32_t s_stack[kSimple ? 1 : kStackDepth * kBlockSize];  // inline traversal of the subsurface walk (general materials only)
-  const LaneStack stack = {s_stack + (kSimple ? 0u : threadIdx.x), kBlockSize};
-  const BlockSlots slots = {&s_scratch};
-  ETX_BLOCK_LOOP(count, i) {
-    const bool valid = i < count;
-    PathState st;
-    float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
-    if (valid) {
-      st = load_path(in, i);
-      h = p.hits[i];
-    }
-    const bool alive = light_step<kSimple>(p, scene, it, st, h, valid, slots, stack);
-    const uint32_t slot = slots.get(alive, out_counter);
-    if (alive)
-      store_path(out, slot, st);
-  }
-}
-
 void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials) {
   const dim3 grid(max(1u, grid_for(min(p.capacity, max_items))));
   if (simple_materials)
     hipLaunchKernelGGL(k_light_shade<true>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
   else
-    hipLaunchKernelGGL(k_light_shade<false>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+    launch_light_shade_general(stream, p, it, in_set, grid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -182,40 +147,12 @@ void launch_camera_generate(hipStream_t stream, const Pipeline& p, const VcmPara
 }
 
 
-// vcm_camera_step, vcm_shared.hxx:927-1079, without the vertex connections and the merge: connectible vertices are
-// written to the camera vertex pool and consumed by k_connect / k_merge of the same bounce.
-template <bool kSimple>
-__global__ __launch_bounds__(kBlockSize) ETX_CAM_ATTR void k_camera_shade(Pipeline p, VcmParams it, uint32_t in_set) {
-  const DScene& scene = p.scene;
-  const PathSet& in = p.paths[in_set];
-  const PathSet& out = p.paths[in_set ^ 1u];
-  const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
-  uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
-  __shared__ BlockScratch s_scratch;
-  __shared__ int32_t s_stack[kSimple ? 1 : kStackDepth * kBlockSize];  // inline traversal of the subsurface walk (general materials only)
-  const LaneStack stack = {s_stack + (kSimple ? 0u : threadIdx.x), kBlockSize};
-  const BlockSlots slots = {&s_scratch};
-  ETX_BLOCK_LOOP(count, i) {
-    const bool valid = i < count;
-    PathState st;
-    float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
-    if (valid) {
-      st = load_path(in, i);
-      h = p.hits[i];
-    }
-    const bool alive = camera_step<kSimple>(p, scene, it, st, h, valid, slots, stack);
-    const uint32_t slot = slots.get(alive, out_counter);
-    if (alive)
-      store_path(out, slot, st);
-  }
-}
-
 void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials) {
   const dim3 grid(max(1u, grid_for(min(p.capacity, max_items))));
   if (simple_materials)
     hipLaunchKernelGGL(k_camera_shade<true>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
   else
-    hipLaunchKernelGGL(k_camera_shade<false>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+    launch_camera_shade_general(stream, p, it, in_set, grid);
 }
 
 #if defined(ETX_HIP_DEBUG_COUNTERS)

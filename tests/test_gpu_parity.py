@@ -112,6 +112,31 @@ def test_traversal_matches_bruteforce(etx, gpu_context, golden_dir, scene):
     np.testing.assert_allclose(hits[both, 0:2], expected[both, 0:2], rtol=0, atol=1e-5)
 
 
+def test_two_ray_packed_sweep_matches_one_ray_sweep(etx, gpu_context, golden_dir, monkeypatch):
+    """The opt-in packed-fp32 sweep (k_trace_closest_flat2, ETX_HIP_DEBUG_FLAGS bit 64: two rays per lane) against the
+    default one-ray sweep and the brute-force oracle, including ragged counts (half-filled 128-ray chunks)."""
+    from oracle import ray_oracle
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_full_128.etxscene"))
+    gpu_context.upload_scene(snap)
+    for n in (1, 64, 65, 127, 129, 20000):
+        rays = make_rays(n, 5 + n)
+        monkeypatch.delenv("ETX_HIP_DEBUG_FLAGS", raising=False)
+        one = gpu_context.trace_rays(rays)
+        monkeypatch.setenv("ETX_HIP_DEBUG_FLAGS", "64")
+        two = gpu_context.trace_rays(rays)
+        monkeypatch.delenv("ETX_HIP_DEBUG_FLAGS", raising=False)
+        tri_one, tri_two = one[:, 3].view(np.uint32), two[:, 3].view(np.uint32)
+        same = tri_one == tri_two
+        assert same.mean() > 0.999 or n < 1000 and same.all()
+        np.testing.assert_allclose(two[:, 2], one[:, 2], rtol=1e-5, atol=1e-5)  # same distance even across a shared edge
+        np.testing.assert_allclose(two[same, 0:2], one[same, 0:2], rtol=0, atol=2e-5)
+        if n == 20000:
+            expected = ray_oracle.closest_hits(snap, rays)
+            tri = tri_two.astype(np.int64)
+            tri[tri == 0xFFFFFFFF] = -1
+            assert (tri == expected[:, 3].astype(np.int64)).mean() > 0.999
+
+
 def test_traversal_empty_and_ragged(etx, gpu_context, golden_dir):
     snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_classic_128.etxscene"))
     gpu_context.upload_scene(snap)
@@ -156,6 +181,8 @@ def render(etx, golden_dir, scene, spp, options=None, first=0, stride=1, size_ov
     res = integ.film(etx.api.LAYER_RESULT)
     stats = integ.status()
     integ.context.close()
+    # the RAW sums must be finite: Film::layer(Result) = max(0, camera + light) would turn a NaN sum into a black pixel
+    assert np.isfinite(cam).all() and np.isfinite(light).all(), "non-finite film sums in %s" % scene
     return cam, light, res, stats
 
 
@@ -224,6 +251,8 @@ def render_pt(etx, golden_dir, scene, spp, options=None, bluenoise=None, first=0
     layers = {name: integ.film(getattr(etx.api, "LAYER_" + name.upper())) for name in ("camera", "light", "result", "normal", "albedo")}
     stats = integ.status()
     integ.context.close()
+    for name, layer in layers.items():
+        assert np.isfinite(layer).all(), "non-finite %s layer in %s" % (name, scene)
     return layers, stats
 
 
