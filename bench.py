@@ -157,6 +157,15 @@ def main():
         isolated = {"rays_per_launch": n_rays, "avg_launch_ms": round(ms, 6), "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6),
                     "note": "the same kernel alone on the device, 20 launches over one queue of incoherent rays"}
 
+    # PMC figures (collected in separate rocprofv3 --pmc passes, profiles/round1_pmc_summary.json): HBM bytes per ray of
+    # the traversal kernel (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE) and the
+    # occupancy / VALU utilisation of the shade kernels
+    pmc = None
+    pmc_path = os.path.join(ROOT, "profiles", "round1_pmc_summary.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+
     if rank == 0:
         samples = float(width) * height * args.steps * world
         value = samples / elapsed / 1.0e6
@@ -188,7 +197,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": None,
+                "traffic": (round(pmc["trace_closest"]["hbm_bytes_per_ray"] * acc["rays"] / max(acc["launches"], 1)) if pmc else None),
+                "traffic_note": ("HBM bytes per average launch = PMC bytes per ray (%.3f B: FETCH_SIZE x 2 + WRITE_SIZE, measured on the kernel alone at 2 073 600 rays "
+                                 "per launch, profiles/round1_pmc_summary.json) x rays per launch of the timed region; algorithmic 48 B per ray" % pmc["trace_closest"]["hbm_bytes_per_ray"]) if pmc else None,
                 "bytes_per_ray": BYTES_PER_RAY,
                 "rays": acc["rays"],
                 "launches": acc["launches"],
@@ -198,6 +209,7 @@ def main():
                         "other kernels; `isolated` is the same kernel alone",
                 "isolated": isolated,
             },
+            "shade_kernels": ({name: pmc["kernels_1lane"][name] for name in ("etxd::k_camera_shade<true>", "etxd::k_light_shade<true>") if name in pmc["kernels_1lane"]} if pmc else None),
             "counters": {
                 "rays_per_sample": round((acc["rays"] + acc["shadow"]) / (float(width) * height * args.steps), 3),
                 "light_vertices_per_path": round(acc["lv"] / (float(width) * height * args.steps), 3),
