@@ -418,6 +418,34 @@ def test_iteration_sharding_is_linear(etx, golden_dir):
     np.testing.assert_allclose(0.5 * (even[..., :3] + odd[..., :3]), all4[..., :3], rtol=2e-4, atol=2e-5)
 
 
+def test_rccl_film_reduce_single_rank(etx, golden_dir):
+    """The multi-GPU exchange of SURVEY.md 8e through the C ABI on the one device a test box has: a world-size-1 RCCL
+    communicator inside libetx_hip.so (etx_hip_comm_unique_id / etx_hip_comm_init), etx_hip_reduce_film = one
+    all-reduce of the film layers + the iteration count. With one rank the reduced film must equal the local film."""
+    from etx_tracer_amd import api, integrator as integ_mod
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_classic_128.etxscene"))
+    snap.samples = 4
+    films = []
+    for with_comm in (False, True):
+        ctx = api.Context(0)
+        ctx.upload_scene(snap)
+        if with_comm:
+            ctx.comm_init(0, 1, api.comm_unique_id(ctx.library))
+        ctx.begin_vcm(integ_mod.vcm_options_from_dict({"vcm-blue_noise": False}), first_iteration=0, iteration_stride=1)
+        for _ in range(4):
+            ctx.render_iteration()
+        ctx.sync()
+        ctx.reduce_film()  # without a communicator: marks the film as final, no exchange
+        assert ctx.stats().completed_iterations == 4
+        films.append((ctx.read_film(api.LAYER_CAMERA), ctx.read_film(api.LAYER_LIGHT), ctx.read_film(api.LAYER_RESULT)))
+        with pytest.raises(api.EtxHipError):
+            ctx.render_iteration()  # after the reduce the film is final until the next etx_hip_begin
+        ctx.close()
+    for local, reduced in zip(*films):
+        assert np.isfinite(reduced).all()
+        np.testing.assert_allclose(reduced[..., :3], local[..., :3], rtol=2e-4, atol=2e-5)  # float atomics reorder the sums
+
+
 def test_merging_off_equals_connection_only_options(etx, golden_dir):
     """vcm-merging=false must zero the merge weights (vm_weight = 0, vcm_cpu.cxx:110) - the image stays finite and
     close to the full estimator (both are unbiased/consistent estimates of the same radiance)."""
