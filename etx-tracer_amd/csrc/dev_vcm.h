@@ -439,15 +439,6 @@ ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool
         case 3: g = tf.rgb_wavelengths.z, b = ext_ior.eta.z; break;
         case 4: g = roughness.x, b = trap_sampler.fixed_u; break;
         case 5: g = float(mat.cls), b = float(isect->material); break;
-        case 6: {
-          Sampler again = trap_sampler;
-          BsdfEval e2 = bsdf_evaluate_s<kSimple>(scene, data, w_o, mat, again);
-          g = (e2.bsdf.z != e2.bsdf.z) ? 1.0f : 2.0f;
-          const f3 wh = normalize(lwi + lwo);
-          const f3 fr = fresnel_calculate(dot(lwi, wh), ext_ior, int_ior, tf);
-          b = (fr.z != fr.z) ? 1.0f : 2.0f;
-          break;
-        }
         case 7: g = tf.ior.k.z, b = ext_ior.k.z; break;
         case 8: g = es.value.z, b = float(emitter_index); break;
         case 9: g = trap_sampler.fixed_v, b = trap_sampler.fixed_w; break;
