@@ -728,155 +728,16 @@ ETX_DEV BsdfSample bsdf_sample_delta_classes(const DScene& s, const BsdfData& d,
   return r;
 }
 
-ETX_DEV BsdfSample bsdf_sample_core(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
-  switch (m.cls) {
-    case ETX_MAT_DIFFUSE:
-      return diffuse_sample(s, d, m, smp);
-    case ETX_MAT_TRANSLUCENT:
-      return translucent_sample(s, d, m, smp);
-    case ETX_MAT_CONDUCTOR:
-      return conductor_sample(s, d, m, smp);
-    case ETX_MAT_DIELECTRIC:
-      return dielectric_sample(s, d, m, smp);
-    case ETX_MAT_THINFILM:
-      return thinfilm_sample(s, d, m, smp);
-    case ETX_MAT_PLASTIC:
-      return plastic_sample(s, d, m, smp);
-    case ETX_MAT_VELVET:
-      return velvet_sample(s, d, m, smp);
-    case ETX_MAT_MIRROR:
-    case ETX_MAT_BOUNDARY:
-      return bsdf_sample_delta_classes(s, d, m);
-    default: {  // Void, bsdf_various.hxx:5-15
-      BsdfSample r = sample_zero();
-      r.w_o = d.w_i;
-      r.properties = kSampleDelta;
-      r.medium_index = d.medium;
-      return r;
-    }
-  }
-}
-
-ETX_DEV BsdfEval bsdf_evaluate_core(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
-  switch (m.cls) {
-    case ETX_MAT_DIFFUSE:
-      return diffuse_evaluate_v(s, d, w_o, m, smp);
-    case ETX_MAT_TRANSLUCENT:
-      return translucent_evaluate(s, d, w_o, m);
-    case ETX_MAT_CONDUCTOR:
-      return conductor_evaluate(s, d, w_o, m, smp);
-    case ETX_MAT_DIELECTRIC:
-      return dielectric_evaluate(s, d, w_o, m, smp);
-    case ETX_MAT_PLASTIC:
-      return plastic_evaluate(s, d, w_o, m, smp);
-    case ETX_MAT_VELVET:
-      return velvet_evaluate(s, d, w_o, m);
-    case ETX_MAT_MIRROR: {  // bsdf_various.hxx:226-240
-      BsdfEval e = eval_zero();
-      Frame frame = normal_frame(d);
-      if (direction_matches(normalize(reflect(d.w_i, frame.nrm)), normalize(w_o))) {
-        e.func = apply_image(s, m.scattering, d.tex, nullptr, d.wavelength);
-        e.bsdf = e.func;
-        e.pdf = 1.0f;
-      }
-      return e;
-    }
-    default:  // Boundary, Void, Thinfilm: bsdf_various.hxx:272-274, 17-19, bsdf_dielectric.hxx:43-45
-      return eval_zero();
-  }
-}
-
-ETX_DEV float bsdf_pdf_core(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
-  switch (m.cls) {
-    case ETX_MAT_DIFFUSE:
-      return diffuse_pdf(d, w_o);
-    case ETX_MAT_TRANSLUCENT:
-      return translucent_pdf(s, d, w_o, m);
-    case ETX_MAT_CONDUCTOR:
-      return conductor_pdf(s, d, w_o, m);
-    case ETX_MAT_DIELECTRIC:
-      return dielectric_pdf(s, d, w_o, m, smp);
-    case ETX_MAT_PLASTIC:
-      return plastic_pdf(s, d, w_o, m, smp);
-    case ETX_MAT_VELVET:
-      return velvet_pdf(d);
-    case ETX_MAT_MIRROR: {
-      Frame frame = normal_frame(d);
-      return direction_matches(normalize(reflect(d.w_i, frame.nrm)), normalize(w_o)) ? 1.0f : 0.0f;
-    }
-    default:
-      return 0.0f;
-  }
-}
-
-// PrincipledBSDF, bsdf_principled.hxx:16-114: one of Conductor / Dielectric / Plastic is picked per call with the
-// path's sampler (metalness, transmission) and evaluated on a modified copy of the material.
-enum : uint32_t { kPrincipledConductor = 0, kPrincipledDielectric = 1, kPrincipledPlastic = 2 };
-ETX_DEV uint32_t principled_pick(const DScene& s, const BsdfData& d, const etx_abi_material& in_m, Sampler& smp, etx_abi_material& m_local) {
-  m_local = in_m;
-  const float metalness = in_m.metalness.value.x * evaluate_image(s, in_m.metalness, d.tex, 1.0f);  // evaluate_metalness, scene.hxx:283-285
-  if (smp.next() < metalness) {
-    m_local.int_ior.cls = kSpectrumClassConductor;
-    m_local.int_ior.eta_index = s.default_conductor_eta;
-    m_local.int_ior.k_index = s.default_conductor_k;
-    m_local.scattering.image_index = kInvalid;
-    m_local.cls = ETX_MAT_CONDUCTOR;
-    return kPrincipledConductor;
-  }
-  m_local.int_ior.cls = kSpectrumClassDielectric;
-  m_local.int_ior.eta_index = s.default_dielectric_eta;
-  m_local.int_ior.k_index = kInvalid;
-  m_local.reflectance.image_index = kInvalid;
-  if (smp.next() < m_local.transmission.value.x) {
-    m_local.cls = ETX_MAT_DIELECTRIC;
-    return kPrincipledDielectric;
-  }
-  m_local.cls = ETX_MAT_PLASTIC;
-  return kPrincipledPlastic;
-}
-
-ETX_DEV float bsdf_pdf(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
-  if (m.cls == ETX_MAT_PRINCIPLED) {
-    etx_abi_material m_local;
-    principled_pick(s, d, m, smp, m_local);
-    return bsdf_pdf_core(s, d, w_o, m_local, smp);
-  }
-  return bsdf_pdf_core(s, d, w_o, m, smp);
-}
-
-ETX_DEV BsdfSample bsdf_sample(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
-  if (m.cls == ETX_MAT_PRINCIPLED) {
-    etx_abi_material m_local;
-    principled_pick(s, d, m, smp, m_local);
-    return bsdf_sample_core(s, d, m_local, smp);
-  }
-  return bsdf_sample_core(s, d, m, smp);
-}
-
-ETX_DEV BsdfEval bsdf_evaluate(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
-  if (m.cls == ETX_MAT_PRINCIPLED) {
-    etx_abi_material m_local;
-    principled_pick(s, d, m, smp, m_local);
-    return bsdf_evaluate_core(s, d, w_o, m_local, smp);
-  }
-  return bsdf_evaluate_core(s, d, w_o, m, smp);
-}
-
-// scene_bsdf.hxx:82-92 reverse_pdf: swap the roles of w_i and w_o
-ETX_DEV float bsdf_reverse_pdf(const DScene& s, const BsdfData& in_d, const f3& in_w_o, const etx_abi_material& m, Sampler& smp) {
-  BsdfData d = in_d;
-  f3 w_o = -in_d.w_i;
-  d.w_i = -in_w_o;
-  return bsdf_pdf(s, d, w_o, m, smp);
-}
+enum : uint32_t { kPrincipledConductor = 0, kPrincipledDielectric = 1, kPrincipledPlastic = 2 };  // material variants (dev_bsdf_ool.h)
 
 // ---------------------------------------------------------------------------------------------------------------
-// "Simple material" instantiation of the dispatch. Scenes whose only non-diffuse surfaces are perfect mirrors
-// (Mirror, Conductor with roughness exactly 0) - Cornell is one - never need the Heitz random walk: with alpha = 0 the
-// walk of ConductorBSDF::sample (bsdf_conductor.hxx:13-70) deterministically reflects about the shading normal after one
+// "Simple material" dispatch. Surfaces whose only non-diffuse lobes are perfect mirrors (Mirror, Conductor with
+// roughness exactly 0) - every Cornell wall - never need the Heitz random walk: with alpha = 0 the walk of
+// ConductorBSDF::sample (bsdf_conductor.hxx:13-70) deterministically reflects about the shading normal after one
 // microsurface interaction (height sample leaves the surface with probability 1, bsdf_external.hxx:76-104), the weight
-// is the Fresnel term of the macro normal and the "pdf" is the same D_ggx expression. Keeping the walk and the
-// stochastic evaluation out of the shade kernels halves their register count (2 -> 4 waves per SIMD).
+// is the Fresnel term of the macro normal and the "pdf" is the same D_ggx expression. Paths that hit such a material
+// are shaded by the simple kernels (2 -> 4 waves per SIMD), the others are binned into the general kernels
+// (DScene::material_group, kernels_shade.inl); the general dispatch is dev_bsdf_ool.h.
 ETX_DEV BsdfSample conductor_sample_delta(const DScene& s, const BsdfData& d, const etx_abi_material& m) {
   Frame frame = normal_frame(d);
   f3 w_i = frame.to_local(-d.w_i);
@@ -908,64 +769,45 @@ ETX_DEV BsdfSample diffuse_sample_lambert(const DScene& s, const BsdfData& d, co
   return r;
 }
 
-template <bool kSimple>
-ETX_DEV BsdfSample bsdf_sample_s(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
-  if (kSimple) {  // the classes host_scene.cpp admits to "simple" scenes; the others are compiled out of these kernels
-    switch (m.cls) {
-      case ETX_MAT_DIFFUSE:
-        return diffuse_sample_lambert(s, d, m, smp);
-      case ETX_MAT_TRANSLUCENT:
-        return translucent_sample(s, d, m, smp);
-      case ETX_MAT_CONDUCTOR:
-        return conductor_sample_delta(s, d, m);
-      case ETX_MAT_MIRROR:
-      case ETX_MAT_BOUNDARY:
-        return bsdf_sample_delta_classes(s, d, m);
-      default: {  // Void
-        BsdfSample r = sample_zero();
-        r.w_o = d.w_i;
-        r.properties = kSampleDelta;
-        r.medium_index = d.medium;
-        return r;
-      }
+ETX_DEV BsdfSample bsdf_sample_simple(const DScene& s, const BsdfData& d, const etx_abi_material& m, Sampler& smp) {
+  switch (m.cls) {
+    case ETX_MAT_DIFFUSE:
+      return diffuse_sample_lambert(s, d, m, smp);
+    case ETX_MAT_TRANSLUCENT:
+      return translucent_sample(s, d, m, smp);
+    case ETX_MAT_CONDUCTOR:
+      return conductor_sample_delta(s, d, m);
+    case ETX_MAT_MIRROR:
+    case ETX_MAT_BOUNDARY:
+      return bsdf_sample_delta_classes(s, d, m);
+    default: {  // Void
+      BsdfSample r = sample_zero();
+      r.w_o = d.w_i;
+      r.properties = kSampleDelta;
+      r.medium_index = d.medium;
+      return r;
     }
   }
-  return bsdf_sample(s, d, m, smp);
 }
-template <bool kSimple>
-ETX_DEV BsdfEval bsdf_evaluate_s(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
-  if (kSimple) {  // delta conductors are never evaluated (only connectible vertices are)
-    switch (m.cls) {
-      case ETX_MAT_DIFFUSE:
-        return diffuse_evaluate(s, d, w_o, m);
-      case ETX_MAT_TRANSLUCENT:
-        return translucent_evaluate(s, d, w_o, m);
-      default:
-        return eval_zero();
-    }
+ETX_DEV BsdfEval bsdf_evaluate_simple(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m) {
+  switch (m.cls) {  // delta conductors are never evaluated (only connectible vertices are)
+    case ETX_MAT_DIFFUSE:
+      return diffuse_evaluate(s, d, w_o, m);
+    case ETX_MAT_TRANSLUCENT:
+      return translucent_evaluate(s, d, w_o, m);
+    default:
+      return eval_zero();
   }
-  return bsdf_evaluate(s, d, w_o, m, smp);
 }
-template <bool kSimple>
-ETX_DEV float bsdf_pdf_s(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
-  if (kSimple) {
-    switch (m.cls) {
-      case ETX_MAT_DIFFUSE:
-        return diffuse_pdf(d, w_o);
-      case ETX_MAT_TRANSLUCENT:
-        return translucent_pdf(s, d, w_o, m);
-      default:
-        return 0.0f;
-    }
+ETX_DEV float bsdf_pdf_simple(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m) {
+  switch (m.cls) {
+    case ETX_MAT_DIFFUSE:
+      return diffuse_pdf(d, w_o);
+    case ETX_MAT_TRANSLUCENT:
+      return translucent_pdf(s, d, w_o, m);
+    default:
+      return 0.0f;
   }
-  return bsdf_pdf(s, d, w_o, m, smp);
-}
-template <bool kSimple>
-ETX_DEV float bsdf_reverse_pdf_s(const DScene& s, const BsdfData& in_d, const f3& in_w_o, const etx_abi_material& m, Sampler& smp) {
-  BsdfData d = in_d;
-  f3 w_o = -in_d.w_i;
-  d.w_i = -in_w_o;
-  return bsdf_pdf_s<kSimple>(s, d, w_o, m, smp);
 }
 
 // Lambert surfaces take the sampler-free fast paths of the connect / merge kernels

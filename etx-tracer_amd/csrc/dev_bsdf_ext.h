@@ -262,17 +262,29 @@ ETX_DEV BsdfEval dielectric_evaluate(const DScene& s, const BsdfData& d, const f
   const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
   const bool forward_path = d.path_source == kPathCamera;
   const float backward_scale = fabsf(1.0f / w_i.z);
-  f3 value;
-  if (w_i.z > 0.0f) {
-    if (w_o.z >= 0.0f)
-      value = forward_path ? ms_eval_dielectric(smp, w_i, w_o, true, roughness, ext_ior, int_ior, tf) : ms_eval_dielectric(smp, w_o, w_i, true, roughness, ext_ior, int_ior, tf) * backward_scale;
-    else
-      value = forward_path ? ms_eval_dielectric(smp, w_i, w_o, false, roughness, ext_ior, int_ior, tf) : ms_eval_dielectric(smp, -w_o, -w_i, false, roughness, int_ior, ext_ior, tf) * backward_scale;
-  } else if (w_o.z <= 0.0f) {
-    value = forward_path ? ms_eval_dielectric(smp, -w_i, -w_o, true, roughness, int_ior, ext_ior, tf) : ms_eval_dielectric(smp, -w_o, -w_i, true, roughness, int_ior, ext_ior, tf) * backward_scale;
-  } else {
-    value = forward_path ? ms_eval_dielectric(smp, -w_i, -w_o, false, roughness, int_ior, ext_ior, tf) : ms_eval_dielectric(smp, w_o, w_i, false, roughness, ext_ior, int_ior, tf) * backward_scale;
+  // bsdf_dielectric.hxx:166-182: eight argument patterns of eval_dielectric, selected here so that the walk is ONE call
+  // site: (a, b) = the two directions in the order the pattern passes them, the media swap for patterns that look from inside
+  const bool i_up = w_i.z > 0.0f;
+  const bool same_side = i_up ? (w_o.z >= 0.0f) : (w_o.z <= 0.0f);
+  f3 a = w_i, b = w_o;
+  bool swap_media = false, scaled = false;
+  if (forward_path) {  // (w_i, w_o) seen from the side of w_i
+    a = i_up ? w_i : -w_i;
+    b = i_up ? w_o : -w_o;
+    swap_media = (i_up == false);
+  } else {             // adjoint: the roles of the directions swap, the walk starts from the side of w_o
+    scaled = true;
+    const bool o_up = same_side ? i_up : (i_up == false);  // side of w_o
+    // patterns: (w_o, w_i) when w_o is above the surface, (-w_o, -w_i) otherwise
+    a = o_up ? w_o : -w_o;
+    b = o_up ? w_i : -w_i;
+    swap_media = (o_up == false);
   }
+  const Ior& first_ior = swap_media ? int_ior : ext_ior;
+  const Ior& second_ior = swap_media ? ext_ior : int_ior;
+  f3 value = ms_eval_dielectric(smp, a, b, same_side, roughness, first_ior, second_ior, tf);
+  if (scaled)
+    value = value * backward_scale;
   if (is_zero_rgb(value))
     return eval_zero();
   const bool reflection = w_i.z * w_o.z > 0.0f;

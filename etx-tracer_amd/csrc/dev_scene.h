@@ -91,6 +91,15 @@ struct DCamera {
   uint32_t lens_image, medium_index;
 };
 
+// Shading groups: after the closest-hit query a path is shaded by the kernel of its hit material's group, so one rough
+// gem does not move every Lambert wall hit of the scene onto the general-material kernel (per path, not per scene).
+enum : uint32_t {
+  kShadeGroupSimple = 0,      // Lambert Diffuse, Translucent, Mirror, Boundary, Void, roughness-0 Conductor without thin film; also misses and medium events
+  kShadeGroupGeneral = 1,     // every other class (Heitz walks, thin film, Plastic, Velvet, Principled, rough-diffuse variations)
+  kShadeGroupSubsurface = 2,  // any class with a subsurface layer: the random walk runs inside the shade kernel
+  kShadeGroupCount = 3,
+};
+
 struct DScene {
   const etx_abi_vertex* vertices;
   const etx_abi_triangle* triangles;
@@ -110,6 +119,9 @@ struct DScene {
   const BvhTri* bvh_tris;
   const FlatPrim* flat_prims;      // bvh_flat scenes: pre-transformed primitives of the sweep
   const FlatPrimInfo* flat_info;   // per primitive
+  const DScene* self;              // device address of the device-resident copy of this struct (out-of-line BSDF calls, dev_bsdf_ool.h)
+  const uint32_t* material_variants;  // per material: first of its three PrincipledBSDF variants (appended to `materials`), kInvalid otherwise
+  const uint8_t* material_group;   // per material: shading group of a path that hits it (kShadeGroup*, kernels_shade.inl)
   uint32_t vertex_count, triangle_count, material_count, emitter_count, emitter_dist_count, spectrum_count, image_count, medium_count;
   uint32_t bvh_node_count, bvh_tri_count, flat_prim_count, pad_flat;
   int32_t bvh_root;  // child encoding (a single leaf scene has a negative root)

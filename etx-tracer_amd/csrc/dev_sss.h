@@ -2,7 +2,7 @@
 #pragma once
 
 #include "dev_bvh.h"
-#include "dev_bsdf.h"
+#include "dev_bsdf_ool.h"
 #include "dev_emitters.h"
 
 namespace etxd {

@@ -3,7 +3,7 @@
 #pragma once
 
 #include "dev_bvh.h"
-#include "dev_bsdf.h"
+#include "dev_bsdf_ool.h"
 #include "dev_emitters.h"
 #include "dev_sss.h"
 #include "pipeline.h"
@@ -200,6 +200,25 @@ ETX_DEV void write_shadow(const Pipeline& p, uint32_t idx, const ShadowRequest& 
   p.shadow.value[idx] = mk4(r.value, r.wavelength);
 }
 
+// Endpoint connection request (pipeline.h EndpointQueue). `hit_or_pos`: (u, v, t, triangle) of a surface vertex or
+// (position, kInvalid) of a medium vertex; `w_i`: direction of arrival; `throughput`: the vertex' throughput, already
+// scaled by a subsurface walk when `exit_material` (the vertex is the exit point, shaded by scene.subsurface_exit_material).
+// The request carries the connection's fixed randoms and a sampler stream of its own (the reference continues the
+// path's stream through the stochastic evaluations; the step function keeps that stream for the continuation).
+ETX_DEV void write_endpoint(const Pipeline& p, uint32_t idx, const float4& hit_or_pos, const f3& w_i, const f3& throughput, bool exit_material, float d_vcm, float d_vc, uint32_t depth,
+  uint32_t medium, uint32_t id, float wavelength, const Sampler& smp) {
+  if (idx >= p.endpoints.capacity) {
+    atomicOr(p.counters + kCntOverflow, kOverflowEndpoints);
+    return;
+  }
+  p.endpoints.hit[idx] = hit_or_pos;
+  p.endpoints.wi_medium[idx] = mk4(w_i, __uint_as_float(medium));
+  p.endpoints.thr_depth[idx] = mk4(throughput, __uint_as_float(depth | (exit_material ? kCvExitMaterialBit : 0u)));
+  p.endpoints.mis_id[idx] = make_float4(d_vcm, d_vc, 0.0f, __uint_as_float(id));
+  p.endpoints.rnd_seed[idx] = make_float4(smp.fixed_u, smp.fixed_v, smp.fixed_w, __uint_as_float(Sampler::random_seed(smp.seed, 0x454e4450u)));
+  p.endpoints.wavelength[idx] = wavelength;
+}
+
 // vcm_shared.hxx:218-283 vcm_next_ray
 template <bool kSimple>
 ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& st, const VcmParams& it, const Isect& isect, const BsdfData& bsdf_data, const BsdfSample& bs,
@@ -372,7 +391,6 @@ template <bool kSimple>
 ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st, uint32_t film_target, ShadowRequest& out) {
   if ((opt_connect_to_light(it) == false) || (st.depth + 1 > scene.max_path_length) || (st.depth + 1 < scene.min_path_length))
     return false;
-  const Sampler trap_sampler = st.sampler;  // NaN trap only (dead otherwise)
   f3 sample_pos = camera_at_medium ? medium_pos : isect->pos;
   uint32_t emitter_index = sample_emitter_index(scene, st.sampler.fixed_w);
   EmitterSample es = sample_emitter(scene, emitter_index, f2{st.sampler.fixed_u, st.sampler.fixed_v}, sample_pos, st.wavelength);
@@ -415,38 +433,6 @@ ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool
   float weight = opt_enable_mis(it) ? 1.0f / (1.0f + w_light + w_camera) : 1.0f;
   out = {origin, es.origin, st.throughput * scatter * es.value * (weight / (es.pdf_dir * es.pdf_sample)) * spectral_film_weight(scene, st.wavelength), st.medium, film_target,
     st.wavelength};
-  if ((kSimple == false) && (it.options & 0x80000000u) && (camera_at_medium == false)) {  // NaN trap (ETX_HIP_TRAP), debugging only
-    const bool bad = (out.value.x != out.value.x) || (out.value.y != out.value.y) || (out.value.z != out.value.z);
-    if (bad) {
-      const float scale = weight / (es.pdf_dir * es.pdf_sample);
-      const uint32_t code = ((st.throughput.z != st.throughput.z) ? 1u : 0u) | ((scatter.z != scatter.z) ? 2u : 0u) | ((es.value.z != es.value.z) ? 4u : 0u) |
-                            (((scale != scale) || isinf(scale)) ? 8u : 0u) | (((scatter.x != scatter.x) || (scatter.y != scatter.y)) ? 16u : 0u);
-      const uint32_t mode = (it.options >> 24u) & 15u;
-      const etx_abi_material& mat = scene.materials[isect->material];
-      BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathCamera, st.wavelength);
-      Frame frame = normal_frame(data);
-      const f3 lwo = frame.to_local(w_o), lwi = frame.to_local(-data.w_i);
-      Sampler probe = trap_sampler;
-      Ior ext_ior = evaluate_refractive_index(scene, mat.ext_ior, data.wavelength);
-      Ior int_ior = evaluate_refractive_index(scene, mat.int_ior, data.wavelength);
-      const ThinfilmEval tf = evaluate_thinfilm(scene, mat.thinfilm, data.tex, probe, data.wavelength);
-      const f2 roughness = evaluate_roughness(scene, mat, data.tex);
-      float g = 0.0f, b = 0.0f;
-      switch (mode) {
-        case 0: g = lwi.z, b = lwo.z; break;
-        case 1: g = int_ior.eta.z, b = int_ior.k.z; break;
-        case 2: g = tf.ior.eta.z, b = tf.thickness; break;
-        case 3: g = tf.rgb_wavelengths.z, b = ext_ior.eta.z; break;
-        case 4: g = roughness.x, b = trap_sampler.fixed_u; break;
-        case 5: g = float(mat.cls), b = float(isect->material); break;
-        case 7: g = tf.ior.k.z, b = ext_ior.k.z; break;
-        case 8: g = es.value.z, b = float(emitter_index); break;
-        case 9: g = trap_sampler.fixed_v, b = trap_sampler.fixed_w; break;
-        default: g = scatter.x, b = scatter.y; break;
-      }
-      out.value = f3{1000.0f + float(code), g, b};
-    }
-  }
   return true;
 }
 
@@ -478,7 +464,7 @@ template <bool kDiffuseOnly>
 ETX_DEV BsdfEval bsdf_evaluate_t(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
   if (kDiffuseOnly)
     return diffuse_evaluate(s, d, w_o, m);
-  return bsdf_evaluate(s, d, w_o, m, smp);
+  return bsdf_evaluate_general(s, d, w_o, uint32_t(&m - s.materials), smp);
 }
 template <bool kDiffuseOnly>
 ETX_DEV float bsdf_reverse_pdf_t(const DScene& s, const BsdfData& d, const f3& w_o, const etx_abi_material& m, Sampler& smp) {
@@ -487,7 +473,7 @@ ETX_DEV float bsdf_reverse_pdf_t(const DScene& s, const BsdfData& d, const f3& w
     r.w_i = -w_o;
     return diffuse_pdf(r, -d.w_i);
   }
-  return bsdf_reverse_pdf(s, d, w_o, m, smp);
+  return bsdf_reverse_pdf_s<false>(s, d, w_o, m, smp);
 }
 
 // vcm_shared.hxx:673-763 vcm_connect_to_light_vertex (surface / medium on either side)
@@ -603,6 +589,33 @@ ETX_DEV CameraVertex load_camera_vertex(const Pipeline& p, const DScene& scene, 
     cv.isect = make_intersection(scene, cv.st.ray_d, h.x, h.y, h.z, tri);
   if ((cv.at_medium == false) && (depth_bits & kCvExitMaterialBit))
     cv.isect.material = scene.subsurface_exit_material;  // exit point of a subsurface walk (vcm_shared.hxx:1037-1038)
+  return cv;
+}
+
+// An endpoint connection request as the step functions wrote it (EndpointQueue): the vertex with the state
+// vcm_connect_to_camera / vcm_connect_to_light read.
+ETX_DEV CameraVertex load_endpoint(const Pipeline& p, const DScene& scene, uint32_t i) {
+  CameraVertex cv;
+  const float4 h = p.endpoints.hit[i], w = p.endpoints.wi_medium[i], t = p.endpoints.thr_depth[i], m = p.endpoints.mis_id[i], r = p.endpoints.rnd_seed[i];
+  cv.st.ray_d = {w.x, w.y, w.z};
+  cv.st.medium = __float_as_uint(w.w);
+  cv.st.throughput = {t.x, t.y, t.z};
+  const uint32_t depth_bits = __float_as_uint(t.w);
+  cv.st.depth = depth_bits & 0x7fffffffu;
+  cv.st.d_vcm = m.x, cv.st.d_vc = m.y, cv.st.d_vm = 0.0f;
+  cv.st.id = __float_as_uint(m.w);
+  cv.st.sampler.seed = __float_as_uint(r.w);
+  cv.st.sampler.fixed_u = r.x, cv.st.sampler.fixed_v = r.y, cv.st.sampler.fixed_w = r.z;
+  cv.st.wavelength = p.endpoints.wavelength[i];
+  cv.st.eta = 1.0f, cv.st.path_distance = 0.0f, cv.st.flags = 0u;
+  cv.st.ray_o = mk3(0.0f), cv.st.ray_tmin = 0.0f, cv.st.ray_tmax = 0.0f;
+  const uint32_t tri = __float_as_uint(h.w);
+  cv.at_medium = tri == kInvalid;
+  cv.medium_pos = {h.x, h.y, h.z};
+  if (cv.at_medium == false)
+    cv.isect = make_intersection(scene, cv.st.ray_d, h.x, h.y, h.z, tri);
+  if ((cv.at_medium == false) && (depth_bits & kCvExitMaterialBit))
+    cv.isect.material = scene.subsurface_exit_material;
   return cv;
 }
 

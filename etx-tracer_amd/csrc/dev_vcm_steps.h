@@ -69,8 +69,10 @@ enum : uint32_t { kEventNone = 0, kEventMedium = 1, kEventSurface = 2, kEventBou
 // `slots.get(wanted, counter)` reserves queue / pool slots: the wavefront kernels call this function from
 // workgroup-uniform control flow (lanes without a path pass valid = false) and reserve once per workgroup, so the
 // reservation points sit outside every data-dependent branch.
-template <bool kSimple, class Slots>
+template <uint32_t kGroup, class Slots>
 ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots, const LaneStack& stack) {
+  constexpr bool kSimple = kGroup == kShadeGroupSimple;      // BSDF classes compiled in (dev_bsdf_ool.h)
+  constexpr bool kWalk = kGroup == kShadeGroupSubsurface;   // the subsurface random walk runs inline
   const uint32_t tri = __float_as_uint(h.w);
   const bool found = valid && (tri != kInvalid);
   Isect isect;
@@ -127,7 +129,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
       store = (bs.properties & kSampleDelta) == 0u;  // is_connectible
       connect = store && opt_connect_to_camera(it) && (st.depth + 1 <= scene.max_path_length);
       // vcm_shared.hxx:1198-1200: a diffuse sample on a subsurface material walks through the object
-      if ((kSimple == false) && (bs.properties & kSampleDiffuse) && (mat.subsurface.cls != 0u)) {
+      if (kWalk && (bs.properties & kSampleDiffuse) && (mat.subsurface.cls != 0u)) {
         subsurface_path = true;
         subsurface_sampled = sss_gather_rw(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight);
         ss_isect.material = scene.subsurface_exit_material;
@@ -143,23 +145,32 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
     else
       store_light_vertex(p, vertex_slot, st, isect.pos, isect.nrm, isect.bc.y, isect.bc.z, isect.tri);
   }
-  ShadowRequest request;
-  bool queue = false;
-  if (connect) {
-    st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-    if (subsurface_sampled) {  // vcm_shared.hxx:1208-1222: from the exit point, through the exit material, scaled by the walk
-      PathState scaled = st;
-      scaled.throughput = st.throughput * ss_weight;
-      queue = vcm_connect_to_camera<kSimple>(scene, it, false, &ss_isect, ms.pos, scaled, request);
-      st.sampler = scaled.sampler;
-    } else {  // also when the walk failed: the reference connects the entry vertex, then ends the path (:1223-1231, 1249-1251)
-      queue = vcm_connect_to_camera<kSimple>(scene, it, at_medium, &isect, ms.pos, st, request);
+  // vcm_shared.hxx:1208-1222: after a walk the connection starts at the exit point, through the exit material, scaled by
+  // the walk; when the walk failed the reference connects the entry vertex, then ends the path (:1223-1231, 1249-1251).
+  const bool from_exit = kWalk && subsurface_sampled;
+  if (kSimple) {  // Lambert / delta surfaces and media: connect inline
+    ShadowRequest request;
+    bool queue = false;
+    if (connect) {
+      st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+      queue = vcm_connect_to_camera<true>(scene, it, at_medium, &isect, ms.pos, st, request);
+      st.sampler.pop_fixed();
     }
-    st.sampler.pop_fixed();
+    const uint32_t shadow_slot = slots.get(queue, p.counters + kCntShadow);
+    if (queue)
+      write_shadow(p, shadow_slot, request);
+  } else {  // general BSDFs: the evaluation runs in k_connect_endpoints (pipeline.h EndpointQueue)
+    connect = connect && (st.depth + 2 <= scene.max_path_length) && (st.depth + 2 >= scene.min_path_length);  // the early-outs of vcm_connect_to_camera
+    const uint32_t endpoint_slot = slots.get(connect, p.counters + kCntEndpoints);
+    if (connect) {
+      st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+      const Isect& from = from_exit ? ss_isect : isect;
+      const float4 where = at_medium ? mk4(ms.pos, __uint_as_float(kInvalid)) : make_float4(from.bc.y, from.bc.z, from.t, __uint_as_float(from.tri));
+      write_endpoint(p, endpoint_slot, where, at_medium ? st.ray_d : from.w_i, from_exit ? st.throughput * ss_weight : st.throughput, from_exit, st.d_vcm, st.d_vc, st.depth, st.medium, st.id,
+        st.wavelength, st.sampler);
+      st.sampler.pop_fixed();
+    }
   }
-  const uint32_t shadow_slot = slots.get(queue, p.counters + kCntShadow);
-  if (queue)
-    write_shadow(p, shadow_slot, request);
 
   // ---- phase C
   if (event == kEventBoundary)
@@ -184,17 +195,15 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
   }
   if (subsurface_path && (subsurface_sampled == false))
     return false;
-  if (subsurface_sampled) {  // vcm_shared.hxx:1237-1247
+  if (kWalk && subsurface_sampled) {  // vcm_shared.hxx:1237-1247: continue from the exit point with a cosine lobe
     st.throughput *= ss_weight;
     bs.w_o = sample_cosine_distribution(rnd_bsdf, ss_isect.nrm, 1.0f);
     bs.pdf = fabsf(dot(bs.w_o, ss_isect.nrm)) / kPi;
     bs.eta = 1.0f;
     bsdf_data = make_bsdf_data(ss_isect, ss_isect.w_i, st.medium, kPathLight, st.wavelength);
-    if (vcm_next_ray<kSimple>(scene, kPathLight, st, it, ss_isect, bsdf_data, bs, true))
-      return st.depth + 1u < scene.max_path_length;
-    return false;
+    isect = ss_isect;
   }
-  if (vcm_next_ray<kSimple>(scene, kPathLight, st, it, isect, bsdf_data, bs))
+  if (vcm_next_ray<kSimple>(scene, kPathLight, st, it, isect, bsdf_data, bs, kWalk && subsurface_sampled))
     return st.depth + 1u < scene.max_path_length;
   return false;
 }
@@ -202,8 +211,10 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
 // vcm_camera_step, vcm_shared.hxx:927-1079 after rt.trace, without the vertex connections and the merge: connectible
 // vertices go to the camera vertex pool (k_expand_pairs / k_connect_pairs / k_merge consume them), NEE segments go to
 // the shadow queue, direct / miss radiance goes straight to the film. Same three-phase shape as light_step.
-template <bool kSimple, class Slots>
+template <uint32_t kGroup, class Slots>
 ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots, const LaneStack& stack) {
+  constexpr bool kSimple = kGroup == kShadeGroupSimple;
+  constexpr bool kWalk = kGroup == kShadeGroupSubsurface;
   const uint32_t tri = __float_as_uint(h.w);
   const bool found = valid && (tri != kInvalid);
   Isect isect;
@@ -284,7 +295,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       nee = is_connectible;
       store = is_connectible && (opt_connect_vertices(it) || (opt_merge_vertices(it) && (st.depth + 1 <= scene.max_path_length)));
       // vcm_shared.hxx:1032-1034
-      if ((kSimple == false) && (bs.properties & kSampleDiffuse) && (mat.subsurface.cls != 0u)) {
+      if (kWalk && (bs.properties & kSampleDiffuse) && (mat.subsurface.cls != 0u)) {
         subsurface_path = true;
         subsurface_sampled = sss_gather_rw(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight);
         ss_isect.material = scene.subsurface_exit_material;
@@ -314,23 +325,31 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       store_camera_vertex(p, vertex_slot, scene, st, h, derived.seed, &isect);
     }
   }
-  ShadowRequest request;
-  bool queue = false;
-  if (nee) {
-    st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-    if (subsurface_sampled) {
-      PathState scaled = st;
-      scaled.throughput = st.throughput * ss_weight;
-      queue = vcm_connect_to_light<kSimple>(scene, it, false, &ss_isect, ms.pos, scaled, film_index(it, st.id), request);
-      st.sampler = scaled.sampler;
-    } else {
-      queue = vcm_connect_to_light<kSimple>(scene, it, at_medium, &isect, ms.pos, st, film_index(it, st.id), request);
+  // next event estimation; vcm_shared.hxx:1036-1046: after a walk, from the exit point scaled by the walk
+  const bool from_exit = kWalk && subsurface_sampled;
+  if (kSimple) {
+    ShadowRequest request;
+    bool queue = false;
+    if (nee) {
+      st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+      queue = vcm_connect_to_light<true>(scene, it, at_medium, &isect, ms.pos, st, film_index(it, st.id), request);
+      st.sampler.pop_fixed();
     }
-    st.sampler.pop_fixed();
+    const uint32_t shadow_slot = slots.get(queue, p.counters + kCntShadow);
+    if (queue)
+      write_shadow(p, shadow_slot, request);
+  } else {  // general BSDFs: k_connect_endpoints (pipeline.h EndpointQueue)
+    nee = nee && opt_connect_to_light(it) && (st.depth + 1 <= scene.max_path_length) && (st.depth + 1 >= scene.min_path_length);  // the early-outs of vcm_connect_to_light
+    const uint32_t endpoint_slot = slots.get(nee, p.counters + kCntEndpoints);
+    if (nee) {
+      st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+      const Isect& from = from_exit ? ss_isect : isect;
+      const float4 where = at_medium ? mk4(ms.pos, __uint_as_float(kInvalid)) : make_float4(from.bc.y, from.bc.z, from.t, __uint_as_float(from.tri));
+      write_endpoint(p, endpoint_slot, where, at_medium ? st.ray_d : from.w_i, from_exit ? st.throughput * ss_weight : st.throughput, from_exit, st.d_vcm, st.d_vc, st.depth, st.medium, st.id,
+        st.wavelength, st.sampler);
+      st.sampler.pop_fixed();
+    }
   }
-  const uint32_t shadow_slot = slots.get(queue, p.counters + kCntShadow);
-  if (queue)
-    write_shadow(p, shadow_slot, request);
 
   // ---- phase C
   if (event == kEventBoundary)
@@ -350,15 +369,15 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
   }
   if (subsurface_path && (subsurface_sampled == false))
     return false;
-  if (subsurface_sampled) {  // vcm_shared.hxx:1049-1061
+  if (kWalk && subsurface_sampled) {  // vcm_shared.hxx:1049-1061
     st.throughput *= ss_weight;
     bs.w_o = sample_cosine_distribution(rnd_bsdf, ss_isect.nrm, 1.0f);
     bs.pdf = fabsf(dot(bs.w_o, ss_isect.nrm)) / kPi;
     bs.eta = 1.0f;
     bsdf_data = make_bsdf_data(ss_isect, ss_isect.w_i, st.medium, kPathCamera, st.wavelength);
-    return vcm_next_ray<kSimple>(scene, kPathCamera, st, it, ss_isect, bsdf_data, bs, true);
+    isect = ss_isect;
   }
-  return vcm_next_ray<kSimple>(scene, kPathCamera, st, it, isect, bsdf_data, bs);
+  return vcm_next_ray<kSimple>(scene, kPathCamera, st, it, isect, bsdf_data, bs, kWalk && subsurface_sampled);
 }
 
 }  // namespace etxd

@@ -198,6 +198,8 @@ int allocate_pipeline(etx_hip_context* ctx) {
   if ((rc = device_alloc(ctx, p.cv.hit, n)) || (rc = device_alloc(ctx, p.cv.wi_medium, n)) || (rc = device_alloc(ctx, p.cv.thr_depth, n)) || (rc = device_alloc(ctx, p.cv.mis_pixel, n)) ||
       (rc = device_alloc(ctx, p.cv.seed, n)) || (rc = device_alloc(ctx, p.cv.pos_info, n)) || (rc = device_alloc(ctx, p.cv.nrm_dvm, n)) || (rc = device_alloc(ctx, p.cv.fthr_dvcm, n)))
     return rc;
+  if ((rc = device_alloc(ctx, p.group_list[0], n)) || (rc = device_alloc(ctx, p.group_list[1], n)))
+    return rc;
   if ((rc = device_alloc(ctx, p.merge_order, n)) || (rc = device_alloc(ctx, p.merge_buckets, kMergeBuckets + 1u + 256u)))
     return rc;
   p.pair_capacity = uint32_t(std::min<uint64_t>(uint64_t(n) * 16u, 1ull << 30));
@@ -276,8 +278,6 @@ VcmParams make_iteration_params(const etx_hip_context* ctx, uint32_t iteration) 
   const auto& sc = ctx->scene.host_copy;
   VcmParams it = {};
   it.options = o.options;
-  if (const char* e = getenv("ETX_HIP_TRAP"))  // NaN trap of vcm_connect_to_light (debugging): mode in bits 24..27
-    it.options |= 0x80000000u | ((uint32_t(strtoul(e, nullptr, 0)) & 15u) << 24u);
   it.kernel = o.kernel;
   it.iteration = iteration;
   it.film_w = ctx->scene.film_w, it.film_h = ctx->scene.film_h;
@@ -295,6 +295,13 @@ VcmParams make_iteration_params(const etx_hip_context* ctx, uint32_t iteration) 
   it.vm_normalization = 1.0f / eta_vcm;
   it.bluenoise = reinterpret_cast<const uint2*>(ctx->active_bluenoise);
   return it;
+}
+
+ShadeGroups shade_groups(const etx_hip_context* ctx) {
+  ShadeGroups g;
+  g.general = ctx->scene.group_general;
+  g.subsurface = ctx->scene.group_subsurface;
+  return g;
 }
 
 // One pass of the wavefront loop: trace + shade rounds until no path is alive. The active count lives on the device;
@@ -346,7 +353,7 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
     [&](uint32_t set, uint32_t max_items) {
       {
         ScopedTimer t(ctx, kTimerShadeLight);
-        launch_light_shade(s, p, it, set, max_items, ctx->scene.simple_materials);
+        launch_light_shade(s, p, it, set, max_items, shade_groups(ctx));
       }
       if (opt_connect_to_camera(it)) {
         ScopedTimer t(ctx, kTimerTraceShadow);
@@ -356,7 +363,7 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
     [&](uint32_t set, uint32_t max_items) {
       {
         ScopedTimer t(ctx, kTimerShadeLight);
-        launch_light_tail(s, p, it, set, max_items, ctx->scene.simple_materials);
+        launch_light_tail(s, p, it, set, max_items, shade_groups(ctx));
       }
       if (opt_connect_to_camera(it)) {
         ScopedTimer t(ctx, kTimerTraceShadow);
@@ -384,7 +391,7 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
     [&](uint32_t set, uint32_t max_items) {
       {
         ScopedTimer t(ctx, kTimerShadeCamera);
-        launch_camera_shade(s, p, it, set, max_items, ctx->scene.simple_materials);
+        launch_camera_shade(s, p, it, set, max_items, shade_groups(ctx));
       }
       if (opt_connect_vertices(it)) {
         ScopedTimer t(ctx, kTimerConnect);
@@ -402,7 +409,7 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
     [&](uint32_t set, uint32_t max_items) {
       {
         ScopedTimer t(ctx, kTimerShadeCamera);
-        launch_camera_tail(s, p, it, set, max_items, ctx->scene.simple_materials);
+        launch_camera_tail(s, p, it, set, max_items, shade_groups(ctx));
       }
       // the tail leaves up to `capacity` camera vertices: drain them with one launch of each consumer
       if (opt_connect_vertices(it)) {
@@ -451,7 +458,7 @@ int render_pt_iteration(etx_hip_context* ctx, uint32_t iteration) {
     [&](uint32_t set, uint32_t max_items) {
       {
         ScopedTimer t(ctx, kTimerShadeCamera);
-        launch_pt_shade(s, p, it, set, max_items, ctx->scene.simple_materials);
+        launch_pt_shade(s, p, it, set, max_items, shade_groups(ctx));
       }
       if (o.direct || o.nee) {
         ScopedTimer t(ctx, kTimerTraceShadow);
@@ -877,6 +884,9 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
     patch(context);
     for (etx_hip_context* helper : context->helpers)
       patch(helper);
+    HIP_OK(context, hipSetDevice(context->device));
+    if (int rc = context->scene.sync_device_copy(context->error))  // the out-of-line BSDF code reads the device-resident header
+      return rc;
   }
   HIP_OK(context, hipSetDevice(context->device));
   context->integrator = integrator;

@@ -26,6 +26,14 @@ void DeviceScene::release() {
   host_copy = {};
 }
 
+int DeviceScene::sync_device_copy(std::string& error) {
+  if ((device != nullptr) && (hipMemcpy(device, &host_copy, sizeof(DScene), hipMemcpyHostToDevice) != hipSuccess)) {
+    error = "hipMemcpy of the scene header failed";
+    return ETX_HIP_ERROR_HIP;
+  }
+  return 0;
+}
+
 void DeviceScene::borrow(const DeviceScene& owner) {
   release();
   flat_prims = owner.flat_prims;
@@ -34,6 +42,7 @@ void DeviceScene::borrow(const DeviceScene& owner) {
   film_w = owner.film_w, film_h = owner.film_h;
   bvh_depth = owner.bvh_depth;
   simple_materials = owner.simple_materials;
+  group_general = owner.group_general, group_subsurface = owner.group_subsurface;
   has_subsurface = owner.has_subsurface;
   generic_materials = owner.generic_materials;
   bvh_bytes = owner.bvh_bytes;
@@ -396,9 +405,9 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   }
   out.generic_materials = false;
   out.simple_materials = true;
+  // Shading group per material (dev_scene.h kShadeGroup*): a path is shaded by the kernel of its hit material's group.
+  std::vector<uint8_t> groups(scene->materials.count, uint8_t(kShadeGroupSimple));
   for (uint64_t i = 0; i < scene->materials.count; ++i) {
-    if (used[i] == false)
-      continue;
     const etx_abi_material& m = materials[i];
     const bool constant_roughness = m.roughness.image_index == ETX_ABI_INVALID;
     const float max_roughness = std::max(m.roughness.value.x, m.roughness.value.y);
@@ -408,13 +417,58 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     const bool lambert = (m.cls == ETX_MAT_DIFFUSE) && (m.diffuse_variation == 0u);
     const bool always_delta = (m.cls == ETX_MAT_MIRROR) || (m.cls == ETX_MAT_THINFILM) || (m.cls == ETX_MAT_BOUNDARY) || (m.cls == ETX_MAT_VOID) ||
                               (((m.cls == ETX_MAT_CONDUCTOR) || (m.cls == ETX_MAT_DIELECTRIC)) && constant_roughness && (max_roughness <= kDeltaAlphaTreshold));
-    if ((lambert == false) && (always_delta == false))
-      out.generic_materials = true;
     // "simple" = the shade kernels need neither the Heitz walk nor a sampler-dependent evaluation (dev_bsdf.h)
     const bool mirror_conductor = (m.cls == ETX_MAT_CONDUCTOR) && constant_roughness && (m.roughness.value.x == 0.0f) && (m.roughness.value.y == 0.0f) && (thin_film == false);
     const bool simple = lambert || (m.cls == ETX_MAT_TRANSLUCENT) || (m.cls == ETX_MAT_MIRROR) || (m.cls == ETX_MAT_BOUNDARY) || (m.cls == ETX_MAT_VOID) || mirror_conductor;
+    groups[i] = uint8_t((m.subsurface.cls != 0u) ? kShadeGroupSubsurface : (simple ? kShadeGroupSimple : kShadeGroupGeneral));
+    if (used[i] == false)
+      continue;
+    if ((lambert == false) && (always_delta == false))
+      out.generic_materials = true;
     if ((simple == false) || (m.subsurface.cls != 0u))
       out.simple_materials = false;
+  }
+  if (const char* e = getenv("ETX_HIP_FORCE_GENERIC_MATERIALS")) {  // tests: every surface through the general kernels
+    if (atoi(e) != 0) {
+      out.simple_materials = false;
+      for (auto& g : groups)
+        g = (g == kShadeGroupSimple) ? uint8_t(kShadeGroupGeneral) : g;
+    }
+  }
+  // PrincipledBSDF (bsdf_principled.hxx:24-114) evaluates Conductor / Dielectric / Plastic on a modified copy of the
+  // material; the three copies are static, so they are appended to the table once (dev_bsdf_ool.h resolve_material)
+  std::vector<etx_abi_material> material_table(materials, materials + scene->materials.count);
+  std::vector<uint32_t> variants(scene->materials.count, kInvalid);
+  for (uint64_t i = 0; i < scene->materials.count; ++i) {
+    if (materials[i].cls != ETX_MAT_PRINCIPLED)
+      continue;
+    variants[i] = uint32_t(material_table.size());
+    etx_abi_material conductor = materials[i];  // bsdf_principled.hxx:34-40
+    conductor.int_ior.cls = kSpectrumClassConductor;
+    conductor.int_ior.eta_index = scene->default_conductor_eta;
+    conductor.int_ior.k_index = scene->default_conductor_k;
+    conductor.scattering.image_index = ETX_ABI_INVALID;
+    conductor.cls = ETX_MAT_CONDUCTOR;
+    etx_abi_material dielectric = materials[i];  // :42-52
+    dielectric.int_ior.cls = kSpectrumClassDielectric;
+    dielectric.int_ior.eta_index = scene->default_dielectric_eta;
+    dielectric.int_ior.k_index = ETX_ABI_INVALID;
+    dielectric.reflectance.image_index = ETX_ABI_INVALID;
+    etx_abi_material plastic = dielectric;
+    dielectric.cls = ETX_MAT_DIELECTRIC;
+    plastic.cls = ETX_MAT_PLASTIC;
+    material_table.push_back(conductor);
+    material_table.push_back(dielectric);
+    material_table.push_back(plastic);
+  }
+  variants.resize(material_table.size(), kInvalid);
+  groups.resize(material_table.size(), uint8_t(kShadeGroupGeneral));
+  out.group_general = out.group_subsurface = false;
+  for (uint64_t i = 0; i < scene->materials.count; ++i) {
+    if (used[i] || (i == scene->subsurface_exit_material)) {
+      out.group_general = out.group_general || (groups[i] == kShadeGroupGeneral);
+      out.group_subsurface = out.group_subsurface || (groups[i] == kShadeGroupSubsurface);
+    }
   }
   DScene d = {};
   int rc = 0;
@@ -424,7 +478,8 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     return rc;
   if ((rc = upload(out, reinterpret_cast<const uint32_t*>(scene->triangle_to_emitter.a), scene->triangle_to_emitter.count, d.triangle_to_emitter, error)))
     return rc;
-  if ((rc = upload(out, materials, scene->materials.count, d.materials, error)))
+  if ((rc = upload(out, material_table.data(), material_table.size(), d.materials, error)) || (rc = upload(out, variants.data(), variants.size(), d.material_variants, error)) ||
+      (rc = upload(out, groups.data(), groups.size(), d.material_group, error)))
     return rc;
   if ((rc = upload(out, reinterpret_cast<const etx_abi_emitter_profile*>(scene->emitter_profiles.a), scene->emitter_profiles.count, d.emitter_profiles, error)))
     return rc;
@@ -574,8 +629,6 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
       fprintf(stderr, "[etx_hip] flat sweep: %zu triangles -> %zu primitives\n", bvh.tris.size(), prims.size());
   }
   d.bvh_root = bvh.root;
-  if (const char* e = getenv("ETX_HIP_FORCE_GENERIC_MATERIALS"))
-    out.simple_materials = (atoi(e) != 0) ? false : out.simple_materials;
   d.bvh_flat = (bvh.tris.size() <= kFlatSweepMaxTriangles) ? 1u : 0u;
   if (const char* e = getenv("ETX_HIP_FORCE_BVH"))
     d.bvh_flat = (atoi(e) != 0) ? 0u : d.bvh_flat;
@@ -617,11 +670,14 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   c.clip_near = camera->clip_near, c.clip_far = camera->clip_far;
   c.lens_image = camera->lens_image, c.medium_index = camera->medium_index;
 
-  out.host_copy = d;
   const DScene* dev = nullptr;
   if ((rc = upload(out, &d, 1, dev, error)))
     return rc;
   out.device = const_cast<DScene*>(dev);
+  d.self = dev;
+  out.host_copy = d;
+  if ((rc = out.sync_device_copy(error)))
+    return rc;
   out.film_w = camera->film_size.x;
   out.film_h = camera->film_size.y;
   return 0;

@@ -23,12 +23,15 @@ struct DeviceScene {
   uint32_t film_w = 0, film_h = 0;
   uint32_t bvh_depth = 0;
   bool simple_materials = false;   // only Diffuse / Translucent / Mirror / Boundary / Void / roughness-0 Conductor in use (dev_bsdf.h)
+  bool group_general = false;      // a material of shading group kShadeGroupGeneral is in use (dev_scene.h)
+  bool group_subsurface = false;   // ... of kShadeGroupSubsurface
   bool has_subsurface = false;     // a random-walk subsurface material is in use (PT only so far)
   bool generic_materials = false;  // a connectible (non delta) surface material other than Diffuse is in use
   size_t bvh_bytes = 0;
 
   ~DeviceScene();
   void release();
+  int sync_device_copy(std::string& error);  // after the host patched host_copy (CIE table): refresh the device-resident header
   void borrow(const DeviceScene& owner);  // non-owning view of the owner's device tables (helper lanes, host_api.cpp)
 };
 

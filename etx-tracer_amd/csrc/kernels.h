@@ -9,6 +9,17 @@ namespace etxd {
 constexpr uint32_t kBlockSize = 256;
 constexpr uint32_t kPersistentBlocks = 256 * 8;  // 256 CUs x 8 blocks of 256 threads, grid-stride loops
 
+// Shading groups the scene holds besides "simple" (dev_scene.h kShadeGroup*, set at upload from the materials in use)
+struct ShadeGroups {
+  bool general = false, subsurface = false;
+  bool binned() const {
+    return general || subsurface;
+  }
+  uint32_t widest() const {  // the group whose kernel shades every material of the scene (tail kernels)
+    return subsurface ? uint32_t(kShadeGroupSubsurface) : (general ? uint32_t(kShadeGroupGeneral) : uint32_t(kShadeGroupSimple));
+  }
+};
+
 // traversal
 // `max_items`: host-side upper bound of the device-resident item count (sizes the grid; kernels grid-stride anyway)
 void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat);
@@ -19,23 +30,23 @@ void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ra
 void launch_stats_finalize(hipStream_t stream, const Pipeline& p);
 void launch_iteration_reset(hipStream_t stream, const Pipeline& p);
 void launch_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
-void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);
+void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups);
 
 // path tracer (kernels_pt.hip)
 void launch_pt_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
-void launch_pt_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);
+void launch_pt_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups);
 void launch_pt_commit(hipStream_t stream, float4* iteration_image, float4* camera_sum, uint32_t pixels, float radiance_clamp);
 
 // tail: the few paths that are still alive after many bounces finish inside one launch (kernels_tail.hip)
-void launch_light_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);
-void launch_camera_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);
+void launch_light_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups);
+void launch_camera_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups);
 
 // photon grid
 void launch_grid_build(hipStream_t stream, const Pipeline& p, const VcmParams& it);
 
 // VCM camera pass
 void launch_camera_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
-void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials);
+void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups);
 void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items);
 void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items);
 

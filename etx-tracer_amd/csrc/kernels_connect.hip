@@ -551,9 +551,9 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
           Sampler smp;  // the reference continues the path's stream through all photons; here one stream per (vertex, photon)
           smp.seed = Sampler::random_seed(v.seed, j);
           smp.fixed_u = smp.fixed_v = smp.fixed_w = 0.0f;
-          const BsdfEval camera_bsdf = bsdf_evaluate(scene, camera_data, -wi, mat, smp);
+          const BsdfEval camera_bsdf = bsdf_evaluate_general(scene, camera_data, -wi, v.material, smp);
           if (camera_bsdf.valid()) {
-            const float rev_pdf = bsdf_reverse_pdf(scene, camera_data, -wi, mat, smp);
+            const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, camera_data, -wi, mat, smp);
             const float w_light = nd.w * it.vc_weight + wd.w * camera_bsdf.pdf;
             const float w_camera = v.w_camera_base + v.d_vm * rev_pdf;
             const float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;

@@ -12,8 +12,7 @@
 //                   segment), accumulation into the camera image; normal / albedo AOVs are added by k_pt_shade
 // PathState reuse: depth = path_length, d_vcm = sampled_bsdf_pdf, flags bit kPtMisWeight = payload.mis_weight.
 // Not implemented (etx_hip_upload_scene / etx_hip_begin reject them): subsurface scattering, spectral mode.
-#include "kernels.h"
-#include "dev_vcm.h"
+#include "kernels_shade.inl"  // shading groups, bin_foreign_groups
 
 namespace etxd {
 
@@ -92,8 +91,10 @@ struct PtRequests {
 };
 
 // run_path_iteration after rt.trace, path_tracing_shared.hxx:479-508
-template <bool kSimple>
+template <uint32_t kGroup>
 ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, PtRequests& out, const LaneStack& stack) {
+  constexpr bool kSimple = kGroup == kShadeGroupSimple;
+  constexpr bool kWalk = kGroup == kShadeGroupSubsurface;
   const bool opt_direct = (it.options & ETX_PT_DIRECT) != 0u, opt_nee = (it.options & ETX_PT_NEE) != 0u, opt_mis = (it.options & ETX_PT_MIS) != 0u;
   if (st.depth > scene.max_path_length)
     return false;
@@ -212,7 +213,7 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
   bool subsurface_sampled = false;
   Isect ss_isect;
   f3 ss_weight = mk3(0.0f);
-  if ((kSimple == false) && (mat.subsurface.cls != 0u) && (bs.properties & kSampleReflection) && (bs.properties & kSampleDiffuse)) {
+  if (kWalk && (mat.subsurface.cls != 0u) && (bs.properties & kSampleReflection) && (bs.properties & kSampleDiffuse)) {
     subsurface_sampled = sss_gather_rw(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight);
     if (subsurface_sampled == false)
       return false;
@@ -267,25 +268,33 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
   return random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
 }
 
-template <bool kSimple>
+template <uint32_t kGroup, bool kBin>
 __global__ __launch_bounds__(kBlockSize) void k_pt_shade(Pipeline p, VcmParams it, uint32_t in_set) {
+  constexpr bool kWalk = kGroup == kShadeGroupSubsurface;
   __shared__ BlockScratch s_scratch;
-  __shared__ int32_t s_stack[kSimple ? 1 : kStackDepth * kBlockSize];  // the subsurface walk traverses inline (general materials only)
-  const LaneStack stack = {s_stack + (kSimple ? 0u : threadIdx.x), kBlockSize};
+  __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];  // the subsurface walk traverses inline
+  const LaneStack stack = {s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize};
   const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const PathSet& out = p.paths[in_set ^ 1u];
-  const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
+  const uint32_t count = shade_item_count<kGroup>(p, in_set);
   uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
   const BlockSlots slots = {&s_scratch};
-  ETX_BLOCK_LOOP(count, i) {
+  ETX_BLOCK_LOOP(count, j) {
+    bool valid = j < count;
+    const uint32_t i = (kGroup == kShadeGroupSimple) ? j : (valid ? p.group_list[kGroup == kShadeGroupSimple ? 0u : kGroup - 1u][j] : 0u);
     PathState st;
     PtRequests requests;
     requests.has_direct = requests.has_nee = false;
+    float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
+    if (valid)
+      h = p.hits[i];
+    if (kBin)
+      valid = bin_foreign_groups(p, slots, i, hit_shade_group(scene, h), valid);
     bool alive = false;
-    if (i < count) {
+    if (valid) {
       st = load_path(in, i);
-      alive = pt_step<kSimple>(p, scene, it, st, p.hits[i], requests, stack);
+      alive = pt_step<kGroup>(p, scene, it, st, h, requests, stack);
     }
     const uint32_t direct_slot = slots.get(requests.has_direct, p.counters + kCntShadow);
     if (requests.has_direct)
@@ -319,12 +328,17 @@ void launch_pt_generate(hipStream_t stream, const Pipeline& p, const VcmParams& 
   hipLaunchKernelGGL(k_pt_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
 }
 
-void launch_pt_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials) {
+void launch_pt_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups) {
   const dim3 grid(max(1u, grid_for(min(p.capacity, max_items))));
-  if (simple_materials)
-    hipLaunchKernelGGL(k_pt_shade<true>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
-  else
-    hipLaunchKernelGGL(k_pt_shade<false>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+  if (groups.binned() == false) {
+    hipLaunchKernelGGL((k_pt_shade<kShadeGroupSimple, false>), grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+    return;
+  }
+  hipLaunchKernelGGL((k_pt_shade<kShadeGroupSimple, true>), grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+  if (groups.general)
+    hipLaunchKernelGGL((k_pt_shade<kShadeGroupGeneral, false>), grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+  if (groups.subsurface)
+    hipLaunchKernelGGL((k_pt_shade<kShadeGroupSubsurface, false>), grid, dim3(kBlockSize), 0, stream, p, it, in_set);
 }
 
 void launch_pt_commit(hipStream_t stream, float4* iteration_image, float4* camera_sum, uint32_t pixels, float radiance_clamp) {

@@ -20,20 +20,20 @@ __global__ void k_reset_round_counters(Pipeline p) {
   }
 }
 
-void launch_light_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials) {
+void launch_light_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups) {
   hipLaunchKernelGGL(k_reset_round_counters, dim3(1), dim3(64), 0, stream, p);
-  if (simple_materials)
-    hipLaunchKernelGGL((k_path_tail<false, true>), dim3(tail_blocks(max_items)), dim3(kBlockSize), 0, stream, p, it, in_set);
+  if (groups.binned() == false)
+    hipLaunchKernelGGL((k_path_tail<false, kShadeGroupSimple>), dim3(tail_blocks(max_items)), dim3(kBlockSize), 0, stream, p, it, in_set);
   else
-    launch_light_tail_general(stream, p, it, in_set, tail_blocks(max_items));
+    launch_light_tail_group(stream, p, it, in_set, tail_blocks(max_items), groups.widest());
 }
 
-void launch_camera_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials) {
+void launch_camera_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups) {
   hipLaunchKernelGGL(k_reset_round_counters, dim3(1), dim3(64), 0, stream, p);
-  if (simple_materials)
-    hipLaunchKernelGGL((k_path_tail<true, true>), dim3(tail_blocks(max_items)), dim3(kBlockSize), 0, stream, p, it, in_set);
+  if (groups.binned() == false)
+    hipLaunchKernelGGL((k_path_tail<true, kShadeGroupSimple>), dim3(tail_blocks(max_items)), dim3(kBlockSize), 0, stream, p, it, in_set);
   else
-    launch_camera_tail_general(stream, p, it, in_set, tail_blocks(max_items));
+    launch_camera_tail_group(stream, p, it, in_set, tail_blocks(max_items), groups.widest());
 }
 
 }  // namespace etxd

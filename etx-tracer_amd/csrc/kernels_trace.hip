@@ -26,6 +26,8 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
     counters[kCntPairs] = 0u;
     counters[kCntShadow] = 0u;
     counters[kCntMergeVertices] = 0u;
+    counters[kCntGroupGeneral] = 0u;
+    counters[kCntGroupSubsurface] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
   }
   const uint32_t lane = threadIdx.x & 63u;
@@ -73,6 +75,8 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_flat2(const DScene
     counters[kCntPairs] = 0u;
     counters[kCntShadow] = 0u;
     counters[kCntMergeVertices] = 0u;
+    counters[kCntGroupGeneral] = 0u;
+    counters[kCntGroupSubsurface] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
   }
   const uint32_t lane = threadIdx.x & 63u;

@@ -93,12 +93,17 @@ void launch_light_generate(hipStream_t stream, const Pipeline& p, const VcmParam
   hipLaunchKernelGGL(k_light_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
 }
 
-void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials) {
+void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups) {
   const dim3 grid(max(1u, grid_for(min(p.capacity, max_items))));
-  if (simple_materials)
-    hipLaunchKernelGGL(k_light_shade<true>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
-  else
-    launch_light_shade_general(stream, p, it, in_set, grid);
+  if (groups.binned() == false) {
+    hipLaunchKernelGGL((k_light_shade<kShadeGroupSimple, false>), grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+    return;
+  }
+  hipLaunchKernelGGL((k_light_shade<kShadeGroupSimple, true>), grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+  if (groups.general)
+    launch_light_shade_group(stream, p, it, in_set, grid, kShadeGroupGeneral);
+  if (groups.subsurface)
+    launch_light_shade_group(stream, p, it, in_set, grid, kShadeGroupSubsurface);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -147,12 +152,17 @@ void launch_camera_generate(hipStream_t stream, const Pipeline& p, const VcmPara
 }
 
 
-void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple_materials) {
+void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups) {
   const dim3 grid(max(1u, grid_for(min(p.capacity, max_items))));
-  if (simple_materials)
-    hipLaunchKernelGGL(k_camera_shade<true>, grid, dim3(kBlockSize), 0, stream, p, it, in_set);
-  else
-    launch_camera_shade_general(stream, p, it, in_set, grid);
+  if (groups.binned() == false) {
+    hipLaunchKernelGGL((k_camera_shade<kShadeGroupSimple, false>), grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+    return;
+  }
+  hipLaunchKernelGGL((k_camera_shade<kShadeGroupSimple, true>), grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+  if (groups.general)
+    launch_camera_shade_group(stream, p, it, in_set, grid, kShadeGroupGeneral);
+  if (groups.subsurface)
+    launch_camera_shade_group(stream, p, it, in_set, grid, kShadeGroupSubsurface);
 }
 
 #if defined(ETX_HIP_DEBUG_COUNTERS)

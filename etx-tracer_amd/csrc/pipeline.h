@@ -83,6 +83,22 @@ struct CameraVertexPool {  // connectible camera vertices of the current bounce 
 };
 
 enum : uint32_t { kCvDiffuse = 1u << 0, kCvMedium = 1u << 1 };
+
+// Endpoint connections of the general / subsurface shading groups: the connection of a light vertex to the camera
+// (vcm_connect_to_camera, vcm_shared.hxx:463-535) or of a camera vertex to a light (vcm_connect_to_light, :608-671).
+// Both evaluate the vertex' BSDF three times (evaluate, reverse pdf, pdf - stochastic walks for the Heitz models); inside
+// the step kernels those calls kept the whole path state alive across them. The step functions of these groups write
+// a 100-byte request instead and k_connect_endpoints evaluates the requests densely, one per lane, then queues the
+// visibility segment like every other connection. The simple group (Lambert / delta) still connects inline.
+struct EndpointQueue {
+  float4* hit;        // u, v, t, triangle bits  (medium vertex: pos.xyz, kInvalid)
+  float4* wi_medium;  // w_i at the vertex, medium index bits
+  float4* thr_depth;  // throughput rgb (scaled by a subsurface walk, if any), total_path_depth | kCvExitMaterialBit
+  float4* mis_id;     // d_vcm, d_vc, unused, path id bits (pixel index in the camera pass)
+  float4* rnd_seed;   // the three fixed randoms of the connection (rnd_connection.xy, rnd_support.y), sampler seed bits
+  float* wavelength;
+  uint32_t capacity;
+};
 constexpr uint32_t kCvExitMaterialBit = 0x80000000u;  // in thr_depth.w: the vertex is the exit point of a subsurface walk, material = scene.subsurface_exit_material
 
 struct ShadowQueue {        // transmittance ("shadow") ray requests of the current bounce: 48 B in, film atomics out
@@ -119,7 +135,11 @@ enum : uint32_t {
   kStatPhotonsMerged = 448,
   kStatSplats = 480,
   kDbgBase = 512,            // u64 debug counters (ETX_HIP_DEBUG_COUNTERS builds)
-  kCounterCount = 544,
+  kCntGroupGeneral = 544,    // paths of the current bounce whose hit material is shaded by the general kernel, cleared per bounce
+  kCntGroupSubsurface = 576, // ... by the subsurface kernel
+  kCntEndpoints = 608,       // endpoint connection requests of the current bounce, cleared per bounce
+  kCntNonFinite = 640,       // film contributions dropped because they were not finite (never cleared within a run: reported by etx_hip_stats)
+  kCounterCount = 672,
 };
 
 // Per-workgroup statistics (u64): workgroup b of any launch adds to row b without atomics (launches on one stream do
@@ -133,6 +153,7 @@ enum : uint32_t {
   kOverflowPairs = 1u << 2,
   kOverflowShadow = 1u << 3,
   kOverflowCameraVertices = 1u << 4,
+  kOverflowEndpoints = 1u << 5,
 };
 
 struct VcmParams {  // VCMOptions + VCMIteration (vcm_shared.hxx:12-89), per iteration, by value
@@ -173,6 +194,8 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   GridParams* grid_params;
   CameraVertexPool cv;
   ShadowQueue shadow;
+  EndpointQueue endpoints;
+  uint32_t* group_list[kShadeGroupCount - 1];  // path slots of the current bounce binned by shading group (general, subsurface); kernels_shade.inl
   uint32_t* merge_order;       // camera vertex slots of the current bounce sorted by coarse spatial bucket (k_merge_*)
   uint32_t* merge_buckets;     // kMergeBuckets + 1 counters / offsets, then 256 scan-group totals
   uint2* pairs;          // (camera vertex slot, light vertex index) of the current bounce

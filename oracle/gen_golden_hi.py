@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""High-sample-count golden films from the reference-based oracle (oracle/_ref/etx_oracle), for the tight parity
+tests of tests/test_gpu_parity_hi.py ("a high-spp oracle reference, e.g. 4096 spp at reduced resolution").
+
+    python3 oracle/gen_golden_hi.py [--spp 4096] [--cores 0-3] [name ...]
+
+  tests/golden/hi/cornell_<flavour>_128_<integrator>_<spp>.npz   camera / light layers (float16 pairs are NOT used:
+      the films are float32, compressed), reference CPUVCM with vcm-blue_noise=false and CPUPathTracing with bn=false
+  tests/golden/hi/cornell_full_128_vcm_<spp>_decorrelated.npz    the same with ETX_ORACLE_DECORRELATE=1 (the BVH shim
+      shifts the camera stream): the estimator the device's re-keyed camera stream claims to match
+
+The snapshots are the committed tests/golden/cornell_<flavour>_128.etxscene files (oracle/gen_golden.py writes them).
+Needs /root/reference only through the prebuilt oracle binary. ~8 min per VCM scene on 8 cores.
+"""
+import argparse
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools import film_io  # noqa: E402
+
+ORACLE = os.path.join(ROOT, "oracle", "_ref", "etx_oracle")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+HI = os.path.join(GOLDEN, "hi")
+
+FLAVOURS = ["full", "rough", "glass", "gems", "cloud", "sss", "classic", "diamond", "spectral"]
+
+
+def render(snapshot, integrator, spp, out_npz, cores, env_extra=None, extra=()):
+    if os.path.exists(out_npz):
+        print("have", out_npz)
+        return
+    film_path = "/tmp/golden_hi_%d.raw" % os.getpid()
+    cmd = [ORACLE, "--load-snapshot", snapshot, "--integrator", integrator, "--spp", str(spp), "--out", film_path, *extra]
+    if cores:
+        cmd = ["taskset", "-c", cores] + cmd
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    t0 = time.time()
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL, env=env)
+    film = film_io.read_film(film_path)
+    os.remove(film_path)
+    layers = {"camera": film["camera"][..., :3].astype(np.float32), "spp": np.int32(film["spp"]), "seconds": np.float64(film["seconds"]), "threads": np.int32(film["threads"])}
+    if integrator == "vcm":
+        layers["light"] = film["light"][..., :3].astype(np.float32)
+    os.makedirs(HI, exist_ok=True)
+    np.savez_compressed(out_npz, **layers)
+    print("  -> %s (%.0f s)" % (out_npz, time.time() - t0), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--spp", type=int, default=4096)
+    ap.add_argument("--cores", default="")
+    ap.add_argument("--integrators", default="vcm,pt")
+    ap.add_argument("names", nargs="*", default=FLAVOURS)
+    args = ap.parse_args()
+    integrators = args.integrators.split(",")
+    for flavour in args.names:
+        snapshot = os.path.join(GOLDEN, "cornell_%s_128.etxscene" % flavour)
+        if "vcm" in integrators:
+            render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d.npz" % (flavour, args.spp)), args.cores, extra=["--opt", "vcm-blue_noise=false"])
+        if (flavour == "full") and ("vcm" in integrators):
+            render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_full_128_vcm_%d_decorrelated.npz" % args.spp), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "1"},
+                   extra=["--opt", "vcm-blue_noise=false"])
+        if "pt" in integrators:
+            render(snapshot, "pt", args.spp, os.path.join(HI, "cornell_%s_128_pt_%d.npz" % (flavour, args.spp)), args.cores, extra=["--opt", "bn=false"])
+
+
+if __name__ == "__main__":
+    main()
