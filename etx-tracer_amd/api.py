@@ -91,7 +91,7 @@ class Stats(ctypes.Structure):
         ("splats", ctypes.c_uint64),
         ("wavefront_bounces", ctypes.c_uint64),
         ("overflow_flags", ctypes.c_uint32),
-        ("pad", ctypes.c_uint32),
+        ("nonfinite_dropped", ctypes.c_uint32),
         ("ms_trace_closest", ctypes.c_double),
         ("ms_trace_shadow", ctypes.c_double),
         ("ms_shade_light", ctypes.c_double),

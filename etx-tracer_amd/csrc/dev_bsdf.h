@@ -271,6 +271,13 @@ ETX_DEV f3 fresnel_calculate(float cos_theta, const Ior& ext_ior, const Ior& int
   return {saturate(values.x), saturate(values.y), saturate(values.z)};
 }
 
+// The general classes call the Fresnel term from many places (every step of the Heitz walks); one real function per
+// translation unit keeps the thin-film complex arithmetic out of each of them (dev_bsdf_ool.h explains the by-value ABI).
+// The simple-material kernels keep the inline version above: with thinfilm_none() the thin-film branch folds away.
+static __device__ __attribute__((noinline)) f3 fresnel_calculate_g(float cos_theta, Ior ext_ior, Ior int_ior, ThinfilmEval tf) {
+  return fresnel_calculate(cos_theta, ext_ior, int_ior, tf);
+}
+
 ETX_DEV ThinfilmEval thinfilm_none() {
   ThinfilmEval r;
   r.ior.cls = 0u, r.ior.spectral = 0u, r.ior.eta = mk3(0.0f), r.ior.k = mk3(0.0f);
@@ -403,7 +410,7 @@ ETX_DEV f3 ms_sample_phase_conductor(const f2 slope_rnd, const f3& wi, const f2 
     wm = normalize(f3{-slope.x, -slope.y, 1.0f});
   }
   float i_dot_m = dot(wi, wm);
-  weight = fresnel_calculate(i_dot_m, ext_ior, int_ior, tf);
+  weight = fresnel_calculate_g(i_dot_m, ext_ior, int_ior, tf);
   return -wi + 2.0f * wm * i_dot_m;
 }
 
@@ -420,7 +427,7 @@ ETX_DEV f3 ms_phase_function_reflection(const MsRay& ray, const f3& wo, const f2
   float w_dot_h = dot(-ray.w, wh);
   if (w_dot_h < kEpsilon)
     return mk3(0.0f);
-  const f3 f = fresnel_calculate(w_dot_h, ext_ior, int_ior, tf);
+  const f3 f = fresnel_calculate_g(w_dot_h, ext_ior, int_ior, tf);
   return f * (D_ggx(wh, alpha) / (4.0f * projected_area));
 }
 
@@ -442,7 +449,7 @@ ETX_DEV f3 ms_eval_conductor(Sampler& smp, const f3& wi, const f3& wo, const f2 
   const f3 wh = normalize(wi + wo);
   const float D = D_ggx(wh, alpha);
   const float G2 = 1.0f / (1.0f + (-ray.Lambda - 1.0f) + ray_shadowing.Lambda);
-  f3 single_scattering = fresnel_calculate(dot(ray.w, wh), ext_ior, int_ior, tf) * (D * G2 / (4.0f * wi.z));
+  f3 single_scattering = fresnel_calculate_g(dot(ray.w, wh), ext_ior, int_ior, tf) * (D * G2 / (4.0f * wi.z));
   float wi_mis_weight = 0.0f;
   f3 multiple_scattering = mk3(0.0f);
   uint32_t order = 0;

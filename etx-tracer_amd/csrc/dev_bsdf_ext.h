@@ -47,7 +47,7 @@ ETX_DEV f3 ms_eval_phase_dielectric(const MsRay& ray, const f3& wo, bool reflect
     return mk3(0.0f);
   const float o_dot_m = dot(wo, wh);
   const float scalar = eta * eta * i_dot_m * fmaxf(0.0f, -o_dot_m) * D_ggx(wh, alpha) / (projected_area * sqr(i_dot_m + eta * o_dot_m));
-  const f3 f = fresnel_calculate(i_dot_m, ext_ior, int_ior, tf);
+  const f3 f = fresnel_calculate_g(i_dot_m, ext_ior, int_ior, tf);
   return (mk3(1.0f) - f) * scalar;
 }
 
@@ -73,7 +73,7 @@ ETX_DEV MsDielectricSample ms_sample_phase_dielectric(const f2 rnd_slope, float 
   else
     wm = normalize(f3{-slope.x, -slope.y, 1.0f});
   const float i_dot_m = dot(wi, wm);
-  const f3 f = fresnel_calculate(i_dot_m, ext_ior, int_ior, tf);
+  const f3 f = fresnel_calculate_g(i_dot_m, ext_ior, int_ior, tf);
   const float eta = ior_eta_ratio(int_ior, ext_ior);
   MsDielectricSample r;
   r.reflection = rnd_reflection < luminance(f);
@@ -94,7 +94,7 @@ ETX_DEV float ms_mis_weight_dielectric(const f3& wi, const f3& wo, bool reflecti
 }
 
 // eval_dielectric, :466-555 (stochastic)
-ETX_DEV f3 ms_eval_dielectric(Sampler& smp, const f3& wi, const f3& wo, bool wo_outside, const f2 alpha, const Ior& ext_ior, const Ior& int_ior, const ThinfilmEval& tf) {
+ETX_DEV f3 ms_eval_dielectric_inline(Sampler& smp, const f3& wi, const f3& wo, bool wo_outside, const f2 alpha, const Ior& ext_ior, const Ior& int_ior, const ThinfilmEval& tf) {
   if ((wi.z <= 0.0f) || (wo.z <= 0.0f && wo_outside) || (wo.z >= 0.0f && !wo_outside))
     return mk3(0.0f);
   MsRay ray = ms_ray(-wi, alpha);
@@ -152,6 +152,21 @@ ETX_DEV f3 ms_eval_dielectric(Sampler& smp, const f3& wi, const f3& wo, bool wo_
   return 0.5f * single_scattering + multiple_scattering;
 }
 
+// one real function for the walk (DielectricBSDF::evaluate and the specular layer of PlasticBSDF share it)
+struct MsEvalRet {
+  f3 value;
+  uint32_t seed;
+};
+static __device__ __attribute__((noinline)) MsEvalRet ms_eval_dielectric_call(Sampler smp, f3 wi, f3 wo, bool wo_outside, f2 alpha, Ior ext_ior, Ior int_ior, ThinfilmEval tf) {
+  const f3 v = ms_eval_dielectric_inline(smp, wi, wo, wo_outside, alpha, ext_ior, int_ior, tf);
+  return {v, smp.seed};
+}
+ETX_DEV f3 ms_eval_dielectric(Sampler& smp, const f3& wi, const f3& wo, bool wo_outside, const f2 alpha, const Ior& ext_ior, const Ior& int_ior, const ThinfilmEval& tf) {
+  const MsEvalRet r = ms_eval_dielectric_call(smp, wi, wo, wo_outside, alpha, ext_ior, int_ior, tf);
+  smp.seed = r.seed;
+  return r.value;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // DielectricBSDF, bsdf_dielectric.hxx:61-259
 
@@ -189,7 +204,7 @@ ETX_DEV float dielectric_pdf(const DScene& s, const BsdfData& d, const f3& in_w_
   const MsRay ray = ms_ray(w_i * (outside ? 1.0f : -1.0f), roughness);
   const float d_ggx = D_ggx(wh, roughness);
   float prob = fmaxf(0.0f, dot(wh, ray.w) * d_ggx / ((1.0f + ray.Lambda) * ray.w.z));
-  const float f = luminance(fresnel_calculate(dot(w_i, wh), outside ? ext_ior : int_ior, outside ? int_ior : ext_ior, tf));
+  const float f = luminance(fresnel_calculate_g(dot(w_i, wh), outside ? ext_ior : int_ior, outside ? int_ior : ext_ior, tf));
   prob *= reflection ? f : (1.0f - f);
   return fabsf(prob * dwh_dwo) + fabsf(w_o.z);
 }
@@ -303,7 +318,7 @@ ETX_DEV BsdfSample thinfilm_sample(const DScene& s, const BsdfData& d, const etx
   const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
   const Ior int_ior = evaluate_refractive_index(s, m.int_ior, d.wavelength);
   const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
-  const f3 fr = fresnel_calculate(dot(d.w_i, d.nrm), ext_ior, int_ior, tf);
+  const f3 fr = fresnel_calculate_g(dot(d.w_i, d.nrm), ext_ior, int_ior, tf);
   const float f = luminance(fr);
   BsdfSample r = sample_zero();
   if (smp.next() <= f) {
@@ -568,7 +583,7 @@ ETX_DEV float plastic_specular_pdf(const DScene& s, const BsdfData& d, const f3&
   const MsRay ray = ms_ray(w_i, roughness);
   const float d_ggx = D_ggx(wh, roughness);
   float prob = fmaxf(0.0f, dot(wh, ray.w) * d_ggx / ((1.0f + ray.Lambda) * ray.w.z));
-  prob *= luminance(fresnel_calculate(dot(w_i, wh), ext_ior, int_ior, tf));
+  prob *= luminance(fresnel_calculate_g(dot(w_i, wh), ext_ior, int_ior, tf));
   return fabsf(prob * dwh_dwo);
 }
 
@@ -584,7 +599,7 @@ ETX_DEV BsdfEval plastic_evaluate(const DScene& s, const BsdfData& d, const f3& 
   const Ior eta_e = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
   const Ior eta_i = evaluate_refractive_index(s, m.int_ior, d.wavelength);
   const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
-  const f3 fr = fresnel_calculate(dot(d.w_i, mh), eta_e, eta_i, tf);
+  const f3 fr = fresnel_calculate_g(dot(d.w_i, mh), eta_e, eta_i, tf);
   const f3 local_w_i = frame.to_local(-d.w_i);
   const f3 local_w_o = frame.to_local(w_o);
   const BsdfEval diff_layer = diffuse_layer_v(s, d, local_w_i, local_w_o, m, smp);
@@ -608,7 +623,7 @@ ETX_DEV float plastic_pdf(const DScene& s, const BsdfData& d, const f3& w_o, con
   const Ior eta_e = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
   const Ior eta_i = evaluate_refractive_index(s, m.int_ior, d.wavelength);
   const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
-  const f3 fr = fresnel_calculate(dot(d.w_i, mh), eta_e, eta_i, tf);
+  const f3 fr = fresnel_calculate_g(dot(d.w_i, mh), eta_e, eta_i, tf);
   const float diff_pdf = kInvPi * n_dot_o;
   const float spec_pdf = plastic_specular_pdf(s, d, w_o, m, smp);
   return diff_pdf * luminance(mk3(1.0f) - fr) + spec_pdf;
@@ -621,7 +636,7 @@ ETX_DEV BsdfSample plastic_sample(const DScene& s, const BsdfData& d, const etx_
   const Ior ext_ior = evaluate_refractive_index(s, m.ext_ior, d.wavelength);
   const Ior int_ior = evaluate_refractive_index(s, m.int_ior, d.wavelength);
   const ThinfilmEval tf = evaluate_thinfilm(s, m.thinfilm, d.tex, smp, d.wavelength);
-  const f3 f = fresnel_calculate(dot(d.w_i, mh), ext_ior, int_ior, tf);
+  const f3 f = fresnel_calculate_g(dot(d.w_i, mh), ext_ior, int_ior, tf);
   const f3 w_i = frame.to_local(-d.w_i);
   if (w_i.z <= kEpsilon)
     return sample_zero();

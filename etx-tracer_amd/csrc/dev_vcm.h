@@ -138,6 +138,20 @@ ETX_DEV void atomic_add_f3(float4* dst, const f3& v) {
   atomicAdd(&dst->z, v.z);
 }
 
+// Every film write goes through this guard: one non-finite contribution would poison its pixel for the rest of the run
+// (all lanes, and after etx_hip_reduce_film all ranks, add into the same sums; Film::layer(Result) = max(0, ...) then shows
+// it as black). Dropped contributions are counted (etx_hip_stats_t::nonfinite_dropped), never silent.
+ETX_DEV bool film_value_ok(const Pipeline& p, const f3& v) {
+  const bool ok = isfinite(v.x + v.y + v.z);
+  if (ok == false)
+    atomicAdd(p.counters + kCntNonFinite, 1u);
+  return ok;
+}
+ETX_DEV void film_add(const Pipeline& p, float4* dst, const f3& v) {
+  if (film_value_ok(p, v))
+    atomic_add_f3(dst, v);
+}
+
 ETX_DEV bool is_zero(const f3& v) {  // SpectralResponse::is_zero, spectrum.hxx:317-319
   return (v.x <= kEpsilon) && (v.y <= kEpsilon) && (v.z <= kEpsilon);
 }

@@ -236,7 +236,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
     if (event == kEventNone) {  // vcm_shared.hxx:997-1000
       f3 gathered = vcm_cam_handle_miss(scene, it, st);
       if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
-        atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered * spectral_film_weight(scene, st.wavelength));
+        film_add(p, p.camera_sum + film_index(it, st.id), gathered * spectral_film_weight(scene, st.wavelength));
     }
   }
   const bool scatter_event = (event == kEventMedium) || (event == kEventSurface);
@@ -290,7 +290,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       if (opt_direct_hit(it) && (isect.emitter != kInvalid) && (st.depth <= scene.max_path_length) && (st.depth >= scene.min_path_length)) {
         f3 gathered = vcm_get_radiance(scene, scene.emitters[isect.emitter], st, it, isect);
         if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
-          atomic_add_f3(p.camera_sum + film_index(it, st.id), gathered * spectral_film_weight(scene, st.wavelength));
+          film_add(p, p.camera_sum + film_index(it, st.id), gathered * spectral_film_weight(scene, st.wavelength));
       }
       nee = is_connectible;
       store = is_connectible && (opt_connect_vertices(it) || (opt_merge_vertices(it) && (st.depth + 1 <= scene.max_path_length)));

@@ -209,6 +209,10 @@ int allocate_pipeline(etx_hip_context* ctx) {
   if ((rc = device_alloc(ctx, p.shadow.p0_medium, p.shadow.capacity)) || (rc = device_alloc(ctx, p.shadow.p1_target, p.shadow.capacity)) ||
       (rc = device_alloc(ctx, p.shadow.value, p.shadow.capacity)))
     return rc;
+  p.endpoints.capacity = n;
+  if ((rc = device_alloc(ctx, p.endpoints.hit, n)) || (rc = device_alloc(ctx, p.endpoints.wi_medium, n)) || (rc = device_alloc(ctx, p.endpoints.thr_depth, n)) ||
+      (rc = device_alloc(ctx, p.endpoints.mis_id, n)) || (rc = device_alloc(ctx, p.endpoints.rnd_seed, n)) || (rc = device_alloc(ctx, p.endpoints.wavelength, n)))
+    return rc;
   if ((rc = device_alloc(ctx, ctx->pt_iteration_image, n)))
     return rc;
   if (ctx->owner == nullptr) {
@@ -311,8 +315,10 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
   uint32_t set = 0;
   uint32_t known_count = ctx->pipe.capacity;  // upper bound of the active paths (the count never grows within a pass)
   const uint32_t tail_threshold = (allow_tail && ctx->tail_divisor) ? std::max(64u, ctx->pipe.capacity / ctx->tail_divisor) : 0u;
-  const uint32_t max_rounds = ctx->scene.host_copy.max_path_length * 2u + 16u;  // boundaries do not add depth
-  for (uint32_t round = 0; round < max_rounds;) {
+  // Alive paths are bounded by depth plus roulette, but boundary crossings do not add depth: the loop runs until the
+  // device reports no active path (a path that never ends would be a defect, reported as an error - never a silent cut).
+  const uint64_t max_rounds = uint64_t(ctx->scene.host_copy.max_path_length) * 64ull + 4096ull;
+  for (uint64_t round = 0; round < max_rounds;) {
     for (uint32_t k = 0; k < ctx->check_interval; ++k, ++round) {
       {
         ScopedTimer t(ctx, kTimerTraceClosest);
@@ -334,7 +340,8 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
       return 0;
     }
   }
-  return 0;
+  ctx->error = "wavefront loop: " + std::to_string(known_count) + " paths still alive after " + std::to_string(max_rounds) + " rounds";
+  return ETX_HIP_ERROR_STATE;
 }
 
 int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
@@ -354,6 +361,8 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
       {
         ScopedTimer t(ctx, kTimerShadeLight);
         launch_light_shade(s, p, it, set, max_items, shade_groups(ctx));
+        if (opt_connect_to_camera(it) && shade_groups(ctx).binned())
+          launch_connect_endpoints(s, p, it, false, max_items);
       }
       if (opt_connect_to_camera(it)) {
         ScopedTimer t(ctx, kTimerTraceShadow);
@@ -364,6 +373,8 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
       {
         ScopedTimer t(ctx, kTimerShadeLight);
         launch_light_tail(s, p, it, set, max_items, shade_groups(ctx));
+        if (opt_connect_to_camera(it) && shade_groups(ctx).binned())
+          launch_connect_endpoints(s, p, it, false, p.endpoints.capacity);
       }
       if (opt_connect_to_camera(it)) {
         ScopedTimer t(ctx, kTimerTraceShadow);
@@ -392,6 +403,8 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
       {
         ScopedTimer t(ctx, kTimerShadeCamera);
         launch_camera_shade(s, p, it, set, max_items, shade_groups(ctx));
+        if (opt_connect_to_light(it) && shade_groups(ctx).binned())
+          launch_connect_endpoints(s, p, it, true, max_items);
       }
       if (opt_connect_vertices(it)) {
         ScopedTimer t(ctx, kTimerConnect);
@@ -410,6 +423,8 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
       {
         ScopedTimer t(ctx, kTimerShadeCamera);
         launch_camera_tail(s, p, it, set, max_items, shade_groups(ctx));
+        if (opt_connect_to_light(it) && shade_groups(ctx).binned())
+          launch_connect_endpoints(s, p, it, true, p.endpoints.capacity);
       }
       // the tail leaves up to `capacity` camera vertices: drain them with one launch of each consumer
       if (opt_connect_vertices(it)) {
@@ -512,6 +527,7 @@ void collect_stats(etx_hip_context* ctx) {
   st.photons_merged = u64(kStatPhotonsMerged);
   st.splats = u64(kStatSplats);
   st.overflow_flags = c[kCntOverflow];
+  st.nonfinite_dropped = c[kCntNonFinite];
 #if defined(ETX_HIP_DEBUG_COUNTERS)
   fprintf(stderr, "[dbg] it %u: lv %u cv %llu pairs %llu shadow %llu list_sum %llu list_max %u ext %llu\n", st.current_iteration, c[kCntLightVertices], (unsigned long long)u64(kStatCameraVertices),
     (unsigned long long)u64(kDbgBase + 0), (unsigned long long)st.rays_shadow, (unsigned long long)u64(kDbgBase + 2), c[kDbgBase + 4], (unsigned long long)st.rays_extension);
@@ -538,7 +554,7 @@ int execute_iteration(etx_hip_context* lane, uint32_t iteration) {
   lane->stats.last_iteration_time = double(ms) * 1.0e-3;
   if (lane->stats.overflow_flags) {
     lane->error = "device pool overflow in iteration " + std::to_string(iteration) + " (flags " + std::to_string(lane->stats.overflow_flags) +
-                  "): light vertex pool (1, raise ETX_HIP_LIGHT_VERTICES_PER_PATH) / connection pair buffer (4) / shadow queue (8) / camera vertex pool (16)";
+                  "): light vertex pool (1, raise ETX_HIP_LIGHT_VERTICES_PER_PATH) / connection pair buffer (4) / shadow queue (8) / camera vertex pool (16) / endpoint queue (32)";
     return ETX_HIP_ERROR_OVERFLOW;
   }
   return ETX_HIP_OK;
@@ -583,6 +599,7 @@ void lane_worker(etx_hip_context* lane) {
         pub->sticky_error_text = lane->error;
       }
       t.overflow_flags |= s.overflow_flags;
+      t.nonfinite_dropped += s.nonfinite_dropped;
       lane->lane_busy = false;
       pub->jobs_in_flight -= 1;
       if (pub->jobs_in_flight == 0u)

@@ -67,9 +67,11 @@ int etx_hip_comm_init(etx_hip_context* context, int rank, int world_size, const 
 int etx_hip_reduce_film(etx_hip_context* context) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
-  int sync_rc = etx_hip_sync(context);  // every iteration handed to a lane has reached the film
-  if (sync_rc)
-    return sync_rc;
+  // Every iteration handed to a lane has reached the film. A failed iteration on THIS rank (for example
+  // ETX_HIP_ERROR_OVERFLOW, a data-dependent condition of the fixed pools) must not keep the rank out of the collective:
+  // the other ranks are already inside ncclAllReduce and would wait for the RCCL timeout. Every rank therefore always
+  // takes part and the error travels with the iteration counter; afterwards ALL ranks return an error.
+  const int sync_rc = etx_hip_sync(context);
   uint32_t* local = nullptr;
   uint64_t* global = nullptr;
   bool* reduced = nullptr;
@@ -77,10 +79,13 @@ int etx_hip_reduce_film(etx_hip_context* context) {
   ncclComm_t comm = reinterpret_cast<ncclComm_t>(*etx_hip_internal_comm(context));
   if (comm == nullptr) {
     // single rank: the reduce is the identity
+    if (sync_rc)
+      return sync_rc;
     *global = *local;
     *reduced = true;
     return ETX_HIP_OK;
   }
+  const std::string local_error = sync_rc ? std::string(etx_hip_last_error(context)) : std::string();
   if (hipSetDevice(etx_hip_internal_device(context)) != hipSuccess) {
     etx_hip_internal_set_error(context, "hipSetDevice failed");
     return ETX_HIP_ERROR_HIP;
@@ -89,35 +94,43 @@ int etx_hip_reduce_film(etx_hip_context* context) {
   float *camera = nullptr, *light = nullptr;
   size_t floats = 0;
   etx_hip_internal_film(context, &camera, &light, &floats);
-  unsigned long long* d_iterations = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&d_iterations), sizeof(unsigned long long)) != hipSuccess) {
+  unsigned long long* d_counters = nullptr;  // {iterations of this rank, 1 if this rank failed}
+  if (hipMalloc(reinterpret_cast<void**>(&d_counters), 2 * sizeof(unsigned long long)) != hipSuccess) {
     etx_hip_internal_set_error(context, "hipMalloc failed");
     return ETX_HIP_ERROR_HIP;
   }
-  unsigned long long h_iterations = *local;
-  (void)hipMemcpyAsync(d_iterations, &h_iterations, sizeof(h_iterations), hipMemcpyHostToDevice, stream);
+  unsigned long long h_counters[2] = {*local, sync_rc ? 1ull : 0ull};
+  (void)hipMemcpyAsync(d_counters, h_counters, sizeof(h_counters), hipMemcpyHostToDevice, stream);
   ncclResult_t r = ncclGroupStart();
   if (r == ncclSuccess)
     r = ncclAllReduce(camera, camera, floats, ncclFloat, ncclSum, comm, stream);  // all film layers, one buffer
   if (r == ncclSuccess)
-    r = ncclAllReduce(d_iterations, d_iterations, 1, ncclUint64, ncclSum, comm, stream);
+    r = ncclAllReduce(d_counters, d_counters, 2, ncclUint64, ncclSum, comm, stream);
   ncclResult_t r2 = ncclGroupEnd();
   if (r == ncclSuccess)
     r = r2;
   if (r != ncclSuccess) {
-    (void)hipFree(d_iterations);
+    (void)hipFree(d_counters);
     etx_hip_internal_set_error(context, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
     return ETX_HIP_ERROR_COMM;
   }
-  (void)hipMemcpyAsync(&h_iterations, d_iterations, sizeof(h_iterations), hipMemcpyDeviceToHost, stream);
+  (void)hipMemcpyAsync(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream);
   if (hipStreamSynchronize(stream) != hipSuccess) {
-    (void)hipFree(d_iterations);
+    (void)hipFree(d_counters);
     etx_hip_internal_set_error(context, "stream synchronize failed after all-reduce");
     return ETX_HIP_ERROR_HIP;
   }
-  (void)hipFree(d_iterations);
-  *global = h_iterations;
+  (void)hipFree(d_counters);
+  *global = h_counters[0];
   *reduced = true;
+  if (sync_rc) {
+    etx_hip_internal_set_error(context, local_error);
+    return sync_rc;
+  }
+  if (h_counters[1] != 0ull) {
+    etx_hip_internal_set_error(context, std::to_string(h_counters[1]) + " other rank(s) reported a failed iteration before the film reduce (their films are incomplete)");
+    return ETX_HIP_ERROR_COMM;
+  }
   return ETX_HIP_OK;
 }
 

@@ -521,6 +521,9 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
         pixels[k] = make_float4(src[4 * k] / 255.0f, src[4 * k + 1] / 255.0f, src[4 * k + 2] / 255.0f, src[4 * k + 3] / 255.0f);
     } else if ((img.format == ETX_IMAGE_FORMAT_RGBA32F) && (pixel_count > 0)) {
       memcpy(pixels.data(), img.pixels.a, pixel_count * sizeof(float4));
+    } else if (pixel_count > 0) {
+      error = "image " + std::to_string(i) + " has pixel format " + std::to_string(img.format) + " (the device path reads RGBA8 and RGBA32F, image.hxx:10-14)";
+      return ETX_HIP_ERROR_UNSUPPORTED;
     }
     if ((rc = upload(out, pixels.data(), pixels.size(), di.pixels, error)))
       return rc;

@@ -127,6 +127,39 @@ __global__ __launch_bounds__(kBlockSize) void k_connect_pairs(Pipeline p, VcmPar
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Endpoint connections of the general / subsurface shading groups (pipeline.h EndpointQueue): one request per lane,
+// vcm_connect_to_camera (light pass) or vcm_connect_to_light (camera pass) over every BSDF class, the visibility
+// segment goes to the shadow queue like every other connection.
+template <bool kCameraPass>
+__global__ __launch_bounds__(kBlockSize) void k_connect_endpoints(Pipeline p, VcmParams it) {
+  __shared__ BlockScratch s_scratch;
+  const DScene& scene = p.scene;
+  const uint32_t count = min(p.counters[kCntEndpoints], p.endpoints.capacity);
+  ETX_BLOCK_LOOP(count, i) {
+    ShadowRequest request;
+    bool queue = false;
+    if (i < count) {
+      CameraVertex v = load_endpoint(p, scene, i);
+      if (kCameraPass)
+        queue = vcm_connect_to_light<false>(scene, it, v.at_medium, &v.isect, v.medium_pos, v.st, film_index(it, v.st.id), request);
+      else
+        queue = vcm_connect_to_camera<false>(scene, it, v.at_medium, &v.isect, v.medium_pos, v.st, request);
+    }
+    const uint32_t slot = block_compact_slot(queue, p.counters + kCntShadow, s_scratch);
+    if (queue)
+      write_shadow(p, slot, request);
+  }
+}
+
+void launch_connect_endpoints(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool camera_pass, uint32_t max_items) {
+  const uint32_t blocks = max(1u, grid_for(min(max_items, p.endpoints.capacity)));
+  if (camera_pass)
+    hipLaunchKernelGGL(k_connect_endpoints<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
+  else
+    hipLaunchKernelGGL(k_connect_endpoints<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
+}
+
 void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items) {
   max_items = min(max_items, p.capacity);
   const uint32_t blocks = max(1u, grid_for(max_items));
@@ -450,7 +483,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
       const float* acc = s_acc[wave][lane_ >> 3u];
       const f3 merged = {acc[0], acc[1], acc[2]};
       if ((merged.x != 0.0f) || (merged.y != 0.0f) || (merged.z != 0.0f))
-        atomic_add_f3(p.camera_sum + film_index(it, pixel), merged * it.vm_normalization);
+        film_add(p, p.camera_sum + film_index(it, pixel), merged * it.vm_normalization);
     }
     __threadfence_block();  // accumulators are zeroed again at the top of the next batch
   }
@@ -611,7 +644,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
       const float* acc = s_acc[wave][lane_ >> 3u];
       const f3 merged = {acc[0], acc[1], acc[2]};
       if ((merged.x != 0.0f) || (merged.y != 0.0f) || (merged.z != 0.0f))
-        atomic_add_f3(p.camera_sum + film_index(it, pixel), merged * it.vm_normalization);
+        film_add(p, p.camera_sum + film_index(it, pixel), merged * it.vm_normalization);
     }
     __threadfence_block();
   }

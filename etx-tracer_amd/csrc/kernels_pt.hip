@@ -157,7 +157,7 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
         }
       }
       if ((accumulated.x != 0.0f) || (accumulated.y != 0.0f) || (accumulated.z != 0.0f))
-        atomic_add_f3(p.camera_sum + film_target, accumulated * film_weight);
+        film_add(p, p.camera_sum + film_target, accumulated * film_weight);
     }
     return false;
   }
@@ -196,8 +196,8 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
   BsdfData bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera, st.wavelength);
   if (st.depth == 1u) {  // view_normal / view_albedo -> Film::accumulate_camera_image(pixel, color, normal, albedo)
     const f3 albedo = bsdf_albedo(scene, mat, isect.tex, st.wavelength) * film_weight;
-    atomic_add_f3(p.normal_sum + film_target, isect.nrm);  // atomics: another lane may add the same pixel of another iteration
-    atomic_add_f3(p.albedo_sum + film_target, albedo);
+    film_add(p, p.normal_sum + film_target, isect.nrm);  // atomics: another lane may add the same pixel of another iteration
+    film_add(p, p.albedo_sum + film_target, albedo);
   }
 
   f2 rnd_bsdf = st.sampler.next_2d();

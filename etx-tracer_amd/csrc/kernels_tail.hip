@@ -17,6 +17,7 @@ __global__ void k_reset_round_counters(Pipeline p) {
     p.counters[kCntPairs] = 0u;
     p.counters[kCntShadow] = 0u;
     p.counters[kCntMergeVertices] = 0u;
+    p.counters[kCntEndpoints] = 0u;
   }
 }
 

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
     counters[kCntPairs] = 0u;
     counters[kCntShadow] = 0u;
     counters[kCntMergeVertices] = 0u;
+    counters[kCntEndpoints] = 0u;
     counters[kCntGroupGeneral] = 0u;
     counters[kCntGroupSubsurface] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_flat2(const DScene
     counters[kCntPairs] = 0u;
     counters[kCntShadow] = 0u;
     counters[kCntMergeVertices] = 0u;
+    counters[kCntEndpoints] = 0u;
     counters[kCntGroupGeneral] = 0u;
     counters[kCntGroupSubsurface] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
@@ -219,13 +221,8 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
       if ((tr.x > kEpsilon) || (tr.y > kEpsilon) || (tr.z > kEpsilon)) {  // SpectralResponse::is_zero
         const float4 v = p.shadow.value[i];
         value = tr * f3{v.x, v.y, v.z};
-        if ((p.debug_flags & 16u) && ((v.x >= 999.5f) == false))  // ETX_HIP_TRAP decoding: keep only the trap records
+        if (film_value_ok(p, value) == false)
           value = mk3(0.0f);
-        if (p.debug_flags & 8u) {  // NaN provenance: red marker = request value, green marker = transmittance
-          const bool bad_v = (v.z != v.z), bad_t = (tr.z != tr.z);
-          if (bad_v || bad_t)
-            value = f3{bad_v ? 1000.0f : 0.0f, bad_t ? 1000.0f : 0.0f, 0.0f};
-        }
         if (target & kShadowTargetLight) {
           // vcm_shared.hxx:1229 + vcm_cpu.cxx:148-153 + film.cxx:148: thresholds of the light splat
           if ((max_component(value) <= kEpsilon) || (dot(value, value) <= kEpsilon))

@@ -98,7 +98,7 @@ class HIPIntegrator(Integrator):
         self.context = api.Context(device)
         self.first_iteration = first_iteration
         self.iteration_stride = iteration_stride
-        self._uploaded = False
+        self._uploaded_version = None  # snapshot.version at the last etx_hip_upload_scene
         self._rendered = 0
         self._have_camera_image = False
         self._have_light_image = False
@@ -119,9 +119,9 @@ class HIPIntegrator(Integrator):
 
     def run(self):
         self.stop(Stop.Immediate)
-        if not self._uploaded:
+        if self._uploaded_version != self.snapshot.version:  # first run, or the host edited the scene since (app.cxx:364-403 restarts)
             self.context.upload_scene(self.snapshot)
-            self._uploaded = True
+            self._uploaded_version = self.snapshot.version
         if self.cie_table is not None:
             self.context.upload_cie_table(*self.cie_table)
         for set_index, table in self.bluenoise_tables.items():

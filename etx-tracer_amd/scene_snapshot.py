@@ -54,6 +54,7 @@ class SceneSnapshot:
         self.scene_address = aligned + scene_off
         self.camera_address = aligned + camera_off
         self.path = path
+        self.version = 0  # bumped by every setter: the integrators re-upload when it changed since their last upload
 
     def _u32(self, address):
         return ctypes.c_uint32.from_address(address)
@@ -74,6 +75,7 @@ class SceneSnapshot:
     @samples.setter
     def samples(self, value):
         self._u32(self.scene_address + _SCENE_SAMPLES).value = int(value)
+        self.version += 1
 
     @property
     def max_path_length(self):
@@ -82,6 +84,7 @@ class SceneSnapshot:
     @max_path_length.setter
     def max_path_length(self, value):
         self._u32(self.scene_address + _SCENE_MAX_PATH).value = int(value)
+        self.version += 1
 
     @property
     def bounding_sphere_radius(self):

@@ -126,7 +126,8 @@ typedef struct etx_hip_stats_t {
   double total_time;
   uint32_t completed_iterations;
   uint32_t current_iteration;
-  /* counters of the last finished iteration ("counters the oracle must emit") */
+  /* counters, TOTALS since etx_hip_begin ("counters the oracle must emit"); divide by completed_iterations for
+   * per-iteration figures */
   uint64_t rays_extension;       /* closest-hit rays (light + camera sub paths) */
   uint64_t rays_shadow;          /* transmittance rays (camera connections, NEE, vertex connections) */
   uint64_t light_vertices;       /* stored light vertices */
@@ -136,8 +137,8 @@ typedef struct etx_hip_stats_t {
   uint64_t splats;               /* light image splats */
   uint64_t wavefront_bounces;    /* kernel rounds (light + camera) */
   uint32_t overflow_flags;       /* != 0: a pool overflowed (result of that iteration is incomplete) */
-  uint32_t pad;
-  /* per-kernel device time of the last finished iteration, milliseconds (HIP events on the launch stream) */
+  uint32_t nonfinite_dropped;    /* film contributions that were not finite and were dropped instead of poisoning their pixel (expected: 0) */
+  /* per-kernel device time since etx_hip_begin, milliseconds (HIP events on the launch streams, summed over the iterations) */
   double ms_trace_closest;
   double ms_trace_shadow;
   double ms_shade_light;
