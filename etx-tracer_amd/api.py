@@ -21,7 +21,7 @@ VCM_FULL_OPTIONS = 0x7F
 
 EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene",
-    "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_poll", "etx_hip_sync",
+    "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
     "etx_hip_read_film", "etx_hip_stats", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh",
 )
@@ -138,6 +138,7 @@ class Library:
         L.etx_hip_upload_cie_table.argtypes = [vp, vp, u32, ctypes.c_float]
         L.etx_hip_begin.argtypes = [vp, i32, vp, sz, u32, u32]
         L.etx_hip_render_iteration.argtypes = [vp]
+        L.etx_hip_try_render_iteration.argtypes = [vp]
         L.etx_hip_poll.argtypes = [vp]
         L.etx_hip_sync.argtypes = [vp]
         L.etx_hip_read_film.argtypes = [vp, i32, vp, sz]
@@ -215,6 +216,10 @@ class Context:
 
     def render_iteration(self):
         self._check(self.library.lib.etx_hip_render_iteration(self.handle))
+
+    def try_render_iteration(self):
+        """1 = handed to a free lane, 0 = every lane busy; never blocks (Integrator::update must not block)."""
+        return self._check(self.library.lib.etx_hip_try_render_iteration(self.handle))
 
     def poll(self):
         return self._check(self.library.lib.etx_hip_poll(self.handle))

@@ -65,20 +65,22 @@ struct etx_hip_context {
   int integrator = ETX_HIP_INTEGRATOR_VCM;
   etx_abi_vcm_options vcm_options = {};
   etx_abi_pt_options pt_options = {};
-  float4* pt_iteration_image = nullptr;  // PT: sum of the current iteration's contributions per pixel (radiance clamp at commit)
+  float4* pt_iteration_image = nullptr;  // camera and light contributions of the iteration this lane renders (2 x pixels), committed to the film at its end
   uint32_t first_iteration = 0, iteration_stride = 1;
   uint32_t next_iteration = 0;       // iteration index to render next
   uint32_t local_iterations = 0;     // iterations rendered by this context since begin
   uint64_t global_iterations = 0;    // after etx_hip_reduce_film: iterations of all ranks
   bool reduced = false;
   uint32_t tail_divisor = 64;        // active paths <= capacity / tail_divisor: finish the pass in the tail kernel (0 = never)
-  uint32_t check_interval = 8;       // bounces enqueued between two reads of the active-path counter
+  uint32_t check_interval = 3;       // rounds the host may enqueue beyond the newest round the device has reported (run_bounce_loop)
   uint32_t timer_mask = (1u << kTimerTraceClosest) | (1u << kTimerTraceShadow);
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
   std::vector<TimedSpan> spans;
   hipEvent_t iteration_begin = nullptr, iteration_end = nullptr;
   uint32_t* host_counters = nullptr;  // pinned
+  unsigned long long* round_mirror = nullptr;  // pinned: (round tag + 1) << 32 | active paths, written by k_trace_closest (run_bounce_loop)
+  uint32_t next_round_tag = 0;               // never reset: stale entries of earlier passes cannot match
   uint8_t* bluenoise[kBlueNoiseSets] = {};  // device tables by sample-count class (etx_hip_upload_bluenoise)
   const uint8_t* active_bluenoise = nullptr;
   float4* cie_table = nullptr;      // spectrum::spectral_xyz (etx_hip_upload_cie_table), spectral scenes only
@@ -213,7 +215,7 @@ int allocate_pipeline(etx_hip_context* ctx) {
   if ((rc = device_alloc(ctx, p.endpoints.hit, n)) || (rc = device_alloc(ctx, p.endpoints.wi_medium, n)) || (rc = device_alloc(ctx, p.endpoints.thr_depth, n)) ||
       (rc = device_alloc(ctx, p.endpoints.mis_id, n)) || (rc = device_alloc(ctx, p.endpoints.rnd_seed, n)) || (rc = device_alloc(ctx, p.endpoints.wavelength, n)))
     return rc;
-  if ((rc = device_alloc(ctx, ctx->pt_iteration_image, n)))
+  if ((rc = device_alloc(ctx, ctx->pt_iteration_image, size_t(n) * 2u)))
     return rc;
   if (ctx->owner == nullptr) {
     if ((rc = device_alloc(ctx, p.camera_sum, size_t(n) * kFilmLayers)) || (rc = device_alloc(ctx, ctx->resolve_buffer, n)))
@@ -232,7 +234,7 @@ int allocate_pipeline(etx_hip_context* ctx) {
   p.albedo_sum = p.camera_sum + 3u * size_t(n);
   if (ctx->owner == nullptr)
     HIP_OK(ctx, hipMemset(p.camera_sum, 0, size_t(n) * kFilmLayers * sizeof(float4)));
-  HIP_OK(ctx, hipMemset(ctx->pt_iteration_image, 0, size_t(n) * sizeof(float4)));
+  HIP_OK(ctx, hipMemset(ctx->pt_iteration_image, 0, size_t(n) * 2u * sizeof(float4)));
   return 0;
 }
 
@@ -308,8 +310,11 @@ ShadeGroups shade_groups(const etx_hip_context* ctx) {
   return g;
 }
 
-// One pass of the wavefront loop: trace + shade rounds until no path is alive. The active count lives on the device;
-// it is read back every `check_interval` rounds (a pass usually ends after a few dozen rounds).
+// One pass of the wavefront loop: trace + shade rounds until no path is alive. The active count lives on the device.
+// The trace kernel of every round mirrors (round tag, active paths entering the round) into pinned host memory; the
+// host enqueues rounds ahead of the device (at most `run_ahead` rounds beyond the newest mirrored one) and reads the
+// mirror without ever draining the stream, so the device does not idle while the host learns that the pass has ended.
+// Rounds enqueued after the last path died are empty launches (at most `run_ahead` of them).
 template <class ShadeFn, class TailFn>
 int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64_t& rounds, bool allow_tail = true) {
   uint32_t set = 0;
@@ -318,22 +323,51 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
   // Alive paths are bounded by depth plus roulette, but boundary crossings do not add depth: the loop runs until the
   // device reports no active path (a path that never ends would be a defect, reported as an error - never a silent cut).
   const uint64_t max_rounds = uint64_t(ctx->scene.host_copy.max_path_length) * 64ull + 4096ull;
-  for (uint64_t round = 0; round < max_rounds;) {
-    for (uint32_t k = 0; k < ctx->check_interval; ++k, ++round) {
-      {
-        ScopedTimer t(ctx, kTimerTraceClosest);
-        launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB, known_count, ctx->scene.host_copy.bvh_flat != 0u);
-      }
-      shade(set, known_count);
-      set ^= 1u;
-      rounds++;
+  const uint32_t run_ahead = std::max(1u, std::min(ctx->check_interval, kRoundMirrorSlots / 2u));
+  const uint32_t first_tag = ctx->next_round_tag;
+  uint32_t newest_seen = first_tag;  // tag of the oldest round whose mirror entry has not been read yet
+  volatile unsigned long long* mirror = ctx->round_mirror;
+  auto poll = [&](uint32_t enqueued_until) {  // consumes the mirror entries that have arrived; returns the newest count
+    while (newest_seen != enqueued_until) {
+      const unsigned long long entry = mirror[newest_seen & (kRoundMirrorSlots - 1u)];
+      if (uint32_t(entry >> 32u) != newest_seen + 1u)
+        break;
+      known_count = uint32_t(entry & 0xffffffffull);
+      newest_seen += 1u;
     }
-    int rc = read_counters(ctx);
-    if (rc)
-      return rc;
-    known_count = ctx->host_counters[set == 0 ? kCntActiveA : kCntActiveB];
+  };
+  for (uint64_t round = 0; round < max_rounds; ++round) {
+    const uint32_t tag = ctx->next_round_tag++;
+    {
+      ScopedTimer t(ctx, kTimerTraceClosest);
+      launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB, known_count, ctx->scene.host_copy.bvh_flat != 0u, ctx->round_mirror, tag);
+    }
+    shade(set, known_count);
+    set ^= 1u;
+    rounds++;
+    // wait until the device is at most `run_ahead` rounds behind what has been enqueued
+    uint32_t spins = 0;
+    for (poll(tag + 1u); (tag + 1u) - newest_seen > run_ahead; poll(tag + 1u)) {
+      if ((++spins & 1023u) == 0u) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if ((q != hipSuccess) && (q != hipErrorNotReady)) {
+          ctx->error = std::string("wavefront loop: ") + hipGetErrorString(q);
+          return ETX_HIP_ERROR_HIP;
+        }
+        if (q == hipSuccess) {  // stream idle: every mirror entry must have arrived
+          poll(tag + 1u);
+          if ((tag + 1u) - newest_seen > run_ahead) {
+            ctx->error = "wavefront loop: the device finished without reporting its rounds";
+            return ETX_HIP_ERROR_STATE;
+          }
+        }
+      }
+      std::this_thread::yield();
+    }
+    if (newest_seen == first_tag)
+      continue;  // nothing known yet
     if (known_count == 0u)
-      return 0;
+      return 0;  // the rounds still in flight are empty
     if (known_count <= tail_threshold) {
       tail(set, known_count);
       rounds++;
@@ -346,7 +380,13 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
 
 int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
   const VcmParams it = make_iteration_params(ctx, iteration);
-  Pipeline& p = ctx->pipe;
+  // The kernels add into the lane's ITERATION images; k_vcm_commit folds them into the film sums at the end of the iteration
+  // (Film::commit_light_iteration, film.cxx:332-343, and the per-iteration camera value of vcm_cpu.cxx:227-241). Adding every
+  // connection / splat straight into sums that have grown over thousands of iterations would absorb the contributions that
+  // are smaller than half an ulp of the sum - a negative bias that grows with the sample count (measured at 4096 spp).
+  Pipeline p = ctx->pipe;
+  p.camera_sum = ctx->pt_iteration_image;
+  p.light_sum = ctx->pt_iteration_image + p.capacity;
   hipStream_t s = ctx->stream;
   uint64_t rounds = 0;
 
@@ -443,6 +483,7 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
     rounds);
   if (rc)
     return rc;
+  launch_vcm_commit(s, p.camera_sum, p.light_sum, ctx->pipe.camera_sum, ctx->pipe.light_sum, p.capacity);
   launch_stats_finalize(s, p);
   ctx->stats.wavefront_bounces = rounds;
   return 0;
@@ -635,6 +676,11 @@ int init_lane(etx_hip_context* lane, int device, std::string& error) {
     return ETX_HIP_ERROR_HIP;
   }
   memset(lane->host_counters, 0, kCounterCount * sizeof(uint32_t));
+  if (hipHostMalloc(reinterpret_cast<void**>(&lane->round_mirror), kRoundMirrorSlots * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+    error = "hipHostMalloc failed";
+    return ETX_HIP_ERROR_HIP;
+  }
+  memset(lane->round_mirror, 0, kRoundMirrorSlots * sizeof(unsigned long long));
   if (const char* e = getenv("ETX_HIP_CHECK_INTERVAL"))
     lane->check_interval = std::max(1, atoi(e));
   if (const char* e = getenv("ETX_HIP_TAIL_DIVISOR"))
@@ -666,6 +712,8 @@ void destroy_lane(etx_hip_context* lane) {
     (void)hipEventDestroy(lane->iteration_end);
   if (lane->host_counters)
     (void)hipHostFree(lane->host_counters);
+  if (lane->round_mirror)
+    (void)hipHostFree(lane->round_mirror);
   if (lane->stream)
     (void)hipStreamDestroy(lane->stream);
 }
@@ -928,15 +976,17 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
   }
   const size_t n = size_t(context->pipe.capacity);
   HIP_OK(context, hipMemsetAsync(context->pipe.camera_sum, 0, n * kFilmLayers * sizeof(float4), context->stream));
-  HIP_OK(context, hipMemsetAsync(context->pt_iteration_image, 0, n * sizeof(float4), context->stream));
+  HIP_OK(context, hipMemsetAsync(context->pt_iteration_image, 0, n * 2u * sizeof(float4), context->stream));
   for (etx_hip_context* helper : context->helpers)
-    HIP_OK(context, hipMemsetAsync(helper->pt_iteration_image, 0, n * sizeof(float4), context->stream));
+    HIP_OK(context, hipMemsetAsync(helper->pt_iteration_image, 0, n * 2u * sizeof(float4), context->stream));
   HIP_OK(context, hipStreamSynchronize(context->stream));  // the lanes run on their own streams
   context->armed = true;
   return ETX_HIP_OK;
 }
 
-int etx_hip_render_iteration(etx_hip_context* context) {
+namespace {
+// Hands the next iteration to a free lane. `wait`: block while every lane is busy; otherwise return 0 at once.
+int submit_iteration(etx_hip_context* context, bool wait) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   if (context->armed == false) {
@@ -947,16 +997,18 @@ int etx_hip_render_iteration(etx_hip_context* context) {
     context->error = "etx_hip_render_iteration after etx_hip_reduce_film: call etx_hip_begin again";
     return ETX_HIP_ERROR_STATE;
   }
-  // hand the iteration to a free lane; blocks only while every lane is busy
   const uint32_t lane_count = uint32_t(context->helpers.size()) + 1u;
   etx_hip_context* lane = nullptr;
   {
     std::unique_lock<std::mutex> lock(context->shared_mutex);
-    context->idle_cv.wait(lock, [&] { return (context->jobs_in_flight < lane_count) || (context->sticky_error != 0); });
+    if (wait)
+      context->idle_cv.wait(lock, [&] { return (context->jobs_in_flight < lane_count) || (context->sticky_error != 0); });
     if (context->sticky_error) {
       context->error = context->sticky_error_text;
       return context->sticky_error;
     }
+    if (context->jobs_in_flight >= lane_count)
+      return 0;  // every lane is busy (try variant)
     lane = context->lane_busy ? nullptr : context;
     for (size_t i = 0; (lane == nullptr) && (i < context->helpers.size()); ++i)
       lane = context->helpers[i]->lane_busy ? nullptr : context->helpers[i];
@@ -976,7 +1028,17 @@ int etx_hip_render_iteration(etx_hip_context* context) {
   }
   lane->lane_cv.notify_one();
   context->next_iteration += context->iteration_stride;
-  return ETX_HIP_OK;
+  return 1;
+}
+}  // namespace
+
+int etx_hip_render_iteration(etx_hip_context* context) {
+  const int rc = submit_iteration(context, true);  // blocks only while every lane is busy
+  return (rc > 0) ? ETX_HIP_OK : ((rc == 0) ? ETX_HIP_ERROR_STATE : rc);
+}
+
+int etx_hip_try_render_iteration(etx_hip_context* context) {
+  return submit_iteration(context, false);
 }
 
 int etx_hip_poll(etx_hip_context* context) {

@@ -22,7 +22,8 @@ struct ShadeGroups {
 
 // traversal
 // `max_items`: host-side upper bound of the device-resident item count (sizes the grid; kernels grid-stride anyway)
-void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat);
+constexpr uint32_t kRoundMirrorSlots = 64;  // ring of (round tag, active count) entries the trace kernel writes to pinned host memory
+void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat, unsigned long long* round_mirror, uint32_t round_tag);
 void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_items, bool flat);
 void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count, bool flat);
 
@@ -52,6 +53,7 @@ void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it, 
 void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items);
 
 // film
+void launch_vcm_commit(hipStream_t stream, float4* iteration_camera, float4* iteration_light, float4* camera_sum, float4* light_sum, uint32_t pixels);
 void launch_film_resolve(hipStream_t stream, const float4* camera_sum, const float4* light_sum, float4* out, uint32_t pixel_count, float scale, int layer);
 
 // known-answer kernels

@@ -14,7 +14,7 @@ namespace etxd {
 
 template <bool kFromCounter, bool kFlat>
 __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
-  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count) {
+  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag) {
   // the flat sweep needs no stack: without the 32 KB of LDS the kernel runs 8 waves per SIMD instead of 5
   __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
   const DScene& scene = scene_arg;  // by value: kernarg (scalar) loads, table pointers known to be global
@@ -30,6 +30,11 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
     counters[kCntGroupGeneral] = 0u;
     counters[kCntGroupSubsurface] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
+    // the host's view of the wavefront (host_api.cpp run_bounce_loop): (round tag + 1, active paths entering this round)
+    // in pinned host memory - the host never drains the stream to learn that a pass has ended
+    if (round_mirror != nullptr)
+      __hip_atomic_store(round_mirror + (round_tag & (kRoundMirrorSlots - 1u)), ((unsigned long long)(round_tag) + 1ull) << 32u | (unsigned long long)count, __ATOMIC_RELEASE,
+        __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -67,7 +72,7 @@ ETX_DEV v2f splat2(float v) {
 
 template <bool kFromCounter>
 __global__ __launch_bounds__(kBlockSize) void k_trace_closest_flat2(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
-  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count) {
+  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag) {
   const DScene& scene = scene_arg;
   const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
   if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
@@ -80,6 +85,9 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_flat2(const DScene
     counters[kCntGroupGeneral] = 0u;
     counters[kCntGroupSubsurface] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
+    if (round_mirror != nullptr)
+      __hip_atomic_store(round_mirror + (round_tag & (kRoundMirrorSlots - 1u)), ((unsigned long long)(round_tag) + 1ull) << 32u | (unsigned long long)count, __ATOMIC_RELEASE,
+        __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6u;
@@ -180,17 +188,17 @@ static uint32_t flat2_blocks(uint32_t items) {  // 512 rays per 256-thread block
   return max(1u, min(limit, (items + 2u * kBlockSize - 1u) / (2u * kBlockSize)));
 }
 
-void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat) {
+void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat, unsigned long long* round_mirror, uint32_t round_tag) {
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.capacity, max_items) + kBlockSize - 1) / kBlockSize));
   // opt-in (ETX_HIP_DEBUG_FLAGS bit 64): alone on the device the two-ray sweep is 10 % faster (39.3 vs 35.7 Grays/s on 2 M incoherent
   // rays), inside the 4-lane pipeline its fatter waves lose against the co-running kernels (51.5 vs 46.6 us per launch) - DESIGN.md 3
   if (flat && (p.debug_flags & 64u))
     hipLaunchKernelGGL((k_trace_closest_flat2<true>), dim3(flat2_blocks(min(p.capacity, max_items))), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits,
-      p.counters, active_counter, 0u);
+      p.counters, active_counter, 0u, round_mirror, round_tag);
   else if (flat)
-    hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u);
+    hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag);
   else
-    hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u);
+    hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -275,11 +283,11 @@ void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ra
     limited.flat_prim_count = min(limited.flat_prim_count, uint32_t(strtoul(e, nullptr, 0)));
   const bool two_ray_sweep = (getenv("ETX_HIP_DEBUG_FLAGS") != nullptr) && ((strtoul(getenv("ETX_HIP_DEBUG_FLAGS"), nullptr, 0) & 64u) != 0u);
   if (flat && two_ray_sweep)
-    hipLaunchKernelGGL((k_trace_closest_flat2<false>), dim3(flat2_blocks(count)), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count);
+    hipLaunchKernelGGL((k_trace_closest_flat2<false>), dim3(flat2_blocks(count)), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u);
   else if (flat)
-    hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count);
+    hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u);
   else
-    hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(blocks), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count);
+    hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(blocks), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u);
 }
 
 }  // namespace etxd

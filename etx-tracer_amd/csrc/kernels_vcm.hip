@@ -210,6 +210,29 @@ void launch_stats_finalize(hipStream_t stream, const Pipeline& p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// End of a VCM iteration: the lane's iteration images go into the film sums (shared by the lanes: atomics) and are
+// cleared for the next iteration. One add per pixel and iteration keeps the fp32 sums unbiased (host_api.cpp).
+__global__ __launch_bounds__(kBlockSize) void k_vcm_commit(float4* __restrict__ iteration_camera, float4* __restrict__ iteration_light, float4* __restrict__ camera_sum,
+  float4* __restrict__ light_sum, uint32_t pixels) {
+  const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += gridDim.x * blockDim.x) {
+    const float4 c = iteration_camera[i], l = iteration_light[i];
+    if ((c.x != 0.0f) || (c.y != 0.0f) || (c.z != 0.0f)) {
+      atomic_add_f3(camera_sum + i, f3{c.x, c.y, c.z});
+      iteration_camera[i] = zero;
+    }
+    if ((l.x != 0.0f) || (l.y != 0.0f) || (l.z != 0.0f)) {
+      atomic_add_f3(light_sum + i, f3{l.x, l.y, l.z});
+      iteration_light[i] = zero;
+    }
+  }
+}
+
+void launch_vcm_commit(hipStream_t stream, float4* iteration_camera, float4* iteration_light, float4* camera_sum, float4* light_sum, uint32_t pixels) {
+  hipLaunchKernelGGL(k_vcm_commit, dim3(grid_for(pixels)), dim3(kBlockSize), 0, stream, iteration_camera, iteration_light, camera_sum, light_sum, pixels);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Film::layer, film.cxx:381-418: float3 sums -> float4 (alpha 1); Result = max(0, camera + light)
 __global__ void k_film_resolve(const float4* __restrict__ camera_sum, const float4* __restrict__ light_sum, float4* __restrict__ out, uint32_t pixel_count, float scale, int layer) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

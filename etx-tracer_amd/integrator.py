@@ -7,6 +7,7 @@ raytracer (INTEGRATION.md shows that class; both sit on the same C ABI). `HIPVCM
 iteration per call and stops at scene.samples, stop() drains the device.
 """
 import enum
+import time
 
 from . import api
 
@@ -135,9 +136,10 @@ class HIPIntegrator(Integrator):
     def update(self):
         if self.current_state == State.Stopped:
             return
-        # asynchronous: hands the iteration to a free device lane (two iterations overlap on the GPU), blocks only
-        # while every lane is busy; the film is complete after sync()
-        self.context.render_iteration()
+        # asynchronous and non-blocking (vcm_cpu.cxx:264-268: update() returns at once while work is in flight): the iteration
+        # goes to a free device lane, or nowhere when every lane is busy - the next update() tries again
+        if self.context.try_render_iteration() == 0:
+            return
         self._rendered += 1
         self._have_camera_image = True
         self._have_light_image = True
@@ -169,7 +171,10 @@ class HIPIntegrator(Integrator):
         """run() + update() until Stopped - what the headless driver does (oracle/driver/etx_oracle.cxx main loop)."""
         self.run()
         while self.state() != State.Stopped:
+            before = self._rendered
             self.update()
+            if (self._rendered == before) and (self.state() != State.Stopped):
+                time.sleep(1.0e-4)  # every lane busy: the GUI would come back at its next frame (driver: sleep_for(200us))
         return self
 
     def film(self, layer=api.LAYER_RESULT):

@@ -104,9 +104,14 @@ int etx_hip_upload_cie_table(etx_hip_context* context, const float* xyz, uint32_
  * iteration; single GPU: 0, 1). */
 int etx_hip_begin(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride);
 
-/* Enqueues one full iteration (VCM: light pass, grid build, camera pass; PT: one sample per pixel) on the
- * context's stream and returns without waiting. */
+/* Hands one full iteration (VCM: light pass, grid build, camera pass; PT: one sample per pixel) to a free device lane and
+ * returns without waiting for it; blocks only while every lane (ETX_HIP_LANES, default 4) is busy. */
 int etx_hip_render_iteration(etx_hip_context* context);
+
+/* The same without ever blocking: 1 = the iteration was handed to a free device lane, 0 = every lane is busy (call again
+ * later, e.g. at the next Integrator::update()), <0 = error. Integrator::update must not block (vcm_cpu.cxx:264-268: CPUVCM
+ * returns at once while its task set is incomplete); etx_hip_render_iteration blocks while every lane is busy. */
+int etx_hip_try_render_iteration(etx_hip_context* context);
 
 /* 1 = all enqueued iterations finished, 0 = still running, <0 = error. Never blocks (Integrator::update must not
  * block: vcm_cpu.cxx:264-268). */

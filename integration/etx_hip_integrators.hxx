@@ -1,0 +1,412 @@
+// etx_hip_integrators.hxx - the reference-side binding of libetx_hip.so: the file a maintainer adds to etx-tracer as
+// sources/etx/rt/integrators/hip_integrators.hxx. It is COMPILED here: oracle/build_ref.sh builds it
+// against the reference's own headers into the headless driver (oracle/_ref/etx_oracle --integrator hip-vcm | hip-pt), and
+// tests/test_gpu_binding.py renders through it on the GPU box and compares with the ctypes binding.
+//
+// Two classes on the reference's plugin interface `struct Integrator` (sources/etx/rt/integrators/integrator.hxx:12-98):
+//   HIPVCM          in place of CPUVCM          (sources/etx/rt/integrators/vcm_cpu.cxx:243-310)
+//   HIPPathTracing  in place of CPUPathTracing  (sources/etx/rt/integrators/path_tracing.cxx:112-172)
+// Only API that exists in the reference is used. The film is published through Film::accumulate_camera_image /
+// atomic_add_light_iteration / commit_light_iteration (film.hxx:57-59): Film::clear resets the per-pixel sample counts,
+// so ONE accumulate per pixel stores the device's running mean verbatim (film.cxx:195-199), and one light "iteration"
+// committed with index 0 stores the device's light image (film.cxx:332-343). That is O(pixels) host work per publish -
+// off the hot path, done every kPublishInterval iterations and at the end; integration/film_merge_iteration.patch is
+// the additive bulk interface that removes it.
+//
+// The library is loaded with dlopen (ETX_HIP_LIBRARY or next to the executable), so a host built with this file still
+// starts on a machine without the backend: enabled() is false there and run() stays Stopped (integrator.hxx:49-51).
+#pragma once
+
+#include <etx/core/core.hxx>
+#include <etx/render/host/film.hxx>
+#include <etx/render/shared/spectrum.hxx>
+#include <etx/rt/integrators/integrator.hxx>
+#include <etx/rt/shared/path_tracing_shared.hxx>
+#include <etx/rt/shared/vcm_shared.hxx>
+#include <bluenoise.hxx>
+
+#include <etx_hip.h>
+
+#include <dlfcn.h>
+
+#include <string>
+#include <vector>
+
+namespace etx {
+
+// log::output walks its va_list twice (core/log.cxx:19-24), which only works where va_list is a plain pointer: texts go
+// through as the format string itself, with '%' escaped.
+inline void hip_report_error(const char* text) {
+  std::string escaped;
+  for (const char* c = (text != nullptr) ? text : "unknown error"; *c != 0; ++c) {
+    escaped += *c;
+    if (*c == '%')
+      escaped += '%';
+  }
+  log::error(escaped.c_str());
+}
+
+// Entry points of include/etx_hip.h, resolved at run time.
+struct HIPBackendLibrary {
+  void* handle = nullptr;
+  decltype(&etx_hip_create) create = nullptr;
+  decltype(&etx_hip_destroy) destroy = nullptr;
+  decltype(&etx_hip_last_error) last_error = nullptr;
+  decltype(&etx_hip_upload_scene) upload_scene = nullptr;
+  decltype(&etx_hip_upload_bluenoise) upload_bluenoise = nullptr;
+  decltype(&etx_hip_upload_cie_table) upload_cie_table = nullptr;
+  decltype(&etx_hip_begin) begin = nullptr;
+  decltype(&etx_hip_try_render_iteration) try_render_iteration = nullptr;
+  decltype(&etx_hip_poll) poll = nullptr;
+  decltype(&etx_hip_sync) sync = nullptr;
+  decltype(&etx_hip_read_film) read_film = nullptr;
+  decltype(&etx_hip_stats) stats = nullptr;
+
+  static HIPBackendLibrary& get() {
+    static HIPBackendLibrary lib = load();
+    return lib;
+  }
+
+  bool ok() const {
+    return handle != nullptr;
+  }
+
+ private:
+  static HIPBackendLibrary load() {
+    HIPBackendLibrary lib;
+    const char* path = getenv("ETX_HIP_LIBRARY");
+    lib.handle = dlopen(path ? path : "libetx_hip.so", RTLD_NOW | RTLD_LOCAL);
+    if (lib.handle == nullptr) {
+      hip_report_error((std::string("HIP backend not available: ") + dlerror()).c_str());
+      return lib;
+    }
+    bool complete = true;
+    auto resolve = [&](auto& fn, const char* name) {
+      fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(lib.handle, name));
+      complete = complete && (fn != nullptr);
+    };
+    resolve(lib.create, "etx_hip_create");
+    resolve(lib.destroy, "etx_hip_destroy");
+    resolve(lib.last_error, "etx_hip_last_error");
+    resolve(lib.upload_scene, "etx_hip_upload_scene");
+    resolve(lib.upload_bluenoise, "etx_hip_upload_bluenoise");
+    resolve(lib.upload_cie_table, "etx_hip_upload_cie_table");
+    resolve(lib.begin, "etx_hip_begin");
+    resolve(lib.try_render_iteration, "etx_hip_try_render_iteration");
+    resolve(lib.poll, "etx_hip_poll");
+    resolve(lib.sync, "etx_hip_sync");
+    resolve(lib.read_film, "etx_hip_read_film");
+    resolve(lib.stats, "etx_hip_stats");
+    if (complete == false) {
+      log::error("libetx_hip.so misses entry points of etx_hip.h");
+      dlclose(lib.handle);
+      lib.handle = nullptr;
+    }
+    return lib;
+  }
+};
+
+static_assert(sizeof(Scene) == sizeof(etx_abi_scene), "etx::Scene is the ABI struct");
+static_assert(sizeof(Camera) == sizeof(etx_abi_camera), "etx::Camera is the ABI struct");
+static_assert(sizeof(VCMOptions) == sizeof(etx_abi_vcm_options), "VCMOptions is passed by value");
+static_assert(sizeof(PTOptions) == sizeof(etx_abi_pt_options), "PTOptions is passed by value");
+
+struct HIPIntegratorBase : public Integrator {
+  static constexpr uint32_t kPublishInterval = 16;  // iterations between two film publishes while rendering
+
+  HIPIntegratorBase(Raytracing& r)
+    : Integrator(r) {
+  }
+
+  ~HIPIntegratorBase() override {
+    if (ctx != nullptr)
+      HIPBackendLibrary::get().destroy(ctx);
+  }
+
+  bool enabled() const override {
+    return HIPBackendLibrary::get().ok();
+  }
+
+  const Status& status() const override {
+    return _status;
+  }
+
+  // CPUVCM::run / CPUPathTracing::run (vcm_cpu.cxx:255-262, path_tracing.cxx:128-135)
+  void run() override {
+    stop(Stop::Immediate);
+    auto& lib = HIPBackendLibrary::get();
+    if ((lib.ok() == false) || (can_run() == false))
+      return;
+    if ((ctx == nullptr) && (lib.create(0, &ctx) != ETX_HIP_OK)) {
+      hip_report_error(lib.last_error(nullptr));
+      ctx = nullptr;
+      return;
+    }
+    // etx::Scene / etx::Camera ARE the ABI structs: the backend borrows them during the call and owns device copies
+    // afterwards (deep copy + BVH build: Raytracing::commit_changes, rt.cxx:58-88, and the disabled sketch rt.cxx:141-238)
+    if (lib.upload_scene(ctx, reinterpret_cast<const etx_abi_scene*>(&rt.scene()), reinterpret_cast<const etx_abi_camera*>(&rt.camera())) != ETX_HIP_OK) {
+      hip_report_error(lib.last_error(ctx));  // e.g. ETX_HIP_ERROR_UNSUPPORTED: stay Stopped, like a failed Embree commit
+      return;
+    }
+    if (rt.scene().spectral() && (upload_cie_table() == false))
+      return;
+    if (begin() == false)
+      return;
+    rt.film().clear(Film::ClearCameraData | Film::ClearLightData);
+    _status = {};
+    submitted = 0;
+    published = 0;
+    current_state = State::Running;
+  }
+
+  // CPUVCM::update (vcm_cpu.cxx:264-276): called once per GUI frame, must not block
+  void update() override {
+    if (current_state == State::Stopped)
+      return;
+    auto& lib = HIPBackendLibrary::get();
+    const uint32_t total = rt.scene().samples;
+    if ((current_state == State::Running) && (submitted < total)) {
+      const int rc = lib.try_render_iteration(ctx);  // 1: handed to a free device lane, 0: every lane is busy
+      if (rc < 0) {
+        hip_report_error(lib.last_error(ctx));
+        current_state = State::Stopped;
+        return;
+      }
+      submitted += uint32_t(rc);
+    }
+    read_status();
+    const bool all_submitted = (submitted >= total) || (current_state == State::WaitingForCompletion);
+    const int idle = lib.poll(ctx);  // 1 = every iteration handed over so far has finished
+    if (idle < 0) {
+      hip_report_error(lib.last_error(ctx));
+      current_state = State::Stopped;
+      return;
+    }
+    if (all_submitted && (idle == 1)) {
+      read_status();
+      publish_film();
+      current_state = State::Stopped;  // vcm_cpu.cxx:234
+    } else if (_status.completed_iterations >= published + kPublishInterval) {
+      publish_film();
+    }
+  }
+
+  // vcm_cpu.cxx:278-288
+  void stop(Stop st) override {
+    if (current_state == State::Stopped)
+      return;
+    if (st == Stop::Immediate) {
+      if (ctx != nullptr) {
+        HIPBackendLibrary::get().sync(ctx);
+        read_status();
+        publish_film();
+      }
+      current_state = State::Stopped;
+    } else {
+      current_state = State::WaitingForCompletion;
+    }
+  }
+
+  void update_options() override {
+    if (current_state == State::Running)
+      run();
+  }
+
+  bool have_updated_camera_image() const override {
+    const bool r = camera_updated;
+    camera_updated = false;
+    return r;
+  }
+
+  bool have_updated_light_image() const override {
+    const bool r = light_updated;
+    light_updated = false;
+    return r;
+  }
+
+ protected:
+  virtual bool begin() = 0;
+  virtual bool writes_light_image() const = 0;
+
+  void read_status() {
+    etx_hip_stats_t s = {};
+    if (HIPBackendLibrary::get().stats(ctx, &s, sizeof(s)) != ETX_HIP_OK)
+      return;
+    _status.last_iteration_time = s.last_iteration_time;  // Integrator::Status, integrator.hxx:24-37
+    _status.total_time = s.total_time;
+    _status.completed_iterations = s.completed_iterations;
+    _status.current_iteration = s.current_iteration;
+  }
+
+  // The device keeps the running means; mirror them into the Film through its per-pixel interface.
+  void publish_film() {
+    auto& lib = HIPBackendLibrary::get();
+    Film& film = rt.film();
+    const uint2 dim = film.size();
+    const size_t pixels = size_t(dim.x) * dim.y;
+    if ((film.pixel_size() != 1u) || (_status.completed_iterations == 0))
+      return;
+    camera.resize(pixels);
+    normal.resize(pixels);
+    albedo.resize(pixels);
+    if (lib.read_film(ctx, ETX_HIP_LAYER_CAMERA, &camera[0].x, pixels * sizeof(float4)) != ETX_HIP_OK) {
+      hip_report_error(lib.last_error(ctx));
+      return;
+    }
+    const bool aovs = writes_light_image() == false;  // the path tracer fills the denoiser AOVs (film.cxx:207-216)
+    if (aovs && ((lib.read_film(ctx, ETX_HIP_LAYER_NORMAL, &normal[0].x, pixels * sizeof(float4)) != ETX_HIP_OK) ||
+                 (lib.read_film(ctx, ETX_HIP_LAYER_ALBEDO, &albedo[0].x, pixels * sizeof(float4)) != ETX_HIP_OK))) {
+      hip_report_error(lib.last_error(ctx));
+      return;
+    }
+    film.clear(Film::ClearCameraData | (writes_light_image() ? uint32_t(Film::ClearLightData) : 0u));
+    // rows of the device film are the Film's storage rows: storage row r holds pixel y = H - 1 - r (film.cxx:189)
+    for (uint32_t row = 0; row < dim.y; ++row) {
+      for (uint32_t x = 0; x < dim.x; ++x) {
+        const size_t i = size_t(row) * dim.x + x;
+        const float4& c = camera[i];
+        // Film::layer(Normals) = n * 0.5 + 0.5 (film.cxx:411): the device returns the layer, the film stores n
+        const float3 n = aovs ? float3{normal[i].x * 2.0f - 1.0f, normal[i].y * 2.0f - 1.0f, normal[i].z * 2.0f - 1.0f} : float3{};
+        const float3 a = aovs ? float3{albedo[i].x, albedo[i].y, albedo[i].z} : float3{};
+        film.accumulate_camera_image({x, dim.y - 1u - row}, {c.x, c.y, c.z}, n, a);
+      }
+    }
+    camera_updated = true;
+    if (writes_light_image()) {
+      light.resize(pixels);
+      if (lib.read_film(ctx, ETX_HIP_LAYER_LIGHT, &light[0].x, pixels * sizeof(float4)) != ETX_HIP_OK) {
+        hip_report_error(lib.last_error(ctx));
+        return;
+      }
+      for (uint32_t row = 0; row < dim.y; ++row) {
+        for (uint32_t x = 0; x < dim.x; ++x) {
+          const float4& l = light[size_t(row) * dim.x + x];
+          const float2 ndc = {(float(x) + 0.5f) / float(dim.x) * 2.0f - 1.0f, (float(dim.y - 1u - row) + 0.5f) / float(dim.y) * 2.0f - 1.0f};
+          film.atomic_add_light_iteration({l.x, l.y, l.z}, ndc);
+        }
+      }
+      film.commit_light_iteration(0);
+      light_updated = true;
+    }
+    published = _status.completed_iterations;
+  }
+
+  // sample_blue_noise (path_tracing.cxx:173-178) is a function of (pixel & 127, sample & 255, dimension & 7) only and its
+  // tables are private to thirdparty/bluenoise: tabulate the sampler for the class BNSampler picks for scene.samples
+  bool upload_bluenoise() {
+    const uint32_t samples = min(max(rt.scene().samples, 1u), 256u);
+    uint32_t set = 0;
+    while ((1u << set) < samples)
+      ++set;
+    if (uploaded_bluenoise_sets & (1u << set))
+      return true;
+    std::vector<uint8_t> values(size_t(128) * 128 * 256 * 8);
+    for (uint32_t py = 0; py < 128; ++py)
+      for (uint32_t px = 0; px < 128; ++px)
+        for (uint32_t sample = 0; sample < 256; ++sample) {
+          BNSampler smp(px, py, rt.scene().samples, sample);
+          for (uint32_t d = 0; d < 8; ++d)
+            values[(((size_t(py) * 128 + px) * 256) + sample) * 8 + d] = uint8_t(smp.get(d) * 256.0f);
+        }
+    if (HIPBackendLibrary::get().upload_bluenoise(ctx, set, values.data(), values.size()) != ETX_HIP_OK) {
+      hip_report_error(HIPBackendLibrary::get().last_error(ctx));
+      return false;
+    }
+    uploaded_bluenoise_sets |= 1u << set;
+    return true;
+  }
+
+  // the CIE observer behind SpectralResponse::to_rgb (spectrum.hxx:28-140, 271-293): the host's data, not compiled into the backend
+  bool upload_cie_table() {
+    std::vector<float> xyz(size_t(spectrum::WavelengthCount) * 3u);
+    for (uint32_t k = 0; k < spectrum::WavelengthCount; ++k) {
+      const float3 v = spectrum::spectral_xyz(k);
+      xyz[3u * k + 0u] = v.x, xyz[3u * k + 1u] = v.y, xyz[3u * k + 2u] = v.z;
+    }
+    if (HIPBackendLibrary::get().upload_cie_table(ctx, xyz.data(), spectrum::WavelengthCount, spectrum::kShortestWavelength) != ETX_HIP_OK) {
+      hip_report_error(HIPBackendLibrary::get().last_error(ctx));
+      return false;
+    }
+    return true;
+  }
+
+  etx_hip_context* ctx = nullptr;
+  Status _status = {};
+  uint32_t submitted = 0, published = 0;
+  uint32_t uploaded_bluenoise_sets = 0;
+  std::vector<float4> camera, light, normal, albedo;
+  mutable bool camera_updated = false, light_updated = false;
+};
+
+struct HIPVCM : public HIPIntegratorBase {
+  HIPVCM(Raytracing& r)
+    : HIPIntegratorBase(r) {
+    VCMOptions::default_values().store(integrator_options);  // the option keys of CPUVCM (vcm_shared.cxx:30-47)
+  }
+
+  const char* name() override {
+    return "VCM (HIP gfx950)";
+  }
+
+  const char* status_str() const override {
+    return (current_state == State::Stopped) ? "Stopped" : "Rendering on the device";
+  }
+
+ protected:
+  bool begin() override {
+    VCMOptions opt = VCMOptions::default_values();
+    opt.load(integrator_options);
+    if (opt.blue_noise && (upload_bluenoise() == false))
+      return false;
+    if (HIPBackendLibrary::get().begin(ctx, ETX_HIP_INTEGRATOR_VCM, &opt, sizeof(opt), /* first iteration */ 0, /* stride */ 1) != ETX_HIP_OK) {
+      hip_report_error(HIPBackendLibrary::get().last_error(ctx));
+      return false;
+    }
+    return true;
+  }
+
+  bool writes_light_image() const override {
+    return true;
+  }
+};
+
+struct HIPPathTracing : public HIPIntegratorBase {
+  HIPPathTracing(Raytracing& r)
+    : HIPIntegratorBase(r) {
+    // the option keys of CPUPathTracing (path_tracing.cxx:137-142)
+    integrator_options.set_bool("direct", true, "Direct Hits");
+    integrator_options.set_bool("nee", true, "Light Sampling");
+    integrator_options.set_bool("mis", true, "Multiple Importance Sampling");
+    integrator_options.set_bool("bn", true, "Use Blue Noise");
+  }
+
+  const char* name() override {
+    return "Path Tracing (HIP gfx950)";
+  }
+
+  const char* status_str() const override {
+    return (current_state == State::Stopped) ? "Stopped" : "Rendering on the device";
+  }
+
+ protected:
+  bool begin() override {
+    PTOptions opt = {};
+    opt.direct = integrator_options.get_bool("direct", opt.direct);  // CPUPathTracingImpl::start, path_tracing.cxx:36-40
+    opt.nee = integrator_options.get_bool("nee", opt.nee);
+    opt.mis = integrator_options.get_bool("mis", opt.mis);
+    opt.blue_noise = integrator_options.get_bool("bn", opt.blue_noise);
+    if (opt.blue_noise && (upload_bluenoise() == false))
+      return false;
+    if (HIPBackendLibrary::get().begin(ctx, ETX_HIP_INTEGRATOR_PT, &opt, sizeof(opt), 0, 1) != ETX_HIP_OK) {
+      hip_report_error(HIPBackendLibrary::get().last_error(ctx));
+      return false;
+    }
+    return true;
+  }
+
+  bool writes_light_image() const override {
+    return false;
+  }
+};
+
+}  // namespace etx

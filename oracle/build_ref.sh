@@ -16,10 +16,10 @@ CXX=/opt/rocm/lib/llvm/bin/clang++   # g++ 11 rejects sources/etx/util/options.h
 CC=/opt/rocm/lib/llvm/bin/clang
 FLAGS="-Wno-invalid-offsetof -std=c++23 -O2 -g0 -DNDEBUG -D_stricmp=strcasecmp -DETX_HAVE_OPENVDB=1 -D_USE_MATH_DEFINES=1 -DETX_LIBRARY=1 -march=native -w -fPIC"
 T="$REF/thirdparty"
-INC="-I$REF/sources -I$T -I$T/enkits -I$T/bluenoise -I$T/json -I$T/tinyobjloader -I$T/tinygltf -I$T/mikktspace -I$T/stb_image -I$T/tinyexr -I$T/nanovdb"
+INC="-I$HERE/../include -I$HERE/../integration -I$REF/sources -I$T -I$T/enkits -I$T/bluenoise -I$T/json -I$T/tinyobjloader -I$T/tinygltf -I$T/mikktspace -I$T/stb_image -I$T/tinyexr -I$T/nanovdb"
 
 compile() { # src obj
-  if [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ "$0" -nt "$2" ]; then
+  if [ ! -f "$2" ] || [ "$1" -nt "$2" ] || [ "$0" -nt "$2" ] || [ "$HERE/../integration/etx_hip_integrators.hxx" -nt "$2" -a "$(basename $1)" = "etx_oracle.cxx" ] || [ "$HERE/../include/etx_hip.h" -nt "$2" -a "$(basename $1)" = "etx_oracle.cxx" ]; then
     echo "  CXX $(basename $1)"
     $CXX $FLAGS $INC -c "$1" -o "$2"
   fi
@@ -41,5 +41,5 @@ done
 if [ ! -f "$OBJ/mikktspace.o" ]; then $CC -O2 -w -fPIC -c "$T/mikktspace/mikktspace.c" -o "$OBJ/mikktspace.o" & pids+=($!); fi
 for p in "${pids[@]}"; do wait $p; done
 
-$CXX -O2 -o "$OUT/etx_oracle" "$OBJ"/*.o -lpthread -static-libstdc++
+$CXX -O2 -o "$OUT/etx_oracle" "$OBJ"/*.o -lpthread -ldl
 echo "built $OUT/etx_oracle"

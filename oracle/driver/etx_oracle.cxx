@@ -25,6 +25,9 @@
 #include <etx/rt/shared/vcm_shared.hxx>
 #include <bluenoise.hxx>
 
+#include <etx_hip_integrators.hxx>  // integration/: the reference-side binding of libetx_hip.so (HIPVCM, HIPPathTracing)
+#include <unistd.h>
+
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -243,7 +246,7 @@ int print_kat() {
 
 void usage() {
   printf(
-    "etx_oracle --scene file.json | --load-snapshot scene.bin --integrator pt|vcm|bdpt [--spp N] [--out film.raw] [--snapshot scene.bin]\n"
+    "etx_oracle --scene file.json | --load-snapshot scene.bin --integrator pt|vcm|bdpt|hip-vcm|hip-pt [--spp N] [--out film.raw] [--snapshot scene.bin]\n"
     "           [--data /root/reference/bin/] [--opt key=value]... [--max-iterations N]\n");
 }
 
@@ -255,6 +258,7 @@ int main(int argc, char** argv) {
   std::vector<std::pair<std::string, std::string>> opts;
   int64_t spp = -1;
   int64_t max_iterations = -1;
+  float noise_threshold = -1.0f;  // < 0: keep the scene value
   uint32_t inject_density = 0;  // N: every medium of the loaded scene becomes Heterogeneous with a procedural N^3 density grid
   for (int i = 1; i < argc; ++i) {
     auto next = [&]() -> const char* {
@@ -309,6 +313,8 @@ int main(int argc, char** argv) {
       spp = atoll(next());
     else if (strcmp(argv[i], "--max-iterations") == 0)
       max_iterations = atoll(next());
+    else if (strcmp(argv[i], "--noise-threshold") == 0)  // Scene::noise_threshold (scene.hxx:45, default 0.1): 0 switches the adaptive sampling of CPUPathTracing off
+      noise_threshold = float(atof(next()));
     else if (strcmp(argv[i], "--out") == 0)
       out_file = next();
     else if (strcmp(argv[i], "--snapshot") == 0)
@@ -386,6 +392,8 @@ int main(int argc, char** argv) {
       const_cast<Scene*>(scene_ptr)->samples = uint32_t(spp);
     }
   }
+  if (noise_threshold >= 0.0f)
+    const_cast<Scene*>(scene_ptr)->noise_threshold = noise_threshold;
   raytracing.link_scene(*scene_ptr);
   raytracing.link_camera(*camera_ptr);
   raytracing.commit_changes();
@@ -407,9 +415,21 @@ int main(int argc, char** argv) {
   if (integrator_name == "none")
     return 0;
 
+  if ((integrator_name.rfind("hip-", 0) == 0) && (getenv("ETX_HIP_LIBRARY") == nullptr)) {
+    // the in-tree library: <repo>/oracle/_ref/etx_oracle -> <repo>/etx-tracer_amd/libetx_hip.so
+    char exe[4096] = {};
+    const ssize_t len = readlink("/proc/self/exe", exe, sizeof(exe) - 1);
+    if (len > 0) {
+      std::string dir(exe, size_t(len));
+      dir = dir.substr(0, dir.find_last_of('/'));
+      setenv("ETX_HIP_LIBRARY", (dir + "/../../etx-tracer_amd/libetx_hip.so").c_str(), 0);
+    }
+  }
   CPUPathTracing pt(raytracing);
   CPUVCM vcm(raytracing);
   CPUBidirectional bdpt(raytracing);
+  HIPVCM hip_vcm(raytracing);          // the device integrators sit behind the same plugin interface (app.hxx:72-82)
+  HIPPathTracing hip_pt(raytracing);
   Integrator* integrator = nullptr;
   if (integrator_name == "pt")
     integrator = &pt;
@@ -417,6 +437,10 @@ int main(int argc, char** argv) {
     integrator = &vcm;
   else if (integrator_name == "bdpt")
     integrator = &bdpt;
+  else if (integrator_name == "hip-vcm")
+    integrator = &hip_vcm;
+  else if (integrator_name == "hip-pt")
+    integrator = &hip_pt;
   else {
     usage();
     return 1;
@@ -432,9 +456,17 @@ int main(int argc, char** argv) {
       o.set_integral(kv.first, uint32_t(atoll(kv.second.c_str())), kv.first);
   }
 
+  if (integrator->enabled() == false) {
+    printf("integrator %s is not available on this machine\n", integrator->name());
+    return 5;
+  }
   raytracing.film().clear(Film::ClearEverything);
   auto t0 = std::chrono::steady_clock::now();
   integrator->run();
+  if (integrator->state() == Integrator::State::Stopped) {
+    printf("integrator %s did not start (see the log above)\n", integrator->name());
+    return 6;
+  }
   while (integrator->state() != Integrator::State::Stopped) {
     integrator->update();
     if ((max_iterations > 0) && (int64_t(integrator->status().completed_iterations) >= max_iterations) && (integrator->state() == Integrator::State::Running)) {

@@ -70,7 +70,9 @@ def main():
             render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_full_128_vcm_%d_decorrelated.npz" % args.spp), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "1"},
                    extra=["--opt", "vcm-blue_noise=false"])
         if "pt" in integrators:
-            render(snapshot, "pt", args.spp, os.path.join(HI, "cornell_%s_128_pt_%d.npz" % (flavour, args.spp)), args.cores, extra=["--opt", "bn=false"])
+            # --noise-threshold 0: every pixel gets all samples (the scenes carry Scene::noise_threshold = 0.1, with which
+            # CPUPathTracing stops sampling converged pixels after 32 samples: a "4096-spp" film would hold ~100-spp noise)
+            render(snapshot, "pt", args.spp, os.path.join(HI, "cornell_%s_128_pt_%d.npz" % (flavour, args.spp)), args.cores, extra=["--opt", "bn=false", "--noise-threshold", "0"])
 
 
 if __name__ == "__main__":

@@ -1,0 +1,74 @@
+"""GPU (-m gpu): the reference-side C++ binding (integration/etx_hip_integrators.hxx: HIPVCM / HIPPathTracing on the
+reference's `struct Integrator`, compiled against the reference's headers into oracle/_ref/etx_oracle) against the ctypes
+binding of the same C ABI. Both drive libetx_hip.so; the C++ side publishes the film through the reference's own Film
+(accumulate_camera_image / atomic_add_light_iteration / commit_light_iteration) and the driver writes Film::layer."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tools import film_io
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE = os.path.join(ROOT, "oracle", "_ref", "etx_oracle")
+
+
+def run_driver(tmp_path, snapshot, integrator, spp, *options):
+    out = str(tmp_path / ("%s.raw" % integrator))
+    cmd = [ORACLE, "--load-snapshot", snapshot, "--integrator", integrator, "--spp", str(spp), "--out", out]
+    for o in options:
+        cmd += ["--opt", o]
+    result = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert result.returncode == 0, result.stdout[-2000:]
+    return film_io.read_film(out), result.stdout
+
+
+def test_cpp_hipvcm_matches_ctypes_binding(etx, golden_dir, tmp_path, bluenoise_64spp):
+    snapshot = os.path.join(golden_dir, "cornell_full_128.etxscene")
+    spp = 64  # scene.samples of the snapshot: VCMOptions defaults (blue noise on), the binding tabulates BNSampler itself
+    film, log = run_driver(tmp_path, snapshot, "hip-vcm", spp)
+    assert film["spp"] == spp and "VCM (HIP gfx950)" in log
+    snap = etx.SceneSnapshot(snapshot)
+    integ = etx.HIPVCM(snap)
+    integ.bluenoise_tables = {6: bluenoise_64spp}
+    integ.render()
+    cam, light, res = (integ.film(getattr(etx.api, "LAYER_" + n)) for n in ("CAMERA", "LIGHT", "RESULT"))
+    integ.context.close()
+    # same iterations, same kernels: the films differ only by the order of the float atomics
+    np.testing.assert_allclose(film["camera"][..., :3], cam[..., :3], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(film["light"][..., :3], light[..., :3], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(film["result"][..., :3], res[..., :3], rtol=2e-4, atol=4e-5)  # Film::layer(Result) of the reference
+
+
+def test_cpp_hip_path_tracer_matches_ctypes_binding(etx, golden_dir, tmp_path):
+    snapshot = os.path.join(golden_dir, "cornell_rough_128.etxscene")
+    film, log = run_driver(tmp_path, snapshot, "hip-pt", 16, "bn=false")
+    assert "Path Tracing (HIP gfx950)" in log
+    snap = etx.SceneSnapshot(snapshot)
+    snap.samples = 16
+    integ = etx.HIPPathTracing(snap)
+    integ.options()["bn"] = False
+    integ.render()
+    layers = {n: integ.film(getattr(etx.api, "LAYER_" + n.upper())) for n in ("camera", "normal", "albedo")}
+    integ.context.close()
+    np.testing.assert_allclose(film["camera"][..., :3], layers["camera"][..., :3], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(film["normal"][..., :3], layers["normal"][..., :3], rtol=0, atol=1e-5)  # Film::layer(Normals) = n * 0.5 + 0.5
+    np.testing.assert_allclose(film["albedo"][..., :3], layers["albedo"][..., :3], rtol=2e-4, atol=2e-5)
+    assert np.abs(film["light"][..., :3]).max() == 0.0
+
+
+def test_cpp_binding_spectral_scene_uploads_the_observer(etx, golden_dir, tmp_path, cie_observer):
+    snapshot = os.path.join(golden_dir, "cornell_diamond_128.etxscene")
+    film, _ = run_driver(tmp_path, snapshot, "hip-vcm", 8, "vcm-blue_noise=false")
+    snap = etx.SceneSnapshot(snapshot)
+    snap.samples = 8
+    integ = etx.HIPVCM(snap)
+    integ.options()["vcm-blue_noise"] = False
+    integ.cie_table = cie_observer
+    integ.render()
+    cam = integ.film(etx.api.LAYER_CAMERA)
+    integ.context.close()
+    np.testing.assert_allclose(film["camera"][..., :3], cam[..., :3], rtol=5e-4, atol=5e-5)

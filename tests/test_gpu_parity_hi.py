@@ -1,0 +1,116 @@
+"""GPU (-m gpu): parity at north_star's tolerance (pixel RMSE < 1e-3) against HIGH-sample-count films of the reference.
+
+The 64 / 256-spp goldens of test_gpu_parity.py leave 1-3 % of noise in their own means, so their thresholds are noise
+allowances. Here the reference's CPUVCM / CPUPathTracing rendered 4096 samples per pixel at 128 x 128
+(tests/golden/hi/*.npz, oracle/gen_golden_hi.py) and the device renders THE SAME iteration set (the VCM merge radius depends
+on the iteration index, vcm_cpu.cxx:100-113) as two interleaved halves (even / odd iterations, two contexts). The halves
+are independent estimates, so their difference measures the Monte-Carlo noise that is still in a 4096-spp film
+(sigma^2 = mean((A - B)^2) / 4 per block); the reference's film carries the same amount. What is asserted:
+  * block-8 RMSE against the reference with that noise removed: sqrt(max(0, MSE - 2 sigma^2)) < 1e-3  (the estimator
+    difference north_star bounds); the raw block-8 RMSE is printed and bounded by 1e-3 + the noise
+  * per-channel relative difference of the image mean     < 0.3 %
+  * per-pixel relative bias (4 x 4 block means, |d| / (ref + 0.02)): 99th percentile asserted
+Light and camera layers are also compared separately for VCM.
+The `full` scene is additionally compared with the DECORRELATED oracle (ETX_ORACLE_DECORRELATE=1): the device re-keys the
+camera stream (kernels_vcm.hip k_camera_generate), the claim of DESIGN.md 4 is that this is the estimator it matches.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SPP = 4096
+
+
+def block_mean(img, b):
+    h, w = img.shape[:2]
+    return img[..., :3].reshape(h // b, b, w // b, b, 3).mean(axis=(1, 3))
+
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def load_hi(golden_dir, name):
+    path = os.path.join(golden_dir, "hi", name)
+    assert os.path.exists(path), "%s is missing: run oracle/gen_golden_hi.py in the build container" % path
+    golden = np.load(path)
+    assert int(golden["spp"]) == SPP
+    return golden
+
+
+def compare(halves, reference, label, rmse_limit=1.0e-3, mean_limit=3.0e-3, bias_p99_limit=0.05):
+    a, b = halves
+    ok = np.isfinite(reference).all(axis=2)  # the reference's release build lets an occasional NaN sample through
+    assert ok.mean() > 0.999, label
+    reference = np.where(ok[..., None], reference, 0.0)
+    a = np.where(ok[..., None], a[..., :3], 0.0).astype(np.float64)
+    b = np.where(ok[..., None], b[..., :3], 0.0).astype(np.float64)
+    device = 0.5 * (a + b)
+    mse = float(np.mean((block_mean(device, 8) - block_mean(reference, 8)) ** 2))
+    noise = float(np.mean((block_mean(a, 8) - block_mean(b, 8)) ** 2)) / 4.0  # variance of the 4096-spp block means
+    excess = float(np.sqrt(max(0.0, mse - 2.0 * noise)))
+    ref_mean = reference.mean(axis=(0, 1))
+    rel_mean = (device.mean(axis=(0, 1)) - ref_mean) / np.maximum(ref_mean, 1e-6)
+    d4, r4 = block_mean(device, 4), block_mean(reference, 4)
+    bias = np.abs(d4 - r4).sum(axis=2) / (r4.sum(axis=2) + 0.02)
+    p99 = float(np.percentile(bias, 99.0))
+    print("%-32s block-8 RMSE %.2e (noise of one film %.2e, excess %.2e)  rel mean %s  bias p99 %.3f" % (label, np.sqrt(mse), np.sqrt(noise), excess, np.round(rel_mean, 4), p99))
+    assert excess < rmse_limit, (label, excess)
+    assert np.sqrt(mse) < rmse_limit + 2.0 * np.sqrt(noise), (label, np.sqrt(mse))
+    assert np.abs(rel_mean).max() < mean_limit, (label, rel_mean)
+    assert p99 < bias_p99_limit, (label, p99)
+
+
+def render_halves(etx, golden_dir, flavour, cie, integrator_class, options):
+    """Iterations 0, 2, 4, ... and 1, 3, 5, ... of the 4096-iteration set: two contexts, etx_hip_begin(first, stride 2)."""
+    films = []
+    for first in (0, 1):
+        snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_%s_128.etxscene" % flavour))
+        snap.samples = SPP
+        integ = integrator_class(snap, first_iteration=first, iteration_stride=2)
+        integ.options().update(options)
+        integ.cie_table = cie
+        integ.render()
+        cam, light = integ.film(etx.api.LAYER_CAMERA), integ.film(etx.api.LAYER_LIGHT)
+        stats = integ.status()
+        integ.context.close()
+        assert stats.completed_iterations == SPP // 2 and stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
+        assert np.isfinite(cam).all() and np.isfinite(light).all()
+        films.append((cam, light))
+    return films
+
+
+def render_vcm(etx, golden_dir, flavour, cie):
+    return render_halves(etx, golden_dir, flavour, cie, etx.HIPVCM, {"vcm-blue_noise": False})
+
+
+def render_pt(etx, golden_dir, flavour, cie):
+    return render_halves(etx, golden_dir, flavour, cie, etx.HIPPathTracing, {"bn": False})
+
+
+SPECTRAL = ("gems", "diamond", "spectral")
+
+
+@pytest.mark.parametrize("flavour", ["classic", "full", "rough", "glass", "gems", "cloud", "sss"])
+def test_vcm_matches_reference_at_4096_spp(etx, golden_dir, cie_observer, flavour):
+    golden = load_hi(golden_dir, "cornell_%s_128_vcm_%d.npz" % (flavour, SPP))
+    (cam_a, light_a), (cam_b, light_b) = render_vcm(etx, golden_dir, flavour, cie_observer if flavour in SPECTRAL else None)
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " vcm camera+light")
+    compare((light_a, light_b), golden["light"], flavour + " vcm light", mean_limit=1.0e-2, bias_p99_limit=0.2)
+    compare((cam_a, cam_b), golden["camera"], flavour + " vcm camera")
+
+
+def test_vcm_full_matches_the_decorrelated_reference(etx, golden_dir):
+    golden = load_hi(golden_dir, "cornell_full_128_vcm_%d_decorrelated.npz" % SPP)
+    (cam_a, light_a), (cam_b, light_b) = render_vcm(etx, golden_dir, "full", None)
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "full vcm vs decorrelated oracle", mean_limit=2.0e-3)
+
+
+@pytest.mark.parametrize("flavour", ["classic", "full", "rough", "glass", "gems", "cloud", "sss"])
+def test_pt_matches_reference_at_4096_spp(etx, golden_dir, cie_observer, flavour):
+    golden = load_hi(golden_dir, "cornell_%s_128_pt_%d.npz" % (flavour, SPP))
+    (cam_a, _), (cam_b, _) = render_pt(etx, golden_dir, flavour, cie_observer if flavour in SPECTRAL else None)
+    compare((cam_a, cam_b), golden["camera"], flavour + " pt camera")

@@ -86,3 +86,20 @@ def test_create_without_gpu_fails_loudly(etx):
     with pytest.raises(api.EtxHipError) as e:
         api.Context(0)
     assert e.value.code == -2  # ETX_HIP_ERROR_NO_DEVICE: no CPU fallback exists
+
+
+def test_cpp_binding_fails_loudly_without_a_device():
+    """integration/etx_hip_integrators.hxx compiled into the reference-based driver: without a gfx950 device etx_hip_create
+    fails, HIPVCM::run() logs the error and stays Stopped (the reference's convention), the driver exits with code 6 - it
+    never falls back to the CPU integrator."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the binding is exercised by tests/test_gpu_binding.py")
+    oracle = os.path.join(ROOT, "oracle", "_ref", "etx_oracle")
+    if not os.path.exists(oracle):
+        pytest.skip("oracle/_ref/etx_oracle is not built (needs /root/reference)")
+    result = subprocess.run([oracle, "--load-snapshot", os.path.join(ROOT, "tests", "golden", "cornell_classic_128.etxscene"), "--integrator", "hip-vcm", "--spp", "2"],
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert result.returncode == 6, result.stdout[-1000:]
+    assert "no HIP device available" in result.stdout
