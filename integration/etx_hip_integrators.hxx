@@ -259,6 +259,25 @@ struct HIPIntegratorBase : public Integrator {
       hip_report_error(lib.last_error(ctx));
       return;
     }
+#if defined(ETX_FILM_HAS_MERGE_ITERATION)
+    // integration/film_merge_iteration.patch applied: one bulk call, no per-pixel accumulate
+    if (writes_light_image()) {
+      light.resize(pixels);
+      if (lib.read_film(ctx, ETX_HIP_LAYER_LIGHT, &light[0].x, pixels * sizeof(float4)) != ETX_HIP_OK) {
+        hip_report_error(lib.last_error(ctx));
+        return;
+      }
+    }
+    if (aovs) {
+      for (size_t i = 0; i < pixels; ++i)  // Film::layer(Normals) = n * 0.5 + 0.5: back to the stored normal
+        normal[i] = {normal[i].x * 2.0f - 1.0f, normal[i].y * 2.0f - 1.0f, normal[i].z * 2.0f - 1.0f, 0.0f};
+    }
+    film.merge_iteration(camera.data(), writes_light_image() ? light.data() : nullptr, aovs ? normal.data() : nullptr, aovs ? albedo.data() : nullptr, _status.completed_iterations);
+    camera_updated = true;
+    light_updated = writes_light_image();
+    published = _status.completed_iterations;
+    return;
+#endif
     film.clear(Film::ClearCameraData | (writes_light_image() ? uint32_t(Film::ClearLightData) : 0u));
     // rows of the device film are the Film's storage rows: storage row r holds pixel y = H - 1 - r (film.cxx:189)
     for (uint32_t row = 0; row < dim.y; ++row) {

@@ -103,3 +103,28 @@ def test_cpp_binding_fails_loudly_without_a_device():
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert result.returncode == 6, result.stdout[-1000:]
     assert "no HIP device available" in result.stdout
+
+
+def test_film_merge_iteration_patch_applies_and_compiles(tmp_path):
+    """integration/film_merge_iteration.patch (the additive bulk film interface) against a scratch copy of the
+    two reference files: it applies cleanly, the patched film.cxx compiles, and the binding compiles against the patched
+    header with ETX_FILM_HAS_MERGE_ITERATION (its bulk publish path)."""
+    import shutil
+    import subprocess
+    ref = "/root/reference"
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not (os.path.isdir(os.path.join(ref, "sources", "etx")) and os.path.exists(cxx)):
+        pytest.skip("needs /root/reference (build container)")
+    host = tmp_path / "sources" / "etx" / "render" / "host"
+    host.mkdir(parents=True)
+    for name in ("film.hxx", "film.cxx"):
+        shutil.copy(os.path.join(ref, "sources", "etx", "render", "host", name), host / name)
+    patch = os.path.join(ROOT, "integration", "film_merge_iteration.patch")
+    subprocess.check_call(["patch", "-p1", "-s", "-i", patch], cwd=tmp_path)
+    t = os.path.join(ref, "thirdparty")
+    flags = ["-std=c++23", "-include", "atomic", "-include", "map", "-DNDEBUG", "-D_stricmp=strcasecmp", "-DETX_LIBRARY=1", "-w", "-fsyntax-only", "-I%s" % (tmp_path / "sources"), "-I%s/sources" % ref, "-I%s" % t,
+             "-I%s/enkits" % t, "-I%s/bluenoise" % t, "-I%s/json" % t, "-I%s" % os.path.join(ROOT, "include"), "-I%s" % os.path.join(ROOT, "integration")]
+    subprocess.check_call([cxx] + flags + [str(host / "film.cxx")])
+    tu = tmp_path / "binding.cxx"
+    tu.write_text("#define ETX_FILM_HAS_MERGE_ITERATION 1\n#include <etx/rt/rt.hxx>\n#include <etx_hip_integrators.hxx>\nint main() { return 0; }\n")
+    subprocess.check_call([cxx] + flags + [str(tu)])
