@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene",
     "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
     "etx_hip_read_film", "etx_hip_stats", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
-    "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh",
+    "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
 )
 
 
@@ -150,6 +150,7 @@ class Library:
         L.etx_hip_trace_rays_device.argtypes = [vp, vp, vp, u64, vp, u32, ctypes.POINTER(ctypes.c_double)]
         L.etx_hip_kat.argtypes = [vp, i32, vp, u64, vp]
         L.etx_hip_host_check_bvh.argtypes = [vp, ctypes.POINTER(u32 * 4)]
+        L.etx_hip_host_bvh_stats.argtypes = [vp, vp, u64, ctypes.POINTER(u64 * 4)]
 
     @classmethod
     def get(cls):
@@ -269,7 +270,16 @@ def host_check_bvh(snapshot, library=None):
     library = library or Library.get()
     info = (ctypes.c_uint32 * 4)()
     rc = library.lib.etx_hip_host_check_bvh(snapshot.scene_address, ctypes.byref(info))
-    return rc, {"nodes": info[0], "triangles": info[1], "depth": info[2], "bytes": info[3]}
+    return rc, {"nodes": info[0], "triangles": info[1], "depth": info[2] & 0xffff, "stack_need": info[2] >> 16, "bytes": info[3]}
+
+
+def host_bvh_stats(snapshot, rays, library=None):
+    """Host-only: the work the traversal does for `rays` (n x 8 float32): node visits, triangle tests, hits, deepest stack use."""
+    library = library or Library.get()
+    rays = np.ascontiguousarray(rays, dtype=np.float32)
+    out = (ctypes.c_uint64 * 4)()
+    rc = library.lib.etx_hip_host_bvh_stats(snapshot.scene_address, rays.ctypes.data, rays.shape[0], ctypes.byref(out))
+    return rc, {"node_visits": out[0], "triangle_tests": out[1], "hits": out[2], "max_stack": out[3]}
 
 
 def comm_unique_id(library=None):

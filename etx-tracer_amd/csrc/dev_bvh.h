@@ -5,8 +5,8 @@
 //   transmittance = Raytracing::trace_transmittance rt.cxx:468-579 (Boundary surfaces are transparent and switch
 //                   the medium by the side of geo_n; anything else occludes; media attenuate the segments)
 // Traversal state: a per-lane stack that lives in LDS, laid out [depth][lane] so a wavefront's pushes/pops hit 64
-// consecutive banks; nodes are 64-byte two-child packets (dev_scene.h). The node/triangle arrays are passed as
-// template-typed pointers so the same code runs from HBM/L2 or from an LDS-staged copy of the tree.
+// consecutive banks; nodes are 128-byte four-child packets (dev_scene.h Bvh4Node), the top of the tree staged in LDS
+// by the traversal kernels (BvhNodes below), the rest read through L2.
 #pragma once
 
 #include "dev_scene.h"
@@ -176,9 +176,39 @@ ETX_DEV Hit bvh_flat_closest(const DScene& scene, Tris, const RayQ& ray, uint32_
   return flat_resolve(scene, best_prim, best_a, best_b, best_t);
 }
 
-// Closest accepted hit in [tmin, tmax]. `Nodes`/`Tris` are pointer types (global or LDS address space).
-template <class Nodes, class Tris>
-ETX_DEV Hit bvh_closest(const DScene& scene, Nodes nodes, Tris tris, int32_t root, const LaneStack& stack, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags,
+// Where the traversal reads its nodes: the first `lds_count` nodes (breadth-first numbering = the top of the tree) from the
+// workgroup's LDS copy when the kernel staged one (north_star: "LDS-staged BVH node packets"), the rest from global
+// memory (L2). 8 float4 per node.
+struct BvhNodes {
+  const float4* global;
+  const float4* lds;
+  uint32_t lds_count;
+};
+
+ETX_DEV BvhNodes global_nodes(const DScene& scene) {
+  return {reinterpret_cast<const float4*>(scene.bvh_nodes), nullptr, 0u};
+}
+
+// Cooperative copy of the top of the tree into LDS (call from workgroup-uniform control flow, ends with a barrier).
+ETX_DEV BvhNodes stage_nodes(const DScene& scene, float4* lds, uint32_t capacity_nodes) {
+  const uint32_t count = min(scene.bvh_node_count, capacity_nodes);
+  const float4* src = reinterpret_cast<const float4*>(scene.bvh_nodes);
+  for (uint32_t i = threadIdx.x; i < count * 8u; i += blockDim.x)
+    lds[i] = src[i];
+  __syncthreads();
+  return {src, lds, count};
+}
+
+ETX_DEV void sort_pair(float& ta, int32_t& ca, float& tb, int32_t& cb) {  // compare-exchange, ascending t
+  const bool swap = tb < ta;
+  const float t0 = swap ? tb : ta, t1 = swap ? ta : tb;
+  const int32_t c0 = swap ? cb : ca, c1 = swap ? ca : cb;
+  ta = t0, tb = t1, ca = c0, cb = c1;
+}
+
+// Closest accepted hit in [tmin, tmax]: BVH4, per-lane stack in LDS, near child first.
+template <class Tris>
+ETX_DEV Hit bvh_closest(const DScene& scene, const BvhNodes& nodes, Tris tris, int32_t root, const LaneStack& stack, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags,
   uint32_t material_filter = kInvalid) {
   if (scene.bvh_flat)
     return bvh_flat_closest(scene, tris, ray, alpha_seed, out_flags, material_filter);
@@ -187,30 +217,58 @@ ETX_DEV Hit bvh_closest(const DScene& scene, Nodes nodes, Tris tris, int32_t roo
   const f3 inv_d = {__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)};
   uint32_t sp = 0;
   int32_t cur = root;
-  const int32_t kDone = 0x7fffffff;
+  const int32_t kDone = kBvhEmptyChild;
   if (scene.bvh_tri_count == 0u)
     cur = kDone;
+  // "while-while" (Aila & Laine): all lanes of the wave walk inner nodes until each of them stands on a leaf (or is done),
+  // then all of them intersect their leaves - the leaf code runs with most lanes active instead of being interleaved with
+  // the node code of the other lanes.
   while (cur != kDone) {
-    if (cur >= 0) {
-      const float4 a = nodes[cur].lo0_hi0x;
-      const float4 b = nodes[cur].hi0yz_lo1xy;
-      const float4 c = nodes[cur].lo1z_hi1;
-      const int32_t c0 = nodes[cur].child0, c1 = nodes[cur].child1;
-      float t0 = slab(f3{a.x, a.y, a.z}, f3{a.w, b.x, b.y}, ray.o, inv_d, ray.tmin, best.t);
-      float t1 = slab(f3{b.z, b.w, c.x}, f3{c.y, c.z, c.w}, ray.o, inv_d, ray.tmin, best.t);
-      bool h0 = t0 < kMaxFloat, h1 = t1 < kMaxFloat;
-      if (h0 && h1) {
-        bool first0 = t0 <= t1;
-        stack.push(sp, first0 ? c1 : c0);
-        cur = first0 ? c0 : c1;
-      } else if (h0) {
-        cur = c0;
-      } else if (h1) {
-        cur = c1;
+    while ((cur >= 0) && (cur != kDone)) {
+      float4 lox, loy, loz, hix, hiy, hiz;
+      int4 children;
+      if (uint32_t(cur) < nodes.lds_count) {
+        const float4* n = nodes.lds + uint32_t(cur) * 8u;
+        lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5];
+        const float4 c = n[6];
+        children = make_int4(__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
       } else {
-        cur = sp ? stack.pop(sp) : kDone;
+        const float4* n = nodes.global + uint32_t(cur) * 8u;
+        lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5];
+        const float4 c = n[6];
+        children = make_int4(__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
       }
-    } else {
+      // four slab tests; an unused slot holds lo = +inf, hi = -inf and is masked by its child code
+      float t0 = slab(f3{lox.x, loy.x, loz.x}, f3{hix.x, hiy.x, hiz.x}, ray.o, inv_d, ray.tmin, best.t);
+      float t1 = slab(f3{lox.y, loy.y, loz.y}, f3{hix.y, hiy.y, hiz.y}, ray.o, inv_d, ray.tmin, best.t);
+      float t2 = slab(f3{lox.z, loy.z, loz.z}, f3{hix.z, hiy.z, hiz.z}, ray.o, inv_d, ray.tmin, best.t);
+      float t3 = slab(f3{lox.w, loy.w, loz.w}, f3{hix.w, hiy.w, hiz.w}, ray.o, inv_d, ray.tmin, best.t);
+      int32_t c0 = children.x, c1 = children.y, c2 = children.z, c3 = children.w;
+      t0 = (c0 == kBvhEmptyChild) ? kMaxFloat : t0;
+      t1 = (c1 == kBvhEmptyChild) ? kMaxFloat : t1;
+      t2 = (c2 == kBvhEmptyChild) ? kMaxFloat : t2;
+      t3 = (c3 == kBvhEmptyChild) ? kMaxFloat : t3;
+      // sorting network of four (t, child) pairs; misses (t = max) end up last
+      sort_pair(t0, c0, t1, c1);
+      sort_pair(t2, c2, t3, c3);
+      sort_pair(t0, c0, t2, c2);
+      sort_pair(t1, c1, t3, c3);
+      sort_pair(t1, c1, t2, c2);
+      if (t0 == kMaxFloat) {
+        cur = sp ? stack.pop(sp) : kDone;
+      } else {  // farthest first, so that the nearest of the rest is popped first
+        if (t3 < kMaxFloat)
+          stack.push(sp, c3);
+        if (t2 < kMaxFloat)
+          stack.push(sp, c2);
+        if (t1 < kMaxFloat)
+          stack.push(sp, c1);
+        cur = c0;
+      }
+    }
+    if (cur == kDone)
+      break;
+    {
       uint32_t leaf = uint32_t(~cur);
       uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
       for (uint32_t i = first; i < first + count; ++i) {
@@ -345,8 +403,8 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
 // The reference collects up to 63 Boundary hits in one traversal and sorts them; here the boundaries are visited in
 // order by restarting the closest-hit search behind each one (same products, no per-lane hit buffer).
 // rays_traced counts the traversals (statistics).
-template <class Nodes, class Tris>
-ETX_DEV f3 bvh_transmittance(const DScene& scene, Nodes nodes, Tris tris, int32_t root, const LaneStack& stack, const f3& p0, const f3& p1, uint32_t medium_index,
+template <class Tris>
+ETX_DEV f3 bvh_transmittance(const DScene& scene, const BvhNodes& nodes, Tris tris, int32_t root, const LaneStack& stack, const f3& p0, const f3& p1, uint32_t medium_index,
   float wavelength, uint32_t& alpha_seed) {
   f3 direction = p1 - p0;
   float t_max = dot(direction, direction);

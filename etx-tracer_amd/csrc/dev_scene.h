@@ -22,6 +22,19 @@ struct __attribute__((aligned(16))) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be one 64-byte line");
 
+// BVH4 node as the device traverses it: the host collapses the binned-SAH BVH2 (above: the builder's intermediate form)
+// into four-wide nodes, children's boxes stored component-wise so that one node fetch (8 x 16 B) decides four children
+// with four-wide slab arithmetic. Half the node visits and dependent fetches of the BVH2; nodes are numbered breadth
+// first, so the first N nodes are the top of the tree - the part the traversal kernels stage in LDS (dev_bvh.h).
+// child: >= 0 inner node index, < 0 leaf (~child = (first_triangle << 3) | (count - 1)), kBvhEmptyChild = unused slot.
+struct __attribute__((aligned(16))) Bvh4Node {
+  float4 lo_x, lo_y, lo_z, hi_x, hi_y, hi_z;
+  int32_t child[4];
+  uint32_t pad[4];
+};
+static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node is two 64-byte lines");
+constexpr int32_t kBvhEmptyChild = 0x7fffffff;
+
 // Triangle in traversal order: v0 + two edges, original index, filter flags.
 struct __attribute__((aligned(16))) BvhTri {
   float4 v0_index;  // v0.xyz, triangle index (u32 bits)
@@ -115,7 +128,7 @@ struct DScene {
   const float4* cie_xyz;         // spectrum::spectral_xyz(i), i = wavelength - cie_first (etx_hip_upload_cie_table)
   const DImage* images;
   const DMedium* mediums;
-  const BvhNode* bvh_nodes;
+  const Bvh4Node* bvh_nodes;
   const BvhTri* bvh_tris;
   const FlatPrim* flat_prims;      // bvh_flat scenes: pre-transformed primitives of the sweep
   const FlatPrimInfo* flat_info;   // per primitive
@@ -125,6 +138,8 @@ struct DScene {
   uint32_t vertex_count, triangle_count, material_count, emitter_count, emitter_dist_count, spectrum_count, image_count, medium_count;
   uint32_t bvh_node_count, bvh_tri_count, flat_prim_count, pad_flat;
   int32_t bvh_root;  // child encoding (a single leaf scene has a negative root)
+  uint32_t bvh_depth; // levels of inner BVH4 nodes
+  uint32_t bvh_stack_need;  // stack entries the traversal can need (host bound over the tree): selects the kernel variant
   uint32_t bvh_flat; // != 0: so few triangles that the wave-uniform linear sweep beats the tree (dev_bvh.h)
   float emitter_dist_total;
   uint32_t env_emitters[ETX_ABI_MAX_ENVIRONMENT_EMITTERS];

@@ -62,7 +62,7 @@ ETX_DEV bool sss_gather_rw(const DScene& scene, const LaneStack& stack, const Is
     float max_t = scattering_distance > 0.0f ? (-logf(1.0f - smp.next()) / scattering_distance) : kMaxFloat;
     if ((i == 0u) && (max_t <= kRayEpsilon))
       return false;
-    const Hit h = bvh_closest(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, RayQ{ray_o, kRayEpsilon, ray_d, max_t}, alpha_seed, nullptr, in.material);
+    const Hit h = bvh_closest(scene, global_nodes(scene), scene.bvh_tris, scene.bvh_root, stack, RayQ{ray_o, kRayEpsilon, ray_d, max_t}, alpha_seed, nullptr, in.material);
     const bool found = h.tri != kInvalid;
     if (found)
       max_t = h.t;

@@ -182,7 +182,7 @@ struct TraceCtx {  // what an inline traversal needs
 
 ETX_DEV f3 trace_transmittance(TraceCtx& tc, const f3& p0, const f3& p1, uint32_t medium, float wavelength) {
   const DScene& s = *tc.scene;
-  return bvh_transmittance(s, s.bvh_nodes, s.bvh_tris, s.bvh_root, tc.stack, p0, p1, medium, wavelength, tc.alpha_seed);
+  return bvh_transmittance(s, global_nodes(s), s.bvh_tris, s.bvh_root, tc.stack, p0, p1, medium, wavelength, tc.alpha_seed);
 }
 
 // A connection whose visibility is still unknown: the shade / connect kernels evaluate everything but the

@@ -1271,12 +1271,152 @@ int etx_hip_host_check_bvh(const etx_abi_scene* scene, uint32_t out_info[4]) {
   }
   for (uint32_t i = 0; ok && (i < n); ++i)
     ok = seen[i] == 1u;
-  ok = ok && (bvh.depth + 2 <= etxd::kStackDepth);
-  out_info[0] = uint32_t(bvh.nodes.size());
+  // the BVH4 the device traverses: the same invariants (every triangle in exactly one leaf, children inside their boxes),
+  // children numbered breadth first (child index > parent index)
+  std::vector<uint32_t> seen4(n, 0u);
+  struct Item4 {
+    int32_t ref;
+    f3 lo, hi;
+  };
+  std::vector<Item4> stack4;
+  if (n > 0)
+    stack4.push_back({bvh.root4, mk3(-kMaxFloat), mk3(kMaxFloat)});
+  while (ok && (stack4.empty() == false)) {
+    const Item4 it = stack4.back();
+    stack4.pop_back();
+    if (it.ref >= 0) {
+      if (size_t(it.ref) >= bvh.nodes4.size()) {
+        ok = false;
+        break;
+      }
+      const Bvh4Node& nd = bvh.nodes4[it.ref];
+      const float* lo[3] = {&nd.lo_x.x, &nd.lo_y.x, &nd.lo_z.x};
+      const float* hi[3] = {&nd.hi_x.x, &nd.hi_y.x, &nd.hi_z.x};
+      for (int k = 0; k < 4; ++k) {
+        if (nd.child[k] == kBvhEmptyChild)
+          continue;
+        ok = ok && ((nd.child[k] < 0) || (nd.child[k] > it.ref));
+        const f3 clo = {lo[0][k], lo[1][k], lo[2][k]}, chi = {hi[0][k], hi[1][k], hi[2][k]};
+        ok = ok && (clo.x >= it.lo.x) && (clo.y >= it.lo.y) && (clo.z >= it.lo.z) && (chi.x <= it.hi.x) && (chi.y <= it.hi.y) && (chi.z <= it.hi.z);
+        stack4.push_back({nd.child[k], clo, chi});
+      }
+    } else {
+      const uint32_t leaf = uint32_t(~it.ref), first = leaf >> 3, count = (leaf & 7u) + 1u;
+      for (uint32_t i = first; ok && (i < first + count); ++i) {
+        if (i >= n) {
+          ok = false;
+          break;
+        }
+        const uint32_t ti = bits(bvh.tris[i].v0_index.w);
+        if (ti >= n) {
+          ok = false;
+          break;
+        }
+        seen4[ti]++;
+        for (int k = 0; k < 3; ++k) {
+          const etx_abi_float3& p = vertices[triangles[ti].i[k]].pos;
+          ok = ok && (p.x >= it.lo.x) && (p.y >= it.lo.y) && (p.z >= it.lo.z) && (p.x <= it.hi.x) && (p.y <= it.hi.y) && (p.z <= it.hi.z);
+        }
+      }
+    }
+  }
+  for (uint32_t i = 0; ok && (i < n); ++i)
+    ok = seen4[i] == 1u;
+  ok = ok && (bvh.stack_need <= etxd::kStackDepth);
+  out_info[0] = uint32_t(bvh.nodes4.size());
   out_info[1] = uint32_t(bvh.tris.size());
-  out_info[2] = bvh.depth;
-  out_info[3] = uint32_t(bvh.nodes.size() * sizeof(BvhNode) + bvh.tris.size() * sizeof(BvhTri));
+  out_info[2] = bvh.depth4 | (bvh.stack_need << 16u);
+  out_info[3] = uint32_t(bvh.nodes4.size() * sizeof(Bvh4Node) + bvh.tris.size() * sizeof(BvhTri));
   return ok ? ETX_HIP_OK : ETX_HIP_ERROR_INVALID_ARGUMENT;
+}
+
+// Host-only: walks the BVH4 exactly as dev_bvh.h bvh_closest does (near child first, three pushes per node at most) for
+// `count` rays {ox,oy,oz,tmin,dx,dy,dz,tmax} and reports the work: out[0] node visits, out[1] triangle tests, out[2] rays
+// that hit, out[3] deepest stack use. Used by tests (stack bound) and to reason about the traversal kernel's cost.
+int etx_hip_host_bvh_stats(const etx_abi_scene* scene, const float* rays_8f, uint64_t count, uint64_t out[4]) {
+  if ((scene == nullptr) || (rays_8f == nullptr) || (out == nullptr))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  etxh::HostBvh bvh;
+  etxh::build_bvh(scene, bvh);
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (bvh.tris.empty())
+    return ETX_HIP_OK;
+  std::vector<int32_t> stack(256);
+  for (uint64_t r = 0; r < count; ++r) {
+    const float* q = rays_8f + 8 * r;
+    const f3 o = {q[0], q[1], q[2]}, d = {q[4], q[5], q[6]};
+    const float tmin = q[3];
+    float best = q[7];
+    bool hit = false;
+    const f3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    size_t sp = 0;
+    int32_t cur = bvh.root4;
+    while (cur != kBvhEmptyChild) {
+      if (cur >= 0) {
+        out[0]++;
+        const Bvh4Node& nd = bvh.nodes4[cur];
+        const float* lo[3] = {&nd.lo_x.x, &nd.lo_y.x, &nd.lo_z.x};
+        const float* hi[3] = {&nd.hi_x.x, &nd.hi_y.x, &nd.hi_z.x};
+        float t[4];
+        int32_t c[4];
+        for (int k = 0; k < 4; ++k) {
+          c[k] = nd.child[k];
+          t[k] = kMaxFloat;
+          if (c[k] == kBvhEmptyChild)
+            continue;
+          float t_enter = tmin, t_exit = best;
+          const float oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+          for (int a = 0; a < 3; ++a) {
+            const float t0 = (lo[a][k] - oo[a]) * ii[a], t1 = (hi[a][k] - oo[a]) * ii[a];
+            t_enter = std::max(t_enter, std::min(t0, t1));
+            t_exit = std::min(t_exit, std::max(t0, t1));
+          }
+          if (t_enter <= t_exit * 1.0000004f)
+            t[k] = t_enter;
+        }
+        for (int i = 0; i < 4; ++i)  // ascending by t (the device uses a five-comparator network: same order up to ties)
+          for (int j = i + 1; j < 4; ++j)
+            if (t[j] < t[i]) {
+              std::swap(t[i], t[j]);
+              std::swap(c[i], c[j]);
+            }
+        if (t[0] == kMaxFloat) {
+          cur = sp ? stack[--sp] : kBvhEmptyChild;
+        } else {
+          for (int k = 3; k >= 1; --k)
+            if (t[k] < kMaxFloat) {
+              if (sp == stack.size())
+                stack.resize(stack.size() * 2);
+              stack[sp++] = c[k];
+            }
+          out[3] = std::max<uint64_t>(out[3], sp);
+          cur = c[0];
+        }
+      } else {
+        const uint32_t leaf = uint32_t(~cur), first = leaf >> 3, n = (leaf & 7u) + 1u;
+        for (uint32_t i = first; i < first + n; ++i) {
+          out[1]++;
+          const BvhTri& tr = bvh.tris[i];
+          const f3 e1 = {tr.e1_flags.x, tr.e1_flags.y, tr.e1_flags.z}, e2 = {tr.e2_mat.x, tr.e2_mat.y, tr.e2_mat.z};
+          const f3 p = cross(d, e2);
+          const float det = dot(e1, p);
+          if (det == 0.0f)
+            continue;
+          const f3 s = o - f3{tr.v0_index.x, tr.v0_index.y, tr.v0_index.z};
+          const float u = dot(s, p) / det;
+          const f3 qv = cross(s, e1);
+          const float v = dot(d, qv) / det, tt = dot(e2, qv) / det;
+          if ((u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f) && (tt >= tmin) && (tt <= best)) {
+            best = tt;
+            hit = true;
+          }
+        }
+        cur = sp ? stack[--sp] : kBvhEmptyChild;
+      }
+    }
+    out[2] += hit ? 1u : 0u;
+  }
+  return ETX_HIP_OK;
 }
 
 }  // extern "C"

@@ -63,6 +63,7 @@ struct Builder {
   std::vector<Prim> prims;
   std::vector<TmpNode> nodes;
   uint32_t max_depth = 0;
+  float traversal_cost = 1.0f;
 
   static float half_area(const f3& mn, const f3& mx) {
     f3 d = mx - mn;
@@ -122,9 +123,10 @@ struct Builder {
     }
     uint32_t mid = first + count / 2;
     if (best_axis >= 0) {
-      // SAH termination: traversal cost 1, intersection cost 1 (relative)
+      // SAH termination: a node visit of the device traversal (fetch 128 B, four slab tests, sort, stack traffic) costs
+      // about as much as `traversal_cost` triangle tests; measured on the gems scene
       float leaf_cost = half_area(mn, mx) * float(count);
-      if ((count <= kMaxLeaf) && (best_cost + half_area(mn, mx) >= leaf_cost))
+      if ((count <= kMaxLeaf) && (best_cost + traversal_cost * half_area(mn, mx) >= leaf_cost))
         return index;
       float lo = axis(cmn, best_axis), hi = axis(cmx, best_axis);
       float scale = float(kBins) / (hi - lo);
@@ -275,9 +277,12 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
   out = {};
   if (n == 0) {
     out.root = ~int32_t(0);
+    out.root4 = ~int32_t(0);
     return;
   }
   Builder b;
+  if (const char* e = getenv("ETX_HIP_BVH_TRAVERSAL_COST"))
+    b.traversal_cost = float(atof(e));
   b.prims.resize(n);
   for (uint32_t i = 0; i < n; ++i) {
     f3 p0 = a3(vertices[triangles[i].i[0]].pos), p1 = a3(vertices[triangles[i].i[1]].pos), p2 = a3(vertices[triangles[i].i[2]].pos);
@@ -346,6 +351,87 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
     dn.pad0 = dn.pad1 = 0;
   }
   out.root = encode(0);
+
+  // BVH2 -> BVH4 (dev_scene.h Bvh4Node): a node adopts its grandchildren, the child with the largest surface area first,
+  // until it has four children or only leaves. Nodes are numbered breadth first: the first N nodes are the top of the
+  // tree, which the traversal kernels keep in LDS.
+  out.nodes4.clear();
+  out.depth4 = 0;
+  if (b.nodes[0].count != 0) {  // the whole scene is one leaf
+    out.root4 = encode(0);
+    return;
+  }
+  struct Pending {
+    int32_t tmp_index;  // BVH2 inner node that becomes this BVH4 node
+    uint32_t level;
+  };
+  std::vector<Pending> queue;
+  queue.push_back({0, 1u});
+  out.root4 = 0;
+  for (size_t head = 0; head < queue.size(); ++head) {
+    const Pending item = queue[head];
+    out.depth4 = std::max(out.depth4, item.level);
+    int32_t kids[4] = {b.nodes[item.tmp_index].left, b.nodes[item.tmp_index].right, -1, -1};
+    uint32_t kid_count = 2;
+    while (kid_count < 4) {
+      int best = -1;
+      float best_area = -1.0f;
+      for (uint32_t k = 0; k < kid_count; ++k) {
+        const auto& kn = b.nodes[kids[k]];
+        if (kn.count != 0)
+          continue;  // leaf
+        const float area = Builder::half_area(kn.bmin, kn.bmax);
+        if (area > best_area)
+          best_area = area, best = int(k);
+      }
+      if (best < 0)
+        break;
+      const int32_t expanded = kids[best];
+      kids[best] = b.nodes[expanded].left;
+      kids[kid_count++] = b.nodes[expanded].right;
+    }
+    Bvh4Node node = {};
+    float lo[3][4], hi[3][4];
+    for (uint32_t k = 0; k < 4; ++k) {
+      for (int a = 0; a < 3; ++a)
+        lo[a][k] = kMaxFloat, hi[a][k] = -kMaxFloat;
+      node.child[k] = kBvhEmptyChild;
+      if (k >= kid_count)
+        continue;
+      const auto& kn = b.nodes[kids[k]];
+      lo[0][k] = kn.bmin.x, lo[1][k] = kn.bmin.y, lo[2][k] = kn.bmin.z;
+      hi[0][k] = kn.bmax.x, hi[1][k] = kn.bmax.y, hi[2][k] = kn.bmax.z;
+      if (kn.count != 0) {
+        node.child[k] = ~int32_t((kn.first << 3) | (kn.count - 1u));
+      } else {
+        node.child[k] = int32_t(queue.size());  // breadth-first index of the child node
+        queue.push_back({kids[k], item.level + 1u});
+      }
+    }
+    node.lo_x = make_float4(lo[0][0], lo[0][1], lo[0][2], lo[0][3]);
+    node.lo_y = make_float4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]);
+    node.lo_z = make_float4(lo[2][0], lo[2][1], lo[2][2], lo[2][3]);
+    node.hi_x = make_float4(hi[0][0], hi[0][1], hi[0][2], hi[0][3]);
+    node.hi_y = make_float4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]);
+    node.hi_z = make_float4(hi[2][0], hi[2][1], hi[2][2], hi[2][3]);
+    out.nodes4.push_back(node);
+  }
+  // Stack entries the near-child-first traversal can need: descending into one child leaves at most the other children of
+  // the node on the stack. Children are numbered after their parents, so one reverse pass resolves the recurrence.
+  std::vector<uint32_t> need(out.nodes4.size(), 0u);
+  for (size_t i = out.nodes4.size(); i-- > 0;) {
+    const Bvh4Node& nd = out.nodes4[i];
+    uint32_t kids = 0, deepest = 0;
+    for (int k = 0; k < 4; ++k) {
+      if (nd.child[k] == kBvhEmptyChild)
+        continue;
+      kids++;
+      if (nd.child[k] >= 0)
+        deepest = std::max(deepest, need[size_t(nd.child[k])]);
+    }
+    need[i] = (kids ? kids - 1u : 0u) + deepest;
+  }
+  out.stack_need = need.empty() ? 0u : need[0];
 }
 
 int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera, DeviceScene& out, std::string& error) {
@@ -586,15 +672,16 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
 
   HostBvh bvh;
   build_bvh(scene, bvh);
-  if (bvh.depth + 2 > kStackDepth) {
-    error = "BVH depth " + std::to_string(bvh.depth) + " exceeds the traversal stack";
+  // near-child-first traversal of a four-wide tree pushes at most three children per level
+  if (bvh.stack_need > kStackDepth) {
+    error = "the BVH needs " + std::to_string(bvh.stack_need) + " traversal stack entries (depth " + std::to_string(bvh.depth4) + "), the device stack holds " + std::to_string(kStackDepth);
     return ETX_HIP_ERROR_UNSUPPORTED;
   }
-  if ((rc = upload(out, bvh.nodes.data(), bvh.nodes.size(), d.bvh_nodes, error)))
+  if ((rc = upload(out, bvh.nodes4.data(), bvh.nodes4.size(), d.bvh_nodes, error)))
     return rc;
   if ((rc = upload(out, bvh.tris.data(), bvh.tris.size(), d.bvh_tris, error)))
     return rc;
-  d.bvh_node_count = uint32_t(bvh.nodes.size());
+  d.bvh_node_count = uint32_t(bvh.nodes4.size());
   d.bvh_tri_count = uint32_t(bvh.tris.size());
   if (bvh.tris.size() <= kFlatSweepMaxTriangles) {
     std::vector<BvhTri> edge_prims;
@@ -631,12 +718,14 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     if (getenv("ETX_HIP_VERBOSE"))
       fprintf(stderr, "[etx_hip] flat sweep: %zu triangles -> %zu primitives\n", bvh.tris.size(), prims.size());
   }
-  d.bvh_root = bvh.root;
+  d.bvh_root = bvh.root4;
+  d.bvh_depth = bvh.depth4;
+  d.bvh_stack_need = bvh.stack_need;
   d.bvh_flat = (bvh.tris.size() <= kFlatSweepMaxTriangles) ? 1u : 0u;
   if (const char* e = getenv("ETX_HIP_FORCE_BVH"))
     d.bvh_flat = (atoi(e) != 0) ? 0u : d.bvh_flat;
-  out.bvh_depth = bvh.depth;
-  out.bvh_bytes = bvh.nodes.size() * sizeof(BvhNode) + bvh.tris.size() * sizeof(BvhTri);
+  out.bvh_depth = bvh.depth4;
+  out.bvh_bytes = bvh.nodes4.size() * sizeof(Bvh4Node) + bvh.tris.size() * sizeof(BvhTri);
 
   d.vertex_count = uint32_t(scene->vertices.count);
   d.triangle_count = uint32_t(scene->triangles.count);

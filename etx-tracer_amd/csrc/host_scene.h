@@ -40,7 +40,11 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
 
 // BVH build exposed for tests of the host logic (no GPU needed)
 struct HostBvh {
-  std::vector<etxd::BvhNode> nodes;
+  std::vector<etxd::BvhNode> nodes;    // the builder's binned-SAH BVH2 (kept for the invariants check)
+  std::vector<etxd::Bvh4Node> nodes4;  // what the device traverses: the BVH2 collapsed to four-wide nodes, breadth first
+  int32_t root4 = 0;
+  uint32_t depth4 = 0;                 // levels of inner BVH4 nodes
+  uint32_t stack_need = 0;             // entries the near-child-first traversal can have on its stack (exact bound over the tree)
   std::vector<etxd::BvhTri> tris;
   int32_t root = 0;
   uint32_t depth = 0;

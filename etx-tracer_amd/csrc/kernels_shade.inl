@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBlockSize) void k_path_tail(Pipeline p, VcmParams 
     uint32_t alpha_seed = st.sampler.seed ^ 0x2545f491u;
     bool alive = true;
     while (alive) {
-      Hit h = bvh_closest(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, RayQ{st.ray_o, st.ray_tmin, st.ray_d, st.ray_tmax}, alpha_seed, nullptr);
+      Hit h = bvh_closest(scene, global_nodes(scene), scene.bvh_tris, scene.bvh_root, stack, RayQ{st.ray_o, st.ray_tmin, st.ray_d, st.ray_tmax}, alpha_seed, nullptr);
       rays++;
       const float4 hit = make_float4(h.u, h.v, h.t, __uint_as_float(h.tri));
       alive = kCamera ? camera_step<kGroup>(p, scene, it, st, hit, true, LaneSlots{}, stack) : light_step<kGroup>(p, scene, it, st, hit, true, LaneSlots{}, stack);

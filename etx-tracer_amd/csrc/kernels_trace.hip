@@ -12,11 +12,17 @@
 
 namespace etxd {
 
+// LDS budget of the BVH traversal kernels: the per-lane stack (kStackDepth x 256 lanes x 4 B = 32 KB) plus the staged top
+// of the tree (kLdsNodes x 128 B). 256 nodes = 32 KB -> 64 KB per workgroup, two workgroups per CU; a BVH4 over a few
+// thousand triangles fits completely (gems: 2 892 triangles), larger trees keep their top five levels in LDS.
+constexpr uint32_t kLdsNodes = 256;
+
 template <bool kFromCounter, bool kFlat>
 __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
-  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag) {
+  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit) {
   // the flat sweep needs no stack: without the 32 KB of LDS the kernel runs 8 waves per SIMD instead of 5
   __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
+  __shared__ float4 s_nodes[kFlat ? 1 : kLdsNodes * 8u];
   const DScene& scene = scene_arg;  // by value: kernarg (scalar) loads, table pointers known to be global
   const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
   if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
@@ -39,6 +45,9 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t stride = gridDim.x * blockDim.x;
   LaneStack stack = {s_stack + (kFlat ? 0u : threadIdx.x), kBlockSize};
+  BvhNodes nodes = global_nodes(scene);
+  if ((kFlat == false) && (blockIdx.x * blockDim.x < count))  // workgroup-uniform: this workgroup has rays
+    nodes = stage_nodes(scene, s_nodes, min(kLdsNodes, lds_node_limit));
   for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {
     const uint32_t i = base + lane;
     if (i >= count)
@@ -48,8 +57,144 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
     uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ i;
     const RayQ ray = {{a.x, a.y, a.z}, a.w, {b.x, b.y, b.z}, b.w};
     Hit h = kFlat ? bvh_flat_closest(scene, scene.bvh_tris, ray, alpha_seed, nullptr)
-                  : bvh_closest(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, ray, alpha_seed, nullptr);
+                  : bvh_closest(scene, nodes, scene.bvh_tris, scene.bvh_root, stack, ray, alpha_seed, nullptr);
     hits[i] = make_float4(h.u, h.v, h.t, __uint_as_float(h.tri));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BVH traversal kernel with dynamic ray fetch (persistent threads, Aila & Laine): one lane = one ray, but a lane whose
+// ray is finished does not wait for the slowest ray of its wavefront. Measured on the gems scene a ray needs 5 node visits
+// and 2.5 triangle tests ON AVERAGE, while the rays that cross a gem need ten times that: with a fixed ray per lane a
+// wavefront costs its worst lane and 64-lane utilisation was ~10 % (4 Grays/s). Here every wavefront owns a contiguous
+// chunk of the queue and whenever kRefillLanes lanes are idle they take the next rays of the chunk (wave-uniform cursor,
+// no atomics); a lane executes one traversal step (inner node or leaf) per loop iteration.
+// LDS per workgroup: the per-lane stacks (32 KB) + the first kLdsNodesPersistent nodes of the tree (top levels, 8 KB).
+constexpr uint32_t kRefillLanes = 16;
+
+template <bool kFromCounter, uint32_t kStack, uint32_t kLdsNodesPersistent>
+__global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
+  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit,
+  uint32_t refill_lanes) {
+  __shared__ int32_t s_stack[kStack * kBlockSize];
+  __shared__ float4 s_nodes[kLdsNodesPersistent * 8u];
+  const DScene& scene = scene_arg;
+  const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
+  if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
+    counters[kCntActiveA + kCntActiveB - active_counter] = 0u;
+    counters[kCntCameraVertices] = 0u;
+    counters[kCntPairs] = 0u;
+    counters[kCntShadow] = 0u;
+    counters[kCntMergeVertices] = 0u;
+    counters[kCntEndpoints] = 0u;
+    counters[kCntGroupGeneral] = 0u;
+    counters[kCntGroupSubsurface] = 0u;
+    atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
+    if (round_mirror != nullptr)
+      __hip_atomic_store(round_mirror + (round_tag & (kRoundMirrorSlots - 1u)), ((unsigned long long)(round_tag) + 1ull) << 32u | (unsigned long long)count, __ATOMIC_RELEASE,
+        __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (count == 0u)
+    return;
+  const BvhNodes nodes = stage_nodes(scene, s_nodes, min(kLdsNodesPersistent, lds_node_limit));
+  const LaneStack stack = {s_stack + threadIdx.x, kBlockSize};
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6u;
+  const uint32_t wave_count = (gridDim.x * blockDim.x) >> 6u;
+  const uint32_t chunk = ((count + wave_count - 1u) / wave_count + 63u) & ~63u;  // rays per wavefront, whole 64-ray rows
+  uint32_t cursor = min(count, wave * chunk);                                    // wave-uniform
+  const uint32_t chunk_end = min(count, cursor + chunk);
+  const int32_t kDone = kBvhEmptyChild;
+  const BvhTri* __restrict__ tris = scene.bvh_tris;
+
+  uint32_t ray_index = kInvalid;
+  RayQ ray = {};
+  f3 inv_d = {};
+  Hit best = {};
+  uint32_t alpha_seed = 0u, sp = 0u;
+  int32_t cur = kDone;
+  for (;;) {
+    const bool idle = cur == kDone;
+    const unsigned long long idle_mask = __ballot(idle);
+    const uint32_t idle_count = uint32_t(__popcll(idle_mask));
+    if ((idle_count >= refill_lanes) || (idle_count == 64u)) {
+      if (cursor < chunk_end) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32u), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
+        const uint32_t take = min(idle_count, chunk_end - cursor);
+        if (idle && (rank < take)) {
+          ray_index = cursor + rank;
+          const float4 a = ray_o_tmin[ray_index];
+          const float4 b = ray_d_tmax[ray_index];
+          alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ ray_index;
+          ray = {{a.x, a.y, a.z}, a.w, {b.x, b.y, b.z}, b.w};
+          inv_d = {__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)};
+          best = {0.0f, 0.0f, ray.tmax, kInvalid};
+          sp = 0u;
+          cur = scene.bvh_root;
+        }
+        cursor += take;
+      } else if (idle_count == 64u) {
+        break;
+      }
+    }
+    if (cur == kDone)
+      continue;
+    if (cur >= 0) {
+      float4 lox, loy, loz, hix, hiy, hiz, cc;
+      if (uint32_t(cur) < nodes.lds_count) {
+        const float4* n = nodes.lds + uint32_t(cur) * 8u;
+        lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5], cc = n[6];
+      } else {
+        const float4* n = nodes.global + uint32_t(cur) * 8u;
+        lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5], cc = n[6];
+      }
+      float t0 = slab(f3{lox.x, loy.x, loz.x}, f3{hix.x, hiy.x, hiz.x}, ray.o, inv_d, ray.tmin, best.t);
+      float t1 = slab(f3{lox.y, loy.y, loz.y}, f3{hix.y, hiy.y, hiz.y}, ray.o, inv_d, ray.tmin, best.t);
+      float t2 = slab(f3{lox.z, loy.z, loz.z}, f3{hix.z, hiy.z, hiz.z}, ray.o, inv_d, ray.tmin, best.t);
+      float t3 = slab(f3{lox.w, loy.w, loz.w}, f3{hix.w, hiy.w, hiz.w}, ray.o, inv_d, ray.tmin, best.t);
+      int32_t c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
+      t0 = (c0 == kBvhEmptyChild) ? kMaxFloat : t0;
+      t1 = (c1 == kBvhEmptyChild) ? kMaxFloat : t1;
+      t2 = (c2 == kBvhEmptyChild) ? kMaxFloat : t2;
+      t3 = (c3 == kBvhEmptyChild) ? kMaxFloat : t3;
+      sort_pair(t0, c0, t1, c1);
+      sort_pair(t2, c2, t3, c3);
+      sort_pair(t0, c0, t2, c2);
+      sort_pair(t1, c1, t3, c3);
+      sort_pair(t1, c1, t2, c2);
+      if (t0 == kMaxFloat) {
+        cur = sp ? stack.pop(sp) : kDone;
+      } else {
+        if (t3 < kMaxFloat)
+          stack.push(sp, c3);
+        if (t2 < kMaxFloat)
+          stack.push(sp, c2);
+        if (t1 < kMaxFloat)
+          stack.push(sp, c1);
+        cur = c0;
+      }
+    } else {
+      const uint32_t leaf = uint32_t(~cur);
+      const uint32_t first = leaf >> 3, leaf_count = (leaf & 7u) + 1u;
+      for (uint32_t i = first; i < first + leaf_count; ++i) {
+        const float4 v0 = tris[i].v0_index;
+        const float4 e1 = tris[i].e1_flags;
+        const float4 e2 = tris[i].e2_mat;
+        float u, v, t;
+        if (triangle_test(v0, e1, e2, ray, best.t, u, v, t) == false)
+          continue;
+        const uint32_t flags = __float_as_uint(e1.w);
+        if (flags & kTriVoid)
+          continue;
+        const uint32_t tri_index = __float_as_uint(v0.w);
+        if ((flags & kTriAlphaTested) && alpha_test_skips(scene, tri_index, __float_as_uint(e2.w), u, v, alpha_seed))
+          continue;
+        best = {u, v, t, tri_index};
+      }
+      cur = sp ? stack.pop(sp) : kDone;
+    }
+    if (cur == kDone)
+      hits[ray_index] = make_float4(best.u, best.v, best.t, __uint_as_float(best.tri));
   }
 }
 
@@ -188,6 +333,48 @@ static uint32_t flat2_blocks(uint32_t items) {  // 512 rays per 256-thread block
   return max(1u, min(limit, (items + 2u * kBlockSize - 1u) / (2u * kBlockSize)));
 }
 
+// Persistent grid of the BVH kernel: as many workgroups as the device keeps resident (4 per CU at 40 KB of LDS each), fewer
+// for small queues so that every wavefront still owns several 64-ray rows to refill from.
+static uint32_t bvh_blocks(uint32_t items) {
+  const uint32_t limit = getenv("ETX_HIP_DEBUG_BLOCKS") ? uint32_t(strtoul(getenv("ETX_HIP_DEBUG_BLOCKS"), nullptr, 0)) : 256u * 4u;
+  return max(1u, min(limit, (items + 4u * kBlockSize - 1u) / (4u * kBlockSize)));
+}
+
+static uint32_t lds_limit() {  // experiments: ETX_HIP_LDS_NODES caps the staged part of the tree (0 = everything through L2)
+  static const uint32_t limit = getenv("ETX_HIP_LDS_NODES") ? uint32_t(strtoul(getenv("ETX_HIP_LDS_NODES"), nullptr, 0)) : kLdsNodes;
+  return limit;
+}
+
+// Variant by the stack the scene's tree needs (three entries per BVH4 level): 16 entries -> 24-32 KB of LDS per workgroup
+// and 5-6 resident workgroups per CU, 32 entries otherwise.
+template <bool kFromCounter>
+static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t* counters, uint32_t active_counter,
+  uint32_t items, unsigned long long* round_mirror, uint32_t round_tag) {
+  static const uint32_t refill = getenv("ETX_HIP_REFILL_LANES") ? uint32_t(strtoul(getenv("ETX_HIP_REFILL_LANES"), nullptr, 0)) : kRefillLanes;
+  static const uint32_t variant = getenv("ETX_HIP_BVH_VARIANT") ? uint32_t(strtoul(getenv("ETX_HIP_BVH_VARIANT"), nullptr, 0)) : 0u;
+  const dim3 grid(bvh_blocks(items)), block(kBlockSize);
+  const uint32_t fixed_count = kFromCounter ? 0u : items;
+#define ETX_LAUNCH_BVH(STACK, NODES)                                                                                                                                              \
+  hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, STACK, NODES>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count, round_mirror, \
+    round_tag, lds_limit(), refill)
+  const uint32_t need = scene.bvh_stack_need;
+  if (variant == 1u) {  // experiments: twice the staged nodes
+    if (need <= 16u)
+      ETX_LAUNCH_BVH(16u, 128u);
+    else if (need <= 24u)
+      ETX_LAUNCH_BVH(24u, 128u);
+    else
+      ETX_LAUNCH_BVH(kStackDepth, 128u);
+  } else if (need <= 16u) {
+    ETX_LAUNCH_BVH(16u, 64u);
+  } else if (need <= 24u) {
+    ETX_LAUNCH_BVH(24u, 64u);
+  } else {
+    ETX_LAUNCH_BVH(kStackDepth, 64u);
+  }
+#undef ETX_LAUNCH_BVH
+}
+
 void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat, unsigned long long* round_mirror, uint32_t round_tag) {
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.capacity, max_items) + kBlockSize - 1) / kBlockSize));
   // opt-in (ETX_HIP_DEBUG_FLAGS bit 64): alone on the device the two-ray sweep is 10 % faster (39.3 vs 35.7 Grays/s on 2 M incoherent
@@ -196,9 +383,9 @@ void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, u
     hipLaunchKernelGGL((k_trace_closest_flat2<true>), dim3(flat2_blocks(min(p.capacity, max_items))), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits,
       p.counters, active_counter, 0u, round_mirror, round_tag);
   else if (flat)
-    hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag);
+    hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag, lds_limit());
   else
-    hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag);
+    launch_bvh_kernel<true>(stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, min(p.capacity, max_items), round_mirror, round_tag);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -208,12 +395,16 @@ void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, u
 template <bool kFlat>
 __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
   __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
+  __shared__ float4 s_nodes[kFlat ? 1 : kLdsNodes * 8u];
   const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntShadow], p.shadow.capacity);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t stride = gridDim.x * blockDim.x;
   LaneStack stack = {s_stack + (kFlat ? 0u : threadIdx.x), kBlockSize};  // a flat scene only touches it when a segment crosses > 4 boundaries
   uint32_t splats = 0;
+  BvhNodes nodes = global_nodes(scene);
+  if ((kFlat == false) && (blockIdx.x * blockDim.x < count))
+    nodes = stage_nodes(scene, s_nodes, kLdsNodes);
   for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {
     const uint32_t i = base + lane;
     f3 value = mk3(0.0f);
@@ -224,7 +415,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
       uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ i;
       f3 tr = mk3(1.0f);
       if ((p.debug_flags & 4u) == 0u)
-        tr = bvh_transmittance(scene, scene.bvh_nodes, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), p.shadow.value[i].w, alpha_seed);
+        tr = bvh_transmittance(scene, nodes, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), p.shadow.value[i].w, alpha_seed);
       target = __float_as_uint(b.w);
       if ((tr.x > kEpsilon) || (tr.y > kEpsilon) || (tr.z > kEpsilon)) {  // SpectralResponse::is_zero
         const float4 v = p.shadow.value[i];
@@ -285,9 +476,9 @@ void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ra
   if (flat && two_ray_sweep)
     hipLaunchKernelGGL((k_trace_closest_flat2<false>), dim3(flat2_blocks(count)), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u);
   else if (flat)
-    hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u);
+    hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u, lds_limit());
   else
-    hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(blocks), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u);
+    launch_bvh_kernel<false>(stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u);
 }
 
 }  // namespace etxd

@@ -195,8 +195,13 @@ int etx_hip_kat(etx_hip_context* context, int which, const float* in, uint64_t c
 
 /* Host-only (no GPU, no context): builds the traversal BVH for `scene` exactly as etx_hip_upload_scene does and checks
  * its invariants (every triangle referenced once, child boxes enclose their triangles, leaf size <= 8, depth within the
- * device stack). out_info = {inner node count, triangle count, depth, bytes}. Returns 0 or ETX_HIP_ERROR_INVALID_ARGUMENT. */
+ * device stack). out_info = {BVH4 node count, triangle count, depth | stack entries needed << 16, bytes}. Returns 0 or ETX_HIP_ERROR_INVALID_ARGUMENT. */
 int etx_hip_host_check_bvh(const etx_abi_scene* scene, uint32_t out_info[4]);
+
+/* Host-only (no GPU, no context): walks the same BVH4 in the same order as the traversal kernels for `count` rays
+ * {ox,oy,oz,tmin,dx,dy,dz,tmax} and returns the work they do: out[0] node visits, out[1] triangle tests, out[2] rays that hit,
+ * out[3] deepest use of the traversal stack. */
+int etx_hip_host_bvh_stats(const etx_abi_scene* scene, const float* rays_8f, uint64_t count, uint64_t out[4]);
 
 #ifdef __cplusplus
 }

@@ -255,11 +255,14 @@ struct RaytracingImpl {
   CpuBVH* bvh = nullptr;
   bool count_rays = false;
   bool decorrelate = false;  // diagnostic only, see Raytracing::trace
+  bool rekey_camera = false; // ETX_ORACLE_DECORRELATE=2, see Raytracing::trace
 
   RaytracingImpl()
     : film(scheduler) {
     count_rays = getenv("ETX_ORACLE_COUNT_RAYS") != nullptr;
-    decorrelate = getenv("ETX_ORACLE_DECORRELATE") != nullptr;
+    const char* mode = getenv("ETX_ORACLE_DECORRELATE");
+    decorrelate = (mode != nullptr) && (atoi(mode) != 2);
+    rekey_camera = (mode != nullptr) && (atoi(mode) == 2);
   }
 
   ~RaytracingImpl() {
@@ -324,6 +327,15 @@ bool Raytracing::trace(const Scene& scene, const Ray& r, Intersection& result_in
     uint32_t k = (to_uint(r.o.x) ^ (to_uint(r.d.y) >> 3u) ^ (to_uint(r.o.z) >> 5u)) % 5u;
     for (uint32_t i = 0; i < k; ++i)
       smp.next();
+  }
+  if (_private->rekey_camera && (_private->source_camera != nullptr) && (_private->source_camera->lens_radius == 0.0f) && (r.o.x == _private->source_camera->position.x) &&
+      (r.o.y == _private->source_camera->position.y) && (r.o.z == _private->source_camera->position.z)) {
+    // DIAGNOSTIC (ETX_ORACLE_DECORRELATE=2): a primary ray of a pinhole camera = the first segment of a camera sub path.
+    // From here on the camera path draws from a stream of its own - exactly what the device does in k_camera_generate
+    // (kernels_vcm.hip), only four draws later (pixel jitter and lens sample were taken from the shared stream). Mode 1
+    // above merely shifts the shared stream: light and camera path of a pixel still consume the SAME numbers in different
+    // roles, which is not independence.
+    smp.seed = Sampler::random_seed(smp.seed, 0x43414d45u);
   }
   IntersectionBase found = {{}, kInvalidIndex, 0.0f};
   _private->bvh->intersect(r, [&](uint32_t triangle_index, float u, float v, float t) {

@@ -57,14 +57,16 @@ def test_snapshot_relocation(etx, golden_dir, name, triangles, size):
 
 def test_host_bvh_invariants(etx, golden_dir):
     from etx_tracer_amd import api
-    for name in ("cornell_classic_128", "cornell_full_128"):
+    for name in ("cornell_classic_128", "cornell_full_128", "cornell_gems_128"):
         snap = etx.SceneSnapshot(os.path.join(golden_dir, name + ".etxscene"))
-        rc, info = api.host_check_bvh(snap)
+        rc, info = api.host_check_bvh(snap)  # BVH2 and the BVH4 the device traverses: every triangle in one leaf, boxes nested
         assert rc == 0
         assert info["triangles"] == snap.triangle_count
-        assert 1 <= info["nodes"] < snap.triangle_count
-        assert info["depth"] <= 12
-        assert info["bytes"] == info["nodes"] * 64 + info["triangles"] * 48
+        assert 1 <= info["nodes"] < snap.triangle_count / 2  # four-wide nodes over leaves of up to four triangles
+        assert info["depth"] <= 10                          # three stack entries per level must fit the 32-entry stack
+        assert info["bytes"] == info["nodes"] * 128 + info["triangles"] * 48
+        if name == "cornell_gems_128":
+            assert info["nodes"] <= 1024, info  # a few hundred nodes: mostly inside the LDS-staged top of the tree
 
 
 def test_options_mapping_follows_vcmoptions_load(etx):
