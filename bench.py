@@ -157,6 +157,42 @@ def main():
         isolated = {"rays_per_launch": n_rays, "avg_launch_ms": round(ms, 6), "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6),
                     "note": "the same kernel alone on the device, 20 launches over one queue of incoherent rays"}
 
+    # Per-kernel-group rooflines: a short extra pass with every kernel group timed by HIP events on its launch stream
+    # (etx_hip_set_timers; the main timed region above times only the two traversal groups). Algorithmic bytes per unit are
+    # the figures of DESIGN.md 3; the units come from the device counters of the same pass.
+    kernels = None
+    if rank == 0:
+        ctx.set_timers(0xff)
+        ctx.begin_vcm(options, first_iteration=0, iteration_stride=1)
+        groups_steps = min(args.steps, 8)
+        for _ in range(groups_steps):
+            ctx.render_iteration()
+        ctx.sync()
+        s = ctx.stats()
+        ctx.set_timers(0x3)
+        merge_vertices = s.camera_vertices
+        units = {
+            "trace_closest": ("ray", s.rays_extension, 48.0 * s.rays_extension, s.ms_trace_closest, "k_trace_closest: 32 B ray in + 16 B hit out"),
+            "trace_shadow": ("segment", s.rays_shadow, 48.0 * s.rays_shadow + 12.0 * s.splats, s.ms_trace_shadow, "k_trace_shadow: 48 B request in, 12 B of film atomics per visible light splat"),
+            "shade_light": ("path segment", s.rays_light, 184.0 * s.rays_light + 96.0 * s.light_vertices, s.ms_shade_light,
+                            "k_light_shade (+ tail): 84 B state + 16 B hit in, 84 B state out, 96 B per stored light vertex"),
+            "shade_camera": ("path segment", s.rays_camera, 184.0 * s.rays_camera + 164.0 * s.camera_vertices, s.ms_shade_camera,
+                             "k_camera_shade (+ tail): 84 B state + 16 B hit in, 84 B out, 116 B vertex record + 48 B NEE request per connectible vertex"),
+            "connect": ("pair", s.pairs, 220.0 * s.pairs, s.ms_connect, "k_expand_pairs + k_connect_pairs: 8 B pair + 96 B light vertex + 68 B camera vertex + 48 B shadow request"),
+            "merge": ("photon examined", s.photons_examined, 16.0 * s.photons_examined + 48.0 * s.photons_merged + 64.0 * merge_vertices, s.ms_merge,
+                      "k_merge_* (sort + k_merge_diffuse / generic): 16 B per photon examined, 48 B per photon accepted, 8 x 8 B cell ranges per vertex"),
+            "grid_build": ("light vertex", s.light_vertices, 176.0 * s.light_vertices, s.ms_grid_build, "k_grid_*: 96 B vertex in + 80 B photon record out"),
+        }
+        total_ms = sum(u[3] for u in units.values()) + s.ms_generate
+        kernels = {}
+        for name, (unit, count, nbytes, ms, what) in units.items():
+            gbs = (nbytes / 1.0e9) / (ms * 1.0e-3) if ms > 0 else 0.0
+            kernels[name] = {"bound": "hbm", "unit": unit, "units_per_step": round(count / groups_steps), "ms_per_step": round(ms / groups_steps, 4), "share": round(ms / total_ms, 4) if total_ms > 0 else None,
+                             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": what}
+        kernels["note"] = ("%d extra steps with all kernel groups timed (HIP events on the launch streams, %s iterations in flight): times include each launch's dispatch and the "
+                           "sharing of the CUs with the other lanes' kernels; rocprofv3 per-kernel times of the same command are in profiles/round2_bench_full_1080p_kernel_stats.csv" %
+                           (groups_steps, os.environ.get("ETX_HIP_LANES", "4")))
+
     # PMC figures (collected in separate rocprofv3 --pmc passes, profiles/round1_pmc_summary.json): HBM bytes per ray of
     # the traversal kernel (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE) and the
     # occupancy / VALU utilisation of the shade kernels
@@ -209,6 +245,7 @@ def main():
                         "other kernels; `isolated` is the same kernel alone",
                 "isolated": isolated,
             },
+            "kernels": kernels,
             "shade_kernels": ({name: pmc["kernels_1lane"][name] for name in ("etxd::k_camera_shade<true>", "etxd::k_light_shade<true>") if name in pmc["kernels_1lane"]} if pmc else None),
             "counters": {
                 "rays_per_sample": round((acc["rays"] + acc["shadow"]) / (float(width) * height * args.steps), 3),

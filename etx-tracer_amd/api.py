@@ -22,7 +22,7 @@ VCM_FULL_OPTIONS = 0x7F
 EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene",
     "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
-    "etx_hip_read_film", "etx_hip_stats", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
+    "etx_hip_read_film", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
 )
 
@@ -102,6 +102,10 @@ class Stats(ctypes.Structure):
         ("ms_generate", ctypes.c_double),
         ("launches_trace_closest", ctypes.c_uint64),
         ("launches_trace_shadow", ctypes.c_uint64),
+        ("rays_light", ctypes.c_uint64),
+        ("rays_camera", ctypes.c_uint64),
+        ("pairs", ctypes.c_uint64),
+        ("endpoints", ctypes.c_uint64),
     ]
 
     def as_dict(self):
@@ -143,6 +147,7 @@ class Library:
         L.etx_hip_sync.argtypes = [vp]
         L.etx_hip_read_film.argtypes = [vp, i32, vp, sz]
         L.etx_hip_stats.argtypes = [vp, ctypes.POINTER(Stats), sz]
+        L.etx_hip_set_timers.argtypes = [vp, u32]
         L.etx_hip_comm_unique_id.argtypes = [vp]
         L.etx_hip_comm_init.argtypes = [vp, i32, i32, vp]
         L.etx_hip_reduce_film.argtypes = [vp]
@@ -217,6 +222,10 @@ class Context:
 
     def render_iteration(self):
         self._check(self.library.lib.etx_hip_render_iteration(self.handle))
+
+    def set_timers(self, mask):
+        """Kernel groups timed with HIP events (bit i = i-th ms_* field of the stats, 0xff = all)."""
+        self._check(self.library.lib.etx_hip_set_timers(self.handle, int(mask)))
 
     def try_render_iteration(self):
         """1 = handed to a free lane, 0 = every lane busy; never blocks (Integrator::update must not block)."""

@@ -316,7 +316,7 @@ ShadeGroups shade_groups(const etx_hip_context* ctx) {
 // mirror without ever draining the stream, so the device does not idle while the host learns that the pass has ended.
 // Rounds enqueued after the last path died are empty launches (at most `run_ahead` of them).
 template <class ShadeFn, class TailFn>
-int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64_t& rounds, bool allow_tail = true) {
+int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64_t& rounds, uint32_t pass_stat, bool allow_tail = true) {
   uint32_t set = 0;
   uint32_t known_count = ctx->pipe.capacity;  // upper bound of the active paths (the count never grows within a pass)
   const uint32_t tail_threshold = (allow_tail && ctx->tail_divisor) ? std::max(64u, ctx->pipe.capacity / ctx->tail_divisor) : 0u;
@@ -340,7 +340,7 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
     const uint32_t tag = ctx->next_round_tag++;
     {
       ScopedTimer t(ctx, kTimerTraceClosest);
-      launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB, known_count, ctx->scene.host_copy.bvh_flat != 0u, ctx->round_mirror, tag);
+      launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB, known_count, ctx->scene.host_copy.bvh_flat != 0u, ctx->round_mirror, tag, pass_stat);
     }
     shade(set, known_count);
     set ^= 1u;
@@ -421,7 +421,7 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
         launch_trace_shadow(s, p, p.shadow.capacity, ctx->scene.host_copy.bvh_flat != 0u);
       }
     },
-    rounds);
+    rounds, kStatRaysLight);
   if (rc)
     return rc;
 
@@ -480,7 +480,7 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
         launch_merge(s, p, it, ctx->scene.generic_materials, p.capacity);
       }
     },
-    rounds);
+    rounds, kStatRaysCamera);
   if (rc)
     return rc;
   launch_vcm_commit(s, p.camera_sum, p.light_sum, ctx->pipe.camera_sum, ctx->pipe.light_sum, p.capacity);
@@ -521,7 +521,7 @@ int render_pt_iteration(etx_hip_context* ctx, uint32_t iteration) {
         launch_trace_shadow(s, p, uint32_t(std::min<uint64_t>(uint64_t(max_items) * 2ull, p.shadow.capacity)), flat);
       }
     },
-    [&](uint32_t, uint32_t) {}, rounds, false);
+    [&](uint32_t, uint32_t) {}, rounds, kStatRaysCamera, false);
   if (rc)
     return rc;
   launch_pt_commit(s, ctx->pt_iteration_image, ctx->pipe.camera_sum, it.path_count, ctx->scene.host_copy.radiance_clamp);
@@ -567,6 +567,10 @@ void collect_stats(etx_hip_context* ctx) {
   st.photons_examined = u64(kStatPhotonsExamined);
   st.photons_merged = u64(kStatPhotonsMerged);
   st.splats = u64(kStatSplats);
+  st.rays_light = u64(kStatRaysLight);
+  st.rays_camera = u64(kStatRaysCamera);
+  st.pairs = u64(kStatPairs);
+  st.endpoints = u64(kStatEndpoints);
   st.overflow_flags = c[kCntOverflow];
   st.nonfinite_dropped = c[kCntNonFinite];
 #if defined(ETX_HIP_DEBUG_COUNTERS)
@@ -629,6 +633,7 @@ void lane_worker(etx_hip_context* lane) {
         t.rays_extension += s.rays_extension, t.rays_shadow += s.rays_shadow;
         t.light_vertices += s.light_vertices, t.camera_vertices += s.camera_vertices;
         t.photons_examined += s.photons_examined, t.photons_merged += s.photons_merged, t.splats += s.splats;
+        t.rays_light += s.rays_light, t.rays_camera += s.rays_camera, t.pairs += s.pairs, t.endpoints += s.endpoints;
         t.wavefront_bounces += s.wavefront_bounces;
         t.ms_trace_closest += s.ms_trace_closest, t.ms_trace_shadow += s.ms_trace_shadow;
         t.ms_shade_light += s.ms_shade_light, t.ms_shade_camera += s.ms_shade_camera;
@@ -1093,6 +1098,16 @@ int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size
     launch_film_resolve(context->stream, context->pipe.camera_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, layer);
   HIP_OK(context, hipMemcpyAsync(dst_rgba, context->resolve_buffer, dst_bytes, hipMemcpyDeviceToHost, context->stream));
   HIP_OK(context, hipStreamSynchronize(context->stream));
+  return ETX_HIP_OK;
+}
+
+int etx_hip_set_timers(etx_hip_context* context, uint32_t mask) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  (void)wait_idle(context);
+  context->timer_mask = mask;
+  for (etx_hip_context* helper : context->helpers)
+    helper->timer_mask = mask;
   return ETX_HIP_OK;
 }
 

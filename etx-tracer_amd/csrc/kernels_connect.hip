@@ -59,6 +59,8 @@ __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmPara
       for (uint32_t w = 0; w < kBlockSize / 64u; ++w)
         total += s_wave_total[w];
       s_base = total ? atomicAdd(p.counters + kCntPairs, total) : 0u;
+      if (total)
+        atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPairs), (unsigned long long)total);
     }
     __syncthreads();
     uint32_t base = s_base + incl - k;
@@ -136,6 +138,8 @@ __global__ __launch_bounds__(kBlockSize) void k_connect_endpoints(Pipeline p, Vc
   __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntEndpoints], p.endpoints.capacity);
+  if ((blockIdx.x == 0) && (threadIdx.x == 0) && (count != 0u))
+    atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatEndpoints), (unsigned long long)count);
   ETX_BLOCK_LOOP(count, i) {
     ShadowRequest request;
     bool queue = false;

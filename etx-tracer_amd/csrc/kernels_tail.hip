@@ -13,6 +13,8 @@ namespace etxd {
 
 __global__ void k_reset_round_counters(Pipeline p) {
   if ((blockIdx.x == 0) && (threadIdx.x == 0)) {
+    if (p.counters[kCntCameraVertices] != 0u)
+      atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatCameraVertices), (unsigned long long)p.counters[kCntCameraVertices]);
     p.counters[kCntCameraVertices] = 0u;
     p.counters[kCntPairs] = 0u;
     p.counters[kCntShadow] = 0u;

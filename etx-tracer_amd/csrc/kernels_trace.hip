@@ -19,7 +19,7 @@ constexpr uint32_t kLdsNodes = 256;
 
 template <bool kFromCounter, bool kFlat>
 __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
-  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit) {
+  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit, uint32_t pass_stat) {
   // the flat sweep needs no stack: without the 32 KB of LDS the kernel runs 8 waves per SIMD instead of 5
   __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
   __shared__ float4 s_nodes[kFlat ? 1 : kLdsNodes * 8u];
@@ -28,6 +28,8 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
   if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
     // housekeeping for the shade kernel that follows: its output counter and the camera vertex pool start empty
     counters[kCntActiveA + kCntActiveB - active_counter] = 0u;
+    if (counters[kCntCameraVertices] != 0u)  // statistics: the connectible camera vertices of the bounce that just ended
+      atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatCameraVertices), (unsigned long long)counters[kCntCameraVertices]);
     counters[kCntCameraVertices] = 0u;
     counters[kCntPairs] = 0u;
     counters[kCntShadow] = 0u;
@@ -36,6 +38,8 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
     counters[kCntGroupGeneral] = 0u;
     counters[kCntGroupSubsurface] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
+    if (pass_stat != 0u)
+      atomicAdd(reinterpret_cast<unsigned long long*>(counters + pass_stat), (unsigned long long)count);
     // the host's view of the wavefront (host_api.cpp run_bounce_loop): (round tag + 1, active paths entering this round)
     // in pinned host memory - the host never drains the stream to learn that a pass has ended
     if (round_mirror != nullptr)
@@ -75,13 +79,15 @@ constexpr uint32_t kRefillLanes = 16;
 template <bool kFromCounter, uint32_t kStack, uint32_t kLdsNodesPersistent>
 __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
   float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit,
-  uint32_t refill_lanes) {
+  uint32_t refill_lanes, uint32_t pass_stat) {
   __shared__ int32_t s_stack[kStack * kBlockSize];
   __shared__ float4 s_nodes[kLdsNodesPersistent * 8u];
   const DScene& scene = scene_arg;
   const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
   if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
     counters[kCntActiveA + kCntActiveB - active_counter] = 0u;
+    if (counters[kCntCameraVertices] != 0u)  // statistics: the connectible camera vertices of the bounce that just ended
+      atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatCameraVertices), (unsigned long long)counters[kCntCameraVertices]);
     counters[kCntCameraVertices] = 0u;
     counters[kCntPairs] = 0u;
     counters[kCntShadow] = 0u;
@@ -90,6 +96,8 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene s
     counters[kCntGroupGeneral] = 0u;
     counters[kCntGroupSubsurface] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
+    if (pass_stat != 0u)
+      atomicAdd(reinterpret_cast<unsigned long long*>(counters + pass_stat), (unsigned long long)count);
     if (round_mirror != nullptr)
       __hip_atomic_store(round_mirror + (round_tag & (kRoundMirrorSlots - 1u)), ((unsigned long long)(round_tag) + 1ull) << 32u | (unsigned long long)count, __ATOMIC_RELEASE,
         __HIP_MEMORY_SCOPE_SYSTEM);
@@ -217,11 +225,13 @@ ETX_DEV v2f splat2(float v) {
 
 template <bool kFromCounter>
 __global__ __launch_bounds__(kBlockSize) void k_trace_closest_flat2(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
-  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag) {
+  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat) {
   const DScene& scene = scene_arg;
   const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
   if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
     counters[kCntActiveA + kCntActiveB - active_counter] = 0u;
+    if (counters[kCntCameraVertices] != 0u)  // statistics: the connectible camera vertices of the bounce that just ended
+      atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatCameraVertices), (unsigned long long)counters[kCntCameraVertices]);
     counters[kCntCameraVertices] = 0u;
     counters[kCntPairs] = 0u;
     counters[kCntShadow] = 0u;
@@ -230,6 +240,8 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_flat2(const DScene
     counters[kCntGroupGeneral] = 0u;
     counters[kCntGroupSubsurface] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
+    if (pass_stat != 0u)
+      atomicAdd(reinterpret_cast<unsigned long long*>(counters + pass_stat), (unsigned long long)count);
     if (round_mirror != nullptr)
       __hip_atomic_store(round_mirror + (round_tag & (kRoundMirrorSlots - 1u)), ((unsigned long long)(round_tag) + 1ull) << 32u | (unsigned long long)count, __ATOMIC_RELEASE,
         __HIP_MEMORY_SCOPE_SYSTEM);
@@ -349,14 +361,14 @@ static uint32_t lds_limit() {  // experiments: ETX_HIP_LDS_NODES caps the staged
 // and 5-6 resident workgroups per CU, 32 entries otherwise.
 template <bool kFromCounter>
 static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t* counters, uint32_t active_counter,
-  uint32_t items, unsigned long long* round_mirror, uint32_t round_tag) {
+  uint32_t items, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat) {
   static const uint32_t refill = getenv("ETX_HIP_REFILL_LANES") ? uint32_t(strtoul(getenv("ETX_HIP_REFILL_LANES"), nullptr, 0)) : kRefillLanes;
   static const uint32_t variant = getenv("ETX_HIP_BVH_VARIANT") ? uint32_t(strtoul(getenv("ETX_HIP_BVH_VARIANT"), nullptr, 0)) : 0u;
   const dim3 grid(bvh_blocks(items)), block(kBlockSize);
   const uint32_t fixed_count = kFromCounter ? 0u : items;
 #define ETX_LAUNCH_BVH(STACK, NODES)                                                                                                                                              \
   hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, STACK, NODES>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count, round_mirror, \
-    round_tag, lds_limit(), refill)
+    round_tag, lds_limit(), refill, pass_stat)
   const uint32_t need = scene.bvh_stack_need;
   if (variant == 1u) {  // experiments: twice the staged nodes
     if (need <= 16u)
@@ -375,17 +387,17 @@ static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const flo
 #undef ETX_LAUNCH_BVH
 }
 
-void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat, unsigned long long* round_mirror, uint32_t round_tag) {
+void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat) {
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.capacity, max_items) + kBlockSize - 1) / kBlockSize));
   // opt-in (ETX_HIP_DEBUG_FLAGS bit 64): alone on the device the two-ray sweep is 10 % faster (39.3 vs 35.7 Grays/s on 2 M incoherent
   // rays), inside the 4-lane pipeline its fatter waves lose against the co-running kernels (51.5 vs 46.6 us per launch) - DESIGN.md 3
   if (flat && (p.debug_flags & 64u))
     hipLaunchKernelGGL((k_trace_closest_flat2<true>), dim3(flat2_blocks(min(p.capacity, max_items))), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits,
-      p.counters, active_counter, 0u, round_mirror, round_tag);
+      p.counters, active_counter, 0u, round_mirror, round_tag, pass_stat);
   else if (flat)
-    hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag, lds_limit());
+    hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag, lds_limit(), pass_stat);
   else
-    launch_bvh_kernel<true>(stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, min(p.capacity, max_items), round_mirror, round_tag);
+    launch_bvh_kernel<true>(stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, min(p.capacity, max_items), round_mirror, round_tag, pass_stat);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -474,11 +486,11 @@ void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ra
     limited.flat_prim_count = min(limited.flat_prim_count, uint32_t(strtoul(e, nullptr, 0)));
   const bool two_ray_sweep = (getenv("ETX_HIP_DEBUG_FLAGS") != nullptr) && ((strtoul(getenv("ETX_HIP_DEBUG_FLAGS"), nullptr, 0) & 64u) != 0u);
   if (flat && two_ray_sweep)
-    hipLaunchKernelGGL((k_trace_closest_flat2<false>), dim3(flat2_blocks(count)), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u);
+    hipLaunchKernelGGL((k_trace_closest_flat2<false>), dim3(flat2_blocks(count)), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u, 0u);
   else if (flat)
-    hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u, lds_limit());
+    hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u, lds_limit(), 0u);
   else
-    launch_bvh_kernel<false>(stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u);
+    launch_bvh_kernel<false>(stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u, 0u);
 }
 
 }  // namespace etxd

@@ -138,8 +138,12 @@ enum : uint32_t {
   kCntGroupGeneral = 544,    // paths of the current bounce whose hit material is shaded by the general kernel, cleared per bounce
   kCntGroupSubsurface = 576, // ... by the subsurface kernel
   kCntEndpoints = 608,       // endpoint connection requests of the current bounce, cleared per bounce
-  kCntNonFinite = 640,       // film contributions dropped because they were not finite (never cleared within a run: reported by etx_hip_stats)
-  kCounterCount = 672,
+  kCntNonFinite = 640,
+  kStatRaysLight = 672,      // u64 statistics: closest-hit rays of the light pass / camera pass, pair connections, endpoint connections
+  kStatRaysCamera = 704,
+  kStatPairs = 736,
+  kStatEndpoints = 768,       // film contributions dropped because they were not finite (never cleared within a run: reported by etx_hip_stats)
+  kCounterCount = 800,
 };
 
 // Per-workgroup statistics (u64): workgroup b of any launch adds to row b without atomics (launches on one stream do

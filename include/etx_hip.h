@@ -154,7 +154,16 @@ typedef struct etx_hip_stats_t {
   double ms_generate;
   uint64_t launches_trace_closest;
   uint64_t launches_trace_shadow;
+  /* more totals since etx_hip_begin (the units the per-kernel rooflines of bench.py are computed from) */
+  uint64_t rays_light;           /* closest-hit rays of the light pass */
+  uint64_t rays_camera;          /* closest-hit rays of the camera pass (PT: all rays) */
+  uint64_t pairs;                /* (camera vertex, light vertex) connections evaluated */
+  uint64_t endpoints;            /* endpoint connections of the general / subsurface shading groups (k_connect_endpoints) */
 } etx_hip_stats_t;
+
+/* Which kernel groups are timed with HIP events (bit i = the i-th ms_* field above, in declaration order; default: the two
+ * traversal groups). Timing costs two events per launch; bench.py switches everything on for its per-kernel roofline pass. */
+int etx_hip_set_timers(etx_hip_context* context, uint32_t mask);
 
 int etx_hip_stats(etx_hip_context* context, etx_hip_stats_t* out_stats, size_t stats_size);
 

@@ -7,7 +7,9 @@ tests of tests/test_gpu_parity_hi.py ("a high-spp oracle reference
   tests/golden/hi/cornell_<flavour>_128_<integrator>_<spp>.npz   camera / light layers (float16 pairs are NOT used:
       the films are float32, compressed), reference CPUVCM with vcm-blue_noise=false and CPUPathTracing with bn=false
   tests/golden/hi/cornell_full_128_vcm_<spp>_decorrelated.npz    the same with ETX_ORACLE_DECORRELATE=1 (the BVH shim
-      shifts the camera stream): the estimator the device's re-keyed camera stream claims to match
+      shifts the shared stream of a pixel's light and camera path by ray-dependent amounts)
+  tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_rekeyed.npz        ETX_ORACLE_DECORRELATE=2: the camera path re-keys its sampler at
+      its first segment = independent light / camera streams, the estimator the device implements
 
 The snapshots are the committed tests/golden/cornell_<flavour>_128.etxscene files (oracle/gen_golden.py writes them).
 Needs /root/reference only through the prebuilt oracle binary. ~8 min per VCM scene on 8 cores.
@@ -58,7 +60,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--spp", type=int, default=4096)
     ap.add_argument("--cores", default="")
-    ap.add_argument("--integrators", default="vcm,pt")
+    ap.add_argument("--integrators", default="vcm,pt,rekeyed")
     ap.add_argument("names", nargs="*", default=FLAVOURS)
     args = ap.parse_args()
     integrators = args.integrators.split(",")
@@ -68,6 +70,10 @@ def main():
             render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d.npz" % (flavour, args.spp)), args.cores, extra=["--opt", "vcm-blue_noise=false"])
         if (flavour == "full") and ("vcm" in integrators):
             render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_full_128_vcm_%d_decorrelated.npz" % args.spp), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "1"},
+                   extra=["--opt", "vcm-blue_noise=false"])
+        if "rekeyed" in integrators:
+            # mode 2: the camera sub path draws from a stream of its own from its first segment on (oracle/shims/raytracing_bvh.cxx)
+            render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_rekeyed.npz" % (flavour, args.spp)), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "2"},
                    extra=["--opt", "vcm-blue_noise=false"])
         if "pt" in integrators:
             # --noise-threshold 0: every pixel gets all samples (the scenes carry Scene::noise_threshold = 0.1, with which
