@@ -11,6 +11,8 @@ Run in the build container (needs /root/reference): python3 oracle/gen_golden.py
                    cornell_{spectral,diamond,gems}_128_{vcm,pt}.npz  spectral mode: classic box / dispersive diamond + thinfilm / 2 892-triangle gems, VCM 64 spp, PT 256 spp
                    cornell_cloud_128_{vcm,pt}.npz                    heterogeneous medium (procedural 32^3 density in the fog box)
                    cornell_sss_128_{vcm,pt}.npz                      random-walk subsurface scattering, CPUVCM 64 spp / CPUPathTracing 256 spp
+                   cornell_{textured,envmap,lens,equirect}_128_{vcm,pt}.npz  textures + alpha cut-out + normal map / image environment map /
+                                                                     thin lens + aperture image / equirectangular camera, VCM 256 spp, PT 1024 spp
   spectral         cie_observer.npz                                  spectrum::spectral_xyz of the reference (etx_hip_upload_cie_table)
   blue noise       bluenoise_64spp.npz                               the reference's sample_blue_noise for the 64-spp class,
                                                                      factorised by tools/bluenoise_tables.py (258 KiB instead of 32 MiB)
@@ -124,6 +126,21 @@ def sss_golden():
                             threads=np.int32(film["threads"]))
 
 
+def features_golden():
+    # branches no other scene reaches: albedo texture + alpha cut-out (stochastic alpha test inside traversal) + normal map;
+    # image environment map (2-D sampling tables) as the only light; thin lens with an aperture image; equirectangular camera
+    for flavour in ("textured", "envmap", "lens", "equirect"):
+        snapshot = os.path.join(GOLDEN, "cornell_%s_128.etxscene" % flavour)
+        run("--scene", os.path.join(SCENES, "%s_test_128.json" % flavour), "--integrator", "none", "--snapshot", snapshot)
+        for integrator, spp, extra in (("vcm", 256, ["--opt", "vcm-blue_noise=false"]), ("pt", 1024, ["--opt", "bn=false", "--noise-threshold", "0"])):
+            film_path = "/tmp/golden_%s_%s.raw" % (flavour, integrator)
+            run("--load-snapshot", snapshot, "--integrator", integrator, "--spp", str(spp), "--out", film_path, *extra)
+            film = film_io.read_film(film_path)
+            np.savez_compressed(os.path.join(GOLDEN, "cornell_%s_128_%s.npz" % (flavour, integrator)), camera=film["camera"][..., :3], light=film["light"][..., :3],
+                                normal=film["normal"][..., :3], albedo=film["albedo"][..., :3], spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]),
+                                threads=np.int32(film["threads"]))
+
+
 def main():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "scenes", "make_scenes.py")])
     for flavour in ("classic", "full"):
@@ -142,6 +159,7 @@ def main():
     spectral_golden()
     cloud_golden()
     sss_golden()
+    features_golden()
     with open(os.path.join(GOLDEN, "kat_reference.json"), "w") as f:
         subprocess.check_call([ORACLE, "--kat"], stdout=f)
 
@@ -159,5 +177,7 @@ if __name__ == "__main__":
         cloud_golden()
     elif (len(sys.argv) > 1) and (sys.argv[1] == "sss"):
         sss_golden()
+    elif (len(sys.argv) > 1) and (sys.argv[1] == "features"):
+        features_golden()
     else:
         main()

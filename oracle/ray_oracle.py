@@ -3,8 +3,8 @@
 numpy restatement of the closest-hit query `Raytracing::trace` (sources/etx/rt/rt.cxx:428-466) by brute force over
 every triangle: skip Material::Class::Void (rt.cxx:441-444), keep the closest accepted hit in [tmin, tmax], report
 (u, v, t, triangle) with Embree's barycentric convention (u, v weight vertices 1 and 2, rt.cxx:352-353 + math.hxx:764).
-The stochastic alpha test (scene_bsdf.hxx:128-144) is the identity for opaque materials (opacity 1, no alpha texture),
-which is what the fixtures contain. "parity unpinned": the reference holds no vectors for this boundary (SURVEY.md 8c);
+The stochastic alpha test (scene_bsdf.hxx:128-144) is the identity for opaque materials (opacity 1, no alpha texture);
+for alpha-tested surfaces `exclude` gives the second outcome (see closest_hits). "parity unpinned": the reference holds no vectors for this boundary (SURVEY.md 8c);
 the restatement is cross-checked against the reference-based oracle binary through the rendered images instead.
 """
 import numpy as np
@@ -12,8 +12,11 @@ import numpy as np
 ETX_MAT_VOID = 10
 
 
-def closest_hits(snapshot, rays):
-    """rays: (n, 8) float32 {ox,oy,oz,tmin,dx,dy,dz,tmax} -> (n, 4) float64 {u, v, t, triangle or -1}"""
+def closest_hits(snapshot, rays, exclude=()):
+    """rays: (n, 8) float32 {ox,oy,oz,tmin,dx,dy,dz,tmax} -> (n, 4) float64 {u, v, t, triangle or -1}.
+    `exclude`: triangle indices treated as absent - the two outcomes of the stochastic alpha test (scene_bsdf.hxx:128-144) for
+    an alpha-tested surface are "hit it" (exclude nothing) and "pass through" (exclude its triangles); the test checks that
+    every device hit is one of the two and that the pass-through frequency matches opacity x texture alpha."""
     vertices = snapshot.vertices()[:, 0:3].astype(np.float64)
     triangles = snapshot.triangles()
     material_class = snapshot.material_classes()
@@ -25,7 +28,7 @@ def closest_hits(snapshot, rays):
     out[:, 0:2] = 0.0
     for ti in range(triangles.shape[0]):
         i0, i1, i2, mat = (int(x) for x in triangles[ti, 0:4])
-        if material_class[mat] == ETX_MAT_VOID:
+        if (material_class[mat] == ETX_MAT_VOID) or (ti in exclude):
             continue
         v0, e1, e2 = vertices[i0], vertices[i1] - vertices[i0], vertices[i2] - vertices[i0]
         p = np.cross(d, e2)

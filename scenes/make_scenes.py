@@ -30,10 +30,11 @@ class Mesh:
     def __init__(self):
         self.v = []
         self.vn = []
-        self.groups = []  # (material, [(vi, ni) * 3])
+        self.vt = []      # texture coordinates, only for quads created with uv=True
+        self.groups = []  # (material, [(vi, ni) * 3]) or (material, [(vi, ni, ti) * 3])
 
-    def quad(self, mat, pts, normal_hint=None):
-        """pts: 4 points, counter-clockwise seen from the side the normal points to."""
+    def quad(self, mat, pts, normal_hint=None, uv=False):
+        """pts: 4 points, counter-clockwise seen from the side the normal points to. uv: corners get (0,0) (1,0) (1,1) (0,1)."""
         base = len(self.v)
         self.v.extend(pts)
         ax = [pts[1][i] - pts[0][i] for i in range(3)]
@@ -45,6 +46,12 @@ class Mesh:
             raise ValueError("winding does not match the requested normal for %s" % mat)
         self.vn.append(n)
         ni = len(self.vn)
+        if uv:
+            tb = len(self.vt)
+            self.vt.extend([(0.0, 0.0), (1.0, 0.0), (1.0, 1.0), (0.0, 1.0)])
+            self.groups.append((mat, [(base + 1, ni, tb + 1), (base + 2, ni, tb + 2), (base + 3, ni, tb + 3)]))
+            self.groups.append((mat, [(base + 1, ni, tb + 1), (base + 3, ni, tb + 3), (base + 4, ni, tb + 4)]))
+            return
         self.groups.append((mat, [(base + 1, ni), (base + 2, ni), (base + 3, ni)]))
         self.groups.append((mat, [(base + 1, ni), (base + 3, ni), (base + 4, ni)]))
 
@@ -116,12 +123,14 @@ class Mesh:
                 f.write("v %.6f %.6f %.6f\n" % tuple(p))
             for n in self.vn:
                 f.write("vn %.6f %.6f %.6f\n" % tuple(n))
+            for t in self.vt:
+                f.write("vt %.6f %.6f\n" % tuple(t))
             current = None
             for mat, idx in self.groups:
                 if mat != current:
                     f.write("usemtl %s\n" % mat)
                     current = mat
-                f.write("f " + " ".join("%d//%d" % (vi, ni) for vi, ni in idx) + "\n")
+                f.write("f " + " ".join(("%d/%d/%d" % (c[0], c[2], c[1])) if len(c) == 3 else ("%d//%d" % c) for c in idx) + "\n")
 
 
 def build_mesh(with_fog, spheres=False):
@@ -364,8 +373,94 @@ CAMERA = {
 }
 
 
-def write_json(name, geometry, materials, viewport, samples, max_path_length=1023, rr_start=6, spectral=False):
-    cam = dict(CAMERA)
+def write_png(path, rgba):
+    """8-bit RGBA PNG (rows top to bottom), written by hand: no image library needed where the scenes are regenerated."""
+    import struct
+    import zlib
+    h, w = len(rgba), len(rgba[0])
+    raw = b"".join(b"\x00" + bytes(c for px in row for c in px) for row in rgba)
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 9)) + chunk(b"IEND", b""))
+
+
+def write_hdr(path, rgb):
+    """Radiance .hdr (flat RGBE scanlines, rows top to bottom)."""
+    import math
+    h, w = len(rgb), len(rgb[0])
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        for row in rgb:
+            for r, g, b in row:
+                m = max(r, g, b)
+                if m < 1e-32:
+                    f.write(bytes([0, 0, 0, 0]))
+                else:
+                    mant, e = math.frexp(m)
+                    scale = mant * 256.0 / m
+                    f.write(bytes([min(255, int(r * scale)), min(255, int(g * scale)), min(255, int(b * scale)), e + 128]))
+
+
+def build_extra_textures():
+    """Images of the feature-coverage scenes (all procedural, a few KB each)."""
+    import math
+    tex = os.path.join(OUT, "textures")
+    os.makedirs(tex, exist_ok=True)
+    # leaf.png: colour stripes with an alpha cut-out pattern (discs) -> stochastic alpha test inside traversal
+    n = 64
+    rows = []
+    for y in range(n):
+        row = []
+        for x in range(n):
+            cx, cy = (x % 16) - 7.5, (y % 16) - 7.5
+            hole = (cx * cx + cy * cy) < 20.0
+            stripe = ((x // 8) % 2) == 0
+            row.append((230 if stripe else 60, 200 if stripe else 120, 40 if stripe else 200, 0 if hole else 255))
+        rows.append(row)
+    write_png(os.path.join(tex, "leaf.png"), rows)
+    # checker.png: opaque albedo texture for the back wall
+    rows = [[(230, 230, 230, 255) if ((x // 8 + y // 8) % 2) == 0 else (90, 90, 200, 255) for x in range(64)] for y in range(64)]
+    write_png(os.path.join(tex, "checker.png"), rows)
+    # bumps.png: tangent-space normal map (sinusoidal ripples)
+    rows = []
+    for y in range(64):
+        row = []
+        for x in range(64):
+            dx = 0.5 * math.cos(x / 64.0 * 8.0 * math.pi)
+            dy = 0.5 * math.cos(y / 64.0 * 6.0 * math.pi)
+            ln = math.sqrt(dx * dx + dy * dy + 1.0)
+            row.append((int((dx / ln * 0.5 + 0.5) * 255), int((dy / ln * 0.5 + 0.5) * 255), int((1.0 / ln * 0.5 + 0.5) * 255), 255))
+        rows.append(row)
+    write_png(os.path.join(tex, "bumps.png"), rows)
+    # sky.hdr: a dim gradient sky with one bright "sun" patch -> image environment map with 2-D sampling tables
+    w, h = 64, 32
+    rows = []
+    for y in range(h):
+        row = []
+        for x in range(w):
+            sun = math.exp(-(((x - 44) / 3.0) ** 2 + ((y - 7) / 2.5) ** 2))
+            base = 0.25 + 0.35 * (1.0 - y / float(h))
+            row.append((base * 0.8 + 60.0 * sun, base * 0.9 + 52.0 * sun, base * 1.2 + 40.0 * sun))
+        rows.append(row)
+    write_hdr(os.path.join(tex, "sky.hdr"), rows)
+    # aperture.png: hexagonal aperture (lens image: sampling table, uniform)
+    rows = []
+    for y in range(32):
+        row = []
+        for x in range(32):
+            px, py = (x + 0.5) / 16.0 - 1.0, (y + 0.5) / 16.0 - 1.0
+            inside = max(abs(px), abs(px) * 0.5 + abs(py) * 0.8660254) < 0.9
+            v = 255 if inside else 0
+            row.append((v, v, v, 255))
+        rows.append(row)
+    write_png(os.path.join(tex, "aperture.png"), rows)
+
+
+def write_json(name, geometry, materials, viewport, samples, max_path_length=1023, rr_start=6, spectral=False, camera=None):
+    cam = dict(camera if camera is not None else CAMERA)
     cam["viewport"] = list(viewport)
     doc = {
         "geometry": geometry,
@@ -453,6 +548,59 @@ two_sided 1
     write_json("sss_test_128.json", "cornell_classic.obj", "cornell_sss.mtl", (128, 128), 64)
     write_json("spectral_test_128.json", "cornell_classic.obj", "cornell_classic.mtl", (128, 128), 64, spectral=True)
     write_json("diamond_test_128.json", "cornell_classic.obj", "cornell_diamond.mtl", (128, 128), 64, spectral=True)
+
+    # Feature-coverage scenes (branches no other scene reaches): textures + stochastic alpha + normal map; image environment
+    # map as the only light; thin lens with an aperture image; equirectangular camera.
+    build_extra_textures()
+    m = build_mesh(False)
+    # re-author two surfaces with texture coordinates: the back wall (checker albedo), and a free-standing cut-out card
+    textured = Mesh()
+    textured.quad("floor", [(-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1)], (0, 1, 0), uv=True)
+    textured.quad("ceiling", [(-1, 2, -1), (1, 2, -1), (1, 2, 1), (-1, 2, 1)], (0, -1, 0))
+    textured.quad("frontWall", [(-1, 0, -1), (1, 0, -1), (1, 2, -1), (-1, 2, -1)], (0, 0, 1), uv=True)
+    textured.quad("leftWall", [(-1, 0, 1), (-1, 0, -1), (-1, 2, -1), (-1, 2, 1)], (1, 0, 0))
+    textured.quad("rightWall", [(1, 0, -1), (1, 0, 1), (1, 2, 1), (1, 2, -1)], (-1, 0, 0))
+    lx0, _, lz0 = cornell_to_scene(343.0, 0, 227.0)
+    lx1, _, lz1 = cornell_to_scene(213.0, 0, 332.0)
+    textured.quad("light", [(lx0, 1.98, lz1), (lx1, 1.98, lz1), (lx1, 1.98, lz0), (lx0, 1.98, lz0)], (0, -1, 0))
+    textured.quad("card", [(-0.6, 0.2, 0.1), (0.5, 0.2, 0.4), (0.5, 1.3, 0.4), (-0.6, 1.3, 0.1)], uv=True)
+    textured.write(os.path.join(OUT, "cornell_textured.obj"), "cornell_textured.mtl")
+    with open(os.path.join(OUT, "cornell_textured.mtl"), "w") as f:
+        f.write(MTL_COMMON.split("newmtl shortBox")[0].replace("newmtl frontWall\nmaterial class diffuse\nKd 0.906 0.906 0.906", "newmtl frontWall\nmaterial class diffuse\nKd 1.000 1.000 1.000\nmap_Kd textures/checker.png")
+                .replace("newmtl floor\nmaterial class diffuse\nKd 1.000 1.000 1.000", "newmtl floor\nmaterial class diffuse\nKd 1.000 1.000 1.000\nnormalmap image textures/bumps.png scale 1.0") + """newmtl card
+material class diffuse
+Kd 1.000 1.000 1.000
+map_Kd textures/leaf.png
+opacity 0.85
+two_sided 1
+
+""" + MTL_LIGHT_CLASSIC)
+    write_json("textured_test_128.json", "cornell_textured.obj", "cornell_textured.mtl", (128, 128), 64)
+    # image environment map only: the box without its area light, lit through the open front
+    with open(os.path.join(OUT, "cornell_envmap.mtl"), "w") as f:
+        f.write("newmtl et::env\nimage textures/sky.hdr\nrotation 30\n\n" + MTL_COMMON + "newmtl light\nmaterial class diffuse\nKd 0.780 0.780 0.780\ntwo_sided 1\n\n")
+    write_json("envmap_test_128.json", "cornell_classic.obj", "cornell_envmap.mtl", (128, 128), 64)
+    # thin lens + aperture image ("shape" is a key of the et::camera material form, scene_representation.cxx:1134-1138)
+    with open(os.path.join(OUT, "cornell_lens.mtl"), "w") as f:
+        f.write(MTL_COMMON + MTL_LIGHT_CLASSIC + """newmtl et::camera
+class perspective
+viewport 128 128
+origin 0.0 1.0 3.82
+target 0.0 1.0 -6.18
+up 0.0 1.0 0.0
+fov 39.597755
+lens-radius 0.08
+focal-distance 4.6
+clip-near 0.1
+clip-far 100.0
+shape textures/aperture.png
+
+""")
+    write_json("lens_test_128.json", "cornell_classic.obj", "cornell_lens.mtl", (128, 128), 64, camera={})
+    # equirectangular camera in the middle of the box (no light image: sample_film returns nothing for this class)
+    eq = dict(CAMERA)
+    eq.update({"class": "eq", "origin": [0.0, 1.0, 0.3], "target": [0.0, 1.0, -1.0]})
+    write_json("equirect_test_128.json", "cornell_classic.obj", "cornell_classic.mtl", (128, 64), 64, camera=eq)
 
     for flavour in ("classic", "full"):
         obj, mtl = "cornell_%s.obj" % flavour, "cornell_%s.mtl" % flavour

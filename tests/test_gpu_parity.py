@@ -480,3 +480,83 @@ def test_unsupported_options_are_rejected(etx, golden_dir):
         integ.run()
     assert e.value.code == -4
     integ.context.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# feature-coverage scenes: the branches no Cornell variant above reaches
+
+@pytest.mark.parametrize("flavour", ["textured", "envmap", "lens", "equirect"])
+def test_feature_scenes_match_reference(etx, golden_dir, flavour):
+    """textured: albedo texture, alpha cut-out card (opacity x texture alpha: stochastic alpha test inside traversal,
+    scene_bsdf.hxx:128-144) and a tangent-space normal map; envmap: an image environment map (2-D sampling tables,
+    emitter_sample_in / emitter_get_radiance on images) as the only light; lens: thin lens with an aperture image (generate_ray and
+    sample_film lens sampling, scene_camera.hxx:26-118); equirect: equirectangular camera (no light image for this class).
+    PT and VCM against the reference's films (scenes/make_scenes.py, oracle/gen_golden.py features)."""
+    golden = np.load(os.path.join(golden_dir, "cornell_%s_128_pt.npz" % flavour))
+    layers, stats = render_pt(etx, golden_dir, "cornell_%s_128" % flavour, int(golden["spp"]))
+    assert stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
+    h, w = golden["camera"].shape[:2]
+    b = 16 if h >= 128 else 8
+    ok = np.isfinite(golden["camera"]).all(axis=2)
+    assert ok.mean() > 0.999
+    ref = np.where(ok[..., None], golden["camera"], 0.0)
+    cam = np.where(ok[..., None], layers["camera"][..., :3], 0.0)
+    assert rmse(block_mean(cam, b), block_mean(ref, b)) < 6.0e-3, flavour
+    rel = (cam.mean(axis=(0, 1)) - ref.mean(axis=(0, 1))) / ref.mean(axis=(0, 1))
+    assert np.abs(rel).max() < 1.5e-2, (flavour, rel)
+    assert rmse(block_mean(layers["normal"], 8), block_mean(golden["normal"], 8)) < 1.0e-2   # normal map / lens blur show up here
+    assert rmse(block_mean(layers["albedo"], 8), block_mean(golden["albedo"], 8)) < 1.0e-2   # albedo texture
+    golden = np.load(os.path.join(golden_dir, "cornell_%s_128_vcm.npz" % flavour))
+    cam, light, res, stats = render(etx, golden_dir, "cornell_%s_128" % flavour, int(golden["spp"]))
+    assert stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
+    ref_result = np.maximum(golden["camera"] + golden["light"], 0.0)
+    ok = np.isfinite(ref_result).all(axis=2)
+    ref_result = np.where(ok[..., None], ref_result, 0.0)
+    res = np.where(ok[..., None], res[..., :3], 0.0)
+    assert rmse(block_mean(res, b), block_mean(ref_result, b)) < 6.0e-3, flavour
+    rel = (res.mean(axis=(0, 1)) - ref_result.mean(axis=(0, 1))) / ref_result.mean(axis=(0, 1))
+    assert np.abs(rel).max() < 1.5e-2, (flavour, rel)
+    if flavour == "equirect":
+        assert np.abs(light[..., :3]).max() == 0.0  # sample_film gives nothing for an equirectangular camera (scene_camera.hxx:70-72)
+    else:
+        light_ref = golden["light"].mean(axis=(0, 1))
+        light_rel = (light[..., :3].mean(axis=(0, 1)) - light_ref) / np.maximum(light_ref, 1e-6)
+        assert np.abs(light_rel).max() < 4.0e-2, (flavour, light_rel)
+
+
+def test_stochastic_alpha_in_traversal(etx, gpu_context, golden_dir):
+    """The cut-out card of the textured scene: opacity 0.85 x the alpha channel of its texture. Every device hit must be one
+    of the two outcomes of alpha_test_pass (hit the card / pass through to what is behind it), and the card is hit with the
+    frequency the texture prescribes."""
+    from oracle import ray_oracle
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_textured_128.etxscene"))
+    gpu_context.upload_scene(snap)
+    v, t = snap.vertices()[:, 0:3], snap.triangles()
+    card = {i for i in range(t.shape[0]) if all((0.05 < v[int(k), 2] < 0.45) and (v[int(k), 1] > 0.15) and (v[int(k), 1] < 1.35) for k in t[i, 0:3])}
+    assert len(card) == 2
+    # rays from the open front towards the card
+    rng = np.random.default_rng(17)
+    n = 40000
+    o = np.stack([rng.uniform(-0.9, 0.9, n), rng.uniform(0.1, 1.9, n), np.full(n, 1.5)], axis=1)
+    target = np.stack([rng.uniform(-0.6, 0.5, n), rng.uniform(0.2, 1.3, n), rng.uniform(0.1, 0.4, n)], axis=1)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.empty((n, 8), dtype=np.float32)
+    rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = o, 2.2889e-4, d, 3.4e38
+    hits = gpu_context.trace_rays(rays)
+    nearest = ray_oracle.closest_hits(snap, rays)
+    behind = ray_oracle.closest_hits(snap, rays, exclude=card)
+    tri = hits[:, 3].view(np.uint32).astype(np.int64)
+    tri[tri == 0xFFFFFFFF] = -1
+    candidates = np.isin(nearest[:, 3].astype(np.int64), list(card))
+    assert candidates.sum() > 20000
+    took_card = candidates & np.isin(tri, list(card))
+    passed = candidates & ~took_card
+    np.testing.assert_allclose(hits[took_card, 2], nearest[took_card, 2], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(hits[passed, 2], behind[passed, 2], rtol=1e-5, atol=1e-5)
+    others = ~candidates
+    assert (tri[others] == nearest[others, 3].astype(np.int64)).mean() > 0.999
+    # leaf.png: discs of radius^2 20 in 16 x 16 cells are transparent -> 1 - pi * 20 / 256 of the card is opaque (bilinear
+    # filtering smooths the edges, the mean stays), opacity 0.85
+    expected = 0.85 * (1.0 - np.pi * 20.0 / 256.0)
+    assert abs(took_card.sum() / candidates.sum() - expected) < 0.02, (took_card.sum() / candidates.sum(), expected)
