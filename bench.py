@@ -129,10 +129,7 @@ def main():
     acc = run_steps(args.steps, args.warmup)
     barrier()
     elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = multi_gpu.max_over_ranks(elapsed, device="cuda")
 
     result = ctx.read_film(api.LAYER_RESULT)
     finite = bool(np.isfinite(result).all())

@@ -22,7 +22,7 @@ VCM_FULL_OPTIONS = 0x7F
 EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene",
     "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
-    "etx_hip_read_film", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
+    "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
 )
 
@@ -146,6 +146,8 @@ class Library:
         L.etx_hip_poll.argtypes = [vp]
         L.etx_hip_sync.argtypes = [vp]
         L.etx_hip_read_film.argtypes = [vp, i32, vp, sz]
+        L.etx_hip_read_film_begin.argtypes = [vp, i32]
+        L.etx_hip_read_film_end.argtypes = [vp, vp, sz, i32]
         L.etx_hip_stats.argtypes = [vp, ctypes.POINTER(Stats), sz]
         L.etx_hip_set_timers.argtypes = [vp, u32]
         L.etx_hip_comm_unique_id.argtypes = [vp]
@@ -242,6 +244,17 @@ class Context:
         out = np.empty((h, w, 4), dtype=np.float32)
         self._check(self.library.lib.etx_hip_read_film(self.handle, layer, out.ctypes.data, out.nbytes))
         return out
+
+    def read_film_begin(self, layer):
+        """Asynchronous read-back: never waits for iterations in flight (etx_hip_read_film_begin)."""
+        self._check(self.library.lib.etx_hip_read_film_begin(self.handle, layer))
+
+    def read_film_end(self, wait=False):
+        """-> the image, or None while the copy is still running (wait=False never blocks)."""
+        w, h = self.film_size
+        out = np.empty((h, w, 4), dtype=np.float32)
+        rc = self._check(self.library.lib.etx_hip_read_film_end(self.handle, out.ctypes.data, out.nbytes, 1 if wait else 0))
+        return out if rc == 1 else None
 
     def stats(self):
         s = Stats()

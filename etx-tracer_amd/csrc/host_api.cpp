@@ -88,6 +88,13 @@ struct etx_hip_context {
   float cie_first = 0.0f, cie_y_scale = 0.0f;
   etx_hip_stats_t stats = {};
   float4* resolve_buffer = nullptr;
+  // asynchronous film read-back (etx_hip_read_film_begin / _end): own stream, device resolve buffer, pinned staging
+  hipStream_t read_stream = nullptr;
+  hipEvent_t read_event = nullptr;
+  float4* read_resolve = nullptr;
+  float4* read_staging = nullptr;
+  size_t read_pixels = 0;
+  bool read_pending = false;
   void* comm = nullptr;  // ncclComm_t (host_comm.cpp)
   int rank = 0, world = 1;
 
@@ -804,6 +811,14 @@ void etx_hip_destroy(etx_hip_context* context) {
       (void)hipFree(table);
   if (context->cie_table)
     (void)hipFree(context->cie_table);
+  if (context->read_resolve)
+    (void)hipFree(context->read_resolve);
+  if (context->read_staging)
+    (void)hipHostFree(context->read_staging);
+  if (context->read_event)
+    (void)hipEventDestroy(context->read_event);
+  if (context->read_stream)
+    (void)hipStreamDestroy(context->read_stream);
   delete context;
 }
 
@@ -815,6 +830,10 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
   HIP_OK(context, hipStreamSynchronize(context->stream));
   context->scene_ready = false;
   context->armed = false;
+  if (context->read_pending) {
+    (void)hipEventSynchronize(context->read_event);
+    context->read_pending = false;
+  }
   for (etx_hip_context* helper : context->helpers)
     release_pipeline(helper);
   int rc = etxh::build_device_scene(scene, camera, context->scene, context->error);
@@ -1099,6 +1118,81 @@ int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size
   HIP_OK(context, hipMemcpyAsync(dst_rgba, context->resolve_buffer, dst_bytes, hipMemcpyDeviceToHost, context->stream));
   HIP_OK(context, hipStreamSynchronize(context->stream));
   return ETX_HIP_OK;
+}
+
+// Asynchronous read-back: the resolve kernel and the device-to-host copy run on a stream of their own and
+// never wait for the lanes - a GUI host polls from Integrator::update() and keeps its frame rate. The film sums only ever
+// hold COMPLETED iterations (every lane commits its iteration image at the end of the iteration), so a snapshot taken
+// while other iterations are in flight is a valid progressive image, normalised by the iterations completed so far.
+int etx_hip_read_film_begin(etx_hip_context* context, int layer) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  if (context->scene_ready == false) {
+    context->error = "etx_hip_read_film_begin: no scene uploaded";
+    return ETX_HIP_ERROR_STATE;
+  }
+  if ((layer < ETX_HIP_LAYER_CAMERA) || (layer > ETX_HIP_LAYER_ALBEDO)) {
+    context->error = "etx_hip_read_film_begin: unknown layer";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  if (context->read_pending) {
+    context->error = "etx_hip_read_film_begin: the previous read-back has not been collected (etx_hip_read_film_end)";
+    return ETX_HIP_ERROR_STATE;
+  }
+  HIP_OK(context, hipSetDevice(context->device));
+  const size_t n = context->pipe.capacity;
+  if (context->read_stream == nullptr) {
+    HIP_OK(context, hipStreamCreateWithFlags(&context->read_stream, hipStreamNonBlocking));
+    HIP_OK(context, hipEventCreateWithFlags(&context->read_event, hipEventDisableTiming));
+  }
+  if (context->read_pixels != n) {
+    if (context->read_resolve)
+      (void)hipFree(context->read_resolve);
+    if (context->read_staging)
+      (void)hipHostFree(context->read_staging);
+    context->read_resolve = nullptr, context->read_staging = nullptr, context->read_pixels = 0;
+    HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&context->read_resolve), n * sizeof(float4)));
+    HIP_OK(context, hipHostMalloc(reinterpret_cast<void**>(&context->read_staging), n * sizeof(float4), hipHostMallocDefault));
+    context->read_pixels = n;
+  }
+  uint64_t iterations = 0;
+  {
+    std::lock_guard<std::mutex> lock(context->shared_mutex);
+    iterations = context->reduced ? context->global_iterations : uint64_t(context->local_iterations);
+  }
+  const float scale = iterations ? float(1.0 / double(iterations)) : 0.0f;
+  const float4* source = (layer == ETX_HIP_LAYER_NORMAL) ? context->pipe.normal_sum : ((layer == ETX_HIP_LAYER_ALBEDO) ? context->pipe.albedo_sum : context->pipe.camera_sum);
+  const int mode = (layer == ETX_HIP_LAYER_NORMAL) ? 3 : ((layer == ETX_HIP_LAYER_ALBEDO) ? 0 : layer);
+  launch_film_resolve(context->read_stream, source, context->pipe.light_sum, context->read_resolve, uint32_t(n), scale, mode);
+  HIP_OK(context, hipMemcpyAsync(context->read_staging, context->read_resolve, n * sizeof(float4), hipMemcpyDeviceToHost, context->read_stream));
+  HIP_OK(context, hipEventRecord(context->read_event, context->read_stream));
+  context->read_pending = true;
+  return ETX_HIP_OK;
+}
+
+int etx_hip_read_film_end(etx_hip_context* context, float* dst_rgba, size_t dst_bytes, int wait) {
+  if ((context == nullptr) || (dst_rgba == nullptr))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  if (context->read_pending == false) {
+    context->error = "etx_hip_read_film_end without etx_hip_read_film_begin";
+    return ETX_HIP_ERROR_STATE;
+  }
+  if (dst_bytes != context->read_pixels * sizeof(float4)) {
+    context->error = "etx_hip_read_film_end: dst_bytes must be width*height*16";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  HIP_OK(context, hipSetDevice(context->device));
+  if (wait) {
+    HIP_OK(context, hipEventSynchronize(context->read_event));
+  } else {
+    const hipError_t q = hipEventQuery(context->read_event);
+    if (q == hipErrorNotReady)
+      return 0;
+    HIP_OK(context, q);
+  }
+  memcpy(dst_rgba, context->read_staging, dst_bytes);
+  context->read_pending = false;
+  return 1;
 }
 
 int etx_hip_set_timers(etx_hip_context* context, uint32_t mask) {

@@ -125,6 +125,14 @@ int etx_hip_sync(etx_hip_context* context);
  * etx_hip_reduce_film was called, else by this context's own iterations. Synchronises the stream. */
 int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size_t dst_bytes);
 
+/* Asynchronous read-back: _begin enqueues the resolve and the device-to-host copy of `layer` on a stream of
+ * its own and returns at once, without waiting for iterations in flight (the sums hold completed iterations only, so the
+ * snapshot is a valid progressive image normalised by the iterations completed so far). _end copies the image out of the
+ * pinned staging buffer: wait = 0 never blocks (returns 0 while the copy is still running, 1 when dst has been filled),
+ * wait = 1 blocks until it has arrived. One read-back can be pending per context. */
+int etx_hip_read_film_begin(etx_hip_context* context, int layer);
+int etx_hip_read_film_end(etx_hip_context* context, float* dst_rgba, size_t dst_bytes, int wait);
+
 typedef struct etx_hip_stats_t {
   /* Integrator::Status (integrator.hxx:24-37) */
   double last_iteration_time; /* seconds, device time of the last finished iteration (HIP events) */

@@ -60,6 +60,8 @@ struct HIPBackendLibrary {
   decltype(&etx_hip_poll) poll = nullptr;
   decltype(&etx_hip_sync) sync = nullptr;
   decltype(&etx_hip_read_film) read_film = nullptr;
+  decltype(&etx_hip_read_film_begin) read_film_begin = nullptr;
+  decltype(&etx_hip_read_film_end) read_film_end = nullptr;
   decltype(&etx_hip_stats) stats = nullptr;
 
   static HIPBackendLibrary& get() {
@@ -96,6 +98,8 @@ struct HIPBackendLibrary {
     resolve(lib.poll, "etx_hip_poll");
     resolve(lib.sync, "etx_hip_sync");
     resolve(lib.read_film, "etx_hip_read_film");
+    resolve(lib.read_film_begin, "etx_hip_read_film_begin");
+    resolve(lib.read_film_end, "etx_hip_read_film_end");
     resolve(lib.stats, "etx_hip_stats");
     if (complete == false) {
       log::error("libetx_hip.so misses entry points of etx_hip.h");
@@ -156,6 +160,7 @@ struct HIPIntegratorBase : public Integrator {
     _status = {};
     submitted = 0;
     published = 0;
+    progressive_stage = 0;
     current_state = State::Running;
   }
 
@@ -186,8 +191,35 @@ struct HIPIntegratorBase : public Integrator {
       read_status();
       publish_film();
       current_state = State::Stopped;  // vcm_cpu.cxx:234
-    } else if (_status.completed_iterations >= published + kPublishInterval) {
-      publish_film();
+    } else {
+      progressive_publish();
+    }
+  }
+
+  // While rendering: the camera and the light layer are fetched one after the other with the asynchronous read-back
+  // (etx_hip_read_film_begin / _end with wait = 0: never blocks the caller's frame), then written to the Film.
+  void progressive_publish() {
+    auto& lib = HIPBackendLibrary::get();
+    const size_t pixels = size_t(rt.film().size().x) * rt.film().size().y;
+    if (progressive_stage == 0) {
+      if (_status.completed_iterations < published + kPublishInterval)
+        return;
+      camera.resize(pixels);
+      light.resize(pixels);
+      if (lib.read_film_begin(ctx, ETX_HIP_LAYER_CAMERA) == ETX_HIP_OK)
+        progressive_stage = 1;
+      progressive_iterations = _status.completed_iterations;
+    } else if (progressive_stage == 1) {
+      if (lib.read_film_end(ctx, &camera[0].x, pixels * sizeof(float4), 0) == 1)
+        progressive_stage = (writes_light_image() && (lib.read_film_begin(ctx, ETX_HIP_LAYER_LIGHT) == ETX_HIP_OK)) ? 2 : 3;
+    } else if (progressive_stage == 2) {
+      if (lib.read_film_end(ctx, &light[0].x, pixels * sizeof(float4), 0) == 1)
+        progressive_stage = 3;
+    }
+    if (progressive_stage == 3) {
+      write_layers_to_film(writes_light_image(), false);
+      published = progressive_iterations;
+      progressive_stage = 0;
     }
   }
 
@@ -278,7 +310,22 @@ struct HIPIntegratorBase : public Integrator {
     published = _status.completed_iterations;
     return;
 #endif
-    film.clear(Film::ClearCameraData | (writes_light_image() ? uint32_t(Film::ClearLightData) : 0u));
+    if (writes_light_image()) {
+      light.resize(pixels);
+      if (lib.read_film(ctx, ETX_HIP_LAYER_LIGHT, &light[0].x, pixels * sizeof(float4)) != ETX_HIP_OK) {
+        hip_report_error(lib.last_error(ctx));
+        return;
+      }
+    }
+    write_layers_to_film(writes_light_image(), aovs);
+    published = _status.completed_iterations;
+  }
+
+  // camera (+ light, + normal / albedo) buffers -> Film, through the per-pixel interface the reference has
+  void write_layers_to_film(bool with_light, bool aovs) {
+    Film& film = rt.film();
+    const uint2 dim = film.size();
+    film.clear(Film::ClearCameraData | (with_light ? uint32_t(Film::ClearLightData) : 0u));
     // rows of the device film are the Film's storage rows: storage row r holds pixel y = H - 1 - r (film.cxx:189)
     for (uint32_t row = 0; row < dim.y; ++row) {
       for (uint32_t x = 0; x < dim.x; ++x) {
@@ -291,12 +338,7 @@ struct HIPIntegratorBase : public Integrator {
       }
     }
     camera_updated = true;
-    if (writes_light_image()) {
-      light.resize(pixels);
-      if (lib.read_film(ctx, ETX_HIP_LAYER_LIGHT, &light[0].x, pixels * sizeof(float4)) != ETX_HIP_OK) {
-        hip_report_error(lib.last_error(ctx));
-        return;
-      }
+    if (with_light) {
       for (uint32_t row = 0; row < dim.y; ++row) {
         for (uint32_t x = 0; x < dim.x; ++x) {
           const float4& l = light[size_t(row) * dim.x + x];
@@ -307,7 +349,6 @@ struct HIPIntegratorBase : public Integrator {
       film.commit_light_iteration(0);
       light_updated = true;
     }
-    published = _status.completed_iterations;
   }
 
   // sample_blue_noise (path_tracing.cxx:173-178) is a function of (pixel & 127, sample & 255, dimension & 7) only and its
@@ -352,6 +393,7 @@ struct HIPIntegratorBase : public Integrator {
   etx_hip_context* ctx = nullptr;
   Status _status = {};
   uint32_t submitted = 0, published = 0;
+  uint32_t progressive_stage = 0, progressive_iterations = 0;  // asynchronous publish while rendering (progressive_publish)
   uint32_t uploaded_bluenoise_sets = 0;
   std::vector<float4> camera, light, normal, albedo;
   mutable bool camera_updated = false, light_updated = false;

@@ -560,3 +560,83 @@ def test_stochastic_alpha_in_traversal(etx, gpu_context, golden_dir):
     # filtering smooths the edges, the mean stays), opacity 0.85
     expected = 0.85 * (1.0 - np.pi * 20.0 / 256.0)
     assert abs(took_card.sum() / candidates.sum() - expected) < 0.02, (took_card.sum() / candidates.sum(), expected)
+
+
+def test_two_shards_with_uneven_iteration_counts(etx, golden_dir):
+    """Multi-GPU arithmetic on the one device a test box has: two contexts render the shards (first, stride) = (0, 2) and
+    (1, 2) of FIVE iterations - three and two iterations (SURVEY.md 8e "if G does not divide spp"). etx_hip_reduce_film
+    all-reduces per-rank SUMS and the iteration counter; the same on the host: sum of (mean x local count) / total count
+    must equal the single-context render of all five."""
+    from etx_tracer_amd import api, integrator as integ_mod
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_classic_128.etxscene"))
+    snap.samples = 5
+    options = integ_mod.vcm_options_from_dict({"vcm-blue_noise": False})
+    shards = []
+    for first in (0, 1):
+        ctx = api.Context(0)
+        ctx.upload_scene(snap)
+        ctx.begin_vcm(options, first_iteration=first, iteration_stride=2)
+        count = (5 - first + 1) // 2
+        for _ in range(count):
+            ctx.render_iteration()
+        ctx.sync()
+        ctx.reduce_film()  # no communicator: the identity, marks the film final
+        assert ctx.stats().completed_iterations == count
+        shards.append((count, ctx.read_film(api.LAYER_CAMERA), ctx.read_film(api.LAYER_LIGHT)))
+        ctx.close()
+    assert [s[0] for s in shards] == [3, 2]
+    camera = sum(c * cam for c, cam, _ in shards) / 5.0
+    light = sum(c * lt for c, _, lt in shards) / 5.0
+    whole_cam, whole_light, _, _ = render(etx, golden_dir, "cornell_classic_128", 5)
+    np.testing.assert_allclose(camera[..., :3], whole_cam[..., :3], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(light[..., :3], whole_light[..., :3], rtol=2e-4, atol=2e-5)
+
+
+def test_pool_overflow_is_reported_and_does_not_skip_the_reduce(etx, golden_dir, monkeypatch):
+    """A data-dependent pool overflow (one light vertex per path) fails the iteration with ETX_HIP_ERROR_OVERFLOW; the film
+    reduce still runs its collective part (single rank: identity) and returns that error instead of hanging its peers."""
+    from etx_tracer_amd import api, integrator as integ_mod
+    monkeypatch.setenv("ETX_HIP_LIGHT_VERTICES_PER_PATH", "1")
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_classic_128.etxscene"))
+    ctx = api.Context(0)
+    ctx.upload_scene(snap)
+    ctx.comm_init(0, 1, api.comm_unique_id(ctx.library))
+    ctx.begin_vcm(integ_mod.vcm_options_from_dict({"vcm-blue_noise": False}), first_iteration=0, iteration_stride=1)
+    ctx.render_iteration()
+    with pytest.raises(api.EtxHipError) as e:
+        ctx.reduce_film()
+    assert e.value.code == -6 and "overflow" in str(e.value)
+    assert ctx.stats().overflow_flags & 1
+    ctx.close()
+
+
+def test_asynchronous_film_readback(etx, golden_dir):
+    """etx_hip_read_film_begin / _end: the read-back runs on its own stream while iterations are in flight (a progressive
+    image of the completed iterations), never blocks with wait = 0, and after the last iteration equals etx_hip_read_film."""
+    from etx_tracer_amd import api, integrator as integ_mod
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_full_128.etxscene"))
+    ctx = api.Context(0)
+    ctx.upload_scene(snap)
+    ctx.begin_vcm(integ_mod.vcm_options_from_dict({"vcm-blue_noise": False}), first_iteration=0, iteration_stride=1)
+    progressive = None
+    for i in range(24):
+        ctx.render_iteration()
+        if i == 12:
+            ctx.read_film_begin(api.LAYER_RESULT)   # iterations are still running
+            with pytest.raises(api.EtxHipError):
+                ctx.read_film_begin(api.LAYER_RESULT)  # one read-back at a time
+    for _ in range(100000):
+        progressive = ctx.read_film_end(wait=False)
+        if progressive is not None:
+            break
+    assert progressive is not None and np.isfinite(progressive).all() and progressive[..., :3].mean() > 0.01
+    ctx.sync()
+    final = ctx.read_film(api.LAYER_RESULT)
+    ctx.read_film_begin(api.LAYER_RESULT)
+    again = ctx.read_film_end(wait=True)
+    np.testing.assert_array_equal(again, final)
+    # the progressive image estimates the same picture from the iterations that were complete at that moment (one at least)
+    assert abs(progressive[..., :3].mean() / final[..., :3].mean() - 1.0) < 0.25
+    with pytest.raises(api.EtxHipError):
+        ctx.read_film_end(wait=True)  # nothing pending
+    ctx.close()

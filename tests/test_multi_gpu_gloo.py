@@ -33,10 +33,23 @@ def worker(rank, world, port, total, h, w, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     first, stride, count = multi_gpu.shard_iterations(total, rank, world)
-    film = multi_gpu.FilmAccumulator(h, w)
+    from tests.film_accumulator import FilmAccumulator
+    film = FilmAccumulator(h, w)
     for k in range(count):
         film.add_iteration(*fake_iteration(first + k * stride, h, w))
     film.reduce()
+    # the id-broadcast plumbing of bench.py / a multi-GPU host: rank 0 makes the 128-byte id, everyone calls comm_init with it
+    calls = []
+
+    class StubContext:
+        library = None
+
+        def comm_init(self, r, w, unique_id):
+            calls.append((r, w, bytes(unique_id)))
+
+    received = multi_gpu.init_context_comm(StubContext(), rank, world, make_id=lambda: bytes(range(128)))
+    assert calls == [(rank, world, bytes(range(128)))] and bytes(received) == bytes(range(128))
+    assert multi_gpu.max_over_ranks(1.0 + rank) == float(world)  # the slowest rank's time
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), film.result().numpy())
     np.save(os.path.join(out_dir, "count%d.npy" % rank), film.iterations.numpy())
     dist.barrier()
@@ -58,7 +71,8 @@ def test_two_ranks_equal_one_rank(tmp_path):
     from etx_tracer_amd import multi_gpu
     total, h, w = 7, 12, 16  # odd count: ranks hold different numbers of iterations (SURVEY.md 8e "if G does not divide spp")
     mp.spawn(worker, args=(2, free_port(), total, h, w, str(tmp_path)), nprocs=2, join=True)
-    single = multi_gpu.FilmAccumulator(h, w)
+    from tests.film_accumulator import FilmAccumulator
+    single = FilmAccumulator(h, w)
     for it in range(total):
         single.add_iteration(*fake_iteration(it, h, w))
     expected = single.result().numpy()
