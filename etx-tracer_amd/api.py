@@ -7,7 +7,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 LAYER_CAMERA, LAYER_LIGHT, LAYER_RESULT, LAYER_NORMAL, LAYER_ALBEDO = 0, 1, 2, 3, 4
-INTEGRATOR_PT, INTEGRATOR_VCM = 0, 1
+INTEGRATOR_PT, INTEGRATOR_VCM, INTEGRATOR_BDPT = 0, 1, 2
+BDPT_MODE_PATH_TRACING, BDPT_MODE_LIGHT_TRACING, BDPT_MODE_FAST, BDPT_MODE_FULL = 0, 1, 2, 3
 
 # etx::VCMOptions bits (sources/etx/rt/shared/vcm_shared.hxx:24-37)
 VCM_CONNECT_TO_CAMERA = 1 << 0
@@ -72,6 +73,27 @@ class PTOptions(ctypes.Structure):
         o = PTOptions()
         o.path_per_iteration = 1
         o.nee = o.direct = o.mis = o.blue_noise = 1
+        return o
+
+
+class BDPTOptions(ctypes.Structure):
+    """etx_abi_bdpt_options: CPUBidirectionalImpl's option members (bidirectional.cxx:323-340, 1443-1466), 16 bytes."""
+    _fields_ = [
+        ("mode", ctypes.c_uint32),
+        ("direct_hit", ctypes.c_uint8),
+        ("connect_to_camera", ctypes.c_uint8),
+        ("connect_to_light", ctypes.c_uint8),
+        ("connect_vertices", ctypes.c_uint8),
+        ("mis", ctypes.c_uint8),
+        ("blue_noise", ctypes.c_uint8),
+        ("_pad", ctypes.c_uint8 * 6),
+    ]
+
+    @staticmethod
+    def default_values():
+        o = BDPTOptions()
+        o.mode = BDPT_MODE_FAST  # CPUBidirectionalImpl::mode, bidirectional.cxx:332
+        o.direct_hit = o.connect_to_camera = o.connect_to_light = o.connect_vertices = o.mis = o.blue_noise = 1
         return o
 
 
@@ -221,6 +243,9 @@ class Context:
 
     def begin_pt(self, options, first_iteration=0, iteration_stride=1):
         self._check(self.library.lib.etx_hip_begin(self.handle, INTEGRATOR_PT, ctypes.byref(options), ctypes.sizeof(options), first_iteration, iteration_stride))
+
+    def begin_bdpt(self, options, first_iteration=0, iteration_stride=1):
+        self._check(self.library.lib.etx_hip_begin(self.handle, INTEGRATOR_BDPT, ctypes.byref(options), ctypes.sizeof(options), first_iteration, iteration_stride))
 
     def render_iteration(self):
         self._check(self.library.lib.etx_hip_render_iteration(self.handle))

@@ -8,7 +8,7 @@ mkdir -p "$OBJ"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-unused-variable"
 pids=()
-for src in kernels_shade_camera_general.hip kernels_tail_camera_general.hip kernels_shade_light_general.hip kernels_tail_light_general.hip kernels_connect.hip kernels_pt.hip kernels_trace.hip kernels_vcm.hip kernels_tail.hip kernels_grid.hip host_scene.cpp host_api.cpp host_comm.cpp; do
+for src in kernels_shade_camera_general.hip kernels_tail_camera_general.hip kernels_shade_light_general.hip kernels_tail_light_general.hip kernels_connect.hip kernels_bdpt.hip kernels_pt.hip kernels_trace.hip kernels_vcm.hip kernels_tail.hip kernels_grid.hip host_scene.cpp host_api.cpp host_comm.cpp; do
   obj="$OBJ/${src%.*}.o"
   newest=$(ls -t "$HERE"/*.h "$HERE"/*.inl "$HERE/$src" "$HERE/../../include"/*.h "$HERE/build.sh" | head -1)
   if [ ! -f "$obj" ] || [ "$newest" -nt "$obj" ]; then

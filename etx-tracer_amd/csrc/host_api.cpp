@@ -65,6 +65,7 @@ struct etx_hip_context {
   int integrator = ETX_HIP_INTEGRATOR_VCM;
   etx_abi_vcm_options vcm_options = {};
   etx_abi_pt_options pt_options = {};
+  etx_abi_bdpt_options bdpt_options = {};
   float4* pt_iteration_image = nullptr;  // camera and light contributions of the iteration this lane renders (2 x pixels), committed to the film at its end
   uint32_t first_iteration = 0, iteration_stride = 1;
   uint32_t next_iteration = 0;       // iteration index to render next
@@ -178,7 +179,8 @@ int allocate_pipeline(etx_hip_context* ctx) {
   int rc = 0;
   for (int s = 0; s < 2; ++s) {
     if ((rc = device_alloc(ctx, p.paths[s].ray_o_tmin, n)) || (rc = device_alloc(ctx, p.paths[s].ray_d_tmax, n)) || (rc = device_alloc(ctx, p.paths[s].thr_eta, n)) ||
-        (rc = device_alloc(ctx, p.paths[s].mis, n)) || (rc = device_alloc(ctx, p.paths[s].meta, n)) || (rc = device_alloc(ctx, p.paths[s].path_id, n)) || (rc = device_alloc(ctx, p.paths[s].wavelength, n)))
+        (rc = device_alloc(ctx, p.paths[s].mis, n)) || (rc = device_alloc(ctx, p.paths[s].meta, n)) || (rc = device_alloc(ctx, p.paths[s].path_id, n)) || (rc = device_alloc(ctx, p.paths[s].wavelength, n)) ||
+        (rc = device_alloc(ctx, p.paths[s].prev_pos, n)) || (rc = device_alloc(ctx, p.paths[s].prev_nrm, n)))
       return rc;
   }
   if ((rc = device_alloc(ctx, p.hits, n)))
@@ -537,6 +539,89 @@ int render_pt_iteration(etx_hip_context* ctx, uint32_t iteration) {
   return 0;
 }
 
+// One bidirectional iteration (CPUBidirectionalImpl::execute_range over all pixels, bidirectional.cxx:352-403): the emitter
+// sub paths of all pixels, then the camera sub paths; every connection's visibility goes through the shadow queue.
+int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
+  const auto& o = ctx->bdpt_options;
+  VcmParams it = {};
+  it.options = (o.connect_to_camera ? ETX_VCM_CONNECT_TO_CAMERA : 0u) | (o.direct_hit ? ETX_VCM_DIRECT_HIT : 0u) | (o.connect_to_light ? ETX_VCM_CONNECT_TO_LIGHT : 0u) |
+               (o.connect_vertices ? ETX_VCM_CONNECT_VERTICES : 0u) | (o.mis ? ETX_VCM_ENABLE_MIS : 0u);
+  it.kernel = o.mode;  // CPUBidirectionalImpl::Mode
+  it.iteration = iteration;
+  it.film_w = ctx->scene.film_w, it.film_h = ctx->scene.film_h;
+  it.path_count = it.film_w * it.film_h;
+  it.bluenoise = reinterpret_cast<const uint2*>(ctx->active_bluenoise);
+  Pipeline p = ctx->pipe;  // iteration images, as in render_vcm_iteration
+  p.camera_sum = ctx->pt_iteration_image;
+  p.light_sum = ctx->pt_iteration_image + p.capacity;
+  hipStream_t s = ctx->stream;
+  const bool flat = ctx->scene.host_copy.bvh_flat != 0u;
+  uint64_t rounds = 0;
+  int rc = 0;
+
+  launch_iteration_reset(s, p);
+  // build_emitter_path, :379 (mode != PathTracing)
+  if (o.mode != ETX_BDPT_MODE_PATH_TRACING) {
+    {
+      ScopedTimer t(ctx, kTimerGenerate);
+      launch_bdpt_light_generate(s, p, it);
+    }
+    const bool to_camera = o.connect_to_camera != 0;
+    rc = run_bounce_loop(
+      ctx,
+      [&](uint32_t set, uint32_t max_items) {
+        {
+          ScopedTimer t(ctx, kTimerShadeLight);
+          launch_bdpt_light_shade(s, p, it, set, max_items);
+          if (to_camera)
+            launch_bdpt_connect_camera(s, p, it, max_items);
+        }
+        if (to_camera) {
+          ScopedTimer t(ctx, kTimerTraceShadow);
+          launch_trace_shadow(s, p, uint32_t(std::min<uint64_t>(uint64_t(max_items) * 2ull, p.shadow.capacity)), flat);
+        }
+      },
+      [&](uint32_t, uint32_t) {}, rounds, kStatRaysLight, false);
+    if (rc)
+      return rc;
+  }
+  // build_camera_path, :388 (mode != LightTracing)
+  if (o.mode != ETX_BDPT_MODE_LIGHT_TRACING) {
+    {
+      ScopedTimer t(ctx, kTimerGenerate);
+      launch_bdpt_camera_generate(s, p, it);
+    }
+    const bool to_light = o.connect_to_light != 0;
+    const bool vertices = (o.connect_vertices != 0) && (o.mode == ETX_BDPT_MODE_FULL);
+    rc = run_bounce_loop(
+      ctx,
+      [&](uint32_t set, uint32_t max_items) {
+        {
+          ScopedTimer t(ctx, kTimerShadeCamera);
+          launch_bdpt_camera_shade(s, p, it, set, max_items);
+          if (to_light)
+            launch_bdpt_connect_light(s, p, it, max_items);
+        }
+        if (vertices) {
+          ScopedTimer t(ctx, kTimerConnect);
+          launch_expand_pairs(s, p, it, max_items);
+          launch_bdpt_connect_pairs(s, p, it, max_items);
+        }
+        if (to_light || vertices) {
+          ScopedTimer t(ctx, kTimerTraceShadow);
+          launch_trace_shadow(s, p, uint32_t(std::min<uint64_t>(uint64_t(max_items) * 6ull, p.shadow.capacity)), flat);
+        }
+      },
+      [&](uint32_t, uint32_t) {}, rounds, kStatRaysCamera, false);
+    if (rc)
+      return rc;
+  }
+  launch_vcm_commit(s, p.camera_sum, p.light_sum, ctx->pipe.camera_sum, ctx->pipe.light_sum, p.capacity);
+  launch_stats_finalize(s, p);
+  ctx->stats.wavefront_bounces = rounds;
+  return 0;
+}
+
 void collect_stats(etx_hip_context* ctx) {
   auto& st = ctx->stats;
   double ms[kTimerCount] = {};
@@ -591,7 +676,9 @@ int execute_iteration(etx_hip_context* lane, uint32_t iteration) {
   HIP_OK(lane, hipEventRecord(lane->iteration_begin, lane->stream));
   lane->stats = {};
   lane->stats.current_iteration = iteration;
-  int rc = (lane->integrator == ETX_HIP_INTEGRATOR_PT) ? render_pt_iteration(lane, iteration) : render_vcm_iteration(lane, iteration);
+  int rc = (lane->integrator == ETX_HIP_INTEGRATOR_PT)     ? render_pt_iteration(lane, iteration)
+           : (lane->integrator == ETX_HIP_INTEGRATOR_BDPT) ? render_bdpt_iteration(lane, iteration)
+                                                           : render_vcm_iteration(lane, iteration);
   if (rc)
     return rc;
   HIP_OK(lane, hipEventRecord(lane->iteration_end, lane->stream));
@@ -953,6 +1040,27 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
       if (rc)
         return rc;
     }
+  } else if (integrator == ETX_HIP_INTEGRATOR_BDPT) {
+    if ((options == nullptr) || (options_size != sizeof(etx_abi_bdpt_options))) {
+      context->error = "BDPT expects etx_abi_bdpt_options (16 bytes)";
+      return ETX_HIP_ERROR_INVALID_ARGUMENT;
+    }
+    memcpy(&context->bdpt_options, options, sizeof(etx_abi_bdpt_options));
+    const uint32_t mode = context->bdpt_options.mode;
+    if ((mode != ETX_BDPT_MODE_PATH_TRACING) && (mode != ETX_BDPT_MODE_LIGHT_TRACING) && (mode != ETX_BDPT_MODE_FULL)) {
+      context->error = (mode == ETX_BDPT_MODE_FAST) ? "bdpt-mode BDPTFast (experimental in the reference) is not implemented by the device path" : "bdpt-mode: unknown value";
+      return ETX_HIP_ERROR_UNSUPPORTED;
+    }
+    if (context->scene.group_subsurface) {
+      context->error = "bidirectional integrator: scenes with random-walk subsurface materials are not implemented by the device path (use VCM or path tracing)";
+      return ETX_HIP_ERROR_UNSUPPORTED;
+    }
+    context->active_bluenoise = nullptr;
+    if (context->bdpt_options.blue_noise) {
+      int rc = select_bluenoise(context, "bdpt-blue_noise");
+      if (rc)
+        return rc;
+    }
   } else {
     context->error = "integrator " + std::to_string(integrator) + " is not implemented by the device path";
     return ETX_HIP_ERROR_UNSUPPORTED;
@@ -996,6 +1104,7 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
     helper->integrator = integrator;
     helper->vcm_options = context->vcm_options;
     helper->pt_options = context->pt_options;
+    helper->bdpt_options = context->bdpt_options;
     helper->active_bluenoise = context->active_bluenoise;
   }
   const size_t n = size_t(context->pipe.capacity);

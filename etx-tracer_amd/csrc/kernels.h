@@ -42,6 +42,16 @@ void launch_pt_commit(hipStream_t stream, float4* iteration_image, float4* camer
 void launch_light_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups);
 void launch_camera_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups);
 
+// bidirectional path tracing (kernels_bdpt.hip)
+void launch_bdpt_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
+void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items);
+void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items);
+void launch_bdpt_camera_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
+void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items);
+void launch_bdpt_connect_light(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items);
+void launch_bdpt_connect_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items);
+void launch_expand_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items);  // kernels_connect.hip
+
 // photon grid
 void launch_grid_build(hipStream_t stream, const Pipeline& p, const VcmParams& it);
 

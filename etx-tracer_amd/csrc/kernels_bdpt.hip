@@ -1,0 +1,664 @@
+// kernels_bdpt.hip - bidirectional path tracing (CPUBidirectional, sources/etx/rt/integrators/bidirectional.cxx) on the
+// wavefront pipeline. Kernel sequence of one iteration (host_api.cpp render_bdpt_iteration):
+//   k_bdpt_light_generate                                   build_emitter_path, start            (:955-1010)
+//   loop: k_trace_closest ; k_bdpt_light_shade ;            build_path, Light mode               (:820-898, handle_surface :572-702,
+//         k_bdpt_connect_camera ; k_trace_shadow                                                   handle_medium :533-570, connect_light_to_camera :1380-1428)
+//   k_bdpt_camera_generate                                  build_camera_path, start             (:900-953)
+//   loop: k_trace_closest ; k_bdpt_camera_shade ;           build_path, Camera mode + direct hits (:1235-1340)
+//         k_bdpt_connect_light ;                            connect_camera_to_light              (:1342-1378)
+//         k_expand_pairs ; k_bdpt_connect_pairs ;           connect_camera_to_light_path         (:438-497, MIS :1184-1209)
+//         k_trace_shadow
+//   k_vcm_commit                                            Film::commit_light_iteration + the iteration's camera estimate
+// dev_bdpt.h explains the data layout. All BSDF classes go through the out-of-line dispatch (dev_bsdf_ool.h).
+#include "kernels.h"
+#include "dev_bdpt.h"
+
+namespace etxd {
+
+static uint32_t grid_for(uint32_t capacity) {
+  return min(kPersistentBlocks, (capacity + kBlockSize - 1) / kBlockSize);
+}
+
+ETX_DEV uint32_t bdpt_mode(const VcmParams& it) {
+  return it.kernel;  // the host passes CPUBidirectionalImpl::Mode here (VcmParams is shared with VCM)
+}
+
+// Film::sample, film.cxx:137-145 (the pixel filter of PT / BDPT; the first iteration uses PixelFilter::empty())
+ETX_DEV f2 bdpt_film_sample(const DScene& scene, bool filtered, uint32_t px, uint32_t py, const VcmParams& it, const f2 rnd) {
+  f2 jitter = {rnd.x * 2.0f - 1.0f, rnd.y * 2.0f - 1.0f};
+  float radius = 0.0f;
+  if (filtered) {
+    radius = scene.pixel_sampler_radius;
+    if (scene.pixel_sampler_image != kInvalid) {
+      float pdf = 0.0f;
+      float4 eval;
+      const f2 uv = image_sample(scene.images[scene.pixel_sampler_image], rnd, pdf, eval);
+      jitter = {uv.x * 2.0f - 1.0f, uv.y * 2.0f - 1.0f};
+    }
+  }
+  return {(float(px) + 0.5f + radius * jitter.x) / float(it.film_w) * 2.0f - 1.0f, (float(py) + 0.5f + radius * jitter.y) / float(it.film_h) * 2.0f - 1.0f};
+}
+
+// bsdf::albedo (scene_bsdf.hxx:95-107), as kernels_pt.hip
+ETX_DEV f3 bdpt_albedo(const DScene& scene, const etx_abi_material& mat, const f2 tex, float wavelength) {
+  switch (mat.cls) {
+    case ETX_MAT_CONDUCTOR:
+      return apply_image(scene, mat.reflectance, tex, nullptr, wavelength);
+    case ETX_MAT_MIRROR:
+    case ETX_MAT_BOUNDARY:
+      return mk3(1.0f);
+    case ETX_MAT_VOID:
+      return mk3(0.0f);
+    default:
+      return apply_image(scene, mat.scattering, tex, nullptr, wavelength);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// build_emitter_path, bidirectional.cxx:955-1010
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_light_generate(Pipeline p, VcmParams it) {
+  __shared__ BlockScratch s_scratch;
+  const DScene& scene = p.scene;
+  ETX_BLOCK_LOOP(it.path_count, i) {
+    bool valid = false;
+    BdptState st = {};
+    if (i < it.path_count) {
+      st.sampler.init(i, it.iteration);
+      st.id = i;
+      st.wavelength = scene.spectral ? spectral_sample_wavelength(st.sampler.next()) : 0.0f;
+      p.path_wavelength[i] = st.wavelength;
+      const EmitterSample es = sample_emission(scene, st.sampler, st.wavelength);
+      if ((es.pdf_area != 0.0f) && (es.pdf_dir != 0.0f) && (is_zero(es.value) == false)) {
+        st.throughput = es.value * (dot(es.direction, es.normal) / (es.pdf_dir * es.pdf_area * es.pdf_sample));
+        st.ray_o = offset_ray(es.origin, es.normal);
+        st.ray_d = es.direction;
+        st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+        st.eta = 1.0f;
+        st.pdf_dir = es.pdf_dir;
+        st.mis_history = 0.0f;
+        st.aux = es.pdf_area;
+        st.path_size = 1u;
+        st.medium = es.medium_index;
+        st.flags = kBpFirst | (es.is_distant ? kBpDistantEmitter : 0u) | (es.emitter_index << kBpEmitterShift);
+        // the emitter vertex itself = emitter_path[0]
+        st.prev.pos = es.origin, st.prev.nrm = es.normal;
+        st.prev.from_prev = es.pdf_area * es.pdf_sample;
+        st.prev.flags = kBvEmitter | kBvConnectible | (es.is_delta ? 0u : kBvMisConnectible) | ((es.triangle_index != kInvalid) ? kBvSurface : 0u);
+        st.prev.tri = es.triangle_index;
+        valid = true;
+      }
+    }
+    const uint32_t slot = block_compact_slot(valid, p.counters + kCntActiveA, s_scratch);
+    if (valid)
+      bdpt_store(p.paths[0], slot, st, st.prev.tri);  // until the emitter vertex is in the pool the slot field carries its triangle
+  }
+}
+
+// One segment of an emitter path after the closest-hit query.
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, VcmParams it, uint32_t in_set) {
+  __shared__ BlockScratch s_scratch;
+  const DScene& scene = p.scene;
+  const PathSet& in = p.paths[in_set];
+  const PathSet& out = p.paths[in_set ^ 1u];
+  const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
+  uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
+  const uint32_t mode = bdpt_mode(it);
+  ETX_BLOCK_LOOP(count, i) {
+    const bool valid = i < count;
+    BdptState st = {};
+    bool alive = false, store_emitter = false, store_vertex = false;
+    // the vertex created by this segment
+    f3 v_pos = mk3(0.0f), v_nrm = mk3(0.0f), v_wi = mk3(0.0f), v_throughput = mk3(0.0f);
+    float v_from_prev = 0.0f, v_bc_u = 0.0f, v_bc_v = 0.0f;
+    uint32_t v_flags = 0u, v_tri = kInvalid, v_medium = kInvalid;
+    BVtx emitter_vertex = {};
+    if (valid) {
+      st = bdpt_load(in, i);
+      uint32_t emitter_tri = kInvalid;
+      if (st.flags & kBpFirst) {
+        emitter_tri = st.prev_slot;  // see k_bdpt_light_generate
+        st.prev.tri = emitter_tri;
+        st.prev_slot = kInvalid;
+      }
+      const float4 h = p.hits[i];
+      const uint32_t tri = __float_as_uint(h.w);
+      const bool found = tri != kInvalid;
+      // regular_step, bidirectional.cxx:712-727
+      MediumSample ms;
+      ms.sampled_medium_t = 0.0f;
+      if (st.medium != kInvalid) {
+        ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+        st.throughput *= ms.weight;
+      }
+      const bool first = (st.flags & kBpFirst) != 0u;
+      if (ms.sampled_medium()) {  // handle_medium, :533-570
+        const DMedium& med = scene.mediums[st.medium];
+        const f2 rnd_bsdf = st.sampler.next_2d();
+        (void)st.sampler.next_2d();
+        (void)st.sampler.next_2d();
+        const f3 w_o = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
+        const float pdf_fwd = phase_function(st.ray_d, w_o, med.g);
+        const float pdf_bck = phase_function(w_o, st.ray_d, med.g);
+        st.path_size += 1u;
+        BVtx curr = {ms.pos, mk3(0.0f), 0.0f, 0.0f, kBvMedium | kBvConnectible | ((st.prev.flags & kBvConnectible) ? kBvMisConnectible : 0u), kInvalid};
+        curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
+        float prev_from_next = bdpt_to_area(pdf_bck, ms.pos, st.prev);
+        if (first && (st.flags & kBpDistantEmitter)) {  // update_distant_emitter_path_pdfs, :423-436
+          st.prev.from_prev = bdpt_emitter_sample_pdf(scene, scene.emitters[st.flags >> kBpEmitterShift], -st.ray_d);
+          curr.from_prev = st.aux;
+        }
+        v_pos = ms.pos, v_wi = st.ray_d, v_throughput = st.throughput, v_from_prev = curr.from_prev, v_flags = curr.flags, v_medium = st.medium;
+        if (med.explicit_connections == 0u)
+          v_flags |= kBvNoCameraConnection;  // handle_medium skips connect() for it; camera paths still connect TO it
+        st.ray_o = ms.pos, st.ray_d = w_o, st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+        st.pdf_dir = pdf_fwd;
+        emitter_vertex = st.prev;
+        bdpt_advance_history(st, prev_from_next, false, mode);
+        emitter_vertex.history = st.prev.history;
+        store_emitter = first, store_vertex = true;
+        st.prev = curr;
+        st.prev.flags = curr.flags;
+        st.flags &= ~kBpFirst;
+        alive = random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
+      } else if (found) {
+        Isect isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
+        const etx_abi_material& mat = scene.materials[isect.material];
+        const f2 rnd_bsdf = st.sampler.next_2d();
+        (void)st.sampler.next_2d();
+        const f2 rnd_support = st.sampler.next_2d();
+        if (mat.cls == ETX_MAT_BOUNDARY) {  // handle_surface :586-593: the path length does not change
+          const etx_abi_triangle& t = scene.triangles[isect.tri];
+          st.medium = (dot(ld3(t.geo_n), st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
+          st.ray_o = shading_pos(scene, t, isect.bc, st.ray_d);
+          st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+          alive = true;
+        } else {
+          const BsdfData data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight, st.wavelength);
+          st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
+          const BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
+          st.sampler.pop_fixed();
+          st.path_size += 1u;
+          const bool connectible = (bs.properties & kSampleDelta) == 0u;
+          BVtx curr = {isect.pos, isect.nrm, 0.0f, 0.0f,
+            kBvSurface | (connectible ? kBvConnectible : 0u) | ((connectible && (st.prev.flags & kBvConnectible)) ? kBvMisConnectible : 0u), isect.tri};
+          curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
+          const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, data, bs.w_o, mat, st.sampler);
+          const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
+          const uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
+          v_pos = isect.pos, v_nrm = isect.nrm, v_wi = isect.w_i, v_throughput = st.throughput, v_flags = curr.flags, v_tri = isect.tri, v_bc_u = isect.bc.y, v_bc_v = isect.bc.z;
+          v_medium = vertex_medium;
+          st.medium = vertex_medium;
+          bool terminate = false;
+          if (bs.valid()) {
+            st.pdf_dir = bs.pdf;
+            st.throughput *= bs.weight;
+            const etx_abi_triangle& t = scene.triangles[isect.tri];
+            st.ray_o = shading_pos(scene, t, isect.bc, bs.w_o);
+            st.ray_d = bs.w_o;
+            st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+            st.throughput *= fix_shading_normal(ld3(t.geo_n), isect.nrm, isect.w_i, bs.w_o);
+          } else {
+            terminate = true;
+          }
+          if (first && (st.flags & kBpDistantEmitter)) {  // update_distant_emitter_path_pdfs
+            st.prev.from_prev = bdpt_emitter_sample_pdf(scene, scene.emitters[st.flags >> kBpEmitterShift], -isect.w_i);
+            curr.from_prev = st.aux * fabsf(dot(isect.w_i, ld3(scene.triangles[isect.tri].geo_n)));
+          }
+          v_from_prev = curr.from_prev;
+          emitter_vertex = st.prev;
+          bdpt_advance_history(st, prev_from_next, false, mode);
+          emitter_vertex.history = st.prev.history;
+          store_emitter = first, store_vertex = true;
+          st.prev = curr;
+          st.flags &= ~kBpFirst;
+          alive = (terminate == false) && random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
+        }
+      }
+    }
+    // pool slots: the emitter vertex (first interaction only), then the new vertex
+    const uint32_t emitter_slot = block_compact_slot(store_emitter, p.counters + kCntLightVertices, s_scratch);
+    const uint32_t vertex_slot = block_compact_slot(store_vertex, p.counters + kCntLightVertices, s_scratch);
+    if (store_emitter)
+      bdpt_store_light_vertex(p, emitter_slot, st.id, emitter_vertex.pos, emitter_vertex.nrm, mk3(0.0f), mk3(0.0f), emitter_vertex.from_prev, emitter_vertex.history, emitter_vertex.flags,
+        emitter_vertex.tri, 0.0f, 0.0f, 0u, 1u, kInvalid, kInvalid, st.wavelength, 0u);
+    if (store_vertex) {
+      const uint32_t previous = store_emitter ? emitter_slot : st.prev_slot;
+      Sampler derived;
+      derived.init(st.sampler.seed, 0x62647074u);
+      // history of the new vertex = the path's running history now (dev_bdpt.h)
+      bdpt_store_light_vertex(p, vertex_slot, st.id, v_pos, v_nrm, v_wi, v_throughput, v_from_prev, st.mis_history, v_flags, v_tri, v_bc_u, v_bc_v, st.path_size - 1u, st.path_size, v_medium,
+        previous, st.wavelength, derived.seed);
+      st.prev_slot = vertex_slot;
+    }
+    const uint32_t slot = block_compact_slot(alive, out_counter, s_scratch);
+    if (alive)
+      bdpt_store(out, slot, st, (st.flags & kBpFirst) ? st.prev.tri : st.prev_slot);
+  }
+}
+
+// connect_light_to_camera (:1380-1428) for the vertices the light pass stored in this bounce
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_camera(Pipeline p, VcmParams it) {
+  __shared__ BlockScratch s_scratch;
+  const DScene& scene = p.scene;
+  const uint32_t begin = p.counters[kCntLightBounceBegin];
+  const uint32_t end = min(p.counters[kCntLightVertices], p.lv.capacity);
+  const uint32_t count = (end > begin) ? (end - begin) : 0u;
+  const uint32_t mode = bdpt_mode(it);
+  ETX_BLOCK_LOOP(count, j) {
+    ShadowRequest request;
+    bool queue = false;
+    if (j < count) {
+      const uint32_t vi = begin + j;
+      const uint32_t flags = __float_as_uint(p.lv.thr_dvm(vi).w);
+      const uint32_t index_in_path = __float_as_uint(p.lv.bc_len_med(vi).z) >> 16u;
+      if ((flags & kBvConnectible) && ((flags & kBvNoCameraConnection) == 0u) && (index_in_path >= 1u) && opt_connect_to_camera(it)) {
+        BdptLightVertex y = bdpt_load_light_vertex(p, scene, vi);
+        const uint32_t target_path_length = y.path_size;  // emitter_path_length() + 1
+        if ((target_path_length <= scene.max_path_length) && (target_path_length >= scene.min_path_length)) {
+          Sampler smp;
+          smp.seed = y.seed, smp.fixed_u = smp.fixed_v = smp.fixed_w = 0.0f;
+          const CameraSample cs = sample_film(scene, smp, y.self.pos);
+          const float len = length(cs.position - y.self.pos);
+          const float cos_t = fabsf(dot(cs.direction, scene.camera.direction));
+          const float near_extent = (scene.camera.clip_near > 0.0f) ? scene.camera.clip_near / cos_t : 0.0f;
+          const float far_extent = (scene.camera.clip_far > 0.0f) ? scene.camera.clip_far / cos_t : kMaxFloat;
+          if ((cs.pdf_dir > 0.0f) && (len >= near_extent) && (len <= far_extent)) {
+            const BdptBsdf bsdf = bdpt_bsdf(scene, y.full, kPathLight, cs.direction, y.wavelength, smp);
+            if (is_zero(bsdf.bsdf) == false) {
+              float weight = 1.0f;
+              if (opt_enable_mis(it) && (mode != kBdptLightTracing)) {  // mis_weight_light_to_camera, :1135-1182 (Full)
+                const BVtx y_prev = bdpt_load_light_summary(p, y.prev);
+                const BVtx camera_vertex = {cs.position, cs.normal, 0.0f, 0.0f, 0u, kInvalid};
+                const float cos_c = dot(normalize(y.self.pos - scene.camera.position), scene.camera.direction);
+                const float film_pdf = 1.0f / fabsf(scene.camera.area * cos_c * cos_c * cos_c);  // film_pdf_out, scene_camera.hxx:20-24
+                const float curr_from_camera = bdpt_to_area(film_pdf, cs.position, y.self);
+                const float prev_from_curr = bdpt_pdf_area(scene, kPathCamera, cs.position, y.full, y_prev, y.wavelength, smp);
+                weight = 1.0f / (1.0f + bdpt_mis_light(curr_from_camera, y.self.from_prev, prev_from_curr, y_prev));
+              }
+              const f3 splat = y.throughput * bsdf.bsdf * (cs.weight * weight) * spectral_film_weight(scene, y.wavelength);
+              const uint32_t x = static_cast<uint32_t>((cs.uv.x * 0.5f + 0.5f) * float(it.film_w));
+              const uint32_t yy = static_cast<uint32_t>((cs.uv.y * 0.5f + 0.5f) * float(it.film_h));
+              if ((x < it.film_w) && (yy < it.film_h) && (is_zero(splat) == false)) {
+                const f3 clip_pos = y.self.pos + cs.direction * fmaxf(0.0f, len - near_extent);
+                request = {bdpt_segment_origin(scene, y.full, clip_pos), clip_pos, splat, y.medium, kShadowTargetLight | (x + (it.film_h - 1u - yy) * it.film_w), y.wavelength};
+                queue = true;
+              }
+            }
+          }
+        }
+      }
+    }
+    const uint32_t slot = block_compact_slot(queue, p.counters + kCntShadow, s_scratch);
+    if (queue)
+      write_shadow(p, slot, request);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// build_camera_path, bidirectional.cxx:900-953 (+ execute_range :366-409)
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_generate(Pipeline p, VcmParams it) {
+  const DScene& scene = p.scene;
+  const uint32_t mode = bdpt_mode(it);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < it.path_count; i += gridDim.x * blockDim.x) {
+    BdptState st = {};
+    st.id = i;
+    // the reference seeds the camera sampler like the light sampler of the same pixel (:377-378); the device gives the
+    // camera path a stream of its own (as for VCM, kernels_vcm.hip k_camera_generate and DESIGN.md 4)
+    st.sampler.init(i, it.iteration);
+    st.sampler.seed = Sampler::random_seed(st.sampler.seed, 0x43414d45u);
+    st.wavelength = 0.0f;
+    if (scene.spectral) {
+      const float u = st.sampler.next();
+      st.wavelength = (mode == kBdptPathTracing) ? spectral_sample_wavelength(u) : p.path_wavelength[i];
+    }
+    const uint32_t px = i % it.film_w, py = i / it.film_w;
+    const f2 uv = bdpt_film_sample(scene, it.iteration != 0u, px, py, it, st.sampler.next_2d());
+    const RayGen r = generate_ray(scene, uv, st.sampler.next_2d());
+    st.ray_o = r.o, st.ray_d = r.d, st.ray_tmin = r.tmin, st.ray_tmax = r.tmax;
+    st.throughput = mk3(1.0f);
+    st.eta = 1.0f;
+    st.pdf_dir = film_evaluate_out_pdf_dir(scene, st.ray_d);
+    st.mis_history = 0.0f;
+    st.aux = 0.0f;
+    st.path_size = 1u;
+    st.medium = scene.camera.medium_index;
+    st.flags = kBpFirst;
+    st.prev = {r.o, scene.camera.direction, 1.0f, 0.0f, kBvConnectible | kBvMisConnectible, kInvalid};
+    bdpt_store(p.paths[0], i, st, kInvalid);
+  }
+  if ((blockIdx.x == 0) && (threadIdx.x == 0))
+    p.counters[kCntActiveA] = it.path_count;
+}
+
+// mis_weight_direct_hit (Full), bidirectional.cxx:1211-1233
+ETX_DEV float bdpt_direct_hit_weight(const BdptState& st, float z_curr_from_prev, float p_sample, float p_from) {
+  return 1.0f / (1.0f + bdpt_mis_camera(st.path_size, p_sample, z_curr_from_prev, p_from, st.prev));
+}
+
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, VcmParams it, uint32_t in_set) {
+  __shared__ BlockScratch s_scratch;
+  const DScene& scene = p.scene;
+  const PathSet& in = p.paths[in_set];
+  const PathSet& out = p.paths[in_set ^ 1u];
+  const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
+  uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
+  const uint32_t mode = bdpt_mode(it);
+  const bool use_mis = opt_enable_mis(it);
+  ETX_BLOCK_LOOP(count, i) {
+    const bool valid = i < count;
+    BdptState st = {};
+    // what the segment did: `created` = a path vertex (curr) exists and becomes prev; `store_vertex` = it is connectible and
+    // goes to the camera vertex pool (the record reads z_prev = st.prev, so prev is replaced AFTER the store)
+    bool alive = false, created = false, store_vertex = false, terminate = false;
+    BVtx curr = {};
+    float4 v_hit = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
+    f3 v_wi = mk3(0.0f), v_throughput = mk3(0.0f), v_rnd = mk3(0.0f);
+    uint32_t v_medium = kInvalid;
+    if (valid) {
+      st = bdpt_load(in, i);
+      st.prev.tri = st.prev_slot;  // camera paths carry the previous vertex' triangle there
+      const float4 h = p.hits[i];
+      const uint32_t tri = __float_as_uint(h.w);
+      const bool found = tri != kInvalid;
+      const uint32_t film_target = film_index(it, st.id);
+      const f3 film_weight = spectral_film_weight(scene, st.wavelength);
+      MediumSample ms;
+      ms.sampled_medium_t = 0.0f;
+      if (st.medium != kInvalid) {
+        ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+        st.throughput *= ms.weight;
+      }
+      const bool first = (st.flags & kBpFirst) != 0u;
+      if (ms.sampled_medium()) {  // handle_medium, :533-570
+        const DMedium& med = scene.mediums[st.medium];
+        f2 rnd_bsdf = st.sampler.next_2d();
+        f2 rnd_em = st.sampler.next_2d();
+        f2 rnd_support = st.sampler.next_2d();
+        if ((it.bluenoise != nullptr) && first && (it.iteration < 256u))
+          bluenoise_samples(it.bluenoise, st.id % it.film_w, st.id / it.film_w, it.iteration, rnd_bsdf, rnd_em, rnd_support);
+        const f3 w_o = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
+        const float pdf_fwd = phase_function(st.ray_d, w_o, med.g);
+        const float pdf_bck = phase_function(w_o, st.ray_d, med.g);
+        st.path_size += 1u;
+        curr = {ms.pos, mk3(0.0f), 0.0f, 0.0f, kBvMedium | kBvConnectible | ((st.prev.flags & kBvConnectible) ? kBvMisConnectible : 0u), kInvalid};
+        curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
+        const float prev_from_next = bdpt_to_area(pdf_bck, ms.pos, st.prev);
+        v_hit = mk4(ms.pos, __uint_as_float(kInvalid)), v_wi = st.ray_d, v_throughput = st.throughput, v_medium = st.medium;
+        v_rnd = {rnd_em.x, rnd_em.y, rnd_support.y};
+        st.ray_o = ms.pos, st.ray_d = w_o, st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+        st.pdf_dir = pdf_fwd;
+        bdpt_advance_history(st, prev_from_next, true, mode);
+        created = true;
+        store_vertex = (med.explicit_connections != 0u) && (mode != kBdptLightTracing);
+      } else if (found) {
+        const Isect isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
+        const etx_abi_material& mat = scene.materials[isect.material];
+        f2 rnd_bsdf = st.sampler.next_2d();
+        f2 rnd_em = st.sampler.next_2d();
+        f2 rnd_support = st.sampler.next_2d();
+        if ((it.bluenoise != nullptr) && first)
+          bluenoise_samples(it.bluenoise, st.id % it.film_w, st.id / it.film_w, it.iteration, rnd_bsdf, rnd_em, rnd_support);
+        if (mat.cls == ETX_MAT_BOUNDARY) {  // handle_surface :586-593: no vertex, the path length does not change
+          const etx_abi_triangle& t = scene.triangles[isect.tri];
+          st.medium = (dot(ld3(t.geo_n), st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
+          st.ray_o = shading_pos(scene, t, isect.bc, st.ray_d);
+          st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+          alive = true;
+        } else {
+          const BsdfData data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera, st.wavelength);
+          if ((st.flags & kBpGBuffer) == 0u) {  // GBuffer, :597-601
+            film_add(p, p.normal_sum + film_target, isect.nrm);
+            film_add(p, p.albedo_sum + film_target, bdpt_albedo(scene, mat, isect.tex, st.wavelength) * film_weight);
+            st.flags |= kBpGBuffer;
+          }
+          st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
+          const BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
+          st.sampler.pop_fixed();
+          st.path_size += 1u;
+          const bool connectible = (bs.properties & kSampleDelta) == 0u;
+          curr = {isect.pos, isect.nrm, 0.0f, 0.0f, kBvSurface | (connectible ? kBvConnectible : 0u) | ((connectible && (st.prev.flags & kBvConnectible)) ? kBvMisConnectible : 0u),
+            isect.tri};
+          curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
+          const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, data, bs.w_o, mat, st.sampler);
+          const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
+          const uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
+          const f3 vertex_throughput = st.throughput;
+          const float prev_sampled_pdf = st.aux;  // z_prev.pdf.bsdf_sample_next (PathTracing mode weights)
+          st.medium = vertex_medium;
+          if (bs.valid()) {
+            st.eta *= bs.eta;
+            st.pdf_dir = bs.pdf;
+            st.throughput *= bs.weight;
+            st.ray_o = shading_pos(scene, scene.triangles[isect.tri], isect.bc, bs.w_o);
+            st.ray_d = bs.w_o;
+            st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+          } else {
+            terminate = true;
+          }
+          bdpt_advance_history(st, prev_from_next, true, mode);
+          // direct_hit_area_emitter, :1235-1287 (the segment itself was the visibility query)
+          if (opt_direct_hit(it) && (isect.emitter != kInvalid) && (mode != kBdptLightTracing)) {
+            const uint32_t target_path_length = st.path_size - 1u;
+            if ((target_path_length <= scene.max_path_length) && (target_path_length >= scene.min_path_length)) {
+              const etx_abi_emitter& em = scene.emitters[isect.emitter];
+              EmitterRadianceQuery q;
+              q.source_position = st.prev.pos;
+              q.target_position = isect.pos;
+              q.direction = mk3(0.0f);
+              q.uv = isect.tex;
+              q.directly_visible = (st.path_size - 1u) <= 1u;
+              float pdf_area = 0.0f, pdf_dir = 0.0f, pdf_dir_out = 0.0f;
+              const f3 value = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out, st.wavelength);
+              if (pdf_dir != 0.0f) {
+                float weight = 1.0f;
+                if (use_mis && (st.path_size > 2u)) {
+                  if (mode == kBdptPathTracing) {
+                    const float p_connect = pdf_dir * emitter_discrete_pdf(scene, em);
+                    weight = (st.prev.flags & kBvConnectible) ? power_heuristic(prev_sampled_pdf, p_connect) : 1.0f;
+                  } else {
+                    const float p_sample = bdpt_emitter_sample_pdf(scene, em, -isect.w_i);
+                    const float p_from = bdpt_pdf_from_emitter(scene, isect.emitter, isect.pos, isect.nrm, st.prev);
+                    weight = bdpt_direct_hit_weight(st, curr.from_prev, p_sample, p_from);
+                  }
+                }
+                const f3 gathered = value * vertex_throughput * weight;
+                if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
+                  film_add(p, p.camera_sum + film_target, gathered * film_weight);
+              }
+            }
+          }
+          created = true;
+          store_vertex = connectible && (mode != kBdptLightTracing);
+          v_hit = h, v_wi = isect.w_i, v_throughput = vertex_throughput, v_medium = vertex_medium;
+          v_rnd = {rnd_em.x, rnd_em.y, rnd_support.y};
+        }
+      } else if (opt_direct_hit(it) && (mode != kBdptLightTracing)) {  // miss: direct_hit_environment_emitter, :1289-1340
+        const float prev_sampled_pdf = st.aux;
+        st.path_size += 1u;
+        bdpt_advance_history(st, 0.0f, true, mode);
+        const uint32_t target_path_length = st.path_size - 1u;
+        if ((scene.env_count > 0u) && (target_path_length <= scene.max_path_length) && (target_path_length >= scene.min_path_length)) {
+          f3 accumulated = mk3(0.0f);
+          for (uint32_t ie = 0; ie < scene.env_count; ++ie) {
+            const etx_abi_emitter& em = scene.emitters[scene.env_emitters[ie]];
+            EmitterRadianceQuery q;
+            q.source_position = q.target_position = mk3(0.0f);
+            q.direction = st.ray_d;
+            q.uv = {0.0f, 0.0f};
+            q.directly_visible = (st.path_size - 1u) <= 1u;
+            float pdf_area = 0.0f, pdf_dir = 0.0f, pdf_dir_out = 0.0f;
+            const f3 value = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out, st.wavelength);
+            float this_weight = 1.0f;
+            if ((mode == kBdptPathTracing) && (st.prev.flags & kBvConnectible) && (st.path_size - 1u > 1u))
+              this_weight = power_heuristic(prev_sampled_pdf, pdf_dir * emitter_discrete_pdf(scene, em));
+            accumulated += value * this_weight;
+          }
+          if (is_zero(accumulated) == false) {
+            float weight = 1.0f;
+            if (use_mis && (st.path_size - 1u > 1u) && (mode != kBdptPathTracing)) {
+              // pdf_for_environment_emitter, :207-222
+              float pdf_dir = 0.0f;
+              for (uint32_t ie = 0; ie < scene.env_count; ++ie)
+                pdf_dir += bdpt_emitter_sample_pdf(scene, scene.emitters[scene.env_emitters[ie]], st.ray_d);
+              pdf_dir /= float(scene.env_count);
+              const float w_dot_n = st.prev.surface() ? fabsf(dot(ld3(scene.triangles[st.prev.tri].geo_n), st.ray_d)) : 1.0f;
+              const float p_from = w_dot_n * env_pdf_area(scene);
+              weight = bdpt_direct_hit_weight(st, st.pdf_dir, pdf_dir, p_from);
+            }
+            film_add(p, p.camera_sum + film_target, accumulated * st.throughput * weight * film_weight);
+          }
+        }
+        if ((st.flags & kBpGBuffer) == 0u)
+          film_add(p, p.normal_sum + film_target, f3{0.0f, 0.0f, 1.0f});  // GBuffer default normal, :335-338
+      } else if ((st.flags & kBpGBuffer) == 0u) {
+        film_add(p, p.normal_sum + film_target, f3{0.0f, 0.0f, 1.0f});
+      }
+    }
+    const uint32_t vertex_slot = block_compact_slot(store_vertex, p.counters + kCntCameraVertices, s_scratch);
+    if (store_vertex) {
+      Sampler derived;
+      derived.init(st.sampler.seed, 0x51ed270bu);
+      bdpt_store_camera_vertex(p, vertex_slot, st, v_hit, v_wi, v_medium, v_throughput, curr.from_prev, v_rnd, derived.seed);
+    }
+    if (created) {  // build_path: prev = curr at the top of the next iteration, then the roulette of this interaction (:890-895)
+      st.prev = curr;
+      st.flags &= ~kBpFirst;
+      st.aux = st.pdf_dir;  // becomes z_prev.pdf.bsdf_sample_next
+      alive = (terminate == false) && random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
+    }
+    const uint32_t slot = block_compact_slot(alive, out_counter, s_scratch);
+    if (alive)
+      bdpt_store(out, slot, st, st.prev.tri);
+  }
+}
+
+// connect_camera_to_light (:1342-1378) with mis_weight_camera_to_light (:1079-1133) for the camera vertices of this bounce
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_light(Pipeline p, VcmParams it) {
+  __shared__ BlockScratch s_scratch;
+  const DScene& scene = p.scene;
+  const uint32_t count = min(p.counters[kCntCameraVertices], p.capacity);
+  const uint32_t mode = bdpt_mode(it);
+  ETX_BLOCK_LOOP(count, i) {
+    ShadowRequest request;
+    bool queue = false;
+    if ((i < count) && opt_connect_to_light(it)) {
+      BdptCameraVertex z = bdpt_load_camera_vertex(p, scene, i);
+      const uint32_t connection_len = z.path_size;  // camera_path_length() + 1
+      if ((connection_len <= scene.max_path_length) && (connection_len >= scene.min_path_length)) {
+        Sampler smp;
+        smp.seed = z.seed, smp.fixed_u = smp.fixed_v = smp.fixed_w = 0.0f;
+        const uint32_t emitter_index = sample_emitter_index(scene, z.rnd_fixed.z);
+        const EmitterSample es = sample_emitter(scene, emitter_index, f2{z.rnd_fixed.x, z.rnd_fixed.y}, z.full.isect.pos, z.wavelength);
+        const f3 dp = es.origin - z.full.isect.pos;
+        if ((is_zero(es.value) == false) && (es.pdf_dir != 0.0f) && (dot(dp, dp) > kEpsilon)) {
+          const BdptBsdf bsdf = bdpt_bsdf(scene, z.full, kPathCamera, es.direction, z.wavelength, smp);
+          if (is_zero(bsdf.bsdf) == false) {
+            const float sampling_pdf = es.pdf_dir * es.pdf_sample;
+            float weight = 1.0f;
+            if (opt_enable_mis(it)) {
+              if (mode == kBdptPathTracing) {
+                weight = power_heuristic(sampling_pdf, es.is_delta ? 0.0f : bsdf.pdf);
+              } else {  // Full
+                const etx_abi_emitter& em = scene.emitters[es.emitter_index];
+                const BVtx sampled = {es.origin, es.normal, 0.0f, 0.0f, kBvEmitter | ((es.triangle_index != kInvalid) ? kBvSurface : 0u), es.triangle_index};
+                const BVtx z_curr = z.full.summary(z.from_prev);
+                const float p_sample = bdpt_emitter_sample_pdf(scene, em, es.direction);
+                const float from_emitter = bdpt_pdf_from_emitter(scene, es.emitter_index, es.origin, es.normal, z_curr);
+                const float z_prev_backward = bdpt_pdf_area(scene, kPathLight, es.origin, z.full, z.prev, z.wavelength, smp);
+                const float p_bsdf_sample = bdpt_pdf_area(scene, kPathCamera, z.prev.pos, z.full, sampled, z.wavelength, smp);
+                const float w_camera = bdpt_mis_camera(z.path_size, from_emitter, z.from_prev, z_prev_backward, z.prev);
+                const float w_light = es.is_delta ? 0.0f : safe_div(p_bsdf_sample, p_sample);
+                weight = 1.0f / (w_camera + 1.0f + w_light);
+              }
+            }
+            const f3 value = z.throughput * bsdf.bsdf * (es.value / sampling_pdf) * weight * spectral_film_weight(scene, z.wavelength);
+            request = {bdpt_segment_origin(scene, z.full, es.origin), es.origin, value, z.medium, film_index(it, z.pixel), z.wavelength};
+            queue = true;
+          }
+        }
+      }
+    }
+    const uint32_t slot = block_compact_slot(queue, p.counters + kCntShadow, s_scratch);
+    if (queue)
+      write_shadow(p, slot, request);
+  }
+}
+
+// connect_camera_to_light_path (:438-497), one (camera vertex, light vertex) pair per lane, with
+// mis_weight_camera_to_light_path (:1184-1209)
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs(Pipeline p, VcmParams it) {
+  __shared__ BlockScratch s_scratch;
+  const DScene& scene = p.scene;
+  const uint32_t count = min(p.counters[kCntPairs], p.pair_capacity);
+  ETX_BLOCK_LOOP(count, i) {
+    ShadowRequest request;
+    bool queue = false;
+    if (i < count) {
+      const uint2 pair = p.pairs[i];
+      const uint32_t y_flags = __float_as_uint(p.lv.thr_dvm(pair.y).w);
+      const uint32_t light_s = __float_as_uint(p.lv.bc_len_med(pair.y).z) >> 16u;
+      const uint32_t camera_path_size = __float_as_uint(p.cv.thr_depth[pair.x].w);
+      const uint32_t target_path_length = (camera_path_size - 1u) + light_s + 1u;
+      if ((light_s >= 1u) && (y_flags & kBvConnectible) && (target_path_length >= scene.min_path_length) && (target_path_length <= scene.max_path_length)) {
+        const BdptCameraVertex z = bdpt_load_camera_vertex(p, scene, pair.x);
+        const BdptLightVertex y = bdpt_load_light_vertex(p, scene, pair.y);
+        f3 dw = z.full.isect.pos - y.self.pos;
+        const float dwl = dot(dw, dw);
+        if (dwl > kInvMaxHalf) {
+          dw = dw * (1.0f / sqrtf(dwl));
+          Sampler smp;
+          smp.seed = Sampler::random_seed(z.seed, pair.y), smp.fixed_u = smp.fixed_v = smp.fixed_w = 0.0f;
+          const f3 bsdf_y = bdpt_bsdf(scene, y.full, kPathLight, dw, z.wavelength, smp).bsdf;
+          const f3 bsdf_z = bdpt_bsdf(scene, z.full, kPathCamera, -dw, z.wavelength, smp).bsdf;
+          const f3 connect = y.throughput * bsdf_y * bsdf_z;
+          if (is_zero(connect) == false) {
+            float weight = 1.0f;
+            if (opt_enable_mis(it)) {
+              const BVtx y_prev = bdpt_load_light_summary(p, y.prev);
+              const BVtx z_curr = z.full.summary(z.from_prev);
+              const float z_curr_pdf = bdpt_pdf_area(scene, kPathLight, y_prev.pos, y.full, z_curr, z.wavelength, smp);
+              const float z_prev_pdf = bdpt_pdf_area(scene, kPathCamera, y.self.pos, z.full, z.prev, z.wavelength, smp);
+              const float y_curr_pdf = bdpt_pdf_area(scene, kPathCamera, z.prev.pos, z.full, y.self, z.wavelength, smp);
+              const float y_prev_pdf = bdpt_pdf_area(scene, kPathLight, z.full.isect.pos, y.full, y_prev, z.wavelength, smp);
+              const float w_camera = bdpt_mis_camera(z.path_size, z_curr_pdf, z.from_prev, z_prev_pdf, z.prev);
+              const float w_light = bdpt_mis_light(y_curr_pdf, y.self.from_prev, y_prev_pdf, y_prev);
+              weight = 1.0f / (1.0f + w_camera + w_light);
+            }
+            const f3 value = connect * z.throughput * (weight / dwl) * spectral_film_weight(scene, z.wavelength);
+            request = {bdpt_segment_origin(scene, y.full, z.full.isect.pos), z.full.isect.pos, value, y.medium, film_index(it, z.pixel), z.wavelength};
+            queue = true;
+          }
+        }
+      }
+    }
+    const uint32_t slot = block_compact_slot(queue, p.counters + kCntShadow, s_scratch);
+    if (queue)
+      write_shadow(p, slot, request);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+void launch_bdpt_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
+  hipLaunchKernelGGL(k_bdpt_light_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
+}
+void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
+  hipLaunchKernelGGL(k_bdpt_light_shade, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
+}
+void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
+  hipLaunchKernelGGL(k_bdpt_connect_camera, dim3(max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 2ull, uint64_t(p.lv.capacity)))))), dim3(kBlockSize), 0, stream, p, it);
+}
+void launch_bdpt_camera_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
+  hipLaunchKernelGGL(k_bdpt_camera_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
+}
+void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
+  hipLaunchKernelGGL(k_bdpt_camera_shade, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
+}
+void launch_bdpt_connect_light(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
+  hipLaunchKernelGGL(k_bdpt_connect_light, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it);
+}
+void launch_bdpt_connect_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
+  const uint32_t pair_blocks = max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 8ull, uint64_t(p.pair_capacity)))));
+  hipLaunchKernelGGL(k_bdpt_connect_pairs, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
+}
+
+}  // namespace etxd

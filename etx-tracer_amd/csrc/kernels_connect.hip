@@ -164,6 +164,10 @@ void launch_connect_endpoints(hipStream_t stream, const Pipeline& p, const VcmPa
     hipLaunchKernelGGL(k_connect_endpoints<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
 }
 
+void launch_expand_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
+  hipLaunchKernelGGL(k_expand_pairs, dim3(max(1u, grid_for(min(max_items, p.capacity)))), dim3(kBlockSize), 0, stream, p, it);
+}
+
 void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items) {
   max_items = min(max_items, p.capacity);
   const uint32_t blocks = max(1u, grid_for(max_items));

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
     counters[kCntMergeVertices] = 0u;
     counters[kCntEndpoints] = 0u;
     counters[kCntGroupGeneral] = 0u;
+    counters[kCntLightBounceBegin] = counters[kCntLightVertices];
     counters[kCntGroupSubsurface] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
     if (pass_stat != 0u)
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene s
     counters[kCntMergeVertices] = 0u;
     counters[kCntEndpoints] = 0u;
     counters[kCntGroupGeneral] = 0u;
+    counters[kCntLightBounceBegin] = counters[kCntLightVertices];
     counters[kCntGroupSubsurface] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
     if (pass_stat != 0u)
@@ -238,6 +240,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_flat2(const DScene
     counters[kCntMergeVertices] = 0u;
     counters[kCntEndpoints] = 0u;
     counters[kCntGroupGeneral] = 0u;
+    counters[kCntLightBounceBegin] = counters[kCntLightVertices];
     counters[kCntGroupSubsurface] = 0u;
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
     if (pass_stat != 0u)

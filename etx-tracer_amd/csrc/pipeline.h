@@ -25,6 +25,9 @@ struct PathSet {
   uint4* meta;       // sampler seed, total_path_depth, medium index, flags
   uint32_t* path_id; // global path index (light pass) / pixel index (camera pass)
   float* wavelength; // spectral mode: the path's wavelength (VCMPathState::spect)
+  // bidirectional path tracing (dev_bdpt.h): summary of the previous path vertex
+  float4* prev_pos;  // position, vertex flags bits
+  float4* prev_nrm;  // shading normal, light path: pool slot of that vertex / camera path: its triangle
 };
 
 enum : uint32_t {  // VCMPathState flags, vcm_shared.hxx:92-98
@@ -139,11 +142,12 @@ enum : uint32_t {
   kCntGroupSubsurface = 576, // ... by the subsurface kernel
   kCntEndpoints = 608,       // endpoint connection requests of the current bounce, cleared per bounce
   kCntNonFinite = 640,
+  kCntLightBounceBegin = 800, // BDPT: light vertex count when the current bounce began (k_bdpt_connect_camera covers [begin, count))
   kStatRaysLight = 672,      // u64 statistics: closest-hit rays of the light pass / camera pass, pair connections, endpoint connections
   kStatRaysCamera = 704,
   kStatPairs = 736,
   kStatEndpoints = 768,       // film contributions dropped because they were not finite (never cleared within a run: reported by etx_hip_stats)
-  kCounterCount = 800,
+  kCounterCount = 832,
 };
 
 // Per-workgroup statistics (u64): workgroup b of any launch adds to row b without atomics (launches on one stream do

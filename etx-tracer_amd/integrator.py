@@ -90,6 +90,16 @@ def pt_options_from_dict(values):
     return o
 
 
+def bdpt_options_from_dict(values):
+    """CPUBidirectionalImpl::start (sources/etx/rt/integrators/bidirectional.cxx:1469-1478): same keys, same defaults."""
+    o = api.BDPTOptions.default_values()
+    o.mode = int(values.get("bdpt-mode", o.mode))
+    for key, field in (("bdpt-conn_direct_hit", "direct_hit"), ("bdpt-conn_connect_to_camera", "connect_to_camera"), ("bdpt-conn_connect_to_light", "connect_to_light"),
+                       ("bdpt-conn_connect_vertices", "connect_vertices"), ("bdpt-conn_mis", "mis"), ("bdpt-blue_noise", "blue_noise")):
+        setattr(o, field, 1 if values.get(key, bool(getattr(o, field))) else 0)
+    return o
+
+
 class HIPIntegrator(Integrator):
     """run / update / stop protocol shared by the device integrators (one iteration per update())."""
 
@@ -200,3 +210,14 @@ class HIPPathTracing(HIPIntegrator):
 
     def _begin(self):
         self.context.begin_pt(pt_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride)
+
+
+class HIPBidirectional(HIPIntegrator):
+    """CPUBidirectional (sources/etx/rt/integrators/bidirectional.cxx:1490-1560) on the device: bdpt-mode PathTracing,
+    LightTracing and BDPTFull; see include/etx_hip.h for what etx_hip_begin rejects."""
+
+    def name(self):
+        return "Bidirectional (HIP gfx950)"
+
+    def _begin(self):
+        self.context.begin_bdpt(bdpt_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride)

@@ -45,7 +45,9 @@ enum {
 /* which integrator the device pipeline runs; names follow the reference classes it stands in for */
 enum {
   ETX_HIP_INTEGRATOR_PT = 0,   /* CPUPathTracing  sources/etx/rt/integrators/path_tracing.cxx:50-110, options = etx_abi_pt_options */
-  ETX_HIP_INTEGRATOR_VCM = 1   /* CPUVCM          sources/etx/rt/integrators/vcm_cpu.cxx:95-241,     options = etx_abi_vcm_options */
+  ETX_HIP_INTEGRATOR_VCM = 1,  /* CPUVCM          sources/etx/rt/integrators/vcm_cpu.cxx:95-241,     options = etx_abi_vcm_options */
+  ETX_HIP_INTEGRATOR_BDPT = 2  /* CPUBidirectional sources/etx/rt/integrators/bidirectional.cxx:342-403, options = etx_abi_bdpt_options
+                                  (modes PathTracing / LightTracing / BDPTFull; BDPTFast and random-walk subsurface scenes: ETX_HIP_ERROR_UNSUPPORTED) */
 };
 
 /* film layers, subset of etx::Film layer ids (sources/etx/render/host/film.hxx:14-27) that the MC loop produces */
@@ -98,7 +100,7 @@ int etx_hip_upload_cie_table(etx_hip_context* context, const float* xyz, uint32_
 /* rendering */
 
 /* Clears the film (Film::clear(ClearCameraData|ClearLightData), vcm_cpu.cxx:86) and arms the pipeline.
- * `options`: etx_abi_vcm_options or etx_abi_pt_options (by integrator). Scene scalars (samples, min/max path length,
+ * `options`: etx_abi_vcm_options, etx_abi_pt_options or etx_abi_bdpt_options (by integrator). Scene scalars (samples, min/max path length,
  * random_path_termination, radiance_clamp) come from the uploaded scene.
  * This context renders iterations first_iteration, first_iteration + iteration_stride, ... (multi-GPU sharding by
  * iteration; single GPU: 0, 1). */

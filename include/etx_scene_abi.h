@@ -195,6 +195,14 @@ typedef struct etx_abi_pt_options {
   uint8_t nee, direct, mis, blue_noise;
 } __attribute__((aligned(16))) etx_abi_pt_options; /* 16 */
 
+/* CPUBidirectionalImpl's options  sources/etx/rt/integrators/bidirectional.cxx:323-340,1443-1466 ("bdpt-mode", "bdpt-conn_*",
+ * "bdpt-blue_noise"). mode: CPUBidirectionalImpl::Mode */
+enum { ETX_BDPT_MODE_PATH_TRACING = 0, ETX_BDPT_MODE_LIGHT_TRACING = 1, ETX_BDPT_MODE_FAST = 2, ETX_BDPT_MODE_FULL = 3 };
+typedef struct etx_abi_bdpt_options {
+  uint32_t mode;
+  uint8_t direct_hit, connect_to_camera, connect_to_light, connect_vertices, mis, blue_noise;
+} __attribute__((aligned(16))) etx_abi_bdpt_options; /* 16 */
+
 #ifdef __cplusplus
 }
 #endif

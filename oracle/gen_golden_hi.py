@@ -8,6 +8,7 @@ tests of tests/test_gpu_parity_hi.py ("a high-spp oracle reference
       the films are float32, compressed), reference CPUVCM with vcm-blue_noise=false and CPUPathTracing with bn=false
   tests/golden/hi/cornell_full_128_vcm_<spp>_decorrelated.npz    the same with ETX_ORACLE_DECORRELATE=1 (the BVH shim
       shifts the shared stream of a pixel's light and camera path by ray-dependent amounts)
+  tests/golden/hi/cornell_<flavour>_128_bdpt<mode>_<spp>[_rekeyed].npz  CPUBidirectional (--integrators bdpt --bdpt-modes 3,0,1)
   tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_rekeyed.npz        ETX_ORACLE_DECORRELATE=2: the camera path re-keys its sampler at
       its first segment = independent light / camera streams, the estimator the device implements
 
@@ -49,7 +50,7 @@ def render(snapshot, integrator, spp, out_npz, cores, env_extra=None, extra=()):
     film = film_io.read_film(film_path)
     os.remove(film_path)
     layers = {"camera": film["camera"][..., :3].astype(np.float32), "spp": np.int32(film["spp"]), "seconds": np.float64(film["seconds"]), "threads": np.int32(film["threads"])}
-    if integrator == "vcm":
+    if integrator in ("vcm", "bdpt"):
         layers["light"] = film["light"][..., :3].astype(np.float32)
     os.makedirs(HI, exist_ok=True)
     np.savez_compressed(out_npz, **layers)
@@ -61,6 +62,7 @@ def main():
     ap.add_argument("--spp", type=int, default=4096)
     ap.add_argument("--cores", default="")
     ap.add_argument("--integrators", default="vcm,pt,rekeyed")
+    ap.add_argument("--bdpt-modes", default="3")
     ap.add_argument("names", nargs="*", default=FLAVOURS)
     args = ap.parse_args()
     integrators = args.integrators.split(",")
@@ -75,6 +77,14 @@ def main():
             # mode 2: the camera sub path draws from a stream of its own from its first segment on (oracle/shims/raytracing_bvh.cxx)
             render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_rekeyed.npz" % (flavour, args.spp)), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "2"},
                    extra=["--opt", "vcm-blue_noise=false"])
+        if "bdpt" in integrators:
+            # CPUBidirectional, bdpt-mode 3 = BDPTFull (bidirectional.cxx:323-330); shared streams and re-keyed like VCM
+            for mode in args.bdpt_modes.split(","):
+                opts = ["--opt", "bdpt-blue_noise=false", "--opt", "bdpt-mode=%s" % mode]
+                render(snapshot, "bdpt", args.spp, os.path.join(HI, "cornell_%s_128_bdpt%s_%d.npz" % (flavour, mode, args.spp)), args.cores, extra=opts)
+                if mode != "0":  # PathTracing mode has no light path to correlate with
+                    render(snapshot, "bdpt", args.spp, os.path.join(HI, "cornell_%s_128_bdpt%s_%d_rekeyed.npz" % (flavour, mode, args.spp)), args.cores,
+                           env_extra={"ETX_ORACLE_DECORRELATE": "2"}, extra=opts)
         if "pt" in integrators:
             # --noise-threshold 0: every pixel gets all samples (the scenes carry Scene::noise_threshold = 0.1, with which
             # CPUPathTracing stops sampling converged pixels after 32 samples: a "4096-spp" film would hold ~100-spp noise)

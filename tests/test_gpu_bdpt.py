@@ -1,0 +1,82 @@
+"""GPU (-m gpu): the bidirectional integrator (HIPBidirectional, kernels_bdpt.hip) against the reference's CPUBidirectional.
+
+Golden films: tests/golden/hi/cornell_<flavour>_128_bdpt<mode>_<spp>[_rekeyed].npz (oracle/gen_golden_hi.py --integrators bdpt),
+mode = CPUBidirectionalImpl::Mode (0 PathTracing, 1 LightTracing, 3 BDPTFull), bdpt-blue_noise=false. As for VCM
+(test_gpu_parity_hi.py), the reference seeds the light and the camera sub path of a pixel with the same sampler state
+(bidirectional.cxx:379-380); the device gives the camera path a stream of its own, so the tight limits are asserted against
+the reference run with independent streams (`_rekeyed`, ETX_ORACLE_DECORRELATE=2) and the unmodified reference is compared
+with the limits its own correlation leaves. The device renders the same iteration set as two interleaved halves; the
+metric (noise-corrected block RMSE, relative mean, bias percentile) is test_gpu_parity_hi.compare.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity_hi import compare
+
+pytestmark = pytest.mark.gpu
+
+
+def load(golden_dir, name):
+    path = os.path.join(golden_dir, "hi", name)
+    assert os.path.exists(path), "%s is missing: run oracle/gen_golden_hi.py --integrators bdpt in the build container" % path
+    return np.load(path)
+
+
+def render_halves(etx, golden_dir, flavour, spp, options):
+    films = []
+    for first in (0, 1):
+        snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_%s_128.etxscene" % flavour))
+        snap.samples = spp
+        integ = etx.HIPBidirectional(snap, first_iteration=first, iteration_stride=2)
+        integ.options().update(options)
+        integ.render()
+        cam, light = integ.film(etx.api.LAYER_CAMERA), integ.film(etx.api.LAYER_LIGHT)
+        stats = integ.status()
+        integ.context.close()
+        assert stats.completed_iterations == spp // 2 and stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
+        assert np.isfinite(cam).all() and np.isfinite(light).all()
+        films.append((cam, light))
+    return films
+
+
+@pytest.mark.parametrize("flavour", ["classic", "full", "cloud", "glass"])
+def test_bdpt_full_matches_reference_at_4096_spp(etx, golden_dir, flavour):
+    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, flavour, 4096, {"bdpt-mode": etx.api.BDPT_MODE_FULL, "bdpt-blue_noise": False})
+    golden = load(golden_dir, "cornell_%s_128_bdpt3_4096_rekeyed.npz" % flavour)
+    assert int(golden["spp"]) == 4096
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " bdpt camera+light (independent streams)")
+    compare((light_a, light_b), golden["light"], flavour + " bdpt light (independent streams)", mean_limit=1.0e-2, bias_p99_limit=0.2)
+    compare((cam_a, cam_b), golden["camera"], flavour + " bdpt camera (independent streams)")
+    golden = load(golden_dir, "cornell_%s_128_bdpt3_4096.npz" % flavour)
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " bdpt camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_bdpt_single_technique_modes(etx, golden_dir, mode):
+    """bdpt-mode PathTracing (camera paths + next event estimation only) and LightTracing (light paths splatted to the camera only)."""
+    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, "full", 1024, {"bdpt-mode": mode, "bdpt-blue_noise": False})
+    golden = load(golden_dir, "cornell_full_128_bdpt%d_1024%s.npz" % (mode, "_rekeyed" if mode else ""))
+    assert int(golden["spp"]) == 1024
+    if mode == 0:
+        assert float(np.abs(light_a).max()) == 0.0
+        compare((cam_a, cam_b), golden["camera"], "full bdpt mode PathTracing camera")
+    else:
+        assert float(np.abs(cam_a).max()) == 0.0
+        compare((light_a, light_b), golden["light"], "full bdpt mode LightTracing light", mean_limit=1.0e-2, bias_p99_limit=0.2)
+
+
+def test_bdpt_rejects_what_it_does_not_implement(etx, golden_dir):
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_sss_128.etxscene"))
+    integ = etx.HIPBidirectional(snap)
+    integ.options().update({"bdpt-mode": etx.api.BDPT_MODE_FULL})
+    with pytest.raises(etx.EtxHipError, match="subsurface"):
+        integ.run()
+    integ.context.close()
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_classic_128.etxscene"))
+    integ = etx.HIPBidirectional(snap)
+    integ.options().update({"bdpt-mode": etx.api.BDPT_MODE_FAST})
+    with pytest.raises(etx.EtxHipError, match="BDPTFast"):
+        integ.run()
+    integ.context.close()
