@@ -14,8 +14,8 @@
 //                its previous-vertex summary; next event estimation (connect_camera_to_light :1342-1378, k_bdpt_connect_light)
 //                and the vertex connections (connect_camera_to_light_path :438-497, k_expand_pairs + k_bdpt_connect_pairs)
 //                read it there; visibility goes through the shadow queue like every other connection.
-// Modes (CPUBidirectionalImpl::Mode :323-330): PathTracing, LightTracing, BDPTFull. BDPTFast (labelled experimental in
-// the reference) is rejected by etx_hip_begin. Random-walk subsurface materials are rejected for this integrator (the
+// Modes (CPUBidirectionalImpl::Mode :323-330): PathTracing, LightTracing, BDPTFast (the reference's default: no vertex
+// connections, product-form weights), BDPTFull. Random-walk subsurface materials are rejected for this integrator (the
 // reference threads the walk's medium vertices through the path; :729-818).
 #pragma once
 
@@ -219,23 +219,35 @@ ETX_DEV float bdpt_mis_light(float y_curr_backward, float y_curr_from_prev, floa
   return r0 * (((y_prev.flags & kBvConnectible) ? 1.0f : 0.0f) + acc);
 }
 
-// precompute_camera_mis / precompute_light_mis (Full mode), bidirectional.cxx:1012-1057: fixes prev.history, advances the path's
-// running history with prev.from_next (just computed by the caller)
-ETX_DEV void bdpt_advance_history(BdptState& st, float prev_from_next, bool camera, uint32_t mode) {
+ETX_DEV float balance_heuristic(float a, float b, float c) {  // bidirectional.cxx:308-311
+  const float denom = a + b + c;
+  return (denom == 0.0f) ? 0.0f : a / denom;
+}
+
+// precompute_camera_mis / precompute_light_mis, bidirectional.cxx:1012-1057: fixes prev.history, advances the path's
+// running history with prev.from_next (just computed by the caller). `curr_connectible`: of the vertex being created.
+ETX_DEV void bdpt_advance_history(BdptState& st, float prev_from_next, bool camera, uint32_t mode, bool curr_connectible) {
   st.prev.history = st.mis_history;
   if ((mode == kBdptPathTracing) || (mode == kBdptLightTracing))
     return;
   const float ratio = safe_div(prev_from_next, st.prev.from_prev);
   float accumulated = 0.0f;
-  if ((camera == false) || (st.path_size - 1u > 1u))
+  if (mode == kBdptFast) {
+    if (camera)  // camera_path_size == 2: "drop backward path, if looking at the scene through the mirror"
+      accumulated = (st.path_size == 2u) ? (curr_connectible ? st.mis_history : 0.0f) : st.mis_history * ratio;
+    else
+      accumulated = st.mis_history * ((st.path_size > 2u) ? ratio : 1.0f);
+  } else if ((camera == false) || (st.path_size - 1u > 1u)) {
     accumulated = ratio * (((st.prev.flags & kBvMisConnectible) ? 1.0f : 0.0f) + st.mis_history);
+  }
   st.mis_history = accumulated;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // pools
 
-// Light vertex record (LightVertexPool, write once). index_in_path 0 is the emitter vertex itself.
+// Light vertex record (LightVertexPool, write once). index_in_path 0 is the emitter vertex itself; its record carries
+// pdf.from_next (fixed when vertex 1 is created, read by the BDPTFast weights) in the barycentric slot.
 ETX_DEV void bdpt_store_light_vertex(const Pipeline& p, uint32_t idx, uint32_t path, const f3& pos, const f3& nrm, const f3& w_i, const f3& throughput, float from_prev, float history,
   uint32_t flags, uint32_t tri, float bc_u, float bc_v, uint32_t index_in_path, uint32_t path_size, uint32_t medium, uint32_t prev, float wavelength, uint32_t seed) {
   if (idx >= p.lv.capacity) {
@@ -247,7 +259,7 @@ ETX_DEV void bdpt_store_light_vertex(const Pipeline& p, uint32_t idx, uint32_t p
   p.lv.thr_dvm(idx) = mk4(throughput, __uint_as_float(flags));
   p.lv.nrm_tri(idx) = mk4(nrm, __uint_as_float(tri));
   p.lv.bc_len_med(idx) = make_float4(bc_u, bc_v, __uint_as_float((index_in_path << 16u) | (path_size & 0xffffu)), __uint_as_float(medium));
-  p.lv.rec[idx * LightVertexPool::kLvStride + 5] = make_float4(__uint_as_float(prev), wavelength, __uint_as_float(seed), 0.0f);
+  p.lv.rec[idx * LightVertexPool::kLvStride + 5] = make_float4(__uint_as_float(prev), wavelength, __uint_as_float(seed), __uint_as_float(path));
   if (index_in_path < kPathTableEntries)
     reinterpret_cast<uint32_t*>(p.light_path_table)[path * kPathTableEntries + index_in_path] = idx;
   p.light_path_head[path] = idx;
@@ -257,7 +269,7 @@ struct BdptLightVertex {
   BFull full;
   BVtx self;  // from_prev, history, flags of the vertex itself
   f3 throughput;
-  uint32_t index_in_path, path_size, medium, prev, seed;
+  uint32_t index_in_path, path_size, medium, prev, seed, path;
   float wavelength;
 };
 
@@ -272,7 +284,7 @@ ETX_DEV BdptLightVertex bdpt_load_light_vertex(const Pipeline& p, const DScene& 
   v.self = {{a.x, a.y, a.z}, {d.x, d.y, d.z}, a.w, b.w, __float_as_uint(c.w), __float_as_uint(d.w)};
   v.throughput = {c.x, c.y, c.z};
   v.index_in_path = __float_as_uint(e.z) >> 16u, v.path_size = __float_as_uint(e.z) & 0xffffu, v.medium = __float_as_uint(e.w);
-  v.prev = __float_as_uint(f.x), v.wavelength = f.y, v.seed = __float_as_uint(f.z);
+  v.prev = __float_as_uint(f.x), v.wavelength = f.y, v.seed = __float_as_uint(f.z), v.path = __float_as_uint(f.w);
   v.full.at_medium = (v.self.flags & kBvMedium) != 0u;
   v.full.g = 0.0f;
   const f3 w_i = {b.x, b.y, b.z};

@@ -1047,9 +1047,9 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
     }
     memcpy(&context->bdpt_options, options, sizeof(etx_abi_bdpt_options));
     const uint32_t mode = context->bdpt_options.mode;
-    if ((mode != ETX_BDPT_MODE_PATH_TRACING) && (mode != ETX_BDPT_MODE_LIGHT_TRACING) && (mode != ETX_BDPT_MODE_FULL)) {
-      context->error = (mode == ETX_BDPT_MODE_FAST) ? "bdpt-mode BDPTFast (experimental in the reference) is not implemented by the device path" : "bdpt-mode: unknown value";
-      return ETX_HIP_ERROR_UNSUPPORTED;
+    if (mode > ETX_BDPT_MODE_FULL) {
+      context->error = "bdpt-mode: unknown value " + std::to_string(mode);
+      return ETX_HIP_ERROR_INVALID_ARGUMENT;
     }
     if (context->scene.group_subsurface) {
       context->error = "bidirectional integrator: scenes with random-walk subsurface materials are not implemented by the device path (use VCM or path tracing)";

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_generate(Pipeline p, 
         st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
         st.eta = 1.0f;
         st.pdf_dir = es.pdf_dir;
-        st.mis_history = 0.0f;
+        st.mis_history = (bdpt_mode(it) == kBdptFast) ? 1.0f : 0.0f;  // :980-984
         st.aux = es.pdf_area;
         st.path_size = 1u;
         st.medium = es.medium_index;
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
     float v_from_prev = 0.0f, v_bc_u = 0.0f, v_bc_v = 0.0f;
     uint32_t v_flags = 0u, v_tri = kInvalid, v_medium = kInvalid;
     BVtx emitter_vertex = {};
+    float emitter_from_next = 0.0f;
     if (valid) {
       st = bdpt_load(in, i);
       uint32_t emitter_tri = kInvalid;
@@ -153,11 +154,11 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
         st.ray_o = ms.pos, st.ray_d = w_o, st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
         st.pdf_dir = pdf_fwd;
         emitter_vertex = st.prev;
-        bdpt_advance_history(st, prev_from_next, false, mode);
+        emitter_from_next = prev_from_next;
+        bdpt_advance_history(st, prev_from_next, false, mode, true);
         emitter_vertex.history = st.prev.history;
         store_emitter = first, store_vertex = true;
         st.prev = curr;
-        st.prev.flags = curr.flags;
         st.flags &= ~kBpFirst;
         alive = random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
       } else if (found) {
@@ -206,7 +207,8 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
           }
           v_from_prev = curr.from_prev;
           emitter_vertex = st.prev;
-          bdpt_advance_history(st, prev_from_next, false, mode);
+          emitter_from_next = prev_from_next;
+          bdpt_advance_history(st, prev_from_next, false, mode, connectible);
           emitter_vertex.history = st.prev.history;
           store_emitter = first, store_vertex = true;
           st.prev = curr;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
     const uint32_t vertex_slot = block_compact_slot(store_vertex, p.counters + kCntLightVertices, s_scratch);
     if (store_emitter)
       bdpt_store_light_vertex(p, emitter_slot, st.id, emitter_vertex.pos, emitter_vertex.nrm, mk3(0.0f), mk3(0.0f), emitter_vertex.from_prev, emitter_vertex.history, emitter_vertex.flags,
-        emitter_vertex.tri, 0.0f, 0.0f, 0u, 1u, kInvalid, kInvalid, st.wavelength, 0u);
+        emitter_vertex.tri, emitter_from_next, 0.0f, 0u, 1u, kInvalid, kInvalid, st.wavelength, 0u);
     if (store_vertex) {
       const uint32_t previous = store_emitter ? emitter_slot : st.prev_slot;
       Sampler derived;
@@ -273,7 +275,25 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_camera(Pipeline p, 
                 const float film_pdf = 1.0f / fabsf(scene.camera.area * cos_c * cos_c * cos_c);  // film_pdf_out, scene_camera.hxx:20-24
                 const float curr_from_camera = bdpt_to_area(film_pdf, cs.position, y.self);
                 const float prev_from_curr = bdpt_pdf_area(scene, kPathCamera, cs.position, y.full, y_prev, y.wavelength, smp);
-                weight = 1.0f / (1.0f + bdpt_mis_light(curr_from_camera, y.self.from_prev, prev_from_curr, y_prev));
+                if (mode == kBdptFast) {
+                  const uint32_t* table = reinterpret_cast<const uint32_t*>(p.light_path_table) + size_t(y.path) * kPathTableEntries;
+                  const uint32_t e0 = table[0], e1 = table[1];
+                  const float p_sample = p.lv.pos_dvcm(e0).w;  // e0.pdf.from_prev
+                  const uint32_t e0_flags = __float_as_uint(p.lv.thr_dvm(e0).w), e1_flags = __float_as_uint(p.lv.thr_dvm(e1).w);
+                  float p_light = y_prev.from_prev * y.self.from_prev;
+                  float p_bck = curr_from_camera * y_prev.history;
+                  float p_direct = prev_from_curr;
+                  if (y.path_size > 2u) {
+                    p_direct = p.lv.bc_len_med(e0).x;  // e0.pdf.from_next: the connection of the first vertex to the emitter
+                    p_bck *= prev_from_curr;
+                    p_light *= p_sample;
+                  }
+                  const float p_camera_direct = (e0_flags & kBvMisConnectible) ? p_bck * p_direct : 0.0f;
+                  const float p_camera_connect = (e1_flags & kBvConnectible) ? p_bck * p_sample : 0.0f;
+                  weight = balance_heuristic(p_light, p_camera_direct, p_camera_connect);
+                } else {
+                  weight = 1.0f / (1.0f + bdpt_mis_light(curr_from_camera, y.self.from_prev, prev_from_curr, y_prev));
+                }
               }
               const f3 splat = y.throughput * bsdf.bsdf * (cs.weight * weight) * spectral_film_weight(scene, y.wavelength);
               const uint32_t x = static_cast<uint32_t>((cs.uv.x * 0.5f + 0.5f) * float(it.film_w));
@@ -318,7 +338,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_generate(Pipeline p,
     st.throughput = mk3(1.0f);
     st.eta = 1.0f;
     st.pdf_dir = film_evaluate_out_pdf_dir(scene, st.ray_d);
-    st.mis_history = 0.0f;
+    st.mis_history = (mode == kBdptFast) ? 1.0f : 0.0f;  // :925-931
     st.aux = 0.0f;
     st.path_size = 1u;
     st.medium = scene.camera.medium_index;
@@ -330,8 +350,13 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_generate(Pipeline p,
     p.counters[kCntActiveA] = it.path_count;
 }
 
-// mis_weight_direct_hit (Full), bidirectional.cxx:1211-1233
-ETX_DEV float bdpt_direct_hit_weight(const BdptState& st, float z_curr_from_prev, float p_sample, float p_from) {
+// mis_weight_direct_hit, bidirectional.cxx:1211-1233
+ETX_DEV float bdpt_direct_hit_weight(const BdptState& st, uint32_t mode, float z_curr_from_prev, float p_sample, float p_from) {
+  if (mode == kBdptFast) {
+    const float to_emitter_direct = st.prev.from_prev * z_curr_from_prev;
+    const float to_emitter_connect = (st.prev.flags & kBvConnectible) ? st.prev.from_prev * p_sample : 0.0f;
+    return balance_heuristic(to_emitter_direct, to_emitter_connect, st.prev.history * (p_from * p_sample));
+  }
   return 1.0f / (1.0f + bdpt_mis_camera(st.path_size, p_sample, z_curr_from_prev, p_from, st.prev));
 }
 
@@ -387,7 +412,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
         v_rnd = {rnd_em.x, rnd_em.y, rnd_support.y};
         st.ray_o = ms.pos, st.ray_d = w_o, st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
         st.pdf_dir = pdf_fwd;
-        bdpt_advance_history(st, prev_from_next, true, mode);
+        bdpt_advance_history(st, prev_from_next, true, mode, true);
         created = true;
         store_vertex = (med.explicit_connections != 0u) && (mode != kBdptLightTracing);
       } else if (found) {
@@ -435,7 +460,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
           } else {
             terminate = true;
           }
-          bdpt_advance_history(st, prev_from_next, true, mode);
+          bdpt_advance_history(st, prev_from_next, true, mode, connectible);
           // direct_hit_area_emitter, :1235-1287 (the segment itself was the visibility query)
           if (opt_direct_hit(it) && (isect.emitter != kInvalid) && (mode != kBdptLightTracing)) {
             const uint32_t target_path_length = st.path_size - 1u;
@@ -458,7 +483,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
                   } else {
                     const float p_sample = bdpt_emitter_sample_pdf(scene, em, -isect.w_i);
                     const float p_from = bdpt_pdf_from_emitter(scene, isect.emitter, isect.pos, isect.nrm, st.prev);
-                    weight = bdpt_direct_hit_weight(st, curr.from_prev, p_sample, p_from);
+                    weight = bdpt_direct_hit_weight(st, mode, curr.from_prev, p_sample, p_from);
                   }
                 }
                 const f3 gathered = value * vertex_throughput * weight;
@@ -475,7 +500,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
       } else if (opt_direct_hit(it) && (mode != kBdptLightTracing)) {  // miss: direct_hit_environment_emitter, :1289-1340
         const float prev_sampled_pdf = st.aux;
         st.path_size += 1u;
-        bdpt_advance_history(st, 0.0f, true, mode);
+        bdpt_advance_history(st, 0.0f, true, mode, false);
         const uint32_t target_path_length = st.path_size - 1u;
         if ((scene.env_count > 0u) && (target_path_length <= scene.max_path_length) && (target_path_length >= scene.min_path_length)) {
           f3 accumulated = mk3(0.0f);
@@ -503,7 +528,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
               pdf_dir /= float(scene.env_count);
               const float w_dot_n = st.prev.surface() ? fabsf(dot(ld3(scene.triangles[st.prev.tri].geo_n), st.ray_d)) : 1.0f;
               const float p_from = w_dot_n * env_pdf_area(scene);
-              weight = bdpt_direct_hit_weight(st, st.pdf_dir, pdf_dir, p_from);
+              weight = bdpt_direct_hit_weight(st, mode, st.pdf_dir, pdf_dir, p_from);
             }
             film_add(p, p.camera_sum + film_target, accumulated * st.throughput * weight * film_weight);
           }
@@ -558,7 +583,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_light(Pipeline p, V
             if (opt_enable_mis(it)) {
               if (mode == kBdptPathTracing) {
                 weight = power_heuristic(sampling_pdf, es.is_delta ? 0.0f : bsdf.pdf);
-              } else {  // Full
+              } else {
                 const etx_abi_emitter& em = scene.emitters[es.emitter_index];
                 const BVtx sampled = {es.origin, es.normal, 0.0f, 0.0f, kBvEmitter | ((es.triangle_index != kInvalid) ? kBvSurface : 0u), es.triangle_index};
                 const BVtx z_curr = z.full.summary(z.from_prev);
@@ -566,9 +591,17 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_light(Pipeline p, V
                 const float from_emitter = bdpt_pdf_from_emitter(scene, es.emitter_index, es.origin, es.normal, z_curr);
                 const float z_prev_backward = bdpt_pdf_area(scene, kPathLight, es.origin, z.full, z.prev, z.wavelength, smp);
                 const float p_bsdf_sample = bdpt_pdf_area(scene, kPathCamera, z.prev.pos, z.full, sampled, z.wavelength, smp);
-                const float w_camera = bdpt_mis_camera(z.path_size, from_emitter, z.from_prev, z_prev_backward, z.prev);
-                const float w_light = es.is_delta ? 0.0f : safe_div(p_bsdf_sample, p_sample);
-                weight = 1.0f / (w_camera + 1.0f + w_light);
+                if (mode == kBdptFast) {  // :1114-1129
+                  const float p_fwd = z.prev.from_prev * z.from_prev;
+                  const float p_connection = p_fwd * p_sample;
+                  const float p_direct = es.is_delta ? 0.0f : p_fwd * p_bsdf_sample;
+                  const float p_bck = z.prev.history * ((z.path_size > 2u) ? z_prev_backward : 1.0f);
+                  weight = balance_heuristic(p_connection, p_direct, p_sample * from_emitter * p_bck);
+                } else {
+                  const float w_camera = bdpt_mis_camera(z.path_size, from_emitter, z.from_prev, z_prev_backward, z.prev);
+                  const float w_light = es.is_delta ? 0.0f : safe_div(p_bsdf_sample, p_sample);
+                  weight = 1.0f / (w_camera + 1.0f + w_light);
+                }
               }
             }
             const f3 value = z.throughput * bsdf.bsdf * (es.value / sampling_pdf) * weight * spectral_film_weight(scene, z.wavelength);

@@ -213,8 +213,8 @@ class HIPPathTracing(HIPIntegrator):
 
 
 class HIPBidirectional(HIPIntegrator):
-    """CPUBidirectional (sources/etx/rt/integrators/bidirectional.cxx:1490-1560) on the device: bdpt-mode PathTracing,
-    LightTracing and BDPTFull; see include/etx_hip.h for what etx_hip_begin rejects."""
+    """CPUBidirectional (sources/etx/rt/integrators/bidirectional.cxx:1490-1560) on the device, all four bdpt-mode values;
+    see include/etx_hip.h for what etx_hip_begin rejects (random-walk subsurface scenes)."""
 
     def name(self):
         return "Bidirectional (HIP gfx950)"

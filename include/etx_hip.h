@@ -47,7 +47,7 @@ enum {
   ETX_HIP_INTEGRATOR_PT = 0,   /* CPUPathTracing  sources/etx/rt/integrators/path_tracing.cxx:50-110, options = etx_abi_pt_options */
   ETX_HIP_INTEGRATOR_VCM = 1,  /* CPUVCM          sources/etx/rt/integrators/vcm_cpu.cxx:95-241,     options = etx_abi_vcm_options */
   ETX_HIP_INTEGRATOR_BDPT = 2  /* CPUBidirectional sources/etx/rt/integrators/bidirectional.cxx:342-403, options = etx_abi_bdpt_options
-                                  (modes PathTracing / LightTracing / BDPTFull; BDPTFast and random-walk subsurface scenes: ETX_HIP_ERROR_UNSUPPORTED) */
+                                  (all four modes; scenes with random-walk subsurface materials: ETX_HIP_ERROR_UNSUPPORTED) */
 };
 
 /* film layers, subset of etx::Film layer ids (sources/etx/render/host/film.hxx:14-27) that the MC loop produces */
