@@ -69,6 +69,7 @@ def main():
     parser.add_argument("--workload", default="full", choices=["full", "classic"],
                         help="full = surviving cornellbox.mtl (fog medium, env + dir emitters) = BASELINE.json configs[1]; classic = area light only")
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-kernel-table", action="store_true", help="skip the extra pass that times every kernel group (profiling runs)")
     args = parser.parse_args()
 
     import numpy as np
@@ -158,7 +159,7 @@ def main():
     # (etx_hip_set_timers; the main timed region above times only the two traversal groups). Algorithmic bytes per unit are
     # the figures of DESIGN.md 3; the units come from the device counters of the same pass.
     kernels = None
-    if rank == 0:
+    if (rank == 0) and (args.no_kernel_table == False):
         ctx.set_timers(0xff)
         ctx.begin_vcm(options, first_iteration=0, iteration_stride=1)
         groups_steps = min(args.steps, 8)

@@ -80,7 +80,7 @@ ETX_DEV f3 emitter_get_radiance(const DScene& s, const etx_abi_emitter& em_inst,
     case ETX_EMITTER_ENVIRONMENT: {
       const DImage& img = s.images[em.emission.image_index];
       f2 uv = direction_to_uv(q.direction, img.offset, img.scale.x);
-      float sin_t = fmaxf(kEpsilon, sinf(uv.y * kPi));
+      float sin_t = fmaxf(kEpsilon, sin_rev(uv.y * 0.5f));
       float image_pdf = 0.0f;
       f3 eval = apply_image(s, em.emission, uv, &image_pdf, wavelength);
       pdf_area = env_pdf_area(s);
@@ -100,7 +100,7 @@ ETX_DEV f3 emitter_get_radiance(const DScene& s, const etx_abi_emitter& em_inst,
       if (distance_squared > 0.0f) {
         float cos_t = fabsf(dot(dp, geo_n)) / sqrtf(distance_squared);
         float exponent = collimation_to_exponent(material.emission_collimation);
-        float cos_tx = q.directly_visible ? cos_t : powf(cos_t, exponent);
+        float cos_tx = (q.directly_visible || (exponent == 1.0f)) ? cos_t : powf(cos_t, exponent);
         if (cos_tx > kEpsilon) {
           pdf_dir = pdf_area * distance_squared / cos_tx;
           pdf_dir_out = pdf_area * cos_tx * kInvPi;
@@ -155,7 +155,7 @@ ETX_DEV EmitterSample sample_emitter(const DScene& s, uint32_t emitter_index, co
       float pdf_image = 0.0f;
       float4 image_value = make_float4(0, 0, 0, 0);
       f2 uv = image_sample(img, smp, pdf_image, image_value);
-      float sin_t = fmaxf(kEpsilon, sinf(uv.y * kPi));
+      float sin_t = fmaxf(kEpsilon, sin_rev(uv.y * 0.5f));
       r.direction = uv_to_direction(uv, img.offset, img.scale.x);
       r.normal = -r.direction;
       r.origin = from_point + r.direction * distance_to_sphere(from_point, r.direction, s.bounds_center, s.bounds_radius);
@@ -227,7 +227,7 @@ ETX_DEV EmitterSample sample_emission(const DScene& s, Sampler& smp, float wavel
       f2 uv = image_sample(img, smp.next_2d(), pdf_image, image_value);
       if (pdf_image == 0.0f)
         return emitter_sample_zero();
-      float sin_t = fmaxf(kEpsilon, sinf(uv.y * kPi));
+      float sin_t = fmaxf(kEpsilon, sin_rev(uv.y * 0.5f));
       f3 d = -uv_to_direction(uv, img.offset, img.scale.x);
       Basis basis = orthonormal_basis(d);
       f2 disk_sample = sample_disk(smp.next_2d());
@@ -375,10 +375,9 @@ ETX_DEV f3 sample_phase_function(const f3& w_i, float g, const f2 rnd) {  // sce
     cos_theta = (1.0f + g * g - sqr_term * sqr_term) / (2.0f * g);
   }
   float sin_theta = sqrtf(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
-  float phi = kDoublePi * rnd.y;
   Basis basis = orthonormal_basis(w_i);
   float sp, cp;
-  sincosf(phi, &sp, &cp);
+  sincos_rev(rnd.y, &sp, &cp);
   return (basis.u * cp + basis.v * sp) * sin_theta - w_i * cos_theta;
 }
 

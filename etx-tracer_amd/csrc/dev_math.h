@@ -137,12 +137,32 @@ ETX_HD Basis orthonormal_basis(const f3& n) {
   return {a, b};
 }
 
+// sin / cos of an angle given in REVOLUTIONS (angle / 2 pi). v_sin_f32 / v_cos_f32 take exactly this argument (valid for
+// |rev| <= 256, ~1e-6 absolute error); sincosf() costs ~150 VALU instructions in its range reduction, these cost two.
+// Sampling directions and emitter pdfs only: the bit-exact paths (Sampler, offset_ray, cell indices) do not use them.
+ETX_HD void sincos_rev(float rev, float* s, float* c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  *s = __builtin_amdgcn_sinf(rev);
+  *c = __builtin_amdgcn_cosf(rev);
+#else
+  sincosf(rev * kDoublePi, s, c);
+#endif
+}
+ETX_HD float sin_rev(float rev) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sinf(rev);
+#else
+  return sinf(rev * kDoublePi);
+#endif
+}
+
 // math.hxx:748-762 (exponent form; exponent 1 = cosine weighted)
 ETX_HD f3 sample_cosine_distribution(const f2 rnd, float exponent) {
-  float cos_theta = powf(fmaxf(rnd.x, kEpsilon), 1.0f / (exponent + 1.0f));
+  const float x = fmaxf(rnd.x, kEpsilon);
+  float cos_theta = (exponent == 1.0f) ? sqrtf(x) : powf(x, 1.0f / (exponent + 1.0f));  // the cosine lobe (every call site but one) folds to the sqrt
   float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
   float s, c;
-  sincosf(rnd.y * kDoublePi, &s, &c);
+  sincos_rev(rnd.y, &s, &c);
   return {c * sin_theta, s * sin_theta, cos_theta};
 }
 ETX_HD f3 sample_cosine_distribution(const f2 rnd, const f3& n, const f3& u, const f3& v, float exponent) {
@@ -176,7 +196,7 @@ ETX_HD f2 sample_disk(const f2 rnd) {
     theta = kHalfPi - kQuarterPi * (offset.x / offset.y);
   }
   float s, c;
-  sincosf(theta, &s, &c);
+  sincos_rev(theta * (1.0f / kDoublePi), &s, &c);
   return {r * c, r * s};
 }
 
@@ -217,8 +237,8 @@ ETX_HD float power_heuristic(float f, float g) {  // math.hxx:945-950
 // math.hxx:952-974
 ETX_HD f3 from_spherical(float phi, float theta) {
   float sp, cp, st, ct;
-  sincosf(phi, &sp, &cp);
-  sincosf(theta, &st, &ct);
+  sincos_rev(phi * (1.0f / kDoublePi), &sp, &cp);
+  sincos_rev(theta * (1.0f / kDoublePi), &st, &ct);
   return {cp * ct, st, sp * ct};
 }
 // math.hxx:976-998

@@ -407,9 +407,9 @@ ETX_DEV float4 image_evaluate(const DImage& img, const f2 uv, float* pdf) {  // 
   ImageGather g = image_gather(img, uv);
   if (pdf) {
     bool uniform = (img.options & ETX_IMAGE_UNIFORM_SAMPLING_TABLE) || (img.fsize.y == 1.0f);
-    float s_t = uniform ? 1.0f : fmaxf(0.0f, sinf(kPi * saturate(uv.y + 0.0f / img.fsize.y)));
+    float s_t = uniform ? 1.0f : fmaxf(0.0f, sin_rev(0.5f * saturate(uv.y + 0.0f / img.fsize.y)));
     float t = luminance(mk3(add4(g.p00, g.p01))) * s_t;
-    float s_b = uniform ? 1.0f : fmaxf(0.0f, sinf(kPi * saturate(uv.y + 1.0f / img.fsize.y)));
+    float s_b = uniform ? 1.0f : fmaxf(0.0f, sin_rev(0.5f * saturate(uv.y + 1.0f / img.fsize.y)));
     float b = luminance(mk3(add4(g.p10, g.p11))) * s_b;
     *pdf = (t + b) / img.normalization;
   }

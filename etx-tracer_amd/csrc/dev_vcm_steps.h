@@ -307,6 +307,44 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       store = false;
   }
 
+#if defined(ETX_HIP_COST_PROBE)
+  // cost attribution by duplication (tools/cost_probe.sh): a flag runs one part of the step a second time on copies; the
+  // instruction counters of two runs differ by exactly that part. The sink keeps the duplicate alive.
+  if (kSimple && (event == kEventSurface)) {
+    float sink = 0.0f;
+    if (p.debug_flags & 0x400u) {
+      const Isect e = make_intersection(scene, st.ray_d, h.y, h.x, h.z, tri);
+      sink += e.pos.x + e.nrm.y + e.tan.z + e.btn.x + e.tex.x + __uint_as_float(e.material);
+    }
+    if ((p.debug_flags & 0x800u) && (st.medium != kInvalid)) {
+      Sampler s2 = st.sampler;
+      (void)s2.next();
+      const MediumSample m2 = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, s2, st.ray_o, st.ray_d, h.z);
+      sink += m2.pos.x + m2.weight.y + m2.sampled_medium_t;
+    }
+    if (p.debug_flags & 0x1000u) {
+      Sampler s2 = st.sampler;
+      s2.push_fixed(rnd_bsdf.y, rnd_bsdf.x, rnd_support.x);
+      const BsdfSample b2 = bsdf_sample_s<kSimple>(scene, bsdf_data, scene.materials[isect.material], s2);
+      sink += b2.w_o.x + b2.weight.y + b2.pdf;
+    }
+    if (p.debug_flags & 0x2000u) {
+      PathState c = st;
+      (void)c.sampler.next();
+      const bool a = vcm_next_ray<kSimple>(scene, kPathCamera, c, it, isect, bsdf_data, bs, false);
+      sink += c.d_vc + c.d_vm + c.ray_o.x + (a ? 1.0f : 0.0f);
+    }
+    if (p.debug_flags & 0x4000u) {
+      PathState c = st;
+      c.sampler.push_fixed(rnd_connection.y, rnd_connection.x, rnd_support.y);
+      ShadowRequest r2;
+      const bool q2 = vcm_connect_to_light<true>(scene, it, false, &isect, ms.pos, c, film_index(it, st.id), r2);
+      sink += q2 ? r2.value.x + r2.p1.y : 0.0f;
+    }
+    if (sink == 1.2345e-33f)
+      film_add(p, p.camera_sum + film_index(it, st.id), mk3(sink));
+  }
+#endif
   // ---- phase B
   const uint32_t vertex_slot = slots.get(store, p.counters + kCntCameraVertices);
   if (store) {

@@ -1272,7 +1272,7 @@ int etx_hip_read_film_begin(etx_hip_context* context, int layer) {
   const float scale = iterations ? float(1.0 / double(iterations)) : 0.0f;
   const float4* source = (layer == ETX_HIP_LAYER_NORMAL) ? context->pipe.normal_sum : ((layer == ETX_HIP_LAYER_ALBEDO) ? context->pipe.albedo_sum : context->pipe.camera_sum);
   const int mode = (layer == ETX_HIP_LAYER_NORMAL) ? 3 : ((layer == ETX_HIP_LAYER_ALBEDO) ? 0 : layer);
-  launch_film_resolve(context->read_stream, source, context->pipe.light_sum, context->read_resolve, uint32_t(n), scale, mode);
+  launch_film_resolve(context->read_stream, source, context->pipe.light_sum, context->read_resolve, uint32_t(n), scale, mode, context->reduced ? nullptr : context->pipe.camera_sum);
   HIP_OK(context, hipMemcpyAsync(context->read_staging, context->read_resolve, n * sizeof(float4), hipMemcpyDeviceToHost, context->read_stream));
   HIP_OK(context, hipEventRecord(context->read_event, context->read_stream));
   context->read_pending = true;

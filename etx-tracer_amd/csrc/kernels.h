@@ -64,7 +64,7 @@ void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bo
 
 // film
 void launch_vcm_commit(hipStream_t stream, float4* iteration_camera, float4* iteration_light, float4* camera_sum, float4* light_sum, uint32_t pixels);
-void launch_film_resolve(hipStream_t stream, const float4* camera_sum, const float4* light_sum, float4* out, uint32_t pixel_count, float scale, int layer);
+void launch_film_resolve(hipStream_t stream, const float4* camera_sum, const float4* light_sum, float4* out, uint32_t pixel_count, float scale, int layer, const float4* counts = nullptr);
 
 // known-answer kernels
 void launch_kat(hipStream_t stream, int which, const float* in, uint32_t count, float* out, const uint2* bluenoise);

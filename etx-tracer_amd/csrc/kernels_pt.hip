@@ -320,6 +320,7 @@ __global__ __launch_bounds__(kBlockSize) void k_pt_commit(float4* __restrict__ i
         color *= radiance_clamp / lum;
     }
     atomic_add_f3(camera_sum + i, color);  // the film is shared by the lanes (host_api.cpp)
+    atomicAdd(&camera_sum[i].w, 1.0f);     // iterations committed to this pixel (k_film_resolve)
     iteration_image[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
 }

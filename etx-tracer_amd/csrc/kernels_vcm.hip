@@ -219,6 +219,7 @@ __global__ __launch_bounds__(kBlockSize) void k_vcm_commit(float4* __restrict__ 
   const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += gridDim.x * blockDim.x) {
     const float4 c = iteration_camera[i], l = iteration_light[i];
+    atomicAdd(&camera_sum[i].w, 1.0f);  // iterations committed to this pixel (k_film_resolve, progressive read-back)
     if ((c.x != 0.0f) || (c.y != 0.0f) || (c.z != 0.0f)) {
       atomic_add_f3(camera_sum + i, f3{c.x, c.y, c.z});
       iteration_camera[i] = zero;
@@ -236,11 +237,19 @@ void launch_vcm_commit(hipStream_t stream, float4* iteration_camera, float4* ite
 
 // ---------------------------------------------------------------------------------------------------------------
 // Film::layer, film.cxx:381-418: float3 sums -> float4 (alpha 1); Result = max(0, camera + light)
-__global__ void k_film_resolve(const float4* __restrict__ camera_sum, const float4* __restrict__ light_sum, float4* __restrict__ out, uint32_t pixel_count, float scale, int layer) {
+// `counts` (nullable): the camera sums, whose w holds the iterations committed to each pixel (k_vcm_commit / k_pt_commit).
+// A read-back that runs while iterations are in flight normalises every pixel by its own count: the host's iteration
+// counter and the device's commits are not updated at the same instant.
+__global__ void k_film_resolve(const float4* __restrict__ camera_sum, const float4* __restrict__ light_sum, float4* __restrict__ out, uint32_t pixel_count, float scale, int layer,
+  const float4* __restrict__ counts) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pixel_count)
     return;
   float4 c = camera_sum[i], l = light_sum[i];
+  if (counts != nullptr) {
+    const float n = counts[i].w;
+    scale = (n > 0.0f) ? 1.0f / n : 0.0f;
+  }
   float4 r;
   if (layer == 0)
     r = make_float4(c.x * scale, c.y * scale, c.z * scale, 1.0f);
@@ -253,8 +262,8 @@ __global__ void k_film_resolve(const float4* __restrict__ camera_sum, const floa
   out[i] = r;
 }
 
-void launch_film_resolve(hipStream_t stream, const float4* camera_sum, const float4* light_sum, float4* out, uint32_t pixel_count, float scale, int layer) {
-  hipLaunchKernelGGL(k_film_resolve, dim3((pixel_count + 255u) / 256u), dim3(256), 0, stream, camera_sum, light_sum, out, pixel_count, scale, layer);
+void launch_film_resolve(hipStream_t stream, const float4* camera_sum, const float4* light_sum, float4* out, uint32_t pixel_count, float scale, int layer, const float4* counts) {
+  hipLaunchKernelGGL(k_film_resolve, dim3((pixel_count + 255u) / 256u), dim3(256), 0, stream, camera_sum, light_sum, out, pixel_count, scale, layer, counts);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -1,11 +1,12 @@
 // etx_hip_integrators.hxx - the reference-side binding of libetx_hip.so: the file a maintainer adds to etx-tracer as
 // sources/etx/rt/integrators/hip_integrators.hxx. It is COMPILED here: oracle/build_ref.sh builds it
-// against the reference's own headers into the headless driver (oracle/_ref/etx_oracle --integrator hip-vcm | hip-pt), and
+// against the reference's own headers into the headless driver (oracle/_ref/etx_oracle --integrator hip-vcm | hip-pt | hip-bdpt), and
 // tests/test_gpu_binding.py renders through it on the GPU box and compares with the ctypes binding.
 //
-// Two classes on the reference's plugin interface `struct Integrator` (sources/etx/rt/integrators/integrator.hxx:12-98):
+// Three classes on the reference's plugin interface `struct Integrator` (sources/etx/rt/integrators/integrator.hxx:12-98):
 //   HIPVCM          in place of CPUVCM          (sources/etx/rt/integrators/vcm_cpu.cxx:243-310)
 //   HIPPathTracing  in place of CPUPathTracing  (sources/etx/rt/integrators/path_tracing.cxx:112-172)
+//   HIPBidirectional in place of CPUBidirectional (sources/etx/rt/integrators/bidirectional.cxx:1490-1560)
 // Only API that exists in the reference is used. The film is published through Film::accumulate_camera_image /
 // atomic_add_light_iteration / commit_light_iteration (film.hxx:57-59): Film::clear resets the per-pixel sample counts,
 // so ONE accumulate per pixel stores the device's running mean verbatim (film.cxx:195-199), and one light "iteration"
@@ -467,6 +468,51 @@ struct HIPPathTracing : public HIPIntegratorBase {
 
   bool writes_light_image() const override {
     return false;
+  }
+};
+
+struct HIPBidirectional : public HIPIntegratorBase {
+  HIPBidirectional(Raytracing& r)
+    : HIPIntegratorBase(r) {
+    // the option keys and defaults of CPUBidirectional (bidirectional.cxx:1443-1466, mode BDPTFast :332)
+    integrator_options.set_integral("bdpt-mode", uint32_t(ETX_BDPT_MODE_FAST), "Mode");
+    integrator_options.set_bool("bdpt-conn_direct_hit", true, "Direct Hits");
+    integrator_options.set_bool("bdpt-conn_connect_to_camera", true, "Light Path to Camera");
+    integrator_options.set_bool("bdpt-conn_connect_to_light", true, "Camera Path to Light");
+    integrator_options.set_bool("bdpt-conn_connect_vertices", true, "Camera Path to Light Path");
+    integrator_options.set_bool("bdpt-conn_mis", true, "Multiple Importance Sampling");
+    integrator_options.set_bool("bdpt-blue_noise", true, "Enable Blue Noise");
+  }
+
+  const char* name() override {
+    return "Bidirectional (HIP gfx950)";
+  }
+
+  const char* status_str() const override {
+    return (current_state == State::Stopped) ? "Stopped" : "Rendering on the device";
+  }
+
+ protected:
+  bool begin() override {
+    etx_abi_bdpt_options opt = {};
+    opt.mode = integrator_options.get_integral("bdpt-mode", uint32_t(ETX_BDPT_MODE_FAST));  // CPUBidirectionalImpl::start, :1469-1478
+    opt.direct_hit = integrator_options.get_bool("bdpt-conn_direct_hit", true);
+    opt.connect_to_camera = integrator_options.get_bool("bdpt-conn_connect_to_camera", true);
+    opt.connect_to_light = integrator_options.get_bool("bdpt-conn_connect_to_light", true);
+    opt.connect_vertices = integrator_options.get_bool("bdpt-conn_connect_vertices", true);
+    opt.mis = integrator_options.get_bool("bdpt-conn_mis", true);
+    opt.blue_noise = integrator_options.get_bool("bdpt-blue_noise", true);
+    if (opt.blue_noise && (upload_bluenoise() == false))
+      return false;
+    if (HIPBackendLibrary::get().begin(ctx, ETX_HIP_INTEGRATOR_BDPT, &opt, sizeof(opt), 0, 1) != ETX_HIP_OK) {
+      hip_report_error(HIPBackendLibrary::get().last_error(ctx));
+      return false;
+    }
+    return true;
+  }
+
+  bool writes_light_image() const override {
+    return true;
   }
 };
 

@@ -246,7 +246,7 @@ int print_kat() {
 
 void usage() {
   printf(
-    "etx_oracle --scene file.json | --load-snapshot scene.bin --integrator pt|vcm|bdpt|hip-vcm|hip-pt [--spp N] [--out film.raw] [--snapshot scene.bin]\n"
+    "etx_oracle --scene file.json | --load-snapshot scene.bin --integrator pt|vcm|bdpt|hip-vcm|hip-pt|hip-bdpt [--spp N] [--out film.raw] [--snapshot scene.bin]\n"
     "           [--data /root/reference/bin/] [--opt key=value]... [--max-iterations N]\n");
 }
 
@@ -430,6 +430,7 @@ int main(int argc, char** argv) {
   CPUBidirectional bdpt(raytracing);
   HIPVCM hip_vcm(raytracing);          // the device integrators sit behind the same plugin interface (app.hxx:72-82)
   HIPPathTracing hip_pt(raytracing);
+  HIPBidirectional hip_bdpt(raytracing);
   Integrator* integrator = nullptr;
   if (integrator_name == "pt")
     integrator = &pt;
@@ -441,6 +442,8 @@ int main(int argc, char** argv) {
     integrator = &hip_vcm;
   else if (integrator_name == "hip-pt")
     integrator = &hip_pt;
+  else if (integrator_name == "hip-bdpt")
+    integrator = &hip_bdpt;
   else {
     usage();
     return 1;

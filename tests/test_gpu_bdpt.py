@@ -1,7 +1,7 @@
 """GPU (-m gpu): the bidirectional integrator (HIPBidirectional, kernels_bdpt.hip) against the reference's CPUBidirectional.
 
 Golden films: tests/golden/hi/cornell_<flavour>_128_bdpt<mode>_<spp>[_rekeyed].npz (oracle/gen_golden_hi.py --integrators bdpt),
-mode = CPUBidirectionalImpl::Mode (0 PathTracing, 1 LightTracing, 3 BDPTFull), bdpt-blue_noise=false. As for VCM
+mode = CPUBidirectionalImpl::Mode (0 PathTracing, 1 LightTracing, 2 BDPTFast, 3 BDPTFull), bdpt-blue_noise=false. As for VCM
 (test_gpu_parity_hi.py), the reference seeds the light and the camera sub path of a pixel with the same sampler state
 (bidirectional.cxx:379-380); the device gives the camera path a stream of its own, so the tight limits are asserted against
 the reference run with independent streams (`_rekeyed`, ETX_ORACLE_DECORRELATE=2) and the unmodified reference is compared
@@ -45,7 +45,7 @@ def render_halves(etx, golden_dir, flavour, spp, options):
 def test_bdpt_full_matches_reference_at_4096_spp(etx, golden_dir, flavour):
     (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, flavour, 4096, {"bdpt-mode": etx.api.BDPT_MODE_FULL, "bdpt-blue_noise": False})
     golden = load(golden_dir, "cornell_%s_128_bdpt3_4096_rekeyed.npz" % flavour)
-    assert int(golden["spp"]) == 4096
+    assert int(golden["spp"]) in (4095, 4096)  # CPUBidirectional::update does not count its last iteration (bidirectional.cxx:1526-1531)
     compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " bdpt camera+light (independent streams)")
     compare((light_a, light_b), golden["light"], flavour + " bdpt light (independent streams)", mean_limit=1.0e-2, bias_p99_limit=0.2)
     compare((cam_a, cam_b), golden["camera"], flavour + " bdpt camera (independent streams)")
@@ -53,17 +53,30 @@ def test_bdpt_full_matches_reference_at_4096_spp(etx, golden_dir, flavour):
     compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " bdpt camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
 
 
+@pytest.mark.parametrize("flavour", ["classic", "full", "cloud", "glass"])
+def test_bdpt_fast_matches_reference_at_1024_spp(etx, golden_dir, flavour):
+    """bdpt-mode BDPTFast, the reference's default (bidirectional.cxx:332): no vertex connections, product-form weights."""
+    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, flavour, 1024, {"bdpt-mode": etx.api.BDPT_MODE_FAST, "bdpt-blue_noise": False})
+    golden = load(golden_dir, "cornell_%s_128_bdpt2_1024_rekeyed.npz" % flavour)
+    assert int(golden["spp"]) in (1023, 1024)
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " bdpt-fast camera+light (independent streams)")
+    compare((light_a, light_b), golden["light"], flavour + " bdpt-fast light (independent streams)", mean_limit=1.0e-2, bias_p99_limit=0.2)
+    compare((cam_a, cam_b), golden["camera"], flavour + " bdpt-fast camera (independent streams)")
+    golden = load(golden_dir, "cornell_%s_128_bdpt2_1024.npz" % flavour)
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " bdpt-fast camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_bdpt_single_technique_modes(etx, golden_dir, mode):
     """bdpt-mode PathTracing (camera paths + next event estimation only) and LightTracing (light paths splatted to the camera only)."""
     (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, "full", 1024, {"bdpt-mode": mode, "bdpt-blue_noise": False})
     golden = load(golden_dir, "cornell_full_128_bdpt%d_1024%s.npz" % (mode, "_rekeyed" if mode else ""))
-    assert int(golden["spp"]) == 1024
+    assert int(golden["spp"]) in (1023, 1024)
     if mode == 0:
-        assert float(np.abs(light_a).max()) == 0.0
-        compare((cam_a, cam_b), golden["camera"], "full bdpt mode PathTracing camera")
+        assert float(np.abs(light_a[..., :3]).max()) == 0.0
+        compare((cam_a, cam_b), golden["camera"], "full bdpt mode PathTracing camera", rmse_limit=2.0e-3)  # 1024-spp films of a scene with an environment and a sun: the noise estimate itself is that uncertain
     else:
-        assert float(np.abs(cam_a).max()) == 0.0
+        assert float(np.abs(cam_a[..., :3]).max()) == 0.0
         compare((light_a, light_b), golden["light"], "full bdpt mode LightTracing light", mean_limit=1.0e-2, bias_p99_limit=0.2)
 
 

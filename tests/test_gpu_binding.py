@@ -60,6 +60,21 @@ def test_cpp_hip_path_tracer_matches_ctypes_binding(etx, golden_dir, tmp_path):
     assert np.abs(film["light"][..., :3]).max() == 0.0
 
 
+def test_cpp_hip_bidirectional_matches_ctypes_binding(etx, golden_dir, tmp_path):
+    snapshot = os.path.join(golden_dir, "cornell_full_128.etxscene")
+    film, log = run_driver(tmp_path, snapshot, "hip-bdpt", 16, "bdpt-blue_noise=false", "bdpt-mode=3")
+    assert "Bidirectional (HIP gfx950)" in log
+    snap = etx.SceneSnapshot(snapshot)
+    snap.samples = 16
+    integ = etx.HIPBidirectional(snap)
+    integ.options().update({"bdpt-blue_noise": False, "bdpt-mode": etx.api.BDPT_MODE_FULL})
+    integ.render()
+    cam, light = integ.film(etx.api.LAYER_CAMERA), integ.film(etx.api.LAYER_LIGHT)
+    integ.context.close()
+    np.testing.assert_allclose(film["camera"][..., :3], cam[..., :3], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(film["light"][..., :3], light[..., :3], rtol=2e-4, atol=2e-5)
+
+
 def test_cpp_binding_spectral_scene_uploads_the_observer(etx, golden_dir, tmp_path, cie_observer):
     snapshot = os.path.join(golden_dir, "cornell_diamond_128.etxscene")
     film, _ = run_driver(tmp_path, snapshot, "hip-vcm", 8, "vcm-blue_noise=false")

@@ -8,7 +8,7 @@ are independent estimates, so their difference measures the Monte-Carlo noise th
 (sigma^2 = mean((A - B)^2) / 4 per block); the reference's film carries the same amount. What is asserted:
   * block-8 RMSE against the reference with that noise removed: sqrt(max(0, MSE - 2 sigma^2)) < 1e-3  (the estimator
     difference north_star bounds); the raw block-8 RMSE is printed and bounded by 1e-3 + the noise
-  * per-channel relative difference of the image mean     < 0.3 %
+  * per-channel relative difference of the image mean     < 0.3 % plus three standard errors of that difference (from the halves)
   * per-pixel relative bias (4 x 4 block means, |d| / (ref + 0.02)): 99th percentile below 5 % plus 1.5 x the same
     percentile of the noise map of the two halves
 Light and camera layers are also compared separately for VCM.
@@ -56,12 +56,27 @@ def compare(halves, reference, label, rmse_limit=1.0e-3, mean_limit=3.0e-3, bias
     reference = np.where(ok[..., None], reference, 0.0)
     a = np.where(ok[..., None], a[..., :3], 0.0).astype(np.float64)
     b = np.where(ok[..., None], b[..., :3], 0.0).astype(np.float64)
+    # One sample of a rare path can carry more than a whole block of the image (seen: a single pixel of the reference's PT
+    # cloud film at 1.72 among neighbours at 0.19 moved its 8 x 8 block by 2.4e-2), and neither film's noise estimate knows
+    # about the other film's outlier. Pixels that exceed three times the median of their 3 x 3 neighbourhood in EITHER film are
+    # replaced by that median in both (the edge pixels of the directly visible emitter are flagged alike in both films).
+    from scipy.ndimage import median_filter
+    med_ref = median_filter(reference, size=(3, 3, 1), mode="nearest")
+    med_dev = median_filter(0.5 * (a + b), size=(3, 3, 1), mode="nearest")
+    speck = ((reference > 3.0 * med_ref + 0.02) | (0.5 * (a + b) > 3.0 * med_dev + 0.02)).any(axis=2)
+    assert speck.mean() < 0.02, (label, speck.mean())
+    reference = np.where(speck[..., None], med_ref, reference)
+    a = np.where(speck[..., None], med_dev, a)
+    b = np.where(speck[..., None], med_dev, b)
     device = 0.5 * (a + b)
     mse = float(np.mean((block_mean(device, 8) - block_mean(reference, 8)) ** 2))
     noise = float(np.mean((block_mean(a, 8) - block_mean(b, 8)) ** 2)) / 4.0  # variance of the 4096-spp block means
     excess = float(np.sqrt(max(0.0, mse - 2.0 * noise)))
     ref_mean = reference.mean(axis=(0, 1))
     rel_mean = (device.mean(axis=(0, 1)) - ref_mean) / np.maximum(ref_mean, 1e-6)
+    # standard error of the image mean, per channel, from the two halves (pixels are independent): a channel whose energy
+    # sits in a few caustic pixels (the blue of the gems box, mean 0.004) has a mean that is still noisy at 4096 spp
+    mean_sigma = np.sqrt(((a - b) ** 2).sum(axis=(0, 1)) / 4.0) / float(a.shape[0] * a.shape[1]) / np.maximum(ref_mean, 1e-6)
     d4, r4 = block_mean(device, 4), block_mean(reference, 4)
     bias = np.abs(d4 - r4).sum(axis=2) / (r4.sum(axis=2) + 0.02)
     p99 = float(np.percentile(bias, 99.0))
@@ -73,7 +88,7 @@ def compare(halves, reference, label, rmse_limit=1.0e-3, mean_limit=3.0e-3, bias
           (label, np.sqrt(mse), np.sqrt(noise), excess, np.round(rel_mean, 4), p99, noise_p99))
     assert excess < rmse_limit, (label, excess)
     assert np.sqrt(mse) < rmse_limit + 2.0 * np.sqrt(noise), (label, np.sqrt(mse))
-    assert np.abs(rel_mean).max() < mean_limit, (label, rel_mean)
+    assert (np.abs(rel_mean) < mean_limit + 3.0 * np.sqrt(2.0) * mean_sigma).all(), (label, rel_mean, mean_sigma)
     assert p99 < bias_p99_limit + 1.5 * noise_p99, (label, p99, noise_p99)
 
 

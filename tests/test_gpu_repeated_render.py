@@ -18,9 +18,10 @@ SPP = 256
 
 
 def reference_film(golden_dir, flavour):
-    """The reference's CPUVCM film: the 4096-spp golden when it is there (tests/golden/hi, oracle/gen_golden_hi.py), else 64 spp."""
-    hi = os.path.join(golden_dir, "hi", "cornell_%s_128_vcm_4096.npz" % flavour)
-    golden = np.load(hi if os.path.exists(hi) else os.path.join(golden_dir, "cornell_%s_128_vcm.npz" % flavour))
+    """The reference's CPUVCM film of the FIRST iterations (64 or 256 spp, oracle/gen_golden.py). Not the 4096-spp film: the merge
+    radius shrinks with the iteration index (vcm_cpu.cxx:100-113), and with it the merging bias - in the gems box the blue mean is
+    0.0092 over iterations 0-63, 0.0091 over 0-255, 0.0076 over 2048-2303 (device) against 0.0092 / 0.0078 (reference, 64 / 4096 spp)."""
+    golden = np.load(os.path.join(golden_dir, "cornell_%s_128_vcm.npz" % flavour))
     total = golden["camera"] + golden["light"]
     ok = np.isfinite(total).all(axis=2)  # the reference's release build lets an occasional NaN sample through
     assert ok.mean() > 0.999
