@@ -22,7 +22,7 @@ VCM_FULL_OPTIONS = 0x7F
 
 EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene",
-    "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
+    "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_upload_rgb_response", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
     "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
 )
@@ -162,6 +162,7 @@ class Library:
         L.etx_hip_upload_scene.argtypes = [vp, vp, vp]
         L.etx_hip_upload_bluenoise.argtypes = [vp, u32, vp, sz]
         L.etx_hip_upload_cie_table.argtypes = [vp, vp, u32, ctypes.c_float]
+        L.etx_hip_upload_rgb_response.argtypes = [vp, vp, u32, ctypes.c_float]
         L.etx_hip_begin.argtypes = [vp, i32, vp, sz, u32, u32]
         L.etx_hip_render_iteration.argtypes = [vp]
         L.etx_hip_try_render_iteration.argtypes = [vp]
@@ -237,6 +238,11 @@ class Context:
         """xyz: float32 [count, 3] = spectrum::spectral_xyz(i) of the host, 1 nm apart from first_wavelength (spectral scenes)."""
         table = np.ascontiguousarray(xyz, dtype=np.float32)
         self._check(self.library.lib.etx_hip_upload_cie_table(self.handle, table.ctypes.data, table.shape[0], float(first_wavelength)))
+
+    def upload_rgb_response(self, rgb, first_wavelength):
+        """rgb_response of the unit colours per integer wavelength (float32 [count, 3]): spectral scenes with RGB images."""
+        table = np.ascontiguousarray(rgb, dtype=np.float32)
+        self._check(self.library.lib.etx_hip_upload_rgb_response(self.handle, table.ctypes.data, table.shape[0], float(first_wavelength)))
 
     def begin_vcm(self, options, first_iteration=0, iteration_stride=1):
         self._check(self.library.lib.etx_hip_begin(self.handle, INTEGRATOR_VCM, ctypes.byref(options), ctypes.sizeof(options), first_iteration, iteration_stride))

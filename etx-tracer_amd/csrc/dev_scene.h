@@ -126,6 +126,7 @@ struct DScene {
   const float2* spectrum_entries;
   const uint2* spectrum_ranges;  // per spectrum: first entry, entry count
   const float4* cie_xyz;         // spectrum::spectral_xyz(i), i = wavelength - cie_first (etx_hip_upload_cie_table)
+  const float4* rgb_response;    // rows of rgb_response's table, i = wavelength - rgb_response_first (etx_hip_upload_rgb_response)
   const DImage* images;
   const DMedium* mediums;
   const Bvh4Node* bvh_nodes;
@@ -156,6 +157,8 @@ struct DScene {
   uint32_t spectral;    // Scene::spectral(): one wavelength per path, SpectralResponse = one float (kept replicated in xyz here)
   uint32_t cie_count;
   float cie_first, cie_y_scale;  // spectrum::kShortestWavelength, 1 / kYIntegral
+  uint32_t rgb_response_count;
+  float rgb_response_first;
   DCamera camera;
 };
 
@@ -449,6 +452,20 @@ ETX_DEV f2 image_sample(const DImage& img, const f2 rnd, float& image_pdf, float
 }
 
 // scene.hxx:250-320 : texture helpers (RGB mode: SpectralResponse = float3 `integrated`)
+// rgb_response, spectrum.cxx:399-612: the weight of an RGB texel at one wavelength (table uploaded by the host)
+ETX_DEV float rgb_response(const DScene& s, float wavelength, const f3& rgb) {
+  if (luminance(rgb) == 0.0f)
+    return 0.0f;
+  const float last = s.rgb_response_first + float(s.rgb_response_count - 1u);
+  if ((wavelength < s.rgb_response_first) || (wavelength > last))
+    return 0.0f;
+  const uint32_t wi = uint32_t(wavelength - s.rgb_response_first);
+  const uint32_t wj = min(wi + 1u, s.rgb_response_count - 1u);
+  const float dw = wavelength - floorf(wavelength);
+  const float4 a = s.rgb_response[wi], b = s.rgb_response[wj];
+  return rgb.x * (a.x + (b.x - a.x) * dw) + rgb.y * (a.y + (b.y - a.y) * dw) + rgb.z * (a.z + (b.z - a.z) * dw);
+}
+
 ETX_DEV f3 apply_image(const DScene& s, const etx_abi_spectral_image& img, const f2 uv, float* image_pdf, float wavelength) {  // scene.hxx:295-309
   if (image_pdf)
     *image_pdf = 0.0f;
@@ -456,6 +473,8 @@ ETX_DEV f3 apply_image(const DScene& s, const etx_abi_spectral_image& img, const
   if (img.image_index == kInvalid)
     return result;
   float4 e = image_evaluate(s.images[img.image_index], uv, image_pdf);
+  if (s.spectral)  // apply_rgb, scene.hxx:249-260
+    return result * rgb_response(s, wavelength, mk3(e));
   return result * mk3(e);
 }
 ETX_DEV float evaluate_image(const DScene& s, const etx_abi_sampled_image& img, const f2 uv, float default_value) {  // scene.hxx:272-281

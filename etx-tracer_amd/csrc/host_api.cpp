@@ -85,6 +85,9 @@ struct etx_hip_context {
   uint8_t* bluenoise[kBlueNoiseSets] = {};  // device tables by sample-count class (etx_hip_upload_bluenoise)
   const uint8_t* active_bluenoise = nullptr;
   float4* cie_table = nullptr;      // spectrum::spectral_xyz (etx_hip_upload_cie_table), spectral scenes only
+  float4* rgb_response_table = nullptr;  // rgb_response rows (etx_hip_upload_rgb_response), spectral scenes with RGB images
+  uint32_t rgb_response_count = 0;
+  float rgb_response_first = 0.0f;
   uint32_t cie_count = 0;
   float cie_first = 0.0f, cie_y_scale = 0.0f;
   etx_hip_stats_t stats = {};
@@ -898,6 +901,8 @@ void etx_hip_destroy(etx_hip_context* context) {
       (void)hipFree(table);
   if (context->cie_table)
     (void)hipFree(context->cie_table);
+  if (context->rgb_response_table)
+    (void)hipFree(context->rgb_response_table);
   if (context->read_resolve)
     (void)hipFree(context->read_resolve);
   if (context->read_staging)
@@ -1000,6 +1005,24 @@ int etx_hip_upload_cie_table(etx_hip_context* context, const float* xyz, uint32_
   return ETX_HIP_OK;
 }
 
+int etx_hip_upload_rgb_response(etx_hip_context* context, const float* rgb, uint32_t count, float first_wavelength) {
+  if ((context == nullptr) || (rgb == nullptr) || (count < 2u) || (count > 4096u))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  (void)wait_idle(context);
+  HIP_OK(context, hipSetDevice(context->device));
+  std::vector<float4> table(count);
+  for (uint32_t i = 0; i < count; ++i)
+    table[i] = make_float4(rgb[3 * i + 0], rgb[3 * i + 1], rgb[3 * i + 2], 0.0f);
+  if (context->rgb_response_table)
+    (void)hipFree(context->rgb_response_table);
+  context->rgb_response_table = nullptr;
+  HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&context->rgb_response_table), count * sizeof(float4)));
+  HIP_OK(context, hipMemcpy(context->rgb_response_table, table.data(), count * sizeof(float4), hipMemcpyHostToDevice));
+  context->rgb_response_count = count;
+  context->rgb_response_first = first_wavelength;
+  return ETX_HIP_OK;
+}
+
 int etx_hip_begin(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
@@ -1070,8 +1093,15 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
       context->error = "spectral scene: the CIE observer table has not been uploaded (etx_hip_upload_cie_table)";
       return ETX_HIP_ERROR_UNSUPPORTED;
     }
+    if (context->scene.needs_rgb_response && (context->rgb_response_table == nullptr)) {
+      context->error = "spectral scene with RGB images: the rgb_response table has not been uploaded (etx_hip_upload_rgb_response)";
+      return ETX_HIP_ERROR_UNSUPPORTED;
+    }
     auto patch = [&](etx_hip_context* lane) {
       for (DScene* d : {&lane->scene.host_copy, &lane->pipe.scene}) {
+        d->rgb_response = context->rgb_response_table;
+        d->rgb_response_count = context->rgb_response_count;
+        d->rgb_response_first = context->rgb_response_first;
         d->cie_xyz = context->cie_table;
         d->cie_count = context->cie_count;
         d->cie_first = context->cie_first;

@@ -45,6 +45,7 @@ void DeviceScene::borrow(const DeviceScene& owner) {
   group_general = owner.group_general, group_subsurface = owner.group_subsurface;
   has_subsurface = owner.has_subsurface;
   generic_materials = owner.generic_materials;
+  needs_rgb_response = owner.needs_rgb_response;
   bvh_bytes = owner.bvh_bytes;
 }
 
@@ -445,6 +446,7 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
   const bool spectral = (scene->flags & ETX_SCENE_SPECTRAL) != 0;
+  out.needs_rgb_response = false;
   if ((camera->film_size.x == 0) || (camera->film_size.y == 0)) {
     error = "camera film size is zero";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
@@ -478,10 +480,8 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
       error = "diffuse_variation " + std::to_string(m.diffuse_variation) + " is unknown (0 Lambert, 1 microfacet, 2 vMF: bsdf_various.hxx:47-69)";
       return ETX_HIP_ERROR_UNSUPPORTED;
     }
-    if (spectral && ((m.scattering.image_index != ETX_ABI_INVALID) || (m.reflectance.image_index != ETX_ABI_INVALID) || (m.emission.image_index != ETX_ABI_INVALID))) {
-      error = "spectral mode with RGB textures (apply_rgb upsampling, scene.hxx:250-270) is not implemented by the device path";
-      return ETX_HIP_ERROR_UNSUPPORTED;
-    }
+    if (spectral && ((m.scattering.image_index != ETX_ABI_INVALID) || (m.reflectance.image_index != ETX_ABI_INVALID) || (m.emission.image_index != ETX_ABI_INVALID)))
+      out.needs_rgb_response = true;  // apply_rgb, scene.hxx:249-260 (etx_hip_upload_rgb_response)
     if (m.subsurface.cls == 2u) {
       error = "Christensen-Burley subsurface scattering (gather_cb, path_tracing_shared.hxx:161-232) is not implemented by the device path (random walk is)";
       return ETX_HIP_ERROR_UNSUPPORTED;
@@ -567,6 +567,9 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   if ((rc = upload(out, material_table.data(), material_table.size(), d.materials, error)) || (rc = upload(out, variants.data(), variants.size(), d.material_variants, error)) ||
       (rc = upload(out, groups.data(), groups.size(), d.material_group, error)))
     return rc;
+  for (uint64_t i = 0; spectral && (i < scene->emitter_profiles.count); ++i)
+    if (reinterpret_cast<const etx_abi_emitter_profile*>(scene->emitter_profiles.a)[i].emission.image_index != ETX_ABI_INVALID)
+      out.needs_rgb_response = true;  // image environment maps / textured emitters
   if ((rc = upload(out, reinterpret_cast<const etx_abi_emitter_profile*>(scene->emitter_profiles.a), scene->emitter_profiles.count, d.emitter_profiles, error)))
     return rc;
   if ((rc = upload(out, reinterpret_cast<const etx_abi_emitter*>(scene->emitter_instances.a), scene->emitter_instances.count, d.emitters, error)))

@@ -27,6 +27,7 @@ struct DeviceScene {
   bool group_subsurface = false;   // ... of kShadeGroupSubsurface
   bool has_subsurface = false;     // a random-walk subsurface material is in use (PT only so far)
   bool generic_materials = false;  // a connectible (non delta) surface material other than Diffuse is in use
+  bool needs_rgb_response = false; // spectral scene with RGB images behind spectra: apply_rgb needs the host's table (etx_hip_upload_rgb_response)
   size_t bvh_bytes = 0;
 
   ~DeviceScene();

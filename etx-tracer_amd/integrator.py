@@ -116,6 +116,7 @@ class HIPIntegrator(Integrator):
         # what the C++ host tabulates from its BNSampler (include/etx_hip.h): {set_index: uint8 [128,128,256,8]}
         self.bluenoise_tables = {}
         self.cie_table = None  # spectral scenes: (float32 [count, 3] spectrum::spectral_xyz, first wavelength) of the host
+        self.rgb_response_table = None  # spectral scenes with RGB images: (float32 [count, 3] rgb_response rows, first wavelength) of the host
         self._bluenoise_uploaded = set()
 
     def _begin(self):
@@ -135,6 +136,8 @@ class HIPIntegrator(Integrator):
             self._uploaded_version = self.snapshot.version
         if self.cie_table is not None:
             self.context.upload_cie_table(*self.cie_table)
+        if self.rgb_response_table is not None:
+            self.context.upload_rgb_response(*self.rgb_response_table)
         for set_index, table in self.bluenoise_tables.items():
             if set_index not in self._bluenoise_uploaded:
                 self.context.upload_bluenoise(set_index, table)

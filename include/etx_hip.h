@@ -96,6 +96,13 @@ int etx_hip_upload_bluenoise(etx_hip_context* context, uint32_t set_index, const
  * ETX_HIP_ERROR_UNSUPPORTED on a spectral scene until the table is uploaded. */
 int etx_hip_upload_cie_table(etx_hip_context* context, const float* xyz, uint32_t count, float first_wavelength);
 
+/* Spectral scenes with RGB textures (albedo / emission images, image environment maps): apply_rgb
+ * (sources/etx/render/shared/scene.hxx:249-260) weighs the texel with rgb_response(wavelength, rgb), a table the host compiles
+ * in (sources/etx/render/host/spectrum.cxx:399-612, 1 nm steps from spectrum::kRGBResponseShortestWavelength). rgb = count * 3
+ * floats: rgb_response of the unit colours (1,0,0), (0,1,0), (0,0,1) at every integer wavelength = the rows of that table.
+ * etx_hip_begin fails with ETX_HIP_ERROR_UNSUPPORTED on such a scene until the table is uploaded. */
+int etx_hip_upload_rgb_response(etx_hip_context* context, const float* rgb, uint32_t count, float first_wavelength);
+
 /* ------------------------------------------------------------------------------------------------------------ */
 /* rendering */
 

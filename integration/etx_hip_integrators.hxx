@@ -56,6 +56,7 @@ struct HIPBackendLibrary {
   decltype(&etx_hip_upload_scene) upload_scene = nullptr;
   decltype(&etx_hip_upload_bluenoise) upload_bluenoise = nullptr;
   decltype(&etx_hip_upload_cie_table) upload_cie_table = nullptr;
+  decltype(&etx_hip_upload_rgb_response) upload_rgb_response = nullptr;
   decltype(&etx_hip_begin) begin = nullptr;
   decltype(&etx_hip_try_render_iteration) try_render_iteration = nullptr;
   decltype(&etx_hip_poll) poll = nullptr;
@@ -94,6 +95,7 @@ struct HIPBackendLibrary {
     resolve(lib.upload_scene, "etx_hip_upload_scene");
     resolve(lib.upload_bluenoise, "etx_hip_upload_bluenoise");
     resolve(lib.upload_cie_table, "etx_hip_upload_cie_table");
+    resolve(lib.upload_rgb_response, "etx_hip_upload_rgb_response");
     resolve(lib.begin, "etx_hip_begin");
     resolve(lib.try_render_iteration, "etx_hip_try_render_iteration");
     resolve(lib.poll, "etx_hip_poll");
@@ -153,7 +155,7 @@ struct HIPIntegratorBase : public Integrator {
       hip_report_error(lib.last_error(ctx));  // e.g. ETX_HIP_ERROR_UNSUPPORTED: stay Stopped, like a failed Embree commit
       return;
     }
-    if (rt.scene().spectral() && (upload_cie_table() == false))
+    if (rt.scene().spectral() && ((upload_cie_table() == false) || (upload_rgb_response() == false)))
       return;
     if (begin() == false)
       return;
@@ -378,6 +380,22 @@ struct HIPIntegratorBase : public Integrator {
   }
 
   // the CIE observer behind SpectralResponse::to_rgb (spectrum.hxx:28-140, 271-293): the host's data, not compiled into the backend
+  // apply_rgb (scene.hxx:249-260): rgb_response of the unit colours at every integer wavelength = the rows of its table
+  bool upload_rgb_response() {
+    std::vector<float> rows(size_t(spectrum::RGBResponseWavelengthCount) * 3u);
+    for (uint32_t k = 0; k < spectrum::RGBResponseWavelengthCount; ++k) {
+      const SpectralQuery q = {spectrum::kRGBResponseShortestWavelength + float(k), SpectralQuery::Spectral};
+      rows[3u * k + 0u] = rgb_response(q, {1.0f, 0.0f, 0.0f}).value;
+      rows[3u * k + 1u] = rgb_response(q, {0.0f, 1.0f, 0.0f}).value;
+      rows[3u * k + 2u] = rgb_response(q, {0.0f, 0.0f, 1.0f}).value;
+    }
+    if (HIPBackendLibrary::get().upload_rgb_response(ctx, rows.data(), spectrum::RGBResponseWavelengthCount, spectrum::kRGBResponseShortestWavelength) != ETX_HIP_OK) {
+      hip_report_error(HIPBackendLibrary::get().last_error(ctx));
+      return false;
+    }
+    return true;
+  }
+
   bool upload_cie_table() {
     std::vector<float> xyz(size_t(spectrum::WavelengthCount) * 3u);
     for (uint32_t k = 0; k < spectrum::WavelengthCount; ++k) {

@@ -285,6 +285,23 @@ int main(int argc, char** argv) {
       fclose(f);
       return 0;
     }
+    else if (strcmp(argv[i], "--dump-rgb-response") == 0) {
+      // --dump-rgb-response <file>: first wavelength, count, then rgb_response (spectrum.cxx:399-612) of the unit colours at every
+      // integer wavelength = the rows of its table (etx_hip_upload_rgb_response)
+      const char* file = next();
+      FILE* f = fopen(file, "wb");
+      if (f == nullptr)
+        return 2;
+      float head[2] = {spectrum::kRGBResponseShortestWavelength, float(spectrum::RGBResponseWavelengthCount)};
+      fwrite(head, sizeof(float), 2, f);
+      for (uint32_t k = 0; k < spectrum::RGBResponseWavelengthCount; ++k) {
+        const SpectralQuery q = {spectrum::kRGBResponseShortestWavelength + float(k), SpectralQuery::Spectral};
+        float row[3] = {rgb_response(q, {1.0f, 0.0f, 0.0f}).value, rgb_response(q, {0.0f, 1.0f, 0.0f}).value, rgb_response(q, {0.0f, 0.0f, 1.0f}).value};
+        fwrite(row, sizeof(float), 3, f);
+      }
+      fclose(f);
+      return 0;
+    }
     else if (strcmp(argv[i], "--dump-bluenoise") == 0) {
       // --dump-bluenoise <samples> <file>: what sample_blue_noise (path_tracing.cxx:173-178) returns for this sample-count
       // class, as bytes: value[(((py * 128 + px) * 256) + sample) * 8 + dimension], float = (0.5 + value) / 256

@@ -576,6 +576,8 @@ two_sided 1
 
 """ + MTL_LIGHT_CLASSIC)
     write_json("textured_test_128.json", "cornell_textured.obj", "cornell_textured.mtl", (128, 128), 64)
+    # the same box in spectral mode: RGB textures go through apply_rgb / rgb_response (scene.hxx:249-260)
+    write_json("spectex_test_128.json", "cornell_textured.obj", "cornell_textured.mtl", (128, 128), 64, spectral=True)
     # image environment map only: the box without its area light, lit through the open front
     with open(os.path.join(OUT, "cornell_envmap.mtl"), "w") as f:
         f.write("newmtl et::env\nimage textures/sky.hdr\nrotation 30\n\n" + MTL_COMMON + "newmtl light\nmaterial class diffuse\nKd 0.780 0.780 0.780\ntwo_sided 1\n\n")

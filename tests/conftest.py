@@ -59,6 +59,14 @@ def bluenoise_64spp():
 
 
 @pytest.fixture(scope="session")
+def rgb_response():
+    """(rgb float32 [391, 3], first wavelength): the rows of the reference's rgb_response table (oracle/gen_golden.py)."""
+    import numpy as np
+    z = np.load(os.path.join(GOLDEN, "rgb_response.npz"))
+    return z["rgb"], float(z["first_wavelength"])
+
+
+@pytest.fixture(scope="session")
 def cie_observer():
     """(xyz float32 [441, 3], first wavelength): spectrum::spectral_xyz of the reference (oracle/gen_golden.py)."""
     import numpy as np

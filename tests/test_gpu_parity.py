@@ -166,11 +166,12 @@ def test_device_bluenoise_lookup_matches_reference(etx, kat_reference, bluenoise
 # ---------------------------------------------------------------------------------------------------------------
 # VCM images against the reference's golden films
 
-def render(etx, golden_dir, scene, spp, options=None, first=0, stride=1, size_override=None, bluenoise=None, cie=None):
+def render(etx, golden_dir, scene, spp, options=None, first=0, stride=1, size_override=None, bluenoise=None, cie=None, rgb_response=None):
     snap = etx.SceneSnapshot(os.path.join(golden_dir, scene + ".etxscene"))
     snap.samples = spp
     integ = etx.HIPVCM(snap, first_iteration=first, iteration_stride=stride)
     integ.cie_table = cie
+    integ.rgb_response_table = rgb_response
     integ.options()["vcm-blue_noise"] = bluenoise is not None
     if bluenoise is not None:
         integ.bluenoise_tables = dict(bluenoise)
@@ -238,11 +239,12 @@ def test_vcm_default_options_with_blue_noise_match_reference(etx, golden_dir, bl
 # ---------------------------------------------------------------------------------------------------------------
 # unidirectional path tracer (BASELINE configs[0]) against the reference's CPUPathTracing
 
-def render_pt(etx, golden_dir, scene, spp, options=None, bluenoise=None, first=0, stride=1, cie=None):
+def render_pt(etx, golden_dir, scene, spp, options=None, bluenoise=None, first=0, stride=1, cie=None, rgb_response=None):
     snap = etx.SceneSnapshot(os.path.join(golden_dir, scene + ".etxscene"))
     snap.samples = spp
     integ = etx.HIPPathTracing(snap, first_iteration=first, iteration_stride=stride)
     integ.cie_table = cie
+    integ.rgb_response_table = rgb_response
     integ.options()["bn"] = bluenoise is not None
     if bluenoise is not None:
         integ.bluenoise_tables = dict(bluenoise)
@@ -485,15 +487,26 @@ def test_unsupported_options_are_rejected(etx, golden_dir):
 # ---------------------------------------------------------------------------------------------------------------
 # feature-coverage scenes: the branches no Cornell variant above reaches
 
-@pytest.mark.parametrize("flavour", ["textured", "envmap", "lens", "equirect"])
-def test_feature_scenes_match_reference(etx, golden_dir, flavour):
+@pytest.mark.parametrize("flavour", ["textured", "envmap", "lens", "equirect", "spectex"])
+def test_feature_scenes_match_reference(etx, golden_dir, cie_observer, rgb_response, flavour):
     """textured: albedo texture, alpha cut-out card (opacity x texture alpha: stochastic alpha test inside traversal,
     scene_bsdf.hxx:128-144) and a tangent-space normal map; envmap: an image environment map (2-D sampling tables,
     emitter_sample_in / emitter_get_radiance on images) as the only light; lens: thin lens with an aperture image (generate_ray and
     sample_film lens sampling, scene_camera.hxx:26-118); equirect: equirectangular camera (no light image for this class).
+    spectex: the textured box in spectral mode - RGB texels through apply_rgb / rgb_response (scene.hxx:249-260; the host's table
+    comes in through etx_hip_upload_rgb_response, without it etx_hip_begin refuses the scene).
     PT and VCM against the reference's films (scenes/make_scenes.py, oracle/gen_golden.py features)."""
+    spectral = {"cie": cie_observer, "rgb_response": rgb_response} if flavour == "spectex" else {}
+    if spectral:
+        snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_spectex_128.etxscene"))
+        integ = etx.HIPVCM(snap)
+        integ.cie_table = cie_observer
+        integ.options()["vcm-blue_noise"] = False
+        with pytest.raises(etx.EtxHipError, match="rgb_response"):
+            integ.run()
+        integ.context.close()
     golden = np.load(os.path.join(golden_dir, "cornell_%s_128_pt.npz" % flavour))
-    layers, stats = render_pt(etx, golden_dir, "cornell_%s_128" % flavour, int(golden["spp"]))
+    layers, stats = render_pt(etx, golden_dir, "cornell_%s_128" % flavour, int(golden["spp"]), **spectral)
     assert stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
     h, w = golden["camera"].shape[:2]
     b = 16 if h >= 128 else 8
@@ -507,7 +520,7 @@ def test_feature_scenes_match_reference(etx, golden_dir, flavour):
     assert rmse(block_mean(layers["normal"], 8), block_mean(golden["normal"], 8)) < 1.0e-2   # normal map / lens blur show up here
     assert rmse(block_mean(layers["albedo"], 8), block_mean(golden["albedo"], 8)) < 1.0e-2   # albedo texture
     golden = np.load(os.path.join(golden_dir, "cornell_%s_128_vcm.npz" % flavour))
-    cam, light, res, stats = render(etx, golden_dir, "cornell_%s_128" % flavour, int(golden["spp"]))
+    cam, light, res, stats = render(etx, golden_dir, "cornell_%s_128" % flavour, int(golden["spp"]), **spectral)
     assert stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
     ref_result = np.maximum(golden["camera"] + golden["light"], 0.0)
     ok = np.isfinite(ref_result).all(axis=2)
