@@ -128,6 +128,8 @@ class Stats(ctypes.Structure):
         ("rays_camera", ctypes.c_uint64),
         ("pairs", ctypes.c_uint64),
         ("endpoints", ctypes.c_uint64),
+        ("active_pixels", ctypes.c_uint64),
+        ("last_active_pixels", ctypes.c_uint64),
     ]
 
     def as_dict(self):

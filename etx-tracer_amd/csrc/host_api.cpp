@@ -66,6 +66,10 @@ struct etx_hip_context {
   etx_abi_vcm_options vcm_options = {};
   etx_abi_pt_options pt_options = {};
   etx_abi_bdpt_options bdpt_options = {};
+  float noise_threshold = 0.0f;       // path tracing: Scene::noise_threshold when adaptive sampling is active for this run, else 0
+  float4* adaptive_sum = nullptr;     // public context: Pipeline::adaptive_sum / pixel_state storage (allocated at the first adaptive run)
+  uint32_t* pixel_state = nullptr;
+  size_t adaptive_pixels = 0;
   float4* pt_iteration_image = nullptr;  // camera and light contributions of the iteration this lane renders (2 x pixels), committed to the film at its end
   uint32_t first_iteration = 0, iteration_stride = 1;
   uint32_t next_iteration = 0;       // iteration index to render next
@@ -162,6 +166,7 @@ void release_pipeline(etx_hip_context* ctx) {
   ctx->pipe = {};
   ctx->resolve_buffer = nullptr;
   ctx->pt_iteration_image = nullptr;
+  ctx->adaptive_sum = nullptr, ctx->pixel_state = nullptr, ctx->adaptive_pixels = 0;
 }
 
 uint32_t next_pow2(uint32_t v) {
@@ -536,7 +541,10 @@ int render_pt_iteration(etx_hip_context* ctx, uint32_t iteration) {
     [&](uint32_t, uint32_t) {}, rounds, kStatRaysCamera, false);
   if (rc)
     return rc;
-  launch_pt_commit(s, ctx->pt_iteration_image, ctx->pipe.camera_sum, it.path_count, ctx->scene.host_copy.radiance_clamp);
+  launch_pt_commit(s, ctx->pt_iteration_image, ctx->pipe.camera_sum, ctx->pipe.adaptive_sum, it.path_count, ctx->scene.host_copy.radiance_clamp);
+  // Film::estimate_noise_levels(status.current_iteration, ...), path_tracing.cxx:99: after even iterations from kMinSamples = 32 on
+  if ((ctx->pipe.pixel_state != nullptr) && (iteration >= 32u) && ((iteration & 1u) == 0u))
+    launch_noise_estimate(s, ctx->pipe, it.film_w, it.film_h, ctx->noise_threshold);
   launch_stats_finalize(s, ctx->pipe);
   ctx->stats.wavefront_bounces = rounds;
   return 0;
@@ -666,6 +674,7 @@ void collect_stats(etx_hip_context* ctx) {
   st.rays_camera = u64(kStatRaysCamera);
   st.pairs = u64(kStatPairs);
   st.endpoints = u64(kStatEndpoints);
+  st.active_pixels = st.last_active_pixels = u64(kStatActivePixels);
   st.overflow_flags = c[kCntOverflow];
   st.nonfinite_dropped = c[kCntNonFinite];
 #if defined(ETX_HIP_DEBUG_COUNTERS)
@@ -731,6 +740,7 @@ void lane_worker(etx_hip_context* lane) {
         t.light_vertices += s.light_vertices, t.camera_vertices += s.camera_vertices;
         t.photons_examined += s.photons_examined, t.photons_merged += s.photons_merged, t.splats += s.splats;
         t.rays_light += s.rays_light, t.rays_camera += s.rays_camera, t.pairs += s.pairs, t.endpoints += s.endpoints;
+        t.active_pixels += s.active_pixels, t.last_active_pixels = s.last_active_pixels;
         t.wavefront_bounces += s.wavefront_bounces;
         t.ms_trace_closest += s.ms_trace_closest, t.ms_trace_shadow += s.ms_trace_shadow;
         t.ms_shade_light += s.ms_shade_light, t.ms_shade_camera += s.ms_shade_camera;
@@ -1026,6 +1036,7 @@ int etx_hip_upload_rgb_response(etx_hip_context* context, const float* rgb, uint
 int etx_hip_begin(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  float noise_threshold = 0.0f;
   if (context->scene_ready == false) {
     context->error = "etx_hip_begin: no scene uploaded";
     return ETX_HIP_ERROR_STATE;
@@ -1062,6 +1073,13 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
       int rc = select_bluenoise(context, "bn");
       if (rc)
         return rc;
+    }
+    // adaptive sampling: CPUPathTracing is the integrator that calls Film::estimate_noise_levels (path_tracing.cxx:99); CPUVCM and
+    // CPUBidirectional never do, every pixel stays active for them whatever the threshold
+    noise_threshold = context->scene.noise_threshold;
+    if ((noise_threshold > 0.0f) && (iteration_stride != 1u)) {
+      context->error = "path tracing with Scene::noise_threshold > 0 (adaptive sampling) on an iteration-sharded context: the convergence mask is per film, set noise_threshold = 0 for multi-GPU runs";
+      return ETX_HIP_ERROR_UNSUPPORTED;
     }
   } else if (integrator == ETX_HIP_INTEGRATOR_BDPT) {
     if ((options == nullptr) || (options_size != sizeof(etx_abi_bdpt_options))) {
@@ -1130,7 +1148,24 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
     context->sticky_error = 0;
     context->sticky_error_text.clear();
   }
+  const size_t pixels = size_t(context->pipe.capacity);
+  if (noise_threshold > 0.0f) {
+    if (context->adaptive_pixels != pixels) {
+      int rc = 0;
+      if ((rc = device_alloc(context, context->adaptive_sum, pixels)) || (rc = device_alloc(context, context->pixel_state, pixels)))
+        return rc;
+      context->adaptive_pixels = pixels;
+    }
+    HIP_OK(context, hipMemsetAsync(context->adaptive_sum, 0, pixels * sizeof(float4), context->stream));
+    HIP_OK(context, hipMemsetAsync(context->pixel_state, 0, pixels * sizeof(uint32_t), context->stream));
+  }
+  context->noise_threshold = noise_threshold;
+  context->pipe.adaptive_sum = (noise_threshold > 0.0f) ? context->adaptive_sum : nullptr;
+  context->pipe.pixel_state = (noise_threshold > 0.0f) ? context->pixel_state : nullptr;
   for (etx_hip_context* helper : context->helpers) {
+    helper->noise_threshold = noise_threshold;
+    helper->pipe.adaptive_sum = context->pipe.adaptive_sum;
+    helper->pipe.pixel_state = context->pipe.pixel_state;
     helper->integrator = integrator;
     helper->vcm_options = context->vcm_options;
     helper->pt_options = context->pt_options;
@@ -1248,12 +1283,14 @@ int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size
   HIP_OK(context, hipSetDevice(context->device));
   uint64_t iterations = context->reduced ? context->global_iterations : context->local_iterations;
   float scale = iterations ? float(1.0 / double(iterations)) : 0.0f;
+  // adaptive sampling: pixels hold different sample counts (Film::accumulate_camera_image keeps a running mean per pixel)
+  const float4* counts = (context->pipe.pixel_state != nullptr) ? context->pipe.camera_sum : nullptr;
   if (layer == ETX_HIP_LAYER_NORMAL)
-    launch_film_resolve(context->stream, context->pipe.normal_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, 3);
+    launch_film_resolve(context->stream, context->pipe.normal_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, 3, counts);
   else if (layer == ETX_HIP_LAYER_ALBEDO)
-    launch_film_resolve(context->stream, context->pipe.albedo_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, 0);
+    launch_film_resolve(context->stream, context->pipe.albedo_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, 0, counts);
   else
-    launch_film_resolve(context->stream, context->pipe.camera_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, layer);
+    launch_film_resolve(context->stream, context->pipe.camera_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, layer, counts);
   HIP_OK(context, hipMemcpyAsync(dst_rgba, context->resolve_buffer, dst_bytes, hipMemcpyDeviceToHost, context->stream));
   HIP_OK(context, hipStreamSynchronize(context->stream));
   return ETX_HIP_OK;

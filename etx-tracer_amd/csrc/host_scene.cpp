@@ -40,6 +40,7 @@ void DeviceScene::borrow(const DeviceScene& owner) {
   host_copy = owner.host_copy;
   device = owner.device;
   film_w = owner.film_w, film_h = owner.film_h;
+  noise_threshold = owner.noise_threshold;
   bvh_depth = owner.bvh_depth;
   simple_materials = owner.simple_materials;
   group_general = owner.group_general, group_subsurface = owner.group_subsurface;
@@ -447,6 +448,7 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   }
   const bool spectral = (scene->flags & ETX_SCENE_SPECTRAL) != 0;
   out.needs_rgb_response = false;
+  out.noise_threshold = scene->noise_threshold;
   if ((camera->film_size.x == 0) || (camera->film_size.y == 0)) {
     error = "camera film size is zero";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;

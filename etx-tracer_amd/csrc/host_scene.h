@@ -21,6 +21,7 @@ struct DeviceScene {
   etxd::DScene* device = nullptr;   // device copy of host_copy
   std::vector<void*> allocations;
   uint32_t film_w = 0, film_h = 0;
+  float noise_threshold = 0.0f;     // Scene::noise_threshold (adaptive sampling of the path tracer)
   uint32_t bvh_depth = 0;
   bool simple_materials = false;   // only Diffuse / Translucent / Mirror / Boundary / Void / roughness-0 Conductor in use (dev_bsdf.h)
   bool group_general = false;      // a material of shading group kShadeGroupGeneral is in use (dev_scene.h)

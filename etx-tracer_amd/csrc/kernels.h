@@ -36,7 +36,8 @@ void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& 
 // path tracer (kernels_pt.hip)
 void launch_pt_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
 void launch_pt_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups);
-void launch_pt_commit(hipStream_t stream, float4* iteration_image, float4* camera_sum, uint32_t pixels, float radiance_clamp);
+void launch_pt_commit(hipStream_t stream, float4* iteration_image, float4* camera_sum, float4* adaptive_sum, uint32_t pixels, float radiance_clamp);
+void launch_noise_estimate(hipStream_t stream, const Pipeline& p, uint32_t width, uint32_t height, float threshold);  // Film::estimate_noise_levels
 
 // tail: the few paths that are still alive after many bounces finish inside one launch (kernels_tail.hip)
 void launch_light_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups);

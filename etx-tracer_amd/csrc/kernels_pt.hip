@@ -61,11 +61,21 @@ ETX_DEV f2 film_sample(const DScene& scene, bool filtered, uint32_t px, uint32_t
 
 // make_ray_payload, path_tracing_shared.hxx:238-259 (RGB mode)
 __global__ __launch_bounds__(kBlockSize) void k_pt_generate(Pipeline p, VcmParams it) {
+  __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if ((i == 0u))
-    p.counters[kCntActiveA] = it.path_count;
-  for (uint32_t id = i; id < it.path_count; id += gridDim.x * blockDim.x) {
+  // Film::active_pixel (film.cxx:434-459): converged pixels are not sampled; the others are marked "sampled" in the iteration
+  // image (k_pt_commit adds nothing to pixels that were not)
+  ETX_BLOCK_LOOP(it.path_count, id) {
+    const bool in_range = id < it.path_count;
+    const uint32_t storage = in_range ? film_index(it, id) : 0u;
+    const bool active = in_range && ((p.pixel_state == nullptr) || ((p.pixel_state[storage] & 1u) == 0u));
+    const uint32_t slot = block_compact_slot(active, p.counters + kCntActiveA, s_scratch);
+    const uint32_t block_active = __syncthreads_count(active);
+    if ((threadIdx.x == 0u) && (block_active != 0u))
+      atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatActivePixels), (unsigned long long)block_active);
+    if (active == false)
+      continue;
+    p.camera_sum[storage].w = 1.0f;
     PathState st;
     st.id = id;
     st.sampler.init(id, it.iteration);
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(kBlockSize) void k_pt_generate(Pipeline p, VcmParam
     st.d_vcm = 0.0f;  // sampled_bsdf_pdf
     st.d_vc = st.d_vm = st.path_distance = 0.0f;
     st.flags = kPtMisWeight;
-    store_path(p.paths[0], id, st);
+    store_path(p.paths[0], slot, st);
   }
 }
 
@@ -134,7 +144,7 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
     st.ray_tmax = kMaxFloat;
     st.ray_tmin = kRayEpsilon;
     st.depth += 1u;
-    p.camera_sum[film_target].w = 1.0f;  // the path is longer than one segment (radiance clamp, path_tracing.cxx:74)
+    p.camera_sum[film_target].w = 2.0f;  // the path is longer than one segment (radiance clamp, path_tracing.cxx:74)
     return random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
   }
 
@@ -264,7 +274,7 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
   st.ray_tmax = kMaxFloat;
   st.ray_tmin = kRayEpsilon;
   st.depth += 1u;
-  p.camera_sum[film_target].w = 1.0f;
+  p.camera_sum[film_target].w = 2.0f;
   return random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
 }
 
@@ -308,20 +318,67 @@ __global__ __launch_bounds__(kBlockSize) void k_pt_shade(Pipeline p, VcmParams i
   }
 }
 
-// path_tracing.cxx:67-82: clamp the iteration's pixel value, add it to the camera image. `iteration_image` holds the
-// sum of the iteration's contributions in xyz and "path continued past its first vertex" in w.
-__global__ __launch_bounds__(kBlockSize) void k_pt_commit(float4* __restrict__ iteration_image, float4* __restrict__ camera_sum, uint32_t pixels, float radiance_clamp) {
+// path_tracing.cxx:67-82 + Film::accumulate_camera_image (film.cxx:173-231): clamp the iteration's pixel value, add it to
+// the camera image. `iteration_image` holds the sum of the iteration's contributions in xyz; w: 0 = the pixel was not sampled
+// (converged), 1 = sampled, 2 = sampled and the path continued past its first vertex (the clamp applies).
+__global__ __launch_bounds__(kBlockSize) void k_pt_commit(float4* __restrict__ iteration_image, float4* __restrict__ camera_sum, float4* __restrict__ adaptive_sum, uint32_t pixels,
+  float radiance_clamp) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += gridDim.x * blockDim.x) {
     const float4 v = iteration_image[i];
+    if (v.w == 0.0f)
+      continue;
     f3 color = {v.x, v.y, v.z};
-    if ((radiance_clamp > 0.0f) && (v.w != 0.0f)) {
+    if ((radiance_clamp > 0.0f) && (v.w == 2.0f)) {
       const float lum = luminance(color);
       if (lum > radiance_clamp)
         color *= radiance_clamp / lum;
     }
     atomic_add_f3(camera_sum + i, color);  // the film is shared by the lanes (host_api.cpp)
-    atomicAdd(&camera_sum[i].w, 1.0f);     // iterations committed to this pixel (k_film_resolve)
+    const float sample_index = atomicAdd(&camera_sum[i].w, 1.0f);  // samples committed to this pixel before this one
+    if ((adaptive_sum != nullptr) && ((uint32_t(sample_index) & 1u) == 0u)) {  // film.cxx:218-225: the mean of the even samples
+      atomic_add_f3(adaptive_sum + i, color);
+      atomicAdd(&adaptive_sum[i].w, 1.0f);
+    }
     iteration_image[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+}
+
+// Film::estimate_noise_levels, film.cxx:233-330. Pass 1: error level of every pixel that is still sampled.
+__global__ __launch_bounds__(kBlockSize) void k_noise_estimate(const float4* __restrict__ camera_sum, const float4* __restrict__ adaptive_sum, uint32_t* __restrict__ pixel_state,
+  uint32_t pixels, float threshold) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += gridDim.x * blockDim.x) {
+    if (pixel_state[i] & 1u)
+      continue;
+    const float4 c = camera_sum[i], a = adaptive_sum[i];
+    const float inv_c = (c.w > 0.0f) ? 1.0f / c.w : 0.0f, inv_a = (a.w > 0.0f) ? 1.0f / a.w : 0.0f;
+    const f3 v_i = f3{c.x, c.y, c.z} * inv_c, v_a = f3{a.x, a.y, a.z} * inv_a;
+    const float error_diff = fabsf(v_i.x - v_a.x) + fabsf(v_i.y - v_a.y) + fabsf(v_i.z - v_a.z);
+    const float error_norm = fabsf(v_i.x) + fabsf(v_i.y) + fabsf(v_i.z);
+    const float error_level = error_diff / (((error_norm < 1.0f) ? sqrtf(error_norm) : error_norm) + kEpsilon);
+    const uint32_t converged = (error_level < threshold) ? 1u : 0u;
+    pixel_state[i] = converged | (converged << 1u);  // converged, tmp = converged
+  }
+}
+// Pass 2: a pixel that is still sampled keeps its row neighbours [x - 5, x + 5) "not converged" in tmp (kBlockSize 5, :283-299)
+__global__ __launch_bounds__(kBlockSize) void k_noise_spread_rows(uint32_t* __restrict__ pixel_state, uint32_t width, uint32_t pixels) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += gridDim.x * blockDim.x) {
+    if (pixel_state[i] & 1u)
+      continue;
+    const uint32_t x = i % width, y = i / width;
+    const uint32_t begin_x = (x >= 5u) ? x - 5u : 0u, end_x = min(width, x + 5u);
+    for (uint32_t q = begin_x; q < end_x; ++q)
+      atomicAnd(pixel_state + q + y * width, ~2u);
+  }
+}
+// Pass 3: every pixel whose tmp is clear re-activates its column neighbours [y - 5, y + 5) (:305-321)
+__global__ __launch_bounds__(kBlockSize) void k_noise_spread_columns(uint32_t* __restrict__ pixel_state, uint32_t width, uint32_t height, uint32_t pixels) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += gridDim.x * blockDim.x) {
+    if (pixel_state[i] & 2u)
+      continue;
+    const uint32_t x = i % width, y = i / width;
+    const uint32_t begin_y = (y >= 5u) ? y - 5u : 0u, end_y = min(height, y + 5u);
+    for (uint32_t q = begin_y; q < end_y; ++q)
+      atomicAnd(pixel_state + x + q * width, ~1u);
   }
 }
 
@@ -342,8 +399,15 @@ void launch_pt_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it,
     hipLaunchKernelGGL((k_pt_shade<kShadeGroupSubsurface, false>), grid, dim3(kBlockSize), 0, stream, p, it, in_set);
 }
 
-void launch_pt_commit(hipStream_t stream, float4* iteration_image, float4* camera_sum, uint32_t pixels, float radiance_clamp) {
-  hipLaunchKernelGGL(k_pt_commit, dim3(grid_for(pixels)), dim3(kBlockSize), 0, stream, iteration_image, camera_sum, pixels, radiance_clamp);
+void launch_noise_estimate(hipStream_t stream, const Pipeline& p, uint32_t width, uint32_t height, float threshold) {
+  const uint32_t pixels = width * height;
+  hipLaunchKernelGGL(k_noise_estimate, dim3(grid_for(pixels)), dim3(kBlockSize), 0, stream, p.camera_sum, p.adaptive_sum, p.pixel_state, pixels, threshold);
+  hipLaunchKernelGGL(k_noise_spread_rows, dim3(grid_for(pixels)), dim3(kBlockSize), 0, stream, p.pixel_state, width, pixels);
+  hipLaunchKernelGGL(k_noise_spread_columns, dim3(grid_for(pixels)), dim3(kBlockSize), 0, stream, p.pixel_state, width, height, pixels);
+}
+
+void launch_pt_commit(hipStream_t stream, float4* iteration_image, float4* camera_sum, float4* adaptive_sum, uint32_t pixels, float radiance_clamp) {
+  hipLaunchKernelGGL(k_pt_commit, dim3(grid_for(pixels)), dim3(kBlockSize), 0, stream, iteration_image, camera_sum, adaptive_sum, pixels, radiance_clamp);
 }
 
 }  // namespace etxd

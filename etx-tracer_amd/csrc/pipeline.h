@@ -147,7 +147,8 @@ enum : uint32_t {
   kStatRaysCamera = 704,
   kStatPairs = 736,
   kStatEndpoints = 768,       // film contributions dropped because they were not finite (never cleared within a run: reported by etx_hip_stats)
-  kCounterCount = 832,
+  kStatActivePixels = 832,  // u64: pixels sampled (path tracing with adaptive sampling: Film::active_pixel)
+  kCounterCount = 864,
 };
 
 // Per-workgroup statistics (u64): workgroup b of any launch adds to row b without atomics (launches on one stream do
@@ -214,6 +215,9 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   float4* light_sum;     // Film::LightImage x iterations
   float4* normal_sum;    // Film::Normals x iterations (PT)
   float4* albedo_sum;    // Film::Albedo x iterations (PT)
+  // adaptive sampling (Film::estimate_noise_levels / active_pixel, film.cxx:233-330,434-459), path tracing with noise_threshold > 0
+  float4* adaptive_sum;  // sum of the EVEN samples of each pixel, their count in w (StorageCameraAdaptive holds their mean)
+  uint32_t* pixel_state; // bit 0 converged, bit 1 tmp (Film's internal_data); nullptr = every pixel is sampled every iteration
   uint32_t* counters;
   unsigned long long* block_stats;  // kBlockStatRows x kBlockStatCount
   uint32_t debug_flags;             // ETX_HIP_DEBUG_FLAGS: ablation switches for kernel timing experiments (0 in production)

@@ -214,6 +214,17 @@ class HIPPathTracing(HIPIntegrator):
     def _begin(self):
         self.context.begin_pt(pt_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride)
 
+    def update(self):
+        super().update()
+        # CPUPathTracingImpl::update (path_tracing.cxx:91-93): an iteration that sampled no pixel - every pixel has converged
+        # (Film::estimate_noise_levels) - ends the render. Iterations already in flight on the device lanes finish as no-ops.
+        if (self.current_state == State.Running) and (self.snapshot.noise_threshold > 0.0) and (self._rendered > 33):
+            stats = self.context.stats()
+            if (stats.completed_iterations > 33) and (stats.last_active_pixels == 0):
+                self.stop(Stop.WaitForCompletion)
+                self.context.sync()
+                self.current_state = State.Stopped
+
 
 class HIPBidirectional(HIPIntegrator):
     """CPUBidirectional (sources/etx/rt/integrators/bidirectional.cxx:1490-1560) on the device, all four bdpt-mode values;

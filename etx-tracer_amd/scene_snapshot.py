@@ -24,6 +24,7 @@ _SCENE_MAX_PATH = 460
 _SCENE_MIN_PATH = 456
 _SCENE_RR_START = 468
 _SCENE_FLAGS = 520
+_SCENE_NOISE_THRESHOLD = _SCENE_RR_START + 4  # float noise_threshold follows random_path_termination (etx_scene_abi.h)
 _SCENE_RADIUS = 444
 _CAMERA_FILM_SIZE = 144
 
@@ -75,6 +76,16 @@ class SceneSnapshot:
     @samples.setter
     def samples(self, value):
         self._u32(self.scene_address + _SCENE_SAMPLES).value = int(value)
+        self.version += 1
+
+    @property
+    def noise_threshold(self):
+        """Scene::noise_threshold: > 0 switches the path tracer's adaptive sampling on (Film::estimate_noise_levels)."""
+        return ctypes.c_float.from_address(self.scene_address + _SCENE_NOISE_THRESHOLD).value
+
+    @noise_threshold.setter
+    def noise_threshold(self, value):
+        ctypes.c_float.from_address(self.scene_address + _SCENE_NOISE_THRESHOLD).value = float(value)
         self.version += 1
 
     @property

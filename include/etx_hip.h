@@ -176,6 +176,9 @@ typedef struct etx_hip_stats_t {
   uint64_t rays_camera;          /* closest-hit rays of the camera pass (PT: all rays) */
   uint64_t pairs;                /* (camera vertex, light vertex) connections evaluated */
   uint64_t endpoints;            /* endpoint connections of the general / subsurface shading groups (k_connect_endpoints) */
+  /* adaptive sampling (path tracing with Scene::noise_threshold > 0: Film::estimate_noise_levels / active_pixel) */
+  uint64_t active_pixels;        /* pixels sampled, total since etx_hip_begin */
+  uint64_t last_active_pixels;   /* pixels sampled by the most recently finished iteration: 0 = every pixel has converged (CPUPathTracing stops, path_tracing.cxx:91-93) */
 } etx_hip_stats_t;
 
 /* Which kernel groups are timed with HIP events (bit i = the i-th ms_* field above, in declaration order; default: the two

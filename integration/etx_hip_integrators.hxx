@@ -262,6 +262,9 @@ struct HIPIntegratorBase : public Integrator {
  protected:
   virtual bool begin() = 0;
   virtual bool writes_light_image() const = 0;
+  virtual bool converges() const {  // the integrator honours Scene::noise_threshold (only CPUPathTracing estimates noise levels)
+    return false;
+  }
 
   void read_status() {
     etx_hip_stats_t s = {};
@@ -271,6 +274,9 @@ struct HIPIntegratorBase : public Integrator {
     _status.total_time = s.total_time;
     _status.completed_iterations = s.completed_iterations;
     _status.current_iteration = s.current_iteration;
+    // path tracing with adaptive sampling: an iteration that sampled no pixel ends the render (path_tracing.cxx:91-93)
+    if ((rt.scene().noise_threshold > 0.0f) && (s.completed_iterations > 33u) && (s.last_active_pixels == 0u) && converges() && (current_state == State::Running))
+      current_state = State::WaitingForCompletion;
   }
 
   // The device keeps the running means; mirror them into the Film through its per-pixel interface.
@@ -486,6 +492,10 @@ struct HIPPathTracing : public HIPIntegratorBase {
 
   bool writes_light_image() const override {
     return false;
+  }
+
+  bool converges() const override {
+    return true;
   }
 };
 

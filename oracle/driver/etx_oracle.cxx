@@ -508,6 +508,7 @@ int main(int argc, char** argv) {
     printf("rays: trace %llu transmittance %llu material %llu -> %.3f rays/sample\n", (unsigned long long)r0, (unsigned long long)r1, (unsigned long long)r2,
       double(r0 + r1 + r2) / samples);
   }
+  printf("adaptive sampling: %u of %u pixels converged at the last noise estimate (Film::active_pixel_count)\n", raytracing.film().active_pixel_count(), uint32_t(pixels));
   // machine readable line for bench.py / tests
   printf("ORACLE_RESULT {\"integrator\": \"%s\", \"iterations\": %u, \"seconds\": %.6f, \"threads\": %u, \"msamples_per_s\": %.6f, \"width\": %u, \"height\": %u}\n",
     integrator_name.c_str(), st.completed_iterations, st.total_time, threads, msamples, cam.film_size.x, cam.film_size.y);

@@ -239,9 +239,11 @@ def test_vcm_default_options_with_blue_noise_match_reference(etx, golden_dir, bl
 # ---------------------------------------------------------------------------------------------------------------
 # unidirectional path tracer (BASELINE configs[0]) against the reference's CPUPathTracing
 
-def render_pt(etx, golden_dir, scene, spp, options=None, bluenoise=None, first=0, stride=1, cie=None, rgb_response=None):
+def render_pt(etx, golden_dir, scene, spp, options=None, bluenoise=None, first=0, stride=1, cie=None, rgb_response=None, noise_threshold=None):
     snap = etx.SceneSnapshot(os.path.join(golden_dir, scene + ".etxscene"))
     snap.samples = spp
+    if noise_threshold is not None:  # the snapshots carry Scene::noise_threshold = 0.1: adaptive sampling, as in the reference's films
+        snap.noise_threshold = noise_threshold
     integ = etx.HIPPathTracing(snap, first_iteration=first, iteration_stride=stride)
     integ.cie_table = cie
     integ.rgb_response_table = rgb_response
@@ -397,9 +399,9 @@ def test_pt_options_and_config1_size(etx, golden_dir):
     assert m(only_nee) < m(full)
     assert m(no_mis) > 1.2 * m(full)  # without MIS the emitter is counted by both strategies
     # iteration sharding is exact for PT as well (independent samples): two halves average to the whole
-    even, _ = render_pt(etx, golden_dir, "cornell_classic_128", 8, first=0, stride=2)
-    odd, _ = render_pt(etx, golden_dir, "cornell_classic_128", 8, first=1, stride=2)
-    whole, _ = render_pt(etx, golden_dir, "cornell_classic_128", 8)
+    even, _ = render_pt(etx, golden_dir, "cornell_classic_128", 8, first=0, stride=2, noise_threshold=0.0)
+    odd, _ = render_pt(etx, golden_dir, "cornell_classic_128", 8, first=1, stride=2, noise_threshold=0.0)
+    whole, _ = render_pt(etx, golden_dir, "cornell_classic_128", 8, noise_threshold=0.0)
     np.testing.assert_allclose(0.5 * (even["camera"][..., :3] + odd["camera"][..., :3]), whole["camera"][..., :3], rtol=2e-4, atol=2e-5)
 
 
@@ -506,7 +508,7 @@ def test_feature_scenes_match_reference(etx, golden_dir, cie_observer, rgb_respo
             integ.run()
         integ.context.close()
     golden = np.load(os.path.join(golden_dir, "cornell_%s_128_pt.npz" % flavour))
-    layers, stats = render_pt(etx, golden_dir, "cornell_%s_128" % flavour, int(golden["spp"]), **spectral)
+    layers, stats = render_pt(etx, golden_dir, "cornell_%s_128" % flavour, int(golden["spp"]), noise_threshold=0.0, **spectral)  # these films: --noise-threshold 0
     assert stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
     h, w = golden["camera"].shape[:2]
     b = 16 if h >= 128 else 8
@@ -653,3 +655,50 @@ def test_asynchronous_film_readback(etx, golden_dir):
     with pytest.raises(api.EtxHipError):
         ctx.read_film_end(wait=True)  # nothing pending
     ctx.close()
+
+
+def test_pt_adaptive_sampling(etx, golden_dir):
+    """Scene::noise_threshold > 0: Film::estimate_noise_levels / active_pixel (film.cxx:233-330, 434-459) on the device. After
+    even iterations from 32 on, pixels whose running mean and even-sample mean agree within the threshold stop being sampled
+    (unless a neighbour within 5 pixels is still noisy); every pixel is normalised by its own sample count; an iteration without
+    an active pixel ends the render (path_tracing.cxx:91-93)."""
+    pixels = 128 * 128
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_classic_128.etxscene"))
+    assert abs(snap.noise_threshold - 0.1) < 1e-6  # what the reference's loader wrote: the committed PT films were sampled adaptively
+    snap.samples = 256
+    integ = etx.HIPPathTracing(snap)
+    integ.options()["bn"] = False
+    integ.render()
+    adaptive = integ.film(etx.api.LAYER_CAMERA)
+    stats = integ.status()
+    assert stats.completed_iterations == 256 and stats.nonfinite_dropped == 0
+    # the first 33 iterations sample everything, later ones only what has not converged. Few pixels drop out at 0.1: 85 % pass the
+    # threshold at iteration 32 (the reference reports 13 961 of 16 384), but a pixel keeps sampling while any pixel of its
+    # 10 x 10 neighbourhood has not passed - 244 of 256 samples per pixel on average, here as there
+    assert 34 * pixels <= stats.active_pixels < 252 * pixels, stats.active_pixels / pixels
+    snap.noise_threshold = 0.0
+    integ.render()
+    full = integ.film(etx.api.LAYER_CAMERA)
+    stats_full = integ.status()
+    assert stats_full.active_pixels == 256 * pixels
+    # same picture (pixels that stopped early are noisier, not darker): the per-pixel normalisation is what this checks
+    rel = (adaptive[..., :3].mean(axis=(0, 1)) - full[..., :3].mean(axis=(0, 1))) / full[..., :3].mean(axis=(0, 1))
+    assert np.abs(rel).max() < 1.0e-2, rel
+    assert rmse(block_mean(adaptive, 16), block_mean(full, 16)) < 3.0e-3
+    # a threshold nothing exceeds: everything converges at the first estimate (iteration 32) and the render ends early
+    snap.noise_threshold = 100.0
+    integ.render()
+    stats_early = integ.status()
+    early = integ.film(etx.api.LAYER_CAMERA)
+    integ.context.close()
+    assert 33 <= stats_early.completed_iterations < 64, stats_early.completed_iterations
+    # iterations 0 - 32 sample everything; up to three more were already generated on the other device lanes when the mask changed
+    assert 33 * pixels <= stats_early.active_pixels <= 36 * pixels, stats_early.active_pixels / pixels
+    assert np.abs((early[..., :3].mean(axis=(0, 1)) - full[..., :3].mean(axis=(0, 1))) / full[..., :3].mean(axis=(0, 1))).max() < 3.0e-2
+    # iteration-sharded contexts refuse the per-film mask instead of ignoring it
+    snap.noise_threshold = 0.1
+    sharded = etx.HIPPathTracing(snap, first_iteration=0, iteration_stride=2)
+    sharded.options()["bn"] = False
+    with pytest.raises(etx.EtxHipError, match="noise_threshold"):
+        sharded.run()
+    sharded.context.close()

@@ -98,6 +98,7 @@ def render_halves(etx, golden_dir, flavour, cie, integrator_class, options):
     for first in (0, 1):
         snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_%s_128.etxscene" % flavour))
         snap.samples = SPP
+        snap.noise_threshold = 0.0  # the 4096-spp PT films were rendered with --noise-threshold 0 (every pixel gets every sample)
         integ = integrator_class(snap, first_iteration=first, iteration_stride=2)
         integ.options().update(options)
         integ.cie_table = cie
