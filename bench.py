@@ -66,8 +66,9 @@ def main():
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=32)
     parser.add_argument("--warmup", type=int, default=8)
-    parser.add_argument("--workload", default="full", choices=["full", "classic"],
-                        help="full = surviving cornellbox.mtl (fog medium, env + dir emitters) = BASELINE.json configs[1]; classic = area light only")
+    parser.add_argument("--workload", default="full", choices=["full", "classic", "gems"],
+                        help="full = surviving cornellbox.mtl (fog medium, env + dir emitters) = BASELINE.json configs[1]; classic = area light only; "
+                             "gems = configs[2] family: 2 892 triangles (BVH4 traversal), dispersive dielectrics + rough conductor, spectral")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-kernel-table", action="store_true", help="skip the extra pass that times every kernel group (profiling runs)")
     args = parser.parse_args()
@@ -94,6 +95,9 @@ def main():
     width, height = snap.film_size
     ctx = api.Context(local_rank)
     ctx.upload_scene(snap)
+    if args.workload == "gems":  # spectral scene: the host's CIE observer (committed fixture of the reference's table)
+        cie = np.load(os.path.join(ROOT, "tests", "golden", "cie_observer.npz"))
+        ctx.upload_cie_table(cie["xyz"], float(cie["first_wavelength"]))
     if distributed:
         multi_gpu.init_context_comm(ctx, rank, world)
 
@@ -191,15 +195,46 @@ def main():
                            "sharing of the CUs with the other lanes' kernels; rocprofv3 per-kernel times of the same command are in profiles/round2_bench_full_1080p_kernel_stats.csv" %
                            (groups_steps, os.environ.get("ETX_HIP_LANES", "4")))
 
-    # PMC figures (collected in separate rocprofv3 --pmc passes, profiles/round1_pmc_summary.json): HBM bytes per ray of
-    # the traversal kernel (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE) and the
-    # occupancy / VALU utilisation of the shade kernels
+    # PMC figures (collected in separate rocprofv3 --pmc passes): HBM bytes per ray of the traversal kernel (FETCH_SIZE doubled as
+    # MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; profiles/round1_pmc_summary.json, the kernel's traffic has not
+    # changed since) and, per kernel of a one-lane run of this command, what the waves spend their cycles on
+    # (profiles/round2_pmc_summary.json, tools/profile_round.sh + tools/pmc_aggregate.py)
     pmc = None
     pmc_path = os.path.join(ROOT, "profiles", "round1_pmc_summary.json")
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
+    pmc2 = None
+    pmc2_path = os.path.join(ROOT, "profiles", "round2_pmc_summary.json")
+    if os.path.exists(pmc2_path):
+        with open(pmc2_path) as f:
+            pmc2 = json.load(f)
+    if (kernels is not None) and (pmc2 is not None):
+        members = {"trace_closest": ["k_trace_closest<true, true>"], "trace_shadow": ["k_trace_shadow<true>"], "shade_light": ["k_light_shade<0u, false>", "k_path_tail<false, 0u>"],
+                   "shade_camera": ["k_camera_shade<0u, false>", "k_path_tail<true, 0u>"], "connect": ["k_expand_pairs", "k_connect_pairs<true>"],
+                   "merge": ["k_merge_diffuse", "k_merge_count", "k_merge_scatter", "k_merge_scan", "k_merge_scan_totals", "k_merge_clear"], "grid_build": ["k_grid_scatter", "k_grid_count", "k_grid_bbox"]}
+        profiled_iterations = max(1, pmc2.get("k_camera_generate", {}).get("launches", 1))
+        for group, names in members.items():
+            rows = [pmc2[n] for n in names if n in pmc2]
+            if not rows:
+                continue
+            main = rows[0]
+            wave_cycles = sum(r.get("SQ_WAVE_CYCLES_sum", 0.0) for r in rows)
+            kernels[group]["counters_1lane"] = {
+                "kernel": names[0],
+                # wave-level VALU instructions x 64 lanes per unit of work: what a unit costs when every lane of its wave is busy
+                "valu_lane_instructions_per_unit": round(sum(r.get("SQ_INSTS_VALU_sum", 0.0) for r in rows) * 64.0 / profiled_iterations / max(kernels[group]["units_per_step"], 1), 1),
+                "waves_waiting_share": round(sum(r.get("SQ_WAIT_ANY_sum", 0.0) for r in rows) / wave_cycles, 3) if wave_cycles else None,
+                "waves_issuing_share": round(sum(r.get("SQ_ACTIVE_INST_ANY_sum", 0.0) for r in rows) / wave_cycles, 3) if wave_cycles else None,
+                "l2_hit_rate": main.get("l2_hit_rate"), "occupancy_percent_mean": main.get("OccupancyPercent_mean"), "valu_busy_percent_mean": main.get("VALUBusy_mean"),
+                "vgprs": main.get("vgprs"),
+            }
 
+    dominant = None
+    if kernels is not None:
+        name = max((k for k in kernels if k != "note"), key=lambda k: kernels[k]["share"] or 0.0)
+        dominant = dict(kernels[name], group=name, note="the kernel group with the largest share of the device time of an iteration; `bound` = the HBM roofline the contract asks for. "
+                        "The group is not bandwidth-bound: its waves wait on dependent gathers and divergent branches (counters_1lane; DESIGN.md 3)")
     if rank == 0:
         samples = float(width) * height * args.steps * world
         value = samples / elapsed / 1.0e6
@@ -220,12 +255,13 @@ def main():
             "config": {
                 "workload": "cornell_%s_vcm_1920x1080" % args.workload,
                 "scene": "Cornell box rebuilt for the reference's surviving camera/materials (scenes/make_scenes.py), loaded by the reference loader",
-                "integrator": "VCM, VCMOptions::default_values() (blue noise on), scene.samples 64, max-path-length 1023, rr start 6, RGB",
+                "integrator": "VCM, VCMOptions::default_values() (blue noise on), scene.samples 64, max-path-length 1023, rr start 6, %s" % ("spectral" if args.workload == "gems" else "RGB"),
                 "samples_per_step": width * height,
                 "parallelism": "iteration-sharded x%d, one RCCL film all-reduce at the end" % world,
             },
             "roofline": {
-                "kernel": "k_trace_closest (ray queue -> hit queue)",
+                "kernel": ("k_trace_closest_bvh (ray queue -> hit queue; BVH4, top levels staged in LDS, persistent workgroups)" if args.workload == "gems"
+                           else "k_trace_closest (ray queue -> hit queue; sweep over the <= 64 pre-transformed primitives of the box)"),
                 "bound": "hbm",
                 "achieved": round(achieved, 3),
                 "peak": HBM_PEAK_GBS,
@@ -244,7 +280,7 @@ def main():
                 "isolated": isolated,
             },
             "kernels": kernels,
-            "shade_kernels": ({name: pmc["kernels_1lane"][name] for name in ("etxd::k_camera_shade<true>", "etxd::k_light_shade<true>") if name in pmc["kernels_1lane"]} if pmc else None),
+            "dominant_kernel": dominant,
             "counters": {
                 "rays_per_sample": round((acc["rays"] + acc["shadow"]) / (float(width) * height * args.steps), 3),
                 "light_vertices_per_path": round(acc["lv"] / (float(width) * height * args.steps), 3),

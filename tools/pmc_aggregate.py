@@ -30,12 +30,17 @@ def short_name(name):
 def main():
     out_path, paths = sys.argv[1], sys.argv[2:]
     table = defaultdict(lambda: defaultdict(float))
+    passes = defaultdict(set)  # counter -> the passes that collected it (a counter listed in two passes is averaged, not added)
     for path in paths:
         seen = set()
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
                 k = short_name(row["Kernel_Name"])
                 table[k][row["Counter_Name"] + "_sum"] += float(row["Counter_Value"])
+                passes[row["Counter_Name"] + "_sum"].add(path)
+                table[k]["vgprs@"] = float(row.get("VGPR_Count", 0) or 0)
+                table[k]["agprs@"] = float(row.get("Accum_VGPR_Count", 0) or 0)
+                table[k]["scratch@"] = float(row.get("Scratch_Size", 0) or 0)
                 key = (row["Dispatch_Id"], k)
                 if key not in seen:
                     seen.add(key)
@@ -45,10 +50,10 @@ def main():
     for k, v in table.items():
         launches = max(val for key, val in v.items() if key.startswith("launches@"))
         duration = max(val for key, val in v.items() if key.startswith("duration_us@"))
-        r = {"launches": int(launches), "duration_us_sum": round(duration, 1)}
+        r = {"launches": int(launches), "duration_us_sum": round(duration, 1), "vgprs": int(v["vgprs@"]), "agprs": int(v["agprs@"]), "scratch_bytes": int(v["scratch@"])}
         for key, val in sorted(v.items()):
             if "@" not in key:
-                r[key] = round(val, 3)
+                r[key] = round(val / max(1, len(passes[key])), 3)
         if "TCC_HIT_sum_sum" in r and (r["TCC_HIT_sum_sum"] + r.get("TCC_MISS_sum_sum", 0.0)) > 0:
             r["l2_hit_rate"] = round(r["TCC_HIT_sum_sum"] / (r["TCC_HIT_sum_sum"] + r["TCC_MISS_sum_sum"]), 4)
         wc = r.get("SQ_WAVE_CYCLES_sum", 0.0)
