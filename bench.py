@@ -227,7 +227,6 @@ def main():
                 "waves_waiting_share": round(sum(r.get("SQ_WAIT_ANY_sum", 0.0) for r in rows) / wave_cycles, 3) if wave_cycles else None,
                 "waves_issuing_share": round(sum(r.get("SQ_ACTIVE_INST_ANY_sum", 0.0) for r in rows) / wave_cycles, 3) if wave_cycles else None,
                 "l2_hit_rate": main.get("l2_hit_rate"), "occupancy_percent_mean": main.get("OccupancyPercent_mean"), "valu_busy_percent_mean": main.get("VALUBusy_mean"),
-                "vgprs": main.get("vgprs"),
             }
 
     dominant = None
