@@ -1106,6 +1106,10 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
     context->error = "integrator " + std::to_string(integrator) + " is not implemented by the device path";
     return ETX_HIP_ERROR_UNSUPPORTED;
   }
+  if (context->scene.has_subsurface_cb && (integrator != ETX_HIP_INTEGRATOR_PT)) {
+    context->error = "Christensen-Burley subsurface materials are implemented for the path tracer only so far (use path tracing, or the random-walk class)";
+    return ETX_HIP_ERROR_UNSUPPORTED;
+  }
   if (context->scene.host_copy.spectral) {
     if (context->cie_table == nullptr) {
       context->error = "spectral scene: the CIE observer table has not been uploaded (etx_hip_upload_cie_table)";

@@ -45,6 +45,7 @@ void DeviceScene::borrow(const DeviceScene& owner) {
   simple_materials = owner.simple_materials;
   group_general = owner.group_general, group_subsurface = owner.group_subsurface;
   has_subsurface = owner.has_subsurface;
+  has_subsurface_cb = owner.has_subsurface_cb;
   generic_materials = owner.generic_materials;
   needs_rgb_response = owner.needs_rgb_response;
   bvh_bytes = owner.bvh_bytes;
@@ -448,6 +449,7 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   }
   const bool spectral = (scene->flags & ETX_SCENE_SPECTRAL) != 0;
   out.needs_rgb_response = false;
+  out.has_subsurface_cb = false;
   out.noise_threshold = scene->noise_threshold;
   if ((camera->film_size.x == 0) || (camera->film_size.y == 0)) {
     error = "camera film size is zero";
@@ -484,10 +486,12 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     }
     if (spectral && ((m.scattering.image_index != ETX_ABI_INVALID) || (m.reflectance.image_index != ETX_ABI_INVALID) || (m.emission.image_index != ETX_ABI_INVALID)))
       out.needs_rgb_response = true;  // apply_rgb, scene.hxx:249-260 (etx_hip_upload_rgb_response)
-    if (m.subsurface.cls == 2u) {
-      error = "Christensen-Burley subsurface scattering (gather_cb, path_tracing_shared.hxx:161-232) is not implemented by the device path (random walk is)";
+    if (m.subsurface.cls > 2u) {
+      error = "subsurface class " + std::to_string(m.subsurface.cls) + " is unknown (1 random walk, 2 Christensen-Burley: material.hxx:36-41)";
       return ETX_HIP_ERROR_UNSUPPORTED;
     }
+    if (m.subsurface.cls == 2u)
+      out.has_subsurface_cb = true;
     if (m.subsurface.cls != 0u)
       out.has_subsurface = true;
   }

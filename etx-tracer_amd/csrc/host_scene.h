@@ -26,7 +26,8 @@ struct DeviceScene {
   bool simple_materials = false;   // only Diffuse / Translucent / Mirror / Boundary / Void / roughness-0 Conductor in use (dev_bsdf.h)
   bool group_general = false;      // a material of shading group kShadeGroupGeneral is in use (dev_scene.h)
   bool group_subsurface = false;   // ... of kShadeGroupSubsurface
-  bool has_subsurface = false;     // a random-walk subsurface material is in use (PT only so far)
+  bool has_subsurface = false;     // a subsurface material is in use
+  bool has_subsurface_cb = false;  // ... of class Christensen-Burley (up to 24 exit points per vertex)
   bool generic_materials = false;  // a connectible (non delta) surface material other than Diffuse is in use
   bool needs_rgb_response = false; // spectral scene with RGB images behind spectra: apply_rgb needs the host's table (etx_hip_upload_rgb_response)
   size_t bvh_bytes = 0;

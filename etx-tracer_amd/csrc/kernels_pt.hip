@@ -220,11 +220,37 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
   const BsdfSample bs = bsdf_sample_s<kSimple>(scene, bsdf_data, mat, st.sampler);
   st.sampler.pop_fixed();
   // path_tracing_shared.hxx:391-408: a diffuse reflection off a subsurface material enters the object instead
-  bool subsurface_sampled = false;
+  bool subsurface_sampled = false, gathered_light = false;
   Isect ss_isect;
   f3 ss_weight = mk3(0.0f);
   if (kWalk && (mat.subsurface.cls != 0u) && (bs.properties & kSampleReflection) && (bs.properties & kSampleDiffuse)) {
-    subsurface_sampled = sss_gather_rw(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight);
+    if (mat.subsurface.cls == 2u) {
+      // Christensen-Burley (subsurface::gather_cb): the light is gathered at EVERY exit point with its weight (:419-426); the
+      // exit points are not buffered (dev_sss.h), so their next-event requests are written as they are found, one queue slot
+      // per lane-level reservation. bsdf_sample.valid() and the medium change are decided before (:405-409).
+      const bool light_them = opt_nee && (st.depth + 1u <= scene.max_path_length) && bs.valid();
+      const uint32_t emitter_index = sample_emitter_index(scene, rnd_support.y);
+      const uint32_t nee_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
+      const etx_abi_material& exit_mat = scene.materials[scene.subsurface_exit_material];
+      gathered_light = true;
+      subsurface_sampled = sss_gather_cb(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight, [&](const Isect& exit_point, const f3& weight) {
+        if (light_them == false)
+          return;
+        const EmitterSample es = sample_emitter(scene, emitter_index, rnd_em_sample, exit_point.pos, st.wavelength);
+        if (es.pdf_dir == 0.0f)
+          return;
+        const BsdfData nee_data = make_bsdf_data(exit_point, exit_point.w_i, nee_medium, kPathCamera, st.wavelength);
+        const BsdfEval eval = bsdf_evaluate_s<kSimple>(scene, nee_data, es.direction, exit_mat, st.sampler);
+        if (eval.valid() == false)
+          return;
+        const f3 pos = shading_pos(scene, scene.triangles[exit_point.tri], exit_point.bc, es.direction);
+        const float mis = ((opt_mis == false) || es.is_delta) ? 1.0f : power_heuristic(es.pdf_dir * es.pdf_sample, eval.pdf);
+        const f3 value = st.throughput * weight * eval.bsdf * es.value * (mis / (es.pdf_dir * es.pdf_sample)) * film_weight;
+        write_shadow(p, atomicAdd(p.counters + kCntShadow, 1u), ShadowRequest{pos, es.origin, value, nee_medium, film_target, st.wavelength});
+      });
+    } else {
+      subsurface_sampled = sss_gather_rw(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight);
+    }
     if (subsurface_sampled == false)
       return false;
   }
@@ -233,7 +259,7 @@ ETX_DEV bool pt_step(const Pipeline& p, const DScene& scene, const VcmParams& it
   if (bs.properties & kSampleMediumChanged)
     st.medium = bs.medium_index;
 
-  if (opt_nee && (st.depth + 1u <= scene.max_path_length)) {  // :409-431 + evaluate_light :300-321
+  if (opt_nee && (gathered_light == false) && (st.depth + 1u <= scene.max_path_length)) {  // :409-431 + evaluate_light :300-321
     st.sampler.push_fixed(rnd_em_sample.x, rnd_em_sample.y, rnd_support.x);
     const uint32_t emitter_index = sample_emitter_index(scene, rnd_support.y);
     // :414-421: after a subsurface walk the light is gathered at the exit point through scene.subsurface_exit_material

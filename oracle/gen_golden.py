@@ -11,7 +11,7 @@ Run in the build container (needs /root/reference): python3 oracle/gen_golden.py
                    cornell_{spectral,diamond,gems}_128_{vcm,pt}.npz  spectral mode: classic box / dispersive diamond + thinfilm / 2 892-triangle gems, VCM 64 spp, PT 256 spp
                    cornell_cloud_128_{vcm,pt}.npz                    heterogeneous medium (procedural 32^3 density in the fog box)
                    cornell_sss_128_{vcm,pt}.npz                      random-walk subsurface scattering, CPUVCM 64 spp / CPUPathTracing 256 spp
-                   cornell_{textured,envmap,lens,equirect,spectex}_128_{vcm,pt}.npz  textures + alpha cut-out + normal map / image environment map /
+                   cornell_{textured,envmap,lens,equirect,spectex,ssscb}_128_{vcm,pt}.npz  textures + alpha cut-out + normal map / image environment map /
                                                                      thin lens + aperture image / equirectangular camera, VCM 256 spp, PT 1024 spp
   spectral         cie_observer.npz                                  spectrum::spectral_xyz of the reference (etx_hip_upload_cie_table)
   blue noise       bluenoise_64spp.npz                               the reference's sample_blue_noise for the 64-spp class,
@@ -133,7 +133,8 @@ def sss_golden():
 def features_golden():
     # branches no other scene reaches: albedo texture + alpha cut-out (stochastic alpha test inside traversal) + normal map;
     # image environment map (2-D sampling tables) as the only light; thin lens with an aperture image; equirectangular camera
-    for flavour in ("textured", "envmap", "lens", "equirect", "spectex"):  # spectex: the textured box in spectral mode (apply_rgb)
+    # spectex: the textured box in spectral mode (apply_rgb); ssscb: the subsurface box with the Christensen-Burley class
+    for flavour in ("textured", "envmap", "lens", "equirect", "spectex", "ssscb"):
         snapshot = os.path.join(GOLDEN, "cornell_%s_128.etxscene" % flavour)
         run("--scene", os.path.join(SCENES, "%s_test_128.json" % flavour), "--integrator", "none", "--snapshot", snapshot)
         for integrator, spp, extra in (("vcm", 256, ["--opt", "vcm-blue_noise=false"]), ("pt", 1024, ["--opt", "bn=false", "--noise-threshold", "0"])):

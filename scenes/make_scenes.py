@@ -546,6 +546,14 @@ two_sided 1
 
 """ + MTL_LIGHT_CLASSIC)
     write_json("sss_test_128.json", "cornell_classic.obj", "cornell_sss.mtl", (128, 128), 64)
+    # the same box with the Christensen-Burley class ("class approximate", scene_representation.cxx:1996-2001): three probe rays,
+    # up to 24 exit points per vertex (subsurface::gather_cb + Raytracing::continuous_trace)
+    with open(os.path.join(OUT, "cornell_sss.mtl")) as f:
+        text = f.read()
+    with open(os.path.join(OUT, "cornell_ssscb.mtl"), "w") as f:
+        f.write(text.replace("subsurface distances 0.30 0.15 0.08 scale 0.5", "subsurface distances 0.30 0.15 0.08 scale 0.5 class approximate")
+                    .replace("subsurface path refracted distances 0.10 0.20 0.40 scale 0.5", "subsurface path refracted distances 0.10 0.20 0.40 scale 0.5 class approximate"))
+    write_json("ssscb_test_128.json", "cornell_classic.obj", "cornell_ssscb.mtl", (128, 128), 64)
     write_json("spectral_test_128.json", "cornell_classic.obj", "cornell_classic.mtl", (128, 128), 64, spectral=True)
     write_json("diamond_test_128.json", "cornell_classic.obj", "cornell_diamond.mtl", (128, 128), 64, spectral=True)
 

@@ -702,3 +702,24 @@ def test_pt_adaptive_sampling(etx, golden_dir):
     with pytest.raises(etx.EtxHipError, match="noise_threshold"):
         sharded.run()
     sharded.context.close()
+
+
+def test_pt_christensen_burley_subsurface(etx, golden_dir):
+    """SubsurfaceMaterial::Class::ChristensenBurley in the path tracer: three probe rays per vertex, every hit of the object's
+    material along them (Raytracing::continuous_trace, rt.cxx:373-426) is an exit point that is lit with its own weight, the path
+    continues from one of them (subsurface::gather_cb, path_tracing_shared.hxx:149-220; device: dev_sss.h sss_gather_cb).
+    Reference film: 1024 spp, --noise-threshold 0."""
+    golden = np.load(os.path.join(golden_dir, "cornell_ssscb_128_pt.npz"))
+    layers, stats = render_pt(etx, golden_dir, "cornell_ssscb_128", int(golden["spp"]), noise_threshold=0.0)
+    assert stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
+    ok = np.isfinite(golden["camera"]).all(axis=2)
+    assert ok.mean() > 0.999
+    ref = np.where(ok[..., None], golden["camera"], 0.0)
+    cam = np.where(ok[..., None], layers["camera"][..., :3], 0.0)
+    rel = (cam.mean(axis=(0, 1)) - ref.mean(axis=(0, 1))) / ref.mean(axis=(0, 1))
+    print("ssscb pt: block-16 RMSE %.2e rel mean %s" % (rmse(block_mean(cam, 16), block_mean(ref, 16)), np.round(rel, 4)))
+    assert rmse(block_mean(cam, 16), block_mean(ref, 16)) < 4.0e-3
+    assert np.abs(rel).max() < 1.0e-2, rel
+    # the two subsurface boxes themselves (the image regions the material covers): the short box in the lower right, the tall one left
+    rw = np.load(os.path.join(golden_dir, "cornell_sss_128_pt.npz"))["camera"]
+    assert abs(np.nanmean(rw) / ref.mean() - 1.0) > 0.03  # the Christensen-Burley film is not the random-walk film (-6 %)
