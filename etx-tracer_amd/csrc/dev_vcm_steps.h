@@ -30,8 +30,8 @@ ETX_DEV void store_light_vertex(const Pipeline& p, uint32_t idx, const PathState
 
 
 ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& scene, const PathState& st, const float4& hit_or_pos, uint32_t seed, const Isect* isect,
-  bool exit_material = false) {
-  if (idx >= p.capacity) {  // only the tail kernel can exceed one vertex per path slot
+  bool exit_material = false, uint32_t use_flags = 0u) {
+  if (idx >= p.cv_capacity) {  // the tail kernel, or more exit points of Christensen-Burley vertices than the pool was sized for
     atomicOr(p.counters + kCntOverflow, kOverflowCameraVertices);
     return;
   }
@@ -50,7 +50,7 @@ ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& 
   f3 fthr = st.throughput;
   if (diffuse)
     fthr = fthr * apply_image(scene, mat.scattering, isect->tex, nullptr, st.wavelength) * kInvPi;  // DiffuseBSDF func (bsdf_various.hxx:60-64) x t_camera
-  p.cv.pos_info[idx] = mk4(isect->pos, __uint_as_float((st.depth << 8u) | (diffuse ? kCvDiffuse : 0u)));
+  p.cv.pos_info[idx] = mk4(isect->pos, __uint_as_float((st.depth << 8u) | (diffuse ? kCvDiffuse : 0u) | use_flags));
   p.cv.nrm_dvm[idx] = mk4(isect->nrm, st.d_vm);
   p.cv.fthr_dvcm[idx] = mk4(fthr, st.d_vcm);
 }
@@ -131,7 +131,23 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
       // vcm_shared.hxx:1198-1200: a diffuse sample on a subsurface material walks through the object
       if (kWalk && (bs.properties & kSampleDiffuse) && (mat.subsurface.cls != 0u)) {
         subsurface_path = true;
-        subsurface_sampled = sss_gather_rw(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight);
+        if (mat.subsurface.cls == 2u) {
+          // Christensen-Burley: EVERY exit point is connected to the camera with its own weight (vcm_shared.hxx:1210-1224); the
+          // exit points are not buffered (dev_sss.h), each request takes its queue slot with a lane-level reservation
+          const bool connect_them = connect && (st.depth + 2 <= scene.max_path_length) && (st.depth + 2 >= scene.min_path_length);
+          subsurface_sampled = sss_gather_cb(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight, [&](const Isect& exit_point, const f3& weight) {
+            if (connect_them == false)
+              return;
+            st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+            write_endpoint(p, atomicAdd(p.counters + kCntEndpoints, 1u), make_float4(exit_point.bc.y, exit_point.bc.z, exit_point.t, __uint_as_float(exit_point.tri)), exit_point.w_i,
+              st.throughput * weight, true, st.d_vcm, st.d_vc, st.depth, st.medium, st.id, st.wavelength, st.sampler);
+            st.sampler.pop_fixed();
+          });
+          if (subsurface_sampled)
+            connect = false;  // done, one request per exit point; a failed gather connects the entry vertex (:1225-1235)
+        } else {
+          subsurface_sampled = sss_gather_rw(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight);
+        }
         ss_isect.material = scene.subsurface_exit_material;
       }
     }
@@ -248,7 +264,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
   f3 w_o_medium = mk3(0.0f);
   float pdf_fwd = 0.0f, pdf_rev = 0.0f;
   bool store = false, nee = false;
-  bool subsurface_path = false, subsurface_sampled = false;
+  bool subsurface_path = false, subsurface_sampled = false, cb_vertex = false;
   Isect ss_isect;
   f3 ss_weight = mk3(0.0f);
   if (scatter_event) {
@@ -297,7 +313,38 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       // vcm_shared.hxx:1032-1034
       if (kWalk && (bs.properties & kSampleDiffuse) && (mat.subsurface.cls != 0u)) {
         subsurface_path = true;
-        subsurface_sampled = sss_gather_rw(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight);
+        if (mat.subsurface.cls == 2u) {
+          // Christensen-Burley (vcm_shared.hxx:1038-1071): EVERY exit point is connected to the light path and to a light with its
+          // own weight - a connect-only camera vertex record and an endpoint request per exit point, written as the points are
+          // found (dev_sss.h) with lane-level reservations; the photon merge happens once, at the exit point the path continues from
+          const bool connect_them = is_connectible;
+          const bool light_them = is_connectible && opt_connect_to_light(it) && (st.depth + 1 <= scene.max_path_length) && (st.depth + 1 >= scene.min_path_length);
+          subsurface_sampled = sss_gather_cb(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight, [&](const Isect& exit_point, const f3& weight) {
+            Isect e = exit_point;
+            e.material = scene.subsurface_exit_material;
+            PathState scaled = st;
+            scaled.throughput = st.throughput * weight;
+            scaled.ray_d = e.w_i;
+            const float4 where = make_float4(e.bc.y, e.bc.z, e.t, __uint_as_float(e.tri));
+            if (connect_them && opt_connect_vertices(it)) {
+              Sampler derived;
+              derived.init(st.sampler.seed, 0x51ed270bu ^ e.tri);
+              store_camera_vertex(p, atomicAdd(p.counters + kCntCameraVertices, 1u), scene, scaled, where, derived.seed, &e, true, kCvNoMerge);
+            }
+            if (light_them) {
+              st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+              write_endpoint(p, atomicAdd(p.counters + kCntEndpoints, 1u), where, e.w_i, scaled.throughput, true, st.d_vcm, st.d_vc, st.depth, st.medium, st.id, st.wavelength, st.sampler);
+              st.sampler.pop_fixed();
+            }
+          });
+          if (subsurface_sampled) {  // a failed gather leaves the entry vertex to be connected and merged as it is (:1048-1054)
+            nee = false;
+            store = is_connectible && opt_merge_vertices(it) && (st.depth + 1 <= scene.max_path_length);  // the merge-only record
+            cb_vertex = true;
+          }
+        } else {
+          subsurface_sampled = sss_gather_rw(scene, stack, isect, st.sampler, st.wavelength, ss_isect, ss_weight);
+        }
         ss_isect.material = scene.subsurface_exit_material;
       }
     }
@@ -358,7 +405,8 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       PathState scaled = st;
       scaled.throughput = st.throughput * ss_weight;
       scaled.ray_d = ss_isect.w_i;
-      store_camera_vertex(p, vertex_slot, scene, scaled, make_float4(ss_isect.bc.y, ss_isect.bc.z, ss_isect.t, __uint_as_float(ss_isect.tri)), derived.seed, &ss_isect, true);
+      store_camera_vertex(p, vertex_slot, scene, scaled, make_float4(ss_isect.bc.y, ss_isect.bc.z, ss_isect.t, __uint_as_float(ss_isect.tri)), derived.seed, &ss_isect, true,
+        cb_vertex ? kCvNoConnect : 0u);
     } else {
       store_camera_vertex(p, vertex_slot, scene, st, h, derived.seed, &isect);
     }

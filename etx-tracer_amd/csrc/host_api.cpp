@@ -204,7 +204,10 @@ int allocate_pipeline(etx_hip_context* ctx) {
   p.lv.capacity = uint32_t(lv_cap64);
   if ((rc = device_alloc(ctx, p.lv.rec, size_t(p.lv.capacity) * LightVertexPool::kLvStride)))
     return rc;
-  if ((rc = device_alloc(ctx, p.path_wavelength, n)) || (rc = device_alloc(ctx, p.cv.wavelength, n)))
+  const uint32_t exit_points = ctx->scene.has_subsurface_cb ? 8u : 1u;  // average exit points per vertex the pools are sized for (overflow is reported)
+  p.cv_capacity = uint32_t(std::min<uint64_t>(uint64_t(n) * exit_points, 1ull << 30));
+  const uint32_t cvn = p.cv_capacity;
+  if ((rc = device_alloc(ctx, p.path_wavelength, n)) || (rc = device_alloc(ctx, p.cv.wavelength, cvn)))
     return rc;
   if ((rc = device_alloc(ctx, p.light_path_head, n)) || (rc = device_alloc(ctx, p.light_path_table, size_t(n) * (kPathTableEntries / 4u))))
     return rc;
@@ -214,23 +217,23 @@ int allocate_pipeline(etx_hip_context* ctx) {
     return rc;
   if ((rc = device_alloc(ctx, p.grid_params, 1)))
     return rc;
-  if ((rc = device_alloc(ctx, p.cv.hit, n)) || (rc = device_alloc(ctx, p.cv.wi_medium, n)) || (rc = device_alloc(ctx, p.cv.thr_depth, n)) || (rc = device_alloc(ctx, p.cv.mis_pixel, n)) ||
-      (rc = device_alloc(ctx, p.cv.seed, n)) || (rc = device_alloc(ctx, p.cv.pos_info, n)) || (rc = device_alloc(ctx, p.cv.nrm_dvm, n)) || (rc = device_alloc(ctx, p.cv.fthr_dvcm, n)))
+  if ((rc = device_alloc(ctx, p.cv.hit, cvn)) || (rc = device_alloc(ctx, p.cv.wi_medium, cvn)) || (rc = device_alloc(ctx, p.cv.thr_depth, cvn)) || (rc = device_alloc(ctx, p.cv.mis_pixel, cvn)) ||
+      (rc = device_alloc(ctx, p.cv.seed, cvn)) || (rc = device_alloc(ctx, p.cv.pos_info, cvn)) || (rc = device_alloc(ctx, p.cv.nrm_dvm, cvn)) || (rc = device_alloc(ctx, p.cv.fthr_dvcm, cvn)))
     return rc;
   if ((rc = device_alloc(ctx, p.group_list[0], n)) || (rc = device_alloc(ctx, p.group_list[1], n)))
     return rc;
-  if ((rc = device_alloc(ctx, p.merge_order, n)) || (rc = device_alloc(ctx, p.merge_buckets, kMergeBuckets + 1u + 256u)))
+  if ((rc = device_alloc(ctx, p.merge_order, cvn)) || (rc = device_alloc(ctx, p.merge_buckets, kMergeBuckets + 1u + 256u)))
     return rc;
-  p.pair_capacity = uint32_t(std::min<uint64_t>(uint64_t(n) * 16u, 1ull << 30));
+  p.pair_capacity = uint32_t(std::min<uint64_t>(uint64_t(n) * 16u * (exit_points > 1u ? 4u : 1u), 1ull << 30));
   if ((rc = device_alloc(ctx, p.pairs, p.pair_capacity)))
     return rc;
-  p.shadow.capacity = uint32_t(std::min<uint64_t>(uint64_t(p.pair_capacity) + 2ull * n, 0xfffffff0ull));
+  p.shadow.capacity = uint32_t(std::min<uint64_t>(uint64_t(p.pair_capacity) + 2ull * cvn, 0xfffffff0ull));
   if ((rc = device_alloc(ctx, p.shadow.p0_medium, p.shadow.capacity)) || (rc = device_alloc(ctx, p.shadow.p1_target, p.shadow.capacity)) ||
       (rc = device_alloc(ctx, p.shadow.value, p.shadow.capacity)))
     return rc;
-  p.endpoints.capacity = n;
-  if ((rc = device_alloc(ctx, p.endpoints.hit, n)) || (rc = device_alloc(ctx, p.endpoints.wi_medium, n)) || (rc = device_alloc(ctx, p.endpoints.thr_depth, n)) ||
-      (rc = device_alloc(ctx, p.endpoints.mis_id, n)) || (rc = device_alloc(ctx, p.endpoints.rnd_seed, n)) || (rc = device_alloc(ctx, p.endpoints.wavelength, n)))
+  p.endpoints.capacity = cvn;
+  if ((rc = device_alloc(ctx, p.endpoints.hit, cvn)) || (rc = device_alloc(ctx, p.endpoints.wi_medium, cvn)) || (rc = device_alloc(ctx, p.endpoints.thr_depth, cvn)) ||
+      (rc = device_alloc(ctx, p.endpoints.mis_id, cvn)) || (rc = device_alloc(ctx, p.endpoints.rnd_seed, cvn)) || (rc = device_alloc(ctx, p.endpoints.wavelength, cvn)))
     return rc;
   if ((rc = device_alloc(ctx, ctx->pt_iteration_image, size_t(n) * 2u)))
     return rc;
@@ -1104,10 +1107,6 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
     }
   } else {
     context->error = "integrator " + std::to_string(integrator) + " is not implemented by the device path";
-    return ETX_HIP_ERROR_UNSUPPORTED;
-  }
-  if (context->scene.has_subsurface_cb && (integrator != ETX_HIP_INTEGRATOR_PT)) {
-    context->error = "Christensen-Burley subsurface materials are implemented for the path tracer only so far (use path tracing, or the random-walk class)";
     return ETX_HIP_ERROR_UNSUPPORTED;
   }
   if (context->scene.host_copy.spectral) {

@@ -32,13 +32,13 @@ ETX_DEV bool material_is_diffuse(const DScene& scene, uint32_t tri) {
 __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmParams it) {
   __shared__ uint32_t s_wave_total[kBlockSize / 64u];
   __shared__ uint32_t s_base;
-  const uint32_t count = p.counters[kCntCameraVertices];
+  const uint32_t count = min(p.counters[kCntCameraVertices], p.cv_capacity);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6u;
   ETX_BLOCK_LOOP(count, i) {
     uint32_t head = kInvalid, k = 0, path = 0;
     if (i < count) {
       path = __float_as_uint(p.cv.mis_pixel[i].w);
-      head = p.light_path_head[path];
+      head = (__float_as_uint(p.cv.pos_info[i].w) & kCvNoConnect) ? kInvalid : p.light_path_head[path];  // merge-only record of a Christensen-Burley vertex
       // the head vertex knows its index in the path (store_light_vertex), so the path length needs no extra table
       k = (head == kInvalid) ? 0u : ((__float_as_uint(p.lv.bc_len_med(head).z) >> 16u) + 1u);
     }
@@ -225,7 +225,7 @@ ETX_DEV bool merge_candidate(const Pipeline& p, const GridParams& g, uint32_t ma
   const float4 pi = p.cv.pos_info[vertex];
   const uint32_t info = __float_as_uint(pi.w);
   pos = {pi.x, pi.y, pi.z};
-  if ((info & kCvMedium) || ((info >> 8u) + 1u > max_path_length))
+  if ((info & (kCvMedium | kCvNoMerge)) || ((info >> 8u) + 1u > max_path_length))
     return false;
   return (pos.x >= g.bbox_min.x) && (pos.y >= g.bbox_min.y) && (pos.z >= g.bbox_min.z) && (pos.x <= g.bbox_max.x) && (pos.y <= g.bbox_max.y) && (pos.z <= g.bbox_max.z);
 }
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_count(Pipeline p) {
   const GridParams g = *p.grid_params;
   if ((g.valid == 0u) || (g.photon_count == 0u))
     return;
-  const uint32_t count = min(p.counters[kCntCameraVertices], p.capacity);
+  const uint32_t count = min(p.counters[kCntCameraVertices], p.cv_capacity);
   const uint32_t max_path_length = p.scene.max_path_length;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     f3 pos;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_scatter(Pipeline p) {
   const GridParams g = *p.grid_params;
   if ((g.valid == 0u) || (g.photon_count == 0u))
     return;
-  const uint32_t count = min(p.counters[kCntCameraVertices], p.capacity);
+  const uint32_t count = min(p.counters[kCntCameraVertices], p.cv_capacity);
   const uint32_t max_path_length = p.scene.max_path_length;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     f3 pos;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
   __shared__ uint2 s_ring[kBlockSize / 64][128];  // (photon, distance^2 bits)
   __shared__ uint32_t s_ring_range[kBlockSize / 64][128];
   const DScene& scene = p.scene;
-  const uint32_t count = min(p.counters[kCntMergeVertices], p.capacity);
+  const uint32_t count = min(p.counters[kCntMergeVertices], p.cv_capacity);
   const GridParams g = *p.grid_params;
   if ((g.valid == 0u) || (g.photon_count == 0u))
     return;
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
   __shared__ uint32_t s_ring_range[kBlockSize / 64][128];
   __shared__ unsigned long long s_stat;
   const DScene& scene = p.scene;
-  const uint32_t count = min(p.counters[kCntMergeVertices], p.capacity);
+  const uint32_t count = min(p.counters[kCntMergeVertices], p.cv_capacity);
   const GridParams g = *p.grid_params;
   if ((g.valid == 0u) || (g.photon_count == 0u))
     return;

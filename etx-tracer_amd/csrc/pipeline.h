@@ -85,7 +85,9 @@ struct CameraVertexPool {  // connectible camera vertices of the current bounce 
   float4* fthr_dvcm;       // diffuse: albedo/pi * throughput (= func * t_camera), else throughput; d_vcm
 };
 
-enum : uint32_t { kCvDiffuse = 1u << 0, kCvMedium = 1u << 1 };
+// kCvNoMerge / kCvNoConnect: the exit points of a Christensen-Burley vertex are connected one by one, the photon merge happens once at
+// the exit point the path continues from, with another throughput (vcm_shared.hxx:1038-1071): two kinds of records
+enum : uint32_t { kCvDiffuse = 1u << 0, kCvMedium = 1u << 1, kCvNoMerge = 1u << 2, kCvNoConnect = 1u << 3 };
 
 // Endpoint connections of the general / subsurface shading groups: the connection of a light vertex to the camera
 // (vcm_connect_to_camera, vcm_shared.hxx:463-535) or of a camera vertex to a light (vcm_connect_to_light, :608-671).
@@ -222,6 +224,7 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   unsigned long long* block_stats;  // kBlockStatRows x kBlockStatCount
   uint32_t debug_flags;             // ETX_HIP_DEBUG_FLAGS: ablation switches for kernel timing experiments (0 in production)
   uint32_t capacity;     // paths per set
+  uint32_t cv_capacity;  // camera vertex records per bounce: = capacity, x 8 when the scene has Christensen-Burley materials (up to 24 exit points per vertex)
 };
 
 }  // namespace etxd

@@ -723,3 +723,23 @@ def test_pt_christensen_burley_subsurface(etx, golden_dir):
     # the two subsurface boxes themselves (the image regions the material covers): the short box in the lower right, the tall one left
     rw = np.load(os.path.join(golden_dir, "cornell_sss_128_pt.npz"))["camera"]
     assert abs(np.nanmean(rw) / ref.mean() - 1.0) > 0.03  # the Christensen-Burley film is not the random-walk film (-6 %)
+
+
+def test_vcm_christensen_burley_subsurface(etx, golden_dir):
+    """The same material class under VCM (vcm_shared.hxx:1033-1071, 1198-1247): every exit point is connected to the light path, to a
+    light and (light pass) to the camera with its own weight - connect-only camera vertex records and endpoint requests per exit
+    point -, the photon merge happens once at the exit point the path continues from (merge-only record). Reference film: 256 spp."""
+    golden = np.load(os.path.join(golden_dir, "cornell_ssscb_128_vcm.npz"))
+    cam, light, res, stats = render(etx, golden_dir, "cornell_ssscb_128", int(golden["spp"]))
+    assert stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
+    ref = np.maximum(golden["camera"] + golden["light"], 0.0)
+    ok = np.isfinite(ref).all(axis=2)
+    ref = np.where(ok[..., None], ref, 0.0)
+    res = np.where(ok[..., None], res[..., :3], 0.0)
+    rel = (res.mean(axis=(0, 1)) - ref.mean(axis=(0, 1))) / ref.mean(axis=(0, 1))
+    light_ref = golden["light"].mean(axis=(0, 1))
+    light_rel = (light[..., :3].mean(axis=(0, 1)) - light_ref) / light_ref
+    print("ssscb vcm: block-16 RMSE %.2e rel mean %s light rel %s" % (rmse(block_mean(res, 16), block_mean(ref, 16)), np.round(rel, 4), np.round(light_rel, 4)))
+    assert rmse(block_mean(res, 16), block_mean(ref, 16)) < 4.0e-3
+    assert np.abs(rel).max() < 1.5e-2, rel
+    assert np.abs(light_rel).max() < 3.0e-2, light_rel
