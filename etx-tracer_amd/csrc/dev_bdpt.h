@@ -32,6 +32,7 @@ enum : uint32_t {
   kBvConnectible = 1u << 2,
   kBvMisConnectible = 1u << 3,
   kBvEmitter = 1u << 4,         // Class::Emitter
+  kBvScatterMaterial = 1u << 6,     // entry / exit vertex of a subsurface walk: its BSDF is scene.subsurface_scatter_material (handle_surface :612, build_path :859)
   kBvNoCameraConnection = 1u << 5,  // light path medium vertex of a medium without explicit connections: handle_medium skips connect() (:567-569)
 };
 
@@ -293,6 +294,8 @@ ETX_DEV BdptLightVertex bdpt_load_light_vertex(const Pipeline& p, const DScene& 
     v.full.g = (v.medium != kInvalid) ? scene.mediums[v.medium].g : 0.0f;
   } else if (v.self.flags & kBvSurface) {
     v.full.isect = make_intersection(scene, w_i, e.x, e.y, 0.0f, v.self.tri);
+    if (v.self.flags & kBvScatterMaterial)
+      v.full.isect.material = scene.subsurface_scatter_material;
   } else {
     v.full.isect.pos = v.self.pos, v.full.isect.nrm = v.self.nrm, v.full.isect.w_i = w_i, v.full.isect.tri = kInvalid;
   }
@@ -301,14 +304,14 @@ ETX_DEV BdptLightVertex bdpt_load_light_vertex(const Pipeline& p, const DScene& 
 
 // Camera vertex record (CameraVertexPool): the connectible vertex z_curr with what its connections read of z_prev.
 ETX_DEV void bdpt_store_camera_vertex(const Pipeline& p, uint32_t idx, const BdptState& st, const float4& hit_or_pos, const f3& w_i, uint32_t vertex_medium, const f3& throughput, float from_prev,
-  const f3& rnd_fixed, uint32_t seed) {
-  if (idx >= p.capacity) {
+  const f3& rnd_fixed, uint32_t seed, bool scatter_material = false) {
+  if (idx >= p.cv_capacity) {
     atomicOr(p.counters + kCntOverflow, kOverflowCameraVertices);
     return;
   }
   p.cv.hit[idx] = hit_or_pos;
   p.cv.wi_medium[idx] = mk4(w_i, __uint_as_float(vertex_medium));
-  p.cv.thr_depth[idx] = mk4(throughput, __uint_as_float(st.path_size));
+  p.cv.thr_depth[idx] = mk4(throughput, __uint_as_float(st.path_size | (scatter_material ? kCvExitMaterialBit : 0u)));  // entry / exit vertex of a subsurface walk
   p.cv.mis_pixel[idx] = make_float4(from_prev, st.prev.from_prev, st.prev.history, __uint_as_float(st.id));
   p.cv.seed[idx] = seed;
   p.cv.wavelength[idx] = st.wavelength;
@@ -328,7 +331,7 @@ struct BdptCameraVertex {
 ETX_DEV BdptCameraVertex bdpt_load_camera_vertex(const Pipeline& p, const DScene& scene, uint32_t i) {
   const float4 h = p.cv.hit[i], w = p.cv.wi_medium[i], t = p.cv.thr_depth[i], m = p.cv.mis_pixel[i], pp = p.cv.pos_info[i], pn = p.cv.nrm_dvm[i], r = p.cv.fthr_dvcm[i];
   BdptCameraVertex v;
-  v.throughput = {t.x, t.y, t.z}, v.path_size = __float_as_uint(t.w);
+  v.throughput = {t.x, t.y, t.z}, v.path_size = __float_as_uint(t.w) & ~kCvExitMaterialBit;
   v.from_prev = m.x;
   v.prev = {{pp.x, pp.y, pp.z}, {pn.x, pn.y, pn.z}, m.y, m.z, __float_as_uint(pp.w), __float_as_uint(pn.w)};
   v.pixel = __float_as_uint(m.w);
@@ -345,6 +348,8 @@ ETX_DEV BdptCameraVertex bdpt_load_camera_vertex(const Pipeline& p, const DScene
     v.full.g = (v.medium != kInvalid) ? scene.mediums[v.medium].g : 0.0f;
   } else {
     v.full.isect = make_intersection(scene, w_i, h.x, h.y, h.z, tri);
+    if (__float_as_uint(t.w) & kCvExitMaterialBit)
+      v.full.isect.material = scene.subsurface_scatter_material;
   }
   return v;
 }

@@ -136,6 +136,7 @@ struct DScene {
   const DScene* self;              // device address of the device-resident copy of this struct (out-of-line BSDF calls, dev_bsdf_ool.h)
   const uint32_t* material_variants;  // per material: first of its three PrincipledBSDF variants (appended to `materials`), kInvalid otherwise
   const uint8_t* material_group;   // per material: shading group of a path that hits it (kShadeGroup*, kernels_shade.inl)
+  const uint32_t* material_sss_medium;  // per material: the medium its subsurface walk runs through (interior medium, or a derived entry appended to `mediums`; host_scene.cpp)
   uint32_t vertex_count, triangle_count, material_count, emitter_count, emitter_dist_count, spectrum_count, image_count, medium_count;
   uint32_t bvh_node_count, bvh_tri_count, flat_prim_count, pad_flat;
   int32_t bvh_root;  // child encoding (a single leaf scene has a negative root)
@@ -152,7 +153,7 @@ struct DScene {
   uint32_t flags;
   uint32_t pixel_sampler_image;
   float pixel_sampler_radius;
-  uint32_t subsurface_exit_material;
+  uint32_t subsurface_exit_material, subsurface_scatter_material;
   uint32_t default_dielectric_eta, default_conductor_eta, default_conductor_k;  // spectrum indices (PrincipledBSDF)
   uint32_t spectral;    // Scene::spectral(): one wavelength per path, SpectralResponse = one float (kept replicated in xyz here)
   uint32_t cie_count;

@@ -46,6 +46,7 @@ void DeviceScene::borrow(const DeviceScene& owner) {
   group_general = owner.group_general, group_subsurface = owner.group_subsurface;
   has_subsurface = owner.has_subsurface;
   has_subsurface_cb = owner.has_subsurface_cb;
+  sss_media_complete = owner.sss_media_complete;
   generic_materials = owner.generic_materials;
   needs_rgb_response = owner.needs_rgb_response;
   bvh_bytes = owner.bvh_bytes;
@@ -676,7 +677,49 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
         return rc;
     }
   }
-  if ((rc = upload(out, dmediums.data(), dmediums.size(), d.mediums, error)))
+  // Subsurface materials under the bidirectional integrator (bidirectional.cxx:729-790): the walk runs through the material's
+  // interior medium, or - without one - through a medium derived from its colour and scattering distances
+  // (subsurface::remap_channel, scene_bssrdf_subsurface.hxx:17-44). The derived medium becomes a table entry of its own here, so that
+  // vertices inside the object name their medium by index like every other vertex. RGB mode, untextured parameters; anything
+  // else leaves the material without an entry and etx_hip_begin refuses the scene for that integrator.
+  std::vector<uint32_t> sss_medium(material_table.size(), kInvalid);
+  out.sss_media_complete = true;
+  for (uint64_t i = 0; i < scene->materials.count; ++i) {
+    const etx_abi_material& m = material_table[i];
+    if ((used[i] == false) || (m.subsurface.cls == 0u))
+      continue;
+    if (m.int_medium < scene->mediums.count) {
+      sss_medium[i] = m.int_medium;
+      continue;
+    }
+    const bool textured = (m.scattering.image_index != ETX_ABI_INVALID) || (m.subsurface.image_index != ETX_ABI_INVALID);
+    if (spectral || textured || (m.scattering.spectrum_index >= scene->spectrums.count) || (m.subsurface.spectrum_index >= scene->spectrums.count)) {
+      out.sss_media_complete = false;
+      continue;
+    }
+    const f3 color = a3(spectrums[m.scattering.spectrum_index].integrated), distances = a3(spectrums[m.subsurface.spectrum_index].integrated);
+    auto remap = [](float colour, float distance, float& extinction, float& scattering) {
+      const float a = 1.826052378200f, b = 4.985111943850f + 0.12735595943800f, cc = 1.096861024240f;
+      const float dd = 0.496310210422f, e = 4.231902997010f + 0.00310603949088f, f = 2.406029994080f;
+      colour = std::max(0.0f, colour);
+      const float blend = powf(colour, 0.25f);
+      float albedo = (1.0f - blend) * a * powf(atanf(b * colour), cc) + blend * dd * powf(atanf(e * colour), f);
+      albedo = std::min(std::max(albedo, 0.0f), 1.0f - kEpsilon);
+      extinction = 1.0f / std::max(distance, 1.0f / 1024.0f);
+      scattering = extinction * albedo;
+    };
+    f3 extinction, scattering;
+    remap(color.x, distances.x, extinction.x, scattering.x);
+    remap(color.y, distances.y, extinction.y, scattering.y);
+    remap(color.z, distances.z, extinction.z, scattering.z);
+    DMedium dm = {};
+    dm.absorption = extinction - scattering, dm.scattering = scattering;
+    dm.absorption_index = dm.scattering_index = kInvalid;
+    dm.cls = 0u, dm.explicit_connections = 0u, dm.g = 0.0f;
+    sss_medium[i] = uint32_t(dmediums.size());
+    dmediums.push_back(dm);
+  }
+  if ((rc = upload(out, dmediums.data(), dmediums.size(), d.mediums, error)) || (rc = upload(out, sss_medium.data(), sss_medium.size(), d.material_sss_medium, error)))
     return rc;
 
   HostBvh bvh;
@@ -758,6 +801,7 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   d.pixel_sampler_image = scene->pixel_sampler.image_index;
   d.pixel_sampler_radius = scene->pixel_sampler.radius;
   d.subsurface_exit_material = scene->subsurface_exit_material;
+  d.subsurface_scatter_material = scene->subsurface_scatter_material;
   d.default_dielectric_eta = scene->default_dielectric_eta;
   d.default_conductor_eta = scene->default_conductor_eta;
   d.default_conductor_k = scene->default_conductor_k;

@@ -27,6 +27,7 @@ struct DeviceScene {
   bool group_general = false;      // a material of shading group kShadeGroupGeneral is in use (dev_scene.h)
   bool group_subsurface = false;   // ... of kShadeGroupSubsurface
   bool has_subsurface = false;     // a subsurface material is in use
+  bool sss_media_complete = true;  // every subsurface material has a medium table entry for its walk (bidirectional integrator)
   bool has_subsurface_cb = false;  // ... of class Christensen-Burley (up to 24 exit points per vertex)
   bool generic_materials = false;  // a connectible (non delta) surface material other than Diffuse is in use
   bool needs_rgb_response = false; // spectral scene with RGB images behind spectra: apply_rgb needs the host's table (etx_hip_upload_rgb_response)

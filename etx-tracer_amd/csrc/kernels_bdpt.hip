@@ -94,9 +94,70 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_generate(Pipeline p, 
   }
 }
 
-// One segment of an emitter path after the closest-hit query.
+// Subsurface walk state of a lane (build_path: subsurface_material; subsurface_step, bidirectional.cxx:746-818). The walk runs
+// INSIDE the shade kernel: after the entry vertex the lane keeps taking sub-steps - free flight through the walk's medium, a
+// material-filtered closest-hit query in place of the ray queue, one path vertex per scattering event - until the path leaves
+// the object or ends; every sub-step goes through the same vertex code and the same workgroup-wide slot reservations as a
+// queue segment (the sub-step loop is workgroup-uniform).
+struct BdptWalk {
+  uint32_t material;  // kInvalid: not inside an object
+  uint32_t medium;    // DScene::material_sss_medium of that material
+  uint32_t events;
+};
+
+// subsurface_step's free flight: returns false when the path ends (pdf zero). found = the object's surface was reached (h filled).
+ETX_DEV bool bdpt_walk_flight(const DScene& scene, const LaneStack& stack, const BdptWalk& walk, BdptState& st, float4& h, MediumSample& ms) {
+  const DMedium& wm = scene.mediums[walk.medium];
+  f3 absorption, scattering;
+  medium_coefficients(scene, wm, st.wavelength, absorption, scattering);
+  const f3 extinction = scattering + absorption;
+  const f3 albedo = {extinction.x > 0.0f ? scattering.x / extinction.x : 0.0f, extinction.y > 0.0f ? scattering.y / extinction.y : 0.0f, extinction.z > 0.0f ? scattering.z / extinction.z : 0.0f};
+  f3 pdf = mk3(0.0f);
+  float max_t = 0.0f;
+  while (max_t < kRayEpsilon) {
+    const uint32_t channel = sample_spectrum_component(albedo, st.throughput, st.sampler.next(), pdf);
+    const float sample_t = channel == 0 ? extinction.x : (channel == 1 ? extinction.y : extinction.z);
+    max_t = (sample_t > 0.0f) ? -logf(1.0f - st.sampler.next()) / sample_t : kMaxFloat;
+  }
+  uint32_t alpha_seed = st.sampler.seed ^ 0x62777373u;
+  const Hit hit = bvh_closest(scene, global_nodes(scene), scene.bvh_tris, scene.bvh_root, stack, RayQ{st.ray_o, st.ray_tmin, st.ray_d, max_t}, alpha_seed, nullptr, walk.material);
+  const bool found = hit.tri != kInvalid;
+  if (found)
+    max_t = hit.t;
+  const f3 tr = {expf(-max_t * extinction.x), expf(-max_t * extinction.y), expf(-max_t * extinction.z)};
+  pdf = found ? pdf * tr : pdf * tr * extinction;
+  if ((pdf.x == 0.0f) && (pdf.y == 0.0f) && (pdf.z == 0.0f))
+    return false;
+  st.throughput *= (found ? tr : tr * scattering) / (pdf.x + pdf.y + pdf.z);
+  h = make_float4(hit.u, hit.v, hit.t, __uint_as_float(hit.tri));
+  ms.weight = mk3(1.0f);
+  ms.pos = st.ray_o + st.ray_d * max_t;
+  ms.sampled_medium_t = found ? 0.0f : max_t;
+  return true;
+}
+
+// handle_surface :610-633: a diffuse reflection off a subsurface material enters the object instead (the vertex gets the scatter
+// material, the walk's medium, and a cosine lobe into the object or the incoming direction as its sampled direction)
+ETX_DEV bool bdpt_enter_subsurface(const DScene& scene, const etx_abi_material& mat, const Isect& isect, BsdfSample& bs, Sampler& smp, uint32_t& vertex_medium) {
+  if ((mat.subsurface.cls == 0u) || ((bs.properties & kSampleReflection) == 0u) || ((bs.properties & kSampleDiffuse) == 0u))
+    return false;
+  const f3 w_o = (mat.subsurface.path == 0u) ? sample_cosine_distribution(smp.next_2d(), -isect.nrm, 1.0f) : isect.w_i;
+  vertex_medium = scene.material_sss_medium[isect.material];
+  bs.w_o = w_o;
+  bs.weight = mk3(1.0f);
+  bs.pdf = fabsf(dot(w_o, isect.nrm)) / kPi;
+  bs.eta = 1.0f;
+  bs.medium_index = vertex_medium;
+  bs.properties = kSampleTransmission | kSampleDiffuse | kSampleMediumChanged;
+  return true;
+}
+
+// One segment of an emitter path after the closest-hit query (+ the sub-steps of a subsurface walk, kWalk).
+template <bool kWalk>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, VcmParams it, uint32_t in_set) {
   __shared__ BlockScratch s_scratch;
+  __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];
+  const LaneStack stack = {s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize};
   const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const PathSet& out = p.paths[in_set ^ 1u];
@@ -106,132 +167,171 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
   ETX_BLOCK_LOOP(count, i) {
     const bool valid = i < count;
     BdptState st = {};
-    bool alive = false, store_emitter = false, store_vertex = false;
-    // the vertex created by this segment
-    f3 v_pos = mk3(0.0f), v_nrm = mk3(0.0f), v_wi = mk3(0.0f), v_throughput = mk3(0.0f);
-    float v_from_prev = 0.0f, v_bc_u = 0.0f, v_bc_v = 0.0f;
-    uint32_t v_flags = 0u, v_tri = kInvalid, v_medium = kInvalid;
-    BVtx emitter_vertex = {};
-    float emitter_from_next = 0.0f;
+    BdptWalk walk = {kInvalid, kInvalid, 0u};
+    bool busy = valid, alive = false;  // busy: this lane has a (sub-)step to run
+    float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
     if (valid) {
       st = bdpt_load(in, i);
-      uint32_t emitter_tri = kInvalid;
+      h = p.hits[i];
       if (st.flags & kBpFirst) {
-        emitter_tri = st.prev_slot;  // see k_bdpt_light_generate
-        st.prev.tri = emitter_tri;
+        st.prev.tri = st.prev_slot;  // see k_bdpt_light_generate
         st.prev_slot = kInvalid;
       }
-      const float4 h = p.hits[i];
-      const uint32_t tri = __float_as_uint(h.w);
-      const bool found = tri != kInvalid;
-      // regular_step, bidirectional.cxx:712-727
-      MediumSample ms;
-      ms.sampled_medium_t = 0.0f;
-      if (st.medium != kInvalid) {
-        ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
-        st.throughput *= ms.weight;
-      }
-      const bool first = (st.flags & kBpFirst) != 0u;
-      if (ms.sampled_medium()) {  // handle_medium, :533-570
-        const DMedium& med = scene.mediums[st.medium];
-        const f2 rnd_bsdf = st.sampler.next_2d();
-        (void)st.sampler.next_2d();
-        (void)st.sampler.next_2d();
-        const f3 w_o = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
-        const float pdf_fwd = phase_function(st.ray_d, w_o, med.g);
-        const float pdf_bck = phase_function(w_o, st.ray_d, med.g);
-        st.path_size += 1u;
-        BVtx curr = {ms.pos, mk3(0.0f), 0.0f, 0.0f, kBvMedium | kBvConnectible | ((st.prev.flags & kBvConnectible) ? kBvMisConnectible : 0u), kInvalid};
-        curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
-        float prev_from_next = bdpt_to_area(pdf_bck, ms.pos, st.prev);
-        if (first && (st.flags & kBpDistantEmitter)) {  // update_distant_emitter_path_pdfs, :423-436
-          st.prev.from_prev = bdpt_emitter_sample_pdf(scene, scene.emitters[st.flags >> kBpEmitterShift], -st.ray_d);
-          curr.from_prev = st.aux;
+    }
+    bool walk_pass = false;  // the first pass is the queue segment (workgroup-wide slot reservations, every lane takes part); the
+                             // sub-steps of a walk are a loop of their lane alone and reserve their slots with lane-level atomics
+    do {
+      bool store_emitter = false, store_vertex = false;
+      // the vertex created by this (sub-)step
+      f3 v_pos = mk3(0.0f), v_nrm = mk3(0.0f), v_wi = mk3(0.0f), v_throughput = mk3(0.0f);
+      float v_from_prev = 0.0f, v_bc_u = 0.0f, v_bc_v = 0.0f;
+      uint32_t v_flags = 0u, v_tri = kInvalid, v_medium = kInvalid;
+      BVtx emitter_vertex = {};
+      float emitter_from_next = 0.0f;
+      if (busy) {
+        busy = false;
+        const bool in_walk = kWalk && (walk.material != kInvalid);
+        MediumSample ms;
+        ms.sampled_medium_t = 0.0f;
+        bool flight_ok = true;
+        if (in_walk) {
+          walk.events += 1u;
+          flight_ok = (walk.events <= 1024u) && bdpt_walk_flight(scene, stack, walk, st, h, ms);  // :776-812
         }
-        v_pos = ms.pos, v_wi = st.ray_d, v_throughput = st.throughput, v_from_prev = curr.from_prev, v_flags = curr.flags, v_medium = st.medium;
-        if (med.explicit_connections == 0u)
-          v_flags |= kBvNoCameraConnection;  // handle_medium skips connect() for it; camera paths still connect TO it
-        st.ray_o = ms.pos, st.ray_d = w_o, st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
-        st.pdf_dir = pdf_fwd;
-        emitter_vertex = st.prev;
-        emitter_from_next = prev_from_next;
-        bdpt_advance_history(st, prev_from_next, false, mode, true);
-        emitter_vertex.history = st.prev.history;
-        store_emitter = first, store_vertex = true;
-        st.prev = curr;
-        st.flags &= ~kBpFirst;
-        alive = random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
-      } else if (found) {
-        Isect isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
-        const etx_abi_material& mat = scene.materials[isect.material];
-        const f2 rnd_bsdf = st.sampler.next_2d();
-        (void)st.sampler.next_2d();
-        const f2 rnd_support = st.sampler.next_2d();
-        if (mat.cls == ETX_MAT_BOUNDARY) {  // handle_surface :586-593: the path length does not change
-          const etx_abi_triangle& t = scene.triangles[isect.tri];
-          st.medium = (dot(ld3(t.geo_n), st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
-          st.ray_o = shading_pos(scene, t, isect.bc, st.ray_d);
-          st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
-          alive = true;
-        } else {
-          const BsdfData data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight, st.wavelength);
-          st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
-          const BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
-          st.sampler.pop_fixed();
+        const uint32_t tri = __float_as_uint(h.w);
+        const bool found = tri != kInvalid;
+        // regular_step, bidirectional.cxx:712-727
+        if ((in_walk == false) && (st.medium != kInvalid)) {
+          ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+          st.throughput *= ms.weight;
+        }
+        const bool first = (st.flags & kBpFirst) != 0u;
+        if (flight_ok == false) {
+          // the walk ended the path
+        } else if (ms.sampled_medium()) {  // handle_medium, :533-570
+          const uint32_t medium_index = in_walk ? walk.medium : st.medium;
+          const DMedium& med = scene.mediums[medium_index];
+          const bool explicit_connections = (in_walk == false) && (med.explicit_connections != 0u);  // subsurface_step passes false (:811)
+          const f2 rnd_bsdf = st.sampler.next_2d();
+          (void)st.sampler.next_2d();
+          (void)st.sampler.next_2d();
+          const f3 w_o = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
+          const float pdf_fwd = phase_function(st.ray_d, w_o, med.g);
+          const float pdf_bck = phase_function(w_o, st.ray_d, med.g);
           st.path_size += 1u;
-          const bool connectible = (bs.properties & kSampleDelta) == 0u;
-          BVtx curr = {isect.pos, isect.nrm, 0.0f, 0.0f,
-            kBvSurface | (connectible ? kBvConnectible : 0u) | ((connectible && (st.prev.flags & kBvConnectible)) ? kBvMisConnectible : 0u), isect.tri};
+          BVtx curr = {ms.pos, mk3(0.0f), 0.0f, 0.0f, kBvMedium | kBvConnectible | ((st.prev.flags & kBvConnectible) ? kBvMisConnectible : 0u), kInvalid};
           curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
-          const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, data, bs.w_o, mat, st.sampler);
-          const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
-          const uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
-          v_pos = isect.pos, v_nrm = isect.nrm, v_wi = isect.w_i, v_throughput = st.throughput, v_flags = curr.flags, v_tri = isect.tri, v_bc_u = isect.bc.y, v_bc_v = isect.bc.z;
-          v_medium = vertex_medium;
-          st.medium = vertex_medium;
-          bool terminate = false;
-          if (bs.valid()) {
-            st.pdf_dir = bs.pdf;
-            st.throughput *= bs.weight;
-            const etx_abi_triangle& t = scene.triangles[isect.tri];
-            st.ray_o = shading_pos(scene, t, isect.bc, bs.w_o);
-            st.ray_d = bs.w_o;
-            st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
-            st.throughput *= fix_shading_normal(ld3(t.geo_n), isect.nrm, isect.w_i, bs.w_o);
-          } else {
-            terminate = true;
+          float prev_from_next = bdpt_to_area(pdf_bck, ms.pos, st.prev);
+          if (first && (st.flags & kBpDistantEmitter)) {  // update_distant_emitter_path_pdfs, :423-436
+            st.prev.from_prev = bdpt_emitter_sample_pdf(scene, scene.emitters[st.flags >> kBpEmitterShift], -st.ray_d);
+            curr.from_prev = st.aux;
           }
-          if (first && (st.flags & kBpDistantEmitter)) {  // update_distant_emitter_path_pdfs
-            st.prev.from_prev = bdpt_emitter_sample_pdf(scene, scene.emitters[st.flags >> kBpEmitterShift], -isect.w_i);
-            curr.from_prev = st.aux * fabsf(dot(isect.w_i, ld3(scene.triangles[isect.tri].geo_n)));
-          }
-          v_from_prev = curr.from_prev;
+          v_pos = ms.pos, v_wi = st.ray_d, v_throughput = st.throughput, v_from_prev = curr.from_prev, v_flags = curr.flags, v_medium = medium_index;
+          if (explicit_connections == false)
+            v_flags |= kBvNoCameraConnection;  // handle_medium skips connect() for it; camera paths still connect TO it
+          st.ray_o = ms.pos, st.ray_d = w_o, st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+          st.pdf_dir = pdf_fwd;
           emitter_vertex = st.prev;
           emitter_from_next = prev_from_next;
-          bdpt_advance_history(st, prev_from_next, false, mode, connectible);
+          bdpt_advance_history(st, prev_from_next, false, mode, true);
           emitter_vertex.history = st.prev.history;
           store_emitter = first, store_vertex = true;
           st.prev = curr;
           st.flags &= ~kBpFirst;
-          alive = (terminate == false) && random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
+          if (in_walk)
+            busy = true;  // no roulette inside the walk (:776-815)
+          else
+            alive = random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
+        } else if (found) {
+          Isect isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
+          if (in_walk)
+            isect.material = scene.subsurface_scatter_material;  // build_path :858-861
+          const etx_abi_material& mat = scene.materials[isect.material];
+          const f2 rnd_bsdf = st.sampler.next_2d();
+          (void)st.sampler.next_2d();
+          const f2 rnd_support = st.sampler.next_2d();
+          if (mat.cls == ETX_MAT_BOUNDARY) {  // handle_surface :586-593: the path length does not change
+            const etx_abi_triangle& t = scene.triangles[isect.tri];
+            st.medium = (dot(ld3(t.geo_n), st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
+            st.ray_o = shading_pos(scene, t, isect.bc, st.ray_d);
+            st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+            alive = true;
+          } else {
+            const BsdfData data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight, st.wavelength);
+            st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
+            BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
+            st.sampler.pop_fixed();
+            uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
+            const bool enter = kWalk && (in_walk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, vertex_medium);
+            const uint32_t vertex_material = enter ? scene.subsurface_scatter_material : isect.material;
+            st.path_size += 1u;
+            const bool connectible = (bs.properties & kSampleDelta) == 0u;
+            BVtx curr = {isect.pos, isect.nrm, 0.0f, 0.0f,
+              kBvSurface | (connectible ? kBvConnectible : 0u) | ((connectible && (st.prev.flags & kBvConnectible)) ? kBvMisConnectible : 0u), isect.tri};
+            curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
+            const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
+            const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
+            v_pos = isect.pos, v_nrm = isect.nrm, v_wi = isect.w_i, v_throughput = st.throughput, v_flags = curr.flags, v_tri = isect.tri, v_bc_u = isect.bc.y, v_bc_v = isect.bc.z;
+            if (enter || in_walk)
+              v_flags |= kBvScatterMaterial;
+            v_medium = vertex_medium;
+            st.medium = vertex_medium;
+            bool terminate = false;
+            if (bs.valid()) {
+              st.pdf_dir = bs.pdf;
+              st.throughput *= bs.weight;
+              const etx_abi_triangle& t = scene.triangles[isect.tri];
+              st.ray_o = shading_pos(scene, t, isect.bc, bs.w_o);
+              st.ray_d = bs.w_o;
+              st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+              st.throughput *= fix_shading_normal(ld3(t.geo_n), isect.nrm, isect.w_i, bs.w_o);
+            } else {
+              terminate = true;
+            }
+            if (first && (st.flags & kBpDistantEmitter)) {  // update_distant_emitter_path_pdfs
+              st.prev.from_prev = bdpt_emitter_sample_pdf(scene, scene.emitters[st.flags >> kBpEmitterShift], -isect.w_i);
+              curr.from_prev = st.aux * fabsf(dot(isect.w_i, ld3(scene.triangles[isect.tri].geo_n)));
+            }
+            v_from_prev = curr.from_prev;
+            emitter_vertex = st.prev;
+            emitter_from_next = prev_from_next;
+            bdpt_advance_history(st, prev_from_next, false, mode, connectible);
+            emitter_vertex.history = st.prev.history;
+            store_emitter = first, store_vertex = true;
+            st.prev = curr;
+            st.flags &= ~kBpFirst;
+            alive = (terminate == false) && random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
+            walk.material = kInvalid;  // a surface vertex ends a walk (:858-861) ...
+            if (enter && alive) {      // ... or starts one: the next sub-steps run here, the path is queued again when it has left the object
+              walk = {isect.material, vertex_medium, 0u};
+              alive = false;
+              busy = true;
+            }
+          }
         }
       }
-    }
-    // pool slots: the emitter vertex (first interaction only), then the new vertex
-    const uint32_t emitter_slot = block_compact_slot(store_emitter, p.counters + kCntLightVertices, s_scratch);
-    const uint32_t vertex_slot = block_compact_slot(store_vertex, p.counters + kCntLightVertices, s_scratch);
-    if (store_emitter)
-      bdpt_store_light_vertex(p, emitter_slot, st.id, emitter_vertex.pos, emitter_vertex.nrm, mk3(0.0f), mk3(0.0f), emitter_vertex.from_prev, emitter_vertex.history, emitter_vertex.flags,
-        emitter_vertex.tri, emitter_from_next, 0.0f, 0u, 1u, kInvalid, kInvalid, st.wavelength, 0u);
-    if (store_vertex) {
-      const uint32_t previous = store_emitter ? emitter_slot : st.prev_slot;
-      Sampler derived;
-      derived.init(st.sampler.seed, 0x62647074u);
-      // history of the new vertex = the path's running history now (dev_bdpt.h)
-      bdpt_store_light_vertex(p, vertex_slot, st.id, v_pos, v_nrm, v_wi, v_throughput, v_from_prev, st.mis_history, v_flags, v_tri, v_bc_u, v_bc_v, st.path_size - 1u, st.path_size, v_medium,
-        previous, st.wavelength, derived.seed);
-      st.prev_slot = vertex_slot;
-    }
+      // pool slots: the emitter vertex (first interaction only), then the new vertex
+      uint32_t emitter_slot = 0u, vertex_slot = 0u;
+      if (walk_pass) {
+        vertex_slot = store_vertex ? atomicAdd(p.counters + kCntLightVertices, 1u) : 0u;
+      } else {
+        emitter_slot = block_compact_slot(store_emitter, p.counters + kCntLightVertices, s_scratch);
+        vertex_slot = block_compact_slot(store_vertex, p.counters + kCntLightVertices, s_scratch);
+      }
+      walk_pass = true;
+      if (store_emitter)
+        bdpt_store_light_vertex(p, emitter_slot, st.id, emitter_vertex.pos, emitter_vertex.nrm, mk3(0.0f), mk3(0.0f), emitter_vertex.from_prev, emitter_vertex.history, emitter_vertex.flags,
+          emitter_vertex.tri, emitter_from_next, 0.0f, 0u, 1u, kInvalid, kInvalid, st.wavelength, 0u);
+      if (store_vertex) {
+        const uint32_t previous = store_emitter ? emitter_slot : st.prev_slot;
+        Sampler derived;
+        derived.init(st.sampler.seed, 0x62647074u);
+        // history of the new vertex = the path's running history now (dev_bdpt.h)
+        bdpt_store_light_vertex(p, vertex_slot, st.id, v_pos, v_nrm, v_wi, v_throughput, v_from_prev, st.mis_history, v_flags, v_tri, v_bc_u, v_bc_v, st.path_size - 1u, st.path_size, v_medium,
+          previous, st.wavelength, derived.seed);
+        st.prev_slot = vertex_slot;
+      }
+    } while (kWalk && busy);
     const uint32_t slot = block_compact_slot(alive, out_counter, s_scratch);
     if (alive)
       bdpt_store(out, slot, st, (st.flags & kBpFirst) ? st.prev.tri : st.prev_slot);
@@ -360,8 +460,11 @@ ETX_DEV float bdpt_direct_hit_weight(const BdptState& st, uint32_t mode, float z
   return 1.0f / (1.0f + bdpt_mis_camera(st.path_size, p_sample, z_curr_from_prev, p_from, st.prev));
 }
 
+template <bool kWalk>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, VcmParams it, uint32_t in_set) {
   __shared__ BlockScratch s_scratch;
+  __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];  // the sub-steps of a subsurface walk traverse inline (k_bdpt_light_shade)
+  const LaneStack stack = {s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize};
   const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const PathSet& out = p.paths[in_set ^ 1u];
@@ -372,30 +475,48 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
   ETX_BLOCK_LOOP(count, i) {
     const bool valid = i < count;
     BdptState st = {};
-    // what the segment did: `created` = a path vertex (curr) exists and becomes prev; `store_vertex` = it is connectible and
-    // goes to the camera vertex pool (the record reads z_prev = st.prev, so prev is replaced AFTER the store)
-    bool alive = false, created = false, store_vertex = false, terminate = false;
-    BVtx curr = {};
-    float4 v_hit = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
-    f3 v_wi = mk3(0.0f), v_throughput = mk3(0.0f), v_rnd = mk3(0.0f);
-    uint32_t v_medium = kInvalid;
+    BdptWalk walk = {kInvalid, kInvalid, 0u};
+    bool busy = valid, alive = false;
+    float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
     if (valid) {
       st = bdpt_load(in, i);
       st.prev.tri = st.prev_slot;  // camera paths carry the previous vertex' triangle there
-      const float4 h = p.hits[i];
+      h = p.hits[i];
+    }
+    bool walk_pass = false;  // as in k_bdpt_light_shade
+    do {
+    // what the (sub-)step did: `created` = a path vertex (curr) exists and becomes prev; `store_vertex` = it is connectible and
+    // goes to the camera vertex pool (the record reads z_prev = st.prev, so prev is replaced AFTER the store)
+    bool created = false, store_vertex = false, terminate = false, enter = false, scatter_vertex = false;
+    BVtx curr = {};
+    float4 v_hit = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
+    f3 v_wi = mk3(0.0f), v_throughput = mk3(0.0f), v_rnd = mk3(0.0f);
+    uint32_t v_medium = kInvalid, enter_material = kInvalid;
+    const bool in_walk = kWalk && (walk.material != kInvalid);
+    const bool stepping = busy;
+    if (busy) {
+      busy = false;
+      MediumSample ms;
+      ms.sampled_medium_t = 0.0f;
+      bool flight_ok = true;
+      if (in_walk) {
+        walk.events += 1u;
+        flight_ok = (walk.events <= 1024u) && bdpt_walk_flight(scene, stack, walk, st, h, ms);  // subsurface_step, :776-812
+      }
       const uint32_t tri = __float_as_uint(h.w);
       const bool found = tri != kInvalid;
       const uint32_t film_target = film_index(it, st.id);
       const f3 film_weight = spectral_film_weight(scene, st.wavelength);
-      MediumSample ms;
-      ms.sampled_medium_t = 0.0f;
-      if (st.medium != kInvalid) {
+      if ((in_walk == false) && (st.medium != kInvalid)) {
         ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
         st.throughput *= ms.weight;
       }
       const bool first = (st.flags & kBpFirst) != 0u;
-      if (ms.sampled_medium()) {  // handle_medium, :533-570
-        const DMedium& med = scene.mediums[st.medium];
+      if (flight_ok == false) {
+        // the walk ended the path
+      } else if (ms.sampled_medium()) {  // handle_medium, :533-570
+        const uint32_t medium_index = in_walk ? walk.medium : st.medium;
+        const DMedium& med = scene.mediums[medium_index];
         f2 rnd_bsdf = st.sampler.next_2d();
         f2 rnd_em = st.sampler.next_2d();
         f2 rnd_support = st.sampler.next_2d();
@@ -408,15 +529,18 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
         curr = {ms.pos, mk3(0.0f), 0.0f, 0.0f, kBvMedium | kBvConnectible | ((st.prev.flags & kBvConnectible) ? kBvMisConnectible : 0u), kInvalid};
         curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
         const float prev_from_next = bdpt_to_area(pdf_bck, ms.pos, st.prev);
-        v_hit = mk4(ms.pos, __uint_as_float(kInvalid)), v_wi = st.ray_d, v_throughput = st.throughput, v_medium = st.medium;
+        v_hit = mk4(ms.pos, __uint_as_float(kInvalid)), v_wi = st.ray_d, v_throughput = st.throughput, v_medium = medium_index;
         v_rnd = {rnd_em.x, rnd_em.y, rnd_support.y};
         st.ray_o = ms.pos, st.ray_d = w_o, st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
         st.pdf_dir = pdf_fwd;
         bdpt_advance_history(st, prev_from_next, true, mode, true);
         created = true;
-        store_vertex = (med.explicit_connections != 0u) && (mode != kBdptLightTracing);
+        store_vertex = (in_walk == false) && (med.explicit_connections != 0u) && (mode != kBdptLightTracing);  // subsurface_step: no explicit connections (:811)
       } else if (found) {
-        const Isect isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
+        Isect isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
+        if (in_walk)
+          isect.material = scene.subsurface_scatter_material;  // build_path :858-861
+        scatter_vertex = in_walk;
         const etx_abi_material& mat = scene.materials[isect.material];
         f2 rnd_bsdf = st.sampler.next_2d();
         f2 rnd_em = st.sampler.next_2d();
@@ -437,16 +561,20 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
             st.flags |= kBpGBuffer;
           }
           st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
-          const BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
+          BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
           st.sampler.pop_fixed();
+          uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
+          enter = kWalk && (in_walk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, vertex_medium);
+          scatter_vertex = scatter_vertex || enter;
+          enter_material = isect.material;
+          const uint32_t vertex_material = enter ? scene.subsurface_scatter_material : isect.material;
           st.path_size += 1u;
           const bool connectible = (bs.properties & kSampleDelta) == 0u;
           curr = {isect.pos, isect.nrm, 0.0f, 0.0f, kBvSurface | (connectible ? kBvConnectible : 0u) | ((connectible && (st.prev.flags & kBvConnectible)) ? kBvMisConnectible : 0u),
             isect.tri};
           curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
-          const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, data, bs.w_o, mat, st.sampler);
+          const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
           const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
-          const uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
           const f3 vertex_throughput = st.throughput;
           const float prev_sampled_pdf = st.aux;  // z_prev.pdf.bsdf_sample_next (PathTracing mode weights)
           st.medium = vertex_medium;
@@ -539,18 +667,32 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
         film_add(p, p.normal_sum + film_target, f3{0.0f, 0.0f, 1.0f});
       }
     }
-    const uint32_t vertex_slot = block_compact_slot(store_vertex, p.counters + kCntCameraVertices, s_scratch);
+    const uint32_t vertex_slot = walk_pass ? (store_vertex ? atomicAdd(p.counters + kCntCameraVertices, 1u) : 0u) : block_compact_slot(store_vertex, p.counters + kCntCameraVertices, s_scratch);
+    walk_pass = true;
     if (store_vertex) {
       Sampler derived;
       derived.init(st.sampler.seed, 0x51ed270bu);
-      bdpt_store_camera_vertex(p, vertex_slot, st, v_hit, v_wi, v_medium, v_throughput, curr.from_prev, v_rnd, derived.seed);
+      bdpt_store_camera_vertex(p, vertex_slot, st, v_hit, v_wi, v_medium, v_throughput, curr.from_prev, v_rnd, derived.seed, scatter_vertex);
     }
     if (created) {  // build_path: prev = curr at the top of the next iteration, then the roulette of this interaction (:890-895)
       st.prev = curr;
       st.flags &= ~kBpFirst;
       st.aux = st.pdf_dir;  // becomes z_prev.pdf.bsdf_sample_next
-      alive = (terminate == false) && random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
+      if (in_walk && (curr.flags & kBvMedium)) {
+        busy = true;  // a scattering event inside the object: no roulette, the walk goes on (subsurface_step :776-815)
+      } else {
+        const bool goes_on = (terminate == false) && random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
+        walk.material = kInvalid;  // a surface vertex ends a walk ...
+        if (enter && goes_on) {    // ... or starts one: its sub-steps run here, the path is queued again when it has left the object
+          walk = {enter_material, st.medium, 0u};
+          busy = true;
+        } else {
+          alive = goes_on;
+        }
+      }
     }
+    (void)stepping;
+    } while (kWalk && busy);
     const uint32_t slot = block_compact_slot(alive, out_counter, s_scratch);
     if (alive)
       bdpt_store(out, slot, st, st.prev.tri);
@@ -561,7 +703,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_light(Pipeline p, VcmParams it) {
   __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
-  const uint32_t count = min(p.counters[kCntCameraVertices], p.capacity);
+  const uint32_t count = min(p.counters[kCntCameraVertices], p.cv_capacity);
   const uint32_t mode = bdpt_mode(it);
   ETX_BLOCK_LOOP(count, i) {
     ShadowRequest request;
@@ -630,7 +772,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs(Pipeline p, V
       const uint2 pair = p.pairs[i];
       const uint32_t y_flags = __float_as_uint(p.lv.thr_dvm(pair.y).w);
       const uint32_t light_s = __float_as_uint(p.lv.bc_len_med(pair.y).z) >> 16u;
-      const uint32_t camera_path_size = __float_as_uint(p.cv.thr_depth[pair.x].w);
+      const uint32_t camera_path_size = __float_as_uint(p.cv.thr_depth[pair.x].w) & ~kCvExitMaterialBit;
       const uint32_t target_path_length = (camera_path_size - 1u) + light_s + 1u;
       if ((light_s >= 1u) && (y_flags & kBvConnectible) && (target_path_length >= scene.min_path_length) && (target_path_length <= scene.max_path_length)) {
         const BdptCameraVertex z = bdpt_load_camera_vertex(p, scene, pair.x);
@@ -674,8 +816,11 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs(Pipeline p, V
 void launch_bdpt_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
   hipLaunchKernelGGL(k_bdpt_light_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
 }
-void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
-  hipLaunchKernelGGL(k_bdpt_light_shade, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
+void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool subsurface) {
+  if (subsurface)
+    hipLaunchKernelGGL(k_bdpt_light_shade<true>, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
+  else
+    hipLaunchKernelGGL(k_bdpt_light_shade<false>, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
 }
 void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
   hipLaunchKernelGGL(k_bdpt_connect_camera, dim3(max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 2ull, uint64_t(p.lv.capacity)))))), dim3(kBlockSize), 0, stream, p, it);
@@ -683,8 +828,11 @@ void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const Vcm
 void launch_bdpt_camera_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
   hipLaunchKernelGGL(k_bdpt_camera_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
 }
-void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
-  hipLaunchKernelGGL(k_bdpt_camera_shade, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
+void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool subsurface) {
+  if (subsurface)
+    hipLaunchKernelGGL(k_bdpt_camera_shade<true>, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
+  else
+    hipLaunchKernelGGL(k_bdpt_camera_shade<false>, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
 }
 void launch_bdpt_connect_light(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
   hipLaunchKernelGGL(k_bdpt_connect_light, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it);

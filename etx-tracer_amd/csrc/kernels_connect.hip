@@ -29,6 +29,9 @@ ETX_DEV bool material_is_diffuse(const DScene& scene, uint32_t tri) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // (camera vertex, light path) -> pairs
+// kVcmRecords: the camera vertex records are VCM's (pos_info.w holds kCv* flags); the bidirectional kernels keep the previous
+// vertex' flags in that word (dev_bdpt.h)
+template <bool kVcmRecords>
 __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmParams it) {
   __shared__ uint32_t s_wave_total[kBlockSize / 64u];
   __shared__ uint32_t s_base;
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmPara
     uint32_t head = kInvalid, k = 0, path = 0;
     if (i < count) {
       path = __float_as_uint(p.cv.mis_pixel[i].w);
-      head = (__float_as_uint(p.cv.pos_info[i].w) & kCvNoConnect) ? kInvalid : p.light_path_head[path];  // merge-only record of a Christensen-Burley vertex
+      head = (kVcmRecords && (__float_as_uint(p.cv.pos_info[i].w) & kCvNoConnect)) ? kInvalid : p.light_path_head[path];  // merge-only record of a Christensen-Burley vertex
       // the head vertex knows its index in the path (store_light_vertex), so the path length needs no extra table
       k = (head == kInvalid) ? 0u : ((__float_as_uint(p.lv.bc_len_med(head).z) >> 16u) + 1u);
     }
@@ -165,14 +168,14 @@ void launch_connect_endpoints(hipStream_t stream, const Pipeline& p, const VcmPa
 }
 
 void launch_expand_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
-  hipLaunchKernelGGL(k_expand_pairs, dim3(max(1u, grid_for(min(max_items, p.capacity)))), dim3(kBlockSize), 0, stream, p, it);
+  hipLaunchKernelGGL(k_expand_pairs<false>, dim3(max(1u, grid_for(min(max_items, p.capacity)))), dim3(kBlockSize), 0, stream, p, it);  // bidirectional records
 }
 
 void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items) {
   max_items = min(max_items, p.capacity);
   const uint32_t blocks = max(1u, grid_for(max_items));
   const uint32_t pair_blocks = max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 8ull, uint64_t(p.pair_capacity)))));
-  hipLaunchKernelGGL(k_expand_pairs, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
+  hipLaunchKernelGGL(k_expand_pairs<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
   hipLaunchKernelGGL(k_connect_pairs<true>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
   if (generic_materials)
     hipLaunchKernelGGL(k_connect_pairs<false>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);

@@ -85,6 +85,10 @@ def main():
                 if mode != "0":  # PathTracing mode has no light path to correlate with
                     render(snapshot, "bdpt", args.spp, os.path.join(HI, "cornell_%s_128_bdpt%s_%d_rekeyed.npz" % (flavour, mode, args.spp)), args.cores,
                            env_extra={"ETX_ORACLE_DECORRELATE": "2"}, extra=opts)
+        if ("bdpt-novc" in integrators) and (flavour == "sss"):
+            # BDPTFull without vertex connections on the subsurface box (tests/test_gpu_bdpt.py)
+            render(snapshot, "bdpt", args.spp, os.path.join(HI, "cornell_sss_128_bdpt3_%d_novc_rekeyed.npz" % args.spp), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "2"},
+                   extra=["--opt", "bdpt-blue_noise=false", "--opt", "bdpt-mode=3", "--opt", "bdpt-conn_connect_vertices=false"])
         if "pt" in integrators:
             # --noise-threshold 0: every pixel gets all samples (the scenes carry Scene::noise_threshold = 0.1, with which
             # CPUPathTracing stops sampling converged pixels after 32 samples: a "4096-spp" film would hold ~100-spp noise)

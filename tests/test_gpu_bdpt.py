@@ -80,13 +80,36 @@ def test_bdpt_single_technique_modes(etx, golden_dir, mode):
         compare((light_a, light_b), golden["light"], "full bdpt mode LightTracing light", mean_limit=1.0e-2, bias_p99_limit=0.2)
 
 
-def test_bdpt_rejects_what_it_does_not_implement(etx, golden_dir):
-    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_sss_128.etxscene"))
-    integ = etx.HIPBidirectional(snap)
-    integ.options().update({"bdpt-mode": etx.api.BDPT_MODE_FULL})
-    with pytest.raises(etx.EtxHipError, match="subsurface"):
-        integ.run()
-    integ.context.close()
+@pytest.mark.parametrize("mode", [2, 3])
+def test_bdpt_subsurface_walk_matches_reference(etx, golden_dir, mode):
+    """configs[3] family: subsurface materials under the bidirectional integrator. The reference threads the walk through the path
+    (bidirectional.cxx:610-633 entry vertex with the scatter material, :746-818 one medium vertex per scattering event, :858-861 exit
+    vertex); the device runs the walk's sub-steps inside the shade kernels (kernels_bdpt.hip BdptWalk). BDPTFull and BDPTFast, 256 spp (a walk is a serial chain of material-filtered traversals per lane: 65 ms per iteration at 128 x 128)."""
+    if mode == 3:
+        # BDPTFull: the vertex connections onto subsurface objects are not at parity yet (~40 % low there, -1 % of the image) and are
+        # refused; everything else of that mode is compared with the reference rendered with the same switch off
+        snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_sss_128.etxscene"))
+        integ = etx.HIPBidirectional(snap)
+        integ.options().update({"bdpt-mode": 3, "bdpt-blue_noise": False})
+        with pytest.raises(etx.EtxHipError, match="BDPTFull"):
+            integ.run()
+        integ.context.close()
+        (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, "sss", 256, {"bdpt-mode": 3, "bdpt-blue_noise": False, "bdpt-conn_connect_vertices": False})
+        golden = load(golden_dir, "cornell_sss_128_bdpt3_256_novc_rekeyed.npz")
+        compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "sss bdpt full without vertex connections (independent streams)", rmse_limit=1.5e-3)
+        return
+    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, "sss", 256, {"bdpt-mode": mode, "bdpt-blue_noise": False})
+    golden = load(golden_dir, "cornell_sss_128_bdpt%d_256_rekeyed.npz" % mode)
+    assert int(golden["spp"]) in (255, 256)
+    label = "sss bdpt mode %d " % mode
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], label + "camera+light (independent streams)", rmse_limit=1.5e-3)
+    compare((light_a, light_b), golden["light"], label + "light (independent streams)", rmse_limit=1.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.2)
+    compare((cam_a, cam_b), golden["camera"], label + "camera (independent streams)", rmse_limit=1.5e-3)
+    golden = load(golden_dir, "cornell_sss_128_bdpt%d_256.npz" % mode)
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], label + "camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
+
+
+def test_bdpt_rejects_what_it_does_not_implement(etx, golden_dir, cie_observer):
     snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_classic_128.etxscene"))
     integ = etx.HIPBidirectional(snap)
     integ.options().update({"bdpt-mode": 7})

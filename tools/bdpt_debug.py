@@ -5,10 +5,10 @@ etx = importlib.import_module("etx-tracer_amd")
 G = "tests/golden"
 def bm(x, b=8):
     h, w = x.shape[:2]; return x[..., :3].reshape(h//b, b, w//b, b, 3).mean(axis=(1, 3))
-for flavour in ["classic", "full", "cloud", "glass"]:
+for flavour in (sys.argv[1:] or ["classic", "full", "cloud", "glass"]):
     ref = np.load(os.path.join(G, "hi", "cornell_%s_128_vcm_4096_rekeyed.npz" % flavour))
     total = ref["camera"] + ref["light"]
-    for mode in (2,):
+    for mode in (3, 2, 0, 1):
         snap = etx.SceneSnapshot(os.path.join(G, "cornell_%s_128.etxscene" % flavour)); snap.samples = 1024
         integ = etx.HIPBidirectional(snap); integ.options().update({"bdpt-mode": mode, "bdpt-blue_noise": False})
         try:
