@@ -4,7 +4,7 @@ the assembly hipcc emits for one translation unit of etx-tracer_amd/csrc:
 
     python3 tools/kernel_resources.py kernels_shade_camera_general.hip [more.hip ...] [--json out.json]
 
-Used by tests/test_build_budget.py: no kernel may exceed 256 registers or spill VGPRs."""
+Used by tests/test_build_budget.py (register budget of the bench-path and general-material kernels)."""
 import json
 import os
 import re
