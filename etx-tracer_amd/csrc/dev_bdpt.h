@@ -264,6 +264,7 @@ ETX_DEV void bdpt_store_light_vertex(const Pipeline& p, uint32_t idx, uint32_t p
   if (index_in_path < kPathTableEntries)
     reinterpret_cast<uint32_t*>(p.light_path_table)[path * kPathTableEntries + index_in_path] = idx;
   p.light_path_head[path] = idx;
+  p.light_path_len[path] = index_in_path + 1u;
 }
 
 struct BdptLightVertex {

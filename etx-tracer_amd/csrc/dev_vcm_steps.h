@@ -26,6 +26,7 @@ ETX_DEV void store_light_vertex(const Pipeline& p, uint32_t idx, const PathState
   if (index_in_path < kPathTableEntries)
     reinterpret_cast<uint32_t*>(p.light_path_table)[st.id * kPathTableEntries + index_in_path] = idx;
   p.light_path_head[st.id] = idx;  // the photon bounding box is reduced by k_grid_bbox (kernels_grid.hip)
+  p.light_path_len[st.id] = index_in_path + 1u;
 }
 
 

@@ -212,7 +212,7 @@ int allocate_pipeline(etx_hip_context* ctx) {
   const uint32_t cvn = p.cv_capacity;
   if ((rc = device_alloc(ctx, p.path_wavelength, n)) || (rc = device_alloc(ctx, p.cv.wavelength, cvn)))
     return rc;
-  if ((rc = device_alloc(ctx, p.light_path_head, n)) || (rc = device_alloc(ctx, p.light_path_table, size_t(n) * (kPathTableEntries / 4u))))
+  if ((rc = device_alloc(ctx, p.light_path_head, n)) || (rc = device_alloc(ctx, p.light_path_len, n)) || (rc = device_alloc(ctx, p.light_path_table, size_t(n) * (kPathTableEntries / 4u))))
     return rc;
   p.grid.hash_capacity = next_pow2(p.lv.capacity);
   if ((rc = device_alloc(ctx, p.grid.cell_ends, p.grid.hash_capacity)) || (rc = device_alloc(ctx, p.grid.pos_len, p.lv.capacity)) ||

@@ -41,9 +41,9 @@ __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmPara
     uint32_t head = kInvalid, k = 0, path = 0;
     if (i < count) {
       path = __float_as_uint(p.cv.mis_pixel[i].w);
-      head = (kVcmRecords && (__float_as_uint(p.cv.pos_info[i].w) & kCvNoConnect)) ? kInvalid : p.light_path_head[path];  // merge-only record of a Christensen-Burley vertex
-      // the head vertex knows its index in the path (store_light_vertex), so the path length needs no extra table
-      k = (head == kInvalid) ? 0u : ((__float_as_uint(p.lv.bc_len_med(head).z) >> 16u) + 1u);
+      const bool skip = kVcmRecords && (__float_as_uint(p.cv.pos_info[i].w) & kCvNoConnect);  // merge-only record of a Christensen-Burley vertex
+      head = skip ? kInvalid : p.light_path_head[path];
+      k = skip ? 0u : p.light_path_len[path];  // independent of the head load (the head record sits somewhere in a 0.8 GB pool)
     }
     // workgroup exclusive prefix sum of k: wave scan, then one reservation for all four waves
     uint32_t incl = k;

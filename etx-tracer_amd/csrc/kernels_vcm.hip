@@ -40,8 +40,10 @@ __global__ __launch_bounds__(kBlockSize) void k_iteration_reset(Pipeline p) {
   }
   if (tid < kBlockStatRows * kBlockStatCount)
     p.block_stats[tid] = 0ull;
-  for (uint32_t i = tid; i < p.capacity; i += stride)
+  for (uint32_t i = tid; i < p.capacity; i += stride) {
     p.light_path_head[i] = kInvalid;
+    p.light_path_len[i] = 0u;
+  }
 }
 
 void launch_iteration_reset(hipStream_t stream, const Pipeline& p) {

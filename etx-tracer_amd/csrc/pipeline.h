@@ -198,6 +198,7 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   float4* hits;          // hit queue, aligned with the "in" path set
   LightVertexPool lv;
   uint32_t* light_path_head;   // per path: last stored vertex (kInvalid = none)
+  uint32_t* light_path_len;    // per path: stored vertices so far (k_expand_pairs sizes a camera vertex' pair run with it: no dependent read of the head record)
   float* path_wavelength;      // spectral mode: wavelength of light path i, reused by camera path i (vcm_cpu.cxx:186)
   uint4* light_path_table;     // per path: its first kPathTableEntries vertices by index in path (expand_pairs reads them
                                // with two independent loads instead of walking the list from the head)
