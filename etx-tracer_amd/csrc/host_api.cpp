@@ -1103,13 +1103,6 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
                        "does that for untextured RGB parameters only (spectral scenes, textured scattering colour / distances: use VCM or path tracing)";
       return ETX_HIP_ERROR_UNSUPPORTED;
     }
-    if (context->scene.has_subsurface && (mode == ETX_BDPT_MODE_FULL) && context->bdpt_options.connect_vertices) {
-      // measured against CPUBidirectional on the subsurface box: light image, next event estimation and direct hits agree (BDPTFast and
-      // BDPTFull without vertex connections match to 0.1 %), the vertex connections onto the subsurface objects come out ~40 % low
-      context->error = "bidirectional integrator, mode BDPTFull with vertex connections on a scene with subsurface materials: not at parity with the reference yet "
-                       "(use bdpt-mode BDPTFast - the reference's default -, or bdpt-conn_connect_vertices=false)";
-      return ETX_HIP_ERROR_UNSUPPORTED;
-    }
     context->active_bluenoise = nullptr;
     if (context->bdpt_options.blue_noise) {
       int rc = select_bluenoise(context, "bdpt-blue_noise");

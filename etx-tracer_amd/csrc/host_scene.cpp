@@ -684,19 +684,10 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   // else leaves the material without an entry and etx_hip_begin refuses the scene for that integrator.
   std::vector<uint32_t> sss_medium(material_table.size(), kInvalid);
   out.sss_media_complete = true;
-  for (uint64_t i = 0; i < scene->materials.count; ++i) {
-    const etx_abi_material& m = material_table[i];
-    if ((used[i] == false) || (m.subsurface.cls == 0u))
-      continue;
-    if (m.int_medium < scene->mediums.count) {
-      sss_medium[i] = m.int_medium;
-      continue;
-    }
+  auto derive_medium = [&](const etx_abi_material& m) -> uint32_t {
     const bool textured = (m.scattering.image_index != ETX_ABI_INVALID) || (m.subsurface.image_index != ETX_ABI_INVALID);
-    if (spectral || textured || (m.scattering.spectrum_index >= scene->spectrums.count) || (m.subsurface.spectrum_index >= scene->spectrums.count)) {
-      out.sss_media_complete = false;
-      continue;
-    }
+    if (spectral || textured || (m.scattering.spectrum_index >= scene->spectrums.count) || (m.subsurface.spectrum_index >= scene->spectrums.count))
+      return kInvalid;
     const f3 color = a3(spectrums[m.scattering.spectrum_index].integrated), distances = a3(spectrums[m.subsurface.spectrum_index].integrated);
     auto remap = [](float colour, float distance, float& extinction, float& scattering) {
       const float a = 1.826052378200f, b = 4.985111943850f + 0.12735595943800f, cc = 1.096861024240f;
@@ -716,8 +707,31 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     dm.absorption = extinction - scattering, dm.scattering = scattering;
     dm.absorption_index = dm.scattering_index = kInvalid;
     dm.cls = 0u, dm.explicit_connections = 0u, dm.g = 0.0f;
-    sss_medium[i] = uint32_t(dmediums.size());
     dmediums.push_back(dm);
+    return uint32_t(dmediums.size() - 1u);
+  };
+  bool any_derived = false;
+  for (uint64_t i = 0; i < scene->materials.count; ++i) {
+    const etx_abi_material& m = material_table[i];
+    if ((used[i] == false) || (m.subsurface.cls == 0u))
+      continue;
+    if (m.int_medium < scene->mediums.count) {
+      sss_medium[i] = m.int_medium;
+      continue;
+    }
+    sss_medium[i] = derive_medium(m);
+    any_derived = true;
+    if (sss_medium[i] == kInvalid)
+      out.sss_media_complete = false;
+  }
+  // The ENTRY vertex of such a walk carries a medium of its own: handle_surface (bidirectional.cxx:629-633) swaps material_index for
+  // scene.subsurface_scatter_material BEFORE it derives the instance, so the extinction a connection from that vertex is attenuated
+  // with comes from the scatter material's parameters (white, and validate_materials' default distances {1, 0.2, 0.04},
+  // scene_representation.cxx:270-272), not from the object's. The device keeps that: the scatter material gets an entry too.
+  if (any_derived && (scene->subsurface_scatter_material < scene->materials.count)) {
+    sss_medium[scene->subsurface_scatter_material] = derive_medium(material_table[scene->subsurface_scatter_material]);
+    if (sss_medium[scene->subsurface_scatter_material] == kInvalid)
+      out.sss_media_complete = false;
   }
   if ((rc = upload(out, dmediums.data(), dmediums.size(), d.mediums, error)) || (rc = upload(out, sss_medium.data(), sss_medium.size(), d.material_sss_medium, error)))
     return rc;

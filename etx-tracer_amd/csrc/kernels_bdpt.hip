@@ -137,17 +137,24 @@ ETX_DEV bool bdpt_walk_flight(const DScene& scene, const LaneStack& stack, const
 }
 
 // handle_surface :610-633: a diffuse reflection off a subsurface material enters the object instead (the vertex gets the scatter
-// material, the walk's medium, and a cosine lobe into the object or the incoming direction as its sampled direction)
-ETX_DEV bool bdpt_enter_subsurface(const DScene& scene, const etx_abi_material& mat, const Isect& isect, BsdfSample& bs, Sampler& smp, uint32_t& vertex_medium) {
+// material and a cosine lobe into the object or the incoming direction as its sampled direction). Three media leave here:
+// walk_medium, the one the walk flies through (subsurface_step derives it from the object's material, :757-771); vertex_medium, the
+// instance the entry VERTEX keeps for the transmittance of its connections - the interior medium, or, without one, the instance
+// :632 derives from the SCATTER material (material_index was swapped at :630), an entry host_scene.cpp builds for that material;
+// and the path's medium index, which is the interior medium or none (:670 payload.medium_index = medium_instance.index).
+ETX_DEV bool bdpt_enter_subsurface(const DScene& scene, const etx_abi_material& mat, const Isect& isect, BsdfSample& bs, Sampler& smp, uint32_t& vertex_medium,
+  uint32_t& walk_medium, uint32_t& path_medium) {
   if ((mat.subsurface.cls == 0u) || ((bs.properties & kSampleReflection) == 0u) || ((bs.properties & kSampleDiffuse) == 0u))
     return false;
   const f3 w_o = (mat.subsurface.path == 0u) ? sample_cosine_distribution(smp.next_2d(), -isect.nrm, 1.0f) : isect.w_i;
-  vertex_medium = scene.material_sss_medium[isect.material];
+  walk_medium = scene.material_sss_medium[isect.material];
+  path_medium = (walk_medium == mat.int_medium) ? walk_medium : kInvalid;
+  vertex_medium = (walk_medium == mat.int_medium) ? walk_medium : scene.material_sss_medium[scene.subsurface_scatter_material];
   bs.w_o = w_o;
   bs.weight = mk3(1.0f);
   bs.pdf = fabsf(dot(w_o, isect.nrm)) / kPi;
   bs.eta = 1.0f;
-  bs.medium_index = vertex_medium;
+  bs.medium_index = path_medium;
   bs.properties = kSampleTransmission | kSampleDiffuse | kSampleMediumChanged;
   return true;
 }
@@ -262,7 +269,8 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
             BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
             st.sampler.pop_fixed();
             uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
-            const bool enter = kWalk && (in_walk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, vertex_medium);
+            uint32_t walk_medium = kInvalid, path_medium = vertex_medium;
+            const bool enter = kWalk && (in_walk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, vertex_medium, walk_medium, path_medium);
             const uint32_t vertex_material = enter ? scene.subsurface_scatter_material : isect.material;
             st.path_size += 1u;
             const bool connectible = (bs.properties & kSampleDelta) == 0u;
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
             if (enter || in_walk)
               v_flags |= kBvScatterMaterial;
             v_medium = vertex_medium;
-            st.medium = vertex_medium;
+            st.medium = path_medium;
             bool terminate = false;
             if (bs.valid()) {
               st.pdf_dir = bs.pdf;
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
             alive = (terminate == false) && random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
             walk.material = kInvalid;  // a surface vertex ends a walk (:858-861) ...
             if (enter && alive) {      // ... or starts one: the next sub-steps run here, the path is queued again when it has left the object
-              walk = {isect.material, vertex_medium, 0u};
+              walk = {isect.material, walk_medium, 0u};
               alive = false;
               busy = true;
             }
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
     BVtx curr = {};
     float4 v_hit = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
     f3 v_wi = mk3(0.0f), v_throughput = mk3(0.0f), v_rnd = mk3(0.0f);
-    uint32_t v_medium = kInvalid, enter_material = kInvalid;
+    uint32_t v_medium = kInvalid, enter_material = kInvalid, enter_medium = kInvalid;
     const bool in_walk = kWalk && (walk.material != kInvalid);
     const bool stepping = busy;
     if (busy) {
@@ -564,7 +572,8 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
           BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
           st.sampler.pop_fixed();
           uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
-          enter = kWalk && (in_walk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, vertex_medium);
+          uint32_t path_medium = vertex_medium;
+          enter = kWalk && (in_walk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, vertex_medium, enter_medium, path_medium);
           scatter_vertex = scatter_vertex || enter;
           enter_material = isect.material;
           const uint32_t vertex_material = enter ? scene.subsurface_scatter_material : isect.material;
@@ -577,7 +586,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
           const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
           const f3 vertex_throughput = st.throughput;
           const float prev_sampled_pdf = st.aux;  // z_prev.pdf.bsdf_sample_next (PathTracing mode weights)
-          st.medium = vertex_medium;
+          st.medium = path_medium;
           if (bs.valid()) {
             st.eta *= bs.eta;
             st.pdf_dir = bs.pdf;
@@ -684,7 +693,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
         const bool goes_on = (terminate == false) && random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
         walk.material = kInvalid;  // a surface vertex ends a walk ...
         if (enter && goes_on) {    // ... or starts one: its sub-steps run here, the path is queued again when it has left the object
-          walk = {enter_material, st.medium, 0u};
+          walk = {enter_material, enter_medium, 0u};
           busy = true;
         } else {
           alive = goes_on;
