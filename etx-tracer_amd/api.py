@@ -23,7 +23,7 @@ VCM_FULL_OPTIONS = 0x7F
 EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene",
     "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_upload_rgb_response", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
-    "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
+    "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_checkpoint_bytes", "etx_hip_checkpoint_save", "etx_hip_checkpoint_load", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
 )
 
@@ -173,6 +173,10 @@ class Library:
         L.etx_hip_read_film.argtypes = [vp, i32, vp, sz]
         L.etx_hip_read_film_begin.argtypes = [vp, i32]
         L.etx_hip_read_film_end.argtypes = [vp, vp, sz, i32]
+        L.etx_hip_checkpoint_bytes.argtypes = [vp]
+        L.etx_hip_checkpoint_bytes.restype = sz
+        L.etx_hip_checkpoint_save.argtypes = [vp, vp, sz]
+        L.etx_hip_checkpoint_load.argtypes = [vp, vp, sz]
         L.etx_hip_stats.argtypes = [vp, ctypes.POINTER(Stats), sz]
         L.etx_hip_set_timers.argtypes = [vp, u32]
         L.etx_hip_comm_unique_id.argtypes = [vp]
@@ -288,6 +292,20 @@ class Context:
         out = np.empty((h, w, 4), dtype=np.float32)
         rc = self._check(self.library.lib.etx_hip_read_film_end(self.handle, out.ctypes.data, out.nbytes, 1 if wait else 0))
         return out if rc == 1 else None
+
+    def checkpoint_save(self):
+        """-> bytes: the film state of the render in progress (etx_hip_checkpoint_save; waits for the iterations in flight)."""
+        size = self.library.lib.etx_hip_checkpoint_bytes(self.handle)
+        if size == 0:
+            raise EtxHipError(-1, "checkpoint_save: call begin() first")
+        buffer = np.empty(size, dtype=np.uint8)
+        self._check(self.library.lib.etx_hip_checkpoint_save(self.handle, buffer.ctypes.data, buffer.nbytes))
+        return buffer.tobytes()
+
+    def checkpoint_load(self, blob):
+        """After begin() with the same integrator, options and sharding: continue the saved render (etx_hip_checkpoint_load)."""
+        buffer = np.frombuffer(blob, dtype=np.uint8)
+        self._check(self.library.lib.etx_hip_checkpoint_load(self.handle, buffer.ctypes.data, buffer.nbytes))
 
     def stats(self):
         s = Stats()

@@ -1378,6 +1378,133 @@ int etx_hip_read_film_end(etx_hip_context* context, float* dst_rgba, size_t dst_
   return 1;
 }
 
+namespace {
+// Film state of a render in progress (etx_hip_checkpoint_*): this header, the four float4 sum layers (camera with the per-pixel
+// sample count in w, light, normal, albedo), and for an adaptive run the even-sample sums and the pixel states.
+struct CheckpointHeader {
+  uint32_t magic, version, integrator, width, height, first_iteration, iteration_stride, next_iteration;
+  uint32_t local_iterations, adaptive, options_hash, last_active_pixels, reserved[4];
+};
+static_assert(sizeof(CheckpointHeader) == 64, "checkpoint header layout");
+constexpr uint32_t kCheckpointMagic = 0x43585445u;  // "ETXC"
+constexpr uint32_t kCheckpointVersion = 1u;
+
+// the named fields only: the padding of the by-value option structs is whatever the caller's stack held
+uint32_t options_hash(const etx_hip_context* c) {
+  uint32_t h = 2166136261u;  // FNV-1a
+  auto mix = [&h](uint32_t v) {
+    for (uint32_t i = 0; i < 4u; ++i)
+      h = (h ^ ((v >> (8u * i)) & 0xffu)) * 16777619u;
+  };
+  if (c->integrator == ETX_HIP_INTEGRATOR_PT) {
+    const auto& o = c->pt_options;
+    mix(o.path_per_iteration), mix(o.nee != 0), mix(o.direct != 0), mix(o.mis != 0), mix(o.blue_noise != 0);
+  } else if (c->integrator == ETX_HIP_INTEGRATOR_BDPT) {
+    const auto& o = c->bdpt_options;
+    mix(o.mode), mix(o.direct_hit != 0), mix(o.connect_to_camera != 0), mix(o.connect_to_light != 0), mix(o.connect_vertices != 0), mix(o.mis != 0), mix(o.blue_noise != 0);
+  } else {
+    const auto& o = c->vcm_options;
+    uint32_t radius_bits = 0;
+    memcpy(&radius_bits, &o.initial_radius, sizeof(radius_bits));
+    mix(o.options), mix(o.radius_decay), mix(o.kernel), mix(radius_bits), mix(o.blue_noise != 0);
+  }
+  return h;
+}
+
+size_t checkpoint_bytes(const etx_hip_context* c) {
+  const size_t n = c->pipe.capacity;
+  return sizeof(CheckpointHeader) + n * kFilmLayers * sizeof(float4) + ((c->pipe.pixel_state != nullptr) ? n * (sizeof(float4) + sizeof(uint32_t)) : 0u);
+}
+}  // namespace
+
+size_t etx_hip_checkpoint_bytes(const etx_hip_context* context) {
+  return ((context == nullptr) || (context->armed == false)) ? 0u : checkpoint_bytes(context);
+}
+
+int etx_hip_checkpoint_save(etx_hip_context* context, void* dst, size_t dst_bytes) {
+  if ((context == nullptr) || (dst == nullptr))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  if ((context->armed == false) || context->reduced) {
+    context->error = "etx_hip_checkpoint_save: between etx_hip_begin and etx_hip_reduce_film only (a checkpoint holds this rank's own sums)";
+    return ETX_HIP_ERROR_STATE;
+  }
+  if (dst_bytes != checkpoint_bytes(context)) {
+    context->error = "etx_hip_checkpoint_save: dst_bytes must be etx_hip_checkpoint_bytes()";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  if (int rc = wait_idle(context))
+    return rc;
+  HIP_OK(context, hipSetDevice(context->device));
+  const size_t n = context->pipe.capacity;
+  CheckpointHeader header = {};
+  header.magic = kCheckpointMagic, header.version = kCheckpointVersion, header.integrator = uint32_t(context->integrator);
+  header.width = context->scene.film_w, header.height = context->scene.film_h;
+  header.first_iteration = context->first_iteration, header.iteration_stride = context->iteration_stride;
+  header.next_iteration = context->next_iteration, header.local_iterations = context->local_iterations;
+  header.adaptive = (context->pipe.pixel_state != nullptr) ? 1u : 0u;
+  header.options_hash = options_hash(context);
+  {
+    std::lock_guard<std::mutex> lock(context->shared_mutex);
+    header.last_active_pixels = context->totals.last_active_pixels;  // the path tracer's host stops on "the last iteration sampled no pixel"
+  }
+  uint8_t* out = static_cast<uint8_t*>(dst);
+  memcpy(out, &header, sizeof(header));
+  out += sizeof(header);
+  HIP_OK(context, hipMemcpyAsync(out, context->pipe.camera_sum, n * kFilmLayers * sizeof(float4), hipMemcpyDeviceToHost, context->stream));
+  out += n * kFilmLayers * sizeof(float4);
+  if (header.adaptive) {
+    HIP_OK(context, hipMemcpyAsync(out, context->pipe.adaptive_sum, n * sizeof(float4), hipMemcpyDeviceToHost, context->stream));
+    HIP_OK(context, hipMemcpyAsync(out + n * sizeof(float4), context->pipe.pixel_state, n * sizeof(uint32_t), hipMemcpyDeviceToHost, context->stream));
+  }
+  HIP_OK(context, hipStreamSynchronize(context->stream));
+  return ETX_HIP_OK;
+}
+
+int etx_hip_checkpoint_load(etx_hip_context* context, const void* src, size_t src_bytes) {
+  if ((context == nullptr) || (src == nullptr))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  if ((context->armed == false) || context->reduced) {
+    context->error = "etx_hip_checkpoint_load: call etx_hip_begin (same integrator, options and iteration sharding as the saved run) first";
+    return ETX_HIP_ERROR_STATE;
+  }
+  if (int rc = wait_idle(context))
+    return rc;
+  CheckpointHeader header = {};
+  if (src_bytes >= sizeof(header))
+    memcpy(&header, src, sizeof(header));
+  if ((src_bytes < sizeof(header)) || (header.magic != kCheckpointMagic) || (header.version != kCheckpointVersion)) {
+    context->error = "etx_hip_checkpoint_load: not a checkpoint of this library version";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  const bool adaptive = context->pipe.pixel_state != nullptr;
+  if ((header.integrator != uint32_t(context->integrator)) || (header.width != context->scene.film_w) || (header.height != context->scene.film_h) ||
+      (header.first_iteration != context->first_iteration) || (header.iteration_stride != context->iteration_stride) || ((header.adaptive != 0u) != adaptive) ||
+      (header.options_hash != options_hash(context)) || (src_bytes != checkpoint_bytes(context))) {
+    context->error = "etx_hip_checkpoint_load: the checkpoint was saved by a different run (integrator, options, film size, adaptive sampling or iteration sharding differ)";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  HIP_OK(context, hipSetDevice(context->device));
+  const size_t n = context->pipe.capacity;
+  const uint8_t* in = static_cast<const uint8_t*>(src) + sizeof(header);
+  HIP_OK(context, hipMemcpyAsync(context->pipe.camera_sum, in, n * kFilmLayers * sizeof(float4), hipMemcpyHostToDevice, context->stream));
+  in += n * kFilmLayers * sizeof(float4);
+  if (adaptive) {
+    HIP_OK(context, hipMemcpyAsync(context->pipe.adaptive_sum, in, n * sizeof(float4), hipMemcpyHostToDevice, context->stream));
+    HIP_OK(context, hipMemcpyAsync(context->pipe.pixel_state, in + n * sizeof(float4), n * sizeof(uint32_t), hipMemcpyHostToDevice, context->stream));
+  }
+  HIP_OK(context, hipStreamSynchronize(context->stream));
+  context->next_iteration = header.next_iteration;
+  context->local_iterations = header.local_iterations;
+  {
+    std::lock_guard<std::mutex> lock(context->shared_mutex);
+    context->totals = {};
+    context->totals.completed_iterations = header.local_iterations;
+    context->totals.current_iteration = header.next_iteration;
+    context->totals.last_active_pixels = header.last_active_pixels;
+  }
+  return ETX_HIP_OK;
+}
+
 int etx_hip_set_timers(etx_hip_context* context, uint32_t mask) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;

@@ -183,6 +183,10 @@ class HIPIntegrator(Integrator):
     def render(self):
         """run() + update() until Stopped - what the headless driver does (oracle/driver/etx_oracle.cxx main loop)."""
         self.run()
+        return self.finish()
+
+    def finish(self):
+        """update() until Stopped (after run() or resume())."""
         while self.state() != State.Stopped:
             before = self._rendered
             self.update()
@@ -192,6 +196,27 @@ class HIPIntegrator(Integrator):
 
     def film(self, layer=api.LAYER_RESULT):
         return self.context.read_film(layer)
+
+    def save_checkpoint(self, path=None):
+        """The film state of the render in progress (waits for the iterations in flight; rendering may go on afterwards).
+        The reference has no checkpoint: this is what a headless driver stores next to its output image."""
+        blob = self.context.checkpoint_save()
+        if path is not None:
+            with open(path, "wb") as f:
+                f.write(blob)
+        return blob
+
+    def resume(self, checkpoint):
+        """run() continued from a checkpoint (bytes or a file name) of the same scene, integrator, options and sharding: the
+        iterations the saved render had completed are not rendered again, the remaining ones carry their own indices."""
+        if isinstance(checkpoint, str):
+            with open(checkpoint, "rb") as f:
+                checkpoint = f.read()
+        self.run()
+        self.context.checkpoint_load(checkpoint)
+        self._rendered = int(self.context.stats().completed_iterations)
+        self.current_state = State.Running if self._rendered < self._iterations_to_render() else State.Stopped
+        return self
 
 
 class HIPVCM(HIPIntegrator):

@@ -142,6 +142,17 @@ int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size
 int etx_hip_read_film_begin(etx_hip_context* context, int layer);
 int etx_hip_read_film_end(etx_hip_context* context, float* dst_rgba, size_t dst_bytes, int wait);
 
+/* Checkpoint / resume (the reference has none: a stopped render starts over, app.cxx:193-216). A checkpoint is the
+ * film state of this context - the sums of its completed iterations with their per-pixel sample counts, the adaptive-sampling state,
+ * and the index of the next iteration - as one host buffer of etx_hip_checkpoint_bytes() bytes (0 before etx_hip_begin), written
+ * by _save (waits for the iterations in flight) between etx_hip_begin and etx_hip_reduce_film. _load, called after an etx_hip_begin
+ * with the same integrator, options, film size and iteration sharding (checked, ETX_HIP_ERROR_INVALID_ARGUMENT otherwise), replaces
+ * the film with the saved one and continues at the saved iteration: iterations are seeded by (pixel, iteration), so the
+ * resumed render is the render that was interrupted. The buffer is the caller's to store (file, object store). */
+size_t etx_hip_checkpoint_bytes(const etx_hip_context* context);
+int etx_hip_checkpoint_save(etx_hip_context* context, void* dst, size_t dst_bytes);
+int etx_hip_checkpoint_load(etx_hip_context* context, const void* src, size_t src_bytes);
+
 typedef struct etx_hip_stats_t {
   /* Integrator::Status (integrator.hxx:24-37) */
   double last_iteration_time; /* seconds, device time of the last finished iteration (HIP events) */

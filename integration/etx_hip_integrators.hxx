@@ -65,6 +65,9 @@ struct HIPBackendLibrary {
   decltype(&etx_hip_read_film_begin) read_film_begin = nullptr;
   decltype(&etx_hip_read_film_end) read_film_end = nullptr;
   decltype(&etx_hip_stats) stats = nullptr;
+  decltype(&etx_hip_checkpoint_bytes) checkpoint_bytes = nullptr;
+  decltype(&etx_hip_checkpoint_save) checkpoint_save = nullptr;
+  decltype(&etx_hip_checkpoint_load) checkpoint_load = nullptr;
 
   static HIPBackendLibrary& get() {
     static HIPBackendLibrary lib = load();
@@ -104,6 +107,9 @@ struct HIPBackendLibrary {
     resolve(lib.read_film_begin, "etx_hip_read_film_begin");
     resolve(lib.read_film_end, "etx_hip_read_film_end");
     resolve(lib.stats, "etx_hip_stats");
+    resolve(lib.checkpoint_bytes, "etx_hip_checkpoint_bytes");
+    resolve(lib.checkpoint_save, "etx_hip_checkpoint_save");
+    resolve(lib.checkpoint_load, "etx_hip_checkpoint_load");
     if (complete == false) {
       log::error("libetx_hip.so misses entry points of etx_hip.h");
       dlclose(lib.handle);
@@ -165,6 +171,39 @@ struct HIPIntegratorBase : public Integrator {
     published = 0;
     progressive_stage = 0;
     current_state = State::Running;
+  }
+
+  // Checkpoint / resume. The reference has neither (a stopped render starts over, app.cxx:193-216): the film state
+  // of the render in progress - sums, per-pixel sample counts, adaptive-sampling state, next iteration - as one buffer the caller
+  // stores. Waits for the iterations in flight; rendering may go on afterwards.
+  bool save_checkpoint(std::vector<uint8_t>& blob) {
+    auto& lib = HIPBackendLibrary::get();
+    if (ctx == nullptr)
+      return false;
+    blob.resize(lib.checkpoint_bytes(ctx));
+    if (blob.empty() || (lib.checkpoint_save(ctx, blob.data(), blob.size()) != ETX_HIP_OK)) {
+      hip_report_error(lib.last_error(ctx));
+      return false;
+    }
+    return true;
+  }
+
+  // run() continued from a checkpoint of the same scene, options and film size: the completed iterations are not rendered again,
+  // the remaining ones carry their own indices (and with them their seeds, radii and MIS weights)
+  bool resume(const std::vector<uint8_t>& blob) {
+    run();
+    if (current_state != State::Running)
+      return false;
+    auto& lib = HIPBackendLibrary::get();
+    if (lib.checkpoint_load(ctx, blob.data(), blob.size()) != ETX_HIP_OK) {
+      hip_report_error(lib.last_error(ctx));
+      current_state = State::Stopped;
+      return false;
+    }
+    read_status();
+    submitted = _status.completed_iterations;
+    publish_film();
+    return true;
   }
 
   // CPUVCM::update (vcm_cpu.cxx:264-276): called once per GUI frame, must not block

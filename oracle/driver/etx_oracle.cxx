@@ -247,13 +247,14 @@ int print_kat() {
 void usage() {
   printf(
     "etx_oracle --scene file.json | --load-snapshot scene.bin --integrator pt|vcm|bdpt|hip-vcm|hip-pt|hip-bdpt [--spp N] [--out film.raw] [--snapshot scene.bin]\n"
-    "           [--data /root/reference/bin/] [--opt key=value]... [--max-iterations N]\n");
+    "           [--data /root/reference/bin/] [--opt key=value]... [--max-iterations N]\n"
+    "           hip-* only: [--checkpoint file] (film state when the render stops) [--resume file] (continue that render)\n");
 }
 
 }  // namespace
 
 int main(int argc, char** argv) {
-  std::string load_snapshot_file;
+  std::string load_snapshot_file, checkpoint_file, resume_file;
   std::string scene_file, integrator_name = "vcm", out_file, snapshot_file, data_folder = "/root/reference/bin/";
   std::vector<std::pair<std::string, std::string>> opts;
   int64_t spp = -1;
@@ -332,6 +333,10 @@ int main(int argc, char** argv) {
       max_iterations = atoll(next());
     else if (strcmp(argv[i], "--noise-threshold") == 0)  // Scene::noise_threshold (scene.hxx:45, default 0.1): 0 switches the adaptive sampling of CPUPathTracing off
       noise_threshold = float(atof(next()));
+    else if (strcmp(argv[i], "--checkpoint") == 0)
+      checkpoint_file = next();
+    else if (strcmp(argv[i], "--resume") == 0)
+      resume_file = next();
     else if (strcmp(argv[i], "--out") == 0)
       out_file = next();
     else if (strcmp(argv[i], "--snapshot") == 0)
@@ -482,8 +487,30 @@ int main(int argc, char** argv) {
   }
   raytracing.film().clear(Film::ClearEverything);
   auto t0 = std::chrono::steady_clock::now();
-  integrator->run();
-  if (integrator->state() == Integrator::State::Stopped) {
+  HIPIntegratorBase* hip = (integrator_name.rfind("hip-", 0) == 0) ? static_cast<HIPIntegratorBase*>(integrator) : nullptr;
+  if ((hip == nullptr) && ((checkpoint_file.empty() == false) || (resume_file.empty() == false))) {
+    printf("--checkpoint / --resume: the reference integrators have no checkpoint\n");
+    return 1;
+  }
+  if (resume_file.empty() == false) {
+    std::vector<uint8_t> blob;
+    if (FILE* f = fopen(resume_file.c_str(), "rb")) {
+      fseek(f, 0, SEEK_END);
+      blob.resize(size_t(ftell(f)));
+      fseek(f, 0, SEEK_SET);
+      if (fread(blob.data(), 1, blob.size(), f) != blob.size())
+        blob.clear();
+      fclose(f);
+    }
+    if (blob.empty() || (hip->resume(blob) == false)) {
+      printf("failed to resume from %s\n", resume_file.c_str());
+      return 7;
+    }
+    printf("resumed at iteration %u\n", integrator->status().completed_iterations);
+  } else {
+    integrator->run();
+  }
+  if ((integrator->state() == Integrator::State::Stopped) && (integrator->status().completed_iterations == 0u)) {
     printf("integrator %s did not start (see the log above)\n", integrator->name());
     return 6;
   }
@@ -513,6 +540,17 @@ int main(int argc, char** argv) {
   printf("ORACLE_RESULT {\"integrator\": \"%s\", \"iterations\": %u, \"seconds\": %.6f, \"threads\": %u, \"msamples_per_s\": %.6f, \"width\": %u, \"height\": %u}\n",
     integrator_name.c_str(), st.completed_iterations, st.total_time, threads, msamples, cam.film_size.x, cam.film_size.y);
 
+  if (checkpoint_file.empty() == false) {
+    std::vector<uint8_t> blob;
+    FILE* f = hip->save_checkpoint(blob) ? fopen(checkpoint_file.c_str(), "wb") : nullptr;
+    const bool written = (f != nullptr) && (fwrite(blob.data(), 1, blob.size(), f) == blob.size());
+    if (f != nullptr)
+      fclose(f);
+    if (written == false) {
+      printf("failed to write %s\n", checkpoint_file.c_str());
+      return 4;
+    }
+  }
   if (out_file.empty() == false) {
     if (write_film(out_file.c_str(), raytracing.film(), st.completed_iterations, st.total_time, threads) == false) {
       printf("failed to write %s\n", out_file.c_str());

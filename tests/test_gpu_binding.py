@@ -16,9 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE = os.path.join(ROOT, "oracle", "_ref", "etx_oracle")
 
 
-def run_driver(tmp_path, snapshot, integrator, spp, *options):
-    out = str(tmp_path / ("%s.raw" % integrator))
-    cmd = [ORACLE, "--load-snapshot", snapshot, "--integrator", integrator, "--spp", str(spp), "--out", out]
+def run_driver(tmp_path, snapshot, integrator, spp, *options, extra=(), name=None):
+    out = str(tmp_path / ("%s.raw" % (name or integrator)))
+    cmd = [ORACLE, "--load-snapshot", snapshot, "--integrator", integrator, "--spp", str(spp), "--out", out] + list(extra)
     for o in options:
         cmd += ["--opt", o]
     result = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
@@ -58,6 +58,21 @@ def test_cpp_hip_path_tracer_matches_ctypes_binding(etx, golden_dir, tmp_path):
     np.testing.assert_allclose(film["normal"][..., :3], layers["normal"][..., :3], rtol=0, atol=1e-5)  # Film::layer(Normals) = n * 0.5 + 0.5
     np.testing.assert_allclose(film["albedo"][..., :3], layers["albedo"][..., :3], rtol=2e-4, atol=2e-5)
     assert np.abs(film["light"][..., :3]).max() == 0.0
+
+
+def test_cpp_driver_checkpoint_and_resume(golden_dir, tmp_path):
+    """The headless driver of the HIP path: --max-iterations + --checkpoint stops a render and stores its film state,
+    --resume continues it in a new process; the result is the uninterrupted render (same iterations, float addition order aside)."""
+    snapshot = os.path.join(golden_dir, "cornell_full_128.etxscene")
+    whole, _ = run_driver(tmp_path, snapshot, "hip-vcm", 32, "vcm-blue_noise=false", name="whole")
+    checkpoint = str(tmp_path / "render.etxc")
+    part, _ = run_driver(tmp_path, snapshot, "hip-vcm", 32, "vcm-blue_noise=false", extra=["--max-iterations", "8", "--checkpoint", checkpoint], name="part")
+    assert 8 <= part["spp"] < 24 and os.path.getsize(checkpoint) > 128 * 128 * 64  # the lanes' iterations in flight finish, the rest is left
+    resumed, log = run_driver(tmp_path, snapshot, "hip-vcm", 32, "vcm-blue_noise=false", extra=["--resume", checkpoint], name="resumed")
+    assert resumed["spp"] == 32 and ("resumed at iteration %d" % part["spp"]) in log
+    np.testing.assert_allclose(resumed["camera"][..., :3], whole["camera"][..., :3], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(resumed["light"][..., :3], whole["light"][..., :3], rtol=2e-4, atol=2e-5)
+    assert np.abs(part["camera"][..., :3] - whole["camera"][..., :3]).max() > 1.0e-3
 
 
 def test_cpp_hip_bidirectional_matches_ctypes_binding(etx, golden_dir, tmp_path):
