@@ -19,9 +19,10 @@ VCM_MERGE_VERTICES = 1 << 4
 VCM_ENABLE_MIS = 1 << 5
 VCM_ENABLE_MERGING = 1 << 6
 VCM_FULL_OPTIONS = 0x7F
+CHANGED_CAMERA, CHANGED_MATERIALS, CHANGED_POSITIONS = 1, 2, 4  # etx_hip_update_scene
 
 EXPORTED_SYMBOLS = (
-    "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene",
+    "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene", "etx_hip_update_scene",
     "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_upload_rgb_response", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
     "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_checkpoint_bytes", "etx_hip_checkpoint_save", "etx_hip_checkpoint_load", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
@@ -162,6 +163,7 @@ class Library:
         L.etx_hip_last_error.argtypes = [vp]
         L.etx_hip_last_error.restype = ctypes.c_char_p
         L.etx_hip_upload_scene.argtypes = [vp, vp, vp]
+        L.etx_hip_update_scene.argtypes = [vp, vp, vp, u32]
         L.etx_hip_upload_bluenoise.argtypes = [vp, u32, vp, sz]
         L.etx_hip_upload_cie_table.argtypes = [vp, vp, u32, ctypes.c_float]
         L.etx_hip_upload_rgb_response.argtypes = [vp, vp, u32, ctypes.c_float]
@@ -232,6 +234,12 @@ class Context:
     def upload_scene(self, snapshot):
         self._check(self.library.lib.etx_hip_upload_scene(self.handle, snapshot.scene_address, snapshot.camera_address))
         self.film_size = snapshot.film_size
+        self._scene_keepalive = snapshot
+
+    def update_scene(self, snapshot, changed):
+        """The host edited the uploaded scene in place: CHANGED_CAMERA | CHANGED_MATERIALS | CHANGED_POSITIONS (etx_hip_update_scene:
+        tables rebuilt, geometry / BVH / images stay on the device, moved vertices refit the BVH there)."""
+        self._check(self.library.lib.etx_hip_update_scene(self.handle, snapshot.scene_address, snapshot.camera_address, int(changed)))
         self._scene_keepalive = snapshot
 
     def upload_bluenoise(self, set_index, values):

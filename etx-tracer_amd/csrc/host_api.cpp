@@ -963,6 +963,57 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
   return ETX_HIP_OK;
 }
 
+int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, const etx_abi_camera* camera, uint32_t changed) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  if (context->scene_ready == false) {
+    context->error = "etx_hip_update_scene: no scene uploaded (etx_hip_upload_scene first)";
+    return ETX_HIP_ERROR_STATE;
+  }
+  if ((changed & ~uint32_t(ETX_HIP_CHANGED_CAMERA | ETX_HIP_CHANGED_MATERIALS | ETX_HIP_CHANGED_POSITIONS)) != 0u) {
+    context->error = "etx_hip_update_scene: unknown bits in `changed` (anything else that changed needs etx_hip_upload_scene)";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  if ((camera != nullptr) && ((camera->film_size.x != context->scene.film_w) || (camera->film_size.y != context->scene.film_h))) {
+    context->error = "etx_hip_update_scene: the film size changed; use etx_hip_upload_scene";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  HIP_OK(context, hipSetDevice(context->device));
+  (void)wait_idle(context);
+  HIP_OK(context, hipStreamSynchronize(context->stream));
+  context->scene_ready = false;  // a failure below leaves no scene, like a failed upload
+  context->armed = false;
+  if (context->read_pending) {
+    (void)hipEventSynchronize(context->read_event);
+    context->read_pending = false;
+  }
+  // the tables (materials, spectra, emitters, media parameters, scene scalars, camera) are small and always rebuilt; vertices,
+  // triangles, BVH, image pixels and density grids stay on the device
+  int rc = etxh::build_device_scene(scene, camera, context->scene, context->error, /* keep geometry and images */ true);
+  if (rc)
+    return rc;
+  if ((changed & (ETX_HIP_CHANGED_POSITIONS | ETX_HIP_CHANGED_MATERIALS)) &&
+      (rc = etxh::update_device_geometry(scene, context->scene, context->stream, (changed & ETX_HIP_CHANGED_POSITIONS) != 0u, context->error)))
+    return rc;
+  // pool sizes follow the materials in use (subsurface scenes keep more vertices per path): the lanes' pipelines are set up again
+  for (etx_hip_context* helper : context->helpers)
+    release_pipeline(helper);
+  rc = allocate_pipeline(context);
+  if (rc)
+    return rc;
+  for (etx_hip_context* helper : context->helpers) {
+    helper->scene.borrow(context->scene);
+    rc = allocate_pipeline(helper);
+    if (rc) {
+      context->error = helper->error;
+      return rc;
+    }
+  }
+  HIP_OK(context, hipDeviceSynchronize());
+  context->scene_ready = true;
+  return ETX_HIP_OK;
+}
+
 int etx_hip_upload_bluenoise(etx_hip_context* context, uint32_t set_index, const uint8_t* values, size_t bytes) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;

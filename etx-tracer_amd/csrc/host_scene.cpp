@@ -1,6 +1,7 @@
 // host_scene.cpp - scene upload for the gfx950 backend (replaces Raytracing::commit_changes, sources/etx/rt/rt.cxx:58-88,
 // and follows the author's disabled device-upload sketch rt.cxx:141-238: deep copy + pointer patching).
 #include "host_scene.h"
+#include "kernels_bvh_build.h"
 #include "dev_bsdf.h"
 #include "dev_bvh.h"
 #include "../../include/etx_hip.h"
@@ -19,11 +20,24 @@ DeviceScene::~DeviceScene() {
 }
 
 void DeviceScene::release() {
+  release_tables();
+  for (void* p : geometry_allocations)
+    (void)hipFree(p);
+  for (void* p : image_allocations)
+    (void)hipFree(p);
+  geometry_allocations.clear();
+  image_allocations.clear();
+  image_table.clear();
+  density_grids.clear();
+  bvh_levels.clear();
+  host_copy = {};
+}
+
+void DeviceScene::release_tables() {
   for (void* p : allocations)
     (void)hipFree(p);
   allocations.clear();
   device = nullptr;
-  host_copy = {};
 }
 
 int DeviceScene::sync_device_copy(std::string& error) {
@@ -159,7 +173,7 @@ int upload(DeviceScene& out, const T* src, size_t count, const T*& dst, std::str
     error = "hipMalloc failed (" + std::to_string(bytes) + " bytes)";
     return ETX_HIP_ERROR_HIP;
   }
-  out.allocations.push_back(p);
+  ((out.alloc_group == 1) ? out.geometry_allocations : ((out.alloc_group == 2) ? out.image_allocations : out.allocations)).push_back(p);
   if ((count > 0) && (hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)) {
     error = "hipMemcpy failed";
     return ETX_HIP_ERROR_HIP;
@@ -374,6 +388,8 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
   out.root4 = 0;
   for (size_t head = 0; head < queue.size(); ++head) {
     const Pending item = queue[head];
+    if (item.level > out.depth4)
+      out.level_offsets.push_back(uint32_t(head));  // breadth first: the nodes of a level are consecutive
     out.depth4 = std::max(out.depth4, item.level);
     int32_t kids[4] = {b.nodes[item.tmp_index].left, b.nodes[item.tmp_index].right, -1, -1};
     uint32_t kid_count = 2;
@@ -420,6 +436,7 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
     node.hi_z = make_float4(hi[2][0], hi[2][1], hi[2][2], hi[2][3]);
     out.nodes4.push_back(node);
   }
+  out.level_offsets.push_back(uint32_t(out.nodes4.size()));
   // Stack entries the near-child-first traversal can need: descending into one child leaves at most the other children of
   // the node on the stack. Children are numbered after their parents, so one reverse pass resolves the recurrence.
   std::vector<uint32_t> need(out.nodes4.size(), 0u);
@@ -438,8 +455,78 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
   out.stack_need = need.empty() ? 0u : need[0];
 }
 
-int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera, DeviceScene& out, std::string& error) {
-  out.release();
+// BVH build + upload (geometry group): the BVH4, the traversal triangles, and for a scene of <= kFlatSweepMaxTriangles the flat-sweep primitives
+int build_traversal_tables(const etx_abi_scene* scene, DeviceScene& out, DScene& d, std::string& error) {
+  int rc = 0;
+  HostBvh bvh;
+  build_bvh(scene, bvh);
+  // near-child-first traversal of a four-wide tree pushes at most three children per level
+  if (bvh.stack_need > kStackDepth) {
+    error = "the BVH needs " + std::to_string(bvh.stack_need) + " traversal stack entries (depth " + std::to_string(bvh.depth4) + "), the device stack holds " + std::to_string(kStackDepth);
+    return ETX_HIP_ERROR_UNSUPPORTED;
+  }
+  if ((rc = upload(out, bvh.nodes4.data(), bvh.nodes4.size(), d.bvh_nodes, error)))
+    return rc;
+  if ((rc = upload(out, bvh.tris.data(), bvh.tris.size(), d.bvh_tris, error)))
+    return rc;
+  d.bvh_node_count = uint32_t(bvh.nodes4.size());
+  d.bvh_tri_count = uint32_t(bvh.tris.size());
+  out.bvh_levels = bvh.level_offsets;
+  if (bvh.tris.size() <= kFlatSweepMaxTriangles) {
+    std::vector<BvhTri> edge_prims;
+    std::vector<FlatPrimInfo> infos;
+    build_flat_prims(scene, bvh, edge_prims, infos);
+    // (v0, e1, e2) -> plane + the two coordinate rows, in double
+    std::vector<FlatPrim> prims(edge_prims.size());
+    for (size_t i = 0; i < edge_prims.size(); ++i) {
+      const BvhTri& t = edge_prims[i];
+      const double v0[3] = {t.v0_index.x, t.v0_index.y, t.v0_index.z}, e1[3] = {t.e1_flags.x, t.e1_flags.y, t.e1_flags.z}, e2[3] = {t.e2_mat.x, t.e2_mat.y, t.e2_mat.z};
+      auto cross3 = [](const double a[3], const double b[3], double r[3]) {
+        r[0] = a[1] * b[2] - a[2] * b[1], r[1] = a[2] * b[0] - a[0] * b[2], r[2] = a[0] * b[1] - a[1] * b[0];
+      };
+      auto dot3 = [](const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+      double n[3], u[3], v[3];
+      cross3(e1, e2, n);
+      const double nn = dot3(n, n);
+      cross3(e2, n, u);
+      cross3(n, e1, v);
+      FlatPrim& p = prims[i];
+      p = {};
+      if (nn > 0.0) {
+        p.plane = make_float4(float(n[0]), float(n[1]), float(n[2]), float(-dot3(n, v0)));
+        p.row_a = make_float4(float(u[0] / nn), float(u[1] / nn), float(u[2] / nn), float(-dot3(u, v0) / nn));
+        p.row_b = make_float4(float(v[0] / nn), float(v[1] / nn), float(v[2] / nn), float(-dot3(v, v0) / nn));
+      }  // a degenerate primitive keeps a zero plane: den = 0 -> never hit
+      memcpy(&p.flags, &t.e1_flags.w, 4);
+      memcpy(&p.material, &t.e2_mat.w, 4);
+    }
+    if ((rc = upload(out, prims.data(), prims.size(), d.flat_prims, error)) || (rc = upload(out, infos.data(), infos.size(), d.flat_info, error)))
+      return rc;
+    d.flat_prim_count = uint32_t(prims.size());
+    out.flat_prims = uint32_t(prims.size());
+    if (getenv("ETX_HIP_VERBOSE"))
+      fprintf(stderr, "[etx_hip] flat sweep: %zu triangles -> %zu primitives\n", bvh.tris.size(), prims.size());
+  }
+  d.bvh_root = bvh.root4;
+  d.bvh_depth = bvh.depth4;
+  d.bvh_stack_need = bvh.stack_need;
+  d.bvh_flat = (bvh.tris.size() <= kFlatSweepMaxTriangles) ? 1u : 0u;
+  if (const char* e = getenv("ETX_HIP_FORCE_BVH"))
+    d.bvh_flat = (atoi(e) != 0) ? 0u : d.bvh_flat;
+  out.bvh_depth = bvh.depth4;
+  out.bvh_bytes = bvh.nodes4.size() * sizeof(Bvh4Node) + bvh.tris.size() * sizeof(BvhTri);
+
+  return 0;
+}
+
+int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera, DeviceScene& out, std::string& error, bool keep) {
+  const DScene kept = out.host_copy;  // keep: the geometry / image pointers and the BVH scalars of the scene in place
+  const uint32_t kept_flat_prims = out.flat_prims;
+  if (keep)
+    out.release_tables();
+  else
+    out.release();
+  out.alloc_group = 0;
   if ((scene == nullptr) || (camera == nullptr)) {
     error = "scene / camera is null";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
@@ -565,10 +652,22 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   }
   DScene d = {};
   int rc = 0;
-  if ((rc = upload(out, reinterpret_cast<const etx_abi_vertex*>(scene->vertices.a), scene->vertices.count, d.vertices, error)))
-    return rc;
-  if ((rc = upload(out, triangles, scene->triangles.count, d.triangles, error)))
-    return rc;
+  if (keep) {
+    if ((scene->vertices.count != kept.vertex_count) || (scene->triangles.count != kept.triangle_count) || (scene->images.count != out.image_table.size()) ||
+        (scene->mediums.count != out.density_grids.size())) {
+      error = "etx_hip_update_scene: vertex, triangle, image and medium counts must be those of the uploaded scene (" + std::to_string(kept.vertex_count) + " / " +
+              std::to_string(kept.triangle_count) + " / " + std::to_string(out.image_table.size()) + " / " + std::to_string(out.density_grids.size()) + "); use etx_hip_upload_scene";
+      return ETX_HIP_ERROR_INVALID_ARGUMENT;
+    }
+    d.vertices = kept.vertices, d.triangles = kept.triangles;
+  } else {
+    out.alloc_group = 1;
+    if ((rc = upload(out, reinterpret_cast<const etx_abi_vertex*>(scene->vertices.a), scene->vertices.count, d.vertices, error)))
+      return rc;
+    if ((rc = upload(out, triangles, scene->triangles.count, d.triangles, error)))
+      return rc;
+    out.alloc_group = 0;
+  }
   if ((rc = upload(out, reinterpret_cast<const uint32_t*>(scene->triangle_to_emitter.a), scene->triangle_to_emitter.count, d.triangle_to_emitter, error)))
     return rc;
   if ((rc = upload(out, material_table.data(), material_table.size(), d.materials, error)) || (rc = upload(out, variants.data(), variants.size(), d.material_variants, error)) ||
@@ -605,7 +704,10 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   }
 
   std::vector<DImage> dimages(scene->images.count);
-  for (uint64_t i = 0; i < scene->images.count; ++i) {
+  if (keep)
+    dimages = out.image_table;
+  out.alloc_group = 2;
+  for (uint64_t i = 0; (keep == false) && (i < scene->images.count); ++i) {
     const etx_abi_image& img = images[i];
     DImage& di = dimages[i];
     di = {};
@@ -646,6 +748,8 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     if ((rc = upload(out, flat.data(), flat.size(), di.x_entries, error)))
       return rc;
   }
+  out.alloc_group = 0;
+  out.image_table = dimages;
   if ((rc = upload(out, dimages.data(), dimages.size(), d.images, error)))
     return rc;
 
@@ -673,9 +777,25 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
         error = "heterogeneous medium " + std::to_string(i) + " has no density grid";
         return ETX_HIP_ERROR_INVALID_ARGUMENT;
       }
-      if ((rc = upload(out, reinterpret_cast<const float*>(m.density.a), cells, dm.density, error)))
-        return rc;
+      if (keep) {
+        dm.density = out.density_grids[i];
+        if (dm.density == nullptr) {
+          error = "etx_hip_update_scene: medium " + std::to_string(i) + " became heterogeneous; use etx_hip_upload_scene";
+          return ETX_HIP_ERROR_INVALID_ARGUMENT;
+        }
+      } else {
+        out.alloc_group = 2;
+        rc = upload(out, reinterpret_cast<const float*>(m.density.a), cells, dm.density, error);
+        out.alloc_group = 0;
+        if (rc)
+          return rc;
+      }
     }
+  }
+  if (keep == false) {
+    out.density_grids.assign(scene->mediums.count, nullptr);
+    for (uint64_t i = 0; i < scene->mediums.count; ++i)
+      out.density_grids[i] = dmediums[i].density;
   }
   // Subsurface materials under the bidirectional integrator (bidirectional.cxx:729-790): the walk runs through the material's
   // interior medium, or - without one - through a medium derived from its colour and scattering distances
@@ -736,63 +856,30 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   if ((rc = upload(out, dmediums.data(), dmediums.size(), d.mediums, error)) || (rc = upload(out, sss_medium.data(), sss_medium.size(), d.material_sss_medium, error)))
     return rc;
 
-  HostBvh bvh;
-  build_bvh(scene, bvh);
-  // near-child-first traversal of a four-wide tree pushes at most three children per level
-  if (bvh.stack_need > kStackDepth) {
-    error = "the BVH needs " + std::to_string(bvh.stack_need) + " traversal stack entries (depth " + std::to_string(bvh.depth4) + "), the device stack holds " + std::to_string(kStackDepth);
-    return ETX_HIP_ERROR_UNSUPPORTED;
-  }
-  if ((rc = upload(out, bvh.nodes4.data(), bvh.nodes4.size(), d.bvh_nodes, error)))
-    return rc;
-  if ((rc = upload(out, bvh.tris.data(), bvh.tris.size(), d.bvh_tris, error)))
-    return rc;
-  d.bvh_node_count = uint32_t(bvh.nodes4.size());
-  d.bvh_tri_count = uint32_t(bvh.tris.size());
-  if (bvh.tris.size() <= kFlatSweepMaxTriangles) {
-    std::vector<BvhTri> edge_prims;
-    std::vector<FlatPrimInfo> infos;
-    build_flat_prims(scene, bvh, edge_prims, infos);
-    // (v0, e1, e2) -> plane + the two coordinate rows, in double
-    std::vector<FlatPrim> prims(edge_prims.size());
-    for (size_t i = 0; i < edge_prims.size(); ++i) {
-      const BvhTri& t = edge_prims[i];
-      const double v0[3] = {t.v0_index.x, t.v0_index.y, t.v0_index.z}, e1[3] = {t.e1_flags.x, t.e1_flags.y, t.e1_flags.z}, e2[3] = {t.e2_mat.x, t.e2_mat.y, t.e2_mat.z};
-      auto cross3 = [](const double a[3], const double b[3], double r[3]) {
-        r[0] = a[1] * b[2] - a[2] * b[1], r[1] = a[2] * b[0] - a[0] * b[2], r[2] = a[0] * b[1] - a[1] * b[0];
-      };
-      auto dot3 = [](const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
-      double n[3], u[3], v[3];
-      cross3(e1, e2, n);
-      const double nn = dot3(n, n);
-      cross3(e2, n, u);
-      cross3(n, e1, v);
-      FlatPrim& p = prims[i];
-      p = {};
-      if (nn > 0.0) {
-        p.plane = make_float4(float(n[0]), float(n[1]), float(n[2]), float(-dot3(n, v0)));
-        p.row_a = make_float4(float(u[0] / nn), float(u[1] / nn), float(u[2] / nn), float(-dot3(u, v0) / nn));
-        p.row_b = make_float4(float(v[0] / nn), float(v[1] / nn), float(v[2] / nn), float(-dot3(v, v0) / nn));
-      }  // a degenerate primitive keeps a zero plane: den = 0 -> never hit
-      memcpy(&p.flags, &t.e1_flags.w, 4);
-      memcpy(&p.material, &t.e2_mat.w, 4);
+  if (keep && (scene->triangles.count > kFlatSweepMaxTriangles)) {
+    // the geometry group stays: traversal tables and the scalars that describe them
+    d.bvh_nodes = kept.bvh_nodes, d.bvh_tris = kept.bvh_tris, d.bvh_node_count = kept.bvh_node_count, d.bvh_tri_count = kept.bvh_tri_count;
+    d.flat_prims = kept.flat_prims, d.flat_info = kept.flat_info, d.flat_prim_count = kept.flat_prim_count;
+    d.bvh_root = kept.bvh_root, d.bvh_depth = kept.bvh_depth, d.bvh_stack_need = kept.bvh_stack_need, d.bvh_flat = kept.bvh_flat;
+    out.flat_prims = kept_flat_prims;
+  } else {
+    // (a scene small enough for the flat sweep is rebuilt in any case: its primitives are pre-transformed on the host)
+    if (keep) {
+      std::vector<void*> retained;
+      for (void* p : out.geometry_allocations) {
+        if ((p == kept.vertices) || (p == kept.triangles))
+          retained.push_back(p);
+        else
+          (void)hipFree(p);
+      }
+      out.geometry_allocations.swap(retained);
     }
-    if ((rc = upload(out, prims.data(), prims.size(), d.flat_prims, error)) || (rc = upload(out, infos.data(), infos.size(), d.flat_info, error)))
+    out.alloc_group = 1;
+    rc = build_traversal_tables(scene, out, d, error);
+    out.alloc_group = 0;
+    if (rc)
       return rc;
-    d.flat_prim_count = uint32_t(prims.size());
-    out.flat_prims = uint32_t(prims.size());
-    if (getenv("ETX_HIP_VERBOSE"))
-      fprintf(stderr, "[etx_hip] flat sweep: %zu triangles -> %zu primitives\n", bvh.tris.size(), prims.size());
   }
-  d.bvh_root = bvh.root4;
-  d.bvh_depth = bvh.depth4;
-  d.bvh_stack_need = bvh.stack_need;
-  d.bvh_flat = (bvh.tris.size() <= kFlatSweepMaxTriangles) ? 1u : 0u;
-  if (const char* e = getenv("ETX_HIP_FORCE_BVH"))
-    d.bvh_flat = (atoi(e) != 0) ? 0u : d.bvh_flat;
-  out.bvh_depth = bvh.depth4;
-  out.bvh_bytes = bvh.nodes4.size() * sizeof(Bvh4Node) + bvh.tris.size() * sizeof(BvhTri);
-
   d.vertex_count = uint32_t(scene->vertices.count);
   d.triangle_count = uint32_t(scene->triangles.count);
   d.material_count = uint32_t(scene->materials.count);
@@ -839,6 +926,32 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     return rc;
   out.film_w = camera->film_size.x;
   out.film_h = camera->film_size.y;
+  return 0;
+}
+
+int update_device_geometry(const etx_abi_scene* scene, DeviceScene& out, hipStream_t stream, bool positions_moved, std::string& error) {
+  const DScene& d = out.host_copy;
+  if ((scene == nullptr) || (scene->vertices.count != d.vertex_count) || (scene->triangles.count != d.triangle_count)) {
+    error = "etx_hip_update_scene: the geometry must keep its vertex and triangle counts; use etx_hip_upload_scene";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  if (positions_moved &&
+      ((hipMemcpyAsync(const_cast<etx_abi_vertex*>(d.vertices), scene->vertices.a, scene->vertices.count * sizeof(etx_abi_vertex), hipMemcpyHostToDevice, stream) != hipSuccess) ||
+       (hipMemcpyAsync(const_cast<etx_abi_triangle*>(d.triangles), scene->triangles.a, scene->triangles.count * sizeof(etx_abi_triangle), hipMemcpyHostToDevice, stream) != hipSuccess))) {
+    error = "hipMemcpy of the moved vertices failed";
+    return ETX_HIP_ERROR_HIP;
+  }
+  // a scene small enough for the flat sweep had its traversal tables rebuilt from the host scene (build_device_scene)
+  if (d.triangle_count > kFlatSweepMaxTriangles) {
+    // positions, and the filter flags that follow the material classes (Void, Boundary, alpha test)
+    launch_bvh_triangles_update(stream, d, const_cast<BvhTri*>(d.bvh_tris), d.bvh_tri_count);
+    for (size_t level = out.bvh_levels.size(); positions_moved && (level-- > 1u);)  // bvh_levels: first node of every level, then the node count
+      launch_bvh_refit_level(stream, d, const_cast<Bvh4Node*>(d.bvh_nodes), out.bvh_levels[level - 1u], out.bvh_levels[level] - out.bvh_levels[level - 1u]);
+  }
+  if ((hipGetLastError() != hipSuccess) || (hipStreamSynchronize(stream) != hipSuccess)) {
+    error = "updating the traversal tables failed on the device";
+    return ETX_HIP_ERROR_HIP;
+  }
   return 0;
 }
 

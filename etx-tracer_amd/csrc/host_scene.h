@@ -19,7 +19,14 @@ struct DeviceScene {
   uint32_t flat_prims = 0;          // primitives of the flat sweep (parallelograms count once), 0 = BVH traversal
   etxd::DScene host_copy = {};      // the struct as uploaded (device pointers inside)
   etxd::DScene* device = nullptr;   // device copy of host_copy
-  std::vector<void*> allocations;
+  // Three groups of device allocations: etx_hip_update_scene (host_api.cpp) rebuilds the tables and keeps the other two.
+  std::vector<void*> allocations;           // material / spectrum / emitter / medium tables, the scene header
+  std::vector<void*> geometry_allocations;  // vertices, triangles, BVH nodes and triangles, flat-sweep primitives
+  std::vector<void*> image_allocations;     // image pixels and their sampling tables, density grids of heterogeneous media
+  int alloc_group = 0;                      // where upload() files the next allocation (0 tables, 1 geometry, 2 images)
+  std::vector<etxd::DImage> image_table;    // host copy of DScene::images (device pointers inside), reused by an update
+  std::vector<const float*> density_grids;  // per medium: its uploaded density grid (nullptr: homogeneous)
+  std::vector<uint32_t> bvh_levels;         // first node of every breadth-first level of the BVH4, then the node count (device refit)
   uint32_t film_w = 0, film_h = 0;
   float noise_threshold = 0.0f;     // Scene::noise_threshold (adaptive sampling of the path tracer)
   uint32_t bvh_depth = 0;
@@ -35,17 +42,26 @@ struct DeviceScene {
 
   ~DeviceScene();
   void release();
+  void release_tables();  // frees `allocations` only
   int sync_device_copy(std::string& error);  // after the host patched host_copy (CIE table): refresh the device-resident header
   void borrow(const DeviceScene& owner);  // non-owning view of the owner's device tables (helper lanes, host_api.cpp)
 };
 
-// Returns 0 or an ETX_HIP_ERROR_* code with `error` set.
-int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera, DeviceScene& out, std::string& error);
+// Returns 0 or an ETX_HIP_ERROR_* code with `error` set. keep_geometry_and_images: `out` holds a scene whose geometry group
+// (same vertex / triangle counts and indices) and image group (same images, same density grids) stay as they are on the device;
+// only the tables are rebuilt from `scene` (etx_hip_update_scene).
+int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera, DeviceScene& out, std::string& error, bool keep_geometry_and_images = false);
+
+// After build_device_scene(keep): brings the kept traversal tables in line with `scene` on `stream` (kernels_bvh_build.hip). The
+// traversal triangles are re-derived (filter flags follow the material classes); positions_moved (same counts and indices): the
+// vertices and triangles of `scene` are copied over the device ones first and the BVH4 boxes refit level by level afterwards.
+int update_device_geometry(const etx_abi_scene* scene, DeviceScene& out, hipStream_t stream, bool positions_moved, std::string& error);
 
 // BVH build exposed for tests of the host logic (no GPU needed)
 struct HostBvh {
   std::vector<etxd::BvhNode> nodes;    // the builder's binned-SAH BVH2 (kept for the invariants check)
   std::vector<etxd::Bvh4Node> nodes4;  // what the device traverses: the BVH2 collapsed to four-wide nodes, breadth first
+  std::vector<uint32_t> level_offsets; // first nodes4 index of every breadth-first level, then nodes4.size()
   int32_t root4 = 0;
   uint32_t depth4 = 0;                 // levels of inner BVH4 nodes
   uint32_t stack_need = 0;             // entries the near-child-first traversal can have on its stack (exact bound over the tree)

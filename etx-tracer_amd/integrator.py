@@ -110,6 +110,7 @@ class HIPIntegrator(Integrator):
         self.first_iteration = first_iteration
         self.iteration_stride = iteration_stride
         self._uploaded_version = None  # snapshot.version at the last etx_hip_upload_scene
+        self._pending_changes = None   # scene_edited(): what the host changed since (None: unknown = upload everything)
         self._rendered = 0
         self._have_camera_image = False
         self._have_light_image = False
@@ -129,11 +130,21 @@ class HIPIntegrator(Integrator):
             return 0
         return (total - self.first_iteration + self.iteration_stride - 1) // self.iteration_stride
 
+    def scene_edited(self, changed):
+        """The host says what it edited in the snapshot since the last run (api.CHANGED_*): the next run() updates the device scene in
+        place (etx_hip_update_scene: no BVH rebuild, no image upload) instead of uploading it again. Without this call an
+        edited snapshot (snapshot.version) is uploaded as a whole - what the reference does on every change (app.cxx:364-403)."""
+        self._pending_changes = (self._pending_changes or 0) | int(changed)
+
     def run(self):
         self.stop(Stop.Immediate)
-        if self._uploaded_version != self.snapshot.version:  # first run, or the host edited the scene since (app.cxx:364-403 restarts)
+        if (self._uploaded_version is not None) and (self._pending_changes is not None):
+            self.context.update_scene(self.snapshot, self._pending_changes)
+            self._uploaded_version = self.snapshot.version
+        elif self._uploaded_version != self.snapshot.version:  # first run, or the host edited the scene since (app.cxx:364-403 restarts)
             self.context.upload_scene(self.snapshot)
             self._uploaded_version = self.snapshot.version
+        self._pending_changes = None
         if self.cie_table is not None:
             self.context.upload_cie_table(*self.cie_table)
         if self.rgb_response_table is not None:

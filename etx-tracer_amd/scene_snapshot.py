@@ -117,6 +117,13 @@ class SceneSnapshot:
         buf = (ctypes.c_uint32 * (count * 8)).from_address(ptr)
         return np.frombuffer(buf, dtype=np.uint32).reshape(count, 8)
 
+    def materials(self):
+        """writable uint32 view (count, 50) of the etx::Material table (class at column 41): for hosts / tests that edit a material
+        in place and then call Context.update_scene(snapshot, CHANGED_MATERIALS)"""
+        ptr, count = self._array(_SCENE_MATERIALS)
+        buf = (ctypes.c_uint32 * (count * 50)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.uint32).reshape(count, 50)
+
     def material_classes(self):
         ptr, count = self._array(_SCENE_MATERIALS)
         buf = (ctypes.c_uint32 * (count * 50)).from_address(ptr)

@@ -79,6 +79,24 @@ const char* etx_hip_last_error(const etx_hip_context* context);
  * camera->film_size. */
 int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, const etx_abi_camera* camera);
 
+/* Scene edits without a full upload. The reference re-commits the whole scene on every change - Embree rebuilds its
+ * BVH in Raytracing::commit_changes (rt.cxx:58-88) whenever the camera, a material or the geometry was touched (app.cxx:368-399).
+ * Here the caller says what it edited in the scene it uploaded before:
+ *   ETX_HIP_CHANGED_CAMERA    camera parameters (same film size)
+ *   ETX_HIP_CHANGED_MATERIALS materials, spectra, emitter profiles / instances / distribution, medium parameters, scene scalars
+ *                             (samples, path lengths, clamp, noise threshold); the traversal filters (Void, Boundary, alpha test)
+ *                             follow the new material classes
+ *   ETX_HIP_CHANGED_POSITIONS vertex data moved (same vertex and triangle counts, same indices): the vertices and triangles are
+ *                             copied over, the traversal triangles re-derived and the BVH boxes refit bottom-up ON THE DEVICE
+ *                             (kernels_bvh_build.hip); the tree keeps its topology, so a refit after large deformations traverses
+ *                             slower than a rebuild (etx_hip_upload_scene)
+ * The small tables and the camera are rebuilt from `scene` / `camera` in any case; vertices, triangles, BVH, image pixels and
+ * density grids stay resident. Counts of vertices, triangles, images and media must be unchanged (ETX_HIP_ERROR_INVALID_ARGUMENT
+ * otherwise; on any error the context holds no scene, as after a failed upload). Waits for the iterations in flight; the next
+ * etx_hip_begin renders the edited scene. */
+enum { ETX_HIP_CHANGED_CAMERA = 1, ETX_HIP_CHANGED_MATERIALS = 2, ETX_HIP_CHANGED_POSITIONS = 4 };
+int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, const etx_abi_camera* camera, uint32_t changed);
+
 /* The blue-noise samples options.blue_noise needs (vcm_shared.hxx:941-945, 1018-1022). The host's sampler is
  * sample_blue_noise(pixel, scene.samples, iteration, dimension) (path_tracing.cxx:173-178 -> thirdparty/bluenoise
  * BNSampler), whose tables are private to that library; the ABI therefore takes the sampler's OUTPUT for one

@@ -54,6 +54,7 @@ struct HIPBackendLibrary {
   decltype(&etx_hip_destroy) destroy = nullptr;
   decltype(&etx_hip_last_error) last_error = nullptr;
   decltype(&etx_hip_upload_scene) upload_scene = nullptr;
+  decltype(&etx_hip_update_scene) update_scene = nullptr;
   decltype(&etx_hip_upload_bluenoise) upload_bluenoise = nullptr;
   decltype(&etx_hip_upload_cie_table) upload_cie_table = nullptr;
   decltype(&etx_hip_upload_rgb_response) upload_rgb_response = nullptr;
@@ -96,6 +97,7 @@ struct HIPBackendLibrary {
     resolve(lib.destroy, "etx_hip_destroy");
     resolve(lib.last_error, "etx_hip_last_error");
     resolve(lib.upload_scene, "etx_hip_upload_scene");
+    resolve(lib.update_scene, "etx_hip_update_scene");
     resolve(lib.upload_bluenoise, "etx_hip_upload_bluenoise");
     resolve(lib.upload_cie_table, "etx_hip_upload_cie_table");
     resolve(lib.upload_rgb_response, "etx_hip_upload_rgb_response");
@@ -157,7 +159,15 @@ struct HIPIntegratorBase : public Integrator {
     }
     // etx::Scene / etx::Camera ARE the ABI structs: the backend borrows them during the call and owns device copies
     // afterwards (deep copy + BVH build: Raytracing::commit_changes, rt.cxx:58-88, and the disabled sketch rt.cxx:141-238)
-    if (lib.upload_scene(ctx, reinterpret_cast<const etx_abi_scene*>(&rt.scene()), reinterpret_cast<const etx_abi_camera*>(&rt.camera())) != ETX_HIP_OK) {
+    // A host that knows what it edited since the last run (scene_edited) keeps geometry, BVH and images on the device and has moved
+    // vertices refit there; otherwise everything is uploaded, which is what commit_changes does on every change (app.cxx:368-399)
+    const auto* scene_abi = reinterpret_cast<const etx_abi_scene*>(&rt.scene());
+    const auto* camera_abi = reinterpret_cast<const etx_abi_camera*>(&rt.camera());
+    const bool in_place = scene_on_device && (pending_changes != kEverythingChanged);
+    const int uploaded = in_place ? lib.update_scene(ctx, scene_abi, camera_abi, pending_changes) : lib.upload_scene(ctx, scene_abi, camera_abi);
+    pending_changes = kEverythingChanged;
+    scene_on_device = uploaded == ETX_HIP_OK;
+    if (uploaded != ETX_HIP_OK) {
       hip_report_error(lib.last_error(ctx));  // e.g. ETX_HIP_ERROR_UNSUPPORTED: stay Stopped, like a failed Embree commit
       return;
     }
@@ -171,6 +181,13 @@ struct HIPIntegratorBase : public Integrator {
     published = 0;
     progressive_stage = 0;
     current_state = State::Running;
+  }
+
+  // The host edited the committed scene in place since the last run(): ETX_HIP_CHANGED_CAMERA | _MATERIALS | _POSITIONS (include/etx_hip.h).
+  // The next run() then calls etx_hip_update_scene instead of etx_hip_upload_scene. Anything else (topology, images) needs no call:
+  // without one, run() uploads the whole scene.
+  void scene_edited(uint32_t changed) {
+    pending_changes = (pending_changes == kEverythingChanged) ? changed : (pending_changes | changed);
   }
 
   // Checkpoint / resume. The reference has neither (a stopped render starts over, app.cxx:193-216): the film state
@@ -455,6 +472,9 @@ struct HIPIntegratorBase : public Integrator {
   }
 
   etx_hip_context* ctx = nullptr;
+  static constexpr uint32_t kEverythingChanged = 0xffffffffu;
+  uint32_t pending_changes = kEverythingChanged;
+  bool scene_on_device = false;
   Status _status = {};
   uint32_t submitted = 0, published = 0;
   uint32_t progressive_stage = 0, progressive_iterations = 0;  // asynchronous publish while rendering (progressive_publish)
