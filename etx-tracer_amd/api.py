@@ -19,13 +19,15 @@ VCM_MERGE_VERTICES = 1 << 4
 VCM_ENABLE_MIS = 1 << 5
 VCM_ENABLE_MERGING = 1 << 6
 VCM_FULL_OPTIONS = 0x7F
-CHANGED_CAMERA, CHANGED_MATERIALS, CHANGED_POSITIONS = 1, 2, 4  # etx_hip_update_scene
+CHANGED_CAMERA, CHANGED_MATERIALS, CHANGED_POSITIONS, REBUILD_BVH = 1, 2, 4, 8  # etx_hip_update_scene
+BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1  # etx_hip_set_bvh_builder
 
 EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene", "etx_hip_update_scene",
     "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_upload_rgb_response", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
     "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_checkpoint_bytes", "etx_hip_checkpoint_save", "etx_hip_checkpoint_load", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
+    "etx_hip_set_bvh_builder", "etx_hip_bvh_info", "etx_hip_host_check_bvh_builder", "etx_hip_host_bvh_stats_builder",
 )
 
 
@@ -189,6 +191,10 @@ class Library:
         L.etx_hip_kat.argtypes = [vp, i32, vp, u64, vp]
         L.etx_hip_host_check_bvh.argtypes = [vp, ctypes.POINTER(u32 * 4)]
         L.etx_hip_host_bvh_stats.argtypes = [vp, vp, u64, ctypes.POINTER(u64 * 4)]
+        L.etx_hip_set_bvh_builder.argtypes = [vp, i32]
+        L.etx_hip_bvh_info.argtypes = [vp, ctypes.POINTER(u32 * 4), ctypes.POINTER(ctypes.c_double)]
+        L.etx_hip_host_check_bvh_builder.argtypes = [vp, i32, ctypes.POINTER(u32 * 4)]
+        L.etx_hip_host_bvh_stats_builder.argtypes = [vp, i32, vp, u64, ctypes.POINTER(u64 * 4), vp]
 
     @classmethod
     def get(cls):
@@ -235,6 +241,17 @@ class Context:
         self._check(self.library.lib.etx_hip_upload_scene(self.handle, snapshot.scene_address, snapshot.camera_address))
         self.film_size = snapshot.film_size
         self._scene_keepalive = snapshot
+
+    def set_bvh_builder(self, builder):
+        """BVH_HOST_SAH (default) or BVH_DEVICE_LBVH: who builds the tree of the next upload_scene (etx_hip_set_bvh_builder)."""
+        self._check(self.library.lib.etx_hip_set_bvh_builder(self.handle, int(builder)))
+
+    def bvh_info(self):
+        """{nodes, triangles, depth, stack_need, bytes, build_ms} of the uploaded scene's traversal tree."""
+        info = (ctypes.c_uint32 * 4)()
+        build_ms = ctypes.c_double(0.0)
+        self._check(self.library.lib.etx_hip_bvh_info(self.handle, ctypes.byref(info), ctypes.byref(build_ms)))
+        return {"nodes": info[0], "triangles": info[1], "depth": info[2] & 0xffff, "stack_need": info[2] >> 16, "bytes": info[3], "build_ms": build_ms.value}
 
     def update_scene(self, snapshot, changed):
         """The host edited the uploaded scene in place: CHANGED_CAMERA | CHANGED_MATERIALS | CHANGED_POSITIONS (etx_hip_update_scene:
@@ -346,21 +363,29 @@ class Context:
         self._check(self.library.lib.etx_hip_reduce_film(self.handle))
 
 
-def host_check_bvh(snapshot, library=None):
-    """(rc, {nodes, triangles, depth, bytes}) - host-only BVH build + invariant check, no GPU needed."""
+def host_check_bvh(snapshot, library=None, builder=BVH_HOST_SAH):
+    """(rc, {nodes, triangles, depth, bytes}) - host-only BVH build + invariant check, no GPU needed. builder=BVH_DEVICE_LBVH: the
+    device build, emulated on the host through the functions its kernels call."""
     library = library or Library.get()
     info = (ctypes.c_uint32 * 4)()
-    rc = library.lib.etx_hip_host_check_bvh(snapshot.scene_address, ctypes.byref(info))
+    rc = library.lib.etx_hip_host_check_bvh_builder(snapshot.scene_address, int(builder), ctypes.byref(info))
     return rc, {"nodes": info[0], "triangles": info[1], "depth": info[2] & 0xffff, "stack_need": info[2] >> 16, "bytes": info[3]}
 
 
-def host_bvh_stats(snapshot, rays, library=None):
-    """Host-only: the work the traversal does for `rays` (n x 8 float32): node visits, triangle tests, hits, deepest stack use."""
+def host_bvh_stats(snapshot, rays, library=None, builder=BVH_HOST_SAH, with_hits=False):
+    """Host-only: the work the traversal does for `rays` (n x 8 float32): node visits, triangle tests, hits, deepest stack use;
+    with_hits: + "t" (float32 n) and "triangle" (int64 n, -1 = miss) of every ray's closest hit."""
     library = library or Library.get()
     rays = np.ascontiguousarray(rays, dtype=np.float32)
     out = (ctypes.c_uint64 * 4)()
-    rc = library.lib.etx_hip_host_bvh_stats(snapshot.scene_address, rays.ctypes.data, rays.shape[0], ctypes.byref(out))
-    return rc, {"node_visits": out[0], "triangle_tests": out[1], "hits": out[2], "max_stack": out[3]}
+    hits = np.zeros((rays.shape[0], 2), dtype=np.float32) if with_hits else None
+    rc = library.lib.etx_hip_host_bvh_stats_builder(snapshot.scene_address, int(builder), rays.ctypes.data, rays.shape[0], ctypes.byref(out), hits.ctypes.data if with_hits else None)
+    result = {"node_visits": out[0], "triangle_tests": out[1], "hits": out[2], "max_stack": out[3]}
+    if with_hits:
+        triangle = hits[:, 1].view(np.uint32).astype(np.int64)
+        triangle[triangle == 0xFFFFFFFF] = -1
+        result["t"], result["triangle"] = hits[:, 0].copy(), triangle
+    return rc, result
 
 
 def comm_unique_id(library=None):

@@ -4,8 +4,8 @@
 //   closest hit   = Raytracing::trace               rt.cxx:428-466 (skip Void, stochastic alpha, keep closest)
 //   transmittance = Raytracing::trace_transmittance rt.cxx:468-579 (Boundary surfaces are transparent and switch
 //                   the medium by the side of geo_n; anything else occludes; media attenuate the segments)
-// Traversal state: a per-lane stack that lives in LDS, laid out [depth][lane] so a wavefront's pushes/pops hit 64
-// consecutive banks; nodes are 128-byte four-child packets (dev_scene.h Bvh4Node), the top of the tree staged in LDS
+// Traversal state: a per-lane stack that lives in LDS (deep trees: its upper part in global memory), laid out [depth][lane] so a
+// wavefront's pushes/pops hit 64 consecutive banks; nodes are 128-byte four-child packets (dev_scene.h Bvh4Node), the top of the tree staged in LDS
 // by the traversal kernels (BvhNodes below), the rest read through L2.
 #pragma once
 
@@ -13,10 +13,12 @@
 
 namespace etxd {
 
-constexpr uint32_t kStackDepth = 32;
+constexpr uint32_t kStackDepth = 32;     // stack entries a lane keeps in LDS
+constexpr uint32_t kMaxStackDepth = 64;  // deepest stack a tree may need (host bound over the tree): the entries above kStackDepth spill
 constexpr uint32_t kFlatSweepMaxTriangles = 64;  // scenes up to this size are swept linearly (all lanes, same triangle)
 
-struct LaneStack {
+// The stack of the two traversal kernels when the tree's bound fits the LDS part (trees up to ~40 000 triangles): no checks.
+struct FastLaneStack {
   int32_t* base;    // LDS, this lane's slot of level 0
   uint32_t stride;  // lanes per level (= block size)
   ETX_DEV void push(uint32_t& sp, int32_t v) const {
@@ -28,6 +30,35 @@ struct LaneStack {
     return base[sp * stride];
   }
 };
+
+// The general stack: kStackDepth entries in LDS, the rest in global memory (DScene::stack_spill, allocated per device lane when the
+// uploaded tree's bound exceeds kStackDepth; laid out [level][lane] like the LDS part). The bound is a worst case over the tree -
+// three pushed children on every level of the deepest path: 43 entries for a million triangles -, real rays stay below 20, so the
+// spill is a guarantee rather than traffic.
+struct LaneStack {
+  int32_t* base;
+  uint32_t stride;
+  int32_t* spill;
+  uint32_t spill_stride;
+  ETX_DEV void push(uint32_t& sp, int32_t v) const {
+    if (sp < kStackDepth)
+      base[sp * stride] = v;
+    else
+      spill[(sp - kStackDepth) * spill_stride] = v;
+    sp += 1u;
+  }
+  ETX_DEV int32_t pop(uint32_t& sp) const {
+    sp -= 1u;
+    return (sp < kStackDepth) ? base[sp * stride] : spill[(sp - kStackDepth) * spill_stride];
+  }
+};
+
+// `lds_slot`: this lane's slot of level 0 in the workgroup's stack array, `stride`: lanes per level
+ETX_DEV LaneStack lane_stack(const DScene& scene, int32_t* lds_slot, uint32_t stride) {
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t* spill = ((scene.stack_spill != nullptr) && (lane < scene.stack_spill_lanes)) ? (scene.stack_spill + lane) : nullptr;
+  return {lds_slot, stride, spill, scene.stack_spill_lanes};
+}
 
 struct Hit {
   float u, v, t;
@@ -207,8 +238,8 @@ ETX_DEV void sort_pair(float& ta, int32_t& ca, float& tb, int32_t& cb) {  // com
 }
 
 // Closest accepted hit in [tmin, tmax]: BVH4, per-lane stack in LDS, near child first.
-template <class Tris>
-ETX_DEV Hit bvh_closest(const DScene& scene, const BvhNodes& nodes, Tris tris, int32_t root, const LaneStack& stack, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags,
+template <class Tris, class Stack>
+ETX_DEV Hit bvh_closest(const DScene& scene, const BvhNodes& nodes, Tris tris, int32_t root, const Stack& stack, const RayQ& ray, uint32_t& alpha_seed, uint32_t* out_flags,
   uint32_t material_filter = kInvalid) {
   if (scene.bvh_flat)
     return bvh_flat_closest(scene, tris, ray, alpha_seed, out_flags, material_filter);
@@ -403,8 +434,8 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
 // The reference collects up to 63 Boundary hits in one traversal and sorts them; here the boundaries are visited in
 // order by restarting the closest-hit search behind each one (same products, no per-lane hit buffer).
 // rays_traced counts the traversals (statistics).
-template <class Tris>
-ETX_DEV f3 bvh_transmittance(const DScene& scene, const BvhNodes& nodes, Tris tris, int32_t root, const LaneStack& stack, const f3& p0, const f3& p1, uint32_t medium_index,
+template <class Tris, class Stack>
+ETX_DEV f3 bvh_transmittance(const DScene& scene, const BvhNodes& nodes, Tris tris, int32_t root, const Stack& stack, const f3& p0, const f3& p1, uint32_t medium_index,
   float wavelength, uint32_t& alpha_seed) {
   f3 direction = p1 - p0;
   float t_max = dot(direction, direction);

@@ -142,6 +142,8 @@ struct DScene {
   int32_t bvh_root;  // child encoding (a single leaf scene has a negative root)
   uint32_t bvh_depth; // levels of inner BVH4 nodes
   uint32_t bvh_stack_need;  // stack entries the traversal can need (host bound over the tree): selects the kernel variant
+  int32_t* stack_spill;     // trees that need more than the LDS stack: [level - kStackDepth][lane], PER DEVICE LANE (set in the lane's Pipeline::scene copy, host_api.cpp)
+  uint32_t stack_spill_lanes;
   uint32_t bvh_flat; // != 0: so few triangles that the wave-uniform linear sweep beats the tree (dev_bvh.h)
   float emitter_dist_total;
   uint32_t env_emitters[ETX_ABI_MAX_ENVIRONMENT_EMITTERS];

@@ -180,6 +180,15 @@ int allocate_pipeline(etx_hip_context* ctx) {
   Pipeline& p = ctx->pipe;
   const uint32_t n = ctx->scene.film_w * ctx->scene.film_h;
   p.scene = ctx->scene.host_copy;
+  // a tree whose stack bound exceeds the LDS part: this lane's spill area (dev_bvh.h LaneStack), one column per thread of the
+  // largest grid any traversing kernel is launched with
+  p.scene.stack_spill = nullptr, p.scene.stack_spill_lanes = 0u;
+  if ((p.scene.bvh_flat == 0u) && (p.scene.bvh_stack_need > kStackDepth)) {
+    const uint32_t spill_lanes = 2u * kPersistentBlocks * kBlockSize;
+    if (int rc = device_alloc(ctx, p.scene.stack_spill, size_t(spill_lanes) * (kMaxStackDepth - kStackDepth)))
+      return rc;
+    p.scene.stack_spill_lanes = spill_lanes;
+  }
   p.debug_flags = 0u;
   if (const char* e = getenv("ETX_HIP_DEBUG_FLAGS"))
     p.debug_flags = uint32_t(strtoul(e, nullptr, 0));
@@ -963,6 +972,27 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
   return ETX_HIP_OK;
 }
 
+int etx_hip_set_bvh_builder(etx_hip_context* context, int builder) {
+  if ((context == nullptr) || ((builder != ETX_HIP_BVH_HOST_SAH) && (builder != ETX_HIP_BVH_DEVICE_LBVH)))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  context->scene.device_bvh_build = builder == ETX_HIP_BVH_DEVICE_LBVH;
+  return ETX_HIP_OK;
+}
+
+int etx_hip_bvh_info(etx_hip_context* context, uint32_t out_info[4], double* out_build_ms) {
+  if ((context == nullptr) || (out_info == nullptr))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  if (context->scene_ready == false) {
+    context->error = "etx_hip_bvh_info: no scene uploaded";
+    return ETX_HIP_ERROR_STATE;
+  }
+  const auto& d = context->scene.host_copy;
+  out_info[0] = d.bvh_node_count, out_info[1] = d.bvh_tri_count, out_info[2] = d.bvh_depth | (d.bvh_stack_need << 16u), out_info[3] = uint32_t(std::min<size_t>(context->scene.bvh_bytes, 0xffffffffu));
+  if (out_build_ms != nullptr)
+    *out_build_ms = context->scene.bvh_build_ms;
+  return ETX_HIP_OK;
+}
+
 int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, const etx_abi_camera* camera, uint32_t changed) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
@@ -970,8 +1000,9 @@ int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, c
     context->error = "etx_hip_update_scene: no scene uploaded (etx_hip_upload_scene first)";
     return ETX_HIP_ERROR_STATE;
   }
-  if ((changed & ~uint32_t(ETX_HIP_CHANGED_CAMERA | ETX_HIP_CHANGED_MATERIALS | ETX_HIP_CHANGED_POSITIONS)) != 0u) {
-    context->error = "etx_hip_update_scene: unknown bits in `changed` (anything else that changed needs etx_hip_upload_scene)";
+  if (((changed & ~uint32_t(ETX_HIP_CHANGED_CAMERA | ETX_HIP_CHANGED_MATERIALS | ETX_HIP_CHANGED_POSITIONS | ETX_HIP_REBUILD_BVH)) != 0u) ||
+      ((changed & ETX_HIP_REBUILD_BVH) && ((changed & ETX_HIP_CHANGED_POSITIONS) == 0u))) {
+    context->error = "etx_hip_update_scene: unknown bits in `changed` (anything else that changed needs etx_hip_upload_scene; ETX_HIP_REBUILD_BVH goes with ETX_HIP_CHANGED_POSITIONS)";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
   if ((camera != nullptr) && ((camera->film_size.x != context->scene.film_w) || (camera->film_size.y != context->scene.film_h))) {
@@ -993,7 +1024,7 @@ int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, c
   if (rc)
     return rc;
   if ((changed & (ETX_HIP_CHANGED_POSITIONS | ETX_HIP_CHANGED_MATERIALS)) &&
-      (rc = etxh::update_device_geometry(scene, context->scene, context->stream, (changed & ETX_HIP_CHANGED_POSITIONS) != 0u, context->error)))
+      (rc = etxh::update_device_geometry(scene, context->scene, context->stream, (changed & ETX_HIP_CHANGED_POSITIONS) != 0u, (changed & ETX_HIP_REBUILD_BVH) != 0u, context->error)))
     return rc;
   // pool sizes follow the materials in use (subsurface scenes keep more vertices per path): the lanes' pipelines are set up again
   for (etx_hip_context* helper : context->helpers)
@@ -1605,7 +1636,7 @@ int etx_hip_trace_rays(etx_hip_context* context, const float* rays_8f, uint64_t 
       rc = ETX_HIP_ERROR_HIP;
       break;
     }
-    launch_trace_rays(context->stream, context->scene.host_copy, d_o, d_d, d_h, uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
+    launch_trace_rays(context->stream, context->pipe.scene, d_o, d_d, d_h, uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
     if ((hipMemcpyAsync(hits_4f, d_h, count * sizeof(float4), hipMemcpyDeviceToHost, context->stream) != hipSuccess) || (hipStreamSynchronize(context->stream) != hipSuccess)) {
       context->error = std::string("trace kernel failed: ") + hipGetErrorString(hipGetLastError());
       rc = ETX_HIP_ERROR_HIP;
@@ -1629,11 +1660,11 @@ int etx_hip_trace_rays_device(etx_hip_context* context, const void* d_rays_o_tmi
   HIP_OK(context, hipEventCreate(&e0));
   HIP_OK(context, hipEventCreate(&e1));
   // one untimed launch (code object load, caches)
-  launch_trace_rays(context->stream, context->scene.host_copy, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
+  launch_trace_rays(context->stream, context->pipe.scene, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
     reinterpret_cast<float4*>(d_hits), uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
   HIP_OK(context, hipEventRecord(e0, context->stream));
   for (uint32_t r = 0; r < repeat; ++r)
-    launch_trace_rays(context->stream, context->scene.host_copy, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
+    launch_trace_rays(context->stream, context->pipe.scene, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
       reinterpret_cast<float4*>(d_hits), uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
   HIP_OK(context, hipEventRecord(e1, context->stream));
   HIP_OK(context, hipEventSynchronize(e1));
@@ -1686,10 +1717,17 @@ int etx_hip_kat(etx_hip_context* context, int which, const float* in, uint64_t c
 }
 
 int etx_hip_host_check_bvh(const etx_abi_scene* scene, uint32_t out_info[4]) {
-  if ((scene == nullptr) || (out_info == nullptr))
+  return etx_hip_host_check_bvh_builder(scene, ETX_HIP_BVH_HOST_SAH, out_info);
+}
+
+int etx_hip_host_check_bvh_builder(const etx_abi_scene* scene, int builder, uint32_t out_info[4]) {
+  if ((scene == nullptr) || (out_info == nullptr) || ((builder != ETX_HIP_BVH_HOST_SAH) && (builder != ETX_HIP_BVH_DEVICE_LBVH)))
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   etxh::HostBvh bvh;
-  etxh::build_bvh(scene, bvh);
+  if (builder == ETX_HIP_BVH_DEVICE_LBVH)
+    etxh::build_lbvh_host(scene, bvh);  // the device build, emulated element by element
+  else
+    etxh::build_bvh(scene, bvh);
   const auto* vertices = reinterpret_cast<const etx_abi_vertex*>(scene->vertices.a);
   const auto* triangles = reinterpret_cast<const etx_abi_triangle*>(scene->triangles.a);
   const uint32_t n = uint32_t(scene->triangles.count);
@@ -1706,7 +1744,7 @@ int etx_hip_host_check_bvh(const etx_abi_scene* scene, uint32_t out_info[4]) {
     f3 lo, hi;
   };
   std::vector<Item> stack;
-  if (n > 0)
+  if ((n > 0) && (bvh.nodes.empty() == false))  // the builder's intermediate BVH2 (the binned-SAH build keeps it; a one-leaf scene and the linear build have none)
     stack.push_back({bvh.root, mk3(-kMaxFloat), mk3(kMaxFloat)});
   while (ok && (stack.empty() == false)) {
     Item it = stack.back();
@@ -1739,7 +1777,7 @@ int etx_hip_host_check_bvh(const etx_abi_scene* scene, uint32_t out_info[4]) {
       }
     }
   }
-  for (uint32_t i = 0; ok && (i < n); ++i)
+  for (uint32_t i = 0; ok && (bvh.nodes.empty() == false) && (i < n); ++i)
     ok = seen[i] == 1u;
   // the BVH4 the device traverses: the same invariants (every triangle in exactly one leaf, children inside their boxes),
   // children numbered breadth first (child index > parent index)
@@ -1792,7 +1830,7 @@ int etx_hip_host_check_bvh(const etx_abi_scene* scene, uint32_t out_info[4]) {
   }
   for (uint32_t i = 0; ok && (i < n); ++i)
     ok = seen4[i] == 1u;
-  ok = ok && (bvh.stack_need <= etxd::kStackDepth);
+  ok = ok && (bvh.stack_need <= etxd::kMaxStackDepth);
   out_info[0] = uint32_t(bvh.nodes4.size());
   out_info[1] = uint32_t(bvh.tris.size());
   out_info[2] = bvh.depth4 | (bvh.stack_need << 16u);
@@ -1804,10 +1842,17 @@ int etx_hip_host_check_bvh(const etx_abi_scene* scene, uint32_t out_info[4]) {
 // `count` rays {ox,oy,oz,tmin,dx,dy,dz,tmax} and reports the work: out[0] node visits, out[1] triangle tests, out[2] rays
 // that hit, out[3] deepest stack use. Used by tests (stack bound) and to reason about the traversal kernel's cost.
 int etx_hip_host_bvh_stats(const etx_abi_scene* scene, const float* rays_8f, uint64_t count, uint64_t out[4]) {
-  if ((scene == nullptr) || (rays_8f == nullptr) || (out == nullptr))
+  return etx_hip_host_bvh_stats_builder(scene, ETX_HIP_BVH_HOST_SAH, rays_8f, count, out, nullptr);
+}
+
+int etx_hip_host_bvh_stats_builder(const etx_abi_scene* scene, int builder, const float* rays_8f, uint64_t count, uint64_t out[4], float* hits_2f) {
+  if ((scene == nullptr) || (rays_8f == nullptr) || (out == nullptr) || ((builder != ETX_HIP_BVH_HOST_SAH) && (builder != ETX_HIP_BVH_DEVICE_LBVH)))
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   etxh::HostBvh bvh;
-  etxh::build_bvh(scene, bvh);
+  if (builder == ETX_HIP_BVH_DEVICE_LBVH)
+    etxh::build_lbvh_host(scene, bvh);
+  else
+    etxh::build_bvh(scene, bvh);
   out[0] = out[1] = out[2] = out[3] = 0;
   if (bvh.tris.empty())
     return ETX_HIP_OK;
@@ -1818,6 +1863,7 @@ int etx_hip_host_bvh_stats(const etx_abi_scene* scene, const float* rays_8f, uin
     const float tmin = q[3];
     float best = q[7];
     bool hit = false;
+    float hit_triangle = 0.0f;  // index as float bits
     const f3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     size_t sp = 0;
     int32_t cur = bvh.root4;
@@ -1879,12 +1925,21 @@ int etx_hip_host_bvh_stats(const etx_abi_scene* scene, const float* rays_8f, uin
           if ((u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f) && (tt >= tmin) && (tt <= best)) {
             best = tt;
             hit = true;
+            hit_triangle = tr.v0_index.w;
           }
         }
         cur = sp ? stack[--sp] : kBvhEmptyChild;
       }
     }
     out[2] += hit ? 1u : 0u;
+    if (hits_2f != nullptr) {
+      const uint32_t miss = 0xffffffffu;
+      hits_2f[2 * r + 0] = hit ? best : 0.0f;
+      if (hit)
+        hits_2f[2 * r + 1] = hit_triangle;
+      else
+        memcpy(hits_2f + 2 * r + 1, &miss, 4);
+    }
   }
   return ETX_HIP_OK;
 }

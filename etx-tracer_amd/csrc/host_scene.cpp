@@ -2,6 +2,7 @@
 // and follows the author's disabled device-upload sketch rt.cxx:141-238: deep copy + pointer patching).
 #include "host_scene.h"
 #include "kernels_bvh_build.h"
+#include "dev_lbvh.h"
 #include "dev_bsdf.h"
 #include "dev_bvh.h"
 #include "../../include/etx_hip.h"
@@ -10,6 +11,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <chrono>
+#include <numeric>
 
 namespace etxh {
 
@@ -455,14 +458,166 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
   out.stack_need = need.empty() ? 0u : need[0];
 }
 
+// The cube the Morton keys of the device build quantize: the scene's bounding sphere (Scene::bounding_sphere_*, computed by the host
+// at commit), or the vertices' box when the scene does not carry one.
+void lbvh_cube(const etx_abi_scene* scene, f3& cube_min, float& cube_extent) {
+  const f3 center = a3(scene->bounding_sphere_center);
+  const float radius = scene->bounding_sphere_radius;
+  if ((radius > 0.0f) && std::isfinite(radius) && std::isfinite(center.x) && std::isfinite(center.y) && std::isfinite(center.z)) {
+    cube_min = center - mk3(radius), cube_extent = 2.0f * radius;
+    return;
+  }
+  const auto* vertices = reinterpret_cast<const etx_abi_vertex*>(scene->vertices.a);
+  f3 lo = mk3(kMaxFloat), hi = mk3(-kMaxFloat);
+  for (uint64_t i = 0; i < scene->vertices.count; ++i)
+    lo = fmin3(lo, a3(vertices[i].pos)), hi = fmax3(hi, a3(vertices[i].pos));
+  cube_min = lo;
+  cube_extent = std::max(std::max(hi.x - lo.x, hi.y - lo.y), std::max(hi.z - lo.z, 1.0e-20f));
+}
+
+void build_lbvh_host(const etx_abi_scene* scene, HostBvh& out) {
+  out = {};
+  const uint32_t n = uint32_t(scene->triangles.count);
+  if (n <= kLbvhLeafMax) {  // the device path is not used for such scenes (flat sweep, host build)
+    build_bvh(scene, out);
+    return;
+  }
+  // a DScene over the HOST arrays: the shared per-element functions only follow its pointers
+  DScene view = {};
+  view.vertices = reinterpret_cast<const etx_abi_vertex*>(scene->vertices.a);
+  view.triangles = reinterpret_cast<const etx_abi_triangle*>(scene->triangles.a);
+  view.materials = reinterpret_cast<const etx_abi_material*>(scene->materials.a);
+  view.material_count = uint32_t(scene->materials.count);
+  std::vector<DImage> image_options(scene->images.count);  // the triangle filter reads DImage::options only
+  for (uint64_t i = 0; i < scene->images.count; ++i)
+    image_options[i].options = reinterpret_cast<const etx_abi_image*>(scene->images.a)[i].options;
+  view.images = image_options.data();
+  view.image_count = uint32_t(scene->images.count);
+  view.triangle_count = n;
+  f3 cube_min;
+  float cube_extent = 0.0f;
+  lbvh_cube(scene, cube_min, cube_extent);
+  std::vector<uint64_t> keys(n);
+  std::vector<uint32_t> order(n);
+  for (uint32_t i = 0; i < n; ++i)
+    keys[i] = lbvh_morton_key(view, i, cube_min, 1.0f / cube_extent);
+  std::iota(order.begin(), order.end(), 0u);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });  // a radix sort is stable
+  std::vector<uint64_t> sorted_keys(n);
+  out.tris.assign(n, BvhTri{});
+  for (uint32_t i = 0; i < n; ++i) {
+    sorted_keys[i] = keys[order[i]];
+    out.tris[i].v0_index.w = lbvh_bits_float(order[i]);
+  }
+  for (uint32_t i = 0; i < n; ++i)
+    bvh_triangle_update(view, out.tris.data(), i);
+  std::vector<LbvhNode> radix(n - 1u);
+  for (uint32_t i = 0; i + 1u < n; ++i)
+    radix[i] = lbvh_node(sorted_keys.data(), int(n), int(i));
+  std::vector<uint32_t> queue = {0u}, next;
+  uint32_t base = 0;
+  while (queue.empty() == false) {
+    out.level_offsets.push_back(base);
+    next.clear();
+    out.nodes4.resize(base + queue.size());
+    for (size_t i = 0; i < queue.size(); ++i) {
+      int32_t child[4];
+      uint32_t inner[4];
+      lbvh_collapse(radix.data(), queue[i], child, inner);
+      for (uint32_t k = 0; k < 4u; ++k) {
+        if (inner[k] == kInvalid)
+          continue;
+        child[k] = int32_t(base + queue.size() + next.size());
+        next.push_back(inner[k]);
+      }
+      Bvh4Node& node = out.nodes4[base + i];
+      node = {};
+      for (uint32_t k = 0; k < 4u; ++k)
+        node.child[k] = child[k];
+    }
+    base += uint32_t(queue.size());
+    queue.swap(next);
+  }
+  out.level_offsets.push_back(base);
+  out.depth4 = uint32_t(out.level_offsets.size()) - 1u;
+  out.root4 = 0;
+  view.bvh_tris = out.tris.data();
+  view.bvh_tri_count = n;
+  for (size_t level = out.level_offsets.size(); level-- > 1u;)
+    for (uint32_t i = out.level_offsets[level - 1u]; i < out.level_offsets[level]; ++i)
+      bvh_refit_node(view, out.nodes4.data(), i);
+  out.stack_need = out.nodes4[0].pad[0];
+}
+
+// The tree built on the device into the geometry group: d.vertices / triangles / materials / images are on the device already.
+// `tris`: the traversal triangle buffer to fill (nullptr: allocate one). The node buffer is sized by the triangle count for the build
+// and replaced by one of the exact size afterwards.
+int build_lbvh_tables(const etx_abi_scene* scene, DeviceScene& out, DScene& d, BvhTri* tris, hipStream_t stream, std::string& error) {
+  const uint32_t n = uint32_t(scene->triangles.count);
+  d.triangle_count = n;
+  d.material_count = uint32_t(scene->materials.count);  // the triangle filter of the build reads the material and image tables
+  d.image_count = uint32_t(scene->images.count);
+  Bvh4Node *scratch = nullptr, *nodes = nullptr;
+  if (hipMalloc(&scratch, size_t(n) * sizeof(Bvh4Node)) != hipSuccess) {
+    error = "hipMalloc failed (" + std::to_string(size_t(n) * sizeof(Bvh4Node)) + " bytes for the BVH build)";
+    return ETX_HIP_ERROR_HIP;
+  }
+  if (tris == nullptr) {
+    if (hipMalloc(&tris, size_t(n) * sizeof(BvhTri)) != hipSuccess) {
+      (void)hipFree(scratch);
+      error = "hipMalloc failed (traversal triangles)";
+      return ETX_HIP_ERROR_HIP;
+    }
+    out.geometry_allocations.push_back(tris);
+  }
+  f3 cube_min;
+  float cube_extent = 0.0f;
+  lbvh_cube(scene, cube_min, cube_extent);
+  LbvhResult result;
+  int rc = lbvh_build_device(stream, d, cube_min, cube_extent, scratch, tris, result, error);
+  if ((rc == 0) && (result.stack_need > kMaxStackDepth)) {
+    error = "the device-built BVH needs " + std::to_string(result.stack_need) + " traversal stack entries (depth " + std::to_string(result.depth) + "), the device stack holds " +
+            std::to_string(kMaxStackDepth) + "; build on the host (etx_hip_set_bvh_builder)";
+    rc = ETX_HIP_ERROR_UNSUPPORTED;
+  }
+  if ((rc == 0) && ((hipMalloc(&nodes, size_t(result.node_count) * sizeof(Bvh4Node)) != hipSuccess) ||
+                    (hipMemcpyAsync(nodes, scratch, size_t(result.node_count) * sizeof(Bvh4Node), hipMemcpyDeviceToDevice, stream) != hipSuccess) || (hipStreamSynchronize(stream) != hipSuccess))) {
+    error = "hipMalloc / copy of the built BVH failed";
+    rc = ETX_HIP_ERROR_HIP;
+  }
+  (void)hipFree(scratch);
+  if (rc) {
+    if (nodes != nullptr)
+      (void)hipFree(nodes);
+    return rc;
+  }
+  out.geometry_allocations.push_back(nodes);
+  d.bvh_nodes = nodes, d.bvh_tris = tris;
+  d.bvh_node_count = result.node_count, d.bvh_tri_count = n;
+  d.flat_prims = nullptr, d.flat_info = nullptr, d.flat_prim_count = 0u;
+  d.bvh_root = result.root, d.bvh_depth = result.depth, d.bvh_stack_need = result.stack_need, d.bvh_flat = 0u;
+  out.flat_prims = 0u;
+  out.bvh_levels = result.level_offsets;
+  out.bvh_depth = result.depth;
+  out.bvh_bytes = size_t(result.node_count) * sizeof(Bvh4Node) + size_t(n) * sizeof(BvhTri);
+  out.bvh_build_ms = result.milliseconds;
+  if (getenv("ETX_HIP_VERBOSE"))
+    fprintf(stderr, "[etx_hip] device BVH build: %u triangles -> %u nodes, depth %u, stack %u, %.3f ms\n", n, result.node_count, result.depth, result.stack_need, result.milliseconds);
+  return 0;
+}
+
 // BVH build + upload (geometry group): the BVH4, the traversal triangles, and for a scene of <= kFlatSweepMaxTriangles the flat-sweep primitives
 int build_traversal_tables(const etx_abi_scene* scene, DeviceScene& out, DScene& d, std::string& error) {
   int rc = 0;
+  if (out.device_bvh_build && (scene->triangles.count > kFlatSweepMaxTriangles))
+    return build_lbvh_tables(scene, out, d, nullptr, nullptr, error);
   HostBvh bvh;
+  const auto build_begin = std::chrono::steady_clock::now();
   build_bvh(scene, bvh);
+  out.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - build_begin).count();
   // near-child-first traversal of a four-wide tree pushes at most three children per level
-  if (bvh.stack_need > kStackDepth) {
-    error = "the BVH needs " + std::to_string(bvh.stack_need) + " traversal stack entries (depth " + std::to_string(bvh.depth4) + "), the device stack holds " + std::to_string(kStackDepth);
+  if (bvh.stack_need > kMaxStackDepth) {
+    error = "the BVH needs " + std::to_string(bvh.stack_need) + " traversal stack entries (depth " + std::to_string(bvh.depth4) + "), the device stack holds " + std::to_string(kMaxStackDepth);
     return ETX_HIP_ERROR_UNSUPPORTED;
   }
   if ((rc = upload(out, bvh.nodes4.data(), bvh.nodes4.size(), d.bvh_nodes, error)))
@@ -929,8 +1084,8 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   return 0;
 }
 
-int update_device_geometry(const etx_abi_scene* scene, DeviceScene& out, hipStream_t stream, bool positions_moved, std::string& error) {
-  const DScene& d = out.host_copy;
+int update_device_geometry(const etx_abi_scene* scene, DeviceScene& out, hipStream_t stream, bool positions_moved, bool rebuild, std::string& error) {
+  DScene& d = out.host_copy;
   if ((scene == nullptr) || (scene->vertices.count != d.vertex_count) || (scene->triangles.count != d.triangle_count)) {
     error = "etx_hip_update_scene: the geometry must keep its vertex and triangle counts; use etx_hip_upload_scene";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
@@ -942,6 +1097,15 @@ int update_device_geometry(const etx_abi_scene* scene, DeviceScene& out, hipStre
     return ETX_HIP_ERROR_HIP;
   }
   // a scene small enough for the flat sweep had its traversal tables rebuilt from the host scene (build_device_scene)
+  if ((d.triangle_count > kFlatSweepMaxTriangles) && rebuild) {
+    // a new tree over the moved vertices, built on the device; the traversal triangle buffer is reused, the node buffer replaced
+    Bvh4Node* old_nodes = const_cast<Bvh4Node*>(d.bvh_nodes);
+    if (int rc = build_lbvh_tables(scene, out, d, const_cast<BvhTri*>(d.bvh_tris), stream, error))
+      return rc;
+    out.geometry_allocations.erase(std::remove(out.geometry_allocations.begin(), out.geometry_allocations.end(), static_cast<void*>(old_nodes)), out.geometry_allocations.end());
+    (void)hipFree(old_nodes);
+    return out.sync_device_copy(error);
+  }
   if (d.triangle_count > kFlatSweepMaxTriangles) {
     // positions, and the filter flags that follow the material classes (Void, Boundary, alpha test)
     launch_bvh_triangles_update(stream, d, const_cast<BvhTri*>(d.bvh_tris), d.bvh_tri_count);

@@ -27,6 +27,8 @@ struct DeviceScene {
   std::vector<etxd::DImage> image_table;    // host copy of DScene::images (device pointers inside), reused by an update
   std::vector<const float*> density_grids;  // per medium: its uploaded density grid (nullptr: homogeneous)
   std::vector<uint32_t> bvh_levels;         // first node of every breadth-first level of the BVH4, then the node count (device refit)
+  bool device_bvh_build = false;            // etx_hip_set_bvh_builder: the tree is built on the device (dev_lbvh.h) instead of the host's binned SAH
+  double bvh_build_ms = 0.0;                // time of the last tree build (host: wall clock of build_bvh; device: HIP events)
   uint32_t film_w = 0, film_h = 0;
   float noise_threshold = 0.0f;     // Scene::noise_threshold (adaptive sampling of the path tracer)
   uint32_t bvh_depth = 0;
@@ -55,7 +57,10 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
 // After build_device_scene(keep): brings the kept traversal tables in line with `scene` on `stream` (kernels_bvh_build.hip). The
 // traversal triangles are re-derived (filter flags follow the material classes); positions_moved (same counts and indices): the
 // vertices and triangles of `scene` are copied over the device ones first and the BVH4 boxes refit level by level afterwards.
-int update_device_geometry(const etx_abi_scene* scene, DeviceScene& out, hipStream_t stream, bool positions_moved, std::string& error);
+// rebuild: the tree is built again on the device from the moved vertices (linear BVH) instead of being refit.
+int update_device_geometry(const etx_abi_scene* scene, DeviceScene& out, hipStream_t stream, bool positions_moved, bool rebuild, std::string& error);
+
+
 
 // BVH build exposed for tests of the host logic (no GPU needed)
 struct HostBvh {
@@ -70,5 +75,9 @@ struct HostBvh {
   uint32_t depth = 0;
 };
 void build_bvh(const etx_abi_scene* scene, HostBvh& out);
+
+// The device build (dev_lbvh.h) run on the host, element by element in the order the kernels' indices run: the tree the device
+// WILL build, for tests without a GPU (invariants, stack bound, rays against the SAH tree).
+void build_lbvh_host(const etx_abi_scene* scene, HostBvh& out);
 
 }  // namespace etxh

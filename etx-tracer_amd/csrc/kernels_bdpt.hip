@@ -164,7 +164,7 @@ template <bool kWalk>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, VcmParams it, uint32_t in_set) {
   __shared__ BlockScratch s_scratch;
   __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];
-  const LaneStack stack = {s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize};
+  const LaneStack stack = lane_stack(p.scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
   const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const PathSet& out = p.paths[in_set ^ 1u];
@@ -472,7 +472,7 @@ template <bool kWalk>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, VcmParams it, uint32_t in_set) {
   __shared__ BlockScratch s_scratch;
   __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];  // the sub-steps of a subsurface walk traverse inline (k_bdpt_light_shade)
-  const LaneStack stack = {s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize};
+  const LaneStack stack = lane_stack(p.scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
   const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const PathSet& out = p.paths[in_set ^ 1u];

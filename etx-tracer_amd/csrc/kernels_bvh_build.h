@@ -3,6 +3,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
 #include "dev_scene.h"
 
 namespace etxd {
@@ -12,7 +14,19 @@ namespace etxd {
 void launch_bvh_triangles_update(hipStream_t stream, const DScene& scene, BvhTri* tris, uint32_t count);
 
 // One breadth-first level [first, first + count) of the BVH4: every node's four child boxes recomputed from the leaves' triangles
-// (original vertices) or from the child node's boxes. Levels are refit from the deepest to the root.
+// (original vertices) or from the child node's boxes, and the stack bound of its subtree (pad[0]). Levels are refit from the
+// deepest to the root.
 void launch_bvh_refit_level(hipStream_t stream, const DScene& scene, Bvh4Node* nodes, uint32_t first, uint32_t count);
+
+// The whole tree built on the device (dev_lbvh.h): `scene` holds device vertices / triangles / materials / images and their counts;
+// `nodes` (capacity: triangle_count entries) and `tris` (triangle_count entries) are device buffers that receive the BVH4 and the
+// traversal triangles. Temporaries live for the call. Returns 0 or an ETX_HIP_ERROR_* code with `error` set.
+struct LbvhResult {
+  uint32_t node_count = 0, depth = 0, stack_need = 0;
+  int32_t root = 0;
+  std::vector<uint32_t> level_offsets;  // first node of every breadth-first level, then node_count
+  double milliseconds = 0.0;            // device time of the build (HIP events)
+};
+int lbvh_build_device(hipStream_t stream, DScene scene, f3 cube_min, float cube_extent, Bvh4Node* nodes, BvhTri* tris, LbvhResult& result, std::string& error);
 
 }  // namespace etxd

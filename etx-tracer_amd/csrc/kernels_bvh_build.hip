@@ -1,93 +1,179 @@
 // kernels_bvh_build.hip - device side of the scene build: what Raytracing::commit_changes (sources/etx/rt/rt.cxx:58-88)
 // hands to Embree - rtcSetSharedGeometryBuffer + rtcCommitScene rebuild everything on every scene change (app.cxx:368-399) -
-// done in place on the device tables when only vertex positions or materials changed.
+// done on the device tables. The per-element steps are in dev_lbvh.h (shared with the host emulation the CPU tests check).
 //   k_bvh_triangles_update : BvhTri slots from the scene tables (one thread per slot, 3 gathered vertices in, 48 B out)
-//   k_bvh_refit_level      : BVH4 child boxes of one breadth-first level, bottom up (one thread per node; a leaf reads its <= 8
-//                            triangles' vertices, an inner child the 96 B of boxes of its node). Both are HBM-latency bound and
-//                            tiny next to an iteration: a refit of the 1.2 M-triangle tree moves ~200 MB.
+//   k_bvh_refit_level      : BVH4 child boxes + stack bound of one breadth-first level, bottom up (one thread per node)
+//   k_lbvh_keys / hipcub radix sort / k_lbvh_radix_nodes / k_lbvh_collapse_level : the linear BVH build
+// All of it is HBM-latency bound and tiny next to an iteration: the build of a 1.2 M-triangle tree moves a few hundred MB.
 #include "kernels_bvh_build.h"
-#include "dev_math.h"
+#include "dev_lbvh.h"
+#include "../../include/etx_hip.h"
+
+#include <hipcub/hipcub.hpp>
 
 namespace etxd {
 
 namespace {
 constexpr uint32_t kBuildBlock = 256;
 
-ETX_DEV f3 vertex_position(const DScene& scene, uint32_t index) {
-  const etx_abi_vertex& v = scene.vertices[index];
-  return {v.pos.x, v.pos.y, v.pos.z};
+uint32_t blocks_for(uint32_t count) {
+  return (count + kBuildBlock - 1u) / kBuildBlock;
 }
 }  // namespace
 
 __global__ __launch_bounds__(kBuildBlock) void k_bvh_triangles_update(DScene scene, BvhTri* tris, uint32_t count) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= count)
-    return;
-  const uint32_t ti = __float_as_uint(tris[slot].v0_index.w);
-  const etx_abi_triangle& t = scene.triangles[ti];
-  const f3 p0 = vertex_position(scene, t.i[0]), p1 = vertex_position(scene, t.i[1]), p2 = vertex_position(scene, t.i[2]);
-  uint32_t flags = 0u;
-  if (t.material_index < scene.material_count) {  // the filters of Raytracing::trace / trace_transmittance (host_scene.cpp build_bvh)
-    const etx_abi_material& m = scene.materials[t.material_index];
-    if (m.cls == ETX_MAT_VOID)
-      flags |= kTriVoid;
-    if (m.cls == ETX_MAT_BOUNDARY)
-      flags |= kTriBoundary;
-    const bool alpha_image = (m.scattering.image_index != kInvalid) && (m.scattering.image_index < scene.image_count) && ((scene.images[m.scattering.image_index].options & ETX_IMAGE_HAS_ALPHA) != 0u);
-    if ((m.opacity < 1.0f) || alpha_image)
-      flags |= kTriAlphaTested;
-  }
-  const f3 e1 = p1 - p0, e2 = p2 - p0;
-  tris[slot].v0_index = make_float4(p0.x, p0.y, p0.z, __uint_as_float(ti));
-  tris[slot].e1_flags = make_float4(e1.x, e1.y, e1.z, __uint_as_float(flags));
-  tris[slot].e2_mat = make_float4(e2.x, e2.y, e2.z, __uint_as_float(t.material_index));
+  if (slot < count)
+    bvh_triangle_update(scene, tris, slot);
 }
 
 __global__ __launch_bounds__(kBuildBlock) void k_bvh_refit_level(DScene scene, Bvh4Node* nodes, uint32_t first, uint32_t count) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count)
+    bvh_refit_node(scene, nodes, first + i);
+}
+
+__global__ __launch_bounds__(kBuildBlock) void k_lbvh_keys(DScene scene, f3 cube_min, float inv_extent, uint64_t* keys, uint32_t* values, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count)
     return;
-  Bvh4Node& node = nodes[first + i];
-  float lo[3][4], hi[3][4];
+  keys[i] = lbvh_morton_key(scene, i, cube_min, inv_extent);
+  values[i] = i;
+}
+
+// sorted triangle order -> the slots of the traversal triangles (filled in by k_bvh_triangles_update afterwards)
+__global__ __launch_bounds__(kBuildBlock) void k_lbvh_assign_slots(const uint32_t* sorted_values, BvhTri* tris, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count)
+    tris[i].v0_index.w = __uint_as_float(sorted_values[i]);
+}
+
+__global__ __launch_bounds__(kBuildBlock) void k_lbvh_radix_nodes(const uint64_t* sorted_keys, LbvhNode* radix, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i + 1u < count)
+    radix[i] = lbvh_node(sorted_keys, int(count), int(i));
+}
+
+// One breadth-first level: `queue` holds the radix nodes that become the BVH4 nodes [base, base + count); their inner children are
+// appended to `next_queue` (slot from an atomic counter: the order inside a level is arbitrary) and numbered base + count + slot.
+__global__ __launch_bounds__(kBuildBlock) void k_lbvh_collapse_level(const LbvhNode* radix, const uint32_t* queue, uint32_t base, uint32_t count, Bvh4Node* nodes, uint32_t* next_queue,
+  uint32_t* next_count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count)
+    return;
+  int32_t child[4];
+  uint32_t inner[4];
+  lbvh_collapse(radix, queue[i], child, inner);
   for (uint32_t k = 0; k < 4u; ++k) {
-    f3 bmin = mk3(kMaxFloat), bmax = mk3(-kMaxFloat);  // an unused slot keeps the empty box the builder gave it
-    const int32_t child = node.child[k];
-    if (child == kBvhEmptyChild) {
-    } else if (child < 0) {
-      const uint32_t leaf = uint32_t(~child), leaf_first = leaf >> 3u, leaf_count = (leaf & 7u) + 1u;
-      for (uint32_t s = 0; s < leaf_count; ++s) {
-        const etx_abi_triangle& t = scene.triangles[__float_as_uint(scene.bvh_tris[leaf_first + s].v0_index.w)];
-        for (uint32_t c = 0; c < 3u; ++c) {  // the vertices themselves, as the host builder bounds them (not v0 + e: one rounding off)
-          const f3 p = vertex_position(scene, t.i[c]);
-          bmin = fmin3(bmin, p), bmax = fmax3(bmax, p);
-        }
-      }
-    } else {
-      const Bvh4Node& below = nodes[child];  // a deeper level: already refit
-      bmin = {fminf(fminf(below.lo_x.x, below.lo_x.y), fminf(below.lo_x.z, below.lo_x.w)), fminf(fminf(below.lo_y.x, below.lo_y.y), fminf(below.lo_y.z, below.lo_y.w)),
-        fminf(fminf(below.lo_z.x, below.lo_z.y), fminf(below.lo_z.z, below.lo_z.w))};
-      bmax = {fmaxf(fmaxf(below.hi_x.x, below.hi_x.y), fmaxf(below.hi_x.z, below.hi_x.w)), fmaxf(fmaxf(below.hi_y.x, below.hi_y.y), fmaxf(below.hi_y.z, below.hi_y.w)),
-        fmaxf(fmaxf(below.hi_z.x, below.hi_z.y), fmaxf(below.hi_z.z, below.hi_z.w))};
-    }
-    lo[0][k] = bmin.x, lo[1][k] = bmin.y, lo[2][k] = bmin.z;
-    hi[0][k] = bmax.x, hi[1][k] = bmax.y, hi[2][k] = bmax.z;
+    if (inner[k] == kInvalid)
+      continue;
+    const uint32_t slot = atomicAdd(next_count, 1u);
+    next_queue[slot] = inner[k];
+    child[k] = int32_t(base + count + slot);
   }
-  node.lo_x = make_float4(lo[0][0], lo[0][1], lo[0][2], lo[0][3]);
-  node.lo_y = make_float4(lo[1][0], lo[1][1], lo[1][2], lo[1][3]);
-  node.lo_z = make_float4(lo[2][0], lo[2][1], lo[2][2], lo[2][3]);
-  node.hi_x = make_float4(hi[0][0], hi[0][1], hi[0][2], hi[0][3]);
-  node.hi_y = make_float4(hi[1][0], hi[1][1], hi[1][2], hi[1][3]);
-  node.hi_z = make_float4(hi[2][0], hi[2][1], hi[2][2], hi[2][3]);
+  Bvh4Node& node = nodes[base + i];
+  node.child[0] = child[0], node.child[1] = child[1], node.child[2] = child[2], node.child[3] = child[3];
+  node.pad[0] = node.pad[1] = node.pad[2] = node.pad[3] = 0u;
 }
 
 void launch_bvh_triangles_update(hipStream_t stream, const DScene& scene, BvhTri* tris, uint32_t count) {
   if (count > 0u)
-    hipLaunchKernelGGL(k_bvh_triangles_update, dim3((count + kBuildBlock - 1u) / kBuildBlock), dim3(kBuildBlock), 0, stream, scene, tris, count);
+    hipLaunchKernelGGL(k_bvh_triangles_update, dim3(blocks_for(count)), dim3(kBuildBlock), 0, stream, scene, tris, count);
 }
 
 void launch_bvh_refit_level(hipStream_t stream, const DScene& scene, Bvh4Node* nodes, uint32_t first, uint32_t count) {
   if (count > 0u)
-    hipLaunchKernelGGL(k_bvh_refit_level, dim3((count + kBuildBlock - 1u) / kBuildBlock), dim3(kBuildBlock), 0, stream, scene, nodes, first, count);
+    hipLaunchKernelGGL(k_bvh_refit_level, dim3(blocks_for(count)), dim3(kBuildBlock), 0, stream, scene, nodes, first, count);
+}
+
+int lbvh_build_device(hipStream_t stream, DScene scene, f3 cube_min, float cube_extent, Bvh4Node* nodes, BvhTri* tris, LbvhResult& result, std::string& error) {
+  const uint32_t n = scene.triangle_count;
+  result = {};
+  if ((n <= kLbvhLeafMax) || (n >= (1u << 28u)) || (!(cube_extent > 0.0f))) {
+    error = "device BVH build: " + std::to_string(n) + " triangles in a cube of extent " + std::to_string(cube_extent) + " (needs more than one leaf, fewer than 2^28 triangles, a finite scene)";
+    return ETX_HIP_ERROR_UNSUPPORTED;
+  }
+  uint64_t *keys = nullptr, *sorted_keys = nullptr;
+  uint32_t *values = nullptr, *sorted_values = nullptr, *queue_a = nullptr, *queue_b = nullptr, *counter = nullptr;
+  LbvhNode* radix = nullptr;
+  void* sort_storage = nullptr;
+  size_t sort_bytes = 0;
+  hipEvent_t begin = nullptr, end = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {static_cast<void*>(keys), static_cast<void*>(sorted_keys), static_cast<void*>(values), static_cast<void*>(sorted_values), static_cast<void*>(queue_a),
+           static_cast<void*>(queue_b), static_cast<void*>(counter), static_cast<void*>(radix), sort_storage})
+      if (p != nullptr)
+        (void)hipFree(p);
+    if (begin != nullptr)
+      (void)hipEventDestroy(begin);
+    if (end != nullptr)
+      (void)hipEventDestroy(end);
+  };
+  auto fail = [&](const char* what) {
+    error = std::string("device BVH build: ") + what + " failed (" + hipGetErrorString(hipGetLastError()) + ")";
+    cleanup();
+    return ETX_HIP_ERROR_HIP;
+  };
+  if ((hipMalloc(&keys, n * sizeof(uint64_t)) != hipSuccess) || (hipMalloc(&sorted_keys, n * sizeof(uint64_t)) != hipSuccess) || (hipMalloc(&values, n * sizeof(uint32_t)) != hipSuccess) ||
+      (hipMalloc(&sorted_values, n * sizeof(uint32_t)) != hipSuccess) || (hipMalloc(&queue_a, n * sizeof(uint32_t)) != hipSuccess) || (hipMalloc(&queue_b, n * sizeof(uint32_t)) != hipSuccess) ||
+      (hipMalloc(&counter, sizeof(uint32_t)) != hipSuccess) || (hipMalloc(&radix, n * sizeof(LbvhNode)) != hipSuccess))
+    return fail("hipMalloc of the temporaries");
+  if (hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, sorted_keys, values, sorted_values, int(n), 0, 63, stream) != hipSuccess)
+    return fail("sizing the radix sort");
+  if (hipMalloc(&sort_storage, std::max<size_t>(sort_bytes, 16)) != hipSuccess)
+    return fail("hipMalloc of the sort storage");
+  if ((hipEventCreate(&begin) != hipSuccess) || (hipEventCreate(&end) != hipSuccess))
+    return fail("hipEventCreate");
+  (void)hipEventRecord(begin, stream);
+
+  hipLaunchKernelGGL(k_lbvh_keys, dim3(blocks_for(n)), dim3(kBuildBlock), 0, stream, scene, cube_min, 1.0f / cube_extent, keys, values, n);
+  if (hipcub::DeviceRadixSort::SortPairs(sort_storage, sort_bytes, keys, sorted_keys, values, sorted_values, int(n), 0, 63, stream) != hipSuccess)
+    return fail("the radix sort");
+  hipLaunchKernelGGL(k_lbvh_assign_slots, dim3(blocks_for(n)), dim3(kBuildBlock), 0, stream, sorted_values, tris, n);
+  scene.bvh_tris = tris;  // the refit reads the slots' triangle indices through the scene
+  scene.bvh_tri_count = n;
+  launch_bvh_triangles_update(stream, scene, tris, n);
+  hipLaunchKernelGGL(k_lbvh_radix_nodes, dim3(blocks_for(n)), dim3(kBuildBlock), 0, stream, sorted_keys, radix, n);
+
+  // collapse, level by level; the host reads one counter per level (a build step, not the render loop)
+  const uint32_t root_source = 0u;  // radix node 0 covers every key
+  if (hipMemcpyAsync(queue_a, &root_source, sizeof(uint32_t), hipMemcpyHostToDevice, stream) != hipSuccess)
+    return fail("hipMemcpy of the root");
+  uint32_t base = 0u, count = 1u;
+  uint32_t *queue = queue_a, *next_queue = queue_b;
+  while (count > 0u) {
+    if (uint64_t(base) + count > uint64_t(n)) {
+      error = "device BVH build: more nodes than triangles (internal error)";
+      cleanup();
+      return ETX_HIP_ERROR_HIP;
+    }
+    result.level_offsets.push_back(base);
+    if (hipMemsetAsync(counter, 0, sizeof(uint32_t), stream) != hipSuccess)
+      return fail("hipMemset of the level counter");
+    hipLaunchKernelGGL(k_lbvh_collapse_level, dim3(blocks_for(count)), dim3(kBuildBlock), 0, stream, radix, queue, base, count, nodes, next_queue, counter);
+    uint32_t next = 0u;
+    if ((hipMemcpyAsync(&next, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) || (hipStreamSynchronize(stream) != hipSuccess))
+      return fail("reading the level counter");
+    base += count;
+    count = next;
+    std::swap(queue, next_queue);
+  }
+  result.node_count = base;
+  result.level_offsets.push_back(base);
+  result.depth = uint32_t(result.level_offsets.size()) - 1u;
+  result.root = 0;
+  for (size_t level = result.level_offsets.size(); level-- > 1u;)
+    launch_bvh_refit_level(stream, scene, nodes, result.level_offsets[level - 1u], result.level_offsets[level] - result.level_offsets[level - 1u]);
+  Bvh4Node root_node;
+  (void)hipEventRecord(end, stream);
+  if ((hipMemcpyAsync(&root_node, nodes, sizeof(Bvh4Node), hipMemcpyDeviceToHost, stream) != hipSuccess) || (hipStreamSynchronize(stream) != hipSuccess) || (hipGetLastError() != hipSuccess))
+    return fail("the box pass");
+  result.stack_need = root_node.pad[0];
+  float ms = 0.0f;
+  (void)hipEventElapsedTime(&ms, begin, end);
+  result.milliseconds = ms;
+  cleanup();
+  return 0;
 }
 
 }  // namespace etxd

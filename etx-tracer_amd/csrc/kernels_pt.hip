@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kBlockSize) void k_pt_shade(Pipeline p, VcmParams i
   constexpr bool kWalk = kGroup == kShadeGroupSubsurface;
   __shared__ BlockScratch s_scratch;
   __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];  // the subsurface walk traverses inline
-  const LaneStack stack = {s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize};
+  const LaneStack stack = lane_stack(p.scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
   const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const PathSet& out = p.paths[in_set ^ 1u];

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kBlockSize) void k_light_shade(Pipeline p, VcmParam
   uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
   __shared__ BlockScratch s_scratch;
   __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];  // inline traversal of the subsurface walk
-  const LaneStack stack = {s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize};
+  const LaneStack stack = lane_stack(p.scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
   const BlockSlots slots = {&s_scratch};
   ETX_BLOCK_LOOP(count, j) {
     bool valid = j < count;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmPara
   uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
   __shared__ BlockScratch s_scratch;
   __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];
-  const LaneStack stack = {s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize};
+  const LaneStack stack = lane_stack(p.scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
   const BlockSlots slots = {&s_scratch};
   ETX_BLOCK_LOOP(count, j) {
     bool valid = j < count;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlockSize) void k_path_tail(Pipeline p, VcmParams 
   const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
-  LaneStack stack = {s_stack + threadIdx.x, kBlockSize};
+  LaneStack stack = lane_stack(p.scene, s_stack + threadIdx.x, kBlockSize);
   unsigned long long rays = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     PathState st = load_path(in, i);

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
   }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t stride = gridDim.x * blockDim.x;
-  LaneStack stack = {s_stack + (kFlat ? 0u : threadIdx.x), kBlockSize};
+  LaneStack stack = lane_stack(scene, s_stack + (kFlat ? 0u : threadIdx.x), kBlockSize);
   BvhNodes nodes = global_nodes(scene);
   if ((kFlat == false) && (blockIdx.x * blockDim.x < count))  // workgroup-uniform: this workgroup has rays
     nodes = stage_nodes(scene, s_nodes, min(kLdsNodes, lds_node_limit));
@@ -77,7 +77,22 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
 // LDS per workgroup: the per-lane stacks (32 KB) + the first kLdsNodesPersistent nodes of the tree (top levels, 8 KB).
 constexpr uint32_t kRefillLanes = 16;
 
-template <bool kFromCounter, uint32_t kStack, uint32_t kLdsNodesPersistent>
+template <bool kDeep>
+struct TraversalStack {
+  typedef FastLaneStack Type;
+  static ETX_DEV Type make(const DScene&, int32_t* lds_slot, uint32_t stride) {
+    return {lds_slot, stride};
+  }
+};
+template <>
+struct TraversalStack<true> {  // the tree's bound exceeds the LDS part: entries above kStackDepth go to DScene::stack_spill
+  typedef LaneStack Type;
+  static ETX_DEV Type make(const DScene& scene, int32_t* lds_slot, uint32_t stride) {
+    return lane_stack(scene, lds_slot, stride);
+  }
+};
+
+template <bool kFromCounter, uint32_t kStack, uint32_t kLdsNodesPersistent, bool kDeep = false>
 __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
   float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit,
   uint32_t refill_lanes, uint32_t pass_stat) {
@@ -107,7 +122,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene s
   if (count == 0u)
     return;
   const BvhNodes nodes = stage_nodes(scene, s_nodes, min(kLdsNodesPersistent, lds_node_limit));
-  const LaneStack stack = {s_stack + threadIdx.x, kBlockSize};
+  const typename TraversalStack<kDeep>::Type stack = TraversalStack<kDeep>::make(scene, s_stack + threadIdx.x, kBlockSize);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6u;
   const uint32_t wave_count = (gridDim.x * blockDim.x) >> 6u;
@@ -373,7 +388,10 @@ static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const flo
   hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, STACK, NODES>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count, round_mirror, \
     round_tag, lds_limit(), refill, pass_stat)
   const uint32_t need = scene.bvh_stack_need;
-  if (variant == 1u) {  // experiments: twice the staged nodes
+  if (need > kStackDepth) {  // a deep tree (> ~40 000 triangles): the checked stack with its global spill (dev_bvh.h LaneStack)
+    hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, kStackDepth, 64u, true>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count,
+      round_mirror, round_tag, lds_limit(), refill, pass_stat);
+  } else if (variant == 1u) {  // experiments: twice the staged nodes
     if (need <= 16u)
       ETX_LAUNCH_BVH(16u, 128u);
     else if (need <= 24u)
@@ -407,7 +425,7 @@ void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, u
 // Shadow kernel: segment queue -> transmittance -> film atomics (Raytracing::trace_transmittance, rt.cxx:468-579, plus
 // the accumulation the callers do: vcm_cpu.cxx:148-153 light splats, vcm_shared.hxx:1049-1053 camera gathers).
 // Algorithmic traffic: 48 B request in, 12 B of float atomics out for visible segments.
-template <bool kFlat>
+template <bool kFlat, bool kDeep = false>
 __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
   __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
   __shared__ float4 s_nodes[kFlat ? 1 : kLdsNodes * 8u];
@@ -415,7 +433,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
   const uint32_t count = min(p.counters[kCntShadow], p.shadow.capacity);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t stride = gridDim.x * blockDim.x;
-  LaneStack stack = {s_stack + (kFlat ? 0u : threadIdx.x), kBlockSize};  // a flat scene only touches it when a segment crosses > 4 boundaries
+  const typename TraversalStack<kDeep>::Type stack = TraversalStack<kDeep>::make(scene, s_stack + (kFlat ? 0u : threadIdx.x), kBlockSize);  // a flat scene only touches it when a segment crosses > 4 boundaries
   uint32_t splats = 0;
   BvhNodes nodes = global_nodes(scene);
   if ((kFlat == false) && (blockIdx.x * blockDim.x < count))
@@ -476,6 +494,8 @@ void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_ite
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.shadow.capacity, max_items) + kBlockSize - 1) / kBlockSize));
   if (flat)
     hipLaunchKernelGGL(k_trace_shadow<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p);
+  else if (p.scene.bvh_stack_need > kStackDepth)
+    hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);
   else
     hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p);
 }

@@ -17,6 +17,7 @@ CAMERA_SIZE = 176  # sizeof(etx::Camera) == sizeof(etx_abi_camera)
 # field offsets inside etx_abi_scene / etx_abi_camera used on the host side (include/etx_scene_abi.h)
 _SCENE_TRIANGLES = 16
 _SCENE_VERTICES = 0
+_SCENE_TRIANGLE_TO_EMITTER = 32
 _SCENE_MATERIALS = 48
 _SCENE_EMITTERS = 80
 _SCENE_SAMPLES = 464
@@ -116,6 +117,25 @@ class SceneSnapshot:
         ptr, count = self._array(_SCENE_TRIANGLES)
         buf = (ctypes.c_uint32 * (count * 8)).from_address(ptr)
         return np.frombuffer(buf, dtype=np.uint32).reshape(count, 8)
+
+    def replace_geometry(self, vertices, triangles, triangle_to_emitter):
+        """New vertex / triangle / triangle_to_emitter arrays for the scene (float32 (V, 14), uint32 (T, 8), uint32 (T,)): what a host
+        with changed TOPOLOGY hands to etx_hip_upload_scene. The snapshot keeps the arrays alive; emitter instances name triangles
+        by index, so the caller keeps emissive triangles where they were."""
+        vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 14)
+        triangles = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 8)
+        triangle_to_emitter = np.ascontiguousarray(triangle_to_emitter, dtype=np.uint32).reshape(-1)
+        if (triangle_to_emitter.shape[0] != triangles.shape[0]) or (int(triangles[:, 0:3].max()) >= vertices.shape[0]):
+            raise ValueError("replace_geometry: one emitter entry per triangle, vertex indices inside the vertex array")
+        self._geometry = (vertices, triangles, triangle_to_emitter)
+        for offset, array in ((_SCENE_VERTICES, vertices), (_SCENE_TRIANGLES, triangles), (_SCENE_TRIANGLE_TO_EMITTER, triangle_to_emitter)):
+            ctypes.c_uint64.from_address(self.scene_address + offset).value = array.ctypes.data
+            ctypes.c_uint64.from_address(self.scene_address + offset + 8).value = array.shape[0]
+        self.version += 1
+
+    def triangle_to_emitter(self):
+        ptr, count = self._array(_SCENE_TRIANGLE_TO_EMITTER)
+        return np.frombuffer((ctypes.c_uint32 * count).from_address(ptr), dtype=np.uint32)
 
     def materials(self):
         """writable uint32 view (count, 50) of the etx::Material table (class at column 41): for hosts / tests that edit a material

@@ -93,9 +93,23 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
  * The small tables and the camera are rebuilt from `scene` / `camera` in any case; vertices, triangles, BVH, image pixels and
  * density grids stay resident. Counts of vertices, triangles, images and media must be unchanged (ETX_HIP_ERROR_INVALID_ARGUMENT
  * otherwise; on any error the context holds no scene, as after a failed upload). Waits for the iterations in flight; the next
- * etx_hip_begin renders the edited scene. */
-enum { ETX_HIP_CHANGED_CAMERA = 1, ETX_HIP_CHANGED_MATERIALS = 2, ETX_HIP_CHANGED_POSITIONS = 4 };
+ * etx_hip_begin renders the edited scene.
+ *   ETX_HIP_REBUILD_BVH       with ETX_HIP_CHANGED_POSITIONS: instead of the refit, a new tree is built over the moved vertices ON THE
+ *                             DEVICE (linear BVH, see etx_hip_set_bvh_builder) - for deformations a refit tree traverses badly */
+enum { ETX_HIP_CHANGED_CAMERA = 1, ETX_HIP_CHANGED_MATERIALS = 2, ETX_HIP_CHANGED_POSITIONS = 4, ETX_HIP_REBUILD_BVH = 8 };
 int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, const etx_abi_camera* camera, uint32_t changed);
+
+/* Who builds the traversal tree of the NEXT etx_hip_upload_scene (Raytracing::commit_changes hands this to Embree, rt.cxx:66-88):
+ *   ETX_HIP_BVH_HOST_SAH     (default) binned-SAH BVH2 on the host, collapsed to the four-wide nodes: the tree that traverses fastest
+ *   ETX_HIP_BVH_DEVICE_LBVH  linear BVH on the device (dev_lbvh.h: 63-bit Morton keys, radix sort, Karras' binary radix tree,
+ *                            collapse to four-wide breadth-first nodes, boxes bottom-up): milliseconds instead of seconds for
+ *                            10^5..10^6 triangles - time to first iteration, geometry that changes every frame - at a traversal
+ *                            cost measured in DESIGN.md. Scenes of <= 64 triangles are swept linearly and always built on the host.
+ * etx_hip_bvh_info: {BVH4 nodes, triangles, depth | traversal stack entries << 16, bytes} of the uploaded scene and the time its
+ * tree took to build (host: wall clock of the builder; device: HIP events around the build kernels), in milliseconds. */
+enum { ETX_HIP_BVH_HOST_SAH = 0, ETX_HIP_BVH_DEVICE_LBVH = 1 };
+int etx_hip_set_bvh_builder(etx_hip_context* context, int builder);
+int etx_hip_bvh_info(etx_hip_context* context, uint32_t out_info[4], double* out_build_ms);
 
 /* The blue-noise samples options.blue_noise needs (vcm_shared.hxx:941-945, 1018-1022). The host's sampler is
  * sample_blue_noise(pixel, scene.samples, iteration, dimension) (path_tracing.cxx:173-178 -> thirdparty/bluenoise
@@ -260,6 +274,12 @@ int etx_hip_host_check_bvh(const etx_abi_scene* scene, uint32_t out_info[4]);
  * {ox,oy,oz,tmin,dx,dy,dz,tmax} and returns the work they do: out[0] node visits, out[1] triangle tests, out[2] rays that hit,
  * out[3] deepest use of the traversal stack. */
 int etx_hip_host_bvh_stats(const etx_abi_scene* scene, const float* rays_8f, uint64_t count, uint64_t out[4]);
+
+/* The same two for either builder (ETX_HIP_BVH_*). ETX_HIP_BVH_DEVICE_LBVH runs the DEVICE build on the host, element by element
+ * through the functions the kernels call (dev_lbvh.h): the tree the device will build can be checked without a GPU. hits_2f
+ * (nullable): per ray {t, triangle index as u32 bits (0xffffffff: miss)} of the walk. */
+int etx_hip_host_check_bvh_builder(const etx_abi_scene* scene, int builder, uint32_t out_info[4]);
+int etx_hip_host_bvh_stats_builder(const etx_abi_scene* scene, int builder, const float* rays_8f, uint64_t count, uint64_t out[4], float* hits_2f);
 
 #ifdef __cplusplus
 }

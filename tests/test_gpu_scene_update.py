@@ -160,3 +160,101 @@ def test_update_scene_argument_errors(etx, golden_dir):
     with pytest.raises(etx.EtxHipError, match="film size"):
         ctx.update_scene(bigger, etx.api.CHANGED_CAMERA)
     ctx.close()
+
+
+def replicate_gems(etx, golden_dir, copies, seed=9):
+    """the gems scene with `copies` scaled copies of its gem triangles scattered through the box: 10^4..10^6 triangles of real
+    shape statistics (small closed facetted objects) without a scene file of that size"""
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_gems_128.etxscene"))
+    vertices, triangles, to_emitter = snap.vertices().copy(), snap.triangles().copy(), snap.triangle_to_emitter().copy()
+    classes = snap.material_classes()
+    gem = np.nonzero(np.isin(classes[triangles[:, 3]], (3, 4)))[0]
+    rng = np.random.default_rng(seed)
+    new_vertices, new_triangles = [vertices], [triangles]
+    base = vertices.shape[0]
+    corner_rows = vertices[triangles[gem, 0:3].reshape(-1).astype(np.int64)]  # (3 * G, 14): unshared copies
+    centre = corner_rows[:, 0:3].mean(axis=0)
+    for _ in range(copies):
+        scale = np.float32(rng.uniform(0.1, 0.3))
+        offset = np.float32([rng.uniform(-0.8, 0.8), rng.uniform(0.15, 1.8), rng.uniform(-0.8, 0.8)])
+        rows = corner_rows.copy()
+        rows[:, 0:3] = (rows[:, 0:3] - centre) * scale + offset
+        tri = triangles[gem].copy()
+        tri[:, 0:3] = base + np.arange(3 * len(gem), dtype=np.uint32).reshape(-1, 3)
+        new_vertices.append(rows)
+        new_triangles.append(tri)
+        base += rows.shape[0]
+    all_triangles = np.concatenate(new_triangles)
+    snap.replace_geometry(np.concatenate(new_vertices), all_triangles, np.concatenate([to_emitter, np.full(all_triangles.shape[0] - to_emitter.shape[0], 0xFFFFFFFF, dtype=np.uint32)]))
+    return snap
+
+
+def test_device_built_tree_is_the_emulated_one_and_finds_the_sah_hits(etx, golden_dir):
+    """etx_hip_set_bvh_builder(ETX_HIP_BVH_DEVICE_LBVH): the kernels of kernels_bvh_build.hip build the tree the host emulation of the
+    same per-element functions builds (tests/test_host_lbvh.py checks that one without a GPU) - same node count, depth and stack
+    bound - and its closest hits are those of the binned-SAH tree."""
+    snap = replicate_gems(etx, golden_dir, 40)
+    assert snap.triangle_count > 100000
+    rc, emulated = etx.api.host_check_bvh(snap, builder=etx.api.BVH_DEVICE_LBVH)
+    assert rc == 0
+    linear = etx.api.Context(0)
+    linear.set_bvh_builder(etx.api.BVH_DEVICE_LBVH)
+    linear.upload_scene(snap)
+    built = linear.bvh_info()
+    assert (built["nodes"], built["depth"], built["stack_need"], built["triangles"]) == (emulated["nodes"], emulated["depth"], emulated["stack_need"], emulated["triangles"])
+    sah = etx.api.Context(0)
+    sah.upload_scene(snap)
+    reference = sah.bvh_info()
+    rays = make_rays(200000, 31)
+    hits_l, hits_s = linear.trace_rays(rays), sah.trace_rays(rays)
+    same = hit_triangles(hits_l) == hit_triangles(hits_s)
+    assert same.mean() > 0.9995 and (hit_triangles(hits_s) >= 0).mean() > 0.4
+    np.testing.assert_allclose(hits_l[same, 2], hits_s[same, 2], rtol=1e-6, atol=1e-6)
+    print("tree build, %d triangles: device linear %.2f ms (%d nodes, depth %d, stack %d), host binned SAH %.1f ms (%d nodes, depth %d, stack %d)" % (
+        snap.triangle_count, built["build_ms"], built["nodes"], built["depth"], built["stack_need"], reference["build_ms"], reference["nodes"], reference["depth"], reference["stack_need"]))
+    assert built["build_ms"] < reference["build_ms"]
+    # the renders agree: same seeds, same hits
+    films = []
+    for ctx_builder in (etx.api.BVH_DEVICE_LBVH, etx.api.BVH_HOST_SAH):
+        snap.samples = 4
+        integ = etx.HIPPathTracing(snap)
+        integ.context.set_bvh_builder(ctx_builder)
+        integ.options()["bn"] = False
+        z = np.load(os.path.join(golden_dir, "cie_observer.npz"))
+        integ.cie_table = (z["xyz"], float(z["first_wavelength"]))
+        films.append(render(etx, integ))
+        integ.context.close()
+    assert_same_render(films[0], films[1], "linear tree vs SAH tree")
+    linear.close()
+    sah.close()
+
+
+def test_rebuild_on_the_device_after_moved_vertices(etx, golden_dir):
+    """ETX_HIP_CHANGED_POSITIONS | ETX_HIP_REBUILD_BVH: a new tree over the moved vertices instead of the refit."""
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_gems_128.etxscene"))
+    rays = make_rays(60000, 12)
+    ctx = etx.api.Context(0)
+    ctx.upload_scene(snap)  # host tree first
+    before = ctx.bvh_info()
+    move_material(snap, gem_material(snap), (0.11, 0.07, -0.05))
+    ctx.update_scene(snap, etx.api.CHANGED_POSITIONS | etx.api.REBUILD_BVH)
+    after = ctx.bvh_info()
+    assert after["triangles"] == before["triangles"] and after["nodes"] != before["nodes"]  # a different builder's tree
+    rebuilt = ctx.trace_rays(rays)
+    fresh = etx.api.Context(0)
+    fresh.upload_scene(snap)
+    reference = fresh.trace_rays(rays)
+    same = hit_triangles(rebuilt) == hit_triangles(reference)
+    assert same.mean() > 0.9995
+    np.testing.assert_allclose(rebuilt[same, 2], reference[same, 2], rtol=1e-6, atol=1e-6)
+    # and a refit of the rebuilt tree works like a refit of the host's
+    move_material(snap, gem_material(snap), (-0.05, 0.0, 0.02))
+    ctx.update_scene(snap, etx.api.CHANGED_POSITIONS)
+    fresh.upload_scene(snap)
+    refit, reference = ctx.trace_rays(rays), fresh.trace_rays(rays)
+    same = hit_triangles(refit) == hit_triangles(reference)
+    assert same.mean() > 0.9995
+    with pytest.raises(etx.EtxHipError, match="REBUILD_BVH"):
+        ctx.update_scene(snap, etx.api.REBUILD_BVH)
+    ctx.close()
+    fresh.close()
