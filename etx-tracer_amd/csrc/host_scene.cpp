@@ -12,6 +12,8 @@
 #include <cmath>
 #include <cstring>
 #include <chrono>
+#include <future>
+#include <thread>
 #include <numeric>
 
 namespace etxh {
@@ -81,7 +83,7 @@ struct Builder {
     int32_t left = -1, right = -1;  // children (TmpNode index) or -1 for leaf
     uint32_t first = 0, count = 0;
   };
-  std::vector<Prim> prims;
+  Prim* prims = nullptr;  // the primitives of the whole scene (owner: build_bvh); a builder works on its range of them
   std::vector<TmpNode> nodes;
   uint32_t max_depth = 0;
   float traversal_cost = 1.0f;
@@ -94,19 +96,18 @@ struct Builder {
     return a == 0 ? v.x : (a == 1 ? v.y : v.z);
   }
 
-  uint32_t subdivide(uint32_t first, uint32_t count, uint32_t depth) {
-    uint32_t index = uint32_t(nodes.size());
-    nodes.emplace_back();
-    max_depth = std::max(max_depth, depth);
-    f3 mn = mk3(kMaxFloat), mx = mk3(-kMaxFloat), cmn = mk3(kMaxFloat), cmx = mk3(-kMaxFloat);
+  // Bounds of the range and, unless it becomes a leaf, its binned-SAH split: the range is partitioned in place, [first, mid) goes left.
+  bool split(uint32_t first, uint32_t count, f3& mn, f3& mx, uint32_t& mid) {
+    Prim* const prims = this->prims;
+    mn = mk3(kMaxFloat), mx = mk3(-kMaxFloat);
+    f3 cmn = mk3(kMaxFloat), cmx = mk3(-kMaxFloat);
     for (uint32_t i = first; i < first + count; ++i) {
       mn = fmin3(mn, prims[i].bmin), mx = fmax3(mx, prims[i].bmax);
       cmn = fmin3(cmn, prims[i].centroid), cmx = fmax3(cmx, prims[i].centroid);
     }
-    nodes[index].bmin = mn, nodes[index].bmax = mx, nodes[index].first = first, nodes[index].count = count;
     constexpr uint32_t kMaxLeaf = 4;  // leaf encoding allows 8
     if (count <= 1)
-      return index;
+      return false;
 
     constexpr int kBins = 16;
     float best_cost = kMaxFloat;
@@ -142,28 +143,87 @@ struct Builder {
           best_cost = cost, best_axis = a, best_split = i;
       }
     }
-    uint32_t mid = first + count / 2;
+    mid = first + count / 2;
     if (best_axis >= 0) {
       // SAH termination: a node visit of the device traversal (fetch 128 B, four slab tests, sort, stack traffic) costs
       // about as much as `traversal_cost` triangle tests; measured on the gems scene
       float leaf_cost = half_area(mn, mx) * float(count);
       if ((count <= kMaxLeaf) && (best_cost + traversal_cost * half_area(mn, mx) >= leaf_cost))
-        return index;
+        return false;
       float lo = axis(cmn, best_axis), hi = axis(cmx, best_axis);
       float scale = float(kBins) / (hi - lo);
-      auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim& p) {
+      Prim* it = std::partition(prims + first, prims + first + count, [&](const Prim& p) {
         return std::min(kBins - 1, int((axis(p.centroid, best_axis) - lo) * scale)) <= best_split;
       });
-      mid = uint32_t(it - prims.begin());
+      mid = uint32_t(it - prims);
       if ((mid == first) || (mid == first + count))
         mid = first + count / 2;
     } else if (count <= kMaxLeaf) {
-      return index;
+      return false;
     }
+    return true;
+  }
+
+  uint32_t subdivide(uint32_t first, uint32_t count, uint32_t depth) {
+    uint32_t index = uint32_t(nodes.size());
+    nodes.emplace_back();
+    max_depth = std::max(max_depth, depth);
+    f3 mn, mx;
+    uint32_t mid = 0;
+    const bool inner = split(first, count, mn, mx, mid);
+    nodes[index].bmin = mn, nodes[index].bmax = mx, nodes[index].first = first, nodes[index].count = count;
+    if (inner == false)
+      return index;
     uint32_t l = subdivide(first, mid - first, depth + 1);
     uint32_t r = subdivide(mid, first + count - mid, depth + 1);
     nodes[index].left = int32_t(l), nodes[index].right = int32_t(r), nodes[index].count = 0;
     return index;
+  }
+
+  // The same tree by tasks: a range above `grain` primitives is split here, its left half built by another thread, and the two
+  // subtrees are appended behind their parent. Ranges are disjoint, so the in-place partitions do not meet; every split sees the
+  // primitives in the order the sequential build would have left them, so the tree is the sequential one (the node NUMBERING
+  // differs, which nothing downstream reads: the BVH4 is numbered breadth first from the structure).
+  struct Subtree {
+    std::vector<TmpNode> nodes;
+    uint32_t max_depth = 0;
+  };
+  static Subtree build_range(Prim* prims, float traversal_cost, uint32_t first, uint32_t count, uint32_t depth, uint32_t grain) {
+    Builder b;
+    b.prims = prims;
+    b.traversal_cost = traversal_cost;
+    if (count <= grain) {
+      b.nodes.reserve(size_t(count));
+      b.subdivide(first, count, depth);
+      return {std::move(b.nodes), b.max_depth};
+    }
+    TmpNode root;
+    uint32_t mid = 0;
+    const bool inner = b.split(first, count, root.bmin, root.bmax, mid);
+    root.first = first, root.count = count;
+    Subtree out;
+    out.max_depth = depth;
+    if (inner == false) {
+      out.nodes.push_back(root);
+      return out;
+    }
+    std::future<Subtree> left_task = std::async(std::launch::async, build_range, prims, traversal_cost, first, mid - first, depth + 1u, grain);
+    Subtree right = build_range(prims, traversal_cost, mid, first + count - mid, depth + 1u, grain);
+    Subtree left = left_task.get();
+    root.count = 0;
+    root.left = 1, root.right = int32_t(1u + left.nodes.size());
+    out.nodes.reserve(1u + left.nodes.size() + right.nodes.size());
+    out.nodes.push_back(root);
+    for (const Subtree* part : {&left, &right}) {
+      const int32_t offset = int32_t(out.nodes.size());
+      for (TmpNode node : part->nodes) {
+        if (node.count == 0)
+          node.left += offset, node.right += offset;
+        out.nodes.push_back(node);
+      }
+    }
+    out.max_depth = std::max(left.max_depth, right.max_depth);
+    return out;
   }
 };
 
@@ -301,10 +361,16 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
     out.root4 = ~int32_t(0);
     return;
   }
+  const auto phase_begin = std::chrono::steady_clock::now();
+  auto phase = [&](const char* name) {
+    if (getenv("ETX_HIP_VERBOSE"))
+      fprintf(stderr, "[etx_hip] build_bvh %s: %.1f ms since start\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - phase_begin).count());
+  };
   Builder b;
   if (const char* e = getenv("ETX_HIP_BVH_TRAVERSAL_COST"))
     b.traversal_cost = float(atof(e));
-  b.prims.resize(n);
+  std::vector<Builder::Prim> primitives(n);
+  b.prims = primitives.data();
   for (uint32_t i = 0; i < n; ++i) {
     f3 p0 = a3(vertices[triangles[i].i[0]].pos), p1 = a3(vertices[triangles[i].i[1]].pos), p2 = a3(vertices[triangles[i].i[2]].pos);
     b.prims[i].bmin = fmin3(p0, fmin3(p1, p2));
@@ -312,9 +378,20 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
     b.prims[i].centroid = (b.prims[i].bmin + b.prims[i].bmax) * 0.5f;
     b.prims[i].index = i;
   }
-  b.nodes.reserve(2 * n);
-  b.subdivide(0, n, 1);
+  phase("primitive bounds");
+  // large scenes are built by tasks (a million triangles: 0.7 s on one core); ETX_HIP_BVH_BUILD_THREADS=1 keeps one thread
+  const char* threads_env = getenv("ETX_HIP_BVH_BUILD_THREADS");
+  const uint32_t threads = threads_env ? uint32_t(std::max(1, atoi(threads_env))) : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+  if ((threads > 1u) && (n >= 32768u)) {
+    Builder::Subtree tree = Builder::build_range(b.prims, b.traversal_cost, 0u, n, 1u, std::max(4096u, n / (4u * threads)));
+    b.nodes = std::move(tree.nodes);
+    b.max_depth = tree.max_depth;
+  } else {
+    b.nodes.reserve(2 * n);
+    b.subdivide(0, n, 1);
+  }
   out.depth = b.max_depth;
+  phase("binned SAH tree");
 
   out.tris.resize(n);
   for (uint32_t i = 0; i < n; ++i) {
@@ -344,6 +421,7 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
     out.tris[i].e2_mat = make_float4(e2.x, e2.y, e2.z, bits(t.material_index));
   }
 
+  phase("traversal triangles");
   // flatten: inner nodes only; a child reference is an inner index (>= 0) or ~((first << 3) | (count - 1))
   std::vector<int32_t> remap(b.nodes.size(), -1);
   uint32_t inner = 0;
@@ -373,6 +451,7 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
   }
   out.root = encode(0);
 
+  phase("BVH2 nodes");
   // BVH2 -> BVH4 (dev_scene.h Bvh4Node): a node adopts its grandchildren, the child with the largest surface area first,
   // until it has four children or only leaves. Nodes are numbered breadth first: the first N nodes are the top of the
   // tree, which the traversal kernels keep in LDS.
@@ -456,6 +535,7 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
     need[i] = (kids ? kids - 1u : 0u) + deepest;
   }
   out.stack_need = need.empty() ? 0u : need[0];
+  phase("BVH4 collapse and stack bound");
 }
 
 // The cube the Morton keys of the device build quantize: the scene's bounding sphere (Scene::bounding_sphere_*, computed by the host

@@ -111,6 +111,7 @@ class HIPIntegrator(Integrator):
         self.iteration_stride = iteration_stride
         self._uploaded_version = None  # snapshot.version at the last etx_hip_upload_scene
         self._pending_changes = None   # scene_edited(): what the host changed since (None: unknown = upload everything)
+        self.bvh_builder = api.BVH_HOST_SAH  # api.BVH_DEVICE_LBVH: the tree of the next upload is built on the device (etx_hip_set_bvh_builder)
         self._rendered = 0
         self._have_camera_image = False
         self._have_light_image = False
@@ -138,6 +139,7 @@ class HIPIntegrator(Integrator):
 
     def run(self):
         self.stop(Stop.Immediate)
+        self.context.set_bvh_builder(self.bvh_builder)
         if (self._uploaded_version is not None) and (self._pending_changes is not None):
             self.context.update_scene(self.snapshot, self._pending_changes)
             self._uploaded_version = self.snapshot.version

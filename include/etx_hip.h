@@ -89,13 +89,13 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
  *   ETX_HIP_CHANGED_POSITIONS vertex data moved (same vertex and triangle counts, same indices): the vertices and triangles are
  *                             copied over, the traversal triangles re-derived and the BVH boxes refit bottom-up ON THE DEVICE
  *                             (kernels_bvh_build.hip); the tree keeps its topology, so a refit after large deformations traverses
- *                             slower than a rebuild (etx_hip_upload_scene)
+ *                             slower than a rebuild
+ *   ETX_HIP_REBUILD_BVH       with ETX_HIP_CHANGED_POSITIONS: instead of the refit, a new tree is built over the moved vertices ON THE
+ *                             DEVICE (linear BVH, see etx_hip_set_bvh_builder) - for deformations a refit tree traverses badly
  * The small tables and the camera are rebuilt from `scene` / `camera` in any case; vertices, triangles, BVH, image pixels and
  * density grids stay resident. Counts of vertices, triangles, images and media must be unchanged (ETX_HIP_ERROR_INVALID_ARGUMENT
  * otherwise; on any error the context holds no scene, as after a failed upload). Waits for the iterations in flight; the next
- * etx_hip_begin renders the edited scene.
- *   ETX_HIP_REBUILD_BVH       with ETX_HIP_CHANGED_POSITIONS: instead of the refit, a new tree is built over the moved vertices ON THE
- *                             DEVICE (linear BVH, see etx_hip_set_bvh_builder) - for deformations a refit tree traverses badly */
+ * etx_hip_begin renders the edited scene. */
 enum { ETX_HIP_CHANGED_CAMERA = 1, ETX_HIP_CHANGED_MATERIALS = 2, ETX_HIP_CHANGED_POSITIONS = 4, ETX_HIP_REBUILD_BVH = 8 };
 int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, const etx_abi_camera* camera, uint32_t changed);
 

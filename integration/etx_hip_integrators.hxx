@@ -55,6 +55,7 @@ struct HIPBackendLibrary {
   decltype(&etx_hip_last_error) last_error = nullptr;
   decltype(&etx_hip_upload_scene) upload_scene = nullptr;
   decltype(&etx_hip_update_scene) update_scene = nullptr;
+  decltype(&etx_hip_set_bvh_builder) set_bvh_builder = nullptr;
   decltype(&etx_hip_upload_bluenoise) upload_bluenoise = nullptr;
   decltype(&etx_hip_upload_cie_table) upload_cie_table = nullptr;
   decltype(&etx_hip_upload_rgb_response) upload_rgb_response = nullptr;
@@ -98,6 +99,7 @@ struct HIPBackendLibrary {
     resolve(lib.last_error, "etx_hip_last_error");
     resolve(lib.upload_scene, "etx_hip_upload_scene");
     resolve(lib.update_scene, "etx_hip_update_scene");
+    resolve(lib.set_bvh_builder, "etx_hip_set_bvh_builder");
     resolve(lib.upload_bluenoise, "etx_hip_upload_bluenoise");
     resolve(lib.upload_cie_table, "etx_hip_upload_cie_table");
     resolve(lib.upload_rgb_response, "etx_hip_upload_rgb_response");
@@ -163,6 +165,9 @@ struct HIPIntegratorBase : public Integrator {
     // vertices refit there; otherwise everything is uploaded, which is what commit_changes does on every change (app.cxx:368-399)
     const auto* scene_abi = reinterpret_cast<const etx_abi_scene*>(&rt.scene());
     const auto* camera_abi = reinterpret_cast<const etx_abi_camera*>(&rt.camera());
+    // option "hip-device_bvh": the tree is built on the device (linear BVH: a millisecond for a million triangles, traverses at
+    // ~0.7 of the rate of the host's binned-SAH tree) - for geometry that changes, or for time to first image
+    lib.set_bvh_builder(ctx, integrator_options.get_bool("hip-device_bvh", false) ? ETX_HIP_BVH_DEVICE_LBVH : ETX_HIP_BVH_HOST_SAH);
     const bool in_place = scene_on_device && (pending_changes != kEverythingChanged);
     const int uploaded = in_place ? lib.update_scene(ctx, scene_abi, camera_abi, pending_changes) : lib.upload_scene(ctx, scene_abi, camera_abi);
     pending_changes = kEverythingChanged;

@@ -85,3 +85,26 @@ def test_deep_trees_are_accepted_up_to_the_spill_bound(etx, golden_dir):
         assert rc == 0 and 32 < info["stack_need"] <= 64, info
         rc, walk = api.host_bvh_stats(snap, rays, builder=builder)
         assert rc == 0 and walk["max_stack"] < 24, walk
+
+
+def test_task_parallel_sah_build_is_the_sequential_tree(etx, golden_dir, monkeypatch):
+    """Scenes of >= 32 768 triangles are built by tasks (host_scene.cpp Builder::build_range): ranges are disjoint and every split sees
+    the primitives in the order the sequential build would have left them, so the tree - and with it every traversal statistic - is
+    the sequential one."""
+    from etx_tracer_amd import api
+    from tests.test_gpu_scene_update import replicate_gems
+    snap = replicate_gems(etx, golden_dir, 40)
+    rays = make_rays(5000, 6)
+    results = []
+    for threads in ("1", "8"):
+        monkeypatch.setenv("ETX_HIP_BVH_BUILD_THREADS", threads)
+        rc, info = api.host_check_bvh(snap)
+        assert rc == 0
+        rc, walk = api.host_bvh_stats(snap, rays, with_hits=True)
+        assert rc == 0
+        results.append((info, walk))
+    assert results[0][0] == results[1][0]
+    for key in ("node_visits", "triangle_tests", "hits", "max_stack"):
+        assert results[0][1][key] == results[1][1][key]
+    np.testing.assert_array_equal(results[0][1]["triangle"], results[1][1]["triangle"])
+    np.testing.assert_array_equal(results[0][1]["t"], results[1][1]["t"])
