@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_upload_rgb_response", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
     "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_checkpoint_bytes", "etx_hip_checkpoint_save", "etx_hip_checkpoint_load", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
-    "etx_hip_set_bvh_builder", "etx_hip_bvh_info", "etx_hip_host_check_bvh_builder", "etx_hip_host_bvh_stats_builder",
+    "etx_hip_set_bvh_builder", "etx_hip_bvh_info", "etx_hip_selftest_stack", "etx_hip_host_check_bvh_builder", "etx_hip_host_bvh_stats_builder",
 )
 
 
@@ -192,6 +192,7 @@ class Library:
         L.etx_hip_host_check_bvh.argtypes = [vp, ctypes.POINTER(u32 * 4)]
         L.etx_hip_host_bvh_stats.argtypes = [vp, vp, u64, ctypes.POINTER(u64 * 4)]
         L.etx_hip_set_bvh_builder.argtypes = [vp, i32]
+        L.etx_hip_selftest_stack.argtypes = [vp, u32, ctypes.POINTER(u32)]
         L.etx_hip_bvh_info.argtypes = [vp, ctypes.POINTER(u32 * 4), ctypes.POINTER(ctypes.c_double)]
         L.etx_hip_host_check_bvh_builder.argtypes = [vp, i32, ctypes.POINTER(u32 * 4)]
         L.etx_hip_host_bvh_stats_builder.argtypes = [vp, i32, vp, u64, ctypes.POINTER(u64 * 4), vp]
@@ -241,6 +242,12 @@ class Context:
         self._check(self.library.lib.etx_hip_upload_scene(self.handle, snapshot.scene_address, snapshot.camera_address))
         self.film_size = snapshot.film_size
         self._scene_keepalive = snapshot
+
+    def selftest_stack(self, depth):
+        """-> mismatches of the traversal stack round trip at `depth` entries per lane (etx_hip_selftest_stack); 0 expected"""
+        errors = ctypes.c_uint32(0xFFFFFFFF)
+        self._check(self.library.lib.etx_hip_selftest_stack(self.handle, int(depth), ctypes.byref(errors)))
+        return errors.value
 
     def set_bvh_builder(self, builder):
         """BVH_HOST_SAH (default) or BVH_DEVICE_LBVH: who builds the tree of the next upload_scene (etx_hip_set_bvh_builder)."""

@@ -3,6 +3,7 @@
 #include "../../include/etx_hip.h"
 
 #include "host_scene.h"
+#include "kernels_bvh_build.h"
 #include "kernels.h"
 #include "dev_bvh.h"
 
@@ -1674,6 +1675,30 @@ int etx_hip_trace_rays_device(etx_hip_context* context, const void* d_rays_o_tmi
   (void)hipEventDestroy(e1);
   if (out_avg_ms)
     *out_avg_ms = double(ms) / double(repeat);
+  return ETX_HIP_OK;
+}
+
+int etx_hip_selftest_stack(etx_hip_context* context, uint32_t depth, uint32_t* out_errors) {
+  if ((context == nullptr) || (out_errors == nullptr) || (depth == 0u) || (depth > kMaxStackDepth))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  HIP_OK(context, hipSetDevice(context->device));
+  const uint32_t blocks = 1024u, lanes = blocks * kBlockSize;
+  int32_t* spill = nullptr;
+  uint32_t* errors = nullptr;
+  HIP_OK(context, hipMalloc(&spill, size_t(lanes) * (kMaxStackDepth - kStackDepth) * sizeof(int32_t)));
+  if (hipMalloc(&errors, sizeof(uint32_t)) != hipSuccess) {
+    (void)hipFree(spill);
+    context->error = "hipMalloc failed";
+    return ETX_HIP_ERROR_HIP;
+  }
+  (void)hipMemsetAsync(errors, 0, sizeof(uint32_t), context->stream);
+  launch_stack_selftest(context->stream, spill, lanes, blocks, depth, errors);
+  const hipError_t copied = hipMemcpyAsync(out_errors, errors, sizeof(uint32_t), hipMemcpyDeviceToHost, context->stream);
+  const hipError_t synced = hipStreamSynchronize(context->stream);
+  (void)hipFree(spill);
+  (void)hipFree(errors);
+  HIP_OK(context, copied);
+  HIP_OK(context, synced);
   return ETX_HIP_OK;
 }
 

@@ -29,4 +29,10 @@ struct LbvhResult {
 };
 int lbvh_build_device(hipStream_t stream, DScene scene, f3 cube_min, float cube_extent, Bvh4Node* nodes, BvhTri* tris, LbvhResult& result, std::string& error);
 
+// Self test of the traversal stack (dev_bvh.h LaneStack: kStackDepth entries per lane in LDS, the rest in the global spill area):
+// every lane of a traversal-sized grid pushes `depth` values, pops half, pushes again and pops everything, checking each value. A
+// real ray never gets near the spill (the bound is a worst case over the tree), so this is what exercises it. Returns the number of
+// mismatches in *errors (device memory).
+void launch_stack_selftest(hipStream_t stream, int32_t* spill, uint32_t spill_lanes, uint32_t blocks, uint32_t depth, uint32_t* errors);
+
 }  // namespace etxd

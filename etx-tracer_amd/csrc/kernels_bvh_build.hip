@@ -7,6 +7,7 @@
 // All of it is HBM-latency bound and tiny next to an iteration: the build of a 1.2 M-triangle tree moves a few hundred MB.
 #include "kernels_bvh_build.h"
 #include "dev_lbvh.h"
+#include "dev_bvh.h"
 #include "../../include/etx_hip.h"
 
 #include <hipcub/hipcub.hpp>
@@ -74,6 +75,31 @@ __global__ __launch_bounds__(kBuildBlock) void k_lbvh_collapse_level(const LbvhN
   Bvh4Node& node = nodes[base + i];
   node.child[0] = child[0], node.child[1] = child[1], node.child[2] = child[2], node.child[3] = child[3];
   node.pad[0] = node.pad[1] = node.pad[2] = node.pad[3] = 0u;
+}
+
+__global__ __launch_bounds__(kBuildBlock) void k_stack_selftest(DScene scene, uint32_t depth, uint32_t* errors) {
+  __shared__ int32_t s_stack[kStackDepth * kBuildBlock];
+  const LaneStack stack = lane_stack(scene, s_stack + threadIdx.x, kBuildBlock);
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t sp = 0u, bad = 0u;
+  for (uint32_t i = 0; i < depth; ++i)
+    stack.push(sp, int32_t(lane * 131u + i * 7u + 1u));
+  for (uint32_t i = depth; i-- > depth / 2u;)
+    bad += (stack.pop(sp) != int32_t(lane * 131u + i * 7u + 1u)) ? 1u : 0u;
+  for (uint32_t i = depth / 2u; i < depth; ++i)
+    stack.push(sp, int32_t(lane * 977u + i));
+  for (uint32_t i = depth; i-- > depth / 2u;)
+    bad += (stack.pop(sp) != int32_t(lane * 977u + i)) ? 1u : 0u;
+  for (uint32_t i = depth / 2u; i-- > 0u;)
+    bad += (stack.pop(sp) != int32_t(lane * 131u + i * 7u + 1u)) ? 1u : 0u;
+  if ((bad != 0u) || (sp != 0u))
+    atomicAdd(errors, bad + ((sp != 0u) ? 1u : 0u));
+}
+
+void launch_stack_selftest(hipStream_t stream, int32_t* spill, uint32_t spill_lanes, uint32_t blocks, uint32_t depth, uint32_t* errors) {
+  DScene scene = {};
+  scene.stack_spill = spill, scene.stack_spill_lanes = spill_lanes;
+  hipLaunchKernelGGL(k_stack_selftest, dim3(blocks), dim3(kBuildBlock), 0, stream, scene, depth, errors);
 }
 
 void launch_bvh_triangles_update(hipStream_t stream, const DScene& scene, BvhTri* tris, uint32_t count) {

@@ -265,6 +265,12 @@ int etx_hip_trace_rays_device(etx_hip_context* context, const void* d_rays_o_tmi
  */
 int etx_hip_kat(etx_hip_context* context, int which, const float* in, uint64_t count, float* out);
 
+/* Self test of the traversal stack: the kernels keep 32 entries per lane in LDS and spill the rest (trees of more than ~40 000
+ * triangles can need up to 64 by their worst-case bound) to global memory. Every lane of a traversal-sized grid pushes `depth` (1..64)
+ * values, pops half, pushes again, pops everything and compares; *out_errors = mismatches (0 expected). A real ray stays below 20
+ * entries, so this is what exercises the spill. */
+int etx_hip_selftest_stack(etx_hip_context* context, uint32_t depth, uint32_t* out_errors);
+
 /* Host-only (no GPU, no context): builds the traversal BVH for `scene` exactly as etx_hip_upload_scene does and checks
  * its invariants (every triangle referenced once, child boxes enclose their triangles, leaf size <= 8, depth within the
  * device stack). out_info = {BVH4 node count, triangle count, depth | stack entries needed << 16, bytes}. Returns 0 or ETX_HIP_ERROR_INVALID_ARGUMENT. */

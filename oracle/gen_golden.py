@@ -130,6 +130,12 @@ def sss_golden():
                             threads=np.int32(film["threads"]))
 
 
+def sssmesh_snapshot():
+    # the two subsurface materials on sphere meshes (21 772 triangles: BVH traversal instead of the flat sweep); the films of this
+    # scene are the high-sample-count ones of oracle/gen_golden_hi.py (... --integrators pt --spp 1024 sssmesh, vcm,rekeyed / bdpt at 256)
+    run("--scene", os.path.join(SCENES, "sssmesh_test_128.json"), "--integrator", "none", "--snapshot", os.path.join(GOLDEN, "cornell_sssmesh_128.etxscene"))
+
+
 def features_golden():
     # branches no other scene reaches: albedo texture + alpha cut-out (stochastic alpha test inside traversal) + normal map;
     # image environment map (2-D sampling tables) as the only light; thin lens with an aperture image; equirectangular camera
@@ -164,6 +170,7 @@ def main():
     spectral_golden()
     cloud_golden()
     sss_golden()
+    sssmesh_snapshot()
     features_golden()
     with open(os.path.join(GOLDEN, "kat_reference.json"), "w") as f:
         subprocess.check_call([ORACLE, "--kat"], stdout=f)
@@ -182,6 +189,8 @@ if __name__ == "__main__":
         cloud_golden()
     elif (len(sys.argv) > 1) and (sys.argv[1] == "sss"):
         sss_golden()
+    elif (len(sys.argv) > 1) and (sys.argv[1] == "sssmesh"):
+        sssmesh_snapshot()
     elif (len(sys.argv) > 1) and (sys.argv[1] == "features"):
         features_golden()
     else:

@@ -133,7 +133,7 @@ class Mesh:
                 f.write("f " + " ".join(("%d/%d/%d" % (c[0], c[2], c[1])) if len(c) == 3 else ("%d//%d" % c) for c in idx) + "\n")
 
 
-def build_mesh(with_fog, spheres=False):
+def build_mesh(with_fog, spheres=False, sss_meshes=False):
     m = Mesh()
     # room, normals pointing inside
     m.quad("floor", [(-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1)], (0, 1, 0))
@@ -158,7 +158,13 @@ def build_mesh(with_fog, spheres=False):
             a += pts[i][2] * pts[j][0] - pts[j][2] * pts[i][0]
         return pts if a > 0 else list(reversed(pts))
 
-    if spheres:
+    if sss_meshes:
+        # subsurface objects as MESHES: 20 480 + 1 280 triangles -> the material-filtered traversal of the walks and the inline
+        # traversal of the shade kernels run on the tree (the box scenes are swept linearly), at a depth whose stack bound exceeds
+        # the per-lane LDS stack
+        m.icosphere("shortBox", (0.35, 0.36, 0.40), 0.36, 5)
+        m.icosphere("tallBox", (-0.38, 0.50, -0.30), 0.50, 3)
+    elif spheres:
         # BVH-sized geometry (2 x 1280 + 320 triangles): a faceted "gem" and two smooth spheres instead of the boxes
         m.icosphere("shortBox", (0.35, 0.33, 0.45), 0.33, 3, flat=True)
         m.icosphere("tallBox", (-0.40, 0.45, -0.30), 0.45, 3)
@@ -546,6 +552,9 @@ two_sided 1
 
 """ + MTL_LIGHT_CLASSIC)
     write_json("sss_test_128.json", "cornell_classic.obj", "cornell_sss.mtl", (128, 128), 64)
+    # the same two materials on sphere meshes (BVH traversal instead of the flat sweep)
+    build_mesh(False, sss_meshes=True).write(os.path.join(OUT, "cornell_sssmesh.obj"), "cornell_sss.mtl")
+    write_json("sssmesh_test_128.json", "cornell_sssmesh.obj", "cornell_sss.mtl", (128, 128), 64)
     # the same box with the Christensen-Burley class ("class approximate", scene_representation.cxx:1996-2001): three probe rays,
     # up to 24 exit points per vertex (subsurface::gather_cb + Raytracing::continuous_trace)
     with open(os.path.join(OUT, "cornell_sss.mtl")) as f:

@@ -1,0 +1,74 @@
+"""GPU (-m gpu): subsurface scattering on MESHES (configs[3] family: "any closed mesh with a subsurface random-walk material"). The
+box scenes of the other subsurface tests have 32 triangles and are swept linearly; here the two objects are sphere meshes
+(20 480 + 1 280 triangles, scenes/make_scenes.py sss_meshes), so the material-filtered closest-hit queries of the walks
+(Raytracing::trace_material, rt.cxx:327-371) and the inline traversals of the shade kernels run on the BVH4, with the checked
+per-lane stack (dev_bvh.h LaneStack). Goldens: oracle/gen_golden_hi.py ... sssmesh (PT 1024 spp, VCM / BDPTFull 256 spp, the
+bidirectional ones also with independent light / camera streams). Limits as in the box tests at these sample counts.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity_hi import compare
+
+pytestmark = pytest.mark.gpu
+
+
+def load(golden_dir, name):
+    path = os.path.join(golden_dir, "hi", name)
+    assert os.path.exists(path), "%s is missing: python oracle/gen_golden_hi.py --integrators ... sssmesh in the build container" % path
+    return np.load(path)
+
+
+def render_halves(etx, golden_dir, cls, spp, options):
+    films = []
+    for first in (0, 1):
+        snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_sssmesh_128.etxscene"))
+        snap.samples = spp
+        snap.noise_threshold = 0.0
+        integ = cls(snap, first_iteration=first, iteration_stride=2)
+        integ.options().update(options)
+        integ.render()
+        cam, light = integ.film(etx.api.LAYER_CAMERA), integ.film(etx.api.LAYER_LIGHT)
+        stats = integ.status()
+        info = integ.context.bvh_info()
+        integ.context.close()
+        assert info["triangles"] == 21772 and info["nodes"] > 1000  # the tree, not the flat sweep
+        assert stats.completed_iterations == spp // 2 and stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
+        assert np.isfinite(cam).all() and np.isfinite(light).all()
+        films.append((cam, light))
+    return films
+
+
+def test_path_tracer_random_walk_on_meshes(etx, golden_dir):
+    golden = load(golden_dir, "cornell_sssmesh_128_pt_1024.npz")
+    assert int(golden["spp"]) == 1024
+    (cam_a, _), (cam_b, _) = render_halves(etx, golden_dir, etx.HIPPathTracing, 1024, {"bn": False})
+    compare((cam_a, cam_b), golden["camera"], "sssmesh pt camera", rmse_limit=1.5e-3)
+
+
+def test_vcm_random_walk_on_meshes(etx, golden_dir):
+    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, etx.HIPVCM, 256, {"vcm-blue_noise": False})
+    golden = load(golden_dir, "cornell_sssmesh_128_vcm_256_rekeyed.npz")
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "sssmesh vcm camera+light (independent streams)", rmse_limit=1.5e-3)
+    compare((light_a, light_b), golden["light"], "sssmesh vcm light (independent streams)", rmse_limit=1.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.2)
+    golden = load(golden_dir, "cornell_sssmesh_128_vcm_256.npz")
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "sssmesh vcm camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
+
+
+def test_bidirectional_walk_vertices_on_meshes(etx, golden_dir):
+    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, etx.HIPBidirectional, 256, {"bdpt-mode": etx.api.BDPT_MODE_FULL, "bdpt-blue_noise": False})
+    golden = load(golden_dir, "cornell_sssmesh_128_bdpt3_256_rekeyed.npz")
+    assert int(golden["spp"]) in (255, 256)
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "sssmesh bdpt camera+light (independent streams)", rmse_limit=1.5e-3)
+    compare((cam_a, cam_b), golden["camera"], "sssmesh bdpt camera (independent streams)", rmse_limit=1.5e-3)
+
+
+@pytest.mark.parametrize("depth", [1, 31, 32, 33, 48, 64])
+def test_traversal_stack_round_trip_through_the_spill(etx, depth):
+    """etx_hip_selftest_stack: 262 144 lanes push / pop `depth` entries each through dev_bvh.h LaneStack - 32 in LDS, the rest in
+    the global spill area a deep tree (> ~40 000 triangles) gets. Real rays stay below 20 entries; this is what walks the spill."""
+    ctx = etx.api.Context(0)
+    assert ctx.selftest_stack(depth) == 0
+    ctx.close()
