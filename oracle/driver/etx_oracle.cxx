@@ -260,6 +260,7 @@ int main(int argc, char** argv) {
   int64_t spp = -1;
   int64_t max_iterations = -1;
   float noise_threshold = -1.0f;  // < 0: keep the scene value
+  int64_t subsurface_class = -1;  // >= 1: every subsurface material of the loaded scene gets this SubsurfaceMaterial::Class (1 random walk, 2 Christensen-Burley)
   uint32_t inject_density = 0;  // N: every medium of the loaded scene becomes Heterogeneous with a procedural N^3 density grid
   for (int i = 1; i < argc; ++i) {
     auto next = [&]() -> const char* {
@@ -337,6 +338,8 @@ int main(int argc, char** argv) {
       checkpoint_file = next();
     else if (strcmp(argv[i], "--resume") == 0)
       resume_file = next();
+    else if (strcmp(argv[i], "--subsurface-class") == 0)
+      subsurface_class = atoll(next());
     else if (strcmp(argv[i], "--out") == 0)
       out_file = next();
     else if (strcmp(argv[i], "--snapshot") == 0)
@@ -416,6 +419,13 @@ int main(int argc, char** argv) {
   }
   if (noise_threshold >= 0.0f)
     const_cast<Scene*>(scene_ptr)->noise_threshold = noise_threshold;
+  if (subsurface_class >= 1) {  // the same geometry under the other subsurface class, without a second scene file (tests/test_gpu_sssmesh.py)
+    auto& materials = const_cast<Scene*>(scene_ptr)->materials;
+    for (uint64_t i = 0; i < materials.count; ++i) {
+      if (materials[i].subsurface.cls != SubsurfaceMaterial::Class::Disabled)
+        materials[i].subsurface.cls = SubsurfaceMaterial::Class(uint32_t(subsurface_class));
+    }
+  }
   raytracing.link_scene(*scene_ptr);
   raytracing.link_camera(*camera_ptr);
   raytracing.commit_changes();

@@ -68,15 +68,19 @@ def main():
     integrators = args.integrators.split(",")
     for flavour in args.names:
         snapshot = os.path.join(GOLDEN, "cornell_%s_128.etxscene" % flavour)
+        variant = []
+        if flavour == "sssmeshcb":  # the sssmesh snapshot with both subsurface materials switched to the Christensen-Burley class by the driver
+            snapshot = os.path.join(GOLDEN, "cornell_sssmesh_128.etxscene")
+            variant = ["--subsurface-class", "2"]
         if "vcm" in integrators:
-            render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d.npz" % (flavour, args.spp)), args.cores, extra=["--opt", "vcm-blue_noise=false"])
+            render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d.npz" % (flavour, args.spp)), args.cores, extra=["--opt", "vcm-blue_noise=false"] + variant)
         if (flavour == "full") and ("vcm" in integrators):
             render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_full_128_vcm_%d_decorrelated.npz" % args.spp), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "1"},
                    extra=["--opt", "vcm-blue_noise=false"])
         if "rekeyed" in integrators:
             # mode 2: the camera sub path draws from a stream of its own from its first segment on (oracle/shims/raytracing_bvh.cxx)
             render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_rekeyed.npz" % (flavour, args.spp)), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "2"},
-                   extra=["--opt", "vcm-blue_noise=false"])
+                   extra=["--opt", "vcm-blue_noise=false"] + variant)
         if "bdpt" in integrators:
             # CPUBidirectional, bdpt-mode 3 = BDPTFull (bidirectional.cxx:323-330); shared streams and re-keyed like VCM
             for mode in args.bdpt_modes.split(","):
@@ -92,7 +96,7 @@ def main():
         if "pt" in integrators:
             # --noise-threshold 0: every pixel gets all samples (the scenes carry Scene::noise_threshold = 0.1, with which
             # CPUPathTracing stops sampling converged pixels after 32 samples: a "4096-spp" film would hold ~100-spp noise)
-            render(snapshot, "pt", args.spp, os.path.join(HI, "cornell_%s_128_pt_%d.npz" % (flavour, args.spp)), args.cores, extra=["--opt", "bn=false", "--noise-threshold", "0"])
+            render(snapshot, "pt", args.spp, os.path.join(HI, "cornell_%s_128_pt_%d.npz" % (flavour, args.spp)), args.cores, extra=["--opt", "bn=false", "--noise-threshold", "0"] + variant)
 
 
 if __name__ == "__main__":

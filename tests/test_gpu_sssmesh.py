@@ -21,12 +21,16 @@ def load(golden_dir, name):
     return np.load(path)
 
 
-def render_halves(etx, golden_dir, cls, spp, options):
+def render_halves(etx, golden_dir, cls, spp, options, christensen_burley=False):
     films = []
     for first in (0, 1):
         snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_sssmesh_128.etxscene"))
         snap.samples = spp
         snap.noise_threshold = 0.0
+        if christensen_burley:  # SubsurfaceMaterial::cls (etx_abi_material.subsurface.cls, u32 column 26): what the driver's --subsurface-class 2 does
+            materials = snap.materials()
+            assert int((materials[:, 26] == 1).sum()) == 2
+            materials[materials[:, 26] == 1, 26] = 2
         integ = cls(snap, first_iteration=first, iteration_stride=2)
         integ.options().update(options)
         integ.render()
@@ -63,6 +67,20 @@ def test_bidirectional_walk_vertices_on_meshes(etx, golden_dir):
     assert int(golden["spp"]) in (255, 256)
     compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "sssmesh bdpt camera+light (independent streams)", rmse_limit=1.5e-3)
     compare((cam_a, cam_b), golden["camera"], "sssmesh bdpt camera (independent streams)", rmse_limit=1.5e-3)
+
+
+def test_christensen_burley_on_meshes(etx, golden_dir):
+    """The same snapshot with both materials switched to SubsurfaceMaterial::Class::ChristensenBurley (the goldens: the driver's
+    --subsurface-class 2): three probe rays per vertex, each followed through the object's mesh by consecutive material-filtered
+    queries on the tree (Raytracing::continuous_trace, rt.cxx:373-426), up to 24 exit points."""
+    golden = load(golden_dir, "cornell_sssmeshcb_128_pt_1024.npz")
+    (cam_a, _), (cam_b, _) = render_halves(etx, golden_dir, etx.HIPPathTracing, 1024, {"bn": False}, christensen_burley=True)
+    compare((cam_a, cam_b), golden["camera"], "sssmesh (Christensen-Burley) pt camera", rmse_limit=1.5e-3)
+    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, etx.HIPVCM, 256, {"vcm-blue_noise": False}, christensen_burley=True)
+    golden = load(golden_dir, "cornell_sssmeshcb_128_vcm_256_rekeyed.npz")
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "sssmesh (Christensen-Burley) vcm camera+light (independent streams)", rmse_limit=1.5e-3)
+    golden = load(golden_dir, "cornell_sssmeshcb_128_vcm_256.npz")
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "sssmesh (Christensen-Burley) vcm camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
 
 
 @pytest.mark.parametrize("depth", [1, 31, 32, 33, 48, 64])
