@@ -5,9 +5,11 @@
 // The build replaces what Raytracing::commit_changes hands to Embree (sources/etx/rt/rt.cxx:58-88) when the geometry changed:
 //   1. 63-bit Morton key of every triangle's centroid inside the scene's bounding cube, radix sort of (key, triangle)
 //   2. the binary radix tree over the sorted keys (Karras 2012: every inner node finds its range and split on its own)
-//   3. collapse to the four-wide breadth-first nodes the traversal reads (dev_scene.h Bvh4Node): level by level, a node adopts
-//      the children of its largest child until it has four; a range of <= kLbvhLeafMax triangles becomes a leaf
-//   4. boxes bottom-up by level from the triangles' vertices (the refit of etx_hip_update_scene), stack bound by level
+//   3. boxes of the radix tree's nodes, bottom-up (the second thread to reach a node joins its children's boxes)
+//   4. collapse to the four-wide breadth-first nodes the traversal reads (dev_scene.h Bvh4Node): level by level, a node adopts
+//      the children of its child with the largest surface area until it has four (what the host builder's collapse does); a range
+//      of <= kLbvhLeafMax triangles becomes a leaf when the surface area heuristic prefers that to its split
+//   5. boxes bottom-up by level from the triangles' vertices (the refit of etx_hip_update_scene), stack bound by level
 // A linear BVH traverses slower than the host's binned-SAH tree (measured: DESIGN.md); it is the builder for geometry that changes.
 #pragma once
 
@@ -105,38 +107,110 @@ ETX_HD LbvhNode lbvh_node(const uint64_t* keys, int n, int i) {
   return {uint32_t((i < j) ? i : j), uint32_t((i < j) ? j : i), uint32_t(gamma), 0u};
 }
 
-// One four-wide node from inner node `source` of the radix tree: `refs` receives the four child references in the ENCODING OF THE
-// CALLER'S CHOICE - a leaf is final (~((first << 3) | (count - 1))), a child that stays an inner node is returned as its radix
-// node index in `inner[k]` (kInvalid otherwise) and the caller assigns the breadth-first index.
-ETX_HD uint32_t lbvh_collapse(const LbvhNode* radix, uint32_t source, int32_t child[4], uint32_t inner[4]) {
-  struct Kid {
-    uint32_t first, last, node;
-  };
+// Boxes the collapse weighs: of a sorted position (its traversal triangle) and of a radix node (LbvhBoxes::lo / hi, bottom-up pass).
+struct LbvhBoxes {
+  const BvhTri* tris;
+  const f3* lo;
+  const f3* hi;
+};
+
+ETX_HD void lbvh_triangle_box(const BvhTri* tris, uint32_t position, f3& lo, f3& hi) {
+  const BvhTri& t = tris[position];
+  const f3 v0 = {t.v0_index.x, t.v0_index.y, t.v0_index.z};
+  const f3 v1 = v0 + f3{t.e1_flags.x, t.e1_flags.y, t.e1_flags.z}, v2 = v0 + f3{t.e2_mat.x, t.e2_mat.y, t.e2_mat.z};
+  lo = fmin3(v0, fmin3(v1, v2)), hi = fmax3(v0, fmax3(v1, v2));
+}
+
+// Box of radix node `i` from its two children (leaf children: their triangle's box); the bottom-up pass calls it once both are known.
+ETX_HD void lbvh_join_children(const LbvhNode* radix, const BvhTri* tris, f3* lo, f3* hi, uint32_t i) {
+  const LbvhNode nd = radix[i];
+  f3 llo, lhi, rlo, rhi;
+  if (nd.first == nd.split)
+    lbvh_triangle_box(tris, nd.first, llo, lhi);
+  else
+    llo = lo[nd.split], lhi = hi[nd.split];
+  if (nd.split + 1u == nd.last)
+    lbvh_triangle_box(tris, nd.last, rlo, rhi);
+  else
+    rlo = lo[nd.split + 1u], rhi = hi[nd.split + 1u];
+  lo[i] = fmin3(llo, rlo), hi[i] = fmax3(lhi, rhi);
+}
+
+// Half the surface area. The decisions below compare these numbers, and the host emulation must take the decisions the kernels
+// take: no contraction into fused multiply-adds (the two compilers would round differently).
+ETX_HD float lbvh_half_area(const f3& lo, const f3& hi) {
+#pragma clang fp contract(off)
+  const f3 d = hi - lo;
+  const float xy = d.x * d.y, yz = d.y * d.z, zx = d.z * d.x;
+  return (xy + yz) + zx;
+}
+
+struct LbvhKid {
+  uint32_t first, last, node;  // sorted positions [first, last]; the radix node that covers them (when more than one)
+};
+
+ETX_HD float lbvh_kid_area(const LbvhBoxes& boxes, const LbvhKid& kid) {
+  f3 lo, hi;
+  if (kid.first == kid.last)
+    lbvh_triangle_box(boxes.tris, kid.first, lo, hi);
+  else
+    lo = boxes.lo[kid.node], hi = boxes.hi[kid.node];
+  return lbvh_half_area(lo, hi);
+}
+
+// A range becomes a leaf when it is one triangle, or at most kLbvhLeafMax and not cheaper to split once more (surface area
+// heuristic with the cost of a node visit = one triangle test, host_scene.cpp Builder::split).
+ETX_HD bool lbvh_is_leaf(const LbvhNode* radix, const LbvhBoxes& boxes, const LbvhKid& kid) {
+#pragma clang fp contract(off)
+  const uint32_t size = kid.last - kid.first + 1u;
+  if (size == 1u)
+    return true;
+  if (size > kLbvhLeafMax)
+    return false;
+  const LbvhNode nd = radix[kid.node];
+  const LbvhKid left = {nd.first, nd.split, nd.split}, right = {nd.split + 1u, nd.last, nd.split + 1u};
+  const float area = lbvh_kid_area(boxes, kid);
+  const float leaf_cost = area * float(size);
+  const float left_cost = lbvh_kid_area(boxes, left) * float(left.last - left.first + 1u);
+  const float right_cost = lbvh_kid_area(boxes, right) * float(right.last - right.first + 1u);
+  const float split_cost = (left_cost + right_cost) + area;
+  return leaf_cost <= split_cost;
+}
+
+// One four-wide node from inner node `source` of the radix tree: a leaf child is final (~((first << 3) | (count - 1))), a child
+// that stays an inner node is returned as its radix node index in `inner[k]` (kInvalid otherwise) and the caller assigns the
+// breadth-first index.
+ETX_HD uint32_t lbvh_collapse(const LbvhNode* radix, const LbvhBoxes& boxes, uint32_t source, int32_t child[4], uint32_t inner[4]) {
   const LbvhNode root = radix[source];
-  Kid kids[4] = {{root.first, root.split, root.split}, {root.split + 1u, root.last, root.split + 1u}, {0u, 0u, 0u}, {0u, 0u, 0u}};
+  LbvhKid kids[4] = {{root.first, root.split, root.split}, {root.split + 1u, root.last, root.split + 1u}, {0u, 0u, 0u}, {0u, 0u, 0u}};
+  bool leaf[4] = {lbvh_is_leaf(radix, boxes, kids[0]), lbvh_is_leaf(radix, boxes, kids[1]), true, true};
   uint32_t count = 2u;
   while (count < 4u) {
     int best = -1;
-    uint32_t best_size = kLbvhLeafMax;
+    float best_area = -1.0f;
     for (uint32_t k = 0; k < count; ++k) {
-      const uint32_t size = kids[k].last - kids[k].first + 1u;
-      if (size > best_size)
-        best_size = size, best = int(k);
+      if (leaf[k])
+        continue;
+      const float area = lbvh_kid_area(boxes, kids[k]);
+      if (area > best_area)
+        best_area = area, best = int(k);
     }
     if (best < 0)
       break;
     const LbvhNode expanded = radix[kids[best].node];
     kids[best] = {expanded.first, expanded.split, expanded.split};
-    kids[count++] = {expanded.split + 1u, expanded.last, expanded.split + 1u};
+    kids[count] = {expanded.split + 1u, expanded.last, expanded.split + 1u};
+    leaf[best] = lbvh_is_leaf(radix, boxes, kids[best]);
+    leaf[count] = lbvh_is_leaf(radix, boxes, kids[count]);
+    count += 1u;
   }
   for (uint32_t k = 0; k < 4u; ++k) {
     child[k] = kBvhEmptyChild;
     inner[k] = kInvalid;
     if (k >= count)
       continue;
-    const uint32_t size = kids[k].last - kids[k].first + 1u;
-    if (size <= kLbvhLeafMax)
-      child[k] = ~int32_t((kids[k].first << 3u) | (size - 1u));
+    if (leaf[k])
+      child[k] = ~int32_t((kids[k].first << 3u) | (kids[k].last - kids[k].first));
     else
       inner[k] = kids[k].node;
   }

@@ -594,6 +594,28 @@ void build_lbvh_host(const etx_abi_scene* scene, HostBvh& out) {
   std::vector<LbvhNode> radix(n - 1u);
   for (uint32_t i = 0; i + 1u < n; ++i)
     radix[i] = lbvh_node(sorted_keys.data(), int(n), int(i));
+  // boxes of the radix nodes: children before parents (the kernel climbs from the leaves; min / max do not care about the order)
+  std::vector<f3> box_lo(n - 1u), box_hi(n - 1u);
+  {
+    std::vector<uint8_t> done(n - 1u, 0);
+    std::vector<uint32_t> pending = {0u};
+    while (pending.empty() == false) {
+      const uint32_t i = pending.back();
+      const LbvhNode nd = radix[i];
+      const bool left_ready = (nd.first == nd.split) || done[nd.split], right_ready = (nd.split + 1u == nd.last) || done[nd.split + 1u];
+      if (left_ready && right_ready) {
+        lbvh_join_children(radix.data(), out.tris.data(), box_lo.data(), box_hi.data(), i);
+        done[i] = 1;
+        pending.pop_back();
+      } else {
+        if (left_ready == false)
+          pending.push_back(nd.split);
+        if (right_ready == false)
+          pending.push_back(nd.split + 1u);
+      }
+    }
+  }
+  const LbvhBoxes boxes = {out.tris.data(), box_lo.data(), box_hi.data()};
   std::vector<uint32_t> queue = {0u}, next;
   uint32_t base = 0;
   while (queue.empty() == false) {
@@ -603,7 +625,7 @@ void build_lbvh_host(const etx_abi_scene* scene, HostBvh& out) {
     for (size_t i = 0; i < queue.size(); ++i) {
       int32_t child[4];
       uint32_t inner[4];
-      lbvh_collapse(radix.data(), queue[i], child, inner);
+      lbvh_collapse(radix.data(), boxes, queue[i], child, inner);
       for (uint32_t k = 0; k < 4u; ++k) {
         if (inner[k] == kInvalid)
           continue;

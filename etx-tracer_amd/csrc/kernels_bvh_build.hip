@@ -3,7 +3,7 @@
 // done on the device tables. The per-element steps are in dev_lbvh.h (shared with the host emulation the CPU tests check).
 //   k_bvh_triangles_update : BvhTri slots from the scene tables (one thread per slot, 3 gathered vertices in, 48 B out)
 //   k_bvh_refit_level      : BVH4 child boxes + stack bound of one breadth-first level, bottom up (one thread per node)
-//   k_lbvh_keys / hipcub radix sort / k_lbvh_radix_nodes / k_lbvh_collapse_level : the linear BVH build
+//   k_lbvh_keys / hipcub radix sort / k_lbvh_radix_nodes / k_lbvh_radix_boxes / k_lbvh_collapse_level : the linear BVH build
 // All of it is HBM-latency bound and tiny next to an iteration: the build of a 1.2 M-triangle tree moves a few hundred MB.
 #include "kernels_bvh_build.h"
 #include "dev_lbvh.h"
@@ -49,22 +49,53 @@ __global__ __launch_bounds__(kBuildBlock) void k_lbvh_assign_slots(const uint32_
     tris[i].v0_index.w = __uint_as_float(sorted_values[i]);
 }
 
-__global__ __launch_bounds__(kBuildBlock) void k_lbvh_radix_nodes(const uint64_t* sorted_keys, LbvhNode* radix, uint32_t count) {
+// radix node i, and who its children's parent is: `parent` of an inner child, `leaf_parent` of a child that is one sorted position
+__global__ __launch_bounds__(kBuildBlock) void k_lbvh_radix_nodes(const uint64_t* sorted_keys, LbvhNode* radix, uint32_t* parent, uint32_t* leaf_parent, uint32_t count) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i + 1u < count)
-    radix[i] = lbvh_node(sorted_keys, int(count), int(i));
+  if (i + 1u >= count)
+    return;
+  const LbvhNode nd = lbvh_node(sorted_keys, int(count), int(i));
+  radix[i] = nd;
+  if (nd.first == nd.split)
+    leaf_parent[nd.first] = i;
+  else
+    parent[nd.split] = i;
+  if (nd.split + 1u == nd.last)
+    leaf_parent[nd.last] = i;
+  else
+    parent[nd.split + 1u] = i;
+}
+
+// Boxes of the radix nodes, bottom-up: one thread per sorted position climbs from its parent; at every node the first thread to
+// arrive stops, the second - both children are complete then - joins their boxes and goes on (Karras 2012, section 3). Nobody waits.
+__global__ __launch_bounds__(kBuildBlock) void k_lbvh_radix_boxes(const LbvhNode* radix, const BvhTri* tris, const uint32_t* parent, const uint32_t* leaf_parent, uint32_t* arrivals, f3* lo, f3* hi,
+  uint32_t count) {
+  const uint32_t position = blockIdx.x * blockDim.x + threadIdx.x;
+  if (position >= count)
+    return;
+  uint32_t node = leaf_parent[position];
+  for (;;) {
+    __threadfence();  // this thread's box of the child below is visible before its arrival is
+    if (atomicAdd(arrivals + node, 1u) == 0u)
+      return;
+    __threadfence();
+    lbvh_join_children(radix, tris, lo, hi, node);
+    if (node == 0u)
+      return;
+    node = parent[node];
+  }
 }
 
 // One breadth-first level: `queue` holds the radix nodes that become the BVH4 nodes [base, base + count); their inner children are
 // appended to `next_queue` (slot from an atomic counter: the order inside a level is arbitrary) and numbered base + count + slot.
-__global__ __launch_bounds__(kBuildBlock) void k_lbvh_collapse_level(const LbvhNode* radix, const uint32_t* queue, uint32_t base, uint32_t count, Bvh4Node* nodes, uint32_t* next_queue,
+__global__ __launch_bounds__(kBuildBlock) void k_lbvh_collapse_level(const LbvhNode* radix, LbvhBoxes boxes, const uint32_t* queue, uint32_t base, uint32_t count, Bvh4Node* nodes, uint32_t* next_queue,
   uint32_t* next_count) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count)
     return;
   int32_t child[4];
   uint32_t inner[4];
-  lbvh_collapse(radix, queue[i], child, inner);
+  lbvh_collapse(radix, boxes, queue[i], child, inner);
   for (uint32_t k = 0; k < 4u; ++k) {
     if (inner[k] == kInvalid)
       continue;
@@ -120,14 +151,16 @@ int lbvh_build_device(hipStream_t stream, DScene scene, f3 cube_min, float cube_
     return ETX_HIP_ERROR_UNSUPPORTED;
   }
   uint64_t *keys = nullptr, *sorted_keys = nullptr;
-  uint32_t *values = nullptr, *sorted_values = nullptr, *queue_a = nullptr, *queue_b = nullptr, *counter = nullptr;
+  uint32_t *values = nullptr, *sorted_values = nullptr, *queue_a = nullptr, *queue_b = nullptr, *counter = nullptr, *parent = nullptr, *leaf_parent = nullptr, *arrivals = nullptr;
+  f3 *box_lo = nullptr, *box_hi = nullptr;
   LbvhNode* radix = nullptr;
   void* sort_storage = nullptr;
   size_t sort_bytes = 0;
   hipEvent_t begin = nullptr, end = nullptr;
   auto cleanup = [&]() {
     for (void* p : {static_cast<void*>(keys), static_cast<void*>(sorted_keys), static_cast<void*>(values), static_cast<void*>(sorted_values), static_cast<void*>(queue_a),
-           static_cast<void*>(queue_b), static_cast<void*>(counter), static_cast<void*>(radix), sort_storage})
+           static_cast<void*>(queue_b), static_cast<void*>(counter), static_cast<void*>(radix), static_cast<void*>(parent), static_cast<void*>(leaf_parent), static_cast<void*>(arrivals),
+           static_cast<void*>(box_lo), static_cast<void*>(box_hi), sort_storage})
       if (p != nullptr)
         (void)hipFree(p);
     if (begin != nullptr)
@@ -142,7 +175,9 @@ int lbvh_build_device(hipStream_t stream, DScene scene, f3 cube_min, float cube_
   };
   if ((hipMalloc(&keys, n * sizeof(uint64_t)) != hipSuccess) || (hipMalloc(&sorted_keys, n * sizeof(uint64_t)) != hipSuccess) || (hipMalloc(&values, n * sizeof(uint32_t)) != hipSuccess) ||
       (hipMalloc(&sorted_values, n * sizeof(uint32_t)) != hipSuccess) || (hipMalloc(&queue_a, n * sizeof(uint32_t)) != hipSuccess) || (hipMalloc(&queue_b, n * sizeof(uint32_t)) != hipSuccess) ||
-      (hipMalloc(&counter, sizeof(uint32_t)) != hipSuccess) || (hipMalloc(&radix, n * sizeof(LbvhNode)) != hipSuccess))
+      (hipMalloc(&counter, sizeof(uint32_t)) != hipSuccess) || (hipMalloc(&radix, n * sizeof(LbvhNode)) != hipSuccess) || (hipMalloc(&parent, n * sizeof(uint32_t)) != hipSuccess) ||
+      (hipMalloc(&leaf_parent, n * sizeof(uint32_t)) != hipSuccess) || (hipMalloc(&arrivals, n * sizeof(uint32_t)) != hipSuccess) || (hipMalloc(&box_lo, n * sizeof(f3)) != hipSuccess) ||
+      (hipMalloc(&box_hi, n * sizeof(f3)) != hipSuccess))
     return fail("hipMalloc of the temporaries");
   if (hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, sorted_keys, values, sorted_values, int(n), 0, 63, stream) != hipSuccess)
     return fail("sizing the radix sort");
@@ -159,7 +194,11 @@ int lbvh_build_device(hipStream_t stream, DScene scene, f3 cube_min, float cube_
   scene.bvh_tris = tris;  // the refit reads the slots' triangle indices through the scene
   scene.bvh_tri_count = n;
   launch_bvh_triangles_update(stream, scene, tris, n);
-  hipLaunchKernelGGL(k_lbvh_radix_nodes, dim3(blocks_for(n)), dim3(kBuildBlock), 0, stream, sorted_keys, radix, n);
+  hipLaunchKernelGGL(k_lbvh_radix_nodes, dim3(blocks_for(n)), dim3(kBuildBlock), 0, stream, sorted_keys, radix, parent, leaf_parent, n);
+  if (hipMemsetAsync(arrivals, 0, n * sizeof(uint32_t), stream) != hipSuccess)
+    return fail("hipMemset of the arrival counters");
+  hipLaunchKernelGGL(k_lbvh_radix_boxes, dim3(blocks_for(n)), dim3(kBuildBlock), 0, stream, radix, tris, parent, leaf_parent, arrivals, box_lo, box_hi, n);
+  const LbvhBoxes boxes = {tris, box_lo, box_hi};
 
   // collapse, level by level; the host reads one counter per level (a build step, not the render loop)
   const uint32_t root_source = 0u;  // radix node 0 covers every key
@@ -176,7 +215,7 @@ int lbvh_build_device(hipStream_t stream, DScene scene, f3 cube_min, float cube_
     result.level_offsets.push_back(base);
     if (hipMemsetAsync(counter, 0, sizeof(uint32_t), stream) != hipSuccess)
       return fail("hipMemset of the level counter");
-    hipLaunchKernelGGL(k_lbvh_collapse_level, dim3(blocks_for(count)), dim3(kBuildBlock), 0, stream, radix, queue, base, count, nodes, next_queue, counter);
+    hipLaunchKernelGGL(k_lbvh_collapse_level, dim3(blocks_for(count)), dim3(kBuildBlock), 0, stream, radix, boxes, queue, base, count, nodes, next_queue, counter);
     uint32_t next = 0u;
     if ((hipMemcpyAsync(&next, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) || (hipStreamSynchronize(stream) != hipSuccess))
       return fail("reading the level counter");

@@ -102,9 +102,9 @@ int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, c
 /* Who builds the traversal tree of the NEXT etx_hip_upload_scene (Raytracing::commit_changes hands this to Embree, rt.cxx:66-88):
  *   ETX_HIP_BVH_HOST_SAH     (default) binned-SAH BVH2 on the host, collapsed to the four-wide nodes: the tree that traverses fastest
  *   ETX_HIP_BVH_DEVICE_LBVH  linear BVH on the device (dev_lbvh.h: 63-bit Morton keys, radix sort, Karras' binary radix tree,
- *                            collapse to four-wide breadth-first nodes, boxes bottom-up): milliseconds instead of seconds for
- *                            10^5..10^6 triangles - time to first iteration, geometry that changes every frame - at a traversal
- *                            cost measured in DESIGN.md. Scenes of <= 64 triangles are swept linearly and always built on the host.
+ *                            surface-area guided collapse to four-wide breadth-first nodes, boxes bottom-up): a few milliseconds
+ *                            for 10^6 triangles - time to first iteration, geometry that changes every frame - at 3-15 % of the
+ *                            traversal rate. Scenes of <= 64 triangles are swept linearly and always built on the host.
  * etx_hip_bvh_info: {BVH4 nodes, triangles, depth | traversal stack entries << 16, bytes} of the uploaded scene and the time its
  * tree took to build (host: wall clock of the builder; device: HIP events around the build kernels), in milliseconds. */
 enum { ETX_HIP_BVH_HOST_SAH = 0, ETX_HIP_BVH_DEVICE_LBVH = 1 };
