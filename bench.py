@@ -66,9 +66,11 @@ def main():
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=32)
     parser.add_argument("--warmup", type=int, default=8)
-    parser.add_argument("--workload", default="full", choices=["full", "classic", "gems"],
+    parser.add_argument("--workload", default="full", choices=["full", "classic", "gems", "gems1m"],
                         help="full = surviving cornellbox.mtl (fog medium, env + dir emitters) = BASELINE.json configs[1]; classic = area light only; "
-                             "gems = configs[2] family: 2 892 triangles (BVH4 traversal), dispersive dielectrics + rough conductor, spectral")
+                             "gems = configs[2] family: 2 892 triangles (BVH4 traversal), dispersive dielectrics + rough conductor, spectral; "
+                             "gems1m = the same with 350 scaled copies of its gems (1 010 892 triangles: mesh size of configs[3-4], tools/synthetic_scenes.py)")
+    parser.add_argument("--bvh", default="host", choices=["host", "device"], help="who builds the traversal tree (etx_hip_set_bvh_builder)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-kernel-table", action="store_true", help="skip the extra pass that times every kernel group (profiling runs)")
     args = parser.parse_args()
@@ -90,12 +92,21 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    snapshot_path = os.path.join(ROOT, "tests", "golden", "cornell_%s_1080p.etxscene" % args.workload)
-    snap = etx.SceneSnapshot(snapshot_path)
+    spectral_workload = args.workload in ("gems", "gems1m")
+    snapshot_path = os.path.join(ROOT, "tests", "golden", "cornell_%s_1080p.etxscene" % ("gems" if spectral_workload else args.workload))
+    if args.workload == "gems1m":
+        from tools import synthetic_scenes
+        snap = synthetic_scenes.replicate_gems(etx, snapshot_path, 350)
+    else:
+        snap = etx.SceneSnapshot(snapshot_path)
     width, height = snap.film_size
     ctx = api.Context(local_rank)
+    ctx.set_bvh_builder(api.BVH_DEVICE_LBVH if args.bvh == "device" else api.BVH_HOST_SAH)
+    upload_t0 = time.perf_counter()
     ctx.upload_scene(snap)
-    if args.workload == "gems":  # spectral scene: the host's CIE observer (committed fixture of the reference's table)
+    upload_seconds = time.perf_counter() - upload_t0
+    tree = ctx.bvh_info()
+    if spectral_workload:  # spectral scene: the host's CIE observer (committed fixture of the reference's table)
         cie = np.load(os.path.join(ROOT, "tests", "golden", "cie_observer.npz"))
         ctx.upload_cie_table(cie["xyz"], float(cie["first_wavelength"]))
     if distributed:
@@ -254,12 +265,14 @@ def main():
             "config": {
                 "workload": "cornell_%s_vcm_1920x1080" % args.workload,
                 "scene": "Cornell box rebuilt for the reference's surviving camera/materials (scenes/make_scenes.py), loaded by the reference loader",
-                "integrator": "VCM, VCMOptions::default_values() (blue noise on), scene.samples 64, max-path-length 1023, rr start 6, %s" % ("spectral" if args.workload == "gems" else "RGB"),
+                "integrator": "VCM, VCMOptions::default_values() (blue noise on), scene.samples 64, max-path-length 1023, rr start 6, %s" % ("spectral" if spectral_workload else "RGB"),
+                "triangles": int(snap.triangle_count), "tree": {"builder": args.bvh, "build_ms": round(tree["build_ms"], 3), "nodes": tree["nodes"], "depth": tree["depth"], "stack_need": tree["stack_need"],
+                                                                "upload_s": round(upload_seconds, 3)},
                 "samples_per_step": width * height,
                 "parallelism": "iteration-sharded x%d, one RCCL film all-reduce at the end" % world,
             },
             "roofline": {
-                "kernel": ("k_trace_closest_bvh (ray queue -> hit queue; BVH4, top levels staged in LDS, persistent workgroups)" if args.workload == "gems"
+                "kernel": ("k_trace_closest_bvh (ray queue -> hit queue; BVH4, top levels staged in LDS, persistent workgroups)" if spectral_workload
                            else "k_trace_closest (ray queue -> hit queue; sweep over the <= 64 pre-transformed primitives of the box)"),
                 "bound": "hbm",
                 "achieved": round(achieved, 3),
@@ -288,7 +301,8 @@ def main():
                 "finite": finite,
             },
         }
-        line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(snapshot_path, width, height)
+        # (gems1m is assembled in memory: there is no snapshot file of it to hand to the reference's driver)
+        line["cpu_baseline"] = None if (args.no_cpu_baseline or (world > 1) or (args.workload == "gems1m")) else cpu_baseline(snapshot_path, width, height)
         print(json.dumps(line))
     if distributed:
         dist.barrier()

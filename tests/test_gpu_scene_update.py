@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from tests.test_gpu_parity import make_rays
+from tools import synthetic_scenes
 
 pytestmark = pytest.mark.gpu
 
@@ -163,30 +164,7 @@ def test_update_scene_argument_errors(etx, golden_dir):
 
 
 def replicate_gems(etx, golden_dir, copies, seed=9):
-    """the gems scene with `copies` scaled copies of its gem triangles scattered through the box: 10^4..10^6 triangles of real
-    shape statistics (small closed facetted objects) without a scene file of that size"""
-    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_gems_128.etxscene"))
-    vertices, triangles, to_emitter = snap.vertices().copy(), snap.triangles().copy(), snap.triangle_to_emitter().copy()
-    classes = snap.material_classes()
-    gem = np.nonzero(np.isin(classes[triangles[:, 3]], (3, 4)))[0]
-    rng = np.random.default_rng(seed)
-    new_vertices, new_triangles = [vertices], [triangles]
-    base = vertices.shape[0]
-    corner_rows = vertices[triangles[gem, 0:3].reshape(-1).astype(np.int64)]  # (3 * G, 14): unshared copies
-    centre = corner_rows[:, 0:3].mean(axis=0)
-    for _ in range(copies):
-        scale = np.float32(rng.uniform(0.1, 0.3))
-        offset = np.float32([rng.uniform(-0.8, 0.8), rng.uniform(0.15, 1.8), rng.uniform(-0.8, 0.8)])
-        rows = corner_rows.copy()
-        rows[:, 0:3] = (rows[:, 0:3] - centre) * scale + offset
-        tri = triangles[gem].copy()
-        tri[:, 0:3] = base + np.arange(3 * len(gem), dtype=np.uint32).reshape(-1, 3)
-        new_vertices.append(rows)
-        new_triangles.append(tri)
-        base += rows.shape[0]
-    all_triangles = np.concatenate(new_triangles)
-    snap.replace_geometry(np.concatenate(new_vertices), all_triangles, np.concatenate([to_emitter, np.full(all_triangles.shape[0] - to_emitter.shape[0], 0xFFFFFFFF, dtype=np.uint32)]))
-    return snap
+    return synthetic_scenes.replicate_gems(etx, os.path.join(golden_dir, "cornell_gems_128.etxscene"), copies, seed)
 
 
 def test_device_built_tree_is_the_emulated_one_and_finds_the_sah_hits(etx, golden_dir):

@@ -1,5 +1,5 @@
 """Tree build and traversal cost of the two builders (etx_hip_set_bvh_builder) on scenes of 10^4..10^6 triangles: the gems scene with
-scaled copies of its gems scattered through the box (tests/test_gpu_scene_update.py replicate_gems). Per scene and builder: build time
+scaled copies of its gems scattered through the box (tools/synthetic_scenes.py replicate_gems). Per scene and builder: build time
 (etx_hip_bvh_info), nodes / depth / stack bound, closest-hit throughput of 2 M incoherent rays with device-resident queues
 (etx_hip_trace_rays_device, HIP events), and for the host tree the time of an in-place refit (etx_hip_update_scene, wall clock incl.
 the vertex copy). One JSON line per row. Usage: python tools/bvh_build_bench.py [copies ...]
@@ -16,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 etx = importlib.import_module("etx-tracer_amd")
-from tests.test_gpu_scene_update import replicate_gems  # noqa: E402
+from tools.synthetic_scenes import replicate_gems  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 N_RAYS = 1 << 21
@@ -36,7 +36,7 @@ def rays():
 def main():
     ro, rd, hits = rays()
     for copies in [int(a) for a in sys.argv[1:]] or [0, 40, 350]:
-        snap = replicate_gems(etx, GOLDEN, copies) if copies else etx.SceneSnapshot(os.path.join(GOLDEN, "cornell_gems_128.etxscene"))
+        snap = replicate_gems(etx, os.path.join(GOLDEN, "cornell_gems_128.etxscene"), copies) if copies else etx.SceneSnapshot(os.path.join(GOLDEN, "cornell_gems_128.etxscene"))
         reference = None
         for name, builder in (("host binned SAH", etx.api.BVH_HOST_SAH), ("device linear", etx.api.BVH_DEVICE_LBVH)):
             ctx = etx.api.Context(0)
