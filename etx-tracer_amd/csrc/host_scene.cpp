@@ -73,6 +73,27 @@ void DeviceScene::borrow(const DeviceScene& owner) {
 
 namespace {
 
+uint32_t build_threads() {  // ETX_HIP_BVH_BUILD_THREADS=1 keeps the host build on one thread
+  const char* e = getenv("ETX_HIP_BVH_BUILD_THREADS");
+  return e ? uint32_t(std::max(1, atoi(e))) : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+}
+
+// body(begin, end) over [0, count) in contiguous chunks, one per thread (per-element loops of the host build of large scenes)
+template <class Body>
+void parallel_chunks(uint32_t count, uint32_t threads, Body body) {
+  if ((threads <= 1u) || (count < 65536u)) {
+    body(0u, count);
+    return;
+  }
+  const uint32_t chunk = (count + threads - 1u) / threads;
+  std::vector<std::thread> workers;
+  for (uint32_t begin = chunk; begin < count; begin += chunk)
+    workers.emplace_back(body, begin, std::min(count, begin + chunk));
+  body(0u, std::min(count, chunk));
+  for (std::thread& w : workers)
+    w.join();
+}
+
 struct Builder {
   struct Prim {
     f3 bmin, bmax, centroid;
@@ -349,7 +370,7 @@ void build_flat_prims(const etx_abi_scene* scene, const HostBvh& bvh, std::vecto
   }
 }
 
-void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
+void build_bvh(const etx_abi_scene* scene, HostBvh& out, bool keep_bvh2) {
   const auto* vertices = reinterpret_cast<const etx_abi_vertex*>(scene->vertices.a);
   const auto* triangles = reinterpret_cast<const etx_abi_triangle*>(scene->triangles.a);
   const auto* materials = reinterpret_cast<const etx_abi_material*>(scene->materials.a);
@@ -371,17 +392,18 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
     b.traversal_cost = float(atof(e));
   std::vector<Builder::Prim> primitives(n);
   b.prims = primitives.data();
-  for (uint32_t i = 0; i < n; ++i) {
-    f3 p0 = a3(vertices[triangles[i].i[0]].pos), p1 = a3(vertices[triangles[i].i[1]].pos), p2 = a3(vertices[triangles[i].i[2]].pos);
-    b.prims[i].bmin = fmin3(p0, fmin3(p1, p2));
-    b.prims[i].bmax = fmax3(p0, fmax3(p1, p2));
-    b.prims[i].centroid = (b.prims[i].bmin + b.prims[i].bmax) * 0.5f;
-    b.prims[i].index = i;
-  }
+  const uint32_t threads = build_threads();
+  parallel_chunks(n, threads, [&](uint32_t begin, uint32_t end) {
+    for (uint32_t i = begin; i < end; ++i) {
+      f3 p0 = a3(vertices[triangles[i].i[0]].pos), p1 = a3(vertices[triangles[i].i[1]].pos), p2 = a3(vertices[triangles[i].i[2]].pos);
+      b.prims[i].bmin = fmin3(p0, fmin3(p1, p2));
+      b.prims[i].bmax = fmax3(p0, fmax3(p1, p2));
+      b.prims[i].centroid = (b.prims[i].bmin + b.prims[i].bmax) * 0.5f;
+      b.prims[i].index = i;
+    }
+  });
   phase("primitive bounds");
   // large scenes are built by tasks (a million triangles: 0.7 s on one core); ETX_HIP_BVH_BUILD_THREADS=1 keeps one thread
-  const char* threads_env = getenv("ETX_HIP_BVH_BUILD_THREADS");
-  const uint32_t threads = threads_env ? uint32_t(std::max(1, atoi(threads_env))) : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
   if ((threads > 1u) && (n >= 32768u)) {
     Builder::Subtree tree = Builder::build_range(b.prims, b.traversal_cost, 0u, n, 1u, std::max(4096u, n / (4u * threads)));
     b.nodes = std::move(tree.nodes);
@@ -394,7 +416,8 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
   phase("binned SAH tree");
 
   out.tris.resize(n);
-  for (uint32_t i = 0; i < n; ++i) {
+  parallel_chunks(n, threads, [&](uint32_t begin, uint32_t end) {
+  for (uint32_t i = begin; i < end; ++i) {
     uint32_t ti = b.prims[i].index;
     const etx_abi_triangle& t = triangles[ti];
     f3 p0 = a3(vertices[t.i[0]].pos), p1 = a3(vertices[t.i[1]].pos), p2 = a3(vertices[t.i[2]].pos);
@@ -420,6 +443,7 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
     out.tris[i].e1_flags = make_float4(e1.x, e1.y, e1.z, bits(flags));
     out.tris[i].e2_mat = make_float4(e2.x, e2.y, e2.z, bits(t.material_index));
   }
+  });
 
   phase("traversal triangles");
   // flatten: inner nodes only; a child reference is an inner index (>= 0) or ~((first << 3) | (count - 1))
@@ -434,8 +458,8 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out) {
       return remap[tmp_index];
     return ~int32_t((tn.first << 3) | (tn.count - 1u));
   };
-  out.nodes.resize(inner);
-  for (size_t i = 0; i < b.nodes.size(); ++i) {
+  out.nodes.resize(keep_bvh2 ? inner : 0u);  // the two-wide form is the invariants check's input; the device reads the four-wide one
+  for (size_t i = 0; keep_bvh2 && (i < b.nodes.size()); ++i) {
     const auto& tn = b.nodes[i];
     if (tn.count != 0)
       continue;
@@ -715,7 +739,7 @@ int build_traversal_tables(const etx_abi_scene* scene, DeviceScene& out, DScene&
     return build_lbvh_tables(scene, out, d, nullptr, nullptr, error);
   HostBvh bvh;
   const auto build_begin = std::chrono::steady_clock::now();
-  build_bvh(scene, bvh);
+  build_bvh(scene, bvh, /* keep the two-wide intermediate */ false);
   out.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - build_begin).count();
   // near-child-first traversal of a four-wide tree pushes at most three children per level
   if (bvh.stack_need > kMaxStackDepth) {

@@ -74,7 +74,7 @@ struct HostBvh {
   int32_t root = 0;
   uint32_t depth = 0;
 };
-void build_bvh(const etx_abi_scene* scene, HostBvh& out);
+void build_bvh(const etx_abi_scene* scene, HostBvh& out, bool keep_bvh2 = true);
 
 // The device build (dev_lbvh.h) run on the host, element by element in the order the kernels' indices run: the tree the device
 // WILL build, for tests without a GPU (invariants, stack bound, rays against the SAH tree).
