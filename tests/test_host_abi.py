@@ -130,3 +130,13 @@ def test_film_merge_iteration_patch_applies_and_compiles(tmp_path):
     tu = tmp_path / "binding.cxx"
     tu.write_text("#define ETX_FILM_HAS_MERGE_ITERATION 1\n#include <etx/rt/rt.hxx>\n#include <etx_hip_integrators.hxx>\nint main() { return 0; }\n")
     subprocess.check_call([cxx] + flags + [str(tu)])
+
+
+def test_public_headers_are_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI (cgo / JNI / ctypes-style bindings include these headers): both compile as C99, pedantic."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    source = tmp_path / "c_abi.c"
+    source.write_text('#include "include/etx_scene_abi.h"\n#include "include/etx_hip.h"\nint main(void) { return (int)sizeof(etx_hip_stats_t) * 0; }\n')
+    result = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + root, "-fsyntax-only", str(source)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert result.returncode == 0, result.stdout
