@@ -28,9 +28,9 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s sp
 BYTES_PER_RAY = 48         # 32 B ray record in + 16 B hit record out (DESIGN.md "traversal kernel")
 
 
-def cpu_baseline(snapshot_path, width, height, seconds_budget=25.0):
-    """Times the reference's CPUVCM (oracle/_ref/etx_oracle = reference integrator + BVH shim, no Embree) on all host
-    cores, on a bounded number of iterations of the SAME workload."""
+def cpu_baseline(snapshot_path, width, height, seconds_budget=25.0, integrator="vcm", extra=()):
+    """Times the reference's CPUVCM / CPUBidirectional (oracle/_ref/etx_oracle = reference integrator + BVH shim, no Embree) on
+    all host cores, on a bounded number of iterations of the SAME workload."""
     binary = os.path.join(ROOT, "oracle", "_ref", "etx_oracle")
     if not os.path.exists(binary):
         return None
@@ -38,8 +38,8 @@ def cpu_baseline(snapshot_path, width, height, seconds_budget=25.0):
     def run(iterations):
         # VCMOptions::default_values() (blue noise on), like the device run; --max-iterations bounds the sample, --spp keeps
         # scene.samples (and with it the blue-noise class) at the workload's 64
-        out = subprocess.run([binary, "--load-snapshot", snapshot_path, "--integrator", "vcm", "--spp", "64", "--max-iterations", str(iterations)],
-                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        out = subprocess.run([binary, "--load-snapshot", snapshot_path, "--integrator", integrator, "--spp", "64", "--max-iterations", str(iterations), *extra],
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         m = re.search(r"ORACLE_RESULT (\{.*\})", out.stdout)
         return json.loads(m.group(1)) if m else None
 
@@ -56,8 +56,8 @@ def cpu_baseline(snapshot_path, width, height, seconds_budget=25.0):
         "cores": os.cpu_count(),
         "threads": result["threads"],
         "kind": "reference",
-        "sample": "%d VCM iterations of the same %dx%d snapshot (reference CPUVCM + oracle BVH shim instead of Embree), %.1f s" % (
-            result["iterations"], width, height, result["seconds"]),
+        "sample": "%d %s iterations of the same %dx%d snapshot (reference %s + oracle BVH shim instead of Embree), %.1f s" % (
+            result["iterations"], integrator.upper(), width, height, "CPUVCM" if integrator == "vcm" else "CPUBidirectional", result["seconds"]),
     }
 
 
@@ -66,10 +66,12 @@ def main():
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=32)
     parser.add_argument("--warmup", type=int, default=8)
-    parser.add_argument("--workload", default="full", choices=["full", "classic", "gems", "gems1m"],
+    parser.add_argument("--workload", default="full", choices=["full", "classic", "gems", "gems1m", "sssdragon_bdpt", "cloud_bdpt"],
                         help="full = surviving cornellbox.mtl (fog medium, env + dir emitters) = BASELINE.json configs[1]; classic = area light only; "
                              "gems = configs[2] family: 2 892 triangles (BVH4 traversal), dispersive dielectrics + rough conductor, spectral; "
-                             "gems1m = the same with 350 scaled copies of its gems (1 010 892 triangles: mesh size of configs[3-4], tools/synthetic_scenes.py)")
+                             "gems1m = the same with 350 scaled copies of its gems (1 010 892 triangles: mesh size of configs[3-4], tools/synthetic_scenes.py); "
+                             "sssdragon_bdpt = configs[3]: two random-walk subsurface blob meshes of 102 400 triangles, BDPTFull, 1920x1080; "
+                             "cloud_bdpt = configs[4]: the fog box with a procedural 256^3 heterogeneous density grid, BDPTFull, 2048x2048")
     parser.add_argument("--bvh", default="host", choices=["host", "device"], help="who builds the traversal tree (etx_hip_set_bvh_builder)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-kernel-table", action="store_true", help="skip the extra pass that times every kernel group (profiling runs)")
@@ -93,10 +95,22 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     spectral_workload = args.workload in ("gems", "gems1m")
+    bdpt_workload = args.workload in ("sssdragon_bdpt", "cloud_bdpt")
     snapshot_path = os.path.join(ROOT, "tests", "golden", "cornell_%s_1080p.etxscene" % ("gems" if spectral_workload else args.workload))
+    cpu_snapshot_path, cpu_extra = snapshot_path, ()
     if args.workload == "gems1m":
         from tools import synthetic_scenes
         snap = synthetic_scenes.replicate_gems(etx, snapshot_path, 350)
+    elif args.workload == "sssdragon_bdpt":
+        from tools import synthetic_scenes
+        snapshot_path = os.path.join(ROOT, "tests", "golden", "cornell_sss_1080p.etxscene")
+        snap = synthetic_scenes.sss_dragon(etx, snapshot_path)
+        cpu_snapshot_path = "/tmp/etx_bench_sssdragon_%d.etxscene" % os.getpid()  # the assembled scene, for the reference's driver
+    elif args.workload == "cloud_bdpt":
+        snapshot_path = os.path.join(ROOT, "tests", "golden", "cornell_cloud_2048.etxscene")
+        snap = etx.SceneSnapshot(snapshot_path)
+        snap.inject_density(256)
+        cpu_snapshot_path, cpu_extra = snapshot_path, ("--inject-density", "256")  # the driver builds the same grid (oracle/driver/etx_oracle.cxx)
     else:
         snap = etx.SceneSnapshot(snapshot_path)
     width, height = snap.film_size
@@ -120,15 +134,24 @@ def main():
         raise SystemExit("bench workload expects scene.samples = 64 (blue-noise class 6), snapshot has %d" % snap_samples)
     ctx.upload_bluenoise(6, bluenoise_tables.load(os.path.join(ROOT, "tests", "golden", "bluenoise_64spp.npz")))
     options = integ_mod.vcm_options_from_dict({})
+    if bdpt_workload:  # CPUBidirectional's defaults except the mode: BDPTFull = all vertex connections
+        options = integ_mod.bdpt_options_from_dict({"bdpt-mode": api.BDPT_MODE_FULL})
+        ctx.set_timers(0xff)  # the roofline kernel of these workloads is whichever group dominates: time all of them
+
+    def begin(first_iteration, iteration_stride):
+        if bdpt_workload:
+            ctx.begin_bdpt(options, first_iteration=first_iteration, iteration_stride=iteration_stride)
+        else:
+            ctx.begin_vcm(options, first_iteration=first_iteration, iteration_stride=iteration_stride)
 
     def run_steps(count, first_offset):
-        ctx.begin_vcm(options, first_iteration=rank + first_offset * world, iteration_stride=world)
+        begin(rank + first_offset * world, world)
         for _ in range(count):
             ctx.render_iteration()  # asynchronous: iterations overlap on the device lanes
         ctx.sync()
         s = ctx.stats()             # totals since begin
         acc = {"rays": s.rays_extension, "trace_ms": s.ms_trace_closest, "launches": s.launches_trace_closest, "shadow": s.rays_shadow, "lv": s.light_vertices,
-               "rounds": s.wavefront_bounces, "examined": s.photons_examined}
+               "rounds": s.wavefront_bounces, "examined": s.photons_examined, "stats": s}
         ctx.reduce_film()
         return acc
 
@@ -173,38 +196,57 @@ def main():
     # Per-kernel-group rooflines: a short extra pass with every kernel group timed by HIP events on its launch stream
     # (etx_hip_set_timers; the main timed region above times only the two traversal groups). Algorithmic bytes per unit are
     # the figures of DESIGN.md 3; the units come from the device counters of the same pass.
+    def kernel_table(s, steps, note):
+        merge_vertices = s.camera_vertices
+        if bdpt_workload:
+            # bidirectional state = 116 B (84 B + the previous vertex' position / normal), records of dev_bdpt.h
+            units = {
+                "trace_closest": ("ray", s.rays_extension, 48.0 * s.rays_extension, s.ms_trace_closest, "k_trace_closest_bvh: 32 B ray in + 16 B hit out (+ the tree: not cache resident at this size)"),
+                "trace_shadow": ("segment", s.rays_shadow, 48.0 * s.rays_shadow + 12.0 * s.splats, s.ms_trace_shadow, "k_trace_shadow: 48 B request in, 12 B of film atomics per visible light splat"),
+                "shade_light": ("path segment", s.rays_light, 248.0 * s.rays_light + 96.0 * s.light_vertices, s.ms_shade_light,
+                                "k_bdpt_light_shade + k_bdpt_walk + k_bdpt_connect_camera: 116 B state + 16 B hit in, 116 B state out, 96 B per stored light vertex (every event of a subsurface walk is one)"),
+                "shade_camera": ("path segment", s.rays_camera, 248.0 * s.rays_camera + 164.0 * s.camera_vertices, s.ms_shade_camera,
+                                 "k_bdpt_camera_shade + k_bdpt_walk + k_bdpt_connect_light: 116 B state + 16 B hit in, 116 B out, 116 B vertex record + 48 B request per connectible vertex"),
+                "connect": ("pair", s.pairs, 220.0 * s.pairs, s.ms_connect, "k_expand_pairs + k_bdpt_connect_pairs: 8 B pair + 96 B light vertex + 68 B camera vertex + 48 B shadow request"),
+            }
+        else:
+            units = {
+                "trace_closest": ("ray", s.rays_extension, 48.0 * s.rays_extension, s.ms_trace_closest, "k_trace_closest: 32 B ray in + 16 B hit out"),
+                "trace_shadow": ("segment", s.rays_shadow, 48.0 * s.rays_shadow + 12.0 * s.splats, s.ms_trace_shadow, "k_trace_shadow: 48 B request in, 12 B of film atomics per visible light splat"),
+                "shade_light": ("path segment", s.rays_light, 184.0 * s.rays_light + 96.0 * s.light_vertices, s.ms_shade_light,
+                                "k_light_shade (+ tail): 84 B state + 16 B hit in, 84 B state out, 96 B per stored light vertex"),
+                "shade_camera": ("path segment", s.rays_camera, 184.0 * s.rays_camera + 164.0 * s.camera_vertices, s.ms_shade_camera,
+                                 "k_camera_shade (+ tail): 84 B state + 16 B hit in, 84 B out, 116 B vertex record + 48 B NEE request per connectible vertex"),
+                "connect": ("pair", s.pairs, 220.0 * s.pairs, s.ms_connect, "k_expand_pairs + k_connect_pairs: 8 B pair + 96 B light vertex + 68 B camera vertex + 48 B shadow request"),
+                "merge": ("photon examined", s.photons_examined, 16.0 * s.photons_examined + 48.0 * s.photons_merged + 64.0 * merge_vertices, s.ms_merge,
+                          "k_merge_* (sort + k_merge_diffuse / generic): 16 B per photon examined, 48 B per photon accepted, 8 x 8 B cell ranges per vertex"),
+                "grid_build": ("light vertex", s.light_vertices, 176.0 * s.light_vertices, s.ms_grid_build, "k_grid_*: 96 B vertex in + 80 B photon record out"),
+            }
+        total_ms = sum(u[3] for u in units.values()) + s.ms_generate
+        table = {}
+        for name, (unit, count, nbytes, ms, what) in units.items():
+            gbs = (nbytes / 1.0e9) / (ms * 1.0e-3) if ms > 0 else 0.0
+            table[name] = {"bound": "hbm", "unit": unit, "units_per_step": round(count / steps), "ms_per_step": round(ms / steps, 4), "share": round(ms / total_ms, 4) if total_ms > 0 else None,
+                           "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": what}
+        table["note"] = note
+        return table
+
     kernels = None
-    if (rank == 0) and (args.no_kernel_table == False):
+    if (rank == 0) and bdpt_workload:
+        kernels = kernel_table(acc["stats"], args.steps, "all kernel groups timed in the timed region itself (HIP events on the launch streams, %s iterations in flight): times include each "
+                               "launch's dispatch and the sharing of the CUs with the other lanes' kernels" % os.environ.get("ETX_HIP_LANES", "4"))
+    elif (rank == 0) and (args.no_kernel_table == False):
         ctx.set_timers(0xff)
-        ctx.begin_vcm(options, first_iteration=0, iteration_stride=1)
+        begin(0, 1)
         groups_steps = min(args.steps, 8)
         for _ in range(groups_steps):
             ctx.render_iteration()
         ctx.sync()
         s = ctx.stats()
         ctx.set_timers(0x3)
-        merge_vertices = s.camera_vertices
-        units = {
-            "trace_closest": ("ray", s.rays_extension, 48.0 * s.rays_extension, s.ms_trace_closest, "k_trace_closest: 32 B ray in + 16 B hit out"),
-            "trace_shadow": ("segment", s.rays_shadow, 48.0 * s.rays_shadow + 12.0 * s.splats, s.ms_trace_shadow, "k_trace_shadow: 48 B request in, 12 B of film atomics per visible light splat"),
-            "shade_light": ("path segment", s.rays_light, 184.0 * s.rays_light + 96.0 * s.light_vertices, s.ms_shade_light,
-                            "k_light_shade (+ tail): 84 B state + 16 B hit in, 84 B state out, 96 B per stored light vertex"),
-            "shade_camera": ("path segment", s.rays_camera, 184.0 * s.rays_camera + 164.0 * s.camera_vertices, s.ms_shade_camera,
-                             "k_camera_shade (+ tail): 84 B state + 16 B hit in, 84 B out, 116 B vertex record + 48 B NEE request per connectible vertex"),
-            "connect": ("pair", s.pairs, 220.0 * s.pairs, s.ms_connect, "k_expand_pairs + k_connect_pairs: 8 B pair + 96 B light vertex + 68 B camera vertex + 48 B shadow request"),
-            "merge": ("photon examined", s.photons_examined, 16.0 * s.photons_examined + 48.0 * s.photons_merged + 64.0 * merge_vertices, s.ms_merge,
-                      "k_merge_* (sort + k_merge_diffuse / generic): 16 B per photon examined, 48 B per photon accepted, 8 x 8 B cell ranges per vertex"),
-            "grid_build": ("light vertex", s.light_vertices, 176.0 * s.light_vertices, s.ms_grid_build, "k_grid_*: 96 B vertex in + 80 B photon record out"),
-        }
-        total_ms = sum(u[3] for u in units.values()) + s.ms_generate
-        kernels = {}
-        for name, (unit, count, nbytes, ms, what) in units.items():
-            gbs = (nbytes / 1.0e9) / (ms * 1.0e-3) if ms > 0 else 0.0
-            kernels[name] = {"bound": "hbm", "unit": unit, "units_per_step": round(count / groups_steps), "ms_per_step": round(ms / groups_steps, 4), "share": round(ms / total_ms, 4) if total_ms > 0 else None,
-                             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes": what}
-        kernels["note"] = ("%d extra steps with all kernel groups timed (HIP events on the launch streams, %s iterations in flight): times include each launch's dispatch and the "
-                           "sharing of the CUs with the other lanes' kernels; rocprofv3 per-kernel times of the same command are in profiles/round2_bench_full_1080p_kernel_stats.csv" %
-                           (groups_steps, os.environ.get("ETX_HIP_LANES", "4")))
+        kernels = kernel_table(s, groups_steps, "%d extra steps with all kernel groups timed (HIP events on the launch streams, %s iterations in flight): times include each launch's dispatch and the "
+                               "sharing of the CUs with the other lanes' kernels; rocprofv3 per-kernel times of the same command are in profiles/round2_bench_full_1080p_kernel_stats.csv" %
+                               (groups_steps, os.environ.get("ETX_HIP_LANES", "4")))
 
     # PMC figures (collected in separate rocprofv3 --pmc passes): HBM bytes per ray of the traversal kernel (FETCH_SIZE doubled as
     # MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; profiles/round1_pmc_summary.json, the kernel's traffic has not
@@ -220,7 +262,7 @@ def main():
     if os.path.exists(pmc2_path):
         with open(pmc2_path) as f:
             pmc2 = json.load(f)
-    if (kernels is not None) and (pmc2 is not None):
+    if (kernels is not None) and (pmc2 is not None) and (bdpt_workload == False):
         members = {"trace_closest": ["k_trace_closest<true, true>"], "trace_shadow": ["k_trace_shadow<true>"], "shade_light": ["k_light_shade<0u, false>", "k_path_tail<false, 0u>"],
                    "shade_camera": ["k_camera_shade<0u, false>", "k_path_tail<true, 0u>"], "connect": ["k_expand_pairs", "k_connect_pairs<true>"],
                    "merge": ["k_merge_diffuse", "k_merge_count", "k_merge_scatter", "k_merge_scan", "k_merge_scan_totals", "k_merge_clear"], "grid_build": ["k_grid_scatter", "k_grid_count", "k_grid_bbox"]}
@@ -250,7 +292,7 @@ def main():
         value = samples / elapsed / 1.0e6
         achieved = (acc["rays"] * BYTES_PER_RAY / 1.0e9) / (acc["trace_ms"] * 1.0e-3) if acc["trace_ms"] > 0 else 0.0
         line = {
-            "metric": "Msamples/s (pixels x spp / s), VCM",
+            "metric": "Msamples/s (pixels x spp / s), %s" % ("BDPT" if bdpt_workload else "VCM"),
             "value": round(value, 4),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -263,9 +305,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "cornell_%s_vcm_1920x1080" % args.workload,
-                "scene": "Cornell box rebuilt for the reference's surviving camera/materials (scenes/make_scenes.py), loaded by the reference loader",
-                "integrator": "VCM, VCMOptions::default_values() (blue noise on), scene.samples 64, max-path-length 1023, rr start 6, %s" % ("spectral" if spectral_workload else "RGB"),
+                "workload": ("cornell_%s_%dx%d" % (args.workload, width, height)) if bdpt_workload else ("cornell_%s_vcm_1920x1080" % args.workload),
+                "scene": {"sssdragon_bdpt": "BASELINE configs[3]: the Cornell box of the reference's camera with two closed blob meshes (102 400 triangles, tools/synthetic_scenes.py sss_dragon) "
+                                            "under the random-walk subsurface materials of scenes/cornell/cornell_sss.mtl",
+                          "cloud_bdpt": "BASELINE configs[4]: the fog Cornell box (env + dir + area emitters) whose medium is a procedural 256^3 heterogeneous density grid "
+                                        "(67 MB, SceneSnapshot.inject_density = etx_oracle --inject-density)"}.get(
+                    args.workload, "Cornell box rebuilt for the reference's surviving camera/materials (scenes/make_scenes.py), loaded by the reference loader"),
+                "integrator": ("BDPT, bdpt-mode BDPTFull, other CPUBidirectional defaults (blue noise on), scene.samples 64, max-path-length 1023, rr start 6, RGB" if bdpt_workload else
+                               "VCM, VCMOptions::default_values() (blue noise on), scene.samples 64, max-path-length 1023, rr start 6, %s" % ("spectral" if spectral_workload else "RGB")),
                 "triangles": int(snap.triangle_count), "tree": {"builder": args.bvh, "build_ms": round(tree["build_ms"], 3), "nodes": tree["nodes"], "depth": tree["depth"], "stack_need": tree["stack_need"],
                                                                 "upload_s": round(upload_seconds, 3)},
                 "samples_per_step": width * height,
@@ -301,8 +348,22 @@ def main():
                 "finite": finite,
             },
         }
-        # (gems1m is assembled in memory: there is no snapshot file of it to hand to the reference's driver)
-        line["cpu_baseline"] = None if (args.no_cpu_baseline or (world > 1) or (args.workload == "gems1m")) else cpu_baseline(snapshot_path, width, height)
+        if bdpt_workload and (dominant is not None):
+            # configs[3-4]: the roofline kernel is the group that dominates the step (HIP events of the timed region itself)
+            line["roofline"] = {"kernel": dominant["group"] + ": " + dominant["bytes"], "bound": "hbm", "achieved": dominant["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": dominant["frac"], "traffic": None, "units_per_step": dominant["units_per_step"], "unit_of_work": dominant["unit"], "ms_per_step": dominant["ms_per_step"],
+                                "share_of_step": dominant["share"],
+                                "note": "algorithmic bytes of the dominant kernel group (DESIGN.md 3) / summed HIP-event time of its launches in the timed region, rank 0; PMC traffic: profiles/"}
+        # (gems1m is assembled in memory and has no file to hand to the reference's driver; the subsurface scene is written out for it)
+        if args.no_cpu_baseline or (world > 1) or (args.workload == "gems1m"):
+            line["cpu_baseline"] = None
+        else:
+            if cpu_snapshot_path != snapshot_path:
+                snap.save(cpu_snapshot_path)
+            line["cpu_baseline"] = cpu_baseline(cpu_snapshot_path, width, height, integrator="bdpt" if bdpt_workload else "vcm",
+                                                extra=(tuple(cpu_extra) + ("--opt", "bdpt-mode=3")) if bdpt_workload else ())
+            if cpu_snapshot_path != snapshot_path:
+                os.remove(cpu_snapshot_path)
         print(json.dumps(line))
     if distributed:
         dist.barrier()

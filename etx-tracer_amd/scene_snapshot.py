@@ -20,6 +20,7 @@ _SCENE_VERTICES = 0
 _SCENE_TRIANGLE_TO_EMITTER = 32
 _SCENE_MATERIALS = 48
 _SCENE_EMITTERS = 80
+_SCENE_MEDIUMS = 112
 _SCENE_SAMPLES = 464
 _SCENE_MAX_PATH = 460
 _SCENE_MIN_PATH = 456
@@ -56,6 +57,7 @@ class SceneSnapshot:
         self.scene_address = aligned + scene_off
         self.camera_address = aligned + camera_off
         self.path = path
+        self._fixups = fixups  # offsets of the pointer fields (save())
         self.version = 0  # bumped by every setter: the integrators re-upload when it changed since their last upload
 
     def _u32(self, address):
@@ -144,7 +146,66 @@ class SceneSnapshot:
         buf = (ctypes.c_uint32 * (count * 50)).from_address(ptr)
         return np.frombuffer(buf, dtype=np.uint32).reshape(count, 50)
 
+    def emitter_instances(self):
+        """writable uint32 view (count, 8) of the etx::Emitter table (cls, profile, triangle_index, weights as float bits)"""
+        ptr, count = self._array(_SCENE_EMITTERS)
+        return np.frombuffer((ctypes.c_uint32 * (count * 8)).from_address(ptr), dtype=np.uint32).reshape(count, 8)
+
     def material_classes(self):
         ptr, count = self._array(_SCENE_MATERIALS)
         buf = (ctypes.c_uint32 * (count * 50)).from_address(ptr)
         return np.frombuffer(buf, dtype=np.uint32).reshape(count, 50)[:, 41].copy()  # offset 164 / 4
+
+    def inject_density(self, n):
+        """Every medium of the scene becomes Heterogeneous with the procedural n^3 density grid of `etx_oracle --inject-density n`
+        (oracle/driver/etx_oracle.cxx: two blobs + a product of sines, normalised to a maximum of 1 = the state MediumPool::add leaves
+        behind, medium_pool.cxx:41-58). The reference's loader only reads .nvdb files and its tree ships none; a 256^3 grid (67 MB,
+        BASELINE configs[4]) cannot be a committed fixture either, so both sides build it from the same formula."""
+        n = int(n)
+        c = (np.arange(n, dtype=np.float32) + np.float32(0.5)) / np.float32(n)
+        fx, fy, fz = c[None, None, :], c[None, :, None], c[:, None, None]
+        f32 = np.float32
+        sq = lambda v: v * v
+        d = np.exp(f32(-12.0) * (sq(fx - f32(0.35)) + sq(fy - f32(0.40)) + sq(fz - f32(0.55))))
+        d = d + f32(0.8) * np.exp(f32(-20.0) * (sq(fx - f32(0.70)) + sq(fy - f32(0.65)) + sq(fz - f32(0.35))))
+        d = d + f32(0.15) * (f32(1.0) + np.sin(f32(9.0) * fx) * np.sin(f32(7.0) * fy + f32(1.0)) * np.sin(f32(8.0) * fz + f32(2.0)))
+        grid = np.ascontiguousarray((d / d.max()).astype(np.float32)).reshape(-1)  # index x + y * n + z * n * n
+        ptr, count = self._array(_SCENE_MEDIUMS)
+        self._density = grid
+        for i in range(count):
+            m = ptr + i * 80  # sizeof(etx_abi_medium)
+            ctypes.c_uint64.from_address(m).value = grid.ctypes.data
+            ctypes.c_uint64.from_address(m + 8).value = grid.shape[0]
+            ctypes.c_uint16.from_address(m + 48).value = 1  # Medium::Class::Heterogeneous
+            for k in range(3):
+                ctypes.c_uint32.from_address(m + 68 + 4 * k).value = n
+        self.version += 1
+        return grid
+
+    def save(self, path):
+        """Writes the snapshot back in the ETXSCENE1 layout WITH what the setters changed: the in-memory image (scene scalars, materials,
+        emitters ... are edited in place) with every listed pointer field turned back into a payload offset; arrays that
+        replace_geometry / inject_density swapped in are appended as new 16-byte aligned chunks. etx_oracle --load-snapshot reads the
+        result (CPU baseline and golden films of scenes that are assembled in memory, tools/synthetic_scenes.py)."""
+        out = bytearray(ctypes.string_at(self.base, self.size))
+        owned = [a for a in getattr(self, "_geometry", ())] + ([self._density] if getattr(self, "_density", None) is not None else [])
+        appended = {}
+        for field in self._fixups:
+            live = ctypes.c_uint64.from_address(self.base + field).value
+            if live == 0:
+                offset = 0
+            elif self.base <= live < self.base + self.size:
+                offset = live - self.base
+            elif live in appended:
+                offset = appended[live]
+            else:
+                match = [a for a in owned if a.ctypes.data == live]
+                if not match:
+                    raise ValueError("save: the pointer field at offset %d points to memory the snapshot does not own" % field)
+                out.extend(b"\0" * ((-len(out)) % 16))
+                offset = appended[live] = len(out)
+                out.extend(match[0].tobytes())
+            struct.pack_into("<Q", out, field, offset)
+        struct.pack_into("<Q", out, 16 + 4 * 8, len(out))  # total_size
+        with open(path, "wb") as f:
+            f.write(bytes(out))

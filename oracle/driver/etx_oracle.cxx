@@ -380,34 +380,6 @@ int main(int argc, char** argv) {
     if (spp > 0) {
       scene.mutable_scene().samples = uint32_t(spp);
     }
-    if (inject_density > 0) {
-      // The loader only reads .nvdb grids (medium_pool.cxx:93-99) and the tree ships none: give the scene's media the
-      // state MediumPool::add leaves behind (medium_pool.cxx:41-58: density normalised to max 1, dimensions, class) with a
-      // smooth procedural field, so that the heterogeneous branches of scene_medium.hxx run on both sides.
-      const uint32_t n = inject_density;
-      for (uint64_t mi = 0; mi < scene.scene().mediums.count; ++mi) {
-        Medium& m = const_cast<Medium&>(scene.scene().mediums[mi]);
-        float* grid = reinterpret_cast<float*>(malloc(sizeof(float) * n * n * n));
-        float max_density = 0.0f;
-        for (uint32_t z = 0; z < n; ++z)
-          for (uint32_t y = 0; y < n; ++y)
-            for (uint32_t x = 0; x < n; ++x) {
-              float fx = (float(x) + 0.5f) / float(n), fy = (float(y) + 0.5f) / float(n), fz = (float(z) + 0.5f) / float(n);
-              float blob0 = expf(-12.0f * (sqr(fx - 0.35f) + sqr(fy - 0.40f) + sqr(fz - 0.55f)));
-              float blob1 = expf(-20.0f * (sqr(fx - 0.70f) + sqr(fy - 0.65f) + sqr(fz - 0.35f)));
-              float waves = 0.15f * (1.0f + sinf(9.0f * fx) * sinf(7.0f * fy + 1.0f) * sinf(8.0f * fz + 2.0f));
-              float d = blob0 + 0.8f * blob1 + waves;
-              grid[x + y * n + z * n * n] = d;
-              max_density = max(max_density, d);
-            }
-        for (uint32_t k = 0; k < n * n * n; ++k)
-          grid[k] /= max_density;
-        m.density.a = grid;
-        m.density.count = uint64_t(n) * n * n;
-        m.dimensions = {n, n, n};
-        m.cls = Medium::Class::Heterogeneous;
-      }
-    }
   } else {
     if (load_snapshot(load_snapshot_file.c_str(), snapshot_storage, scene_ptr, camera_ptr) == false) {
       printf("failed to load snapshot %s\n", load_snapshot_file.c_str());
@@ -415,6 +387,34 @@ int main(int argc, char** argv) {
     }
     if (spp > 0) {
       const_cast<Scene*>(scene_ptr)->samples = uint32_t(spp);
+    }
+  }
+  if (inject_density > 0) {
+    // The loader only reads .nvdb grids (medium_pool.cxx:93-99) and the tree ships none: give the scene's media the
+    // state MediumPool::add leaves behind (medium_pool.cxx:41-58: density normalised to max 1, dimensions, class) with a
+    // smooth procedural field, so that the heterogeneous branches of scene_medium.hxx run on both sides.
+    const uint32_t n = inject_density;
+    for (uint64_t mi = 0; mi < scene_ptr->mediums.count; ++mi) {
+      Medium& m = const_cast<Medium&>(scene_ptr->mediums[mi]);
+      float* grid = reinterpret_cast<float*>(malloc(sizeof(float) * n * n * n));
+      float max_density = 0.0f;
+      for (uint32_t z = 0; z < n; ++z)
+        for (uint32_t y = 0; y < n; ++y)
+          for (uint32_t x = 0; x < n; ++x) {
+            float fx = (float(x) + 0.5f) / float(n), fy = (float(y) + 0.5f) / float(n), fz = (float(z) + 0.5f) / float(n);
+            float blob0 = expf(-12.0f * (sqr(fx - 0.35f) + sqr(fy - 0.40f) + sqr(fz - 0.55f)));
+            float blob1 = expf(-20.0f * (sqr(fx - 0.70f) + sqr(fy - 0.65f) + sqr(fz - 0.35f)));
+            float waves = 0.15f * (1.0f + sinf(9.0f * fx) * sinf(7.0f * fy + 1.0f) * sinf(8.0f * fz + 2.0f));
+            float d = blob0 + 0.8f * blob1 + waves;
+            grid[x + y * n + z * n * n] = d;
+            max_density = max(max_density, d);
+          }
+      for (uint32_t k = 0; k < n * n * n; ++k)
+        grid[k] /= max_density;
+      m.density.a = grid;
+      m.density.count = uint64_t(n) * n * n;
+      m.dimensions = {n, n, n};
+      m.cls = Medium::Class::Heterogeneous;
     }
   }
   if (noise_threshold >= 0.0f)

@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
-"""Config-size reference films (BASELINE.json configs[1] and configs[2] at their own 1920x1080): runs the reference's CPUVCM
+"""Config-size reference films (BASELINE.json configs[1..4] at their own size): runs the reference's CPUVCM / CPUBidirectional
 through the prebuilt oracle binary on the many-core host of the GPU box and keeps 8 x 8 block means of the film.
 
-    gpurun -- 'python3 oracle/gen_golden_1080p.py'        (no GPU work; ~6 min of a 256-thread host)
+    gpurun -- 'python3 oracle/gen_golden_1080p.py [name ...]'        (no GPU work; minutes of a 256-thread host)
     mv gpurun_out/golden_1080p/*.npz tests/golden/
 
-  cornell_full_1080p_vcm_64_blocks.npz   64 iterations, vcm-blue_noise=false, ETX_ORACLE_DECORRELATE=2 (independent light / camera
-  cornell_gems_1080p_vcm_8_blocks.npz     8 iterations   streams - the estimator the device implements)
-      camera, light: float32 [135, 240, 3] block means; spp; seconds; threads
+  cornell_full_1080p_vcm_64_blocks[_asis].npz        configs[1]: 64 VCM iterations, vcm-blue_noise=false
+  cornell_gems_1080p_vcm_8_blocks.npz                configs[2]:  8 VCM iterations
+  cornell_sssdragon_1080p_bdpt3_16_blocks[_asis].npz configs[3]: 16 BDPTFull iterations of the scene tools/synthetic_scenes.py sss_dragon
+                                                     assembles (written out with SceneSnapshot.save for the driver)
+  cornell_cloud_2048_bdpt3_8_blocks[_asis].npz       configs[4]:  8 BDPTFull iterations, 256^3 density grid (--inject-density 256)
+      camera, light: float32 [H/8, W/8, 3] block means; spp; seconds; threads
+  default flavour: ETX_ORACLE_DECORRELATE=2 (independent light / camera streams - the estimator the device implements);
+  `_asis`: the unmodified reference (light path i and camera path i share their seed).
 
-The block means keep the fixture small (a 1080p float film is 25 MB); the test (tests/test_gpu_parity_size.py) reduces the device
+The block means keep the fixtures small (a 1080p float film is 25 MB); the test (tests/test_gpu_parity_size.py) reduces the device
 film the same way. Needs nothing of /root/reference at run time: the binary and the snapshots travel with the repository.
 """
 import os
@@ -27,6 +32,14 @@ ORACLE = os.path.join(ROOT, "oracle", "_ref", "etx_oracle")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 OUT = os.path.join(ROOT, "gpurun_out", "golden_1080p")
 
+# name -> (snapshot flavour, integrator, iterations, extra driver arguments, output stem)
+JOBS = {
+    "full": ("full_1080p", "vcm", 64, ["--opt", "vcm-blue_noise=false"], "cornell_full_1080p_vcm_64_blocks"),
+    "gems": ("gems_1080p", "vcm", 8, ["--opt", "vcm-blue_noise=false"], "cornell_gems_1080p_vcm_8_blocks"),
+    "sssdragon": ("sssdragon", "bdpt", 16, ["--opt", "bdpt-blue_noise=false", "--opt", "bdpt-mode=3"], "cornell_sssdragon_1080p_bdpt3_16_blocks"),
+    "cloud": ("cloud_2048", "bdpt", 8, ["--opt", "bdpt-blue_noise=false", "--opt", "bdpt-mode=3", "--inject-density", "256"], "cornell_cloud_2048_bdpt3_8_blocks"),
+}
+
 
 def block_mean(img, b=8):
     h, w = img.shape[:2]
@@ -35,12 +48,21 @@ def block_mean(img, b=8):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    for flavour, spp in (("full", 64), ("gems", 8)):
+    names = sys.argv[1:] or ["full", "gems"]
+    for name in names:
+        as_is = name.endswith("_asis")
+        flavour, integrator, spp, extra, stem = JOBS[name[:-5] if as_is else name]
+        snapshot = os.path.join(GOLDEN, "cornell_%s.etxscene" % flavour)
+        if flavour == "sssdragon":  # assembled in memory, handed to the driver as a file
+            import etx_tracer_amd as etx
+            from tools import synthetic_scenes
+            snapshot = "/tmp/golden_sssdragon.etxscene"
+            synthetic_scenes.sss_dragon(etx, os.path.join(GOLDEN, "cornell_sss_1080p.etxscene")).save(snapshot)
         film_path = "/tmp/golden_1080p.raw"
-        cmd = [ORACLE, "--load-snapshot", os.path.join(GOLDEN, "cornell_%s_1080p.etxscene" % flavour), "--integrator", "vcm", "--spp", str(spp), "--out", film_path,
-               "--opt", "vcm-blue_noise=false"]
+        cmd = [ORACLE, "--load-snapshot", snapshot, "--integrator", integrator, "--spp", str(spp), "--out", film_path] + extra
         env = dict(os.environ)
-        env["ETX_ORACLE_DECORRELATE"] = "2"
+        if as_is == False:
+            env["ETX_ORACLE_DECORRELATE"] = "2"
         t0 = time.time()
         print("+", " ".join(cmd), flush=True)
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL, env=env)
@@ -49,7 +71,7 @@ def main():
         cam, light = film["camera"][..., :3], film["light"][..., :3]
         finite = np.isfinite(cam).all(axis=2) & np.isfinite(light).all(axis=2)  # the release build lets an occasional NaN sample through
         cam, light = np.where(finite[..., None], cam, 0.0), np.where(finite[..., None], light, 0.0)
-        out = os.path.join(OUT, "cornell_%s_1080p_vcm_%d_blocks.npz" % (flavour, spp))
+        out = os.path.join(OUT, stem + ("_asis" if as_is else "") + ".npz")
         np.savez_compressed(out, camera=block_mean(cam), light=block_mean(light), spp=np.int32(film["spp"]), seconds=np.float64(film["seconds"]), threads=np.int32(film["threads"]),
                             nonfinite_pixels=np.int32((~finite).sum()))
         print("  -> %s (%.0f s, %d threads, %d non-finite pixels)" % (out, time.time() - t0, film["threads"], (~finite).sum()), flush=True)

@@ -9,6 +9,8 @@ tests of tests/test_gpu_parity_hi.py ("a high-spp oracle reference
   tests/golden/hi/cornell_full_128_vcm_<spp>_decorrelated.npz    the same with ETX_ORACLE_DECORRELATE=1 (the BVH shim
       shifts the shared stream of a pixel's light and camera path by ray-dependent amounts)
   tests/golden/hi/cornell_<flavour>_128_bdpt<mode>_<spp>[_rekeyed].npz  CPUBidirectional (--integrators bdpt --bdpt-modes 3,0,1)
+  tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_<far_first|random_child>.npz   (--integrators orders) the unmodified reference under
+      ETX_ORACLE_BVH_ORDER = another child order of the BVH shim
   tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_rekeyed.npz        ETX_ORACLE_DECORRELATE=2: the camera path re-keys its sampler at
       its first segment = independent light / camera streams, the estimator the device implements
 
@@ -77,6 +79,12 @@ def main():
         if (flavour == "full") and ("vcm" in integrators):
             render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_full_128_vcm_%d_decorrelated.npz" % args.spp), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "1"},
                    extra=["--opt", "vcm-blue_noise=false"])
+        if "orders" in integrators:
+            # the unmodified estimator (shared light / camera streams) under two more traversal orders of the BVH shim: how far the
+            # reference's own film moves when only the order candidates reach alpha_test_pass changes (Embree's order is unknown)
+            for order in ("far_first", "random_child"):
+                render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_%s.npz" % (flavour, args.spp, order)), args.cores, env_extra={"ETX_ORACLE_BVH_ORDER": order},
+                       extra=["--opt", "vcm-blue_noise=false"] + variant)
         if "rekeyed" in integrators:
             # mode 2: the camera sub path draws from a stream of its own from its first segment on (oracle/shims/raytracing_bvh.cxx)
             render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_rekeyed.npz" % (flavour, args.spp)), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "2"},

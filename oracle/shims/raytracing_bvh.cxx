@@ -21,6 +21,7 @@
 #include <etx/render/host/film.hxx>
 
 #include <algorithm>
+#include <cstring>
 #include <atomic>
 #include <vector>
 
@@ -43,6 +44,13 @@ struct BTri {
 struct CpuBVH {
   std::vector<BNode> nodes;
   std::vector<BTri> tris;
+  // ETX_ORACLE_BVH_ORDER: the order in which the two children of an inner node are visited when the ray enters both.
+  // The closest accepted hit does not depend on it; the ORDER in which candidate triangles reach alpha_test_pass (one
+  // draw of the path's sampler each, scene_bsdf.hxx:128-144) and their number (a nearer hit found earlier culls more) do.
+  // Embree's own order is unknown here; rendering the same scene under several orders measures how far the reference's
+  // film moves with it (tests/test_gpu_parity_hi.py).
+  enum Order : uint32_t { NearFirst = 0, FarFirst = 1, RandomChild = 2 };
+  uint32_t order = NearFirst;
 
   struct BuildPrim {
     float3 bmin, bmax, centroid;
@@ -224,7 +232,16 @@ struct CpuBVH {
       bool h0 = slab(nodes[n.left_or_first], t0);
       bool h1 = slab(nodes[n.left_or_first + 1u], t1);
       if (h0 && h1) {
-        if (t0 <= t1) {
+        bool left_first = t0 <= t1;
+        if (order == FarFirst) {
+          left_first = (left_first == false);
+        } else if (order == RandomChild) {
+          // a fixed pseudo-random choice per (node, ray): no draw from any sampler
+          uint32_t h = (n.left_or_first * 0x9E3779B1u) ^ to_uint(d.x) ^ (to_uint(d.y) >> 7u) ^ (to_uint(o.z) << 5u);
+          h ^= h >> 15u, h *= 0x2C1B3C6Du, h ^= h >> 12u;
+          left_first = (h & 1u) != 0u;
+        }
+        if (left_first) {
           stack[sp++] = n.left_or_first + 1u;
           stack[sp++] = n.left_or_first;
         } else {
@@ -313,6 +330,9 @@ void Raytracing::commit_changes() {
   _private->film.allocate(_private->source_camera->film_size);
   delete _private->bvh;
   _private->bvh = new CpuBVH();
+  if (const char* order = getenv("ETX_ORACLE_BVH_ORDER")) {
+    _private->bvh->order = (strcmp(order, "far_first") == 0) ? CpuBVH::FarFirst : ((strcmp(order, "random_child") == 0) ? CpuBVH::RandomChild : CpuBVH::NearFirst);
+  }
   _private->bvh->build(*_private->source_scene);
 }
 

@@ -555,6 +555,9 @@ two_sided 1
     # the same two materials on sphere meshes (BVH traversal instead of the flat sweep)
     build_mesh(False, sss_meshes=True).write(os.path.join(OUT, "cornell_sssmesh.obj"), "cornell_sss.mtl")
     write_json("sssmesh_test_128.json", "cornell_sssmesh.obj", "cornell_sss.mtl", (128, 128), 64)
+    # BASELINE configs[3] at its own size: this box at 1920 x 1080 is the BASE of bench.py --workload sssdragon_bdpt, which swaps the
+    # two boxes for closed blob meshes of 102 400 triangles (tools/synthetic_scenes.py sss_dragon: the tree ships no mesh)
+    write_json("sss_c4_1080p.json", "cornell_classic.obj", "cornell_sss.mtl", (1920, 1080), 64)
     # the same box with the Christensen-Burley class ("class approximate", scene_representation.cxx:1996-2001): three probe rays,
     # up to 24 exit points per vertex (subsurface::gather_cb + Raytracing::continuous_trace)
     with open(os.path.join(OUT, "cornell_sss.mtl")) as f:
@@ -626,6 +629,10 @@ shape textures/aperture.png
         # BASELINE.json configs[0]: PT 512x512 16 spp ; configs[1]: VCM 1920x1080 64 spp
         write_json("%s_c1_512.json" % flavour, obj, mtl, (512, 512), 16)
         write_json("%s_c2_1080p.json" % flavour, obj, mtl, (1920, 1080), 64)
+        if flavour == "full":
+            # BASELINE configs[4]: 2048 x 2048; the fog medium becomes a 256^3 heterogeneous density grid at load time
+            # (etx_oracle --inject-density 256 / SceneSnapshot.inject_density: the tree ships no .nvdb file)
+            write_json("cloud_c5_2048.json", obj, mtl, (2048, 2048), 64)
         # test-sized variants (oracle finishes in seconds)
         write_json("%s_test_128.json" % flavour, obj, mtl, (128, 128), 64)
         write_json("%s_test_192x108.json" % flavour, obj, mtl, (192, 108), 64)
