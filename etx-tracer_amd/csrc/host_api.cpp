@@ -203,6 +203,18 @@ int allocate_pipeline(etx_hip_context* ctx) {
   }
   if ((rc = device_alloc(ctx, p.hits, n)))
     return rc;
+  p.walk = {}, p.walk_info = nullptr, p.walk_exit = {}, p.walk_exit_hits = nullptr;
+  if (ctx->scene.has_subsurface) {  // walk queue of the bidirectional integrator (k_bdpt_walk)
+    if ((rc = device_alloc(ctx, p.walk.ray_o_tmin, n)) || (rc = device_alloc(ctx, p.walk.ray_d_tmax, n)) || (rc = device_alloc(ctx, p.walk.thr_eta, n)) || (rc = device_alloc(ctx, p.walk.mis, n)) ||
+        (rc = device_alloc(ctx, p.walk.meta, n)) || (rc = device_alloc(ctx, p.walk.path_id, n)) || (rc = device_alloc(ctx, p.walk.wavelength, n)) || (rc = device_alloc(ctx, p.walk.prev_pos, n)) ||
+        (rc = device_alloc(ctx, p.walk.prev_nrm, n)) || (rc = device_alloc(ctx, p.walk_info, n)))
+      return rc;
+    PathSet& e = p.walk_exit;
+    if ((rc = device_alloc(ctx, e.ray_o_tmin, n)) || (rc = device_alloc(ctx, e.ray_d_tmax, n)) || (rc = device_alloc(ctx, e.thr_eta, n)) || (rc = device_alloc(ctx, e.mis, n)) ||
+        (rc = device_alloc(ctx, e.meta, n)) || (rc = device_alloc(ctx, e.path_id, n)) || (rc = device_alloc(ctx, e.wavelength, n)) || (rc = device_alloc(ctx, e.prev_pos, n)) ||
+        (rc = device_alloc(ctx, e.prev_nrm, n)) || (rc = device_alloc(ctx, p.walk_exit_hits, n)))
+      return rc;
+  }
   // light vertex pool: the reference grows a std::vector (vcm_cpu.cxx:131-171); here a fixed pool sized for
   // 16 stored vertices per path on average, overflow is detected and reported (never silently dropped).
   // a subsurface walk under the bidirectional integrator stores one vertex per scattering event inside the object
@@ -599,7 +611,9 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
       [&](uint32_t set, uint32_t max_items) {
         {
           ScopedTimer t(ctx, kTimerShadeLight);
-          launch_bdpt_light_shade(s, p, it, set, max_items, ctx->scene.has_subsurface);
+          launch_bdpt_light_shade(s, p, it, set, max_items);
+          if (ctx->scene.has_subsurface)
+            launch_bdpt_walk(s, p, it, false, set ^ 1u, max_items);
           if (to_camera)
             launch_bdpt_connect_camera(s, p, it, max_items);
         }
@@ -625,7 +639,9 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
       [&](uint32_t set, uint32_t max_items) {
         {
           ScopedTimer t(ctx, kTimerShadeCamera);
-          launch_bdpt_camera_shade(s, p, it, set, max_items, ctx->scene.has_subsurface);
+          launch_bdpt_camera_shade(s, p, it, set, max_items);
+          if (ctx->scene.has_subsurface)
+            launch_bdpt_walk(s, p, it, true, set ^ 1u, max_items);
           if (to_light)
             launch_bdpt_connect_light(s, p, it, max_items);
         }

@@ -94,11 +94,12 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_generate(Pipeline p, 
   }
 }
 
-// Subsurface walk state of a lane (build_path: subsurface_material; subsurface_step, bidirectional.cxx:746-818). The walk runs
-// INSIDE the shade kernel: after the entry vertex the lane keeps taking sub-steps - free flight through the walk's medium, a
-// material-filtered closest-hit query in place of the ray queue, one path vertex per scattering event - until the path leaves
-// the object or ends; every sub-step goes through the same vertex code and the same workgroup-wide slot reservations as a
-// queue segment (the sub-step loop is workgroup-uniform).
+// Subsurface walks (build_path: subsurface_material; subsurface_step, bidirectional.cxx:746-818). A path that enters a subsurface
+// object leaves the wavefront: the shade kernel writes its state to the WALK QUEUE (Pipeline::walk) instead of the next round's
+// path set, and k_bdpt_walk - persistent wavefronts that take entries from that queue whenever enough of their lanes are idle -
+// runs the walk: free flight through the walk's medium, a material-filtered closest-hit query in place of the ray queue, one path
+// vertex per scattering event, until the path has left the object; then it joins the next round's path set. Every sub-step goes
+// through the same vertex code as a queue segment (bdpt_light_step / bdpt_camera_step).
 struct BdptWalk {
   uint32_t material;  // kInvalid: not inside an object
   uint32_t medium;    // DScene::material_sss_medium of that material
@@ -159,12 +160,218 @@ ETX_DEV bool bdpt_enter_subsurface(const DScene& scene, const etx_abi_material& 
   return true;
 }
 
-// One segment of an emitter path after the closest-hit query (+ the sub-steps of a subsurface walk, kWalk).
-template <bool kWalk>
+// Wave-level slot reservation of the walk kernels: a wavefront takes kWalkChunk pool slots with ONE atomic and hands them to its
+// lanes step by step (the atomics on a counter are serialised by its L2 channel at ~11 ns each, pipeline.h: one per lane and event
+// - 50 M per iteration in a scene of subsurface objects - would take longer than the walks). What is left of the last chunk when the
+// wavefront ends is marked unused (flags 0: no consumer of the pool connects to such a record).
+constexpr uint32_t kWalkChunk = 256u;
+struct WaveChunk {
+  uint32_t next, end;  // wave-uniform
+};
+ETX_DEV uint32_t wave_chunk_slot(bool wanted, WaveChunk& chunk, uint32_t* counter) {
+  const unsigned long long mask = __ballot(wanted);
+  const uint32_t need = uint32_t(__popcll(mask));
+  if (need == 0u)
+    return 0u;
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32u), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+  const uint32_t left = chunk.end - chunk.next;
+  uint32_t fresh = 0u;
+  if (need > left) {  // wave-uniform
+    if ((threadIdx.x & 63u) == 0u)
+      fresh = atomicAdd(counter, kWalkChunk);
+    fresh = __builtin_amdgcn_readfirstlane(fresh);
+  }
+  // the first `left` lanes finish the old chunk, the others start the new one
+  const uint32_t slot = (rank < left) ? (chunk.next + rank) : (fresh + (rank - left));
+  if (need > left)
+    chunk.next = fresh + (need - left), chunk.end = fresh + kWalkChunk;
+  else
+    chunk.next += need;
+  return slot;
+}
+
+// The three kinds of (sub-)steps. A walk is split by event class: its scattering events (free flight, material-filtered query,
+// medium vertex - no BSDF, few registers, thousands of them) run in the persistent kernel k_bdpt_walk; the surface vertex where it
+// leaves the object (BSDF sample of the scatter material, roulette - the out-of-line BSDF calls cost the kernel its occupancy) is
+// queued and shaded densely by k_bdpt_walk_exit.
+enum : uint32_t {
+  kStepSegment = 0,    // a segment of the ray queue: the hit comes from the hit queue
+  kStepWalkEvent = 1,  // sub-step of a walk: free flight + query; a scattering event is handled, a surface hit is handed back (r.exit, hit in `h`)
+  kStepWalkExit = 2,   // the surface vertex that ends a walk
+};
+
+// What one (sub-)step of an emitter path leaves behind: the vertices to store and where the path goes.
+struct BdptLightStep {
+  bool store_emitter, store_vertex;
+  bool alive;   // the path continues on the ray queue
+  bool walking; // kStepWalkEvent: the walk continues with another sub-step; kStepSegment: the path has just entered an object (walk = which)
+  bool exit;    // kStepWalkEvent: the flight reached the object's surface
+  f3 v_pos, v_nrm, v_wi, v_throughput;
+  float v_from_prev, v_bc_u, v_bc_v;
+  uint32_t v_flags, v_tri, v_medium;
+  BVtx emitter_vertex;
+  float emitter_from_next;
+};
+
+// One segment of an emitter path after the closest-hit query (kInWalk = false, `h` from the hit queue), or one sub-step of a
+// subsurface walk (kInWalk = true: the free flight and its material-filtered query happen here).
+template <uint32_t kStep>
+ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const LaneStack& stack, uint32_t mode, BdptState& st, BdptWalk& walk, float4& h) {
+  constexpr bool kInWalk = kStep != kStepSegment;
+  BdptLightStep r = {};
+  MediumSample ms;
+  ms.sampled_medium_t = 0.0f;
+  bool flight_ok = true;
+  if (kStep == kStepWalkEvent) {
+    walk.events += 1u;
+    flight_ok = (walk.events <= 1024u) && bdpt_walk_flight(scene, stack, walk, st, h, ms);  // :776-812
+  }
+  const uint32_t tri = __float_as_uint(h.w);
+  const bool found = tri != kInvalid;
+  // regular_step, bidirectional.cxx:712-727
+  if ((kInWalk == false) && (st.medium != kInvalid)) {
+    ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+    st.throughput *= ms.weight;
+  }
+  const bool first = (st.flags & kBpFirst) != 0u;
+  if (flight_ok == false) {
+    // the walk ended the path
+  } else if (ms.sampled_medium()) {  // handle_medium, :533-570
+    const uint32_t medium_index = kInWalk ? walk.medium : st.medium;
+    const DMedium& med = scene.mediums[medium_index];
+    const bool explicit_connections = (kInWalk == false) && (med.explicit_connections != 0u);  // subsurface_step passes false (:811)
+    const f2 rnd_bsdf = st.sampler.next_2d();
+    (void)st.sampler.next_2d();
+    (void)st.sampler.next_2d();
+    const f3 w_o = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
+    const float pdf_fwd = phase_function(st.ray_d, w_o, med.g);
+    const float pdf_bck = phase_function(w_o, st.ray_d, med.g);
+    st.path_size += 1u;
+    BVtx curr = {ms.pos, mk3(0.0f), 0.0f, 0.0f, kBvMedium | kBvConnectible | ((st.prev.flags & kBvConnectible) ? kBvMisConnectible : 0u), kInvalid};
+    curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
+    float prev_from_next = bdpt_to_area(pdf_bck, ms.pos, st.prev);
+    if (first && (st.flags & kBpDistantEmitter)) {  // update_distant_emitter_path_pdfs, :423-436
+      st.prev.from_prev = bdpt_emitter_sample_pdf(scene, scene.emitters[st.flags >> kBpEmitterShift], -st.ray_d);
+      curr.from_prev = st.aux;
+    }
+    r.v_pos = ms.pos, r.v_wi = st.ray_d, r.v_throughput = st.throughput, r.v_from_prev = curr.from_prev, r.v_flags = curr.flags, r.v_medium = medium_index, r.v_tri = kInvalid;
+    if (explicit_connections == false)
+      r.v_flags |= kBvNoCameraConnection;  // handle_medium skips connect() for it; camera paths still connect TO it
+    st.ray_o = ms.pos, st.ray_d = w_o, st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+    st.pdf_dir = pdf_fwd;
+    r.emitter_vertex = st.prev;
+    r.emitter_from_next = prev_from_next;
+    bdpt_advance_history(st, prev_from_next, false, mode, true);
+    r.emitter_vertex.history = st.prev.history;
+    r.store_emitter = first, r.store_vertex = true;
+    st.prev = curr;
+    st.flags &= ~kBpFirst;
+    if (kInWalk)
+      r.walking = true;  // no roulette inside the walk (:776-815)
+    else
+      r.alive = random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
+  } else if (found) {
+   if constexpr (kStep == kStepWalkEvent) {
+    r.exit = true;
+   } else {
+    Isect isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
+    if (kInWalk)
+      isect.material = scene.subsurface_scatter_material;  // build_path :858-861
+    const etx_abi_material& mat = scene.materials[isect.material];
+    const f2 rnd_bsdf = st.sampler.next_2d();
+    (void)st.sampler.next_2d();
+    const f2 rnd_support = st.sampler.next_2d();
+    if (mat.cls == ETX_MAT_BOUNDARY) {  // handle_surface :586-593: the path length does not change
+      const etx_abi_triangle& t = scene.triangles[isect.tri];
+      st.medium = (dot(ld3(t.geo_n), st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
+      st.ray_o = shading_pos(scene, t, isect.bc, st.ray_d);
+      st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+      r.alive = true;
+    } else {
+      const BsdfData data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight, st.wavelength);
+      st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
+      BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
+      st.sampler.pop_fixed();
+      uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
+      uint32_t walk_medium = kInvalid, path_medium = vertex_medium;
+      const bool enter = (kInWalk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, vertex_medium, walk_medium, path_medium);
+      const uint32_t vertex_material = enter ? scene.subsurface_scatter_material : isect.material;
+      st.path_size += 1u;
+      const bool connectible = (bs.properties & kSampleDelta) == 0u;
+      BVtx curr = {isect.pos, isect.nrm, 0.0f, 0.0f,
+        kBvSurface | (connectible ? kBvConnectible : 0u) | ((connectible && (st.prev.flags & kBvConnectible)) ? kBvMisConnectible : 0u), isect.tri};
+      curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
+      const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
+      const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
+      r.v_pos = isect.pos, r.v_nrm = isect.nrm, r.v_wi = isect.w_i, r.v_throughput = st.throughput, r.v_flags = curr.flags, r.v_tri = isect.tri, r.v_bc_u = isect.bc.y, r.v_bc_v = isect.bc.z;
+      if (enter || kInWalk)
+        r.v_flags |= kBvScatterMaterial;
+      r.v_medium = vertex_medium;
+      st.medium = path_medium;
+      bool terminate = false;
+      if (bs.valid()) {
+        st.pdf_dir = bs.pdf;
+        st.throughput *= bs.weight;
+        const etx_abi_triangle& t = scene.triangles[isect.tri];
+        st.ray_o = shading_pos(scene, t, isect.bc, bs.w_o);
+        st.ray_d = bs.w_o;
+        st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+        st.throughput *= fix_shading_normal(ld3(t.geo_n), isect.nrm, isect.w_i, bs.w_o);
+      } else {
+        terminate = true;
+      }
+      if (first && (st.flags & kBpDistantEmitter)) {  // update_distant_emitter_path_pdfs
+        st.prev.from_prev = bdpt_emitter_sample_pdf(scene, scene.emitters[st.flags >> kBpEmitterShift], -isect.w_i);
+        curr.from_prev = st.aux * fabsf(dot(isect.w_i, ld3(scene.triangles[isect.tri].geo_n)));
+      }
+      r.v_from_prev = curr.from_prev;
+      r.emitter_vertex = st.prev;
+      r.emitter_from_next = prev_from_next;
+      bdpt_advance_history(st, prev_from_next, false, mode, connectible);
+      r.emitter_vertex.history = st.prev.history;
+      r.store_emitter = first, r.store_vertex = true;
+      st.prev = curr;
+      st.flags &= ~kBpFirst;
+      r.alive = (terminate == false) && random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
+      // a surface vertex ends a walk (:858-861) or starts one: the path goes to the walk queue and joins the ray queue again when it has left the object
+      if (enter && r.alive) {
+        walk = {isect.material, walk_medium, 0u};
+        r.alive = false;
+        r.walking = true;
+      }
+    }
+   }
+  }
+  return r;
+}
+
+// the pool records of a (sub-)step, slots reserved by the caller
+ETX_DEV void bdpt_light_store(const Pipeline& p, BdptState& st, const BdptLightStep& r, uint32_t emitter_slot, uint32_t vertex_slot) {
+  if (r.store_emitter)
+    bdpt_store_light_vertex(p, emitter_slot, st.id, r.emitter_vertex.pos, r.emitter_vertex.nrm, mk3(0.0f), mk3(0.0f), r.emitter_vertex.from_prev, r.emitter_vertex.history, r.emitter_vertex.flags,
+      r.emitter_vertex.tri, r.emitter_from_next, 0.0f, 0u, 1u, kInvalid, kInvalid, st.wavelength, 0u);
+  if (r.store_vertex) {
+    const uint32_t previous = r.store_emitter ? emitter_slot : st.prev_slot;
+    Sampler derived;
+    derived.init(st.sampler.seed, 0x62647074u);
+    // history of the new vertex = the path's running history now (dev_bdpt.h)
+    bdpt_store_light_vertex(p, vertex_slot, st.id, r.v_pos, r.v_nrm, r.v_wi, r.v_throughput, r.v_from_prev, st.mis_history, r.v_flags, r.v_tri, r.v_bc_u, r.v_bc_v, st.path_size - 1u, st.path_size, r.v_medium,
+      previous, st.wavelength, derived.seed);
+    st.prev_slot = vertex_slot;
+  }
+}
+
+ETX_DEV void bdpt_walk_push(const Pipeline& p, uint32_t slot, const BdptState& st, uint32_t prev_w, const BdptWalk& walk) {
+  if (slot >= p.capacity)
+    return;  // cannot happen: a path enters at most one object per bounce
+  bdpt_store(p.walk, slot, st, prev_w);
+  p.walk_info[slot] = make_uint2(walk.material, walk.medium);
+}
+
+// One segment of an emitter path after the closest-hit query
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, VcmParams it, uint32_t in_set) {
   __shared__ BlockScratch s_scratch;
-  __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];
-  const LaneStack stack = lane_stack(p.scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
+  const LaneStack no_stack = {};
   const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const PathSet& out = p.paths[in_set ^ 1u];
@@ -175,174 +382,120 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
     const bool valid = i < count;
     BdptState st = {};
     BdptWalk walk = {kInvalid, kInvalid, 0u};
-    bool busy = valid, alive = false;  // busy: this lane has a (sub-)step to run
-    float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
+    BdptLightStep r = {};
     if (valid) {
       st = bdpt_load(in, i);
-      h = p.hits[i];
+      float4 h = p.hits[i];
       if (st.flags & kBpFirst) {
         st.prev.tri = st.prev_slot;  // see k_bdpt_light_generate
         st.prev_slot = kInvalid;
       }
+      r = bdpt_light_step<kStepSegment>(scene, no_stack, mode, st, walk, h);
     }
-    bool walk_pass = false;  // the first pass is the queue segment (workgroup-wide slot reservations, every lane takes part); the
-                             // sub-steps of a walk are a loop of their lane alone and reserve their slots with lane-level atomics
-    do {
-      bool store_emitter = false, store_vertex = false;
-      // the vertex created by this (sub-)step
-      f3 v_pos = mk3(0.0f), v_nrm = mk3(0.0f), v_wi = mk3(0.0f), v_throughput = mk3(0.0f);
-      float v_from_prev = 0.0f, v_bc_u = 0.0f, v_bc_v = 0.0f;
-      uint32_t v_flags = 0u, v_tri = kInvalid, v_medium = kInvalid;
-      BVtx emitter_vertex = {};
-      float emitter_from_next = 0.0f;
-      if (busy) {
-        busy = false;
-        const bool in_walk = kWalk && (walk.material != kInvalid);
-        MediumSample ms;
-        ms.sampled_medium_t = 0.0f;
-        bool flight_ok = true;
-        if (in_walk) {
-          walk.events += 1u;
-          flight_ok = (walk.events <= 1024u) && bdpt_walk_flight(scene, stack, walk, st, h, ms);  // :776-812
-        }
-        const uint32_t tri = __float_as_uint(h.w);
-        const bool found = tri != kInvalid;
-        // regular_step, bidirectional.cxx:712-727
-        if ((in_walk == false) && (st.medium != kInvalid)) {
-          ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
-          st.throughput *= ms.weight;
-        }
-        const bool first = (st.flags & kBpFirst) != 0u;
-        if (flight_ok == false) {
-          // the walk ended the path
-        } else if (ms.sampled_medium()) {  // handle_medium, :533-570
-          const uint32_t medium_index = in_walk ? walk.medium : st.medium;
-          const DMedium& med = scene.mediums[medium_index];
-          const bool explicit_connections = (in_walk == false) && (med.explicit_connections != 0u);  // subsurface_step passes false (:811)
-          const f2 rnd_bsdf = st.sampler.next_2d();
-          (void)st.sampler.next_2d();
-          (void)st.sampler.next_2d();
-          const f3 w_o = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
-          const float pdf_fwd = phase_function(st.ray_d, w_o, med.g);
-          const float pdf_bck = phase_function(w_o, st.ray_d, med.g);
-          st.path_size += 1u;
-          BVtx curr = {ms.pos, mk3(0.0f), 0.0f, 0.0f, kBvMedium | kBvConnectible | ((st.prev.flags & kBvConnectible) ? kBvMisConnectible : 0u), kInvalid};
-          curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
-          float prev_from_next = bdpt_to_area(pdf_bck, ms.pos, st.prev);
-          if (first && (st.flags & kBpDistantEmitter)) {  // update_distant_emitter_path_pdfs, :423-436
-            st.prev.from_prev = bdpt_emitter_sample_pdf(scene, scene.emitters[st.flags >> kBpEmitterShift], -st.ray_d);
-            curr.from_prev = st.aux;
-          }
-          v_pos = ms.pos, v_wi = st.ray_d, v_throughput = st.throughput, v_from_prev = curr.from_prev, v_flags = curr.flags, v_medium = medium_index;
-          if (explicit_connections == false)
-            v_flags |= kBvNoCameraConnection;  // handle_medium skips connect() for it; camera paths still connect TO it
-          st.ray_o = ms.pos, st.ray_d = w_o, st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
-          st.pdf_dir = pdf_fwd;
-          emitter_vertex = st.prev;
-          emitter_from_next = prev_from_next;
-          bdpt_advance_history(st, prev_from_next, false, mode, true);
-          emitter_vertex.history = st.prev.history;
-          store_emitter = first, store_vertex = true;
-          st.prev = curr;
-          st.flags &= ~kBpFirst;
-          if (in_walk)
-            busy = true;  // no roulette inside the walk (:776-815)
-          else
-            alive = random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
-        } else if (found) {
-          Isect isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
-          if (in_walk)
-            isect.material = scene.subsurface_scatter_material;  // build_path :858-861
-          const etx_abi_material& mat = scene.materials[isect.material];
-          const f2 rnd_bsdf = st.sampler.next_2d();
-          (void)st.sampler.next_2d();
-          const f2 rnd_support = st.sampler.next_2d();
-          if (mat.cls == ETX_MAT_BOUNDARY) {  // handle_surface :586-593: the path length does not change
-            const etx_abi_triangle& t = scene.triangles[isect.tri];
-            st.medium = (dot(ld3(t.geo_n), st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
-            st.ray_o = shading_pos(scene, t, isect.bc, st.ray_d);
-            st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
-            alive = true;
-          } else {
-            const BsdfData data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight, st.wavelength);
-            st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
-            BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
-            st.sampler.pop_fixed();
-            uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
-            uint32_t walk_medium = kInvalid, path_medium = vertex_medium;
-            const bool enter = kWalk && (in_walk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, vertex_medium, walk_medium, path_medium);
-            const uint32_t vertex_material = enter ? scene.subsurface_scatter_material : isect.material;
-            st.path_size += 1u;
-            const bool connectible = (bs.properties & kSampleDelta) == 0u;
-            BVtx curr = {isect.pos, isect.nrm, 0.0f, 0.0f,
-              kBvSurface | (connectible ? kBvConnectible : 0u) | ((connectible && (st.prev.flags & kBvConnectible)) ? kBvMisConnectible : 0u), isect.tri};
-            curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
-            const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
-            const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
-            v_pos = isect.pos, v_nrm = isect.nrm, v_wi = isect.w_i, v_throughput = st.throughput, v_flags = curr.flags, v_tri = isect.tri, v_bc_u = isect.bc.y, v_bc_v = isect.bc.z;
-            if (enter || in_walk)
-              v_flags |= kBvScatterMaterial;
-            v_medium = vertex_medium;
-            st.medium = path_medium;
-            bool terminate = false;
-            if (bs.valid()) {
-              st.pdf_dir = bs.pdf;
-              st.throughput *= bs.weight;
-              const etx_abi_triangle& t = scene.triangles[isect.tri];
-              st.ray_o = shading_pos(scene, t, isect.bc, bs.w_o);
-              st.ray_d = bs.w_o;
-              st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
-              st.throughput *= fix_shading_normal(ld3(t.geo_n), isect.nrm, isect.w_i, bs.w_o);
-            } else {
-              terminate = true;
-            }
-            if (first && (st.flags & kBpDistantEmitter)) {  // update_distant_emitter_path_pdfs
-              st.prev.from_prev = bdpt_emitter_sample_pdf(scene, scene.emitters[st.flags >> kBpEmitterShift], -isect.w_i);
-              curr.from_prev = st.aux * fabsf(dot(isect.w_i, ld3(scene.triangles[isect.tri].geo_n)));
-            }
-            v_from_prev = curr.from_prev;
-            emitter_vertex = st.prev;
-            emitter_from_next = prev_from_next;
-            bdpt_advance_history(st, prev_from_next, false, mode, connectible);
-            emitter_vertex.history = st.prev.history;
-            store_emitter = first, store_vertex = true;
-            st.prev = curr;
-            st.flags &= ~kBpFirst;
-            alive = (terminate == false) && random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
-            walk.material = kInvalid;  // a surface vertex ends a walk (:858-861) ...
-            if (enter && alive) {      // ... or starts one: the next sub-steps run here, the path is queued again when it has left the object
-              walk = {isect.material, walk_medium, 0u};
-              alive = false;
-              busy = true;
-            }
-          }
-        }
-      }
-      // pool slots: the emitter vertex (first interaction only), then the new vertex
-      uint32_t emitter_slot = 0u, vertex_slot = 0u;
-      if (walk_pass) {
-        vertex_slot = store_vertex ? atomicAdd(p.counters + kCntLightVertices, 1u) : 0u;
-      } else {
-        emitter_slot = block_compact_slot(store_emitter, p.counters + kCntLightVertices, s_scratch);
-        vertex_slot = block_compact_slot(store_vertex, p.counters + kCntLightVertices, s_scratch);
-      }
-      walk_pass = true;
-      if (store_emitter)
-        bdpt_store_light_vertex(p, emitter_slot, st.id, emitter_vertex.pos, emitter_vertex.nrm, mk3(0.0f), mk3(0.0f), emitter_vertex.from_prev, emitter_vertex.history, emitter_vertex.flags,
-          emitter_vertex.tri, emitter_from_next, 0.0f, 0u, 1u, kInvalid, kInvalid, st.wavelength, 0u);
-      if (store_vertex) {
-        const uint32_t previous = store_emitter ? emitter_slot : st.prev_slot;
-        Sampler derived;
-        derived.init(st.sampler.seed, 0x62647074u);
-        // history of the new vertex = the path's running history now (dev_bdpt.h)
-        bdpt_store_light_vertex(p, vertex_slot, st.id, v_pos, v_nrm, v_wi, v_throughput, v_from_prev, st.mis_history, v_flags, v_tri, v_bc_u, v_bc_v, st.path_size - 1u, st.path_size, v_medium,
-          previous, st.wavelength, derived.seed);
-        st.prev_slot = vertex_slot;
-      }
-    } while (kWalk && busy);
-    const uint32_t slot = block_compact_slot(alive, out_counter, s_scratch);
-    if (alive)
+    // pool slots: the emitter vertex (first interaction only), then the new vertex
+    const uint32_t emitter_slot = block_compact_slot(r.store_emitter, p.counters + kCntLightVertices, s_scratch);
+    const uint32_t vertex_slot = block_compact_slot(r.store_vertex, p.counters + kCntLightVertices, s_scratch);
+    bdpt_light_store(p, st, r, emitter_slot, vertex_slot);
+    const uint32_t slot = block_compact_slot(r.alive, out_counter, s_scratch);
+    if (r.alive)
       bdpt_store(out, slot, st, (st.flags & kBpFirst) ? st.prev.tri : st.prev_slot);
+    if (p.walk_info != nullptr) {  // kernel-uniform: the scene has subsurface materials
+      const uint32_t walk_slot = block_compact_slot(r.walking, p.counters + kCntWalk, s_scratch);
+      if (r.walking)
+        bdpt_walk_push(p, walk_slot, st, st.prev_slot, walk);
+    }
+  }
+}
+
+// The subsurface walks of the paths that entered an object in this bounce (walk queue -> "out" path set). Persistent wavefronts:
+// a lane runs the sub-steps of ITS walk; whenever kWalkRefill lanes of a wavefront are idle they take the next entries of the queue.
+constexpr uint32_t kWalkRefill = 16u;
+constexpr uint32_t kWalkBlocks = 1024u;
+
+// Taking the next entries of the walk queue: called by all lanes of a wavefront; lanes without a walk get one while the queue lasts.
+// Returns false when the wavefront has nothing left to do.
+ETX_DEV bool walk_refill(const Pipeline& p, uint32_t count, bool& active, bool& exhausted, uint32_t& entry) {
+  const unsigned long long idle_mask = __ballot(active == false);
+  const uint32_t idle_count = uint32_t(__popcll(idle_mask));
+  entry = kInvalid;
+  if ((exhausted == false) && ((idle_count >= kWalkRefill) || (idle_count == 64u))) {
+    uint32_t base = 0u;
+    if ((threadIdx.x & 63u) == 0u)
+      base = atomicAdd(p.counters + kCntWalkFetch, idle_count);
+    base = __builtin_amdgcn_readfirstlane(base);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32u), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
+    if ((active == false) && (base + rank < count))
+      entry = base + rank;
+    exhausted = base + idle_count >= count;
+  }
+  return (__ballot(active || (entry != kInvalid)) != 0ull) || (exhausted == false);
+}
+
+// The scattering events of the walks of this bounce, emitter paths: walk queue -> (medium vertices in the light vertex pool) -> exit queue
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_light(Pipeline p, VcmParams it) {
+  __shared__ int32_t s_stack[kStackDepth * kBlockSize];
+  const LaneStack stack = lane_stack(p.scene, s_stack + threadIdx.x, kBlockSize);
+  const DScene& scene = p.scene;
+  const uint32_t count = min(p.counters[kCntWalk], p.capacity);
+  if (count == 0u)
+    return;
+  const uint32_t mode = bdpt_mode(it);
+  const uint32_t lane = threadIdx.x & 63u;
+  BdptState st = {};
+  BdptWalk walk = {kInvalid, kInvalid, 0u};
+  WaveChunk chunk = {0u, 0u};
+  bool active = false, exhausted = false;
+  uint32_t entry = kInvalid;
+  while (walk_refill(p, count, active, exhausted, entry)) {
+    if (entry != kInvalid) {
+      st = bdpt_load(p.walk, entry);
+      const uint2 info = p.walk_info[entry];
+      walk = {info.x, info.y, 0u};
+      active = true;
+    }
+    BdptLightStep r = {};
+    float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
+    if (active)
+      r = bdpt_light_step<kStepWalkEvent>(scene, stack, mode, st, walk, h);
+    const uint32_t vertex_slot = wave_chunk_slot(r.store_vertex, chunk, p.counters + kCntLightVertices);
+    bdpt_light_store(p, st, r, 0u, vertex_slot);  // a walk never holds the emitter vertex: its entry vertex came first
+    const uint32_t exit_slot = wave_compact_slot(r.exit, p.counters + kCntWalkExit);
+    if (r.exit && (exit_slot < p.capacity)) {
+      bdpt_store(p.walk_exit, exit_slot, st, st.prev_slot);
+      p.walk_exit_hits[exit_slot] = h;
+    }
+    active = active && r.walking;
+  }
+  // the unused rest of this wavefront's last chunk: records nobody may connect to
+  for (uint32_t i = chunk.next + lane; i < min(chunk.end, p.lv.capacity); i += 64u) {
+    p.lv.thr_dvm(i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    p.lv.bc_len_med(i) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
+  }
+}
+
+// ... and the surface vertices where they leave their objects: exit queue -> "out" path set
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_exit_light(Pipeline p, VcmParams it, uint32_t out_set) {
+  __shared__ BlockScratch s_scratch;
+  const LaneStack no_stack = {};
+  const DScene& scene = p.scene;
+  const uint32_t count = min(p.counters[kCntWalkExit], p.capacity);
+  const PathSet& out = p.paths[out_set];
+  uint32_t* out_counter = p.counters + (out_set == 0 ? kCntActiveA : kCntActiveB);
+  const uint32_t mode = bdpt_mode(it);
+  ETX_BLOCK_LOOP(count, i) {
+    BdptState st = {};
+    BdptWalk walk = {kInvalid, kInvalid, 0u};
+    BdptLightStep r = {};
+    if (i < count) {
+      st = bdpt_load(p.walk_exit, i);
+      float4 h = p.walk_exit_hits[i];
+      r = bdpt_light_step<kStepWalkExit>(scene, no_stack, mode, st, walk, h);
+    }
+    const uint32_t vertex_slot = block_compact_slot(r.store_vertex, p.counters + kCntLightVertices, s_scratch);
+    bdpt_light_store(p, st, r, 0u, vertex_slot);
+    const uint32_t slot = block_compact_slot(r.alive, out_counter, s_scratch);
+    if (r.alive)
+      bdpt_store(out, slot, st, st.prev_slot);
   }
 }
 
@@ -468,11 +621,235 @@ ETX_DEV float bdpt_direct_hit_weight(const BdptState& st, uint32_t mode, float z
   return 1.0f / (1.0f + bdpt_mis_camera(st.path_size, p_sample, z_curr_from_prev, p_from, st.prev));
 }
 
-template <bool kWalk>
+// What one (sub-)step of a camera path leaves behind.
+struct BdptCameraStep {
+  bool store_vertex;    // a connectible vertex for the camera vertex pool (written BEFORE `created` replaces st.prev: the record reads z_prev)
+  bool created;         // a path vertex (curr) exists and becomes prev
+  bool terminate, enter, scatter_vertex, in_medium_event;
+  bool exit;            // kStepWalkEvent: the flight reached the object's surface (hit in `h`)
+  bool alive;           // boundary crossing: the path continues on the ray queue without a vertex
+  BVtx curr;
+  float4 v_hit;
+  f3 v_wi, v_throughput, v_rnd;
+  uint32_t v_medium, enter_material, enter_medium;
+};
+
+// One segment of a camera path after the closest-hit query (kInWalk = false), or one sub-step of a subsurface walk (kInWalk = true).
+// Film contributions of direct hits are added here; pool records and the roulette are the caller's (bdpt_camera_finish).
+template <uint32_t kStep>
+ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, const LaneStack& stack, const VcmParams& it, uint32_t mode, bool use_mis, BdptState& st, BdptWalk& walk, float4& h) {
+  constexpr bool kInWalk = kStep != kStepSegment;
+  BdptCameraStep r = {};
+  r.v_hit = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
+  r.v_medium = r.enter_material = r.enter_medium = kInvalid;
+  MediumSample ms;
+  ms.sampled_medium_t = 0.0f;
+  bool flight_ok = true;
+  if (kStep == kStepWalkEvent) {
+    walk.events += 1u;
+    flight_ok = (walk.events <= 1024u) && bdpt_walk_flight(scene, stack, walk, st, h, ms);  // subsurface_step, :776-812
+  }
+  const uint32_t tri = __float_as_uint(h.w);
+  const bool found = tri != kInvalid;
+  const uint32_t film_target = film_index(it, st.id);
+  const f3 film_weight = spectral_film_weight(scene, st.wavelength);
+  if ((kInWalk == false) && (st.medium != kInvalid)) {
+    ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+    st.throughput *= ms.weight;
+  }
+  const bool first = (st.flags & kBpFirst) != 0u;
+  if (flight_ok == false) {
+    // the walk ended the path
+  } else if (ms.sampled_medium()) {  // handle_medium, :533-570
+    const uint32_t medium_index = kInWalk ? walk.medium : st.medium;
+    const DMedium& med = scene.mediums[medium_index];
+    f2 rnd_bsdf = st.sampler.next_2d();
+    f2 rnd_em = st.sampler.next_2d();
+    f2 rnd_support = st.sampler.next_2d();
+    if ((it.bluenoise != nullptr) && first && (it.iteration < 256u))
+      bluenoise_samples(it.bluenoise, st.id % it.film_w, st.id / it.film_w, it.iteration, rnd_bsdf, rnd_em, rnd_support);
+    const f3 w_o = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
+    const float pdf_fwd = phase_function(st.ray_d, w_o, med.g);
+    const float pdf_bck = phase_function(w_o, st.ray_d, med.g);
+    st.path_size += 1u;
+    r.curr = {ms.pos, mk3(0.0f), 0.0f, 0.0f, kBvMedium | kBvConnectible | ((st.prev.flags & kBvConnectible) ? kBvMisConnectible : 0u), kInvalid};
+    r.curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, r.curr);
+    const float prev_from_next = bdpt_to_area(pdf_bck, ms.pos, st.prev);
+    r.v_hit = mk4(ms.pos, __uint_as_float(kInvalid)), r.v_wi = st.ray_d, r.v_throughput = st.throughput, r.v_medium = medium_index;
+    r.v_rnd = {rnd_em.x, rnd_em.y, rnd_support.y};
+    st.ray_o = ms.pos, st.ray_d = w_o, st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+    st.pdf_dir = pdf_fwd;
+    bdpt_advance_history(st, prev_from_next, true, mode, true);
+    r.created = true;
+    r.in_medium_event = true;
+    r.store_vertex = (kInWalk == false) && (med.explicit_connections != 0u) && (mode != kBdptLightTracing);  // subsurface_step: no explicit connections (:811)
+  } else if (found) {
+   if constexpr (kStep == kStepWalkEvent) {
+    r.exit = true;
+   } else {
+    Isect isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
+    if (kInWalk)
+      isect.material = scene.subsurface_scatter_material;  // build_path :858-861
+    r.scatter_vertex = kInWalk;
+    const etx_abi_material& mat = scene.materials[isect.material];
+    f2 rnd_bsdf = st.sampler.next_2d();
+    f2 rnd_em = st.sampler.next_2d();
+    f2 rnd_support = st.sampler.next_2d();
+    if ((it.bluenoise != nullptr) && first)
+      bluenoise_samples(it.bluenoise, st.id % it.film_w, st.id / it.film_w, it.iteration, rnd_bsdf, rnd_em, rnd_support);
+    if (mat.cls == ETX_MAT_BOUNDARY) {  // handle_surface :586-593: no vertex, the path length does not change
+      const etx_abi_triangle& t = scene.triangles[isect.tri];
+      st.medium = (dot(ld3(t.geo_n), st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
+      st.ray_o = shading_pos(scene, t, isect.bc, st.ray_d);
+      st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+      r.alive = true;
+    } else {
+      const BsdfData data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera, st.wavelength);
+      if ((st.flags & kBpGBuffer) == 0u) {  // GBuffer, :597-601
+        film_add(p, p.normal_sum + film_target, isect.nrm);
+        film_add(p, p.albedo_sum + film_target, bdpt_albedo(scene, mat, isect.tex, st.wavelength) * film_weight);
+        st.flags |= kBpGBuffer;
+      }
+      st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
+      BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
+      st.sampler.pop_fixed();
+      uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
+      uint32_t path_medium = vertex_medium;
+      r.enter = (kInWalk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, vertex_medium, r.enter_medium, path_medium);
+      r.scatter_vertex = r.scatter_vertex || r.enter;
+      r.enter_material = isect.material;
+      const uint32_t vertex_material = r.enter ? scene.subsurface_scatter_material : isect.material;
+      st.path_size += 1u;
+      const bool connectible = (bs.properties & kSampleDelta) == 0u;
+      r.curr = {isect.pos, isect.nrm, 0.0f, 0.0f, kBvSurface | (connectible ? kBvConnectible : 0u) | ((connectible && (st.prev.flags & kBvConnectible)) ? kBvMisConnectible : 0u),
+        isect.tri};
+      r.curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, r.curr);
+      const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
+      const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
+      const f3 vertex_throughput = st.throughput;
+      const float prev_sampled_pdf = st.aux;  // z_prev.pdf.bsdf_sample_next (PathTracing mode weights)
+      st.medium = path_medium;
+      if (bs.valid()) {
+        st.eta *= bs.eta;
+        st.pdf_dir = bs.pdf;
+        st.throughput *= bs.weight;
+        st.ray_o = shading_pos(scene, scene.triangles[isect.tri], isect.bc, bs.w_o);
+        st.ray_d = bs.w_o;
+        st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
+      } else {
+        r.terminate = true;
+      }
+      bdpt_advance_history(st, prev_from_next, true, mode, connectible);
+      // direct_hit_area_emitter, :1235-1287 (the segment itself was the visibility query)
+      if (opt_direct_hit(it) && (isect.emitter != kInvalid) && (mode != kBdptLightTracing)) {
+        const uint32_t target_path_length = st.path_size - 1u;
+        if ((target_path_length <= scene.max_path_length) && (target_path_length >= scene.min_path_length)) {
+          const etx_abi_emitter& em = scene.emitters[isect.emitter];
+          EmitterRadianceQuery q;
+          q.source_position = st.prev.pos;
+          q.target_position = isect.pos;
+          q.direction = mk3(0.0f);
+          q.uv = isect.tex;
+          q.directly_visible = (st.path_size - 1u) <= 1u;
+          float pdf_area = 0.0f, pdf_dir = 0.0f, pdf_dir_out = 0.0f;
+          const f3 value = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out, st.wavelength);
+          if (pdf_dir != 0.0f) {
+            float weight = 1.0f;
+            if (use_mis && (st.path_size > 2u)) {
+              if (mode == kBdptPathTracing) {
+                const float p_connect = pdf_dir * emitter_discrete_pdf(scene, em);
+                weight = (st.prev.flags & kBvConnectible) ? power_heuristic(prev_sampled_pdf, p_connect) : 1.0f;
+              } else {
+                const float p_sample = bdpt_emitter_sample_pdf(scene, em, -isect.w_i);
+                const float p_from = bdpt_pdf_from_emitter(scene, isect.emitter, isect.pos, isect.nrm, st.prev);
+                weight = bdpt_direct_hit_weight(st, mode, r.curr.from_prev, p_sample, p_from);
+              }
+            }
+            const f3 gathered = value * vertex_throughput * weight;
+            if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
+              film_add(p, p.camera_sum + film_target, gathered * film_weight);
+          }
+        }
+      }
+      r.created = true;
+      r.store_vertex = connectible && (mode != kBdptLightTracing);
+      r.v_hit = h, r.v_wi = isect.w_i, r.v_throughput = vertex_throughput, r.v_medium = vertex_medium;
+      r.v_rnd = {rnd_em.x, rnd_em.y, rnd_support.y};
+    }
+   }
+  } else if ((kInWalk == false) && opt_direct_hit(it) && (mode != kBdptLightTracing)) {  // miss: direct_hit_environment_emitter, :1289-1340
+    const float prev_sampled_pdf = st.aux;
+    st.path_size += 1u;
+    bdpt_advance_history(st, 0.0f, true, mode, false);
+    const uint32_t target_path_length = st.path_size - 1u;
+    if ((scene.env_count > 0u) && (target_path_length <= scene.max_path_length) && (target_path_length >= scene.min_path_length)) {
+      f3 accumulated = mk3(0.0f);
+      for (uint32_t ie = 0; ie < scene.env_count; ++ie) {
+        const etx_abi_emitter& em = scene.emitters[scene.env_emitters[ie]];
+        EmitterRadianceQuery q;
+        q.source_position = q.target_position = mk3(0.0f);
+        q.direction = st.ray_d;
+        q.uv = {0.0f, 0.0f};
+        q.directly_visible = (st.path_size - 1u) <= 1u;
+        float pdf_area = 0.0f, pdf_dir = 0.0f, pdf_dir_out = 0.0f;
+        const f3 value = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out, st.wavelength);
+        float this_weight = 1.0f;
+        if ((mode == kBdptPathTracing) && (st.prev.flags & kBvConnectible) && (st.path_size - 1u > 1u))
+          this_weight = power_heuristic(prev_sampled_pdf, pdf_dir * emitter_discrete_pdf(scene, em));
+        accumulated += value * this_weight;
+      }
+      if (is_zero(accumulated) == false) {
+        float weight = 1.0f;
+        if (use_mis && (st.path_size - 1u > 1u) && (mode != kBdptPathTracing)) {
+          // pdf_for_environment_emitter, :207-222
+          float pdf_dir = 0.0f;
+          for (uint32_t ie = 0; ie < scene.env_count; ++ie)
+            pdf_dir += bdpt_emitter_sample_pdf(scene, scene.emitters[scene.env_emitters[ie]], st.ray_d);
+          pdf_dir /= float(scene.env_count);
+          const float w_dot_n = st.prev.surface() ? fabsf(dot(ld3(scene.triangles[st.prev.tri].geo_n), st.ray_d)) : 1.0f;
+          const float p_from = w_dot_n * env_pdf_area(scene);
+          weight = bdpt_direct_hit_weight(st, mode, st.pdf_dir, pdf_dir, p_from);
+        }
+        film_add(p, p.camera_sum + film_target, accumulated * st.throughput * weight * film_weight);
+      }
+    }
+    if ((st.flags & kBpGBuffer) == 0u)
+      film_add(p, p.normal_sum + film_target, f3{0.0f, 0.0f, 1.0f});  // GBuffer default normal, :335-338
+  } else if ((kInWalk == false) && ((st.flags & kBpGBuffer) == 0u)) {
+    film_add(p, p.normal_sum + film_target, f3{0.0f, 0.0f, 1.0f});
+  }
+  return r;
+}
+
+// After the (sub-)step: the camera vertex record (slot reserved by the caller), prev = curr, the roulette of this interaction
+// (build_path :890-895). Returns: 0 = the path ended, 1 = it continues on the ray queue, 2 = it is inside an object (walk = which;
+// kInWalk: the walk goes on, else: it has just entered).
+template <uint32_t kStep>
+ETX_DEV uint32_t bdpt_camera_finish(const Pipeline& p, const DScene& scene, BdptState& st, BdptWalk& walk, const BdptCameraStep& r, uint32_t vertex_slot) {
+  if (r.store_vertex) {
+    Sampler derived;
+    derived.init(st.sampler.seed, 0x51ed270bu);
+    bdpt_store_camera_vertex(p, vertex_slot, st, r.v_hit, r.v_wi, r.v_medium, r.v_throughput, r.curr.from_prev, r.v_rnd, derived.seed, r.scatter_vertex);
+  }
+  constexpr bool kInWalk = kStep != kStepSegment;
+  if (r.created == false)
+    return r.alive ? 1u : 0u;
+  st.prev = r.curr;
+  st.flags &= ~kBpFirst;
+  st.aux = st.pdf_dir;  // becomes z_prev.pdf.bsdf_sample_next
+  if (kInWalk && r.in_medium_event)
+    return 2u;  // a scattering event inside the object: no roulette, the walk goes on (subsurface_step :776-815)
+  const bool goes_on = (r.terminate == false) && random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
+  if (r.enter && goes_on) {  // a surface vertex ends a walk or starts one
+    walk = {r.enter_material, r.enter_medium, 0u};
+    return 2u;
+  }
+  return goes_on ? 1u : 0u;
+}
+
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, VcmParams it, uint32_t in_set) {
   __shared__ BlockScratch s_scratch;
-  __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];  // the sub-steps of a subsurface walk traverse inline (k_bdpt_light_shade)
-  const LaneStack stack = lane_stack(p.scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
+  const LaneStack no_stack = {};
   const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const PathSet& out = p.paths[in_set ^ 1u];
@@ -484,226 +861,89 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
     const bool valid = i < count;
     BdptState st = {};
     BdptWalk walk = {kInvalid, kInvalid, 0u};
-    bool busy = valid, alive = false;
-    float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
+    BdptCameraStep r = {};
     if (valid) {
       st = bdpt_load(in, i);
       st.prev.tri = st.prev_slot;  // camera paths carry the previous vertex' triangle there
-      h = p.hits[i];
+      float4 h = p.hits[i];
+      r = bdpt_camera_step<kStepSegment>(p, scene, no_stack, it, mode, use_mis, st, walk, h);
     }
-    bool walk_pass = false;  // as in k_bdpt_light_shade
-    do {
-    // what the (sub-)step did: `created` = a path vertex (curr) exists and becomes prev; `store_vertex` = it is connectible and
-    // goes to the camera vertex pool (the record reads z_prev = st.prev, so prev is replaced AFTER the store)
-    bool created = false, store_vertex = false, terminate = false, enter = false, scatter_vertex = false;
-    BVtx curr = {};
-    float4 v_hit = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
-    f3 v_wi = mk3(0.0f), v_throughput = mk3(0.0f), v_rnd = mk3(0.0f);
-    uint32_t v_medium = kInvalid, enter_material = kInvalid, enter_medium = kInvalid;
-    const bool in_walk = kWalk && (walk.material != kInvalid);
-    const bool stepping = busy;
-    if (busy) {
-      busy = false;
-      MediumSample ms;
-      ms.sampled_medium_t = 0.0f;
-      bool flight_ok = true;
-      if (in_walk) {
-        walk.events += 1u;
-        flight_ok = (walk.events <= 1024u) && bdpt_walk_flight(scene, stack, walk, st, h, ms);  // subsurface_step, :776-812
-      }
-      const uint32_t tri = __float_as_uint(h.w);
-      const bool found = tri != kInvalid;
-      const uint32_t film_target = film_index(it, st.id);
-      const f3 film_weight = spectral_film_weight(scene, st.wavelength);
-      if ((in_walk == false) && (st.medium != kInvalid)) {
-        ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
-        st.throughput *= ms.weight;
-      }
-      const bool first = (st.flags & kBpFirst) != 0u;
-      if (flight_ok == false) {
-        // the walk ended the path
-      } else if (ms.sampled_medium()) {  // handle_medium, :533-570
-        const uint32_t medium_index = in_walk ? walk.medium : st.medium;
-        const DMedium& med = scene.mediums[medium_index];
-        f2 rnd_bsdf = st.sampler.next_2d();
-        f2 rnd_em = st.sampler.next_2d();
-        f2 rnd_support = st.sampler.next_2d();
-        if ((it.bluenoise != nullptr) && first && (it.iteration < 256u))
-          bluenoise_samples(it.bluenoise, st.id % it.film_w, st.id / it.film_w, it.iteration, rnd_bsdf, rnd_em, rnd_support);
-        const f3 w_o = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
-        const float pdf_fwd = phase_function(st.ray_d, w_o, med.g);
-        const float pdf_bck = phase_function(w_o, st.ray_d, med.g);
-        st.path_size += 1u;
-        curr = {ms.pos, mk3(0.0f), 0.0f, 0.0f, kBvMedium | kBvConnectible | ((st.prev.flags & kBvConnectible) ? kBvMisConnectible : 0u), kInvalid};
-        curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
-        const float prev_from_next = bdpt_to_area(pdf_bck, ms.pos, st.prev);
-        v_hit = mk4(ms.pos, __uint_as_float(kInvalid)), v_wi = st.ray_d, v_throughput = st.throughput, v_medium = medium_index;
-        v_rnd = {rnd_em.x, rnd_em.y, rnd_support.y};
-        st.ray_o = ms.pos, st.ray_d = w_o, st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
-        st.pdf_dir = pdf_fwd;
-        bdpt_advance_history(st, prev_from_next, true, mode, true);
-        created = true;
-        store_vertex = (in_walk == false) && (med.explicit_connections != 0u) && (mode != kBdptLightTracing);  // subsurface_step: no explicit connections (:811)
-      } else if (found) {
-        Isect isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
-        if (in_walk)
-          isect.material = scene.subsurface_scatter_material;  // build_path :858-861
-        scatter_vertex = in_walk;
-        const etx_abi_material& mat = scene.materials[isect.material];
-        f2 rnd_bsdf = st.sampler.next_2d();
-        f2 rnd_em = st.sampler.next_2d();
-        f2 rnd_support = st.sampler.next_2d();
-        if ((it.bluenoise != nullptr) && first)
-          bluenoise_samples(it.bluenoise, st.id % it.film_w, st.id / it.film_w, it.iteration, rnd_bsdf, rnd_em, rnd_support);
-        if (mat.cls == ETX_MAT_BOUNDARY) {  // handle_surface :586-593: no vertex, the path length does not change
-          const etx_abi_triangle& t = scene.triangles[isect.tri];
-          st.medium = (dot(ld3(t.geo_n), st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
-          st.ray_o = shading_pos(scene, t, isect.bc, st.ray_d);
-          st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
-          alive = true;
-        } else {
-          const BsdfData data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera, st.wavelength);
-          if ((st.flags & kBpGBuffer) == 0u) {  // GBuffer, :597-601
-            film_add(p, p.normal_sum + film_target, isect.nrm);
-            film_add(p, p.albedo_sum + film_target, bdpt_albedo(scene, mat, isect.tex, st.wavelength) * film_weight);
-            st.flags |= kBpGBuffer;
-          }
-          st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
-          BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
-          st.sampler.pop_fixed();
-          uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
-          uint32_t path_medium = vertex_medium;
-          enter = kWalk && (in_walk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, vertex_medium, enter_medium, path_medium);
-          scatter_vertex = scatter_vertex || enter;
-          enter_material = isect.material;
-          const uint32_t vertex_material = enter ? scene.subsurface_scatter_material : isect.material;
-          st.path_size += 1u;
-          const bool connectible = (bs.properties & kSampleDelta) == 0u;
-          curr = {isect.pos, isect.nrm, 0.0f, 0.0f, kBvSurface | (connectible ? kBvConnectible : 0u) | ((connectible && (st.prev.flags & kBvConnectible)) ? kBvMisConnectible : 0u),
-            isect.tri};
-          curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
-          const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
-          const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
-          const f3 vertex_throughput = st.throughput;
-          const float prev_sampled_pdf = st.aux;  // z_prev.pdf.bsdf_sample_next (PathTracing mode weights)
-          st.medium = path_medium;
-          if (bs.valid()) {
-            st.eta *= bs.eta;
-            st.pdf_dir = bs.pdf;
-            st.throughput *= bs.weight;
-            st.ray_o = shading_pos(scene, scene.triangles[isect.tri], isect.bc, bs.w_o);
-            st.ray_d = bs.w_o;
-            st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
-          } else {
-            terminate = true;
-          }
-          bdpt_advance_history(st, prev_from_next, true, mode, connectible);
-          // direct_hit_area_emitter, :1235-1287 (the segment itself was the visibility query)
-          if (opt_direct_hit(it) && (isect.emitter != kInvalid) && (mode != kBdptLightTracing)) {
-            const uint32_t target_path_length = st.path_size - 1u;
-            if ((target_path_length <= scene.max_path_length) && (target_path_length >= scene.min_path_length)) {
-              const etx_abi_emitter& em = scene.emitters[isect.emitter];
-              EmitterRadianceQuery q;
-              q.source_position = st.prev.pos;
-              q.target_position = isect.pos;
-              q.direction = mk3(0.0f);
-              q.uv = isect.tex;
-              q.directly_visible = (st.path_size - 1u) <= 1u;
-              float pdf_area = 0.0f, pdf_dir = 0.0f, pdf_dir_out = 0.0f;
-              const f3 value = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out, st.wavelength);
-              if (pdf_dir != 0.0f) {
-                float weight = 1.0f;
-                if (use_mis && (st.path_size > 2u)) {
-                  if (mode == kBdptPathTracing) {
-                    const float p_connect = pdf_dir * emitter_discrete_pdf(scene, em);
-                    weight = (st.prev.flags & kBvConnectible) ? power_heuristic(prev_sampled_pdf, p_connect) : 1.0f;
-                  } else {
-                    const float p_sample = bdpt_emitter_sample_pdf(scene, em, -isect.w_i);
-                    const float p_from = bdpt_pdf_from_emitter(scene, isect.emitter, isect.pos, isect.nrm, st.prev);
-                    weight = bdpt_direct_hit_weight(st, mode, curr.from_prev, p_sample, p_from);
-                  }
-                }
-                const f3 gathered = value * vertex_throughput * weight;
-                if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
-                  film_add(p, p.camera_sum + film_target, gathered * film_weight);
-              }
-            }
-          }
-          created = true;
-          store_vertex = connectible && (mode != kBdptLightTracing);
-          v_hit = h, v_wi = isect.w_i, v_throughput = vertex_throughput, v_medium = vertex_medium;
-          v_rnd = {rnd_em.x, rnd_em.y, rnd_support.y};
-        }
-      } else if (opt_direct_hit(it) && (mode != kBdptLightTracing)) {  // miss: direct_hit_environment_emitter, :1289-1340
-        const float prev_sampled_pdf = st.aux;
-        st.path_size += 1u;
-        bdpt_advance_history(st, 0.0f, true, mode, false);
-        const uint32_t target_path_length = st.path_size - 1u;
-        if ((scene.env_count > 0u) && (target_path_length <= scene.max_path_length) && (target_path_length >= scene.min_path_length)) {
-          f3 accumulated = mk3(0.0f);
-          for (uint32_t ie = 0; ie < scene.env_count; ++ie) {
-            const etx_abi_emitter& em = scene.emitters[scene.env_emitters[ie]];
-            EmitterRadianceQuery q;
-            q.source_position = q.target_position = mk3(0.0f);
-            q.direction = st.ray_d;
-            q.uv = {0.0f, 0.0f};
-            q.directly_visible = (st.path_size - 1u) <= 1u;
-            float pdf_area = 0.0f, pdf_dir = 0.0f, pdf_dir_out = 0.0f;
-            const f3 value = emitter_get_radiance(scene, em, q, pdf_area, pdf_dir, pdf_dir_out, st.wavelength);
-            float this_weight = 1.0f;
-            if ((mode == kBdptPathTracing) && (st.prev.flags & kBvConnectible) && (st.path_size - 1u > 1u))
-              this_weight = power_heuristic(prev_sampled_pdf, pdf_dir * emitter_discrete_pdf(scene, em));
-            accumulated += value * this_weight;
-          }
-          if (is_zero(accumulated) == false) {
-            float weight = 1.0f;
-            if (use_mis && (st.path_size - 1u > 1u) && (mode != kBdptPathTracing)) {
-              // pdf_for_environment_emitter, :207-222
-              float pdf_dir = 0.0f;
-              for (uint32_t ie = 0; ie < scene.env_count; ++ie)
-                pdf_dir += bdpt_emitter_sample_pdf(scene, scene.emitters[scene.env_emitters[ie]], st.ray_d);
-              pdf_dir /= float(scene.env_count);
-              const float w_dot_n = st.prev.surface() ? fabsf(dot(ld3(scene.triangles[st.prev.tri].geo_n), st.ray_d)) : 1.0f;
-              const float p_from = w_dot_n * env_pdf_area(scene);
-              weight = bdpt_direct_hit_weight(st, mode, st.pdf_dir, pdf_dir, p_from);
-            }
-            film_add(p, p.camera_sum + film_target, accumulated * st.throughput * weight * film_weight);
-          }
-        }
-        if ((st.flags & kBpGBuffer) == 0u)
-          film_add(p, p.normal_sum + film_target, f3{0.0f, 0.0f, 1.0f});  // GBuffer default normal, :335-338
-      } else if ((st.flags & kBpGBuffer) == 0u) {
-        film_add(p, p.normal_sum + film_target, f3{0.0f, 0.0f, 1.0f});
-      }
+    const uint32_t vertex_slot = block_compact_slot(r.store_vertex, p.counters + kCntCameraVertices, s_scratch);
+    const uint32_t next = valid ? bdpt_camera_finish<kStepSegment>(p, scene, st, walk, r, vertex_slot) : 0u;
+    const uint32_t slot = block_compact_slot(next == 1u, out_counter, s_scratch);
+    if (next == 1u)
+      bdpt_store(out, slot, st, st.prev.tri);
+    if (p.walk_info != nullptr) {  // kernel-uniform: the scene has subsurface materials
+      const uint32_t walk_slot = block_compact_slot(next == 2u, p.counters + kCntWalk, s_scratch);
+      if (next == 2u)
+        bdpt_walk_push(p, walk_slot, st, st.prev.tri, walk);
     }
-    const uint32_t vertex_slot = walk_pass ? (store_vertex ? atomicAdd(p.counters + kCntCameraVertices, 1u) : 0u) : block_compact_slot(store_vertex, p.counters + kCntCameraVertices, s_scratch);
-    walk_pass = true;
-    if (store_vertex) {
-      Sampler derived;
-      derived.init(st.sampler.seed, 0x51ed270bu);
-      bdpt_store_camera_vertex(p, vertex_slot, st, v_hit, v_wi, v_medium, v_throughput, curr.from_prev, v_rnd, derived.seed, scatter_vertex);
+  }
+}
+
+// The scattering events of the walks of this bounce, camera paths: walk queue -> exit queue (only the exit vertex of a walk is
+// connectible, :811: the events leave nothing but the path's running MIS history behind)
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_camera(Pipeline p, VcmParams it) {
+  __shared__ int32_t s_stack[kStackDepth * kBlockSize];
+  const LaneStack stack = lane_stack(p.scene, s_stack + threadIdx.x, kBlockSize);
+  const DScene& scene = p.scene;
+  const uint32_t count = min(p.counters[kCntWalk], p.capacity);
+  if (count == 0u)
+    return;
+  const uint32_t mode = bdpt_mode(it);
+  const bool use_mis = opt_enable_mis(it);
+  BdptState st = {};
+  BdptWalk walk = {kInvalid, kInvalid, 0u};
+  bool active = false, exhausted = false;
+  uint32_t entry = kInvalid;
+  while (walk_refill(p, count, active, exhausted, entry)) {
+    if (entry != kInvalid) {
+      st = bdpt_load(p.walk, entry);
+      st.prev.tri = st.prev_slot;
+      const uint2 info = p.walk_info[entry];
+      walk = {info.x, info.y, 0u};
+      active = true;
     }
-    if (created) {  // build_path: prev = curr at the top of the next iteration, then the roulette of this interaction (:890-895)
-      st.prev = curr;
-      st.flags &= ~kBpFirst;
-      st.aux = st.pdf_dir;  // becomes z_prev.pdf.bsdf_sample_next
-      if (in_walk && (curr.flags & kBvMedium)) {
-        busy = true;  // a scattering event inside the object: no roulette, the walk goes on (subsurface_step :776-815)
-      } else {
-        const bool goes_on = (terminate == false) && random_continue(st.path_size - 2u, scene.random_path_termination, st.eta, st.sampler, st.throughput) && (st.path_size - 1u < scene.max_path_length);
-        walk.material = kInvalid;  // a surface vertex ends a walk ...
-        if (enter && goes_on) {    // ... or starts one: its sub-steps run here, the path is queued again when it has left the object
-          walk = {enter_material, enter_medium, 0u};
-          busy = true;
-        } else {
-          alive = goes_on;
-        }
-      }
+    BdptCameraStep r = {};
+    float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
+    uint32_t next = 0u;
+    if (active) {
+      r = bdpt_camera_step<kStepWalkEvent>(p, scene, stack, it, mode, use_mis, st, walk, h);
+      next = bdpt_camera_finish<kStepWalkEvent>(p, scene, st, walk, r, 0u);
     }
-    (void)stepping;
-    } while (kWalk && busy);
-    const uint32_t slot = block_compact_slot(alive, out_counter, s_scratch);
-    if (alive)
+    const uint32_t exit_slot = wave_compact_slot(r.exit, p.counters + kCntWalkExit);
+    if (r.exit && (exit_slot < p.capacity)) {
+      bdpt_store(p.walk_exit, exit_slot, st, st.prev.tri);
+      p.walk_exit_hits[exit_slot] = h;
+    }
+    active = next == 2u;
+  }
+}
+
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_exit_camera(Pipeline p, VcmParams it, uint32_t out_set) {
+  __shared__ BlockScratch s_scratch;
+  const LaneStack no_stack = {};
+  const DScene& scene = p.scene;
+  const uint32_t count = min(p.counters[kCntWalkExit], p.capacity);
+  const PathSet& out = p.paths[out_set];
+  uint32_t* out_counter = p.counters + (out_set == 0 ? kCntActiveA : kCntActiveB);
+  const uint32_t mode = bdpt_mode(it);
+  const bool use_mis = opt_enable_mis(it);
+  ETX_BLOCK_LOOP(count, i) {
+    const bool valid = i < count;
+    BdptState st = {};
+    BdptWalk walk = {kInvalid, kInvalid, 0u};
+    BdptCameraStep r = {};
+    if (valid) {
+      st = bdpt_load(p.walk_exit, i);
+      st.prev.tri = st.prev_slot;
+      float4 h = p.walk_exit_hits[i];
+      r = bdpt_camera_step<kStepWalkExit>(p, scene, no_stack, it, mode, use_mis, st, walk, h);
+    }
+    const uint32_t vertex_slot = block_compact_slot(r.store_vertex, p.counters + kCntCameraVertices, s_scratch);
+    const uint32_t next = valid ? bdpt_camera_finish<kStepWalkExit>(p, scene, st, walk, r, vertex_slot) : 0u;
+    const uint32_t slot = block_compact_slot(next == 1u, out_counter, s_scratch);
+    if (next == 1u)
       bdpt_store(out, slot, st, st.prev.tri);
   }
 }
@@ -825,11 +1065,21 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs(Pipeline p, V
 void launch_bdpt_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
   hipLaunchKernelGGL(k_bdpt_light_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
 }
-void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool subsurface) {
-  if (subsurface)
-    hipLaunchKernelGGL(k_bdpt_light_shade<true>, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
-  else
-    hipLaunchKernelGGL(k_bdpt_light_shade<false>, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
+void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
+  hipLaunchKernelGGL(k_bdpt_light_shade, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
+}
+// the walks of the paths the shade kernel of this round put on the walk queue: the scattering events in persistent wavefronts (at most
+// kWalkBlocks workgroups: 32 KB of traversal stack each), then the exit vertices as a dense kernel
+void launch_bdpt_walk(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool camera, uint32_t out_set, uint32_t max_items) {
+  const uint32_t items = min(p.capacity, max_items);
+  const uint32_t blocks = max(1u, min(kWalkBlocks, (items + kBlockSize - 1u) / kBlockSize));
+  if (camera) {
+    hipLaunchKernelGGL(k_bdpt_walk_camera, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
+    hipLaunchKernelGGL(k_bdpt_walk_exit_camera, dim3(max(1u, grid_for(items))), dim3(kBlockSize), 0, stream, p, it, out_set);
+  } else {
+    hipLaunchKernelGGL(k_bdpt_walk_light, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
+    hipLaunchKernelGGL(k_bdpt_walk_exit_light, dim3(max(1u, grid_for(items))), dim3(kBlockSize), 0, stream, p, it, out_set);
+  }
 }
 void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
   hipLaunchKernelGGL(k_bdpt_connect_camera, dim3(max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 2ull, uint64_t(p.lv.capacity)))))), dim3(kBlockSize), 0, stream, p, it);
@@ -837,11 +1087,8 @@ void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const Vcm
 void launch_bdpt_camera_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
   hipLaunchKernelGGL(k_bdpt_camera_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
 }
-void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool subsurface) {
-  if (subsurface)
-    hipLaunchKernelGGL(k_bdpt_camera_shade<true>, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
-  else
-    hipLaunchKernelGGL(k_bdpt_camera_shade<false>, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
+void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
+  hipLaunchKernelGGL(k_bdpt_camera_shade, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
 }
 void launch_bdpt_connect_light(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
   hipLaunchKernelGGL(k_bdpt_connect_light, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it);

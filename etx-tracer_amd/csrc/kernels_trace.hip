@@ -17,6 +17,32 @@ namespace etxd {
 // thousand triangles fits completely (gems: 2 892 triangles), larger trees keep their top five levels in LDS.
 constexpr uint32_t kLdsNodes = 256;
 
+// Housekeeping of a wavefront round, done by one thread of the round's traversal kernel for the shade / connect kernels that follow:
+// the per-bounce queues start empty, the statistics of the bounce that just ended are folded, and the host's view of the wavefront
+// (host_api.cpp run_bounce_loop) gets its entry: (round tag + 1, active paths entering this round) in pinned host memory - the host
+// never drains the stream to learn that a pass has ended.
+ETX_DEV void round_housekeeping(uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t count, uint32_t pass_stat, unsigned long long* round_mirror, uint32_t round_tag) {
+  counters[kCntActiveA + kCntActiveB - active_counter] = 0u;
+  if (counters[kCntCameraVertices] != 0u)  // statistics: the connectible camera vertices of the bounce that just ended
+    atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatCameraVertices), (unsigned long long)counters[kCntCameraVertices]);
+  counters[kCntCameraVertices] = 0u;
+  counters[kCntPairs] = 0u;
+  counters[kCntShadow] = 0u;
+  counters[kCntMergeVertices] = 0u;
+  counters[kCntEndpoints] = 0u;
+  counters[kCntGroupGeneral] = 0u;
+  counters[kCntLightBounceBegin] = counters[kCntLightVertices];
+  counters[kCntGroupSubsurface] = 0u;
+  counters[kCntWalk] = 0u;
+  counters[kCntWalkFetch] = 0u;
+  counters[kCntWalkExit] = 0u;
+  atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
+  if (pass_stat != 0u)
+    atomicAdd(reinterpret_cast<unsigned long long*>(counters + pass_stat), (unsigned long long)count);
+  if (round_mirror != nullptr)
+    __hip_atomic_store(round_mirror + (round_tag & (kRoundMirrorSlots - 1u)), ((unsigned long long)(round_tag) + 1ull) << 32u | (unsigned long long)count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <bool kFromCounter, bool kFlat>
 __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
   float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit, uint32_t pass_stat) {
@@ -26,26 +52,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
   const DScene& scene = scene_arg;  // by value: kernarg (scalar) loads, table pointers known to be global
   const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
   if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
-    // housekeeping for the shade kernel that follows: its output counter and the camera vertex pool start empty
-    counters[kCntActiveA + kCntActiveB - active_counter] = 0u;
-    if (counters[kCntCameraVertices] != 0u)  // statistics: the connectible camera vertices of the bounce that just ended
-      atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatCameraVertices), (unsigned long long)counters[kCntCameraVertices]);
-    counters[kCntCameraVertices] = 0u;
-    counters[kCntPairs] = 0u;
-    counters[kCntShadow] = 0u;
-    counters[kCntMergeVertices] = 0u;
-    counters[kCntEndpoints] = 0u;
-    counters[kCntGroupGeneral] = 0u;
-    counters[kCntLightBounceBegin] = counters[kCntLightVertices];
-    counters[kCntGroupSubsurface] = 0u;
-    atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
-    if (pass_stat != 0u)
-      atomicAdd(reinterpret_cast<unsigned long long*>(counters + pass_stat), (unsigned long long)count);
-    // the host's view of the wavefront (host_api.cpp run_bounce_loop): (round tag + 1, active paths entering this round)
-    // in pinned host memory - the host never drains the stream to learn that a pass has ended
-    if (round_mirror != nullptr)
-      __hip_atomic_store(round_mirror + (round_tag & (kRoundMirrorSlots - 1u)), ((unsigned long long)(round_tag) + 1ull) << 32u | (unsigned long long)count, __ATOMIC_RELEASE,
-        __HIP_MEMORY_SCOPE_SYSTEM);
+    round_housekeeping(counters, active_counter, count, pass_stat, round_mirror, round_tag);
   }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -101,23 +108,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene s
   const DScene& scene = scene_arg;
   const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
   if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
-    counters[kCntActiveA + kCntActiveB - active_counter] = 0u;
-    if (counters[kCntCameraVertices] != 0u)  // statistics: the connectible camera vertices of the bounce that just ended
-      atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatCameraVertices), (unsigned long long)counters[kCntCameraVertices]);
-    counters[kCntCameraVertices] = 0u;
-    counters[kCntPairs] = 0u;
-    counters[kCntShadow] = 0u;
-    counters[kCntMergeVertices] = 0u;
-    counters[kCntEndpoints] = 0u;
-    counters[kCntGroupGeneral] = 0u;
-    counters[kCntLightBounceBegin] = counters[kCntLightVertices];
-    counters[kCntGroupSubsurface] = 0u;
-    atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
-    if (pass_stat != 0u)
-      atomicAdd(reinterpret_cast<unsigned long long*>(counters + pass_stat), (unsigned long long)count);
-    if (round_mirror != nullptr)
-      __hip_atomic_store(round_mirror + (round_tag & (kRoundMirrorSlots - 1u)), ((unsigned long long)(round_tag) + 1ull) << 32u | (unsigned long long)count, __ATOMIC_RELEASE,
-        __HIP_MEMORY_SCOPE_SYSTEM);
+    round_housekeeping(counters, active_counter, count, pass_stat, round_mirror, round_tag);
   }
   if (count == 0u)
     return;
@@ -246,23 +237,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_flat2(const DScene
   const DScene& scene = scene_arg;
   const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
   if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
-    counters[kCntActiveA + kCntActiveB - active_counter] = 0u;
-    if (counters[kCntCameraVertices] != 0u)  // statistics: the connectible camera vertices of the bounce that just ended
-      atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatCameraVertices), (unsigned long long)counters[kCntCameraVertices]);
-    counters[kCntCameraVertices] = 0u;
-    counters[kCntPairs] = 0u;
-    counters[kCntShadow] = 0u;
-    counters[kCntMergeVertices] = 0u;
-    counters[kCntEndpoints] = 0u;
-    counters[kCntGroupGeneral] = 0u;
-    counters[kCntLightBounceBegin] = counters[kCntLightVertices];
-    counters[kCntGroupSubsurface] = 0u;
-    atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
-    if (pass_stat != 0u)
-      atomicAdd(reinterpret_cast<unsigned long long*>(counters + pass_stat), (unsigned long long)count);
-    if (round_mirror != nullptr)
-      __hip_atomic_store(round_mirror + (round_tag & (kRoundMirrorSlots - 1u)), ((unsigned long long)(round_tag) + 1ull) << 32u | (unsigned long long)count, __ATOMIC_RELEASE,
-        __HIP_MEMORY_SCOPE_SYSTEM);
+    round_housekeeping(counters, active_counter, count, pass_stat, round_mirror, round_tag);
   }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6u;

@@ -1,4 +1,4 @@
-"""GPU (-m gpu): BASELINE.json configs[1] and configs[2] compared with the reference AT THEIR OWN SIZE (1920 x 1080).
+"""GPU (-m gpu): BASELINE.json configs[1] .. configs[4] compared with the reference AT THEIR OWN SIZE (1920 x 1080, 2048 x 2048).
 
 tests/golden/cornell_{full,gems}_1080p_vcm_<spp>_blocks.npz hold 8 x 8 block means of the reference's CPUVCM film of the
 bench snapshots (oracle/gen_golden_1080p.py: 64 / 8 iterations on the 256-thread host of the GPU box, vcm-blue_noise=false,
@@ -6,6 +6,11 @@ independent light / camera streams = ETX_ORACLE_DECORRELATE=2). The device rende
 snapshot; both films are reduced to 32 x 32-pixel block means (1024 pixels x spp samples per block) and compared:
   * per-channel relative difference of the image mean
   * relative difference per block, |device - reference| / (reference + 0.01): median and 95th percentile
+configs[3] (two random-walk subsurface blob meshes of 102 400 triangles, tools/synthetic_scenes.py sss_dragon, BDPTFull, 16 iterations) and
+configs[4] (the fog box with the procedural 256^3 density grid, BDPTFull, 2048 x 2048, 8 iterations) have films of CPUBidirectional in
+both flavours: re-keyed (ETX_ORACLE_DECORRELATE=2) and `_asis` = the unmodified reference; configs[1] has the as-is film next to the
+re-keyed one as well. The as-is comparisons carry the reference's own light / camera stream correlation (its size under
+different traversal orders is measured by tests/test_gpu_parity_hi.py), so their mean limits are wider.
 The limits are what the Monte-Carlo noise of the two films leaves at these sample counts (both films are noisy: 64 spp in
 the fog box, 8 spp in the spectral gems box); the estimator itself is pinned by the 4096-spp tests at 128 x 128.
 """
@@ -66,3 +71,47 @@ def test_config2_gems_1080p_matches_reference_at_size(etx, golden_dir, cie_obser
     assert int(golden["spp"]) == 8
     cam, light = render(etx, golden_dir, "gems", 8, cie_observer)
     compare(cam + light, golden["camera"] + golden["light"], "gems 1080p camera+light", 2.5e-2, 0.025, 0.09)  # measured at 8 spp: +1.0 % (blue), 1.5 %, 5.0 %
+
+
+def test_config1_full_1080p_matches_unmodified_reference_at_size(etx, golden_dir):
+    """the same render against the reference AS IS (shared light / camera streams)"""
+    golden = np.load(os.path.join(golden_dir, "cornell_full_1080p_vcm_64_blocks_asis.npz"))
+    assert int(golden["spp"]) == 64
+    cam, light = render(etx, golden_dir, "full", 64, None)
+    compare(cam + light, golden["camera"] + golden["light"], "full 1080p as is camera+light", 8.0e-3, 0.008, 0.02)
+
+
+def render_bdpt(etx, snap, spp):
+    snap.samples = spp
+    integ = etx.HIPBidirectional(snap)
+    integ.options()["bdpt-blue_noise"] = False
+    integ.options()["bdpt-mode"] = etx.api.BDPT_MODE_FULL
+    integ.render()
+    cam, light = integ.film(etx.api.LAYER_CAMERA), integ.film(etx.api.LAYER_LIGHT)
+    stats = integ.status()
+    integ.context.close()
+    assert stats.completed_iterations == spp and stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
+    assert np.isfinite(cam).all() and np.isfinite(light).all()
+    return cam[..., :3], light[..., :3]
+
+
+def test_config3_sssdragon_1080p_bdpt_matches_reference_at_size(etx, golden_dir):
+    from tools import synthetic_scenes
+    snap = synthetic_scenes.sss_dragon(etx, os.path.join(golden_dir, "cornell_sss_1080p.etxscene"))
+    assert snap.film_size == (1920, 1080) and snap.triangle_count >= 100000
+    cam, light = render_bdpt(etx, snap, 16)
+    for flavour, mean_limit in (("", 6.0e-3), ("_asis", 1.2e-2)):
+        golden = np.load(os.path.join(golden_dir, "cornell_sssdragon_1080p_bdpt3_16_blocks%s.npz" % flavour))
+        assert int(golden["spp"]) == 16
+        compare(cam + light, golden["camera"] + golden["light"], "sssdragon 1080p bdpt%s camera+light" % flavour, mean_limit, 0.02, 0.06)
+
+
+def test_config4_cloud_2048_bdpt_matches_reference_at_size(etx, golden_dir):
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_cloud_2048.etxscene"))
+    assert snap.film_size == (2048, 2048)
+    snap.inject_density(256)
+    cam, light = render_bdpt(etx, snap, 8)
+    for flavour, mean_limit in (("", 8.0e-3), ("_asis", 1.5e-2)):
+        golden = np.load(os.path.join(golden_dir, "cornell_cloud_2048_bdpt3_8_blocks%s.npz" % flavour))
+        assert int(golden["spp"]) == 8
+        compare(cam + light, golden["camera"] + golden["light"], "cloud 2048 bdpt%s camera+light" % flavour, mean_limit, 0.03, 0.08)
