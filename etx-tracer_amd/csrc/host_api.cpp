@@ -203,16 +203,16 @@ int allocate_pipeline(etx_hip_context* ctx) {
   }
   if ((rc = device_alloc(ctx, p.hits, n)))
     return rc;
-  p.walk = {}, p.walk_info = nullptr, p.walk_exit = {}, p.walk_exit_hits = nullptr;
-  if (ctx->scene.has_subsurface) {  // walk queue of the bidirectional integrator (k_bdpt_walk)
-    if ((rc = device_alloc(ctx, p.walk.ray_o_tmin, n)) || (rc = device_alloc(ctx, p.walk.ray_d_tmax, n)) || (rc = device_alloc(ctx, p.walk.thr_eta, n)) || (rc = device_alloc(ctx, p.walk.mis, n)) ||
-        (rc = device_alloc(ctx, p.walk.meta, n)) || (rc = device_alloc(ctx, p.walk.path_id, n)) || (rc = device_alloc(ctx, p.walk.wavelength, n)) || (rc = device_alloc(ctx, p.walk.prev_pos, n)) ||
-        (rc = device_alloc(ctx, p.walk.prev_nrm, n)) || (rc = device_alloc(ctx, p.walk_info, n)))
-      return rc;
-    PathSet& e = p.walk_exit;
-    if ((rc = device_alloc(ctx, e.ray_o_tmin, n)) || (rc = device_alloc(ctx, e.ray_d_tmax, n)) || (rc = device_alloc(ctx, e.thr_eta, n)) || (rc = device_alloc(ctx, e.mis, n)) ||
-        (rc = device_alloc(ctx, e.meta, n)) || (rc = device_alloc(ctx, e.path_id, n)) || (rc = device_alloc(ctx, e.wavelength, n)) || (rc = device_alloc(ctx, e.prev_pos, n)) ||
-        (rc = device_alloc(ctx, e.prev_nrm, n)) || (rc = device_alloc(ctx, p.walk_exit_hits, n)))
+  p.walk[0] = p.walk[1] = p.walk_exit = {}, p.walk_info[0] = p.walk_info[1] = nullptr, p.walk_exit_hits = nullptr;
+  if (ctx->scene.has_subsurface) {  // walk and exit queues of the bidirectional integrator (k_bdpt_walk_*)
+    PathSet* sets[3] = {&p.walk[0], &p.walk[1], &p.walk_exit};
+    for (PathSet* e : sets) {
+      if ((rc = device_alloc(ctx, e->ray_o_tmin, n)) || (rc = device_alloc(ctx, e->ray_d_tmax, n)) || (rc = device_alloc(ctx, e->thr_eta, n)) || (rc = device_alloc(ctx, e->mis, n)) ||
+          (rc = device_alloc(ctx, e->meta, n)) || (rc = device_alloc(ctx, e->path_id, n)) || (rc = device_alloc(ctx, e->wavelength, n)) || (rc = device_alloc(ctx, e->prev_pos, n)) ||
+          (rc = device_alloc(ctx, e->prev_nrm, n)))
+        return rc;
+    }
+    if ((rc = device_alloc(ctx, p.walk_info[0], n)) || (rc = device_alloc(ctx, p.walk_info[1], n)) || (rc = device_alloc(ctx, p.walk_exit_hits, n)))
       return rc;
   }
   // light vertex pool: the reference grows a std::vector (vcm_cpu.cxx:131-171); here a fixed pool sized for
@@ -613,7 +613,7 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
           ScopedTimer t(ctx, kTimerShadeLight);
           launch_bdpt_light_shade(s, p, it, set, max_items);
           if (ctx->scene.has_subsurface)
-            launch_bdpt_walk(s, p, it, false, set ^ 1u, max_items);
+            launch_bdpt_walk(s, p, it, false, set, max_items);
           if (to_camera)
             launch_bdpt_connect_camera(s, p, it, max_items);
         }
@@ -641,7 +641,7 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
           ScopedTimer t(ctx, kTimerShadeCamera);
           launch_bdpt_camera_shade(s, p, it, set, max_items);
           if (ctx->scene.has_subsurface)
-            launch_bdpt_walk(s, p, it, true, set ^ 1u, max_items);
+            launch_bdpt_walk(s, p, it, true, set, max_items);
           if (to_light)
             launch_bdpt_connect_light(s, p, it, max_items);
         }
@@ -1182,10 +1182,11 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
     // adaptive sampling: CPUPathTracing is the integrator that calls Film::estimate_noise_levels (path_tracing.cxx:99); CPUVCM and
     // CPUBidirectional never do, every pixel stays active for them whatever the threshold
     noise_threshold = context->scene.noise_threshold;
-    if ((noise_threshold > 0.0f) && (iteration_stride != 1u)) {
-      context->error = "path tracing with Scene::noise_threshold > 0 (adaptive sampling) on an iteration-sharded context: the convergence mask is per film, set noise_threshold = 0 for multi-GPU runs";
-      return ETX_HIP_ERROR_UNSUPPORTED;
-    }
+    // An iteration-sharded context (multi-GPU) holds a film of ITS iterations only, and the convergence mask is a property of the whole
+    // film: such a run samples every pixel in every iteration (a superset of what the adaptive render samples; the reference's default
+    // threshold is 0.1, so this is what every unedited scene gets on several GPUs)
+    if (iteration_stride != 1u)
+      noise_threshold = 0.0f;
   } else if (integrator == ETX_HIP_INTEGRATOR_BDPT) {
     if ((options == nullptr) || (options_size != sizeof(etx_abi_bdpt_options))) {
       context->error = "BDPT expects etx_abi_bdpt_options (16 bytes)";
@@ -1301,7 +1302,11 @@ int submit_iteration(etx_hip_context* context, bool wait) {
     context->error = "etx_hip_render_iteration after etx_hip_reduce_film: call etx_hip_begin again";
     return ETX_HIP_ERROR_STATE;
   }
-  const uint32_t lane_count = uint32_t(context->helpers.size()) + 1u;
+  // Adaptive sampling (path tracing with Scene::noise_threshold > 0): the convergence mask an iteration reads is the one the estimate
+  // after the previous iteration left (Film::estimate_noise_levels runs serially between iterations, path_tracing.cxx:91-99), so such a
+  // render uses ONE lane: iterations neither overlap nor race on the shared mask, and a render is the same every time it runs.
+  const bool serial = (context->integrator == ETX_HIP_INTEGRATOR_PT) && (context->noise_threshold > 0.0f);
+  const uint32_t lane_count = serial ? 1u : (uint32_t(context->helpers.size()) + 1u);
   etx_hip_context* lane = nullptr;
   {
     std::unique_lock<std::mutex> lock(context->shared_mutex);
@@ -1314,7 +1319,7 @@ int submit_iteration(etx_hip_context* context, bool wait) {
     if (context->jobs_in_flight >= lane_count)
       return 0;  // every lane is busy (try variant)
     lane = context->lane_busy ? nullptr : context;
-    for (size_t i = 0; (lane == nullptr) && (i < context->helpers.size()); ++i)
+    for (size_t i = 0; (serial == false) && (lane == nullptr) && (i < context->helpers.size()); ++i)
       lane = context->helpers[i]->lane_busy ? nullptr : context->helpers[i];
     if (lane == nullptr) {
       context->error = "internal: no free lane";

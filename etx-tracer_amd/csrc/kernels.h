@@ -46,7 +46,7 @@ void launch_camera_tail(hipStream_t stream, const Pipeline& p, const VcmParams& 
 // bidirectional path tracing (kernels_bdpt.hip)
 void launch_bdpt_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
 void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items);
-void launch_bdpt_walk(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool camera, uint32_t out_set, uint32_t max_items);  // subsurface walks of the round (walk queue -> out set)
+void launch_bdpt_walk(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool camera, uint32_t in_set, uint32_t max_items);  // subsurface walks of the round: walk queue in_set -> path set / walk queue in_set ^ 1
 void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items);
 void launch_bdpt_camera_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
 void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items);

@@ -361,11 +361,15 @@ ETX_DEV void bdpt_light_store(const Pipeline& p, BdptState& st, const BdptLightS
   }
 }
 
-ETX_DEV void bdpt_walk_push(const Pipeline& p, uint32_t slot, const BdptState& st, uint32_t prev_w, const BdptWalk& walk) {
+ETX_DEV void bdpt_walk_push(const Pipeline& p, uint32_t queue, uint32_t slot, const BdptState& st, uint32_t prev_w, const BdptWalk& walk) {
   if (slot >= p.capacity)
-    return;  // cannot happen: a path enters at most one object per bounce
-  bdpt_store(p.walk, slot, st, prev_w);
-  p.walk_info[slot] = make_uint2(walk.material, walk.medium);
+    return;  // cannot happen: every path is in one place (path set, walk queue or exit queue)
+  bdpt_store(p.walk[queue], slot, st, prev_w);
+  p.walk_info[queue][slot] = make_uint2(walk.material, walk.medium | (walk.events << 16u));
+}
+ETX_DEV BdptWalk bdpt_walk_info(const Pipeline& p, uint32_t queue, uint32_t entry) {
+  const uint2 info = p.walk_info[queue][entry];
+  return {info.x, info.y & 0xffffu, info.y >> 16u};
 }
 
 // One segment of an emitter path after the closest-hit query
@@ -399,10 +403,10 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
     const uint32_t slot = block_compact_slot(r.alive, out_counter, s_scratch);
     if (r.alive)
       bdpt_store(out, slot, st, (st.flags & kBpFirst) ? st.prev.tri : st.prev_slot);
-    if (p.walk_info != nullptr) {  // kernel-uniform: the scene has subsurface materials
-      const uint32_t walk_slot = block_compact_slot(r.walking, p.counters + kCntWalk, s_scratch);
+    if (p.walk_info[0] != nullptr) {  // kernel-uniform: the scene has subsurface materials
+      const uint32_t walk_slot = block_compact_slot(r.walking, p.counters + kCntWalk + 32u * in_set, s_scratch);
       if (r.walking)
-        bdpt_walk_push(p, walk_slot, st, st.prev_slot, walk);
+        bdpt_walk_push(p, in_set, walk_slot, st, st.prev_slot, walk);
     }
   }
 }
@@ -411,6 +415,11 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
 // a lane runs the sub-steps of ITS walk; whenever kWalkRefill lanes of a wavefront are idle they take the next entries of the queue.
 constexpr uint32_t kWalkRefill = 16u;
 constexpr uint32_t kWalkBlocks = 1024u;
+// Scattering events a walk gets per round. Most walks leave their object after a few events, a few take hundreds (the reference
+// allows 1024, :776): a kernel that ran every walk of a bounce to its end lasted as long as its longest walk (measured 7 ms per
+// launch, 100 ms per iteration, with nearly all lanes idle). A walk that is still inside after its budget goes to the other walk
+// queue and continues in the next round, next to that round's new walks.
+constexpr uint32_t kWalkBudget = 32u;
 
 // Taking the next entries of the walk queue: called by all lanes of a wavefront; lanes without a walk get one while the queue lasts.
 // Returns false when the wavefront has nothing left to do.
@@ -432,11 +441,11 @@ ETX_DEV bool walk_refill(const Pipeline& p, uint32_t count, bool& active, bool& 
 }
 
 // The scattering events of the walks of this bounce, emitter paths: walk queue -> (medium vertices in the light vertex pool) -> exit queue
-__global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_light(Pipeline p, VcmParams it) {
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_light(Pipeline p, VcmParams it, uint32_t queue) {
   __shared__ int32_t s_stack[kStackDepth * kBlockSize];
   const LaneStack stack = lane_stack(p.scene, s_stack + threadIdx.x, kBlockSize);
   const DScene& scene = p.scene;
-  const uint32_t count = min(p.counters[kCntWalk], p.capacity);
+  const uint32_t count = min(p.counters[kCntWalk + 32u * queue], p.capacity);
   if (count == 0u)
     return;
   const uint32_t mode = bdpt_mode(it);
@@ -445,12 +454,12 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_light(Pipeline p, VcmP
   BdptWalk walk = {kInvalid, kInvalid, 0u};
   WaveChunk chunk = {0u, 0u};
   bool active = false, exhausted = false;
-  uint32_t entry = kInvalid;
+  uint32_t entry = kInvalid, budget = 0u;
   while (walk_refill(p, count, active, exhausted, entry)) {
     if (entry != kInvalid) {
-      st = bdpt_load(p.walk, entry);
-      const uint2 info = p.walk_info[entry];
-      walk = {info.x, info.y, 0u};
+      st = bdpt_load(p.walk[queue], entry);
+      walk = bdpt_walk_info(p, queue, entry);
+      budget = kWalkBudget;
       active = true;
     }
     BdptLightStep r = {};
@@ -465,6 +474,13 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_light(Pipeline p, VcmP
       p.walk_exit_hits[exit_slot] = h;
     }
     active = active && r.walking;
+    // out of budget: the walk continues in the next round
+    budget -= active ? 1u : 0u;
+    const bool later = active && (budget == 0u);
+    const uint32_t later_slot = wave_compact_slot(later, p.counters + kCntWalk + 32u * (queue ^ 1u));
+    if (later)
+      bdpt_walk_push(p, queue ^ 1u, later_slot, st, st.prev_slot, walk);
+    active = active && (later == false);
   }
   // the unused rest of this wavefront's last chunk: records nobody may connect to
   for (uint32_t i = chunk.next + lane; i < min(chunk.end, p.lv.capacity); i += 64u) {
@@ -607,8 +623,10 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_generate(Pipeline p,
     st.prev = {r.o, scene.camera.direction, 1.0f, 0.0f, kBvConnectible | kBvMisConnectible, kInvalid};
     bdpt_store(p.paths[0], i, st, kInvalid);
   }
-  if ((blockIdx.x == 0) && (threadIdx.x == 0))
+  if ((blockIdx.x == 0) && (threadIdx.x == 0)) {
     p.counters[kCntActiveA] = it.path_count;
+    p.counters[kCntWalk] = p.counters[kCntWalk + 32u] = 0u;  // the light pass has drained its walk queues; their last counts are stale
+  }
 }
 
 // mis_weight_direct_hit, bidirectional.cxx:1211-1233
@@ -873,21 +891,21 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
     const uint32_t slot = block_compact_slot(next == 1u, out_counter, s_scratch);
     if (next == 1u)
       bdpt_store(out, slot, st, st.prev.tri);
-    if (p.walk_info != nullptr) {  // kernel-uniform: the scene has subsurface materials
-      const uint32_t walk_slot = block_compact_slot(next == 2u, p.counters + kCntWalk, s_scratch);
+    if (p.walk_info[0] != nullptr) {  // kernel-uniform: the scene has subsurface materials
+      const uint32_t walk_slot = block_compact_slot(next == 2u, p.counters + kCntWalk + 32u * in_set, s_scratch);
       if (next == 2u)
-        bdpt_walk_push(p, walk_slot, st, st.prev.tri, walk);
+        bdpt_walk_push(p, in_set, walk_slot, st, st.prev.tri, walk);
     }
   }
 }
 
 // The scattering events of the walks of this bounce, camera paths: walk queue -> exit queue (only the exit vertex of a walk is
 // connectible, :811: the events leave nothing but the path's running MIS history behind)
-__global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_camera(Pipeline p, VcmParams it) {
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_camera(Pipeline p, VcmParams it, uint32_t queue) {
   __shared__ int32_t s_stack[kStackDepth * kBlockSize];
   const LaneStack stack = lane_stack(p.scene, s_stack + threadIdx.x, kBlockSize);
   const DScene& scene = p.scene;
-  const uint32_t count = min(p.counters[kCntWalk], p.capacity);
+  const uint32_t count = min(p.counters[kCntWalk + 32u * queue], p.capacity);
   if (count == 0u)
     return;
   const uint32_t mode = bdpt_mode(it);
@@ -895,13 +913,13 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_camera(Pipeline p, Vcm
   BdptState st = {};
   BdptWalk walk = {kInvalid, kInvalid, 0u};
   bool active = false, exhausted = false;
-  uint32_t entry = kInvalid;
+  uint32_t entry = kInvalid, budget = 0u;
   while (walk_refill(p, count, active, exhausted, entry)) {
     if (entry != kInvalid) {
-      st = bdpt_load(p.walk, entry);
+      st = bdpt_load(p.walk[queue], entry);
       st.prev.tri = st.prev_slot;
-      const uint2 info = p.walk_info[entry];
-      walk = {info.x, info.y, 0u};
+      walk = bdpt_walk_info(p, queue, entry);
+      budget = kWalkBudget;
       active = true;
     }
     BdptCameraStep r = {};
@@ -917,6 +935,12 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_camera(Pipeline p, Vcm
       p.walk_exit_hits[exit_slot] = h;
     }
     active = next == 2u;
+    budget -= active ? 1u : 0u;
+    const bool later = active && (budget == 0u);  // out of budget: the walk continues in the next round
+    const uint32_t later_slot = wave_compact_slot(later, p.counters + kCntWalk + 32u * (queue ^ 1u));
+    if (later)
+      bdpt_walk_push(p, queue ^ 1u, later_slot, st, st.prev.tri, walk);
+    active = active && (later == false);
   }
 }
 
@@ -1070,15 +1094,15 @@ void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmPar
 }
 // the walks of the paths the shade kernel of this round put on the walk queue: the scattering events in persistent wavefronts (at most
 // kWalkBlocks workgroups: 32 KB of traversal stack each), then the exit vertices as a dense kernel
-void launch_bdpt_walk(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool camera, uint32_t out_set, uint32_t max_items) {
+void launch_bdpt_walk(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool camera, uint32_t in_set, uint32_t max_items) {
   const uint32_t items = min(p.capacity, max_items);
   const uint32_t blocks = max(1u, min(kWalkBlocks, (items + kBlockSize - 1u) / kBlockSize));
   if (camera) {
-    hipLaunchKernelGGL(k_bdpt_walk_camera, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
-    hipLaunchKernelGGL(k_bdpt_walk_exit_camera, dim3(max(1u, grid_for(items))), dim3(kBlockSize), 0, stream, p, it, out_set);
+    hipLaunchKernelGGL(k_bdpt_walk_camera, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
+    hipLaunchKernelGGL(k_bdpt_walk_exit_camera, dim3(max(1u, grid_for(items))), dim3(kBlockSize), 0, stream, p, it, in_set ^ 1u);
   } else {
-    hipLaunchKernelGGL(k_bdpt_walk_light, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
-    hipLaunchKernelGGL(k_bdpt_walk_exit_light, dim3(max(1u, grid_for(items))), dim3(kBlockSize), 0, stream, p, it, out_set);
+    hipLaunchKernelGGL(k_bdpt_walk_light, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
+    hipLaunchKernelGGL(k_bdpt_walk_exit_light, dim3(max(1u, grid_for(items))), dim3(kBlockSize), 0, stream, p, it, in_set ^ 1u);
   }
 }
 void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {

@@ -19,7 +19,7 @@ constexpr uint32_t kLdsNodes = 256;
 
 // Housekeeping of a wavefront round, done by one thread of the round's traversal kernel for the shade / connect kernels that follow:
 // the per-bounce queues start empty, the statistics of the bounce that just ended are folded, and the host's view of the wavefront
-// (host_api.cpp run_bounce_loop) gets its entry: (round tag + 1, active paths entering this round) in pinned host memory - the host
+// (host_api.cpp run_bounce_loop) gets its entry: (round tag + 1, live paths entering this round) in pinned host memory - the host
 // never drains the stream to learn that a pass has ended.
 ETX_DEV void round_housekeeping(uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t count, uint32_t pass_stat, unsigned long long* round_mirror, uint32_t round_tag) {
   counters[kCntActiveA + kCntActiveB - active_counter] = 0u;
@@ -33,14 +33,19 @@ ETX_DEV void round_housekeeping(uint32_t* __restrict__ counters, uint32_t active
   counters[kCntGroupGeneral] = 0u;
   counters[kCntLightBounceBegin] = counters[kCntLightVertices];
   counters[kCntGroupSubsurface] = 0u;
-  counters[kCntWalk] = 0u;
+  // subsurface walks of the bidirectional integrator (kernels_bdpt.hip): this round works on walk queue `set` (what the last round left
+  // unfinished + what this round's shade kernel adds) and fills queue `set ^ 1`; walks in flight count as live paths for the host
+  const uint32_t set = (active_counter == kCntActiveA) ? 0u : 1u;
+  const uint32_t walking = counters[kCntWalk + 32u * set];
+  counters[kCntWalk + 32u * (set ^ 1u)] = 0u;
   counters[kCntWalkFetch] = 0u;
   counters[kCntWalkExit] = 0u;
   atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatRaysExtension), (unsigned long long)count);
   if (pass_stat != 0u)
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + pass_stat), (unsigned long long)count);
   if (round_mirror != nullptr)
-    __hip_atomic_store(round_mirror + (round_tag & (kRoundMirrorSlots - 1u)), ((unsigned long long)(round_tag) + 1ull) << 32u | (unsigned long long)count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(round_mirror + (round_tag & (kRoundMirrorSlots - 1u)), ((unsigned long long)(round_tag) + 1ull) << 32u | (unsigned long long)(count + walking), __ATOMIC_RELEASE,
+      __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <bool kFromCounter, bool kFlat>

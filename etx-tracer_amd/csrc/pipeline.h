@@ -150,10 +150,12 @@ enum : uint32_t {
   kStatPairs = 736,
   kStatEndpoints = 768,       // film contributions dropped because they were not finite (never cleared within a run: reported by etx_hip_stats)
   kStatActivePixels = 832,  // u64: pixels sampled (path tracing with adaptive sampling: Film::active_pixel)
-  kCntWalk = 864,            // BDPT: paths that entered a subsurface object in the current bounce (walk queue, k_bdpt_walk), cleared per bounce
-  kCntWalkFetch = 896,       // ... and how many of them the walk kernel's wavefronts have taken
-  kCntWalkExit = 928,        // ... and the walks that have reached their object's surface (exit queue, k_bdpt_walk_exit), cleared per bounce
-  kCounterCount = 960,
+  kCntWalk = 864,            // BDPT: entries of walk queue 0 / 1 (+ 32): paths inside a subsurface object. The round whose input path set is s takes
+                             // its walks from queue s (new ones of this bounce + the unfinished ones of the previous round) and leaves the walks
+                             // that are still unfinished after kWalkBudget events in queue s ^ 1
+  kCntWalkFetch = 928,       // ... and how many entries the walk kernel's wavefronts have taken in this round
+  kCntWalkExit = 960,        // ... and the walks that have reached their object's surface (exit queue, k_bdpt_walk_exit), cleared per bounce
+  kCounterCount = 992,
 };
 
 // Per-workgroup statistics (u64): workgroup b of any launch adds to row b without atomics (launches on one stream do
@@ -198,9 +200,9 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   DScene scene;          // by value: travels in the kernel argument segment, so its fields are scalar loads and its
                          // table pointers are known global pointers (not flat) to the compiler
   PathSet paths[2];
-  PathSet walk;          // BDPT walk queue: the state of the paths that entered a subsurface object in the current bounce (k_bdpt_walk
-                         // takes them from here and writes them to the "out" set when they have left the object); null without such materials
-  uint2* walk_info;      // ... their object: (material, DScene::material_sss_medium of it)
+  PathSet walk[2];       // BDPT walk queues (kCntWalk): the state of the paths that are inside a subsurface object (k_bdpt_walk_* take them from
+                         // here; a path joins the "out" set again when it has left the object); null without such materials
+  uint2* walk_info[2];   // ... their object: (material, DScene::material_sss_medium of it | events of the walk so far << 16)
   PathSet walk_exit;     // BDPT exit queue: walks whose free flight reached the surface of their object, with that hit
   float4* walk_exit_hits;
   float4* hits;          // hit queue, aligned with the "in" path set

@@ -47,7 +47,7 @@ enum {
   ETX_HIP_INTEGRATOR_PT = 0,   /* CPUPathTracing  sources/etx/rt/integrators/path_tracing.cxx:50-110, options = etx_abi_pt_options */
   ETX_HIP_INTEGRATOR_VCM = 1,  /* CPUVCM          sources/etx/rt/integrators/vcm_cpu.cxx:95-241,     options = etx_abi_vcm_options */
   ETX_HIP_INTEGRATOR_BDPT = 2  /* CPUBidirectional sources/etx/rt/integrators/bidirectional.cxx:342-403, options = etx_abi_bdpt_options
-                                  (all four modes; scenes with random-walk subsurface materials: ETX_HIP_ERROR_UNSUPPORTED) */
+                                  (all four modes, random-walk subsurface materials included: their walks run as their own kernels) */
 };
 
 /* film layers, subset of etx::Film layer ids (sources/etx/render/host/film.hxx:14-27) that the MC loop produces */
@@ -142,7 +142,11 @@ int etx_hip_upload_rgb_response(etx_hip_context* context, const float* rgb, uint
  * `options`: etx_abi_vcm_options, etx_abi_pt_options or etx_abi_bdpt_options (by integrator). Scene scalars (samples, min/max path length,
  * random_path_termination, radiance_clamp) come from the uploaded scene.
  * This context renders iterations first_iteration, first_iteration + iteration_stride, ... (multi-GPU sharding by
- * iteration; single GPU: 0, 1). */
+ * iteration; single GPU: 0, 1).
+ * Path tracing with Scene::noise_threshold > 0 (adaptive sampling, Film::estimate_noise_levels): iterations run one after the other
+ * on ONE device lane, each reading the convergence mask its predecessor left (as the reference does, path_tracing.cxx:91-99), so the
+ * render is reproducible; on an iteration-sharded context (iteration_stride != 1) the mask would be a property of a film no rank
+ * holds, and every pixel is sampled in every iteration instead (noise_threshold treated as 0). */
 int etx_hip_begin(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride);
 
 /* Hands one full iteration (VCM: light pass, grid build, camera pass; PT: one sample per pixel) to a free device lane and

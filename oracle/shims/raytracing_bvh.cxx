@@ -273,13 +273,15 @@ struct RaytracingImpl {
   bool count_rays = false;
   bool decorrelate = false;  // diagnostic only, see Raytracing::trace
   bool rekey_camera = false; // ETX_ORACLE_DECORRELATE=2, see Raytracing::trace
+  bool rekey_second = false; // ETX_ORACLE_DECORRELATE=3, see Raytracing::trace
 
   RaytracingImpl()
     : film(scheduler) {
     count_rays = getenv("ETX_ORACLE_COUNT_RAYS") != nullptr;
     const char* mode = getenv("ETX_ORACLE_DECORRELATE");
-    decorrelate = (mode != nullptr) && (atoi(mode) != 2);
+    decorrelate = (mode != nullptr) && (atoi(mode) == 1);
     rekey_camera = (mode != nullptr) && (atoi(mode) == 2);
+    rekey_second = (mode != nullptr) && (atoi(mode) == 3);
   }
 
   ~RaytracingImpl() {
@@ -356,6 +358,21 @@ bool Raytracing::trace(const Scene& scene, const Ray& r, Intersection& result_in
     // above merely shifts the shared stream: light and camera path of a pixel still consume the SAME numbers in different
     // roles, which is not independence.
     smp.seed = Sampler::random_seed(smp.seed, 0x43414d45u);
+  }
+  if (_private->rekey_second && (_private->source_camera != nullptr) && (_private->source_camera->lens_radius == 0.0f)) {
+    // DIAGNOSTIC (ETX_ORACLE_DECORRELATE=3): the camera path keeps the shared stream through its FIRST vertex (primary ray, its
+    // candidate draws, the six random numbers of that vertex, its connections) and draws from a stream of its own from its second
+    // segment on. Tells how much of the correlation of the unmodified reference sits in the first camera vertex - the part a
+    // wavefront device could reproduce without serialising its shadow rays (the later alignment of the two streams depends on the
+    // candidate draws of every connection ray).
+    static thread_local const Sampler* camera_sampler = nullptr;
+    const bool primary = (r.o.x == _private->source_camera->position.x) && (r.o.y == _private->source_camera->position.y) && (r.o.z == _private->source_camera->position.z);
+    if (primary) {
+      camera_sampler = &smp;
+    } else if (camera_sampler == &smp) {
+      smp.seed = Sampler::random_seed(smp.seed, 0x43414d45u);
+      camera_sampler = nullptr;
+    }
   }
   IntersectionBase found = {{}, kInvalidIndex, 0.0f};
   _private->bvh->intersect(r, [&](uint32_t triangle_index, float u, float v, float t) {

@@ -102,7 +102,7 @@ def test_config3_sssdragon_1080p_bdpt_matches_reference_at_size(etx, golden_dir)
     cam, light = render_bdpt(etx, snap, 16)
     for flavour, mean_limit in (("", 6.0e-3), ("_asis", 1.2e-2)):
         golden = np.load(os.path.join(golden_dir, "cornell_sssdragon_1080p_bdpt3_16_blocks%s.npz" % flavour))
-        assert int(golden["spp"]) == 16
+        assert int(golden["spp"]) in (15, 16)  # CPUBidirectional::update does not count its last iteration (bidirectional.cxx:1526-1531)
         compare(cam + light, golden["camera"] + golden["light"], "sssdragon 1080p bdpt%s camera+light" % flavour, mean_limit, 0.02, 0.06)
 
 
@@ -113,5 +113,5 @@ def test_config4_cloud_2048_bdpt_matches_reference_at_size(etx, golden_dir):
     cam, light = render_bdpt(etx, snap, 8)
     for flavour, mean_limit in (("", 8.0e-3), ("_asis", 1.5e-2)):
         golden = np.load(os.path.join(golden_dir, "cornell_cloud_2048_bdpt3_8_blocks%s.npz" % flavour))
-        assert int(golden["spp"]) == 8
+        assert int(golden["spp"]) in (7, 8)
         compare(cam + light, golden["camera"] + golden["light"], "cloud 2048 bdpt%s camera+light" % flavour, mean_limit, 0.03, 0.08)
