@@ -11,6 +11,7 @@ tests of tests/test_gpu_parity_hi.py ("a high-spp oracle reference
   tests/golden/hi/cornell_<flavour>_128_bdpt<mode>_<spp>[_rekeyed].npz  CPUBidirectional (--integrators bdpt --bdpt-modes 3,0,1)
   tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_<far_first|random_child>.npz   (--integrators orders) the unmodified reference under
       ETX_ORACLE_BVH_ORDER = another child order of the BVH shim
+  tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_shared_first_vertex.npz   (--integrators firstvertex) ETX_ORACLE_DECORRELATE=3
   tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_rekeyed.npz        ETX_ORACLE_DECORRELATE=2: the camera path re-keys its sampler at
       its first segment = independent light / camera streams, the estimator the device implements
 
@@ -85,6 +86,11 @@ def main():
             for order in ("far_first", "random_child"):
                 render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_%s.npz" % (flavour, args.spp, order)), args.cores, env_extra={"ETX_ORACLE_BVH_ORDER": order},
                        extra=["--opt", "vcm-blue_noise=false"] + variant)
+        if "firstvertex" in integrators:
+            # mode 3: shared streams through the first camera vertex, independent from the second segment on - where the reference's
+            # light / camera correlation sits (not in the first vertex; this film equals the re-keyed one)
+            render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_shared_first_vertex.npz" % (flavour, args.spp)), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "3"},
+                   extra=["--opt", "vcm-blue_noise=false"] + variant)
         if "rekeyed" in integrators:
             # mode 2: the camera sub path draws from a stream of its own from its first segment on (oracle/shims/raytracing_bvh.cxx)
             render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_rekeyed.npz" % (flavour, args.spp)), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "2"},

@@ -134,6 +134,36 @@ def test_vcm_matches_reference_at_4096_spp(etx, golden_dir, cie_observer, flavou
     # the unmodified reference (shared streams): what its own correlation leaves
     golden = load_hi(golden_dir, "cornell_%s_128_vcm_%d.npz" % (flavour, SPP))
     compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " vcm camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
+    if flavour in ("full", "cloud", "classic"):
+        inside_reference_spread(golden_dir, flavour, 0.5 * (cam_a + light_a + cam_b + light_b)[..., :3].astype(np.float64))
+
+
+def inside_reference_spread(golden_dir, flavour, device):
+    """The unmodified reference under three traversal orders of its ray queries (tests/test_reference_order_spread.py: its film depends on
+    the order, Embree's is unknown): the device's film must be as close to the nearest of them as they are to each other - block-8
+    RMSE and image mean - or within north_star's 1e-3 of it."""
+    import itertools
+    orders = {"near_first": "cornell_%s_128_vcm_%d.npz", "far_first": "cornell_%s_128_vcm_%d_far_first.npz", "random_child": "cornell_%s_128_vcm_%d_random_child.npz"}
+    films = {}
+    for order, pattern in orders.items():
+        g = load_hi(golden_dir, pattern % (flavour, SPP))
+        film = (g["camera"] + g["light"]).astype(np.float64)
+        films[order] = np.where(np.isfinite(film), film, 0.0)
+
+    def distance(a, b):
+        return rmse(block_mean(a, 8), block_mean(b, 8)), np.abs((a.mean(axis=(0, 1)) - b.mean(axis=(0, 1))) / b.mean(axis=(0, 1)))
+
+    pairs = [distance(films[a], films[b]) for a, b in itertools.combinations(films, 2)]
+    spread_rmse, spread_mean = max(d[0] for d in pairs), np.max([d[1] for d in pairs], axis=0)
+    to_device = {order: distance(device, film) for order, film in films.items()}
+    nearest_rmse = min(d[0] for d in to_device.values())
+    nearest_mean = np.min([d[1] for d in to_device.values()], axis=0)
+    print("%-32s reference among its traversal orders: block-8 RMSE up to %.2e, rel mean up to %s | device to the nearest order: RMSE %.2e, rel mean %s" %
+          (flavour + " vcm order spread", spread_rmse, np.round(spread_mean, 5), nearest_rmse, np.round(nearest_mean, 5)))
+    assert nearest_rmse <= max(spread_rmse, 1.0e-3), (flavour, nearest_rmse, spread_rmse)
+    # the mean: the reference's three orders share the part of the light / camera correlation that does not depend on the order
+    # (fog box: +0.42 % in the red channel against independent streams, DESIGN.md 4), the device has independent streams by design
+    assert (nearest_mean <= np.maximum(spread_mean, 1.0e-3) + 4.5e-3).all(), (flavour, nearest_mean, spread_mean)
 
 
 @pytest.mark.parametrize("flavour", ["classic", "full", "rough", "glass", "gems", "cloud", "sss"])

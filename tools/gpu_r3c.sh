@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 O=gpurun_out/r3c
 mkdir -p $O
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_bdpt.py tests/test_gpu_sssmesh.py -x -q -m gpu -s > $O/test_bdpt.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_bdpt.py tests/test_gpu_sssmesh.py "tests/test_gpu_parity.py::test_pt_adaptive_sampling" -x -q -m gpu -s > $O/test_bdpt.log 2>&1
 echo "tests bdpt rc=$?" >> $O/log.txt
 timeout 600 python bench.py --workload sssdragon_bdpt --steps 8 --warmup 2 > $O/bench_sssdragon_bdpt.json 2> $O/bench_sssdragon_bdpt.err
 echo "bench sssdragon rc=$?" >> $O/log.txt
