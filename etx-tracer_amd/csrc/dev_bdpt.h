@@ -34,6 +34,7 @@ enum : uint32_t {
   kBvEmitter = 1u << 4,         // Class::Emitter
   kBvScatterMaterial = 1u << 6,     // entry / exit vertex of a subsurface walk: its BSDF is scene.subsurface_scatter_material (handle_surface :612, build_path :859)
   kBvNoCameraConnection = 1u << 5,  // light path medium vertex of a medium without explicit connections: handle_medium skips connect() (:567-569)
+  kBvGeneralBsdf = 1u << 7,         // the vertex' material is not of the simple shading group (dev_scene.h): its connections run in the general-BSDF kernels
 };
 
 // path flags (meta.w)
@@ -130,6 +131,7 @@ struct BFull {
 };
 
 // PathVertex::pdf_area, bidirectional.cxx:102-128: pdf of going prev -> curr -> next, measured as area density at next
+template <bool kSimple>
 ETX_DEV float bdpt_pdf_area(const DScene& scene, uint32_t source, const f3& prev_pos, const BFull& curr, const BVtx& next, float wavelength, Sampler& smp) {
   f3 w_i = curr.isect.pos - prev_pos;
   float len = dot(w_i, w_i);
@@ -146,7 +148,7 @@ ETX_DEV float bdpt_pdf_area(const DScene& scene, uint32_t source, const f3& prev
     eval_pdf = phase_function(w_i, w_o, curr.g);
   } else {
     const BsdfData data = make_bsdf_data(curr.isect, w_i, kInvalid, source, wavelength);
-    eval_pdf = bsdf_pdf_s<false>(scene, data, w_o, scene.materials[curr.isect.material], smp);
+    eval_pdf = bsdf_pdf_s<kSimple>(scene, data, w_o, scene.materials[curr.isect.material], smp);
   }
   return bdpt_to_area(eval_pdf, curr.isect.pos, next);
 }
@@ -156,13 +158,14 @@ struct BdptBsdf {
   f3 bsdf;
   float pdf;
 };
+template <bool kSimple>
 ETX_DEV BdptBsdf bdpt_bsdf(const DScene& scene, const BFull& v, uint32_t source, const f3& w_o, float wavelength, Sampler& smp) {
   if (v.at_medium) {
     const float p = phase_function(v.isect.w_i, w_o, v.g);
     return {mk3(p), p};
   }
   const BsdfData data = make_bsdf_data(v.isect, v.isect.w_i, kInvalid, source, wavelength);
-  BsdfEval e = bsdf_evaluate_s<false>(scene, data, w_o, scene.materials[v.isect.material], smp);
+  BsdfEval e = bsdf_evaluate_s<kSimple>(scene, data, w_o, scene.materials[v.isect.material], smp);
   if (source == kPathLight)
     e.bsdf = e.bsdf * fix_shading_normal(ld3(scene.triangles[v.isect.tri].geo_n), v.isect.nrm, v.isect.w_i, w_o);
   return {e.bsdf, e.pdf};
@@ -305,14 +308,14 @@ ETX_DEV BdptLightVertex bdpt_load_light_vertex(const Pipeline& p, const DScene& 
 
 // Camera vertex record (CameraVertexPool): the connectible vertex z_curr with what its connections read of z_prev.
 ETX_DEV void bdpt_store_camera_vertex(const Pipeline& p, uint32_t idx, const BdptState& st, const float4& hit_or_pos, const f3& w_i, uint32_t vertex_medium, const f3& throughput, float from_prev,
-  const f3& rnd_fixed, uint32_t seed, bool scatter_material = false) {
+  const f3& rnd_fixed, uint32_t seed, bool scatter_material, bool general_bsdf) {
   if (idx >= p.cv_capacity) {
     atomicOr(p.counters + kCntOverflow, kOverflowCameraVertices);
     return;
   }
   p.cv.hit[idx] = hit_or_pos;
   p.cv.wi_medium[idx] = mk4(w_i, __uint_as_float(vertex_medium));
-  p.cv.thr_depth[idx] = mk4(throughput, __uint_as_float(st.path_size | (scatter_material ? kCvExitMaterialBit : 0u)));  // entry / exit vertex of a subsurface walk
+  p.cv.thr_depth[idx] = mk4(throughput, __uint_as_float(st.path_size | (scatter_material ? kCvExitMaterialBit : 0u) | (general_bsdf ? kCvGeneralBsdfBit : 0u)));  // entry / exit vertex of a subsurface walk
   p.cv.mis_pixel[idx] = make_float4(from_prev, st.prev.from_prev, st.prev.history, __uint_as_float(st.id));
   p.cv.seed[idx] = seed;
   p.cv.wavelength[idx] = st.wavelength;
@@ -332,7 +335,7 @@ struct BdptCameraVertex {
 ETX_DEV BdptCameraVertex bdpt_load_camera_vertex(const Pipeline& p, const DScene& scene, uint32_t i) {
   const float4 h = p.cv.hit[i], w = p.cv.wi_medium[i], t = p.cv.thr_depth[i], m = p.cv.mis_pixel[i], pp = p.cv.pos_info[i], pn = p.cv.nrm_dvm[i], r = p.cv.fthr_dvcm[i];
   BdptCameraVertex v;
-  v.throughput = {t.x, t.y, t.z}, v.path_size = __float_as_uint(t.w) & ~kCvExitMaterialBit;
+  v.throughput = {t.x, t.y, t.z}, v.path_size = __float_as_uint(t.w) & ~(kCvExitMaterialBit | kCvGeneralBsdfBit);
   v.from_prev = m.x;
   v.prev = {{pp.x, pp.y, pp.z}, {pn.x, pn.y, pn.z}, m.y, m.z, __float_as_uint(pp.w), __float_as_uint(pn.w)};
   v.pixel = __float_as_uint(m.w);

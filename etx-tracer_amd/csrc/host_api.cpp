@@ -105,6 +105,7 @@ struct etx_hip_context {
   size_t read_pixels = 0;
   bool read_pending = false;
   void* comm = nullptr;  // ncclComm_t (host_comm.cpp)
+  void* comm_scratch = nullptr;  // device words of the film reduce, allocated with the communicator
   int rank = 0, world = 1;
 
   // Asynchronous execution. A context is a set of LANES: the public context itself plus helper contexts, each with its
@@ -391,9 +392,13 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
     set ^= 1u;
     rounds++;
     // wait until the device is at most `run_ahead` rounds behind what has been enqueued
+    // (a few hundred polls cover the rounds of a busy pass; after that the thread sleeps between polls instead of keeping a host core
+    // at 100 % per lane, and asks the stream for errors about once per millisecond)
     uint32_t spins = 0;
     for (poll(tag + 1u); (tag + 1u) - newest_seen > run_ahead; poll(tag + 1u)) {
-      if ((++spins & 1023u) == 0u) {
+      spins += 1u;
+      const bool dozing = spins > 256u;
+      if (dozing ? (((spins - 256u) & 31u) == 0u) : ((spins & 127u) == 0u)) {
         const hipError_t q = hipStreamQuery(ctx->stream);
         if ((q != hipSuccess) && (q != hipErrorNotReady)) {
           ctx->error = std::string("wavefront loop: ") + hipGetErrorString(q);
@@ -407,7 +412,10 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
           }
         }
       }
-      std::this_thread::yield();
+      if (dozing)
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+      else
+        std::this_thread::yield();
     }
     if (newest_seen == first_tag)
       continue;  // nothing known yet
@@ -595,6 +603,7 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
   p.light_sum = ctx->pt_iteration_image + p.capacity;
   hipStream_t s = ctx->stream;
   const bool flat = ctx->scene.host_copy.bvh_flat != 0u;
+  const bool simple = ctx->scene.simple_materials;  // the BSDF instantiations of the bidirectional kernels (kernels_bdpt.hip)
   uint64_t rounds = 0;
   int rc = 0;
 
@@ -611,11 +620,11 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
       [&](uint32_t set, uint32_t max_items) {
         {
           ScopedTimer t(ctx, kTimerShadeLight);
-          launch_bdpt_light_shade(s, p, it, set, max_items);
+          launch_bdpt_light_shade(s, p, it, set, max_items, simple);
           if (ctx->scene.has_subsurface)
-            launch_bdpt_walk(s, p, it, false, set, max_items);
+            launch_bdpt_walk(s, p, it, false, set, max_items, simple);
           if (to_camera)
-            launch_bdpt_connect_camera(s, p, it, max_items);
+            launch_bdpt_connect_camera(s, p, it, max_items, simple);
         }
         if (to_camera) {
           ScopedTimer t(ctx, kTimerTraceShadow);
@@ -639,16 +648,16 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
       [&](uint32_t set, uint32_t max_items) {
         {
           ScopedTimer t(ctx, kTimerShadeCamera);
-          launch_bdpt_camera_shade(s, p, it, set, max_items);
+          launch_bdpt_camera_shade(s, p, it, set, max_items, simple);
           if (ctx->scene.has_subsurface)
-            launch_bdpt_walk(s, p, it, true, set, max_items);
+            launch_bdpt_walk(s, p, it, true, set, max_items, simple);
           if (to_light)
-            launch_bdpt_connect_light(s, p, it, max_items);
+            launch_bdpt_connect_light(s, p, it, max_items, simple);
         }
         if (vertices) {
           ScopedTimer t(ctx, kTimerConnect);
           launch_expand_pairs(s, p, it, max_items);
-          launch_bdpt_connect_pairs(s, p, it, max_items);
+          launch_bdpt_connect_pairs(s, p, it, max_items, simple);
         }
         if (to_light || vertices) {
           ScopedTimer t(ctx, kTimerTraceShadow);
@@ -1487,7 +1496,7 @@ namespace {
 // sample count in w, light, normal, albedo), and for an adaptive run the even-sample sums and the pixel states.
 struct CheckpointHeader {
   uint32_t magic, version, integrator, width, height, first_iteration, iteration_stride, next_iteration;
-  uint32_t local_iterations, adaptive, options_hash, last_active_pixels, reserved[4];
+  uint32_t local_iterations, adaptive, options_hash, last_active_pixels, scene_hash, reserved[3];
 };
 static_assert(sizeof(CheckpointHeader) == 64, "checkpoint header layout");
 constexpr uint32_t kCheckpointMagic = 0x43585445u;  // "ETXC"
@@ -1512,6 +1521,27 @@ uint32_t options_hash(const etx_hip_context* c) {
     memcpy(&radius_bits, &o.initial_radius, sizeof(radius_bits));
     mix(o.options), mix(o.radius_decay), mix(o.kernel), mix(radius_bits), mix(o.blue_noise != 0);
   }
+  return h;
+}
+
+// What a film is a film OF, as far as the uploaded scene tells: the scalars the integrators read, the camera, the sizes of the tables
+// (a checkpoint does not hold the scene; this keeps it from being continued on another one by mistake)
+uint32_t scene_hash(const etx_hip_context* c) {
+  const DScene& sc = c->scene.host_copy;
+  uint32_t h = 2166136261u;
+  auto mix_bytes = [&h](const void* data, size_t size) {
+    const uint8_t* b = static_cast<const uint8_t*>(data);
+    for (size_t i = 0; i < size; ++i)
+      h = (h ^ b[i]) * 16777619u;
+  };
+  const uint32_t words[] = {sc.vertex_count, sc.triangle_count, sc.material_count, sc.emitter_count, sc.medium_count, sc.image_count, sc.spectrum_count, sc.min_path_length, sc.max_path_length,
+    sc.samples, sc.random_path_termination, sc.flags, sc.spectral};
+  mix_bytes(words, sizeof(words));
+  mix_bytes(&sc.radiance_clamp, sizeof(float));
+  mix_bytes(&sc.bounds_center, sizeof(sc.bounds_center));
+  mix_bytes(&sc.bounds_radius, sizeof(float));
+  mix_bytes(&sc.camera, sizeof(sc.camera));
+  mix_bytes(&c->scene.content_hash, sizeof(uint32_t));
   return h;
 }
 
@@ -1547,6 +1577,7 @@ int etx_hip_checkpoint_save(etx_hip_context* context, void* dst, size_t dst_byte
   header.next_iteration = context->next_iteration, header.local_iterations = context->local_iterations;
   header.adaptive = (context->pipe.pixel_state != nullptr) ? 1u : 0u;
   header.options_hash = options_hash(context);
+  header.scene_hash = scene_hash(context);
   {
     std::lock_guard<std::mutex> lock(context->shared_mutex);
     header.last_active_pixels = context->totals.last_active_pixels;  // the path tracer's host stops on "the last iteration sampled no pixel"
@@ -1583,8 +1614,12 @@ int etx_hip_checkpoint_load(etx_hip_context* context, const void* src, size_t sr
   const bool adaptive = context->pipe.pixel_state != nullptr;
   if ((header.integrator != uint32_t(context->integrator)) || (header.width != context->scene.film_w) || (header.height != context->scene.film_h) ||
       (header.first_iteration != context->first_iteration) || (header.iteration_stride != context->iteration_stride) || ((header.adaptive != 0u) != adaptive) ||
-      (header.options_hash != options_hash(context)) || (src_bytes != checkpoint_bytes(context))) {
-    context->error = "etx_hip_checkpoint_load: the checkpoint was saved by a different run (integrator, options, film size, adaptive sampling or iteration sharding differ)";
+      (header.options_hash != options_hash(context)) || (header.scene_hash != scene_hash(context)) || (src_bytes != checkpoint_bytes(context))) {
+    context->error = "etx_hip_checkpoint_load: the checkpoint was saved by a different run (integrator, options, scene scalars / camera / table sizes, film size, adaptive sampling or iteration sharding differ)";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  if (uint64_t(header.next_iteration) != uint64_t(header.first_iteration) + uint64_t(header.local_iterations) * uint64_t(header.iteration_stride)) {
+    context->error = "etx_hip_checkpoint_load: inconsistent iteration counters in the checkpoint header";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
   HIP_OK(context, hipSetDevice(context->device));
@@ -1995,6 +2030,9 @@ int etx_hip_host_bvh_stats_builder(const etx_abi_scene* scene, int builder, cons
 // accessors for host_comm.cpp (kept out of the public header)
 hipStream_t etx_hip_internal_stream(etx_hip_context* c) {
   return c->stream;
+}
+void** etx_hip_internal_comm_scratch(etx_hip_context* c) {
+  return &c->comm_scratch;
 }
 void** etx_hip_internal_comm(etx_hip_context* c) {
   return &c->comm;

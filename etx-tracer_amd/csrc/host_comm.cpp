@@ -19,6 +19,7 @@ void etx_hip_internal_set_error(etx_hip_context* c, const std::string& e);
 void etx_hip_internal_rank(etx_hip_context* c, int** rank, int** world);
 void etx_hip_internal_iterations(etx_hip_context* c, uint32_t** local, uint64_t** global, bool** reduced);
 int etx_hip_internal_device(etx_hip_context* c);
+void** etx_hip_internal_comm_scratch(etx_hip_context* c);  // device words {iterations of this rank, 1 if this rank failed}, allocated with the communicator
 
 extern "C" {
 
@@ -27,6 +28,11 @@ void etx_hip_comm_destroy_internal(etx_hip_context* context) {
   if (*comm) {
     (void)ncclCommDestroy(reinterpret_cast<ncclComm_t>(*comm));
     *comm = nullptr;
+  }
+  void** scratch = etx_hip_internal_comm_scratch(context);
+  if (*scratch) {
+    (void)hipFree(*scratch);
+    *scratch = nullptr;
   }
 }
 
@@ -56,7 +62,15 @@ int etx_hip_comm_init(etx_hip_context* context, int rank, int world_size, const 
     etx_hip_internal_set_error(context, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
     return ETX_HIP_ERROR_COMM;
   }
+  // everything the reduce needs is allocated here: a rank must not find out inside etx_hip_reduce_film that it cannot join
+  void* scratch = nullptr;
+  if (hipMalloc(&scratch, 2 * sizeof(unsigned long long)) != hipSuccess) {
+    (void)ncclCommDestroy(comm);
+    etx_hip_internal_set_error(context, "hipMalloc failed (film reduce counters)");
+    return ETX_HIP_ERROR_HIP;
+  }
   *etx_hip_internal_comm(context) = comm;
+  *etx_hip_internal_comm_scratch(context) = scratch;
   int *prank = nullptr, *pworld = nullptr;
   etx_hip_internal_rank(context, &prank, &pworld);
   *prank = rank;
@@ -85,21 +99,20 @@ int etx_hip_reduce_film(etx_hip_context* context) {
     *reduced = true;
     return ETX_HIP_OK;
   }
-  const std::string local_error = sync_rc ? std::string(etx_hip_last_error(context)) : std::string();
+  std::string local_error = sync_rc ? std::string(etx_hip_last_error(context)) : std::string();
+  // No early return between here and the collective: a local failure (even of hipSetDevice) is carried INTO the all-reduce as this
+  // rank's failed flag; whether the collective itself can run is for RCCL to say.
+  int local_rc = sync_rc;
   if (hipSetDevice(etx_hip_internal_device(context)) != hipSuccess) {
-    etx_hip_internal_set_error(context, "hipSetDevice failed");
-    return ETX_HIP_ERROR_HIP;
+    if (local_rc == 0)
+      local_rc = ETX_HIP_ERROR_HIP, local_error = "hipSetDevice failed before the film reduce";
   }
   hipStream_t stream = etx_hip_internal_stream(context);
   float *camera = nullptr, *light = nullptr;
   size_t floats = 0;
   etx_hip_internal_film(context, &camera, &light, &floats);
-  unsigned long long* d_counters = nullptr;  // {iterations of this rank, 1 if this rank failed}
-  if (hipMalloc(reinterpret_cast<void**>(&d_counters), 2 * sizeof(unsigned long long)) != hipSuccess) {
-    etx_hip_internal_set_error(context, "hipMalloc failed");
-    return ETX_HIP_ERROR_HIP;
-  }
-  unsigned long long h_counters[2] = {*local, sync_rc ? 1ull : 0ull};
+  unsigned long long* d_counters = reinterpret_cast<unsigned long long*>(*etx_hip_internal_comm_scratch(context));  // allocated by etx_hip_comm_init
+  unsigned long long h_counters[2] = {*local, local_rc ? 1ull : 0ull};
   (void)hipMemcpyAsync(d_counters, h_counters, sizeof(h_counters), hipMemcpyHostToDevice, stream);
   ncclResult_t r = ncclGroupStart();
   if (r == ncclSuccess)
@@ -110,22 +123,19 @@ int etx_hip_reduce_film(etx_hip_context* context) {
   if (r == ncclSuccess)
     r = r2;
   if (r != ncclSuccess) {
-    (void)hipFree(d_counters);
     etx_hip_internal_set_error(context, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
     return ETX_HIP_ERROR_COMM;
   }
   (void)hipMemcpyAsync(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream);
   if (hipStreamSynchronize(stream) != hipSuccess) {
-    (void)hipFree(d_counters);
     etx_hip_internal_set_error(context, "stream synchronize failed after all-reduce");
     return ETX_HIP_ERROR_HIP;
   }
-  (void)hipFree(d_counters);
   *global = h_counters[0];
   *reduced = true;
-  if (sync_rc) {
+  if (local_rc) {
     etx_hip_internal_set_error(context, local_error);
-    return sync_rc;
+    return local_rc;
   }
   if (h_counters[1] != 0ull) {
     etx_hip_internal_set_error(context, std::to_string(h_counters[1]) + " other rank(s) reported a failed iteration before the film reduce (their films are incomplete)");

@@ -69,6 +69,7 @@ void DeviceScene::borrow(const DeviceScene& owner) {
   generic_materials = owner.generic_materials;
   needs_rgb_response = owner.needs_rgb_response;
   bvh_bytes = owner.bvh_bytes;
+  content_hash = owner.content_hash;
 }
 
 namespace {
@@ -820,6 +821,27 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   out.needs_rgb_response = false;
   out.has_subsurface_cb = false;
   out.noise_threshold = scene->noise_threshold;
+  {
+    // what the scene IS, cheaply (a checkpoint names the scene it belongs to with this): the material and emitter tables, the scalar
+    // part of the media, up to 4096 evenly spaced vertices
+    uint32_t h = 2166136261u;  // FNV-1a
+    auto mix = [&h](const void* data, size_t size) {
+      const uint8_t* b = static_cast<const uint8_t*>(data);
+      for (size_t i = 0; i < size; ++i)
+        h = (h ^ b[i]) * 16777619u;
+    };
+    mix(scene->materials.a, scene->materials.count * sizeof(etx_abi_material));
+    mix(scene->emitter_instances.a, scene->emitter_instances.count * sizeof(etx_abi_emitter));
+    mix(scene->emitter_profiles.a, scene->emitter_profiles.count * sizeof(etx_abi_emitter_profile));
+    for (uint64_t i = 0; i < scene->mediums.count; ++i) {
+      const etx_abi_medium& m = static_cast<const etx_abi_medium*>(scene->mediums.a)[i];
+      mix(&m.bounds_min, sizeof(etx_abi_medium) - offsetof(etx_abi_medium, bounds_min));  // everything but the density pointer
+    }
+    const uint64_t step = std::max<uint64_t>(1u, scene->vertices.count / 4096u);
+    for (uint64_t i = 0; i < scene->vertices.count; i += step)
+      mix(static_cast<const etx_abi_vertex*>(scene->vertices.a) + i, sizeof(etx_abi_vertex));
+    out.content_hash = h;
+  }
   if ((camera->film_size.x == 0) || (camera->film_size.y == 0)) {
     error = "camera film size is zero";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;

@@ -41,6 +41,7 @@ struct DeviceScene {
   bool generic_materials = false;  // a connectible (non delta) surface material other than Diffuse is in use
   bool needs_rgb_response = false; // spectral scene with RGB images behind spectra: apply_rgb needs the host's table (etx_hip_upload_rgb_response)
   size_t bvh_bytes = 0;
+  uint32_t content_hash = 0;       // of the host tables the scene was built from (materials, emitters, media scalars, a sample of the vertices): etx_hip_checkpoint_*
 
   ~DeviceScene();
   void release();

@@ -215,7 +215,7 @@ struct BdptLightStep {
 
 // One segment of an emitter path after the closest-hit query (kInWalk = false, `h` from the hit queue), or one sub-step of a
 // subsurface walk (kInWalk = true: the free flight and its material-filtered query happen here).
-template <uint32_t kStep>
+template <uint32_t kStep, bool kSimple>
 ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const LaneStack& stack, uint32_t mode, BdptState& st, BdptWalk& walk, float4& h) {
   constexpr bool kInWalk = kStep != kStepSegment;
   BdptLightStep r = {};
@@ -290,7 +290,7 @@ ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const LaneStack& stac
     } else {
       const BsdfData data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight, st.wavelength);
       st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
-      BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
+      BsdfSample bs = bsdf_sample_s<kSimple>(scene, data, mat, st.sampler);
       st.sampler.pop_fixed();
       uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
       uint32_t walk_medium = kInvalid, path_medium = vertex_medium;
@@ -301,11 +301,13 @@ ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const LaneStack& stac
       BVtx curr = {isect.pos, isect.nrm, 0.0f, 0.0f,
         kBvSurface | (connectible ? kBvConnectible : 0u) | ((connectible && (st.prev.flags & kBvConnectible)) ? kBvMisConnectible : 0u), isect.tri};
       curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
-      const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
+      const float rev_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
       const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
       r.v_pos = isect.pos, r.v_nrm = isect.nrm, r.v_wi = isect.w_i, r.v_throughput = st.throughput, r.v_flags = curr.flags, r.v_tri = isect.tri, r.v_bc_u = isect.bc.y, r.v_bc_v = isect.bc.z;
       if (enter || kInWalk)
         r.v_flags |= kBvScatterMaterial;
+      if (scene.material_group[vertex_material] != kShadeGroupSimple)
+        r.v_flags |= kBvGeneralBsdf;
       r.v_medium = vertex_medium;
       st.medium = path_medium;
       bool terminate = false;
@@ -373,6 +375,7 @@ ETX_DEV BdptWalk bdpt_walk_info(const Pipeline& p, uint32_t queue, uint32_t entr
 }
 
 // One segment of an emitter path after the closest-hit query
+template <bool kSimple>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, VcmParams it, uint32_t in_set) {
   __shared__ BlockScratch s_scratch;
   const LaneStack no_stack = {};
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
         st.prev.tri = st.prev_slot;  // see k_bdpt_light_generate
         st.prev_slot = kInvalid;
       }
-      r = bdpt_light_step<kStepSegment>(scene, no_stack, mode, st, walk, h);
+      r = bdpt_light_step<kStepSegment, kSimple>(scene, no_stack, mode, st, walk, h);
     }
     // pool slots: the emitter vertex (first interaction only), then the new vertex
     const uint32_t emitter_slot = block_compact_slot(r.store_emitter, p.counters + kCntLightVertices, s_scratch);
@@ -441,7 +444,7 @@ ETX_DEV bool walk_refill(const Pipeline& p, uint32_t count, bool& active, bool& 
 }
 
 // The scattering events of the walks of this bounce, emitter paths: walk queue -> (medium vertices in the light vertex pool) -> exit queue
-__global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_light(Pipeline p, VcmParams it, uint32_t queue) {
+__global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_light(Pipeline p, VcmParams it, uint32_t queue) {
   __shared__ int32_t s_stack[kStackDepth * kBlockSize];
   const LaneStack stack = lane_stack(p.scene, s_stack + threadIdx.x, kBlockSize);
   const DScene& scene = p.scene;
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_light(Pipeline p, VcmP
     BdptLightStep r = {};
     float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
     if (active)
-      r = bdpt_light_step<kStepWalkEvent>(scene, stack, mode, st, walk, h);
+      r = bdpt_light_step<kStepWalkEvent, true>(scene, stack, mode, st, walk, h);
     const uint32_t vertex_slot = wave_chunk_slot(r.store_vertex, chunk, p.counters + kCntLightVertices);
     bdpt_light_store(p, st, r, 0u, vertex_slot);  // a walk never holds the emitter vertex: its entry vertex came first
     const uint32_t exit_slot = wave_compact_slot(r.exit, p.counters + kCntWalkExit);
@@ -490,6 +493,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_light(Pipeline p, VcmP
 }
 
 // ... and the surface vertices where they leave their objects: exit queue -> "out" path set
+template <bool kSimple>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_exit_light(Pipeline p, VcmParams it, uint32_t out_set) {
   __shared__ BlockScratch s_scratch;
   const LaneStack no_stack = {};
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_exit_light(Pipeline p,
     if (i < count) {
       st = bdpt_load(p.walk_exit, i);
       float4 h = p.walk_exit_hits[i];
-      r = bdpt_light_step<kStepWalkExit>(scene, no_stack, mode, st, walk, h);
+      r = bdpt_light_step<kStepWalkExit, kSimple>(scene, no_stack, mode, st, walk, h);
     }
     const uint32_t vertex_slot = block_compact_slot(r.store_vertex, p.counters + kCntLightVertices, s_scratch);
     bdpt_light_store(p, st, r, 0u, vertex_slot);
@@ -516,6 +520,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_exit_light(Pipeline p,
 }
 
 // connect_light_to_camera (:1380-1428) for the vertices the light pass stored in this bounce
+template <bool kSimple>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_camera(Pipeline p, VcmParams it) {
   __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_camera(Pipeline p, 
           const float near_extent = (scene.camera.clip_near > 0.0f) ? scene.camera.clip_near / cos_t : 0.0f;
           const float far_extent = (scene.camera.clip_far > 0.0f) ? scene.camera.clip_far / cos_t : kMaxFloat;
           if ((cs.pdf_dir > 0.0f) && (len >= near_extent) && (len <= far_extent)) {
-            const BdptBsdf bsdf = bdpt_bsdf(scene, y.full, kPathLight, cs.direction, y.wavelength, smp);
+            const BdptBsdf bsdf = bdpt_bsdf<kSimple>(scene, y.full, kPathLight, cs.direction, y.wavelength, smp);
             if (is_zero(bsdf.bsdf) == false) {
               float weight = 1.0f;
               if (opt_enable_mis(it) && (mode != kBdptLightTracing)) {  // mis_weight_light_to_camera, :1135-1182 (Full)
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_camera(Pipeline p, 
                 const float cos_c = dot(normalize(y.self.pos - scene.camera.position), scene.camera.direction);
                 const float film_pdf = 1.0f / fabsf(scene.camera.area * cos_c * cos_c * cos_c);  // film_pdf_out, scene_camera.hxx:20-24
                 const float curr_from_camera = bdpt_to_area(film_pdf, cs.position, y.self);
-                const float prev_from_curr = bdpt_pdf_area(scene, kPathCamera, cs.position, y.full, y_prev, y.wavelength, smp);
+                const float prev_from_curr = bdpt_pdf_area<kSimple>(scene, kPathCamera, cs.position, y.full, y_prev, y.wavelength, smp);
                 if (mode == kBdptFast) {
                   const uint32_t* table = reinterpret_cast<const uint32_t*>(p.light_path_table) + size_t(y.path) * kPathTableEntries;
                   const uint32_t e0 = table[0], e1 = table[1];
@@ -643,7 +648,7 @@ ETX_DEV float bdpt_direct_hit_weight(const BdptState& st, uint32_t mode, float z
 struct BdptCameraStep {
   bool store_vertex;    // a connectible vertex for the camera vertex pool (written BEFORE `created` replaces st.prev: the record reads z_prev)
   bool created;         // a path vertex (curr) exists and becomes prev
-  bool terminate, enter, scatter_vertex, in_medium_event;
+  bool terminate, enter, scatter_vertex, in_medium_event, general_bsdf;
   bool exit;            // kStepWalkEvent: the flight reached the object's surface (hit in `h`)
   bool alive;           // boundary crossing: the path continues on the ray queue without a vertex
   BVtx curr;
@@ -654,7 +659,7 @@ struct BdptCameraStep {
 
 // One segment of a camera path after the closest-hit query (kInWalk = false), or one sub-step of a subsurface walk (kInWalk = true).
 // Film contributions of direct hits are added here; pool records and the roulette are the caller's (bdpt_camera_finish).
-template <uint32_t kStep>
+template <uint32_t kStep, bool kSimple>
 ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, const LaneStack& stack, const VcmParams& it, uint32_t mode, bool use_mis, BdptState& st, BdptWalk& walk, float4& h) {
   constexpr bool kInWalk = kStep != kStepSegment;
   BdptCameraStep r = {};
@@ -729,7 +734,7 @@ ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, 
         st.flags |= kBpGBuffer;
       }
       st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
-      BsdfSample bs = bsdf_sample_s<false>(scene, data, mat, st.sampler);
+      BsdfSample bs = bsdf_sample_s<kSimple>(scene, data, mat, st.sampler);
       st.sampler.pop_fixed();
       uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
       uint32_t path_medium = vertex_medium;
@@ -742,7 +747,7 @@ ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, 
       r.curr = {isect.pos, isect.nrm, 0.0f, 0.0f, kBvSurface | (connectible ? kBvConnectible : 0u) | ((connectible && (st.prev.flags & kBvConnectible)) ? kBvMisConnectible : 0u),
         isect.tri};
       r.curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, r.curr);
-      const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
+      const float rev_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
       const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
       const f3 vertex_throughput = st.throughput;
       const float prev_sampled_pdf = st.aux;  // z_prev.pdf.bsdf_sample_next (PathTracing mode weights)
@@ -793,6 +798,7 @@ ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, 
       r.store_vertex = connectible && (mode != kBdptLightTracing);
       r.v_hit = h, r.v_wi = isect.w_i, r.v_throughput = vertex_throughput, r.v_medium = vertex_medium;
       r.v_rnd = {rnd_em.x, rnd_em.y, rnd_support.y};
+      r.general_bsdf = scene.material_group[vertex_material] != kShadeGroupSimple;
     }
    }
   } else if ((kInWalk == false) && opt_direct_hit(it) && (mode != kBdptLightTracing)) {  // miss: direct_hit_environment_emitter, :1289-1340
@@ -847,7 +853,7 @@ ETX_DEV uint32_t bdpt_camera_finish(const Pipeline& p, const DScene& scene, Bdpt
   if (r.store_vertex) {
     Sampler derived;
     derived.init(st.sampler.seed, 0x51ed270bu);
-    bdpt_store_camera_vertex(p, vertex_slot, st, r.v_hit, r.v_wi, r.v_medium, r.v_throughput, r.curr.from_prev, r.v_rnd, derived.seed, r.scatter_vertex);
+    bdpt_store_camera_vertex(p, vertex_slot, st, r.v_hit, r.v_wi, r.v_medium, r.v_throughput, r.curr.from_prev, r.v_rnd, derived.seed, r.scatter_vertex, r.general_bsdf);
   }
   constexpr bool kInWalk = kStep != kStepSegment;
   if (r.created == false)
@@ -865,6 +871,7 @@ ETX_DEV uint32_t bdpt_camera_finish(const Pipeline& p, const DScene& scene, Bdpt
   return goes_on ? 1u : 0u;
 }
 
+template <bool kSimple>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, VcmParams it, uint32_t in_set) {
   __shared__ BlockScratch s_scratch;
   const LaneStack no_stack = {};
@@ -884,7 +891,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
       st = bdpt_load(in, i);
       st.prev.tri = st.prev_slot;  // camera paths carry the previous vertex' triangle there
       float4 h = p.hits[i];
-      r = bdpt_camera_step<kStepSegment>(p, scene, no_stack, it, mode, use_mis, st, walk, h);
+      r = bdpt_camera_step<kStepSegment, kSimple>(p, scene, no_stack, it, mode, use_mis, st, walk, h);
     }
     const uint32_t vertex_slot = block_compact_slot(r.store_vertex, p.counters + kCntCameraVertices, s_scratch);
     const uint32_t next = valid ? bdpt_camera_finish<kStepSegment>(p, scene, st, walk, r, vertex_slot) : 0u;
@@ -901,7 +908,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
 
 // The scattering events of the walks of this bounce, camera paths: walk queue -> exit queue (only the exit vertex of a walk is
 // connectible, :811: the events leave nothing but the path's running MIS history behind)
-__global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_camera(Pipeline p, VcmParams it, uint32_t queue) {
+__global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_camera(Pipeline p, VcmParams it, uint32_t queue) {
   __shared__ int32_t s_stack[kStackDepth * kBlockSize];
   const LaneStack stack = lane_stack(p.scene, s_stack + threadIdx.x, kBlockSize);
   const DScene& scene = p.scene;
@@ -926,7 +933,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_camera(Pipeline p, Vcm
     float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
     uint32_t next = 0u;
     if (active) {
-      r = bdpt_camera_step<kStepWalkEvent>(p, scene, stack, it, mode, use_mis, st, walk, h);
+      r = bdpt_camera_step<kStepWalkEvent, true>(p, scene, stack, it, mode, use_mis, st, walk, h);
       next = bdpt_camera_finish<kStepWalkEvent>(p, scene, st, walk, r, 0u);
     }
     const uint32_t exit_slot = wave_compact_slot(r.exit, p.counters + kCntWalkExit);
@@ -944,6 +951,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_camera(Pipeline p, Vcm
   }
 }
 
+template <bool kSimple>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_exit_camera(Pipeline p, VcmParams it, uint32_t out_set) {
   __shared__ BlockScratch s_scratch;
   const LaneStack no_stack = {};
@@ -962,7 +970,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_exit_camera(Pipeline p
       st = bdpt_load(p.walk_exit, i);
       st.prev.tri = st.prev_slot;
       float4 h = p.walk_exit_hits[i];
-      r = bdpt_camera_step<kStepWalkExit>(p, scene, no_stack, it, mode, use_mis, st, walk, h);
+      r = bdpt_camera_step<kStepWalkExit, kSimple>(p, scene, no_stack, it, mode, use_mis, st, walk, h);
     }
     const uint32_t vertex_slot = block_compact_slot(r.store_vertex, p.counters + kCntCameraVertices, s_scratch);
     const uint32_t next = valid ? bdpt_camera_finish<kStepWalkExit>(p, scene, st, walk, r, vertex_slot) : 0u;
@@ -973,6 +981,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_exit_camera(Pipeline p
 }
 
 // connect_camera_to_light (:1342-1378) with mis_weight_camera_to_light (:1079-1133) for the camera vertices of this bounce
+template <bool kSimple>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_light(Pipeline p, VcmParams it) {
   __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
@@ -991,7 +1000,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_light(Pipeline p, V
         const EmitterSample es = sample_emitter(scene, emitter_index, f2{z.rnd_fixed.x, z.rnd_fixed.y}, z.full.isect.pos, z.wavelength);
         const f3 dp = es.origin - z.full.isect.pos;
         if ((is_zero(es.value) == false) && (es.pdf_dir != 0.0f) && (dot(dp, dp) > kEpsilon)) {
-          const BdptBsdf bsdf = bdpt_bsdf(scene, z.full, kPathCamera, es.direction, z.wavelength, smp);
+          const BdptBsdf bsdf = bdpt_bsdf<kSimple>(scene, z.full, kPathCamera, es.direction, z.wavelength, smp);
           if (is_zero(bsdf.bsdf) == false) {
             const float sampling_pdf = es.pdf_dir * es.pdf_sample;
             float weight = 1.0f;
@@ -1004,8 +1013,8 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_light(Pipeline p, V
                 const BVtx z_curr = z.full.summary(z.from_prev);
                 const float p_sample = bdpt_emitter_sample_pdf(scene, em, es.direction);
                 const float from_emitter = bdpt_pdf_from_emitter(scene, es.emitter_index, es.origin, es.normal, z_curr);
-                const float z_prev_backward = bdpt_pdf_area(scene, kPathLight, es.origin, z.full, z.prev, z.wavelength, smp);
-                const float p_bsdf_sample = bdpt_pdf_area(scene, kPathCamera, z.prev.pos, z.full, sampled, z.wavelength, smp);
+                const float z_prev_backward = bdpt_pdf_area<kSimple>(scene, kPathLight, es.origin, z.full, z.prev, z.wavelength, smp);
+                const float p_bsdf_sample = bdpt_pdf_area<kSimple>(scene, kPathCamera, z.prev.pos, z.full, sampled, z.wavelength, smp);
                 if (mode == kBdptFast) {  // :1114-1129
                   const float p_fwd = z.prev.from_prev * z.from_prev;
                   const float p_connection = p_fwd * p_sample;
@@ -1034,6 +1043,10 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_light(Pipeline p, V
 
 // connect_camera_to_light_path (:438-497), one (camera vertex, light vertex) pair per lane, with
 // mis_weight_camera_to_light_path (:1184-1209)
+// kFilter: 0 = every pair; 1 = the pairs whose two vertices are of the simple shading group (kSimple instantiation, scenes that also
+// hold other materials); 2 = the pairs with a vertex of another group. The class of a pair is in the flag words both instantiations
+// read anyway, and the pairs of one camera vertex are adjacent, so wavefronts are mostly of one class.
+template <bool kSimple, uint32_t kFilter>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs(Pipeline p, VcmParams it) {
   __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
@@ -1045,9 +1058,12 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs(Pipeline p, V
       const uint2 pair = p.pairs[i];
       const uint32_t y_flags = __float_as_uint(p.lv.thr_dvm(pair.y).w);
       const uint32_t light_s = __float_as_uint(p.lv.bc_len_med(pair.y).z) >> 16u;
-      const uint32_t camera_path_size = __float_as_uint(p.cv.thr_depth[pair.x].w) & ~kCvExitMaterialBit;
+      const uint32_t z_word = __float_as_uint(p.cv.thr_depth[pair.x].w);
+      const uint32_t camera_path_size = z_word & ~(kCvExitMaterialBit | kCvGeneralBsdfBit);
       const uint32_t target_path_length = (camera_path_size - 1u) + light_s + 1u;
-      if ((light_s >= 1u) && (y_flags & kBvConnectible) && (target_path_length >= scene.min_path_length) && (target_path_length <= scene.max_path_length)) {
+      const bool general_pair = ((y_flags & kBvGeneralBsdf) != 0u) || ((z_word & kCvGeneralBsdfBit) != 0u);
+      const bool mine = (kFilter == 0u) || ((kFilter == 1u) != general_pair);
+      if (mine && (light_s >= 1u) && (y_flags & kBvConnectible) && (target_path_length >= scene.min_path_length) && (target_path_length <= scene.max_path_length)) {
         const BdptCameraVertex z = bdpt_load_camera_vertex(p, scene, pair.x);
         const BdptLightVertex y = bdpt_load_light_vertex(p, scene, pair.y);
         f3 dw = z.full.isect.pos - y.self.pos;
@@ -1056,18 +1072,18 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs(Pipeline p, V
           dw = dw * (1.0f / sqrtf(dwl));
           Sampler smp;
           smp.seed = Sampler::random_seed(z.seed, pair.y), smp.fixed_u = smp.fixed_v = smp.fixed_w = 0.0f;
-          const f3 bsdf_y = bdpt_bsdf(scene, y.full, kPathLight, dw, z.wavelength, smp).bsdf;
-          const f3 bsdf_z = bdpt_bsdf(scene, z.full, kPathCamera, -dw, z.wavelength, smp).bsdf;
+          const f3 bsdf_y = bdpt_bsdf<kSimple>(scene, y.full, kPathLight, dw, z.wavelength, smp).bsdf;
+          const f3 bsdf_z = bdpt_bsdf<kSimple>(scene, z.full, kPathCamera, -dw, z.wavelength, smp).bsdf;
           const f3 connect = y.throughput * bsdf_y * bsdf_z;
           if (is_zero(connect) == false) {
             float weight = 1.0f;
             if (opt_enable_mis(it)) {
               const BVtx y_prev = bdpt_load_light_summary(p, y.prev);
               const BVtx z_curr = z.full.summary(z.from_prev);
-              const float z_curr_pdf = bdpt_pdf_area(scene, kPathLight, y_prev.pos, y.full, z_curr, z.wavelength, smp);
-              const float z_prev_pdf = bdpt_pdf_area(scene, kPathCamera, y.self.pos, z.full, z.prev, z.wavelength, smp);
-              const float y_curr_pdf = bdpt_pdf_area(scene, kPathCamera, z.prev.pos, z.full, y.self, z.wavelength, smp);
-              const float y_prev_pdf = bdpt_pdf_area(scene, kPathLight, z.full.isect.pos, y.full, y_prev, z.wavelength, smp);
+              const float z_curr_pdf = bdpt_pdf_area<kSimple>(scene, kPathLight, y_prev.pos, y.full, z_curr, z.wavelength, smp);
+              const float z_prev_pdf = bdpt_pdf_area<kSimple>(scene, kPathCamera, y.self.pos, z.full, z.prev, z.wavelength, smp);
+              const float y_curr_pdf = bdpt_pdf_area<kSimple>(scene, kPathCamera, z.prev.pos, z.full, y.self, z.wavelength, smp);
+              const float y_prev_pdf = bdpt_pdf_area<kSimple>(scene, kPathLight, z.full.isect.pos, y.full, y_prev, z.wavelength, smp);
               const float w_camera = bdpt_mis_camera(z.path_size, z_curr_pdf, z.from_prev, z_prev_pdf, z.prev);
               const float w_light = bdpt_mis_light(y_curr_pdf, y.self.from_prev, y_prev_pdf, y_prev);
               weight = 1.0f / (1.0f + w_camera + w_light);
@@ -1089,37 +1105,54 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs(Pipeline p, V
 void launch_bdpt_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
   hipLaunchKernelGGL(k_bdpt_light_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
 }
-void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
-  hipLaunchKernelGGL(k_bdpt_light_shade, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
+// `simple`: every material in use is of the simple shading group (DeviceScene::simple_materials) -> the instantiations with the inline
+// Lambert / delta BSDFs; otherwise every class through the out-of-line dispatch (dev_bsdf_ool.h)
+#define ETX_BDPT_LAUNCH(KERNEL, GRID, ...)                                                                  \
+  do {                                                                                                      \
+    if (simple)                                                                                             \
+      hipLaunchKernelGGL(KERNEL<true>, dim3(GRID), dim3(kBlockSize), 0, stream, __VA_ARGS__);               \
+    else                                                                                                    \
+      hipLaunchKernelGGL(KERNEL<false>, dim3(GRID), dim3(kBlockSize), 0, stream, __VA_ARGS__);              \
+  } while (0)
+
+void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple) {
+  ETX_BDPT_LAUNCH(k_bdpt_light_shade, max(1u, grid_for(min(p.capacity, max_items))), p, it, in_set);
 }
 // the walks of the paths the shade kernel of this round put on the walk queue: the scattering events in persistent wavefronts (at most
 // kWalkBlocks workgroups: 32 KB of traversal stack each), then the exit vertices as a dense kernel
-void launch_bdpt_walk(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool camera, uint32_t in_set, uint32_t max_items) {
+void launch_bdpt_walk(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool camera, uint32_t in_set, uint32_t max_items, bool simple) {
   const uint32_t items = min(p.capacity, max_items);
   const uint32_t blocks = max(1u, min(kWalkBlocks, (items + kBlockSize - 1u) / kBlockSize));
   if (camera) {
     hipLaunchKernelGGL(k_bdpt_walk_camera, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
-    hipLaunchKernelGGL(k_bdpt_walk_exit_camera, dim3(max(1u, grid_for(items))), dim3(kBlockSize), 0, stream, p, it, in_set ^ 1u);
+    ETX_BDPT_LAUNCH(k_bdpt_walk_exit_camera, max(1u, grid_for(items)), p, it, in_set ^ 1u);
   } else {
     hipLaunchKernelGGL(k_bdpt_walk_light, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
-    hipLaunchKernelGGL(k_bdpt_walk_exit_light, dim3(max(1u, grid_for(items))), dim3(kBlockSize), 0, stream, p, it, in_set ^ 1u);
+    ETX_BDPT_LAUNCH(k_bdpt_walk_exit_light, max(1u, grid_for(items)), p, it, in_set ^ 1u);
   }
 }
-void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
-  hipLaunchKernelGGL(k_bdpt_connect_camera, dim3(max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 2ull, uint64_t(p.lv.capacity)))))), dim3(kBlockSize), 0, stream, p, it);
+void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, bool simple) {
+  ETX_BDPT_LAUNCH(k_bdpt_connect_camera, max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 2ull, uint64_t(p.lv.capacity))))), p, it);
 }
 void launch_bdpt_camera_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
   hipLaunchKernelGGL(k_bdpt_camera_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
 }
-void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items) {
-  hipLaunchKernelGGL(k_bdpt_camera_shade, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it, in_set);
+void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple) {
+  ETX_BDPT_LAUNCH(k_bdpt_camera_shade, max(1u, grid_for(min(p.capacity, max_items))), p, it, in_set);
 }
-void launch_bdpt_connect_light(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
-  hipLaunchKernelGGL(k_bdpt_connect_light, dim3(max(1u, grid_for(min(p.capacity, max_items)))), dim3(kBlockSize), 0, stream, p, it);
+void launch_bdpt_connect_light(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, bool simple) {
+  ETX_BDPT_LAUNCH(k_bdpt_connect_light, max(1u, grid_for(min(p.capacity, max_items))), p, it);
 }
-void launch_bdpt_connect_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
+// Vertex connections. A scene of simple materials: one kernel; otherwise the pairs of two simple vertices go through the inline
+// Lambert / phase-function kernel and only the others through the general one (both run over the pair list and take their class).
+void launch_bdpt_connect_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, bool simple) {
   const uint32_t pair_blocks = max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 8ull, uint64_t(p.pair_capacity)))));
-  hipLaunchKernelGGL(k_bdpt_connect_pairs, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
+  if (simple) {
+    hipLaunchKernelGGL((k_bdpt_connect_pairs<true, 0u>), dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
+  } else {
+    hipLaunchKernelGGL((k_bdpt_connect_pairs<true, 1u>), dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
+    hipLaunchKernelGGL((k_bdpt_connect_pairs<false, 2u>), dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
+  }
 }
 
 }  // namespace etxd

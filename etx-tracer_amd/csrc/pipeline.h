@@ -104,6 +104,7 @@ struct EndpointQueue {
   float* wavelength;
   uint32_t capacity;
 };
+constexpr uint32_t kCvGeneralBsdfBit = 0x40000000u;   // in thr_depth.w (bidirectional records): the vertex' material is not of the simple shading group
 constexpr uint32_t kCvExitMaterialBit = 0x80000000u;  // in thr_depth.w: the vertex is the exit point of a subsurface walk, material = scene.subsurface_exit_material
 
 struct ShadowQueue {        // transmittance ("shadow") ray requests of the current bounce: 48 B in, film atomics out
