@@ -6,6 +6,7 @@
 #include "kernels_bvh_build.h"
 #include "kernels.h"
 #include "dev_bvh.h"
+#include "tuning_knobs.h"
 
 #include <hip/hip_runtime.h>
 
@@ -80,6 +81,7 @@ struct etx_hip_context {
   uint32_t tail_divisor = 64;        // active paths <= capacity / tail_divisor: finish the pass in the tail kernel (0 = never)
   uint32_t check_interval = 3;       // rounds the host may enqueue beyond the newest round the device has reported (run_bounce_loop)
   uint32_t timer_mask = (1u << kTimerTraceClosest) | (1u << kTimerTraceShadow);
+  uint32_t debug_flags = 0;          // etx_hip_set_debug_flags: ablation switches of the kernels (Pipeline::debug_flags), 0 in production
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
   std::vector<TimedSpan> spans;
@@ -191,9 +193,7 @@ int allocate_pipeline(etx_hip_context* ctx) {
       return rc;
     p.scene.stack_spill_lanes = spill_lanes;
   }
-  p.debug_flags = 0u;
-  if (const char* e = getenv("ETX_HIP_DEBUG_FLAGS"))
-    p.debug_flags = uint32_t(strtoul(e, nullptr, 0));
+  p.debug_flags = ctx->debug_flags;
   p.capacity = n;
   int rc = 0;
   for (int s = 0; s < 2; ++s) {
@@ -834,12 +834,10 @@ int init_lane(etx_hip_context* lane, int device, std::string& error) {
     return ETX_HIP_ERROR_HIP;
   }
   memset(lane->round_mirror, 0, kRoundMirrorSlots * sizeof(unsigned long long));
-  if (const char* e = getenv("ETX_HIP_CHECK_INTERVAL"))
-    lane->check_interval = std::max(1, atoi(e));
-  if (const char* e = getenv("ETX_HIP_TAIL_DIVISOR"))
-    lane->tail_divisor = uint32_t(std::max(0, atoi(e)));
-  if (const char* e = getenv("ETX_HIP_TIMERS"))
-    lane->timer_mask = uint32_t(strtoul(e, nullptr, 0));
+  lane->check_interval = std::max(1u, etxh::tuning_knob("ETX_HIP_CHECK_INTERVAL", lane->check_interval));
+  lane->tail_divisor = etxh::tuning_knob("ETX_HIP_TAIL_DIVISOR", lane->tail_divisor);
+  lane->timer_mask = etxh::tuning_knob("ETX_HIP_TIMERS", lane->timer_mask);
+  lane->debug_flags = etxh::tuning_knob("ETX_HIP_DEBUG_FLAGS", 0u);
   lane->worker = std::thread(lane_worker, lane);
   return ETX_HIP_OK;
 }
@@ -1644,6 +1642,17 @@ int etx_hip_checkpoint_load(etx_hip_context* context, const void* src, size_t sr
   return ETX_HIP_OK;
 }
 
+int etx_hip_set_debug_flags(etx_hip_context* context, uint32_t flags) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  if (int rc = wait_idle(context))
+    return rc;
+  context->debug_flags = context->pipe.debug_flags = flags;
+  for (etx_hip_context* helper : context->helpers)
+    helper->debug_flags = helper->pipe.debug_flags = flags;
+  return ETX_HIP_OK;
+}
+
 int etx_hip_set_timers(etx_hip_context* context, uint32_t mask) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
@@ -1693,7 +1702,7 @@ int etx_hip_trace_rays(etx_hip_context* context, const float* rays_8f, uint64_t 
       rc = ETX_HIP_ERROR_HIP;
       break;
     }
-    launch_trace_rays(context->stream, context->pipe.scene, d_o, d_d, d_h, uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
+    launch_trace_rays(context->stream, context->pipe.scene, d_o, d_d, d_h, uint32_t(count), context->scene.host_copy.bvh_flat != 0u, context->debug_flags);
     if ((hipMemcpyAsync(hits_4f, d_h, count * sizeof(float4), hipMemcpyDeviceToHost, context->stream) != hipSuccess) || (hipStreamSynchronize(context->stream) != hipSuccess)) {
       context->error = std::string("trace kernel failed: ") + hipGetErrorString(hipGetLastError());
       rc = ETX_HIP_ERROR_HIP;
@@ -1718,11 +1727,11 @@ int etx_hip_trace_rays_device(etx_hip_context* context, const void* d_rays_o_tmi
   HIP_OK(context, hipEventCreate(&e1));
   // one untimed launch (code object load, caches)
   launch_trace_rays(context->stream, context->pipe.scene, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
-    reinterpret_cast<float4*>(d_hits), uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
+    reinterpret_cast<float4*>(d_hits), uint32_t(count), context->scene.host_copy.bvh_flat != 0u, context->debug_flags);
   HIP_OK(context, hipEventRecord(e0, context->stream));
   for (uint32_t r = 0; r < repeat; ++r)
     launch_trace_rays(context->stream, context->pipe.scene, reinterpret_cast<const float4*>(d_rays_o_tmin), reinterpret_cast<const float4*>(d_rays_d_tmax),
-      reinterpret_cast<float4*>(d_hits), uint32_t(count), context->scene.host_copy.bvh_flat != 0u);
+      reinterpret_cast<float4*>(d_hits), uint32_t(count), context->scene.host_copy.bvh_flat != 0u, context->debug_flags);
   HIP_OK(context, hipEventRecord(e1, context->stream));
   HIP_OK(context, hipEventSynchronize(e1));
   float ms = 0.0f;

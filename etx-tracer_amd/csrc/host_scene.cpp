@@ -6,6 +6,7 @@
 #include "dev_bsdf.h"
 #include "dev_bvh.h"
 #include "../../include/etx_hip.h"
+#include "tuning_knobs.h"
 
 #include <cstdio>
 #include <algorithm>
@@ -389,8 +390,7 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out, bool keep_bvh2) {
       fprintf(stderr, "[etx_hip] build_bvh %s: %.1f ms since start\n", name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - phase_begin).count());
   };
   Builder b;
-  if (const char* e = getenv("ETX_HIP_BVH_TRAVERSAL_COST"))
-    b.traversal_cost = float(atof(e));
+  b.traversal_cost = tuning_knob_f("ETX_HIP_BVH_TRAVERSAL_COST", b.traversal_cost);
   std::vector<Builder::Prim> primitives(n);
   b.prims = primitives.data();
   const uint32_t threads = build_threads();
@@ -793,8 +793,8 @@ int build_traversal_tables(const etx_abi_scene* scene, DeviceScene& out, DScene&
   d.bvh_depth = bvh.depth4;
   d.bvh_stack_need = bvh.stack_need;
   d.bvh_flat = (bvh.tris.size() <= kFlatSweepMaxTriangles) ? 1u : 0u;
-  if (const char* e = getenv("ETX_HIP_FORCE_BVH"))
-    d.bvh_flat = (atoi(e) != 0) ? 0u : d.bvh_flat;
+  if (tuning_knob("ETX_HIP_FORCE_BVH", 0u) != 0u)
+    d.bvh_flat = 0u;
   out.bvh_depth = bvh.depth4;
   out.bvh_bytes = bvh.nodes4.size() * sizeof(Bvh4Node) + bvh.tris.size() * sizeof(BvhTri);
 
@@ -911,12 +911,10 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     if ((simple == false) || (m.subsurface.cls != 0u))
       out.simple_materials = false;
   }
-  if (const char* e = getenv("ETX_HIP_FORCE_GENERIC_MATERIALS")) {  // tests: every surface through the general kernels
-    if (atoi(e) != 0) {
-      out.simple_materials = false;
-      for (auto& g : groups)
-        g = (g == kShadeGroupSimple) ? uint8_t(kShadeGroupGeneral) : g;
-    }
+  if (tuning_knob("ETX_HIP_FORCE_GENERIC_MATERIALS", 0u) != 0u) {  // experiments: every surface through the general kernels
+    out.simple_materials = false;
+    for (auto& g : groups)
+      g = (g == kShadeGroupSimple) ? uint8_t(kShadeGroupGeneral) : g;
   }
   // PrincipledBSDF (bsdf_principled.hxx:24-114) evaluates Conductor / Dielectric / Plastic on a modified copy of the
   // material; the three copies are static, so they are appended to the table once (dev_bsdf_ool.h resolve_material)

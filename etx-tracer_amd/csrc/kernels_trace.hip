@@ -4,11 +4,11 @@
 // index-aligned with the path state, so no per-ray path index is moved); BVH bytes are not counted while the tree is
 // L2/LDS resident (Cornell: 3 KB). One lane = one ray; 256-thread blocks, persistent grid (256 CUs x 8 blocks),
 // wave-uniform grid-stride loop; per-lane traversal stack in LDS laid out [level][lane] (bank conflict free).
-#include <cstdlib>
 #include "kernels.h"
 #include "dev_bvh.h"
 #include "dev_vcm.h"
 #include "pipeline.h"
+#include "tuning_knobs.h"
 
 namespace etxd {
 
@@ -339,19 +339,19 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_flat2(const DScene
 }
 
 static uint32_t flat2_blocks(uint32_t items) {  // 512 rays per 256-thread block and loop iteration
-  const uint32_t limit = getenv("ETX_HIP_DEBUG_BLOCKS") ? uint32_t(strtoul(getenv("ETX_HIP_DEBUG_BLOCKS"), nullptr, 0)) : kFlat2Blocks;
+  const uint32_t limit = etxh::tuning_knob("ETX_HIP_DEBUG_BLOCKS", kFlat2Blocks);
   return max(1u, min(limit, (items + 2u * kBlockSize - 1u) / (2u * kBlockSize)));
 }
 
 // Persistent grid of the BVH kernel: as many workgroups as the device keeps resident (4 per CU at 40 KB of LDS each), fewer
 // for small queues so that every wavefront still owns several 64-ray rows to refill from.
 static uint32_t bvh_blocks(uint32_t items) {
-  const uint32_t limit = getenv("ETX_HIP_DEBUG_BLOCKS") ? uint32_t(strtoul(getenv("ETX_HIP_DEBUG_BLOCKS"), nullptr, 0)) : 256u * 4u;
+  const uint32_t limit = etxh::tuning_knob("ETX_HIP_DEBUG_BLOCKS", 256u * 4u);
   return max(1u, min(limit, (items + 4u * kBlockSize - 1u) / (4u * kBlockSize)));
 }
 
 static uint32_t lds_limit() {  // experiments: ETX_HIP_LDS_NODES caps the staged part of the tree (0 = everything through L2)
-  static const uint32_t limit = getenv("ETX_HIP_LDS_NODES") ? uint32_t(strtoul(getenv("ETX_HIP_LDS_NODES"), nullptr, 0)) : kLdsNodes;
+  static const uint32_t limit = etxh::tuning_knob("ETX_HIP_LDS_NODES", kLdsNodes);
   return limit;
 }
 
@@ -360,8 +360,8 @@ static uint32_t lds_limit() {  // experiments: ETX_HIP_LDS_NODES caps the staged
 template <bool kFromCounter>
 static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t* counters, uint32_t active_counter,
   uint32_t items, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat) {
-  static const uint32_t refill = getenv("ETX_HIP_REFILL_LANES") ? uint32_t(strtoul(getenv("ETX_HIP_REFILL_LANES"), nullptr, 0)) : kRefillLanes;
-  static const uint32_t variant = getenv("ETX_HIP_BVH_VARIANT") ? uint32_t(strtoul(getenv("ETX_HIP_BVH_VARIANT"), nullptr, 0)) : 0u;
+  static const uint32_t refill = etxh::tuning_knob("ETX_HIP_REFILL_LANES", kRefillLanes);
+  static const uint32_t variant = etxh::tuning_knob("ETX_HIP_BVH_VARIANT", 0u);
   const dim3 grid(bvh_blocks(items)), block(kBlockSize);
   const uint32_t fixed_count = kFromCounter ? 0u : items;
 #define ETX_LAUNCH_BVH(STACK, NODES)                                                                                                                                              \
@@ -480,14 +480,13 @@ void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_ite
     hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p);
 }
 
-void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count, bool flat) {
+void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count, bool flat, uint32_t debug_flags) {
   uint32_t blocks = min(kPersistentBlocks, (count + kBlockSize - 1) / kBlockSize);
   if (blocks == 0)
     return;
   DScene limited = scene;  // experiments: ETX_HIP_DEBUG_PRIMS caps the primitive count of the flat sweep (cost per primitive vs memory floor)
-  if (const char* e = getenv("ETX_HIP_DEBUG_PRIMS"))
-    limited.flat_prim_count = min(limited.flat_prim_count, uint32_t(strtoul(e, nullptr, 0)));
-  const bool two_ray_sweep = (getenv("ETX_HIP_DEBUG_FLAGS") != nullptr) && ((strtoul(getenv("ETX_HIP_DEBUG_FLAGS"), nullptr, 0) & 64u) != 0u);
+  limited.flat_prim_count = min(limited.flat_prim_count, etxh::tuning_knob("ETX_HIP_DEBUG_PRIMS", 0xffffffffu));
+  const bool two_ray_sweep = (debug_flags & 64u) != 0u;  // etx_hip_set_debug_flags: the packed two-ray sweep (kept, measured, not the default)
   if (flat && two_ray_sweep)
     hipLaunchKernelGGL((k_trace_closest_flat2<false>), dim3(flat2_blocks(count)), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u, 0u);
   else if (flat)

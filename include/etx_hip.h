@@ -234,6 +234,12 @@ int etx_hip_set_timers(etx_hip_context* context, uint32_t mask);
 
 int etx_hip_stats(etx_hip_context* context, etx_hip_stats_t* out_stats, size_t stats_size);
 
+/* Ablation switches of the kernels for timing experiments and kernel-level tests (0 = production, the default): bit 0 no film
+ * atomics in the shadow kernel, bit 2 no transmittance traversal, bit 6 (64) the packed two-ray flat sweep in etx_hip_trace_rays*,
+ * bits 8 / 9 no next event estimation / no camera vertex storage. Waits for the iterations in flight. The library reads no
+ * environment variable for these; builds with -DETX_HIP_DEBUG additionally read tuning knobs (csrc/tuning_knobs.h). */
+int etx_hip_set_debug_flags(etx_hip_context* context, uint32_t flags);
+
 /* ------------------------------------------------------------------------------------------------------------ */
 /* multi GPU: iterations are sharded over ranks (etx_hip_begin first/stride); the only exchange is one RCCL
  * sum-reduce of the two float4 film accumulators. The 128-byte ncclUniqueId is created by rank 0

@@ -112,19 +112,19 @@ def test_traversal_matches_bruteforce(etx, gpu_context, golden_dir, scene):
     np.testing.assert_allclose(hits[both, 0:2], expected[both, 0:2], rtol=0, atol=1e-5)
 
 
-def test_two_ray_packed_sweep_matches_one_ray_sweep(etx, gpu_context, golden_dir, monkeypatch):
-    """The opt-in packed-fp32 sweep (k_trace_closest_flat2, ETX_HIP_DEBUG_FLAGS bit 64: two rays per lane) against the
+def test_two_ray_packed_sweep_matches_one_ray_sweep(etx, gpu_context, golden_dir):
+    """The opt-in packed-fp32 sweep (k_trace_closest_flat2, etx_hip_set_debug_flags bit 64: two rays per lane) against the
     default one-ray sweep and the brute-force oracle, including ragged counts (half-filled 128-ray chunks)."""
     from oracle import ray_oracle
     snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_full_128.etxscene"))
     gpu_context.upload_scene(snap)
     for n in (1, 64, 65, 127, 129, 20000):
         rays = make_rays(n, 5 + n)
-        monkeypatch.delenv("ETX_HIP_DEBUG_FLAGS", raising=False)
+        gpu_context.set_debug_flags(0)
         one = gpu_context.trace_rays(rays)
-        monkeypatch.setenv("ETX_HIP_DEBUG_FLAGS", "64")
+        gpu_context.set_debug_flags(64)
         two = gpu_context.trace_rays(rays)
-        monkeypatch.delenv("ETX_HIP_DEBUG_FLAGS", raising=False)
+        gpu_context.set_debug_flags(0)
         tri_one, tri_two = one[:, 3].view(np.uint32), two[:, 3].view(np.uint32)
         same = tri_one == tri_two
         assert same.mean() > 0.999 or n < 1000 and same.all()

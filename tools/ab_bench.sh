@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B in ONE gpurun call (boxes differ by a few percent): tools/ab_bench.sh <workload> <repeats> tag[:FLAGS] ...
+# (ETX_HIP_DEBUG_FLAGS and the other knobs are read by ETX_HIP_DEBUG builds only: build the variants with tools/build_variant.sh <tag> "" host_api.cpp)
 # tag = base (regular library) or a tools/build_variant.sh tag; FLAGS = ETX_HIP_DEBUG_FLAGS for that run. Interleaved repeats.
 w=$1; n=$2; shift 2
 for r in $(seq $n); do
