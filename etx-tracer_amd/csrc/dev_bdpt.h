@@ -130,6 +130,29 @@ struct BFull {
   }
 };
 
+// bsdf::reverse_pdf at a vertex of ANY class: the bidirectional MIS weights carry the reverse pdf of every vertex of a path, delta
+// ones included (precompute_*_mis, :1012-1057), while the simple-group functions of dev_bsdf.h leave out the classes that are never
+// evaluated at a CONNECTIBLE vertex. Here the delta conductor and the mirror answer as scene_bsdf.hxx:94-104 does.
+template <bool kSimple>
+ETX_DEV float bdpt_reverse_pdf(const DScene& scene, const BsdfData& in_d, const f3& in_w_o, const etx_abi_material& m, Sampler& smp) {
+  if (kSimple) {
+    BsdfData d = in_d;
+    const f3 w_o = -in_d.w_i;
+    d.w_i = -in_w_o;
+    switch (m.cls) {
+      case ETX_MAT_CONDUCTOR:
+        return conductor_pdf(scene, d, w_o, m);
+      case ETX_MAT_MIRROR: {
+        const Frame frame = normal_frame(d);
+        return direction_matches(normalize(reflect(d.w_i, frame.nrm)), normalize(w_o)) ? 1.0f : 0.0f;
+      }
+      default:
+        return bsdf_pdf_simple(scene, d, w_o, m);
+    }
+  }
+  return bsdf_reverse_pdf_s<false>(scene, in_d, in_w_o, m, smp);
+}
+
 // PathVertex::pdf_area, bidirectional.cxx:102-128: pdf of going prev -> curr -> next, measured as area density at next
 template <bool kSimple>
 ETX_DEV float bdpt_pdf_area(const DScene& scene, uint32_t source, const f3& prev_pos, const BFull& curr, const BVtx& next, float wavelength, Sampler& smp) {

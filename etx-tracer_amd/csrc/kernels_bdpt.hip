@@ -301,7 +301,7 @@ ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const LaneStack& stac
       BVtx curr = {isect.pos, isect.nrm, 0.0f, 0.0f,
         kBvSurface | (connectible ? kBvConnectible : 0u) | ((connectible && (st.prev.flags & kBvConnectible)) ? kBvMisConnectible : 0u), isect.tri};
       curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, curr);
-      const float rev_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
+      const float rev_pdf = bdpt_reverse_pdf<kSimple>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
       const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
       r.v_pos = isect.pos, r.v_nrm = isect.nrm, r.v_wi = isect.w_i, r.v_throughput = st.throughput, r.v_flags = curr.flags, r.v_tri = isect.tri, r.v_bc_u = isect.bc.y, r.v_bc_v = isect.bc.z;
       if (enter || kInWalk)
@@ -747,7 +747,7 @@ ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, 
       r.curr = {isect.pos, isect.nrm, 0.0f, 0.0f, kBvSurface | (connectible ? kBvConnectible : 0u) | ((connectible && (st.prev.flags & kBvConnectible)) ? kBvMisConnectible : 0u),
         isect.tri};
       r.curr.from_prev = bdpt_to_area(st.pdf_dir, st.prev.pos, r.curr);
-      const float rev_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
+      const float rev_pdf = bdpt_reverse_pdf<kSimple>(scene, data, bs.w_o, scene.materials[vertex_material], st.sampler);
       const float prev_from_next = bdpt_to_area(rev_pdf, isect.pos, st.prev);
       const f3 vertex_throughput = st.throughput;
       const float prev_sampled_pdf = st.aux;  // z_prev.pdf.bsdf_sample_next (PathTracing mode weights)
@@ -1043,10 +1043,57 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_light(Pipeline p, V
 
 // connect_camera_to_light_path (:438-497), one (camera vertex, light vertex) pair per lane, with
 // mis_weight_camera_to_light_path (:1184-1209)
-// kFilter: 0 = every pair; 1 = the pairs whose two vertices are of the simple shading group (kSimple instantiation, scenes that also
-// hold other materials); 2 = the pairs with a vertex of another group. The class of a pair is in the flag words both instantiations
-// read anyway, and the pairs of one camera vertex are adjacent, so wavefronts are mostly of one class.
-template <bool kSimple, uint32_t kFilter>
+// The class of a pair (both instantiations read these words anyway) and whether it takes part at all
+struct BdptPairClass {
+  bool connects, general;
+};
+ETX_DEV BdptPairClass bdpt_pair_class(const Pipeline& p, const DScene& scene, const uint2 pair) {
+  const uint32_t y_flags = __float_as_uint(p.lv.thr_dvm(pair.y).w);
+  const uint32_t light_s = __float_as_uint(p.lv.bc_len_med(pair.y).z) >> 16u;
+  const uint32_t z_word = __float_as_uint(p.cv.thr_depth[pair.x].w);
+  const uint32_t camera_path_size = z_word & ~(kCvExitMaterialBit | kCvGeneralBsdfBit);
+  const uint32_t target_path_length = (camera_path_size - 1u) + light_s + 1u;
+  return {(light_s >= 1u) && ((y_flags & kBvConnectible) != 0u) && (target_path_length >= scene.min_path_length) && (target_path_length <= scene.max_path_length),
+    ((y_flags & kBvGeneralBsdf) != 0u) || ((z_word & kCvGeneralBsdfBit) != 0u)};
+}
+
+// connect_camera_to_light_path for one (camera vertex, light vertex) pair: the visibility request, or false
+template <bool kSimple>
+ETX_DEV bool bdpt_connect_pair(const Pipeline& p, const DScene& scene, const VcmParams& it, const uint2 pair, ShadowRequest& request) {
+  const BdptCameraVertex z = bdpt_load_camera_vertex(p, scene, pair.x);
+  const BdptLightVertex y = bdpt_load_light_vertex(p, scene, pair.y);
+  f3 dw = z.full.isect.pos - y.self.pos;
+  const float dwl = dot(dw, dw);
+  if ((dwl > kInvMaxHalf) == false)
+    return false;
+  dw = dw * (1.0f / sqrtf(dwl));
+  Sampler smp;
+  smp.seed = Sampler::random_seed(z.seed, pair.y), smp.fixed_u = smp.fixed_v = smp.fixed_w = 0.0f;
+  const f3 bsdf_y = bdpt_bsdf<kSimple>(scene, y.full, kPathLight, dw, z.wavelength, smp).bsdf;
+  const f3 bsdf_z = bdpt_bsdf<kSimple>(scene, z.full, kPathCamera, -dw, z.wavelength, smp).bsdf;
+  const f3 connect = y.throughput * bsdf_y * bsdf_z;
+  if (is_zero(connect))
+    return false;
+  float weight = 1.0f;
+  if (opt_enable_mis(it)) {
+    const BVtx y_prev = bdpt_load_light_summary(p, y.prev);
+    const BVtx z_curr = z.full.summary(z.from_prev);
+    const float z_curr_pdf = bdpt_pdf_area<kSimple>(scene, kPathLight, y_prev.pos, y.full, z_curr, z.wavelength, smp);
+    const float z_prev_pdf = bdpt_pdf_area<kSimple>(scene, kPathCamera, y.self.pos, z.full, z.prev, z.wavelength, smp);
+    const float y_curr_pdf = bdpt_pdf_area<kSimple>(scene, kPathCamera, z.prev.pos, z.full, y.self, z.wavelength, smp);
+    const float y_prev_pdf = bdpt_pdf_area<kSimple>(scene, kPathLight, z.full.isect.pos, y.full, y_prev, z.wavelength, smp);
+    const float w_camera = bdpt_mis_camera(z.path_size, z_curr_pdf, z.from_prev, z_prev_pdf, z.prev);
+    const float w_light = bdpt_mis_light(y_curr_pdf, y.self.from_prev, y_prev_pdf, y_prev);
+    weight = 1.0f / (1.0f + w_camera + w_light);
+  }
+  const f3 value = connect * z.throughput * (weight / dwl) * spectral_film_weight(scene, z.wavelength);
+  request = {bdpt_segment_origin(scene, y.full, z.full.isect.pos), z.full.isect.pos, value, y.medium, film_index(it, z.pixel), z.wavelength};
+  return true;
+}
+
+// The inline-BSDF kernel. kOnlySimple = false: every pair (a scene of simple materials); true: the pairs whose two vertices are of
+// the simple shading group, in a scene that also holds other materials (the rest: k_bdpt_connect_pairs_general).
+template <bool kOnlySimple>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs(Pipeline p, VcmParams it) {
   __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
@@ -1056,49 +1103,67 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs(Pipeline p, V
     bool queue = false;
     if (i < count) {
       const uint2 pair = p.pairs[i];
-      const uint32_t y_flags = __float_as_uint(p.lv.thr_dvm(pair.y).w);
-      const uint32_t light_s = __float_as_uint(p.lv.bc_len_med(pair.y).z) >> 16u;
-      const uint32_t z_word = __float_as_uint(p.cv.thr_depth[pair.x].w);
-      const uint32_t camera_path_size = z_word & ~(kCvExitMaterialBit | kCvGeneralBsdfBit);
-      const uint32_t target_path_length = (camera_path_size - 1u) + light_s + 1u;
-      const bool general_pair = ((y_flags & kBvGeneralBsdf) != 0u) || ((z_word & kCvGeneralBsdfBit) != 0u);
-      const bool mine = (kFilter == 0u) || ((kFilter == 1u) != general_pair);
-      if (mine && (light_s >= 1u) && (y_flags & kBvConnectible) && (target_path_length >= scene.min_path_length) && (target_path_length <= scene.max_path_length)) {
-        const BdptCameraVertex z = bdpt_load_camera_vertex(p, scene, pair.x);
-        const BdptLightVertex y = bdpt_load_light_vertex(p, scene, pair.y);
-        f3 dw = z.full.isect.pos - y.self.pos;
-        const float dwl = dot(dw, dw);
-        if (dwl > kInvMaxHalf) {
-          dw = dw * (1.0f / sqrtf(dwl));
-          Sampler smp;
-          smp.seed = Sampler::random_seed(z.seed, pair.y), smp.fixed_u = smp.fixed_v = smp.fixed_w = 0.0f;
-          const f3 bsdf_y = bdpt_bsdf<kSimple>(scene, y.full, kPathLight, dw, z.wavelength, smp).bsdf;
-          const f3 bsdf_z = bdpt_bsdf<kSimple>(scene, z.full, kPathCamera, -dw, z.wavelength, smp).bsdf;
-          const f3 connect = y.throughput * bsdf_y * bsdf_z;
-          if (is_zero(connect) == false) {
-            float weight = 1.0f;
-            if (opt_enable_mis(it)) {
-              const BVtx y_prev = bdpt_load_light_summary(p, y.prev);
-              const BVtx z_curr = z.full.summary(z.from_prev);
-              const float z_curr_pdf = bdpt_pdf_area<kSimple>(scene, kPathLight, y_prev.pos, y.full, z_curr, z.wavelength, smp);
-              const float z_prev_pdf = bdpt_pdf_area<kSimple>(scene, kPathCamera, y.self.pos, z.full, z.prev, z.wavelength, smp);
-              const float y_curr_pdf = bdpt_pdf_area<kSimple>(scene, kPathCamera, z.prev.pos, z.full, y.self, z.wavelength, smp);
-              const float y_prev_pdf = bdpt_pdf_area<kSimple>(scene, kPathLight, z.full.isect.pos, y.full, y_prev, z.wavelength, smp);
-              const float w_camera = bdpt_mis_camera(z.path_size, z_curr_pdf, z.from_prev, z_prev_pdf, z.prev);
-              const float w_light = bdpt_mis_light(y_curr_pdf, y.self.from_prev, y_prev_pdf, y_prev);
-              weight = 1.0f / (1.0f + w_camera + w_light);
-            }
-            const f3 value = connect * z.throughput * (weight / dwl) * spectral_film_weight(scene, z.wavelength);
-            request = {bdpt_segment_origin(scene, y.full, z.full.isect.pos), z.full.isect.pos, value, y.medium, film_index(it, z.pixel), z.wavelength};
-            queue = true;
-          }
-        }
-      }
+      const BdptPairClass c = bdpt_pair_class(p, scene, pair);
+      if (c.connects && ((kOnlySimple == false) || (c.general == false)))
+        queue = bdpt_connect_pair<true>(p, scene, it, pair, request);
     }
     const uint32_t slot = block_compact_slot(queue, p.counters + kCntShadow, s_scratch);
     if (queue)
       write_shadow(p, slot, request);
   }
+}
+
+// The pairs with a vertex of another shading group, through the out-of-line BSDF dispatch. They are few (the vertices on the
+// non-Lambert lobes of the scene) and scattered over the pair list; a kernel that took them where they stand paid a whole
+// wavefront of this register-heavy code for one or two live lanes. Each workgroup therefore collects the indices of its general
+// pairs in LDS while it streams over its part of the list and evaluates them 256 at a time, all lanes busy.
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs_general(Pipeline p, VcmParams it) {
+  __shared__ BlockScratch s_scratch;
+  __shared__ uint32_t s_queue[2u * kBlockSize];
+  __shared__ uint32_t s_queued;
+  const DScene& scene = p.scene;
+  const uint32_t count = min(p.counters[kCntPairs], p.pair_capacity);
+  if (threadIdx.x == 0u)
+    s_queued = 0u;
+  __syncthreads();
+  auto evaluate = [&](bool live, uint32_t index) {  // workgroup-uniform call
+    ShadowRequest request;
+    bool queue = false;
+    if (live)
+      queue = bdpt_connect_pair<false>(p, scene, it, p.pairs[index], request);
+    const uint32_t slot = block_compact_slot(queue, p.counters + kCntShadow, s_scratch);
+    if (queue)
+      write_shadow(p, slot, request);
+  };
+  ETX_BLOCK_LOOP(count, i) {
+    bool mine = false;
+    if (i < count) {
+      const BdptPairClass c = bdpt_pair_class(p, scene, p.pairs[i]);
+      mine = c.connects && c.general;
+    }
+    const unsigned long long mask = __ballot(mine);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32u), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+    uint32_t base = 0u;
+    if (((threadIdx.x & 63u) == 0u) && (mask != 0ull))
+      base = atomicAdd(&s_queued, uint32_t(__popcll(mask)));
+    base = __shfl(base, 0);
+    if (mine)
+      s_queue[base + rank] = i;
+    __syncthreads();
+    const uint32_t queued = s_queued;  // < 2 x 256: at most 255 were left over, at most 256 came in
+    __syncthreads();
+    if (queued >= kBlockSize) {  // workgroup-uniform
+      const uint32_t index = s_queue[queued - kBlockSize + threadIdx.x];
+      __syncthreads();
+      if (threadIdx.x == 0u)
+        s_queued = queued - kBlockSize;
+      evaluate(true, index);  // ends with a barrier (block_compact_slot)
+    }
+  }
+  __syncthreads();
+  const uint32_t rest = s_queued;
+  if (rest != 0u)  // workgroup-uniform
+    evaluate(threadIdx.x < rest, (threadIdx.x < rest) ? s_queue[threadIdx.x] : 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1148,10 +1213,11 @@ void launch_bdpt_connect_light(hipStream_t stream, const Pipeline& p, const VcmP
 void launch_bdpt_connect_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, bool simple) {
   const uint32_t pair_blocks = max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 8ull, uint64_t(p.pair_capacity)))));
   if (simple) {
-    hipLaunchKernelGGL((k_bdpt_connect_pairs<true, 0u>), dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
+    hipLaunchKernelGGL(k_bdpt_connect_pairs<false>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
   } else {
-    hipLaunchKernelGGL((k_bdpt_connect_pairs<true, 1u>), dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
-    hipLaunchKernelGGL((k_bdpt_connect_pairs<false, 2u>), dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
+    hipLaunchKernelGGL(k_bdpt_connect_pairs<true>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
+    // fewer, fatter workgroups: each collects its general pairs over a long stretch of the list
+    hipLaunchKernelGGL(k_bdpt_connect_pairs_general, dim3(max(1u, min(pair_blocks, 512u))), dim3(kBlockSize), 0, stream, p, it);
   }
 }
 
