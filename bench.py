@@ -61,7 +61,9 @@ def cpu_baseline(snapshot_path, width, height, seconds_budget=25.0, integrator="
     }
 
 
-def main():
+def main(argv=None, context_factory=None, backend="nccl"):
+    """`context_factory` / `backend`: the CPU test of the N > 1 control flow (tests/test_multi_gpu_gloo.py) runs this function in two
+    gloo processes with a stand-in for api.Context; the driver's command line uses neither."""
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=32)
@@ -75,7 +77,8 @@ def main():
     parser.add_argument("--bvh", default="host", choices=["host", "device"], help="who builds the traversal tree (etx_hip_set_bvh_builder)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-kernel-table", action="store_true", help="skip the extra pass that times every kernel group (profiling runs)")
-    args = parser.parse_args()
+    args = parser.parse_args(argv)
+    device = "cuda" if backend == "nccl" else "cpu"
 
     import numpy as np
     import torch
@@ -89,10 +92,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
+    if device == "cuda":
+        torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if device == "cuda":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     spectral_workload = args.workload in ("gems", "gems1m")
     bdpt_workload = args.workload in ("sssdragon_bdpt", "cloud_bdpt")
@@ -114,7 +121,7 @@ def main():
     else:
         snap = etx.SceneSnapshot(snapshot_path)
     width, height = snap.film_size
-    ctx = api.Context(local_rank)
+    ctx = (context_factory or api.Context)(local_rank)
     ctx.set_bvh_builder(api.BVH_DEVICE_LBVH if args.bvh == "device" else api.BVH_HOST_SAH)
     upload_t0 = time.perf_counter()
     ctx.upload_scene(snap)
@@ -158,7 +165,8 @@ def main():
     def barrier():
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+        if device == "cuda":
+            torch.cuda.synchronize()
         ctx.sync()
 
     if args.warmup > 0:
@@ -168,7 +176,7 @@ def main():
     acc = run_steps(args.steps, args.warmup)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = multi_gpu.max_over_ranks(elapsed, device="cuda")
+    elapsed = multi_gpu.max_over_ranks(elapsed, device=device)
 
     result = ctx.read_film(api.LAYER_RESULT)
     finite = bool(np.isfinite(result).all())
@@ -178,17 +186,19 @@ def main():
     isolated = None
     if rank == 0:
         n_rays = width * height
-        g = torch.Generator(device="cuda").manual_seed(1)
-        o = torch.stack([torch.rand(n_rays, generator=g, device="cuda") * 1.9 - 0.95, torch.rand(n_rays, generator=g, device="cuda") * 1.85 + 0.05,
-                         torch.rand(n_rays, generator=g, device="cuda") * 1.9 - 0.95], dim=1)
-        d = torch.randn(n_rays, 3, generator=g, device="cuda")
+        g = torch.Generator(device=device).manual_seed(1)
+        o = torch.stack([torch.rand(n_rays, generator=g, device=device) * 1.9 - 0.95, torch.rand(n_rays, generator=g, device=device) * 1.85 + 0.05,
+                         torch.rand(n_rays, generator=g, device=device) * 1.9 - 0.95], dim=1)
+        d = torch.randn(n_rays, 3, generator=g, device=device)
         d = d / d.norm(dim=1, keepdim=True)
-        ro = torch.cat([o, torch.full((n_rays, 1), 2.2889e-4, device="cuda")], dim=1).contiguous()
-        rd = torch.cat([d, torch.full((n_rays, 1), 3.0e38, device="cuda")], dim=1).contiguous()
-        hits = torch.empty((n_rays, 4), device="cuda")
-        torch.cuda.synchronize()
+        ro = torch.cat([o, torch.full((n_rays, 1), 2.2889e-4, device=device)], dim=1).contiguous()
+        rd = torch.cat([d, torch.full((n_rays, 1), 3.0e38, device=device)], dim=1).contiguous()
+        hits = torch.empty((n_rays, 4), device=device)
+        if device == "cuda":
+            torch.cuda.synchronize()
         ms = ctx.trace_rays_device(ro.data_ptr(), rd.data_ptr(), n_rays, hits.data_ptr(), 20)
-        torch.cuda.synchronize()
+        if device == "cuda":
+            torch.cuda.synchronize()
         gbs = n_rays * BYTES_PER_RAY / ms / 1.0e6
         isolated = {"rays_per_launch": n_rays, "avg_launch_ms": round(ms, 6), "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6),
                     "note": "the same kernel alone on the device, 20 launches over one queue of incoherent rays"}
@@ -364,11 +374,12 @@ def main():
                                                 extra=(tuple(cpu_extra) + ("--opt", "bdpt-mode=3")) if bdpt_workload else ())
             if cpu_snapshot_path != snapshot_path:
                 os.remove(cpu_snapshot_path)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    return line if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -91,7 +91,11 @@ struct DMedium {
   uint32_t absorption_index, scattering_index;  // spectra (spectral mode), kInvalid = zero
   uint32_t cls, explicit_connections;
   float g, max_sigma;
-  uint32_t dim_x, dim_y, dim_z, pad;
+  uint32_t dim_x, dim_y, dim_z;
+  // spectral scenes, walk medium DERIVED from a subsurface material (bidirectional integrator, host_scene.cpp): the spectra of the material's
+  // colour and scattering distances; the coefficients at a wavelength are subsurface::remap_channel of their values there
+  uint32_t derived_color, derived_distances;  // spectrum indices, kInvalid = not a derived medium
+  uint32_t pad;
 };
 
 
@@ -230,10 +234,30 @@ ETX_DEV f3 spectral_film_weight(const DScene& s, float wavelength) {
 }
 
 // absorption / scattering coefficients of a medium at the path's wavelength (RGB mode: the resolved RGB values)
+// subsurface::remap_channel, scene_bssrdf_subsurface.hxx:17-44 (van de Hulst style albedo inversion)
+ETX_DEV void sss_remap_channel(float color, float scattering_distance, float& albedo, float& extinction, float& scattering) {
+  const float a = 1.826052378200f, b = 4.985111943850f + 0.12735595943800f, c = 1.096861024240f;
+  const float d = 0.496310210422f, e = 4.231902997010f + 0.00310603949088f, f = 2.406029994080f;
+  const float kMinScattering = 1.0f / 1024.0f;
+  color = fmaxf(0.0f, color);
+  const float blend = powf(color, 0.25f);
+  albedo = (1.0f - blend) * a * powf(atanf(b * color), c) + blend * d * powf(atanf(e * color), f);
+  albedo = fminf(fmaxf(albedo, 0.0f), 1.0f - kEpsilon);
+  extinction = 1.0f / fmaxf(scattering_distance, kMinScattering);
+  scattering = extinction * albedo;
+}
+
 ETX_DEV void medium_coefficients(const DScene& s, const DMedium& m, float wavelength, f3& absorption, f3& scattering) {
   if (s.spectral == 0u) {
     absorption = m.absorption;
     scattering = m.scattering;
+    return;
+  }
+  if (m.derived_color != kInvalid) {  // subsurface_to_medium_instance / subsurface_step at this wavelength (bidirectional.cxx:729-771)
+    float albedo, extinction, scatter;
+    sss_remap_channel(spectrum_eval(s, m.derived_color, wavelength).x, spectrum_eval(s, m.derived_distances, wavelength).x, albedo, extinction, scatter);
+    scattering = f3{scatter, scatter, scatter};
+    absorption = f3{extinction - scatter, extinction - scatter, extinction - scatter};
     return;
   }
   absorption = (m.absorption_index == kInvalid) ? f3{0.0f, 0.0f, 0.0f} : spectrum_eval(s, m.absorption_index, wavelength);

@@ -12,21 +12,9 @@ ETX_DEV bool is_zero_sss(const f3& v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Random-walk subsurface scattering: subsurface::remap_channel (scene_bssrdf_subsurface.hxx:17-44) and
+// Random-walk subsurface scattering: subsurface::remap_channel (scene_bssrdf_subsurface.hxx:17-44, dev_scene.h sss_remap_channel) and
 // subsurface::gather_rw (path_tracing_shared.hxx:64-159). The walk runs inside the shade kernel with an inline
 // material-filtered closest-hit query (Raytracing::trace_material, rt.cxx:327-371) until it leaves the object.
-ETX_DEV void sss_remap_channel(float color, float scattering_distance, float& albedo, float& extinction, float& scattering) {
-  const float a = 1.826052378200f, b = 4.985111943850f + 0.12735595943800f, c = 1.096861024240f;
-  const float d = 0.496310210422f, e = 4.231902997010f + 0.00310603949088f, f = 2.406029994080f;
-  const float kMinScattering = 1.0f / 1024.0f;
-  color = fmaxf(0.0f, color);
-  const float blend = powf(color, 0.25f);
-  albedo = (1.0f - blend) * a * powf(atanf(b * color), c) + blend * d * powf(atanf(e * color), f);
-  albedo = fminf(fmaxf(albedo, 0.0f), 1.0f - kEpsilon);
-  extinction = 1.0f / fmaxf(scattering_distance, kMinScattering);
-  scattering = extinction * albedo;
-}
-
 ETX_DEV float sss_safe_mul(float a, float b) {  // path_tracing_shared.hxx:51-53
   return ((a == 0.0f) || (b == 0.0f)) ? 0.0f : a * b;
 }

@@ -1207,7 +1207,7 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
     }
     if (context->scene.has_subsurface && (context->scene.sss_media_complete == false)) {
       context->error = "bidirectional integrator: a subsurface material without an interior medium derives its walk medium from its colour and distances; the device path "
-                       "does that for untextured RGB parameters only (spectral scenes, textured scattering colour / distances: use VCM or path tracing)";
+                       "does that for untextured parameters only (a textured scattering colour / distance map makes the medium a property of the entry point: use VCM or path tracing)";
       return ETX_HIP_ERROR_UNSUPPORTED;
     }
     context->active_bluenoise = nullptr;

@@ -1059,6 +1059,7 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     const etx_abi_medium& m = mediums[i];
     DMedium& dm = dmediums[i];
     dm = {};
+    dm.derived_color = dm.derived_distances = kInvalid;
     dm.bounds_min = a3(m.bounds_min), dm.bounds_max = a3(m.bounds_max);
     auto resolve = [&](uint32_t idx) {  // scene_medium.hxx:146-158: invalid index => zero
       return ((idx == ETX_ABI_INVALID) || (idx >= scene->spectrums.count)) ? mk3(0.0f) : a3(spectrums[idx].integrated);
@@ -1101,13 +1102,14 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   // Subsurface materials under the bidirectional integrator (bidirectional.cxx:729-790): the walk runs through the material's
   // interior medium, or - without one - through a medium derived from its colour and scattering distances
   // (subsurface::remap_channel, scene_bssrdf_subsurface.hxx:17-44). The derived medium becomes a table entry of its own here, so that
-  // vertices inside the object name their medium by index like every other vertex. RGB mode, untextured parameters; anything
-  // else leaves the material without an entry and etx_hip_begin refuses the scene for that integrator.
+  // vertices inside the object name their medium by index like every other vertex. Untextured parameters (a textured colour would make
+  // the coefficients a property of the entry POINT, not of the material): such a material is left without an entry and etx_hip_begin
+  // refuses the scene for that integrator. Spectral scenes: the entry names the two spectra and the device remaps at the path's wavelength.
   std::vector<uint32_t> sss_medium(material_table.size(), kInvalid);
   out.sss_media_complete = true;
   auto derive_medium = [&](const etx_abi_material& m) -> uint32_t {
     const bool textured = (m.scattering.image_index != ETX_ABI_INVALID) || (m.subsurface.image_index != ETX_ABI_INVALID);
-    if (spectral || textured || (m.scattering.spectrum_index >= scene->spectrums.count) || (m.subsurface.spectrum_index >= scene->spectrums.count))
+    if (textured || (m.scattering.spectrum_index >= scene->spectrums.count) || (m.subsurface.spectrum_index >= scene->spectrums.count))
       return kInvalid;
     const f3 color = a3(spectrums[m.scattering.spectrum_index].integrated), distances = a3(spectrums[m.subsurface.spectrum_index].integrated);
     auto remap = [](float colour, float distance, float& extinction, float& scattering) {
@@ -1127,6 +1129,8 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     DMedium dm = {};
     dm.absorption = extinction - scattering, dm.scattering = scattering;
     dm.absorption_index = dm.scattering_index = kInvalid;
+    dm.derived_color = spectral ? m.scattering.spectrum_index : kInvalid;
+    dm.derived_distances = spectral ? m.subsurface.spectrum_index : kInvalid;
     dm.cls = 0u, dm.explicit_connections = 0u, dm.g = 0.0f;
     dmediums.push_back(dm);
     return uint32_t(dmediums.size() - 1u);

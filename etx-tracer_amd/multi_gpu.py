@@ -26,7 +26,7 @@ def init_context_comm(context, rank, world_size, make_id=None):
     receives its 128 bytes through the torch.distributed process group (any backend) and calls etx_hip_comm_init.
     `make_id`: replaces etx_hip_comm_unique_id where no GPU exists (the gloo tests)."""
     from . import api
-    make_id = make_id or (lambda: api.comm_unique_id(context.library))
+    make_id = make_id or getattr(context, "make_unique_id", None) or (lambda: api.comm_unique_id(context.library))
     payload = [make_id() if rank == 0 else None]
     dist.broadcast_object_list(payload, src=0)
     context.comm_init(rank, world_size, payload[0])

@@ -346,8 +346,13 @@ struct HIPIntegratorBase : public Integrator {
     Film& film = rt.film();
     const uint2 dim = film.size();
     const size_t pixels = size_t(dim.x) * dim.y;
-    if ((film.pixel_size() != 1u) || (_status.completed_iterations == 0))
+    if (_status.completed_iterations == 0)
       return;
+    // Film::pixel_size() > 1 (the GUI sets 8 while the camera moves, app.cxx:135): the reference renders one path per BLOCK and
+    // accumulate_camera_image / atomic_add_light_iteration fill the block (film.cxx:152-168, 185-199). The device renders the full
+    // frame in either case - an iteration costs it milliseconds -, so the preview is published as block means through those same
+    // two calls (write_layers_to_film); the bulk interface below writes single pixels and is used at pixel size 1 only.
+    const bool preview = film.pixel_size() != 1u;
     camera.resize(pixels);
     normal.resize(pixels);
     albedo.resize(pixels);
@@ -363,6 +368,7 @@ struct HIPIntegratorBase : public Integrator {
     }
 #if defined(ETX_FILM_HAS_MERGE_ITERATION)
     // integration/film_merge_iteration.patch applied: one bulk call, no per-pixel accumulate
+    if (preview == false) {
     if (writes_light_image()) {
       light.resize(pixels);
       if (lib.read_film(ctx, ETX_HIP_LAYER_LIGHT, &light[0].x, pixels * sizeof(float4)) != ETX_HIP_OK) {
@@ -379,7 +385,9 @@ struct HIPIntegratorBase : public Integrator {
     light_updated = writes_light_image();
     published = _status.completed_iterations;
     return;
+    }
 #endif
+    (void)preview;
     if (writes_light_image()) {
       light.resize(pixels);
       if (lib.read_film(ctx, ETX_HIP_LAYER_LIGHT, &light[0].x, pixels * sizeof(float4)) != ETX_HIP_OK) {
@@ -396,24 +404,40 @@ struct HIPIntegratorBase : public Integrator {
     Film& film = rt.film();
     const uint2 dim = film.size();
     film.clear(Film::ClearCameraData | (with_light ? uint32_t(Film::ClearLightData) : 0u));
-    // rows of the device film are the Film's storage rows: storage row r holds pixel y = H - 1 - r (film.cxx:189)
-    for (uint32_t row = 0; row < dim.y; ++row) {
-      for (uint32_t x = 0; x < dim.x; ++x) {
-        const size_t i = size_t(row) * dim.x + x;
-        const float4& c = camera[i];
+    // Film::clear applies a pending set_pixel_size (film.cxx:365): read it afterwards. One call per block of pixel_size^2 pixels
+    // (= per pixel at size 1) with the mean of the device's full-resolution film over the block; both Film calls fill the block.
+    const uint32_t block = film.pixel_size();
+    // mean of a layer over the block whose base pixel is (bx, by); rows of the device film are the Film's storage rows: storage
+    // row r holds pixel y = H - 1 - r (film.cxx:189)
+    auto block_mean = [&](const std::vector<float4>& layer, uint32_t bx, uint32_t by) {
+      float3 sum = {};
+      uint32_t n = 0;
+      for (uint32_t y = by, ye = min(by + block, dim.y); y < ye; ++y) {
+        for (uint32_t x = bx, xe = min(bx + block, dim.x); x < xe; ++x, ++n) {
+          const float4& v = layer[size_t(dim.y - 1u - y) * dim.x + x];
+          sum += float3{v.x, v.y, v.z};
+        }
+      }
+      return sum / float(max(n, 1u));
+    };
+    for (uint32_t by = 0; by < dim.y; by += block) {
+      for (uint32_t bx = 0; bx < dim.x; bx += block) {
+        const float3 c = block_mean(camera, bx, by);
         // Film::layer(Normals) = n * 0.5 + 0.5 (film.cxx:411): the device returns the layer, the film stores n
-        const float3 n = aovs ? float3{normal[i].x * 2.0f - 1.0f, normal[i].y * 2.0f - 1.0f, normal[i].z * 2.0f - 1.0f} : float3{};
-        const float3 a = aovs ? float3{albedo[i].x, albedo[i].y, albedo[i].z} : float3{};
-        film.accumulate_camera_image({x, dim.y - 1u - row}, {c.x, c.y, c.z}, n, a);
+        const float3 n = aovs ? block_mean(normal, bx, by) * 2.0f - float3{1.0f, 1.0f, 1.0f} : float3{};
+        const float3 a = aovs ? block_mean(albedo, bx, by) : float3{};
+        film.accumulate_camera_image({bx, by}, c, n, a);
       }
     }
     camera_updated = true;
     if (with_light) {
-      for (uint32_t row = 0; row < dim.y; ++row) {
-        for (uint32_t x = 0; x < dim.x; ++x) {
-          const float4& l = light[size_t(row) * dim.x + x];
-          const float2 ndc = {(float(x) + 0.5f) / float(dim.x) * 2.0f - 1.0f, (float(dim.y - 1u - row) + 0.5f) / float(dim.y) * 2.0f - 1.0f};
-          film.atomic_add_light_iteration({l.x, l.y, l.z}, ndc);
+      // atomic_add_light_iteration maps ndc -> reduced-resolution pixel -> block (film.cxx:152-159): aim at the block's centre
+      const uint2 reduced = film.dimensions();
+      for (uint32_t by = 0; by < dim.y; by += block) {
+        for (uint32_t bx = 0; bx < dim.x; bx += block) {
+          const float3 l = block_mean(light, bx, by);
+          const float2 ndc = {(float(bx / block) + 0.5f) / float(reduced.x) * 2.0f - 1.0f, (float(by / block) + 0.5f) / float(reduced.y) * 2.0f - 1.0f};
+          film.atomic_add_light_iteration(l, ndc);
         }
       }
       film.commit_light_iteration(0);

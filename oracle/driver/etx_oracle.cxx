@@ -247,7 +247,7 @@ int print_kat() {
 void usage() {
   printf(
     "etx_oracle --scene file.json | --load-snapshot scene.bin --integrator pt|vcm|bdpt|hip-vcm|hip-pt|hip-bdpt [--spp N] [--out film.raw] [--snapshot scene.bin]\n"
-    "           [--data /root/reference/bin/] [--opt key=value]... [--max-iterations N]\n"
+    "           [--data /root/reference/bin/] [--opt key=value]... [--max-iterations N] [--pixel-size N] [--inject-density N]\n"
     "           hip-* only: [--checkpoint file] (film state when the render stops) [--resume file] (continue that render)\n");
 }
 
@@ -261,6 +261,7 @@ int main(int argc, char** argv) {
   int64_t max_iterations = -1;
   float noise_threshold = -1.0f;  // < 0: keep the scene value
   int64_t subsurface_class = -1;  // >= 1: every subsurface material of the loaded scene gets this SubsurfaceMaterial::Class (1 random walk, 2 Christensen-Burley)
+  uint32_t pixel_size = 0;      // >= 1: Film::set_pixel_size before the render (the GUI's preview while the camera moves, app.cxx:135)
   uint32_t inject_density = 0;  // N: every medium of the loaded scene becomes Heterogeneous with a procedural N^3 density grid
   for (int i = 1; i < argc; ++i) {
     auto next = [&]() -> const char* {
@@ -326,6 +327,8 @@ int main(int argc, char** argv) {
     }
     else if (strcmp(argv[i], "--inject-density") == 0)
       inject_density = uint32_t(atoll(next()));
+    else if (strcmp(argv[i], "--pixel-size") == 0)
+      pixel_size = uint32_t(atoll(next()));
     else if (strcmp(argv[i], "--integrator") == 0)
       integrator_name = next();
     else if (strcmp(argv[i], "--spp") == 0)
@@ -495,6 +498,8 @@ int main(int argc, char** argv) {
     printf("integrator %s is not available on this machine\n", integrator->name());
     return 5;
   }
+  if (pixel_size >= 1u)
+    raytracing.film().set_pixel_size(pixel_size);  // takes effect at the next Film::clear (film.cxx:365)
   raytracing.film().clear(Film::ClearEverything);
   auto t0 = std::chrono::steady_clock::now();
   HIPIntegratorBase* hip = (integrator_name.rfind("hip-", 0) == 0) ? static_cast<HIPIntegratorBase*>(integrator) : nullptr;

@@ -552,6 +552,8 @@ two_sided 1
 
 """ + MTL_LIGHT_CLASSIC)
     write_json("sss_test_128.json", "cornell_classic.obj", "cornell_sss.mtl", (128, 128), 64)
+    # ... in spectral mode: the walk medium the bidirectional integrator derives from colour and distances depends on the wavelength
+    write_json("sssspec_test_128.json", "cornell_classic.obj", "cornell_sss.mtl", (128, 128), 64, spectral=True)
     # the same two materials on sphere meshes (BVH traversal instead of the flat sweep)
     build_mesh(False, sss_meshes=True).write(os.path.join(OUT, "cornell_sssmesh.obj"), "cornell_sss.mtl")
     write_json("sssmesh_test_128.json", "cornell_sssmesh.obj", "cornell_sss.mtl", (128, 128), 64)

@@ -1,0 +1,118 @@
+"""TEST DOUBLE (not product code): stands in for etx_tracer_amd.api.Context where no GPU exists, so that bench.py's N > 1 control
+flow - process group, id broadcast, iteration sharding, warm-up / timed region, barrier, max over ranks, film reduce, the JSON line -
+runs line by line under gloo (tests/test_multi_gpu_gloo.py). An "iteration" is a deterministic image that depends on its index only;
+reduce_film all-reduces the sums and the iteration count like etx_hip_reduce_film does over RCCL."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from etx_tracer_amd import api
+
+
+def fake_iteration(iteration, h=12, w=16):
+    g = torch.Generator().manual_seed(1234 + iteration)
+    camera = torch.rand((h, w, 4), generator=g) * (1.0 + 0.01 * iteration)
+    light = torch.rand((h, w, 4), generator=g) * 0.1
+    return camera, light
+
+
+class StubContext:
+    instances = []
+
+    def __init__(self, device=0):
+        self.device = device
+        self.library = None
+        self.calls = []
+        self.film_size = (0, 0)
+        self.iterations_rendered = []  # since the last begin
+        self.camera_sum = self.light_sum = None
+        self.count = torch.zeros((1,), dtype=torch.int64)
+        self.reduced = False
+        StubContext.instances.append(self)
+
+    def make_unique_id(self):  # multi_gpu.init_context_comm: instead of etx_hip_comm_unique_id
+        return bytes(range(128))
+
+    def comm_init(self, rank, world, unique_id):
+        self.calls.append(("comm_init", rank, world, bytes(unique_id)))
+
+    def set_bvh_builder(self, builder):
+        self.calls.append(("set_bvh_builder", builder))
+
+    def upload_scene(self, snapshot):
+        self.film_size = snapshot.film_size
+        self.calls.append(("upload_scene",))
+
+    def bvh_info(self):
+        return {"nodes": 1, "triangles": 32, "depth": 1, "stack_need": 3, "bytes": 128, "build_ms": 0.0}
+
+    def upload_cie_table(self, xyz, first):
+        self.calls.append(("upload_cie_table",))
+
+    def upload_bluenoise(self, set_index, table):
+        self.calls.append(("upload_bluenoise", set_index))
+
+    def set_timers(self, mask):
+        self.calls.append(("set_timers", mask))
+
+    def _begin(self, first_iteration, iteration_stride):
+        self.next_iteration, self.stride = first_iteration, iteration_stride
+        self.iterations_rendered = []
+        self.camera_sum = torch.zeros((12, 16, 4))
+        self.light_sum = torch.zeros((12, 16, 4))
+        self.count.zero_()
+        self.reduced = False
+
+    def begin_vcm(self, options, first_iteration=0, iteration_stride=1):
+        self.calls.append(("begin_vcm", first_iteration, iteration_stride))
+        self._begin(first_iteration, iteration_stride)
+
+    def begin_bdpt(self, options, first_iteration=0, iteration_stride=1):
+        self.calls.append(("begin_bdpt", first_iteration, iteration_stride))
+        self._begin(first_iteration, iteration_stride)
+
+    def render_iteration(self):
+        assert self.reduced is False
+        camera, light = fake_iteration(self.next_iteration)
+        self.camera_sum += camera
+        self.light_sum += light
+        self.count += 1
+        self.iterations_rendered.append(self.next_iteration)
+        self.next_iteration += self.stride
+
+    def sync(self):
+        pass
+
+    def stats(self):
+        s = api.Stats()
+        n = len(self.iterations_rendered)
+        s.completed_iterations = n
+        s.rays_extension, s.rays_shadow, s.light_vertices = 1000 * n, 2000 * n, 300 * n
+        s.ms_trace_closest, s.launches_trace_closest = 0.5 * n, 10 * n
+        s.wavefront_bounces = 20 * n
+        return s
+
+    def reduce_film(self):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.camera_sum, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self.light_sum, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self.count, op=dist.ReduceOp.SUM)
+        self.reduced = True
+        # what the LAST reduce held (bench.py renders more afterwards: its per-kernel pass on rank 0)
+        self.reduced_result = self.result()
+        self.reduced_iterations = list(self.iterations_rendered)
+
+    def result(self):
+        out = torch.clamp((self.camera_sum + self.light_sum) / max(int(self.count.item()), 1), min=0.0)
+        out[..., 3] = 1.0
+        return out.numpy()
+
+    def read_film(self, layer):
+        w, h = self.film_size
+        return np.zeros((h, w, 4), dtype=np.float32)
+
+    def trace_rays_device(self, d_o, d_d, count, d_hits, repeat):
+        return 0.05
+
+    def close(self):
+        self.calls.append(("close",))

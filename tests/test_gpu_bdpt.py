@@ -24,13 +24,14 @@ def load(golden_dir, name):
     return np.load(path)
 
 
-def render_halves(etx, golden_dir, flavour, spp, options):
+def render_halves(etx, golden_dir, flavour, spp, options, cie=None):
     films = []
     for first in (0, 1):
         snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_%s_128.etxscene" % flavour))
         snap.samples = spp
         integ = etx.HIPBidirectional(snap, first_iteration=first, iteration_stride=2)
         integ.options().update(options)
+        integ.cie_table = cie
         integ.render()
         cam, light = integ.film(etx.api.LAYER_CAMERA), integ.film(etx.api.LAYER_LIGHT)
         stats = integ.status()
@@ -84,7 +85,8 @@ def test_bdpt_single_technique_modes(etx, golden_dir, mode):
 def test_bdpt_subsurface_walk_matches_reference(etx, golden_dir, mode):
     """configs[3] family: subsurface materials under the bidirectional integrator. The reference threads the walk through the path
     (bidirectional.cxx:610-633 entry vertex with the scatter material, :746-818 one medium vertex per scattering event, :858-861 exit
-    vertex); the device runs the walk's sub-steps inside the shade kernels (kernels_bdpt.hip BdptWalk). BDPTFull and BDPTFast, 256 spp (a walk is a serial chain of material-filtered traversals per lane: 65 ms per iteration at 128 x 128).
+    vertex); the device takes such a path out of the wavefront: walk queue, k_bdpt_walk_* for the scattering events, k_bdpt_walk_exit_* for the
+    exit vertex (kernels_bdpt.hip). BDPTFull and BDPTFast, 256 spp.
     The entry vertex's connections are attenuated with the medium the reference derives from the SCATTER material (:630-632), which is what
     the vertex-connection comparison of BDPTFull pins."""
     if mode == 3:  # the same mode with the vertex connections off isolates them in a failure
@@ -100,6 +102,30 @@ def test_bdpt_subsurface_walk_matches_reference(etx, golden_dir, mode):
     compare((cam_a, cam_b), golden["camera"], label + "camera (independent streams)", rmse_limit=1.5e-3)
     golden = load(golden_dir, "cornell_sss_128_bdpt%d_256.npz" % mode)
     compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], label + "camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
+
+
+def test_bdpt_spectral_scene_matches_reference(etx, golden_dir, cie_observer):
+    """configs[2]'s scene family under the bidirectional integrator: one wavelength per path (the camera path reuses the light path's,
+    bidirectional.cxx:377-391), dispersive dielectrics, a rough conductor; 2 892 triangles on the tree. BDPTFull, 1024 spp."""
+    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, "gems", 1024, {"bdpt-mode": etx.api.BDPT_MODE_FULL, "bdpt-blue_noise": False}, cie=cie_observer)
+    golden = load(golden_dir, "cornell_gems_128_bdpt3_1024_rekeyed.npz")
+    assert int(golden["spp"]) in (1023, 1024)
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "gems bdpt camera+light (independent streams)", rmse_limit=1.5e-3)
+    compare((cam_a, cam_b), golden["camera"], "gems bdpt camera (independent streams)", rmse_limit=1.5e-3)
+    golden = load(golden_dir, "cornell_gems_128_bdpt3_1024.npz")
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "gems bdpt camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
+
+
+def test_bdpt_spectral_subsurface_walk_matches_reference(etx, golden_dir, cie_observer):
+    """The subsurface box in spectral mode: the medium a walk runs through is derived from the material's colour and scattering distances
+    AT THE PATH'S WAVELENGTH (subsurface_step, bidirectional.cxx:757-771; device: DMedium::derived_color / _distances + medium_coefficients)."""
+    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, "sssspec", 256, {"bdpt-mode": etx.api.BDPT_MODE_FULL, "bdpt-blue_noise": False}, cie=cie_observer)
+    golden = load(golden_dir, "cornell_sssspec_128_bdpt3_256_rekeyed.npz")
+    assert int(golden["spp"]) in (255, 256)
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "sss spectral bdpt camera+light (independent streams)", rmse_limit=1.5e-3)
+    compare((cam_a, cam_b), golden["camera"], "sss spectral bdpt camera (independent streams)", rmse_limit=1.5e-3)
+    golden = load(golden_dir, "cornell_sssspec_128_bdpt3_256.npz")
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "sss spectral bdpt camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
 
 
 def test_bdpt_rejects_what_it_does_not_implement(etx, golden_dir, cie_observer):

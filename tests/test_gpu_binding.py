@@ -102,3 +102,19 @@ def test_cpp_binding_spectral_scene_uploads_the_observer(etx, golden_dir, tmp_pa
     cam = integ.film(etx.api.LAYER_CAMERA)
     integ.context.close()
     np.testing.assert_allclose(film["camera"][..., :3], cam[..., :3], rtol=5e-4, atol=5e-5)
+
+
+def test_cpp_binding_publishes_the_preview_at_pixel_size_8(golden_dir, tmp_path):
+    """Film::pixel_size() > 1 - the GUI sets 8 while the camera moves (app.cxx:135) and the CPU integrators then render one path per
+    block (film.cxx:152-168, 185-199). The device renders the full frame regardless; the binding publishes block means through the
+    same two Film calls, which fill the blocks: the film shows the current render, coarse, as the reference's preview does."""
+    snapshot = os.path.join(golden_dir, "cornell_full_128.etxscene")
+    fine, _ = run_driver(tmp_path, snapshot, "hip-vcm", 16, "vcm-blue_noise=false", name="fine")
+    coarse, _ = run_driver(tmp_path, snapshot, "hip-vcm", 16, "vcm-blue_noise=false", extra=["--pixel-size", "8"], name="coarse")
+    assert coarse["spp"] == 16
+    for layer in ("camera", "light"):
+        blocks = coarse[layer][..., :3].reshape(16, 8, 16, 8, 3)
+        assert np.abs(blocks - blocks[:, :1, :, :1]).max() == 0.0, layer  # every 8 x 8 block holds one value
+        expected = fine[layer][..., :3].reshape(16, 8, 16, 8, 3).mean(axis=(1, 3))
+        np.testing.assert_allclose(blocks[:, 0, :, 0], expected, rtol=1e-3, atol=1e-4, err_msg=layer)  # ... the mean of the full render
+    assert float(coarse["camera"][..., :3].mean()) > 0.01

@@ -81,3 +81,52 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert int(np.load(tmp_path / "count0.npy")[0]) == total
     np.testing.assert_array_equal(r0, r1)                    # every rank holds the whole-job image
     np.testing.assert_allclose(r0, expected, rtol=1e-6, atol=1e-6)  # fp32 sums in a different order
+
+
+def bench_worker(rank, world, port, out_dir):
+    """bench.py's main() as the driver launches it for N = 2 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), with gloo
+    in place of nccl and tests/stub_context.StubContext in place of the device context: every line of the N > 1 branch runs."""
+    import contextlib
+    import io
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    import bench
+    from tests.stub_context import StubContext
+    stdout = io.StringIO()
+    with contextlib.redirect_stdout(stdout):
+        line = bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--workload", "classic"], context_factory=StubContext, backend="gloo")
+    ctx = StubContext.instances[-1]
+    printed = [l for l in stdout.getvalue().splitlines() if l.startswith("{")]
+    assert (len(printed) == 1) == (rank == 0)  # ONE JSON line, from rank 0
+    if rank == 0:
+        assert json.loads(printed[0]) == json.loads(json.dumps(line))
+        with open(os.path.join(out_dir, "line.json"), "w") as f:
+            f.write(printed[0])
+    assert ("comm_init", rank, world, bytes(range(128))) in ctx.calls
+    assert ("begin_vcm", rank + 1 * world, world) in ctx.calls and ctx.calls[-1] == ("close",)
+    np.save(os.path.join(out_dir, "bench_film%d.npy" % rank), ctx.reduced_result)
+    np.save(os.path.join(out_dir, "bench_iterations%d.npy" % rank), np.array(ctx.reduced_iterations))
+
+
+def test_bench_two_gpu_control_flow_under_gloo(tmp_path):
+    import json
+    from tests.stub_context import fake_iteration as stub_iteration
+    world, steps, warmup = 2, 3, 1
+    mp.spawn(bench_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    line = json.loads(open(tmp_path / "line.json").read())
+    assert line["n_gpus"] == 2 and line["steps"] == steps and line["warmup"] == warmup and line["scaling"] == "weak" and line["cpu_baseline"] is None
+    assert line["config"]["workload"] == "cornell_classic_vcm_1920x1080" and line["unit"] == "Msamples/s"
+    # value = the samples ALL ranks rendered in the timed region / the slowest rank's time
+    assert abs(line["value"] - 1920 * 1080 * steps * world / (line["ms_per_step"] * 1.0e-3 * steps) / 1.0e6) < 1.0e-3 * line["value"]
+    # the timed region: rank r rendered iterations r + (warmup + k) * world, and after the reduce every rank holds their mean
+    rendered = sorted(int(i) for r in range(world) for i in np.load(tmp_path / ("bench_iterations%d.npy" % r)))
+    assert rendered == list(range(warmup * world, (warmup + steps) * world))
+    camera = sum(stub_iteration(i)[0] for i in rendered)
+    light = sum(stub_iteration(i)[1] for i in rendered)
+    expected = torch.clamp((camera + light) / len(rendered), min=0.0)
+    expected[..., 3] = 1.0
+    for r in range(world):
+        np.testing.assert_allclose(np.load(tmp_path / ("bench_film%d.npy" % r)), expected.numpy(), rtol=1e-6, atol=1e-6)
