@@ -485,7 +485,9 @@ void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ra
   if (blocks == 0)
     return;
   DScene limited = scene;  // experiments: ETX_HIP_DEBUG_PRIMS caps the primitive count of the flat sweep (cost per primitive vs memory floor)
-  limited.flat_prim_count = min(limited.flat_prim_count, etxh::tuning_knob("ETX_HIP_DEBUG_PRIMS", 0xffffffffu));
+  const uint32_t prim_cap = etxh::tuning_knob("ETX_HIP_DEBUG_PRIMS", 0u);  // 0 = no cap
+  if ((prim_cap != 0u) && (prim_cap < limited.flat_prim_count))
+    limited.flat_prim_count = prim_cap;
   const bool two_ray_sweep = (debug_flags & 64u) != 0u;  // etx_hip_set_debug_flags: the packed two-ray sweep (kept, measured, not the default)
   if (flat && two_ray_sweep)
     hipLaunchKernelGGL((k_trace_closest_flat2<false>), dim3(flat2_blocks(count)), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u, 0u);
