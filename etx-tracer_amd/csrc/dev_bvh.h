@@ -329,6 +329,81 @@ ETX_DEV Hit bvh_closest(const DScene& scene, const BvhNodes& nodes, Tris tris, i
 }
 
 
+// Any accepted hit in [tmin, tmax]? The occlusion test of a scene WITHOUT Boundary materials (Raytracing::trace_transmittance,
+// rt.cxx:488-516: the first candidate that is neither Void nor alpha-skipped ends the query). No order among the children of a node
+// is needed and nothing is tracked: a traversal that stops at the first hit instead of shrinking the interval around the nearest one.
+template <class Tris, class Stack>
+ETX_DEV bool bvh_occluded(const DScene& scene, const BvhNodes& nodes, Tris tris, int32_t root, const Stack& stack, const RayQ& ray, uint32_t& alpha_seed) {
+  const f3 inv_d = {__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)};
+  uint32_t sp = 0;
+  int32_t cur = root;
+  const int32_t kDone = kBvhEmptyChild;
+  if (scene.bvh_tri_count == 0u)
+    cur = kDone;
+  while (cur != kDone) {
+    while ((cur >= 0) && (cur != kDone)) {
+      float4 lox, loy, loz, hix, hiy, hiz;
+      int4 children;
+      if (uint32_t(cur) < nodes.lds_count) {
+        const float4* n = nodes.lds + uint32_t(cur) * 8u;
+        lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5];
+        const float4 c = n[6];
+        children = make_int4(__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
+      } else {
+        const float4* n = nodes.global + uint32_t(cur) * 8u;
+        lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5];
+        const float4 c = n[6];
+        children = make_int4(__float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w));
+      }
+      const float t0 = slab(f3{lox.x, loy.x, loz.x}, f3{hix.x, hiy.x, hiz.x}, ray.o, inv_d, ray.tmin, ray.tmax);
+      const float t1 = slab(f3{lox.y, loy.y, loz.y}, f3{hix.y, hiy.y, hiz.y}, ray.o, inv_d, ray.tmin, ray.tmax);
+      const float t2 = slab(f3{lox.z, loy.z, loz.z}, f3{hix.z, hiy.z, hiz.z}, ray.o, inv_d, ray.tmin, ray.tmax);
+      const float t3 = slab(f3{lox.w, loy.w, loz.w}, f3{hix.w, hiy.w, hiz.w}, ray.o, inv_d, ray.tmin, ray.tmax);
+      const bool h0 = (children.x != kBvhEmptyChild) && (t0 < kMaxFloat), h1 = (children.y != kBvhEmptyChild) && (t1 < kMaxFloat);
+      const bool h2 = (children.z != kBvhEmptyChild) && (t2 < kMaxFloat), h3 = (children.w != kBvhEmptyChild) && (t3 < kMaxFloat);
+      int32_t next = kDone;
+      if (h3)
+        next = children.w;
+      if (h2) {
+        if (next != kDone)
+          stack.push(sp, next);
+        next = children.z;
+      }
+      if (h1) {
+        if (next != kDone)
+          stack.push(sp, next);
+        next = children.y;
+      }
+      if (h0) {
+        if (next != kDone)
+          stack.push(sp, next);
+        next = children.x;
+      }
+      cur = (next != kDone) ? next : (sp ? stack.pop(sp) : kDone);
+    }
+    if (cur == kDone)
+      break;
+    const uint32_t leaf = uint32_t(~cur);
+    const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+    for (uint32_t i = first; i < first + count; ++i) {
+      const float4 v0 = tris[i].v0_index;
+      const float4 e1 = tris[i].e1_flags;
+      const float4 e2 = tris[i].e2_mat;
+      float u, v, t;
+      if (triangle_test(v0, e1, e2, ray, ray.tmax, u, v, t) == false)
+        continue;
+      const uint32_t flags = __float_as_uint(e1.w);
+      if (flags & kTriVoid)
+        continue;
+      if ((flags & kTriAlphaTested) && alpha_test_skips(scene, __float_as_uint(v0.w), __float_as_uint(e2.w), u, v, alpha_seed))
+        continue;
+      return true;
+    }
+    cur = sp ? stack.pop(sp) : kDone;
+  }
+  return false;
+}
+
 // scene_medium.hxx:187-193 (homogeneous branch): exp(-sigma_t * distance)
 // medium_transmittance, scene_medium.hxx:191-239: homogeneous exp(-sigma_t d); heterogeneous ratio tracking against the
 // majorant with Russian roulette below 0.1 (draws from `smp`: the per-request stream of the shadow kernel).
@@ -453,6 +528,12 @@ ETX_DEV f3 bvh_transmittance(const DScene& scene, const BvhNodes& nodes, Tris tr
   Sampler medium_rng;  // heterogeneous media draw from the segment's own stream
   medium_rng.seed = alpha_seed ^ 0x6d656469u, medium_rng.fixed_u = medium_rng.fixed_v = medium_rng.fixed_w = 0.0f;
   float t_min = kRayEpsilon;
+  if ((scene.bvh_flat == 0u) && (scene.boundary_materials == 0u)) {
+    // no medium boundary anywhere: the segment is occluded or it is not, and what it crosses is the medium it started in
+    if (bvh_occluded(scene, nodes, tris, root, stack, RayQ{p0, t_min, direction, t_max}, alpha_seed))
+      return mk3(0.0f);
+    return (medium_index != kInvalid) ? medium_transmittance(scene, scene.mediums[medium_index], wavelength, medium_rng, p0, direction, t_max) : mk3(1.0f);
+  }
   uint32_t medium = medium_index;
   for (uint32_t crossings = 0; crossings < 64u; ++crossings) {
     uint32_t flags = 0u;

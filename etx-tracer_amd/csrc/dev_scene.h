@@ -142,7 +142,8 @@ struct DScene {
   const uint8_t* material_group;   // per material: shading group of a path that hits it (kShadeGroup*, kernels_shade.inl)
   const uint32_t* material_sss_medium;  // per material: the medium its subsurface walk runs through (interior medium, or a derived entry appended to `mediums`; host_scene.cpp)
   uint32_t vertex_count, triangle_count, material_count, emitter_count, emitter_dist_count, spectrum_count, image_count, medium_count;
-  uint32_t bvh_node_count, bvh_tri_count, flat_prim_count, pad_flat;
+  uint32_t bvh_node_count, bvh_tri_count, flat_prim_count;
+  uint32_t boundary_materials;  // materials of Class::Boundary in the table: 0 = a transmittance query is a pure occlusion test (dev_bvh.h bvh_occluded)
   int32_t bvh_root;  // child encoding (a single leaf scene has a negative root)
   uint32_t bvh_depth; // levels of inner BVH4 nodes
   uint32_t bvh_stack_need;  // stack entries the traversal can need (host bound over the tree): selects the kernel variant

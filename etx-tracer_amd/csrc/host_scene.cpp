@@ -1185,6 +1185,9 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     if (rc)
       return rc;
   }
+  d.boundary_materials = 0u;
+  for (uint64_t i = 0; i < scene->materials.count; ++i)
+    d.boundary_materials += (materials[i].cls == ETX_MAT_BOUNDARY) ? 1u : 0u;
   d.vertex_count = uint32_t(scene->vertices.count);
   d.triangle_count = uint32_t(scene->triangles.count);
   d.material_count = uint32_t(scene->materials.count);

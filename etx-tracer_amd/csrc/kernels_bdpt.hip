@@ -107,7 +107,7 @@ struct BdptWalk {
 };
 
 // subsurface_step's free flight: returns false when the path ends (pdf zero). found = the object's surface was reached (h filled).
-ETX_DEV bool bdpt_walk_flight(const DScene& scene, const LaneStack& stack, const BdptWalk& walk, BdptState& st, float4& h, MediumSample& ms) {
+ETX_DEV bool bdpt_walk_flight(const DScene& scene, const BvhNodes& nodes, const LaneStack& stack, const BdptWalk& walk, BdptState& st, float4& h, MediumSample& ms) {
   const DMedium& wm = scene.mediums[walk.medium];
   f3 absorption, scattering;
   medium_coefficients(scene, wm, st.wavelength, absorption, scattering);
@@ -121,7 +121,7 @@ ETX_DEV bool bdpt_walk_flight(const DScene& scene, const LaneStack& stack, const
     max_t = (sample_t > 0.0f) ? -logf(1.0f - st.sampler.next()) / sample_t : kMaxFloat;
   }
   uint32_t alpha_seed = st.sampler.seed ^ 0x62777373u;
-  const Hit hit = bvh_closest(scene, global_nodes(scene), scene.bvh_tris, scene.bvh_root, stack, RayQ{st.ray_o, st.ray_tmin, st.ray_d, max_t}, alpha_seed, nullptr, walk.material);
+  const Hit hit = bvh_closest(scene, nodes, scene.bvh_tris, scene.bvh_root, stack, RayQ{st.ray_o, st.ray_tmin, st.ray_d, max_t}, alpha_seed, nullptr, walk.material);
   const bool found = hit.tri != kInvalid;
   if (found)
     max_t = hit.t;
@@ -216,7 +216,7 @@ struct BdptLightStep {
 // One segment of an emitter path after the closest-hit query (kInWalk = false, `h` from the hit queue), or one sub-step of a
 // subsurface walk (kInWalk = true: the free flight and its material-filtered query happen here).
 template <uint32_t kStep, bool kSimple>
-ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const LaneStack& stack, uint32_t mode, BdptState& st, BdptWalk& walk, float4& h) {
+ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const BvhNodes& nodes, const LaneStack& stack, uint32_t mode, BdptState& st, BdptWalk& walk, float4& h) {
   constexpr bool kInWalk = kStep != kStepSegment;
   BdptLightStep r = {};
   MediumSample ms;
@@ -224,7 +224,7 @@ ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const LaneStack& stac
   bool flight_ok = true;
   if (kStep == kStepWalkEvent) {
     walk.events += 1u;
-    flight_ok = (walk.events <= 1024u) && bdpt_walk_flight(scene, stack, walk, st, h, ms);  // :776-812
+    flight_ok = (walk.events <= 1024u) && bdpt_walk_flight(scene, nodes, stack, walk, st, h, ms);  // :776-812
   }
   const uint32_t tri = __float_as_uint(h.w);
   const bool found = tri != kInvalid;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
         st.prev.tri = st.prev_slot;  // see k_bdpt_light_generate
         st.prev_slot = kInvalid;
       }
-      r = bdpt_light_step<kStepSegment, kSimple>(scene, no_stack, mode, st, walk, h);
+      r = bdpt_light_step<kStepSegment, kSimple>(scene, global_nodes(scene), no_stack, mode, st, walk, h);
     }
     // pool slots: the emitter vertex (first interaction only), then the new vertex
     const uint32_t emitter_slot = block_compact_slot(r.store_emitter, p.counters + kCntLightVertices, s_scratch);
@@ -423,6 +423,7 @@ constexpr uint32_t kWalkBlocks = 1024u;
 // launch, 100 ms per iteration, with nearly all lanes idle). A walk that is still inside after its budget goes to the other walk
 // queue and continues in the next round, next to that round's new walks.
 constexpr uint32_t kWalkBudget = 32u;
+constexpr uint32_t kWalkLdsNodes = 64u;  // 8 KB next to the 32 KB of stacks: four workgroups per CU
 
 // Taking the next entries of the walk queue: called by all lanes of a wavefront; lanes without a walk get one while the queue lasts.
 // Returns false when the wavefront has nothing left to do.
@@ -446,11 +447,13 @@ ETX_DEV bool walk_refill(const Pipeline& p, uint32_t count, bool& active, bool& 
 // The scattering events of the walks of this bounce, emitter paths: walk queue -> (medium vertices in the light vertex pool) -> exit queue
 __global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_light(Pipeline p, VcmParams it, uint32_t queue) {
   __shared__ int32_t s_stack[kStackDepth * kBlockSize];
+  __shared__ float4 s_nodes[kWalkLdsNodes * 8u];
   const LaneStack stack = lane_stack(p.scene, s_stack + threadIdx.x, kBlockSize);
   const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntWalk + 32u * queue], p.capacity);
   if (count == 0u)
     return;
+  const BvhNodes nodes = stage_nodes(scene, s_nodes, kWalkLdsNodes);  // every event descends from the root: its first levels come from LDS
   const uint32_t mode = bdpt_mode(it);
   const uint32_t lane = threadIdx.x & 63u;
   BdptState st = {};
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_light(Pipeline p, V
     BdptLightStep r = {};
     float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
     if (active)
-      r = bdpt_light_step<kStepWalkEvent, true>(scene, stack, mode, st, walk, h);
+      r = bdpt_light_step<kStepWalkEvent, true>(scene, nodes, stack, mode, st, walk, h);
     const uint32_t vertex_slot = wave_chunk_slot(r.store_vertex, chunk, p.counters + kCntLightVertices);
     bdpt_light_store(p, st, r, 0u, vertex_slot);  // a walk never holds the emitter vertex: its entry vertex came first
     const uint32_t exit_slot = wave_compact_slot(r.exit, p.counters + kCntWalkExit);
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_exit_light(Pipeline p,
     if (i < count) {
       st = bdpt_load(p.walk_exit, i);
       float4 h = p.walk_exit_hits[i];
-      r = bdpt_light_step<kStepWalkExit, kSimple>(scene, no_stack, mode, st, walk, h);
+      r = bdpt_light_step<kStepWalkExit, kSimple>(scene, global_nodes(scene), no_stack, mode, st, walk, h);
     }
     const uint32_t vertex_slot = block_compact_slot(r.store_vertex, p.counters + kCntLightVertices, s_scratch);
     bdpt_light_store(p, st, r, 0u, vertex_slot);
@@ -660,7 +663,7 @@ struct BdptCameraStep {
 // One segment of a camera path after the closest-hit query (kInWalk = false), or one sub-step of a subsurface walk (kInWalk = true).
 // Film contributions of direct hits are added here; pool records and the roulette are the caller's (bdpt_camera_finish).
 template <uint32_t kStep, bool kSimple>
-ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, const LaneStack& stack, const VcmParams& it, uint32_t mode, bool use_mis, BdptState& st, BdptWalk& walk, float4& h) {
+ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, const BvhNodes& nodes, const LaneStack& stack, const VcmParams& it, uint32_t mode, bool use_mis, BdptState& st, BdptWalk& walk, float4& h) {
   constexpr bool kInWalk = kStep != kStepSegment;
   BdptCameraStep r = {};
   r.v_hit = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
@@ -670,7 +673,7 @@ ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, 
   bool flight_ok = true;
   if (kStep == kStepWalkEvent) {
     walk.events += 1u;
-    flight_ok = (walk.events <= 1024u) && bdpt_walk_flight(scene, stack, walk, st, h, ms);  // subsurface_step, :776-812
+    flight_ok = (walk.events <= 1024u) && bdpt_walk_flight(scene, nodes, stack, walk, st, h, ms);  // subsurface_step, :776-812
   }
   const uint32_t tri = __float_as_uint(h.w);
   const bool found = tri != kInvalid;
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
       st = bdpt_load(in, i);
       st.prev.tri = st.prev_slot;  // camera paths carry the previous vertex' triangle there
       float4 h = p.hits[i];
-      r = bdpt_camera_step<kStepSegment, kSimple>(p, scene, no_stack, it, mode, use_mis, st, walk, h);
+      r = bdpt_camera_step<kStepSegment, kSimple>(p, scene, global_nodes(scene), no_stack, it, mode, use_mis, st, walk, h);
     }
     const uint32_t vertex_slot = block_compact_slot(r.store_vertex, p.counters + kCntCameraVertices, s_scratch);
     const uint32_t next = valid ? bdpt_camera_finish<kStepSegment>(p, scene, st, walk, r, vertex_slot) : 0u;
@@ -910,11 +913,13 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
 // connectible, :811: the events leave nothing but the path's running MIS history behind)
 __global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_camera(Pipeline p, VcmParams it, uint32_t queue) {
   __shared__ int32_t s_stack[kStackDepth * kBlockSize];
+  __shared__ float4 s_nodes[kWalkLdsNodes * 8u];
   const LaneStack stack = lane_stack(p.scene, s_stack + threadIdx.x, kBlockSize);
   const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntWalk + 32u * queue], p.capacity);
   if (count == 0u)
     return;
+  const BvhNodes nodes = stage_nodes(scene, s_nodes, kWalkLdsNodes);  // every event descends from the root: its first levels come from LDS
   const uint32_t mode = bdpt_mode(it);
   const bool use_mis = opt_enable_mis(it);
   BdptState st = {};
@@ -933,7 +938,7 @@ __global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_camera(Pipeline p, 
     float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
     uint32_t next = 0u;
     if (active) {
-      r = bdpt_camera_step<kStepWalkEvent, true>(p, scene, stack, it, mode, use_mis, st, walk, h);
+      r = bdpt_camera_step<kStepWalkEvent, true>(p, scene, nodes, stack, it, mode, use_mis, st, walk, h);
       next = bdpt_camera_finish<kStepWalkEvent>(p, scene, st, walk, r, 0u);
     }
     const uint32_t exit_slot = wave_compact_slot(r.exit, p.counters + kCntWalkExit);
@@ -970,7 +975,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_exit_camera(Pipeline p
       st = bdpt_load(p.walk_exit, i);
       st.prev.tri = st.prev_slot;
       float4 h = p.walk_exit_hits[i];
-      r = bdpt_camera_step<kStepWalkExit, kSimple>(p, scene, no_stack, it, mode, use_mis, st, walk, h);
+      r = bdpt_camera_step<kStepWalkExit, kSimple>(p, scene, global_nodes(scene), no_stack, it, mode, use_mis, st, walk, h);
     }
     const uint32_t vertex_slot = block_compact_slot(r.store_vertex, p.counters + kCntCameraVertices, s_scratch);
     const uint32_t next = valid ? bdpt_camera_finish<kStepWalkExit>(p, scene, st, walk, r, vertex_slot) : 0u;

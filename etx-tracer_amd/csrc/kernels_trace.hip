@@ -405,10 +405,14 @@ void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, u
 // Shadow kernel: segment queue -> transmittance -> film atomics (Raytracing::trace_transmittance, rt.cxx:468-579, plus
 // the accumulation the callers do: vcm_cpu.cxx:148-153 light splats, vcm_shared.hxx:1049-1053 camera gathers).
 // Algorithmic traffic: 48 B request in, 12 B of float atomics out for visible segments.
+// LDS: the per-lane stacks (32 KB) + the top kShadowLdsNodes nodes of the tree (8 KB): 40 KB per workgroup, three to four resident
+// workgroups per CU. (256 staged nodes = 64 KB left two: the kernel waits on the node fetches below the staged levels, and more
+// wavefronts hide more of that than more staged levels save.)
+constexpr uint32_t kShadowLdsNodes = 64u;
 template <bool kFlat, bool kDeep = false>
 __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
   __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
-  __shared__ float4 s_nodes[kFlat ? 1 : kLdsNodes * 8u];
+  __shared__ float4 s_nodes[kFlat ? 1 : kShadowLdsNodes * 8u];
   const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntShadow], p.shadow.capacity);
   const uint32_t lane = threadIdx.x & 63u;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
   uint32_t splats = 0;
   BvhNodes nodes = global_nodes(scene);
   if ((kFlat == false) && (blockIdx.x * blockDim.x < count))
-    nodes = stage_nodes(scene, s_nodes, kLdsNodes);
+    nodes = stage_nodes(scene, s_nodes, kShadowLdsNodes);
   for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {
     const uint32_t i = base + lane;
     f3 value = mk3(0.0f);
