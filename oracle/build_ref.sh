@@ -35,6 +35,11 @@ compile "$HERE/shims/denoiser_stub.cxx"   "$OBJ/denoiser_stub.o" & pids+=($!)
 compile "$HERE/shims/raytracing_bvh.cxx"  "$OBJ/raytracing_bvh.o" & pids+=($!)
 compile "$HERE/driver/etx_oracle.cxx"     "$OBJ/etx_oracle.o" & pids+=($!)
 compile "$HERE/ref/abi_check.cxx"         "$OBJ/abi_check.o" & pids+=($!)
+# the headless host of the HIP backend alone: the same driver without the CPU integrators
+mkdir -p "$OBJ/hip_only"
+compile "$HERE/ref/unity_rt_host.cxx"     "$OBJ/hip_only/unity_rt_host.o" & pids+=($!)
+( if [ ! -f "$OBJ/hip_only/etx_hip_render.o" ] || [ "$HERE/driver/etx_oracle.cxx" -nt "$OBJ/hip_only/etx_hip_render.o" ] || [ "$HERE/../integration/etx_hip_integrators.hxx" -nt "$OBJ/hip_only/etx_hip_render.o" ] || [ "$HERE/../include/etx_hip.h" -nt "$OBJ/hip_only/etx_hip_render.o" ] || [ "$0" -nt "$OBJ/hip_only/etx_hip_render.o" ]; then
+    echo "  CXX etx_oracle.cxx (hip only)"; $CXX $FLAGS -DETX_DRIVER_HIP_ONLY $INC -c "$HERE/driver/etx_oracle.cxx" -o "$OBJ/hip_only/etx_hip_render.o"; fi ) & pids+=($!)
 for f in bluenoise/bluenoise.cxx stb_image/stb_image.cxx tinyexr/tinyexr.cxx tinygltf/tiny_gltf.cxx tinyobjloader/tiny_obj_loader.cxx; do
   compile "$T/$f" "$OBJ/$(basename ${f%.cxx}).o" & pids+=($!)
 done
@@ -43,3 +48,6 @@ for p in "${pids[@]}"; do wait $p; done
 
 $CXX -O2 -o "$OUT/etx_oracle" "$OBJ"/*.o -lpthread -ldl
 echo "built $OUT/etx_oracle"
+HOST_OBJECTS=$(ls "$OBJ"/*.o | grep -v "/unity_rt.o$" | grep -v "/etx_oracle.o$")
+$CXX -O2 -o "$OUT/etx_hip_render" $HOST_OBJECTS "$OBJ/hip_only/unity_rt_host.o" "$OBJ/hip_only/etx_hip_render.o" -lpthread -ldl
+echo "built $OUT/etx_hip_render"

@@ -19,9 +19,16 @@
 #include <etx/render/host/film.hxx>
 #include <etx/render/host/scene_representation.hxx>
 #include <etx/render/shared/ior_database.hxx>
+// Two targets from this file (oracle/build_ref.sh): etx_oracle = the checker, with the reference's CPU integrators next to the HIP binding;
+// etx_hip_render (-DETX_DRIVER_HIP_ONLY) = the headless host of the HIP backend alone: scene loader, film and the
+// binding of integration/etx_hip_integrators.hxx, no CPU integrator linked.
+#if !defined(ETX_DRIVER_HIP_ONLY)
 #include <etx/rt/integrators/path_tracing.hxx>
 #include <etx/rt/integrators/vcm_cpu.hxx>
 #include <etx/rt/integrators/bidirectional.hxx>
+#else
+#include <etx/rt/integrators/integrator.hxx>
+#endif
 #include <etx/rt/shared/vcm_shared.hxx>
 #include <bluenoise.hxx>
 
@@ -189,6 +196,7 @@ bool load_snapshot(const char* path, std::vector<uint8_t>& storage, const Scene*
   return true;
 }
 
+#if !defined(ETX_DRIVER_HIP_ONLY)
 // Known-answer vectors straight from the reference's headers (pins oracle/kat.c and the device KAT kernels).
 int print_kat() {
   printf("{\n");
@@ -243,6 +251,7 @@ int print_kat() {
   printf("]\n}\n");
   return 0;
 }
+#endif
 
 void usage() {
   printf(
@@ -271,8 +280,10 @@ int main(int argc, char** argv) {
       scene_file = next();
     else if (strcmp(argv[i], "--load-snapshot") == 0)
       load_snapshot_file = next();
+#if !defined(ETX_DRIVER_HIP_ONLY)
     else if (strcmp(argv[i], "--kat") == 0)
       return print_kat();
+#endif
     else if (strcmp(argv[i], "--dump-cie") == 0) {
       // --dump-cie <file>: first wavelength, count, then spectrum::spectral_xyz(i) (the observer behind SpectralResponse::to_xyz)
       const char* file = next();
@@ -460,20 +471,25 @@ int main(int argc, char** argv) {
       setenv("ETX_HIP_LIBRARY", (dir + "/../../etx-tracer_amd/libetx_hip.so").c_str(), 0);
     }
   }
+#if !defined(ETX_DRIVER_HIP_ONLY)
   CPUPathTracing pt(raytracing);
   CPUVCM vcm(raytracing);
   CPUBidirectional bdpt(raytracing);
+#endif
   HIPVCM hip_vcm(raytracing);          // the device integrators sit behind the same plugin interface (app.hxx:72-82)
   HIPPathTracing hip_pt(raytracing);
   HIPBidirectional hip_bdpt(raytracing);
   Integrator* integrator = nullptr;
+#if !defined(ETX_DRIVER_HIP_ONLY)
   if (integrator_name == "pt")
     integrator = &pt;
   else if (integrator_name == "vcm")
     integrator = &vcm;
   else if (integrator_name == "bdpt")
     integrator = &bdpt;
-  else if (integrator_name == "hip-vcm")
+  else
+#endif
+  if (integrator_name == "hip-vcm")
     integrator = &hip_vcm;
   else if (integrator_name == "hip-pt")
     integrator = &hip_pt;

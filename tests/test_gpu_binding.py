@@ -14,11 +14,12 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE = os.path.join(ROOT, "oracle", "_ref", "etx_oracle")
+HIP_RENDER = os.path.join(ROOT, "oracle", "_ref", "etx_hip_render")  # the same driver without the reference's CPU integrators: the backend's own headless host
 
 
-def run_driver(tmp_path, snapshot, integrator, spp, *options, extra=(), name=None):
+def run_driver(tmp_path, snapshot, integrator, spp, *options, extra=(), name=None, binary=ORACLE):
     out = str(tmp_path / ("%s.raw" % (name or integrator)))
-    cmd = [ORACLE, "--load-snapshot", snapshot, "--integrator", integrator, "--spp", str(spp), "--out", out] + list(extra)
+    cmd = [binary, "--load-snapshot", snapshot, "--integrator", integrator, "--spp", str(spp), "--out", out] + list(extra)
     for o in options:
         cmd += ["--opt", o]
     result = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
@@ -64,11 +65,12 @@ def test_cpp_driver_checkpoint_and_resume(golden_dir, tmp_path):
     """The headless driver of the HIP path: --max-iterations + --checkpoint stops a render and stores its film state,
     --resume continues it in a new process; the result is the uninterrupted render (same iterations, float addition order aside)."""
     snapshot = os.path.join(golden_dir, "cornell_full_128.etxscene")
-    whole, _ = run_driver(tmp_path, snapshot, "hip-vcm", 32, "vcm-blue_noise=false", name="whole")
+    assert subprocess.run([HIP_RENDER, "--load-snapshot", snapshot, "--integrator", "vcm"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).returncode == 1  # no CPU integrator in this binary
+    whole, _ = run_driver(tmp_path, snapshot, "hip-vcm", 32, "vcm-blue_noise=false", name="whole", binary=HIP_RENDER)
     checkpoint = str(tmp_path / "render.etxc")
-    part, _ = run_driver(tmp_path, snapshot, "hip-vcm", 32, "vcm-blue_noise=false", extra=["--max-iterations", "8", "--checkpoint", checkpoint], name="part")
+    part, _ = run_driver(tmp_path, snapshot, "hip-vcm", 32, "vcm-blue_noise=false", extra=["--max-iterations", "8", "--checkpoint", checkpoint], name="part", binary=HIP_RENDER)
     assert 8 <= part["spp"] < 24 and os.path.getsize(checkpoint) > 128 * 128 * 64  # the lanes' iterations in flight finish, the rest is left
-    resumed, log = run_driver(tmp_path, snapshot, "hip-vcm", 32, "vcm-blue_noise=false", extra=["--resume", checkpoint], name="resumed")
+    resumed, log = run_driver(tmp_path, snapshot, "hip-vcm", 32, "vcm-blue_noise=false", extra=["--resume", checkpoint], name="resumed", binary=HIP_RENDER)
     assert resumed["spp"] == 32 and ("resumed at iteration %d" % part["spp"]) in log
     np.testing.assert_allclose(resumed["camera"][..., :3], whole["camera"][..., :3], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(resumed["light"][..., :3], whole["light"][..., :3], rtol=2e-4, atol=2e-5)
