@@ -107,6 +107,22 @@ def test_cpp_binding_fails_loudly_without_a_device():
     assert "no HIP device available" in result.stdout
 
 
+def test_headless_driver_of_the_backend_links_no_cpu_integrator():
+    """oracle/_ref/etx_hip_render = the driver built with -DETX_DRIVER_HIP_ONLY (oracle/build_ref.sh): the headless host of the HIP backend
+     holds the scene loader, the Film and the binding - none of the reference's CPU integrators, and it refuses their names."""
+    import subprocess
+    binary = os.path.join(ROOT, "oracle", "_ref", "etx_hip_render")
+    if not os.path.exists(binary):
+        pytest.skip("oracle/_ref/etx_hip_render is not built (needs /root/reference)")
+    symbols = subprocess.run(["nm", "-C", binary], stdout=subprocess.PIPE, text=True).stdout
+    assert ("HIPVCM" in symbols) and ("HIPBidirectional" in symbols)
+    for name in ("CPUVCM", "CPUPathTracing", "CPUBidirectional"):
+        assert name not in symbols, name
+    snapshot = os.path.join(ROOT, "tests", "golden", "cornell_classic_128.etxscene")
+    result = subprocess.run([binary, "--load-snapshot", snapshot, "--integrator", "vcm"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert result.returncode == 1 and "hip-vcm" in result.stdout  # usage
+
+
 def test_film_merge_iteration_patch_applies_and_compiles(tmp_path):
     """integration/film_merge_iteration.patch (the additive bulk film interface) against a scratch copy of the
     two reference files: it applies cleanly, the patched film.cxx compiles, and the binding compiles against the patched
