@@ -15,8 +15,8 @@
 //                and the vertex connections (connect_camera_to_light_path :438-497, k_expand_pairs + k_bdpt_connect_pairs)
 //                read it there; visibility goes through the shadow queue like every other connection.
 // Modes (CPUBidirectionalImpl::Mode :323-330): PathTracing, LightTracing, BDPTFast (the reference's default: no vertex
-// connections, product-form weights), BDPTFull. Random-walk subsurface materials are rejected for this integrator (the
-// reference threads the walk's medium vertices through the path; :729-818).
+// connections, product-form weights), BDPTFull. Random-walk subsurface materials: the reference threads the walk's medium vertices through
+// the path (:729-818); here such a path leaves the wavefront for the walk queue (kernels_bdpt.hip).
 #pragma once
 
 #include "dev_vcm.h"
