@@ -81,6 +81,7 @@ struct etx_hip_context {
   uint32_t tail_divisor = 64;        // active paths <= capacity / tail_divisor: finish the pass in the tail kernel (0 = never)
   uint32_t check_interval = 3;       // rounds the host may enqueue beyond the newest round the device has reported (run_bounce_loop)
   uint32_t timer_mask = (1u << kTimerTraceClosest) | (1u << kTimerTraceShadow);
+  uint32_t cross_mode = 0;           // which path state the traversal kernel may advance across medium boundaries (kernels.h launch_trace_closest): set per iteration by the integrator
   uint32_t debug_flags = 0;          // etx_hip_set_debug_flags: ablation switches of the kernels (Pipeline::debug_flags), 0 in production
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
@@ -386,7 +387,7 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
     const uint32_t tag = ctx->next_round_tag++;
     {
       ScopedTimer t(ctx, kTimerTraceClosest);
-      launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB, known_count, ctx->scene.host_copy.bvh_flat != 0u, ctx->round_mirror, tag, pass_stat);
+      launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB, known_count, ctx->scene.host_copy.bvh_flat != 0u, ctx->round_mirror, tag, pass_stat, ctx->cross_mode);
     }
     shade(set, known_count);
     set ^= 1u;
@@ -433,6 +434,7 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
 
 int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
   const VcmParams it = make_iteration_params(ctx, iteration);
+  ctx->cross_mode = 1u;  // VCMPathState: medium in meta.z, path distance in mis.w
   // The kernels add into the lane's ITERATION images; k_vcm_commit folds them into the film sums at the end of the iteration
   // (Film::commit_light_iteration, film.cxx:332-343, and the per-iteration camera value of vcm_cpu.cxx:227-241). Adding every
   // connection / splat straight into sums that have grown over thousands of iterations would absorb the contributions that
@@ -551,6 +553,7 @@ int render_pt_iteration(etx_hip_context* ctx, uint32_t iteration) {
   it.film_w = ctx->scene.film_w, it.film_h = ctx->scene.film_h;
   it.path_count = it.film_w * it.film_h;
   it.bluenoise = reinterpret_cast<const uint2*>(ctx->active_bluenoise);
+  ctx->cross_mode = 0u;
   hipStream_t s = ctx->stream;
   // the shade and shadow kernels add into the ITERATION image (radiance clamp applies to the iteration's pixel value)
   Pipeline p = ctx->pipe;
@@ -594,6 +597,7 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
   it.options = (o.connect_to_camera ? ETX_VCM_CONNECT_TO_CAMERA : 0u) | (o.direct_hit ? ETX_VCM_DIRECT_HIT : 0u) | (o.connect_to_light ? ETX_VCM_CONNECT_TO_LIGHT : 0u) |
                (o.connect_vertices ? ETX_VCM_CONNECT_VERTICES : 0u) | (o.mis ? ETX_VCM_ENABLE_MIS : 0u);
   it.kernel = o.mode;  // CPUBidirectionalImpl::Mode
+  ctx->cross_mode = 2u;  // BdptState: medium in meta.z, no path distance
   it.iteration = iteration;
   it.film_w = ctx->scene.film_w, it.film_h = ctx->scene.film_h;
   it.path_count = it.film_w * it.film_h;

@@ -48,9 +48,17 @@ ETX_DEV void round_housekeeping(uint32_t* __restrict__ counters, uint32_t active
       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <bool kFromCounter, bool kFlat>
-__global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
-  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit, uint32_t pass_stat) {
+// kCross (pipeline, flat scenes that hold Boundary materials): a path that is in NO medium and whose closest hit is a medium boundary
+// crosses it right here - vcm_handle_boundary_bsdf (vcm_shared.hxx:436-449) / handle_surface's Boundary branch (bidirectional.cxx:586-593)
+// draw nothing and leave only the medium, the ray origin and (VCM) the path distance changed - and is traced again from the other side;
+// the shade kernel then meets the segment INSIDE the medium. In the fog box that is the primary segment of every camera path and every
+// segment that leaves a wall: a quarter of all segments no longer cost a round of their own. A path that is inside a medium when it
+// reaches a boundary is left to the shade kernel (the medium is sampled first).
+enum : uint32_t { kCrossNone = 0, kCrossVcm = 1, kCrossBdpt = 2 };
+template <bool kFromCounter, bool kFlat, bool kCross = false>
+__global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene_arg, const float4* ray_o_tmin, const float4* ray_d_tmax,
+  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit, uint32_t pass_stat,
+  PathSet set = {}, uint32_t cross_mode = kCrossNone) {
   // the flat sweep needs no stack: without the 32 KB of LDS the kernel runs 8 waves per SIMD instead of 5
   __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
   __shared__ float4 s_nodes[kFlat ? 1 : kLdsNodes * 8u];
@@ -73,8 +81,41 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
     const float4 b = ray_d_tmax[i];
     uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ i;
     const RayQ ray = {{a.x, a.y, a.z}, a.w, {b.x, b.y, b.z}, b.w};
-    Hit h = kFlat ? bvh_flat_closest(scene, scene.bvh_tris, ray, alpha_seed, nullptr)
-                  : bvh_closest(scene, nodes, scene.bvh_tris, scene.bvh_root, stack, ray, alpha_seed, nullptr);
+    uint32_t flags = 0u;
+    Hit h = kFlat ? bvh_flat_closest(scene, scene.bvh_tris, ray, alpha_seed, kCross ? &flags : nullptr)
+                  : bvh_closest(scene, nodes, scene.bvh_tris, scene.bvh_root, stack, ray, alpha_seed, kCross ? &flags : nullptr);
+    if (kCross) {
+      uint32_t crossings = 0u, medium = kInvalid;
+      float crossed = 0.0f;
+      f3 origin = ray.o;
+      while ((h.tri != kInvalid) && (flags & kTriBoundary) && (crossings < 8u)) {
+        if (crossings == 0u)
+          medium = set.meta[i].z;
+        if (medium != kInvalid)
+          break;
+        const etx_abi_triangle& tri = scene.triangles[h.tri];
+        const etx_abi_material& mat = scene.materials[tri.material_index];
+        medium = (dot(ld3(tri.geo_n), ray.d) < 0.0f) ? mat.int_medium : mat.ext_medium;
+        crossed += h.t;
+        origin = shading_pos(scene, tri, barycentrics(h.u, h.v), ray.d);
+        crossings += 1u;
+        const RayQ beyond = {origin, kRayEpsilon, ray.d, kMaxFloat};
+        h = kFlat ? bvh_flat_closest(scene, scene.bvh_tris, beyond, alpha_seed, &flags)
+                  : bvh_closest(scene, nodes, scene.bvh_tris, scene.bvh_root, stack, beyond, alpha_seed, &flags);
+      }
+      if (crossings != 0u) {
+        const_cast<float4*>(ray_o_tmin)[i] = mk4(origin, kRayEpsilon);
+        const_cast<float4*>(ray_d_tmax)[i] = mk4(ray.d, kMaxFloat);
+        uint4 meta = set.meta[i];
+        meta.z = medium;
+        set.meta[i] = meta;
+        if (cross_mode == kCrossVcm) {  // state.path_distance += intersection.t
+          float4 mis = set.mis[i];
+          mis.w += crossed;
+          set.mis[i] = mis;
+        }
+      }
+    }
     hits[i] = make_float4(h.u, h.v, h.t, __uint_as_float(h.tri));
   }
 }
@@ -388,13 +429,17 @@ static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const flo
 #undef ETX_LAUNCH_BVH
 }
 
-void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat) {
+void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat,
+  uint32_t cross_mode) {
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.capacity, max_items) + kBlockSize - 1) / kBlockSize));
   // opt-in (ETX_HIP_DEBUG_FLAGS bit 64): alone on the device the two-ray sweep is 10 % faster (39.3 vs 35.7 Grays/s on 2 M incoherent
   // rays), inside the 4-lane pipeline its fatter waves lose against the co-running kernels (51.5 vs 46.6 us per launch) - DESIGN.md 3
   if (flat && (p.debug_flags & 64u))
     hipLaunchKernelGGL((k_trace_closest_flat2<true>), dim3(flat2_blocks(min(p.capacity, max_items))), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits,
       p.counters, active_counter, 0u, round_mirror, round_tag, pass_stat);
+  else if (flat && (cross_mode != kCrossNone) && (p.scene.boundary_materials != 0u))
+    hipLaunchKernelGGL((k_trace_closest<true, true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag,
+      lds_limit(), pass_stat, p.paths[set], cross_mode);
   else if (flat)
     hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag, lds_limit(), pass_stat);
   else

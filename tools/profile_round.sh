@@ -4,6 +4,7 @@
 # Usage: tools/profile_round.sh <tag> [bench args...]
 set -u
 tag=$1; shift
+bench_args=("$@")
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
@@ -12,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- p
 export ETX_HIP_LANES=1
 pass() {  # name counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $out/pmc_$name -o pmc -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-table > $out/pmc_$name.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $out/pmc_$name -o pmc -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-table "${bench_args[@]}" > $out/pmc_$name.log 2>&1
 }
 pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM
 pass sq2 SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU
