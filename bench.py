@@ -354,16 +354,34 @@ def main(argv=None, context_factory=None, backend="nccl"):
                 "rays_per_sample": round((acc["rays"] + acc["shadow"]) / (float(width) * height * args.steps), 3),
                 "light_vertices_per_path": round(acc["lv"] / (float(width) * height * args.steps), 3),
                 "wavefront_rounds_per_step": round(acc["rounds"] / args.steps, 2),
+                "boundary_crossings_per_sample": round(acc["stats"].boundary_crossings / (float(width) * height * args.steps), 3),
                 "photons_examined_per_sample": round(acc["examined"] / (float(width) * height * args.steps), 2),
                 "finite": finite,
             },
         }
         if bdpt_workload and (dominant is not None):
-            # configs[3-4]: the roofline kernel is the group that dominates the step (HIP events of the timed region itself)
+            # configs[3-4]: the roofline kernel is the group that dominates the step (HIP events of the timed region itself).
+            # traffic = HBM bytes per step of that group's kernels from the separate rocprofv3 --pmc passes of this command on one lane
+            # (tools/profile_round.sh: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; KiB -> bytes)
+            group_kernels = {"trace_closest": ("k_trace_closest",), "trace_shadow": ("k_trace_shadow",),
+                             "shade_light": ("k_bdpt_light_shade", "k_bdpt_walk_light", "k_bdpt_walk_exit_light", "k_bdpt_connect_camera"),
+                             "shade_camera": ("k_bdpt_camera_shade", "k_bdpt_walk_camera", "k_bdpt_walk_exit_camera", "k_bdpt_connect_light"),
+                             "connect": ("k_expand_pairs", "k_bdpt_connect_pairs")}
+            traffic = None
+            pmc3_path = os.path.join(ROOT, "profiles", "round3_pmc_%s_1lane_summary.json" % args.workload)
+            if os.path.exists(pmc3_path):
+                with open(pmc3_path) as f:
+                    pmc3 = json.load(f)
+                iterations = max(1, max((row.get("launches", 0) for name, row in pmc3.items() if "k_bdpt_camera_generate" in name), default=1))
+                rows = [row for name, row in pmc3.items() if any(k in name for k in group_kernels[dominant["group"]])]
+                if rows and all(("FETCH_SIZE_sum" in r) and ("WRITE_SIZE_sum" in r) for r in rows):
+                    traffic = round(sum(2.0 * r["FETCH_SIZE_sum"] + r["WRITE_SIZE_sum"] for r in rows) * 1024.0 / iterations)
             line["roofline"] = {"kernel": dominant["group"] + ": " + dominant["bytes"], "bound": "hbm", "achieved": dominant["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": dominant["frac"], "traffic": None, "units_per_step": dominant["units_per_step"], "unit_of_work": dominant["unit"], "ms_per_step": dominant["ms_per_step"],
+                                "frac": dominant["frac"], "traffic": traffic, "algorithmic_bytes_per_step": round(dominant["achieved"] * 1.0e9 * dominant["ms_per_step"] * 1.0e-3),
+                                "units_per_step": dominant["units_per_step"], "unit_of_work": dominant["unit"], "ms_per_step": dominant["ms_per_step"],
                                 "share_of_step": dominant["share"],
-                                "note": "algorithmic bytes of the dominant kernel group (DESIGN.md 3) / summed HIP-event time of its launches in the timed region, rank 0; PMC traffic: profiles/"}
+                                "note": "algorithmic bytes of the dominant kernel group (DESIGN.md 3) / summed HIP-event time of its launches in the timed region, rank 0; "
+                                        "traffic = HBM bytes per step of the group's kernels (profiles/round3_pmc_%s_1lane_summary.json, one-lane PMC passes)" % args.workload}
         # (gems1m is assembled in memory and has no file to hand to the reference's driver; the subsurface scene is written out for it)
         if args.no_cpu_baseline or (world > 1) or (args.workload == "gems1m"):
             line["cpu_baseline"] = None

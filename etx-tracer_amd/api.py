@@ -133,6 +133,7 @@ class Stats(ctypes.Structure):
         ("endpoints", ctypes.c_uint64),
         ("active_pixels", ctypes.c_uint64),
         ("last_active_pixels", ctypes.c_uint64),
+        ("boundary_crossings", ctypes.c_uint64),
     ]
 
     def as_dict(self):

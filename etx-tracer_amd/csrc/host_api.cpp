@@ -720,6 +720,7 @@ void collect_stats(etx_hip_context* ctx) {
   st.pairs = u64(kStatPairs);
   st.endpoints = u64(kStatEndpoints);
   st.active_pixels = st.last_active_pixels = u64(kStatActivePixels);
+  st.boundary_crossings = u64(kStatCrossings);
   st.overflow_flags = c[kCntOverflow];
   st.nonfinite_dropped = c[kCntNonFinite];
 #if defined(ETX_HIP_DEBUG_COUNTERS)
@@ -786,6 +787,7 @@ void lane_worker(etx_hip_context* lane) {
         t.photons_examined += s.photons_examined, t.photons_merged += s.photons_merged, t.splats += s.splats;
         t.rays_light += s.rays_light, t.rays_camera += s.rays_camera, t.pairs += s.pairs, t.endpoints += s.endpoints;
         t.active_pixels += s.active_pixels, t.last_active_pixels = s.last_active_pixels;
+        t.boundary_crossings += s.boundary_crossings;
         t.wavefront_bounces += s.wavefront_bounces;
         t.ms_trace_closest += s.ms_trace_closest, t.ms_trace_shadow += s.ms_trace_shadow;
         t.ms_shade_light += s.ms_shade_light, t.ms_shade_camera += s.ms_shade_camera;

@@ -58,7 +58,7 @@ enum : uint32_t { kCrossNone = 0, kCrossVcm = 1, kCrossBdpt = 2 };
 template <bool kFromCounter, bool kFlat, bool kCross = false>
 __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene_arg, const float4* ray_o_tmin, const float4* ray_d_tmax,
   float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit, uint32_t pass_stat,
-  PathSet set = {}, uint32_t cross_mode = kCrossNone) {
+  PathSet set = {}, uint32_t cross_mode = kCrossNone, unsigned long long* block_stats = nullptr) {
   // the flat sweep needs no stack: without the 32 KB of LDS the kernel runs 8 waves per SIMD instead of 5
   __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
   __shared__ float4 s_nodes[kFlat ? 1 : kLdsNodes * 8u];
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
   BvhNodes nodes = global_nodes(scene);
   if ((kFlat == false) && (blockIdx.x * blockDim.x < count))  // workgroup-uniform: this workgroup has rays
     nodes = stage_nodes(scene, s_nodes, min(kLdsNodes, lds_node_limit));
+  unsigned long long crossed_queries = 0ull;
   for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {
     const uint32_t i = base + lane;
     if (i >= count)
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
         h = kFlat ? bvh_flat_closest(scene, scene.bvh_tris, beyond, alpha_seed, &flags)
                   : bvh_closest(scene, nodes, scene.bvh_tris, scene.bvh_root, stack, beyond, alpha_seed, &flags);
       }
+      crossed_queries += crossings;
       if (crossings != 0u) {
         const_cast<float4*>(ray_o_tmin)[i] = mk4(origin, kRayEpsilon);
         const_cast<float4*>(ray_d_tmax)[i] = mk4(ray.d, kMaxFloat);
@@ -117,6 +119,12 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
       }
     }
     hits[i] = make_float4(h.u, h.v, h.t, __uint_as_float(h.tri));
+  }
+  if (kCross) {  // the queries beyond crossed boundaries are rays too (statistics: one row per workgroup, no atomics)
+    __shared__ unsigned long long s_stat;
+    Pipeline stats_only = {};
+    stats_only.block_stats = block_stats;
+    block_stat_add(stats_only, kBlockStatCrossings, crossed_queries, &s_stat);
   }
 }
 
@@ -439,7 +447,7 @@ void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, u
       p.counters, active_counter, 0u, round_mirror, round_tag, pass_stat);
   else if (flat && (cross_mode != kCrossNone) && (p.scene.boundary_materials != 0u))
     hipLaunchKernelGGL((k_trace_closest<true, true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag,
-      lds_limit(), pass_stat, p.paths[set], cross_mode);
+      lds_limit(), pass_stat, p.paths[set], cross_mode, p.block_stats);
   else if (flat)
     hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag, lds_limit(), pass_stat);
   else

@@ -204,6 +204,8 @@ __global__ __launch_bounds__(kBlockSize) void k_stats_finalize(Pipeline p) {
     *reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsExamined) = s_sum[kBlockStatExamined];
     *reinterpret_cast<unsigned long long*>(p.counters + kStatPhotonsMerged) = s_sum[kBlockStatMerged];
     *reinterpret_cast<unsigned long long*>(p.counters + kStatSplats) = s_sum[kBlockStatSplats];
+    *reinterpret_cast<unsigned long long*>(p.counters + kStatCrossings) = s_sum[kBlockStatCrossings];
+    *reinterpret_cast<unsigned long long*>(p.counters + kStatRaysExtension) += s_sum[kBlockStatCrossings];
     // the camera vertices the tail kernel (or the last bounce) left behind
     *reinterpret_cast<unsigned long long*>(p.counters + kStatCameraVertices) += (unsigned long long)p.counters[kCntCameraVertices];
   }

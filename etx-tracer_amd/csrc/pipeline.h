@@ -156,12 +156,13 @@ enum : uint32_t {
                              // that are still unfinished after kWalkBudget events in queue s ^ 1
   kCntWalkFetch = 928,       // ... and how many entries the walk kernel's wavefronts have taken in this round
   kCntWalkExit = 960,        // ... and the walks that have reached their object's surface (exit queue, k_bdpt_walk_exit), cleared per bounce
-  kCounterCount = 992,
+  kStatCrossings = 992,      // u64: closest-hit queries the traversal kernel ran BEYOND a medium boundary it crossed itself (kernels_trace.hip kCross); part of kStatRaysExtension
+  kCounterCount = 1024,
 };
 
 // Per-workgroup statistics (u64): workgroup b of any launch adds to row b without atomics (launches on one stream do
 // not overlap); k_stats_finalize folds the rows into the counters above once per iteration.
-enum : uint32_t { kBlockStatExamined = 0, kBlockStatMerged = 1, kBlockStatSplats = 2, kBlockStatCount = 4 };
+enum : uint32_t { kBlockStatExamined = 0, kBlockStatMerged = 1, kBlockStatSplats = 2, kBlockStatCrossings = 3, kBlockStatCount = 4 };
 constexpr uint32_t kBlockStatRows = 2048 + 8;
 
 enum : uint32_t {

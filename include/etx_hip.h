@@ -226,6 +226,8 @@ typedef struct etx_hip_stats_t {
   /* adaptive sampling (path tracing with Scene::noise_threshold > 0: Film::estimate_noise_levels / active_pixel) */
   uint64_t active_pixels;        /* pixels sampled, total since etx_hip_begin */
   uint64_t last_active_pixels;   /* pixels sampled by the most recently finished iteration: 0 = every pixel has converged (CPUPathTracing stops, path_tracing.cxx:91-93) */
+  uint64_t boundary_crossings;   /* closest-hit queries the traversal kernel ran beyond a medium boundary it crossed itself (paths outside any medium:
+                                    vcm_handle_boundary_bsdf draws nothing); included in rays_extension, not in rays_light / rays_camera (segments shaded) */
 } etx_hip_stats_t;
 
 /* Which kernel groups are timed with HIP events (bit i = the i-th ms_* field above, in declaration order; default: the two
