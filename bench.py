@@ -327,6 +327,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
                                                                 "upload_s": round(upload_seconds, 3)},
                 "samples_per_step": width * height,
                 "parallelism": "iteration-sharded x%d, one RCCL film all-reduce at the end" % world,
+                "working_set_gb": round(ctx.device_bytes() / 1.0e9, 2),  # queues, pools, grid and film of all lanes (etx_hip_device_bytes)
             },
             "roofline": {
                 "kernel": ("k_trace_closest_bvh (ray queue -> hit queue; BVH4, top levels staged in LDS, persistent workgroups)" if spectral_workload

@@ -82,6 +82,8 @@ struct etx_hip_context {
   uint32_t check_interval = 3;       // rounds the host may enqueue beyond the newest round the device has reported (run_bounce_loop)
   uint32_t timer_mask = (1u << kTimerTraceClosest) | (1u << kTimerTraceShadow);
   uint32_t cross_mode = 0;           // which path state the traversal kernel may advance across medium boundaries (kernels.h launch_trace_closest): set per iteration by the integrator
+  size_t allocated_bytes = 0;        // of this lane's pipeline (etx_hip_device_bytes)
+  uint32_t base_lanes = 1, active_lanes = 1;  // public context: lanes every integrator uses / lanes the armed integrator uses
   uint32_t debug_flags = 0;          // etx_hip_set_debug_flags: ablation switches of the kernels (Pipeline::debug_flags), 0 in production
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
@@ -160,6 +162,7 @@ int device_alloc(etx_hip_context* ctx, T*& ptr, size_t count) {
     return ETX_HIP_ERROR_HIP;
   }
   ctx->allocations.push_back(p);
+  ctx->allocated_bytes += bytes;
   ptr = reinterpret_cast<T*>(p);
   return 0;
 }
@@ -168,6 +171,7 @@ void release_pipeline(etx_hip_context* ctx) {
   for (void* p : ctx->allocations)
     (void)hipFree(p);
   ctx->allocations.clear();
+  ctx->allocated_bytes = 0;
   ctx->pipe = {};
   ctx->resolve_buffer = nullptr;
   ctx->pt_iteration_image = nullptr;
@@ -238,10 +242,10 @@ int allocate_pipeline(etx_hip_context* ctx) {
     return rc;
   if ((rc = device_alloc(ctx, p.light_path_head, n)) || (rc = device_alloc(ctx, p.light_path_len, n)) || (rc = device_alloc(ctx, p.light_path_table, size_t(n) * (kPathTableEntries / 4u))))
     return rc;
+  // the photon grid (a quarter of a lane's memory: 176 B per pooled light vertex) is allocated by the first etx_hip_begin(VCM): the path
+  // tracer and the bidirectional integrator never touch it (allocate_photon_grid)
+  p.grid = {};
   p.grid.hash_capacity = next_pow2(p.lv.capacity);
-  if ((rc = device_alloc(ctx, p.grid.cell_ends, p.grid.hash_capacity)) || (rc = device_alloc(ctx, p.grid.pos_len, p.lv.capacity)) ||
-      (rc = device_alloc(ctx, p.grid.rec, size_t(p.lv.capacity) * PhotonGrid::kPhotonStride)) || (rc = device_alloc(ctx, p.grid.block_sums, p.grid.hash_capacity / 2048u + 1024u)))
-    return rc;
   if ((rc = device_alloc(ctx, p.grid_params, 1)))
     return rc;
   if ((rc = device_alloc(ctx, p.cv.hit, cvn)) || (rc = device_alloc(ctx, p.cv.wi_medium, cvn)) || (rc = device_alloc(ctx, p.cv.thr_depth, cvn)) || (rc = device_alloc(ctx, p.cv.mis_pixel, cvn)) ||
@@ -282,6 +286,43 @@ int allocate_pipeline(etx_hip_context* ctx) {
   if (ctx->owner == nullptr)
     HIP_OK(ctx, hipMemset(p.camera_sum, 0, size_t(n) * kFilmLayers * sizeof(float4)));
   HIP_OK(ctx, hipMemset(ctx->pt_iteration_image, 0, size_t(n) * 2u * sizeof(float4)));
+  return 0;
+}
+
+// VCMSpatialGrid storage of one lane, on first use (etx_hip_begin with the VCM integrator)
+int allocate_photon_grid(etx_hip_context* ctx) {
+  Pipeline& p = ctx->pipe;
+  if (p.grid.rec != nullptr)
+    return 0;
+  HIP_OK(ctx, hipSetDevice(ctx->device));
+  int rc = 0;
+  if ((rc = device_alloc(ctx, p.grid.cell_ends, p.grid.hash_capacity)) || (rc = device_alloc(ctx, p.grid.pos_len, p.lv.capacity)) ||
+      (rc = device_alloc(ctx, p.grid.rec, size_t(p.lv.capacity) * PhotonGrid::kPhotonStride)) || (rc = device_alloc(ctx, p.grid.block_sums, p.grid.hash_capacity / 2048u + 1024u)))
+    return rc;
+  return 0;
+}
+
+constexpr int kBaseLanes = 4, kBidirectionalLanes = 6;
+
+bool lane_ready(const etx_hip_context* lane) {
+  return lane->allocations.empty() == false;
+}
+
+uint32_t lanes_for_integrator(const etx_hip_context* context, int integrator) {
+  const uint32_t created = uint32_t(context->helpers.size()) + 1u;
+  return (integrator == ETX_HIP_INTEGRATOR_BDPT) ? created : std::min(created, context->base_lanes);
+}
+
+// pools of the lanes every integrator uses, after the public context's own (etx_hip_upload_scene / etx_hip_update_scene)
+int allocate_base_lanes(etx_hip_context* context) {
+  for (size_t i = 0; i + 1u < context->base_lanes && i < context->helpers.size(); ++i) {
+    etx_hip_context* helper = context->helpers[i];
+    helper->scene.borrow(context->scene);
+    if (int rc = allocate_pipeline(helper)) {
+      context->error = helper->error;
+      return rc;
+    }
+  }
   return 0;
 }
 
@@ -921,9 +962,14 @@ int etx_hip_create(int device, etx_hip_context** out_context) {
   int rc = init_lane(ctx.get(), device, g_create_error);
   // ETX_HIP_LANES: iterations in flight. Measured at 1080p (fog Cornell): 1 lane 55, 2 lanes 78, 3 lanes 89, 4 lanes 92,
   // 6 lanes 93 Msamples/s - the thin tails and small bounces of one iteration hide behind the wide bounces of the others.
-  int lanes = 4;
+  // The bidirectional integrator gains from more (configs[3]: 25.3 -> 26.6 with six, configs[4]: 192 -> 201): its walk / shadow / connect
+  // kernels are latency-bound and narrow. Lanes past the fourth get their pools on the first etx_hip_begin that uses them
+  // (lanes_for_integrator), so VCM and path-tracing renders do not pay their memory.
+  int lanes = kBidirectionalLanes;
+  ctx->base_lanes = kBaseLanes;
   if (const char* e = getenv("ETX_HIP_LANES"))
-    lanes = std::min(8, std::max(1, atoi(e)));
+    ctx->base_lanes = lanes = std::min(8, std::max(1, atoi(e)));
+  ctx->active_lanes = ctx->base_lanes;
   for (int l = 1; (rc == ETX_HIP_OK) && (l < lanes); ++l) {
     auto* helper = new etx_hip_context();
     helper->owner = ctx.get();
@@ -989,14 +1035,8 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
   rc = allocate_pipeline(context);
   if (rc)
     return rc;
-  for (etx_hip_context* helper : context->helpers) {
-    helper->scene.borrow(context->scene);
-    rc = allocate_pipeline(helper);
-    if (rc) {
-      context->error = helper->error;
-      return rc;
-    }
-  }
+  if ((rc = allocate_base_lanes(context)))
+    return rc;
   HIP_OK(context, hipDeviceSynchronize());
   context->scene_ready = true;
   return ETX_HIP_OK;
@@ -1062,14 +1102,8 @@ int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, c
   rc = allocate_pipeline(context);
   if (rc)
     return rc;
-  for (etx_hip_context* helper : context->helpers) {
-    helper->scene.borrow(context->scene);
-    rc = allocate_pipeline(helper);
-    if (rc) {
-      context->error = helper->error;
-      return rc;
-    }
-  }
+  if ((rc = allocate_base_lanes(context)))
+    return rc;
   HIP_OK(context, hipDeviceSynchronize());
   context->scene_ready = true;
   return ETX_HIP_OK;
@@ -1164,6 +1198,18 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
   (void)wait_idle(context);  // iterations of the previous run
+  const uint32_t lanes_wanted = lanes_for_integrator(context, integrator);
+  for (uint32_t i = 0; i + 1u < lanes_wanted; ++i) {
+    etx_hip_context* helper = context->helpers[i];
+    if (lane_ready(helper))
+      continue;
+    helper->scene.borrow(context->scene);
+    if (int rc = allocate_pipeline(helper)) {
+      context->error = helper->error;
+      release_pipeline(helper);
+      return rc;
+    }
+  }
   if (integrator == ETX_HIP_INTEGRATOR_VCM) {
     if ((options == nullptr) || (options_size != sizeof(etx_abi_vcm_options))) {
       context->error = "VCM expects etx_abi_vcm_options (32 bytes)";
@@ -1268,6 +1314,18 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
     context->sticky_error = 0;
     context->sticky_error_text.clear();
   }
+  if (integrator == ETX_HIP_INTEGRATOR_VCM) {
+    if (int rc = allocate_photon_grid(context))
+      return rc;
+    for (etx_hip_context* helper : context->helpers) {
+      if (lane_ready(helper) == false)
+        continue;
+      if (int rc = allocate_photon_grid(helper)) {
+        context->error = helper->error;
+        return rc;
+      }
+    }
+  }
   const size_t pixels = size_t(context->pipe.capacity);
   if (noise_threshold > 0.0f) {
     if (context->adaptive_pixels != pixels) {
@@ -1282,6 +1340,7 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
   context->noise_threshold = noise_threshold;
   context->pipe.adaptive_sum = (noise_threshold > 0.0f) ? context->adaptive_sum : nullptr;
   context->pipe.pixel_state = (noise_threshold > 0.0f) ? context->pixel_state : nullptr;
+  context->active_lanes = lanes_wanted;
   for (etx_hip_context* helper : context->helpers) {
     helper->noise_threshold = noise_threshold;
     helper->pipe.adaptive_sum = context->pipe.adaptive_sum;
@@ -1295,8 +1354,10 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
   const size_t n = size_t(context->pipe.capacity);
   HIP_OK(context, hipMemsetAsync(context->pipe.camera_sum, 0, n * kFilmLayers * sizeof(float4), context->stream));
   HIP_OK(context, hipMemsetAsync(context->pt_iteration_image, 0, n * 2u * sizeof(float4), context->stream));
-  for (etx_hip_context* helper : context->helpers)
-    HIP_OK(context, hipMemsetAsync(helper->pt_iteration_image, 0, n * 2u * sizeof(float4), context->stream));
+  for (etx_hip_context* helper : context->helpers) {
+    if (lane_ready(helper))
+      HIP_OK(context, hipMemsetAsync(helper->pt_iteration_image, 0, n * 2u * sizeof(float4), context->stream));
+  }
   HIP_OK(context, hipStreamSynchronize(context->stream));  // the lanes run on their own streams
   context->armed = true;
   return ETX_HIP_OK;
@@ -1319,7 +1380,7 @@ int submit_iteration(etx_hip_context* context, bool wait) {
   // after the previous iteration left (Film::estimate_noise_levels runs serially between iterations, path_tracing.cxx:91-99), so such a
   // render uses ONE lane: iterations neither overlap nor race on the shared mask, and a render is the same every time it runs.
   const bool serial = (context->integrator == ETX_HIP_INTEGRATOR_PT) && (context->noise_threshold > 0.0f);
-  const uint32_t lane_count = serial ? 1u : (uint32_t(context->helpers.size()) + 1u);
+  const uint32_t lane_count = serial ? 1u : context->active_lanes;
   etx_hip_context* lane = nullptr;
   {
     std::unique_lock<std::mutex> lock(context->shared_mutex);
@@ -1332,7 +1393,7 @@ int submit_iteration(etx_hip_context* context, bool wait) {
     if (context->jobs_in_flight >= lane_count)
       return 0;  // every lane is busy (try variant)
     lane = context->lane_busy ? nullptr : context;
-    for (size_t i = 0; (serial == false) && (lane == nullptr) && (i < context->helpers.size()); ++i)
+    for (size_t i = 0; (serial == false) && (lane == nullptr) && (i + 1u < lane_count); ++i)
       lane = context->helpers[i]->lane_busy ? nullptr : context->helpers[i];
     if (lane == nullptr) {
       context->error = "internal: no free lane";
@@ -1646,6 +1707,15 @@ int etx_hip_checkpoint_load(etx_hip_context* context, const void* src, size_t sr
     context->totals.last_active_pixels = header.last_active_pixels;
   }
   return ETX_HIP_OK;
+}
+
+size_t etx_hip_device_bytes(const etx_hip_context* context) {
+  if (context == nullptr)
+    return 0;
+  size_t bytes = context->allocated_bytes;
+  for (const etx_hip_context* helper : context->helpers)
+    bytes += helper->allocated_bytes;
+  return bytes;
 }
 
 int etx_hip_set_debug_flags(etx_hip_context* context, uint32_t flags) {

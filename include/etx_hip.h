@@ -150,7 +150,8 @@ int etx_hip_upload_rgb_response(etx_hip_context* context, const float* rgb, uint
 int etx_hip_begin(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride);
 
 /* Hands one full iteration (VCM: light pass, grid build, camera pass; PT: one sample per pixel) to a free device lane and
- * returns without waiting for it; blocks only while every lane (ETX_HIP_LANES, default 4) is busy. */
+ * returns without waiting for it; blocks only while every lane is busy (four for VCM and path tracing, six for the
+ * bidirectional integrator; ETX_HIP_LANES=n, 1..8, fixes one count for all three). */
 int etx_hip_render_iteration(etx_hip_context* context);
 
 /* The same without ever blocking: 1 = the iteration was handed to a free device lane, 0 = every lane is busy (call again
@@ -241,6 +242,12 @@ int etx_hip_stats(etx_hip_context* context, etx_hip_stats_t* out_stats, size_t s
  * bits 8 / 9 no next event estimation / no camera vertex storage. Waits for the iterations in flight. The library reads no
  * environment variable for these; builds with -DETX_HIP_DEBUG additionally read tuning knobs (csrc/tuning_knobs.h). */
 int etx_hip_set_debug_flags(etx_hip_context* context, uint32_t flags);
+
+/* Device memory of the per-iteration working sets (queues, vertex pools, photon grid, film) of all lanes, in bytes: what a render of
+ * the uploaded scene with the integrators used so far holds besides the scene itself. The photon grid of a lane exists from the first
+ * etx_hip_begin(VCM) on, the pools of the fifth and sixth lane from the first etx_hip_begin(BDPT) on; both until the next
+ * etx_hip_upload_scene / etx_hip_update_scene. */
+size_t etx_hip_device_bytes(const etx_hip_context* context);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* multi GPU: iterations are sharded over ranks (etx_hip_begin first/stride); the only exchange is one RCCL

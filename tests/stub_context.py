@@ -52,6 +52,9 @@ class StubContext:
     def upload_bluenoise(self, set_index, table):
         self.calls.append(("upload_bluenoise", set_index))
 
+    def device_bytes(self):
+        return 0
+
     def set_timers(self, mask):
         self.calls.append(("set_timers", mask))
 

@@ -136,3 +136,36 @@ def test_checkpoint_of_another_run_is_refused(etx, golden_dir):
     with pytest.raises(etx.EtxHipError, match="different run"):
         sharded.resume(blob)
     sharded.context.close()
+
+
+def test_working_set_follows_the_integrators_in_use(etx, golden_dir):
+    """etx_hip_device_bytes: the photon grid belongs to VCM and the fifth / sixth lane to the bidirectional integrator - a context that
+    never runs them never allocates them, one that switches integrators (the reference's GUI does, app.cxx integrator list) renders the
+    same films afterwards."""
+    if os.environ.get("ETX_HIP_LANES"):
+        pytest.skip("lane counts fixed by ETX_HIP_LANES")
+    pt = make(etx, golden_dir, etx.HIPPathTracing, "full", 8, {"bn": False}, noise_threshold=0.0)
+    pt.render()
+    pt_bytes = pt.context.device_bytes()
+    pt.context.close()
+
+    bdpt = make(etx, golden_dir, etx.HIPBidirectional, "full", 16, {"bdpt-mode": etx.api.BDPT_MODE_FULL, "bdpt-blue_noise": False})
+    bdpt.render()
+    bdpt_bytes = bdpt.context.device_bytes()
+    cam_b, light_b = films(etx, bdpt)
+    assert bdpt_bytes > pt_bytes * 1.3, "six lanes against four: %d vs %d bytes" % (bdpt_bytes, pt_bytes)
+
+    # the same context, now VCM: the grid arrives for the four lanes VCM uses; then the bidirectional render again
+    vcm = etx.HIPVCM(bdpt.snapshot)
+    vcm.context.close()
+    vcm.context, vcm._uploaded_version = bdpt.context, bdpt._uploaded_version  # the scene is on the device already
+    vcm.options().update({"vcm-blue_noise": False})
+    vcm.render()
+    vcm_bytes = bdpt.context.device_bytes()
+    assert vcm_bytes > bdpt_bytes, "photon grid: %d vs %d bytes" % (vcm_bytes, bdpt_bytes)
+    bdpt.render()
+    assert bdpt.context.device_bytes() == vcm_bytes
+    cam_b2, light_b2 = films(etx, bdpt)
+    close_films(cam_b, cam_b2, "bdpt camera film after a VCM render in the same context")
+    close_films(light_b, light_b2, "bdpt light film after a VCM render in the same context")
+    bdpt.context.close()
