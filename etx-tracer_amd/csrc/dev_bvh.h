@@ -505,6 +505,29 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
   return true;
 }
 
+// The same query on a tree scene that holds no Class::Boundary material and no density grid (DScene::boundary_materials,
+// heterogeneous_mediums): the segment is occluded or it is not, and what it crosses is the homogeneous medium it started in -
+// one any-hit traversal and one exp, a third fewer registers than the general function (k_trace_shadow<false, kDeep, true>).
+template <class Tris, class Stack>
+ETX_DEV f3 bvh_transmittance_opaque(const DScene& scene, const BvhNodes& nodes, Tris tris, int32_t root, const Stack& stack, const f3& p0, const f3& p1, uint32_t medium_index,
+  float wavelength, uint32_t& alpha_seed) {
+  f3 direction = p1 - p0;
+  float t_max = dot(direction, direction);
+  if (t_max <= kRayEpsilon)
+    return mk3(1.0f);
+  t_max = sqrtf(t_max);
+  direction = direction / t_max;
+  t_max -= fmaxf(kRayEpsilon, t_max * kRayEpsilon);
+  if (bvh_occluded(scene, nodes, tris, root, stack, RayQ{p0, kRayEpsilon, direction, t_max}, alpha_seed))
+    return mk3(0.0f);
+  if (medium_index == kInvalid)
+    return mk3(1.0f);
+  f3 absorption, scattering;
+  medium_coefficients(scene, scene.mediums[medium_index], wavelength, absorption, scattering);
+  const f3 ext = absorption + scattering;
+  return {expf(-ext.x * t_max), expf(-ext.y * t_max), expf(-ext.z * t_max)};
+}
+
 // Transmittance between p0 and p1 starting in `medium_index` (rt.cxx:468-579).
 // The reference collects up to 63 Boundary hits in one traversal and sorts them; here the boundaries are visited in
 // order by restarting the closest-hit search behind each one (same products, no per-lane hit buffer).

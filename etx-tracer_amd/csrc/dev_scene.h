@@ -144,6 +144,7 @@ struct DScene {
   uint32_t vertex_count, triangle_count, material_count, emitter_count, emitter_dist_count, spectrum_count, image_count, medium_count;
   uint32_t bvh_node_count, bvh_tri_count, flat_prim_count;
   uint32_t boundary_materials;  // materials of Class::Boundary in the table: 0 = a transmittance query is a pure occlusion test (dev_bvh.h bvh_occluded)
+  uint32_t heterogeneous_mediums;  // media with a density grid: 0 = every medium_transmittance is one exp (selects the lean shadow kernel together with boundary_materials)
   int32_t bvh_root;  // child encoding (a single leaf scene has a negative root)
   uint32_t bvh_depth; // levels of inner BVH4 nodes
   uint32_t bvh_stack_need;  // stack entries the traversal can need (host bound over the tree): selects the kernel variant

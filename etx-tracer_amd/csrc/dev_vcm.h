@@ -10,6 +10,35 @@
 
 namespace etxd {
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cell-ordered photon merge (kernels_connect.hip): camera vertices are counting-sorted by a coarse spatial bucket. The predicate and
+// the bucket are shared by the histogram (store_camera_vertex, dev_vcm_steps.h) and the scatter (k_merge_scatter).
+ETX_DEV uint32_t spread_bits_6(uint32_t v) {  // 6 bits -> every third bit
+  v &= 0x3fu;
+  v = (v | (v << 8u)) & 0x300fu;
+  v = (v | (v << 4u)) & 0x30c3u;
+  v = (v | (v << 2u)) & 0x9249u;
+  return v;
+}
+
+ETX_DEV uint32_t merge_bucket(const GridParams& g, const f3& pos) {
+  // coarse block coordinates: the scene extent maps to 64 blocks per axis
+  f3 ext = g.bbox_max - g.bbox_min;
+  float scale = float(1u << kMergeBucketBits) / fmaxf(fmaxf(ext.x, ext.y), fmaxf(ext.z, g.cell_size));
+  f3 q = (pos - g.bbox_min) * scale;
+  uint32_t x = min(uint32_t(fmaxf(q.x, 0.0f)), (1u << kMergeBucketBits) - 1u);
+  uint32_t y = min(uint32_t(fmaxf(q.y, 0.0f)), (1u << kMergeBucketBits) - 1u);
+  uint32_t z = min(uint32_t(fmaxf(q.z, 0.0f)), (1u << kMergeBucketBits) - 1u);
+  return spread_bits_6(x) | (spread_bits_6(y) << 1u) | (spread_bits_6(z) << 2u);
+}
+
+// VCMSpatialGridData::gather's early-outs (vcm_shared.hxx:886-893) on a stored camera vertex: pos_info.w = (depth << 8) | kCv* flags
+ETX_DEV bool merge_candidate(const GridParams& g, uint32_t max_path_length, uint32_t info, const f3& pos) {
+  if ((g.valid == 0u) || (g.photon_count == 0u) || (info & (kCvMedium | kCvNoMerge)) || ((info >> 8u) + 1u > max_path_length))
+    return false;
+  return (pos.x >= g.bbox_min.x) && (pos.y >= g.bbox_min.y) && (pos.z >= g.bbox_min.z) && (pos.x <= g.bbox_max.x) && (pos.y <= g.bbox_max.y) && (pos.z <= g.bbox_max.z);
+}
+
 struct PathState {  // VCMPathState (vcm_shared.hxx:91-150) minus the per-pixel accumulators (they live in the film)
   f3 ray_o;
   float ray_tmin;

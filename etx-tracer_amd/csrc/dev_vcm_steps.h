@@ -30,8 +30,9 @@ ETX_DEV void store_light_vertex(const Pipeline& p, uint32_t idx, const PathState
 }
 
 
+// merge_histogram: the iteration merges photons - a vertex k_merge_scatter will sort counts itself into its coarse bucket here
 ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& scene, const PathState& st, const float4& hit_or_pos, uint32_t seed, const Isect* isect,
-  bool exit_material = false, uint32_t use_flags = 0u) {
+  bool exit_material = false, uint32_t use_flags = 0u, bool merge_histogram = false) {
   if (idx >= p.cv_capacity) {  // the tail kernel, or more exit points of Christensen-Burley vertices than the pool was sized for
     atomicOr(p.counters + kCntOverflow, kOverflowCameraVertices);
     return;
@@ -51,9 +52,15 @@ ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& 
   f3 fthr = st.throughput;
   if (diffuse)
     fthr = fthr * apply_image(scene, mat.scattering, isect->tex, nullptr, st.wavelength) * kInvPi;  // DiffuseBSDF func (bsdf_various.hxx:60-64) x t_camera
-  p.cv.pos_info[idx] = mk4(isect->pos, __uint_as_float((st.depth << 8u) | (diffuse ? kCvDiffuse : 0u) | use_flags));
+  const uint32_t info = (st.depth << 8u) | (diffuse ? kCvDiffuse : 0u) | use_flags;
+  p.cv.pos_info[idx] = mk4(isect->pos, __uint_as_float(info));
   p.cv.nrm_dvm[idx] = mk4(isect->nrm, st.d_vm);
   p.cv.fthr_dvcm[idx] = mk4(fthr, st.d_vcm);
+  if (merge_histogram) {
+    const GridParams& g = *p.grid_params;
+    if (merge_candidate(g, scene.max_path_length, info, isect->pos))
+      atomicAdd(p.merge_buckets + merge_bucket(g, isect->pos), 1u);
+  }
 }
 
 
@@ -407,9 +414,9 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       scaled.throughput = st.throughput * ss_weight;
       scaled.ray_d = ss_isect.w_i;
       store_camera_vertex(p, vertex_slot, scene, scaled, make_float4(ss_isect.bc.y, ss_isect.bc.z, ss_isect.t, __uint_as_float(ss_isect.tri)), derived.seed, &ss_isect, true,
-        cb_vertex ? kCvNoConnect : 0u);
+        cb_vertex ? kCvNoConnect : 0u, opt_merge_vertices(it));
     } else {
-      store_camera_vertex(p, vertex_slot, scene, st, h, derived.seed, &isect);
+      store_camera_vertex(p, vertex_slot, scene, st, h, derived.seed, &isect, false, 0u, opt_merge_vertices(it));
     }
   }
   // next event estimation; vcm_shared.hxx:1036-1046: after a walk, from the exit point scaled by the walk

@@ -533,6 +533,8 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
     ScopedTimer t(ctx, kTimerGenerate);
     launch_camera_generate(s, p, it);
   }
+  if (opt_merge_vertices(it))
+    launch_merge_reset(s, p);
   rc = run_bounce_loop(
     ctx,
     [&](uint32_t set, uint32_t max_items) {

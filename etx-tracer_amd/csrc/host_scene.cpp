@@ -1197,6 +1197,9 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   d.spectrum_count = uint32_t(scene->spectrums.count);
   d.image_count = uint32_t(scene->images.count);
   d.medium_count = uint32_t(scene->mediums.count);
+  d.heterogeneous_mediums = 0u;
+  for (uint64_t i = 0; i < scene->mediums.count; ++i)
+    d.heterogeneous_mediums += (reinterpret_cast<const etx_abi_medium*>(scene->mediums.a)[i].cls != 0) ? 1u : 0u;
   d.env_count = scene->environment_emitters.count;
   memcpy(d.env_emitters, scene->environment_emitters.emitters, sizeof(d.env_emitters));
   d.bounds_center = a3(scene->bounding_sphere_center);

@@ -63,6 +63,7 @@ void launch_camera_generate(hipStream_t stream, const Pipeline& p, const VcmPara
 void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups);
 void launch_connect_endpoints(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool camera_pass, uint32_t max_items);  // general / subsurface groups (pipeline.h EndpointQueue)
 void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items);
+void launch_merge_reset(hipStream_t stream, const Pipeline& p);
 void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items);
 
 // film

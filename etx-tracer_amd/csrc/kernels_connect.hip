@@ -204,53 +204,9 @@ ETX_DEV bool merge_cell_range(const Pipeline& p, const GridParams& g, const f3& 
 // its photons from HBM (PMC: 42 GB per iteration, 22 % L2 hits). The vertices of a bounce are therefore counting-sorted
 // by a coarse spatial bucket (64^3 Morton-ordered blocks) and the merge walks them in that order, each XCD owning one
 // contiguous eighth of the list so that its private L2 sees a compact working set (PMC after: 13 GB, 59 % L2 hits).
-// Only indices are sorted (4 B per vertex).
-ETX_DEV uint32_t spread_bits_6(uint32_t v) {  // 6 bits -> every third bit
-  v &= 0x3fu;
-  v = (v | (v << 8u)) & 0x300fu;
-  v = (v | (v << 4u)) & 0x30c3u;
-  v = (v | (v << 2u)) & 0x9249u;
-  return v;
-}
-
-ETX_DEV uint32_t merge_bucket(const GridParams& g, const f3& pos) {
-  // coarse block coordinates: the scene extent maps to 64 blocks per axis
-  f3 ext = g.bbox_max - g.bbox_min;
-  float scale = float(1u << kMergeBucketBits) / fmaxf(fmaxf(ext.x, ext.y), fmaxf(ext.z, g.cell_size));
-  f3 q = (pos - g.bbox_min) * scale;
-  uint32_t x = min(uint32_t(fmaxf(q.x, 0.0f)), (1u << kMergeBucketBits) - 1u);
-  uint32_t y = min(uint32_t(fmaxf(q.y, 0.0f)), (1u << kMergeBucketBits) - 1u);
-  uint32_t z = min(uint32_t(fmaxf(q.z, 0.0f)), (1u << kMergeBucketBits) - 1u);
-  return spread_bits_6(x) | (spread_bits_6(y) << 1u) | (spread_bits_6(z) << 2u);
-}
-
-ETX_DEV bool merge_candidate(const Pipeline& p, const GridParams& g, uint32_t max_path_length, uint32_t vertex, f3& pos) {
-  const float4 pi = p.cv.pos_info[vertex];
-  const uint32_t info = __float_as_uint(pi.w);
-  pos = {pi.x, pi.y, pi.z};
-  if ((info & (kCvMedium | kCvNoMerge)) || ((info >> 8u) + 1u > max_path_length))
-    return false;
-  return (pos.x >= g.bbox_min.x) && (pos.y >= g.bbox_min.y) && (pos.z >= g.bbox_min.z) && (pos.x <= g.bbox_max.x) && (pos.y <= g.bbox_max.y) && (pos.z <= g.bbox_max.z);
-}
-
-__global__ __launch_bounds__(kBlockSize) void k_merge_clear(Pipeline p) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= kMergeBuckets; i += gridDim.x * blockDim.x)
-    p.merge_buckets[i] = 0u;
-}
-
-__global__ __launch_bounds__(kBlockSize) void k_merge_count(Pipeline p) {
-  const GridParams g = *p.grid_params;
-  if ((g.valid == 0u) || (g.photon_count == 0u))
-    return;
-  const uint32_t count = min(p.counters[kCntCameraVertices], p.cv_capacity);
-  const uint32_t max_path_length = p.scene.max_path_length;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-    f3 pos;
-    if (merge_candidate(p, g, max_path_length, i, pos))
-      atomicAdd(p.merge_buckets + merge_bucket(g, pos), 1u);
-  }
-}
-
+// Only indices are sorted (4 B per vertex). The histogram is taken where the vertices are written (store_camera_vertex, dev_vcm_steps.h:
+// one atomic per vertex in the shade kernel instead of a pass over the pool) and zeroed again by k_merge_diffuse, which no longer needs it:
+// per bounce the sort costs two scan launches and one scatter (merge_bucket / merge_candidate: dev_vcm.h).
 // Exclusive scan of the 2^18 bucket counters in two small launches (one block over 1 MiB took 96 us per bounce):
 // kMergeScanBlocks workgroups of 256 threads, one uint4 per thread; the first launch leaves every workgroup's total
 // behind the counters, the second scans those totals in LDS (every workgroup redundantly) and then its own 1024 counters.
@@ -320,8 +276,9 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_scatter(Pipeline p) {
   const uint32_t count = min(p.counters[kCntCameraVertices], p.cv_capacity);
   const uint32_t max_path_length = p.scene.max_path_length;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-    f3 pos;
-    if (merge_candidate(p, g, max_path_length, i, pos))
+    const float4 pi = p.cv.pos_info[i];
+    const f3 pos = {pi.x, pi.y, pi.z};
+    if (merge_candidate(g, max_path_length, __float_as_uint(pi.w), pos))
       p.merge_order[atomicAdd(p.merge_buckets + merge_bucket(g, pos), 1u)] = i;
   }
 }
@@ -358,6 +315,9 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
   const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntMergeVertices], p.cv_capacity);
   const GridParams g = *p.grid_params;
+  // the bucket cursors k_merge_scatter left behind: zero for the next bounce's histogram (nothing below reads them)
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= kMergeBuckets; i += gridDim.x * blockDim.x)
+    p.merge_buckets[i] = 0u;
   if ((g.valid == 0u) || (g.photon_count == 0u))
     return;
   const uint32_t items = count * 8u;
@@ -663,10 +623,13 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
   block_stat_add(p, kBlockStatMerged, merged_count, &s_stat);
 }
 
+// before the first camera bounce of an iteration: an empty histogram (afterwards k_merge_diffuse leaves one behind)
+void launch_merge_reset(hipStream_t stream, const Pipeline& p) {
+  (void)hipMemsetAsync(p.merge_buckets, 0, (kMergeBuckets + 1u) * sizeof(uint32_t), stream);
+}
+
 void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items) {
   const uint32_t vertex_blocks = max(1u, grid_for(min(max_items, p.capacity)));
-  hipLaunchKernelGGL(k_merge_clear, dim3(256), dim3(kBlockSize), 0, stream, p);
-  hipLaunchKernelGGL(k_merge_count, dim3(vertex_blocks), dim3(kBlockSize), 0, stream, p);
   hipLaunchKernelGGL(k_merge_scan_totals, dim3(kMergeScanBlocks), dim3(kBlockSize), 0, stream, p);
   hipLaunchKernelGGL(k_merge_scan, dim3(kMergeScanBlocks), dim3(kBlockSize), 0, stream, p);
   hipLaunchKernelGGL(k_merge_scatter, dim3(vertex_blocks), dim3(kBlockSize), 0, stream, p);

@@ -462,10 +462,18 @@ void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, u
 // workgroups per CU. (256 staged nodes = 64 KB left two: the kernel waits on the node fetches below the staged levels, and more
 // wavefronts hide more of that than more staged levels save.)
 constexpr uint32_t kShadowLdsNodes = 64u;
-template <bool kFlat, bool kDeep = false>
+// The opaque kernel (no boundaries, no density grids: 94 VGPRs instead of 137) stages no nodes: 32 KB of stacks = five workgroups per CU,
+// which its registers allow as well. configs[3] (47 M segments on a 102 k-triangle tree per iteration), six lanes: general kernel 26.5,
+// opaque with 64 staged nodes 27.6, without 28.7 Msamples/s (interleaved A/B in one session, tools/gpu_r3n.sh).
+#if !defined(ETX_SHADOW_OPAQUE_NODES)
+#define ETX_SHADOW_OPAQUE_NODES 0u
+#endif
+// kOpaque (tree scenes only): no Class::Boundary material and no density grid in the scene - bvh_transmittance_opaque
+template <bool kFlat, bool kDeep = false, bool kOpaque = false>
 __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
   __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
-  __shared__ float4 s_nodes[kFlat ? 1 : kShadowLdsNodes * 8u];
+  constexpr uint32_t kLdsNodes = kOpaque ? uint32_t(ETX_SHADOW_OPAQUE_NODES) : kShadowLdsNodes;
+  __shared__ float4 s_nodes[(kFlat || (kLdsNodes == 0u)) ? 1 : kLdsNodes * 8u];
   const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntShadow], p.shadow.capacity);
   const uint32_t lane = threadIdx.x & 63u;
@@ -473,8 +481,8 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
   const typename TraversalStack<kDeep>::Type stack = TraversalStack<kDeep>::make(scene, s_stack + (kFlat ? 0u : threadIdx.x), kBlockSize);  // a flat scene only touches it when a segment crosses > 4 boundaries
   uint32_t splats = 0;
   BvhNodes nodes = global_nodes(scene);
-  if ((kFlat == false) && (blockIdx.x * blockDim.x < count))
-    nodes = stage_nodes(scene, s_nodes, kShadowLdsNodes);
+  if ((kFlat == false) && (kLdsNodes != 0u) && (blockIdx.x * blockDim.x < count))
+    nodes = stage_nodes(scene, s_nodes, kLdsNodes);
   for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {
     const uint32_t i = base + lane;
     f3 value = mk3(0.0f);
@@ -484,7 +492,9 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
       const float4 b = p.shadow.p1_target[i];
       uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ i;
       f3 tr = mk3(1.0f);
-      if ((p.debug_flags & 4u) == 0u)
+      if (kOpaque)
+        tr = bvh_transmittance_opaque(scene, nodes, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), p.shadow.value[i].w, alpha_seed);
+      else if ((p.debug_flags & 4u) == 0u)
         tr = bvh_transmittance(scene, nodes, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), p.shadow.value[i].w, alpha_seed);
       target = __float_as_uint(b.w);
       if ((tr.x > kEpsilon) || (tr.y > kEpsilon) || (tr.z > kEpsilon)) {  // SpectralResponse::is_zero
@@ -529,10 +539,20 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
 
 void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_items, bool flat) {
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.shadow.capacity, max_items) + kBlockSize - 1) / kBlockSize));
+#if defined(ETX_NO_OPAQUE_SHADOW)
+  const bool opaque = false;
+#else
+  const bool opaque = (p.scene.boundary_materials == 0u) && (p.scene.heterogeneous_mediums == 0u) && ((p.debug_flags & 4u) == 0u);
+#endif
   if (flat)
     hipLaunchKernelGGL(k_trace_shadow<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p);
-  else if (p.scene.bvh_stack_need > kStackDepth)
-    hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);
+  else if (p.scene.bvh_stack_need > kStackDepth) {
+    if (opaque)
+      hipLaunchKernelGGL((k_trace_shadow<false, true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);
+    else
+      hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);
+  } else if (opaque)
+    hipLaunchKernelGGL((k_trace_shadow<false, false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);
   else
     hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p);
 }

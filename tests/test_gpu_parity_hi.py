@@ -123,7 +123,7 @@ def render_pt(etx, golden_dir, flavour, cie):
 SPECTRAL = ("gems", "diamond", "spectral")
 
 
-@pytest.mark.parametrize("flavour", ["classic", "full", "rough", "glass", "gems", "cloud", "sss"])
+@pytest.mark.parametrize("flavour", ["classic", "full", "rough", "glass", "gems", "cloud", "sss", "ssscb"])
 def test_vcm_matches_reference_at_4096_spp(etx, golden_dir, cie_observer, flavour):
     (cam_a, light_a), (cam_b, light_b) = render_vcm(etx, golden_dir, flavour, cie_observer if flavour in SPECTRAL else None)
     # the reference's estimator with independent light / camera streams: north_star's tolerance
@@ -166,7 +166,7 @@ def inside_reference_spread(golden_dir, flavour, device):
     assert (nearest_mean <= np.maximum(spread_mean, 1.0e-3) + 4.5e-3).all(), (flavour, nearest_mean, spread_mean)
 
 
-@pytest.mark.parametrize("flavour", ["classic", "full", "rough", "glass", "gems", "cloud", "sss"])
+@pytest.mark.parametrize("flavour", ["classic", "full", "rough", "glass", "gems", "cloud", "sss", "ssscb"])
 def test_pt_matches_reference_at_4096_spp(etx, golden_dir, cie_observer, flavour):
     golden = load_hi(golden_dir, "cornell_%s_128_pt_%d.npz" % (flavour, SPP))
     (cam_a, _), (cam_b, _) = render_pt(etx, golden_dir, flavour, cie_observer if flavour in SPECTRAL else None)
