@@ -53,6 +53,33 @@ struct LaneStack {
   }
 };
 
+// The same with kShortStackDepth entries in LDS: kernels that are short of LDS rather than of registers (16 KB of stacks per workgroup
+// instead of 32). Real rays stay below 20 entries, so a few per cent of the pushes go to the spill rows (level - kShortStackDepth).
+constexpr uint32_t kShortStackDepth = 16;
+struct ShortLaneStack {
+  int32_t* base;
+  uint32_t stride;
+  int32_t* spill;
+  uint32_t spill_stride;
+  ETX_DEV void push(uint32_t& sp, int32_t v) const {
+    if (sp < kShortStackDepth)
+      base[sp * stride] = v;
+    else
+      spill[(sp - kShortStackDepth) * spill_stride] = v;
+    sp += 1u;
+  }
+  ETX_DEV int32_t pop(uint32_t& sp) const {
+    sp -= 1u;
+    return (sp < kShortStackDepth) ? base[sp * stride] : spill[(sp - kShortStackDepth) * spill_stride];
+  }
+};
+
+ETX_DEV ShortLaneStack short_lane_stack(const DScene& scene, int32_t* lds_slot, uint32_t stride) {
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t* spill = ((scene.stack_spill != nullptr) && (lane < scene.stack_spill_lanes)) ? (scene.stack_spill + lane) : nullptr;
+  return {lds_slot, stride, spill, scene.stack_spill_lanes};
+}
+
 // `lds_slot`: this lane's slot of level 0 in the workgroup's stack array, `stride`: lanes per level
 ETX_DEV LaneStack lane_stack(const DScene& scene, int32_t* lds_slot, uint32_t stride) {
   const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;

@@ -23,8 +23,8 @@ ETX_DEV void store_light_vertex(const Pipeline& p, uint32_t idx, const PathState
   p.lv.bc_len_med(idx) = make_float4(bc_u, bc_v, __uint_as_float((index_in_path << 16u) | (st.depth & 0xffffu)), __uint_as_float(st.medium));
   p.lv.next(idx) = prev;
   p.lv.wavelength(idx) = st.wavelength;
-  if (index_in_path < kPathTableEntries)
-    reinterpret_cast<uint32_t*>(p.light_path_table)[st.id * kPathTableEntries + index_in_path] = idx;
+  if (index_in_path < p.path_table_entries)
+    reinterpret_cast<uint32_t*>(p.light_path_table)[size_t(st.id) * p.path_table_entries + index_in_path] = idx;
   p.light_path_head[st.id] = idx;  // the photon bounding box is reduced by k_grid_bbox (kernels_grid.hip)
   p.light_path_len[st.id] = index_in_path + 1u;
 }

@@ -78,7 +78,7 @@ struct etx_hip_context {
   uint32_t local_iterations = 0;     // iterations rendered by this context since begin
   uint64_t global_iterations = 0;    // after etx_hip_reduce_film: iterations of all ranks
   bool reduced = false;
-  uint32_t tail_divisor = 64;        // active paths <= capacity / tail_divisor: finish the pass in the tail kernel (0 = never)
+  uint32_t tail_divisor = 32;        // active paths <= capacity / tail_divisor: finish the pass in the tail kernel (0 = never); configs[1]: 64 -> 94.2, 32 -> 96.3, 16 -> 95.2 Msamples/s
   uint32_t check_interval = 3;       // rounds the host may enqueue beyond the newest round the device has reported (run_bounce_loop)
   uint32_t timer_mask = (1u << kTimerTraceClosest) | (1u << kTimerTraceShadow);
   uint32_t cross_mode = 0;           // which path state the traversal kernel may advance across medium boundaries (kernels.h launch_trace_closest): set per iteration by the integrator
@@ -192,9 +192,9 @@ int allocate_pipeline(etx_hip_context* ctx) {
   // a tree whose stack bound exceeds the LDS part: this lane's spill area (dev_bvh.h LaneStack), one column per thread of the
   // largest grid any traversing kernel is launched with
   p.scene.stack_spill = nullptr, p.scene.stack_spill_lanes = 0u;
-  if ((p.scene.bvh_flat == 0u) && (p.scene.bvh_stack_need > kStackDepth)) {
+  if ((p.scene.bvh_flat == 0u) && (p.scene.bvh_stack_need > kShortStackDepth)) {  // rows for the kernels with the short LDS stack, which cover the others'
     const uint32_t spill_lanes = 2u * kPersistentBlocks * kBlockSize;
-    if (int rc = device_alloc(ctx, p.scene.stack_spill, size_t(spill_lanes) * (kMaxStackDepth - kStackDepth)))
+    if (int rc = device_alloc(ctx, p.scene.stack_spill, size_t(spill_lanes) * (kMaxStackDepth - kShortStackDepth)))
       return rc;
     p.scene.stack_spill_lanes = spill_lanes;
   }
@@ -240,7 +240,10 @@ int allocate_pipeline(etx_hip_context* ctx) {
   const uint32_t cvn = p.cv_capacity;
   if ((rc = device_alloc(ctx, p.path_wavelength, n)) || (rc = device_alloc(ctx, p.cv.wavelength, cvn)))
     return rc;
-  if ((rc = device_alloc(ctx, p.light_path_head, n)) || (rc = device_alloc(ctx, p.light_path_len, n)) || (rc = device_alloc(ctx, p.light_path_table, size_t(n) * (kPathTableEntries / 4u))))
+  // a light path that walks through a subsurface object under the bidirectional integrator stores a vertex per scattering event: a longer
+  // table keeps k_expand_pairs off the per-lane list walk (configs[3]: 181 us per launch with eight entries)
+  p.path_table_entries = etxh::tuning_knob("ETX_HIP_PATH_TABLE", ctx->scene.has_subsurface ? kPathTableEntriesWalk : kPathTableEntries) & ~3u;
+  if ((rc = device_alloc(ctx, p.light_path_head, n)) || (rc = device_alloc(ctx, p.light_path_len, n)) || (rc = device_alloc(ctx, p.light_path_table, size_t(n) * (p.path_table_entries / 4u))))
     return rc;
   // the photon grid (a quarter of a lane's memory: 176 B per pooled light vertex) is allocated by the first etx_hip_begin(VCM): the path
   // tracer and the bidirectional integrator never touch it (allocate_photon_grid)

@@ -78,17 +78,23 @@ __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmPara
     }
     if (k == 0u)
       continue;
-    // the first kPathTableEntries vertices come from the path table (two independent 16-byte loads), only longer
+    // the first path_table_entries vertices come from the path table (independent 16-byte loads), only longer
     // paths walk the list from the head down to that index
-    const uint4 t0 = p.light_path_table[path * 2u + 0u];
-    const uint4 t1 = (k > 4u) ? p.light_path_table[path * 2u + 1u] : make_uint4(0u, 0u, 0u, 0u);
-    const uint32_t table[kPathTableEntries] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-    for (uint32_t j = 0; j < kPathTableEntries; ++j)
-      if (j < k)
-        p.pairs[base + j] = make_uint2(i, table[j]);
+    const uint32_t table_entries = p.path_table_entries;
+    const uint4* table = p.light_path_table + size_t(path) * (table_entries >> 2u);
+    for (uint32_t q = 0; (q << 2u) < min(k, table_entries); ++q) {
+      const uint4 t = table[q];
+      const uint32_t j = q << 2u;
+      p.pairs[base + j] = make_uint2(i, t.x);
+      if (j + 1u < k)
+        p.pairs[base + j + 1u] = make_uint2(i, t.y);
+      if (j + 2u < k)
+        p.pairs[base + j + 2u] = make_uint2(i, t.z);
+      if (j + 3u < k)
+        p.pairs[base + j + 3u] = make_uint2(i, t.w);
+    }
     uint32_t vi = head;
-    for (uint32_t j = k; j > kPathTableEntries; --j) {
+    for (uint32_t j = k; j > table_entries; --j) {
       p.pairs[base + j - 1u] = make_uint2(i, vi);
       vi = p.lv.next(vi);
     }

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
 // LDS per workgroup: the per-lane stacks (32 KB) + the first kLdsNodesPersistent nodes of the tree (top levels, 8 KB).
 constexpr uint32_t kRefillLanes = 16;
 
-template <bool kDeep>
+template <bool kDeep, uint32_t kLdsEntries = kStackDepth>
 struct TraversalStack {
   typedef FastLaneStack Type;
   static ETX_DEV Type make(const DScene&, int32_t* lds_slot, uint32_t stride) {
@@ -146,10 +146,17 @@ struct TraversalStack {
   }
 };
 template <>
-struct TraversalStack<true> {  // the tree's bound exceeds the LDS part: entries above kStackDepth go to DScene::stack_spill
+struct TraversalStack<true, kStackDepth> {  // the tree's bound exceeds the LDS part: entries above kStackDepth go to DScene::stack_spill
   typedef LaneStack Type;
   static ETX_DEV Type make(const DScene& scene, int32_t* lds_slot, uint32_t stride) {
     return lane_stack(scene, lds_slot, stride);
+  }
+};
+template <>
+struct TraversalStack<true, kShortStackDepth> {  // half the LDS: entries above kShortStackDepth spill
+  typedef ShortLaneStack Type;
+  static ETX_DEV Type make(const DScene& scene, int32_t* lds_slot, uint32_t stride) {
+    return short_lane_stack(scene, lds_slot, stride);
   }
 };
 
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene s
   if (count == 0u)
     return;
   const BvhNodes nodes = stage_nodes(scene, s_nodes, min(kLdsNodesPersistent, lds_node_limit));
-  const typename TraversalStack<kDeep>::Type stack = TraversalStack<kDeep>::make(scene, s_stack + threadIdx.x, kBlockSize);
+  const typename TraversalStack<kDeep, kDeep ? kStack : kStackDepth>::Type stack = TraversalStack<kDeep, kDeep ? kStack : kStackDepth>::make(scene, s_stack + threadIdx.x, kBlockSize);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6u;
   const uint32_t wave_count = (gridDim.x * blockDim.x) >> 6u;
@@ -417,8 +424,11 @@ static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const flo
   hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, STACK, NODES>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count, round_mirror, \
     round_tag, lds_limit(), refill, pass_stat)
   const uint32_t need = scene.bvh_stack_need;
-  if (need > kStackDepth) {  // a deep tree (> ~40 000 triangles): the checked stack with its global spill (dev_bvh.h LaneStack)
-    hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, kStackDepth, 64u, true>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count,
+  if (((variant == 2u) && (need > kShortStackDepth)) || (need > kStackDepth)) {
+    // a deep tree (> ~40 000 triangles): the checked stack, 16 entries in LDS (24 KB per workgroup with the staged nodes), the rest in the global
+    // spill rows (dev_bvh.h ShortLaneStack). A million triangles: 13.1 vs 12.8 Msamples/s with 32 entries in LDS; trees whose bound fits 32
+    // entries keep the unchecked stack (configs[3], bound 31: no difference)
+    hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, kShortStackDepth, 64u, true>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count,
       round_mirror, round_tag, lds_limit(), refill, pass_stat);
   } else if (variant == 1u) {  // experiments: twice the staged nodes
     if (need <= 16u)
@@ -469,16 +479,26 @@ constexpr uint32_t kShadowLdsNodes = 64u;
 #define ETX_SHADOW_OPAQUE_NODES 0u
 #endif
 // kOpaque (tree scenes only): no Class::Boundary material and no density grid in the scene - bvh_transmittance_opaque
+#if !defined(ETX_SHADOW_OPAQUE_STACK)
+#define ETX_SHADOW_OPAQUE_STACK kShortStackDepth
+#endif
+// waves per SIMD the opaque kernel is compiled for: 7 = 72 VGPRs (three spilled), LDS for sixteen stack entries per lane. configs[3], same
+// session: 98 VGPRs / five waves 28.7, 80 / six 29.0, 72 / seven 29.2 Msamples/s (tools/gpu_r3o.sh)
+#if !defined(ETX_SHADOW_OPAQUE_WAVES)
+#define ETX_SHADOW_OPAQUE_WAVES 7
+#endif
 template <bool kFlat, bool kDeep = false, bool kOpaque = false>
-__global__ __launch_bounds__(kBlockSize) void k_trace_shadow(Pipeline p) {
-  __shared__ int32_t s_stack[kFlat ? 1 : kStackDepth * kBlockSize];
+__global__ __launch_bounds__(kBlockSize, kOpaque ? ETX_SHADOW_OPAQUE_WAVES : 1) void k_trace_shadow(Pipeline p) {
+  constexpr bool kShort = kOpaque && (uint32_t(ETX_SHADOW_OPAQUE_STACK) == kShortStackDepth);  // the opaque kernel: LDS for 16 entries per lane, the rest spills
+  __shared__ int32_t s_stack[kFlat ? 1 : (kShort ? kShortStackDepth : kStackDepth) * kBlockSize];
   constexpr uint32_t kLdsNodes = kOpaque ? uint32_t(ETX_SHADOW_OPAQUE_NODES) : kShadowLdsNodes;
   __shared__ float4 s_nodes[(kFlat || (kLdsNodes == 0u)) ? 1 : kLdsNodes * 8u];
   const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntShadow], p.shadow.capacity);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t stride = gridDim.x * blockDim.x;
-  const typename TraversalStack<kDeep>::Type stack = TraversalStack<kDeep>::make(scene, s_stack + (kFlat ? 0u : threadIdx.x), kBlockSize);  // a flat scene only touches it when a segment crosses > 4 boundaries
+  typedef TraversalStack<kDeep || kShort, kShort ? kShortStackDepth : kStackDepth> StackKind;
+  const typename StackKind::Type stack = StackKind::make(scene, s_stack + (kFlat ? 0u : threadIdx.x), kBlockSize);  // a flat scene only touches it when a segment crosses > 4 boundaries
   uint32_t splats = 0;
   BvhNodes nodes = global_nodes(scene);
   if ((kFlat == false) && (kLdsNodes != 0u) && (blockIdx.x * blockDim.x < count))

@@ -115,7 +115,8 @@ struct ShadowQueue {        // transmittance ("shadow") ray requests of the curr
 };
 
 constexpr uint32_t kShadowTargetLight = 0x80000000u;
-constexpr uint32_t kPathTableEntries = 8;
+constexpr uint32_t kPathTableEntries = 8;          // Pipeline::path_table_entries of scenes without subsurface materials
+constexpr uint32_t kPathTableEntriesWalk = 32;     // ... with: a light path that walked through an object has a vertex per scattering event
 constexpr uint32_t kMergeBucketBits = 6;                                  // per axis
 constexpr uint32_t kMergeBuckets = 1u << (3u * kMergeBucketBits);         // 64^3 coarse buckets
 
@@ -212,8 +213,9 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   uint32_t* light_path_head;   // per path: last stored vertex (kInvalid = none)
   uint32_t* light_path_len;    // per path: stored vertices so far (k_expand_pairs sizes a camera vertex' pair run with it: no dependent read of the head record)
   float* path_wavelength;      // spectral mode: wavelength of light path i, reused by camera path i (vcm_cpu.cxx:186)
-  uint4* light_path_table;     // per path: its first kPathTableEntries vertices by index in path (expand_pairs reads them
-                               // with two independent loads instead of walking the list from the head)
+  uint4* light_path_table;     // per path: its first path_table_entries vertices by index in path (expand_pairs reads them
+                               // with independent 16-byte loads instead of walking the list from the head)
+  uint32_t path_table_entries; // kPathTableEntries or kPathTableEntriesWalk (a multiple of four)
   PhotonGrid grid;
   GridParams* grid_params;
   CameraVertexPool cv;
