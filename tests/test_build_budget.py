@@ -27,11 +27,11 @@ def test_kernel_register_budget():
         k = kernels[name]
         assert k["total_vgprs"] <= 256 and k.get("agprs", 0) == 0 and k["vgpr_spills"] == 0, (name, k)
     assert kernels["void etxd::k_camera_shade<0u, false>"]["total_vgprs"] <= 208  # two waves per SIMD with room; 199 today
-    # shadow segments of tree scenes without Class::Boundary materials and density grids: one any-hit traversal and one exp - five
-    # wavefronts per SIMD where the general kernel has three
+    # shadow segments of tree scenes without Class::Boundary materials and density grids: one any-hit traversal and one exp - compiled for
+    # seven wavefronts per SIMD (a handful of spilled registers) where the general kernel has three
     for name in ("void etxd::k_trace_shadow<false, false, true>", "void etxd::k_trace_shadow<false, true, true>"):
         k = kernels[name]
-        assert k["total_vgprs"] <= 102 and k["scratch"] == 0 and k["vgpr_spills"] == 0, (name, k)
+        assert k["total_vgprs"] <= 72 and k["scratch"] <= 32 and k["vgpr_spills"] <= 6, (name, k)
     # bidirectional (round 3): the walk-event kernels carry no BSDF code and fit four wavefronts per SIMD; the inline-BSDF instantiations
     # need no AGPRs and (almost) no scratch, three wavefronts per SIMD
     for name in ("etxd::k_bdpt_walk_light", "etxd::k_bdpt_walk_camera"):
