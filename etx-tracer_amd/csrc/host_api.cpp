@@ -1831,7 +1831,7 @@ int etx_hip_selftest_stack(etx_hip_context* context, uint32_t depth, uint32_t* o
   const uint32_t blocks = 1024u, lanes = blocks * kBlockSize;
   int32_t* spill = nullptr;
   uint32_t* errors = nullptr;
-  HIP_OK(context, hipMalloc(&spill, size_t(lanes) * (kMaxStackDepth - kStackDepth) * sizeof(int32_t)));
+  HIP_OK(context, hipMalloc(&spill, size_t(lanes) * (kMaxStackDepth - kShortStackDepth) * sizeof(int32_t)));  // rows of the short stack cover the other's
   if (hipMalloc(&errors, sizeof(uint32_t)) != hipSuccess) {
     (void)hipFree(spill);
     context->error = "hipMalloc failed";

@@ -108,9 +108,15 @@ __global__ __launch_bounds__(kBuildBlock) void k_lbvh_collapse_level(const LbvhN
   node.pad[0] = node.pad[1] = node.pad[2] = node.pad[3] = 0u;
 }
 
+template <bool kShort>  // dev_bvh.h LaneStack (32 entries in LDS) or ShortLaneStack (16)
 __global__ __launch_bounds__(kBuildBlock) void k_stack_selftest(DScene scene, uint32_t depth, uint32_t* errors) {
-  __shared__ int32_t s_stack[kStackDepth * kBuildBlock];
-  const LaneStack stack = lane_stack(scene, s_stack + threadIdx.x, kBuildBlock);
+  __shared__ int32_t s_stack[(kShort ? kShortStackDepth : kStackDepth) * kBuildBlock];
+  typedef typename std::conditional<kShort, ShortLaneStack, LaneStack>::type Stack;
+  Stack stack;
+  if constexpr (kShort)
+    stack = short_lane_stack(scene, s_stack + threadIdx.x, kBuildBlock);
+  else
+    stack = lane_stack(scene, s_stack + threadIdx.x, kBuildBlock);
   const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t sp = 0u, bad = 0u;
   for (uint32_t i = 0; i < depth; ++i)
@@ -130,7 +136,8 @@ __global__ __launch_bounds__(kBuildBlock) void k_stack_selftest(DScene scene, ui
 void launch_stack_selftest(hipStream_t stream, int32_t* spill, uint32_t spill_lanes, uint32_t blocks, uint32_t depth, uint32_t* errors) {
   DScene scene = {};
   scene.stack_spill = spill, scene.stack_spill_lanes = spill_lanes;
-  hipLaunchKernelGGL(k_stack_selftest, dim3(blocks), dim3(kBuildBlock), 0, stream, scene, depth, errors);
+  hipLaunchKernelGGL(k_stack_selftest<false>, dim3(blocks), dim3(kBuildBlock), 0, stream, scene, depth, errors);
+  hipLaunchKernelGGL(k_stack_selftest<true>, dim3(blocks), dim3(kBuildBlock), 0, stream, scene, depth, errors);
 }
 
 void launch_bvh_triangles_update(hipStream_t stream, const DScene& scene, BvhTri* tris, uint32_t count) {

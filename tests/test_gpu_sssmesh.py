@@ -83,10 +83,11 @@ def test_christensen_burley_on_meshes(etx, golden_dir):
     compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "sssmesh (Christensen-Burley) vcm camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
 
 
-@pytest.mark.parametrize("depth", [1, 31, 32, 33, 48, 64])
+@pytest.mark.parametrize("depth", [1, 15, 16, 17, 31, 32, 33, 48, 64])
 def test_traversal_stack_round_trip_through_the_spill(etx, depth):
-    """etx_hip_selftest_stack: 262 144 lanes push / pop `depth` entries each through dev_bvh.h LaneStack - 32 in LDS, the rest in
-    the global spill area a deep tree (> ~40 000 triangles) gets. Real rays stay below 20 entries; this is what walks the spill."""
+    """etx_hip_selftest_stack: 262 144 lanes push / pop `depth` entries each through dev_bvh.h LaneStack (32 in LDS) and ShortLaneStack
+    (16 in LDS: the closest-hit kernel of deep trees and the shadow kernel of opaque scenes), the rest in the global spill area a tree
+    with a bound above 16 gets. Real rays stay below 20 entries; this is what walks the spill."""
     ctx = etx.api.Context(0)
     assert ctx.selftest_stack(depth) == 0
     ctx.close()
