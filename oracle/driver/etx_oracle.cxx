@@ -268,6 +268,7 @@ int main(int argc, char** argv) {
   std::vector<std::pair<std::string, std::string>> opts;
   int64_t spp = -1;
   int64_t max_iterations = -1;
+  std::string adaptive_log;  // --adaptive-log: pixels Film::active_pixel reports as still sampled, after every completed iteration
   float noise_threshold = -1.0f;  // < 0: keep the scene value
   int64_t subsurface_class = -1;  // >= 1: every subsurface material of the loaded scene gets this SubsurfaceMaterial::Class (1 random walk, 2 Christensen-Burley)
   uint32_t pixel_size = 0;      // >= 1: Film::set_pixel_size before the render (the GUI's preview while the camera moves, app.cxx:135)
@@ -346,6 +347,8 @@ int main(int argc, char** argv) {
       spp = atoll(next());
     else if (strcmp(argv[i], "--max-iterations") == 0)
       max_iterations = atoll(next());
+    else if (strcmp(argv[i], "--adaptive-log") == 0)
+      adaptive_log = next();
     else if (strcmp(argv[i], "--noise-threshold") == 0)  // Scene::noise_threshold (scene.hxx:45, default 0.1): 0 switches the adaptive sampling of CPUPathTracing off
       noise_threshold = float(atof(next()));
     else if (strcmp(argv[i], "--checkpoint") == 0)
@@ -545,8 +548,29 @@ int main(int argc, char** argv) {
     printf("integrator %s did not start (see the log above)\n", integrator->name());
     return 6;
   }
+  // Adaptive sampling of CPUPathTracing (path_tracing.cxx:57-99, film.cxx:233-330): which pixels the next iteration samples is the film's
+  // active mask; the driver reads it whenever the integrator reports another completed iteration (the mask changes after even iterations
+  // from 32 on, an iteration of the test scenes takes milliseconds: the 200 us poll sees every one).
+  std::vector<uint32_t> active_series;
+  uint32_t logged_iterations = 0;
+  auto log_active = [&]() {
+    if (adaptive_log.empty())
+      return;
+    const uint32_t done = integrator->status().completed_iterations;
+    if (done == logged_iterations)
+      return;
+    uint32_t active = 0;
+    const uint32_t pixel_count = cam.film_size.x * cam.film_size.y;
+    for (uint32_t i = 0; i < pixel_count; ++i) {
+      uint2 location = {};
+      active += raytracing.film().active_pixel(i, location) ? 1u : 0u;
+    }
+    for (; logged_iterations < done; ++logged_iterations)
+      active_series.push_back(active);
+  };
   while (integrator->state() != Integrator::State::Stopped) {
     integrator->update();
+    log_active();
     if ((max_iterations > 0) && (int64_t(integrator->status().completed_iterations) >= max_iterations) && (integrator->state() == Integrator::State::Running)) {
       integrator->stop(Integrator::Stop::WaitForCompletion);
     }
@@ -565,6 +589,19 @@ int main(int argc, char** argv) {
     double samples = double(pixels) * double(st.completed_iterations);
     printf("rays: trace %llu transmittance %llu material %llu -> %.3f rays/sample\n", (unsigned long long)r0, (unsigned long long)r1, (unsigned long long)r2,
       double(r0 + r1 + r2) / samples);
+  }
+  if (adaptive_log.empty() == false) {
+    log_active();
+    // row k: pixels still active once k + 1 iterations were complete = what iteration k + 1 samples; iteration 0 samples every pixel
+    if (FILE* f = fopen(adaptive_log.c_str(), "w")) {
+      unsigned long long total = pixels;
+      for (size_t k = 0; k + 1u < active_series.size(); ++k)
+        total += active_series[k];
+      fprintf(f, "# completed_iterations active_pixels_afterwards ; sampled pixel-iterations of the render: %llu\n", total);
+      for (size_t k = 0; k < active_series.size(); ++k)
+        fprintf(f, "%zu %u\n", k + 1u, active_series[k]);
+      fclose(f);
+    }
   }
   printf("adaptive sampling: %u of %u pixels converged at the last noise estimate (Film::active_pixel_count)\n", raytracing.film().active_pixel_count(), uint32_t(pixels));
   // machine readable line for bench.py / tests
