@@ -474,7 +474,7 @@ void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, u
 constexpr uint32_t kShadowLdsNodes = 64u;
 // The opaque kernel (no boundaries, no density grids: 94 VGPRs instead of 137) stages no nodes: 32 KB of stacks = five workgroups per CU,
 // which its registers allow as well. configs[3] (47 M segments on a 102 k-triangle tree per iteration), six lanes: general kernel 26.5,
-// opaque with 64 staged nodes 27.6, without 28.7 Msamples/s (interleaved A/B in one session, tools/gpu_r3n.sh).
+// opaque with 64 staged nodes 27.6, without 28.7 Msamples/s (interleaved A/B in one session, tools/gpu_calls/gpu_r3n.sh).
 #if !defined(ETX_SHADOW_OPAQUE_NODES)
 #define ETX_SHADOW_OPAQUE_NODES 0u
 #endif
@@ -483,7 +483,7 @@ constexpr uint32_t kShadowLdsNodes = 64u;
 #define ETX_SHADOW_OPAQUE_STACK kShortStackDepth
 #endif
 // waves per SIMD the opaque kernel is compiled for: 7 = 72 VGPRs (three spilled), LDS for sixteen stack entries per lane. configs[3], same
-// session: 98 VGPRs / five waves 28.7, 80 / six 29.0, 72 / seven 29.2 Msamples/s (tools/gpu_r3o.sh)
+// session: 98 VGPRs / five waves 28.7, 80 / six 29.0, 72 / seven 29.2 Msamples/s (tools/gpu_calls/gpu_r3o.sh)
 #if !defined(ETX_SHADOW_OPAQUE_WAVES)
 #define ETX_SHADOW_OPAQUE_WAVES 7
 #endif
