@@ -64,7 +64,13 @@ enum {
 
 int etx_hip_abi_version(void);
 
-/* Opens HIP device `device` (must be gfx950) and creates the streams / queues. */
+/* Opens HIP device `device` (must be gfx950) and creates the streams / queues.
+ * Environment the library reads (deployment settings, nothing else is read from the environment by the product build):
+ *   ETX_HIP_LANES=n                      iterations in flight, 1..8 (default: four, six for the bidirectional integrator) - etx_hip_create
+ *   ETX_HIP_LIGHT_VERTICES_PER_PATH=n    size of the light vertex pool in stored vertices per pixel (default 16; 64 for scenes with
+ *                                        subsurface materials); a pool that is too small is reported as ETX_HIP_ERROR_OVERFLOW - etx_hip_upload_scene
+ *   ETX_HIP_BVH_BUILD_THREADS=n          host threads of the binned-SAH tree build (default: the hardware's) - etx_hip_upload_scene
+ *   ETX_HIP_VERBOSE=1                    build phases and their times on stderr */
 int etx_hip_create(int device, etx_hip_context** out_context);
 void etx_hip_destroy(etx_hip_context* context);
 
