@@ -3,7 +3,8 @@ box scenes of the other subsurface tests have 32 triangles and are swept linearl
 (20 480 + 1 280 triangles, scenes/make_scenes.py sss_meshes), so the material-filtered closest-hit queries of the walks
 (Raytracing::trace_material, rt.cxx:327-371) and the inline traversals of the shade kernels run on the BVH4, with the checked
 per-lane stack (dev_bvh.h LaneStack). Goldens: oracle/gen_golden_hi.py ... sssmesh (PT 1024 spp, VCM / BDPTFull 256 spp, the
-bidirectional ones also with independent light / camera streams). Limits as in the box tests at these sample counts.
+bidirectional ones also with independent light / camera streams). Limits as in the box tests at these sample counts; the 4096-spp
+films with the contract's limits further down.
 """
 import os
 
@@ -81,6 +82,46 @@ def test_christensen_burley_on_meshes(etx, golden_dir):
     compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "sssmesh (Christensen-Burley) vcm camera+light (independent streams)", rmse_limit=1.5e-3)
     golden = load(golden_dir, "cornell_sssmeshcb_128_vcm_256.npz")
     compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "sssmesh (Christensen-Burley) vcm camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
+
+
+# The contract's own limits (north_star: pixel RMSE < 1e-3; image means within 0.3 %) need the noise of both films out of the way: 4096 spp,
+# as for the box scenes of test_gpu_parity_hi.py. These films were rendered (oracle/gen_golden_hi.py --spp 4096 ... sssmesh sssmeshcb) after
+# the round's last GPU minute was spent, so the cases have not run on a device yet: they report (XPASS / XFAIL) without deciding the
+# suite until their first run has been looked at; the 256 / 1024-spp cases above stay the gate. Same estimator code as the box scenes,
+# which pass these limits (sss, ssscb).
+FIRST_RUN_PENDING = pytest.mark.xfail(strict=False, reason="4096 / 1024-spp mesh films: first device run pending (limits of the contract, no allowance)")
+
+
+@FIRST_RUN_PENDING
+@pytest.mark.parametrize("christensen_burley", [False, True])
+def test_path_tracer_on_meshes_at_4096_spp(etx, golden_dir, christensen_burley):
+    name = "sssmeshcb" if christensen_burley else "sssmesh"
+    golden = load(golden_dir, "cornell_%s_128_pt_4096.npz" % name)
+    assert int(golden["spp"]) == 4096
+    (cam_a, _), (cam_b, _) = render_halves(etx, golden_dir, etx.HIPPathTracing, 4096, {"bn": False}, christensen_burley=christensen_burley)
+    compare((cam_a, cam_b), golden["camera"], name + " pt camera, 4096 spp")
+
+
+@FIRST_RUN_PENDING
+def test_vcm_on_meshes_at_4096_spp(etx, golden_dir):
+    name = "sssmesh"
+    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, etx.HIPVCM, 4096, {"vcm-blue_noise": False})
+    golden = load(golden_dir, "cornell_%s_128_vcm_4096_rekeyed.npz" % name)
+    assert int(golden["spp"]) == 4096
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], name + " vcm camera+light (independent streams), 4096 spp")
+    compare((light_a, light_b), golden["light"], name + " vcm light (independent streams), 4096 spp", mean_limit=1.0e-2, bias_p99_limit=0.2)
+    compare((cam_a, cam_b), golden["camera"], name + " vcm camera (independent streams), 4096 spp")
+    golden = load(golden_dir, "cornell_%s_128_vcm_4096.npz" % name)
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], name + " vcm camera+light (reference as is), 4096 spp", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
+
+
+@FIRST_RUN_PENDING
+def test_bidirectional_on_meshes_at_1024_spp(etx, golden_dir):
+    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, etx.HIPBidirectional, 1024, {"bdpt-mode": etx.api.BDPT_MODE_FULL, "bdpt-blue_noise": False})
+    golden = load(golden_dir, "cornell_sssmesh_128_bdpt3_1024_rekeyed.npz")
+    assert int(golden["spp"]) in (1023, 1024)  # CPUBidirectional does not count its last iteration
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "sssmesh bdpt camera+light (independent streams), 1024 spp")
+    compare((cam_a, cam_b), golden["camera"], "sssmesh bdpt camera (independent streams), 1024 spp")
 
 
 @pytest.mark.parametrize("depth", [1, 15, 16, 17, 31, 32, 33, 48, 64])
