@@ -1048,9 +1048,12 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
 }
 
 int etx_hip_set_bvh_builder(etx_hip_context* context, int builder) {
-  if ((context == nullptr) || ((builder != ETX_HIP_BVH_HOST_SAH) && (builder != ETX_HIP_BVH_DEVICE_LBVH)))
+  const bool wide = (builder & ETX_HIP_BVH_WIDE) != 0;
+  builder &= ~int(ETX_HIP_BVH_WIDE);
+  if ((context == nullptr) || ((builder != ETX_HIP_BVH_HOST_SAH) && (builder != ETX_HIP_BVH_DEVICE_LBVH)) || (wide && (builder != ETX_HIP_BVH_HOST_SAH)))
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   context->scene.device_bvh_build = builder == ETX_HIP_BVH_DEVICE_LBVH;
+  context->scene.wide_bvh = wide;
   return ETX_HIP_OK;
 }
 

@@ -563,6 +563,132 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out, bool keep_bvh2) {
   phase("BVH4 collapse and stack bound");
 }
 
+// BVH2 -> Bvh8Node. Collapse as for the four-wide nodes (the inner child with the largest surface area is replaced by its two children until
+// the node has eight or only leaves). Quantisation per node and axis: origin = the children's minimum minus a margin, step = the smallest
+// power of two whose 255 steps span the children (plus margins), lower bounds rounded down, upper bounds up. The margin (a few units in
+// the last place of the scene's extent) covers the rounding of the folded slab test of dev_bvh8.h, which evaluates a bound as
+// q * (step / d) + (origin - o) / d instead of ((origin + q * step) - o) / d.
+bool encode_bvh8(const HostBvh& bvh, HostBvh8& out, std::string& error) {
+  out = {};
+  if (bvh.tris.empty())
+    return true;
+  if (bvh.root < 0) {
+    out.root = bvh.root;
+    return true;
+  }
+  if (bvh.nodes.empty()) {
+    error = "encode_bvh8: the host tree was built without its two-wide form";
+    return false;
+  }
+  struct Box {
+    float lo[3], hi[3];
+  };
+  auto child_boxes = [](const BvhNode& n, Box& b0, Box& b1) {
+    b0 = {{n.lo0_hi0x.x, n.lo0_hi0x.y, n.lo0_hi0x.z}, {n.lo0_hi0x.w, n.hi0yz_lo1xy.x, n.hi0yz_lo1xy.y}};
+    b1 = {{n.hi0yz_lo1xy.z, n.hi0yz_lo1xy.w, n.lo1z_hi1.x}, {n.lo1z_hi1.y, n.lo1z_hi1.z, n.lo1z_hi1.w}};
+  };
+  auto half_area = [](const Box& b) {
+    const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+    return x * y + y * z + z * x;
+  };
+  // scene extent -> margin
+  Box root0, root1;
+  child_boxes(bvh.nodes[size_t(bvh.root)], root0, root1);
+  double reach = 0.0;
+  for (int a = 0; a < 3; ++a)
+    reach = std::max({reach, std::fabs(double(root0.lo[a])), std::fabs(double(root0.hi[a])), std::fabs(double(root1.lo[a])), std::fabs(double(root1.hi[a]))});
+  const double margin = 2.0e-6 * std::max(reach, 1.0e-30);
+  struct Pending {
+    int32_t bvh2;
+    uint32_t level;
+  };
+  std::vector<Pending> queue;
+  queue.push_back({bvh.root, 1u});
+  out.root = 0;
+  for (size_t head = 0; head < queue.size(); ++head) {
+    const Pending item = queue[head];
+    out.levels = std::max(out.levels, item.level);
+    int32_t kids[8];
+    Box boxes[8];
+    uint32_t kid_count = 2;
+    kids[0] = bvh.nodes[size_t(item.bvh2)].child0, kids[1] = bvh.nodes[size_t(item.bvh2)].child1;
+    child_boxes(bvh.nodes[size_t(item.bvh2)], boxes[0], boxes[1]);
+    while (kid_count < 8u) {
+      int best = -1;
+      float best_area = -1.0f;
+      for (uint32_t k = 0; k < kid_count; ++k) {
+        if (kids[k] < 0)
+          continue;
+        const float area = half_area(boxes[k]);
+        if (area > best_area)
+          best_area = area, best = int(k);
+      }
+      if (best < 0)
+        break;
+      const BvhNode& expanded = bvh.nodes[size_t(kids[best])];
+      kids[best] = expanded.child0, kids[kid_count] = expanded.child1;
+      child_boxes(expanded, boxes[best], boxes[kid_count]);
+      kid_count++;
+    }
+    Bvh8Node node = {};
+    for (uint32_t k = 0; k < 8u; ++k) {
+      node.child[k] = kBvhEmptyChild;
+      for (int a = 0; a < 3; ++a)
+        node.qlo[a][k] = 255u, node.qhi[a][k] = 0u;  // an inverted box: never entered
+    }
+    for (int a = 0; a < 3; ++a) {
+      double lo = kMaxFloat, hi = -kMaxFloat;
+      for (uint32_t k = 0; k < kid_count; ++k)
+        lo = std::min(lo, double(boxes[k].lo[a])), hi = std::max(hi, double(boxes[k].hi[a]));
+      const float origin = float(lo - margin) <= lo - margin ? float(lo - margin) : std::nextafter(float(lo - margin), -kMaxFloat);
+      const double extent = (hi + margin) - double(origin);
+      int biased = 1;
+      while ((biased < 254) && (std::ldexp(255.0, biased - 127) < extent))
+        ++biased;
+      if (std::ldexp(255.0, biased - 127) < extent) {
+        error = "encode_bvh8: a node spans more than the grid can address";
+        return false;
+      }
+      const double step = std::ldexp(1.0, biased - 127);
+      node.origin[a] = origin;
+      node.exponents |= uint32_t(biased) << (8u * uint32_t(a));
+      for (uint32_t k = 0; k < kid_count; ++k) {
+        const double ql = std::floor((double(boxes[k].lo[a]) - margin - double(origin)) / step);
+        const double qh = std::ceil((double(boxes[k].hi[a]) + margin - double(origin)) / step);
+        if ((ql < 0.0) || (qh > 255.0) || (double(origin) + ql * step > double(boxes[k].lo[a])) || (double(origin) + qh * step < double(boxes[k].hi[a]))) {
+          error = "encode_bvh8: a quantised box does not contain its child";
+          return false;
+        }
+        node.qlo[a][k] = uint8_t(ql), node.qhi[a][k] = uint8_t(qh);
+      }
+    }
+    for (uint32_t k = 0; k < kid_count; ++k) {
+      if (kids[k] < 0) {
+        node.child[k] = kids[k];
+      } else {
+        node.child[k] = int32_t(queue.size());
+        queue.push_back({kids[k], item.level + 1u});
+      }
+    }
+    out.nodes.push_back(node);
+  }
+  std::vector<uint32_t> need(out.nodes.size(), 0u);
+  for (size_t i = out.nodes.size(); i-- > 0;) {
+    const Bvh8Node& nd = out.nodes[i];
+    uint32_t kids = 0, deepest = 0;
+    for (int k = 0; k < 8; ++k) {
+      if (nd.child[k] == kBvhEmptyChild)
+        continue;
+      kids++;
+      if (nd.child[k] >= 0)
+        deepest = std::max(deepest, need[size_t(nd.child[k])]);
+    }
+    need[i] = (kids ? kids - 1u : 0u) + deepest;
+  }
+  out.stack_need = need.empty() ? 0u : need[0];
+  return true;
+}
+
 // The cube the Morton keys of the device build quantize: the scene's bounding sphere (Scene::bounding_sphere_*, computed by the host
 // at commit), or the vertices' box when the scene does not carry one.
 void lbvh_cube(const etx_abi_scene* scene, f3& cube_min, float& cube_extent) {
@@ -736,12 +862,29 @@ int build_lbvh_tables(const etx_abi_scene* scene, DeviceScene& out, DScene& d, B
 // BVH build + upload (geometry group): the BVH4, the traversal triangles, and for a scene of <= kFlatSweepMaxTriangles the flat-sweep primitives
 int build_traversal_tables(const etx_abi_scene* scene, DeviceScene& out, DScene& d, std::string& error) {
   int rc = 0;
+  d.bvh8_nodes = nullptr, d.bvh8_node_count = 0u, d.bvh8_root = kBvhEmptyChild;
   if (out.device_bvh_build && (scene->triangles.count > kFlatSweepMaxTriangles))
     return build_lbvh_tables(scene, out, d, nullptr, nullptr, error);
   HostBvh bvh;
   const auto build_begin = std::chrono::steady_clock::now();
-  build_bvh(scene, bvh, /* keep the two-wide intermediate */ false);
+  const bool wide = out.wide_bvh && (scene->triangles.count > kFlatSweepMaxTriangles);
+  build_bvh(scene, bvh, /* keep the two-wide intermediate: the eight-wide collapse starts from it */ wide);
+  HostBvh8 bvh8;
+  if (wide && (encode_bvh8(bvh, bvh8, error) == false))
+    return ETX_HIP_ERROR_STATE;
   out.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - build_begin).count();
+  if (wide && (bvh8.stack_need > kMaxStackDepth)) {
+    error = "the eight-wide tree needs " + std::to_string(bvh8.stack_need) + " traversal stack entries, the device stack holds " + std::to_string(kMaxStackDepth) + " (use the four-wide tree)";
+    return ETX_HIP_ERROR_UNSUPPORTED;
+  }
+  d.bvh8_nodes = nullptr, d.bvh8_node_count = 0u, d.bvh8_root = kBvhEmptyChild;
+  if (wide && (bvh8.nodes.empty() == false)) {
+    if ((rc = upload(out, bvh8.nodes.data(), bvh8.nodes.size(), d.bvh8_nodes, error)))
+      return rc;
+    d.bvh8_node_count = uint32_t(bvh8.nodes.size());
+    d.bvh8_root = bvh8.root;
+    out.bvh8_stack_need = bvh8.stack_need;
+  }
   // near-child-first traversal of a four-wide tree pushes at most three children per level
   if (bvh.stack_need > kMaxStackDepth) {
     error = "the BVH needs " + std::to_string(bvh.stack_need) + " traversal stack entries (depth " + std::to_string(bvh.depth4) + "), the device stack holds " + std::to_string(kMaxStackDepth);
@@ -1166,6 +1309,7 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     d.bvh_nodes = kept.bvh_nodes, d.bvh_tris = kept.bvh_tris, d.bvh_node_count = kept.bvh_node_count, d.bvh_tri_count = kept.bvh_tri_count;
     d.flat_prims = kept.flat_prims, d.flat_info = kept.flat_info, d.flat_prim_count = kept.flat_prim_count;
     d.bvh_root = kept.bvh_root, d.bvh_depth = kept.bvh_depth, d.bvh_stack_need = kept.bvh_stack_need, d.bvh_flat = kept.bvh_flat;
+    d.bvh8_nodes = kept.bvh8_nodes, d.bvh8_node_count = kept.bvh8_node_count, d.bvh8_root = kept.bvh8_root;
     out.flat_prims = kept_flat_prims;
   } else {
     // (a scene small enough for the flat sweep is rebuilt in any case: its primitives are pre-transformed on the host)
@@ -1252,6 +1396,10 @@ int update_device_geometry(const etx_abi_scene* scene, DeviceScene& out, hipStre
     error = "hipMemcpy of the moved vertices failed";
     return ETX_HIP_ERROR_HIP;
   }
+  // the eight-wide tree is a host product over the uploaded positions: moved vertices leave the four-wide tree (refit or rebuilt below) as
+  // the only one until the next etx_hip_upload_scene
+  if (positions_moved || rebuild)
+    d.bvh8_nodes = nullptr, d.bvh8_node_count = 0u, d.bvh8_root = kBvhEmptyChild;
   // a scene small enough for the flat sweep had its traversal tables rebuilt from the host scene (build_device_scene)
   if ((d.triangle_count > kFlatSweepMaxTriangles) && rebuild) {
     // a new tree over the moved vertices, built on the device; the traversal triangle buffer is reused, the node buffer replaced

@@ -111,9 +111,14 @@ int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, c
  *                            surface-area guided collapse to four-wide breadth-first nodes, boxes bottom-up): a few milliseconds
  *                            for 10^6 triangles - time to first iteration, geometry that changes every frame - at 3-15 % of the
  *                            traversal rate. Scenes of <= 64 triangles are swept linearly and always built on the host.
+ *   ... | ETX_HIP_BVH_WIDE   (with ETX_HIP_BVH_HOST_SAH only; opt-in, round 3: compiled and emulated on the host, not yet run on a device) the host
+ *                            ALSO collapses its tree to eight children per node with 8-bit child boxes (csrc/dev_bvh8.h: 128 B per
+ *                            node, a third fewer dependent node fetches per ray) and the kernels that have a variant for it - closest
+ *                            hit, shadow segments of scenes without Boundary materials and density grids, the bidirectional
+ *                            integrator's subsurface walks - traverse that one; edits that move vertices drop it again.
  * etx_hip_bvh_info: {BVH4 nodes, triangles, depth | traversal stack entries << 16, bytes} of the uploaded scene and the time its
  * tree took to build (host: wall clock of the builder; device: HIP events around the build kernels), in milliseconds. */
-enum { ETX_HIP_BVH_HOST_SAH = 0, ETX_HIP_BVH_DEVICE_LBVH = 1 };
+enum { ETX_HIP_BVH_HOST_SAH = 0, ETX_HIP_BVH_DEVICE_LBVH = 1, ETX_HIP_BVH_WIDE = 256 };
 int etx_hip_set_bvh_builder(etx_hip_context* context, int builder);
 int etx_hip_bvh_info(etx_hip_context* context, uint32_t out_info[4], double* out_build_ms);
 
@@ -318,6 +323,11 @@ int etx_hip_host_bvh_stats_builder(const etx_abi_scene* scene, int builder, cons
  * stack, [4] nodes, [5] inner levels, [6] sum of the visits a ray had made when it found its final hit, [7] most visits of one ray.
  * No kernel reads these formats: the numbers size the next traversal kernel. */
 int etx_hip_host_bvh_study(const etx_abi_scene* scene, uint32_t width, int quantised, int sorted_pushes, const float* rays_8f, uint64_t count, uint64_t out[8], float* hits_2f);
+
+/* Host-only: the ENCODED eight-wide tree of ETX_HIP_BVH_WIDE (csrc/host_scene.cpp encode_bvh8) walked through the node function the kernels
+ * call (csrc/dev_bvh8.h bvh8_visit: byte decoding and the folded slab test included). `occlusion`: any-hit walk (the shadow kernel's), hits_2f
+ * then holds {0, index of the triangle that ended the query}. Outputs as etx_hip_host_bvh_study. */
+int etx_hip_host_bvh8_stats(const etx_abi_scene* scene, int occlusion, const float* rays_8f, uint64_t count, uint64_t out[8], float* hits_2f);
 
 #ifdef __cplusplus
 }
