@@ -21,6 +21,7 @@ VCM_ENABLE_MERGING = 1 << 6
 VCM_FULL_OPTIONS = 0x7F
 CHANGED_CAMERA, CHANGED_MATERIALS, CHANGED_POSITIONS, REBUILD_BVH = 1, 2, 4, 8  # etx_hip_update_scene
 BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1  # etx_hip_set_bvh_builder
+BVH_WIDE = 256  # | BVH_HOST_SAH: also the eight-wide tree with 8-bit child boxes (csrc/dev_bvh8.h; opt-in)
 
 EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene", "etx_hip_update_scene",

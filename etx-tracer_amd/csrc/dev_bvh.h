@@ -535,8 +535,8 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
 // The same query on a tree scene that holds no Class::Boundary material and no density grid (DScene::boundary_materials,
 // heterogeneous_mediums): the segment is occluded or it is not, and what it crosses is the homogeneous medium it started in -
 // one any-hit traversal and one exp, a third fewer registers than the general function (k_trace_shadow<false, kDeep, true>).
-template <class Tris, class Stack>
-ETX_DEV f3 bvh_transmittance_opaque(const DScene& scene, const BvhNodes& nodes, Tris tris, int32_t root, const Stack& stack, const f3& p0, const f3& p1, uint32_t medium_index,
+template <class Nodes, class Tris, class Stack>  // Nodes: BvhNodes, or Bvh8Nodes (dev_bvh8.h: bvh_occluded has an overload for the eight-wide tree)
+ETX_DEV f3 bvh_transmittance_opaque(const DScene& scene, const Nodes& nodes, Tris tris, int32_t root, const Stack& stack, const f3& p0, const f3& p1, uint32_t medium_index,
   float wavelength, uint32_t& alpha_seed) {
   f3 direction = p1 - p0;
   float t_max = dot(direction, direction);

@@ -192,7 +192,7 @@ int allocate_pipeline(etx_hip_context* ctx) {
   // a tree whose stack bound exceeds the LDS part: this lane's spill area (dev_bvh.h LaneStack), one column per thread of the
   // largest grid any traversing kernel is launched with
   p.scene.stack_spill = nullptr, p.scene.stack_spill_lanes = 0u;
-  if ((p.scene.bvh_flat == 0u) && (p.scene.bvh_stack_need > kShortStackDepth)) {  // rows for the kernels with the short LDS stack, which cover the others'
+  if ((p.scene.bvh_flat == 0u) && (std::max(p.scene.bvh_stack_need, (p.scene.bvh8_nodes != nullptr) ? ctx->scene.bvh8_stack_need : 0u) > kShortStackDepth)) {  // rows for the kernels with the short LDS stack, which cover the others'
     const uint32_t spill_lanes = 2u * kPersistentBlocks * kBlockSize;
     if (int rc = device_alloc(ctx, p.scene.stack_spill, size_t(spill_lanes) * (kMaxStackDepth - kShortStackDepth)))
       return rc;

@@ -939,7 +939,7 @@ int build_traversal_tables(const etx_abi_scene* scene, DeviceScene& out, DScene&
   if (tuning_knob("ETX_HIP_FORCE_BVH", 0u) != 0u)
     d.bvh_flat = 0u;
   out.bvh_depth = bvh.depth4;
-  out.bvh_bytes = bvh.nodes4.size() * sizeof(Bvh4Node) + bvh.tris.size() * sizeof(BvhTri);
+  out.bvh_bytes = bvh.nodes4.size() * sizeof(Bvh4Node) + bvh.tris.size() * sizeof(BvhTri) + bvh8.nodes.size() * sizeof(Bvh8Node);
 
   return 0;
 }

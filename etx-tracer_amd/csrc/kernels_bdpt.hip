@@ -12,6 +12,7 @@
 // dev_bdpt.h explains the data layout. All BSDF classes go through the out-of-line dispatch (dev_bsdf_ool.h).
 #include "kernels.h"
 #include "dev_bdpt.h"
+#include "dev_bvh8.h"
 
 namespace etxd {
 
@@ -107,7 +108,8 @@ struct BdptWalk {
 };
 
 // subsurface_step's free flight: returns false when the path ends (pdf zero). found = the object's surface was reached (h filled).
-ETX_DEV bool bdpt_walk_flight(const DScene& scene, const BvhNodes& nodes, const LaneStack& stack, const BdptWalk& walk, BdptState& st, float4& h, MediumSample& ms) {
+template <class Nodes>  // BvhNodes, or Bvh8Nodes of the eight-wide tree (dev_bvh8.h)
+ETX_DEV bool bdpt_walk_flight(const DScene& scene, const Nodes& nodes, const LaneStack& stack, const BdptWalk& walk, BdptState& st, float4& h, MediumSample& ms) {
   const DMedium& wm = scene.mediums[walk.medium];
   f3 absorption, scattering;
   medium_coefficients(scene, wm, st.wavelength, absorption, scattering);
@@ -215,8 +217,8 @@ struct BdptLightStep {
 
 // One segment of an emitter path after the closest-hit query (kInWalk = false, `h` from the hit queue), or one sub-step of a
 // subsurface walk (kInWalk = true: the free flight and its material-filtered query happen here).
-template <uint32_t kStep, bool kSimple>
-ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const BvhNodes& nodes, const LaneStack& stack, uint32_t mode, BdptState& st, BdptWalk& walk, float4& h) {
+template <uint32_t kStep, bool kSimple, class Nodes>
+ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const Nodes& nodes, const LaneStack& stack, uint32_t mode, BdptState& st, BdptWalk& walk, float4& h) {
   constexpr bool kInWalk = kStep != kStepSegment;
   BdptLightStep r = {};
   MediumSample ms;
@@ -447,6 +449,8 @@ ETX_DEV bool walk_refill(const Pipeline& p, uint32_t count, bool& active, bool& 
 }
 
 // The scattering events of the walks of this bounce, emitter paths: walk queue -> (medium vertices in the light vertex pool) -> exit queue
+// kWide: the material-filtered queries of the events run on the eight-wide tree (dev_bvh8.h; ETX_HIP_BVH_WIDE)
+template <bool kWide>
 __global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_light(Pipeline p, VcmParams it, uint32_t queue) {
   __shared__ int32_t s_stack[kStackDepth * kBlockSize];
   __shared__ float4 s_nodes[kWalkLdsNodes * 8u];
@@ -455,7 +459,11 @@ __global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_light(Pipeline p, V
   const uint32_t count = min(p.counters[kCntWalk + 32u * queue], p.capacity);
   if (count == 0u)
     return;
-  const BvhNodes nodes = stage_nodes(scene, s_nodes, kWalkLdsNodes);  // every event descends from the root: its first levels come from LDS
+  typename std::conditional<kWide, Bvh8Nodes, BvhNodes>::type nodes;  // every event descends from the root: its first levels come from LDS
+  if constexpr (kWide)
+    nodes = stage_nodes8(scene, reinterpret_cast<uint4*>(s_nodes), kWalkLdsNodes);
+  else
+    nodes = stage_nodes(scene, s_nodes, kWalkLdsNodes);
   const uint32_t mode = bdpt_mode(it);
   const uint32_t lane = threadIdx.x & 63u;
   BdptState st = {};
@@ -664,8 +672,8 @@ struct BdptCameraStep {
 
 // One segment of a camera path after the closest-hit query (kInWalk = false), or one sub-step of a subsurface walk (kInWalk = true).
 // Film contributions of direct hits are added here; pool records and the roulette are the caller's (bdpt_camera_finish).
-template <uint32_t kStep, bool kSimple>
-ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, const BvhNodes& nodes, const LaneStack& stack, const VcmParams& it, uint32_t mode, bool use_mis, BdptState& st, BdptWalk& walk, float4& h) {
+template <uint32_t kStep, bool kSimple, class Nodes>
+ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, const Nodes& nodes, const LaneStack& stack, const VcmParams& it, uint32_t mode, bool use_mis, BdptState& st, BdptWalk& walk, float4& h) {
   constexpr bool kInWalk = kStep != kStepSegment;
   BdptCameraStep r = {};
   r.v_hit = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
@@ -913,6 +921,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
 
 // The scattering events of the walks of this bounce, camera paths: walk queue -> exit queue (only the exit vertex of a walk is
 // connectible, :811: the events leave nothing but the path's running MIS history behind)
+template <bool kWide>
 __global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_camera(Pipeline p, VcmParams it, uint32_t queue) {
   __shared__ int32_t s_stack[kStackDepth * kBlockSize];
   __shared__ float4 s_nodes[kWalkLdsNodes * 8u];
@@ -921,7 +930,11 @@ __global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_camera(Pipeline p, 
   const uint32_t count = min(p.counters[kCntWalk + 32u * queue], p.capacity);
   if (count == 0u)
     return;
-  const BvhNodes nodes = stage_nodes(scene, s_nodes, kWalkLdsNodes);  // every event descends from the root: its first levels come from LDS
+  typename std::conditional<kWide, Bvh8Nodes, BvhNodes>::type nodes;  // every event descends from the root: its first levels come from LDS
+  if constexpr (kWide)
+    nodes = stage_nodes8(scene, reinterpret_cast<uint4*>(s_nodes), kWalkLdsNodes);
+  else
+    nodes = stage_nodes(scene, s_nodes, kWalkLdsNodes);
   const uint32_t mode = bdpt_mode(it);
   const bool use_mis = opt_enable_mis(it);
   BdptState st = {};
@@ -1196,10 +1209,16 @@ void launch_bdpt_walk(hipStream_t stream, const Pipeline& p, const VcmParams& it
   const uint32_t items = min(p.capacity, max_items);
   const uint32_t blocks = max(1u, min(kWalkBlocks, (items + kBlockSize - 1u) / kBlockSize));
   if (camera) {
-    hipLaunchKernelGGL(k_bdpt_walk_camera, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
+    if (p.scene.bvh8_nodes != nullptr)
+      hipLaunchKernelGGL(k_bdpt_walk_camera<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
+    else
+      hipLaunchKernelGGL(k_bdpt_walk_camera<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
     ETX_BDPT_LAUNCH(k_bdpt_walk_exit_camera, max(1u, grid_for(items)), p, it, in_set ^ 1u);
   } else {
-    hipLaunchKernelGGL(k_bdpt_walk_light, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
+    if (p.scene.bvh8_nodes != nullptr)
+      hipLaunchKernelGGL(k_bdpt_walk_light<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
+    else
+      hipLaunchKernelGGL(k_bdpt_walk_light<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
     ETX_BDPT_LAUNCH(k_bdpt_walk_exit_light, max(1u, grid_for(items)), p, it, in_set ^ 1u);
   }
 }

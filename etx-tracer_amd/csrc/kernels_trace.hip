@@ -6,6 +6,7 @@
 // wave-uniform grid-stride loop; per-lane traversal stack in LDS laid out [level][lane] (bank conflict free).
 #include "kernels.h"
 #include "dev_bvh.h"
+#include "dev_bvh8.h"
 #include "dev_vcm.h"
 #include "pipeline.h"
 #include "tuning_knobs.h"
@@ -160,7 +161,9 @@ struct TraversalStack<true, kShortStackDepth> {  // half the LDS: entries above 
   }
 };
 
-template <bool kFromCounter, uint32_t kStack, uint32_t kLdsNodesPersistent, bool kDeep = false>
+// kWide: the eight-wide tree of dev_bvh8.h (checked short stack, kDeep and kStack = kShortStackDepth): one 128-byte node decides eight children,
+// the nearest hit child is entered, the others pushed as they come.
+template <bool kFromCounter, uint32_t kStack, uint32_t kLdsNodesPersistent, bool kDeep = false, bool kWide = false>
 __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
   float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit,
   uint32_t refill_lanes, uint32_t pass_stat) {
@@ -173,7 +176,12 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene s
   }
   if (count == 0u)
     return;
-  const BvhNodes nodes = stage_nodes(scene, s_nodes, min(kLdsNodesPersistent, lds_node_limit));
+  typedef typename std::conditional<kWide, Bvh8Nodes, BvhNodes>::type Nodes;
+  Nodes nodes;
+  if constexpr (kWide)
+    nodes = stage_nodes8(scene, reinterpret_cast<uint4*>(s_nodes), min(kLdsNodesPersistent, lds_node_limit));
+  else
+    nodes = stage_nodes(scene, s_nodes, min(kLdsNodesPersistent, lds_node_limit));
   const typename TraversalStack<kDeep, kDeep ? kStack : kStackDepth>::Type stack = TraversalStack<kDeep, kDeep ? kStack : kStackDepth>::make(scene, s_stack + threadIdx.x, kBlockSize);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6u;
@@ -204,10 +212,13 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene s
           const float4 b = ray_d_tmax[ray_index];
           alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ ray_index;
           ray = {{a.x, a.y, a.z}, a.w, {b.x, b.y, b.z}, b.w};
-          inv_d = {__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)};
+          if constexpr (kWide)
+            inv_d = {bvh8_reciprocal(ray.d.x), bvh8_reciprocal(ray.d.y), bvh8_reciprocal(ray.d.z)};
+          else
+            inv_d = {__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)};
           best = {0.0f, 0.0f, ray.tmax, kInvalid};
           sp = 0u;
-          cur = scene.bvh_root;
+          cur = kWide ? scene.bvh8_root : scene.bvh_root;
         }
         cursor += take;
       } else if (idle_count == 64u) {
@@ -217,6 +228,10 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene s
     if (cur == kDone)
       continue;
     if (cur >= 0) {
+     if constexpr (kWide) {
+      const int32_t next = bvh8_visit<true>(bvh8_fetch(nodes, cur), ray.o, inv_d, ray.tmin, best.t, stack, sp);
+      cur = (next != kDone) ? next : (sp ? stack.pop(sp) : kDone);
+     } else {
       float4 lox, loy, loz, hix, hiy, hiz, cc;
       if (uint32_t(cur) < nodes.lds_count) {
         const float4* n = nodes.lds + uint32_t(cur) * 8u;
@@ -250,6 +265,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene s
           stack.push(sp, c1);
         cur = c0;
       }
+     }
     } else {
       const uint32_t leaf = uint32_t(~cur);
       const uint32_t first = leaf >> 3, leaf_count = (leaf & 7u) + 1u;
@@ -424,6 +440,11 @@ static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const flo
   hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, STACK, NODES>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count, round_mirror, \
     round_tag, lds_limit(), refill, pass_stat)
   const uint32_t need = scene.bvh_stack_need;
+  if (scene.bvh8_nodes != nullptr) {  // ETX_HIP_BVH_WIDE: the eight-wide tree, checked short stack
+    hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, kShortStackDepth, 64u, true, true>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count,
+      round_mirror, round_tag, lds_limit(), refill, pass_stat);
+    return;
+  }
   if (((variant == 2u) && (need > kShortStackDepth)) || (need > kStackDepth)) {
     // a deep tree (> ~40 000 triangles): the checked stack, 16 entries in LDS (24 KB per workgroup with the staged nodes), the rest in the global
     // spill rows (dev_bvh.h ShortLaneStack). A million triangles: 13.1 vs 12.8 Msamples/s with 32 entries in LDS; trees whose bound fits 32
@@ -487,8 +508,10 @@ constexpr uint32_t kShadowLdsNodes = 64u;
 #if !defined(ETX_SHADOW_OPAQUE_WAVES)
 #define ETX_SHADOW_OPAQUE_WAVES 7
 #endif
-template <bool kFlat, bool kDeep = false, bool kOpaque = false>
+// kWide (with kOpaque): the eight-wide tree of dev_bvh8.h
+template <bool kFlat, bool kDeep = false, bool kOpaque = false, bool kWide = false>
 __global__ __launch_bounds__(kBlockSize, kOpaque ? ETX_SHADOW_OPAQUE_WAVES : 1) void k_trace_shadow(Pipeline p) {
+  static_assert((kWide == false) || kOpaque, "the eight-wide tree is read by the opaque shadow kernel only");
   constexpr bool kShort = kOpaque && (uint32_t(ETX_SHADOW_OPAQUE_STACK) == kShortStackDepth);  // the opaque kernel: LDS for 16 entries per lane, the rest spills
   __shared__ int32_t s_stack[kFlat ? 1 : (kShort ? kShortStackDepth : kStackDepth) * kBlockSize];
   constexpr uint32_t kLdsNodes = kOpaque ? uint32_t(ETX_SHADOW_OPAQUE_NODES) : kShadowLdsNodes;
@@ -503,6 +526,7 @@ __global__ __launch_bounds__(kBlockSize, kOpaque ? ETX_SHADOW_OPAQUE_WAVES : 1) 
   BvhNodes nodes = global_nodes(scene);
   if ((kFlat == false) && (kLdsNodes != 0u) && (blockIdx.x * blockDim.x < count))
     nodes = stage_nodes(scene, s_nodes, kLdsNodes);
+  const Bvh8Nodes nodes8 = global_nodes8(scene);
   for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {
     const uint32_t i = base + lane;
     f3 value = mk3(0.0f);
@@ -512,7 +536,9 @@ __global__ __launch_bounds__(kBlockSize, kOpaque ? ETX_SHADOW_OPAQUE_WAVES : 1) 
       const float4 b = p.shadow.p1_target[i];
       uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ i;
       f3 tr = mk3(1.0f);
-      if (kOpaque)
+      if (kWide)
+        tr = bvh_transmittance_opaque(scene, nodes8, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), p.shadow.value[i].w, alpha_seed);
+      else if (kOpaque)
         tr = bvh_transmittance_opaque(scene, nodes, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), p.shadow.value[i].w, alpha_seed);
       else if ((p.debug_flags & 4u) == 0u)
         tr = bvh_transmittance(scene, nodes, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), p.shadow.value[i].w, alpha_seed);
@@ -567,11 +593,15 @@ void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_ite
   if (flat)
     hipLaunchKernelGGL(k_trace_shadow<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p);
   else if (p.scene.bvh_stack_need > kStackDepth) {
-    if (opaque)
+    if (opaque && (p.scene.bvh8_nodes != nullptr))
+      hipLaunchKernelGGL((k_trace_shadow<false, false, true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);  // its short stack is the checked one
+    else if (opaque)
       hipLaunchKernelGGL((k_trace_shadow<false, true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);
     else
       hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);
-  } else if (opaque)
+  } else if (opaque && (p.scene.bvh8_nodes != nullptr))
+    hipLaunchKernelGGL((k_trace_shadow<false, false, true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);
+  else if (opaque)
     hipLaunchKernelGGL((k_trace_shadow<false, false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);
   else
     hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p);
