@@ -70,6 +70,7 @@ void DeviceScene::borrow(const DeviceScene& owner) {
   generic_materials = owner.generic_materials;
   needs_rgb_response = owner.needs_rgb_response;
   bvh_bytes = owner.bvh_bytes;
+  bvh8_stack_need = owner.bvh8_stack_need;
   content_hash = owner.content_hash;
 }
 
