@@ -599,6 +599,104 @@ bool encode_bvh8(const HostBvh& bvh, HostBvh8& out, std::string& error) {
   for (int a = 0; a < 3; ++a)
     reach = std::max({reach, std::fabs(double(root0.lo[a])), std::fabs(double(root0.hi[a])), std::fabs(double(root1.lo[a])), std::fabs(double(root1.hi[a]))});
   const double margin = 2.0e-6 * std::max(reach, 1.0e-30);
+  // Which BVH2 nodes become the children of a wide node: the surface-area cost of the collapsed tree, minimised bottom-up (Ylitie,
+  // Karras, Laine 2017, "Efficient incoherent ray traversal on GPUs through compressed wide BVHs", section 3.1). cost[n][i - 1] = cheapest
+  // way to represent the subtree of BVH2 node n by at most i roots (wide nodes or leaves), i = 1..7:
+  //   one root   : a leaf over all its triangles (they are contiguous in traversal order; up to 8), or a wide node whose eight slots are
+  //                shared between the two children: A(n) * kNodeCost + min_k (cost[left][k] + cost[right][8 - k])
+  //   i > 1 roots: the better of splitting the budget between the children and of using fewer roots
+  // The greedy collapse used for the four-wide nodes (largest child first) leaves eight-wide nodes half empty (4.4 children on
+  // average on the 102 k-triangle meshes): the parents of two leaves at the bottom of the tree stay nodes of their own.
+  // Measured on the host (node visits / triangle tests per ray; greedy = largest child first): gems incoherent 2.06 / 1.39 -> 1.83 / 1.74,
+  // gems walk segments 5.15 / 1.45 -> 4.79 / 1.92, 102 k-triangle meshes incoherent 2.75 / 1.36 -> 2.68 / 1.60, walk segments 6.39 / 1.02 ->
+  // 6.90 / 1.33 - about even in visits, a third of the nodes (617 -> 209, 23 715 -> 7 799: 1 MB instead of 3 MB for the meshes). The
+  // triangle cost is a tuning knob of debug builds (0.6 and above: no merged leaves).
+  const float kNodeCost = 1.0f, kTriangleCost = tuning_knob_f("ETX_HIP_BVH8_TRIANGLE_COST", 0.3f);
+  constexpr uint32_t kMaxLeaf = 8u;
+  const size_t inner_count = bvh.nodes.size();
+  struct Plan {
+    float cost[7];
+    uint8_t split[7];   // i >= 2: roots given to the left child (0: same as with i - 1 roots); i == 1: slots given to the left child of the wide node
+    bool leaf;          // one root: a merged leaf
+    float area;
+    uint32_t first, count;  // triangle range of the subtree
+  };
+  std::vector<Plan> plan(inner_count);
+  auto leaf_first = [](int32_t c) { return uint32_t(~c) >> 3; };
+  auto leaf_count = [](int32_t c) { return (uint32_t(~c) & 7u) + 1u; };
+  {
+    // post-order over the inner nodes without recursion
+    std::vector<std::pair<int32_t, bool>> todo;
+    todo.push_back({bvh.root, false});
+    while (todo.empty() == false) {
+      const auto [n, expanded] = todo.back();
+      todo.pop_back();
+      const BvhNode& node = bvh.nodes[size_t(n)];
+      if (expanded == false) {
+        todo.push_back({n, true});
+        if (node.child0 >= 0)
+          todo.push_back({node.child0, false});
+        if (node.child1 >= 0)
+          todo.push_back({node.child1, false});
+        continue;
+      }
+      Box b0, b1;
+      child_boxes(node, b0, b1);
+      Box own;
+      for (int a = 0; a < 3; ++a)
+        own.lo[a] = std::min(b0.lo[a], b1.lo[a]), own.hi[a] = std::max(b0.hi[a], b1.hi[a]);
+      Plan& p = plan[size_t(n)];
+      p.area = half_area(own);
+      const int32_t kid[2] = {node.child0, node.child1};
+      const Box* kid_box[2] = {&b0, &b1};
+      float kid_cost[2][7];
+      uint32_t first[2], count[2];
+      for (int c = 0; c < 2; ++c) {
+        if (kid[c] < 0) {
+          first[c] = leaf_first(kid[c]), count[c] = leaf_count(kid[c]);
+          for (int i = 0; i < 7; ++i)
+            kid_cost[c][i] = half_area(*kid_box[c]) * float(count[c]) * kTriangleCost;
+        } else {
+          const Plan& q = plan[size_t(kid[c])];
+          first[c] = q.first, count[c] = q.count;
+          for (int i = 0; i < 7; ++i)
+            kid_cost[c][i] = q.cost[i];
+        }
+      }
+      p.first = std::min(first[0], first[1]), p.count = count[0] + count[1];
+      const bool contiguous = (std::max(first[0], first[1]) == p.first + ((first[0] < first[1]) ? count[0] : count[1]));
+      auto distribute = [&](uint32_t slots, uint8_t& best_k) {  // min over k of cost[left][k] + cost[right][slots - k], both in 1..7
+        float best = kMaxFloat;
+        best_k = 1;
+        for (uint32_t k = 1; k < slots; ++k) {
+          if ((k > 7u) || (slots - k > 7u))
+            continue;
+          const float c = kid_cost[0][k - 1u] + kid_cost[1][slots - k - 1u];
+          if (c < best)
+            best = c, best_k = uint8_t(k);
+        }
+        return best;
+      };
+      uint8_t k8 = 1;
+      const float as_node = p.area * kNodeCost + distribute(8u, k8);
+      const float as_leaf = (contiguous && (p.count <= kMaxLeaf)) ? p.area * float(p.count) * kTriangleCost : kMaxFloat;
+      p.leaf = as_leaf < as_node;
+      p.cost[0] = std::min(as_leaf, as_node);
+      p.split[0] = k8;
+      for (uint32_t i = 2; i <= 7u; ++i) {
+        uint8_t k = 1;
+        const float split_cost = distribute(i, k);
+        if (split_cost < p.cost[i - 2u])
+          p.cost[i - 1u] = split_cost, p.split[i - 1u] = k;
+        else
+          p.cost[i - 1u] = p.cost[i - 2u], p.split[i - 1u] = 0u;
+      }
+    }
+  }
+  if (plan[size_t(bvh.root)].leaf) {  // the whole scene fits one leaf
+    out.root = ~int32_t((plan[size_t(bvh.root)].first << 3) | (plan[size_t(bvh.root)].count - 1u));
+    return true;
+  }
   struct Pending {
     int32_t bvh2;
     uint32_t level;
@@ -609,27 +707,54 @@ bool encode_bvh8(const HostBvh& bvh, HostBvh8& out, std::string& error) {
   for (size_t head = 0; head < queue.size(); ++head) {
     const Pending item = queue[head];
     out.levels = std::max(out.levels, item.level);
-    int32_t kids[8];
+    int32_t kids[8];  // >= 0: BVH2 node that becomes a wide node; < 0: leaf code
     Box boxes[8];
-    uint32_t kid_count = 2;
-    kids[0] = bvh.nodes[size_t(item.bvh2)].child0, kids[1] = bvh.nodes[size_t(item.bvh2)].child1;
-    child_boxes(bvh.nodes[size_t(item.bvh2)], boxes[0], boxes[1]);
-    while (kid_count < 8u) {
-      int best = -1;
-      float best_area = -1.0f;
-      for (uint32_t k = 0; k < kid_count; ++k) {
-        if (kids[k] < 0)
-          continue;
-        const float area = half_area(boxes[k]);
-        if (area > best_area)
-          best_area = area, best = int(k);
+    uint32_t kid_count = 0;
+    // the roots the plan gives to a child with `roots` of them to spend
+    struct Frame {
+      int32_t node;
+      Box box;
+      uint32_t roots;
+    };
+    std::vector<Frame> frames;
+    {
+      Box b0, b1;
+      const BvhNode& top = bvh.nodes[size_t(item.bvh2)];
+      child_boxes(top, b0, b1);
+      const uint32_t k = plan[size_t(item.bvh2)].split[0];
+      frames.push_back({top.child1, b1, 8u - k});
+      frames.push_back({top.child0, b0, k});
+    }
+    while (frames.empty() == false) {
+      const Frame f = frames.back();
+      frames.pop_back();
+      if (kid_count == 8u) {
+        error = "encode_bvh8: the collapse plan produced more than eight children";
+        return false;
       }
-      if (best < 0)
-        break;
-      const BvhNode& expanded = bvh.nodes[size_t(kids[best])];
-      kids[best] = expanded.child0, kids[kid_count] = expanded.child1;
-      child_boxes(expanded, boxes[best], boxes[kid_count]);
-      kid_count++;
+      if (f.node < 0) {
+        kids[kid_count] = f.node, boxes[kid_count] = f.box, kid_count++;
+        continue;
+      }
+      const Plan& q = plan[size_t(f.node)];
+      uint32_t roots = f.roots;
+      while ((roots > 1u) && (q.split[roots - 1u] == 0u))  // fewer roots are as good
+        roots--;
+      if (roots == 1u) {
+        kids[kid_count] = q.leaf ? ~int32_t((q.first << 3) | (q.count - 1u)) : f.node;
+        boxes[kid_count] = f.box, kid_count++;
+        continue;
+      }
+      Box b0, b1;
+      const BvhNode& n = bvh.nodes[size_t(f.node)];
+      child_boxes(n, b0, b1);
+      const uint32_t k = q.split[roots - 1u];
+      frames.push_back({n.child1, b1, roots - k});
+      frames.push_back({n.child0, b0, k});
+    }
+    if ((kid_count == 0u) || (kid_count > 8u)) {
+      error = "encode_bvh8: the collapse plan produced " + std::to_string(kid_count) + " children";
+      return false;
     }
     Bvh8Node node = {};
     for (uint32_t k = 0; k < 8u; ++k) {

@@ -37,10 +37,11 @@ def test_encoded_wide_tree_finds_the_hits_of_the_four_wide_tree(etx, golden_dir,
     np.testing.assert_array_equal(wide["t"][same], today["t"][same])
     assert wide["node_visits"] < 0.8 * today["node_visits"], (wide["node_visits"], today["node_visits"])
     assert wide["max_stack"] <= 48 and wide["nodes"] < today["node_visits"]
-    # the study's idealised format (exact decode, no margin) and the encoded one agree on the work within a few per cent
+    # the study's eight-wide format (greedy collapse, exact decode, no margin) against the encoded one (cost-driven collapse with merged
+    # leaves): about the same visits, a third to a half of the nodes
     rc, study = api.host_bvh_study(snap, rays, width=8, quantised=True, sorted_pushes=False)
-    assert rc == 0 and study["nodes"] == wide["nodes"] and study["levels"] == wide["levels"]
-    assert abs(wide["node_visits"] / study["node_visits"] - 1.0) < 0.05
+    assert rc == 0 and wide["nodes"] < 0.6 * study["nodes"] and wide["levels"] <= study["levels"]
+    assert abs(wide["node_visits"] / study["node_visits"] - 1.0) < 0.15
     # occlusion walk: a blocker for exactly the rays with a hit (any blocker: the first accepted triangle in traversal order)
     rc, shadow = api.host_bvh8_stats(snap, rays, occlusion=True, with_hits=True)
     assert rc == 0 and shadow["hits"] == today["hits"]
