@@ -17,5 +17,8 @@ for w in sssdragon_bdpt gems gems1m; do
     echo "$w --bvh $b: $v" >> $O/ab.txt
   done
 done
+for t in "" wide; do
+  timeout 120 python tools/trace_bench.py tests/golden/cornell_gems_1080p.etxscene 2073600 20 $t >> $O/trace_bench.txt 2>&1
+done
 tail -n 3 $O/wide_tests.log $O/mesh_4096.log
-cat $O/log.txt $O/ab.txt
+cat $O/log.txt $O/ab.txt $O/trace_bench.txt
