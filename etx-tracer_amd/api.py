@@ -434,8 +434,8 @@ def host_bvh8_stats(snapshot, rays, occlusion=False, library=None, with_hits=Fal
     out = (ctypes.c_uint64 * 8)()
     hits = np.zeros((rays.shape[0], 2), dtype=np.float32) if with_hits else None
     rc = library.lib.etx_hip_host_bvh8_stats(snapshot.scene_address, int(bool(occlusion)), rays.ctypes.data, rays.shape[0], ctypes.byref(out), hits.ctypes.data if with_hits else None)
-    result = {"node_visits": out[0], "triangle_tests": out[1], "hits": out[2], "max_stack": out[3], "nodes": out[4], "levels": out[5], "visits_to_final_hit": out[6],
-              "max_visits_of_a_ray": out[7]}
+    result = {"node_visits": out[0], "triangle_tests": out[1], "hits": out[2], "max_stack": out[3], "nodes": out[4], "levels": out[5] & 0xffff, "stack_need": out[5] >> 16,
+              "visits_to_final_hit": out[6], "max_visits_of_a_ray": out[7]}
     if with_hits:
         triangle = hits[:, 1].view(np.uint32).astype(np.int64)
         triangle[triangle == 0xFFFFFFFF] = -1

@@ -15,6 +15,7 @@ namespace etxd {
 
 constexpr uint32_t kStackDepth = 32;     // stack entries a lane keeps in LDS
 constexpr uint32_t kMaxStackDepth = 64;  // deepest stack a tree may need (host bound over the tree): the entries above kStackDepth spill
+constexpr uint32_t kMaxWideStackDepth = 128;  // the same for the eight-wide tree (dev_bvh8.h: up to seven pushes per level; a million triangles: bound 70, observed 25)
 constexpr uint32_t kFlatSweepMaxTriangles = 64;  // scenes up to this size are swept linearly (all lanes, same triangle)
 
 // The stack of the two traversal kernels when the tree's bound fits the LDS part (trees up to ~40 000 triangles): no checks.

@@ -194,7 +194,10 @@ int allocate_pipeline(etx_hip_context* ctx) {
   p.scene.stack_spill = nullptr, p.scene.stack_spill_lanes = 0u;
   if ((p.scene.bvh_flat == 0u) && (std::max(p.scene.bvh_stack_need, (p.scene.bvh8_nodes != nullptr) ? ctx->scene.bvh8_stack_need : 0u) > kShortStackDepth)) {  // rows for the kernels with the short LDS stack, which cover the others'
     const uint32_t spill_lanes = 2u * kPersistentBlocks * kBlockSize;
-    if (int rc = device_alloc(ctx, p.scene.stack_spill, size_t(spill_lanes) * (kMaxStackDepth - kShortStackDepth)))
+    // rows: what the deepest accepted tree can need beyond the short LDS stack (an eight-wide tree may need more than kMaxStackDepth: up to
+    // seven pushes per level; host_scene.cpp accepts it up to kMaxWideStackDepth)
+    const uint32_t deepest = std::max(kMaxStackDepth, (p.scene.bvh8_nodes != nullptr) ? ctx->scene.bvh8_stack_need : 0u);
+    if (int rc = device_alloc(ctx, p.scene.stack_spill, size_t(spill_lanes) * (deepest - kShortStackDepth)))
       return rc;
     p.scene.stack_spill_lanes = spill_lanes;
   }

@@ -288,7 +288,7 @@ extern "C" int etx_hip_host_bvh8_stats(const etx_abi_scene* scene, int occlusion
   std::string error;
   if (etxh::encode_bvh8(bvh, wide, error) == false)
     return ETX_HIP_ERROR_STATE;
-  out[4] = wide.nodes.size(), out[5] = wide.levels;
+  out[4] = wide.nodes.size(), out[5] = uint64_t(wide.levels) | (uint64_t(wide.stack_need) << 16u);  // levels | exact stack bound << 16
   std::vector<int32_t> storage(512);
   const HostStack stack = {&storage};
   for (uint64_t r = 0; r < count; ++r) {

@@ -999,8 +999,8 @@ int build_traversal_tables(const etx_abi_scene* scene, DeviceScene& out, DScene&
   if (wide && (encode_bvh8(bvh, bvh8, error) == false))
     return ETX_HIP_ERROR_STATE;
   out.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - build_begin).count();
-  if (wide && (bvh8.stack_need > kMaxStackDepth)) {
-    error = "the eight-wide tree needs " + std::to_string(bvh8.stack_need) + " traversal stack entries, the device stack holds " + std::to_string(kMaxStackDepth) + " (use the four-wide tree)";
+  if (wide && (bvh8.stack_need > kMaxWideStackDepth)) {
+    error = "the eight-wide tree needs " + std::to_string(bvh8.stack_need) + " traversal stack entries, the device stack holds " + std::to_string(kMaxWideStackDepth) + " (use the four-wide tree)";
     return ETX_HIP_ERROR_UNSUPPORTED;
   }
   d.bvh8_nodes = nullptr, d.bvh8_node_count = 0u, d.bvh8_root = kBvhEmptyChild;

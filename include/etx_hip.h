@@ -326,7 +326,8 @@ int etx_hip_host_bvh_study(const etx_abi_scene* scene, uint32_t width, int quant
 
 /* Host-only: the ENCODED eight-wide tree of ETX_HIP_BVH_WIDE (csrc/host_scene.cpp encode_bvh8) walked through the node function the kernels
  * call (csrc/dev_bvh8.h bvh8_visit: byte decoding and the folded slab test included). `occlusion`: any-hit walk (the shadow kernel's), hits_2f
- * then holds {0, index of the triangle that ended the query}. Outputs as etx_hip_host_bvh_study. */
+ * then holds {0, index of the triangle that ended the query}. Outputs as etx_hip_host_bvh_study; out[5] = levels | (the tree's exact bound
+ * of the traversal stack << 16). */
 int etx_hip_host_bvh8_stats(const etx_abi_scene* scene, int occlusion, const float* rays_8f, uint64_t count, uint64_t out[8], float* hits_2f);
 
 #ifdef __cplusplus
