@@ -62,6 +62,23 @@ struct etx_hip_context {
   etxh::DeviceScene scene;
   Pipeline pipe = {};
   std::vector<void*> allocations;
+  // The per-iteration pools whose fill depends on the scene and the sample (light vertices + photon grid, camera vertices, pairs, shadow and
+  // endpoint queues) start at what typical paths need and GROW: an iteration that overflows one is not committed (k_vcm_commit), the pool is
+  // doubled and the iteration rendered again (execute_iteration). `pool_sizes` = what this lane holds, `pool_wanted` (public context) =
+  // what every lane adopts before its next iteration; sizes only grow between two etx_hip_upload_scene / etx_hip_update_scene calls.
+  struct PoolSizes {
+    uint32_t light_vertices = 0, pairs = 0, shadow = 0, camera_vertices = 0, endpoints = 0;
+    bool operator==(const PoolSizes& o) const {
+      return (light_vertices == o.light_vertices) && (pairs == o.pairs) && (shadow == o.shadow) && (camera_vertices == o.camera_vertices) && (endpoints == o.endpoints);
+    }
+  };
+  PoolSizes pool_sizes, pool_wanted;
+  std::vector<void*> pool_allocations;
+  size_t pool_bytes = 0;             // of this lane's growable pools (part of allocated_bytes)
+  bool retry_attempt = false;        // execute_iteration: the iteration being rendered was discarded once (pool overflow)
+  bool grid_wanted = false;          // the photon grid belongs to the pools once a VCM run has begun (allocate_photon_grid)
+  uint32_t pool_initial_per_path = 0;  // etx_hip_set_pool_policy: light vertices per path the pools start with (0 = default), public context
+  size_t pool_limit_bytes = 0;       // ... and the size a lane's pools may grow to (0 = no limit but the device's memory), public context
   bool scene_ready = false;
   bool armed = false;
   int integrator = ETX_HIP_INTEGRATOR_VCM;
@@ -167,7 +184,30 @@ int device_alloc(etx_hip_context* ctx, T*& ptr, size_t count) {
   return 0;
 }
 
+template <class T>
+int pool_alloc(etx_hip_context* ctx, T*& ptr, size_t count) {
+  const size_t before = ctx->allocated_bytes;
+  if (int rc = device_alloc(ctx, ptr, count))
+    return rc;
+  ctx->pool_allocations.push_back(ctx->allocations.back());
+  ctx->allocations.pop_back();
+  ctx->pool_bytes += ctx->allocated_bytes - before;
+  return 0;
+}
+
+void release_pools(etx_hip_context* ctx) {
+  for (void* p : ctx->pool_allocations)
+    (void)hipFree(p);
+  ctx->pool_allocations.clear();
+  ctx->allocated_bytes -= std::min(ctx->allocated_bytes, ctx->pool_bytes);
+  ctx->pool_bytes = 0;
+  ctx->pool_sizes = {};
+  ctx->pipe.grid.cell_ends = nullptr, ctx->pipe.grid.pos_len = nullptr, ctx->pipe.grid.rec = nullptr, ctx->pipe.grid.block_sums = nullptr;
+}
+
 void release_pipeline(etx_hip_context* ctx) {
+  release_pools(ctx);
+  ctx->grid_wanted = false;
   for (void* p : ctx->allocations)
     (void)hipFree(p);
   ctx->allocations.clear();
@@ -182,6 +222,75 @@ uint32_t next_pow2(uint32_t v) {
   v--;
   v |= v >> 1, v |= v >> 2, v |= v >> 4, v |= v >> 8, v |= v >> 16;
   return v + 1;
+}
+
+constexpr uint32_t kPoolRecordLimit = 1u << 30;
+
+// What the pools start with. The reference grows a std::vector of light vertices under a mutex (vcm_cpu.cxx:131-171); measured at 1080p the
+// bench scenes store 2.9-3.8 vertices per light path (fog box 3.8, classic 3.5, gems 3.4, density-grid box 2.9), the subsurface scene of
+// configs[3] 9.7 (one per scattering event of a walk). Round 3 sized for 16 / 64 per path and for sixteen pairs per camera vertex of a
+// bounce - 9.2 GB per lane on a 44-triangle box, 185 GB for configs[3] on six lanes. Now: 6 (16 with subsurface materials) per path,
+// as many pairs per bounce, and whatever a scene needs beyond that is found by the overflow / retry path.
+etx_hip_context::PoolSizes initial_pool_sizes(const etx_hip_context* pub, uint32_t n) {
+  etx_hip_context::PoolSizes sizes;
+  const bool sss = pub->scene.has_subsurface;
+  uint32_t per_path = sss ? 16u : 6u;
+  if (pub->pool_initial_per_path != 0u)
+    per_path = pub->pool_initial_per_path;
+  sizes.light_vertices = uint32_t(std::min<uint64_t>(uint64_t(n) * per_path, kPoolRecordLimit));
+  // camera vertex records per path and bounce: Christensen-Burley vertices have up to 24 exit points; a subsurface walk under the
+  // bidirectional integrator stores its entry and its exit vertex in one kernel invocation
+  const uint32_t exit_points = pub->scene.has_subsurface_cb ? 8u : (sss ? 2u : 1u);
+  sizes.camera_vertices = uint32_t(std::min<uint64_t>(uint64_t(n) * exit_points, kPoolRecordLimit));
+  sizes.pairs = uint32_t(std::min<uint64_t>(uint64_t(n) * std::max(per_path, 4u), kPoolRecordLimit));
+  sizes.shadow = uint32_t(std::min<uint64_t>(uint64_t(sizes.pairs) + 2ull * sizes.camera_vertices, 0xfffffff0ull));
+  // endpoint requests come from the general / subsurface shading groups only (k_connect_endpoints)
+  sizes.endpoints = (pub->scene.group_general || pub->scene.group_subsurface) ? sizes.camera_vertices : 1024u;
+  return sizes;
+}
+
+size_t pool_bytes_for(const etx_hip_context::PoolSizes& z, bool with_grid) {
+  size_t bytes = size_t(z.light_vertices) * LightVertexPool::kLvStride * sizeof(float4);
+  if (with_grid)
+    bytes += size_t(next_pow2(z.light_vertices)) * 4u + size_t(z.light_vertices) * (1u + PhotonGrid::kPhotonStride) * sizeof(float4);
+  bytes += size_t(z.camera_vertices) * (7u * sizeof(float4) + 3u * 4u);
+  bytes += size_t(z.pairs) * sizeof(uint2) + size_t(z.shadow) * 3u * sizeof(float4) + size_t(z.endpoints) * (5u * sizeof(float4) + 4u);
+  return bytes;
+}
+
+// (Re)allocates this lane's growable pools at `sizes`; the lane's stream must be idle.
+int allocate_pools(etx_hip_context* ctx, const etx_hip_context::PoolSizes& sizes) {
+  release_pools(ctx);
+  Pipeline& p = ctx->pipe;
+  int rc = 0;
+  p.lv.capacity = sizes.light_vertices;
+  if ((rc = pool_alloc(ctx, p.lv.rec, size_t(p.lv.capacity) * LightVertexPool::kLvStride)))
+    return rc;
+  p.grid.hash_capacity = next_pow2(p.lv.capacity);
+  if (ctx->grid_wanted) {
+    if ((rc = pool_alloc(ctx, p.grid.cell_ends, p.grid.hash_capacity)) || (rc = pool_alloc(ctx, p.grid.pos_len, p.lv.capacity)) ||
+        (rc = pool_alloc(ctx, p.grid.rec, size_t(p.lv.capacity) * PhotonGrid::kPhotonStride)) || (rc = pool_alloc(ctx, p.grid.block_sums, p.grid.hash_capacity / 2048u + 1024u)))
+      return rc;
+  }
+  p.cv_capacity = sizes.camera_vertices;
+  const uint32_t cvn = p.cv_capacity;
+  if ((rc = pool_alloc(ctx, p.cv.wavelength, cvn)) || (rc = pool_alloc(ctx, p.cv.hit, cvn)) || (rc = pool_alloc(ctx, p.cv.wi_medium, cvn)) || (rc = pool_alloc(ctx, p.cv.thr_depth, cvn)) ||
+      (rc = pool_alloc(ctx, p.cv.mis_pixel, cvn)) || (rc = pool_alloc(ctx, p.cv.seed, cvn)) || (rc = pool_alloc(ctx, p.cv.pos_info, cvn)) || (rc = pool_alloc(ctx, p.cv.nrm_dvm, cvn)) ||
+      (rc = pool_alloc(ctx, p.cv.fthr_dvcm, cvn)) || (rc = pool_alloc(ctx, p.merge_order, cvn)))
+    return rc;
+  p.pair_capacity = sizes.pairs;
+  if ((rc = pool_alloc(ctx, p.pairs, p.pair_capacity)))
+    return rc;
+  p.shadow.capacity = sizes.shadow;
+  if ((rc = pool_alloc(ctx, p.shadow.p0_medium, p.shadow.capacity)) || (rc = pool_alloc(ctx, p.shadow.p1_target, p.shadow.capacity)) || (rc = pool_alloc(ctx, p.shadow.value, p.shadow.capacity)))
+    return rc;
+  p.endpoints.capacity = sizes.endpoints;
+  const uint32_t epn = sizes.endpoints;
+  if ((rc = pool_alloc(ctx, p.endpoints.hit, epn)) || (rc = pool_alloc(ctx, p.endpoints.wi_medium, epn)) || (rc = pool_alloc(ctx, p.endpoints.thr_depth, epn)) ||
+      (rc = pool_alloc(ctx, p.endpoints.mis_id, epn)) || (rc = pool_alloc(ctx, p.endpoints.rnd_seed, epn)) || (rc = pool_alloc(ctx, p.endpoints.wavelength, epn)))
+    return rc;
+  ctx->pool_sizes = sizes;
+  return 0;
 }
 
 int allocate_pipeline(etx_hip_context* ctx) {
@@ -224,54 +333,28 @@ int allocate_pipeline(etx_hip_context* ctx) {
     if ((rc = device_alloc(ctx, p.walk_info[0], n)) || (rc = device_alloc(ctx, p.walk_info[1], n)) || (rc = device_alloc(ctx, p.walk_exit_hits, n)))
       return rc;
   }
-  // light vertex pool: the reference grows a std::vector (vcm_cpu.cxx:131-171); here a fixed pool sized for
-  // 16 stored vertices per path on average, overflow is detected and reported (never silently dropped).
-  // a subsurface walk under the bidirectional integrator stores one vertex per scattering event inside the object
-  uint32_t per_path = ctx->scene.has_subsurface ? 64 : 16;
-  if (const char* e = getenv("ETX_HIP_LIGHT_VERTICES_PER_PATH"))
-    per_path = std::max(1, atoi(e));
-  uint64_t lv_cap64 = uint64_t(n) * per_path;
-  if (lv_cap64 > (1ull << 30))
-    lv_cap64 = 1ull << 30;
-  p.lv.capacity = uint32_t(lv_cap64);
-  if ((rc = device_alloc(ctx, p.lv.rec, size_t(p.lv.capacity) * LightVertexPool::kLvStride)))
-    return rc;
-  // camera vertex records per path and bounce the pools are sized for (overflow is reported): Christensen-Burley vertices have up to 24
-  // exit points; a subsurface walk under the bidirectional integrator stores its entry and its exit vertex in one kernel invocation
-  const uint32_t exit_points = ctx->scene.has_subsurface_cb ? 8u : (ctx->scene.has_subsurface ? 2u : 1u);
-  p.cv_capacity = uint32_t(std::min<uint64_t>(uint64_t(n) * exit_points, 1ull << 30));
-  const uint32_t cvn = p.cv_capacity;
-  if ((rc = device_alloc(ctx, p.path_wavelength, n)) || (rc = device_alloc(ctx, p.cv.wavelength, cvn)))
+  if ((rc = device_alloc(ctx, p.path_wavelength, n)))
     return rc;
   // a light path that walks through a subsurface object under the bidirectional integrator stores a vertex per scattering event: a longer
   // table keeps k_expand_pairs off the per-lane list walk (configs[3]: 181 us per launch with eight entries)
   p.path_table_entries = etxh::tuning_knob("ETX_HIP_PATH_TABLE", ctx->scene.has_subsurface ? kPathTableEntriesWalk : kPathTableEntries) & ~3u;
   if ((rc = device_alloc(ctx, p.light_path_head, n)) || (rc = device_alloc(ctx, p.light_path_len, n)) || (rc = device_alloc(ctx, p.light_path_table, size_t(n) * (p.path_table_entries / 4u))))
     return rc;
-  // the photon grid (a quarter of a lane's memory: 176 B per pooled light vertex) is allocated by the first etx_hip_begin(VCM): the path
-  // tracer and the bidirectional integrator never touch it (allocate_photon_grid)
   p.grid = {};
-  p.grid.hash_capacity = next_pow2(p.lv.capacity);
   if ((rc = device_alloc(ctx, p.grid_params, 1)))
-    return rc;
-  if ((rc = device_alloc(ctx, p.cv.hit, cvn)) || (rc = device_alloc(ctx, p.cv.wi_medium, cvn)) || (rc = device_alloc(ctx, p.cv.thr_depth, cvn)) || (rc = device_alloc(ctx, p.cv.mis_pixel, cvn)) ||
-      (rc = device_alloc(ctx, p.cv.seed, cvn)) || (rc = device_alloc(ctx, p.cv.pos_info, cvn)) || (rc = device_alloc(ctx, p.cv.nrm_dvm, cvn)) || (rc = device_alloc(ctx, p.cv.fthr_dvcm, cvn)))
     return rc;
   if ((rc = device_alloc(ctx, p.group_list[0], n)) || (rc = device_alloc(ctx, p.group_list[1], n)))
     return rc;
-  if ((rc = device_alloc(ctx, p.merge_order, cvn)) || (rc = device_alloc(ctx, p.merge_buckets, kMergeBuckets + 1u + 256u)))
+  if ((rc = device_alloc(ctx, p.merge_buckets, kMergeBuckets + 1u + 256u)))
     return rc;
-  p.pair_capacity = uint32_t(std::min<uint64_t>(uint64_t(n) * 16u * (ctx->scene.has_subsurface ? 8u : 1u)  /* a light path with a subsurface walk has one vertex per scattering event */, 1ull << 30));
-  if ((rc = device_alloc(ctx, p.pairs, p.pair_capacity)))
-    return rc;
-  p.shadow.capacity = uint32_t(std::min<uint64_t>(uint64_t(p.pair_capacity) + 2ull * cvn, 0xfffffff0ull));
-  if ((rc = device_alloc(ctx, p.shadow.p0_medium, p.shadow.capacity)) || (rc = device_alloc(ctx, p.shadow.p1_target, p.shadow.capacity)) ||
-      (rc = device_alloc(ctx, p.shadow.value, p.shadow.capacity)))
-    return rc;
-  p.endpoints.capacity = cvn;
-  if ((rc = device_alloc(ctx, p.endpoints.hit, cvn)) || (rc = device_alloc(ctx, p.endpoints.wi_medium, cvn)) || (rc = device_alloc(ctx, p.endpoints.thr_depth, cvn)) ||
-      (rc = device_alloc(ctx, p.endpoints.mis_id, cvn)) || (rc = device_alloc(ctx, p.endpoints.rnd_seed, cvn)) || (rc = device_alloc(ctx, p.endpoints.wavelength, cvn)))
-    return rc;
+  // the growable pools (light vertices, camera vertices, pairs, shadow and endpoint queues; the photon grid from the first VCM run on)
+  {
+    etx_hip_context* pub = ctx->owner ? ctx->owner : ctx;
+    if (pub->pool_wanted.light_vertices == 0u)
+      pub->pool_wanted = initial_pool_sizes(pub, n);
+    if ((rc = allocate_pools(ctx, pub->pool_wanted)))
+      return rc;
+  }
   if ((rc = device_alloc(ctx, ctx->pt_iteration_image, size_t(n) * 2u)))
     return rc;
   if (ctx->owner == nullptr) {
@@ -295,15 +378,17 @@ int allocate_pipeline(etx_hip_context* ctx) {
   return 0;
 }
 
-// VCMSpatialGrid storage of one lane, on first use (etx_hip_begin with the VCM integrator)
+// VCMSpatialGrid storage of one lane (80 B per pooled light vertex), on first use (etx_hip_begin with the VCM integrator): from then on it is
+// part of the lane's growable pools
 int allocate_photon_grid(etx_hip_context* ctx) {
   Pipeline& p = ctx->pipe;
+  ctx->grid_wanted = true;
   if (p.grid.rec != nullptr)
     return 0;
   HIP_OK(ctx, hipSetDevice(ctx->device));
   int rc = 0;
-  if ((rc = device_alloc(ctx, p.grid.cell_ends, p.grid.hash_capacity)) || (rc = device_alloc(ctx, p.grid.pos_len, p.lv.capacity)) ||
-      (rc = device_alloc(ctx, p.grid.rec, size_t(p.lv.capacity) * PhotonGrid::kPhotonStride)) || (rc = device_alloc(ctx, p.grid.block_sums, p.grid.hash_capacity / 2048u + 1024u)))
+  if ((rc = pool_alloc(ctx, p.grid.cell_ends, p.grid.hash_capacity)) || (rc = pool_alloc(ctx, p.grid.pos_len, p.lv.capacity)) ||
+      (rc = pool_alloc(ctx, p.grid.rec, size_t(p.lv.capacity) * PhotonGrid::kPhotonStride)) || (rc = pool_alloc(ctx, p.grid.block_sums, p.grid.hash_capacity / 2048u + 1024u)))
     return rc;
   return 0;
 }
@@ -587,7 +672,7 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
     rounds, kStatRaysCamera);
   if (rc)
     return rc;
-  launch_vcm_commit(s, p.camera_sum, p.light_sum, ctx->pipe.camera_sum, ctx->pipe.light_sum, p.capacity);
+  launch_vcm_commit(s, p.camera_sum, p.light_sum, ctx->pipe.camera_sum, ctx->pipe.light_sum, p.capacity, p.counters);
   launch_stats_finalize(s, p);
   ctx->stats.wavefront_bounces = rounds;
   return 0;
@@ -645,6 +730,8 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
   VcmParams it = {};
   it.options = (o.connect_to_camera ? ETX_VCM_CONNECT_TO_CAMERA : 0u) | (o.direct_hit ? ETX_VCM_DIRECT_HIT : 0u) | (o.connect_to_light ? ETX_VCM_CONNECT_TO_LIGHT : 0u) |
                (o.connect_vertices ? ETX_VCM_CONNECT_VERTICES : 0u) | (o.mis ? ETX_VCM_ENABLE_MIS : 0u);
+  if (ctx->retry_attempt)
+    it.options |= kOptionRetryKeepsAovs;  // the discarded first attempt has added this iteration's normal / albedo values
   it.kernel = o.mode;  // CPUBidirectionalImpl::Mode
   ctx->cross_mode = 2u;  // BdptState: medium in meta.z, no path distance
   it.iteration = iteration;
@@ -721,7 +808,7 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
     if (rc)
       return rc;
   }
-  launch_vcm_commit(s, p.camera_sum, p.light_sum, ctx->pipe.camera_sum, ctx->pipe.light_sum, p.capacity);
+  launch_vcm_commit(s, p.camera_sum, p.light_sum, ctx->pipe.camera_sum, ctx->pipe.light_sum, p.capacity, p.counters);
   launch_stats_finalize(s, p);
   ctx->stats.wavefront_bounces = rounds;
   return 0;
@@ -778,36 +865,87 @@ void collect_stats(etx_hip_context* ctx) {
 #endif
 }
 
-// Renders one iteration on `lane` (worker thread of that lane) and folds its statistics into the public context.
-int execute_iteration(etx_hip_context* lane, uint32_t iteration) {
-  HIP_OK(lane, hipEventRecord(lane->iteration_begin, lane->stream));
-  lane->stats = {};
-  lane->stats.current_iteration = iteration;
-  int rc = (lane->integrator == ETX_HIP_INTEGRATOR_PT)     ? render_pt_iteration(lane, iteration)
-           : (lane->integrator == ETX_HIP_INTEGRATOR_BDPT) ? render_bdpt_iteration(lane, iteration)
-                                                           : render_vcm_iteration(lane, iteration);
-  if (rc)
-    return rc;
-  HIP_OK(lane, hipEventRecord(lane->iteration_end, lane->stream));
-  // the bounce loop already synchronised on the counters; the tail (nothing after the last read) is short
-  HIP_OK(lane, hipEventSynchronize(lane->iteration_end));
-  rc = read_counters(lane);
-  if (rc)
-    return rc;
-  float ms = 0.0f;
-  (void)hipEventElapsedTime(&ms, lane->iteration_begin, lane->iteration_end);
-  collect_stats(lane);
-  lane->stats.last_iteration_time = double(ms) * 1.0e-3;
-  if (lane->stats.overflow_flags) {
-    lane->error = "device pool overflow in iteration " + std::to_string(iteration) + " (flags " + std::to_string(lane->stats.overflow_flags) +
-                  "): light vertex pool (1, raise ETX_HIP_LIGHT_VERTICES_PER_PATH) / connection pair buffer (4) / shadow queue (8) / camera vertex pool (16) / endpoint queue (32)";
-    return ETX_HIP_ERROR_OVERFLOW;
-  }
-  return ETX_HIP_OK;
-}
-
 etx_hip_context* public_context(etx_hip_context* lane) {
   return lane->owner ? lane->owner : lane;
+}
+
+// A pool overflowed: double what overflowed (bounded by the record limit and etx_hip_set_pool_policy's byte limit) in the sizes every lane
+// adopts. False: nothing can grow any more.
+bool grow_pools(etx_hip_context* lane, uint32_t flags) {
+  etx_hip_context* pub = public_context(lane);
+  std::lock_guard<std::mutex> lock(pub->shared_mutex);
+  etx_hip_context::PoolSizes w = pub->pool_wanted;
+  // another lane may have grown the pools since this lane adopted its sizes: take those first
+  if ((w == lane->pool_sizes) == false)
+    return true;
+  auto twice = [](uint32_t v, uint64_t limit) { return uint32_t(std::min<uint64_t>(uint64_t(v) * 2ull, limit)); };
+  if (flags & kOverflowLightVertices)
+    w.light_vertices = twice(w.light_vertices, kPoolRecordLimit);
+  if (flags & kOverflowPairs)
+    w.pairs = twice(w.pairs, kPoolRecordLimit);
+  if (flags & kOverflowCameraVertices)
+    w.camera_vertices = twice(w.camera_vertices, kPoolRecordLimit);
+  if (flags & kOverflowEndpoints)
+    w.endpoints = twice(w.endpoints, kPoolRecordLimit);
+  if (flags & kOverflowShadow)
+    w.shadow = twice(w.shadow, 0xfffffff0ull);
+  w.shadow = std::max(w.shadow, uint32_t(std::min<uint64_t>(uint64_t(w.pairs) + 2ull * w.camera_vertices, 0xfffffff0ull)));
+  if (w == pub->pool_wanted)
+    return false;
+  if ((pub->pool_limit_bytes != 0u) && (pool_bytes_for(w, lane->grid_wanted) > pub->pool_limit_bytes))
+    return false;
+  pub->pool_wanted = w;
+  pub->totals.pool_grows += 1u;
+  return true;
+}
+
+// Renders one iteration on `lane` (worker thread of that lane) and folds its statistics into the public context. An iteration whose pools
+// overflowed has not been committed to the film (k_vcm_commit): the pools grow and the same iteration is rendered again.
+int execute_iteration(etx_hip_context* lane, uint32_t iteration) {
+  etx_hip_context* pub = public_context(lane);
+  for (uint32_t attempt = 0;; ++attempt) {
+    etx_hip_context::PoolSizes wanted;
+    {
+      std::lock_guard<std::mutex> lock(pub->shared_mutex);
+      wanted = pub->pool_wanted;
+    }
+    if ((wanted == lane->pool_sizes) == false) {
+      HIP_OK(lane, hipStreamSynchronize(lane->stream));
+      if (int rc = allocate_pools(lane, wanted))
+        return rc;
+    }
+    lane->retry_attempt = attempt != 0u;
+    HIP_OK(lane, hipEventRecord(lane->iteration_begin, lane->stream));
+    lane->stats = {};
+    lane->stats.current_iteration = iteration;
+    int rc = (lane->integrator == ETX_HIP_INTEGRATOR_PT)     ? render_pt_iteration(lane, iteration)
+             : (lane->integrator == ETX_HIP_INTEGRATOR_BDPT) ? render_bdpt_iteration(lane, iteration)
+                                                             : render_vcm_iteration(lane, iteration);
+    if (rc)
+      return rc;
+    HIP_OK(lane, hipEventRecord(lane->iteration_end, lane->stream));
+    // the bounce loop already synchronised on the counters; the tail (nothing after the last read) is short
+    HIP_OK(lane, hipEventSynchronize(lane->iteration_end));
+    rc = read_counters(lane);
+    if (rc)
+      return rc;
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, lane->iteration_begin, lane->iteration_end);
+    collect_stats(lane);
+    lane->stats.last_iteration_time = double(ms) * 1.0e-3;
+    const uint32_t flags = lane->stats.overflow_flags;
+    if (flags == 0u)
+      return ETX_HIP_OK;
+    // the path tracer commits unconditionally (its queues are bounded by construction: two requests per path and round); a traversal stack
+    // cannot grow
+    const bool growable = (lane->integrator != ETX_HIP_INTEGRATOR_PT) && ((flags & kOverflowStack) == 0u) && (attempt < 8u);
+    if ((growable == false) || (grow_pools(lane, flags) == false)) {
+      lane->error = "device pool overflow in iteration " + std::to_string(iteration) + " (flags " + std::to_string(flags) +
+                    "): light vertex pool (1) / traversal stack (2) / connection pair buffer (4) / shadow queue (8) / camera vertex pool (16) / endpoint queue (32) "
+                    "cannot grow any further (etx_hip_set_pool_policy limits a lane's pools to " + std::to_string(pub->pool_limit_bytes) + " bytes; 0 = the device's memory)";
+      return ETX_HIP_ERROR_OVERFLOW;
+    }
+  }
 }
 
 void lane_worker(etx_hip_context* lane) {
@@ -1040,6 +1178,7 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
   int rc = etxh::build_device_scene(scene, camera, context->scene, context->error);
   if (rc)
     return rc;
+  context->pool_wanted = {};  // the pools start over at what this scene typically needs (initial_pool_sizes)
   rc = allocate_pipeline(context);
   if (rc)
     return rc;
@@ -1110,6 +1249,7 @@ int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, c
   // pool sizes follow the materials in use (subsurface scenes keep more vertices per path): the lanes' pipelines are set up again
   for (etx_hip_context* helper : context->helpers)
     release_pipeline(helper);
+  context->pool_wanted = {};
   rc = allocate_pipeline(context);
   if (rc)
     return rc;
@@ -1117,6 +1257,14 @@ int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, c
     return rc;
   HIP_OK(context, hipDeviceSynchronize());
   context->scene_ready = true;
+  return ETX_HIP_OK;
+}
+
+int etx_hip_set_pool_policy(etx_hip_context* context, uint32_t initial_light_vertices_per_path, size_t max_pool_bytes_per_lane) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  context->pool_initial_per_path = initial_light_vertices_per_path;
+  context->pool_limit_bytes = max_pool_bytes_per_lane;
   return ETX_HIP_OK;
 }
 
@@ -1751,10 +1899,11 @@ int etx_hip_set_timers(etx_hip_context* context, uint32_t mask) {
 }
 
 int etx_hip_stats(etx_hip_context* context, etx_hip_stats_t* out_stats, size_t stats_size) {
-  if ((context == nullptr) || (out_stats == nullptr) || (stats_size != sizeof(etx_hip_stats_t)))
+  // a client built against an earlier header asks for the prefix it knows (fields are only ever appended, ETX_HIP_ABI_VERSION counts them)
+  if ((context == nullptr) || (out_stats == nullptr) || (stats_size == 0u) || (stats_size > sizeof(etx_hip_stats_t)))
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> lock(context->shared_mutex);
-  *out_stats = context->totals;
+  memcpy(out_stats, &context->totals, stats_size);
   return ETX_HIP_OK;
 }
 

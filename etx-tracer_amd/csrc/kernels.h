@@ -67,7 +67,7 @@ void launch_merge_reset(hipStream_t stream, const Pipeline& p);
 void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items);
 
 // film
-void launch_vcm_commit(hipStream_t stream, float4* iteration_camera, float4* iteration_light, float4* camera_sum, float4* light_sum, uint32_t pixels);
+void launch_vcm_commit(hipStream_t stream, float4* iteration_camera, float4* iteration_light, float4* camera_sum, float4* light_sum, uint32_t pixels, const uint32_t* counters);
 void launch_film_resolve(hipStream_t stream, const float4* camera_sum, const float4* light_sum, float4* out, uint32_t pixel_count, float scale, int layer, const float4* counts = nullptr);
 
 // known-answer kernels

@@ -620,7 +620,8 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_generate(Pipeline p,
     // the reference seeds the camera sampler like the light sampler of the same pixel (:377-378); the device gives the
     // camera path a stream of its own (as for VCM, kernels_vcm.hip k_camera_generate and DESIGN.md 4)
     st.sampler.init(i, it.iteration);
-    st.sampler.seed = Sampler::random_seed(st.sampler.seed, 0x43414d45u);
+    if ((p.debug_flags & 0x8000u) == 0u)  // bit 15: shared streams, see k_camera_generate
+      st.sampler.seed = Sampler::random_seed(st.sampler.seed, 0x43414d45u);
     st.wavelength = 0.0f;
     if (scene.spectral) {
       const float u = st.sampler.next();
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_generate(Pipeline p,
     st.aux = 0.0f;
     st.path_size = 1u;
     st.medium = scene.camera.medium_index;
-    st.flags = kBpFirst;
+    st.flags = kBpFirst | ((it.options & kOptionRetryKeepsAovs) ? kBpGBuffer : 0u);
     st.prev = {r.o, scene.camera.direction, 1.0f, 0.0f, kBvConnectible | kBvMisConnectible, kInvalid};
     bdpt_store(p.paths[0], i, st, kInvalid);
   }

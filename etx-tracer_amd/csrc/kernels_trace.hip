@@ -138,6 +138,9 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
 // no atomics); a lane executes one traversal step (inner node or leaf) per loop iteration.
 // LDS per workgroup: the per-lane stacks (32 KB) + the first kLdsNodesPersistent nodes of the tree (top levels, 8 KB).
 constexpr uint32_t kRefillLanes = 16;
+#if !defined(ETX_WIDE_LDS_NODES)
+#define ETX_WIDE_LDS_NODES 64u  // staged nodes of the eight-wide kernel: the root and its children (8 KB; with the 16 KB short stack six workgroups per CU)
+#endif
 
 template <bool kDeep, uint32_t kLdsEntries = kStackDepth>
 struct TraversalStack {
@@ -441,7 +444,7 @@ static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const flo
     round_tag, lds_limit(), refill, pass_stat)
   const uint32_t need = scene.bvh_stack_need;
   if (scene.bvh8_nodes != nullptr) {  // ETX_HIP_BVH_WIDE: the eight-wide tree, checked short stack
-    hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, kShortStackDepth, 64u, true, true>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count,
+    hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, kShortStackDepth, ETX_WIDE_LDS_NODES, true, true>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count,
       round_mirror, round_tag, lds_limit(), refill, pass_stat);
     return;
   }

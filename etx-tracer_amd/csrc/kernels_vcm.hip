@@ -123,8 +123,11 @@ __global__ __launch_bounds__(kBlockSize) void k_camera_generate(Pipeline p, VcmP
     // the device traversal draws none for opaque triangles, so with the same seed camera draw k+1 would equal
     // light draw k forever and the (pixel i, light path i) vertex connections become correlated -> biased
     // (measured: -7% in the connection-only image). The camera stream is therefore re-keyed.
+    // Debug flag bit 15 (etx_hip_set_debug_flags) keeps the shared seed: the state the reference is in when its candidate draws are
+    // taken off the path's stream (oracle shim, ETX_ORACLE_BVH_DRAWS=opaque_none) - tests/test_gpu_parity_hi.py compares the two.
     st.sampler.init(i, it.iteration);
-    st.sampler.seed = Sampler::random_seed(st.sampler.seed, 0x43414d45u);
+    if ((p.debug_flags & 0x8000u) == 0u)
+      st.sampler.seed = Sampler::random_seed(st.sampler.seed, 0x43414d45u);
     // vcm_shared.hxx:358-359: one draw is consumed, the wavelength is the one of light path i (vcm_cpu.cxx:186)
     st.wavelength = 0.0f;
     if (scene.spectral) {
@@ -218,10 +221,17 @@ void launch_stats_finalize(hipStream_t stream, const Pipeline& p) {
 // ---------------------------------------------------------------------------------------------------------------
 // End of a VCM iteration: the lane's iteration images go into the film sums (shared by the lanes: atomics) and are
 // cleared for the next iteration. One add per pixel and iteration keeps the fp32 sums unbiased (host_api.cpp).
+// An iteration whose pools overflowed is NOT committed: its images are cleared, the film stays as it was, and the host renders the same
+// iteration again with larger pools (host_api.cpp execute_iteration) - the decision is taken here, on the device, from the overflow word.
 __global__ __launch_bounds__(kBlockSize) void k_vcm_commit(float4* __restrict__ iteration_camera, float4* __restrict__ iteration_light, float4* __restrict__ camera_sum,
-  float4* __restrict__ light_sum, uint32_t pixels) {
+  float4* __restrict__ light_sum, uint32_t pixels, const uint32_t* __restrict__ counters) {
   const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  const bool discard = counters[kCntOverflow] != 0u;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += gridDim.x * blockDim.x) {
+    if (discard) {
+      iteration_camera[i] = zero, iteration_light[i] = zero;
+      continue;
+    }
     const float4 c = iteration_camera[i], l = iteration_light[i];
     atomicAdd(&camera_sum[i].w, 1.0f);  // iterations committed to this pixel (k_film_resolve, progressive read-back)
     if ((c.x != 0.0f) || (c.y != 0.0f) || (c.z != 0.0f)) {
@@ -235,8 +245,8 @@ __global__ __launch_bounds__(kBlockSize) void k_vcm_commit(float4* __restrict__ 
   }
 }
 
-void launch_vcm_commit(hipStream_t stream, float4* iteration_camera, float4* iteration_light, float4* camera_sum, float4* light_sum, uint32_t pixels) {
-  hipLaunchKernelGGL(k_vcm_commit, dim3(grid_for(pixels)), dim3(kBlockSize), 0, stream, iteration_camera, iteration_light, camera_sum, light_sum, pixels);
+void launch_vcm_commit(hipStream_t stream, float4* iteration_camera, float4* iteration_light, float4* camera_sum, float4* light_sum, uint32_t pixels, const uint32_t* counters) {
+  hipLaunchKernelGGL(k_vcm_commit, dim3(grid_for(pixels)), dim3(kBlockSize), 0, stream, iteration_camera, iteration_light, camera_sum, light_sum, pixels, counters);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -188,6 +188,10 @@ struct VcmParams {  // VCMOptions + VCMIteration (vcm_shared.hxx:12-89), per ite
   const uint2* bluenoise;  // [128*128][256] x 8 bytes (etx_hip_upload_bluenoise), nullptr = options.blue_noise off
 };
 
+// VcmParams::options bit 31 (bidirectional integrator): this is the second attempt at an iteration whose pools overflowed - the first attempt
+// was not committed (k_vcm_commit) but has already added the iteration's normal / albedo values, which go straight to the film
+constexpr uint32_t kOptionRetryKeepsAovs = 1u << 31;
+
 // PT: VcmParams::options carries PTOptions (path_tracing_shared.hxx:8-14)
 enum : uint32_t { ETX_PT_DIRECT = 1u << 0, ETX_PT_NEE = 1u << 1, ETX_PT_MIS = 1u << 2 };
 

@@ -2,7 +2,7 @@
 // The product library runs with the defaults compiled in: `tuning_knob` returns `fallback`. A build with -DETX_HIP_DEBUG
 // (ETX_HIP_EXTRA_FLAGS=-DETX_HIP_DEBUG etx-tracer_amd/csrc/build.sh, tools/build_variant.sh) reads the ETX_HIP_* environment variable of
 // that name instead - what the A/B and cost-attribution tools (tools/ab_bench.sh, tools/cost_probe.sh, tools/option_cost.py) switch.
-// Documented run-time configuration is NOT a knob and is always read: ETX_HIP_LANES, ETX_HIP_LIGHT_VERTICES_PER_PATH,
+// Documented run-time configuration is NOT a knob and is always read: ETX_HIP_LANES,
 // ETX_HIP_BVH_BUILD_THREADS, ETX_HIP_VERBOSE (include/etx_hip.h).
 #pragma once
 

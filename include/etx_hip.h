@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ETX_HIP_ABI_VERSION 1
+#define ETX_HIP_ABI_VERSION 2
 
 typedef struct etx_hip_context etx_hip_context; /* opaque */
 
@@ -67,8 +67,6 @@ int etx_hip_abi_version(void);
 /* Opens HIP device `device` (must be gfx950) and creates the streams / queues.
  * Environment the library reads (deployment settings, nothing else is read from the environment by the product build):
  *   ETX_HIP_LANES=n                      iterations in flight, 1..8 (default: four, six for the bidirectional integrator) - etx_hip_create
- *   ETX_HIP_LIGHT_VERTICES_PER_PATH=n    size of the light vertex pool in stored vertices per pixel (default 16; 64 for scenes with
- *                                        subsurface materials); a pool that is too small is reported as ETX_HIP_ERROR_OVERFLOW - etx_hip_upload_scene
  *   ETX_HIP_BVH_BUILD_THREADS=n          host threads of the binned-SAH tree build (default: the hardware's) - etx_hip_upload_scene
  *   ETX_HIP_VERBOSE=1                    build phases and their times on stderr */
 int etx_hip_create(int device, etx_hip_context** out_context);
@@ -217,7 +215,7 @@ typedef struct etx_hip_stats_t {
   uint64_t photons_merged;       /* photons accepted by the merge */
   uint64_t splats;               /* light image splats */
   uint64_t wavefront_bounces;    /* kernel rounds (light + camera) */
-  uint32_t overflow_flags;       /* != 0: a pool overflowed (result of that iteration is incomplete) */
+  uint32_t overflow_flags;       /* != 0: a pool overflowed and could not grow (that iteration failed with ETX_HIP_ERROR_OVERFLOW and is not in the film) */
   uint32_t nonfinite_dropped;    /* film contributions that were not finite and were dropped instead of poisoning their pixel (expected: 0) */
   /* per-kernel device time since etx_hip_begin, milliseconds (HIP events on the launch streams, summed over the iterations) */
   double ms_trace_closest;
@@ -240,6 +238,9 @@ typedef struct etx_hip_stats_t {
   uint64_t last_active_pixels;   /* pixels sampled by the most recently finished iteration: 0 = every pixel has converged (CPUPathTracing stops, path_tracing.cxx:91-93) */
   uint64_t boundary_crossings;   /* closest-hit queries the traversal kernel ran beyond a medium boundary it crossed itself (paths outside any medium:
                                     vcm_handle_boundary_bsdf draws nothing); included in rays_extension, not in rays_light / rays_camera (segments shaded) */
+  /* ABI 2 */
+  uint32_t pool_grows;           /* times an iteration overflowed a device pool, was discarded before its commit and rendered again with larger pools */
+  uint32_t reserved_0;
 } etx_hip_stats_t;
 
 /* Which kernel groups are timed with HIP events (bit i = the i-th ms_* field above, in declaration order; default: the two
@@ -250,9 +251,19 @@ int etx_hip_stats(etx_hip_context* context, etx_hip_stats_t* out_stats, size_t s
 
 /* Ablation switches of the kernels for timing experiments and kernel-level tests (0 = production, the default): bit 0 no film
  * atomics in the shadow kernel, bit 2 no transmittance traversal, bit 6 (64) the packed two-ray flat sweep in etx_hip_trace_rays*,
- * bits 8 / 9 no next event estimation / no camera vertex storage. Waits for the iterations in flight. The library reads no
+ * bits 8 / 9 no next event estimation / no camera vertex storage, bit 15 the camera path keeps the seed of the light path of its pixel
+ * (the reference's seeding, vcm_shared.hxx:312,357; parity experiment of DESIGN.md 4). Waits for the iterations in flight. The library reads no
  * environment variable for these; builds with -DETX_HIP_DEBUG additionally read tuning knobs (csrc/tuning_knobs.h). */
 int etx_hip_set_debug_flags(etx_hip_context* context, uint32_t flags);
+
+/* The device pools whose fill depends on the scene and on the sample (light vertices and the photon grid built over them, camera vertices,
+ * connection pairs, shadow and endpoint queues) start at what typical paths need - six stored light vertices per path, sixteen in scenes
+ * with subsurface materials - and grow on demand: an iteration that overflows a pool is discarded before it reaches the film, the pool is
+ * doubled for all lanes and the same iteration is rendered again (etx_hip_stats_t::pool_grows counts these). The reference grows a
+ * std::vector under a mutex at the same place (vcm_cpu.cxx:131-171). This call sets, for the NEXT etx_hip_upload_scene / _update_scene:
+ * the light vertices per path the pools start with (0 = the default) and the bytes one lane's pools may grow to (0 = no limit but the
+ * device's memory); beyond the limit an overflow fails the iteration with ETX_HIP_ERROR_OVERFLOW, as a failed allocation would. */
+int etx_hip_set_pool_policy(etx_hip_context* context, uint32_t initial_light_vertices_per_path, size_t max_pool_bytes_per_lane);
 
 /* Device memory of the per-iteration working sets (queues, vertex pools, photon grid, film) of all lanes, in bytes: what a render of
  * the uploaded scene with the integrators used so far holds besides the scene itself. The photon grid of a lane exists from the first

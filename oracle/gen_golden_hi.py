@@ -12,6 +12,8 @@ tests of tests/test_gpu_parity_hi.py ("a high-spp oracle reference
   tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_<far_first|random_child>.npz   (--integrators orders) the unmodified reference under
       ETX_ORACLE_BVH_ORDER = another child order of the BVH shim
   tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_shared_first_vertex.npz   (--integrators firstvertex) ETX_ORACLE_DECORRELATE=3
+  tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_bluenoise[_rekeyed].npz   (--integrators bluenoise) VCMOptions defaults = blue noise on
+  tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_opaque_none.npz   (--integrators opaque_none) ETX_ORACLE_BVH_DRAWS=opaque_none, shared seeds
   tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_rekeyed.npz        ETX_ORACLE_DECORRELATE=2: the camera path re-keys its sampler at
       its first segment = independent light / camera streams, the estimator the device implements
 
@@ -90,6 +92,17 @@ def main():
             # mode 3: shared streams through the first camera vertex, independent from the second segment on - where the reference's
             # light / camera correlation sits (not in the first vertex; this film equals the re-keyed one)
             render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_shared_first_vertex.npz" % (flavour, args.spp)), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "3"},
+                   extra=["--opt", "vcm-blue_noise=false"] + variant)
+        if "bluenoise" in integrators:
+            # VCMOptions::default_values(): blue noise ON (vcm_shared.cxx:6-13; the override of the first camera vertex in the first
+            # 256 iterations, vcm_shared.hxx:941-945,1018-1022) - the option set bench.py times. As is and re-keyed.
+            render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_bluenoise.npz" % (flavour, args.spp)), args.cores, extra=variant)
+            render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_bluenoise_rekeyed.npz" % (flavour, args.spp)), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "2"},
+                   extra=variant)
+        if "opaque_none" in integrators:
+            # the UNMODIFIED integrator (shared seeds) with the candidate draws of always-opaque triangles taken off the path's stream
+            # (ETX_ORACLE_BVH_DRAWS=opaque_none, oracle/shims/raytracing_bvh.cxx): a film that no longer depends on the traversal order
+            render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_opaque_none.npz" % (flavour, args.spp)), args.cores, env_extra={"ETX_ORACLE_BVH_DRAWS": "opaque_none"},
                    extra=["--opt", "vcm-blue_noise=false"] + variant)
         if "rekeyed" in integrators:
             # mode 2: the camera sub path draws from a stream of its own from its first segment on (oracle/shims/raytracing_bvh.cxx)

@@ -264,6 +264,27 @@ std::atomic<uint64_t> g_oracle_rays_trace{0};
 std::atomic<uint64_t> g_oracle_rays_transmittance{0};
 std::atomic<uint64_t> g_oracle_rays_material{0};
 
+// ETX_ORACLE_BVH_DRAWS=opaque_none: alpha_test_pass draws one number of the PATH's sampler per candidate (scene_bsdf.hxx:128-144), also
+// for triangles that can never fail the test (opacity 1, no alpha image: `1 <= next()` is false for every draw). In this mode such a
+// candidate is tested with a scratch copy of the sampler, so the path's stream no longer depends on how many candidates a query met -
+// i.e. on the traversal order of whichever tree is used. The film of the UNMODIFIED integrator (shared light / camera seeds,
+// vcm_shared.hxx:312,357) is then unique: identical under every ETX_ORACLE_BVH_ORDER, which is what pins it (tests/test_reference_order_spread.py).
+// No reference source is touched; accepted / rejected candidates are the same as without the mode.
+static bool g_oracle_opaque_none = false;
+
+static inline bool shim_alpha_test_pass(const Material& mat, const Triangle& tri, const float3& bc, const Scene& scene, Sampler& smp) {
+  if (g_oracle_opaque_none && (mat.opacity >= 1.0f)) {
+    bool has_alpha = false;
+    if (mat.scattering.image_index != kInvalidIndex)
+      has_alpha = (scene.images[mat.scattering.image_index].options & Image::HasAlphaChannel) != 0;
+    if (has_alpha == false) {
+      Sampler scratch = smp;
+      return alpha_test_pass(mat, tri, bc, scene, scratch);
+    }
+  }
+  return alpha_test_pass(mat, tri, bc, scene, smp);
+}
+
 struct RaytracingImpl {
   TaskScheduler scheduler;
   Film film;
@@ -282,6 +303,8 @@ struct RaytracingImpl {
     decorrelate = (mode != nullptr) && (atoi(mode) == 1);
     rekey_camera = (mode != nullptr) && (atoi(mode) == 2);
     rekey_second = (mode != nullptr) && (atoi(mode) == 3);
+    const char* draws = getenv("ETX_ORACLE_BVH_DRAWS");
+    g_oracle_opaque_none = (draws != nullptr) && (strcmp(draws, "opaque_none") == 0);
   }
 
   ~RaytracingImpl() {
@@ -380,7 +403,7 @@ bool Raytracing::trace(const Scene& scene, const Ray& r, Intersection& result_in
     const auto& mat = scene.materials[tri.material_index];
     if (mat.cls == Material::Class::Void)
       return false;
-    if (alpha_test_pass(mat, tri, barycentrics({u, v}), scene, smp))
+    if (shim_alpha_test_pass(mat, tri, barycentrics({u, v}), scene, smp))
       return false;
     found = {{u, v}, triangle_index, t};
     return true;
@@ -402,7 +425,7 @@ bool Raytracing::trace_material(const Scene& scene, const Ray& r, const uint32_t
     const auto& mat = scene.materials[tri.material_index];
     if (mat.cls == Material::Class::Void)
       return false;
-    if (alpha_test_pass(mat, tri, barycentrics({u, v}), scene, smp))
+    if (shim_alpha_test_pass(mat, tri, barycentrics({u, v}), scene, smp))
       return false;
     found = {{u, v}, triangle_index, t};
     return true;
@@ -424,7 +447,7 @@ uint32_t Raytracing::continuous_trace(const Scene& scene, const Ray& r, const Co
     const auto& mat = scene.materials[tri.material_index];
     if (mat.cls == Material::Class::Void)
       return false;
-    if (alpha_test_pass(mat, tri, barycentrics({u, v}), scene, smp))
+    if (shim_alpha_test_pass(mat, tri, barycentrics({u, v}), scene, smp))
       return false;
     if (count < options.max_intersections) {
       options.intersection_buffer[count] = {{u, v}, triangle_index, t};
@@ -462,7 +485,7 @@ SpectralResponse Raytracing::trace_transmittance(const SpectralQuery spect, cons
     const auto& mat = scene.materials[tri.material_index];
     if (mat.cls == Material::Class::Void)
       return false;
-    if (alpha_test_pass(mat, tri, barycentrics({u, v}), scene, smp))
+    if (shim_alpha_test_pass(mat, tri, barycentrics({u, v}), scene, smp))
       return false;
     if ((mat.cls != Material::Class::Boundary) || (hit_count + 1u >= kIntersectionBufferSize)) {
       occluded = true;

@@ -59,6 +59,13 @@ def bluenoise_64spp():
 
 
 @pytest.fixture(scope="session")
+def bluenoise_256spp():
+    """... for the 256-spp class (set 8: scenes of 129 samples and more), oracle/_ref/etx_oracle --dump-bluenoise 256."""
+    from tools import bluenoise_tables
+    return bluenoise_tables.load(os.path.join(GOLDEN, "bluenoise_256spp.npz"))
+
+
+@pytest.fixture(scope="session")
 def rgb_response():
     """(rgb float32 [391, 3], first wavelength): the rows of the reference's rgb_response table (oracle/gen_golden.py)."""
     import numpy as np

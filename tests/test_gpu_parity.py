@@ -607,13 +607,13 @@ def test_two_shards_with_uneven_iteration_counts(etx, golden_dir):
     np.testing.assert_allclose(light[..., :3], whole_light[..., :3], rtol=2e-4, atol=2e-5)
 
 
-def test_pool_overflow_is_reported_and_does_not_skip_the_reduce(etx, golden_dir, monkeypatch):
-    """A data-dependent pool overflow (one light vertex per path) fails the iteration with ETX_HIP_ERROR_OVERFLOW; the film
-    reduce still runs its collective part (single rank: identity) and returns that error instead of hanging its peers."""
+def test_pool_overflow_is_reported_and_does_not_skip_the_reduce(etx, golden_dir):
+    """A pool that may not grow (one light vertex per path to start with, a byte limit below the next size) fails the iteration with
+    ETX_HIP_ERROR_OVERFLOW; the film reduce still runs its collective part (single rank: identity) and returns that error instead of hanging its peers."""
     from etx_tracer_amd import api, integrator as integ_mod
-    monkeypatch.setenv("ETX_HIP_LIGHT_VERTICES_PER_PATH", "1")
     snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_classic_128.etxscene"))
     ctx = api.Context(0)
+    ctx.set_pool_policy(1, 1 << 20)
     ctx.upload_scene(snap)
     ctx.comm_init(0, 1, api.comm_unique_id(ctx.library))
     ctx.begin_vcm(integ_mod.vcm_options_from_dict({"vcm-blue_noise": False}), first_iteration=0, iteration_stride=1)
@@ -623,6 +623,41 @@ def test_pool_overflow_is_reported_and_does_not_skip_the_reduce(etx, golden_dir,
     assert e.value.code == -6 and "overflow" in str(e.value)
     assert ctx.stats().overflow_flags & 1
     ctx.close()
+
+
+def test_pools_grow_and_the_overflowed_iteration_is_rendered_again(etx, golden_dir):
+    """Pools that start far too small (one light vertex per path; pairs and shadow queue sized from it) grow: the iterations that overflowed
+    are discarded before their commit and rendered again, so the film equals the film of a render whose pools were large from the start
+    (same iterations, same seeds: float addition order aside) - VCM on four lanes, the bidirectional integrator incl. its normal / albedo layers."""
+    from etx_tracer_amd import api, integrator as integ_mod
+    snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_classic_128.etxscene"))
+
+    def films(integrator, per_path):
+        ctx = api.Context(0)
+        ctx.set_pool_policy(per_path, 0)
+        ctx.upload_scene(snap)
+        if integrator == "vcm":
+            ctx.begin_vcm(integ_mod.vcm_options_from_dict({"vcm-blue_noise": False}), first_iteration=0, iteration_stride=1)
+        else:
+            ctx.begin_bdpt(integ_mod.bdpt_options_from_dict({"bdpt-blue_noise": False, "bdpt-mode": api.BDPT_MODE_FULL}), first_iteration=0, iteration_stride=1)
+        for _ in range(8):
+            ctx.render_iteration()
+        ctx.sync()
+        stats = ctx.stats()
+        out = [ctx.read_film(layer) for layer in (api.LAYER_CAMERA, api.LAYER_LIGHT, api.LAYER_NORMAL, api.LAYER_ALBEDO)]
+        bytes_held = ctx.device_bytes()
+        ctx.close()
+        assert stats.completed_iterations == 8 and stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
+        return out, stats, bytes_held
+
+    for integrator in ("vcm", "bdpt"):
+        small, small_stats, small_bytes = films(integrator, 1)
+        large, large_stats, large_bytes = films(integrator, 16)
+        assert small_stats.pool_grows >= 1 and large_stats.pool_grows == 0, (integrator, small_stats.pool_grows, large_stats.pool_grows)
+        assert small_bytes < large_bytes
+        assert small_stats.light_vertices == large_stats.light_vertices and small_stats.rays_shadow == large_stats.rays_shadow
+        for a, b in zip(small, large):
+            np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=2e-4, atol=2e-5)
 
 
 def test_asynchronous_film_readback(etx, golden_dir):

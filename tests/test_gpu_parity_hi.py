@@ -92,7 +92,7 @@ def compare(halves, reference, label, rmse_limit=1.0e-3, mean_limit=3.0e-3, bias
     assert p99 < bias_p99_limit + 1.5 * noise_p99, (label, p99, noise_p99)
 
 
-def render_halves(etx, golden_dir, flavour, cie, integrator_class, options):
+def render_halves(etx, golden_dir, flavour, cie, integrator_class, options, debug_flags=0, bluenoise=None):
     """Iterations 0, 2, 4, ... and 1, 3, 5, ... of the 4096-iteration set: two contexts, etx_hip_begin(first, stride 2)."""
     films = []
     for first in (0, 1):
@@ -102,6 +102,10 @@ def render_halves(etx, golden_dir, flavour, cie, integrator_class, options):
         integ = integrator_class(snap, first_iteration=first, iteration_stride=2)
         integ.options().update(options)
         integ.cie_table = cie
+        if bluenoise is not None:
+            integ.bluenoise_tables = dict(bluenoise)
+        if debug_flags:
+            integ.context.set_debug_flags(debug_flags)  # kept by the pipelines etx_hip_upload_scene allocates
         integ.render()
         cam, light = integ.film(etx.api.LAYER_CAMERA), integ.film(etx.api.LAYER_LIGHT)
         stats = integ.status()
@@ -112,8 +116,8 @@ def render_halves(etx, golden_dir, flavour, cie, integrator_class, options):
     return films
 
 
-def render_vcm(etx, golden_dir, flavour, cie):
-    return render_halves(etx, golden_dir, flavour, cie, etx.HIPVCM, {"vcm-blue_noise": False})
+def render_vcm(etx, golden_dir, flavour, cie, options=None, debug_flags=0, bluenoise=None):
+    return render_halves(etx, golden_dir, flavour, cie, etx.HIPVCM, {"vcm-blue_noise": False} if options is None else options, debug_flags, bluenoise)
 
 
 def render_pt(etx, golden_dir, flavour, cie):
@@ -136,6 +140,34 @@ def test_vcm_matches_reference_at_4096_spp(etx, golden_dir, cie_observer, flavou
     compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " vcm camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
     if flavour in ("full", "cloud", "classic"):
         inside_reference_spread(golden_dir, flavour, 0.5 * (cam_a + light_a + cam_b + light_b)[..., :3].astype(np.float64))
+
+
+def test_vcm_default_options_blue_noise_at_4096_spp(etx, golden_dir, bluenoise_256spp):
+    """The option set bench.py times: VCMOptions::default_values() = blue noise ON (vcm_shared.cxx:6-13). The first camera vertex of the first
+    256 iterations takes its six numbers from the host's blue-noise sampler (vcm_shared.hxx:941-945, 1018-1022; sample-count class of a
+    4096-spp scene: 256 = set 8), the other 3840 iterations run on the path's own stream. Same limits as the films without the override."""
+    (cam_a, light_a), (cam_b, light_b) = render_vcm(etx, golden_dir, "full", None, options={}, bluenoise={8: bluenoise_256spp})
+    golden = load_hi(golden_dir, "cornell_full_128_vcm_%d_bluenoise_rekeyed.npz" % SPP)
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "full vcm defaults (blue noise) camera+light (independent streams)")
+    compare((light_a, light_b), golden["light"], "full vcm defaults (blue noise) light (independent streams)", mean_limit=1.0e-2, bias_p99_limit=0.2)
+    compare((cam_a, cam_b), golden["camera"], "full vcm defaults (blue noise) camera (independent streams)")
+    golden = load_hi(golden_dir, "cornell_full_128_vcm_%d_bluenoise.npz" % SPP)
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], "full vcm defaults (blue noise) camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2,
+            bias_p99_limit=0.08)
+
+
+@pytest.mark.parametrize("flavour", ["classic", "full"])
+def test_vcm_shared_streams_match_the_pinned_reference(etx, golden_dir, flavour):
+    """The converse of the `_rekeyed` comparison: instead of giving the reference the device's stream policy, the
+    DEVICE takes the reference's - camera path i keeps the seed of light path i (debug flag bit 15, kernels_vcm.hip k_camera_generate) - and
+    is compared with the UNMODIFIED integrator in the one regime where its film is pinned: ETX_ORACLE_BVH_DRAWS=opaque_none takes the
+    candidate draws of always-opaque triangles off the path's stream (oracle/shims/raytracing_bvh.cxx), after which the reference's film is
+    the same under every traversal order (tests/test_reference_order_spread.py). north_star's limits, no allowance."""
+    (cam_a, light_a), (cam_b, light_b) = render_vcm(etx, golden_dir, flavour, None, debug_flags=0x8000)
+    golden = load_hi(golden_dir, "cornell_%s_128_vcm_%d_opaque_none.npz" % (flavour, SPP))
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " vcm camera+light (shared streams, pinned reference)")
+    compare((light_a, light_b), golden["light"], flavour + " vcm light (shared streams, pinned reference)", mean_limit=1.0e-2, bias_p99_limit=0.2)
+    compare((cam_a, cam_b), golden["camera"], flavour + " vcm camera (shared streams, pinned reference)")
 
 
 def inside_reference_spread(golden_dir, flavour, device):

@@ -85,14 +85,10 @@ def test_christensen_burley_on_meshes(etx, golden_dir):
 
 
 # The contract's own limits (north_star: pixel RMSE < 1e-3; image means within 0.3 %) need the noise of both films out of the way: 4096 spp,
-# as for the box scenes of test_gpu_parity_hi.py. These films were rendered (oracle/gen_golden_hi.py --spp 4096 ... sssmesh sssmeshcb) after
-# the round's last GPU minute was spent, so the cases have not run on a device yet: they report (XPASS / XFAIL) without deciding the
-# suite until their first run has been looked at; the 256 / 1024-spp cases above stay the gate. Same estimator code as the box scenes,
-# which pass these limits (sss, ssscb).
-FIRST_RUN_PENDING = pytest.mark.xfail(strict=False, reason="4096 / 1024-spp mesh films: first device run pending (limits of the contract, no allowance)")
+# as for the box scenes of test_gpu_parity_hi.py (oracle/gen_golden_hi.py --spp 4096 ... sssmesh sssmeshcb). First device run: round 4
+# (gpurun_out/r4a), all four inside the limits.
 
 
-@FIRST_RUN_PENDING
 @pytest.mark.parametrize("christensen_burley", [False, True])
 def test_path_tracer_on_meshes_at_4096_spp(etx, golden_dir, christensen_burley):
     name = "sssmeshcb" if christensen_burley else "sssmesh"
@@ -102,7 +98,6 @@ def test_path_tracer_on_meshes_at_4096_spp(etx, golden_dir, christensen_burley):
     compare((cam_a, cam_b), golden["camera"], name + " pt camera, 4096 spp")
 
 
-@FIRST_RUN_PENDING
 def test_vcm_on_meshes_at_4096_spp(etx, golden_dir):
     name = "sssmesh"
     (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, etx.HIPVCM, 4096, {"vcm-blue_noise": False})
@@ -115,7 +110,6 @@ def test_vcm_on_meshes_at_4096_spp(etx, golden_dir):
     compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], name + " vcm camera+light (reference as is), 4096 spp", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
 
 
-@FIRST_RUN_PENDING
 def test_bidirectional_on_meshes_at_1024_spp(etx, golden_dir):
     (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, etx.HIPBidirectional, 1024, {"bdpt-mode": etx.api.BDPT_MODE_FULL, "bdpt-blue_noise": False})
     golden = load(golden_dir, "cornell_sssmesh_128_bdpt3_1024_rekeyed.npz")

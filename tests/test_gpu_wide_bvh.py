@@ -1,9 +1,7 @@
 """GPU (-m gpu): the eight-wide tree with 8-bit child boxes (etx_hip_set_bvh_builder(BVH_HOST_SAH | BVH_WIDE), csrc/dev_bvh8.h).
 
-Written in round 3 after the round's GPU minutes were spent: the node function is the one tests/test_host_bvh8.py walks on the host,
-the kernels have compiled for gfx950 (register budgets in tests/test_build_budget.py) and have NOT run on a device yet. Until their
-first, deliberate run these cases are skipped (see below); the default tree is the four-wide one and nothing else in the suite selects
-this one.
+The node function is the one tests/test_host_bvh8.py walks on the host; register budgets in tests/test_build_budget.py. First device
+run: round 4 (tools/gpu_calls/gpu_r4a.sh), all cases green.
 
 What they check: the closest hits of the default tree ray by ray (the traversal visits other nodes in another order, a closest hit does
 not depend on that), the occlusion-only shadow kernel and the bidirectional walk kernels through renders that must agree with the
@@ -18,11 +16,7 @@ import pytest
 from tests.test_gpu_parity import make_rays
 from tests.test_gpu_scene_update import assert_same_render, hit_triangles, render
 
-# Device code that has never executed does not belong in a gate run: a wrong index in a kernel nobody has watched is a memory fault that
-# takes the test process (and the rest of the suite) with it. The first run is a deliberate one: ETX_TEST_WIDE_BVH=1 python -m pytest
-# tests/test_gpu_wide_bvh.py -m gpu (tools/gpu_calls of the next round); after it this switch goes away.
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("ETX_TEST_WIDE_BVH", "") != "1",
-                                                   reason="eight-wide tree: first device run pending (opt-in code path; set ETX_TEST_WIDE_BVH=1 to run)")]
+pytestmark = pytest.mark.gpu
 
 
 def contexts(etx, snap):

@@ -86,3 +86,39 @@ def test_where_the_correlation_sits():
     assert 1.5e-3 < red["extra draws"] < 3.5e-3
     assert abs(red["shared first vertex"]) < 5.0e-4
     assert distance(load("full", "cornell_%s_128_vcm_4096_shared_first_vertex.npz"), rekeyed)[0] < 8.0e-4  # two independent 4096-spp films of this scene: 6e-4
+
+
+def test_opaque_none_pins_the_unmodified_reference(tmp_path):
+    """ETX_ORACLE_BVH_DRAWS=opaque_none (oracle/shims/raytracing_bvh.cxx): the candidate draws of triangles that can never fail the alpha test
+    (opacity 1, no alpha image) are taken from a scratch copy of the sampler, so the path's stream no longer depends on how many candidates a
+    query met. The UNMODIFIED integrator (shared light / camera seeds) then renders THE SAME film under every traversal order - the pin the
+    traversal boundary did not have - while without the mode the orders differ sample by sample. Live run of oracle/_ref
+    (built by __graft_entry__.build() where /root/reference exists); 128 x 128, 4 iterations of the fog box."""
+    import subprocess
+    import sys
+    import pytest
+    root = os.path.dirname(HERE)
+    oracle = os.path.join(root, "oracle", "_ref", "etx_oracle")
+    if not os.path.exists(oracle):
+        pytest.skip("oracle/_ref/etx_oracle is not built here")
+    sys.path.insert(0, root)
+    from tools import film_io
+
+    def render(order, draws):
+        out = str(tmp_path / ("film_%s_%s.raw" % (order, draws or "asis")))
+        env = dict(os.environ, ETX_ORACLE_BVH_ORDER=order)
+        if draws:
+            env["ETX_ORACLE_BVH_DRAWS"] = draws
+        subprocess.check_call([oracle, "--load-snapshot", os.path.join(HERE, "golden", "cornell_full_128.etxscene"), "--integrator", "vcm", "--spp", "4", "--out", out,
+                               "--opt", "vcm-blue_noise=false"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+        film = film_io.read_film(out)
+        return film["camera"][..., :3].astype(np.float64) + film["light"][..., :3].astype(np.float64)
+
+    pinned = {order: render(order, "opaque_none") for order in ORDERS}
+    for order in ("far_first", "random_child"):
+        # the light image is added with float atomics by several threads: the last bit may differ, nothing else
+        np.testing.assert_allclose(pinned[order], pinned["near_first"], rtol=0.0, atol=2.0e-6)
+    as_is = {order: render(order, None) for order in ("near_first", "far_first")}
+    assert np.abs(as_is["far_first"] - as_is["near_first"]).max() > 0.1  # other streams: the films differ pixel by pixel
+    # same estimator either way: the pinned film is one more member of the family, not another image
+    assert abs(pinned["near_first"].mean() / as_is["near_first"].mean() - 1.0) < 0.02

@@ -1,5 +1,5 @@
 #!/bin/bash
-# DRAFT for the first GPU call of the next round (written at the end of round 3, never run): the code that has not executed on a device yet.
+# First GPU call of round 4: the code that has not executed on a device yet.
 #   1. the eight-wide tree (csrc/dev_bvh8.h): its tests under their own timeout, so that a fault in a never-run kernel costs this step only
 #   2. the 4096 / 1024-spp subsurface mesh cases (default tree) that were added after the last GPU minute
 #   3. A/B of the two trees on the tree-bound workloads
