@@ -61,6 +61,16 @@ def cpu_baseline(snapshot_path, width, height, seconds_budget=25.0, integrator="
     }
 
 
+def library_sha16():
+    import hashlib
+    from etx_tracer_amd import api
+    try:
+        with open(api.library_path(), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def main(argv=None, context_factory=None, backend="nccl"):
     """`context_factory` / `backend`: the CPU test of the N > 1 control flow (tests/test_multi_gpu_gloo.py) runs this function in two
     gloo processes with a stand-in for api.Context; the driver's command line uses neither."""
@@ -124,6 +134,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
     width, height = snap.film_size
     ctx = (context_factory or api.Context)(local_rank)
     ctx.set_bvh_builder({"device": api.BVH_DEVICE_LBVH, "wide": api.BVH_HOST_SAH | api.BVH_WIDE}.get(args.bvh, api.BVH_HOST_SAH))
+    lanes = ctx.lanes(api.INTEGRATOR_BDPT if bdpt_workload else api.INTEGRATOR_VCM)  # iterations in flight (etx_hip_lanes)
     upload_t0 = time.perf_counter()
     ctx.upload_scene(snap)
     upload_seconds = time.perf_counter() - upload_t0
@@ -244,8 +255,8 @@ def main(argv=None, context_factory=None, backend="nccl"):
 
     kernels = None
     if (rank == 0) and bdpt_workload:
-        kernels = kernel_table(acc["stats"], args.steps, "all kernel groups timed in the timed region itself (HIP events on the launch streams, %s iterations in flight): times include each "
-                               "launch's dispatch and the sharing of the CUs with the other lanes' kernels" % os.environ.get("ETX_HIP_LANES", "4"))
+        kernels = kernel_table(acc["stats"], args.steps, "all kernel groups timed in the timed region itself (HIP events on the launch streams, %d iterations in flight): times include each "
+                               "launch's dispatch and the sharing of the CUs with the other lanes' kernels" % lanes)
     elif (rank == 0) and (args.no_kernel_table == False):
         ctx.set_timers(0xff)
         begin(0, 1)
@@ -255,53 +266,32 @@ def main(argv=None, context_factory=None, backend="nccl"):
         ctx.sync()
         s = ctx.stats()
         ctx.set_timers(0x3)
-        kernels = kernel_table(s, groups_steps, "%d extra steps with all kernel groups timed (HIP events on the launch streams, %s iterations in flight): times include each launch's dispatch and the "
-                               "sharing of the CUs with the other lanes' kernels; rocprofv3 per-kernel times of the same command are in profiles/round2_bench_full_1080p_kernel_stats.csv" %
-                               (groups_steps, os.environ.get("ETX_HIP_LANES", "4")))
+        kernels = kernel_table(s, groups_steps, "%d extra steps with all kernel groups timed (HIP events on the launch streams, %d iterations in flight): times include each launch's dispatch and the "
+                               "sharing of the CUs with the other lanes' kernels" % (groups_steps, lanes))
 
-    # PMC figures (collected in separate rocprofv3 --pmc passes): HBM bytes per ray of the traversal kernel (FETCH_SIZE doubled as
-    # MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; profiles/round1_pmc_summary.json, the kernel's traffic has not
-    # changed since) and, per kernel of a one-lane run of this command, what the waves spend their cycles on
-    # (profiles/round2_pmc_summary.json, tools/profile_round.sh + tools/pmc_aggregate.py)
-    pmc = None
-    pmc_path = os.path.join(ROOT, "profiles", "round1_pmc_summary.json")
-    if os.path.exists(pmc_path):
-        with open(pmc_path) as f:
-            pmc = json.load(f)
-    pmc2 = None
-    pmc2_path = os.path.join(ROOT, "profiles", "round2_pmc_summary.json")
-    if os.path.exists(pmc2_path):
-        with open(pmc2_path) as f:
-            pmc2 = json.load(f)
-    if (kernels is not None) and (pmc2 is not None) and (bdpt_workload == False):
-        members = {"trace_closest": ["k_trace_closest<true, true>"], "trace_shadow": ["k_trace_shadow<true>"], "shade_light": ["k_light_shade<0u, false>", "k_path_tail<false, 0u>"],
-                   "shade_camera": ["k_camera_shade<0u, false>", "k_path_tail<true, 0u>"], "connect": ["k_expand_pairs", "k_connect_pairs<true>"],
-                   "merge": ["k_merge_diffuse", "k_merge_count", "k_merge_scatter", "k_merge_scan", "k_merge_scan_totals", "k_merge_clear"], "grid_build": ["k_grid_scatter", "k_grid_count", "k_grid_bbox"]}
-        profiled_iterations = max(1, pmc2.get("k_camera_generate", {}).get("launches", 1))
-        for group, names in members.items():
-            rows = [pmc2[n] for n in names if n in pmc2]
-            if not rows:
-                continue
-            main = rows[0]
-            wave_cycles = sum(r.get("SQ_WAVE_CYCLES_sum", 0.0) for r in rows)
-            kernels[group]["counters_1lane"] = {
-                "kernel": names[0],
-                # wave-level VALU instructions x 64 lanes per unit of work: what a unit costs when every lane of its wave is busy
-                "valu_lane_instructions_per_unit": round(sum(r.get("SQ_INSTS_VALU_sum", 0.0) for r in rows) * 64.0 / profiled_iterations / max(kernels[group]["units_per_step"], 1), 1),
-                "waves_waiting_share": round(sum(r.get("SQ_WAIT_ANY_sum", 0.0) for r in rows) / wave_cycles, 3) if wave_cycles else None,
-                "waves_issuing_share": round(sum(r.get("SQ_ACTIVE_INST_ANY_sum", 0.0) for r in rows) / wave_cycles, 3) if wave_cycles else None,
-                "l2_hit_rate": main.get("l2_hit_rate"), "occupancy_percent_mean": main.get("OccupancyPercent_mean"), "valu_busy_percent_mean": main.get("VALUBusy_mean"),
-            }
+    # Counters of the one-lane rocprofv3 --pmc passes of THIS workload (tools/profile_round.sh -> profiles/round*_pmc_<workload>_1lane_summary.json):
+    # the newest committed summary that names this workload; a group's figures come from the rows whose kernel names match it and are divided
+    # by the units of work of the profiled run itself; whatever is not in the file is null (tools/profile_lookup.py).
+    from tools import profile_lookup
+    pmc_path, pmc = profile_lookup.summary_for(args.workload)
+    pmc_groups = profile_lookup.BDPT_GROUPS if bdpt_workload else profile_lookup.VCM_GROUPS
+    pmc_source = os.path.relpath(pmc_path, ROOT) if pmc_path else None
+    if kernels is not None:
+        for group, prefixes in pmc_groups.items():
+            if group in kernels:
+                kernels[group]["counters_1lane"] = profile_lookup.group_counters(pmc, prefixes, profile_lookup.GROUP_UNITS[group])
+        kernels["counters_1lane_source"] = pmc_source
 
     dominant = None
     if kernels is not None:
-        name = max((k for k in kernels if k != "note"), key=lambda k: kernels[k]["share"] or 0.0)
+        name = max((k for k in kernels if isinstance(kernels[k], dict)), key=lambda k: kernels[k]["share"] or 0.0)
         dominant = dict(kernels[name], group=name, note="the kernel group with the largest share of the device time of an iteration; `bound` = the HBM roofline the contract asks for. "
                         "The group is not bandwidth-bound: its waves wait on dependent gathers and divergent branches (counters_1lane; DESIGN.md 3)")
     if rank == 0:
         samples = float(width) * height * args.steps * world
         value = samples / elapsed / 1.0e6
         achieved = (acc["rays"] * BYTES_PER_RAY / 1.0e9) / (acc["trace_ms"] * 1.0e-3) if acc["trace_ms"] > 0 else 0.0
+        trace_pmc = profile_lookup.group_counters(pmc, pmc_groups["trace_closest"], "rays_extension")
         line = {
             "metric": "Msamples/s (pixels x spp / s), %s" % ("BDPT" if bdpt_workload else "VCM"),
             "value": round(value, 4),
@@ -329,6 +319,8 @@ def main(argv=None, context_factory=None, backend="nccl"):
                 "samples_per_step": width * height,
                 "parallelism": "iteration-sharded x%d, one RCCL film all-reduce at the end" % world,
                 "working_set_gb": round(ctx.device_bytes() / 1.0e9, 2),  # queues, pools, grid and film of all lanes (etx_hip_device_bytes)
+                "pool_grows": int(acc["stats"].pool_grows),  # iterations of the timed region that overflowed a pool and were rendered again (0 once the pools have their size)
+                "lanes": lanes, "workload_key": args.workload, "library_sha16": library_sha16(),
             },
             "roofline": {
                 "kernel": ("k_trace_closest_bvh (ray queue -> hit queue; BVH4, top levels staged in LDS, persistent workgroups)" if spectral_workload
@@ -338,14 +330,16 @@ def main(argv=None, context_factory=None, backend="nccl"):
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": (round(pmc["trace_closest"]["hbm_bytes_per_ray"] * acc["rays"] / max(acc["launches"], 1)) if pmc else None),
-                "traffic_note": ("HBM bytes per average launch = PMC bytes per ray (%.3f B: FETCH_SIZE x 2 + WRITE_SIZE, measured on the kernel alone at 2 073 600 rays "
-                                 "per launch, profiles/round1_pmc_summary.json) x rays per launch of the timed region; algorithmic 48 B per ray" % pmc["trace_closest"]["hbm_bytes_per_ray"]) if pmc else None,
+                "traffic": (round(trace_pmc["hbm_bytes_per_unit"] * acc["rays"] / max(acc["launches"], 1)) if trace_pmc and trace_pmc["hbm_bytes_per_unit"] else None),
+                "traffic_note": ("HBM bytes per average launch = PMC bytes per ray of the traversal kernel INSIDE a one-lane run of this pipeline (%s B: FETCH_SIZE x 2 + WRITE_SIZE of %s, %s) "
+                                 "x rays per launch of the timed region; algorithmic 48 B per ray" % (trace_pmc["hbm_bytes_per_unit"], ", ".join(trace_pmc["kernels"]), pmc_source))
+                                if trace_pmc and trace_pmc["hbm_bytes_per_unit"] else "no committed PMC summary of this workload names the traversal kernel of this build",
                 "bytes_per_ray": BYTES_PER_RAY,
                 "rays": acc["rays"],
                 "launches": acc["launches"],
                 "avg_launch_ms": round(acc["trace_ms"] / max(acc["launches"], 1), 6),
-                "note": "algorithmic bytes = rays x 48 B summed over the timed region / summed HIP-event time of the trace launches (rank 0). "
+                "note": "algorithmic bytes = rays x 48 B summed over the timed region / summed HIP-event time of the trace launches (rank 0); rays include the "
+                        "queries the kernel runs beyond medium boundaries it crosses itself (counters.boundary_crossings_per_sample). "
                         "The timed region overlaps several iterations on separate streams (ETX_HIP_LANES), so a launch shares the CUs with "
                         "other kernels; `isolated` is the same kernel alone",
                 "isolated": isolated,
@@ -359,31 +353,23 @@ def main(argv=None, context_factory=None, backend="nccl"):
                 "boundary_crossings_per_sample": round(acc["stats"].boundary_crossings / (float(width) * height * args.steps), 3),
                 "photons_examined_per_sample": round(acc["examined"] / (float(width) * height * args.steps), 2),
                 "finite": finite,
+                # per step, the units the per-kernel figures are divided by (tools/profile_round.sh copies them into its PMC summary)
+                "units_per_step": {k: round(getattr(acc["stats"], k) / args.steps) for k in ("rays_extension", "rays_shadow", "rays_light", "rays_camera", "pairs", "photons_examined",
+                                                                                             "light_vertices", "camera_vertices", "boundary_crossings")},
             },
         }
         if bdpt_workload and (dominant is not None):
             # configs[3-4]: the roofline kernel is the group that dominates the step (HIP events of the timed region itself).
             # traffic = HBM bytes per step of that group's kernels from the separate rocprofv3 --pmc passes of this command on one lane
             # (tools/profile_round.sh: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; KiB -> bytes)
-            group_kernels = {"trace_closest": ("k_trace_closest",), "trace_shadow": ("k_trace_shadow",),
-                             "shade_light": ("k_bdpt_light_shade", "k_bdpt_walk_light", "k_bdpt_walk_exit_light", "k_bdpt_connect_camera"),
-                             "shade_camera": ("k_bdpt_camera_shade", "k_bdpt_walk_camera", "k_bdpt_walk_exit_camera", "k_bdpt_connect_light"),
-                             "connect": ("k_expand_pairs", "k_bdpt_connect_pairs")}
-            traffic = None
-            pmc3_path = os.path.join(ROOT, "profiles", "round3_pmc_%s_1lane_summary.json" % args.workload)
-            if os.path.exists(pmc3_path):
-                with open(pmc3_path) as f:
-                    pmc3 = json.load(f)
-                iterations = max(1, max((row.get("launches", 0) for name, row in pmc3.items() if "k_bdpt_camera_generate" in name), default=1))
-                rows = [row for name, row in pmc3.items() if any(k in name for k in group_kernels[dominant["group"]])]
-                if rows and all(("FETCH_SIZE_sum" in r) and ("WRITE_SIZE_sum" in r) for r in rows):
-                    traffic = round(sum(2.0 * r["FETCH_SIZE_sum"] + r["WRITE_SIZE_sum"] for r in rows) * 1024.0 / iterations)
+            group_pmc = (dominant.get("counters_1lane") or {})
+            traffic = group_pmc.get("hbm_bytes_per_step")
             line["roofline"] = {"kernel": dominant["group"] + ": " + dominant["bytes"], "bound": "hbm", "achieved": dominant["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": dominant["frac"], "traffic": traffic, "algorithmic_bytes_per_step": round(dominant["achieved"] * 1.0e9 * dominant["ms_per_step"] * 1.0e-3),
                                 "units_per_step": dominant["units_per_step"], "unit_of_work": dominant["unit"], "ms_per_step": dominant["ms_per_step"],
                                 "share_of_step": dominant["share"],
                                 "note": "algorithmic bytes of the dominant kernel group (DESIGN.md 3) / summed HIP-event time of its launches in the timed region, rank 0; "
-                                        "traffic = HBM bytes per step of the group's kernels (profiles/round3_pmc_%s_1lane_summary.json, one-lane PMC passes)" % args.workload}
+                                        "traffic = HBM bytes per step of the group's kernels in the one-lane PMC passes (%s)" % pmc_source}
         # (gems1m is assembled in memory and has no file to hand to the reference's driver; the subsurface scene is written out for it)
         if args.no_cpu_baseline or (world > 1) or (args.workload == "gems1m"):
             line["cpu_baseline"] = None

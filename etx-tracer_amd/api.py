@@ -26,7 +26,7 @@ BVH_WIDE = 256  # | BVH_HOST_SAH: also the eight-wide tree with 8-bit child boxe
 EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene", "etx_hip_update_scene",
     "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_upload_rgb_response", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
-    "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_checkpoint_bytes", "etx_hip_checkpoint_save", "etx_hip_checkpoint_load", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_set_debug_flags", "etx_hip_set_pool_policy", "etx_hip_device_bytes", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
+    "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_checkpoint_bytes", "etx_hip_checkpoint_save", "etx_hip_checkpoint_load", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_set_debug_flags", "etx_hip_set_pool_policy", "etx_hip_lanes", "etx_hip_device_bytes", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
     "etx_hip_set_bvh_builder", "etx_hip_bvh_info", "etx_hip_selftest_stack", "etx_hip_host_check_bvh_builder", "etx_hip_host_bvh_stats_builder", "etx_hip_host_bvh_study", "etx_hip_host_bvh8_stats",
 )
@@ -189,6 +189,8 @@ class Library:
         L.etx_hip_set_timers.argtypes = [vp, u32]
         L.etx_hip_set_debug_flags.argtypes = [vp, u32]
         L.etx_hip_set_pool_policy.argtypes = [vp, u32, sz]
+        L.etx_hip_lanes.argtypes = [vp, ctypes.c_int]
+        L.etx_hip_lanes.restype = u32
         L.etx_hip_device_bytes.argtypes = [vp]
         L.etx_hip_device_bytes.restype = ctypes.c_size_t
         L.etx_hip_comm_unique_id.argtypes = [vp]
@@ -303,6 +305,10 @@ class Context:
 
     def render_iteration(self):
         self._check(self.library.lib.etx_hip_render_iteration(self.handle))
+
+    def lanes(self, integrator=INTEGRATOR_VCM):
+        """Iterations in flight under that integrator (etx_hip_lanes)."""
+        return int(self.library.lib.etx_hip_lanes(self.handle, int(integrator)))
 
     def device_bytes(self):
         """Device memory of the lanes' working sets in bytes (etx_hip_device_bytes)."""

@@ -229,12 +229,12 @@ constexpr uint32_t kPoolRecordLimit = 1u << 30;
 // What the pools start with. The reference grows a std::vector of light vertices under a mutex (vcm_cpu.cxx:131-171); measured at 1080p the
 // bench scenes store 2.9-3.8 vertices per light path (fog box 3.8, classic 3.5, gems 3.4, density-grid box 2.9), the subsurface scene of
 // configs[3] 9.7 (one per scattering event of a walk). Round 3 sized for 16 / 64 per path and for sixteen pairs per camera vertex of a
-// bounce - 9.2 GB per lane on a 44-triangle box, 185 GB for configs[3] on six lanes. Now: 6 (16 with subsurface materials) per path,
+// bounce - 9.2 GB per lane on a 44-triangle box, 185 GB for configs[3] on six lanes. Now: 5 (16 with subsurface materials) per path,
 // as many pairs per bounce, and whatever a scene needs beyond that is found by the overflow / retry path.
 etx_hip_context::PoolSizes initial_pool_sizes(const etx_hip_context* pub, uint32_t n) {
   etx_hip_context::PoolSizes sizes;
   const bool sss = pub->scene.has_subsurface;
-  uint32_t per_path = sss ? 16u : 6u;
+  uint32_t per_path = sss ? 16u : 5u;
   if (pub->pool_initial_per_path != 0u)
     per_path = pub->pool_initial_per_path;
   sizes.light_vertices = uint32_t(std::min<uint64_t>(uint64_t(n) * per_path, kPoolRecordLimit));
@@ -1258,6 +1258,10 @@ int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, c
   HIP_OK(context, hipDeviceSynchronize());
   context->scene_ready = true;
   return ETX_HIP_OK;
+}
+
+uint32_t etx_hip_lanes(const etx_hip_context* context, int integrator) {
+  return (context == nullptr) ? 0u : lanes_for_integrator(context, integrator);
 }
 
 int etx_hip_set_pool_policy(etx_hip_context* context, uint32_t initial_light_vertices_per_path, size_t max_pool_bytes_per_lane) {

@@ -257,13 +257,17 @@ int etx_hip_stats(etx_hip_context* context, etx_hip_stats_t* out_stats, size_t s
 int etx_hip_set_debug_flags(etx_hip_context* context, uint32_t flags);
 
 /* The device pools whose fill depends on the scene and on the sample (light vertices and the photon grid built over them, camera vertices,
- * connection pairs, shadow and endpoint queues) start at what typical paths need - six stored light vertices per path, sixteen in scenes
+ * connection pairs, shadow and endpoint queues) start at what typical paths need - five stored light vertices per path, sixteen in scenes
  * with subsurface materials - and grow on demand: an iteration that overflows a pool is discarded before it reaches the film, the pool is
  * doubled for all lanes and the same iteration is rendered again (etx_hip_stats_t::pool_grows counts these). The reference grows a
  * std::vector under a mutex at the same place (vcm_cpu.cxx:131-171). This call sets, for the NEXT etx_hip_upload_scene / _update_scene:
  * the light vertices per path the pools start with (0 = the default) and the bytes one lane's pools may grow to (0 = no limit but the
  * device's memory); beyond the limit an overflow fails the iteration with ETX_HIP_ERROR_OVERFLOW, as a failed allocation would. */
 int etx_hip_set_pool_policy(etx_hip_context* context, uint32_t initial_light_vertices_per_path, size_t max_pool_bytes_per_lane);
+
+/* Iterations the context keeps in flight (device lanes) under the given integrator: what ETX_HIP_LANES set, else four, six for the
+ * bidirectional integrator. */
+uint32_t etx_hip_lanes(const etx_hip_context* context, int integrator);
 
 /* Device memory of the per-iteration working sets (queues, vertex pools, photon grid, film) of all lanes, in bytes: what a render of
  * the uploaded scene with the integrators used so far holds besides the scene itself. The photon grid of a lane exists from the first

@@ -55,6 +55,9 @@ class StubContext:
     def device_bytes(self):
         return 0
 
+    def lanes(self, integrator=1):
+        return 4
+
     def set_timers(self, mask):
         self.calls.append(("set_timers", mask))
 

@@ -7,6 +7,11 @@ mkdir -p $O
 export TMPDIR=/tmp
 timeout 500 python -m pytest tests/test_gpu_parity_hi.py -q -m gpu -s -k "blue_noise_at_4096 or shared_streams" > $O/hi_tests.log 2>&1
 echo "hi tests rc=$?" >> $O/log.txt
+timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -s -k "pool" > $O/pool_tests.log 2>&1
+echo "pool tests rc=$?" >> $O/log.txt
+for w in full sssdragon_bdpt cloud_bdpt; do
+  timeout 300 python bench.py --workload $w --steps 16 --warmup 4 --no-cpu-baseline --no-kernel-table 2>$O/bench_$w.err | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w', d['value'], 'Msamples/s, working set', d['config']['working_set_gb'], 'GB')" >> $O/log.txt
+done
 S=tests/golden/cornell_gems_1080p.etxscene
 run() { # label env... -- tree
   label=$1; shift
@@ -32,5 +37,5 @@ for b in 1024 1536; do
   v=$(ETX_HIP_LIBRARY=$V/libetx_hip_dbg.so ETX_HIP_DEBUG_BLOCKS=$b timeout 300 python bench.py --workload sssdragon_bdpt --bvh wide --steps 16 --warmup 4 --no-cpu-baseline --no-kernel-table 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'])")
   echo "sssdragon_bdpt wide blocks $b: $v" >> $O/sweep.txt
 done
-tail -n 25 $O/hi_tests.log
+tail -n 25 $O/hi_tests.log; tail -n 5 $O/pool_tests.log
 cat $O/log.txt $O/sweep.txt

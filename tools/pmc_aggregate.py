@@ -28,6 +28,23 @@ def short_name(name):
 
 
 def main():
+    # --meta <file>: a log of the profiled command whose last JSON line is bench.py's; its workload, step counts and units of work per step go
+    # into the summary (`_meta`) so that readers (tools/profile_lookup.py, bench.py) divide these counters by THIS run's units, not another's
+    meta = None
+    if "--meta" in sys.argv:
+        i = sys.argv.index("--meta")
+        meta_path = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
+        line = None
+        with open(meta_path) as f:
+            for text in f:
+                text = text.strip()
+                if text.startswith("{") and '"metric"' in text:
+                    line = json.loads(text)
+        if line is not None:
+            meta = {"workload": line.get("config", {}).get("workload_key"), "iterations": int(line["steps"]) + int(line["warmup"]), "lanes": line.get("config", {}).get("lanes"),
+                    "units_per_step": line.get("counters", {}).get("units_per_step", {}), "ms_per_step": line.get("ms_per_step"), "value": line.get("value"),
+                    "library_sha16": line.get("config", {}).get("library_sha16")}
     out_path, paths = sys.argv[1], sys.argv[2:]
     table = defaultdict(lambda: defaultdict(float))
     passes = defaultdict(set)  # counter -> the passes that collected it (a counter listed in two passes is averaged, not added)
@@ -78,8 +95,11 @@ def main():
     total = sum(r["duration_us_sum"] for r in result.values())
     for r in result.values():
         r["time_share"] = round(r["duration_us_sum"] / total, 4) if total else 0.0
+    ordered = dict(sorted(result.items(), key=lambda kv: -kv[1]["duration_us_sum"]))
+    if meta is not None:
+        ordered = dict([("_meta", meta)] + list(ordered.items()))
     with open(out_path, "w") as f:
-        json.dump(dict(sorted(result.items(), key=lambda kv: -kv[1]["duration_us_sum"])), f, indent=1)
+        json.dump(ordered, f, indent=1)
     for k, r in sorted(result.items(), key=lambda kv: -kv[1]["duration_us_sum"])[:14]:
         print("%-44s %5.1f%% " % (k[:44], 100.0 * r["time_share"]), {a: b for a, b in r.items() if a.endswith(("share", "rate", "mean")) or (len(sys.argv) > 8 and a.endswith("_sum"))})
 

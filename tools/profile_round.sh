@@ -23,7 +23,7 @@ pass lds LDSBankConflict MemUnitBusy
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 cd $root
-python3 tools/pmc_aggregate.py $out/pmc_summary.json $(find $out -name "*counter_collection.csv" | sort) > $out/pmc_summary.txt 2>&1
+python3 tools/pmc_aggregate.py --meta $out/pmc_fetch.log $out/pmc_summary.json $(find $out -name "*counter_collection.csv" | sort) > $out/pmc_summary.txt 2>&1
 find $out -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
 # the raw per-dispatch rows are large: keep the per-kernel aggregate, the kernel statistics and the two HBM passes
 find $out -name "*kernel_trace.csv" -delete
