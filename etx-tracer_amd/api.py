@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = (
     "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_upload_rgb_response", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
     "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_checkpoint_bytes", "etx_hip_checkpoint_save", "etx_hip_checkpoint_load", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_set_debug_flags", "etx_hip_set_pool_policy", "etx_hip_lanes", "etx_hip_device_bytes", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
-    "etx_hip_set_bvh_builder", "etx_hip_bvh_info", "etx_hip_selftest_stack", "etx_hip_host_check_bvh_builder", "etx_hip_host_bvh_stats_builder", "etx_hip_host_bvh_study", "etx_hip_host_bvh8_stats",
+    "etx_hip_set_bvh_builder", "etx_hip_bvh_info", "etx_hip_selftest_stack", "etx_hip_host_check_bvh_builder", "etx_hip_host_bvh_stats_builder", "etx_hip_host_bvh8_stats",
 )
 
 
@@ -206,7 +206,6 @@ class Library:
         L.etx_hip_bvh_info.argtypes = [vp, ctypes.POINTER(u32 * 4), ctypes.POINTER(ctypes.c_double)]
         L.etx_hip_host_check_bvh_builder.argtypes = [vp, i32, ctypes.POINTER(u32 * 4)]
         L.etx_hip_host_bvh_stats_builder.argtypes = [vp, i32, vp, u64, ctypes.POINTER(u64 * 4), vp]
-        L.etx_hip_host_bvh_study.argtypes = [vp, u32, i32, i32, vp, u64, ctypes.POINTER(u64 * 8), vp]
         L.etx_hip_host_bvh8_stats.argtypes = [vp, i32, vp, u64, ctypes.POINTER(u64 * 8), vp]
 
     @classmethod
@@ -416,23 +415,6 @@ def host_bvh_stats(snapshot, rays, library=None, builder=BVH_HOST_SAH, with_hits
     hits = np.zeros((rays.shape[0], 2), dtype=np.float32) if with_hits else None
     rc = library.lib.etx_hip_host_bvh_stats_builder(snapshot.scene_address, int(builder), rays.ctypes.data, rays.shape[0], ctypes.byref(out), hits.ctypes.data if with_hits else None)
     result = {"node_visits": out[0], "triangle_tests": out[1], "hits": out[2], "max_stack": out[3]}
-    if with_hits:
-        triangle = hits[:, 1].view(np.uint32).astype(np.int64)
-        triangle[triangle == 0xFFFFFFFF] = -1
-        result["t"], result["triangle"] = hits[:, 0].copy(), triangle
-    return rc, result
-
-
-def host_bvh_study(snapshot, rays, width=4, quantised=False, sorted_pushes=True, library=None, with_hits=False):
-    """Host-only design study (etx_hip_host_bvh_study): what `rays` cost in a tree of `width` children per node, boxes exact or 8-bit."""
-    library = library or Library.get()
-    rays = np.ascontiguousarray(rays, dtype=np.float32)
-    out = (ctypes.c_uint64 * 8)()
-    hits = np.zeros((rays.shape[0], 2), dtype=np.float32) if with_hits else None
-    rc = library.lib.etx_hip_host_bvh_study(snapshot.scene_address, int(width), int(bool(quantised)), int(bool(sorted_pushes)), rays.ctypes.data, rays.shape[0], ctypes.byref(out),
-                                            hits.ctypes.data if with_hits else None)
-    result = {"node_visits": out[0], "triangle_tests": out[1], "hits": out[2], "max_stack": out[3], "nodes": out[4], "levels": out[5], "visits_to_final_hit": out[6],
-              "max_visits_of_a_ray": out[7]}
     if with_hits:
         triangle = hits[:, 1].view(np.uint32).astype(np.int64)
         triangle[triangle == 0xFFFFFFFF] = -1

@@ -120,14 +120,12 @@ ETX_DEV EmitterSample sample_emitter(const DScene& s, uint32_t emitter_index, co
     case ETX_EMITTER_AREA: {
       const etx_abi_triangle& tri = s.triangles[em_inst.triangle_index];
       r.barycentric = random_barycentric(smp);
-      r.origin = lerp_pos(s, tri, r.barycentric);
-      r.normal = lerp_normal(s, tri, r.barycentric);
-      r.direction = normalize(r.origin - from_point);
       EmitterRadianceQuery q;
+      lerp_pos_normal_uv(s, tri, r.barycentric, r.origin, r.normal, q.uv);  // lerp_pos, lerp_normal, lerp_uv from the six rows they share
+      r.direction = normalize(r.origin - from_point);
       q.source_position = from_point;
       q.target_position = r.origin;
       q.direction = mk3(0.0f);
-      q.uv = lerp_uv(s, tri, r.barycentric);
       q.directly_visible = false;
       r.value = emitter_get_radiance(s, em_inst, q, r.pdf_area, r.pdf_dir, r.pdf_dir_out, wavelength);
       break;

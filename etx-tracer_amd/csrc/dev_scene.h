@@ -134,6 +134,7 @@ struct DScene {
   const etx_abi_vertex* vertices;
   const etx_abi_triangle* triangles;
   const uint32_t* triangle_to_emitter;
+  const float4* tri_shade;  // per triangle: kTriShadeStride 16-byte rows of everything a shading point reads of its triangle (k_build_tri_shade)
   const etx_abi_material* materials;
   const etx_abi_emitter_profile* emitter_profiles;
   const etx_abi_emitter* emitters;
@@ -354,6 +355,24 @@ struct Vtx {
   f2 tex;
 };
 
+// The shading record of a triangle (DScene::tri_shade, built on the device from the vertex / triangle tables whenever they are uploaded).
+// A gather costs the vector memory pipeline about one cycle per ACTIVE LANE whatever its width (tools/micro/gather_bench.hip: dword,
+// dwordx2 and dwordx4 loads at per-lane addresses all run at 0.5-0.9 lane-loads per clock and CU), and the shading kernels are bound by
+// exactly that: the reference's layout (three indices, then three 56-byte vertices read as 3-float pieces) costs a shading point 18 loads
+// and every later use of the triangle (the offset ray origins of the next segment and of each connection) 7 more. Here the same numbers sit
+// in thirteen aligned 16-byte rows:
+//   rows 0-2  position of vertex i, u of its texture coordinate       rows 3-5  normal of vertex i, v
+//   row  6    geometric normal, material index (bits)                 rows 7-9  tangents, rows 10-12 bitangents
+constexpr uint32_t kTriShadeStride = 13;
+#if !defined(ETX_TRI_CACHE)
+#define ETX_TRI_CACHE 1  // A/B switch (tools/build_variant.sh): 0 = the simple-group kernels read the rows again instead of keeping them (Isect::tv)
+#endif
+constexpr bool kTriCache = ETX_TRI_CACHE != 0;
+
+struct TriVerts {  // what shading_pos reads: kept with the intersection by the kernels that have the registers (simple shading group)
+  f3 p0, p1, p2, n0, n1, n2, geo_n;
+};
+
 struct Isect : public Vtx {
   f3 bc;
   uint32_t tri;
@@ -361,19 +380,39 @@ struct Isect : public Vtx {
   float t;
   uint32_t material;
   uint32_t emitter;
+  TriVerts tv;  // set by make_intersection; dead (and free) in kernels that never read it
 };
 
+ETX_DEV const float4* tri_rows(const DScene& s, const etx_abi_triangle& t) {
+  return s.tri_shade + size_t(&t - s.triangles) * kTriShadeStride;
+}
+ETX_DEV f3 xyz(const float4& v) {
+  return {v.x, v.y, v.z};
+}
+
+ETX_DEV TriVerts load_tri_verts(const DScene& s, const etx_abi_triangle& t) {
+  const float4* r = tri_rows(s, t);
+  return {xyz(r[0]), xyz(r[1]), xyz(r[2]), xyz(r[3]), xyz(r[4]), xyz(r[5]), xyz(r[6])};
+}
+
 // scene.hxx:90-112 lerp_vertex: interpolate, re-orthogonalise (Gram-Schmidt), keep bitangent handedness
-ETX_DEV Vtx lerp_vertex(const DScene& s, const etx_abi_triangle& t, const f3& bc) {
-  const etx_abi_vertex& v0 = s.vertices[t.i[0]];
-  const etx_abi_vertex& v1 = s.vertices[t.i[1]];
-  const etx_abi_vertex& v2 = s.vertices[t.i[2]];
+ETX_DEV Vtx lerp_vertex(const DScene& s, const etx_abi_triangle& t, const f3& bc, TriVerts* keep = nullptr, uint32_t* material = nullptr) {
+  const float4* r = tri_rows(s, t);
+  const float4 p0 = r[0], p1 = r[1], p2 = r[2], n0 = r[3], n1 = r[4], n2 = r[5];
+  const float4 t0 = r[7], t1 = r[8], t2 = r[9], b0 = r[10], b1 = r[11], b2 = r[12];
+  if ((keep != nullptr) || (material != nullptr)) {
+    const float4 g = r[6];
+    if (keep != nullptr)
+      *keep = {xyz(p0), xyz(p1), xyz(p2), xyz(n0), xyz(n1), xyz(n2), xyz(g)};
+    if (material != nullptr)
+      *material = __float_as_uint(g.w);
+  }
   Vtx v;
-  v.pos = ld3(v0.pos) * bc.x + ld3(v1.pos) * bc.y + ld3(v2.pos) * bc.z;
-  v.nrm = ld3(v0.nrm) * bc.x + ld3(v1.nrm) * bc.y + ld3(v2.nrm) * bc.z;
-  v.tan = ld3(v0.tan) * bc.x + ld3(v1.tan) * bc.y + ld3(v2.tan) * bc.z;
-  f3 b = ld3(v0.btn) * bc.x + ld3(v1.btn) * bc.y + ld3(v2.btn) * bc.z;
-  v.tex = {v0.tex.x * bc.x + v1.tex.x * bc.y + v2.tex.x * bc.z, v0.tex.y * bc.x + v1.tex.y * bc.y + v2.tex.y * bc.z};
+  v.pos = xyz(p0) * bc.x + xyz(p1) * bc.y + xyz(p2) * bc.z;
+  v.nrm = xyz(n0) * bc.x + xyz(n1) * bc.y + xyz(n2) * bc.z;
+  v.tan = xyz(t0) * bc.x + xyz(t1) * bc.y + xyz(t2) * bc.z;
+  f3 b = xyz(b0) * bc.x + xyz(b1) * bc.y + xyz(b2) * bc.z;
+  v.tex = {p0.w * bc.x + p1.w * bc.y + p2.w * bc.z, n0.w * bc.x + n1.w * bc.y + n2.w * bc.z};
   v.nrm = normalize(v.nrm);
   v.tan = normalize(v.tan - dot(v.tan, v.nrm) * v.nrm);
   f3 btn = cross(v.nrm, v.tan);
@@ -382,22 +421,30 @@ ETX_DEV Vtx lerp_vertex(const DScene& s, const etx_abi_triangle& t, const f3& bc
 }
 
 ETX_DEV f3 lerp_pos(const DScene& s, const etx_abi_triangle& t, const f3& bc) {  // scene.hxx:77-81
-  return ld3(s.vertices[t.i[0]].pos) * bc.x + ld3(s.vertices[t.i[1]].pos) * bc.y + ld3(s.vertices[t.i[2]].pos) * bc.z;
+  const float4* r = tri_rows(s, t);
+  return xyz(r[0]) * bc.x + xyz(r[1]) * bc.y + xyz(r[2]) * bc.z;
 }
 ETX_DEV f3 lerp_normal(const DScene& s, const etx_abi_triangle& t, const f3& bc) {  // scene.hxx:83-87
-  return normalize(ld3(s.vertices[t.i[0]].nrm) * bc.x + ld3(s.vertices[t.i[1]].nrm) * bc.y + ld3(s.vertices[t.i[2]].nrm) * bc.z);
+  const float4* r = tri_rows(s, t);
+  return normalize(xyz(r[3]) * bc.x + xyz(r[4]) * bc.y + xyz(r[5]) * bc.z);
 }
 ETX_DEV f2 lerp_uv(const DScene& s, const etx_abi_triangle& t, const f3& b) {  // scene.hxx:103-107
-  const etx_abi_float2& a = s.vertices[t.i[0]].tex;
-  const etx_abi_float2& bb = s.vertices[t.i[1]].tex;
-  const etx_abi_float2& c = s.vertices[t.i[2]].tex;
-  return {a.x * b.x + bb.x * b.y + c.x * b.z, a.y * b.x + bb.y * b.y + c.y * b.z};
+  const float4* r = tri_rows(s, t);
+  const float4 p0 = r[0], p1 = r[1], p2 = r[2], n0 = r[3], n1 = r[4], n2 = r[5];
+  return {p0.w * b.x + p1.w * b.y + p2.w * b.z, n0.w * b.x + n1.w * b.y + n2.w * b.z};
+}
+// position, normal and texture coordinate of a point of a triangle from the six rows they share (area emitters: sample_emitter)
+ETX_DEV void lerp_pos_normal_uv(const DScene& s, const etx_abi_triangle& t, const f3& b, f3& pos, f3& nrm, f2& uv) {
+  const float4* r = tri_rows(s, t);
+  const float4 p0 = r[0], p1 = r[1], p2 = r[2], n0 = r[3], n1 = r[4], n2 = r[5];
+  pos = xyz(p0) * b.x + xyz(p1) * b.y + xyz(p2) * b.z;
+  nrm = normalize(xyz(n0) * b.x + xyz(n1) * b.y + xyz(n2) * b.z);
+  uv = {p0.w * b.x + p1.w * b.y + p2.w * b.z, n0.w * b.x + n1.w * b.y + n2.w * b.z};
 }
 
 // scene.hxx:172-186 shading_pos: Phong-tessellation style origin (avoids the shadow terminator), then offset_ray
-ETX_DEV f3 shading_pos(const DScene& s, const etx_abi_triangle& t, const f3& bc, const f3& w_o) {
-  f3 p0v = ld3(s.vertices[t.i[0]].pos), p1v = ld3(s.vertices[t.i[1]].pos), p2v = ld3(s.vertices[t.i[2]].pos);
-  f3 n0 = ld3(s.vertices[t.i[0]].nrm), n1 = ld3(s.vertices[t.i[1]].nrm), n2 = ld3(s.vertices[t.i[2]].nrm);
+ETX_DEV f3 shading_pos(const TriVerts& tv, const f3& bc, const f3& w_o) {
+  const f3 p0v = tv.p0, p1v = tv.p1, p2v = tv.p2, n0 = tv.n0, n1 = tv.n1, n2 = tv.n2;
   f3 geo_pos = p0v * bc.x + p1v * bc.y + p2v * bc.z;
   f3 sh_normal = normalize(n0 * bc.x + n1 * bc.y + n2 * bc.z);
   float direction = (dot(sh_normal, w_o) >= 0.0f) ? +1.0f : -1.0f;
@@ -407,7 +454,10 @@ ETX_DEV f3 shading_pos(const DScene& s, const etx_abi_triangle& t, const f3& bc,
   f3 p2 = geo_pos - dot(geo_pos - p2v, d2) * d2;
   f3 sh_pos = p0 * bc.x + p1 * bc.y + p2 * bc.z;
   bool convex = dot(sh_pos - geo_pos, sh_normal) * direction > 0.0f;
-  return offset_ray(convex ? sh_pos : geo_pos, ld3(t.geo_n) * direction);
+  return offset_ray(convex ? sh_pos : geo_pos, tv.geo_n * direction);
+}
+ETX_DEV f3 shading_pos(const DScene& s, const etx_abi_triangle& t, const f3& bc, const f3& w_o) {
+  return shading_pos(load_tri_verts(s, t), bc, w_o);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -549,12 +599,11 @@ ETX_DEV Isect make_intersection(const DScene& s, const f3& w_i, float u, float v
   f3 bc = barycentrics(u, v);
   const etx_abi_triangle& tri = s.triangles[tri_index];
   Isect r;
-  static_cast<Vtx&>(r) = lerp_vertex(s, tri, bc);
+  static_cast<Vtx&>(r) = lerp_vertex(s, tri, bc, &r.tv, &r.material);
   r.bc = bc;
   r.tri = tri_index;
   r.w_i = w_i;
   r.t = t;
-  r.material = tri.material_index;
   r.emitter = s.triangle_to_emitter[tri_index];
   const etx_abi_material& mat = s.materials[r.material];
   if ((mat.normal_image_index != kInvalid) && (mat.normal_scale > kEpsilon)) {
@@ -562,7 +611,7 @@ ETX_DEV Isect make_intersection(const DScene& s, const f3& w_i, float u, float v
     float sc = mat.normal_scale;
     f3 sn = {sc * (value.x * 2.0f - 1.0f), sc * (value.y * 2.0f - 1.0f), sc * (value.z * 2.0f - 1.0f) + (1.0f - sc)};
     r.nrm = normalize(r.tan * sn.x + r.btn * sn.y + r.nrm * sn.z);
-    r.nrm = orient_normals_to_hemisphere(r.nrm, ld3(tri.geo_n), w_i);
+    r.nrm = orient_normals_to_hemisphere(r.nrm, r.tv.geo_n, w_i);
     r.tan = normalize(r.tan - dot(r.tan, r.nrm) * r.nrm);
     r.btn = normalize(cross(r.nrm, r.tan));
   }

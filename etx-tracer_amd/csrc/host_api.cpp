@@ -1362,17 +1362,6 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
   }
   (void)wait_idle(context);  // iterations of the previous run
   const uint32_t lanes_wanted = lanes_for_integrator(context, integrator);
-  for (uint32_t i = 0; i + 1u < lanes_wanted; ++i) {
-    etx_hip_context* helper = context->helpers[i];
-    if (lane_ready(helper))
-      continue;
-    helper->scene.borrow(context->scene);
-    if (int rc = allocate_pipeline(helper)) {
-      context->error = helper->error;
-      release_pipeline(helper);
-      return rc;
-    }
-  }
   if (integrator == ETX_HIP_INTEGRATOR_VCM) {
     if ((options == nullptr) || (options_size != sizeof(etx_abi_vcm_options))) {
       context->error = "VCM expects etx_abi_vcm_options (32 bytes)";
@@ -1463,6 +1452,19 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
       return rc;
   }
   HIP_OK(context, hipSetDevice(context->device));
+  // the lanes this integrator uses beyond the base ones get their pools now - after every check above, so a refused begin leaves the
+  // working set as it was
+  for (uint32_t i = 0; i + 1u < lanes_wanted; ++i) {
+    etx_hip_context* helper = context->helpers[i];
+    if (lane_ready(helper))
+      continue;
+    helper->scene.borrow(context->scene);
+    if (int rc = allocate_pipeline(helper)) {
+      context->error = helper->error;
+      release_pipeline(helper);
+      return rc;
+    }
+  }
   context->integrator = integrator;
   context->first_iteration = first_iteration;
   context->iteration_stride = iteration_stride;
@@ -1480,7 +1482,8 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
   if (integrator == ETX_HIP_INTEGRATOR_VCM) {
     if (int rc = allocate_photon_grid(context))
       return rc;
-    for (etx_hip_context* helper : context->helpers) {
+    for (uint32_t i = 0; i + 1u < lanes_wanted; ++i) {  // the lanes VCM schedules, not the bidirectional integrator's extra ones
+      etx_hip_context* helper = context->helpers[i];
       if (lane_ready(helper) == false)
         continue;
       if (int rc = allocate_photon_grid(helper)) {
@@ -1728,7 +1731,7 @@ struct CheckpointHeader {
 };
 static_assert(sizeof(CheckpointHeader) == 64, "checkpoint header layout");
 constexpr uint32_t kCheckpointMagic = 0x43585445u;  // "ETXC"
-constexpr uint32_t kCheckpointVersion = 1u;
+constexpr uint32_t kCheckpointVersion = 2u;  // 2: scene_hash (a formerly reserved word) names the scene, hashed field by field (host_scene.cpp content_hash)
 
 // the named fields only: the padding of the by-value option structs is whatever the caller's stack held
 uint32_t options_hash(const etx_hip_context* c) {
@@ -1836,7 +1839,7 @@ int etx_hip_checkpoint_load(etx_hip_context* context, const void* src, size_t sr
   if (src_bytes >= sizeof(header))
     memcpy(&header, src, sizeof(header));
   if ((src_bytes < sizeof(header)) || (header.magic != kCheckpointMagic) || (header.version != kCheckpointVersion)) {
-    context->error = "etx_hip_checkpoint_load: not a checkpoint of this library version";
+    context->error = "etx_hip_checkpoint_load: not a checkpoint of this library version (expected version " + std::to_string(kCheckpointVersion) + ")";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
   const bool adaptive = context->pipe.pixel_state != nullptr;

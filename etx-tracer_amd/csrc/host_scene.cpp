@@ -1092,23 +1092,51 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   out.noise_threshold = scene->noise_threshold;
   {
     // what the scene IS, cheaply (a checkpoint names the scene it belongs to with this): the material and emitter tables, the scalar
-    // part of the media, up to 4096 evenly spaced vertices
+    // part of the media, up to 4096 evenly spaced vertices and triangles
     uint32_t h = 2166136261u;  // FNV-1a
     auto mix = [&h](const void* data, size_t size) {
       const uint8_t* b = static_cast<const uint8_t*>(data);
       for (size_t i = 0; i < size; ++i)
         h = (h ^ b[i]) * 16777619u;
     };
-    mix(scene->materials.a, scene->materials.count * sizeof(etx_abi_material));
-    mix(scene->emitter_instances.a, scene->emitter_instances.count * sizeof(etx_abi_emitter));
-    mix(scene->emitter_profiles.a, scene->emitter_profiles.count * sizeof(etx_abi_emitter_profile));
+    // field by field: the ABI structs carry explicit pad members and alignment padding whose bytes belong to nobody - a host
+    // that builds the same scene in another process may leave other values there, and a checkpoint must still find its scene
+    auto mix_u32 = [&mix](uint32_t v) { mix(&v, sizeof(v)); };
+    auto mix_f32 = [&mix](float v) { mix(&v, sizeof(v)); };
+    mix_u32(uint32_t(scene->materials.count)), mix_u32(uint32_t(scene->triangles.count)), mix_u32(uint32_t(scene->vertices.count));
+    for (uint64_t i = 0; i < scene->materials.count; ++i) {
+      const etx_abi_material& m = static_cast<const etx_abi_material*>(scene->materials.a)[i];
+      for (const etx_abi_spectral_image* si : {&m.reflectance, &m.scattering, &m.emission})
+        mix_u32(si->spectrum_index), mix_u32(si->image_index);
+      for (const etx_abi_sampled_image* si : {&m.roughness, &m.metalness, &m.transmission})
+        mix_f32(si->value.x), mix_f32(si->value.y), mix_f32(si->value.z), mix_f32(si->value.w), mix_u32(si->image_index), mix_u32(si->channel);
+      mix_u32(m.subsurface.cls);
+      mix_u32(m.cls), mix_u32(m.int_medium), mix_u32(m.ext_medium), mix_u32(m.normal_image_index), mix_u32(m.diffuse_variation), mix_u32(m.two_sided);
+      mix_f32(m.normal_scale), mix_f32(m.opacity), mix_f32(m.emission_collimation);
+    }
+    for (uint64_t i = 0; i < scene->emitter_instances.count; ++i) {
+      const etx_abi_emitter& e = static_cast<const etx_abi_emitter*>(scene->emitter_instances.a)[i];
+      mix_u32(e.cls), mix_u32(e.profile), mix_u32(e.triangle_index), mix_f32(e.spectrum_weight), mix_f32(e.additional_weight), mix_f32(e.triangle_area);
+    }
+    for (uint64_t i = 0; i < scene->emitter_profiles.count; ++i) {
+      const etx_abi_emitter_profile& e = static_cast<const etx_abi_emitter_profile*>(scene->emitter_profiles.a)[i];
+      mix_u32(e.emission.spectrum_index), mix_u32(e.emission.image_index), mix_f32(e.direction.x), mix_f32(e.direction.y), mix_f32(e.direction.z), mix_u32(e.cls);
+      mix_f32(e.angular_size), mix_f32(e.equivalent_disk_size), mix_f32(e.angular_size_cosine);
+    }
     for (uint64_t i = 0; i < scene->mediums.count; ++i) {
       const etx_abi_medium& m = static_cast<const etx_abi_medium*>(scene->mediums.a)[i];
-      mix(&m.bounds_min, sizeof(etx_abi_medium) - offsetof(etx_abi_medium, bounds_min));  // everything but the density pointer
+      mix_f32(m.bounds_min.x), mix_f32(m.bounds_min.y), mix_f32(m.bounds_min.z), mix_f32(m.bounds_max.x), mix_f32(m.bounds_max.y), mix_f32(m.bounds_max.z);
+      mix_u32(m.cls), mix_u32(m.enable_explicit_connections), mix_u32(m.absorption_index), mix_u32(m.scattering_index), mix_f32(m.phase_function_g), mix_f32(m.max_sigma);
+      mix_u32(m.dimensions.x), mix_u32(m.dimensions.y), mix_u32(m.dimensions.z);
     }
     const uint64_t step = std::max<uint64_t>(1u, scene->vertices.count / 4096u);
     for (uint64_t i = 0; i < scene->vertices.count; i += step)
-      mix(static_cast<const etx_abi_vertex*>(scene->vertices.a) + i, sizeof(etx_abi_vertex));
+      mix(static_cast<const etx_abi_vertex*>(scene->vertices.a) + i, sizeof(etx_abi_vertex));  // fourteen floats, no padding
+    const uint64_t tri_step = std::max<uint64_t>(1u, scene->triangles.count / 4096u);
+    for (uint64_t i = 0; i < scene->triangles.count; i += tri_step) {
+      const etx_abi_triangle& t = static_cast<const etx_abi_triangle*>(scene->triangles.a)[i];
+      mix_u32(t.i[0]), mix_u32(t.i[1]), mix_u32(t.i[2]), mix_u32(t.material_index);
+    }
     out.content_hash = h;
   }
   if ((camera->film_size.x == 0) || (camera->film_size.y == 0)) {
@@ -1229,13 +1257,31 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
               std::to_string(kept.triangle_count) + " / " + std::to_string(out.image_table.size()) + " / " + std::to_string(out.density_grids.size()) + "); use etx_hip_upload_scene";
       return ETX_HIP_ERROR_INVALID_ARGUMENT;
     }
-    d.vertices = kept.vertices, d.triangles = kept.triangles;
+    d.vertices = kept.vertices, d.triangles = kept.triangles, d.tri_shade = kept.tri_shade;
   } else {
     out.alloc_group = 1;
     if ((rc = upload(out, reinterpret_cast<const etx_abi_vertex*>(scene->vertices.a), scene->vertices.count, d.vertices, error)))
       return rc;
     if ((rc = upload(out, triangles, scene->triangles.count, d.triangles, error)))
       return rc;
+    // the shading records of the triangles (dev_scene.h kTriShadeStride): built on the device from the two tables just uploaded
+    {
+      void* rows = nullptr;
+      const size_t bytes = std::max<size_t>(scene->triangles.count, 1u) * kTriShadeStride * sizeof(float4);
+      if (hipMalloc(&rows, bytes) != hipSuccess) {
+        error = "hipMalloc failed (" + std::to_string(bytes) + " bytes)";
+        return ETX_HIP_ERROR_HIP;
+      }
+      out.geometry_allocations.push_back(rows);
+      d.tri_shade = static_cast<const float4*>(rows);
+      DScene tables = {};
+      tables.vertices = d.vertices, tables.triangles = d.triangles;
+      launch_build_tri_shade(nullptr, tables, static_cast<float4*>(rows), uint32_t(scene->triangles.count));
+      if ((hipGetLastError() != hipSuccess) || (hipStreamSynchronize(nullptr) != hipSuccess)) {
+        error = "building the triangles' shading records failed on the device";
+        return ETX_HIP_ERROR_HIP;
+      }
+    }
     out.alloc_group = 0;
   }
   if ((rc = upload(out, reinterpret_cast<const uint32_t*>(scene->triangle_to_emitter.a), scene->triangle_to_emitter.count, d.triangle_to_emitter, error)))
@@ -1442,7 +1488,7 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     if (keep) {
       std::vector<void*> retained;
       for (void* p : out.geometry_allocations) {
-        if ((p == kept.vertices) || (p == kept.triangles))
+        if ((p == kept.vertices) || (p == kept.triangles) || (p == kept.tri_shade))
           retained.push_back(p);
         else
           (void)hipFree(p);
@@ -1522,6 +1568,8 @@ int update_device_geometry(const etx_abi_scene* scene, DeviceScene& out, hipStre
     error = "hipMemcpy of the moved vertices failed";
     return ETX_HIP_ERROR_HIP;
   }
+  if (positions_moved)
+    launch_build_tri_shade(stream, d, const_cast<float4*>(d.tri_shade), d.triangle_count);
   // the eight-wide tree is a host product over the uploaded positions: moved vertices leave the four-wide tree (refit or rebuilt below) as
   // the only one until the next etx_hip_upload_scene
   if (positions_moved || rebuild)

@@ -13,6 +13,10 @@ namespace etxd {
 // the slot -> triangle assignment (v0_index.w) is kept. After vertex positions or material classes changed.
 void launch_bvh_triangles_update(hipStream_t stream, const DScene& scene, BvhTri* tris, uint32_t count);
 
+// The shading records (DScene::tri_shade, dev_scene.h kTriShadeStride rows per triangle) from the scene's vertex and triangle tables: after every
+// upload of those tables.
+void launch_build_tri_shade(hipStream_t stream, const DScene& scene, float4* rows, uint32_t triangle_count);
+
 // One breadth-first level [first, first + count) of the BVH4: every node's four child boxes recomputed from the leaves' triangles
 // (original vertices) or from the child node's boxes, and the stack bound of its subtree (pad[0]). Levels are refit from the
 // deepest to the root.

@@ -28,6 +28,23 @@ __global__ __launch_bounds__(kBuildBlock) void k_bvh_triangles_update(DScene sce
     bvh_triangle_update(scene, tris, slot);
 }
 
+// one thread per triangle: three gathered vertices in, thirteen 16-byte rows out (dev_scene.h: the layout and why)
+__global__ __launch_bounds__(kBuildBlock) void k_build_tri_shade(DScene scene, float4* rows, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count)
+    return;
+  const etx_abi_triangle& t = scene.triangles[i];
+  float4* r = rows + size_t(i) * kTriShadeStride;
+  for (uint32_t k = 0; k < 3u; ++k) {
+    const etx_abi_vertex& v = scene.vertices[t.i[k]];
+    r[k] = make_float4(v.pos.x, v.pos.y, v.pos.z, v.tex.x);
+    r[3u + k] = make_float4(v.nrm.x, v.nrm.y, v.nrm.z, v.tex.y);
+    r[7u + k] = make_float4(v.tan.x, v.tan.y, v.tan.z, 0.0f);
+    r[10u + k] = make_float4(v.btn.x, v.btn.y, v.btn.z, 0.0f);
+  }
+  r[6] = make_float4(t.geo_n.x, t.geo_n.y, t.geo_n.z, __uint_as_float(t.material_index));
+}
+
 __global__ __launch_bounds__(kBuildBlock) void k_bvh_refit_level(DScene scene, Bvh4Node* nodes, uint32_t first, uint32_t count) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count)
@@ -138,6 +155,11 @@ void launch_stack_selftest(hipStream_t stream, int32_t* spill, uint32_t spill_la
   scene.stack_spill = spill, scene.stack_spill_lanes = spill_lanes;
   hipLaunchKernelGGL(k_stack_selftest<false>, dim3(blocks), dim3(kBuildBlock), 0, stream, scene, depth, errors);
   hipLaunchKernelGGL(k_stack_selftest<true>, dim3(blocks), dim3(kBuildBlock), 0, stream, scene, depth, errors);
+}
+
+void launch_build_tri_shade(hipStream_t stream, const DScene& scene, float4* rows, uint32_t triangle_count) {
+  if (triangle_count > 0u)
+    hipLaunchKernelGGL(k_build_tri_shade, dim3(blocks_for(triangle_count)), dim3(kBuildBlock), 0, stream, scene, rows, triangle_count);
 }
 
 void launch_bvh_triangles_update(hipStream_t stream, const DScene& scene, BvhTri* tris, uint32_t count) {

@@ -50,9 +50,10 @@ ETX_DEV void round_housekeeping(uint32_t* __restrict__ counters, uint32_t active
 }
 
 // kCross (pipeline, flat scenes that hold Boundary materials): a path that is in NO medium and whose closest hit is a medium boundary
-// crosses it right here - vcm_handle_boundary_bsdf (vcm_shared.hxx:436-449) / handle_surface's Boundary branch (bidirectional.cxx:586-593)
-// draw nothing and leave only the medium, the ray origin and (VCM) the path distance changed - and is traced again from the other side;
-// the shade kernel then meets the segment INSIDE the medium. In the fog box that is the primary segment of every camera path and every
+// crosses it right here - vcm_handle_boundary_bsdf (vcm_shared.hxx:436-449) draws nothing and leaves only the medium, the ray origin and the
+// path distance changed; handle_surface's Boundary branch (bidirectional.cxx:586-593) comes after three next_2d draws of the vertex
+// (six numbers the crossing here does not take from the path's stream: another stream position from there on, the same distribution) -
+// and is traced again from the other side; the shade kernel then meets the segment INSIDE the medium. In the fog box that is the primary segment of every camera path and every
 // segment that leaves a wall: a quarter of all segments no longer cost a round of their own. A path that is inside a medium when it
 // reaches a boundary is left to the shade kernel (the medium is sampled first).
 enum : uint32_t { kCrossNone = 0, kCrossVcm = 1, kCrossBdpt = 2 };

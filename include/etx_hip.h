@@ -332,16 +332,10 @@ int etx_hip_host_bvh_stats(const etx_abi_scene* scene, const float* rays_8f, uin
 int etx_hip_host_check_bvh_builder(const etx_abi_scene* scene, int builder, uint32_t out_info[4]);
 int etx_hip_host_bvh_stats_builder(const etx_abi_scene* scene, int builder, const float* rays_8f, uint64_t count, uint64_t out[4], float* hits_2f);
 
-/* Host-only design study (csrc/host_bvh_study.cpp): the binned-SAH tree collapsed to `width` (4 or 8) children per node, the child
- * boxes exact or (`quantised`) as outward-rounded 8-bit offsets in the node's frame, walked nearest child first with the other hit
- * children pushed sorted (`sorted_pushes`) or in node order. out[0] node visits, [1] triangle tests, [2] rays that hit, [3] deepest
- * stack, [4] nodes, [5] inner levels, [6] sum of the visits a ray had made when it found its final hit, [7] most visits of one ray.
- * No kernel reads these formats: the numbers size the next traversal kernel. */
-int etx_hip_host_bvh_study(const etx_abi_scene* scene, uint32_t width, int quantised, int sorted_pushes, const float* rays_8f, uint64_t count, uint64_t out[8], float* hits_2f);
-
 /* Host-only: the ENCODED eight-wide tree of ETX_HIP_BVH_WIDE (csrc/host_scene.cpp encode_bvh8) walked through the node function the kernels
  * call (csrc/dev_bvh8.h bvh8_visit: byte decoding and the folded slab test included). `occlusion`: any-hit walk (the shadow kernel's), hits_2f
- * then holds {0, index of the triangle that ended the query}. Outputs as etx_hip_host_bvh_study; out[5] = levels | (the tree's exact bound
+ * then holds {0, index of the triangle that ended the query}. out[0] node visits, [1] triangle tests, [2] rays that hit, [3] deepest stack, [4] nodes, [6] sum of the
+ * visits a ray had made when it found its final hit, [7] most visits of one ray; out[5] = levels | (the tree's exact bound
  * of the traversal stack << 16). */
 int etx_hip_host_bvh8_stats(const etx_abi_scene* scene, int occlusion, const float* rays_8f, uint64_t count, uint64_t out[8], float* hits_2f);
 

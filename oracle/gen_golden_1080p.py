@@ -8,7 +8,6 @@ through the prebuilt oracle binary on the many-core host of the GPU box and keep
   cornell_full_1080p_vcm_64_blocks[_asis].npz        configs[1]: 64 VCM iterations, vcm-blue_noise=false
   cornell_full_1080p_vcm_64_blocks_bluenoise[_asis].npz   configs[1] with VCMOptions::default_values() (blue noise on): job full_bn
   cornell_gems_1080p_vcm_32_blocks.npz               configs[2]: 32 VCM iterations (job gems32)
-  cornell_gems_1080p_vcm_8_blocks.npz                configs[2]:  8 VCM iterations
   cornell_sssdragon_1080p_bdpt3_16_blocks[_asis].npz configs[3]: 16 BDPTFull iterations of the scene tools/synthetic_scenes.py sss_dragon
                                                      assembles (written out with SceneSnapshot.save for the driver)
   cornell_cloud_2048_bdpt3_8_blocks[_asis].npz       configs[4]:  8 BDPTFull iterations, 256^3 density grid (--inject-density 256)
@@ -39,7 +38,6 @@ JOBS = {
     "full": ("full_1080p", "vcm", 64, ["--opt", "vcm-blue_noise=false"], "cornell_full_1080p_vcm_64_blocks"),
     "full_bn": ("full_1080p", "vcm", 64, [], "cornell_full_1080p_vcm_64_blocks_bluenoise"),  # VCMOptions defaults: what bench.py times
     "gems32": ("gems_1080p", "vcm", 32, ["--opt", "vcm-blue_noise=false"], "cornell_gems_1080p_vcm_32_blocks"),
-    "gems": ("gems_1080p", "vcm", 8, ["--opt", "vcm-blue_noise=false"], "cornell_gems_1080p_vcm_8_blocks"),
     "sssdragon": ("sssdragon", "bdpt", 16, ["--opt", "bdpt-blue_noise=false", "--opt", "bdpt-mode=3"], "cornell_sssdragon_1080p_bdpt3_16_blocks"),
     "cloud": ("cloud_2048", "bdpt", 8, ["--opt", "bdpt-blue_noise=false", "--opt", "bdpt-mode=3", "--inject-density", "256"], "cornell_cloud_2048_bdpt3_8_blocks"),
 }
@@ -52,7 +50,7 @@ def block_mean(img, b=8):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    names = sys.argv[1:] or ["full", "gems"]
+    names = sys.argv[1:] or ["full", "gems32"]
     for name in names:
         as_is = name.endswith("_asis")
         flavour, integrator, spp, extra, stem = JOBS[name[:-5] if as_is else name]

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from tests.test_gpu_parity import make_rays
+from tools import bvh_study
 
 
 def rays_for(seed, n=30000):
@@ -40,7 +41,7 @@ def test_encoded_wide_tree_finds_the_hits_of_the_four_wide_tree(etx, golden_dir,
     assert wide["max_stack"] <= wide["stack_need"] <= 128 and wide["max_stack"] <= 24, (wide["max_stack"], wide["stack_need"])
     # the study's eight-wide format (greedy collapse, exact decode, no margin) against the encoded one (cost-driven collapse with merged
     # leaves): about the same visits, a third to a half of the nodes
-    rc, study = api.host_bvh_study(snap, rays, width=8, quantised=True, sorted_pushes=False)
+    rc, study = bvh_study.host_bvh_study(snap, rays, width=8, quantised=True, sorted_pushes=False)
     assert rc == 0 and wide["nodes"] < 0.6 * study["nodes"] and wide["levels"] <= study["levels"]
     assert abs(wide["node_visits"] / study["node_visits"] - 1.0) < 0.15
     # occlusion walk: a blocker for exactly the rays with a hit (any blocker: the first accepted triangle in traversal order)

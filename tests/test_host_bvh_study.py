@@ -1,4 +1,4 @@
-"""CPU: the node formats of csrc/host_bvh_study.cpp (four / eight children per node, exact or 8-bit outward-rounded boxes, sorted or
+"""CPU: the node formats of tools/bvh_study_src/bvh_study.cpp (four / eight children per node, exact or 8-bit outward-rounded boxes, sorted or
 unsorted pushes) find the closest hits of the tree the device traverses today (etx_hip_host_bvh_stats: the float BVH4 walked as
 dev_bvh.h bvh_closest walks it). A quantised box contains its exact box, so such a walk visits a superset of the nodes; the order of
 the pushes changes the work, not the result. tools/bvh_study.py prints the work per format for the bench scenes."""
@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from tests.test_gpu_parity import make_rays
+from tools import bvh_study
 
 
 @pytest.fixture(scope="module")
@@ -25,7 +26,7 @@ def test_every_format_finds_the_hits_of_the_device_tree(etx, gems):
     for width in (4, 8):
         for quantised in (False, True):
             for sorted_pushes in (True, False):
-                rc, got = api.host_bvh_study(gems, rays, width=width, quantised=quantised, sorted_pushes=sorted_pushes, with_hits=True)
+                rc, got = bvh_study.host_bvh_study(gems, rays, width=width, quantised=quantised, sorted_pushes=sorted_pushes, with_hits=True)
                 assert rc == 0, (width, quantised, sorted_pushes)
                 assert got["hits"] == today["hits"]
                 same = got["triangle"] == today["triangle"]
@@ -51,5 +52,5 @@ def test_every_format_finds_the_hits_of_the_device_tree(etx, gems):
 
 def test_study_rejects_other_widths(etx, gems):
     from etx_tracer_amd import api
-    rc, _ = api.host_bvh_study(gems, make_rays(16, 1), width=6)
+    rc, _ = bvh_study.host_bvh_study(gems, make_rays(16, 1), width=6)
     assert rc == -1  # ETX_HIP_ERROR_INVALID_ARGUMENT

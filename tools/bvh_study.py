@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""What a ray costs in the node formats of csrc/host_bvh_study.cpp, on the host (no GPU):
+"""What a ray costs in the node formats of tools/bvh_study_src/bvh_study.cpp, on the host (no GPU) - a design study, not part of the product
+library (the tool builds its own small library on first use and links it against libetx_hip.so for the host tree builder):
 
     python3 tools/bvh_study.py [gems] [dragon] [gems1m] [--rays 200000]
 
@@ -20,6 +21,44 @@ from etx_tracer_amd import api  # noqa: E402
 from tools import synthetic_scenes  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+STUDY_SOURCE = os.path.join(ROOT, "tools", "bvh_study_src", "bvh_study.cpp")
+STUDY_LIBRARY = os.path.join(ROOT, "tools", "bvh_study_src", "libetx_bvh_study.so")
+_study = None
+
+
+def study_library():
+    """tools/bvh_study_src/libetx_bvh_study.so, compiled on first use (hipcc, host code only)."""
+    global _study
+    if _study is not None:
+        return _study
+    import ctypes
+    import subprocess
+    product = api.library_path()
+    stale = (not os.path.exists(STUDY_LIBRARY)) or (os.path.getmtime(STUDY_LIBRARY) < max(os.path.getmtime(STUDY_SOURCE), os.path.getmtime(product)))
+    if stale:
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip", STUDY_SOURCE, "-o", STUDY_LIBRARY,
+                               "-L" + os.path.dirname(product), "-l:" + os.path.basename(product), "-Wl,-rpath," + os.path.dirname(product)], stderr=subprocess.DEVNULL)
+    api.Library.get()  # the product library first: the study resolves the host tree builder in it
+    _study = ctypes.CDLL(STUDY_LIBRARY)
+    _study.etx_bvh_study.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64 * 8), ctypes.c_void_p]
+    return _study
+
+
+def host_bvh_study(snapshot, rays, width=4, quantised=False, sorted_pushes=True, with_hits=False):
+    """What `rays` cost in a tree of `width` children per node, boxes exact or 8-bit (etx_bvh_study)."""
+    import ctypes
+    rays = np.ascontiguousarray(rays, dtype=np.float32)
+    out = (ctypes.c_uint64 * 8)()
+    hits = np.zeros((rays.shape[0], 2), dtype=np.float32) if with_hits else None
+    rc = study_library().etx_bvh_study(snapshot.scene_address, int(width), int(bool(quantised)), int(bool(sorted_pushes)), rays.ctypes.data, rays.shape[0], ctypes.byref(out),
+                                       hits.ctypes.data if with_hits else None)
+    result = {"node_visits": out[0], "triangle_tests": out[1], "hits": out[2], "max_stack": out[3], "nodes": out[4], "levels": out[5], "visits_to_final_hit": out[6],
+              "max_visits_of_a_ray": out[7]}
+    if with_hits:
+        triangle = hits[:, 1].view(np.uint32).astype(np.int64)
+        triangle[triangle == 0xFFFFFFFF] = -1
+        result["t"], result["triangle"] = hits[:, 0].copy(), triangle
+    return rc, result
 
 
 def make_rays(n, seed):
@@ -83,7 +122,7 @@ def main():
         print("  %-40s %9s %9s %7s %12s %12s %12s %9s %9s" % ("format", "nodes", "MB", "levels", "visits/ray", "tests/ray", "node B/ray", "max stack", "max visits"))
         base = None
         for label, width, quantised, sorted_pushes, node_bytes in FORMATS:
-            rc, w = api.host_bvh_study(snap, rays, width=width, quantised=quantised, sorted_pushes=sorted_pushes, with_hits=True)
+            rc, w = host_bvh_study(snap, rays, width=width, quantised=quantised, sorted_pushes=sorted_pushes, with_hits=True)
             assert rc == 0, label
             if base is None:
                 base = w

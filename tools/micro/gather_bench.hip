@@ -35,6 +35,22 @@ __global__ __launch_bounds__(256) void k_gather(const float4* __restrict__ table
   if (acc == 123.456f) sink[0] = acc;
 }
 
+// every lane of a wave picks one of `distinct` records (the records differ from instruction to instruction): what a gather into a SMALL table
+// costs - a material or emitter table of a few entries, where many lanes of a wave want the same record
+__global__ __launch_bounds__(256) void k_gather_few(const float4* __restrict__ table, uint32_t records, uint32_t distinct, uint32_t iters, float* sink) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t wave = tid >> 6;
+  float acc = 0.0f;
+#pragma unroll 2
+  for (uint32_t i = 0; i < iters; ++i) {
+    const uint32_t pick = hash_u32(tid * 0x9e3779b9u + i) % distinct;            // which of the wave's records this lane wants
+    const uint32_t r = hash_u32((wave * 64u + pick) * 0x85ebca6bu + i) & (records - 1u);
+    const float4 v = table[size_t(r) * 8u];
+    acc += v.x + v.w;
+  }
+  if (acc == 123.456f) sink[0] = acc;
+}
+
 template <int kDwords>
 __global__ __launch_bounds__(256) void k_gather_narrow(const float* __restrict__ table, uint32_t records, uint32_t iters, float* sink) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -146,6 +162,11 @@ int main() {
     RUN((k_gather<8, true>), "dwordx4, record per WAVE", 8, 16, records, table, records, iters, sink)
     RUN((k_gather_narrow<1>), "dword, record per lane", 1, 4, records, reinterpret_cast<const float*>(table), records, iters, sink)
     RUN((k_gather_narrow<2>), "dwordx2, record per lane", 1, 8, records, reinterpret_cast<const float*>(table), records, iters, sink)
+  }
+  for (uint32_t distinct : {1u, 2u, 4u, 8u, 16u, 32u}) {
+    char name[64];
+    snprintf(name, sizeof(name), "dwordx4, %u records per wave", distinct);
+    RUN((k_gather_few), name, 1, 16, 1024, table, 1024u, distinct, iters, sink)
   }
   RUN((k_no_load), "no load (index arithmetic only)", 1, 0, 0, iters, sink)
   RUN((k_gather_lds_narrow<1>), "LDS ds_read_b32, dword per lane", 1, 4, 256, table, iters, sink)

@@ -45,6 +45,9 @@ def main():
             meta = {"workload": line.get("config", {}).get("workload_key"), "iterations": int(line["steps"]) + int(line["warmup"]), "lanes": line.get("config", {}).get("lanes"),
                     "units_per_step": line.get("counters", {}).get("units_per_step", {}), "ms_per_step": line.get("ms_per_step"), "value": line.get("value"),
                     "library_sha16": line.get("config", {}).get("library_sha16")}
+    verbose = "--all" in sys.argv  # print every counter sum, not only the derived shares
+    if verbose:
+        sys.argv.remove("--all")
     out_path, paths = sys.argv[1], sys.argv[2:]
     table = defaultdict(lambda: defaultdict(float))
     passes = defaultdict(set)  # counter -> the passes that collected it (a counter listed in two passes is averaged, not added)
@@ -101,7 +104,7 @@ def main():
     with open(out_path, "w") as f:
         json.dump(ordered, f, indent=1)
     for k, r in sorted(result.items(), key=lambda kv: -kv[1]["duration_us_sum"])[:14]:
-        print("%-44s %5.1f%% " % (k[:44], 100.0 * r["time_share"]), {a: b for a, b in r.items() if a.endswith(("share", "rate", "mean")) or (len(sys.argv) > 8 and a.endswith("_sum"))})
+        print("%-44s %5.1f%% " % (k[:44], 100.0 * r["time_share"]), {a: b for a, b in r.items() if a.endswith(("share", "rate", "mean")) or (verbose and a.endswith("_sum"))})
 
 
 if __name__ == "__main__":
