@@ -190,7 +190,7 @@ ETX_DEV BdptBsdf bdpt_bsdf(const DScene& scene, const BFull& v, uint32_t source,
   const BsdfData data = make_bsdf_data(v.isect, v.isect.w_i, kInvalid, source, wavelength);
   BsdfEval e = bsdf_evaluate_s<kSimple>(scene, data, w_o, scene.materials[v.isect.material], smp);
   if (source == kPathLight)
-    e.bsdf = e.bsdf * fix_shading_normal(ld3(scene.triangles[v.isect.tri].geo_n), v.isect.nrm, v.isect.w_i, w_o);
+    e.bsdf = e.bsdf * fix_shading_normal(v.isect.geo_n, v.isect.nrm, v.isect.w_i, w_o);
   return {e.bsdf, e.pdf};
 }
 

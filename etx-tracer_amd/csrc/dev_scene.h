@@ -364,12 +364,9 @@ struct Vtx {
 //   rows 0-2  position of vertex i, u of its texture coordinate       rows 3-5  normal of vertex i, v
 //   row  6    geometric normal, material index (bits)                 rows 7-9  tangents, rows 10-12 bitangents
 constexpr uint32_t kTriShadeStride = 13;
-#if !defined(ETX_TRI_CACHE)
-#define ETX_TRI_CACHE 1  // A/B switch (tools/build_variant.sh): 0 = the simple-group kernels read the rows again instead of keeping them (Isect::tv)
-#endif
-constexpr bool kTriCache = ETX_TRI_CACHE != 0;
 
-struct TriVerts {  // what shading_pos reads: kept with the intersection by the kernels that have the registers (simple shading group)
+struct TriVerts {  // what shading_pos reads (rows 0-6). Keeping these 21 registers with the intersection was tried: an Isect of 180 bytes is no longer
+                   // split into registers by the compiler (the whole struct went to scratch, 200 bytes per lane) - the rows are read again instead
   f3 p0, p1, p2, n0, n1, n2, geo_n;
 };
 
@@ -380,7 +377,7 @@ struct Isect : public Vtx {
   float t;
   uint32_t material;
   uint32_t emitter;
-  TriVerts tv;  // set by make_intersection; dead (and free) in kernels that never read it
+  f3 geo_n;  // the triangle's geometric normal (row 6 comes with the shading point)
 };
 
 ETX_DEV const float4* tri_rows(const DScene& s, const etx_abi_triangle& t) {
@@ -396,18 +393,20 @@ ETX_DEV TriVerts load_tri_verts(const DScene& s, const etx_abi_triangle& t) {
 }
 
 // scene.hxx:90-112 lerp_vertex: interpolate, re-orthogonalise (Gram-Schmidt), keep bitangent handedness
-ETX_DEV Vtx lerp_vertex(const DScene& s, const etx_abi_triangle& t, const f3& bc, TriVerts* keep = nullptr, uint32_t* material = nullptr) {
-  const float4* r = tri_rows(s, t);
-  const float4 p0 = r[0], p1 = r[1], p2 = r[2], n0 = r[3], n1 = r[4], n2 = r[5];
-  const float4 t0 = r[7], t1 = r[8], t2 = r[9], b0 = r[10], b1 = r[11], b2 = r[12];
-  if ((keep != nullptr) || (material != nullptr)) {
-    const float4 g = r[6];
-    if (keep != nullptr)
-      *keep = {xyz(p0), xyz(p1), xyz(p2), xyz(n0), xyz(n1), xyz(n2), xyz(g)};
-    if (material != nullptr)
-      *material = __float_as_uint(g.w);
-  }
+struct TriPoint {  // the interpolated vertex and what came with the triangle's rows (by value: out-pointers kept the caller's Isect in scratch)
   Vtx v;
+  TriVerts tv;
+  uint32_t material;
+};
+
+ETX_DEV TriPoint lerp_tri_point(const DScene& s, const etx_abi_triangle& t, const f3& bc) {
+  const float4* r = tri_rows(s, t);
+  const float4 p0 = r[0], p1 = r[1], p2 = r[2], n0 = r[3], n1 = r[4], n2 = r[5], g = r[6];
+  const float4 t0 = r[7], t1 = r[8], t2 = r[9], b0 = r[10], b1 = r[11], b2 = r[12];
+  TriPoint out;
+  out.tv = {xyz(p0), xyz(p1), xyz(p2), xyz(n0), xyz(n1), xyz(n2), xyz(g)};
+  out.material = __float_as_uint(g.w);
+  Vtx& v = out.v;
   v.pos = xyz(p0) * bc.x + xyz(p1) * bc.y + xyz(p2) * bc.z;
   v.nrm = xyz(n0) * bc.x + xyz(n1) * bc.y + xyz(n2) * bc.z;
   v.tan = xyz(t0) * bc.x + xyz(t1) * bc.y + xyz(t2) * bc.z;
@@ -417,7 +416,11 @@ ETX_DEV Vtx lerp_vertex(const DScene& s, const etx_abi_triangle& t, const f3& bc
   v.tan = normalize(v.tan - dot(v.tan, v.nrm) * v.nrm);
   f3 btn = cross(v.nrm, v.tan);
   v.btn = normalize(btn * (dot(btn, b) > 0.0f ? 1.0f : -1.0f));
-  return v;
+  return out;
+}
+
+ETX_DEV Vtx lerp_vertex(const DScene& s, const etx_abi_triangle& t, const f3& bc) {
+  return lerp_tri_point(s, t, bc).v;
 }
 
 ETX_DEV f3 lerp_pos(const DScene& s, const etx_abi_triangle& t, const f3& bc) {  // scene.hxx:77-81
@@ -598,8 +601,11 @@ ETX_DEV f3 orient_normals_to_hemisphere(f3 n_s, const f3& n_g, const f3& v) {
 ETX_DEV Isect make_intersection(const DScene& s, const f3& w_i, float u, float v, float t, uint32_t tri_index) {
   f3 bc = barycentrics(u, v);
   const etx_abi_triangle& tri = s.triangles[tri_index];
+  const TriPoint point = lerp_tri_point(s, tri, bc);
   Isect r;
-  static_cast<Vtx&>(r) = lerp_vertex(s, tri, bc, &r.tv, &r.material);
+  static_cast<Vtx&>(r) = point.v;
+  r.geo_n = point.tv.geo_n;
+  r.material = point.material;
   r.bc = bc;
   r.tri = tri_index;
   r.w_i = w_i;
@@ -611,7 +617,7 @@ ETX_DEV Isect make_intersection(const DScene& s, const f3& w_i, float u, float v
     float sc = mat.normal_scale;
     f3 sn = {sc * (value.x * 2.0f - 1.0f), sc * (value.y * 2.0f - 1.0f), sc * (value.z * 2.0f - 1.0f) + (1.0f - sc)};
     r.nrm = normalize(r.tan * sn.x + r.btn * sn.y + r.nrm * sn.z);
-    r.nrm = orient_normals_to_hemisphere(r.nrm, r.tv.geo_n, w_i);
+    r.nrm = orient_normals_to_hemisphere(r.nrm, r.geo_n, w_i);
     r.tan = normalize(r.tan - dot(r.tan, r.nrm) * r.nrm);
     r.btn = normalize(cross(r.nrm, r.tan));
   }

@@ -273,9 +273,8 @@ ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& 
   const etx_abi_triangle& tri = scene.triangles[isect.tri];
   const etx_abi_material& mat = scene.materials[isect.material];
   st.throughput *= bs.weight;
-  // kSimple: the triangle's rows are still in registers (Isect::tv); the general kernels have none to spare and read them again
   if (path_source == kPathLight)
-    st.throughput *= fix_shading_normal((kSimple && kTriCache) ? isect.tv.geo_n : ld3(tri.geo_n), isect.nrm, isect.w_i, bs.w_o);
+    st.throughput *= fix_shading_normal(isect.geo_n, isect.nrm, isect.w_i, bs.w_o);
   if (is_zero(st.throughput))
     return false;
   if (random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput) == false)
@@ -295,7 +294,7 @@ ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& 
     st.d_vcm = 1.0f / bs.pdf;
   }
   st.ray_d = bs.w_o;
-  st.ray_o = (kSimple && kTriCache) ? shading_pos(isect.tv, isect.bc, bs.w_o) : shading_pos(scene, tri, isect.bc, bs.w_o);
+  st.ray_o = shading_pos(scene, tri, isect.bc, bs.w_o);
   st.ray_tmax = kMaxFloat;
   st.ray_tmin = kRayEpsilon;
   st.eta *= bs.eta;
@@ -308,10 +307,10 @@ ETX_DEV bool vcm_handle_boundary(const DScene& scene, const Isect& isect, PathSt
   const etx_abi_material& mat = scene.materials[isect.material];
   if (mat.cls != ETX_MAT_BOUNDARY)
     return false;
-  uint32_t new_medium = (dot(isect.tv.geo_n, st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;  // Isect::tv: straight after make_intersection
+  uint32_t new_medium = (dot(isect.geo_n, st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
   st.path_distance += isect.t;
   st.medium = new_medium;
-  st.ray_o = shading_pos(isect.tv, isect.bc, st.ray_d);
+  st.ray_o = shading_pos(scene, scene.triangles[isect.tri], isect.bc, st.ray_d);
   st.ray_tmax = kMaxFloat;
   st.ray_tmin = kRayEpsilon;
   return true;
@@ -344,7 +343,7 @@ ETX_DEV bool vcm_connect_to_camera(const DScene& scene, const VcmParams& it, boo
       return false;
     scatter = eval.bsdf;
     reverse_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, w_o, mat, st.sampler);
-    origin = (kSimple && kTriCache) ? shading_pos(isect->tv, isect->bc, w_o) : shading_pos(scene, scene.triangles[isect->tri], isect->bc, w_o);
+    origin = shading_pos(scene, scene.triangles[isect->tri], isect->bc, w_o);
   } else {
     const DMedium& medium = scene.mediums[st.medium];
     float p = phase_function(st.ray_d, w_o, medium.g);
@@ -361,7 +360,7 @@ ETX_DEV bool vcm_connect_to_camera(const DScene& scene, const VcmParams& it, boo
   float w_light = camera_pdf * (vmW_cam + st.d_vcm + st.d_vc * reverse_pdf);
   float weight = opt_enable_mis(it) ? (1.0f / (1.0f + w_light)) : 1.0f;
   if (camera_at_medium == false)
-    weight *= fix_shading_normal((kSimple && kTriCache) ? isect->tv.geo_n : ld3(scene.triangles[isect->tri].geo_n), isect->nrm, isect->w_i, w_o);
+    weight *= fix_shading_normal(isect->geo_n, isect->nrm, isect->w_i, w_o);
   // film.cxx:147-171 atomic_add_light_iteration: NDC -> pixel, y flip
   uint32_t x = static_cast<uint32_t>((cs.uv.x * 0.5f + 0.5f) * float(it.film_w));
   uint32_t y = static_cast<uint32_t>((cs.uv.y * 0.5f + 0.5f) * float(it.film_h));
@@ -461,8 +460,8 @@ ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool
     scatter = eval.bsdf;
     reverse_pdf = bsdf_reverse_pdf_s<kSimple>(scene, data, w_o, mat, st.sampler);
     const etx_abi_triangle& tri = scene.triangles[isect->tri];
-    origin = (kSimple && kTriCache) ? shading_pos(isect->tv, isect->bc, normalize(es.origin - isect->pos)) : shading_pos(scene, tri, isect->bc, normalize(es.origin - isect->pos));
-    camera_factor = fabsf(dot(w_o, (kSimple && kTriCache) ? isect->tv.geo_n : ld3(tri.geo_n)));
+    origin = shading_pos(scene, tri, isect->bc, normalize(es.origin - isect->pos));
+    camera_factor = fabsf(dot(w_o, isect->geo_n));
     conn_pdf = bsdf_pdf_s<kSimple>(scene, data, w_o, mat, st.sampler);
   }
   float l_dot_e = fabsf(dot(es.direction, es.normal));
@@ -524,10 +523,12 @@ template <bool kDiffuseOnly>
 ETX_DEV bool vcm_connect_to_light_vertex(const DScene& scene, const PathState& st, const LightVertex& lv, const VcmParams& it, bool camera_at_medium, const Isect* cam, const f3& medium_pos,
   Sampler& smp, f3& target_position, f3& value) {
   Vtx light_v;
-  TriVerts light_tv;  // its geometric normal and the material index come with the triangle's rows
+  f3 light_geo_n = mk3(0.0f);  // the geometric normal and the material index come with the triangle's rows
   uint32_t light_material = 0u;
-  if (lv.is_medium() == false)
-    light_v = lerp_vertex(scene, scene.triangles[lv.tri], barycentrics(lv.bc_u, lv.bc_v), &light_tv, &light_material);
+  if (lv.is_medium() == false) {
+    const TriPoint point = lerp_tri_point(scene, scene.triangles[lv.tri], barycentrics(lv.bc_u, lv.bc_v));
+    light_v = point.v, light_geo_n = point.tv.geo_n, light_material = point.material;
+  }
   target_position = lv.is_medium() ? lv.pos : light_v.pos;
   f3 w_o = target_position - (camera_at_medium ? medium_pos : cam->pos);
   float distance_squared = dot(w_o, w_o);
@@ -575,7 +576,7 @@ ETX_DEV bool vcm_connect_to_light_vertex(const DScene& scene, const PathState& s
       return false;
     light_area_pdf = camera_at_medium ? (light_bsdf.pdf / distance_squared) : (light_bsdf.pdf * fabsf(dot(cam->nrm, w_o)) / distance_squared);
     light_rev_pdf = bsdf_reverse_pdf_t<kDiffuseOnly>(scene, light_data, -w_o, light_mat, smp);
-    light_scatter = light_bsdf.bsdf * fix_shading_normal(light_tv.geo_n, light_data.nrm, light_data.w_i, -w_o);
+    light_scatter = light_bsdf.bsdf * fix_shading_normal(light_geo_n, light_data.nrm, light_data.w_i, -w_o);
   }
 
   float vmW_pair = (camera_at_medium || lv.is_medium()) ? 0.0f : it.vm_weight;

@@ -285,7 +285,7 @@ ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const Nodes& nodes, c
     const f2 rnd_support = st.sampler.next_2d();
     if (mat.cls == ETX_MAT_BOUNDARY) {  // handle_surface :586-593: the path length does not change
       const etx_abi_triangle& t = scene.triangles[isect.tri];
-      st.medium = (dot(ld3(t.geo_n), st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
+      st.medium = (dot(isect.geo_n, st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
       st.ray_o = shading_pos(scene, t, isect.bc, st.ray_d);
       st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
       r.alive = true;
@@ -320,13 +320,13 @@ ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const Nodes& nodes, c
         st.ray_o = shading_pos(scene, t, isect.bc, bs.w_o);
         st.ray_d = bs.w_o;
         st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
-        st.throughput *= fix_shading_normal(ld3(t.geo_n), isect.nrm, isect.w_i, bs.w_o);
+        st.throughput *= fix_shading_normal(isect.geo_n, isect.nrm, isect.w_i, bs.w_o);
       } else {
         terminate = true;
       }
       if (first && (st.flags & kBpDistantEmitter)) {  // update_distant_emitter_path_pdfs
         st.prev.from_prev = bdpt_emitter_sample_pdf(scene, scene.emitters[st.flags >> kBpEmitterShift], -isect.w_i);
-        curr.from_prev = st.aux * fabsf(dot(isect.w_i, ld3(scene.triangles[isect.tri].geo_n)));
+        curr.from_prev = st.aux * fabsf(dot(isect.w_i, isect.geo_n));
       }
       r.v_from_prev = curr.from_prev;
       r.emitter_vertex = st.prev;
@@ -736,7 +736,7 @@ ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, 
       bluenoise_samples(it.bluenoise, st.id % it.film_w, st.id / it.film_w, it.iteration, rnd_bsdf, rnd_em, rnd_support);
     if (mat.cls == ETX_MAT_BOUNDARY) {  // handle_surface :586-593: no vertex, the path length does not change
       const etx_abi_triangle& t = scene.triangles[isect.tri];
-      st.medium = (dot(ld3(t.geo_n), st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
+      st.medium = (dot(isect.geo_n, st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
       st.ray_o = shading_pos(scene, t, isect.bc, st.ray_d);
       st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
       r.alive = true;

@@ -125,8 +125,7 @@ __global__ __launch_bounds__(kBlockSize) void k_connect_pairs(Pipeline p, VcmPar
           if (vcm_connect_to_light_vertex<kDiffuseOnly>(scene, cv.st, lv, it, cv.at_medium, &cv.isect, cv.medium_pos, cv.st.sampler, target_position, value)) {
             f3 p0 = cv.medium_pos;
             if (cv.at_medium == false)
-              p0 = (kDiffuseOnly && kTriCache) ? shading_pos(cv.isect.tv, cv.isect.bc, normalize(target_position - cv.isect.pos))
-                                : shading_pos(scene, scene.triangles[cv.isect.tri], cv.isect.bc, normalize(target_position - cv.isect.pos));
+              p0 = shading_pos(scene, scene.triangles[cv.isect.tri], cv.isect.bc, normalize(target_position - cv.isect.pos));
             request = {p0, cv.at_medium ? lv.pos : target_position, value * spectral_film_weight(scene, cv.st.wavelength), cv.st.medium, film_index(it, cv.st.id), cv.st.wavelength};
             queue = true;
           }
