@@ -169,11 +169,13 @@ typedef const __attribute__((address_space(4))) float* ConstantFloats;
 struct FlatRow {  // one FlatPrim as it sits in SGPRs
   float4 plane, row_a, row_b;
   uint32_t flags, material;
+  uint32_t medium_against, medium_along;
 };
 
 ETX_DEV FlatRow load_flat_prim(ConstantFloats table, uint32_t i) {
   ConstantFloats t = table + i * 16u;
-  return {make_float4(t[0], t[1], t[2], t[3]), make_float4(t[4], t[5], t[6], t[7]), make_float4(t[8], t[9], t[10], t[11]), __float_as_uint(t[12]), __float_as_uint(t[13])};
+  return {make_float4(t[0], t[1], t[2], t[3]), make_float4(t[4], t[5], t[6], t[7]), make_float4(t[8], t[9], t[10], t[11]), __float_as_uint(t[12]), __float_as_uint(t[13]),
+    __float_as_uint(t[14]), __float_as_uint(t[15])};
 }
 
 // Plane hit, then parallelogram coordinates of the hit point. A triangle needs a + b <= 1, a parallelogram a <= 1 and
@@ -488,7 +490,6 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
       continue;
     if (flags & kTriVoid)
       continue;
-    const uint32_t tri_index = i;  // primitive index; both halves of a parallelogram share plane, winding and material
     if ((flags & kTriAlphaTested) && alpha_test_skips(scene, scene.flat_info[i].tri_a, tri.material, u, v, alpha_seed))
       continue;
     if ((flags & kTriBoundary) == 0u) {
@@ -496,9 +497,11 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
       continue;
     }
     crossings++;
-    // insertion into the sorted 4-slot list (compare-exchange chain, all in registers)
+    // insertion into the sorted 4-slot list (compare-exchange chain, all in registers). What is kept of a crossing is the medium BEYOND it:
+    // the row holds both candidates in scalar registers and the side is the sign of N . d (FlatPrim::medium_against / _along) - walking the
+    // media afterwards gathers nothing (it read primitive info -> triangle -> material per crossing: three dependent loads)
     float ct = t;
-    uint32_t ci = tri_index;
+    uint32_t ci = ((tri.plane.x * direction.x + tri.plane.y * direction.y + tri.plane.z * direction.z) < 0.0f) ? tri.medium_against : tri.medium_along;
     if (ct < bt0) { float tt = bt0; uint32_t ti = bi0; bt0 = ct, bi0 = ci, ct = tt, ci = ti; }
     if (ct < bt1) { float tt = bt1; uint32_t ti = bi1; bt1 = ct, bi1 = ci, ct = tt, ci = ti; }
     if (ct < bt2) { float tt = bt2; uint32_t ti = bi2; bt2 = ct, bi2 = ci, ct = tt, ci = ti; }
@@ -522,9 +525,7 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
     if (k < crossings) {
       if (medium != kInvalid)
         result *= medium_transmittance(scene, scene.mediums[medium], wavelength, medium_rng, p0 + direction * current_t, direction, fmaxf(0.0f, bts[k] - current_t));
-      const etx_abi_triangle& tri = scene.triangles[scene.flat_info[bis[k]].tri_a];
-      const etx_abi_material& mat = scene.materials[tri.material_index];
-      medium = (dot(ld3(tri.geo_n), direction) < 0.0f) ? mat.int_medium : mat.ext_medium;
+      medium = bis[k];
       current_t = bts[k];
     }
   }

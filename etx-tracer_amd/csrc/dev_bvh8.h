@@ -69,6 +69,9 @@ ETX_HD Bvh8Words bvh8_load(const uint4* node) {
 // The ray in the frame of a node: t(q) = q * step + base per axis
 struct Bvh8RayFrame {
   f3 step, base;
+  float slack;  // what rounding can move a slab distance by: the folded form t = q * step + base loses the bits of `base`, which grows with the
+                // distance of the ray origin from the node (a camera far outside the scene): a few ulps of |base| are given back to the interval.
+                // The host's outward rounding (encode_bvh8) covers origins inside the scene's reach; this covers the rest.
 };
 
 ETX_HD Bvh8RayFrame bvh8_ray_frame(const float4& frame, const f3& ray_o, const f3& inv_d) {
@@ -79,7 +82,11 @@ ETX_HD Bvh8RayFrame bvh8_ray_frame(const float4& frame, const f3& ray_o, const f
   memcpy(&exps, &frame.w, 4);
 #endif
   const f3 scale = {bvh8_bits_to_float((exps & 0xffu) << 23u), bvh8_bits_to_float(((exps >> 8u) & 0xffu) << 23u), bvh8_bits_to_float(((exps >> 16u) & 0xffu) << 23u)};
-  return {{scale.x * inv_d.x, scale.y * inv_d.y, scale.z * inv_d.z}, {(frame.x - ray_o.x) * inv_d.x, (frame.y - ray_o.y) * inv_d.y, (frame.z - ray_o.z) * inv_d.z}};
+  const f3 base = {(frame.x - ray_o.x) * inv_d.x, (frame.y - ray_o.y) * inv_d.y, (frame.z - ray_o.z) * inv_d.z};
+  // an axis the ray is parallel to has a clamped reciprocal (bvh8_reciprocal): its bounds sit at +-1e30 x distance and decide by sign alone
+  const float kClamped = 1.0e29f;
+  const float magnitude = ((fabsf(inv_d.x) < kClamped) ? fabsf(base.x) : 0.0f) + ((fabsf(inv_d.y) < kClamped) ? fabsf(base.y) : 0.0f) + ((fabsf(inv_d.z) < kClamped) ? fabsf(base.z) : 0.0f);
+  return {{scale.x * inv_d.x, scale.y * inv_d.y, scale.z * inv_d.z}, base, 4.0e-7f * magnitude};
 }
 
 // Entry distance of child k (its six bytes given as the words they sit in and the byte index), +inf when missed
@@ -89,7 +96,7 @@ ETX_HD float bvh8_slab(const Bvh8RayFrame& rf, uint32_t lox, uint32_t loy, uint3
   const float tz0 = fmaf(bvh8_byte(loz, k), rf.step.z, rf.base.z), tz1 = fmaf(bvh8_byte(hiz, k), rf.step.z, rf.base.z);
   const float t_enter = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
   const float t_exit = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
-  return (t_enter <= t_exit * 1.0000004f) ? t_enter : kMaxFloat;
+  return (t_enter <= t_exit * 1.0000004f + rf.slack) ? t_enter : kMaxFloat;
 }
 
 // Tests the eight children of a node against the ray segment [tmin, tmax]; returns the nearest hit child (kBvhEmptyChild: none) and

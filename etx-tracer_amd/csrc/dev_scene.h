@@ -74,7 +74,8 @@ struct __attribute__((aligned(16))) FlatPrim {
   float4 plane;   // N.xyz (= e1 x e2), nd = -N . v0
   float4 row_a;   // U.xyz = (e2 x N) / |N|^2, ud = -U . v0
   float4 row_b;   // V.xyz = (N x e1) / |N|^2, vd = -V . v0
-  uint32_t flags, material, pad0, pad1;
+  uint32_t flags, material;
+  uint32_t medium_against, medium_along;  // Boundary primitives: the medium beyond the plane for a ray with N . d < 0 / >= 0 (host_scene.cpp)
 };
 static_assert(sizeof(FlatPrim) == 64, "FlatPrim");
 

@@ -478,6 +478,15 @@ ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool
   return true;
 }
 
+// Pairs of the bounce for the connection kernels. k_expand_pairs reserves a camera vertex' whole run of pairs and writes nothing of a run that
+// does not fit the buffer: the list then has HOLES (whatever the memory held) below its end. The bounce has overflowed and its iteration will
+// be rendered again with a larger buffer (host_api.cpp execute_iteration) - nothing of it is evaluated.
+ETX_DEV uint32_t pair_list_count(const Pipeline& p) {
+  if (p.counters[kCntOverflow] & kOverflowPairs)
+    return 0u;
+  return min(p.counters[kCntPairs], p.pair_capacity);
+}
+
 struct LightVertex {  // VCMLightVertex, vcm_shared.hxx:154-197
   f3 pos, w_i, throughput, nrm;
   float d_vcm, d_vc, d_vm;

@@ -109,6 +109,15 @@ struct etx_hip_context {
   uint32_t* host_counters = nullptr;  // pinned
   unsigned long long* round_mirror = nullptr;  // pinned: (round tag + 1) << 32 | active paths, written by k_trace_closest (run_bounce_loop)
   uint32_t next_round_tag = 0;               // never reset: stale entries of earlier passes cannot match
+  // The launch plan of a pass (run_bounce_loop): live paths entering each round of this lane's previous iteration, read from the round mirror
+  // after the iteration. With a plan the host enqueues the whole pass - every round with the plan's launch shape, then the tail kernel -
+  // without waiting for the device in between; the kernels take their true counts from the device counters as always.
+  struct PassPlan {
+    std::vector<uint32_t> entering;
+    uint32_t first_tag = 0, rounds_enqueued = 0;  // of the pass being / last rendered: where its mirror entries are
+  };
+  PassPlan plans[2];                         // light pass, camera pass (path tracing: [1] only)
+  bool scheduled_passes = true;              // ETX_HIP_SCHEDULED_PASSES=0 (debug builds): always poll
   uint8_t* bluenoise[kBlueNoiseSets] = {};  // device tables by sample-count class (etx_hip_upload_bluenoise)
   const uint8_t* active_bluenoise = nullptr;
   float4* cie_table = nullptr;      // spectrum::spectral_xyz (etx_hip_upload_cie_table), spectral scenes only
@@ -499,6 +508,33 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
   uint32_t set = 0;
   uint32_t known_count = ctx->pipe.capacity;  // upper bound of the active paths (the count never grows within a pass)
   const uint32_t tail_threshold = (allow_tail && ctx->tail_divisor) ? std::max(64u, ctx->pipe.capacity / ctx->tail_divisor) : 0u;
+  etx_hip_context::PassPlan& plan = ctx->plans[(pass_stat == kStatRaysLight) ? 0 : 1];
+  const std::vector<uint32_t> planned = plan.entering;
+  plan.first_tag = ctx->next_round_tag, plan.rounds_enqueued = 0u;
+  // A pass that ends in the tail kernel needs no answer from the device at all: the rounds of the plan (launch shapes of this lane's last
+  // iteration: which round follows which is fixed, how many paths a round finds is on the device), then the tail kernel, which runs whatever
+  // is alive to its end - fewer or more paths than the plan expected cost time, not correctness. The host comes back at the end of the
+  // iteration and reads the round mirror for the next plan.
+  if (ctx->scheduled_passes && allow_tail && (tail_threshold != 0u) && (planned.empty() == false) && (planned.size() + 2u < kRoundMirrorSlots)) {
+    uint32_t bound = ctx->pipe.capacity;
+    for (size_t r = 0; r < planned.size(); ++r) {
+      if (planned[r] <= tail_threshold)
+        break;
+      bound = uint32_t(std::min<uint64_t>(ctx->pipe.capacity, uint64_t(planned[r]) + planned[r] / 8u + 4096u));
+      const uint32_t tag = ctx->next_round_tag++;
+      {
+        ScopedTimer t(ctx, kTimerTraceClosest);
+        launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB, bound, ctx->scene.host_copy.bvh_flat != 0u, ctx->round_mirror, tag, pass_stat, ctx->cross_mode);
+      }
+      shade(set, bound);
+      set ^= 1u;
+      rounds++;
+      plan.rounds_enqueued++;
+    }
+    tail(set, bound);
+    rounds++;
+    return 0;
+  }
   // Alive paths are bounded by depth plus roulette, but boundary crossings do not add depth: the loop runs until the
   // device reports no active path (a path that never ends would be a defect, reported as an error - never a silent cut).
   const uint64_t max_rounds = uint64_t(ctx->scene.host_copy.max_path_length) * 64ull + 4096ull;
@@ -524,6 +560,7 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
     shade(set, known_count);
     set ^= 1u;
     rounds++;
+    plan.rounds_enqueued++;
     // wait until the device is at most `run_ahead` rounds behind what has been enqueued
     // (a few hundred polls cover the rounds of a busy pass; after that the thread sleeps between polls instead of keeping a host core
     // at 100 % per lane, and asks the stream for errors about once per millisecond)
@@ -933,6 +970,20 @@ int execute_iteration(etx_hip_context* lane, uint32_t iteration) {
     (void)hipEventElapsedTime(&ms, lane->iteration_begin, lane->iteration_end);
     collect_stats(lane);
     lane->stats.last_iteration_time = double(ms) * 1.0e-3;
+    // the next iteration's launch plans: what every round of this one found (the stream is idle, every mirror entry has arrived)
+    for (etx_hip_context::PassPlan& plan : lane->plans) {
+      plan.entering.clear();
+      for (uint32_t r = 0; (r < plan.rounds_enqueued) && (r < kRoundMirrorSlots); ++r) {
+        const uint32_t tag = plan.first_tag + r;
+        const unsigned long long entry = lane->round_mirror[tag & (kRoundMirrorSlots - 1u)];
+        if (uint32_t(entry >> 32u) != tag + 1u)
+          break;  // overwritten by a later round of a pass longer than the ring: no plan, the next iteration polls
+        plan.entering.push_back(uint32_t(entry & 0xffffffffull));
+      }
+      if (plan.entering.size() != plan.rounds_enqueued)
+        plan.entering.clear();
+      plan.rounds_enqueued = 0u;
+    }
     const uint32_t flags = lane->stats.overflow_flags;
     if (flags == 0u)
       return ETX_HIP_OK;
@@ -1029,6 +1080,7 @@ int init_lane(etx_hip_context* lane, int device, std::string& error) {
   memset(lane->round_mirror, 0, kRoundMirrorSlots * sizeof(unsigned long long));
   lane->check_interval = std::max(1u, etxh::tuning_knob("ETX_HIP_CHECK_INTERVAL", lane->check_interval));
   lane->tail_divisor = etxh::tuning_knob("ETX_HIP_TAIL_DIVISOR", lane->tail_divisor);
+  lane->scheduled_passes = etxh::tuning_knob("ETX_HIP_SCHEDULED_PASSES", 1u) != 0u;
   lane->timer_mask = etxh::tuning_knob("ETX_HIP_TIMERS", lane->timer_mask);
   lane->debug_flags = etxh::tuning_knob("ETX_HIP_DEBUG_FLAGS", 0u);
   lane->worker = std::thread(lane_worker, lane);
@@ -1507,7 +1559,9 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
   context->pipe.adaptive_sum = (noise_threshold > 0.0f) ? context->adaptive_sum : nullptr;
   context->pipe.pixel_state = (noise_threshold > 0.0f) ? context->pixel_state : nullptr;
   context->active_lanes = lanes_wanted;
+  context->plans[0] = context->plans[1] = {};  // launch plans belong to a run (integrator, options, scene)
   for (etx_hip_context* helper : context->helpers) {
+    helper->plans[0] = helper->plans[1] = {};
     helper->noise_threshold = noise_threshold;
     helper->pipe.adaptive_sum = context->pipe.adaptive_sum;
     helper->pipe.pixel_state = context->pipe.pixel_state;

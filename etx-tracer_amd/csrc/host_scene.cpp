@@ -1050,6 +1050,17 @@ int build_traversal_tables(const etx_abi_scene* scene, DeviceScene& out, DScene&
       }  // a degenerate primitive keeps a zero plane: den = 0 -> never hit
       memcpy(&p.flags, &t.e1_flags.w, 4);
       memcpy(&p.material, &t.e2_mat.w, 4);
+      // a medium boundary: the medium a ray is in after crossing the primitive against (`medium_against`) or along (`medium_along`) the plane
+      // normal N - Medium::Instance of rt.cxx:569-573 (entering = dot(geo_n, direction) < 0 -> int_medium) with the side test moved to N,
+      // which the sweep has in scalar registers (the crossing then needs no gather of triangle and material)
+      p.medium_against = p.medium_along = ETX_ABI_INVALID;
+      if ((p.flags & kTriBoundary) && (p.material < scene->materials.count)) {
+        const etx_abi_material& m = reinterpret_cast<const etx_abi_material*>(scene->materials.a)[p.material];
+        const etx_abi_float3& g = reinterpret_cast<const etx_abi_triangle*>(scene->triangles.a)[infos[i].tri_a].geo_n;
+        const bool same_side = (n[0] * g.x + n[1] * g.y + n[2] * g.z) >= 0.0;
+        p.medium_against = same_side ? m.int_medium : m.ext_medium;
+        p.medium_along = same_side ? m.ext_medium : m.int_medium;
+      }
     }
     if ((rc = upload(out, prims.data(), prims.size(), d.flat_prims, error)) || (rc = upload(out, infos.data(), infos.size(), d.flat_info, error)))
       return rc;

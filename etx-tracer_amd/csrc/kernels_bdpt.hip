@@ -1118,7 +1118,7 @@ template <bool kOnlySimple>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs(Pipeline p, VcmParams it) {
   __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
-  const uint32_t count = min(p.counters[kCntPairs], p.pair_capacity);
+  const uint32_t count = pair_list_count(p);
   ETX_BLOCK_LOOP(count, i) {
     ShadowRequest request;
     bool queue = false;
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs_general(Pipel
   __shared__ uint32_t s_queue[2u * kBlockSize];
   __shared__ uint32_t s_queued;
   const DScene& scene = p.scene;
-  const uint32_t count = min(p.counters[kCntPairs], p.pair_capacity);
+  const uint32_t count = pair_list_count(p);
   if (threadIdx.x == 0u)
     s_queued = 0u;
   __syncthreads();

@@ -101,11 +101,13 @@ __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmPara
   }
 }
 
+// `classify`: the scene holds connectible materials other than Lambert, so a pair is routed by the classes of its two vertices (two dependent
+// gathers each). In a scene of Lambert / delta materials every stored vertex is Lambert or a medium vertex: nothing to look up.
 template <bool kDiffuseOnly>
-__global__ __launch_bounds__(kBlockSize) void k_connect_pairs(Pipeline p, VcmParams it) {
+__global__ __launch_bounds__(kBlockSize) void k_connect_pairs(Pipeline p, VcmParams it, uint32_t classify) {
   __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
-  const uint32_t count = min(p.counters[kCntPairs], p.pair_capacity);
+  const uint32_t count = pair_list_count(p);
   ETX_BLOCK_LOOP(count, i) {
     ShadowRequest request;
     bool queue = false;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(kBlockSize) void k_connect_pairs(Pipeline p, VcmPar
       LightVertex lv = load_light_vertex(p.lv, pair.y);
       const uint32_t cam_tri = __float_as_uint(p.cv.hit[pair.x].w);
       const bool cam_exit = (__float_as_uint(p.cv.thr_depth[pair.x].w) & kCvExitMaterialBit) != 0u;  // subsurface exit point: white Lambert
-      bool all_diffuse = ((cam_tri == kInvalid) || cam_exit || material_is_diffuse(scene, cam_tri)) && (lv.is_medium() || material_is_diffuse(scene, lv.tri));
+      bool all_diffuse = (classify == 0u) || (((cam_tri == kInvalid) || cam_exit || material_is_diffuse(scene, cam_tri)) && (lv.is_medium() || material_is_diffuse(scene, lv.tri)));
       if (all_diffuse == kDiffuseOnly) {
         CameraVertex cv = load_camera_vertex(p, scene, pair.x);
         const uint32_t target_path_length = cv.st.depth + lv.index_in_path + 2u;  // vcm_shared.hxx:774
@@ -182,9 +184,9 @@ void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it, 
   const uint32_t blocks = max(1u, grid_for(max_items));
   const uint32_t pair_blocks = max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 8ull, uint64_t(p.pair_capacity)))));
   hipLaunchKernelGGL(k_expand_pairs<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
-  hipLaunchKernelGGL(k_connect_pairs<true>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
+  hipLaunchKernelGGL(k_connect_pairs<true>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it, generic_materials ? 1u : 0u);
   if (generic_materials)
-    hipLaunchKernelGGL(k_connect_pairs<false>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
+    hipLaunchKernelGGL(k_connect_pairs<false>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
