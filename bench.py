@@ -332,7 +332,8 @@ def main(argv=None, context_factory=None, backend="nccl"):
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": (round(trace_pmc["hbm_bytes_per_unit"] * acc["rays"] / max(acc["launches"], 1)) if trace_pmc and trace_pmc["hbm_bytes_per_unit"] else None),
                 "traffic_note": ("HBM bytes per average launch = PMC bytes per ray of the traversal kernel INSIDE a one-lane run of this pipeline (%s B: FETCH_SIZE x 2 + WRITE_SIZE of %s, %s) "
-                                 "x rays per launch of the timed region; algorithmic 48 B per ray" % (trace_pmc["hbm_bytes_per_unit"], ", ".join(trace_pmc["kernels"]), pmc_source))
+                                 "x rays per launch of the timed region; algorithmic 48 B per ray. A query that crosses a medium boundary also rewrites its path's ray, medium and "
+                                 "path distance (about 112 B of state per crossing, counters.boundary_crossings_per_sample)" % (trace_pmc["hbm_bytes_per_unit"], ", ".join(trace_pmc["kernels"]), pmc_source))
                                 if trace_pmc and trace_pmc["hbm_bytes_per_unit"] else "no committed PMC summary of this workload names the traversal kernel of this build",
                 "bytes_per_ray": BYTES_PER_RAY,
                 "rays": acc["rays"],

@@ -17,8 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROFILES = os.path.join(ROOT, "profiles")
 
 # kernel-name prefixes of the groups bench.py times (host_api.cpp: which launches sit inside which timer)
+# (k_trace_closest<true / _bvh<true: the pipeline's kernels - kFromCounter; the <false instantiations are bench.py's isolated launches over a fixed queue)
 VCM_GROUPS = {
-    "trace_closest": ("k_trace_closest",),
+    "trace_closest": ("k_trace_closest<true", "k_trace_closest_bvh<true"),
     "trace_shadow": ("k_trace_shadow",),
     "shade_light": ("k_light_shade", "k_path_tail<false", "k_connect_endpoints<false"),
     "shade_camera": ("k_camera_shade", "k_path_tail<true", "k_connect_endpoints<true"),
@@ -27,7 +28,7 @@ VCM_GROUPS = {
     "grid_build": ("k_grid_", "k_scan_"),
 }
 BDPT_GROUPS = {
-    "trace_closest": ("k_trace_closest",),
+    "trace_closest": ("k_trace_closest<true", "k_trace_closest_bvh<true"),
     "trace_shadow": ("k_trace_shadow",),
     "shade_light": ("k_bdpt_light_shade", "k_bdpt_walk_light", "k_bdpt_walk_exit_light", "k_bdpt_connect_camera"),
     "shade_camera": ("k_bdpt_camera_shade", "k_bdpt_walk_camera", "k_bdpt_walk_exit_camera", "k_bdpt_connect_light"),
