@@ -279,7 +279,15 @@ def main(argv=None, context_factory=None, backend="nccl"):
     if kernels is not None:
         for group, prefixes in pmc_groups.items():
             if group in kernels:
-                kernels[group]["counters_1lane"] = profile_lookup.group_counters(pmc, prefixes, profile_lookup.GROUP_UNITS[group])
+                row = profile_lookup.group_counters(pmc, prefixes, profile_lookup.GROUP_UNITS[group])
+                kernels[group]["counters_1lane"] = row
+                if row and row.get("ms_per_step") and kernels[group]["units_per_step"]:
+                    # the group ALONE on the device (one lane: no other iteration's kernels share the CUs): the algorithmic bytes of this run's
+                    # units over the kernel time of the profiled one-lane run, scaled by the units of that run
+                    bytes_per_unit = kernels[group]["achieved"] * 1.0e9 * kernels[group]["ms_per_step"] * 1.0e-3 / kernels[group]["units_per_step"]
+                    exclusive = bytes_per_unit * row["units_per_step_profiled"] / (row["ms_per_step"] * 1.0e-3) / 1.0e9 if row.get("units_per_step_profiled") else None
+                    kernels[group]["exclusive_1lane"] = {"ms_per_step": row["ms_per_step"], "achieved": round(exclusive, 1) if exclusive else None,
+                                                         "frac": round(exclusive / HBM_PEAK_GBS, 5) if exclusive else None}
         kernels["counters_1lane_source"] = pmc_source
 
     dominant = None
