@@ -44,13 +44,35 @@ ETX_DEV float collimation_to_exponent(float normalized) {  // scene.hxx:67-71
   return 1.0f / fmaxf(kEpsilon, denom);
 }
 
+// The emitter records (32 bytes) and their profiles (48 bytes, 16-byte aligned) sit in tables the upload aligns: read as whole 16-byte rows - two and
+// three loads instead of a dword gather per field (a gather costs the same whatever its width) - and handed on by value.
+ETX_DEV etx_abi_emitter load_emitter(const DScene& s, uint32_t index) {
+  const float4* r = reinterpret_cast<const float4*>(s.emitters + index);
+  const float4 a = r[0], b = r[1];
+  etx_abi_emitter e;
+  e.cls = __float_as_uint(a.x), e.profile = __float_as_uint(a.y), e.triangle_index = __float_as_uint(a.z);
+  e.spectrum_weight = a.w, e.additional_weight = b.x, e.triangle_area = b.y, e.pad0 = 0.0f, e.pad1 = 0.0f;
+  return e;
+}
+ETX_DEV etx_abi_emitter_profile load_emitter_profile(const DScene& s, uint32_t index) {
+  const float4* r = reinterpret_cast<const float4*>(s.emitter_profiles + index);
+  const float4 a = r[0], b = r[1], c = r[2];
+  etx_abi_emitter_profile p;
+  p.emission.spectrum_index = __float_as_uint(a.x), p.emission.image_index = __float_as_uint(a.y);
+  p.direction = {a.z, a.w, b.x};
+  p.cls = __float_as_uint(b.y);
+  p.angular_size = b.z, p.equivalent_disk_size = b.w, p.angular_size_cosine = c.x, p.pad0 = 0.0f, p.pad1 = 0.0f;
+  return p;
+}
+static_assert((sizeof(etx_abi_emitter) == 32) && (sizeof(etx_abi_emitter_profile) == 48), "row loads of the emitter tables");
+
 ETX_DEV uint32_t emitter_external_medium_index(const DScene& s, const etx_abi_emitter& em) {  // scene_emitters.hxx:10-19
   if ((em.cls != ETX_EMITTER_AREA) || (em.triangle_index >= s.triangle_count))
     return kInvalid;
-  const etx_abi_triangle& tri = s.triangles[em.triangle_index];
-  if (tri.material_index >= s.material_count)
+  const uint32_t material_index = __float_as_uint(s.tri_shade[size_t(em.triangle_index) * kTriShadeStride + 6u].w);  // row 6: geometric normal, material
+  if (material_index >= s.material_count)
     return kInvalid;
-  return s.materials[tri.material_index].ext_medium;
+  return s.materials[material_index].ext_medium;
 }
 
 ETX_DEV float emitter_discrete_pdf(const DScene& s, const etx_abi_emitter& em) {  // scene_emitters.hxx:205-207
@@ -62,8 +84,8 @@ ETX_DEV float env_pdf_area(const DScene& s) {
 }
 
 // scene_emitters.hxx:40-105 emitter_get_radiance
-ETX_DEV f3 emitter_get_radiance(const DScene& s, const etx_abi_emitter& em_inst, const EmitterRadianceQuery& q, float& pdf_area, float& pdf_dir, float& pdf_dir_out, float wavelength) {
-  const etx_abi_emitter_profile& em = s.emitter_profiles[em_inst.profile];
+ETX_DEV f3 emitter_get_radiance(const DScene& s, const etx_abi_emitter& em_inst, const etx_abi_emitter_profile& em, const EmitterRadianceQuery& q, float& pdf_area, float& pdf_dir,
+  float& pdf_dir_out, float wavelength) {
   pdf_dir = 0.0f, pdf_area = 0.0f, pdf_dir_out = 0.0f;
   switch (em_inst.cls) {
     case ETX_EMITTER_DIRECTIONAL: {
@@ -89,9 +111,9 @@ ETX_DEV f3 emitter_get_radiance(const DScene& s, const etx_abi_emitter& em_inst,
       return eval;
     }
     default: {  // Area
-      const etx_abi_triangle& tri = s.triangles[em_inst.triangle_index];
-      const etx_abi_material& material = s.materials[tri.material_index];
-      f3 geo_n = ld3(tri.geo_n);
+      const float4 row = s.tri_shade[size_t(em_inst.triangle_index) * kTriShadeStride + 6u];  // geometric normal, material index
+      const etx_abi_material& material = s.materials[__float_as_uint(row.w)];
+      f3 geo_n = xyz(row);
       if (dot(geo_n, q.target_position - q.source_position) >= 0.0f)
         return mk3(0.0f);
       pdf_area = 1.0f / em_inst.triangle_area;
@@ -111,10 +133,14 @@ ETX_DEV f3 emitter_get_radiance(const DScene& s, const etx_abi_emitter& em_inst,
   }
 }
 
+ETX_DEV f3 emitter_get_radiance(const DScene& s, const etx_abi_emitter& em_inst, const EmitterRadianceQuery& q, float& pdf_area, float& pdf_dir, float& pdf_dir_out, float wavelength) {
+  return emitter_get_radiance(s, em_inst, load_emitter_profile(s, em_inst.profile), q, pdf_area, pdf_dir, pdf_dir_out, wavelength);
+}
+
 // scene_emitters.hxx:139-203 emitter_sample_in + :216-224 sample_emitter
 ETX_DEV EmitterSample sample_emitter(const DScene& s, uint32_t emitter_index, const f2 smp, const f3& from_point, float wavelength) {
-  const etx_abi_emitter& em_inst = s.emitters[emitter_index];
-  const etx_abi_emitter_profile& em = s.emitter_profiles[em_inst.profile];
+  const etx_abi_emitter em_inst = load_emitter(s, emitter_index);
+  const etx_abi_emitter_profile em = load_emitter_profile(s, em_inst.profile);
   EmitterSample r = emitter_sample_zero();
   switch (em_inst.cls) {
     case ETX_EMITTER_AREA: {
@@ -127,7 +153,7 @@ ETX_DEV EmitterSample sample_emitter(const DScene& s, uint32_t emitter_index, co
       q.target_position = r.origin;
       q.direction = mk3(0.0f);
       q.directly_visible = false;
-      r.value = emitter_get_radiance(s, em_inst, q, r.pdf_area, r.pdf_dir, r.pdf_dir_out, wavelength);
+      r.value = emitter_get_radiance(s, em_inst, em, q, r.pdf_area, r.pdf_dir, r.pdf_dir_out, wavelength);
       break;
     }
     case ETX_EMITTER_DIRECTIONAL: {
@@ -181,8 +207,8 @@ ETX_DEV EmitterSample sample_emission(const DScene& s, Sampler& smp, float wavel
   EmitterSample r = emitter_sample_zero();
   r.emitter_index = distribution_sample(s.emitter_dist, s.emitter_dist_count, smp.next());
   r.pdf_sample = s.emitter_dist[r.emitter_index].pdf;
-  const etx_abi_emitter& em_inst = s.emitters[r.emitter_index];
-  const etx_abi_emitter_profile& em = s.emitter_profiles[em_inst.profile];
+  const etx_abi_emitter em_inst = load_emitter(s, r.emitter_index);
+  const etx_abi_emitter_profile em = load_emitter_profile(s, em_inst.profile);
   switch (em_inst.cls) {
     case ETX_EMITTER_AREA: {
       const etx_abi_triangle& tri = s.triangles[em_inst.triangle_index];

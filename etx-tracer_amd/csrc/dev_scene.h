@@ -381,7 +381,10 @@ struct Isect : public Vtx {
   f3 geo_n;  // the triangle's geometric normal (row 6 comes with the shading point)
 };
 
-ETX_DEV const float4* tri_rows(const DScene& s, const etx_abi_triangle& t) {
+// (Reading the rows through the constant address space, whose loads the compiler may re-use across the kernels' stores, changed nothing: the uses sit
+// in different conditional blocks and are issued again either way - 697 vector loads in k_camera_shade<0,false> with and without.)
+typedef const float4* TriRowsPtr;
+ETX_DEV TriRowsPtr tri_rows(const DScene& s, const etx_abi_triangle& t) {
   return s.tri_shade + size_t(&t - s.triangles) * kTriShadeStride;
 }
 ETX_DEV f3 xyz(const float4& v) {
@@ -389,7 +392,7 @@ ETX_DEV f3 xyz(const float4& v) {
 }
 
 ETX_DEV TriVerts load_tri_verts(const DScene& s, const etx_abi_triangle& t) {
-  const float4* r = tri_rows(s, t);
+  const TriRowsPtr r = tri_rows(s, t);
   return {xyz(r[0]), xyz(r[1]), xyz(r[2]), xyz(r[3]), xyz(r[4]), xyz(r[5]), xyz(r[6])};
 }
 
@@ -401,7 +404,7 @@ struct TriPoint {  // the interpolated vertex and what came with the triangle's 
 };
 
 ETX_DEV TriPoint lerp_tri_point(const DScene& s, const etx_abi_triangle& t, const f3& bc) {
-  const float4* r = tri_rows(s, t);
+  const TriRowsPtr r = tri_rows(s, t);
   const float4 p0 = r[0], p1 = r[1], p2 = r[2], n0 = r[3], n1 = r[4], n2 = r[5], g = r[6];
   const float4 t0 = r[7], t1 = r[8], t2 = r[9], b0 = r[10], b1 = r[11], b2 = r[12];
   TriPoint out;
@@ -425,21 +428,21 @@ ETX_DEV Vtx lerp_vertex(const DScene& s, const etx_abi_triangle& t, const f3& bc
 }
 
 ETX_DEV f3 lerp_pos(const DScene& s, const etx_abi_triangle& t, const f3& bc) {  // scene.hxx:77-81
-  const float4* r = tri_rows(s, t);
+  const TriRowsPtr r = tri_rows(s, t);
   return xyz(r[0]) * bc.x + xyz(r[1]) * bc.y + xyz(r[2]) * bc.z;
 }
 ETX_DEV f3 lerp_normal(const DScene& s, const etx_abi_triangle& t, const f3& bc) {  // scene.hxx:83-87
-  const float4* r = tri_rows(s, t);
+  const TriRowsPtr r = tri_rows(s, t);
   return normalize(xyz(r[3]) * bc.x + xyz(r[4]) * bc.y + xyz(r[5]) * bc.z);
 }
 ETX_DEV f2 lerp_uv(const DScene& s, const etx_abi_triangle& t, const f3& b) {  // scene.hxx:103-107
-  const float4* r = tri_rows(s, t);
+  const TriRowsPtr r = tri_rows(s, t);
   const float4 p0 = r[0], p1 = r[1], p2 = r[2], n0 = r[3], n1 = r[4], n2 = r[5];
   return {p0.w * b.x + p1.w * b.y + p2.w * b.z, n0.w * b.x + n1.w * b.y + n2.w * b.z};
 }
 // position, normal and texture coordinate of a point of a triangle from the six rows they share (area emitters: sample_emitter)
 ETX_DEV void lerp_pos_normal_uv(const DScene& s, const etx_abi_triangle& t, const f3& b, f3& pos, f3& nrm, f2& uv) {
-  const float4* r = tri_rows(s, t);
+  const TriRowsPtr r = tri_rows(s, t);
   const float4 p0 = r[0], p1 = r[1], p2 = r[2], n0 = r[3], n1 = r[4], n2 = r[5];
   pos = xyz(p0) * b.x + xyz(p1) * b.y + xyz(p2) * b.z;
   nrm = normalize(xyz(n0) * b.x + xyz(n1) * b.y + xyz(n2) * b.z);
