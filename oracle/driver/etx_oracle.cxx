@@ -272,6 +272,8 @@ int main(int argc, char** argv) {
   float noise_threshold = -1.0f;  // < 0: keep the scene value
   int64_t subsurface_class = -1;  // >= 1: every subsurface material of the loaded scene gets this SubsurfaceMaterial::Class (1 random walk, 2 Christensen-Burley)
   uint32_t pixel_size = 0;      // >= 1: Film::set_pixel_size before the render (the GUI's preview while the camera moves, app.cxx:135)
+  float probe_ray[7] = {};
+  uint32_t probe_material = kInvalidIndex, probe_max_hits = 0;  // --probe-continuous-trace
   uint32_t inject_density = 0;  // N: every medium of the loaded scene becomes Heterogeneous with a procedural N^3 density grid
   for (int i = 1; i < argc; ++i) {
     auto next = [&]() -> const char* {
@@ -336,6 +338,15 @@ int main(int argc, char** argv) {
       fwrite(table.data(), 1, table.size(), f);
       fclose(f);
       return 0;
+    }
+    else if (strcmp(argv[i], "--probe-continuous-trace") == 0) {
+      // --probe-continuous-trace ox oy oz dx dy dz tmax material max_hits: after the scene is committed, Raytracing::continuous_trace
+      // (rt.cxx:373-426) along that ray; prints PROBE_HITS {"count": n, "t": [...], "triangle": [...]} and exits (tests: which hits the reference
+      // keeps when a probe ray of the Christensen-Burley gather meets more surfaces of its material than the buffer holds)
+      for (int k = 0; k < 7; ++k)
+        probe_ray[k] = float(atof(next()));
+      probe_material = uint32_t(atoll(next()));
+      probe_max_hits = uint32_t(atoll(next()));
     }
     else if (strcmp(argv[i], "--inject-density") == 0)
       inject_density = uint32_t(atoll(next()));
@@ -459,6 +470,22 @@ int main(int argc, char** argv) {
       printf("failed to write %s\n", snapshot_file.c_str());
       return 3;
     }
+  }
+
+  if (probe_max_hits > 0u) {
+    std::vector<IntersectionBase> hits(probe_max_hits);
+    const Ray ray = {{probe_ray[0], probe_ray[1], probe_ray[2]}, {probe_ray[3], probe_ray[4], probe_ray[5]}, kRayEpsilon, probe_ray[6]};
+    ContinousTraceOptions ct = {hits.data(), probe_max_hits, probe_material};
+    Sampler smp(1u, 2u);
+    const uint32_t count = raytracing.continuous_trace(sc, ray, ct, smp);
+    printf("PROBE_HITS {\"count\": %u, \"t\": [", count);
+    for (uint32_t k = 0; k < count; ++k)
+      printf("%s%.9g", k ? ", " : "", hits[k].t);
+    printf("], \"triangle\": [");
+    for (uint32_t k = 0; k < count; ++k)
+      printf("%s%u", k ? ", " : "", hits[k].triangle_index);
+    printf("]}\n");
+    return 0;
   }
 
   if (integrator_name == "none")

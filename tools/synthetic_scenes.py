@@ -112,3 +112,64 @@ def sss_dragon(etx, snapshot_path, subdivisions=(6, 5)):
     area = emitters[:, 2] != 0xFFFFFFFF  # etx_abi_emitter::triangle_index
     emitters[area, 2] = new_index[emitters[area, 2]].astype(np.uint32)
     return snap
+
+
+def sss_sheets(etx, snapshot_path, slabs=6, fill=0.6):
+    """-> SceneSnapshot of `snapshot_path` (a cornell_sss* box) whose first subsurface object is cut into `slabs` separate closed slabs stacked
+    along y (each `fill` of its share of the height thick): a probe ray of the Christensen-Burley gather that runs along the stack meets
+    2 * slabs surfaces of ONE material - more than the eight hits Raytracing::continuous_trace keeps (rt.cxx:412-421 keeps the first eight
+    in TRAVERSAL order; tests/test_gpu_sssmesh.py::test_more_than_eight_hits_along_a_probe)."""
+    snap = etx.SceneSnapshot(snapshot_path)
+    vertices, triangles, to_emitter = snap.vertices().copy(), snap.triangles().copy(), snap.triangle_to_emitter().copy()
+    sss_materials = np.nonzero(snap.materials()[:, 26] != 0)[0]  # etx_abi_material::subsurface.cls
+    if len(sss_materials) == 0:
+        raise ValueError("sss_sheets: no subsurface material in the scene")
+    material = sss_materials[0]
+    mine = triangles[:, 3] == material
+    corners = vertices[triangles[mine, 0:3].reshape(-1).astype(np.int64), 0:3]
+    lo, hi = corners.min(axis=0), corners.max(axis=0)
+    keep = ~mine
+    new_index = np.cumsum(keep) - 1
+    # one axis-aligned box = 6 faces x 4 vertices with face normals (flat shading), 12 outward-wound triangles
+    faces = (((0, -1), (1, 2)), ((0, +1), (2, 1)), ((1, -1), (2, 0)), ((1, +1), (0, 2)), ((2, -1), (0, 1)), ((2, +1), (1, 0)))
+    rows, tris = [], []
+    base = vertices.shape[0]
+    for k in range(slabs):
+        y0 = lo[1] + (hi[1] - lo[1]) * k / slabs
+        y1 = y0 + (hi[1] - lo[1]) * fill / slabs
+        blo, bhi = np.array([lo[0], y0, lo[2]]), np.array([hi[0], y1, hi[2]])
+        for (axis, sign), (ua, va) in faces:
+            n = np.zeros(3)
+            n[axis] = sign
+            t = np.zeros(3)
+            t[ua] = 1.0
+            b = np.cross(n, t)
+            quad = []
+            for (su, sv) in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                p = np.where(np.arange(3) == axis, bhi if sign > 0 else blo, 0.0)
+                p[ua] = bhi[ua] if su else blo[ua]
+                p[va] = bhi[va] if sv else blo[va]
+                quad.append(p)
+            # outward winding: (q1 - q0) x (q3 - q0) must point along n
+            if np.dot(np.cross(quad[1] - quad[0], quad[3] - quad[0]), n) < 0.0:
+                quad = [quad[0], quad[3], quad[2], quad[1]]
+            for i, p in enumerate(quad):
+                row = np.zeros(14, dtype=np.float32)
+                row[0:3], row[3:6], row[6:9], row[9:12] = p, n, t, b
+                row[12:14] = ((0, 0), (1, 0), (1, 1), (0, 1))[i]
+                rows.append(row)
+            for a, bq, c in ((0, 1, 2), (0, 2, 3)):
+                tri = np.zeros(8, dtype=np.uint32)
+                tri[0:3] = base + np.array([a, bq, c], dtype=np.uint32)
+                tri[3] = material
+                tri[4:7] = n.astype(np.float32).view(np.uint32)
+                tris.append(tri)
+            base += 4
+    all_triangles = np.concatenate([triangles[keep], np.array(tris, dtype=np.uint32)])
+    kept_emitters = to_emitter[keep]
+    snap.replace_geometry(np.concatenate([vertices, np.array(rows, dtype=np.float32)]), all_triangles,
+                          np.concatenate([kept_emitters, np.full(all_triangles.shape[0] - kept_emitters.shape[0], 0xFFFFFFFF, dtype=np.uint32)]))
+    emitters = snap.emitter_instances()
+    area = emitters[:, 2] != 0xFFFFFFFF
+    emitters[area, 2] = new_index[emitters[area, 2]].astype(np.uint32)
+    return snap
