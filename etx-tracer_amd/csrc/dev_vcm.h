@@ -263,15 +263,27 @@ ETX_DEV void write_endpoint(const Pipeline& p, uint32_t idx, const float4& hit_o
 }
 
 // vcm_shared.hxx:218-283 vcm_next_ray
+// The material of a shading point as the simple shading group reads it (Lambert / translucent / mirror / delta conductor / boundary): the head of the
+// reference's 200-byte record (reflectance, scattering, emission) and its scalar tail (class .. emission collimation) copied ONCE per shading point -
+// adjacent fields read in one place become five wide loads - into a local record the step's helpers take instead of looking the table up again after
+// every store (a step read the class, the scattering colour's indices and its colour four times over). The general groups keep the table reference
+// (their out-of-line BSDFs take the material by index).
+ETX_DEV void load_simple_material(const DScene& scene, uint32_t index, etx_abi_material& m) {
+  const etx_abi_material& t = scene.materials[index];
+  m.reflectance = t.reflectance, m.scattering = t.scattering, m.emission = t.emission;
+  m.cls = t.cls, m.int_medium = t.int_medium, m.ext_medium = t.ext_medium, m.normal_image_index = t.normal_image_index, m.diffuse_variation = t.diffuse_variation;
+  m.two_sided = t.two_sided, m.normal_scale = t.normal_scale, m.opacity = t.opacity, m.emission_collimation = t.emission_collimation;
+  m.ext_ior = t.ext_ior, m.int_ior = t.int_ior;  // (the delta conductor of the simple group; they sit right before the class: one more wide load)
+}
+
 template <bool kSimple>
 ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& st, const VcmParams& it, const Isect& isect, const BsdfData& bsdf_data, const BsdfSample& bs,
-  bool subsurface_sample = false) {
+  bool subsurface_sample, const etx_abi_material& mat) {
   if (st.depth + 1 > scene.max_path_length)
     return false;
   if (bs.valid() == false)
     return false;
   const etx_abi_triangle& tri = scene.triangles[isect.tri];
-  const etx_abi_material& mat = scene.materials[isect.material];
   st.throughput *= bs.weight;
   if (path_source == kPathLight)
     st.throughput *= fix_shading_normal(isect.geo_n, isect.nrm, isect.w_i, bs.w_o);
@@ -302,9 +314,14 @@ ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& 
   return true;
 }
 
+template <bool kSimple>
+ETX_DEV bool vcm_next_ray(const DScene& scene, uint32_t path_source, PathState& st, const VcmParams& it, const Isect& isect, const BsdfData& bsdf_data, const BsdfSample& bs,
+  bool subsurface_sample = false) {
+  return vcm_next_ray<kSimple>(scene, path_source, st, it, isect, bsdf_data, bs, subsurface_sample, scene.materials[isect.material]);
+}
+
 // vcm_shared.hxx:436-449 vcm_handle_boundary_bsdf
-ETX_DEV bool vcm_handle_boundary(const DScene& scene, const Isect& isect, PathState& st) {
-  const etx_abi_material& mat = scene.materials[isect.material];
+ETX_DEV bool vcm_handle_boundary(const DScene& scene, const Isect& isect, PathState& st, const etx_abi_material& mat) {
   if (mat.cls != ETX_MAT_BOUNDARY)
     return false;
   uint32_t new_medium = (dot(isect.geo_n, st.ray_d) < 0.0f) ? mat.int_medium : mat.ext_medium;
@@ -315,12 +332,16 @@ ETX_DEV bool vcm_handle_boundary(const DScene& scene, const Isect& isect, PathSt
   st.ray_tmin = kRayEpsilon;
   return true;
 }
+ETX_DEV bool vcm_handle_boundary(const DScene& scene, const Isect& isect, PathState& st) {
+  return vcm_handle_boundary(scene, isect, st, scene.materials[isect.material]);
+}
 
 // vcm_shared.hxx:463-535 vcm_connect_to_camera, minus the transmittance: queues the segment, the splat value
 // (vcm_cpu.cxx:148-153) is completed by k_trace_shadow.
 // Returns true when `out` holds a request for the shadow queue.
 template <bool kSimple>
-ETX_DEV bool vcm_connect_to_camera(const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st, ShadowRequest& out) {
+ETX_DEV bool vcm_connect_to_camera(const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st, ShadowRequest& out,
+  const etx_abi_material& mat) {  // mat: the vertex' material (unused at a medium vertex)
   if ((opt_connect_to_camera(it) == false) || (st.depth + 2 > scene.max_path_length) || (st.depth + 2 < scene.min_path_length))
     return false;
   f3 sample_pos = camera_at_medium ? medium_pos : isect->pos;
@@ -336,7 +357,6 @@ ETX_DEV bool vcm_connect_to_camera(const DScene& scene, const VcmParams& it, boo
   float reverse_pdf = 0.0f;
   f3 origin = sample_pos;
   if (camera_at_medium == false) {
-    const etx_abi_material& mat = scene.materials[isect->material];
     BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathLight, st.wavelength);
     BsdfEval eval = bsdf_evaluate_s<kSimple>(scene, data, w_o, mat, st.sampler);
     if (eval.valid() == false)
@@ -430,7 +450,8 @@ ETX_DEV f3 vcm_cam_handle_miss(const DScene& scene, const VcmParams& it, PathSta
 // sampler.fixed_* hold (rnd_connection.xy, rnd_support.y). `film_target` = film index of the path's pixel.
 // Returns true when `out` holds a request for the shadow queue.
 template <bool kSimple>
-ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st, uint32_t film_target, ShadowRequest& out) {
+ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool camera_at_medium, const Isect* isect, const f3& medium_pos, PathState& st, uint32_t film_target, ShadowRequest& out,
+  const etx_abi_material& mat) {  // mat: the vertex' material (unused at a medium vertex)
   if ((opt_connect_to_light(it) == false) || (st.depth + 1 > scene.max_path_length) || (st.depth + 1 < scene.min_path_length))
     return false;
   f3 sample_pos = camera_at_medium ? medium_pos : isect->pos;
@@ -452,7 +473,6 @@ ETX_DEV bool vcm_connect_to_light(const DScene& scene, const VcmParams& it, bool
     scatter = mk3(p);
     reverse_pdf = phase_function(w_o, st.ray_d, medium.g);
   } else {
-    const etx_abi_material& mat = scene.materials[isect->material];
     BsdfData data = make_bsdf_data(*isect, isect->w_i, st.medium, kPathCamera, st.wavelength);
     BsdfEval eval = bsdf_evaluate_s<kSimple>(scene, data, w_o, mat, st.sampler);
     if (eval.valid() == false)

@@ -31,8 +31,8 @@ ETX_DEV void store_light_vertex(const Pipeline& p, uint32_t idx, const PathState
 
 
 // merge_histogram: the iteration merges photons - a vertex k_merge_scatter will sort counts itself into its coarse bucket here
-ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& scene, const PathState& st, const float4& hit_or_pos, uint32_t seed, const Isect* isect,
-  bool exit_material = false, uint32_t use_flags = 0u, bool merge_histogram = false) {
+ETX_DEV void store_camera_vertex_m(const Pipeline& p, uint32_t idx, const DScene& scene, const PathState& st, const float4& hit_or_pos, uint32_t seed, const Isect* isect,
+  const etx_abi_material& mat, bool exit_material = false, uint32_t use_flags = 0u, bool merge_histogram = false) {  // mat: the vertex' material (unused when isect == nullptr)
   if (idx >= p.cv_capacity) {  // the tail kernel, or more exit points of Christensen-Burley vertices than the pool was sized for
     atomicOr(p.counters + kCntOverflow, kOverflowCameraVertices);
     return;
@@ -47,7 +47,6 @@ ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& 
     p.cv.pos_info[idx] = make_float4(hit_or_pos.x, hit_or_pos.y, hit_or_pos.z, __uint_as_float((st.depth << 8u) | kCvMedium));
     return;
   }
-  const etx_abi_material& mat = scene.materials[isect->material];
   const bool diffuse = material_is_lambert(mat);
   f3 fthr = st.throughput;
   if (diffuse)
@@ -61,6 +60,10 @@ ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& 
     if (merge_candidate(g, scene.max_path_length, info, isect->pos))
       atomicAdd(p.merge_buckets + merge_bucket(g, isect->pos), 1u);
   }
+}
+ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& scene, const PathState& st, const float4& hit_or_pos, uint32_t seed, const Isect* isect,
+  bool exit_material = false, uint32_t use_flags = 0u, bool merge_histogram = false) {
+  store_camera_vertex_m(p, idx, scene, st, hit_or_pos, seed, isect, scene.materials[isect ? isect->material : 0u], exit_material, use_flags, merge_histogram);
 }
 
 
@@ -84,6 +87,8 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
   const uint32_t tri = __float_as_uint(h.w);
   const bool found = valid && (tri != kInvalid);
   Isect isect;
+  etx_abi_material simple_material;  // kSimple: the hit material's hot fields, read once (load_simple_material); never copied as a whole
+  const etx_abi_material& step_material = kSimple ? simple_material : scene.materials[(found && (kSimple == false)) ? scene.triangles[tri].material_index : 0u];
   MediumSample ms;
   ms.sampled_medium_t = 0.0f;
   uint32_t event = kEventNone;
@@ -101,8 +106,11 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
     // ---- phase A
     if (ms.sampled_medium())
       event = kEventMedium;
-    else if (found)
-      event = vcm_handle_boundary(scene, isect, st) ? kEventBoundary : kEventSurface;
+    else if (found) {
+      if (kSimple)
+        load_simple_material(scene, isect.material, simple_material);
+      event = vcm_handle_boundary(scene, isect, st, step_material) ? kEventBoundary : kEventSurface;
+    }
   }
   const bool scatter_event = (event == kEventMedium) || (event == kEventSurface);  // None: path ends, Boundary: continues as is
   const bool at_medium = event == kEventMedium;
@@ -124,7 +132,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
       store = opt_connect_vertices(it) && (st.depth + 1 <= scene.max_path_length);
       connect = opt_connect_to_camera(it) && scene.mediums[st.medium].explicit_connections && (st.depth + 1 <= scene.max_path_length);
     } else {
-      const etx_abi_material& mat = scene.materials[isect.material];
+      const etx_abi_material& mat = step_material;
       bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight, st.wavelength);
       st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
       bs = bsdf_sample_s<kSimple>(scene, bsdf_data, mat, st.sampler);
@@ -180,7 +188,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
     bool queue = false;
     if (connect) {
       st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-      queue = vcm_connect_to_camera<true>(scene, it, at_medium, &isect, ms.pos, st, request);
+      queue = vcm_connect_to_camera<true>(scene, it, at_medium, &isect, ms.pos, st, request, step_material);
       st.sampler.pop_fixed();
     }
     const uint32_t shadow_slot = slots.get(queue, p.counters + kCntShadow);
@@ -230,7 +238,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
     bsdf_data = make_bsdf_data(ss_isect, ss_isect.w_i, st.medium, kPathLight, st.wavelength);
     isect = ss_isect;
   }
-  if (vcm_next_ray<kSimple>(scene, kPathLight, st, it, isect, bsdf_data, bs, kWalk && subsurface_sampled))
+  if (vcm_next_ray<kSimple>(scene, kPathLight, st, it, isect, bsdf_data, bs, kWalk && subsurface_sampled, (kWalk && subsurface_sampled) ? scene.materials[isect.material] : step_material))
     return st.depth + 1u < scene.max_path_length;
   return false;
 }
@@ -245,6 +253,8 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
   const uint32_t tri = __float_as_uint(h.w);
   const bool found = valid && (tri != kInvalid);
   Isect isect;
+  etx_abi_material simple_material;  // as in light_step
+  const etx_abi_material& step_material = kSimple ? simple_material : scene.materials[(found && (kSimple == false)) ? scene.triangles[tri].material_index : 0u];
   MediumSample ms;
   ms.sampled_medium_t = 0.0f;
   uint32_t event = kEventNone;
@@ -258,8 +268,11 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
     // ---- phase A
     if (ms.sampled_medium())
       event = kEventMedium;
-    else if (found)
-      event = vcm_handle_boundary(scene, isect, st) ? kEventBoundary : kEventSurface;
+    else if (found) {
+      if (kSimple)
+        load_simple_material(scene, isect.material, simple_material);
+      event = vcm_handle_boundary(scene, isect, st, step_material) ? kEventBoundary : kEventSurface;
+    }
     if (event == kEventNone) {  // vcm_shared.hxx:997-1000
       f3 gathered = vcm_cam_handle_miss(scene, it, st);
       if ((gathered.x != 0.0f) || (gathered.y != 0.0f) || (gathered.z != 0.0f))
@@ -299,7 +312,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       nee = explicit_connections && opt_connect_to_light(it);
       store = explicit_connections && opt_connect_vertices(it);
     } else {
-      const etx_abi_material& mat = scene.materials[isect.material];
+      const etx_abi_material& mat = step_material;
       bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathCamera, st.wavelength);
       st.sampler.push_fixed(rnd_bsdf.x, rnd_bsdf.y, rnd_support.x);
       bs = bsdf_sample_s<kSimple>(scene, bsdf_data, mat, st.sampler);
@@ -396,7 +409,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       PathState c = st;
       c.sampler.push_fixed(rnd_connection.y, rnd_connection.x, rnd_support.y);
       ShadowRequest r2;
-      const bool q2 = vcm_connect_to_light<true>(scene, it, false, &isect, ms.pos, c, film_index(it, st.id), r2);
+      const bool q2 = vcm_connect_to_light<true>(scene, it, false, &isect, ms.pos, c, film_index(it, st.id), r2, step_material);
       sink += q2 ? r2.value.x + r2.p1.y : 0.0f;
     }
     if (sink == 1.2345e-33f)
@@ -419,7 +432,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       store_camera_vertex(p, vertex_slot, scene, scaled, make_float4(ss_isect.bc.y, ss_isect.bc.z, ss_isect.t, __uint_as_float(ss_isect.tri)), derived.seed, &ss_isect, true,
         cb_vertex ? kCvNoConnect : 0u, opt_merge_vertices(it));
     } else {
-      store_camera_vertex(p, vertex_slot, scene, st, h, derived.seed, &isect, false, 0u, opt_merge_vertices(it));
+      store_camera_vertex_m(p, vertex_slot, scene, st, h, derived.seed, &isect, step_material, false, 0u, opt_merge_vertices(it));
     }
   }
   // next event estimation; vcm_shared.hxx:1036-1046: after a walk, from the exit point scaled by the walk
@@ -429,7 +442,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
     bool queue = false;
     if (nee) {
       st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-      queue = vcm_connect_to_light<true>(scene, it, at_medium, &isect, ms.pos, st, film_index(it, st.id), request);
+      queue = vcm_connect_to_light<true>(scene, it, at_medium, &isect, ms.pos, st, film_index(it, st.id), request, step_material);
       st.sampler.pop_fixed();
     }
     const uint32_t shadow_slot = slots.get(queue, p.counters + kCntShadow);
@@ -474,7 +487,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
     bsdf_data = make_bsdf_data(ss_isect, ss_isect.w_i, st.medium, kPathCamera, st.wavelength);
     isect = ss_isect;
   }
-  return vcm_next_ray<kSimple>(scene, kPathCamera, st, it, isect, bsdf_data, bs, kWalk && subsurface_sampled);
+  return vcm_next_ray<kSimple>(scene, kPathCamera, st, it, isect, bsdf_data, bs, kWalk && subsurface_sampled, (kWalk && subsurface_sampled) ? scene.materials[isect.material] : step_material);
 }
 
 }  // namespace etxd

@@ -157,9 +157,9 @@ __global__ __launch_bounds__(kBlockSize) void k_connect_endpoints(Pipeline p, Vc
     if (i < count) {
       CameraVertex v = load_endpoint(p, scene, i);
       if (kCameraPass)
-        queue = vcm_connect_to_light<false>(scene, it, v.at_medium, &v.isect, v.medium_pos, v.st, film_index(it, v.st.id), request);
+        queue = vcm_connect_to_light<false>(scene, it, v.at_medium, &v.isect, v.medium_pos, v.st, film_index(it, v.st.id), request, scene.materials[v.at_medium ? 0u : v.isect.material]);
       else
-        queue = vcm_connect_to_camera<false>(scene, it, v.at_medium, &v.isect, v.medium_pos, v.st, request);
+        queue = vcm_connect_to_camera<false>(scene, it, v.at_medium, &v.isect, v.medium_pos, v.st, request, scene.materials[v.at_medium ? 0u : v.isect.material]);
     }
     const uint32_t slot = block_compact_slot(queue, p.counters + kCntShadow, s_scratch);
     if (queue)
