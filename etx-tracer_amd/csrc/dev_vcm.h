@@ -125,17 +125,65 @@ ETX_DEV uint32_t block_compact_slot(bool alive, uint32_t* counter, BlockScratch&
   return slot;
 }
 
+// Three reservations at once: the step functions of the simple shading group need a vertex slot, a shadow-queue slot and a slot in the next path
+// set per lane. Taken one after the other (above) a step met nine barriers and waited three times for an atomic's round trip to the L2; here the
+// three counters are scanned together - the same three barriers ONCE, thread 0 issues the three atomics back to back.
+struct BlockScratch3 {  // in LDS
+  uint32_t wave_total[3][kBlockSize / 64u];
+  uint32_t base[3];
+};
+struct Slots3 {
+  uint32_t a, b, c;
+};
+
+ETX_DEV Slots3 block_compact_slot3(bool fa, uint32_t* ca, bool fb, uint32_t* cb, bool fc, uint32_t* cc, BlockScratch3& scratch) {
+  const uint64_t ma = __ballot(fa), mb = __ballot(fb), mc = __ballot(fc);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6u;
+  auto prefix = [](uint64_t mask) { return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32u), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)); };
+  if (lane == 0u) {
+    scratch.wave_total[0][wave] = uint32_t(__popcll(ma));
+    scratch.wave_total[1][wave] = uint32_t(__popcll(mb));
+    scratch.wave_total[2][wave] = uint32_t(__popcll(mc));
+  }
+  __syncthreads();
+  if (threadIdx.x < 3u) {  // one lane per counter: the three atomics are in flight together
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlockSize / 64u; ++w)
+      total += scratch.wave_total[threadIdx.x][w];
+    uint32_t* counter = (threadIdx.x == 0u) ? ca : ((threadIdx.x == 1u) ? cb : cc);
+    scratch.base[threadIdx.x] = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  Slots3 r = {scratch.base[0] + prefix(ma), scratch.base[1] + prefix(mb), scratch.base[2] + prefix(mc)};
+#pragma unroll
+  for (uint32_t w = 0; w < kBlockSize / 64u; ++w) {
+    r.a += (w < wave) ? scratch.wave_total[0][w] : 0u;
+    r.b += (w < wave) ? scratch.wave_total[1][w] : 0u;
+    r.c += (w < wave) ? scratch.wave_total[2][w] : 0u;
+  }
+  __syncthreads();
+  return r;
+}
+
 // Slot reservation policy of the step functions (dev_vcm_steps.h). The wavefront kernels reserve per workgroup; the
 // tail kernels, whose lanes loop independently over the few surviving paths, reserve per lane.
 struct BlockSlots {
   BlockScratch* scratch;
+  BlockScratch3* scratch3;
   ETX_DEV uint32_t get(bool wanted, uint32_t* counter) const {
     return block_compact_slot(wanted, counter, *scratch);
+  }
+  ETX_DEV Slots3 get3(bool fa, uint32_t* ca, bool fb, uint32_t* cb, bool fc, uint32_t* cc) const {
+    return block_compact_slot3(fa, ca, fb, cb, fc, cc, *scratch3);
   }
 };
 struct LaneSlots {
   ETX_DEV uint32_t get(bool wanted, uint32_t* counter) const {
     return wanted ? atomicAdd(counter, 1u) : 0u;
+  }
+  ETX_DEV Slots3 get3(bool fa, uint32_t* ca, bool fb, uint32_t* cb, bool fc, uint32_t* cc) const {
+    return {get(fa, ca), get(fb, cb), get(fc, cc)};
   }
 };
 

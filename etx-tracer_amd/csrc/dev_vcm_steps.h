@@ -80,8 +80,13 @@ enum : uint32_t { kEventNone = 0, kEventMedium = 1, kEventSurface = 2, kEventBou
 // `slots.get(wanted, counter)` reserves queue / pool slots: the wavefront kernels call this function from
 // workgroup-uniform control flow (lanes without a path pass valid = false) and reserve once per workgroup, so the
 // reservation points sit outside every data-dependent branch.
+// `out` / `out_counter` (wavefront kernels; null in the tail kernels, whose lanes keep their path): the path set a surviving path is appended to.
+// The simple shading group takes its three slots - vertex, shadow request, next path set - with ONE reservation at the end of the step
+// (Slots::get3) and stores everything after it; the other groups reserve one by one as the step goes (their walks and endpoint requests reserve
+// inside data-dependent code anyway) and leave the path to the caller.
 template <uint32_t kGroup, class Slots>
-ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots, const LaneStack& stack) {
+ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots, const LaneStack& stack,
+  const PathSet* out = nullptr, uint32_t* out_counter = nullptr) {
   constexpr bool kSimple = kGroup == kShadeGroupSimple;      // BSDF classes compiled in (dev_bsdf_ool.h)
   constexpr bool kWalk = kGroup == kShadeGroupSubsurface;   // the subsurface random walk runs inline
   const uint32_t tri = __float_as_uint(h.w);
@@ -172,6 +177,67 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
     }
   }
 
+  // ---- phase C as a function: continue the path (phase function / vcm_next_ray, Russian roulette); true = alive, st advanced
+  auto continue_path = [&]() -> bool {
+    if (event == kEventBoundary)
+      return true;
+    if (scatter_event == false)
+      return false;
+    if (at_medium) {  // vcm_shared.hxx:1143-1169
+      const DMedium& med = scene.mediums[st.medium];
+      f3 w_i = st.ray_d;
+      f3 w_o = sample_phase_function(w_i, med.g, rnd_bsdf);
+      float pdf_fwd = phase_function(w_i, w_o, med.g);
+      float pdf_rev = phase_function(w_o, w_i, med.g);
+      st.d_vc = (1.0f / pdf_fwd) * (st.d_vc * pdf_rev + st.d_vcm);
+      st.d_vm = (1.0f / pdf_fwd) * (st.d_vm * pdf_rev + 0.0f);
+      st.d_vcm = 1.0f / pdf_fwd;
+      st.ray_o = ms.pos;
+      st.ray_d = w_o;
+      st.ray_tmax = kMaxFloat;
+      st.ray_tmin = kRayEpsilon;
+      st.depth += 1u;
+      return (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
+    }
+    if (subsurface_path && (subsurface_sampled == false))
+      return false;
+    if (kWalk && subsurface_sampled) {  // vcm_shared.hxx:1237-1247: continue from the exit point with a cosine lobe
+      st.throughput *= ss_weight;
+      bs.w_o = sample_cosine_distribution(rnd_bsdf, ss_isect.nrm, 1.0f);
+      bs.pdf = fabsf(dot(bs.w_o, ss_isect.nrm)) / kPi;
+      bs.eta = 1.0f;
+      bsdf_data = make_bsdf_data(ss_isect, ss_isect.w_i, st.medium, kPathLight, st.wavelength);
+      isect = ss_isect;
+    }
+    if (vcm_next_ray<kSimple>(scene, kPathLight, st, it, isect, bsdf_data, bs, kWalk && subsurface_sampled, (kWalk && subsurface_sampled) ? scene.materials[isect.material] : step_material))
+      return st.depth + 1u < scene.max_path_length;
+    return false;
+  };
+
+  if (kSimple) {  // Lambert / delta surfaces and media: connect inline; ONE reservation for vertex, shadow request and next path set
+    ShadowRequest request;
+    bool queue = false;
+    if (connect) {
+      st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+      queue = vcm_connect_to_camera<true>(scene, it, at_medium, &isect, ms.pos, st, request, step_material);
+      st.sampler.pop_fixed();
+    }
+    const PathState at_vertex = st;  // what the vertex record holds; phase C advances st
+    const bool alive = continue_path();
+    const Slots3 slot = slots.get3(store, p.counters + kCntLightVertices, queue, p.counters + kCntShadow, alive && (out != nullptr), out_counter);
+    if (store) {
+      if (at_medium)
+        store_light_vertex(p, slot.a, at_vertex, ms.pos, mk3(0.0f), 0.0f, 0.0f, kInvalid);
+      else
+        store_light_vertex(p, slot.a, at_vertex, isect.pos, isect.nrm, isect.bc.y, isect.bc.z, isect.tri);
+    }
+    if (queue)
+      write_shadow(p, slot.b, request);
+    if (alive && (out != nullptr))
+      store_path(*out, slot.c, st);
+    return alive;
+  }
+
   // ---- phase B
   const uint32_t vertex_slot = slots.get(store, p.counters + kCntLightVertices);
   if (store) {
@@ -183,18 +249,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
   // vcm_shared.hxx:1208-1222: after a walk the connection starts at the exit point, through the exit material, scaled by
   // the walk; when the walk failed the reference connects the entry vertex, then ends the path (:1223-1231, 1249-1251).
   const bool from_exit = kWalk && subsurface_sampled;
-  if (kSimple) {  // Lambert / delta surfaces and media: connect inline
-    ShadowRequest request;
-    bool queue = false;
-    if (connect) {
-      st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-      queue = vcm_connect_to_camera<true>(scene, it, at_medium, &isect, ms.pos, st, request, step_material);
-      st.sampler.pop_fixed();
-    }
-    const uint32_t shadow_slot = slots.get(queue, p.counters + kCntShadow);
-    if (queue)
-      write_shadow(p, shadow_slot, request);
-  } else {  // general BSDFs: the evaluation runs in k_connect_endpoints (pipeline.h EndpointQueue)
+  {  // general BSDFs: the evaluation runs in k_connect_endpoints (pipeline.h EndpointQueue)
     connect = connect && (st.depth + 2 <= scene.max_path_length) && (st.depth + 2 >= scene.min_path_length);  // the early-outs of vcm_connect_to_camera
     const uint32_t endpoint_slot = slots.get(connect, p.counters + kCntEndpoints);
     if (connect) {
@@ -208,46 +263,15 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
   }
 
   // ---- phase C
-  if (event == kEventBoundary)
-    return true;
-  if (scatter_event == false)
-    return false;
-  if (at_medium) {  // vcm_shared.hxx:1143-1169
-    const DMedium& med = scene.mediums[st.medium];
-    f3 w_i = st.ray_d;
-    f3 w_o = sample_phase_function(w_i, med.g, rnd_bsdf);
-    float pdf_fwd = phase_function(w_i, w_o, med.g);
-    float pdf_rev = phase_function(w_o, w_i, med.g);
-    st.d_vc = (1.0f / pdf_fwd) * (st.d_vc * pdf_rev + st.d_vcm);
-    st.d_vm = (1.0f / pdf_fwd) * (st.d_vm * pdf_rev + 0.0f);
-    st.d_vcm = 1.0f / pdf_fwd;
-    st.ray_o = ms.pos;
-    st.ray_d = w_o;
-    st.ray_tmax = kMaxFloat;
-    st.ray_tmin = kRayEpsilon;
-    st.depth += 1u;
-    return (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
-  }
-  if (subsurface_path && (subsurface_sampled == false))
-    return false;
-  if (kWalk && subsurface_sampled) {  // vcm_shared.hxx:1237-1247: continue from the exit point with a cosine lobe
-    st.throughput *= ss_weight;
-    bs.w_o = sample_cosine_distribution(rnd_bsdf, ss_isect.nrm, 1.0f);
-    bs.pdf = fabsf(dot(bs.w_o, ss_isect.nrm)) / kPi;
-    bs.eta = 1.0f;
-    bsdf_data = make_bsdf_data(ss_isect, ss_isect.w_i, st.medium, kPathLight, st.wavelength);
-    isect = ss_isect;
-  }
-  if (vcm_next_ray<kSimple>(scene, kPathLight, st, it, isect, bsdf_data, bs, kWalk && subsurface_sampled, (kWalk && subsurface_sampled) ? scene.materials[isect.material] : step_material))
-    return st.depth + 1u < scene.max_path_length;
-  return false;
+  return continue_path();
 }
 
 // vcm_camera_step, vcm_shared.hxx:927-1079 after rt.trace, without the vertex connections and the merge: connectible
 // vertices go to the camera vertex pool (k_expand_pairs / k_connect_pairs / k_merge consume them), NEE segments go to
 // the shadow queue, direct / miss radiance goes straight to the film. Same three-phase shape as light_step.
 template <uint32_t kGroup, class Slots>
-ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots, const LaneStack& stack) {
+ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots, const LaneStack& stack,
+  const PathSet* out = nullptr, uint32_t* out_counter = nullptr) {  // out / out_counter: as for light_step
   constexpr bool kSimple = kGroup == kShadeGroupSimple;
   constexpr bool kWalk = kGroup == kShadeGroupSubsurface;
   const uint32_t tri = __float_as_uint(h.w);
@@ -416,6 +440,62 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
       film_add(p, p.camera_sum + film_index(it, st.id), mk3(sink));
   }
 #endif
+  // ---- phase C as a function: continue the path; true = alive, st advanced
+  auto continue_path = [&]() -> bool {
+    if (event == kEventBoundary)
+      return true;
+    if (scatter_event == false)
+      return false;
+    if (at_medium) {  // vcm_shared.hxx:973-994
+      st.d_vc = (1.0f / pdf_fwd) * (st.d_vc * pdf_rev + st.d_vcm);
+      st.d_vm = (1.0f / pdf_fwd) * (st.d_vm * pdf_rev + 0.0f);
+      st.d_vcm = 1.0f / pdf_fwd;
+      st.ray_o = ms.pos;
+      st.ray_d = w_o_medium;
+      st.ray_tmax = kMaxFloat;
+      st.ray_tmin = kRayEpsilon;
+      st.depth += 1u;
+      return (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
+    }
+    if (subsurface_path && (subsurface_sampled == false))
+      return false;
+    if (kWalk && subsurface_sampled) {  // vcm_shared.hxx:1049-1061
+      st.throughput *= ss_weight;
+      bs.w_o = sample_cosine_distribution(rnd_bsdf, ss_isect.nrm, 1.0f);
+      bs.pdf = fabsf(dot(bs.w_o, ss_isect.nrm)) / kPi;
+      bs.eta = 1.0f;
+      bsdf_data = make_bsdf_data(ss_isect, ss_isect.w_i, st.medium, kPathCamera, st.wavelength);
+      isect = ss_isect;
+    }
+    return vcm_next_ray<kSimple>(scene, kPathCamera, st, it, isect, bsdf_data, bs, kWalk && subsurface_sampled, (kWalk && subsurface_sampled) ? scene.materials[isect.material] : step_material);
+  };
+
+  if (kSimple) {  // ONE reservation for vertex record, NEE request and next path set (light_step)
+    ShadowRequest request;
+    bool queue = false;
+    if (nee) {
+      st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
+      queue = vcm_connect_to_light<true>(scene, it, at_medium, &isect, ms.pos, st, film_index(it, st.id), request, step_material);
+      st.sampler.pop_fixed();
+    }
+    const PathState at_vertex = st;
+    const bool alive = continue_path();
+    const Slots3 slot = slots.get3(store, p.counters + kCntCameraVertices, queue, p.counters + kCntShadow, alive && (out != nullptr), out_counter);
+    if (store) {
+      Sampler derived;
+      derived.init(at_vertex.sampler.seed, 0x51ed270bu);
+      if (at_medium)
+        store_camera_vertex(p, slot.a, scene, at_vertex, mk4(ms.pos, __uint_as_float(kInvalid)), derived.seed, nullptr);
+      else
+        store_camera_vertex_m(p, slot.a, scene, at_vertex, h, derived.seed, &isect, step_material, false, 0u, opt_merge_vertices(it));
+    }
+    if (queue)
+      write_shadow(p, slot.b, request);
+    if (alive && (out != nullptr))
+      store_path(*out, slot.c, st);
+    return alive;
+  }
+
   // ---- phase B
   const uint32_t vertex_slot = slots.get(store, p.counters + kCntCameraVertices);
   if (store) {
@@ -437,18 +517,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
   }
   // next event estimation; vcm_shared.hxx:1036-1046: after a walk, from the exit point scaled by the walk
   const bool from_exit = kWalk && subsurface_sampled;
-  if (kSimple) {
-    ShadowRequest request;
-    bool queue = false;
-    if (nee) {
-      st.sampler.push_fixed(rnd_connection.x, rnd_connection.y, rnd_support.y);
-      queue = vcm_connect_to_light<true>(scene, it, at_medium, &isect, ms.pos, st, film_index(it, st.id), request, step_material);
-      st.sampler.pop_fixed();
-    }
-    const uint32_t shadow_slot = slots.get(queue, p.counters + kCntShadow);
-    if (queue)
-      write_shadow(p, shadow_slot, request);
-  } else {  // general BSDFs: k_connect_endpoints (pipeline.h EndpointQueue)
+  {  // general BSDFs: k_connect_endpoints (pipeline.h EndpointQueue)
     nee = nee && opt_connect_to_light(it) && (st.depth + 1 <= scene.max_path_length) && (st.depth + 1 >= scene.min_path_length);  // the early-outs of vcm_connect_to_light
     const uint32_t endpoint_slot = slots.get(nee, p.counters + kCntEndpoints);
     if (nee) {
@@ -462,32 +531,7 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
   }
 
   // ---- phase C
-  if (event == kEventBoundary)
-    return true;
-  if (scatter_event == false)
-    return false;
-  if (at_medium) {  // vcm_shared.hxx:973-994
-    st.d_vc = (1.0f / pdf_fwd) * (st.d_vc * pdf_rev + st.d_vcm);
-    st.d_vm = (1.0f / pdf_fwd) * (st.d_vm * pdf_rev + 0.0f);
-    st.d_vcm = 1.0f / pdf_fwd;
-    st.ray_o = ms.pos;
-    st.ray_d = w_o_medium;
-    st.ray_tmax = kMaxFloat;
-    st.ray_tmin = kRayEpsilon;
-    st.depth += 1u;
-    return (st.depth + 1 <= scene.max_path_length) && random_continue(st.depth, scene.random_path_termination, st.eta, st.sampler, st.throughput);
-  }
-  if (subsurface_path && (subsurface_sampled == false))
-    return false;
-  if (kWalk && subsurface_sampled) {  // vcm_shared.hxx:1049-1061
-    st.throughput *= ss_weight;
-    bs.w_o = sample_cosine_distribution(rnd_bsdf, ss_isect.nrm, 1.0f);
-    bs.pdf = fabsf(dot(bs.w_o, ss_isect.nrm)) / kPi;
-    bs.eta = 1.0f;
-    bsdf_data = make_bsdf_data(ss_isect, ss_isect.w_i, st.medium, kPathCamera, st.wavelength);
-    isect = ss_isect;
-  }
-  return vcm_next_ray<kSimple>(scene, kPathCamera, st, it, isect, bsdf_data, bs, kWalk && subsurface_sampled, (kWalk && subsurface_sampled) ? scene.materials[isect.material] : step_material);
+  return continue_path();
 }
 
 }  // namespace etxd

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kBlockSize) void k_pt_shade(Pipeline p, VcmParams i
   const PathSet& out = p.paths[in_set ^ 1u];
   const uint32_t count = shade_item_count<kGroup>(p, in_set);
   uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
-  const BlockSlots slots = {&s_scratch};
+  const BlockSlots slots = {&s_scratch, nullptr};
   ETX_BLOCK_LOOP(count, j) {
     bool valid = j < count;
     const uint32_t i = (kGroup == kShadeGroupSimple) ? j : (valid ? p.group_list[kGroup == kShadeGroupSimple ? 0u : kGroup - 1u][j] : 0u);

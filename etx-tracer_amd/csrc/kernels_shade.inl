@@ -55,9 +55,10 @@ __global__ __launch_bounds__(kBlockSize) void k_light_shade(Pipeline p, VcmParam
   const uint32_t count = shade_item_count<kGroup>(p, in_set);
   uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
   __shared__ BlockScratch s_scratch;
+  __shared__ BlockScratch3 s_scratch3;
   __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];  // inline traversal of the subsurface walk
   const LaneStack stack = lane_stack(p.scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
-  const BlockSlots slots = {&s_scratch};
+  const BlockSlots slots = {&s_scratch, &s_scratch3};
   ETX_BLOCK_LOOP(count, j) {
     bool valid = j < count;
     const uint32_t i = (kGroup == kShadeGroupSimple) ? j : (valid ? p.group_list[kGroup == kShadeGroupSimple ? 0u : kGroup - 1u][j] : 0u);
@@ -69,10 +70,14 @@ __global__ __launch_bounds__(kBlockSize) void k_light_shade(Pipeline p, VcmParam
       valid = bin_foreign_groups(p, slots, i, hit_shade_group(scene, h), valid);
     if (valid)
       st = load_path(in, i);
-    const bool alive = light_step<kGroup>(p, scene, it, st, h, valid, slots, stack);
-    const uint32_t slot = slots.get(alive, out_counter);
-    if (alive)
-      store_path(out, slot, st);
+    if (kGroup == kShadeGroupSimple) {  // the step reserves the path's slot together with its vertex and shadow-request slots and stores the path
+      (void)light_step<kGroup>(p, scene, it, st, h, valid, slots, stack, &out, out_counter);
+    } else {
+      const bool alive = light_step<kGroup>(p, scene, it, st, h, valid, slots, stack);
+      const uint32_t slot = slots.get(alive, out_counter);
+      if (alive)
+        store_path(out, slot, st);
+    }
   }
 }
 
@@ -87,9 +92,10 @@ __global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmPara
   const uint32_t count = shade_item_count<kGroup>(p, in_set);
   uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
   __shared__ BlockScratch s_scratch;
+  __shared__ BlockScratch3 s_scratch3;
   __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];
   const LaneStack stack = lane_stack(p.scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
-  const BlockSlots slots = {&s_scratch};
+  const BlockSlots slots = {&s_scratch, &s_scratch3};
   ETX_BLOCK_LOOP(count, j) {
     bool valid = j < count;
     const uint32_t i = (kGroup == kShadeGroupSimple) ? j : (valid ? p.group_list[kGroup == kShadeGroupSimple ? 0u : kGroup - 1u][j] : 0u);
@@ -101,10 +107,14 @@ __global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmPara
       valid = bin_foreign_groups(p, slots, i, hit_shade_group(scene, h), valid);
     if (valid)
       st = load_path(in, i);
-    const bool alive = camera_step<kGroup>(p, scene, it, st, h, valid, slots, stack);
-    const uint32_t slot = slots.get(alive, out_counter);
-    if (alive)
-      store_path(out, slot, st);
+    if (kGroup == kShadeGroupSimple) {
+      (void)camera_step<kGroup>(p, scene, it, st, h, valid, slots, stack, &out, out_counter);
+    } else {
+      const bool alive = camera_step<kGroup>(p, scene, it, st, h, valid, slots, stack);
+      const uint32_t slot = slots.get(alive, out_counter);
+      if (alive)
+        store_path(out, slot, st);
+    }
   }
 }
 
