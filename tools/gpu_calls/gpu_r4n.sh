@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, call n: A/B of the emitter records read as 16-byte rows in next event estimation (base = the committed build before it).
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-O=gpurun_out/r4n
+O=gpurun_out/${ETX_AB_TAG:-r4n}
 mkdir -p $O
 export TMPDIR=/tmp
 V=etx-tracer_amd/variants
