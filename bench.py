@@ -86,6 +86,10 @@ def main(argv=None, context_factory=None, backend="nccl"):
                              "cloud_bdpt = configs[4]: the fog box with a procedural 256^3 heterogeneous density grid, BDPTFull, 2048x2048")
     parser.add_argument("--bvh", default="host", choices=["host", "device", "wide"],
                         help="who builds the traversal tree (etx_hip_set_bvh_builder); wide: the host tree plus its eight-wide form with 8-bit boxes (opt-in)")
+    parser.add_argument("--shard", default="iterations", choices=["iterations", "pixels"],
+                        help="how N > 1 ranks split the job. iterations (default): rank r renders iterations r, r + N, ... of the full frame - weak scaling, every integrator. "
+                             "pixels: every rank renders ALL iterations of pixels r, r + N, ... (etx_hip_begin_ex; bidirectional workloads only) - strong scaling: the job "
+                             "is --steps iterations of the frame whatever N is, and each rank holds 1/N of the vertex pools")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-kernel-table", action="store_true", help="skip the extra pass that times every kernel group (profiling runs)")
     args = parser.parse_args(argv)
@@ -157,14 +161,23 @@ def main(argv=None, context_factory=None, backend="nccl"):
         options = integ_mod.bdpt_options_from_dict({"bdpt-mode": api.BDPT_MODE_FULL})
         ctx.set_timers(0xff)  # the roofline kernel of these workloads is whichever group dominates: time all of them
 
+    pixel_sharded = (args.shard == "pixels") and (world > 1)
+    if pixel_sharded and (bdpt_workload is False):
+        raise SystemExit("--shard pixels: the bidirectional workloads only (a VCM iteration's photon map needs the light paths of every pixel)")
+
     def begin(first_iteration, iteration_stride):
-        if bdpt_workload:
+        if pixel_sharded:
+            ctx.begin_bdpt(options, first_iteration=first_iteration, iteration_stride=iteration_stride, pixel_first=rank, pixel_stride=world)
+        elif bdpt_workload:
             ctx.begin_bdpt(options, first_iteration=first_iteration, iteration_stride=iteration_stride)
         else:
             ctx.begin_vcm(options, first_iteration=first_iteration, iteration_stride=iteration_stride)
 
     def run_steps(count, first_offset):
-        begin(rank + first_offset * world, world)
+        if pixel_sharded:
+            begin(first_offset, 1)  # the same iterations on every rank, each for its own pixels
+        else:
+            begin(rank + first_offset * world, world)
         for _ in range(count):
             ctx.render_iteration()  # asynchronous: iterations overlap on the device lanes
         ctx.sync()
@@ -296,7 +309,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
         dominant = dict(kernels[name], group=name, note="the kernel group with the largest share of the device time of an iteration; `bound` = the HBM roofline the contract asks for. "
                         "The group is not bandwidth-bound: its waves wait on dependent gathers and divergent branches (counters_1lane; DESIGN.md 3)")
     if rank == 0:
-        samples = float(width) * height * args.steps * world
+        samples = float(width) * height * args.steps * (1 if pixel_sharded else world)
         value = samples / elapsed / 1.0e6
         achieved = (acc["rays"] * BYTES_PER_RAY / 1.0e9) / (acc["trace_ms"] * 1.0e-3) if acc["trace_ms"] > 0 else 0.0
         trace_pmc = profile_lookup.group_counters(pmc, pmc_groups["trace_closest"], "rays_extension")
@@ -309,7 +322,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1.0e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if pixel_sharded else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -325,7 +338,8 @@ def main(argv=None, context_factory=None, backend="nccl"):
                 "triangles": int(snap.triangle_count), "tree": {"builder": args.bvh, "build_ms": round(tree["build_ms"], 3), "nodes": tree["nodes"], "depth": tree["depth"], "stack_need": tree["stack_need"],
                                                                 "upload_s": round(upload_seconds, 3)},
                 "samples_per_step": width * height,
-                "parallelism": "iteration-sharded x%d, one RCCL film all-reduce at the end" % world,
+                "parallelism": ("pixel-sharded x%d (rank r: pixels r, r + N, ... of every iteration), one RCCL film all-reduce of zero-padded sums at the end" if pixel_sharded
+                                else "iteration-sharded x%d, one RCCL film all-reduce at the end") % world,
                 "working_set_gb": round(ctx.device_bytes() / 1.0e9, 2),  # queues, pools, grid and film of all lanes (etx_hip_device_bytes)
                 "pool_grows": int(acc["stats"].pool_grows),  # iterations of the timed region that overflowed a pool and were rendered again (0 once the pools have their size)
                 "lanes": lanes, "workload_key": args.workload, "library_sha16": library_sha16(),

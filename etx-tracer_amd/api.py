@@ -25,7 +25,7 @@ BVH_WIDE = 256  # | BVH_HOST_SAH: also the eight-wide tree with 8-bit child boxe
 
 EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene", "etx_hip_update_scene",
-    "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_upload_rgb_response", "etx_hip_begin", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
+    "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_upload_rgb_response", "etx_hip_begin", "etx_hip_begin_ex", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
     "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_checkpoint_bytes", "etx_hip_checkpoint_save", "etx_hip_checkpoint_load", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_set_debug_flags", "etx_hip_set_pool_policy", "etx_hip_lanes", "etx_hip_device_bytes", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
     "etx_hip_set_bvh_builder", "etx_hip_bvh_info", "etx_hip_selftest_stack", "etx_hip_host_check_bvh_builder", "etx_hip_host_bvh_stats_builder", "etx_hip_host_bvh8_stats",
@@ -174,6 +174,7 @@ class Library:
         L.etx_hip_upload_cie_table.argtypes = [vp, vp, u32, ctypes.c_float]
         L.etx_hip_upload_rgb_response.argtypes = [vp, vp, u32, ctypes.c_float]
         L.etx_hip_begin.argtypes = [vp, i32, vp, sz, u32, u32]
+        L.etx_hip_begin_ex.argtypes = [vp, i32, vp, sz, u32, u32, u32, u32]
         L.etx_hip_render_iteration.argtypes = [vp]
         L.etx_hip_try_render_iteration.argtypes = [vp]
         L.etx_hip_poll.argtypes = [vp]
@@ -296,11 +297,16 @@ class Context:
     def begin_vcm(self, options, first_iteration=0, iteration_stride=1):
         self._check(self.library.lib.etx_hip_begin(self.handle, INTEGRATOR_VCM, ctypes.byref(options), ctypes.sizeof(options), first_iteration, iteration_stride))
 
-    def begin_pt(self, options, first_iteration=0, iteration_stride=1):
-        self._check(self.library.lib.etx_hip_begin(self.handle, INTEGRATOR_PT, ctypes.byref(options), ctypes.sizeof(options), first_iteration, iteration_stride))
+    def begin_pt(self, options, first_iteration=0, iteration_stride=1, pixel_first=0, pixel_stride=1):
+        self.begin_ex(INTEGRATOR_PT, options, first_iteration, iteration_stride, pixel_first, pixel_stride)
 
-    def begin_bdpt(self, options, first_iteration=0, iteration_stride=1):
-        self._check(self.library.lib.etx_hip_begin(self.handle, INTEGRATOR_BDPT, ctypes.byref(options), ctypes.sizeof(options), first_iteration, iteration_stride))
+    def begin_bdpt(self, options, first_iteration=0, iteration_stride=1, pixel_first=0, pixel_stride=1):
+        self.begin_ex(INTEGRATOR_BDPT, options, first_iteration, iteration_stride, pixel_first, pixel_stride)
+
+    def begin_ex(self, integrator, options, first_iteration=0, iteration_stride=1, pixel_first=0, pixel_stride=1):
+        """etx_hip_begin_ex: iteration sharding and, for the path tracer / bidirectional integrator, pixel-interleaved sharding."""
+        self._check(self.library.lib.etx_hip_begin_ex(self.handle, int(integrator), ctypes.byref(options), ctypes.sizeof(options), first_iteration, iteration_stride,
+                                                     pixel_first, pixel_stride))
 
     def render_iteration(self):
         self._check(self.library.lib.etx_hip_render_iteration(self.handle))

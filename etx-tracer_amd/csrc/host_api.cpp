@@ -91,6 +91,8 @@ struct etx_hip_context {
   size_t adaptive_pixels = 0;
   float4* pt_iteration_image = nullptr;  // camera and light contributions of the iteration this lane renders (2 x pixels), committed to the film at its end
   uint32_t first_iteration = 0, iteration_stride = 1;
+  uint32_t pixel_first = 0, pixel_stride = 1;  // etx_hip_begin_ex: this context's share of the pixels (path tracer, bidirectional integrator)
+  uint32_t pool_paths = 0;                     // paths per sub pass pool_wanted was first sized for
   uint32_t next_iteration = 0;       // iteration index to render next
   uint32_t local_iterations = 0;     // iterations rendered by this context since begin
   uint64_t global_iterations = 0;    // after etx_hip_reduce_film: iterations of all ranks
@@ -359,8 +361,10 @@ int allocate_pipeline(etx_hip_context* ctx) {
   // the growable pools (light vertices, camera vertices, pairs, shadow and endpoint queues; the photon grid from the first VCM run on)
   {
     etx_hip_context* pub = ctx->owner ? ctx->owner : ctx;
-    if (pub->pool_wanted.light_vertices == 0u)
+    if (pub->pool_wanted.light_vertices == 0u) {
       pub->pool_wanted = initial_pool_sizes(pub, n);
+      pub->pool_paths = n;
+    }
     if ((rc = allocate_pools(ctx, pub->pool_wanted)))
       return rc;
   }
@@ -466,6 +470,11 @@ int read_counters(etx_hip_context* ctx) {
   return 0;
 }
 
+// pixels first, first + stride, ... below n
+uint32_t shard_paths(uint32_t n, uint32_t first, uint32_t stride) {
+  return (first < n) ? (n - first + stride - 1u) / stride : 0u;
+}
+
 // vcm_cpu.cxx:95-124 start_next_iteration: radius schedule and VC/VM weights
 VcmParams make_iteration_params(const etx_hip_context* ctx, uint32_t iteration) {
   const auto& o = ctx->vcm_options;
@@ -476,6 +485,7 @@ VcmParams make_iteration_params(const etx_hip_context* ctx, uint32_t iteration) 
   it.iteration = iteration;
   it.film_w = ctx->scene.film_w, it.film_h = ctx->scene.film_h;
   it.path_count = it.film_w * it.film_h;
+  it.pixel_first = 0u, it.pixel_stride = 1u;  // a photon map holds the light paths of every pixel: VCM is never pixel-sharded (etx_hip_begin_ex)
   float used_radius = o.initial_radius;
   if (used_radius == 0.0f) {
     uint32_t max_dim = std::max(it.film_w, it.film_h);
@@ -722,7 +732,8 @@ int render_pt_iteration(etx_hip_context* ctx, uint32_t iteration) {
   it.options = (o.direct ? ETX_PT_DIRECT : 0u) | (o.nee ? ETX_PT_NEE : 0u) | (o.mis ? ETX_PT_MIS : 0u);
   it.iteration = iteration;
   it.film_w = ctx->scene.film_w, it.film_h = ctx->scene.film_h;
-  it.path_count = it.film_w * it.film_h;
+  it.pixel_first = ctx->pixel_first, it.pixel_stride = ctx->pixel_stride;
+  it.path_count = shard_paths(it.film_w * it.film_h, it.pixel_first, it.pixel_stride);
   it.bluenoise = reinterpret_cast<const uint2*>(ctx->active_bluenoise);
   ctx->cross_mode = 0u;
   hipStream_t s = ctx->stream;
@@ -751,7 +762,7 @@ int render_pt_iteration(etx_hip_context* ctx, uint32_t iteration) {
     [&](uint32_t, uint32_t) {}, rounds, kStatRaysCamera, false);
   if (rc)
     return rc;
-  launch_pt_commit(s, ctx->pt_iteration_image, ctx->pipe.camera_sum, ctx->pipe.adaptive_sum, it.path_count, ctx->scene.host_copy.radiance_clamp);
+  launch_pt_commit(s, ctx->pt_iteration_image, ctx->pipe.camera_sum, ctx->pipe.adaptive_sum, ctx->pipe.capacity, ctx->scene.host_copy.radiance_clamp);  // the whole frame: a pixel shard's pixels are spread over it
   // Film::estimate_noise_levels(status.current_iteration, ...), path_tracing.cxx:99: after even iterations from kMinSamples = 32 on
   if ((ctx->pipe.pixel_state != nullptr) && (iteration >= 32u) && ((iteration & 1u) == 0u))
     launch_noise_estimate(s, ctx->pipe, it.film_w, it.film_h, ctx->noise_threshold);
@@ -773,7 +784,8 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
   ctx->cross_mode = 2u;  // BdptState: medium in meta.z, no path distance
   it.iteration = iteration;
   it.film_w = ctx->scene.film_w, it.film_h = ctx->scene.film_h;
-  it.path_count = it.film_w * it.film_h;
+  it.pixel_first = ctx->pixel_first, it.pixel_stride = ctx->pixel_stride;
+  it.path_count = shard_paths(it.film_w * it.film_h, it.pixel_first, it.pixel_stride);
   it.bluenoise = reinterpret_cast<const uint2*>(ctx->active_bluenoise);
   Pipeline p = ctx->pipe;  // iteration images, as in render_vcm_iteration
   p.camera_sum = ctx->pt_iteration_image;
@@ -1401,6 +1413,11 @@ int etx_hip_upload_rgb_response(etx_hip_context* context, const float* rgb, uint
 }
 
 int etx_hip_begin(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride) {
+  return etx_hip_begin_ex(context, integrator, options, options_size, first_iteration, iteration_stride, 0u, 1u);
+}
+
+int etx_hip_begin_ex(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride, uint32_t pixel_first,
+  uint32_t pixel_stride) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   float noise_threshold = 0.0f;
@@ -1411,6 +1428,15 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
   if (iteration_stride == 0) {
     context->error = "iteration_stride must be >= 1";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  if ((pixel_stride == 0u) || (pixel_first >= pixel_stride)) {
+    context->error = "pixel sharding: pixel_stride must be >= 1 and pixel_first below it";
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  }
+  if ((integrator == ETX_HIP_INTEGRATOR_VCM) && (pixel_stride != 1u)) {
+    context->error = "VCM cannot be sharded by pixels: the photon map of an iteration holds the light paths of EVERY pixel and the merge is normalised by their number "
+                     "(vcm_cpu.cxx:100-113); shard its iterations (first_iteration / iteration_stride)";
+    return ETX_HIP_ERROR_UNSUPPORTED;
   }
   (void)wait_idle(context);  // iterations of the previous run
   const uint32_t lanes_wanted = lanes_for_integrator(context, integrator);
@@ -1448,7 +1474,8 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
     // An iteration-sharded context (multi-GPU) holds a film of ITS iterations only, and the convergence mask is a property of the whole
     // film: such a run samples every pixel in every iteration (a superset of what the adaptive render samples; the reference's default
     // threshold is 0.1, so this is what every unedited scene gets on several GPUs)
-    if (iteration_stride != 1u)
+    // - and the mask looks at a pixel's row and column neighbours (film.cxx:283-321), which a pixel-sharded context does not render
+    if ((iteration_stride != 1u) || (pixel_stride != 1u))
       noise_threshold = 0.0f;
   } else if (integrator == ETX_HIP_INTEGRATOR_BDPT) {
     if ((options == nullptr) || (options_size != sizeof(etx_abi_bdpt_options))) {
@@ -1504,6 +1531,17 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
       return rc;
   }
   HIP_OK(context, hipSetDevice(context->device));
+  context->pixel_first = pixel_first, context->pixel_stride = pixel_stride;
+  {
+    // the growable pools follow the paths a sub pass holds: a context that renders every second pixel starts (and stays, unless it overflows)
+    // at half the vertex, pair and queue records; the lanes adopt the size before their next iteration (execute_iteration)
+    const uint32_t paths = shard_paths(context->scene.film_w * context->scene.film_h, pixel_first, pixel_stride);
+    std::lock_guard<std::mutex> lock(context->shared_mutex);
+    if (paths != context->pool_paths) {
+      context->pool_wanted = initial_pool_sizes(context, std::max(paths, 1u));
+      context->pool_paths = paths;
+    }
+  }
   // the lanes this integrator uses beyond the base ones get their pools now - after every check above, so a refused begin leaves the
   // working set as it was
   for (uint32_t i = 0; i + 1u < lanes_wanted; ++i) {
@@ -1562,6 +1600,7 @@ int etx_hip_begin(etx_hip_context* context, int integrator, const void* options,
   context->plans[0] = context->plans[1] = {};  // launch plans belong to a run (integrator, options, scene)
   for (etx_hip_context* helper : context->helpers) {
     helper->plans[0] = helper->plans[1] = {};
+    helper->pixel_first = pixel_first, helper->pixel_stride = pixel_stride;
     helper->noise_threshold = noise_threshold;
     helper->pipe.adaptive_sum = context->pipe.adaptive_sum;
     helper->pipe.pixel_state = context->pipe.pixel_state;
@@ -1781,7 +1820,9 @@ namespace {
 // sample count in w, light, normal, albedo), and for an adaptive run the even-sample sums and the pixel states.
 struct CheckpointHeader {
   uint32_t magic, version, integrator, width, height, first_iteration, iteration_stride, next_iteration;
-  uint32_t local_iterations, adaptive, options_hash, last_active_pixels, scene_hash, reserved[3];
+  uint32_t local_iterations, adaptive, options_hash, last_active_pixels, scene_hash;
+  uint32_t pixel_first, pixel_stride_minus_1;  // pixel sharding (etx_hip_begin_ex); zero = every pixel, which is what version-2 checkpoints written before it hold
+  uint32_t reserved;
 };
 static_assert(sizeof(CheckpointHeader) == 64, "checkpoint header layout");
 constexpr uint32_t kCheckpointMagic = 0x43585445u;  // "ETXC"
@@ -1859,6 +1900,7 @@ int etx_hip_checkpoint_save(etx_hip_context* context, void* dst, size_t dst_byte
   header.magic = kCheckpointMagic, header.version = kCheckpointVersion, header.integrator = uint32_t(context->integrator);
   header.width = context->scene.film_w, header.height = context->scene.film_h;
   header.first_iteration = context->first_iteration, header.iteration_stride = context->iteration_stride;
+  header.pixel_first = context->pixel_first, header.pixel_stride_minus_1 = context->pixel_stride - 1u;
   header.next_iteration = context->next_iteration, header.local_iterations = context->local_iterations;
   header.adaptive = (context->pipe.pixel_state != nullptr) ? 1u : 0u;
   header.options_hash = options_hash(context);
@@ -1898,9 +1940,10 @@ int etx_hip_checkpoint_load(etx_hip_context* context, const void* src, size_t sr
   }
   const bool adaptive = context->pipe.pixel_state != nullptr;
   if ((header.integrator != uint32_t(context->integrator)) || (header.width != context->scene.film_w) || (header.height != context->scene.film_h) ||
-      (header.first_iteration != context->first_iteration) || (header.iteration_stride != context->iteration_stride) || ((header.adaptive != 0u) != adaptive) ||
+      (header.first_iteration != context->first_iteration) || (header.iteration_stride != context->iteration_stride) || (header.pixel_first != context->pixel_first) ||
+      (header.pixel_stride_minus_1 != context->pixel_stride - 1u) || ((header.adaptive != 0u) != adaptive) ||
       (header.options_hash != options_hash(context)) || (header.scene_hash != scene_hash(context)) || (src_bytes != checkpoint_bytes(context))) {
-    context->error = "etx_hip_checkpoint_load: the checkpoint was saved by a different run (integrator, options, scene scalars / camera / table sizes, film size, adaptive sampling or iteration sharding differ)";
+    context->error = "etx_hip_checkpoint_load: the checkpoint was saved by a different run (integrator, options, scene scalars / camera / table sizes, film size, adaptive sampling or iteration / pixel sharding differ)";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
   if (uint64_t(header.next_iteration) != uint64_t(header.first_iteration) + uint64_t(header.local_iterations) * uint64_t(header.iteration_stride)) {
@@ -2359,6 +2402,11 @@ void etx_hip_internal_iterations(etx_hip_context* c, uint32_t** local, uint64_t*
   *local = &c->local_iterations;
   *global = &c->global_iterations;
   *reduced = &c->reduced;
+}
+// What this rank adds to the global iteration count of the film reduce. Ranks that share their iterations and split the PIXELS hold the same
+// iterations: the rank of the first pixel shard counts them, the others add zero (so R pixel shards x S iteration shards sum to the run's iterations).
+uint32_t etx_hip_internal_counted_iterations(etx_hip_context* c) {
+  return (c->pixel_first == 0u) ? c->local_iterations : 0u;
 }
 int etx_hip_internal_device(etx_hip_context* c) {
   return c->device;

@@ -18,6 +18,7 @@ void etx_hip_internal_film(etx_hip_context* c, float** camera, float** light, si
 void etx_hip_internal_set_error(etx_hip_context* c, const std::string& e);
 void etx_hip_internal_rank(etx_hip_context* c, int** rank, int** world);
 void etx_hip_internal_iterations(etx_hip_context* c, uint32_t** local, uint64_t** global, bool** reduced);
+uint32_t etx_hip_internal_counted_iterations(etx_hip_context* c);
 int etx_hip_internal_device(etx_hip_context* c);
 void** etx_hip_internal_comm_scratch(etx_hip_context* c);  // device words {iterations of this rank, 1 if this rank failed}, allocated with the communicator
 
@@ -112,7 +113,7 @@ int etx_hip_reduce_film(etx_hip_context* context) {
   size_t floats = 0;
   etx_hip_internal_film(context, &camera, &light, &floats);
   unsigned long long* d_counters = reinterpret_cast<unsigned long long*>(*etx_hip_internal_comm_scratch(context));  // allocated by etx_hip_comm_init
-  unsigned long long h_counters[2] = {*local, local_rc ? 1ull : 0ull};
+  unsigned long long h_counters[2] = {etx_hip_internal_counted_iterations(context), local_rc ? 1ull : 0ull};
   (void)hipMemcpyAsync(d_counters, h_counters, sizeof(h_counters), hipMemcpyHostToDevice, stream);
   ncclResult_t r = ncclGroupStart();
   if (r == ncclSuccess)

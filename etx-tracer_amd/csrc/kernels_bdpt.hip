@@ -60,10 +60,11 @@ ETX_DEV f3 bdpt_albedo(const DScene& scene, const etx_abi_material& mat, const f
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_generate(Pipeline p, VcmParams it) {
   __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
-  ETX_BLOCK_LOOP(it.path_count, i) {
+  ETX_BLOCK_LOOP(it.path_count, k) {
     bool valid = false;
     BdptState st = {};
-    if (i < it.path_count) {
+    if (k < it.path_count) {
+      const uint32_t i = path_pixel(it, k);  // the emitter path of pixel i (:377-379)
       st.sampler.init(i, it.iteration);
       st.id = i;
       st.wavelength = scene.spectral ? spectral_sample_wavelength(st.sampler.next()) : 0.0f;
@@ -614,7 +615,8 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_camera(Pipeline p, 
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_generate(Pipeline p, VcmParams it) {
   const DScene& scene = p.scene;
   const uint32_t mode = bdpt_mode(it);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < it.path_count; i += gridDim.x * blockDim.x) {
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < it.path_count; k += gridDim.x * blockDim.x) {
+    const uint32_t i = path_pixel(it, k);
     BdptState st = {};
     st.id = i;
     // the reference seeds the camera sampler like the light sampler of the same pixel (:377-378); the device gives the
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_generate(Pipeline p,
     st.medium = scene.camera.medium_index;
     st.flags = kBpFirst | ((it.options & kOptionRetryKeepsAovs) ? kBpGBuffer : 0u);
     st.prev = {r.o, scene.camera.direction, 1.0f, 0.0f, kBvConnectible | kBvMisConnectible, kInvalid};
-    bdpt_store(p.paths[0], i, st, kInvalid);
+    bdpt_store(p.paths[0], k, st, kInvalid);
   }
   if ((blockIdx.x == 0) && (threadIdx.x == 0)) {
     p.counters[kCntActiveA] = it.path_count;

@@ -65,8 +65,9 @@ __global__ __launch_bounds__(kBlockSize) void k_pt_generate(Pipeline p, VcmParam
   const DScene& scene = p.scene;
   // Film::active_pixel (film.cxx:434-459): converged pixels are not sampled; the others are marked "sampled" in the iteration
   // image (k_pt_commit adds nothing to pixels that were not)
-  ETX_BLOCK_LOOP(it.path_count, id) {
-    const bool in_range = id < it.path_count;
+  ETX_BLOCK_LOOP(it.path_count, k) {
+    const bool in_range = k < it.path_count;
+    const uint32_t id = path_pixel(it, k);
     const uint32_t storage = in_range ? film_index(it, id) : 0u;
     const bool active = in_range && ((p.pixel_state == nullptr) || ((p.pixel_state[storage] & 1u) == 0u));
     const uint32_t slot = block_compact_slot(active, p.counters + kCntActiveA, s_scratch);

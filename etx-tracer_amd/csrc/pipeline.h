@@ -179,14 +179,20 @@ struct VcmParams {  // VCMOptions + VCMIteration (vcm_shared.hxx:12-89), per ite
   uint32_t options;
   uint32_t kernel;
   uint32_t iteration;
-  uint32_t path_count;   // W * H
+  uint32_t path_count;   // paths per sub pass: W * H, or this context's share of the pixels (pixel_first / pixel_stride)
   float current_radius;
   float vm_weight;
   float vc_weight;
   float vm_normalization;
   uint32_t film_w, film_h;
   const uint2* bluenoise;  // [128*128][256] x 8 bytes (etx_hip_upload_bluenoise), nullptr = options.blue_noise off
+  // pixel-interleaved sharding of the path tracer and the bidirectional integrator (etx_hip_begin_ex): path k of this context belongs to
+  // pixel pixel_first + k * pixel_stride; VCM always runs (0, 1) - a photon map needs the light paths of every pixel
+  uint32_t pixel_first, pixel_stride;
 };
+
+// the pixel (= path id: sampler seed, film position, per-path tables) of the k-th path a context generates
+ETX_HD uint32_t path_pixel(const VcmParams& it, uint32_t k) { return it.pixel_first + k * it.pixel_stride; }
 
 // VcmParams::options bit 31 (bidirectional integrator): this is the second attempt at an iteration whose pools overflowed - the first attempt
 // was not committed (k_vcm_commit) but has already added the iteration's normal / albedo values, which go straight to the film

@@ -103,12 +103,15 @@ def bdpt_options_from_dict(values):
 class HIPIntegrator(Integrator):
     """run / update / stop protocol shared by the device integrators (one iteration per update())."""
 
-    def __init__(self, snapshot, device=0, first_iteration=0, iteration_stride=1):
+    def __init__(self, snapshot, device=0, first_iteration=0, iteration_stride=1, pixel_first=0, pixel_stride=1):
         super().__init__()
         self.snapshot = snapshot
         self.context = api.Context(device)
         self.first_iteration = first_iteration
         self.iteration_stride = iteration_stride
+        # pixel-interleaved sharding (etx_hip_begin_ex; path tracer and bidirectional integrator): this rank's film is a zero-padded part of the job's
+        self.pixel_first = pixel_first
+        self.pixel_stride = pixel_stride
         self._uploaded_version = None  # snapshot.version at the last etx_hip_upload_scene
         self._pending_changes = None   # scene_edited(): what the host changed since (None: unknown = upload everything)
         self.bvh_builder = api.BVH_HOST_SAH  # api.BVH_DEVICE_LBVH: the tree of the next upload is built on the device (etx_hip_set_bvh_builder)
@@ -239,6 +242,8 @@ class HIPVCM(HIPIntegrator):
         return "VCM (HIP gfx950)"
 
     def _begin(self):
+        if self.pixel_stride != 1:  # refused by the library with its reason (the photon map needs every pixel's light path)
+            self.context.begin_ex(api.INTEGRATOR_VCM, vcm_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride, self.pixel_first, self.pixel_stride)
         self.context.begin_vcm(vcm_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride)
 
 
@@ -250,7 +255,7 @@ class HIPPathTracing(HIPIntegrator):
         return "Path Tracing (HIP gfx950)"
 
     def _begin(self):
-        self.context.begin_pt(pt_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride)
+        self.context.begin_pt(pt_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride, self.pixel_first, self.pixel_stride)
 
     def update(self):
         super().update()
@@ -272,4 +277,4 @@ class HIPBidirectional(HIPIntegrator):
         return "Bidirectional (HIP gfx950)"
 
     def _begin(self):
-        self.context.begin_bdpt(bdpt_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride)
+        self.context.begin_bdpt(bdpt_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride, self.pixel_first, self.pixel_stride)

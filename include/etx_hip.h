@@ -158,6 +158,19 @@ int etx_hip_upload_rgb_response(etx_hip_context* context, const float* rgb, uint
  * holds, and every pixel is sampled in every iteration instead (noise_threshold treated as 0). */
 int etx_hip_begin(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride);
 
+/* etx_hip_begin with a second way to shard a run ("tile-split"): this context renders pixels pixel_first, pixel_first +
+ * pixel_stride, ... of every one of its iterations (pixels in the reference's order, y * width + x). For the path tracer and the
+ * bidirectional integrator only: both pair light path i with pixel i (bidirectional.cxx:379-391), so a context traces the emitter and camera
+ * paths of ITS pixels - the same samples as an unsharded render, seeded by (pixel, iteration). The camera image of the context is tile-local
+ * (other pixels stay zero), its light image is full-frame (splats land anywhere, bidirectional.cxx:516-520) and holds the splats of its own
+ * light paths; the job's film is the SUM of the contexts' films - the same single all-reduce of zero-padded sums as iteration sharding
+ * (etx_hip_reduce_film; the rank of pixel shard 0 contributes the iteration count), or the sum of the etx_hip_read_film images. The
+ * growable pools start at the share of the paths (half of everything for pixel_stride 2). Adaptive sampling is off on a pixel-sharded
+ * context (the mask reads row and column neighbours, film.cxx:283-321). VCM: ETX_HIP_ERROR_UNSUPPORTED unless (0, 1) - the photon map
+ * of an iteration needs the light paths of every pixel. etx_hip_begin = (0, 1). */
+int etx_hip_begin_ex(etx_hip_context* context, int integrator, const void* options, size_t options_size, uint32_t first_iteration, uint32_t iteration_stride, uint32_t pixel_first,
+  uint32_t pixel_stride);
+
 /* Hands one full iteration (VCM: light pass, grid build, camera pass; PT: one sample per pixel) to a free device lane and
  * returns without waiting for it; blocks only while every lane is busy (four for VCM and path tracing, six for the
  * bidirectional integrator; ETX_HIP_LANES=n, 1..8, fixes one count for all three). */

@@ -16,6 +16,19 @@ def fake_iteration(iteration, h=12, w=16):
     return camera, light
 
 
+def pixel_shard_images(camera, light, iteration, pixel_first, pixel_stride):
+    """What a pixel-sharded context adds for one iteration (etx_hip_begin_ex): the camera values of ITS pixels (zero elsewhere) and the
+    splats of its own light paths anywhere on the frame - here a deterministic partition of the light image whose parts sum to it."""
+    if pixel_stride == 1:
+        return camera, light
+    h, w = camera.shape[:2]
+    owned = (torch.arange(h * w).reshape(h, w, 1) % pixel_stride) == pixel_first
+    g = torch.Generator().manual_seed(99 + iteration)
+    parts = torch.rand((pixel_stride, h, w, 1), generator=g)
+    parts = parts / parts.sum(dim=0, keepdim=True)
+    return camera * owned, light * parts[pixel_first]
+
+
 class StubContext:
     instances = []
 
@@ -61,8 +74,9 @@ class StubContext:
     def set_timers(self, mask):
         self.calls.append(("set_timers", mask))
 
-    def _begin(self, first_iteration, iteration_stride):
+    def _begin(self, first_iteration, iteration_stride, pixel_first=0, pixel_stride=1):
         self.next_iteration, self.stride = first_iteration, iteration_stride
+        self.pixel_first, self.pixel_stride = pixel_first, pixel_stride
         self.iterations_rendered = []
         self.camera_sum = torch.zeros((12, 16, 4))
         self.light_sum = torch.zeros((12, 16, 4))
@@ -73,13 +87,13 @@ class StubContext:
         self.calls.append(("begin_vcm", first_iteration, iteration_stride))
         self._begin(first_iteration, iteration_stride)
 
-    def begin_bdpt(self, options, first_iteration=0, iteration_stride=1):
-        self.calls.append(("begin_bdpt", first_iteration, iteration_stride))
-        self._begin(first_iteration, iteration_stride)
+    def begin_bdpt(self, options, first_iteration=0, iteration_stride=1, pixel_first=0, pixel_stride=1):
+        self.calls.append(("begin_bdpt", first_iteration, iteration_stride, pixel_first, pixel_stride))
+        self._begin(first_iteration, iteration_stride, pixel_first, pixel_stride)
 
     def render_iteration(self):
         assert self.reduced is False
-        camera, light = fake_iteration(self.next_iteration)
+        camera, light = pixel_shard_images(*fake_iteration(self.next_iteration), self.next_iteration, self.pixel_first, self.pixel_stride)
         self.camera_sum += camera
         self.light_sum += light
         self.count += 1
@@ -102,7 +116,9 @@ class StubContext:
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.camera_sum, op=dist.ReduceOp.SUM)
             dist.all_reduce(self.light_sum, op=dist.ReduceOp.SUM)
-            dist.all_reduce(self.count, op=dist.ReduceOp.SUM)
+            counted = self.count if self.pixel_first == 0 else torch.zeros_like(self.count)  # pixel shards hold the SAME iterations: shard 0 counts them
+            dist.all_reduce(counted, op=dist.ReduceOp.SUM)
+            self.count = counted
         self.reduced = True
         # what the LAST reduce held (bench.py renders more afterwards: its per-kernel pass on rank 0)
         self.reduced_result = self.result()

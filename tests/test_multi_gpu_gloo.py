@@ -130,3 +130,47 @@ def test_bench_two_gpu_control_flow_under_gloo(tmp_path):
     expected[..., 3] = 1.0
     for r in range(world):
         np.testing.assert_allclose(np.load(tmp_path / ("bench_film%d.npy" % r)), expected.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def pixel_bench_worker(rank, world, port, out_dir):
+    """bench.py --shard pixels for N = 2 under gloo: every rank renders the SAME iterations for its own pixels (etx_hip_begin_ex)."""
+    import contextlib
+    import io
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    import bench
+    from tests.stub_context import StubContext
+    stdout = io.StringIO()
+    with contextlib.redirect_stdout(stdout):
+        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--workload", "cloud_bdpt", "--shard", "pixels", "--no-cpu-baseline", "--no-kernel-table"],
+                   context_factory=StubContext, backend="gloo")
+    ctx = StubContext.instances[-1]
+    if rank == 0:
+        with open(os.path.join(out_dir, "pixel_line.json"), "w") as f:
+            f.write([l for l in stdout.getvalue().splitlines() if l.startswith("{")][0])
+    assert ("begin_bdpt", 1, 1, rank, world) in ctx.calls  # timed region: iterations warmup .. warmup + steps - 1 on EVERY rank, pixels rank, rank + world, ...
+    np.save(os.path.join(out_dir, "pixel_film%d.npy" % rank), ctx.reduced_result)
+    np.save(os.path.join(out_dir, "pixel_iterations%d.npy" % rank), np.array(ctx.reduced_iterations))
+
+
+def test_bench_pixel_sharding_control_flow_under_gloo(tmp_path):
+    """camera images tile-local, light images full-frame, ONE sum-reduce of zero-padded sums; the iteration count comes from
+    pixel shard 0 alone. The reduced film equals the unsharded mean of the same iterations."""
+    import json
+    from tests.stub_context import fake_iteration as stub_iteration
+    world, steps, warmup = 2, 3, 1
+    mp.spawn(pixel_bench_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    line = json.loads(open(tmp_path / "pixel_line.json").read())
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["parallelism"].startswith("pixel-sharded x2")
+    # the job is `steps` iterations of the frame, whatever the rank count
+    assert abs(line["value"] - 2048 * 2048 * steps / (line["ms_per_step"] * 1.0e-3 * steps) / 1.0e6) < 1.0e-3 * line["value"]
+    for r in range(world):
+        assert [int(i) for i in np.load(tmp_path / ("pixel_iterations%d.npy" % r))] == list(range(warmup, warmup + steps))
+    camera = sum(stub_iteration(i)[0] for i in range(warmup, warmup + steps))
+    light = sum(stub_iteration(i)[1] for i in range(warmup, warmup + steps))
+    expected = torch.clamp((camera + light) / steps, min=0.0)
+    expected[..., 3] = 1.0
+    for r in range(world):
+        np.testing.assert_allclose(np.load(tmp_path / ("pixel_film%d.npy" % r)), expected.numpy(), rtol=1e-6, atol=1e-6)
