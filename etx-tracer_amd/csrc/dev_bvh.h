@@ -438,10 +438,14 @@ ETX_DEV bool bvh_occluded(const DScene& scene, const BvhNodes& nodes, Tris tris,
 // medium_transmittance, scene_medium.hxx:191-239: homogeneous exp(-sigma_t d); heterogeneous ratio tracking against the
 // majorant with Russian roulette below 0.1 (draws from `smp`: the per-request stream of the shadow kernel).
 ETX_DEV f3 medium_transmittance(const DScene& scene, const DMedium& m, float wavelength, Sampler& smp, const f3& pos, const f3& direction, float distance) {
-  if (m.cls == 0u) {
-    f3 absorption, scattering;
-    medium_coefficients(scene, m, wavelength, absorption, scattering);
-    f3 ext = absorption + scattering;
+  const float4 row = reinterpret_cast<const float4*>(&m)[2];  // extinction (RGB mode), class: one load (DMedium, dev_scene.h)
+  if (__float_as_uint(row.w) == 0u) {
+    f3 ext = {row.x, row.y, row.z};
+    if (scene.spectral != 0u) {
+      f3 absorption, scattering;
+      medium_coefficients(scene, m, wavelength, absorption, scattering);
+      ext = absorption + scattering;
+    }
     return {expf(-ext.x * distance), expf(-ext.y * distance), expf(-ext.z * distance)};
   }
   if (m.max_sigma <= 0.0f)
@@ -551,9 +555,13 @@ ETX_DEV f3 bvh_transmittance_opaque(const DScene& scene, const Nodes& nodes, Tri
     return mk3(0.0f);
   if (medium_index == kInvalid)
     return mk3(1.0f);
-  f3 absorption, scattering;
-  medium_coefficients(scene, scene.mediums[medium_index], wavelength, absorption, scattering);
-  const f3 ext = absorption + scattering;
+  const float4 row = reinterpret_cast<const float4*>(&scene.mediums[medium_index])[2];  // extinction (RGB mode)
+  f3 ext = {row.x, row.y, row.z};
+  if (scene.spectral != 0u) {
+    f3 absorption, scattering;
+    medium_coefficients(scene, scene.mediums[medium_index], wavelength, absorption, scattering);
+    ext = absorption + scattering;
+  }
   return {expf(-ext.x * t_max), expf(-ext.y * t_max), expf(-ext.z * t_max)};
 }
 

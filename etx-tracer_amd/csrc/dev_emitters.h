@@ -473,11 +473,14 @@ ETX_DEV MediumSample sample_medium_heterogeneous(const DScene& s, const DMedium&
   return r;
 }
 
-ETX_DEV MediumSample sample_medium_homogeneous(const DScene& s, const DMedium& m, float wavelength, const f3& throughput, Sampler& smp, const f3& pos, const f3& w_i, float max_t) {
-  if (m.cls != 0u)  // Medium::Class::Heterogeneous
+// `rows`: load_medium_rows(m), which the caller keeps for the phase function and the explicit-connection switch
+ETX_DEV MediumSample sample_medium_homogeneous(const DScene& s, const DMedium& m, const MediumRows& rows, float wavelength, const f3& throughput, Sampler& smp, const f3& pos, const f3& w_i,
+  float max_t) {
+  if (rows.cls != 0u)  // Medium::Class::Heterogeneous
     return sample_medium_heterogeneous(s, m, wavelength, smp, pos, w_i, max_t);
-  f3 absorption, scattering;
-  medium_coefficients(s, m, wavelength, absorption, scattering);
+  f3 absorption = rows.absorption, scattering = rows.scattering;
+  if (s.spectral != 0u)
+    medium_coefficients(s, m, wavelength, absorption, scattering);
   f3 extinction = scattering + absorption;
   f3 albedo = {extinction.x > 0.0f ? scattering.x / extinction.x : 0.0f, extinction.y > 0.0f ? scattering.y / extinction.y : 0.0f,
     extinction.z > 0.0f ? scattering.z / extinction.z : 0.0f};
@@ -503,6 +506,9 @@ ETX_DEV MediumSample sample_medium_homogeneous(const DScene& s, const DMedium& m
   r.sampled_medium_t = sampled ? t : 0.0f;
   r.weight = (sampled ? tr * scattering : tr) / (pdf.x + pdf.y + pdf.z);
   return r;
+}
+ETX_DEV MediumSample sample_medium_homogeneous(const DScene& s, const DMedium& m, float wavelength, const f3& throughput, Sampler& smp, const f3& pos, const f3& w_i, float max_t) {
+  return sample_medium_homogeneous(s, m, load_medium_rows(m), wavelength, throughput, smp, pos, w_i, max_t);
 }
 
 }  // namespace etxd

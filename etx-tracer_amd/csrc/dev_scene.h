@@ -98,20 +98,45 @@ struct DImage {
   uint32_t options;
 };
 
-struct DMedium {
+// The first three 16-byte rows hold what a homogeneous RGB query needs - one float4 load each instead of a dword per field (a lane's loads
+// cost per instruction, not per byte: DESIGN.md 3). Filled by pack_rows() before the upload (host_scene.cpp).
+struct alignas(16) DMedium {
+  f3 absorption;  // RGB-resolved (RGB mode)
+  float g;
+  f3 scattering;
+  uint32_t cls_explicit;  // cls | explicit_connections << 16
+  f3 extinction;          // absorption + scattering
+  uint32_t cls_copy;
   const float* density;
   f3 bounds_min, bounds_max;
-  f3 absorption, scattering;  // RGB-resolved (RGB mode)
   uint32_t absorption_index, scattering_index;  // spectra (spectral mode), kInvalid = zero
   uint32_t cls, explicit_connections;
-  float g, max_sigma;
+  float max_sigma;
   uint32_t dim_x, dim_y, dim_z;
   // spectral scenes, walk medium DERIVED from a subsurface material (bidirectional integrator, host_scene.cpp): the spectra of the material's
   // colour and scattering distances; the coefficients at a wavelength are subsurface::remap_channel of their values there
   uint32_t derived_color, derived_distances;  // spectrum indices, kInvalid = not a derived medium
-  uint32_t pad;
+  void pack_rows() {
+    cls_explicit = cls | (explicit_connections ? 0x10000u : 0u);
+    extinction = {absorption.x + scattering.x, absorption.y + scattering.y, absorption.z + scattering.z};
+    cls_copy = cls;
+  }
 };
+static_assert(sizeof(DMedium) % 16 == 0, "rows of the medium table are read as float4");
 
+// rows 0-1 of a medium: the free-flight sampler and the phase function (RGB mode, homogeneous)
+struct MediumRows {
+  f3 absorption, scattering;
+  float g;
+  uint32_t cls;
+  bool explicit_connections;
+};
+ETX_DEV MediumRows load_medium_rows(const DMedium& m) {
+  const float4* rows = reinterpret_cast<const float4*>(&m);
+  const float4 a = rows[0], b = rows[1];
+  const uint32_t bits = __float_as_uint(b.w);
+  return {{a.x, a.y, a.z}, {b.x, b.y, b.z}, a.w, bits & 0xffffu, (bits & 0x10000u) != 0u};
+}
 
 struct DCamera {
   float view_proj[16];
@@ -162,6 +187,8 @@ struct DScene {
   uint32_t bvh8_node_count;
   int32_t bvh8_root;
   uint32_t boundary_materials;  // materials of Class::Boundary in the table: 0 = a transmittance query is a pure occlusion test (dev_bvh.h bvh_occluded)
+  uint32_t normal_mapped_materials;  // materials with a normal map: 0 = a shading point is the interpolated vertex (make_intersection reads no material for it)
+  uint32_t textured_materials;  // materials that reference any image (normal map included): 0 = no BSDF reads a texture coordinate
   uint32_t heterogeneous_mediums;  // media with a density grid: 0 = every medium_transmittance is one exp (selects the lean shadow kernel together with boundary_materials)
   int32_t bvh_root;  // child encoding (a single leaf scene has a negative root)
   uint32_t bvh_depth; // levels of inner BVH4 nodes
@@ -615,6 +642,8 @@ ETX_DEV Isect make_intersection(const DScene& s, const f3& w_i, float u, float v
   r.w_i = w_i;
   r.t = t;
   r.emitter = s.triangle_to_emitter[tri_index];
+  if (s.normal_mapped_materials == 0u)  // scene-uniform: the two loads below are not issued at all
+    return r;
   const etx_abi_material& mat = s.materials[r.material];
   if ((mat.normal_image_index != kInvalid) && (mat.normal_scale > kEpsilon)) {
     float4 value = image_evaluate(s.images[mat.normal_image_index], r.tex, nullptr);  // image.hxx:117-124 evaluate_normal

@@ -603,8 +603,17 @@ ETX_DEV bool vcm_connect_to_light_vertex(const DScene& scene, const PathState& s
   f3 light_geo_n = mk3(0.0f);  // the geometric normal and the material index come with the triangle's rows
   uint32_t light_material = 0u;
   if (lv.is_medium() == false) {
-    const TriPoint point = lerp_tri_point(scene, scene.triangles[lv.tri], barycentrics(lv.bc_u, lv.bc_v));
-    light_v = point.v, light_geo_n = point.tv.geo_n, light_material = point.material;
+    if (kDiffuseOnly && (scene.textured_materials == 0u)) {
+      // no normal map, no texture anywhere: the interpolated vertex the reference rebuilds here (lerp_vertex, vcm_shared.hxx:770-772) is the
+      // position and shading normal the record already holds, and a Lambert BSDF reads nothing else of it - one row instead of seven
+      const float4 row = scene.tri_shade[size_t(lv.tri) * kTriShadeStride + 6u];  // geometric normal, material index
+      light_v.pos = lv.pos, light_v.nrm = lv.nrm;
+      light_v.tan = light_v.btn = mk3(0.0f), light_v.tex = {0.0f, 0.0f};
+      light_geo_n = xyz(row), light_material = __float_as_uint(row.w);
+    } else {
+      const TriPoint point = lerp_tri_point(scene, scene.triangles[lv.tri], barycentrics(lv.bc_u, lv.bc_v));
+      light_v = point.v, light_geo_n = point.tv.geo_n, light_material = point.material;
+    }
   }
   target_position = lv.is_medium() ? lv.pos : light_v.pos;
   f3 w_o = target_position - (camera_at_medium ? medium_pos : cam->pos);

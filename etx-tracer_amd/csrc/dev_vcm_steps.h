@@ -96,6 +96,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
   const etx_abi_material& step_material = kSimple ? simple_material : scene.materials[(found && (kSimple == false)) ? scene.triangles[tri].material_index : 0u];
   MediumSample ms;
   ms.sampled_medium_t = 0.0f;
+  MediumRows medium_rows = {};  // of st.medium at the start of the segment: free flight, phase function, explicit-connection switch
   uint32_t event = kEventNone;
   if (valid) {
     // the shading point first: its gathers are in flight while the medium is sampled. (Expanding it only for lanes whose free flight reaches the
@@ -105,7 +106,8 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
       isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
     // vcm_try_sampling_medium, vcm_shared.hxx:379-388
     if (st.medium != kInvalid) {
-      ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+      medium_rows = load_medium_rows(scene.mediums[st.medium]);
+      ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], medium_rows, st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
       st.throughput *= ms.weight;
     }
     // ---- phase A
@@ -135,7 +137,7 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
       st.d_vcm *= sqr(st.path_distance + ms.sampled_medium_t);
       st.path_distance = 0.0f;
       store = opt_connect_vertices(it) && (st.depth + 1 <= scene.max_path_length);
-      connect = opt_connect_to_camera(it) && scene.mediums[st.medium].explicit_connections && (st.depth + 1 <= scene.max_path_length);
+      connect = opt_connect_to_camera(it) && medium_rows.explicit_connections && (st.depth + 1 <= scene.max_path_length);
     } else {
       const etx_abi_material& mat = step_material;
       bsdf_data = make_bsdf_data(isect, isect.w_i, st.medium, kPathLight, st.wavelength);
@@ -184,11 +186,10 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
     if (scatter_event == false)
       return false;
     if (at_medium) {  // vcm_shared.hxx:1143-1169
-      const DMedium& med = scene.mediums[st.medium];
       f3 w_i = st.ray_d;
-      f3 w_o = sample_phase_function(w_i, med.g, rnd_bsdf);
-      float pdf_fwd = phase_function(w_i, w_o, med.g);
-      float pdf_rev = phase_function(w_o, w_i, med.g);
+      f3 w_o = sample_phase_function(w_i, medium_rows.g, rnd_bsdf);
+      float pdf_fwd = phase_function(w_i, w_o, medium_rows.g);
+      float pdf_rev = phase_function(w_o, w_i, medium_rows.g);
       st.d_vc = (1.0f / pdf_fwd) * (st.d_vc * pdf_rev + st.d_vcm);
       st.d_vm = (1.0f / pdf_fwd) * (st.d_vm * pdf_rev + 0.0f);
       st.d_vcm = 1.0f / pdf_fwd;
@@ -281,12 +282,14 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
   const etx_abi_material& step_material = kSimple ? simple_material : scene.materials[(found && (kSimple == false)) ? scene.triangles[tri].material_index : 0u];
   MediumSample ms;
   ms.sampled_medium_t = 0.0f;
+  MediumRows medium_rows = {};  // of st.medium at the start of the segment: free flight, phase function, explicit-connection switch
   uint32_t event = kEventNone;
   if (valid) {
     if (found)  // before the medium sampling, as in light_step
       isect = make_intersection(scene, st.ray_d, h.x, h.y, h.z, tri);
     if (st.medium != kInvalid) {
-      ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
+      medium_rows = load_medium_rows(scene.mediums[st.medium]);
+      ms = sample_medium_homogeneous(scene, scene.mediums[st.medium], medium_rows, st.wavelength, st.throughput, st.sampler, st.ray_o, st.ray_d, found ? h.z : kMaxFloat);
       st.throughput *= ms.weight;
     }
     // ---- phase A
@@ -327,12 +330,11 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
     if (at_medium) {
       st.d_vcm *= sqr(st.path_distance + ms.sampled_medium_t);
       st.path_distance = 0.0f;
-      const DMedium& med = scene.mediums[st.medium];
       // phase sampling before the explicit connections (vcm_shared.hxx:954-959)
-      w_o_medium = sample_phase_function(st.ray_d, med.g, rnd_bsdf);
-      pdf_fwd = phase_function(st.ray_d, w_o_medium, med.g);
-      pdf_rev = phase_function(w_o_medium, st.ray_d, med.g);
-      const bool explicit_connections = med.explicit_connections && (st.depth + 1 <= scene.max_path_length);
+      w_o_medium = sample_phase_function(st.ray_d, medium_rows.g, rnd_bsdf);
+      pdf_fwd = phase_function(st.ray_d, w_o_medium, medium_rows.g);
+      pdf_rev = phase_function(w_o_medium, st.ray_d, medium_rows.g);
+      const bool explicit_connections = medium_rows.explicit_connections && (st.depth + 1 <= scene.max_path_length);
       nee = explicit_connections && opt_connect_to_light(it);
       store = explicit_connections && opt_connect_vertices(it);
     } else {

@@ -1484,6 +1484,8 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     if (sss_medium[scene->subsurface_scatter_material] == kInvalid)
       out.sss_media_complete = false;
   }
+  for (DMedium& dm : dmediums)
+    dm.pack_rows();
   if ((rc = upload(out, dmediums.data(), dmediums.size(), d.mediums, error)) || (rc = upload(out, sss_medium.data(), sss_medium.size(), d.material_sss_medium, error)))
     return rc;
 
@@ -1512,9 +1514,17 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     if (rc)
       return rc;
   }
-  d.boundary_materials = 0u;
-  for (uint64_t i = 0; i < scene->materials.count; ++i)
-    d.boundary_materials += (materials[i].cls == ETX_MAT_BOUNDARY) ? 1u : 0u;
+  d.boundary_materials = d.normal_mapped_materials = d.textured_materials = 0u;
+  for (uint64_t i = 0; i < scene->materials.count; ++i) {
+    const etx_abi_material& m = materials[i];
+    d.boundary_materials += (m.cls == ETX_MAT_BOUNDARY) ? 1u : 0u;
+    const bool normal_map = (m.normal_image_index != ETX_ABI_INVALID) && (m.normal_scale > kEpsilon);
+    d.normal_mapped_materials += normal_map ? 1u : 0u;
+    const bool textured = normal_map || (m.reflectance.image_index != ETX_ABI_INVALID) || (m.scattering.image_index != ETX_ABI_INVALID) || (m.emission.image_index != ETX_ABI_INVALID) ||
+                          (m.roughness.image_index != ETX_ABI_INVALID) || (m.metalness.image_index != ETX_ABI_INVALID) || (m.transmission.image_index != ETX_ABI_INVALID) ||
+                          (m.subsurface.image_index != ETX_ABI_INVALID) || (m.thinfilm.thickness_image != ETX_ABI_INVALID);
+    d.textured_materials += textured ? 1u : 0u;
+  }
   d.vertex_count = uint32_t(scene->vertices.count);
   d.triangle_count = uint32_t(scene->triangles.count);
   d.material_count = uint32_t(scene->materials.count);

@@ -9,6 +9,14 @@ namespace etxd {
 constexpr uint32_t kBlockSize = 256;
 constexpr uint32_t kPersistentBlocks = 256 * 8;  // 256 CUs x 8 blocks of 256 threads, grid-stride loops
 
+// Workgroups of kBlockSize threads of `kernel` the device holds at once (hipOccupancyMaxActiveBlocksPerMultiprocessor x compute units, cached per
+// kernel). The persistent kernels grid-stride over their items: more workgroups than that only queue behind the resident ones and pay their
+// prologue again. Applied to the simple group's shade kernels (two workgroups per CU: 512 instead of 2048, 105.4 -> 106.6 Msamples/s on configs[1]); the
+// same cap on the pair, merge and shadow kernels changed nothing (profiles/round4_ab_lds_tables_and_grid.txt) and is not applied.
+uint32_t resident_blocks(const void* kernel);
+// grid of a persistent kernel: what the items need, at most `percent` % of the resident workgroups (0: at most kPersistentBlocks)
+uint32_t persistent_grid(uint32_t blocks_needed, const void* kernel, uint32_t percent);
+
 // Shading groups the scene holds besides "simple" (dev_scene.h kShadeGroup*, set at upload from the materials in use)
 struct ShadeGroups {
   bool general = false, subsurface = false;

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kBlockSize) void k_light_shade(Pipeline p, VcmParam
   __shared__ BlockScratch s_scratch;
   __shared__ BlockScratch3 s_scratch3;
   __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];  // inline traversal of the subsurface walk
-  const LaneStack stack = lane_stack(p.scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
+  const LaneStack stack = lane_stack(scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
   const BlockSlots slots = {&s_scratch, &s_scratch3};
   ETX_BLOCK_LOOP(count, j) {
     bool valid = j < count;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmPara
   __shared__ BlockScratch s_scratch;
   __shared__ BlockScratch3 s_scratch3;
   __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];
-  const LaneStack stack = lane_stack(p.scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
+  const LaneStack stack = lane_stack(scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
   const BlockSlots slots = {&s_scratch, &s_scratch3};
   ETX_BLOCK_LOOP(count, j) {
     bool valid = j < count;

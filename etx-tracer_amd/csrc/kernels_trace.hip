@@ -589,6 +589,7 @@ __global__ __launch_bounds__(kBlockSize, kOpaque ? ETX_SHADOW_OPAQUE_WAVES : 1) 
 
 void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_items, bool flat) {
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.shadow.capacity, max_items) + kBlockSize - 1) / kBlockSize));
+
 #if defined(ETX_NO_OPAQUE_SHADOW)
   const bool opaque = false;
 #else

@@ -12,7 +12,35 @@
 // ballot + one atomic per wavefront. Shading is fp32 VALU / divergence bound (no MFMA: there is no contraction).
 #include "kernels_shade.inl"  // k_light_shade / k_camera_shade templates; the <false> instantiations are separate translation units
 
+#include <mutex>
+#include <unordered_map>
+#include "tuning_knobs.h"
+
 namespace etxd {
+
+uint32_t resident_blocks(const void* kernel) {
+  static std::mutex guard;
+  static std::unordered_map<const void*, uint32_t> cache;
+  std::lock_guard<std::mutex> lock(guard);
+  auto found = cache.find(kernel);
+  if (found != cache.end())
+    return found->second;
+  int per_cu = 0, device = 0, cus = 0;
+  uint32_t value = kPersistentBlocks;
+  if ((hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, int(kBlockSize), 0) == hipSuccess) && (hipGetDevice(&device) == hipSuccess) &&
+      (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) && (per_cu > 0) && (cus > 0))
+    value = uint32_t(per_cu) * uint32_t(cus);
+  cache.emplace(kernel, value);
+  return value;
+}
+
+uint32_t persistent_grid(uint32_t blocks_needed, const void* kernel, uint32_t percent) {
+  uint32_t limit = kPersistentBlocks;
+  if (percent != 0u)
+    limit = uint32_t(min(uint64_t(kPersistentBlocks), max(uint64_t(64), uint64_t(resident_blocks(kernel)) * percent / 100u)));
+  return max(1u, min(blocks_needed, limit));
+}
+
 
 #define ETX_WAVE_LOOP(COUNT)                                                          \
   const uint32_t lane_ = threadIdx.x & 63u;                                            \
@@ -97,11 +125,16 @@ void launch_light_generate(hipStream_t stream, const Pipeline& p, const VcmParam
 
 void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups) {
   const dim3 grid(max(1u, grid_for(min(p.capacity, max_items))));
+  // the simple group's kernel stages the small tables in LDS once per workgroup (dev_stage.h) and runs two workgroups per CU: no more workgroups
+  // than are resident at once, each loops longer
+  static const uint32_t percent = etxh::tuning_knob("ETX_HIP_GRID_SHADE", 100u);
+  const void* simple_kernel = groups.binned() ? reinterpret_cast<const void*>(&k_light_shade<kShadeGroupSimple, true>) : reinterpret_cast<const void*>(&k_light_shade<kShadeGroupSimple, false>);
+  const dim3 simple_grid(persistent_grid(grid.x, simple_kernel, percent));
   if (groups.binned() == false) {
-    hipLaunchKernelGGL((k_light_shade<kShadeGroupSimple, false>), grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+    hipLaunchKernelGGL((k_light_shade<kShadeGroupSimple, false>), simple_grid, dim3(kBlockSize), 0, stream, p, it, in_set);
     return;
   }
-  hipLaunchKernelGGL((k_light_shade<kShadeGroupSimple, true>), grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+  hipLaunchKernelGGL((k_light_shade<kShadeGroupSimple, true>), simple_grid, dim3(kBlockSize), 0, stream, p, it, in_set);
   if (groups.general)
     launch_light_shade_group(stream, p, it, in_set, grid, kShadeGroupGeneral);
   if (groups.subsurface)
@@ -159,11 +192,16 @@ void launch_camera_generate(hipStream_t stream, const Pipeline& p, const VcmPara
 
 void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups) {
   const dim3 grid(max(1u, grid_for(min(p.capacity, max_items))));
+  // the simple group's kernel stages the small tables in LDS once per workgroup (dev_stage.h) and runs two workgroups per CU: no more workgroups
+  // than are resident at once, each loops longer
+  static const uint32_t percent = etxh::tuning_knob("ETX_HIP_GRID_SHADE", 100u);
+  const void* simple_kernel = groups.binned() ? reinterpret_cast<const void*>(&k_camera_shade<kShadeGroupSimple, true>) : reinterpret_cast<const void*>(&k_camera_shade<kShadeGroupSimple, false>);
+  const dim3 simple_grid(persistent_grid(grid.x, simple_kernel, percent));
   if (groups.binned() == false) {
-    hipLaunchKernelGGL((k_camera_shade<kShadeGroupSimple, false>), grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+    hipLaunchKernelGGL((k_camera_shade<kShadeGroupSimple, false>), simple_grid, dim3(kBlockSize), 0, stream, p, it, in_set);
     return;
   }
-  hipLaunchKernelGGL((k_camera_shade<kShadeGroupSimple, true>), grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+  hipLaunchKernelGGL((k_camera_shade<kShadeGroupSimple, true>), simple_grid, dim3(kBlockSize), 0, stream, p, it, in_set);
   if (groups.general)
     launch_camera_shade_group(stream, p, it, in_set, grid, kShadeGroupGeneral);
   if (groups.subsurface)

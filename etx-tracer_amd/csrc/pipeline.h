@@ -115,7 +115,9 @@ struct ShadowQueue {        // transmittance ("shadow") ray requests of the curr
 };
 
 constexpr uint32_t kShadowTargetLight = 0x80000000u;
-constexpr uint32_t kPathTableEntries = 8;          // Pipeline::path_table_entries of scenes without subsurface materials
+constexpr uint32_t kPathTableEntries = 32;         // Pipeline::path_table_entries of scenes without subsurface materials: k_expand_pairs reads a light path's first entries from the
+                                                   // table (16-byte loads) and WALKS the list beyond it, one dependent gather per vertex - a wavefront waits for its longest path. Fog box
+                                                   // (3.8 vertices per path, long tail): 8 entries 101.7, 16 103.0, 32 103.9 Msamples/s (profiles/round4_ab_medium_rows_and_path_table.txt)
 constexpr uint32_t kPathTableEntriesWalk = 32;     // ... with: a light path that walked through an object has a vertex per scattering event
 constexpr uint32_t kMergeBucketBits = 6;                                  // per axis
 constexpr uint32_t kMergeBuckets = 1u << (3u * kMergeBucketBits);         // 64^3 coarse buckets

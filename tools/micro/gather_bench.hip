@@ -112,6 +112,34 @@ __global__ __launch_bounds__(256) void k_gather_lds_narrow(const float4* __restr
   if (acc == 123.456f) sink[0] = acc;
 }
 
+// a small table staged in LDS and read through a GENERIC pointer (flat_load: the address decides between the LDS and the global path) - what code
+// written against `const T*` tables costs when a kernel redirects a table pointer to its LDS copy without retyping the code. kDwords 1 / 2 / 4.
+template <int kDwords>
+__global__ __launch_bounds__(256) void k_gather_flat_lds(const float4* __restrict__ table, uint32_t iters, float* sink) {
+  __shared__ float s_table[256 * 32];
+  for (uint32_t i = threadIdx.x; i < 256u * 32u; i += 256u)
+    s_table[i] = reinterpret_cast<const float*>(table)[i];
+  __syncthreads();
+  const float* generic = s_table;
+  asm volatile("" : "+v"(generic));  // the compiler no longer knows the address space
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  float acc = 0.0f;
+#pragma unroll 2
+  for (uint32_t i = 0; i < iters; ++i) {
+    const uint32_t r = hash_u32(tid * 0x9e3779b9u + i) & 8191u;
+    if (kDwords == 1) {
+      acc += generic[r];
+    } else if (kDwords == 2) {
+      const float2 v = *reinterpret_cast<const float2*>(generic + (r & ~1u));
+      acc += v.x + v.y;
+    } else {
+      const float4 v = *reinterpret_cast<const float4*>(generic + (r & ~3u));
+      acc += v.x + v.w;
+    }
+  }
+  if (acc == 123.456f) sink[0] = acc;
+}
+
 // no load at all: the cost of the index arithmetic of the loops above
 __global__ __launch_bounds__(256) void k_no_load(uint32_t iters, float* sink) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -171,6 +199,9 @@ int main() {
   RUN((k_no_load), "no load (index arithmetic only)", 1, 0, 0, iters, sink)
   RUN((k_gather_lds_narrow<1>), "LDS ds_read_b32, dword per lane", 1, 4, 256, table, iters, sink)
   RUN((k_gather_lds_narrow<2>), "LDS ds_read_b64, pair per lane", 1, 8, 256, table, iters, sink)
+  RUN((k_gather_flat_lds<1>), "LDS via flat_load_dword", 1, 4, 256, table, iters, sink)
+  RUN((k_gather_flat_lds<2>), "LDS via flat_load_dwordx2", 1, 8, 256, table, iters, sink)
+  RUN((k_gather_flat_lds<4>), "LDS via flat_load_dwordx4", 1, 16, 256, table, iters, sink)
   RUN((k_gather_lds<1>), "LDS ds_read_b128, record per lane", 1, 16, 256, table, iters, sink)
   RUN((k_gather_lds<8>), "LDS ds_read_b128, record per lane", 8, 16, 256, table, iters, sink)
   return 0;
