@@ -1091,7 +1091,8 @@ ETX_DEV bool bdpt_connect_pair(const Pipeline& p, const DScene& scene, const Vcm
     return false;
   dw = dw * (1.0f / sqrtf(dwl));
   Sampler smp;
-  smp.seed = Sampler::random_seed(z.seed, pair.y), smp.fixed_u = smp.fixed_v = smp.fixed_w = 0.0f;
+  // one stream per (camera vertex, light vertex), keyed by the two vertices' own seeds - not by the light vertex's pool slot, which differs from run to run
+  smp.seed = Sampler::random_seed(z.seed, y.seed ^ y.index_in_path), smp.fixed_u = smp.fixed_v = smp.fixed_w = 0.0f;
   const f3 bsdf_y = bdpt_bsdf<kSimple>(scene, y.full, kPathLight, dw, z.wavelength, smp).bsdf;
   const f3 bsdf_z = bdpt_bsdf<kSimple>(scene, z.full, kPathCamera, -dw, z.wavelength, smp).bsdf;
   const f3 connect = y.throughput * bsdf_y * bsdf_z;

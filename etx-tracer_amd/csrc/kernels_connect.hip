@@ -121,8 +121,9 @@ __global__ __launch_bounds__(kBlockSize) void k_connect_pairs(Pipeline p, VcmPar
         CameraVertex cv = load_camera_vertex(p, scene, pair.x);
         const uint32_t target_path_length = cv.st.depth + lv.index_in_path + 2u;  // vcm_shared.hxx:774
         if ((target_path_length >= scene.min_path_length) && (target_path_length <= scene.max_path_length)) {
-          // the reference evaluates every connection of a vertex with the path's sampler; decorrelate per pair
-          cv.st.sampler.seed = Sampler::random_seed(cv.st.sampler.seed, pair.y);
+          // the reference evaluates every connection of a vertex with the path's sampler; decorrelate per pair - by the light vertex's index in
+          // ITS path (the pairs of a camera vertex are the vertices of one light path), not by its pool slot, which differs from run to run
+          cv.st.sampler.seed = Sampler::random_seed(cv.st.sampler.seed, lv.index_in_path);
           f3 target_position, value;
           if (vcm_connect_to_light_vertex<kDiffuseOnly>(scene, cv.st, lv, it, cv.at_medium, &cv.isect, cv.medium_pos, cv.st.sampler, target_position, value)) {
             f3 p0 = cv.medium_pos;
@@ -560,8 +561,8 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
           const f3 wi = {wd.x, wd.y, wd.z};
           const etx_abi_material& mat = scene.materials[v.material];
           const BsdfData camera_data = {v.nrm, v.tan, v.btn, v.tex, v.w_i, v.medium, kPathCamera, v.wavelength};
-          Sampler smp;  // the reference continues the path's stream through all photons; here one stream per (vertex, photon)
-          smp.seed = Sampler::random_seed(v.seed, j);
+          Sampler smp;  // the reference continues the path's stream through all photons; here one stream per (vertex, photon), keyed by the photon's
+          smp.seed = Sampler::random_seed(v.seed, __float_as_uint(wd.x) ^ (__float_as_uint(wd.w) * 0x9e3779b9u));  // own values, not by where the sort put it
           smp.fixed_u = smp.fixed_v = smp.fixed_w = 0.0f;
           const BsdfEval camera_bsdf = bsdf_evaluate_general(scene, camera_data, -wi, v.material, smp);
           if (camera_bsdf.valid()) {

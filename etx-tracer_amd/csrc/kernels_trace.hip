@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
       continue;
     const float4 a = ray_o_tmin[i];
     const float4 b = ray_d_tmax[i];
-    uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ i;
+    uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ (__float_as_uint(a.z) * 0x85ebca6bu) ^ (__float_as_uint(b.x) * 0xc2b2ae35u);  // of the ray itself, not of its queue slot (run-dependent)
     const RayQ ray = {{a.x, a.y, a.z}, a.w, {b.x, b.y, b.z}, b.w};
     uint32_t flags = 0u;
     Hit h = kFlat ? bvh_flat_closest(scene, scene.bvh_tris, ray, alpha_seed, kCross ? &flags : nullptr)
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene s
           ray_index = cursor + rank;
           const float4 a = ray_o_tmin[ray_index];
           const float4 b = ray_d_tmax[ray_index];
-          alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ ray_index;
+          alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ (__float_as_uint(a.z) * 0x85ebca6bu) ^ (__float_as_uint(b.x) * 0xc2b2ae35u);
           ray = {{a.x, a.y, a.z}, a.w, {b.x, b.y, b.z}, b.w};
           if constexpr (kWide)
             inv_d = {bvh8_reciprocal(ray.d.x), bvh8_reciprocal(ray.d.y), bvh8_reciprocal(ray.d.z)};
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(kBlockSize, kOpaque ? ETX_SHADOW_OPAQUE_WAVES : 1) 
     if (i < count) {
       const float4 a = p.shadow.p0_medium[i];
       const float4 b = p.shadow.p1_target[i];
-      uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ i;
+      uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ (__float_as_uint(a.z) * 0x85ebca6bu) ^ (__float_as_uint(b.x) * 0xc2b2ae35u);  // of the segment itself, not of its queue slot
       f3 tr = mk3(1.0f);
       if (kWide)
         tr = bvh_transmittance_opaque(scene, nodes8, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), p.shadow.value[i].w, alpha_seed);

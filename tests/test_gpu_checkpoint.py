@@ -73,6 +73,31 @@ def test_resumed_render_is_the_uninterrupted_render(etx, golden_dir, tmp_path, k
     assert float(np.abs(cam_w - cam_cut).max()) > 1.0e-3  # the comparison above is not trivially true: 24 and 64 spp differ
 
 
+def test_checkpoint_crosses_processes(etx, golden_dir, tmp_path):
+    """A checkpoint written by ANOTHER process resumes here: the header's scene hash is taken field by field (host_scene.cpp content_hash), so nothing
+    of it depends on what a process left in the padding of the scene's structs."""
+    import subprocess
+    import sys
+    spp, cut = 32, 12
+    path = str(tmp_path / "child.etxc")
+    snapshot = os.path.join(golden_dir, "cornell_classic_128.etxscene")
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "checkpoint_child.py")
+    subprocess.run([sys.executable, child, snapshot, str(spp), str(cut), path], check=True, timeout=300)
+    whole = make(etx, golden_dir, etx.HIPVCM, "classic", spp, {"vcm-blue_noise": False})
+    whole.render()
+    cam_w, light_w = films(etx, whole)
+    whole.context.close()
+    second = make(etx, golden_dir, etx.HIPVCM, "classic", spp, {"vcm-blue_noise": False})
+    second.resume(path)
+    assert second.status().completed_iterations == cut
+    second.finish()
+    assert second.status().completed_iterations == spp
+    cam_r, light_r = films(etx, second)
+    second.context.close()
+    close_films(cam_w, cam_r, "cross-process camera image")
+    close_films(light_w, light_r, "cross-process light image")
+
+
 def test_checkpoint_keeps_the_adaptive_sampling_state(etx, golden_dir):
     """Path tracing with Scene::noise_threshold: the even-sample sums, the per-pixel sample counts and the converged flags travel with
     the film, so the resumed render goes on sampling exactly the pixels the interrupted one would have."""

@@ -29,8 +29,10 @@ def render(etx, golden_dir, cls, flavour, spp, options, pixel_first=0, pixel_str
     return cam[..., :3], light[..., :3], stats, pool_bytes
 
 
-@pytest.mark.parametrize("flavour", ["classic", "full"])
+@pytest.mark.parametrize("flavour", ["classic", "full", "glass"])
 def test_bdpt_two_pixel_shards_sum_to_the_unsharded_film(etx, golden_dir, flavour):
+    """glass: rough dielectric / conductor / plastic BSDFs evaluated stochastically - the stream of a connection is keyed by its two vertices' own seeds
+    (kernels_bdpt.hip bdpt_connect_pair), not by a pool slot, so a shard evaluates exactly what the unsharded render evaluates."""
     options = {"bdpt-mode": etx.api.BDPT_MODE_FULL, "bdpt-blue_noise": False}
     spp = 16
     cam, light, whole, whole_bytes = render(etx, golden_dir, etx.HIPBidirectional, flavour, spp, options)
@@ -63,3 +65,20 @@ def test_vcm_refuses_pixel_sharding(etx, golden_dir):
     with pytest.raises(api.EtxHipError, match="photon map"):
         integ.render()
     integ.context.close()
+
+
+def test_vcm_render_is_reproducible_on_stochastic_bsdfs(etx, golden_dir):
+    """Two renders of the rough-material box: every random stream - also those of the stochastically evaluated BSDFs in connections and merges and
+    the alpha / medium streams of the ray queries - is keyed by path data (pixel, iteration, index in path, the photon's own values), never by a pool
+    or queue position, so the films differ by fp32 summation order only (float atomics, several iterations in flight)."""
+    films = []
+    for _ in range(2):
+        snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_rough_128.etxscene"))
+        snap.samples = 16
+        integ = etx.HIPVCM(snap)
+        integ.options()["vcm-blue_noise"] = False
+        integ.render()
+        films.append((integ.film(etx.api.LAYER_CAMERA)[..., :3], integ.film(etx.api.LAYER_LIGHT)[..., :3]))
+        integ.context.close()
+    for a, b in zip(*films):
+        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)
