@@ -52,7 +52,7 @@ ETX_DEV void round_housekeeping(uint32_t* __restrict__ counters, uint32_t active
 // kCross (pipeline, flat scenes that hold Boundary materials): a path that is in NO medium and whose closest hit is a medium boundary
 // crosses it right here - vcm_handle_boundary_bsdf (vcm_shared.hxx:436-449) draws nothing and leaves only the medium, the ray origin and the
 // path distance changed; handle_surface's Boundary branch (bidirectional.cxx:586-593) comes after three next_2d draws of the vertex
-// (six numbers the crossing here does not take from the path's stream: another stream position from there on, the same distribution) -
+// (six numbers: the crossing here advances the path's stream by them, so that under the reference's seeding the two stay aligned draw by draw) -
 // and is traced again from the other side; the shade kernel then meets the segment INSIDE the medium. In the fog box that is the primary segment of every camera path and every
 // segment that leaves a wall: a quarter of all segments no longer cost a round of their own. A path that is inside a medium when it
 // reaches a boundary is left to the shade kernel (the medium is sampled first).
@@ -112,6 +112,13 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
         const_cast<float4*>(ray_d_tmax)[i] = mk4(ray.d, kMaxFloat);
         uint4 meta = set.meta[i];
         meta.z = medium;
+        if (cross_mode == kCrossBdpt) {  // the six numbers handle_surface draws before its Boundary branch (bidirectional.cxx:586-593): the path's stream stays where the reference's is
+          Sampler stream;
+          stream.seed = meta.x;
+          for (uint32_t k = 0; k < crossings * 6u; ++k)
+            (void)stream.next();
+          meta.x = stream.seed;
+        }
         set.meta[i] = meta;
         if (cross_mode == kCrossVcm) {  // state.path_distance += intersection.t
           float4 mis = set.mis[i];

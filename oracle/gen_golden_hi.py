@@ -14,6 +14,7 @@ tests of tests/test_gpu_parity_hi.py ("a high-spp oracle reference
   tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_shared_first_vertex.npz   (--integrators firstvertex) ETX_ORACLE_DECORRELATE=3
   tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_bluenoise[_rekeyed].npz   (--integrators bluenoise) VCMOptions defaults = blue noise on
   tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_opaque_none.npz   (--integrators opaque_none) ETX_ORACLE_BVH_DRAWS=opaque_none, shared seeds
+  tests/golden/hi/cornell_<flavour>_128_bdpt3_<spp>_opaque_none.npz   (--integrators bdpt_opaque_none) the same pin for CPUBidirectional, BDPTFull
   tests/golden/hi/cornell_<flavour>_128_vcm_<spp>_rekeyed.npz        ETX_ORACLE_DECORRELATE=2: the camera path re-keys its sampler at
       its first segment = independent light / camera streams, the estimator the device implements
 
@@ -104,6 +105,10 @@ def main():
             # (ETX_ORACLE_BVH_DRAWS=opaque_none, oracle/shims/raytracing_bvh.cxx): a film that no longer depends on the traversal order
             render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_opaque_none.npz" % (flavour, args.spp)), args.cores, env_extra={"ETX_ORACLE_BVH_DRAWS": "opaque_none"},
                    extra=["--opt", "vcm-blue_noise=false"] + variant)
+        if "bdpt_opaque_none" in integrators:
+            # the same pin for CPUBidirectional (BDPTFull): shared light / camera seeds (bidirectional.cxx:377-380), candidate draws of opaque triangles off the stream
+            render(snapshot, "bdpt", args.spp, os.path.join(HI, "cornell_%s_128_bdpt3_%d_opaque_none.npz" % (flavour, args.spp)), args.cores, env_extra={"ETX_ORACLE_BVH_DRAWS": "opaque_none"},
+                   extra=["--opt", "bdpt-blue_noise=false", "--opt", "bdpt-mode=3"])
         if "rekeyed" in integrators:
             # mode 2: the camera sub path draws from a stream of its own from its first segment on (oracle/shims/raytracing_bvh.cxx)
             render(snapshot, "vcm", args.spp, os.path.join(HI, "cornell_%s_128_vcm_%d_rekeyed.npz" % (flavour, args.spp)), args.cores, env_extra={"ETX_ORACLE_DECORRELATE": "2"},

@@ -24,7 +24,7 @@ def load(golden_dir, name):
     return np.load(path)
 
 
-def render_halves(etx, golden_dir, flavour, spp, options, cie=None):
+def render_halves(etx, golden_dir, flavour, spp, options, cie=None, debug_flags=0):
     films = []
     for first in (0, 1):
         snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_%s_128.etxscene" % flavour))
@@ -32,6 +32,8 @@ def render_halves(etx, golden_dir, flavour, spp, options, cie=None):
         integ = etx.HIPBidirectional(snap, first_iteration=first, iteration_stride=2)
         integ.options().update(options)
         integ.cie_table = cie
+        if debug_flags:
+            integ.context.set_debug_flags(debug_flags)
         integ.render()
         cam, light = integ.film(etx.api.LAYER_CAMERA), integ.film(etx.api.LAYER_LIGHT)
         stats = integ.status()
@@ -52,6 +54,20 @@ def test_bdpt_full_matches_reference_at_4096_spp(etx, golden_dir, flavour):
     compare((cam_a, cam_b), golden["camera"], flavour + " bdpt camera (independent streams)")
     golden = load(golden_dir, "cornell_%s_128_bdpt3_4096.npz" % flavour)
     compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " bdpt camera+light (reference as is)", rmse_limit=2.5e-3, mean_limit=1.0e-2, bias_p99_limit=0.08)
+
+
+@pytest.mark.parametrize("flavour", ["classic", "full"])
+def test_bdpt_shared_streams_match_the_pinned_reference(etx, golden_dir, flavour):
+    """As test_gpu_parity_hi.test_vcm_shared_streams_match_the_pinned_reference, for CPUBidirectional (BDPTFull): the device takes the reference's
+    seeding - camera path i keeps the seed of light path i (bidirectional.cxx:377-380; debug flag bit 15, k_bdpt_camera_generate) - and is compared
+    with the UNMODIFIED integrator whose film ETX_ORACLE_BVH_DRAWS=opaque_none pins (the same film under every traversal order,
+    tests/test_reference_order_spread.py). north_star's limits, no allowance."""
+    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, flavour, 4096, {"bdpt-mode": etx.api.BDPT_MODE_FULL, "bdpt-blue_noise": False}, debug_flags=0x8000)
+    golden = load(golden_dir, "cornell_%s_128_bdpt3_4096_opaque_none.npz" % flavour)
+    assert int(golden["spp"]) in (4095, 4096)
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " bdpt camera+light (shared streams, pinned reference)")
+    compare((light_a, light_b), golden["light"], flavour + " bdpt light (shared streams, pinned reference)", mean_limit=1.0e-2, bias_p99_limit=0.2)
+    compare((cam_a, cam_b), golden["camera"], flavour + " bdpt camera (shared streams, pinned reference)")
 
 
 @pytest.mark.parametrize("flavour", ["classic", "full", "cloud", "glass"])

@@ -18,6 +18,7 @@ import itertools
 import os
 
 import numpy as np
+import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HI = os.path.join(HERE, "golden", "hi")
@@ -88,7 +89,8 @@ def test_where_the_correlation_sits():
     assert distance(load("full", "cornell_%s_128_vcm_4096_shared_first_vertex.npz"), rekeyed)[0] < 8.0e-4  # two independent 4096-spp films of this scene: 6e-4
 
 
-def test_opaque_none_pins_the_unmodified_reference(tmp_path):
+@pytest.mark.parametrize("integrator", ["vcm", "bdpt"])
+def test_opaque_none_pins_the_unmodified_reference(tmp_path, integrator):
     """ETX_ORACLE_BVH_DRAWS=opaque_none (oracle/shims/raytracing_bvh.cxx): the candidate draws of triangles that can never fail the alpha test
     (opacity 1, no alpha image) are taken from a scratch copy of the sampler, so the path's stream no longer depends on how many candidates a
     query met. The UNMODIFIED integrator (shared light / camera seeds) then renders THE SAME film under every traversal order - the pin the
@@ -96,7 +98,6 @@ def test_opaque_none_pins_the_unmodified_reference(tmp_path):
     (built by __graft_entry__.build() where /root/reference exists); 128 x 128, 4 iterations of the fog box."""
     import subprocess
     import sys
-    import pytest
     root = os.path.dirname(HERE)
     oracle = os.path.join(root, "oracle", "_ref", "etx_oracle")
     if not os.path.exists(oracle):
@@ -109,8 +110,9 @@ def test_opaque_none_pins_the_unmodified_reference(tmp_path):
         env = dict(os.environ, ETX_ORACLE_BVH_ORDER=order)
         if draws:
             env["ETX_ORACLE_BVH_DRAWS"] = draws
-        subprocess.check_call([oracle, "--load-snapshot", os.path.join(HERE, "golden", "cornell_full_128.etxscene"), "--integrator", "vcm", "--spp", "4", "--out", out,
-                               "--opt", "vcm-blue_noise=false"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+        options = ["--opt", "vcm-blue_noise=false"] if integrator == "vcm" else ["--opt", "bdpt-blue_noise=false", "--opt", "bdpt-mode=3"]  # CPUBidirectional: BDPTFull
+        subprocess.check_call([oracle, "--load-snapshot", os.path.join(HERE, "golden", "cornell_full_128.etxscene"), "--integrator", integrator, "--spp", "4", "--out", out] + options,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
         film = film_io.read_film(out)
         return film["camera"][..., :3].astype(np.float64) + film["light"][..., :3].astype(np.float64)
 
