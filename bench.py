@@ -3,9 +3,13 @@
 
 One "step" = one full VCM iteration (light pass, photon grid, camera pass with connections + merge, film
 accumulation) over the whole 1920x1080 frame = 2 073 600 samples. N GPUs: every rank renders `steps` iterations of
-its own shard of the iteration sequence (rank r: r, r+N, ...; weak scaling), the timed region ends with the single
-RCCL all-reduce of the film. Scene upload / BVH build happen before the timed region (inputs resident
-in HBM).
+its own shard of the iteration sequence (rank r: r, r+N, ...; weak scaling) and the film is reduced over RCCL at the
+end of every iteration (--reduce-every 1 = north_star; k: every k-th): asynchronous, out of place, from a snapshot, on a
+communication stream of its own while the lanes keep rendering (csrc/host_reduce.h); the last reduce of the timed
+region is the blocking one (etx_hip_reduce_film) that leaves every rank with the whole-job film. All reduces are
+inside the timed region. Scene upload / BVH build happen before the timed region (inputs resident in HBM).
+The timed region is repeated --repeats times (each: exactly --steps steps between barrier + synchronize on both
+sides); `value` / `ms_per_step` are the median repeat's, `repeats` lists all of them.
 
   python bench.py --gpus 1 --steps 8 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -90,6 +94,13 @@ def main(argv=None, context_factory=None, backend="nccl"):
                         help="how N > 1 ranks split the job. iterations (default): rank r renders iterations r, r + N, ... of the full frame - weak scaling, every integrator. "
                              "pixels: every rank renders ALL iterations of pixels r, r + N, ... (etx_hip_begin_ex; bidirectional workloads only) - strong scaling: the job "
                              "is --steps iterations of the frame whatever N is, and each rank holds 1/N of the vertex pools")
+    parser.add_argument("--reduce-every", type=int, default=1,
+                        help="film reduce cadence in iterations (N > 1, or N = 1 with --comm-single): 1 = at the end of every iteration (north_star), k = every k-th, "
+                             "0 = only the final reduce of the timed region")
+    parser.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; value = the median one")
+    parser.add_argument("--comm-single", action="store_true",
+                        help="N = 1 only: create a one-rank RCCL communicator, so that the reduces of the timed region run (snapshot kernel + one-rank all-reduce) and their "
+                             "device time can be read on one GPU (reduce.device_ms_avg); without it a single GPU has nothing to reduce")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-kernel-table", action="store_true", help="skip the extra pass that times every kernel group (profiling runs)")
     args = parser.parse_args(argv)
@@ -148,6 +159,8 @@ def main(argv=None, context_factory=None, backend="nccl"):
         ctx.upload_cie_table(cie["xyz"], float(cie["first_wavelength"]))
     if distributed:
         multi_gpu.init_context_comm(ctx, rank, world)
+    elif args.comm_single:
+        ctx.comm_init(0, 1, api.comm_unique_id(ctx.library))
 
     # VCMOptions::default_values(): blue noise on. The C++ host tabulates its BNSampler for the class of scene.samples
     # (64 -> set 6, include/etx_hip.h); here the same table comes from the committed fixture of the reference's sampler.
@@ -178,13 +191,33 @@ def main(argv=None, context_factory=None, backend="nccl"):
             begin(first_offset, 1)  # the same iterations on every rank, each for its own pixels
         else:
             begin(rank + first_offset * world, world)
-        for _ in range(count):
+        reduces_before = ctx.reduce_info()
+        host_blocked = 0.0
+        for step in range(count):
             ctx.render_iteration()  # asynchronous: iterations overlap on the device lanes
+            # north_star: the film reduce "at the end of each iteration". Enqueued behind the commits handed over so far, on the communication
+            # stream; the lanes keep rendering. (The last one of the region is the blocking etx_hip_reduce_film below.)
+            if (args.reduce_every > 0) and ((step + 1) % args.reduce_every == 0) and (step + 1 < count):
+                t_reduce = time.perf_counter()
+                ctx.reduce_film_begin()  # waits only if the previous reduce is still running
+                host_blocked += time.perf_counter() - t_reduce
         ctx.sync()
         s = ctx.stats()             # totals since begin
         acc = {"rays": s.rays_extension, "trace_ms": s.ms_trace_closest, "launches": s.launches_trace_closest, "shadow": s.rays_shadow, "lv": s.light_vertices,
                "rounds": s.wavefront_bounces, "examined": s.photons_examined, "stats": s}
-        ctx.reduce_film()
+        t_reduce = time.perf_counter()
+        ctx.reduce_film()           # every iteration of every rank is in the reduced copy; rendering could go on
+        final_blocked = time.perf_counter() - t_reduce
+        after = ctx.reduce_info()
+        n_reduces = int(after.reduces - reduces_before.reduces)
+        acc["reduce"] = {
+            "every": args.reduce_every, "count": n_reduces, "payload_mb": round(after.payload_bytes / 1.0e6, 2),
+            # device time of a reduce = snapshot kernel + collectives, HIP events on the communication stream (overlaps the lanes' kernels)
+            "device_ms_avg": round((after.total_device_ms - reduces_before.total_device_ms) / n_reduces, 4) if n_reduces else None,
+            "device_ms_last": round(after.last_device_ms, 4) if n_reduces else None,
+            # what the host thread spent inside the reduce calls: the asynchronous ones (waiting for a predecessor still in flight) and the final blocking one
+            "host_blocked_async_ms": round(host_blocked * 1.0e3, 4), "host_blocked_final_ms": round(final_blocked * 1.0e3, 4),
+        }
         return acc
 
     def barrier():
@@ -196,12 +229,16 @@ def main(argv=None, context_factory=None, backend="nccl"):
 
     if args.warmup > 0:
         run_steps(args.warmup, 0)
-    barrier()
-    t0 = time.perf_counter()
-    acc = run_steps(args.steps, args.warmup)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = multi_gpu.max_over_ranks(elapsed, device=device)
+    regions = []
+    for repeat in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        region_acc = run_steps(args.steps, args.warmup + repeat * args.steps)
+        barrier()
+        region_elapsed = multi_gpu.max_over_ranks(time.perf_counter() - t0, device=device)  # the same number on every rank: all pick the same region
+        regions.append((region_elapsed, repeat, region_acc))
+    # the headline is the MEDIAN region (its own steps, time and counters); min / max show the spread of this box
+    elapsed, median_repeat, acc = sorted(regions, key=lambda r: r[0])[(len(regions) - 1) // 2]
 
     result = ctx.read_film(api.LAYER_RESULT)
     finite = bool(np.isfinite(result).all())
@@ -289,6 +326,12 @@ def main(argv=None, context_factory=None, backend="nccl"):
     pmc_path, pmc = profile_lookup.summary_for(args.workload)
     pmc_groups = profile_lookup.BDPT_GROUPS if bdpt_workload else profile_lookup.VCM_GROUPS
     pmc_source = os.path.relpath(pmc_path, ROOT) if pmc_path else None
+    # The counters describe the library they were collected on (tools/profile_round.sh records its hash in _meta). A summary of another build
+    # is not evidence about this one: the counter fields are nulled and the line says so instead of quoting them.
+    profiled_sha = (pmc or {}).get("_meta", {}).get("library_sha16")
+    counters_stale = bool(pmc is not None and context_factory is None and profiled_sha != library_sha16())
+    if counters_stale:
+        pmc = None
     if kernels is not None:
         for group, prefixes in pmc_groups.items():
             if group in kernels:
@@ -302,6 +345,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
                     kernels[group]["exclusive_1lane"] = {"ms_per_step": row["ms_per_step"], "achieved": round(exclusive, 1) if exclusive else None,
                                                          "frac": round(exclusive / HBM_PEAK_GBS, 5) if exclusive else None}
         kernels["counters_1lane_source"] = pmc_source
+        kernels["counters_stale"] = counters_stale
 
     dominant = None
     if kernels is not None:
@@ -321,6 +365,10 @@ def main(argv=None, context_factory=None, backend="nccl"):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1.0e3, 4),
+            "repeats": {"count": len(regions), "values": [round(samples / r[0] / 1.0e6, 4) for r in regions], "min": round(samples / max(r[0] for r in regions) / 1.0e6, 4),
+                        "median": round(value, 4), "max": round(samples / min(r[0] for r in regions) / 1.0e6, 4),
+                        "note": "each value: exactly `steps` steps between barrier + synchronize; `value` is the median region, whose counters the line reports"},
+            "reduce": acc["reduce"],
             "higher_is_better": True,
             "scaling": "strong" if pixel_sharded else "weak",
             "vs_baseline": None,
@@ -338,8 +386,9 @@ def main(argv=None, context_factory=None, backend="nccl"):
                 "triangles": int(snap.triangle_count), "tree": {"builder": args.bvh, "build_ms": round(tree["build_ms"], 3), "nodes": tree["nodes"], "depth": tree["depth"], "stack_need": tree["stack_need"],
                                                                 "upload_s": round(upload_seconds, 3)},
                 "samples_per_step": width * height,
-                "parallelism": ("pixel-sharded x%d (rank r: pixels r, r + N, ... of every iteration), one RCCL film all-reduce of zero-padded sums at the end" if pixel_sharded
-                                else "iteration-sharded x%d, one RCCL film all-reduce at the end") % world,
+                "parallelism": ("pixel-sharded x%d (rank r: pixels r, r + N, ... of every iteration), RCCL film all-reduce of zero-padded sums, " if pixel_sharded
+                                else "iteration-sharded x%d, RCCL film all-reduce (out of place, from a snapshot, overlapped with rendering), ") % world +
+                               ("every %d iteration(s) + the final one" % args.reduce_every if args.reduce_every > 0 else "once at the end of the timed region"),
                 "working_set_gb": round(ctx.device_bytes() / 1.0e9, 2),  # queues, pools, grid and film of all lanes (etx_hip_device_bytes)
                 "pool_grows": int(acc["stats"].pool_grows),  # iterations of the timed region that overflowed a pool and were rendered again (0 once the pools have their size)
                 "lanes": lanes, "workload_key": args.workload, "library_sha16": library_sha16(),
@@ -356,7 +405,9 @@ def main(argv=None, context_factory=None, backend="nccl"):
                 "traffic_note": ("HBM bytes per average launch = PMC bytes per ray of the traversal kernel INSIDE a one-lane run of this pipeline (%s B: FETCH_SIZE x 2 + WRITE_SIZE of %s, %s) "
                                  "x rays per launch of the timed region; algorithmic 48 B per ray. A query that crosses a medium boundary also rewrites its path's ray, medium and "
                                  "path distance (about 112 B of state per crossing, counters.boundary_crossings_per_sample)" % (trace_pmc["hbm_bytes_per_unit"], ", ".join(trace_pmc["kernels"]), pmc_source))
-                                if trace_pmc and trace_pmc["hbm_bytes_per_unit"] else "no committed PMC summary of this workload names the traversal kernel of this build",
+                                if trace_pmc and trace_pmc["hbm_bytes_per_unit"] else
+                                ("the committed PMC summary %s was collected on library %s, this run loaded %s: counters withheld (counters_stale)" % (pmc_source, profiled_sha, library_sha16())
+                                 if counters_stale else "no committed PMC summary of this workload names the traversal kernel of this build"),
                 "bytes_per_ray": BYTES_PER_RAY,
                 "rays": acc["rays"],
                 "launches": acc["launches"],
@@ -369,6 +420,8 @@ def main(argv=None, context_factory=None, backend="nccl"):
             },
             "kernels": kernels,
             "dominant_kernel": dominant,
+            "counters_stale": counters_stale,
+            "counters_profiled_library_sha16": profiled_sha,
             "counters": {
                 "rays_per_sample": round((acc["rays"] + acc["shadow"]) / (float(width) * height * args.steps), 3),
                 "light_vertices_per_path": round(acc["lv"] / (float(width) * height * args.steps), 3),

@@ -26,7 +26,7 @@ BVH_WIDE = 256  # | BVH_HOST_SAH: also the eight-wide tree with 8-bit child boxe
 EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene", "etx_hip_update_scene",
     "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_upload_rgb_response", "etx_hip_begin", "etx_hip_begin_ex", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
-    "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_checkpoint_bytes", "etx_hip_checkpoint_save", "etx_hip_checkpoint_load", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_set_debug_flags", "etx_hip_set_pool_policy", "etx_hip_lanes", "etx_hip_device_bytes", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film",
+    "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_checkpoint_bytes", "etx_hip_checkpoint_save", "etx_hip_checkpoint_load", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_set_debug_flags", "etx_hip_set_pool_policy", "etx_hip_lanes", "etx_hip_device_bytes", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film", "etx_hip_reduce_film_begin", "etx_hip_reduce_film_end", "etx_hip_reduce_info",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
     "etx_hip_set_bvh_builder", "etx_hip_bvh_info", "etx_hip_selftest_stack", "etx_hip_host_check_bvh_builder", "etx_hip_host_bvh_stats_builder", "etx_hip_host_bvh8_stats",
 )
@@ -46,7 +46,8 @@ class VCMOptions(ctypes.Structure):
         ("kernel", ctypes.c_uint32),
         ("initial_radius", ctypes.c_float),
         ("blue_noise", ctypes.c_uint8),
-        ("_pad", ctypes.c_uint8 * 15),
+        ("reference_seeding", ctypes.c_uint8),  # in VCMOptions' tail padding: option key "hip-reference_seeding" (etx_scene_abi.h)
+        ("_pad", ctypes.c_uint8 * 14),
     ]
 
     @staticmethod
@@ -90,7 +91,8 @@ class BDPTOptions(ctypes.Structure):
         ("connect_vertices", ctypes.c_uint8),
         ("mis", ctypes.c_uint8),
         ("blue_noise", ctypes.c_uint8),
-        ("_pad", ctypes.c_uint8 * 6),
+        ("reference_seeding", ctypes.c_uint8),
+        ("_pad", ctypes.c_uint8 * 5),
     ]
 
     @staticmethod
@@ -99,6 +101,19 @@ class BDPTOptions(ctypes.Structure):
         o.mode = BDPT_MODE_FAST  # CPUBidirectionalImpl::mode, bidirectional.cxx:332
         o.direct_hit = o.connect_to_camera = o.connect_to_light = o.connect_vertices = o.mis = o.blue_noise = 1
         return o
+
+
+class ReduceInfo(ctypes.Structure):
+    """etx_hip_reduce_info_t"""
+    _fields_ = [
+        ("reduces", ctypes.c_uint64),
+        ("payload_bytes", ctypes.c_uint64),
+        ("global_iterations", ctypes.c_uint64),
+        ("last_device_ms", ctypes.c_double),
+        ("total_device_ms", ctypes.c_double),
+        ("pending", ctypes.c_uint32),
+        ("layer_mask", ctypes.c_uint32),
+    ]
 
 
 class Stats(ctypes.Structure):
@@ -197,6 +212,9 @@ class Library:
         L.etx_hip_comm_unique_id.argtypes = [vp]
         L.etx_hip_comm_init.argtypes = [vp, i32, i32, vp]
         L.etx_hip_reduce_film.argtypes = [vp]
+        L.etx_hip_reduce_film_begin.argtypes = [vp]
+        L.etx_hip_reduce_film_end.argtypes = [vp, i32]
+        L.etx_hip_reduce_info.argtypes = [vp, vp, ctypes.c_size_t]
         L.etx_hip_trace_rays.argtypes = [vp, vp, u64, vp]
         L.etx_hip_trace_rays_device.argtypes = [vp, vp, vp, u64, vp, u32, ctypes.POINTER(ctypes.c_double)]
         L.etx_hip_kat.argtypes = [vp, i32, vp, u64, vp]
@@ -400,7 +418,24 @@ class Context:
         self._check(self.library.lib.etx_hip_comm_init(self.handle, rank, world, buf))
 
     def reduce_film(self):
+        """etx_hip_sync + one film reduce, blocking; rendering may continue afterwards."""
         self._check(self.library.lib.etx_hip_reduce_film(self.handle))
+
+    def reduce_film_begin(self):
+        """Enqueues a film reduce (snapshot + out-of-place all-reduce) on the communication stream and returns; the lanes keep rendering."""
+        self._check(self.library.lib.etx_hip_reduce_film_begin(self.handle))
+
+    def reduce_film_end(self, wait=True):
+        """True once the reduced copy is complete (False while it is still running, wait=False only)."""
+        rc = self.library.lib.etx_hip_reduce_film_end(self.handle, 1 if wait else 0)
+        if rc < 0:
+            self._check(rc)
+        return rc == 1
+
+    def reduce_info(self):
+        info = ReduceInfo()
+        self._check(self.library.lib.etx_hip_reduce_info(self.handle, ctypes.byref(info), ctypes.sizeof(info)))
+        return info
 
 
 def host_check_bvh(snapshot, library=None, builder=BVH_HOST_SAH):

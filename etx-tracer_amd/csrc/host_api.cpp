@@ -3,6 +3,7 @@
 #include "../../include/etx_hip.h"
 
 #include "host_scene.h"
+#include "host_reduce.h"
 #include "kernels_bvh_build.h"
 #include "kernels.h"
 #include "dev_bvh.h"
@@ -13,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -55,6 +57,11 @@ struct TimedSpan {
 constexpr uint32_t kFilmLayers = 4;     // camera, light, normal, albedo sums (pipeline.h)
 constexpr uint32_t kBlueNoiseSets = 9;  // sample-count classes 1, 2, 4, ... 256 of the host's blue-noise sampler
 
+struct etx_hip_context;
+int etx_hip_internal_reduce_reset(etx_hip_context* c);
+int etx_hip_internal_reduce_allocate(etx_hip_context* c);
+void etx_hip_internal_reduce_release(etx_hip_context* c);
+
 struct etx_hip_context {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -95,8 +102,10 @@ struct etx_hip_context {
   uint32_t pool_paths = 0;                     // paths per sub pass pool_wanted was first sized for
   uint32_t next_iteration = 0;       // iteration index to render next
   uint32_t local_iterations = 0;     // iterations rendered by this context since begin
-  uint64_t global_iterations = 0;    // after etx_hip_reduce_film: iterations of all ranks
-  bool reduced = false;
+  uint64_t global_iterations = 0;    // after a film reduce: iterations of all ranks at the time of that reduce
+  EtxReduceState reduce;             // public context: the multi-GPU film reduce (host_reduce.h, host_comm.cpp)
+  hipEvent_t commit_done = nullptr;  // recorded behind this lane's newest commit kernel, under the public context's reduce.mutex
+  bool commit_recorded = false;
   uint32_t tail_divisor = 32;        // active paths <= capacity / tail_divisor: finish the pass in the tail kernel (0 = never); configs[1]: 64 -> 94.2, 32 -> 96.3, 16 -> 95.2 Msamples/s
   uint32_t check_interval = 3;       // rounds the host may enqueue beyond the newest round the device has reported (run_bounce_loop)
   uint32_t timer_mask = (1u << kTimerTraceClosest) | (1u << kTimerTraceShadow);
@@ -120,6 +129,7 @@ struct etx_hip_context {
   };
   PassPlan plans[2];                         // light pass, camera pass (path tracing: [1] only)
   bool scheduled_passes = true;              // ETX_HIP_SCHEDULED_PASSES=0 (debug builds): always poll
+  uint32_t iterations_on_plan = 0;           // iterations since this lane last polled its passes (execute_iteration drops the plans every kPlanLifetime)
   uint8_t* bluenoise[kBlueNoiseSets] = {};  // device tables by sample-count class (etx_hip_upload_bluenoise)
   const uint8_t* active_bluenoise = nullptr;
   float4* cie_table = nullptr;      // spectrum::spectral_xyz (etx_hip_upload_cie_table), spectral scenes only
@@ -138,7 +148,6 @@ struct etx_hip_context {
   size_t read_pixels = 0;
   bool read_pending = false;
   void* comm = nullptr;  // ncclComm_t (host_comm.cpp)
-  void* comm_scratch = nullptr;  // device words of the film reduce, allocated with the communicator
   int rank = 0, world = 1;
 
   // Asynchronous execution. A context is a set of LANES: the public context itself plus helper contexts, each with its
@@ -213,7 +222,14 @@ void release_pools(etx_hip_context* ctx) {
   ctx->allocated_bytes -= std::min(ctx->allocated_bytes, ctx->pool_bytes);
   ctx->pool_bytes = 0;
   ctx->pool_sizes = {};
-  ctx->pipe.grid.cell_ends = nullptr, ctx->pipe.grid.pos_len = nullptr, ctx->pipe.grid.rec = nullptr, ctx->pipe.grid.block_sums = nullptr;
+  // nothing may keep pointing at freed memory: every pool pointer and capacity of the pipeline is cleared with the pools
+  Pipeline& p = ctx->pipe;
+  p.grid.cell_ends = nullptr, p.grid.pos_len = nullptr, p.grid.rec = nullptr, p.grid.block_sums = nullptr;
+  p.lv.rec = nullptr, p.lv.capacity = 0u;
+  p.cv = {}, p.merge_order = nullptr, p.cv_capacity = 0u;
+  p.pairs = nullptr, p.pair_capacity = 0u;
+  p.shadow = {};
+  p.endpoints = {};
 }
 
 void release_pipeline(etx_hip_context* ctx) {
@@ -440,6 +456,29 @@ hipEvent_t take_event(etx_hip_context* ctx) {
   return ctx->event_pool[ctx->events_used++];
 }
 
+// A lane's commit kernel (iteration image -> film sums) and the snapshot of a film reduce exclude each other on the DEVICE (host_reduce.h):
+// the commit is enqueued behind the newest snapshot, and its own end is recorded for the next snapshot to wait for - both under the public
+// context's reduce.mutex, so every snapshot holds whole iterations. No host thread waits; a lane's stream stalls only if its commit falls
+// into the ~30 us a snapshot kernel runs.
+struct CommitSection {
+  etx_hip_context* lane;
+  EtxReduceState& reduce;
+  explicit CommitSection(etx_hip_context* l)
+    : lane(l)
+    , reduce((l->owner ? l->owner : l)->reduce) {
+    reduce.mutex.lock();
+    if (reduce.snapshot_recorded)
+      (void)hipStreamWaitEvent(lane->stream, reduce.snapshot_done, 0);
+  }
+  ~CommitSection() {
+    if (lane->commit_done != nullptr) {
+      (void)hipEventRecord(lane->commit_done, lane->stream);
+      lane->commit_recorded = true;
+    }
+    reduce.mutex.unlock();
+  }
+};
+
 struct ScopedTimer {
   etx_hip_context* ctx;
   bool active;
@@ -480,7 +519,7 @@ VcmParams make_iteration_params(const etx_hip_context* ctx, uint32_t iteration) 
   const auto& o = ctx->vcm_options;
   const auto& sc = ctx->scene.host_copy;
   VcmParams it = {};
-  it.options = o.options;
+  it.options = (o.options & ETX_VCM_FULL_OPTIONS) | (o.reference_seeding ? kOptionReferenceSeeding : 0u);
   it.kernel = o.kernel;
   it.iteration = iteration;
   it.film_w = ctx->scene.film_w, it.film_h = ctx->scene.film_h;
@@ -543,6 +582,12 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
     }
     tail(set, bound);
     rounds++;
+    // a scheduled pass never reads the device's answers: one query per pass keeps a device fault from surfacing only at the iteration's end event
+    const hipError_t q = hipStreamQuery(ctx->stream);
+    if ((q != hipSuccess) && (q != hipErrorNotReady)) {
+      ctx->error = std::string("wavefront loop (scheduled pass): ") + hipGetErrorString(q);
+      return ETX_HIP_ERROR_HIP;
+    }
     return 0;
   }
   // Alive paths are bounded by depth plus roulette, but boundary crossings do not add depth: the loop runs until the
@@ -719,7 +764,10 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
     rounds, kStatRaysCamera);
   if (rc)
     return rc;
-  launch_vcm_commit(s, p.camera_sum, p.light_sum, ctx->pipe.camera_sum, ctx->pipe.light_sum, p.capacity, p.counters);
+  {
+    CommitSection commit(ctx);
+    launch_vcm_commit(s, p.camera_sum, p.light_sum, ctx->pipe.camera_sum, ctx->pipe.light_sum, p.capacity, p.counters);
+  }
   launch_stats_finalize(s, p);
   ctx->stats.wavefront_bounces = rounds;
   return 0;
@@ -762,7 +810,10 @@ int render_pt_iteration(etx_hip_context* ctx, uint32_t iteration) {
     [&](uint32_t, uint32_t) {}, rounds, kStatRaysCamera, false);
   if (rc)
     return rc;
-  launch_pt_commit(s, ctx->pt_iteration_image, ctx->pipe.camera_sum, ctx->pipe.adaptive_sum, ctx->pipe.capacity, ctx->scene.host_copy.radiance_clamp);  // the whole frame: a pixel shard's pixels are spread over it
+  {
+    CommitSection commit(ctx);
+    launch_pt_commit(s, ctx->pt_iteration_image, ctx->pipe.camera_sum, ctx->pipe.adaptive_sum, ctx->pipe.capacity, ctx->scene.host_copy.radiance_clamp);  // the whole frame: a pixel shard's pixels are spread over it
+  }
   // Film::estimate_noise_levels(status.current_iteration, ...), path_tracing.cxx:99: after even iterations from kMinSamples = 32 on
   if ((ctx->pipe.pixel_state != nullptr) && (iteration >= 32u) && ((iteration & 1u) == 0u))
     launch_noise_estimate(s, ctx->pipe, it.film_w, it.film_h, ctx->noise_threshold);
@@ -777,7 +828,7 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
   const auto& o = ctx->bdpt_options;
   VcmParams it = {};
   it.options = (o.connect_to_camera ? ETX_VCM_CONNECT_TO_CAMERA : 0u) | (o.direct_hit ? ETX_VCM_DIRECT_HIT : 0u) | (o.connect_to_light ? ETX_VCM_CONNECT_TO_LIGHT : 0u) |
-               (o.connect_vertices ? ETX_VCM_CONNECT_VERTICES : 0u) | (o.mis ? ETX_VCM_ENABLE_MIS : 0u);
+               (o.connect_vertices ? ETX_VCM_CONNECT_VERTICES : 0u) | (o.mis ? ETX_VCM_ENABLE_MIS : 0u) | (o.reference_seeding ? kOptionReferenceSeeding : 0u);
   if (ctx->retry_attempt)
     it.options |= kOptionRetryKeepsAovs;  // the discarded first attempt has added this iteration's normal / albedo values
   it.kernel = o.mode;  // CPUBidirectionalImpl::Mode
@@ -857,7 +908,10 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
     if (rc)
       return rc;
   }
-  launch_vcm_commit(s, p.camera_sum, p.light_sum, ctx->pipe.camera_sum, ctx->pipe.light_sum, p.capacity, p.counters);
+  {
+    CommitSection commit(ctx);
+    launch_vcm_commit(s, p.camera_sum, p.light_sum, ctx->pipe.camera_sum, ctx->pipe.light_sum, p.capacity, p.counters);
+  }
   launch_stats_finalize(s, p);
   ctx->stats.wavefront_bounces = rounds;
   return 0;
@@ -941,7 +995,7 @@ bool grow_pools(etx_hip_context* lane, uint32_t flags) {
   w.shadow = std::max(w.shadow, uint32_t(std::min<uint64_t>(uint64_t(w.pairs) + 2ull * w.camera_vertices, 0xfffffff0ull)));
   if (w == pub->pool_wanted)
     return false;
-  if ((pub->pool_limit_bytes != 0u) && (pool_bytes_for(w, lane->grid_wanted) > pub->pool_limit_bytes))
+  if ((pub->pool_limit_bytes != 0u) && (pool_bytes_for(w, pub->grid_wanted || lane->grid_wanted) > pub->pool_limit_bytes))
     return false;
   pub->pool_wanted = w;
   pub->totals.pool_grows += 1u;
@@ -960,8 +1014,21 @@ int execute_iteration(etx_hip_context* lane, uint32_t iteration) {
     }
     if ((wanted == lane->pool_sizes) == false) {
       HIP_OK(lane, hipStreamSynchronize(lane->stream));
-      if (int rc = allocate_pools(lane, wanted))
-        return rc;
+      const etx_hip_context::PoolSizes previous = lane->pool_sizes;
+      if (allocate_pools(lane, wanted) != 0) {
+        // out of device memory while growing: the lane goes back to the pools it had (never left without any), every lane is told to stay
+        // there, and the iteration that needed the larger pools fails as an overflow that cannot grow
+        const std::string why = lane->error;
+        {
+          std::lock_guard<std::mutex> lock(pub->shared_mutex);
+          if (previous.light_vertices != 0u)
+            pub->pool_wanted = previous;
+        }
+        if ((previous.light_vertices == 0u) || (allocate_pools(lane, previous) != 0))
+          return ETX_HIP_ERROR_HIP;  // not even the previous sizes: lane->error says which allocation
+        lane->error = "device pools cannot grow for iteration " + std::to_string(iteration) + ": " + why;
+        return ETX_HIP_ERROR_OVERFLOW;
+      }
     }
     lane->retry_attempt = attempt != 0u;
     HIP_OK(lane, hipEventRecord(lane->iteration_begin, lane->stream));
@@ -995,6 +1062,15 @@ int execute_iteration(etx_hip_context* lane, uint32_t iteration) {
       if (plan.entering.size() != plan.rounds_enqueued)
         plan.entering.clear();
       plan.rounds_enqueued = 0u;
+    }
+    // A scheduled pass enqueues only the rounds its plan holds and the next plan is read back from exactly those: a plan can shrink (noise
+    // pushes the last round under the tail threshold) but never grow again, and the tail kernel would absorb that round for good (ADVICE
+    // round 4). Every kPlanLifetime-th iteration of a lane therefore polls and rebuilds its plans from what the device reports.
+    constexpr uint32_t kPlanLifetime = 32u;
+    if (++lane->iterations_on_plan >= kPlanLifetime) {
+      lane->iterations_on_plan = 0u;
+      for (etx_hip_context::PassPlan& plan : lane->plans)
+        plan.entering.clear();
     }
     const uint32_t flags = lane->stats.overflow_flags;
     if (flags == 0u)
@@ -1076,7 +1152,8 @@ int init_lane(etx_hip_context* lane, int device, std::string& error) {
     error = "hipStreamCreate failed";
     return ETX_HIP_ERROR_HIP;
   }
-  if ((hipEventCreate(&lane->iteration_begin) != hipSuccess) || (hipEventCreate(&lane->iteration_end) != hipSuccess)) {
+  if ((hipEventCreate(&lane->iteration_begin) != hipSuccess) || (hipEventCreate(&lane->iteration_end) != hipSuccess) ||
+      (hipEventCreateWithFlags(&lane->commit_done, hipEventDisableTiming) != hipSuccess)) {
     error = "hipEventCreate failed";
     return ETX_HIP_ERROR_HIP;
   }
@@ -1118,6 +1195,8 @@ void destroy_lane(etx_hip_context* lane) {
     (void)hipEventDestroy(lane->iteration_begin);
   if (lane->iteration_end)
     (void)hipEventDestroy(lane->iteration_end);
+  if (lane->commit_done)
+    (void)hipEventDestroy(lane->commit_done);
   if (lane->host_counters)
     (void)hipHostFree(lane->host_counters);
   if (lane->round_mirror)
@@ -1537,9 +1616,30 @@ int etx_hip_begin_ex(etx_hip_context* context, int integrator, const void* optio
     // at half the vertex, pair and queue records; the lanes adopt the size before their next iteration (execute_iteration)
     const uint32_t paths = shard_paths(context->scene.film_w * context->scene.film_h, pixel_first, pixel_stride);
     std::lock_guard<std::mutex> lock(context->shared_mutex);
-    if (paths != context->pool_paths) {
-      context->pool_wanted = initial_pool_sizes(context, std::max(paths, 1u));
+    if ((paths != context->pool_paths) && (context->pool_paths != 0u)) {
+      // another share of the pixels than the pools were sized for: what the pools have GROWN to is kept in proportion (a scene that needed
+      // twice the start size needs it on any share), never below the start size of the new share (starting over made the
+      // first iterations after every switch overflow and render twice)
+      const etx_hip_context::PoolSizes start = initial_pool_sizes(context, std::max(paths, 1u));
+      const double ratio = double(std::max(paths, 1u)) / double(context->pool_paths);
+      auto scaled = [ratio](uint32_t grown, uint32_t at_least, uint64_t limit) {
+        return uint32_t(std::min<uint64_t>(std::max<uint64_t>(uint64_t(std::ceil(double(grown) * ratio)), at_least), limit));
+      };
+      etx_hip_context::PoolSizes w = context->pool_wanted;
+      w.light_vertices = scaled(w.light_vertices, start.light_vertices, kPoolRecordLimit);
+      w.camera_vertices = scaled(w.camera_vertices, start.camera_vertices, kPoolRecordLimit);
+      w.pairs = scaled(w.pairs, start.pairs, kPoolRecordLimit);
+      w.shadow = scaled(w.shadow, start.shadow, 0xfffffff0ull);
+      w.endpoints = scaled(w.endpoints, start.endpoints, kPoolRecordLimit);
+      context->pool_wanted = w;
       context->pool_paths = paths;
+    }
+    // etx_hip_set_pool_policy's byte limit bounds the sizes a run STARTS with as well (a large per-path start, the photon grid a VCM run adds)
+    const bool with_grid = context->grid_wanted || (integrator == ETX_HIP_INTEGRATOR_VCM);
+    if ((context->pool_limit_bytes != 0u) && (pool_bytes_for(context->pool_wanted, with_grid) > context->pool_limit_bytes)) {
+      context->error = "etx_hip_begin: the pools this run starts with (" + std::to_string(pool_bytes_for(context->pool_wanted, with_grid)) +
+                       " bytes per lane) exceed etx_hip_set_pool_policy's limit of " + std::to_string(context->pool_limit_bytes) + " bytes";
+      return ETX_HIP_ERROR_OVERFLOW;
     }
   }
   // the lanes this integrator uses beyond the base ones get their pools now - after every check above, so a refused begin leaves the
@@ -1561,7 +1661,8 @@ int etx_hip_begin_ex(etx_hip_context* context, int integrator, const void* optio
   context->next_iteration = first_iteration;
   context->local_iterations = 0;
   context->global_iterations = 0;
-  context->reduced = false;
+  if (int rc = etx_hip_internal_reduce_reset(context))  // a reduce of the previous run still in flight is waited for; its result belongs to that run
+    return rc;
   context->stats = {};
   {
     std::lock_guard<std::mutex> lock(context->shared_mutex);
@@ -1629,10 +1730,6 @@ int submit_iteration(etx_hip_context* context, bool wait) {
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   if (context->armed == false) {
     context->error = "etx_hip_render_iteration: call etx_hip_begin first";
-    return ETX_HIP_ERROR_STATE;
-  }
-  if (context->reduced) {
-    context->error = "etx_hip_render_iteration after etx_hip_reduce_film: call etx_hip_begin again";
     return ETX_HIP_ERROR_STATE;
   }
   // Adaptive sampling (path tracing with Scene::noise_threshold > 0): the convergence mask an iteration reads is the one the estimate
@@ -1721,11 +1818,29 @@ int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size
     context->error = "etx_hip_read_film: unknown layer";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
+  HIP_OK(context, hipSetDevice(context->device));
+  if (context->comm != nullptr) {
+    // a context with a communicator: the whole-job film of the newest reduce, once there is one (a reduce that is still in flight is waited for).
+    // Normalised pixel by pixel by the reduced sample count (camera layer's w): ranks need not have finished the same number of iterations.
+    if (context->reduce.pending) {
+      const int rc = etx_hip_reduce_film_end(context, 1);
+      if (rc < 0)
+        return rc;
+    }
+    if (context->reduce.valid) {
+      const EtxReduceState& r = context->reduce;
+      const float4* source = (layer == ETX_HIP_LAYER_NORMAL) ? r.reduced + 2u * n : ((layer == ETX_HIP_LAYER_ALBEDO) ? r.reduced + 3u * n : r.reduced);
+      const int mode = (layer == ETX_HIP_LAYER_NORMAL) ? 3 : ((layer == ETX_HIP_LAYER_ALBEDO) ? 0 : layer);
+      launch_film_resolve(r.stream, source, r.reduced + n, context->resolve_buffer, uint32_t(n), 0.0f, mode, r.reduced);
+      HIP_OK(context, hipMemcpyAsync(dst_rgba, context->resolve_buffer, dst_bytes, hipMemcpyDeviceToHost, r.stream));
+      HIP_OK(context, hipStreamSynchronize(r.stream));
+      return ETX_HIP_OK;
+    }
+  }
   int sync_rc = wait_idle(context);
   if (sync_rc)
     return sync_rc;
-  HIP_OK(context, hipSetDevice(context->device));
-  uint64_t iterations = context->reduced ? context->global_iterations : context->local_iterations;
+  uint64_t iterations = context->local_iterations;
   float scale = iterations ? float(1.0 / double(iterations)) : 0.0f;
   // adaptive sampling: pixels hold different sample counts (Film::accumulate_camera_image keeps a running mean per pixel)
   const float4* counts = (context->pipe.pixel_state != nullptr) ? context->pipe.camera_sum : nullptr;
@@ -1775,15 +1890,24 @@ int etx_hip_read_film_begin(etx_hip_context* context, int layer) {
     HIP_OK(context, hipHostMalloc(reinterpret_cast<void**>(&context->read_staging), n * sizeof(float4), hipHostMallocDefault));
     context->read_pixels = n;
   }
-  uint64_t iterations = 0;
-  {
-    std::lock_guard<std::mutex> lock(context->shared_mutex);
-    iterations = context->reduced ? context->global_iterations : uint64_t(context->local_iterations);
-  }
-  const float scale = iterations ? float(1.0 / double(iterations)) : 0.0f;
-  const float4* source = (layer == ETX_HIP_LAYER_NORMAL) ? context->pipe.normal_sum : ((layer == ETX_HIP_LAYER_ALBEDO) ? context->pipe.albedo_sum : context->pipe.camera_sum);
   const int mode = (layer == ETX_HIP_LAYER_NORMAL) ? 3 : ((layer == ETX_HIP_LAYER_ALBEDO) ? 0 : layer);
-  launch_film_resolve(context->read_stream, source, context->pipe.light_sum, context->read_resolve, uint32_t(n), scale, mode, context->reduced ? nullptr : context->pipe.camera_sum);
+  if ((context->comm != nullptr) && context->reduce.valid) {
+    // the reduced copy (whole job): behind the newest reduce on the communication stream - also one that is still in flight, whose result this
+    // read-back then returns; the next reduce waits for this read (etx_hip_internal_reduce_prepare)
+    const EtxReduceState& r = context->reduce;
+    HIP_OK(context, hipStreamWaitEvent(context->read_stream, r.done, 0));
+    const float4* reduced_source = (layer == ETX_HIP_LAYER_NORMAL) ? r.reduced + 2u * n : ((layer == ETX_HIP_LAYER_ALBEDO) ? r.reduced + 3u * n : r.reduced);
+    launch_film_resolve(context->read_stream, reduced_source, r.reduced + n, context->read_resolve, uint32_t(n), 0.0f, mode, r.reduced);
+  } else {
+    uint64_t iterations = 0;
+    {
+      std::lock_guard<std::mutex> lock(context->shared_mutex);
+      iterations = uint64_t(context->local_iterations);
+    }
+    const float scale = iterations ? float(1.0 / double(iterations)) : 0.0f;
+    const float4* source = (layer == ETX_HIP_LAYER_NORMAL) ? context->pipe.normal_sum : ((layer == ETX_HIP_LAYER_ALBEDO) ? context->pipe.albedo_sum : context->pipe.camera_sum);
+    launch_film_resolve(context->read_stream, source, context->pipe.light_sum, context->read_resolve, uint32_t(n), scale, mode, context->pipe.camera_sum);
+  }
   HIP_OK(context, hipMemcpyAsync(context->read_staging, context->read_resolve, n * sizeof(float4), hipMemcpyDeviceToHost, context->read_stream));
   HIP_OK(context, hipEventRecord(context->read_event, context->read_stream));
   context->read_pending = true;
@@ -1841,11 +1965,15 @@ uint32_t options_hash(const etx_hip_context* c) {
   } else if (c->integrator == ETX_HIP_INTEGRATOR_BDPT) {
     const auto& o = c->bdpt_options;
     mix(o.mode), mix(o.direct_hit != 0), mix(o.connect_to_camera != 0), mix(o.connect_to_light != 0), mix(o.connect_vertices != 0), mix(o.mis != 0), mix(o.blue_noise != 0);
+    if (o.reference_seeding)
+      mix(0x73656564u);  // only when set: checkpoints written before the field existed keep their hash
   } else {
     const auto& o = c->vcm_options;
     uint32_t radius_bits = 0;
     memcpy(&radius_bits, &o.initial_radius, sizeof(radius_bits));
     mix(o.options), mix(o.radius_decay), mix(o.kernel), mix(radius_bits), mix(o.blue_noise != 0);
+    if (o.reference_seeding)
+      mix(0x73656564u);
   }
   return h;
 }
@@ -1884,8 +2012,8 @@ size_t etx_hip_checkpoint_bytes(const etx_hip_context* context) {
 int etx_hip_checkpoint_save(etx_hip_context* context, void* dst, size_t dst_bytes) {
   if ((context == nullptr) || (dst == nullptr))
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
-  if ((context->armed == false) || context->reduced) {
-    context->error = "etx_hip_checkpoint_save: between etx_hip_begin and etx_hip_reduce_film only (a checkpoint holds this rank's own sums)";
+  if (context->armed == false) {
+    context->error = "etx_hip_checkpoint_save: call etx_hip_begin first (a checkpoint holds this rank's own sums; film reduces do not touch them)";
     return ETX_HIP_ERROR_STATE;
   }
   if (dst_bytes != checkpoint_bytes(context)) {
@@ -1925,7 +2053,7 @@ int etx_hip_checkpoint_save(etx_hip_context* context, void* dst, size_t dst_byte
 int etx_hip_checkpoint_load(etx_hip_context* context, const void* src, size_t src_bytes) {
   if ((context == nullptr) || (src == nullptr))
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
-  if ((context->armed == false) || context->reduced) {
+  if (context->armed == false) {
     context->error = "etx_hip_checkpoint_load: call etx_hip_begin (same integrator, options and iteration sharding as the saved run) first";
     return ETX_HIP_ERROR_STATE;
   }
@@ -1962,6 +2090,7 @@ int etx_hip_checkpoint_load(etx_hip_context* context, const void* src, size_t sr
   HIP_OK(context, hipStreamSynchronize(context->stream));
   context->next_iteration = header.next_iteration;
   context->local_iterations = header.local_iterations;
+  context->reduce.valid = false;  // a reduced copy of the film before the load no longer describes this context's run
   {
     std::lock_guard<std::mutex> lock(context->shared_mutex);
     context->totals = {};
@@ -2003,8 +2132,10 @@ int etx_hip_set_timers(etx_hip_context* context, uint32_t mask) {
 }
 
 int etx_hip_stats(etx_hip_context* context, etx_hip_stats_t* out_stats, size_t stats_size) {
-  // a client built against an earlier header asks for the prefix it knows (fields are only ever appended, ETX_HIP_ABI_VERSION counts them)
-  if ((context == nullptr) || (out_stats == nullptr) || (stats_size == 0u) || (stats_size > sizeof(etx_hip_stats_t)))
+  // a client built against an earlier header asks for the prefix it knows - exactly one of the layouts that ever shipped (fields are only
+  // appended): ABI 1 ended before pool_grows, ABI 2 and later hold the whole struct. Any other size is a binding that has drifted.
+  const bool known_layout = (stats_size == offsetof(etx_hip_stats_t, pool_grows)) || (stats_size == sizeof(etx_hip_stats_t));
+  if ((context == nullptr) || (out_stats == nullptr) || (known_layout == false))
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> lock(context->shared_mutex);
   memcpy(out_stats, &context->totals, stats_size);
@@ -2376,20 +2507,16 @@ int etx_hip_host_bvh_stats_builder(const etx_abi_scene* scene, int builder, cons
 
 }  // extern "C"
 
-// accessors for host_comm.cpp (kept out of the public header)
+// ---------------------------------------------------------------------------------------------------------------
+// The context's half of the multi-GPU film reduce (host_reduce.h; the RCCL half is host_comm.cpp). Kept out of the public header.
 hipStream_t etx_hip_internal_stream(etx_hip_context* c) {
   return c->stream;
-}
-void** etx_hip_internal_comm_scratch(etx_hip_context* c) {
-  return &c->comm_scratch;
 }
 void** etx_hip_internal_comm(etx_hip_context* c) {
   return &c->comm;
 }
-void etx_hip_internal_film(etx_hip_context* c, float** camera, float** light, size_t* floats) {
-  *camera = reinterpret_cast<float*>(c->pipe.camera_sum);
-  *light = reinterpret_cast<float*>(c->pipe.light_sum);
-  *floats = size_t(c->pipe.capacity) * 4u * kFilmLayers;  // camera, light, normal, albedo are one allocation
+EtxReduceState* etx_hip_internal_reduce(etx_hip_context* c) {
+  return &c->reduce;
 }
 void etx_hip_internal_set_error(etx_hip_context* c, const std::string& e) {
   c->error = e;
@@ -2398,16 +2525,159 @@ void etx_hip_internal_rank(etx_hip_context* c, int** rank, int** world) {
   *rank = &c->rank;
   *world = &c->world;
 }
-void etx_hip_internal_iterations(etx_hip_context* c, uint32_t** local, uint64_t** global, bool** reduced) {
-  *local = &c->local_iterations;
-  *global = &c->global_iterations;
-  *reduced = &c->reduced;
-}
-// What this rank adds to the global iteration count of the film reduce. Ranks that share their iterations and split the PIXELS hold the same
-// iterations: the rank of the first pixel shard counts them, the others add zero (so R pixel shards x S iteration shards sum to the run's iterations).
-uint32_t etx_hip_internal_counted_iterations(etx_hip_context* c) {
-  return (c->pixel_first == 0u) ? c->local_iterations : 0u;
+uint64_t* etx_hip_internal_global_iterations(etx_hip_context* c) {
+  return &c->global_iterations;
 }
 int etx_hip_internal_device(etx_hip_context* c) {
   return c->device;
+}
+
+namespace {
+void free_reduce_buffers(EtxReduceState& r) {
+  if (r.snapshot)
+    (void)hipFree(r.snapshot);
+  if (r.reduced)
+    (void)hipFree(r.reduced);
+  r.snapshot = r.reduced = nullptr;
+  r.pixels = 0;
+}
+}  // namespace
+
+// Stream, events, counters and - once the film size is known - the two film-sized buffers of the reduce. Called by etx_hip_comm_init (so that a
+// rank finds out there, not inside a collective, that it cannot join), by etx_hip_begin on a context that has a communicator, and by the
+// reduce itself as a last resort.
+int etx_hip_internal_reduce_allocate(etx_hip_context* c) {
+  EtxReduceState& r = c->reduce;
+  HIP_OK(c, hipSetDevice(c->device));
+  if (r.stream == nullptr) {
+    HIP_OK(c, hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+    HIP_OK(c, hipEventCreateWithFlags(&r.snapshot_done, hipEventDisableTiming));
+    HIP_OK(c, hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+    HIP_OK(c, hipEventCreate(&r.time_begin));
+    HIP_OK(c, hipEventCreate(&r.time_end));
+    HIP_OK(c, hipMalloc(reinterpret_cast<void**>(&r.d_counters), 4 * sizeof(unsigned long long)));
+    HIP_OK(c, hipHostMalloc(reinterpret_cast<void**>(&r.h_counters), 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    memset(r.h_counters, 0, 4 * sizeof(unsigned long long));
+  }
+  const size_t n = c->scene_ready ? size_t(c->pipe.capacity) : 0u;
+  if ((n != 0u) && (r.pixels != n)) {
+    HIP_OK(c, hipStreamSynchronize(r.stream));
+    free_reduce_buffers(r);
+    r.valid = false;
+    HIP_OK(c, hipMalloc(reinterpret_cast<void**>(&r.snapshot), n * kFilmLayers * sizeof(float4)));
+    HIP_OK(c, hipMalloc(reinterpret_cast<void**>(&r.reduced), n * kFilmLayers * sizeof(float4)));
+    r.pixels = n;
+    HIP_OK(c, hipMemsetAsync(r.snapshot, 0, n * kFilmLayers * sizeof(float4), r.stream));
+    HIP_OK(c, hipMemsetAsync(r.reduced, 0, n * kFilmLayers * sizeof(float4), r.stream));
+    HIP_OK(c, hipStreamSynchronize(r.stream));
+  }
+  return ETX_HIP_OK;
+}
+
+void etx_hip_internal_reduce_release(etx_hip_context* c) {
+  EtxReduceState& r = c->reduce;
+  if (r.stream)
+    (void)hipStreamSynchronize(r.stream);
+  free_reduce_buffers(r);
+  if (r.d_counters)
+    (void)hipFree(r.d_counters);
+  if (r.h_counters)
+    (void)hipHostFree(r.h_counters);
+  for (hipEvent_t* e : {&r.snapshot_done, &r.done, &r.time_begin, &r.time_end}) {
+    if (*e)
+      (void)hipEventDestroy(*e);
+    *e = nullptr;
+  }
+  if (r.stream)
+    (void)hipStreamDestroy(r.stream);
+  r.stream = nullptr, r.d_counters = nullptr, r.h_counters = nullptr;
+  r.pending = r.valid = r.snapshot_recorded = false;
+}
+
+// etx_hip_begin: the reduced copy belongs to the run that produced it. A reduce still in flight is waited for (every rank begins the same
+// runs, so the collective completes); layers the new run's integrator does not write must read as zero.
+int etx_hip_internal_reduce_reset(etx_hip_context* c) {
+  EtxReduceState& r = c->reduce;
+  if (r.stream == nullptr)
+    return ETX_HIP_OK;
+  HIP_OK(c, hipSetDevice(c->device));
+  HIP_OK(c, hipStreamSynchronize(r.stream));
+  r.pending = false, r.valid = false;
+  r.pending_local_rc = 0, r.pending_local_error.clear();
+  {
+    std::lock_guard<std::mutex> lock(r.mutex);
+    r.snapshot_recorded = false;  // nothing of the new run has to wait for a snapshot of the old one (the stream is idle)
+    c->commit_recorded = false;
+    for (etx_hip_context* helper : c->helpers)
+      helper->commit_recorded = false;
+  }
+  if (c->comm != nullptr) {
+    if (int rc = etx_hip_internal_reduce_allocate(c))
+      return rc;
+  }
+  if (r.pixels != 0u) {
+    HIP_OK(c, hipMemsetAsync(r.snapshot, 0, r.pixels * kFilmLayers * sizeof(float4), r.stream));
+    HIP_OK(c, hipMemsetAsync(r.reduced, 0, r.pixels * kFilmLayers * sizeof(float4), r.stream));
+    HIP_OK(c, hipStreamSynchronize(r.stream));
+  }
+  return ETX_HIP_OK;
+}
+
+// First half of a reduce, everything before the collectives: the snapshot of the film behind every lane's newest commit, and this rank's
+// counter words {iterations it counts, 1 if it failed}. Never waits for the lanes.
+// Which layers: what the armed integrator writes (VCM: camera + light; path tracer: camera + normal + albedo; bidirectional: all four). The
+// normal / albedo sums of the path tracer and the bidirectional integrator are added by the shade kernels of iterations in flight, not by
+// their commits: a snapshot taken while lanes render may hold a part of those iterations' AOV values (progressive display only; after
+// etx_hip_sync - which etx_hip_reduce_film does - every layer holds whole iterations).
+int etx_hip_internal_reduce_prepare(etx_hip_context* c, int local_rc, float4** out_snapshot, float4** out_reduced, size_t* out_pixels, uint32_t* out_layer_mask) {
+  EtxReduceState& r = c->reduce;
+  if (c->scene_ready == false) {
+    c->error = "film reduce: no scene uploaded";
+    return ETX_HIP_ERROR_STATE;
+  }
+  if (int rc = etx_hip_internal_reduce_allocate(c))
+    return rc;
+  const size_t n = r.pixels;
+  const uint32_t layer_mask = (c->integrator == ETX_HIP_INTEGRATOR_VCM) ? 0x3u : ((c->integrator == ETX_HIP_INTEGRATOR_PT) ? 0xdu : 0xfu);
+  // the bidirectional integrator's commit counts every pixel of the frame on every pixel shard (k_vcm_commit): the count of shard 0 is the job's
+  const bool drop_counts = (c->integrator == ETX_HIP_INTEGRATOR_BDPT) && (c->pixel_first != 0u);
+  uint32_t counted = 0;
+  {
+    std::lock_guard<std::mutex> lock(c->shared_mutex);
+    // ranks that share their iterations and split the PIXELS hold the same iterations: the rank of the first pixel shard counts them
+    counted = (c->pixel_first == 0u) ? c->local_iterations : 0u;
+    if ((local_rc == 0) && (c->sticky_error != 0))
+      local_rc = c->sticky_error;  // an iteration in flight has failed since the last call
+  }
+  r.h_counters[0] = counted;
+  r.h_counters[1] = local_rc ? 1ull : 0ull;
+  {
+    std::lock_guard<std::mutex> lock(r.mutex);
+    if (c->commit_recorded)
+      HIP_OK(c, hipStreamWaitEvent(r.stream, c->commit_done, 0));
+    for (etx_hip_context* helper : c->helpers) {
+      if (helper->commit_recorded)
+        HIP_OK(c, hipStreamWaitEvent(r.stream, helper->commit_done, 0));
+    }
+    if (c->read_pending && (c->read_event != nullptr))
+      HIP_OK(c, hipStreamWaitEvent(r.stream, c->read_event, 0));  // an asynchronous read-back of the reduced copy still in flight
+    HIP_OK(c, hipEventRecord(r.time_begin, r.stream));
+    launch_film_snapshot(r.stream, c->pipe.camera_sum, r.snapshot, uint32_t(n), layer_mask, drop_counts);
+    HIP_OK(c, hipEventRecord(r.snapshot_done, r.stream));
+    r.snapshot_recorded = true;
+  }
+  HIP_OK(c, hipMemcpyAsync(r.d_counters, r.h_counters, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, r.stream));
+  r.layer_mask = layer_mask;
+  r.payload_bytes = uint64_t(__builtin_popcount(layer_mask)) * n * sizeof(float4);
+  *out_snapshot = r.snapshot, *out_reduced = r.reduced, *out_pixels = n, *out_layer_mask = layer_mask;
+  return ETX_HIP_OK;
+}
+
+// Second half, behind the collectives: the received counter words travel to pinned memory, the reduce's end is recorded.
+int etx_hip_internal_reduce_finish(etx_hip_context* c) {
+  EtxReduceState& r = c->reduce;
+  HIP_OK(c, hipMemcpyAsync(r.h_counters + 2, r.d_counters + 2, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, r.stream));
+  HIP_OK(c, hipEventRecord(r.time_end, r.stream));
+  HIP_OK(c, hipEventRecord(r.done, r.stream));
+  return ETX_HIP_OK;
 }

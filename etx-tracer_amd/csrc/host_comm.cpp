@@ -1,8 +1,13 @@
 // host_comm.cpp - multi-GPU film reduction over RCCL (xGMI).
-// The reference has no communication layer at all; iterations are sharded over ranks
-// (etx_hip_begin first/stride) and the ONLY exchange is one sum-reduce of the two float4 film accumulators plus the
-// iteration counter. Payload at 1080p: 2 x 33 MB fp32 - one ring all-reduce, per-link bound.
+// The reference has no communication layer at all; iterations (or pixels, etx_hip_begin_ex) are sharded over ranks and the
+// ONLY exchange is a sum-reduce of the float4 film layers the armed integrator writes plus two counter words. north_star asks for
+// it "at the end of each iteration": the reduce here is asynchronous, out of place and NOT terminal - it runs on a communication stream of its
+// own from a snapshot of the film while the lanes keep rendering, and rendering continues afterwards (host_reduce.h has the whole scheme; the
+// reference's film is consumed progressively too: Film::commit_light_iteration per iteration, film.cxx:332-343; GUI pump app.cxx:150-155).
+// Payload at 1080p: VCM 2 x 33 MB fp32 per reduce - one ring all-reduce over xGMI, per-link bound (DESIGN.md 6 has the model).
 #include "../../include/etx_hip.h"
+
+#include "host_reduce.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -12,29 +17,80 @@
 
 static_assert(sizeof(ncclUniqueId) == ETX_HIP_UNIQUE_ID_BYTES, "ncclUniqueId size");
 
-hipStream_t etx_hip_internal_stream(etx_hip_context* c);
 void** etx_hip_internal_comm(etx_hip_context* c);
-void etx_hip_internal_film(etx_hip_context* c, float** camera, float** light, size_t* floats);
+EtxReduceState* etx_hip_internal_reduce(etx_hip_context* c);
 void etx_hip_internal_set_error(etx_hip_context* c, const std::string& e);
 void etx_hip_internal_rank(etx_hip_context* c, int** rank, int** world);
-void etx_hip_internal_iterations(etx_hip_context* c, uint32_t** local, uint64_t** global, bool** reduced);
-uint32_t etx_hip_internal_counted_iterations(etx_hip_context* c);
+uint64_t* etx_hip_internal_global_iterations(etx_hip_context* c);
 int etx_hip_internal_device(etx_hip_context* c);
-void** etx_hip_internal_comm_scratch(etx_hip_context* c);  // device words {iterations of this rank, 1 if this rank failed}, allocated with the communicator
+int etx_hip_internal_reduce_allocate(etx_hip_context* c);
+void etx_hip_internal_reduce_release(etx_hip_context* c);
+int etx_hip_internal_reduce_prepare(etx_hip_context* c, int local_rc, float4** out_snapshot, float4** out_reduced, size_t* out_pixels, uint32_t* out_layer_mask);
+int etx_hip_internal_reduce_finish(etx_hip_context* c);
+
+namespace {
+
+// One reduce, enqueued: snapshot, the collectives, the counter read-back. `local_rc`: this rank's own failure so far (travels INTO the collective
+// as its failed flag; reported by reduce_end after the collective, so no rank ever stays out of an all-reduce the others are already in).
+int reduce_begin(etx_hip_context* context, int local_rc, const std::string& local_error) {
+  ncclComm_t comm = reinterpret_cast<ncclComm_t>(*etx_hip_internal_comm(context));
+  EtxReduceState* r = etx_hip_internal_reduce(context);
+  if (comm == nullptr)
+    return local_rc;  // single rank: the film IS the job's film, nothing to exchange
+  if (r->pending) {  // one reduce in flight: the previous one is finished first (its buffers are this one's)
+    const int rc = etx_hip_reduce_film_end(context, 1);
+    if (rc < 0)
+      return rc;
+  }
+  float4 *snapshot = nullptr, *reduced = nullptr;
+  size_t pixels = 0;
+  uint32_t layer_mask = 0;
+  if (int rc = etx_hip_internal_reduce_prepare(context, local_rc, &snapshot, &reduced, &pixels, &layer_mask))
+    return rc;  // before any collective call: nothing has been enqueued that another rank could wait for... except the collective itself (see etx_hip.h)
+  // contiguous runs of layers become one all-reduce each (VCM: [camera, light]; path tracer: [camera], [normal, albedo]; bidirectional: all four)
+  ncclResult_t res = ncclGroupStart();
+  for (uint32_t layer = 0; (res == ncclSuccess) && (layer < 4u);) {
+    if (((layer_mask >> layer) & 1u) == 0u) {
+      ++layer;
+      continue;
+    }
+    uint32_t end = layer;
+    while ((end < 4u) && ((layer_mask >> end) & 1u))
+      ++end;
+    res = ncclAllReduce(snapshot + size_t(layer) * pixels, reduced + size_t(layer) * pixels, size_t(end - layer) * pixels * 4u, ncclFloat, ncclSum, comm, r->stream);
+    layer = end;
+  }
+  if (res == ncclSuccess)
+    res = ncclAllReduce(r->d_counters, r->d_counters + 2, 2, ncclUint64, ncclSum, comm, r->stream);
+  const ncclResult_t res_end = ncclGroupEnd();
+  if (res == ncclSuccess)
+    res = res_end;
+  if (res != ncclSuccess) {
+    etx_hip_internal_set_error(context, std::string("ncclAllReduce: ") + ncclGetErrorString(res));
+    return ETX_HIP_ERROR_COMM;
+  }
+  if (int rc = etx_hip_internal_reduce_finish(context))
+    return rc;
+  r->pending = true;
+  r->pending_local_rc = local_rc;
+  r->pending_local_error = local_error;
+  return ETX_HIP_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
 void etx_hip_comm_destroy_internal(etx_hip_context* context) {
+  EtxReduceState* r = etx_hip_internal_reduce(context);
+  if (r->stream)
+    (void)hipStreamSynchronize(r->stream);  // a reduce still in flight
   void** comm = etx_hip_internal_comm(context);
   if (*comm) {
     (void)ncclCommDestroy(reinterpret_cast<ncclComm_t>(*comm));
     *comm = nullptr;
   }
-  void** scratch = etx_hip_internal_comm_scratch(context);
-  if (*scratch) {
-    (void)hipFree(*scratch);
-    *scratch = nullptr;
-  }
+  etx_hip_internal_reduce_release(context);
 }
 
 int etx_hip_comm_unique_id(void* out_id_128_bytes) {
@@ -63,15 +119,16 @@ int etx_hip_comm_init(etx_hip_context* context, int rank, int world_size, const 
     etx_hip_internal_set_error(context, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
     return ETX_HIP_ERROR_COMM;
   }
-  // everything the reduce needs is allocated here: a rank must not find out inside etx_hip_reduce_film that it cannot join
-  void* scratch = nullptr;
-  if (hipMalloc(&scratch, 2 * sizeof(unsigned long long)) != hipSuccess) {
+  // everything the reduce needs is allocated here (the film-sized buffers as soon as a scene is uploaded: here, or at the next etx_hip_begin):
+  // a rank must not find out inside a reduce that it cannot join
+  if (int rc = etx_hip_internal_reduce_allocate(context)) {
     (void)ncclCommDestroy(comm);
-    etx_hip_internal_set_error(context, "hipMalloc failed (film reduce counters)");
-    return ETX_HIP_ERROR_HIP;
+    etx_hip_internal_reduce_release(context);
+    return rc;
   }
   *etx_hip_internal_comm(context) = comm;
-  *etx_hip_internal_comm_scratch(context) = scratch;
+  EtxReduceState* state = etx_hip_internal_reduce(context);
+  state->reduces = 0, state->last_device_ms = state->total_device_ms = 0.0;
   int *prank = nullptr, *pworld = nullptr;
   etx_hip_internal_rank(context, &prank, &pworld);
   *prank = rank;
@@ -79,69 +136,87 @@ int etx_hip_comm_init(etx_hip_context* context, int rank, int world_size, const 
   return ETX_HIP_OK;
 }
 
+int etx_hip_reduce_film_begin(etx_hip_context* context) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  return reduce_begin(context, 0, std::string());
+}
+
+int etx_hip_reduce_film_end(etx_hip_context* context, int wait) {
+  if (context == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  EtxReduceState* r = etx_hip_internal_reduce(context);
+  if (r->pending == false)
+    return 1;  // nothing in flight (also: no communicator)
+  if (hipSetDevice(etx_hip_internal_device(context)) != hipSuccess) {
+    etx_hip_internal_set_error(context, "hipSetDevice failed");
+    return ETX_HIP_ERROR_HIP;
+  }
+  if (wait) {
+    if (hipEventSynchronize(r->done) != hipSuccess) {
+      etx_hip_internal_set_error(context, "event synchronize failed after the film all-reduce");
+      return ETX_HIP_ERROR_HIP;
+    }
+  } else {
+    const hipError_t q = hipEventQuery(r->done);
+    if (q == hipErrorNotReady)
+      return 0;
+    if (q != hipSuccess) {
+      etx_hip_internal_set_error(context, std::string("film all-reduce: ") + hipGetErrorString(q));
+      return ETX_HIP_ERROR_HIP;
+    }
+  }
+  r->pending = false;
+  r->valid = true;
+  float ms = 0.0f;
+  if (hipEventElapsedTime(&ms, r->time_begin, r->time_end) == hipSuccess) {
+    r->last_device_ms = double(ms);
+    r->total_device_ms += double(ms);
+  }
+  r->reduces += 1;
+  *etx_hip_internal_global_iterations(context) = r->h_counters[2];
+  if (r->pending_local_rc) {
+    etx_hip_internal_set_error(context, r->pending_local_error);
+    return r->pending_local_rc;
+  }
+  if (r->h_counters[3] != 0ull) {
+    etx_hip_internal_set_error(context, std::to_string(r->h_counters[3]) + " rank(s) reported a failed iteration before the film reduce (their films are incomplete)");
+    return ETX_HIP_ERROR_COMM;
+  }
+  return 1;
+}
+
 int etx_hip_reduce_film(etx_hip_context* context) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
-  // Every iteration handed to a lane has reached the film. A failed iteration on THIS rank (for example
-  // ETX_HIP_ERROR_OVERFLOW, a data-dependent condition of the fixed pools) must not keep the rank out of the collective:
-  // the other ranks are already inside ncclAllReduce and would wait for the RCCL timeout. Every rank therefore always
-  // takes part and the error travels with the iteration counter; afterwards ALL ranks return an error.
+  // Every iteration handed to a lane has reached the film. A failed iteration on THIS rank (for example ETX_HIP_ERROR_OVERFLOW beyond the
+  // pool limit) must not keep the rank out of the collective: the other ranks are already inside ncclAllReduce and would wait for the RCCL
+  // timeout. Every rank therefore always takes part and the error travels with the counters; afterwards ALL ranks return an error.
   const int sync_rc = etx_hip_sync(context);
-  uint32_t* local = nullptr;
-  uint64_t* global = nullptr;
-  bool* reduced = nullptr;
-  etx_hip_internal_iterations(context, &local, &global, &reduced);
+  const std::string local_error = sync_rc ? std::string(etx_hip_last_error(context)) : std::string();
   ncclComm_t comm = reinterpret_cast<ncclComm_t>(*etx_hip_internal_comm(context));
-  if (comm == nullptr) {
-    // single rank: the reduce is the identity
-    if (sync_rc)
-      return sync_rc;
-    *global = *local;
-    *reduced = true;
-    return ETX_HIP_OK;
-  }
-  std::string local_error = sync_rc ? std::string(etx_hip_last_error(context)) : std::string();
-  // No early return between here and the collective: a local failure (even of hipSetDevice) is carried INTO the all-reduce as this
-  // rank's failed flag; whether the collective itself can run is for RCCL to say.
-  int local_rc = sync_rc;
-  if (hipSetDevice(etx_hip_internal_device(context)) != hipSuccess) {
-    if (local_rc == 0)
-      local_rc = ETX_HIP_ERROR_HIP, local_error = "hipSetDevice failed before the film reduce";
-  }
-  hipStream_t stream = etx_hip_internal_stream(context);
-  float *camera = nullptr, *light = nullptr;
-  size_t floats = 0;
-  etx_hip_internal_film(context, &camera, &light, &floats);
-  unsigned long long* d_counters = reinterpret_cast<unsigned long long*>(*etx_hip_internal_comm_scratch(context));  // allocated by etx_hip_comm_init
-  unsigned long long h_counters[2] = {etx_hip_internal_counted_iterations(context), local_rc ? 1ull : 0ull};
-  (void)hipMemcpyAsync(d_counters, h_counters, sizeof(h_counters), hipMemcpyHostToDevice, stream);
-  ncclResult_t r = ncclGroupStart();
-  if (r == ncclSuccess)
-    r = ncclAllReduce(camera, camera, floats, ncclFloat, ncclSum, comm, stream);  // all film layers, one buffer
-  if (r == ncclSuccess)
-    r = ncclAllReduce(d_counters, d_counters, 2, ncclUint64, ncclSum, comm, stream);
-  ncclResult_t r2 = ncclGroupEnd();
-  if (r == ncclSuccess)
-    r = r2;
-  if (r != ncclSuccess) {
-    etx_hip_internal_set_error(context, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
-    return ETX_HIP_ERROR_COMM;
-  }
-  (void)hipMemcpyAsync(h_counters, d_counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream);
-  if (hipStreamSynchronize(stream) != hipSuccess) {
-    etx_hip_internal_set_error(context, "stream synchronize failed after all-reduce");
-    return ETX_HIP_ERROR_HIP;
-  }
-  *global = h_counters[0];
-  *reduced = true;
-  if (local_rc) {
-    etx_hip_internal_set_error(context, local_error);
-    return local_rc;
-  }
-  if (h_counters[1] != 0ull) {
-    etx_hip_internal_set_error(context, std::to_string(h_counters[1]) + " other rank(s) reported a failed iteration before the film reduce (their films are incomplete)");
-    return ETX_HIP_ERROR_COMM;
-  }
+  if (comm == nullptr)
+    return sync_rc;  // single rank: the reduce is the identity
+  const int begun = reduce_begin(context, sync_rc, local_error);
+  if (begun != ETX_HIP_OK)
+    return begun;
+  const int ended = etx_hip_reduce_film_end(context, 1);
+  return (ended < 0) ? ended : ETX_HIP_OK;
+}
+
+int etx_hip_reduce_info(etx_hip_context* context, etx_hip_reduce_info_t* out_info, size_t info_size) {
+  if ((context == nullptr) || (out_info == nullptr) || (info_size != sizeof(etx_hip_reduce_info_t)))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  const EtxReduceState* r = etx_hip_internal_reduce(context);
+  etx_hip_reduce_info_t info = {};
+  info.reduces = r->reduces;
+  info.payload_bytes = r->payload_bytes;
+  info.global_iterations = *etx_hip_internal_global_iterations(context);
+  info.last_device_ms = r->last_device_ms;
+  info.total_device_ms = r->total_device_ms;
+  info.pending = r->pending ? 1u : 0u;
+  info.layer_mask = r->layer_mask;
+  *out_info = info;
   return ETX_HIP_OK;
 }
 

@@ -622,7 +622,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_generate(Pipeline p,
     // the reference seeds the camera sampler like the light sampler of the same pixel (:377-378); the device gives the
     // camera path a stream of its own (as for VCM, kernels_vcm.hip k_camera_generate and DESIGN.md 4)
     st.sampler.init(i, it.iteration);
-    if ((p.debug_flags & 0x8000u) == 0u)  // bit 15: shared streams, see k_camera_generate
+    if ((it.options & kOptionReferenceSeeding) == 0u)  // reference_seeding: shared streams, see k_camera_generate
       st.sampler.seed = Sampler::random_seed(st.sampler.seed, 0x43414d45u);
     st.wavelength = 0.0f;
     if (scene.spectral) {

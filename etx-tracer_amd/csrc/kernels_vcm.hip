@@ -156,10 +156,11 @@ __global__ __launch_bounds__(kBlockSize) void k_camera_generate(Pipeline p, VcmP
     // the device traversal draws none for opaque triangles, so with the same seed camera draw k+1 would equal
     // light draw k forever and the (pixel i, light path i) vertex connections become correlated -> biased
     // (measured: -7% in the connection-only image). The camera stream is therefore re-keyed.
-    // Debug flag bit 15 (etx_hip_set_debug_flags) keeps the shared seed: the state the reference is in when its candidate draws are
-    // taken off the path's stream (oracle shim, ETX_ORACLE_BVH_DRAWS=opaque_none) - tests/test_gpu_parity_hi.py compares the two.
+    // etx_abi_vcm_options::reference_seeding ("hip-reference_seeding") keeps the shared seed: the state the reference is in when its
+    // candidate draws are taken off the path's stream (oracle shim, ETX_ORACLE_BVH_DRAWS=opaque_none) - tests/test_gpu_parity_hi.py and
+    // tests/test_gpu_options.py compare the two.
     st.sampler.init(i, it.iteration);
-    if ((p.debug_flags & 0x8000u) == 0u)
+    if ((it.options & kOptionReferenceSeeding) == 0u)
       st.sampler.seed = Sampler::random_seed(st.sampler.seed, 0x43414d45u);
     // vcm_shared.hxx:358-359: one draw is consumed, the wavelength is the one of light path i (vcm_cpu.cxx:186)
     st.wavelength = 0.0f;
@@ -285,6 +286,30 @@ __global__ __launch_bounds__(kBlockSize) void k_vcm_commit(float4* __restrict__ 
 
 void launch_vcm_commit(hipStream_t stream, float4* iteration_camera, float4* iteration_light, float4* camera_sum, float4* light_sum, uint32_t pixels, const uint32_t* counters) {
   hipLaunchKernelGGL(k_vcm_commit, dim3(grid_for(pixels)), dim3(kBlockSize), 0, stream, iteration_camera, iteration_light, camera_sum, light_sum, pixels, counters);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Snapshot of the film sums for the multi-GPU reduce (host_reduce.h): the layers of `layer_mask` (bit = layer index in the film allocation) are
+// copied, the others are left as they are in `snapshot` (zero since allocation). HBM-bound: 32 B per pixel and layer, 16-byte lanes.
+// `drop_counts`: the w of the camera layer (iterations committed per pixel) is written as 0 - for the ranks of pixel shards other than the
+// first under the bidirectional integrator, whose commit counts every pixel of the frame on every pixel shard (the reduced count must be
+// the job's iterations, not shards x iterations; the path tracer counts only the pixels it sampled).
+__global__ __launch_bounds__(kBlockSize) void k_film_snapshot(const float4* __restrict__ film, float4* __restrict__ snapshot, uint32_t pixels, uint32_t layer_mask, uint32_t drop_counts) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += gridDim.x * blockDim.x) {
+#pragma unroll
+    for (uint32_t layer = 0; layer < 4u; ++layer) {
+      if ((layer_mask >> layer) & 1u) {
+        float4 v = film[size_t(layer) * pixels + i];
+        if ((layer == 0u) && drop_counts)
+          v.w = 0.0f;
+        snapshot[size_t(layer) * pixels + i] = v;
+      }
+    }
+  }
+}
+
+void launch_film_snapshot(hipStream_t stream, const float4* film, float4* snapshot, uint32_t pixels, uint32_t layer_mask, bool drop_counts) {
+  hipLaunchKernelGGL(k_film_snapshot, dim3(grid_for(pixels)), dim3(kBlockSize), 0, stream, film, snapshot, pixels, layer_mask, drop_counts ? 1u : 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -199,6 +199,9 @@ ETX_HD uint32_t path_pixel(const VcmParams& it, uint32_t k) { return it.pixel_fi
 // VcmParams::options bit 31 (bidirectional integrator): this is the second attempt at an iteration whose pools overflowed - the first attempt
 // was not committed (k_vcm_commit) but has already added the iteration's normal / albedo values, which go straight to the film
 constexpr uint32_t kOptionRetryKeepsAovs = 1u << 31;
+// VcmParams::options bit of etx_abi_vcm_options / _bdpt_options::reference_seeding: camera path i starts from the sampler state of light path i
+// (vcm_shared.hxx:312,357; bidirectional.cxx:377-378) instead of a stream of its own (k_camera_generate, k_bdpt_camera_generate)
+constexpr uint32_t kOptionReferenceSeeding = 1u << 30;
 
 // PT: VcmParams::options carries PTOptions (path_tracing_shared.hxx:8-14)
 enum : uint32_t { ETX_PT_DIRECT = 1u << 0, ETX_PT_NEE = 1u << 1, ETX_PT_MIS = 1u << 2 };

@@ -77,6 +77,8 @@ def vcm_options_from_dict(values):
     flag("vcm-merge_vertices", api.VCM_MERGE_VERTICES)
     flag("vcm-mis", api.VCM_ENABLE_MIS)
     flag("vcm-merging", api.VCM_ENABLE_MERGING)
+    # the backend's own key (integration/etx_hip_integrators.hxx): camera path i keeps the sampler state of light path i (vcm_shared.hxx:312,357)
+    o.reference_seeding = 1 if values.get("hip-reference_seeding", False) else 0
     return o
 
 
@@ -97,6 +99,7 @@ def bdpt_options_from_dict(values):
     for key, field in (("bdpt-conn_direct_hit", "direct_hit"), ("bdpt-conn_connect_to_camera", "connect_to_camera"), ("bdpt-conn_connect_to_light", "connect_to_light"),
                        ("bdpt-conn_connect_vertices", "connect_vertices"), ("bdpt-conn_mis", "mis"), ("bdpt-blue_noise", "blue_noise")):
         setattr(o, field, 1 if values.get(key, bool(getattr(o, field))) else 0)
+    o.reference_seeding = 1 if values.get("hip-reference_seeding", False) else 0  # bidirectional.cxx:377-378
     return o
 
 

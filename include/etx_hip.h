@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ETX_HIP_ABI_VERSION 2
+#define ETX_HIP_ABI_VERSION 3 /* 3: reference_seeding in the option structs, the asynchronous film reduce (etx_hip_reduce_film_begin / _end / _info) */
 
 typedef struct etx_hip_context etx_hip_context; /* opaque */
 
@@ -109,7 +109,7 @@ int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, c
  *                            surface-area guided collapse to four-wide breadth-first nodes, boxes bottom-up): a few milliseconds
  *                            for 10^6 triangles - time to first iteration, geometry that changes every frame - at 3-15 % of the
  *                            traversal rate. Scenes of <= 64 triangles are swept linearly and always built on the host.
- *   ... | ETX_HIP_BVH_WIDE   (with ETX_HIP_BVH_HOST_SAH only; opt-in, round 3: compiled and emulated on the host, not yet run on a device) the host
+ *   ... | ETX_HIP_BVH_WIDE   (with ETX_HIP_BVH_HOST_SAH only; opt-in: measured no faster than the four-wide tree) the host
  *                            ALSO collapses its tree to eight children per node with 8-bit child boxes (csrc/dev_bvh8.h: 128 B per
  *                            node, a third fewer dependent node fetches per ray) and the kernels that have a variant for it - closest
  *                            hit, shadow segments of scenes without Boundary materials and density grids, the bidirectional
@@ -189,8 +189,9 @@ int etx_hip_poll(etx_hip_context* context);
 int etx_hip_sync(etx_hip_context* context);
 
 /* Copies a film layer as float4 RGBA (alpha = 1), row order and y-flip as etx::Film stores it
- * (film.cxx:165,189: row (H-1-y)). Normalised by the number of iterations rendered so far on ALL ranks if
- * etx_hip_reduce_film was called, else by this context's own iterations. Synchronises the stream. */
+ * (film.cxx:165,189: row (H-1-y)). A context without a communicator: waits for the iterations in flight, the image is this context's own
+ * film normalised by its iterations. A context WITH a communicator that has finished a reduce in this run: the reduced copy (whole job, see
+ * etx_hip_reduce_film_*; does not wait for iterations in flight, does wait for a reduce in flight). */
 int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size_t dst_bytes);
 
 /* Asynchronous read-back: _begin enqueues the resolve and the device-to-host copy of `layer` on a stream of
@@ -204,7 +205,7 @@ int etx_hip_read_film_end(etx_hip_context* context, float* dst_rgba, size_t dst_
 /* Checkpoint / resume (the reference has none: a stopped render starts over, app.cxx:193-216). A checkpoint is the
  * film state of this context - the sums of its completed iterations with their per-pixel sample counts, the adaptive-sampling state,
  * and the index of the next iteration - as one host buffer of etx_hip_checkpoint_bytes() bytes (0 before etx_hip_begin), written
- * by _save (waits for the iterations in flight) between etx_hip_begin and etx_hip_reduce_film. _load, called after an etx_hip_begin
+ * by _save (waits for the iterations in flight) any time after etx_hip_begin (film reduces are out of place: the sums stay this rank's own). _load, called after an etx_hip_begin
  * with the same integrator, options, film size and iteration sharding (checked, ETX_HIP_ERROR_INVALID_ARGUMENT otherwise), replaces
  * the film with the saved one and continues at the saved iteration: iterations are seeded by (pixel, iteration), so the
  * resumed render is the render that was interrupted. The buffer is the caller's to store (file, object store). */
@@ -264,8 +265,8 @@ int etx_hip_stats(etx_hip_context* context, etx_hip_stats_t* out_stats, size_t s
 
 /* Ablation switches of the kernels for timing experiments and kernel-level tests (0 = production, the default): bit 0 no film
  * atomics in the shadow kernel, bit 2 no transmittance traversal, bit 6 (64) the packed two-ray flat sweep in etx_hip_trace_rays*,
- * bits 8 / 9 no next event estimation / no camera vertex storage, bit 15 the camera path keeps the seed of the light path of its pixel
- * (the reference's seeding, vcm_shared.hxx:312,357; parity experiment of DESIGN.md 4). Waits for the iterations in flight. The library reads no
+ * bits 8 / 9 no next event estimation / no camera vertex storage. (The reference's seeding of the camera path, bit 15 until ABI 2, is a product
+ * option now: etx_abi_vcm_options / etx_abi_bdpt_options::reference_seeding.) Waits for the iterations in flight. The library reads no
  * environment variable for these; builds with -DETX_HIP_DEBUG additionally read tuning knobs (csrc/tuning_knobs.h). */
 int etx_hip_set_debug_flags(etx_hip_context* context, uint32_t flags);
 
@@ -289,15 +290,53 @@ uint32_t etx_hip_lanes(const etx_hip_context* context, int integrator);
 size_t etx_hip_device_bytes(const etx_hip_context* context);
 
 /* ------------------------------------------------------------------------------------------------------------ */
-/* multi GPU: iterations are sharded over ranks (etx_hip_begin first/stride); the only exchange is one RCCL
- * sum-reduce of the two float4 film accumulators. The 128-byte ncclUniqueId is created by rank 0
- * with etx_hip_comm_unique_id and distributed by the host (bench.py: torch.distributed). */
+/* multi GPU: iterations (etx_hip_begin first / stride) or pixels (etx_hip_begin_ex) are sharded over ranks; the only exchange is an RCCL
+ * sum-reduce of the float4 film layers the armed integrator writes - VCM: camera + light, 32 B per pixel (66 MB at 1080p); path tracer: camera +
+ * normal + albedo; bidirectional: all four - plus two counter words. The 128-byte ncclUniqueId is created by rank 0 with
+ * etx_hip_comm_unique_id and distributed by the host (bench.py: torch.distributed). */
 #define ETX_HIP_UNIQUE_ID_BYTES 128
 int etx_hip_comm_unique_id(void* out_id_128_bytes);
+/* Joins the communicator and allocates what a reduce needs (communication stream, events, counters; the two film-sized buffers as soon as a scene
+ * is uploaded - here or at the next etx_hip_begin), so that a rank finds out HERE, not inside a collective, that it cannot take part. */
 int etx_hip_comm_init(etx_hip_context* context, int rank, int world_size, const void* id_128_bytes);
-/* All ranks call it after their last etx_hip_render_iteration: ncclAllReduce(sum) of camera/light sums and of the
- * iteration counter; afterwards etx_hip_read_film on any rank returns the whole-job image. */
+
+/* The film reduce. The reference's film is consumed while the render runs (Film::commit_light_iteration once per iteration, film.cxx:332-343; the
+ * GUI reads it every frame, app.cxx:150-155) and north_star places the reduce "at the end of each iteration": a reduce therefore neither ends the
+ * render nor waits for it. Every rank calls the same sequence of reduces (they are collectives); any cadence - after every iteration, every k-th,
+ * once at the end - gives the same final film.
+ *
+ *   etx_hip_reduce_film_begin  enqueues, on a communication stream of the context's own: (1) a SNAPSHOT of the film sums behind every commit the
+ *       lanes have enqueued so far - commits and snapshots exclude each other on the device, so a snapshot holds whole iterations; the lanes keep
+ *       rendering and no host thread waits; (2) ncclAllReduce(sum) OUT OF PLACE from the snapshot into the context's reduced copy, and of the
+ *       counter words {iterations, failed flag}. Returns at once. One reduce is in flight per context: a _begin while the previous one is still
+ *       running finishes that one first (blocking). Without a communicator (single GPU): nothing to do, returns ETX_HIP_OK.
+ *   etx_hip_reduce_film_end    wait = 0: 0 while the reduce is running, 1 once the reduced copy is complete (also when none was in flight);
+ *       wait = 1: blocks until it is. < 0: error - this rank's own failed iteration, ETX_HIP_ERROR_COMM when another rank reported one (every
+ *       rank always joins the collective; the error travels with the counters so that nobody waits for the RCCL timeout), or a HIP / RCCL error.
+ *   etx_hip_reduce_film        = etx_hip_sync + _begin + _end(wait): every iteration handed over so far, on every rank, is in the reduced copy
+ *       when it returns. Rendering may continue afterwards (until ABI 2 the reduce was in place and final).
+ * After the first finished reduce of a run, etx_hip_read_film / _read_film_begin on a context WITH a communicator return the reduced copy - the
+ * whole job's film as of the newest finished reduce, normalised pixel by pixel by the reduced sample count (the camera layer's w), so ranks need
+ * not have completed the same number of iterations; a context without a communicator keeps returning its own film. The film sums of the rank
+ * itself are never modified: checkpoints, statistics and further iterations are unaffected. etx_hip_begin starts a new run (a reduce still in
+ * flight is waited for, the reduced copy is cleared). Normal / albedo values of the path tracer and the bidirectional integrator are added by the
+ * shade kernels of iterations in flight: a reduce taken while lanes render can hold part of those iterations' AOV values (a progressive display
+ * issue only; etx_hip_reduce_film syncs first). Should a rank fail to ALLOCATE inside _begin (the buffers normally exist since etx_hip_comm_init /
+ * etx_hip_begin), it returns the error without joining - the one case in which the other ranks are left to the RCCL timeout. */
+int etx_hip_reduce_film_begin(etx_hip_context* context);
+int etx_hip_reduce_film_end(etx_hip_context* context, int wait);
 int etx_hip_reduce_film(etx_hip_context* context);
+
+typedef struct etx_hip_reduce_info_t {
+  uint64_t reduces;            /* finished reduces since etx_hip_comm_init */
+  uint64_t payload_bytes;      /* film bytes one reduce sums per rank (layers of the armed integrator x pixels x 16) */
+  uint64_t global_iterations;  /* iterations of all ranks in the newest finished reduce (host-side count at the time of each rank's _begin) */
+  double last_device_ms;       /* device time of the newest finished reduce: snapshot kernel + collectives (HIP events on the communication stream) */
+  double total_device_ms;      /* ... summed over all finished reduces */
+  uint32_t pending;            /* 1: a reduce is in flight */
+  uint32_t layer_mask;         /* film layers of the newest reduce (bit 0 camera, 1 light, 2 normal, 3 albedo) */
+} etx_hip_reduce_info_t;
+int etx_hip_reduce_info(etx_hip_context* context, etx_hip_reduce_info_t* out_info, size_t info_size);
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* kernel-level entry points (used by tests/ and bench.py; the host integrator does not need them) */

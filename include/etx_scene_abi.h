@@ -187,6 +187,13 @@ typedef struct etx_abi_vcm_options {
   uint32_t options, radius_decay, kernel;
   float initial_radius;
   uint8_t blue_noise;
+  /* Not a member of etx::VCMOptions: it lives in that struct's tail padding (offset 17 of 32), so a VCMOptions copied over this
+   * struct leaves it where the binding sets it (integration/etx_hip_integrators.hxx, option key "hip-reference_seeding").
+   * 0 (default): the camera path of pixel i draws from a stream of its own. 1: it starts from the SAME sampler state as light path i,
+   * as the reference does (vcm_shared.hxx:312,357) - the device then reproduces the unmodified reference's estimator wherever the
+   * reference's own film is defined (its candidate draws pinned: DESIGN.md 4, tests/test_gpu_options.py); the vertex connections of a
+   * pixel are correlated with its light path in that mode, which is the reference's behaviour, not a defect of the option. */
+  uint8_t reference_seeding;
 } __attribute__((aligned(16))) etx_abi_vcm_options; /* 32 */
 
 /* etx::PTOptions  sources/etx/rt/shared/path_tracing_shared.hxx:8-14 */
@@ -201,6 +208,7 @@ enum { ETX_BDPT_MODE_PATH_TRACING = 0, ETX_BDPT_MODE_LIGHT_TRACING = 1, ETX_BDPT
 typedef struct etx_abi_bdpt_options {
   uint32_t mode;
   uint8_t direct_hit, connect_to_camera, connect_to_light, connect_vertices, mis, blue_noise;
+  uint8_t reference_seeding; /* as in etx_abi_vcm_options: camera path i keeps the seed of emitter path i (bidirectional.cxx:377-378) */
 } __attribute__((aligned(16))) etx_abi_bdpt_options; /* 16 */
 
 #ifdef __cplusplus

@@ -502,6 +502,16 @@ struct HIPIntegratorBase : public Integrator {
 
   etx_hip_context* ctx = nullptr;
   static constexpr uint32_t kEverythingChanged = 0xffffffffu;
+  // Options of the backend itself, next to the reference integrator's own keys (they show up in the GUI's option panel like any other).
+  // "hip-reference_seeding": the camera path of pixel i starts from the sampler state of light path i, as CPUVCM / CPUBidirectional do
+  // (vcm_shared.hxx:312,357; bidirectional.cxx:377-378). Off by default: the device's ray queries draw nothing for opaque triangles, so with
+  // shared seeds the two paths of a pixel stay aligned draw for draw and their vertex connections are correlated; on, the
+  // device renders the unmodified reference's estimator (asserted against the pinned reference, tests/test_gpu_options.py).
+  static constexpr const char* kReferenceSeedingKey = "hip-reference_seeding";
+  void add_backend_options() {
+    integrator_options.set_bool(kReferenceSeedingKey, false, "Reference seeding (light / camera paths share their stream)");
+  }
+
   uint32_t pending_changes = kEverythingChanged;
   bool scene_on_device = false;
   Status _status = {};
@@ -516,6 +526,7 @@ struct HIPVCM : public HIPIntegratorBase {
   HIPVCM(Raytracing& r)
     : HIPIntegratorBase(r) {
     VCMOptions::default_values().store(integrator_options);  // the option keys of CPUVCM (vcm_shared.cxx:30-47)
+    add_backend_options();
   }
 
   const char* name() override {
@@ -528,10 +539,16 @@ struct HIPVCM : public HIPIntegratorBase {
 
  protected:
   bool begin() override {
-    VCMOptions opt = VCMOptions::default_values();
-    opt.load(integrator_options);
-    if (opt.blue_noise && (upload_bluenoise() == false))
+    VCMOptions loaded = VCMOptions::default_values();
+    loaded.load(integrator_options);
+    if (loaded.blue_noise && (upload_bluenoise() == false))
       return false;
+    // etx_abi_vcm_options IS VCMOptions plus one byte in its tail padding (static_assert above, oracle/ref/abi_check.cxx): the members are
+    // copied one by one, so whatever the padding of `loaded` holds never reaches the backend
+    etx_abi_vcm_options opt = {};
+    opt.options = loaded.options, opt.radius_decay = loaded.radius_decay, opt.kernel = loaded.kernel;
+    opt.initial_radius = loaded.initial_radius, opt.blue_noise = loaded.blue_noise ? 1u : 0u;
+    opt.reference_seeding = integrator_options.get_bool(kReferenceSeedingKey, false) ? 1u : 0u;
     if (HIPBackendLibrary::get().begin(ctx, ETX_HIP_INTEGRATOR_VCM, &opt, sizeof(opt), /* first iteration */ 0, /* stride */ 1) != ETX_HIP_OK) {
       hip_report_error(HIPBackendLibrary::get().last_error(ctx));
       return false;
@@ -598,6 +615,7 @@ struct HIPBidirectional : public HIPIntegratorBase {
     integrator_options.set_bool("bdpt-conn_connect_vertices", true, "Camera Path to Light Path");
     integrator_options.set_bool("bdpt-conn_mis", true, "Multiple Importance Sampling");
     integrator_options.set_bool("bdpt-blue_noise", true, "Enable Blue Noise");
+    add_backend_options();
   }
 
   const char* name() override {
@@ -618,6 +636,7 @@ struct HIPBidirectional : public HIPIntegratorBase {
     opt.connect_vertices = integrator_options.get_bool("bdpt-conn_connect_vertices", true);
     opt.mis = integrator_options.get_bool("bdpt-conn_mis", true);
     opt.blue_noise = integrator_options.get_bool("bdpt-blue_noise", true);
+    opt.reference_seeding = integrator_options.get_bool(kReferenceSeedingKey, false) ? 1u : 0u;
     if (opt.blue_noise && (upload_bluenoise() == false))
       return false;
     if (HIPBackendLibrary::get().begin(ctx, ETX_HIP_INTEGRATOR_BDPT, &opt, sizeof(opt), 0, 1) != ETX_HIP_OK) {

@@ -532,6 +532,10 @@ int main(int argc, char** argv) {
 
   for (const auto& kv : opts) {
     auto& o = integrator->options();
+    // Options::make appends a SECOND entry when the class differs from the stored one and Options::get returns the first match
+    // (options.hxx:121-128,141-152): "vcm-kernel" is stored as a bool (vcm_shared.cxx:43) but read as an integral (:19), so without
+    // the removal --opt vcm-kernel=0 would be shadowed by the stored bool and the top-hat branch could not be reached
+    o.remove(kv.first);
     if ((kv.second == "true") || (kv.second == "false"))
       o.set_bool(kv.first, kv.second == "true", kv.first);
     else if (kv.second.find('.') != std::string::npos)

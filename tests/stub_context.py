@@ -1,7 +1,8 @@
 """TEST DOUBLE (not product code): stands in for etx_tracer_amd.api.Context where no GPU exists, so that bench.py's N > 1 control
 flow - process group, id broadcast, iteration sharding, warm-up / timed region, barrier, max over ranks, film reduce, the JSON line -
 runs line by line under gloo (tests/test_multi_gpu_gloo.py). An "iteration" is a deterministic image that depends on its index only;
-reduce_film all-reduces the sums and the iteration count like etx_hip_reduce_film does over RCCL."""
+a reduce all-reduces a COPY of the sums and of the iteration count like etx_hip_reduce_film* does over RCCL: out of place (the context's own
+sums stay its own), not terminal (rendering continues), any number of times per run - every rank the same number."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -40,7 +41,9 @@ class StubContext:
         self.iterations_rendered = []  # since the last begin
         self.camera_sum = self.light_sum = None
         self.count = torch.zeros((1,), dtype=torch.int64)
-        self.reduced = False
+        self.reduces = 0            # since comm_init
+        self.reduce_log = []        # per reduce of the current run: iterations this rank had rendered when its snapshot was taken
+        self.reduced_camera = self.reduced_light = self.reduced_count = None
         StubContext.instances.append(self)
 
     def make_unique_id(self):  # multi_gpu.init_context_comm: instead of etx_hip_comm_unique_id
@@ -81,7 +84,8 @@ class StubContext:
         self.camera_sum = torch.zeros((12, 16, 4))
         self.light_sum = torch.zeros((12, 16, 4))
         self.count.zero_()
-        self.reduced = False
+        self.reduce_log = []
+        self.reduced_camera = self.reduced_light = self.reduced_count = None
 
     def begin_vcm(self, options, first_iteration=0, iteration_stride=1):
         self.calls.append(("begin_vcm", first_iteration, iteration_stride))
@@ -92,7 +96,6 @@ class StubContext:
         self._begin(first_iteration, iteration_stride, pixel_first, pixel_stride)
 
     def render_iteration(self):
-        assert self.reduced is False
         camera, light = pixel_shard_images(*fake_iteration(self.next_iteration), self.next_iteration, self.pixel_first, self.pixel_stride)
         self.camera_sum += camera
         self.light_sum += light
@@ -112,20 +115,43 @@ class StubContext:
         s.wavefront_bounces = 20 * n
         return s
 
-    def reduce_film(self):
+    def _reduce(self):
+        camera, light = self.camera_sum.clone(), self.light_sum.clone()  # the snapshot: the context's own sums are never modified
+        counted = self.count.clone() if self.pixel_first == 0 else torch.zeros_like(self.count)  # pixel shards hold the SAME iterations: shard 0 counts them
         if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.camera_sum, op=dist.ReduceOp.SUM)
-            dist.all_reduce(self.light_sum, op=dist.ReduceOp.SUM)
-            counted = self.count if self.pixel_first == 0 else torch.zeros_like(self.count)  # pixel shards hold the SAME iterations: shard 0 counts them
+            dist.all_reduce(camera, op=dist.ReduceOp.SUM)
+            dist.all_reduce(light, op=dist.ReduceOp.SUM)
             dist.all_reduce(counted, op=dist.ReduceOp.SUM)
-            self.count = counted
-        self.reduced = True
+        self.reduced_camera, self.reduced_light, self.reduced_count = camera, light, counted
+        self.reduces += 1
+        self.reduce_log.append(len(self.iterations_rendered))
         # what the LAST reduce held (bench.py renders more afterwards: its per-kernel pass on rank 0)
         self.reduced_result = self.result()
         self.reduced_iterations = list(self.iterations_rendered)
 
+    def reduce_film(self):
+        self.calls.append(("reduce_film",))
+        self._reduce()
+
+    def reduce_film_begin(self):
+        self.calls.append(("reduce_film_begin",))
+        self._reduce()
+
+    def reduce_film_end(self, wait=True):
+        return True
+
+    def reduce_info(self):
+        info = api.ReduceInfo()
+        info.reduces = self.reduces
+        info.payload_bytes = int(self.camera_sum.numel() + self.light_sum.numel()) * 4 if self.camera_sum is not None else 0
+        info.global_iterations = int(self.reduced_count.item()) if self.reduced_count is not None else 0
+        info.last_device_ms, info.total_device_ms = 0.25, 0.25 * self.reduces
+        info.layer_mask = 3
+        return info
+
     def result(self):
-        out = torch.clamp((self.camera_sum + self.light_sum) / max(int(self.count.item()), 1), min=0.0)
+        """The whole-job image of the newest reduce (etx_hip_read_film on a context with a communicator)."""
+        out = torch.clamp((self.reduced_camera + self.reduced_light) / max(int(self.reduced_count.item()), 1), min=0.0)
         out[..., 3] = 1.0
         return out.numpy()
 

@@ -59,10 +59,10 @@ def test_bdpt_full_matches_reference_at_4096_spp(etx, golden_dir, flavour):
 @pytest.mark.parametrize("flavour", ["classic", "full"])
 def test_bdpt_shared_streams_match_the_pinned_reference(etx, golden_dir, flavour):
     """As test_gpu_parity_hi.test_vcm_shared_streams_match_the_pinned_reference, for CPUBidirectional (BDPTFull): the device takes the reference's
-    seeding - camera path i keeps the seed of light path i (bidirectional.cxx:377-380; debug flag bit 15, k_bdpt_camera_generate) - and is compared
+    seeding - camera path i keeps the seed of light path i (bidirectional.cxx:377-380; option hip-reference_seeding = etx_abi_bdpt_options::reference_seeding, k_bdpt_camera_generate) - and is compared
     with the UNMODIFIED integrator whose film ETX_ORACLE_BVH_DRAWS=opaque_none pins (the same film under every traversal order,
     tests/test_reference_order_spread.py). north_star's limits, no allowance."""
-    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, flavour, 4096, {"bdpt-mode": etx.api.BDPT_MODE_FULL, "bdpt-blue_noise": False}, debug_flags=0x8000)
+    (cam_a, light_a), (cam_b, light_b) = render_halves(etx, golden_dir, flavour, 4096, {"bdpt-mode": etx.api.BDPT_MODE_FULL, "bdpt-blue_noise": False, "hip-reference_seeding": True})
     golden = load(golden_dir, "cornell_%s_128_bdpt3_4096_opaque_none.npz" % flavour)
     assert int(golden["spp"]) in (4095, 4096)
     compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " bdpt camera+light (shared streams, pinned reference)")

@@ -44,6 +44,26 @@ def test_cpp_hipvcm_matches_ctypes_binding(etx, golden_dir, tmp_path, bluenoise_
     np.testing.assert_allclose(film["result"][..., :3], res[..., :3], rtol=2e-4, atol=4e-5)  # Film::layer(Result) of the reference
 
 
+def test_cpp_binding_reference_seeding_option(etx, golden_dir, tmp_path):
+    """`hip-reference_seeding` is an option key of the compiled binding (integration/etx_hip_integrators.hxx), next to the reference integrator's
+    own keys: the host asks for the reference's seeding of the camera path (vcm_shared.hxx:312,357) through the same Options store, and the
+    byte travels in etx_abi_vcm_options::reference_seeding. Same films as the ctypes path with the same option, another film than the default."""
+    snapshot = os.path.join(golden_dir, "cornell_full_128.etxscene")
+    seeded, _ = run_driver(tmp_path, snapshot, "hip-vcm", 16, "vcm-blue_noise=false", "hip-reference_seeding=true", name="seeded")
+    default, _ = run_driver(tmp_path, snapshot, "hip-vcm", 16, "vcm-blue_noise=false", name="default")
+    snap = etx.SceneSnapshot(snapshot)
+    snap.samples = 16
+    integ = etx.HIPVCM(snap)
+    integ.options().update({"vcm-blue_noise": False, "hip-reference_seeding": True})
+    integ.render()
+    cam, light = integ.film(etx.api.LAYER_CAMERA), integ.film(etx.api.LAYER_LIGHT)
+    integ.context.close()
+    np.testing.assert_allclose(seeded["camera"][..., :3], cam[..., :3], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(seeded["light"][..., :3], light[..., :3], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(seeded["light"][..., :3], default["light"][..., :3], rtol=2e-4, atol=2e-5)  # the light paths are seeded alike in both
+    assert np.abs(seeded["camera"][..., :3] - default["camera"][..., :3]).max() > 1.0e-2                  # the camera paths are not
+
+
 def test_cpp_hip_path_tracer_matches_ctypes_binding(etx, golden_dir, tmp_path):
     snapshot = os.path.join(golden_dir, "cornell_rough_128.etxscene")
     film, log = run_driver(tmp_path, snapshot, "hip-pt", 16, "bn=false")

@@ -1,0 +1,99 @@
+"""GPU (-m gpu): every NON-DEFAULT option branch of the three integrators against films of the reference rendered with that option
+(until round 4 these branches were compared with the device itself, or not at all).
+
+Option keys: VCMOptions::load (sources/etx/rt/integrators/vcm_shared.cxx:15-29), CPUPathTracingImpl::start
+(sources/etx/rt/integrators/path_tracing.cxx:36-40), CPUBidirectionalImpl::start (sources/etx/rt/integrators/bidirectional.cxx:1469-1478).
+Every key is switched away from its default in at least one set (oracle/gen_golden_options.py lists them); the default
+sets are what tests/test_gpu_parity_hi.py / test_gpu_bdpt.py compare at 4096 spp.
+
+Reference films: tests/golden/opt/*.npz, 1024 spp at 128 x 128, blue noise off, two flavours of the reference:
+  `_rekeyed`      independent light / camera streams = the estimator the device implements by default
+  `_opaque_none`  the UNMODIFIED integrator (shared seeds) with the candidate draws of always-opaque triangles taken off the path's
+                  stream, which pins its film (the same under every traversal order); the device renders it with the product option
+                  hip-reference_seeding (etx_abi_vcm_options::reference_seeding) - north_star's limits, no allowance.
+The device renders the same iteration set as two interleaved halves; compare() of test_gpu_parity_hi.py removes the Monte-Carlo noise
+the halves measure and asserts block-8 RMSE < 1e-3, image mean within 0.3 % (+ 3 standard errors), per-block bias p99 < 5 % (+ noise).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity_hi import compare, load_hi, render_halves
+from tests import test_gpu_bdpt
+
+pytestmark = pytest.mark.gpu
+
+SPP = 1024
+
+VCM_SETS = {
+    "nomis": {"vcm-mis": False},
+    "tophat": {"vcm-kernel": 0},
+    "connonly": {"vcm-merging": False},
+    "mergeonly": {"vcm-connect_vertices": False, "vcm-connect_to_light": False},
+    "nodirect": {"vcm-direct_hit": False, "vcm-connect_to_camera": False},
+    "radius": {"vcm-initial_radius": 0.05, "vcm-radius_decay": 16},
+    "nomergev": {"vcm-merge_vertices": False},
+}
+PT_SETS = {
+    "nonee": {"nee": False},
+    "nomis": {"mis": False},
+    "nodirect": {"direct": False},
+}
+BDPT_SETS = {
+    "nomis": {"bdpt-conn_mis": False},
+    "nodirect": {"bdpt-conn_direct_hit": False, "bdpt-conn_connect_to_camera": False},
+    "noconnect": {"bdpt-conn_connect_to_light": False, "bdpt-conn_connect_vertices": False},
+}
+
+
+def compare_layers(halves, golden, label, light_is_empty=False):
+    (cam_a, light_a), (cam_b, light_b) = halves
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], label + " camera+light")
+    compare((cam_a, cam_b), golden["camera"], label + " camera")
+    if light_is_empty:  # no camera connections: nothing may reach the light image, on either side
+        assert float(np.abs(golden["light"]).max()) == 0.0
+        assert float(np.abs(light_a[..., :3]).max()) == 0.0 and float(np.abs(light_b[..., :3]).max()) == 0.0, label
+    else:
+        compare((light_a, light_b), golden["light"], label + " light", mean_limit=1.0e-2, bias_p99_limit=0.2)
+
+
+@pytest.mark.parametrize("name", sorted(VCM_SETS))
+@pytest.mark.parametrize("flavour", ["classic", "full"])
+def test_vcm_option_set_matches_reference(etx, golden_dir, flavour, name):
+    options = dict(VCM_SETS[name], **{"vcm-blue_noise": False})
+    light_is_empty = options.get("vcm-connect_to_camera", True) is False
+    pinned = load_hi(golden_dir, "cornell_%s_128_vcm_%d_%s_opaque_none.npz" % (flavour, SPP, name), folder="opt", spp=SPP)
+    # the device under the reference's own seeding against the pinned, unmodified reference
+    stats = []
+    seeded = render_halves(etx, golden_dir, flavour, None, etx.HIPVCM, dict(options, **{"hip-reference_seeding": True}), spp=SPP, want_stats=stats)
+    compare_layers(seeded, pinned, "%s vcm %s (reference seeding, pinned reference)" % (flavour, name), light_is_empty)
+    if name in ("connonly", "nomergev"):  # merging switched off / merge weights without merges: no photon is looked at
+        assert all(s.photons_examined == 0 for s in stats)
+    if name == "mergeonly":
+        assert all((s.pairs == 0) and (s.photons_merged > 0) for s in stats)
+    # the default product configuration (camera stream of its own) against the reference with independent streams; on the classic box the two
+    # flavours of the reference are the same film to within noise (no medium, nothing but opaque triangles: DESIGN.md 4), so the pinned film serves
+    default = render_halves(etx, golden_dir, flavour, None, etx.HIPVCM, options, spp=SPP)
+    golden = load_hi(golden_dir, "cornell_%s_128_vcm_%d_%s_rekeyed.npz" % (flavour, SPP, name), folder="opt", spp=SPP) if flavour == "full" else pinned
+    compare_layers(default, golden, "%s vcm %s (independent streams)" % (flavour, name), light_is_empty)
+
+
+@pytest.mark.parametrize("name", sorted(PT_SETS))
+@pytest.mark.parametrize("flavour", ["classic", "full"])
+def test_pt_option_set_matches_reference(etx, golden_dir, flavour, name):
+    golden = load_hi(golden_dir, "cornell_%s_128_pt_%d_%s.npz" % (flavour, SPP, name), folder="opt", spp=SPP)
+    (cam_a, _), (cam_b, _) = render_halves(etx, golden_dir, flavour, None, etx.HIPPathTracing, dict(PT_SETS[name], bn=False), spp=SPP)
+    compare((cam_a, cam_b), golden["camera"], "%s pt %s camera" % (flavour, name))
+
+
+@pytest.mark.parametrize("name", sorted(BDPT_SETS))
+@pytest.mark.parametrize("flavour", ["classic", "full"])
+def test_bdpt_option_set_matches_reference(etx, golden_dir, flavour, name):
+    """CPUBidirectional, BDPTFull, one connection switch (or the MIS switch) off at a time; the device under the reference's seeding against the
+    pinned reference (as test_gpu_bdpt.test_bdpt_shared_streams_match_the_pinned_reference does for the default set)."""
+    options = dict(BDPT_SETS[name], **{"bdpt-mode": etx.api.BDPT_MODE_FULL, "bdpt-blue_noise": False, "hip-reference_seeding": True})
+    golden = np.load(os.path.join(golden_dir, "opt", "cornell_%s_128_bdpt3_%d_%s_opaque_none.npz" % (flavour, SPP, name)))
+    assert int(golden["spp"]) in (SPP - 1, SPP)  # CPUBidirectional::update does not count its last iteration (bidirectional.cxx:1526-1531)
+    halves = test_gpu_bdpt.render_halves(etx, golden_dir, flavour, SPP, options)
+    compare_layers(halves, golden, "%s bdpt %s (reference seeding, pinned reference)" % (flavour, name), light_is_empty=(name == "nodirect"))

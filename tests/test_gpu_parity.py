@@ -383,21 +383,13 @@ def test_subsurface_random_walk_matches_reference(etx, golden_dir):
     assert np.abs(rel).max() < 2.0e-2, rel
 
 
-def test_pt_options_and_config1_size(etx, golden_dir):
-    # configs[0]: 512 x 512, 16 spp. Size-independent properties + the option switches of CPUPathTracingImpl::start
+def test_pt_config0_size_and_sharding(etx, golden_dir):
+    # configs[0]: 512 x 512, 16 spp: size-independent properties. (The option switches of CPUPathTracingImpl::start - nee / mis / direct - are
+    # compared with films of the reference rendered with those switches: tests/test_gpu_options.py.)
     full, stats = render_pt(etx, golden_dir, "cornell_classic_512", 16)
     res = full["result"]
     assert res.shape == (512, 512, 4) and np.isfinite(res).all() and stats.completed_iterations == 16
     assert res[..., :3].mean() > 0.02
-    no_nee, _ = render_pt(etx, golden_dir, "cornell_classic_512", 16, options={"nee": False, "mis": False})
-    only_nee, _ = render_pt(etx, golden_dir, "cornell_classic_512", 16, options={"direct": False})
-    no_mis, _ = render_pt(etx, golden_dir, "cornell_classic_512", 16, options={"mis": False})
-    m = lambda layers: layers["camera"][..., :3].mean()
-    # BSDF sampling alone (no NEE, no MIS weights) estimates the same image as the MIS combination, with more noise;
-    # direct=false drops the emitter hits; nee + direct without MIS weights count the emitter twice
-    assert abs(m(no_nee) - m(full)) / m(full) < 0.08
-    assert m(only_nee) < m(full)
-    assert m(no_mis) > 1.2 * m(full)  # without MIS the emitter is counted by both strategies
     # iteration sharding is exact for PT as well (independent samples): two halves average to the whole
     even, _ = render_pt(etx, golden_dir, "cornell_classic_128", 8, first=0, stride=2, noise_threshold=0.0)
     odd, _ = render_pt(etx, golden_dir, "cornell_classic_128", 8, first=1, stride=2, noise_threshold=0.0)
@@ -422,41 +414,84 @@ def test_iteration_sharding_is_linear(etx, golden_dir):
     np.testing.assert_allclose(0.5 * (even[..., :3] + odd[..., :3]), all4[..., :3], rtol=2e-4, atol=2e-5)
 
 
-def test_rccl_film_reduce_single_rank(etx, golden_dir):
-    """The multi-GPU exchange of SURVEY.md 8e through the C ABI on the one device a test box has: a world-size-1 RCCL
-    communicator inside libetx_hip.so (etx_hip_comm_unique_id / etx_hip_comm_init), etx_hip_reduce_film = one
-    all-reduce of the film layers + the iteration count. With one rank the reduced film must equal the local film."""
+def test_rccl_film_reduce_cadence_single_rank(etx, golden_dir):
+    """The multi-GPU exchange of SURVEY.md 8e through the C ABI on the one device a test box has: a world-size-1 RCCL communicator inside
+    libetx_hip.so (etx_hip_comm_unique_id / etx_hip_comm_init). north_star places the film reduce "at the end of each iteration": the reduce is
+    asynchronous (snapshot + out-of-place all-reduce on a communication stream of its own), NOT terminal, and any cadence gives the same film:
+      * 8 iterations with a reduce begun after each  ==  8 iterations with one reduce at the end  ==  the film of a context without a communicator
+      * rendering continues after a reduce; the rank's own sums (checkpoint) are untouched
+      * etx_hip_read_film on a context with a communicator returns the reduced copy: the film AS OF the newest reduce."""
     from etx_tracer_amd import api, integrator as integ_mod
     snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_classic_128.etxscene"))
-    snap.samples = 4
-    films = []
-    for with_comm in (False, True):
+    snap.samples = 16
+    options = integ_mod.vcm_options_from_dict({"vcm-blue_noise": False})
+    layers = (api.LAYER_CAMERA, api.LAYER_LIGHT, api.LAYER_RESULT)
+
+    def run(with_comm, reduce_each):
         ctx = api.Context(0)
         ctx.upload_scene(snap)
         if with_comm:
             ctx.comm_init(0, 1, api.comm_unique_id(ctx.library))
-        ctx.begin_vcm(integ_mod.vcm_options_from_dict({"vcm-blue_noise": False}), first_iteration=0, iteration_stride=1)
-        for _ in range(4):
+        ctx.begin_vcm(options, first_iteration=0, iteration_stride=1)
+        for _ in range(8):
             ctx.render_iteration()
-        ctx.sync()
-        ctx.reduce_film()  # without a communicator: marks the film as final, no exchange
-        assert ctx.stats().completed_iterations == 4
-        films.append((ctx.read_film(api.LAYER_CAMERA), ctx.read_film(api.LAYER_LIGHT), ctx.read_film(api.LAYER_RESULT)))
-        with pytest.raises(api.EtxHipError):
-            ctx.render_iteration()  # after the reduce the film is final until the next etx_hip_begin
-        ctx.close()
-    for local, reduced in zip(*films):
-        assert np.isfinite(reduced).all()
-        np.testing.assert_allclose(reduced[..., :3], local[..., :3], rtol=2e-4, atol=2e-5)  # float atomics reorder the sums
+            if reduce_each:
+                ctx.reduce_film_begin()  # returns at once; finishes the previous one first if that is still in flight
+        ctx.reduce_film()                # sync + reduce: all 8 iterations
+        assert ctx.stats().completed_iterations == 8
+        films = [ctx.read_film(layer) for layer in layers]
+        info = ctx.reduce_info()
+        return ctx, films, info
 
-
-def test_merging_off_equals_connection_only_options(etx, golden_dir):
-    """vcm-merging=false must zero the merge weights (vm_weight = 0, vcm_cpu.cxx:110) - the image stays finite and
-    close to the full estimator (both are unbiased/consistent estimates of the same radiance)."""
-    _, _, full, _ = render(etx, golden_dir, "cornell_classic_128", 32)
-    _, _, conn, st = render(etx, golden_dir, "cornell_classic_128", 32, {"vcm-merging": False})
-    assert st.photons_examined == 0
-    assert rmse(block_mean(full, 32), block_mean(conn, 32)) < 6e-3
+    ctx0, local, info0 = run(False, False)
+    assert info0.reduces == 0 and info0.pending == 0  # nothing to exchange without a communicator
+    ctx0.close()
+    ctx1, once, info1 = run(True, False)
+    assert info1.reduces == 1 and info1.payload_bytes == 2 * 128 * 128 * 16 and info1.layer_mask == 3 and info1.global_iterations == 8  # VCM: camera + light only
+    assert info1.last_device_ms > 0.0
+    ctx1.close()
+    ctx2, each, info2 = run(True, True)
+    assert info2.reduces == 9 and info2.global_iterations == 8
+    for a, b, c in zip(local, once, each):
+        assert np.isfinite(b).all() and np.isfinite(c).all()
+        np.testing.assert_allclose(b[..., :3], a[..., :3], rtol=2e-4, atol=2e-5)  # float atomics reorder the sums
+        np.testing.assert_allclose(c[..., :3], a[..., :3], rtol=2e-4, atol=2e-5)
+    # not terminal: the same context renders on; its reduced copy stays the film of the last reduce until the next one
+    blob = ctx2.checkpoint_save()  # the rank's own sums: 8 iterations, untouched by nine reduces
+    for _ in range(4):
+        ctx2.render_iteration()
+    ctx2.sync()
+    assert ctx2.stats().completed_iterations == 12
+    stale = ctx2.read_film(api.LAYER_RESULT)
+    np.testing.assert_array_equal(stale, each[2])
+    ctx2.reduce_film_begin()
+    assert ctx2.reduce_film_end(True) is True and ctx2.reduce_film_end(False) is True
+    fresh = ctx2.read_film(api.LAYER_RESULT)
+    assert ctx2.reduce_info().global_iterations == 12
+    assert np.abs(fresh[..., :3] - stale[..., :3]).max() > 1.0e-4
+    # 12 iterations of a context without a communicator
+    ctx3 = api.Context(0)
+    ctx3.upload_scene(snap)
+    ctx3.begin_vcm(options, first_iteration=0, iteration_stride=1)
+    for _ in range(12):
+        ctx3.render_iteration()
+    ctx3.sync()
+    np.testing.assert_allclose(fresh[..., :3], ctx3.read_film(api.LAYER_RESULT)[..., :3], rtol=2e-4, atol=2e-5)
+    # the checkpoint taken between reduces continues as a run of its own
+    ctx3.begin_vcm(options, first_iteration=0, iteration_stride=1)
+    ctx3.checkpoint_load(blob)
+    for _ in range(4):
+        ctx3.render_iteration()
+    ctx3.sync()
+    np.testing.assert_allclose(ctx3.read_film(api.LAYER_RESULT)[..., :3], fresh[..., :3], rtol=2e-4, atol=2e-5)
+    ctx3.close()
+    # a new run clears the reduced copy
+    ctx2.begin_vcm(options, first_iteration=0, iteration_stride=1)
+    ctx2.render_iteration()
+    ctx2.sync()
+    one = ctx2.read_film(api.LAYER_RESULT)  # no reduce yet in this run: the context's own film (1 iteration)
+    assert np.isfinite(one).all() and np.abs(one[..., :3] - fresh[..., :3]).max() > 1.0e-3
+    ctx2.close()
 
 
 def test_full_size_iteration_properties(etx, golden_dir):

@@ -41,11 +41,11 @@ def rmse(a, b):
     return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
 
 
-def load_hi(golden_dir, name):
-    path = os.path.join(golden_dir, "hi", name)
-    assert os.path.exists(path), "%s is missing: run oracle/gen_golden_hi.py in the build container" % path
+def load_hi(golden_dir, name, folder="hi", spp=SPP):
+    path = os.path.join(golden_dir, folder, name)
+    assert os.path.exists(path), "%s is missing: run oracle/gen_golden_hi.py (hi) or oracle/gen_golden_options.py (opt) in the build container" % path
     golden = np.load(path)
-    assert int(golden["spp"]) == SPP
+    assert int(golden["spp"]) == spp
     return golden
 
 
@@ -92,12 +92,12 @@ def compare(halves, reference, label, rmse_limit=1.0e-3, mean_limit=3.0e-3, bias
     assert p99 < bias_p99_limit + 1.5 * noise_p99, (label, p99, noise_p99)
 
 
-def render_halves(etx, golden_dir, flavour, cie, integrator_class, options, debug_flags=0, bluenoise=None):
-    """Iterations 0, 2, 4, ... and 1, 3, 5, ... of the 4096-iteration set: two contexts, etx_hip_begin(first, stride 2)."""
+def render_halves(etx, golden_dir, flavour, cie, integrator_class, options, debug_flags=0, bluenoise=None, spp=SPP, want_stats=None):
+    """Iterations 0, 2, 4, ... and 1, 3, 5, ... of the `spp`-iteration set: two contexts, etx_hip_begin(first, stride 2)."""
     films = []
     for first in (0, 1):
         snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_%s_128.etxscene" % flavour))
-        snap.samples = SPP
+        snap.samples = spp
         snap.noise_threshold = 0.0  # the 4096-spp PT films were rendered with --noise-threshold 0 (every pixel gets every sample)
         integ = integrator_class(snap, first_iteration=first, iteration_stride=2)
         integ.options().update(options)
@@ -110,9 +110,11 @@ def render_halves(etx, golden_dir, flavour, cie, integrator_class, options, debu
         cam, light = integ.film(etx.api.LAYER_CAMERA), integ.film(etx.api.LAYER_LIGHT)
         stats = integ.status()
         integ.context.close()
-        assert stats.completed_iterations == SPP // 2 and stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
+        assert stats.completed_iterations == spp // 2 and stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
         assert np.isfinite(cam).all() and np.isfinite(light).all()
         films.append((cam, light))
+        if want_stats is not None:
+            want_stats.append(stats)
     return films
 
 
@@ -159,11 +161,12 @@ def test_vcm_default_options_blue_noise_at_4096_spp(etx, golden_dir, bluenoise_2
 @pytest.mark.parametrize("flavour", ["classic", "full"])
 def test_vcm_shared_streams_match_the_pinned_reference(etx, golden_dir, flavour):
     """The converse of the `_rekeyed` comparison: instead of giving the reference the device's stream policy, the
-    DEVICE takes the reference's - camera path i keeps the seed of light path i (debug flag bit 15, kernels_vcm.hip k_camera_generate) - and
+    DEVICE takes the reference's - camera path i keeps the seed of light path i (option hip-reference_seeding = etx_abi_vcm_options::reference_seeding,
+    kernels_vcm.hip k_camera_generate) - and
     is compared with the UNMODIFIED integrator in the one regime where its film is pinned: ETX_ORACLE_BVH_DRAWS=opaque_none takes the
     candidate draws of always-opaque triangles off the path's stream (oracle/shims/raytracing_bvh.cxx), after which the reference's film is
     the same under every traversal order (tests/test_reference_order_spread.py). north_star's limits, no allowance."""
-    (cam_a, light_a), (cam_b, light_b) = render_vcm(etx, golden_dir, flavour, None, debug_flags=0x8000)
+    (cam_a, light_a), (cam_b, light_b) = render_vcm(etx, golden_dir, flavour, None, options={"vcm-blue_noise": False, "hip-reference_seeding": True})
     golden = load_hi(golden_dir, "cornell_%s_128_vcm_%d_opaque_none.npz" % (flavour, SPP))
     compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], flavour + " vcm camera+light (shared streams, pinned reference)")
     compare((light_a, light_b), golden["light"], flavour + " vcm light (shared streams, pinned reference)", mean_limit=1.0e-2, bias_p99_limit=0.2)

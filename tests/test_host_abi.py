@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(etx):
     missing = [s for s in symbols if not lib.has_symbol(s)]
     assert missing == []
     assert set(etx.api.EXPORTED_SYMBOLS) == set(symbols)
-    assert lib.lib.etx_hip_abi_version() == 2  # etx_hip_stats_t grew (pool_grows), etx_hip_set_pool_policy
+    assert lib.lib.etx_hip_abi_version() == 3  # 2: etx_hip_stats_t grew (pool_grows), etx_hip_set_pool_policy; 3: reference_seeding, asynchronous film reduce
 
 
 def test_missing_library_is_an_error(etx, tmp_path):

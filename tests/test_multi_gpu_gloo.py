@@ -107,6 +107,12 @@ def bench_worker(rank, world, port, out_dir):
             f.write(printed[0])
     assert ("comm_init", rank, world, bytes(range(128))) in ctx.calls
     assert ("begin_vcm", rank + 1 * world, world) in ctx.calls and ctx.calls[-1] == ("close",)
+    # north_star's cadence (--reduce-every 1, the default): inside every region of 3 steps a reduce is begun after the first and the second
+    # iteration and the blocking one closes the region; the warm-up run of 1 step has only its closing reduce. The same sequence on every rank.
+    sequence = [c[0] for c in ctx.calls if c[0] in ("begin_vcm", "reduce_film_begin", "reduce_film")]
+    region = ["begin_vcm", "reduce_film_begin", "reduce_film_begin", "reduce_film"]
+    expected_sequence = ["begin_vcm", "reduce_film"] + region * 3 + (["begin_vcm"] if rank == 0 else [])  # rank 0: the per-kernel pass afterwards, no reduce
+    assert sequence == expected_sequence, sequence
     np.save(os.path.join(out_dir, "bench_film%d.npy" % rank), ctx.reduced_result)
     np.save(os.path.join(out_dir, "bench_iterations%d.npy" % rank), np.array(ctx.reduced_iterations))
 
@@ -114,16 +120,19 @@ def bench_worker(rank, world, port, out_dir):
 def test_bench_two_gpu_control_flow_under_gloo(tmp_path):
     import json
     from tests.stub_context import fake_iteration as stub_iteration
-    world, steps, warmup = 2, 3, 1
+    world, steps, warmup, repeats = 2, 3, 1, 3
     mp.spawn(bench_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
     line = json.loads(open(tmp_path / "line.json").read())
     assert line["n_gpus"] == 2 and line["steps"] == steps and line["warmup"] == warmup and line["scaling"] == "weak" and line["cpu_baseline"] is None
+    assert line["repeats"]["count"] == repeats and line["repeats"]["min"] <= line["value"] == line["repeats"]["median"] <= line["repeats"]["max"]
+    assert line["reduce"]["every"] == 1 and line["reduce"]["count"] == steps  # one reduce per iteration of the (median) region, the last one blocking
     assert line["config"]["workload"] == "cornell_classic_vcm_1920x1080" and line["unit"] == "Msamples/s"
     # value = the samples ALL ranks rendered in the timed region / the slowest rank's time
     assert abs(line["value"] - 1920 * 1080 * steps * world / (line["ms_per_step"] * 1.0e-3 * steps) / 1.0e6) < 1.0e-3 * line["value"]
-    # the timed region: rank r rendered iterations r + (warmup + k) * world, and after the reduce every rank holds their mean
+    # the last timed region: rank r rendered iterations r + (offset + k) * world, and after its closing reduce every rank holds their mean
+    offset = warmup + (repeats - 1) * steps
     rendered = sorted(int(i) for r in range(world) for i in np.load(tmp_path / ("bench_iterations%d.npy" % r)))
-    assert rendered == list(range(warmup * world, (warmup + steps) * world))
+    assert rendered == list(range(offset * world, (offset + steps) * world))
     camera = sum(stub_iteration(i)[0] for i in rendered)
     light = sum(stub_iteration(i)[1] for i in rendered)
     expected = torch.clamp((camera + light) / len(rendered), min=0.0)
@@ -144,13 +153,17 @@ def pixel_bench_worker(rank, world, port, out_dir):
     from tests.stub_context import StubContext
     stdout = io.StringIO()
     with contextlib.redirect_stdout(stdout):
-        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--workload", "cloud_bdpt", "--shard", "pixels", "--no-cpu-baseline", "--no-kernel-table"],
+        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--workload", "cloud_bdpt", "--shard", "pixels", "--no-cpu-baseline", "--no-kernel-table", "--reduce-every", "2",
+                    "--repeats", "2"],
                    context_factory=StubContext, backend="gloo")
     ctx = StubContext.instances[-1]
     if rank == 0:
         with open(os.path.join(out_dir, "pixel_line.json"), "w") as f:
             f.write([l for l in stdout.getvalue().splitlines() if l.startswith("{")][0])
-    assert ("begin_bdpt", 1, 1, rank, world) in ctx.calls  # timed region: iterations warmup .. warmup + steps - 1 on EVERY rank, pixels rank, rank + world, ...
+    assert ("begin_bdpt", 1, 1, rank, world) in ctx.calls  # first timed region: iterations warmup .. warmup + steps - 1 on EVERY rank, pixels rank, rank + world, ...
+    # --reduce-every 2 over 3 steps: one asynchronous reduce (after the second iteration) and the closing one, in every region
+    sequence = [c[0] for c in ctx.calls if c[0] in ("begin_bdpt", "reduce_film_begin", "reduce_film")]
+    assert sequence == ["begin_bdpt", "reduce_film"] + ["begin_bdpt", "reduce_film_begin", "reduce_film"] * 2, sequence
     np.save(os.path.join(out_dir, "pixel_film%d.npy" % rank), ctx.reduced_result)
     np.save(os.path.join(out_dir, "pixel_iterations%d.npy" % rank), np.array(ctx.reduced_iterations))
 
@@ -160,17 +173,71 @@ def test_bench_pixel_sharding_control_flow_under_gloo(tmp_path):
     pixel shard 0 alone. The reduced film equals the unsharded mean of the same iterations."""
     import json
     from tests.stub_context import fake_iteration as stub_iteration
-    world, steps, warmup = 2, 3, 1
+    world, steps, warmup, repeats = 2, 3, 1, 2
     mp.spawn(pixel_bench_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
     line = json.loads(open(tmp_path / "pixel_line.json").read())
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["parallelism"].startswith("pixel-sharded x2")
     # the job is `steps` iterations of the frame, whatever the rank count
     assert abs(line["value"] - 2048 * 2048 * steps / (line["ms_per_step"] * 1.0e-3 * steps) / 1.0e6) < 1.0e-3 * line["value"]
+    assert line["reduce"]["every"] == 2 and line["reduce"]["count"] == 2 and line["repeats"]["count"] == repeats
+    first = warmup + (repeats - 1) * steps  # the last region's iterations
     for r in range(world):
-        assert [int(i) for i in np.load(tmp_path / ("pixel_iterations%d.npy" % r))] == list(range(warmup, warmup + steps))
-    camera = sum(stub_iteration(i)[0] for i in range(warmup, warmup + steps))
-    light = sum(stub_iteration(i)[1] for i in range(warmup, warmup + steps))
+        assert [int(i) for i in np.load(tmp_path / ("pixel_iterations%d.npy" % r))] == list(range(first, first + steps))
+    camera = sum(stub_iteration(i)[0] for i in range(first, first + steps))
+    light = sum(stub_iteration(i)[1] for i in range(first, first + steps))
     expected = torch.clamp((camera + light) / steps, min=0.0)
     expected[..., 3] = 1.0
     for r in range(world):
         np.testing.assert_allclose(np.load(tmp_path / ("pixel_film%d.npy" % r)), expected.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def cadence_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.stub_context import StubContext
+
+    class Snapshot:
+        film_size = (16, 12)
+
+    ctx = StubContext(rank)
+    ctx.upload_scene(Snapshot())
+    ctx.begin_vcm(None, first_iteration=rank, iteration_stride=world)
+    films = []
+    # the ranks progress UNEVENLY between reduces (rank 0 two iterations, rank 1 one): every reduce still yields the mean of exactly the
+    # iterations the ranks had committed, because the count travels with the sums
+    for _ in range(3):
+        for _ in range(2 - rank):
+            ctx.render_iteration()
+        ctx.reduce_film_begin()
+        assert ctx.reduce_film_end(True)
+        films.append((ctx.result().copy(), int(ctx.reduced_count.item())))
+    ctx.render_iteration()  # rendering goes on after a reduce
+    ctx.reduce_film()
+    films.append((ctx.result().copy(), int(ctx.reduced_count.item())))
+    np.save(os.path.join(out_dir, "cadence%d.npy" % rank), np.stack([f[0] for f in films]))
+    np.save(os.path.join(out_dir, "cadence_counts%d.npy" % rank), np.array([f[1] for f in films]))
+    np.save(os.path.join(out_dir, "cadence_own%d.npy" % rank), np.array(ctx.iterations_rendered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_cadence_progressive_and_not_terminal(tmp_path):
+    """SURVEY.md 8e row 2 / north_star: the film is reduced while the render runs - every reduce returns the job's film so far, the ranks'
+    own sums stay their own, and the film after the last reduce equals the one-reduce-at-the-end film of the same iterations."""
+    from tests.stub_context import fake_iteration as stub_iteration
+    world = 2
+    mp.spawn(cadence_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    films = [np.load(tmp_path / ("cadence%d.npy" % r)) for r in range(world)]
+    counts = [np.load(tmp_path / ("cadence_counts%d.npy" % r)) for r in range(world)]
+    np.testing.assert_array_equal(films[0], films[1])
+    assert list(counts[0]) == list(counts[1]) == [3, 6, 9, 11]
+    own = [[int(i) for i in np.load(tmp_path / ("cadence_own%d.npy" % r))] for r in range(world)]
+    assert own[0] == [0, 2, 4, 6, 8, 10, 12] and own[1] == [1, 3, 5, 7]
+    for k, (n0, n1) in enumerate([(2, 1), (4, 2), (6, 3), (7, 4)]):
+        rendered = own[0][:n0] + own[1][:n1]
+        expected = torch.clamp(sum(stub_iteration(i)[0] + stub_iteration(i)[1] for i in rendered) / len(rendered), min=0.0)
+        expected[..., 3] = 1.0
+        np.testing.assert_allclose(films[0][k], expected.numpy(), rtol=1e-6, atol=1e-6)

@@ -11,7 +11,7 @@ export ETX_HIP_LANES=1
 n=0
 for counters in "$@"; do
   n=$((n+1))
-  rocprofv3 --kernel-trace --output-format csv --pmc $counters -d $out/pass$n -o pmc -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-table > $out/pass$n.log 2>&1 || echo "pass $n failed"
+  rocprofv3 --kernel-trace --output-format csv --pmc $counters -d $out/pass$n -o pmc -- python $root/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-kernel-table > $out/pass$n.log 2>&1 || echo "pass $n failed"
   grep -i "error\|invalid\|unable" $out/pass$n.log | head -3
 done
 cd $root

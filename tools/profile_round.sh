@@ -9,11 +9,11 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- python $root/bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" > $out/bench_stats.json 2> $out/bench_stats.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- python $root/bench.py --steps 8 --warmup 2 --repeats 1 --no-cpu-baseline "$@" > $out/bench_stats.json 2> $out/bench_stats.err
 export ETX_HIP_LANES=1
 pass() {  # name counters...
   local name=$1; shift
-  timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $out/pmc_$name -o pmc -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-table "${bench_args[@]}" > $out/pmc_$name.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $out/pmc_$name -o pmc -- python $root/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-kernel-table "${bench_args[@]}" > $out/pmc_$name.log 2>&1
 }
 pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM
 pass sq2 SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU
