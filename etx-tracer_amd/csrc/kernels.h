@@ -33,6 +33,7 @@ struct ShadeGroups {
 constexpr uint32_t kRoundMirrorSlots = 1024;  // ring of (round tag, active count) entries the trace kernel writes to pinned host memory
 void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat,
   uint32_t cross_mode);  // pass_stat: kStatRaysLight / kStatRaysCamera / 0; cross_mode: 0 / 1 (VCM state) / 2 (bidirectional state): medium boundaries crossed inside the kernel (kernels_trace.hip kCross)
+void launch_round_housekeeping(hipStream_t stream, const Pipeline& p, uint32_t active_counter, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat);  // fused rounds (Pipeline::fuse_trace)
 void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_items, bool flat);
 void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count, bool flat, uint32_t debug_flags);
 

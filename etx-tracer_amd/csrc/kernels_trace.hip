@@ -479,21 +479,33 @@ static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const flo
 #undef ETX_LAUNCH_BVH
 }
 
+// A fused round (Pipeline::fuse_trace, kernels_shade.inl kFuse): the shade kernel of the previous round has answered this round's closest-hit
+// queries, what is left of the traversal launch is its housekeeping - queue counters, statistics, the host's round mirror.
+__global__ void k_round_housekeeping(uint32_t* __restrict__ counters, uint32_t active_counter, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat) {
+  if ((blockIdx.x == 0) && (threadIdx.x == 0))
+    round_housekeeping(counters, active_counter, counters[active_counter], pass_stat, round_mirror, round_tag);
+}
+
+void launch_round_housekeeping(hipStream_t stream, const Pipeline& p, uint32_t active_counter, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat) {
+  hipLaunchKernelGGL(k_round_housekeeping, dim3(1), dim3(64), 0, stream, p.counters, active_counter, round_mirror, round_tag, pass_stat);
+}
+
 void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat,
   uint32_t cross_mode) {
+  float4* const hits = ((p.fuse_trace != 0u) && (set == 1u)) ? p.hits_alt : p.hits;  // dev_vcm_steps.h hits_of
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.capacity, max_items) + kBlockSize - 1) / kBlockSize));
   // opt-in (ETX_HIP_DEBUG_FLAGS bit 64): alone on the device the two-ray sweep is 10 % faster (39.3 vs 35.7 Grays/s on 2 M incoherent
   // rays), inside the 4-lane pipeline its fatter waves lose against the co-running kernels (51.5 vs 46.6 us per launch) - DESIGN.md 3
   if (flat && (p.debug_flags & 64u))
-    hipLaunchKernelGGL((k_trace_closest_flat2<true>), dim3(flat2_blocks(min(p.capacity, max_items))), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits,
+    hipLaunchKernelGGL((k_trace_closest_flat2<true>), dim3(flat2_blocks(min(p.capacity, max_items))), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, hits,
       p.counters, active_counter, 0u, round_mirror, round_tag, pass_stat);
   else if (flat && (cross_mode != kCrossNone) && (p.scene.boundary_materials != 0u))
-    hipLaunchKernelGGL((k_trace_closest<true, true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag,
+    hipLaunchKernelGGL((k_trace_closest<true, true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, hits, p.counters, active_counter, 0u, round_mirror, round_tag,
       lds_limit(), pass_stat, p.paths[set], cross_mode, p.block_stats);
   else if (flat)
-    hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag, lds_limit(), pass_stat);
+    hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, hits, p.counters, active_counter, 0u, round_mirror, round_tag, lds_limit(), pass_stat);
   else
-    launch_bvh_kernel<true>(stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, min(p.capacity, max_items), round_mirror, round_tag, pass_stat);
+    launch_bvh_kernel<true>(stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, hits, p.counters, active_counter, min(p.capacity, max_items), round_mirror, round_tag, pass_stat);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -131,6 +131,11 @@ void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& 
   const void* simple_kernel = groups.binned() ? reinterpret_cast<const void*>(&k_light_shade<kShadeGroupSimple, true>) : reinterpret_cast<const void*>(&k_light_shade<kShadeGroupSimple, false>);
   const dim3 simple_grid(persistent_grid(grid.x, simple_kernel, percent));
   if (groups.binned() == false) {
+    if (p.fuse_trace != 0u) {  // flat scene: the kernel also sweeps for the next segment of every path it appends (kernels_shade.inl kFuse)
+      const dim3 fused_grid(persistent_grid(grid.x, reinterpret_cast<const void*>(&k_light_shade<kShadeGroupSimple, false, true>), percent));
+      hipLaunchKernelGGL((k_light_shade<kShadeGroupSimple, false, true>), fused_grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+      return;
+    }
     hipLaunchKernelGGL((k_light_shade<kShadeGroupSimple, false>), simple_grid, dim3(kBlockSize), 0, stream, p, it, in_set);
     return;
   }
@@ -199,6 +204,11 @@ void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams&
   const void* simple_kernel = groups.binned() ? reinterpret_cast<const void*>(&k_camera_shade<kShadeGroupSimple, true>) : reinterpret_cast<const void*>(&k_camera_shade<kShadeGroupSimple, false>);
   const dim3 simple_grid(persistent_grid(grid.x, simple_kernel, percent));
   if (groups.binned() == false) {
+    if (p.fuse_trace != 0u) {
+      const dim3 fused_grid(persistent_grid(grid.x, reinterpret_cast<const void*>(&k_camera_shade<kShadeGroupSimple, false, true>), percent));
+      hipLaunchKernelGGL((k_camera_shade<kShadeGroupSimple, false, true>), fused_grid, dim3(kBlockSize), 0, stream, p, it, in_set);
+      return;
+    }
     hipLaunchKernelGGL((k_camera_shade<kShadeGroupSimple, false>), simple_grid, dim3(kBlockSize), 0, stream, p, it, in_set);
     return;
   }
