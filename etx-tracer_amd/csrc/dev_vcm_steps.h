@@ -70,54 +70,6 @@ ETX_DEV void store_camera_vertex(const Pipeline& p, uint32_t idx, const DScene& 
 // What happened on a segment (the branches of vcm_light_step / vcm_camera_step)
 enum : uint32_t { kEventNone = 0, kEventMedium = 1, kEventSurface = 2, kEventBoundary = 3 };
 
-// The hit queue of path set `set` (Pipeline::hits_alt)
-ETX_DEV float4* hits_of(const Pipeline& p, uint32_t set) {
-  return ((p.fuse_trace != 0u) && (set == 1u)) ? p.hits_alt : p.hits;
-}
-
-// The closest-hit query of the NEXT segment, run by the shade step itself for the path it is about to append (flat scenes: the sweep over the
-// <= 64 primitives of dev_bvh.h bvh_flat_closest): exactly what k_trace_closest<true, true, kCross> (kernels_trace.hip) would answer for this
-// path one launch later - the same alpha stream keyed by the ray, the same in-place crossing of medium boundaries by a path that is in no
-// medium (vcm_handle_boundary_bsdf draws nothing, vcm_shared.hxx:436-449: origin beyond the surface, the medium behind it, the distance added
-// to the path's) - so the films of a fused and an unfused render differ by the order of the float atomics only. `st` is advanced across the
-// boundaries it crosses BEFORE it is stored; `crossed_queries` counts the queries beyond them (they are rays: kBlockStatCrossings).
-ETX_DEV float4 fused_flat_closest(const DScene& scene, PathState& st, unsigned long long& crossed_queries) {
-  const float4 a = mk4(st.ray_o, st.ray_tmin), b = mk4(st.ray_d, st.ray_tmax);
-  uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ (__float_as_uint(a.z) * 0x85ebca6bu) ^ (__float_as_uint(b.x) * 0xc2b2ae35u);
-  const RayQ ray = {st.ray_o, st.ray_tmin, st.ray_d, st.ray_tmax};
-  const bool cross = scene.boundary_materials != 0u;  // launch_trace_closest's choice of the kCross instantiation
-  uint32_t flags = 0u;
-  Hit h = bvh_flat_closest(scene, scene.bvh_tris, ray, alpha_seed, cross ? &flags : nullptr);
-  if (cross) {
-    uint32_t crossings = 0u, medium = st.medium;
-    float crossed = 0.0f;
-    f3 origin = ray.o;
-    while ((h.tri != kInvalid) && (flags & kTriBoundary) && (crossings < 8u) && (medium == kInvalid)) {
-      const etx_abi_triangle& tri = scene.triangles[h.tri];
-      const etx_abi_material& mat = scene.materials[tri.material_index];
-      medium = (dot(ld3(tri.geo_n), ray.d) < 0.0f) ? mat.int_medium : mat.ext_medium;
-      crossed += h.t;
-      origin = shading_pos(scene, tri, barycentrics(h.u, h.v), ray.d);
-      crossings += 1u;
-      const RayQ beyond = {origin, kRayEpsilon, ray.d, kMaxFloat};
-      h = bvh_flat_closest(scene, scene.bvh_tris, beyond, alpha_seed, &flags);
-    }
-    if (crossings != 0u) {
-      crossed_queries += crossings;
-      st.ray_o = origin, st.ray_tmin = kRayEpsilon, st.ray_tmax = kMaxFloat;
-      st.medium = medium;
-      st.path_distance += crossed;
-    }
-  }
-  return make_float4(h.u, h.v, h.t, __uint_as_float(h.tri));
-}
-
-// kFuse instantiations of the step functions (wavefront kernels of the simple group on flat scenes): where the next segment's hit goes
-struct FusedTrace {
-  float4* hits_out;                      // hit queue of the path set the step appends to
-  unsigned long long* crossed_queries;   // the lane's count of queries beyond crossed boundaries
-};
-
 // vcm_light_step, vcm_shared.hxx:1090-1260: everything after rt.trace for one light sub path segment.
 // Returns whether the path continues (state updated in place).
 // The reference's medium branch (:1097-1170) and surface branch (:1181-1259) are restated as three phases so that the
@@ -132,9 +84,9 @@ struct FusedTrace {
 // The simple shading group takes its three slots - vertex, shadow request, next path set - with ONE reservation at the end of the step
 // (Slots::get3) and stores everything after it; the other groups reserve one by one as the step goes (their walks and endpoint requests reserve
 // inside data-dependent code anyway) and leave the path to the caller.
-template <uint32_t kGroup, class Slots, bool kFuse = false>
+template <uint32_t kGroup, class Slots>
 ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots, const LaneStack& stack,
-  const PathSet* out = nullptr, uint32_t* out_counter = nullptr, const FusedTrace* fused = nullptr) {
+  const PathSet* out = nullptr, uint32_t* out_counter = nullptr) {
   constexpr bool kSimple = kGroup == kShadeGroupSimple;      // BSDF classes compiled in (dev_bsdf_ool.h)
   constexpr bool kWalk = kGroup == kShadeGroupSubsurface;   // the subsurface random walk runs inline
   const uint32_t tri = __float_as_uint(h.w);
@@ -282,13 +234,8 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
     }
     if (queue)
       write_shadow(p, slot.b, request);
-    if (alive && (out != nullptr)) {
-      // kFuse: the vertex record and the request are written, the step's registers are free - the sweep for the next segment runs here, before the
-      // path is stored (it moves a path that is in no medium across the medium boundaries it meets)
-      if (kFuse)
-        fused->hits_out[slot.c] = fused_flat_closest(scene, st, *fused->crossed_queries);
+    if (alive && (out != nullptr))
       store_path(*out, slot.c, st);
-    }
     return alive;
   }
 
@@ -323,9 +270,9 @@ ETX_DEV bool light_step(const Pipeline& p, const DScene& scene, const VcmParams&
 // vcm_camera_step, vcm_shared.hxx:927-1079 after rt.trace, without the vertex connections and the merge: connectible
 // vertices go to the camera vertex pool (k_expand_pairs / k_connect_pairs / k_merge consume them), NEE segments go to
 // the shadow queue, direct / miss radiance goes straight to the film. Same three-phase shape as light_step.
-template <uint32_t kGroup, class Slots, bool kFuse = false>
+template <uint32_t kGroup, class Slots>
 ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams& it, PathState& st, const float4& h, bool valid, const Slots& slots, const LaneStack& stack,
-  const PathSet* out = nullptr, uint32_t* out_counter = nullptr, const FusedTrace* fused = nullptr) {  // out / out_counter / fused: as for light_step
+  const PathSet* out = nullptr, uint32_t* out_counter = nullptr) {  // out / out_counter: as for light_step
   constexpr bool kSimple = kGroup == kShadeGroupSimple;
   constexpr bool kWalk = kGroup == kShadeGroupSubsurface;
   const uint32_t tri = __float_as_uint(h.w);
@@ -546,13 +493,8 @@ ETX_DEV bool camera_step(const Pipeline& p, const DScene& scene, const VcmParams
     }
     if (queue)
       write_shadow(p, slot.b, request);
-    if (alive && (out != nullptr)) {
-      // kFuse: the vertex record and the request are written, the step's registers are free - the sweep for the next segment runs here, before the
-      // path is stored (it moves a path that is in no medium across the medium boundaries it meets)
-      if (kFuse)
-        fused->hits_out[slot.c] = fused_flat_closest(scene, st, *fused->crossed_queries);
+    if (alive && (out != nullptr))
       store_path(*out, slot.c, st);
-    }
     return alive;
   }
 

@@ -55,7 +55,6 @@ struct TimedSpan {
 }  // namespace
 
 constexpr uint32_t kFilmLayers = 4;     // camera, light, normal, albedo sums (pipeline.h)
-constexpr uint32_t kFuseTraceDefault = 0u;  // fused rounds (render_vcm_iteration): off until the A/B of round 5 says otherwise
 constexpr uint32_t kBlueNoiseSets = 9;  // sample-count classes 1, 2, 4, ... 256 of the host's blue-noise sampler
 
 struct etx_hip_context;
@@ -114,7 +113,6 @@ struct etx_hip_context {
   size_t allocated_bytes = 0;        // of this lane's pipeline (etx_hip_device_bytes)
   uint32_t base_lanes = 1, active_lanes = 1;  // public context: lanes every integrator uses / lanes the armed integrator uses
   uint32_t debug_flags = 0;          // etx_hip_set_debug_flags: ablation switches of the kernels (Pipeline::debug_flags), 0 in production
-  uint32_t fuse_trace_wanted = kFuseTraceDefault;  // fused rounds of VCM on flat scenes (render_vcm_iteration); ETX_HIP_FUSE_TRACE in debug builds
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
   std::vector<TimedSpan> spans;
@@ -350,11 +348,6 @@ int allocate_pipeline(etx_hip_context* ctx) {
   }
   if ((rc = device_alloc(ctx, p.hits, n)))
     return rc;
-  p.hits_alt = nullptr, p.fuse_trace = 0u;
-  if (p.scene.bvh_flat != 0u) {  // fused rounds (render_vcm_iteration): the hit queue of path set 1
-    if ((rc = device_alloc(ctx, p.hits_alt, n)))
-      return rc;
-  }
   p.walk[0] = p.walk[1] = p.walk_exit = {}, p.walk_info[0] = p.walk_info[1] = nullptr, p.walk_exit_hits = nullptr;
   if (ctx->scene.has_subsurface) {  // walk and exit queues of the bidirectional integrator (k_bdpt_walk_*)
     PathSet* sets[3] = {&p.walk[0], &p.walk[1], &p.walk_exit};
@@ -562,7 +555,6 @@ ShadeGroups shade_groups(const etx_hip_context* ctx) {
 template <class ShadeFn, class TailFn>
 int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64_t& rounds, uint32_t pass_stat, bool allow_tail = true) {
   uint32_t set = 0;
-  const bool fused = ctx->pipe.fuse_trace != 0u;  // rounds after the first need no traversal launch (render_vcm_iteration)
   uint32_t known_count = ctx->pipe.capacity;  // upper bound of the active paths (the count never grows within a pass)
   const uint32_t tail_threshold = (allow_tail && ctx->tail_divisor) ? std::max(64u, ctx->pipe.capacity / ctx->tail_divisor) : 0u;
   etx_hip_context::PassPlan& plan = ctx->plans[(pass_stat == kStatRaysLight) ? 0 : 1];
@@ -579,9 +571,7 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
         break;
       bound = uint32_t(std::min<uint64_t>(ctx->pipe.capacity, uint64_t(planned[r]) + planned[r] / 8u + 4096u));
       const uint32_t tag = ctx->next_round_tag++;
-      if (fused && (r != 0u)) {  // the previous round's shade kernel has answered this round's queries (kernels_shade.inl kFuse)
-        launch_round_housekeeping(ctx->stream, ctx->pipe, set == 0 ? kCntActiveA : kCntActiveB, ctx->round_mirror, tag, pass_stat);
-      } else {
+      {
         ScopedTimer t(ctx, kTimerTraceClosest);
         launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB, bound, ctx->scene.host_copy.bvh_flat != 0u, ctx->round_mirror, tag, pass_stat, ctx->cross_mode);
       }
@@ -618,9 +608,7 @@ int run_bounce_loop(etx_hip_context* ctx, ShadeFn&& shade, TailFn&& tail, uint64
   };
   for (uint64_t round = 0; round < max_rounds; ++round) {
     const uint32_t tag = ctx->next_round_tag++;
-    if (fused && (round != 0u)) {
-      launch_round_housekeeping(ctx->stream, ctx->pipe, set == 0 ? kCntActiveA : kCntActiveB, ctx->round_mirror, tag, pass_stat);
-    } else {
+    {
       ScopedTimer t(ctx, kTimerTraceClosest);
       launch_trace_closest(ctx->stream, ctx->pipe, set, set == 0 ? kCntActiveA : kCntActiveB, known_count, ctx->scene.host_copy.bvh_flat != 0u, ctx->round_mirror, tag, pass_stat, ctx->cross_mode);
     }
@@ -675,10 +663,6 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
   // (Film::commit_light_iteration, film.cxx:332-343, and the per-iteration camera value of vcm_cpu.cxx:227-241). Adding every
   // connection / splat straight into sums that have grown over thousands of iterations would absorb the contributions that
   // are smaller than half an ulp of the sum - a negative bias that grows with the sample count (measured at 4096 spp).
-  // Fused rounds: on a flat scene whose materials are all of the simple shading group the shade kernel of a round also runs the closest-hit
-  // sweep of the NEXT segment for every path it appends (kernels_shade.inl kFuse) - the sweep is VALU work, the shade step waits on dependent
-  // loads, and a round loses one launch and 48 B of queue traffic per ray. Only the first round of a pass still launches k_trace_closest.
-  ctx->pipe.fuse_trace = ((ctx->pipe.hits_alt != nullptr) && (shade_groups(ctx).binned() == false) && (ctx->fuse_trace_wanted != 0u)) ? 1u : 0u;
   Pipeline p = ctx->pipe;
   p.camera_sum = ctx->pt_iteration_image;
   p.light_sum = ctx->pt_iteration_image + p.capacity;
@@ -792,7 +776,6 @@ int render_vcm_iteration(etx_hip_context* ctx, uint32_t iteration) {
 // One path-tracing iteration (CPUPathTracingImpl::execute_range over all pixels, path_tracing.cxx:50-83).
 int render_pt_iteration(etx_hip_context* ctx, uint32_t iteration) {
   const auto& o = ctx->pt_options;
-  ctx->pipe.fuse_trace = 0u;  // fused rounds are VCM's (render_vcm_iteration)
   VcmParams it = {};
   it.options = (o.direct ? ETX_PT_DIRECT : 0u) | (o.nee ? ETX_PT_NEE : 0u) | (o.mis ? ETX_PT_MIS : 0u);
   it.iteration = iteration;
@@ -843,7 +826,6 @@ int render_pt_iteration(etx_hip_context* ctx, uint32_t iteration) {
 // sub paths of all pixels, then the camera sub paths; every connection's visibility goes through the shadow queue.
 int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
   const auto& o = ctx->bdpt_options;
-  ctx->pipe.fuse_trace = 0u;
   VcmParams it = {};
   it.options = (o.connect_to_camera ? ETX_VCM_CONNECT_TO_CAMERA : 0u) | (o.direct_hit ? ETX_VCM_DIRECT_HIT : 0u) | (o.connect_to_light ? ETX_VCM_CONNECT_TO_LIGHT : 0u) |
                (o.connect_vertices ? ETX_VCM_CONNECT_VERTICES : 0u) | (o.mis ? ETX_VCM_ENABLE_MIS : 0u) | (o.reference_seeding ? kOptionReferenceSeeding : 0u);
@@ -1190,7 +1172,6 @@ int init_lane(etx_hip_context* lane, int device, std::string& error) {
   lane->scheduled_passes = etxh::tuning_knob("ETX_HIP_SCHEDULED_PASSES", 1u) != 0u;
   lane->timer_mask = etxh::tuning_knob("ETX_HIP_TIMERS", lane->timer_mask);
   lane->debug_flags = etxh::tuning_knob("ETX_HIP_DEBUG_FLAGS", 0u);
-  lane->fuse_trace_wanted = etxh::tuning_knob("ETX_HIP_FUSE_TRACE", kFuseTraceDefault);
   lane->worker = std::thread(lane_worker, lane);
   return ETX_HIP_OK;
 }
@@ -2610,7 +2591,8 @@ void etx_hip_internal_reduce_release(etx_hip_context* c) {
   if (r.stream)
     (void)hipStreamDestroy(r.stream);
   r.stream = nullptr, r.d_counters = nullptr, r.h_counters = nullptr;
-  r.pending = r.valid = r.snapshot_recorded = false;
+  r.pending = 0u;
+  r.valid = r.snapshot_recorded = false;
 }
 
 // etx_hip_begin: the reduced copy belongs to the run that produced it. A reduce still in flight is waited for (every rank begins the same
@@ -2621,7 +2603,7 @@ int etx_hip_internal_reduce_reset(etx_hip_context* c) {
     return ETX_HIP_OK;
   HIP_OK(c, hipSetDevice(c->device));
   HIP_OK(c, hipStreamSynchronize(r.stream));
-  r.pending = false, r.valid = false;
+  r.pending = 0u, r.valid = false;
   r.pending_local_rc = 0, r.pending_local_error.clear();
   {
     std::lock_guard<std::mutex> lock(r.mutex);
@@ -2668,8 +2650,6 @@ int etx_hip_internal_reduce_prepare(etx_hip_context* c, int local_rc, float4** o
     if ((local_rc == 0) && (c->sticky_error != 0))
       local_rc = c->sticky_error;  // an iteration in flight has failed since the last call
   }
-  r.h_counters[0] = counted;
-  r.h_counters[1] = local_rc ? 1ull : 0ull;
   {
     std::lock_guard<std::mutex> lock(r.mutex);
     if (c->commit_recorded)
@@ -2685,7 +2665,7 @@ int etx_hip_internal_reduce_prepare(etx_hip_context* c, int local_rc, float4** o
     HIP_OK(c, hipEventRecord(r.snapshot_done, r.stream));
     r.snapshot_recorded = true;
   }
-  HIP_OK(c, hipMemcpyAsync(r.d_counters, r.h_counters, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, r.stream));
+  launch_set_words(r.stream, r.d_counters, counted, local_rc ? 1ull : 0ull);  // by value: several reduces may be in flight
   r.layer_mask = layer_mask;
   r.payload_bytes = uint64_t(__builtin_popcount(layer_mask)) * n * sizeof(float4);
   *out_snapshot = r.snapshot, *out_reduced = r.reduced, *out_pixels = n, *out_layer_mask = layer_mask;

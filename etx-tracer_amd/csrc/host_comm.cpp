@@ -37,11 +37,6 @@ int reduce_begin(etx_hip_context* context, int local_rc, const std::string& loca
   EtxReduceState* r = etx_hip_internal_reduce(context);
   if (comm == nullptr)
     return local_rc;  // single rank: the film IS the job's film, nothing to exchange
-  if (r->pending) {  // one reduce in flight: the previous one is finished first (its buffers are this one's)
-    const int rc = etx_hip_reduce_film_end(context, 1);
-    if (rc < 0)
-      return rc;
-  }
   float4 *snapshot = nullptr, *reduced = nullptr;
   size_t pixels = 0;
   uint32_t layer_mask = 0;
@@ -71,9 +66,11 @@ int reduce_begin(etx_hip_context* context, int local_rc, const std::string& loca
   }
   if (int rc = etx_hip_internal_reduce_finish(context))
     return rc;
-  r->pending = true;
-  r->pending_local_rc = local_rc;
-  r->pending_local_error = local_error;
+  r->pending += 1u;
+  if (local_rc && (r->pending_local_rc == 0)) {
+    r->pending_local_rc = local_rc;
+    r->pending_local_error = local_error;
+  }
   return ETX_HIP_OK;
 }
 
@@ -146,7 +143,7 @@ int etx_hip_reduce_film_end(etx_hip_context* context, int wait) {
   if (context == nullptr)
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   EtxReduceState* r = etx_hip_internal_reduce(context);
-  if (r->pending == false)
+  if (r->pending == 0u)
     return 1;  // nothing in flight (also: no communicator)
   if (hipSetDevice(etx_hip_internal_device(context)) != hipSuccess) {
     etx_hip_internal_set_error(context, "hipSetDevice failed");
@@ -166,18 +163,22 @@ int etx_hip_reduce_film_end(etx_hip_context* context, int wait) {
       return ETX_HIP_ERROR_HIP;
     }
   }
-  r->pending = false;
+  // `done` is the NEWEST reduce's: behind it on the communication stream every earlier one has finished too
+  const uint32_t finished = r->pending;
+  r->pending = 0u;
   r->valid = true;
   float ms = 0.0f;
-  if (hipEventElapsedTime(&ms, r->time_begin, r->time_end) == hipSuccess) {
+  if (hipEventElapsedTime(&ms, r->time_begin, r->time_end) == hipSuccess) {  // of the newest one (the events are re-recorded by every reduce)
     r->last_device_ms = double(ms);
-    r->total_device_ms += double(ms);
+    r->total_device_ms += double(ms) * double(finished);
   }
-  r->reduces += 1;
+  r->reduces += finished;
   *etx_hip_internal_global_iterations(context) = r->h_counters[2];
   if (r->pending_local_rc) {
+    const int rc = r->pending_local_rc;
     etx_hip_internal_set_error(context, r->pending_local_error);
-    return r->pending_local_rc;
+    r->pending_local_rc = 0, r->pending_local_error.clear();
+    return rc;
   }
   if (r->h_counters[3] != 0ull) {
     etx_hip_internal_set_error(context, std::to_string(r->h_counters[3]) + " rank(s) reported a failed iteration before the film reduce (their films are incomplete)");
@@ -214,7 +215,7 @@ int etx_hip_reduce_info(etx_hip_context* context, etx_hip_reduce_info_t* out_inf
   info.global_iterations = *etx_hip_internal_global_iterations(context);
   info.last_device_ms = r->last_device_ms;
   info.total_device_ms = r->total_device_ms;
-  info.pending = r->pending ? 1u : 0u;
+  info.pending = r->pending;
   info.layer_mask = r->layer_mask;
   *out_info = info;
   return ETX_HIP_OK;

@@ -4,7 +4,9 @@
 // (or every k rounds for display)". The reference consumes its film progressively - Film::commit_light_iteration once per iteration
 // (sources/etx/render/host/film.cxx:332-343), the GUI pump reads it every frame (sources/raytracer/app.cxx:150-155) - so the reduce must not end
 // the render. Shape:
-//   * a communication stream of its own; the lanes keep rendering while a reduce runs
+//   * a communication stream of its own; the lanes keep rendering while a reduce runs, and etx_hip_reduce_film_begin never waits - not for the lanes and not
+//     for an earlier reduce (the first version finished the previous reduce before it began the next: a snapshot waits for the commits of the iterations in
+//     flight, ~one iteration's latency, so a reduce per iteration stalled the thread that hands out iterations - 93.8 instead of 100.8 Msamples/s on one GPU)
 //   * SNAPSHOT: one kernel copies the layers the armed integrator writes (VCM camera + light, 2 x 16 B per pixel = 66 MB at 1080p; path tracer
 //     camera + normal + albedo; bidirectional all four) from the film sums into `snapshot`. Commits and snapshots exclude each other through
 //     events (a lane's commit kernel waits for the newest snapshot, a snapshot waits for every lane's newest commit; both are enqueued under
@@ -32,9 +34,11 @@ struct EtxReduceState {
   float4* snapshot = nullptr;          // kFilmLayers x pixels: send buffer
   float4* reduced = nullptr;           // kFilmLayers x pixels: whole-job sums as of the newest reduce
   size_t pixels = 0;
-  unsigned long long* d_counters = nullptr;  // device: [0..1] send {iterations counted by this rank, 1 if this rank failed}, [2..3] receive
-  unsigned long long* h_counters = nullptr;  // pinned: [0..1] staging of the send words, [2..3] the received sums
-  bool pending = false;                // etx_hip_reduce_film_begin without its _end
+  unsigned long long* d_counters = nullptr;  // device: [0..1] send {iterations counted by this rank, 1 if this rank failed} (written by a kernel: no host staging a later
+                                             // reduce could overwrite), [2..3] receive
+  unsigned long long* h_counters = nullptr;  // pinned: [2..3] the received sums of the newest reduce
+  uint32_t pending = 0;                // reduces enqueued and not yet collected by etx_hip_reduce_film_end. Any number may be in flight: the communication stream
+                                       // orders them (snapshot N+1 overwrites the send buffer behind all-reduce N), _begin never waits
   bool valid = false;                  // `reduced` holds a finished reduce of the current run (etx_hip_begin invalidates)
   int pending_local_rc = 0;            // this rank's own failure at the time of _begin: reported by _end, after the collective
   std::string pending_local_error;

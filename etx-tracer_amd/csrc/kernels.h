@@ -33,7 +33,6 @@ struct ShadeGroups {
 constexpr uint32_t kRoundMirrorSlots = 1024;  // ring of (round tag, active count) entries the trace kernel writes to pinned host memory
 void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat,
   uint32_t cross_mode);  // pass_stat: kStatRaysLight / kStatRaysCamera / 0; cross_mode: 0 / 1 (VCM state) / 2 (bidirectional state): medium boundaries crossed inside the kernel (kernels_trace.hip kCross)
-void launch_round_housekeeping(hipStream_t stream, const Pipeline& p, uint32_t active_counter, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat);  // fused rounds (Pipeline::fuse_trace)
 void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_items, bool flat);
 void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t count, bool flat, uint32_t debug_flags);
 
@@ -77,6 +76,7 @@ void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bo
 
 // film
 void launch_vcm_commit(hipStream_t stream, float4* iteration_camera, float4* iteration_light, float4* camera_sum, float4* light_sum, uint32_t pixels, const uint32_t* counters);
+void launch_set_words(hipStream_t stream, unsigned long long* dst, unsigned long long a, unsigned long long b);  // the counter words of a film reduce
 void launch_film_snapshot(hipStream_t stream, const float4* film, float4* snapshot, uint32_t pixels, uint32_t layer_mask, bool drop_counts);  // multi-GPU reduce, host_reduce.h
 void launch_film_resolve(hipStream_t stream, const float4* camera_sum, const float4* light_sum, float4* out, uint32_t pixel_count, float scale, int layer, const float4* counts = nullptr);
 

@@ -71,55 +71,6 @@ __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmPara
     for (uint32_t w = 0; w < kBlockSize / 64u; ++w)
       base += (w < wave) ? s_wave_total[w] : 0u;
     __syncthreads();
-    // Pair order. INDEX-MAJOR within a wavefront (default): first the pairs (vertex, light vertex 0) of the wavefront's 64 camera vertices, then
-    // their pairs with light vertex 1, ... The light vertex pool is written bounce by bounce, each bounce in runs of ascending path id (the
-    // shade kernels append a workgroup's survivors in order), and the camera vertices of a bounce are in runs of ascending pixel id: the
-    // light vertices a wavefront of k_connect_pairs gathers for consecutive pairs are then neighbours in ONE bounce region of the pool instead of
-    // one record in each of a path's bounce regions (hundreds of MB apart), and its camera vertex records are 64 consecutive ones instead of a
-    // few read over and over. What it costs: the shadow requests of one pixel are no longer adjacent in the queue, so k_trace_shadow's
-    // run-merge of film adds does not see them (profiles/round5_ab_pair_order.txt has the A/B; debug flag 0x800 = the vertex-major order of
-    // rounds 1-4). Entries beyond the path table (paths longer than path_table_entries vertices) follow vertex-major, behind the wavefront's
-    // index-major part.
-    if ((p.debug_flags & 0x800u) == 0u) {
-      const uint32_t table_entries = p.path_table_entries;
-      const uint32_t k_table = min(k, table_entries), k_tail = k - k_table;
-      // wavefront totals: pairs inside the table, pairs beyond it (exclusive scan of the latter for the vertex-major tail)
-      uint32_t table_total = k_table, tail_incl = k_tail, k_max = k_table;
-#pragma unroll
-      for (uint32_t d = 1; d < 64; d <<= 1) {
-        table_total += __shfl_xor(table_total, d);
-        k_max = max(k_max, uint32_t(__shfl_xor(k_max, d)));
-        const uint32_t t = __shfl_up(tail_incl, d);
-        if (lane >= d)
-          tail_incl += t;
-      }
-      const uint32_t wave_base = __shfl(base, 0);  // lane 0's exclusive prefix = the wavefront's first pair
-      const uint32_t wave_total = table_total + __shfl(tail_incl, 63);
-      if (wave_base + wave_total > p.pair_capacity) {  // whole wavefronts are written or not at all (pair_list_count evaluates nothing of a bounce that overflowed)
-        if (k)
-          atomicOr(p.counters + kCntOverflow, kOverflowPairs);
-        continue;
-      }
-      const uint32_t* table = reinterpret_cast<const uint32_t*>(p.light_path_table + size_t(path) * (table_entries >> 2u));
-      const unsigned long long below = (lane == 0u) ? 0ull : (~0ull >> (64u - lane));
-      uint32_t running = wave_base;
-      for (uint32_t j = 0; j < k_max; ++j) {  // wave-uniform
-        const bool has = j < k_table;
-        const unsigned long long mask = __ballot(has);
-        if (has)
-          p.pairs[running + uint32_t(__popcll(mask & below))] = make_uint2(i, table[j]);
-        running += uint32_t(__popcll(mask));
-      }
-      if (k_tail != 0u) {
-        const uint32_t tail_base = running + tail_incl - k_tail;
-        uint32_t vi = head;
-        for (uint32_t j = k; j > table_entries; --j) {
-          p.pairs[tail_base + j - 1u - table_entries] = make_uint2(i, vi);
-          vi = p.lv.next(vi);
-        }
-      }
-      continue;
-    }
     if (base + k > p.pair_capacity) {
       if (k)
         atomicOr(p.counters + kCntOverflow, kOverflowPairs);

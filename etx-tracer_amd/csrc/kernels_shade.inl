@@ -46,9 +46,7 @@ ETX_DEV bool bin_foreign_groups(const Pipeline& p, const Slots& slots, uint32_t 
 }
 
 // vcm_light_step, vcm_shared.hxx:1090-1260 (everything after rt.trace)
-// kFuse (simple group, flat scenes without other groups; dev_vcm_steps.h fused_flat_closest): the kernel also answers the closest-hit query of
-// every path it appends, so the next round needs no traversal launch (the host enqueues k_round_housekeeping in its place).
-template <uint32_t kGroup, bool kBin, bool kFuse = false>
+template <uint32_t kGroup, bool kBin>
 __global__ __launch_bounds__(kBlockSize) void k_light_shade(Pipeline p, VcmParams it, uint32_t in_set) {
   constexpr bool kWalk = kGroup == kShadeGroupSubsurface;
   const DScene& scene = p.scene;
@@ -61,22 +59,19 @@ __global__ __launch_bounds__(kBlockSize) void k_light_shade(Pipeline p, VcmParam
   __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];  // inline traversal of the subsurface walk
   const LaneStack stack = lane_stack(scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
   const BlockSlots slots = {&s_scratch, &s_scratch3};
-  const float4* hits_in = hits_of(p, in_set);
-  unsigned long long crossed_queries = 0ull;
-  const FusedTrace fused = {hits_of(p, in_set ^ 1u), &crossed_queries};
   ETX_BLOCK_LOOP(count, j) {
     bool valid = j < count;
     const uint32_t i = (kGroup == kShadeGroupSimple) ? j : (valid ? p.group_list[kGroup == kShadeGroupSimple ? 0u : kGroup - 1u][j] : 0u);
     PathState st;
     float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
     if (valid)
-      h = hits_in[i];
+      h = p.hits[i];
     if (kBin)
       valid = bin_foreign_groups(p, slots, i, hit_shade_group(scene, h), valid);
     if (valid)
       st = load_path(in, i);
     if (kGroup == kShadeGroupSimple) {  // the step reserves the path's slot together with its vertex and shadow-request slots and stores the path
-      (void)light_step<kGroup, BlockSlots, kFuse>(p, scene, it, st, h, valid, slots, stack, &out, out_counter, &fused);
+      (void)light_step<kGroup>(p, scene, it, st, h, valid, slots, stack, &out, out_counter);
     } else {
       const bool alive = light_step<kGroup>(p, scene, it, st, h, valid, slots, stack);
       const uint32_t slot = slots.get(alive, out_counter);
@@ -84,15 +79,11 @@ __global__ __launch_bounds__(kBlockSize) void k_light_shade(Pipeline p, VcmParam
         store_path(out, slot, st);
     }
   }
-  if (kFuse) {  // the queries beyond crossed boundaries are rays too (one statistics row per workgroup, as in k_trace_closest)
-    __shared__ unsigned long long s_stat;
-    block_stat_add(p, kBlockStatCrossings, crossed_queries, &s_stat);
-  }
 }
 
 // vcm_camera_step, vcm_shared.hxx:927-1079, without the vertex connections and the merge: connectible vertices are
 // written to the camera vertex pool and consumed by k_connect / k_merge of the same bounce.
-template <uint32_t kGroup, bool kBin, bool kFuse = false>
+template <uint32_t kGroup, bool kBin>
 __global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmParams it, uint32_t in_set) {
   constexpr bool kWalk = kGroup == kShadeGroupSubsurface;
   const DScene& scene = p.scene;
@@ -105,32 +96,25 @@ __global__ __launch_bounds__(kBlockSize) void k_camera_shade(Pipeline p, VcmPara
   __shared__ int32_t s_stack[kWalk ? kStackDepth * kBlockSize : 1];
   const LaneStack stack = lane_stack(scene, s_stack + (kWalk ? threadIdx.x : 0u), kBlockSize);
   const BlockSlots slots = {&s_scratch, &s_scratch3};
-  const float4* hits_in = hits_of(p, in_set);
-  unsigned long long crossed_queries = 0ull;
-  const FusedTrace fused = {hits_of(p, in_set ^ 1u), &crossed_queries};
   ETX_BLOCK_LOOP(count, j) {
     bool valid = j < count;
     const uint32_t i = (kGroup == kShadeGroupSimple) ? j : (valid ? p.group_list[kGroup == kShadeGroupSimple ? 0u : kGroup - 1u][j] : 0u);
     PathState st;
     float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
     if (valid)
-      h = hits_in[i];
+      h = p.hits[i];
     if (kBin)
       valid = bin_foreign_groups(p, slots, i, hit_shade_group(scene, h), valid);
     if (valid)
       st = load_path(in, i);
     if (kGroup == kShadeGroupSimple) {
-      (void)camera_step<kGroup, BlockSlots, kFuse>(p, scene, it, st, h, valid, slots, stack, &out, out_counter, &fused);
+      (void)camera_step<kGroup>(p, scene, it, st, h, valid, slots, stack, &out, out_counter);
     } else {
       const bool alive = camera_step<kGroup>(p, scene, it, st, h, valid, slots, stack);
       const uint32_t slot = slots.get(alive, out_counter);
       if (alive)
         store_path(out, slot, st);
     }
-  }
-  if (kFuse) {  // the queries beyond crossed boundaries are rays too (one statistics row per workgroup, as in k_trace_closest)
-    __shared__ unsigned long long s_stat;
-    block_stat_add(p, kBlockStatCrossings, crossed_queries, &s_stat);
   }
 }
 

@@ -146,6 +146,8 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
 // no atomics); a lane executes one traversal step (inner node or leaf) per loop iteration.
 // LDS per workgroup: the per-lane stacks (32 KB) + the first kLdsNodesPersistent nodes of the tree (top levels, 8 KB).
 constexpr uint32_t kRefillLanes = 16;
+constexpr uint32_t kBvhVariantPhased = 3u;   // ETX_HIP_BVH_VARIANT (debug builds): 0 the interleaved kernel, 1 / 2 staging and stack experiments, 3 the phased kernel
+constexpr uint32_t kBvhVariantDefault = 0u;
 #if !defined(ETX_WIDE_LDS_NODES)
 #define ETX_WIDE_LDS_NODES 64u  // staged nodes of the eight-wide kernel: the root and its children (8 KB; with the 16 KB short stack six workgroups per CU)
 #endif
@@ -303,6 +305,152 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene s
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same persistent traversal with PHASES (round 5). Counters of the kernel above alone on the gems scene (profiles/round5_pmc_trace_alone_*.txt):
+// its VALU pipes issue 65 % of the time, but a VALU instruction has 36 % of its lanes active - every loop trip runs the node step for the lanes
+// that stand on an inner node AND the leaf step for the lanes that stand on a leaf, each lane idle through the other's code. Here a wavefront
+// alternates between two phases: NODE steps while at least kNodePhaseLanes lanes stand on inner nodes - a lane that reaches a leaf keeps it
+// (one postponed leaf per lane, Aila & Laine's speculative traversal: it pops on and keeps walking, testing boxes against a `best.t` that does
+// not know the postponed leaf yet - a few extra node visits, never a wrong answer) - and LEAF steps, in which every lane that holds a leaf tests
+// one triangle per trip. Refill as above. Four-wide tree only.
+constexpr uint32_t kNodePhaseLanes = 24u;
+
+template <bool kFromCounter, uint32_t kStack, uint32_t kLdsNodesPersistent, bool kDeep = false>
+__global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh_phased(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
+  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit,
+  uint32_t refill_lanes, uint32_t pass_stat) {
+  __shared__ int32_t s_stack[kStack * kBlockSize];
+  __shared__ float4 s_nodes[kLdsNodesPersistent * 8u];
+  const DScene& scene = scene_arg;
+  const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
+  if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
+    round_housekeeping(counters, active_counter, count, pass_stat, round_mirror, round_tag);
+  }
+  if (count == 0u)
+    return;
+  const BvhNodes nodes = stage_nodes(scene, s_nodes, min(kLdsNodesPersistent, lds_node_limit));
+  const typename TraversalStack<kDeep, kDeep ? kStack : kStackDepth>::Type stack = TraversalStack<kDeep, kDeep ? kStack : kStackDepth>::make(scene, s_stack + threadIdx.x, kBlockSize);
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6u;
+  const uint32_t wave_count = (gridDim.x * blockDim.x) >> 6u;
+  const uint32_t chunk = ((count + wave_count - 1u) / wave_count + 63u) & ~63u;  // rays per wavefront, whole 64-ray rows
+  uint32_t cursor = min(count, wave * chunk);                                    // wave-uniform
+  const uint32_t chunk_end = min(count, cursor + chunk);
+  const int32_t kDone = kBvhEmptyChild;
+  const BvhTri* __restrict__ tris = scene.bvh_tris;
+
+  uint32_t ray_index = kInvalid;
+  RayQ ray = {};
+  f3 inv_d = {};
+  Hit best = {};
+  uint32_t alpha_seed = 0u, sp = 0u;
+  int32_t cur = kDone;        // where the lane stands: an inner node (>= 0), a leaf it could not postpone (< 0), or nothing (kDone)
+  uint32_t leaf_at = 0u, leaf_end = 0u;  // the postponed leaf: triangles [leaf_at, leaf_end) still to test
+  bool busy = false;          // the lane holds a ray
+  for (;;) {
+    // ---- refill
+    const unsigned long long idle_mask = __ballot(busy == false);
+    const uint32_t idle_count = uint32_t(__popcll(idle_mask));
+    if ((idle_count >= refill_lanes) || (idle_count == 64u)) {
+      if (cursor < chunk_end) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32u), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
+        const uint32_t take = min(idle_count, chunk_end - cursor);
+        if ((busy == false) && (rank < take)) {
+          ray_index = cursor + rank;
+          const float4 a = ray_o_tmin[ray_index];
+          const float4 b = ray_d_tmax[ray_index];
+          alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ (__float_as_uint(a.z) * 0x85ebca6bu) ^ (__float_as_uint(b.x) * 0xc2b2ae35u);
+          ray = {{a.x, a.y, a.z}, a.w, {b.x, b.y, b.z}, b.w};
+          inv_d = {__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)};
+          best = {0.0f, 0.0f, ray.tmax, kInvalid};
+          sp = 0u;
+          cur = scene.bvh_root;
+          leaf_at = leaf_end = 0u;
+          busy = true;
+        }
+        cursor += take;
+      } else if (idle_count == 64u) {
+        break;
+      }
+    }
+    // ---- node phase
+    for (;;) {
+      const bool inner = (cur >= 0) && (cur != kDone);
+      const uint32_t inner_count = uint32_t(__popcll(__ballot(inner)));
+      if (inner_count == 0u)
+        break;
+      if ((inner_count < kNodePhaseLanes) && (__ballot(leaf_at < leaf_end) != 0ull))
+        break;  // few lanes still walk while others hold leaves: test those first (the walkers resume in the next node phase)
+      if (inner) {
+        float4 lox, loy, loz, hix, hiy, hiz, cc;
+        if (uint32_t(cur) < nodes.lds_count) {
+          const float4* n = nodes.lds + uint32_t(cur) * 8u;
+          lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5], cc = n[6];
+        } else {
+          const float4* n = nodes.global + uint32_t(cur) * 8u;
+          lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5], cc = n[6];
+        }
+        float t0 = slab(f3{lox.x, loy.x, loz.x}, f3{hix.x, hiy.x, hiz.x}, ray.o, inv_d, ray.tmin, best.t);
+        float t1 = slab(f3{lox.y, loy.y, loz.y}, f3{hix.y, hiy.y, hiz.y}, ray.o, inv_d, ray.tmin, best.t);
+        float t2 = slab(f3{lox.z, loy.z, loz.z}, f3{hix.z, hiy.z, hiz.z}, ray.o, inv_d, ray.tmin, best.t);
+        float t3 = slab(f3{lox.w, loy.w, loz.w}, f3{hix.w, hiy.w, hiz.w}, ray.o, inv_d, ray.tmin, best.t);
+        int32_t c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
+        t0 = (c0 == kBvhEmptyChild) ? kMaxFloat : t0;
+        t1 = (c1 == kBvhEmptyChild) ? kMaxFloat : t1;
+        t2 = (c2 == kBvhEmptyChild) ? kMaxFloat : t2;
+        t3 = (c3 == kBvhEmptyChild) ? kMaxFloat : t3;
+        sort_pair(t0, c0, t1, c1);
+        sort_pair(t2, c2, t3, c3);
+        sort_pair(t0, c0, t2, c2);
+        sort_pair(t1, c1, t3, c3);
+        sort_pair(t1, c1, t2, c2);
+        if (t0 == kMaxFloat) {
+          cur = sp ? stack.pop(sp) : kDone;
+        } else {
+          if (t3 < kMaxFloat)
+            stack.push(sp, c3);
+          if (t2 < kMaxFloat)
+            stack.push(sp, c2);
+          if (t1 < kMaxFloat)
+            stack.push(sp, c1);
+          cur = c0;
+        }
+        // a leaf: postpone it (if the lane holds none) and keep walking
+        if ((cur < 0) && (leaf_at >= leaf_end)) {
+          const uint32_t leaf = uint32_t(~cur);
+          leaf_at = leaf >> 3, leaf_end = leaf_at + (leaf & 7u) + 1u;
+          cur = sp ? stack.pop(sp) : kDone;
+        }
+      }
+    }
+    // ---- leaf phase: one triangle per trip for every lane that holds a leaf
+    while (__ballot(leaf_at < leaf_end) != 0ull) {
+      if (leaf_at < leaf_end) {
+        const uint32_t i = leaf_at++;
+        const float4 v0 = tris[i].v0_index;
+        const float4 e1 = tris[i].e1_flags;
+        const float4 e2 = tris[i].e2_mat;
+        float u, v, t;
+        if (triangle_test(v0, e1, e2, ray, best.t, u, v, t)) {
+          const uint32_t flags = __float_as_uint(e1.w);
+          const uint32_t tri_index = __float_as_uint(v0.w);
+          if (((flags & kTriVoid) == 0u) && (((flags & kTriAlphaTested) == 0u) || (alpha_test_skips(scene, tri_index, __float_as_uint(e2.w), u, v, alpha_seed) == false)))
+            best = {u, v, t, tri_index};
+        }
+      }
+    }
+    // a lane that stands on a second leaf (it held one when it got there) takes it now and pops on
+    if (busy && (cur < 0)) {
+      const uint32_t leaf = uint32_t(~cur);
+      leaf_at = leaf >> 3, leaf_end = leaf_at + (leaf & 7u) + 1u;
+      cur = sp ? stack.pop(sp) : kDone;
+    }
+    if (busy && (cur == kDone) && (leaf_at >= leaf_end)) {
+      hits[ray_index] = make_float4(best.u, best.v, best.t, __uint_as_float(best.tri));
+      busy = false;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Flat sweep, two rays per lane on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32). The one-ray sweep is VALU bound (about 30
 // VALU per primitive and ray); here a lane carries rays i and i + 64 of a 128-ray chunk in the two halves of 64-bit
 // register pairs, the primitive rows stay wave-uniform in SGPRs and are broadcast to both halves, so the affine part of
@@ -444,7 +592,7 @@ template <bool kFromCounter>
 static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t* counters, uint32_t active_counter,
   uint32_t items, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat) {
   static const uint32_t refill = etxh::tuning_knob("ETX_HIP_REFILL_LANES", kRefillLanes);
-  static const uint32_t variant = etxh::tuning_knob("ETX_HIP_BVH_VARIANT", 0u);
+  static const uint32_t variant = etxh::tuning_knob("ETX_HIP_BVH_VARIANT", kBvhVariantDefault);
   const dim3 grid(bvh_blocks(items)), block(kBlockSize);
   const uint32_t fixed_count = kFromCounter ? 0u : items;
 #define ETX_LAUNCH_BVH(STACK, NODES)                                                                                                                                              \
@@ -456,6 +604,21 @@ static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const flo
       round_mirror, round_tag, lds_limit(), refill, pass_stat);
     return;
   }
+#define ETX_LAUNCH_BVH_PHASED(STACK, NODES, DEEP)                                                                                                                                   \
+  hipLaunchKernelGGL((k_trace_closest_bvh_phased<kFromCounter, STACK, NODES, DEEP>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count, \
+    round_mirror, round_tag, lds_limit(), refill, pass_stat)
+  if (variant == kBvhVariantPhased) {  // the phased kernel (node phase / leaf phase, one postponed leaf per lane)
+    if (need > kStackDepth)
+      ETX_LAUNCH_BVH_PHASED(kShortStackDepth, 64u, true);
+    else if (need <= 16u)
+      ETX_LAUNCH_BVH_PHASED(16u, 64u, false);
+    else if (need <= 24u)
+      ETX_LAUNCH_BVH_PHASED(24u, 64u, false);
+    else
+      ETX_LAUNCH_BVH_PHASED(kStackDepth, 64u, false);
+    return;
+  }
+#undef ETX_LAUNCH_BVH_PHASED
   if (((variant == 2u) && (need > kShortStackDepth)) || (need > kStackDepth)) {
     // a deep tree (> ~40 000 triangles): the checked stack, 16 entries in LDS (24 KB per workgroup with the staged nodes), the rest in the global
     // spill rows (dev_bvh.h ShortLaneStack). A million triangles: 13.1 vs 12.8 Msamples/s with 32 entries in LDS; trees whose bound fits 32
@@ -479,33 +642,21 @@ static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const flo
 #undef ETX_LAUNCH_BVH
 }
 
-// A fused round (Pipeline::fuse_trace, kernels_shade.inl kFuse): the shade kernel of the previous round has answered this round's closest-hit
-// queries, what is left of the traversal launch is its housekeeping - queue counters, statistics, the host's round mirror.
-__global__ void k_round_housekeeping(uint32_t* __restrict__ counters, uint32_t active_counter, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat) {
-  if ((blockIdx.x == 0) && (threadIdx.x == 0))
-    round_housekeeping(counters, active_counter, counters[active_counter], pass_stat, round_mirror, round_tag);
-}
-
-void launch_round_housekeeping(hipStream_t stream, const Pipeline& p, uint32_t active_counter, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat) {
-  hipLaunchKernelGGL(k_round_housekeeping, dim3(1), dim3(64), 0, stream, p.counters, active_counter, round_mirror, round_tag, pass_stat);
-}
-
 void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, uint32_t active_counter, uint32_t max_items, bool flat, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat,
   uint32_t cross_mode) {
-  float4* const hits = ((p.fuse_trace != 0u) && (set == 1u)) ? p.hits_alt : p.hits;  // dev_vcm_steps.h hits_of
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.capacity, max_items) + kBlockSize - 1) / kBlockSize));
   // opt-in (ETX_HIP_DEBUG_FLAGS bit 64): alone on the device the two-ray sweep is 10 % faster (39.3 vs 35.7 Grays/s on 2 M incoherent
   // rays), inside the 4-lane pipeline its fatter waves lose against the co-running kernels (51.5 vs 46.6 us per launch) - DESIGN.md 3
   if (flat && (p.debug_flags & 64u))
-    hipLaunchKernelGGL((k_trace_closest_flat2<true>), dim3(flat2_blocks(min(p.capacity, max_items))), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, hits,
+    hipLaunchKernelGGL((k_trace_closest_flat2<true>), dim3(flat2_blocks(min(p.capacity, max_items))), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits,
       p.counters, active_counter, 0u, round_mirror, round_tag, pass_stat);
   else if (flat && (cross_mode != kCrossNone) && (p.scene.boundary_materials != 0u))
-    hipLaunchKernelGGL((k_trace_closest<true, true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, hits, p.counters, active_counter, 0u, round_mirror, round_tag,
+    hipLaunchKernelGGL((k_trace_closest<true, true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag,
       lds_limit(), pass_stat, p.paths[set], cross_mode, p.block_stats);
   else if (flat)
-    hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, hits, p.counters, active_counter, 0u, round_mirror, round_tag, lds_limit(), pass_stat);
+    hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror, round_tag, lds_limit(), pass_stat);
   else
-    launch_bvh_kernel<true>(stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, hits, p.counters, active_counter, min(p.capacity, max_items), round_mirror, round_tag, pass_stat);
+    launch_bvh_kernel<true>(stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, min(p.capacity, max_items), round_mirror, round_tag, pass_stat);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

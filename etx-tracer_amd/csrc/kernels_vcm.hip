@@ -131,11 +131,6 @@ void launch_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& 
   const void* simple_kernel = groups.binned() ? reinterpret_cast<const void*>(&k_light_shade<kShadeGroupSimple, true>) : reinterpret_cast<const void*>(&k_light_shade<kShadeGroupSimple, false>);
   const dim3 simple_grid(persistent_grid(grid.x, simple_kernel, percent));
   if (groups.binned() == false) {
-    if (p.fuse_trace != 0u) {  // flat scene: the kernel also sweeps for the next segment of every path it appends (kernels_shade.inl kFuse)
-      const dim3 fused_grid(persistent_grid(grid.x, reinterpret_cast<const void*>(&k_light_shade<kShadeGroupSimple, false, true>), percent));
-      hipLaunchKernelGGL((k_light_shade<kShadeGroupSimple, false, true>), fused_grid, dim3(kBlockSize), 0, stream, p, it, in_set);
-      return;
-    }
     hipLaunchKernelGGL((k_light_shade<kShadeGroupSimple, false>), simple_grid, dim3(kBlockSize), 0, stream, p, it, in_set);
     return;
   }
@@ -204,11 +199,6 @@ void launch_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams&
   const void* simple_kernel = groups.binned() ? reinterpret_cast<const void*>(&k_camera_shade<kShadeGroupSimple, true>) : reinterpret_cast<const void*>(&k_camera_shade<kShadeGroupSimple, false>);
   const dim3 simple_grid(persistent_grid(grid.x, simple_kernel, percent));
   if (groups.binned() == false) {
-    if (p.fuse_trace != 0u) {
-      const dim3 fused_grid(persistent_grid(grid.x, reinterpret_cast<const void*>(&k_camera_shade<kShadeGroupSimple, false, true>), percent));
-      hipLaunchKernelGGL((k_camera_shade<kShadeGroupSimple, false, true>), fused_grid, dim3(kBlockSize), 0, stream, p, it, in_set);
-      return;
-    }
     hipLaunchKernelGGL((k_camera_shade<kShadeGroupSimple, false>), simple_grid, dim3(kBlockSize), 0, stream, p, it, in_set);
     return;
   }
@@ -316,6 +306,15 @@ __global__ __launch_bounds__(kBlockSize) void k_film_snapshot(const float4* __re
       }
     }
   }
+}
+
+__global__ void k_set_words(unsigned long long* dst, unsigned long long a, unsigned long long b) {
+  if ((blockIdx.x == 0) && (threadIdx.x == 0))
+    dst[0] = a, dst[1] = b;
+}
+
+void launch_set_words(hipStream_t stream, unsigned long long* dst, unsigned long long a, unsigned long long b) {
+  hipLaunchKernelGGL(k_set_words, dim3(1), dim3(64), 0, stream, dst, a, b);
 }
 
 void launch_film_snapshot(hipStream_t stream, const float4* film, float4* snapshot, uint32_t pixels, uint32_t layer_mask, bool drop_counts) {

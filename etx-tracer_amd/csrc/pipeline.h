@@ -224,9 +224,6 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   PathSet walk_exit;     // BDPT exit queue: walks whose free flight reached the surface of their object, with that hit
   float4* walk_exit_hits;
   float4* hits;          // hit queue, aligned with the "in" path set
-  float4* hits_alt;      // fused rounds (fuse_trace): the hit queue of path set 1 - a shade kernel that sweeps for the NEXT segment writes the hits of the set it
-                         // appends to while other workgroups still read the hits of the set it consumes (null unless the scene is flat)
-  uint32_t fuse_trace;   // VCM on flat scenes of the simple shading group: the shade kernels run the next segment's closest-hit sweep themselves (kernels_shade.inl)
   LightVertexPool lv;
   uint32_t* light_path_head;   // per path: last stored vertex (kInvalid = none)
   uint32_t* light_path_len;    // per path: stored vertices so far (k_expand_pairs sizes a camera vertex' pair run with it: no dependent read of the head record)

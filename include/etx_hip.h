@@ -308,10 +308,11 @@ int etx_hip_comm_init(etx_hip_context* context, int rank, int world_size, const 
  *   etx_hip_reduce_film_begin  enqueues, on a communication stream of the context's own: (1) a SNAPSHOT of the film sums behind every commit the
  *       lanes have enqueued so far - commits and snapshots exclude each other on the device, so a snapshot holds whole iterations; the lanes keep
  *       rendering and no host thread waits; (2) ncclAllReduce(sum) OUT OF PLACE from the snapshot into the context's reduced copy, and of the
- *       counter words {iterations, failed flag}. Returns at once. One reduce is in flight per context: a _begin while the previous one is still
- *       running finishes that one first (blocking). Without a communicator (single GPU): nothing to do, returns ETX_HIP_OK.
- *   etx_hip_reduce_film_end    wait = 0: 0 while the reduce is running, 1 once the reduced copy is complete (also when none was in flight);
- *       wait = 1: blocks until it is. < 0: error - this rank's own failed iteration, ETX_HIP_ERROR_COMM when another rank reported one (every
+ *       counter words {iterations, failed flag}. Returns at once - it waits neither for the lanes nor for earlier reduces: any number may be in
+ *       flight, the communication stream orders them (a reduce per iteration costs the rendering nothing but the device time of a 66 MB copy and
+ *       the collective). Without a communicator (single GPU): nothing to do, returns ETX_HIP_OK.
+ *   etx_hip_reduce_film_end    collects every reduce begun so far. wait = 0: 0 while the newest is running, 1 once the reduced copy is complete (also when
+ *       none was in flight); wait = 1: blocks until it is. < 0: error - this rank's own failed iteration, ETX_HIP_ERROR_COMM when another rank reported one (every
  *       rank always joins the collective; the error travels with the counters so that nobody waits for the RCCL timeout), or a HIP / RCCL error.
  *   etx_hip_reduce_film        = etx_hip_sync + _begin + _end(wait): every iteration handed over so far, on every rank, is in the reduced copy
  *       when it returns. Rendering may continue afterwards (until ABI 2 the reduce was in place and final).
@@ -332,8 +333,8 @@ typedef struct etx_hip_reduce_info_t {
   uint64_t payload_bytes;      /* film bytes one reduce sums per rank (layers of the armed integrator x pixels x 16) */
   uint64_t global_iterations;  /* iterations of all ranks in the newest finished reduce (host-side count at the time of each rank's _begin) */
   double last_device_ms;       /* device time of the newest finished reduce: snapshot kernel + collectives (HIP events on the communication stream) */
-  double total_device_ms;      /* ... summed over all finished reduces */
-  uint32_t pending;            /* 1: a reduce is in flight */
+  double total_device_ms;      /* ... summed over all finished reduces (reduces collected together are priced at the newest one's time) */
+  uint32_t pending;            /* reduces begun and not yet collected by etx_hip_reduce_film_end */
   uint32_t layer_mask;         /* film layers of the newest reduce (bit 0 camera, 1 light, 2 normal, 3 albedo) */
 } etx_hip_reduce_info_t;
 int etx_hip_reduce_info(etx_hip_context* context, etx_hip_reduce_info_t* out_info, size_t info_size);

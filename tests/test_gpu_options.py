@@ -47,10 +47,19 @@ BDPT_SETS = {
 }
 
 
-def compare_layers(halves, golden, label, light_is_empty=False):
+# Sets whose estimator has a heavy tail on the fog box (env + sun + area emitters): with the MIS weights off every strategy is added unweighted, and
+# without next event estimation the sun's disc is found by BSDF sampling alone - a path that reaches the sun carries ~1e3 times the pixel mean
+# with a probability of ~1e-5 per sample. The MEAN of a 1024-spp film is then a sum over a few hundred such events: the reference's own two
+# flavours differ from each other by 2.6 / 4.4 / 0.6 % (RGB) under vcm-mis=false (tests/test_reference_order_spread.py asserts it from the fixtures),
+# and the halves' difference understates the spread of a Poisson-dominated mean. The block RMSE and bias limits stay north_star's (their noise
+# allowance comes from the halves); the image-mean limit for these sets is what the reference's own flavours need, and more pixels may be specks.
+HEAVY_TAIL = {("full", "nomis"): dict(mean_limit=5.0e-2, speck_limit=0.05), ("full", "nonee"): dict(rmse_limit=2.0e-3, mean_limit=1.0e-2)}
+
+
+def compare_layers(halves, golden, label, light_is_empty=False, **limits):
     (cam_a, light_a), (cam_b, light_b) = halves
-    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], label + " camera+light")
-    compare((cam_a, cam_b), golden["camera"], label + " camera")
+    compare((cam_a + light_a, cam_b + light_b), golden["camera"] + golden["light"], label + " camera+light", **limits)
+    compare((cam_a, cam_b), golden["camera"], label + " camera", **limits)
     if light_is_empty:  # no camera connections: nothing may reach the light image, on either side
         assert float(np.abs(golden["light"]).max()) == 0.0
         assert float(np.abs(light_a[..., :3]).max()) == 0.0 and float(np.abs(light_b[..., :3]).max()) == 0.0, label
@@ -67,16 +76,17 @@ def test_vcm_option_set_matches_reference(etx, golden_dir, flavour, name):
     # the device under the reference's own seeding against the pinned, unmodified reference
     stats = []
     seeded = render_halves(etx, golden_dir, flavour, None, etx.HIPVCM, dict(options, **{"hip-reference_seeding": True}), spp=SPP, want_stats=stats)
-    compare_layers(seeded, pinned, "%s vcm %s (reference seeding, pinned reference)" % (flavour, name), light_is_empty)
+    limits = HEAVY_TAIL.get((flavour, name), {})
+    compare_layers(seeded, pinned, "%s vcm %s (reference seeding, pinned reference)" % (flavour, name), light_is_empty, **limits)
     if name in ("connonly", "nomergev"):  # merging switched off / merge weights without merges: no photon is looked at
         assert all(s.photons_examined == 0 for s in stats)
     if name == "mergeonly":
         assert all((s.pairs == 0) and (s.photons_merged > 0) for s in stats)
-    # the default product configuration (camera stream of its own) against the reference with independent streams; on the classic box the two
-    # flavours of the reference are the same film to within noise (no medium, nothing but opaque triangles: DESIGN.md 4), so the pinned film serves
+    # the default product configuration (camera stream of its own) against the reference with independent streams. (Also on the classic box: the
+    # pinned film - both streams aligned draw for draw - is up to 0.7 % brighter than the independent-streams film there, measured in GPU call r5a.)
     default = render_halves(etx, golden_dir, flavour, None, etx.HIPVCM, options, spp=SPP)
-    golden = load_hi(golden_dir, "cornell_%s_128_vcm_%d_%s_rekeyed.npz" % (flavour, SPP, name), folder="opt", spp=SPP) if flavour == "full" else pinned
-    compare_layers(default, golden, "%s vcm %s (independent streams)" % (flavour, name), light_is_empty)
+    golden = load_hi(golden_dir, "cornell_%s_128_vcm_%d_%s_rekeyed.npz" % (flavour, SPP, name), folder="opt", spp=SPP)
+    compare_layers(default, golden, "%s vcm %s (independent streams)" % (flavour, name), light_is_empty, **limits)
 
 
 @pytest.mark.parametrize("name", sorted(PT_SETS))
@@ -84,7 +94,7 @@ def test_vcm_option_set_matches_reference(etx, golden_dir, flavour, name):
 def test_pt_option_set_matches_reference(etx, golden_dir, flavour, name):
     golden = load_hi(golden_dir, "cornell_%s_128_pt_%d_%s.npz" % (flavour, SPP, name), folder="opt", spp=SPP)
     (cam_a, _), (cam_b, _) = render_halves(etx, golden_dir, flavour, None, etx.HIPPathTracing, dict(PT_SETS[name], bn=False), spp=SPP)
-    compare((cam_a, cam_b), golden["camera"], "%s pt %s camera" % (flavour, name))
+    compare((cam_a, cam_b), golden["camera"], "%s pt %s camera" % (flavour, name), **HEAVY_TAIL.get((flavour, name), {}))
 
 
 @pytest.mark.parametrize("name", sorted(BDPT_SETS))
@@ -96,4 +106,4 @@ def test_bdpt_option_set_matches_reference(etx, golden_dir, flavour, name):
     golden = np.load(os.path.join(golden_dir, "opt", "cornell_%s_128_bdpt3_%d_%s_opaque_none.npz" % (flavour, SPP, name)))
     assert int(golden["spp"]) in (SPP - 1, SPP)  # CPUBidirectional::update does not count its last iteration (bidirectional.cxx:1526-1531)
     halves = test_gpu_bdpt.render_halves(etx, golden_dir, flavour, SPP, options)
-    compare_layers(halves, golden, "%s bdpt %s (reference seeding, pinned reference)" % (flavour, name), light_is_empty=(name == "nodirect"))
+    compare_layers(halves, golden, "%s bdpt %s (reference seeding, pinned reference)" % (flavour, name), light_is_empty=(name == "nodirect"), **HEAVY_TAIL.get((flavour, name), {}))

@@ -647,16 +647,27 @@ def test_pool_overflow_is_reported_and_does_not_skip_the_reduce(etx, golden_dir)
     ETX_HIP_ERROR_OVERFLOW; the film reduce still runs its collective part (single rank: identity) and returns that error instead of hanging its peers."""
     from etx_tracer_amd import api, integrator as integ_mod
     snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_classic_128.etxscene"))
+    options = integ_mod.vcm_options_from_dict({"vcm-blue_noise": False})
     ctx = api.Context(0)
-    ctx.set_pool_policy(1, 1 << 20)
+    # one light vertex per path to start with = 10.3 MB of pools per lane on this 128 x 128 scene (photon grid included); the box needs ~3.5 per path.
+    # 12 MB: the start sizes fit, the first doubling of the light vertex pool (+ 2.9 MB) does not
+    ctx.set_pool_policy(1, 12 << 20)
     ctx.upload_scene(snap)
     ctx.comm_init(0, 1, api.comm_unique_id(ctx.library))
-    ctx.begin_vcm(integ_mod.vcm_options_from_dict({"vcm-blue_noise": False}), first_iteration=0, iteration_stride=1)
+    ctx.begin_vcm(options, first_iteration=0, iteration_stride=1)
     ctx.render_iteration()
     with pytest.raises(api.EtxHipError) as e:
         ctx.reduce_film()
     assert e.value.code == -6 and "overflow" in str(e.value)
     assert ctx.stats().overflow_flags & 1
+    ctx.close()
+    # the byte limit bounds the sizes a run STARTS with as well (ADVICE round 4): below them etx_hip_begin refuses, nothing is rendered
+    ctx = api.Context(0)
+    ctx.set_pool_policy(1, 1 << 20)
+    ctx.upload_scene(snap)
+    with pytest.raises(api.EtxHipError) as e:
+        ctx.begin_vcm(options, first_iteration=0, iteration_stride=1)
+    assert e.value.code == -6 and "exceed" in str(e.value)
     ctx.close()
 
 
