@@ -88,8 +88,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
                              "gems1m = the same with 350 scaled copies of its gems (1 010 892 triangles: mesh size of configs[3-4], tools/synthetic_scenes.py); "
                              "sssdragon_bdpt = configs[3]: two random-walk subsurface blob meshes of 102 400 triangles, BDPTFull, 1920x1080; "
                              "cloud_bdpt = configs[4]: the fog box with a procedural 256^3 heterogeneous density grid, BDPTFull, 2048x2048")
-    parser.add_argument("--bvh", default="host", choices=["host", "device", "wide"],
-                        help="who builds the traversal tree (etx_hip_set_bvh_builder); wide: the host tree plus its eight-wide form with 8-bit boxes (opt-in)")
+    parser.add_argument("--bvh", default="host", choices=["host", "device"], help="who builds the traversal tree (etx_hip_set_bvh_builder)")
     parser.add_argument("--shard", default="iterations", choices=["iterations", "pixels"],
                         help="how N > 1 ranks split the job. iterations (default): rank r renders iterations r, r + N, ... of the full frame - weak scaling, every integrator. "
                              "pixels: every rank renders ALL iterations of pixels r, r + N, ... (etx_hip_begin_ex; bidirectional workloads only) - strong scaling: the job "
@@ -148,7 +147,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
         snap = etx.SceneSnapshot(snapshot_path)
     width, height = snap.film_size
     ctx = (context_factory or api.Context)(local_rank)
-    ctx.set_bvh_builder({"device": api.BVH_DEVICE_LBVH, "wide": api.BVH_HOST_SAH | api.BVH_WIDE}.get(args.bvh, api.BVH_HOST_SAH))
+    ctx.set_bvh_builder(api.BVH_DEVICE_LBVH if args.bvh == "device" else api.BVH_HOST_SAH)
     lanes = ctx.lanes(api.INTEGRATOR_BDPT if bdpt_workload else api.INTEGRATOR_VCM)  # iterations in flight (etx_hip_lanes)
     upload_t0 = time.perf_counter()
     ctx.upload_scene(snap)

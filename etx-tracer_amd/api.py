@@ -21,14 +21,13 @@ VCM_ENABLE_MERGING = 1 << 6
 VCM_FULL_OPTIONS = 0x7F
 CHANGED_CAMERA, CHANGED_MATERIALS, CHANGED_POSITIONS, REBUILD_BVH = 1, 2, 4, 8  # etx_hip_update_scene
 BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1  # etx_hip_set_bvh_builder
-BVH_WIDE = 256  # | BVH_HOST_SAH: also the eight-wide tree with 8-bit child boxes (csrc/dev_bvh8.h; opt-in)
 
 EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene", "etx_hip_update_scene",
     "etx_hip_upload_bluenoise", "etx_hip_upload_cie_table", "etx_hip_upload_rgb_response", "etx_hip_begin", "etx_hip_begin_ex", "etx_hip_render_iteration", "etx_hip_try_render_iteration", "etx_hip_poll", "etx_hip_sync",
     "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_checkpoint_bytes", "etx_hip_checkpoint_save", "etx_hip_checkpoint_load", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_set_debug_flags", "etx_hip_set_pool_policy", "etx_hip_lanes", "etx_hip_device_bytes", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film", "etx_hip_reduce_film_begin", "etx_hip_reduce_film_end", "etx_hip_reduce_info",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
-    "etx_hip_set_bvh_builder", "etx_hip_bvh_info", "etx_hip_selftest_stack", "etx_hip_host_check_bvh_builder", "etx_hip_host_bvh_stats_builder", "etx_hip_host_bvh8_stats",
+    "etx_hip_set_bvh_builder", "etx_hip_bvh_info", "etx_hip_selftest_stack", "etx_hip_host_check_bvh_builder", "etx_hip_host_bvh_stats_builder",
 )
 
 
@@ -225,7 +224,6 @@ class Library:
         L.etx_hip_bvh_info.argtypes = [vp, ctypes.POINTER(u32 * 4), ctypes.POINTER(ctypes.c_double)]
         L.etx_hip_host_check_bvh_builder.argtypes = [vp, i32, ctypes.POINTER(u32 * 4)]
         L.etx_hip_host_bvh_stats_builder.argtypes = [vp, i32, vp, u64, ctypes.POINTER(u64 * 4), vp]
-        L.etx_hip_host_bvh8_stats.argtypes = [vp, i32, vp, u64, ctypes.POINTER(u64 * 8), vp]
 
     @classmethod
     def get(cls):
@@ -456,22 +454,6 @@ def host_bvh_stats(snapshot, rays, library=None, builder=BVH_HOST_SAH, with_hits
     hits = np.zeros((rays.shape[0], 2), dtype=np.float32) if with_hits else None
     rc = library.lib.etx_hip_host_bvh_stats_builder(snapshot.scene_address, int(builder), rays.ctypes.data, rays.shape[0], ctypes.byref(out), hits.ctypes.data if with_hits else None)
     result = {"node_visits": out[0], "triangle_tests": out[1], "hits": out[2], "max_stack": out[3]}
-    if with_hits:
-        triangle = hits[:, 1].view(np.uint32).astype(np.int64)
-        triangle[triangle == 0xFFFFFFFF] = -1
-        result["t"], result["triangle"] = hits[:, 0].copy(), triangle
-    return rc, result
-
-
-def host_bvh8_stats(snapshot, rays, occlusion=False, library=None, with_hits=False):
-    """Host-only: the encoded eight-wide tree (ETX_HIP_BVH_WIDE) walked through the kernels' node function (etx_hip_host_bvh8_stats)."""
-    library = library or Library.get()
-    rays = np.ascontiguousarray(rays, dtype=np.float32)
-    out = (ctypes.c_uint64 * 8)()
-    hits = np.zeros((rays.shape[0], 2), dtype=np.float32) if with_hits else None
-    rc = library.lib.etx_hip_host_bvh8_stats(snapshot.scene_address, int(bool(occlusion)), rays.ctypes.data, rays.shape[0], ctypes.byref(out), hits.ctypes.data if with_hits else None)
-    result = {"node_visits": out[0], "triangle_tests": out[1], "hits": out[2], "max_stack": out[3], "nodes": out[4], "levels": out[5] & 0xffff, "stack_need": out[5] >> 16,
-              "visits_to_final_hit": out[6], "max_visits_of_a_ray": out[7]}
     if with_hits:
         triangle = hits[:, 1].view(np.uint32).astype(np.int64)
         triangle[triangle == 0xFFFFFFFF] = -1

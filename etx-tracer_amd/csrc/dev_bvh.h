@@ -15,7 +15,6 @@ namespace etxd {
 
 constexpr uint32_t kStackDepth = 32;     // stack entries a lane keeps in LDS
 constexpr uint32_t kMaxStackDepth = 64;  // deepest stack a tree may need (host bound over the tree): the entries above kStackDepth spill
-constexpr uint32_t kMaxWideStackDepth = 128;  // the same for the eight-wide tree (dev_bvh8.h: up to seven pushes per level; a million triangles: bound 70, observed 25)
 constexpr uint32_t kFlatSweepMaxTriangles = 64;  // scenes up to this size are swept linearly (all lanes, same triangle)
 
 // The stack of the two traversal kernels when the tree's bound fits the LDS part (trees up to ~40 000 triangles): no checks.
@@ -541,7 +540,7 @@ ETX_DEV bool flat_transmittance(const DScene& scene, Tris tris, const f3& p0, co
 // The same query on a tree scene that holds no Class::Boundary material and no density grid (DScene::boundary_materials,
 // heterogeneous_mediums): the segment is occluded or it is not, and what it crosses is the homogeneous medium it started in -
 // one any-hit traversal and one exp, a third fewer registers than the general function (k_trace_shadow<false, kDeep, true>).
-template <class Nodes, class Tris, class Stack>  // Nodes: BvhNodes, or Bvh8Nodes (dev_bvh8.h: bvh_occluded has an overload for the eight-wide tree)
+template <class Nodes, class Tris, class Stack>
 ETX_DEV f3 bvh_transmittance_opaque(const DScene& scene, const Nodes& nodes, Tris tris, int32_t root, const Stack& stack, const f3& p0, const f3& p1, uint32_t medium_index,
   float wavelength, uint32_t& alpha_seed) {
   f3 direction = p1 - p0;

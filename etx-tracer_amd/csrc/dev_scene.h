@@ -35,18 +35,6 @@ struct __attribute__((aligned(16))) Bvh4Node {
 static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node is two 64-byte lines");
 constexpr int32_t kBvhEmptyChild = 0x7fffffff;
 
-// Eight-wide node with 8-bit child boxes (dev_bvh8.h; opt-in, ETX_HIP_BVH_WIDE): box of child k on axis a =
-// origin[a] + {qlo, qhi}[a][k] * 2^(exponent[a] - 127), rounded outwards by the host. Children as in Bvh4Node; an unused slot holds
-// kBvhEmptyChild and an inverted box (qlo 255, qhi 0). Breadth-first numbering.
-struct __attribute__((aligned(16))) Bvh8Node {
-  float origin[3];
-  uint32_t exponents;   // ex | ey << 8 | ez << 16: biased exponents of the grid steps (the exponent field of a float)
-  uint8_t qlo[3][8];    // [axis][child]
-  uint8_t qhi[3][8];
-  int32_t child[8];
-  uint32_t pad[8];
-};
-static_assert(sizeof(Bvh8Node) == 128, "Bvh8Node is one 128-byte line");
 
 // Triangle in traversal order: v0 + two edges, original index, filter flags.
 struct __attribute__((aligned(16))) BvhTri {
@@ -174,7 +162,6 @@ struct DScene {
   const DImage* images;
   const DMedium* mediums;
   const Bvh4Node* bvh_nodes;
-  const Bvh8Node* bvh8_nodes;      // the eight-wide tree over the same bvh_tris (nullptr unless the host asked for it: ETX_HIP_BVH_WIDE)
   const BvhTri* bvh_tris;
   const FlatPrim* flat_prims;      // bvh_flat scenes: pre-transformed primitives of the sweep
   const FlatPrimInfo* flat_info;   // per primitive
@@ -184,8 +171,6 @@ struct DScene {
   const uint32_t* material_sss_medium;  // per material: the medium its subsurface walk runs through (interior medium, or a derived entry appended to `mediums`; host_scene.cpp)
   uint32_t vertex_count, triangle_count, material_count, emitter_count, emitter_dist_count, spectrum_count, image_count, medium_count;
   uint32_t bvh_node_count, bvh_tri_count, flat_prim_count;
-  uint32_t bvh8_node_count;
-  int32_t bvh8_root;
   uint32_t boundary_materials;  // materials of Class::Boundary in the table: 0 = a transmittance query is a pure occlusion test (dev_bvh.h bvh_occluded)
   uint32_t normal_mapped_materials;  // materials with a normal map: 0 = a shading point is the interpolated vertex (make_intersection reads no material for it)
   uint32_t textured_materials;  // materials that reference any image (normal map included): 0 = no BSDF reads a texture coordinate

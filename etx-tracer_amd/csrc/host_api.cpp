@@ -328,12 +328,10 @@ int allocate_pipeline(etx_hip_context* ctx) {
   // a tree whose stack bound exceeds the LDS part: this lane's spill area (dev_bvh.h LaneStack), one column per thread of the
   // largest grid any traversing kernel is launched with
   p.scene.stack_spill = nullptr, p.scene.stack_spill_lanes = 0u;
-  if ((p.scene.bvh_flat == 0u) && (std::max(p.scene.bvh_stack_need, (p.scene.bvh8_nodes != nullptr) ? ctx->scene.bvh8_stack_need : 0u) > kShortStackDepth)) {  // rows for the kernels with the short LDS stack, which cover the others'
+  if ((p.scene.bvh_flat == 0u) && (p.scene.bvh_stack_need > kShortStackDepth)) {  // rows for the kernels with the short LDS stack, which cover the others'
     const uint32_t spill_lanes = 2u * kPersistentBlocks * kBlockSize;
-    // rows: what the deepest accepted tree can need beyond the short LDS stack (an eight-wide tree may need more than kMaxStackDepth: up to
-    // seven pushes per level; host_scene.cpp accepts it up to kMaxWideStackDepth)
-    const uint32_t deepest = std::max(kMaxStackDepth, (p.scene.bvh8_nodes != nullptr) ? ctx->scene.bvh8_stack_need : 0u);
-    if (int rc = device_alloc(ctx, p.scene.stack_spill, size_t(spill_lanes) * (deepest - kShortStackDepth)))
+    // rows: what the deepest accepted tree can need beyond the short LDS stack
+    if (int rc = device_alloc(ctx, p.scene.stack_spill, size_t(spill_lanes) * (kMaxStackDepth - kShortStackDepth)))
       return rc;
     p.scene.stack_spill_lanes = spill_lanes;
   }
@@ -1333,12 +1331,9 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
 }
 
 int etx_hip_set_bvh_builder(etx_hip_context* context, int builder) {
-  const bool wide = (builder & ETX_HIP_BVH_WIDE) != 0;
-  builder &= ~int(ETX_HIP_BVH_WIDE);
-  if ((context == nullptr) || ((builder != ETX_HIP_BVH_HOST_SAH) && (builder != ETX_HIP_BVH_DEVICE_LBVH)) || (wide && (builder != ETX_HIP_BVH_HOST_SAH)))
+  if ((context == nullptr) || ((builder != ETX_HIP_BVH_HOST_SAH) && (builder != ETX_HIP_BVH_DEVICE_LBVH)))
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   context->scene.device_bvh_build = builder == ETX_HIP_BVH_DEVICE_LBVH;
-  context->scene.wide_bvh = wide;
   return ETX_HIP_OK;
 }
 

@@ -70,7 +70,6 @@ void DeviceScene::borrow(const DeviceScene& owner) {
   generic_materials = owner.generic_materials;
   needs_rgb_response = owner.needs_rgb_response;
   bvh_bytes = owner.bvh_bytes;
-  bvh8_stack_need = owner.bvh8_stack_need;
   content_hash = owner.content_hash;
 }
 
@@ -564,257 +563,6 @@ void build_bvh(const etx_abi_scene* scene, HostBvh& out, bool keep_bvh2) {
   phase("BVH4 collapse and stack bound");
 }
 
-// BVH2 -> Bvh8Node. Collapse as for the four-wide nodes (the inner child with the largest surface area is replaced by its two children until
-// the node has eight or only leaves). Quantisation per node and axis: origin = the children's minimum minus a margin, step = the smallest
-// power of two whose 255 steps span the children (plus margins), lower bounds rounded down, upper bounds up. The margin (a few units in
-// the last place of the scene's extent) covers the rounding of the folded slab test of dev_bvh8.h, which evaluates a bound as
-// q * (step / d) + (origin - o) / d instead of ((origin + q * step) - o) / d.
-bool encode_bvh8(const HostBvh& bvh, HostBvh8& out, std::string& error) {
-  out = {};
-  if (bvh.tris.empty())
-    return true;
-  if (bvh.root < 0) {
-    out.root = bvh.root;
-    return true;
-  }
-  if (bvh.nodes.empty()) {
-    error = "encode_bvh8: the host tree was built without its two-wide form";
-    return false;
-  }
-  struct Box {
-    float lo[3], hi[3];
-  };
-  auto child_boxes = [](const BvhNode& n, Box& b0, Box& b1) {
-    b0 = {{n.lo0_hi0x.x, n.lo0_hi0x.y, n.lo0_hi0x.z}, {n.lo0_hi0x.w, n.hi0yz_lo1xy.x, n.hi0yz_lo1xy.y}};
-    b1 = {{n.hi0yz_lo1xy.z, n.hi0yz_lo1xy.w, n.lo1z_hi1.x}, {n.lo1z_hi1.y, n.lo1z_hi1.z, n.lo1z_hi1.w}};
-  };
-  auto half_area = [](const Box& b) {
-    const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
-    return x * y + y * z + z * x;
-  };
-  // scene extent -> margin
-  Box root0, root1;
-  child_boxes(bvh.nodes[size_t(bvh.root)], root0, root1);
-  double reach = 0.0;
-  for (int a = 0; a < 3; ++a)
-    reach = std::max({reach, std::fabs(double(root0.lo[a])), std::fabs(double(root0.hi[a])), std::fabs(double(root1.lo[a])), std::fabs(double(root1.hi[a]))});
-  const double margin = 2.0e-6 * std::max(reach, 1.0e-30);
-  // Which BVH2 nodes become the children of a wide node: the surface-area cost of the collapsed tree, minimised bottom-up (Ylitie,
-  // Karras, Laine 2017, "Efficient incoherent ray traversal on GPUs through compressed wide BVHs", section 3.1). cost[n][i - 1] = cheapest
-  // way to represent the subtree of BVH2 node n by at most i roots (wide nodes or leaves), i = 1..7:
-  //   one root   : a leaf over all its triangles (they are contiguous in traversal order; up to 8), or a wide node whose eight slots are
-  //                shared between the two children: A(n) * kNodeCost + min_k (cost[left][k] + cost[right][8 - k])
-  //   i > 1 roots: the better of splitting the budget between the children and of using fewer roots
-  // The greedy collapse used for the four-wide nodes (largest child first) leaves eight-wide nodes half empty (4.4 children on
-  // average on the 102 k-triangle meshes): the parents of two leaves at the bottom of the tree stay nodes of their own.
-  // Measured on the host (node visits / triangle tests per ray; greedy = largest child first): gems incoherent 2.06 / 1.39 -> 1.83 / 1.74,
-  // gems walk segments 5.15 / 1.45 -> 4.79 / 1.92, 102 k-triangle meshes incoherent 2.75 / 1.36 -> 2.68 / 1.60, walk segments 6.39 / 1.02 ->
-  // 6.90 / 1.33 - about even in visits, a third of the nodes (617 -> 209, 23 715 -> 7 799: 1 MB instead of 3 MB for the meshes). The
-  // triangle cost is a tuning knob of debug builds (0.6 and above: no merged leaves).
-  const float kNodeCost = 1.0f, kTriangleCost = tuning_knob_f("ETX_HIP_BVH8_TRIANGLE_COST", 0.3f);
-  constexpr uint32_t kMaxLeaf = 8u;
-  const size_t inner_count = bvh.nodes.size();
-  struct Plan {
-    float cost[7];
-    uint8_t split[7];   // i >= 2: roots given to the left child (0: same as with i - 1 roots); i == 1: slots given to the left child of the wide node
-    bool leaf;          // one root: a merged leaf
-    float area;
-    uint32_t first, count;  // triangle range of the subtree
-  };
-  std::vector<Plan> plan(inner_count);
-  auto leaf_first = [](int32_t c) { return uint32_t(~c) >> 3; };
-  auto leaf_count = [](int32_t c) { return (uint32_t(~c) & 7u) + 1u; };
-  {
-    // post-order over the inner nodes without recursion
-    std::vector<std::pair<int32_t, bool>> todo;
-    todo.push_back({bvh.root, false});
-    while (todo.empty() == false) {
-      const auto [n, expanded] = todo.back();
-      todo.pop_back();
-      const BvhNode& node = bvh.nodes[size_t(n)];
-      if (expanded == false) {
-        todo.push_back({n, true});
-        if (node.child0 >= 0)
-          todo.push_back({node.child0, false});
-        if (node.child1 >= 0)
-          todo.push_back({node.child1, false});
-        continue;
-      }
-      Box b0, b1;
-      child_boxes(node, b0, b1);
-      Box own;
-      for (int a = 0; a < 3; ++a)
-        own.lo[a] = std::min(b0.lo[a], b1.lo[a]), own.hi[a] = std::max(b0.hi[a], b1.hi[a]);
-      Plan& p = plan[size_t(n)];
-      p.area = half_area(own);
-      const int32_t kid[2] = {node.child0, node.child1};
-      const Box* kid_box[2] = {&b0, &b1};
-      float kid_cost[2][7];
-      uint32_t first[2], count[2];
-      for (int c = 0; c < 2; ++c) {
-        if (kid[c] < 0) {
-          first[c] = leaf_first(kid[c]), count[c] = leaf_count(kid[c]);
-          for (int i = 0; i < 7; ++i)
-            kid_cost[c][i] = half_area(*kid_box[c]) * float(count[c]) * kTriangleCost;
-        } else {
-          const Plan& q = plan[size_t(kid[c])];
-          first[c] = q.first, count[c] = q.count;
-          for (int i = 0; i < 7; ++i)
-            kid_cost[c][i] = q.cost[i];
-        }
-      }
-      p.first = std::min(first[0], first[1]), p.count = count[0] + count[1];
-      const bool contiguous = (std::max(first[0], first[1]) == p.first + ((first[0] < first[1]) ? count[0] : count[1]));
-      auto distribute = [&](uint32_t slots, uint8_t& best_k) {  // min over k of cost[left][k] + cost[right][slots - k], both in 1..7
-        float best = kMaxFloat;
-        best_k = 1;
-        for (uint32_t k = 1; k < slots; ++k) {
-          if ((k > 7u) || (slots - k > 7u))
-            continue;
-          const float c = kid_cost[0][k - 1u] + kid_cost[1][slots - k - 1u];
-          if (c < best)
-            best = c, best_k = uint8_t(k);
-        }
-        return best;
-      };
-      uint8_t k8 = 1;
-      const float as_node = p.area * kNodeCost + distribute(8u, k8);
-      const float as_leaf = (contiguous && (p.count <= kMaxLeaf)) ? p.area * float(p.count) * kTriangleCost : kMaxFloat;
-      p.leaf = as_leaf < as_node;
-      p.cost[0] = std::min(as_leaf, as_node);
-      p.split[0] = k8;
-      for (uint32_t i = 2; i <= 7u; ++i) {
-        uint8_t k = 1;
-        const float split_cost = distribute(i, k);
-        if (split_cost < p.cost[i - 2u])
-          p.cost[i - 1u] = split_cost, p.split[i - 1u] = k;
-        else
-          p.cost[i - 1u] = p.cost[i - 2u], p.split[i - 1u] = 0u;
-      }
-    }
-  }
-  if (plan[size_t(bvh.root)].leaf) {  // the whole scene fits one leaf
-    out.root = ~int32_t((plan[size_t(bvh.root)].first << 3) | (plan[size_t(bvh.root)].count - 1u));
-    return true;
-  }
-  struct Pending {
-    int32_t bvh2;
-    uint32_t level;
-  };
-  std::vector<Pending> queue;
-  queue.push_back({bvh.root, 1u});
-  out.root = 0;
-  for (size_t head = 0; head < queue.size(); ++head) {
-    const Pending item = queue[head];
-    out.levels = std::max(out.levels, item.level);
-    int32_t kids[8];  // >= 0: BVH2 node that becomes a wide node; < 0: leaf code
-    Box boxes[8];
-    uint32_t kid_count = 0;
-    // the roots the plan gives to a child with `roots` of them to spend
-    struct Frame {
-      int32_t node;
-      Box box;
-      uint32_t roots;
-    };
-    std::vector<Frame> frames;
-    {
-      Box b0, b1;
-      const BvhNode& top = bvh.nodes[size_t(item.bvh2)];
-      child_boxes(top, b0, b1);
-      const uint32_t k = plan[size_t(item.bvh2)].split[0];
-      frames.push_back({top.child1, b1, 8u - k});
-      frames.push_back({top.child0, b0, k});
-    }
-    while (frames.empty() == false) {
-      const Frame f = frames.back();
-      frames.pop_back();
-      if (kid_count == 8u) {
-        error = "encode_bvh8: the collapse plan produced more than eight children";
-        return false;
-      }
-      if (f.node < 0) {
-        kids[kid_count] = f.node, boxes[kid_count] = f.box, kid_count++;
-        continue;
-      }
-      const Plan& q = plan[size_t(f.node)];
-      uint32_t roots = f.roots;
-      while ((roots > 1u) && (q.split[roots - 1u] == 0u))  // fewer roots are as good
-        roots--;
-      if (roots == 1u) {
-        kids[kid_count] = q.leaf ? ~int32_t((q.first << 3) | (q.count - 1u)) : f.node;
-        boxes[kid_count] = f.box, kid_count++;
-        continue;
-      }
-      Box b0, b1;
-      const BvhNode& n = bvh.nodes[size_t(f.node)];
-      child_boxes(n, b0, b1);
-      const uint32_t k = q.split[roots - 1u];
-      frames.push_back({n.child1, b1, roots - k});
-      frames.push_back({n.child0, b0, k});
-    }
-    if ((kid_count == 0u) || (kid_count > 8u)) {
-      error = "encode_bvh8: the collapse plan produced " + std::to_string(kid_count) + " children";
-      return false;
-    }
-    Bvh8Node node = {};
-    for (uint32_t k = 0; k < 8u; ++k) {
-      node.child[k] = kBvhEmptyChild;
-      for (int a = 0; a < 3; ++a)
-        node.qlo[a][k] = 255u, node.qhi[a][k] = 0u;  // an inverted box: never entered
-    }
-    for (int a = 0; a < 3; ++a) {
-      double lo = kMaxFloat, hi = -kMaxFloat;
-      for (uint32_t k = 0; k < kid_count; ++k)
-        lo = std::min(lo, double(boxes[k].lo[a])), hi = std::max(hi, double(boxes[k].hi[a]));
-      const float origin = float(lo - margin) <= lo - margin ? float(lo - margin) : std::nextafter(float(lo - margin), -kMaxFloat);
-      const double extent = (hi + margin) - double(origin);
-      int biased = 1;
-      while ((biased < 254) && (std::ldexp(255.0, biased - 127) < extent))
-        ++biased;
-      if (std::ldexp(255.0, biased - 127) < extent) {
-        error = "encode_bvh8: a node spans more than the grid can address";
-        return false;
-      }
-      const double step = std::ldexp(1.0, biased - 127);
-      node.origin[a] = origin;
-      node.exponents |= uint32_t(biased) << (8u * uint32_t(a));
-      for (uint32_t k = 0; k < kid_count; ++k) {
-        const double ql = std::floor((double(boxes[k].lo[a]) - margin - double(origin)) / step);
-        const double qh = std::ceil((double(boxes[k].hi[a]) + margin - double(origin)) / step);
-        if ((ql < 0.0) || (qh > 255.0) || (double(origin) + ql * step > double(boxes[k].lo[a])) || (double(origin) + qh * step < double(boxes[k].hi[a]))) {
-          error = "encode_bvh8: a quantised box does not contain its child";
-          return false;
-        }
-        node.qlo[a][k] = uint8_t(ql), node.qhi[a][k] = uint8_t(qh);
-      }
-    }
-    for (uint32_t k = 0; k < kid_count; ++k) {
-      if (kids[k] < 0) {
-        node.child[k] = kids[k];
-      } else {
-        node.child[k] = int32_t(queue.size());
-        queue.push_back({kids[k], item.level + 1u});
-      }
-    }
-    out.nodes.push_back(node);
-  }
-  std::vector<uint32_t> need(out.nodes.size(), 0u);
-  for (size_t i = out.nodes.size(); i-- > 0;) {
-    const Bvh8Node& nd = out.nodes[i];
-    uint32_t kids = 0, deepest = 0;
-    for (int k = 0; k < 8; ++k) {
-      if (nd.child[k] == kBvhEmptyChild)
-        continue;
-      kids++;
-      if (nd.child[k] >= 0)
-        deepest = std::max(deepest, need[size_t(nd.child[k])]);
-    }
-    need[i] = (kids ? kids - 1u : 0u) + deepest;
-  }
-  out.stack_need = need.empty() ? 0u : need[0];
-  return true;
-}
-
 // The cube the Morton keys of the device build quantize: the scene's bounding sphere (Scene::bounding_sphere_*, computed by the host
 // at commit), or the vertices' box when the scene does not carry one.
 void lbvh_cube(const etx_abi_scene* scene, f3& cube_min, float& cube_extent) {
@@ -988,29 +736,12 @@ int build_lbvh_tables(const etx_abi_scene* scene, DeviceScene& out, DScene& d, B
 // BVH build + upload (geometry group): the BVH4, the traversal triangles, and for a scene of <= kFlatSweepMaxTriangles the flat-sweep primitives
 int build_traversal_tables(const etx_abi_scene* scene, DeviceScene& out, DScene& d, std::string& error) {
   int rc = 0;
-  d.bvh8_nodes = nullptr, d.bvh8_node_count = 0u, d.bvh8_root = kBvhEmptyChild;
   if (out.device_bvh_build && (scene->triangles.count > kFlatSweepMaxTriangles))
     return build_lbvh_tables(scene, out, d, nullptr, nullptr, error);
   HostBvh bvh;
   const auto build_begin = std::chrono::steady_clock::now();
-  const bool wide = out.wide_bvh && (scene->triangles.count > kFlatSweepMaxTriangles);
-  build_bvh(scene, bvh, /* keep the two-wide intermediate: the eight-wide collapse starts from it */ wide);
-  HostBvh8 bvh8;
-  if (wide && (encode_bvh8(bvh, bvh8, error) == false))
-    return ETX_HIP_ERROR_STATE;
+  build_bvh(scene, bvh, /* the two-wide intermediate is the invariants check's input only */ false);
   out.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - build_begin).count();
-  if (wide && (bvh8.stack_need > kMaxWideStackDepth)) {
-    error = "the eight-wide tree needs " + std::to_string(bvh8.stack_need) + " traversal stack entries, the device stack holds " + std::to_string(kMaxWideStackDepth) + " (use the four-wide tree)";
-    return ETX_HIP_ERROR_UNSUPPORTED;
-  }
-  d.bvh8_nodes = nullptr, d.bvh8_node_count = 0u, d.bvh8_root = kBvhEmptyChild;
-  if (wide && (bvh8.nodes.empty() == false)) {
-    if ((rc = upload(out, bvh8.nodes.data(), bvh8.nodes.size(), d.bvh8_nodes, error)))
-      return rc;
-    d.bvh8_node_count = uint32_t(bvh8.nodes.size());
-    d.bvh8_root = bvh8.root;
-    out.bvh8_stack_need = bvh8.stack_need;
-  }
   // near-child-first traversal of a four-wide tree pushes at most three children per level
   if (bvh.stack_need > kMaxStackDepth) {
     error = "the BVH needs " + std::to_string(bvh.stack_need) + " traversal stack entries (depth " + std::to_string(bvh.depth4) + "), the device stack holds " + std::to_string(kMaxStackDepth);
@@ -1076,7 +807,7 @@ int build_traversal_tables(const etx_abi_scene* scene, DeviceScene& out, DScene&
   if (tuning_knob("ETX_HIP_FORCE_BVH", 0u) != 0u)
     d.bvh_flat = 0u;
   out.bvh_depth = bvh.depth4;
-  out.bvh_bytes = bvh.nodes4.size() * sizeof(Bvh4Node) + bvh.tris.size() * sizeof(BvhTri) + bvh8.nodes.size() * sizeof(Bvh8Node);
+  out.bvh_bytes = bvh.nodes4.size() * sizeof(Bvh4Node) + bvh.tris.size() * sizeof(BvhTri);
 
   return 0;
 }
@@ -1494,7 +1225,6 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     d.bvh_nodes = kept.bvh_nodes, d.bvh_tris = kept.bvh_tris, d.bvh_node_count = kept.bvh_node_count, d.bvh_tri_count = kept.bvh_tri_count;
     d.flat_prims = kept.flat_prims, d.flat_info = kept.flat_info, d.flat_prim_count = kept.flat_prim_count;
     d.bvh_root = kept.bvh_root, d.bvh_depth = kept.bvh_depth, d.bvh_stack_need = kept.bvh_stack_need, d.bvh_flat = kept.bvh_flat;
-    d.bvh8_nodes = kept.bvh8_nodes, d.bvh8_node_count = kept.bvh8_node_count, d.bvh8_root = kept.bvh8_root;
     out.flat_prims = kept_flat_prims;
   } else {
     // (a scene small enough for the flat sweep is rebuilt in any case: its primitives are pre-transformed on the host)
@@ -1591,10 +1321,6 @@ int update_device_geometry(const etx_abi_scene* scene, DeviceScene& out, hipStre
   }
   if (positions_moved)
     launch_build_tri_shade(stream, d, const_cast<float4*>(d.tri_shade), d.triangle_count);
-  // the eight-wide tree is a host product over the uploaded positions: moved vertices leave the four-wide tree (refit or rebuilt below) as
-  // the only one until the next etx_hip_upload_scene
-  if (positions_moved || rebuild)
-    d.bvh8_nodes = nullptr, d.bvh8_node_count = 0u, d.bvh8_root = kBvhEmptyChild;
   // a scene small enough for the flat sweep had its traversal tables rebuilt from the host scene (build_device_scene)
   if ((d.triangle_count > kFlatSweepMaxTriangles) && rebuild) {
     // a new tree over the moved vertices, built on the device; the traversal triangle buffer is reused, the node buffer replaced

@@ -27,8 +27,6 @@ struct DeviceScene {
   std::vector<etxd::DImage> image_table;    // host copy of DScene::images (device pointers inside), reused by an update
   std::vector<const float*> density_grids;  // per medium: its uploaded density grid (nullptr: homogeneous)
   std::vector<uint32_t> bvh_levels;         // first node of every breadth-first level of the BVH4, then the node count (device refit)
-  uint32_t bvh8_stack_need = 0;
-  bool wide_bvh = false;                    // etx_hip_set_bvh_builder(... | ETX_HIP_BVH_WIDE): also build the eight-wide tree (dev_bvh8.h) over the host tree's triangles
   bool device_bvh_build = false;            // etx_hip_set_bvh_builder: the tree is built on the device (dev_lbvh.h) instead of the host's binned SAH
   double bvh_build_ms = 0.0;                // time of the last tree build (host: wall clock of build_bvh; device: HIP events)
   uint32_t film_w = 0, film_h = 0;
@@ -78,16 +76,6 @@ struct HostBvh {
   uint32_t depth = 0;
 };
 void build_bvh(const etx_abi_scene* scene, HostBvh& out, bool keep_bvh2 = true);
-
-// The eight-wide tree with 8-bit child boxes (dev_scene.h Bvh8Node) over the same triangle order: the BVH2 of `bvh` (built with
-// keep_bvh2) collapsed to eight children per node, breadth first, child boxes rounded outwards on the node's grid.
-struct HostBvh8 {
-  std::vector<etxd::Bvh8Node> nodes;
-  int32_t root = etxd::kBvhEmptyChild;  // a one-leaf scene has a negative root
-  uint32_t levels = 0;
-  uint32_t stack_need = 0;              // entries the nearest-first traversal can have on its stack (exact bound over the tree)
-};
-bool encode_bvh8(const HostBvh& bvh, HostBvh8& out, std::string& error);
 
 // The device build (dev_lbvh.h) run on the host, element by element in the order the kernels' indices run: the tree the device
 // WILL build, for tests without a GPU (invariants, stack bound, rays against the SAH tree).

@@ -12,7 +12,6 @@
 // dev_bdpt.h explains the data layout. All BSDF classes go through the out-of-line dispatch (dev_bsdf_ool.h).
 #include "kernels.h"
 #include "dev_bdpt.h"
-#include "dev_bvh8.h"
 
 namespace etxd {
 
@@ -109,7 +108,7 @@ struct BdptWalk {
 };
 
 // subsurface_step's free flight: returns false when the path ends (pdf zero). found = the object's surface was reached (h filled).
-template <class Nodes>  // BvhNodes, or Bvh8Nodes of the eight-wide tree (dev_bvh8.h)
+template <class Nodes>
 ETX_DEV bool bdpt_walk_flight(const DScene& scene, const Nodes& nodes, const LaneStack& stack, const BdptWalk& walk, BdptState& st, float4& h, MediumSample& ms) {
   const DMedium& wm = scene.mediums[walk.medium];
   f3 absorption, scattering;
@@ -450,8 +449,6 @@ ETX_DEV bool walk_refill(const Pipeline& p, uint32_t count, bool& active, bool& 
 }
 
 // The scattering events of the walks of this bounce, emitter paths: walk queue -> (medium vertices in the light vertex pool) -> exit queue
-// kWide: the material-filtered queries of the events run on the eight-wide tree (dev_bvh8.h; ETX_HIP_BVH_WIDE)
-template <bool kWide>
 __global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_light(Pipeline p, VcmParams it, uint32_t queue) {
   __shared__ int32_t s_stack[kStackDepth * kBlockSize];
   __shared__ float4 s_nodes[kWalkLdsNodes * 8u];
@@ -460,11 +457,7 @@ __global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_light(Pipeline p, V
   const uint32_t count = min(p.counters[kCntWalk + 32u * queue], p.capacity);
   if (count == 0u)
     return;
-  typename std::conditional<kWide, Bvh8Nodes, BvhNodes>::type nodes;  // every event descends from the root: its first levels come from LDS
-  if constexpr (kWide)
-    nodes = stage_nodes8(scene, reinterpret_cast<uint4*>(s_nodes), kWalkLdsNodes);
-  else
-    nodes = stage_nodes(scene, s_nodes, kWalkLdsNodes);
+  const BvhNodes nodes = stage_nodes(scene, s_nodes, kWalkLdsNodes);  // every event descends from the root: its first levels come from LDS
   const uint32_t mode = bdpt_mode(it);
   const uint32_t lane = threadIdx.x & 63u;
   BdptState st = {};
@@ -924,7 +917,6 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, Vc
 
 // The scattering events of the walks of this bounce, camera paths: walk queue -> exit queue (only the exit vertex of a walk is
 // connectible, :811: the events leave nothing but the path's running MIS history behind)
-template <bool kWide>
 __global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_camera(Pipeline p, VcmParams it, uint32_t queue) {
   __shared__ int32_t s_stack[kStackDepth * kBlockSize];
   __shared__ float4 s_nodes[kWalkLdsNodes * 8u];
@@ -933,11 +925,7 @@ __global__ __launch_bounds__(kBlockSize, 4) void k_bdpt_walk_camera(Pipeline p, 
   const uint32_t count = min(p.counters[kCntWalk + 32u * queue], p.capacity);
   if (count == 0u)
     return;
-  typename std::conditional<kWide, Bvh8Nodes, BvhNodes>::type nodes;  // every event descends from the root: its first levels come from LDS
-  if constexpr (kWide)
-    nodes = stage_nodes8(scene, reinterpret_cast<uint4*>(s_nodes), kWalkLdsNodes);
-  else
-    nodes = stage_nodes(scene, s_nodes, kWalkLdsNodes);
+  const BvhNodes nodes = stage_nodes(scene, s_nodes, kWalkLdsNodes);  // every event descends from the root: its first levels come from LDS
   const uint32_t mode = bdpt_mode(it);
   const bool use_mis = opt_enable_mis(it);
   BdptState st = {};
@@ -1213,16 +1201,10 @@ void launch_bdpt_walk(hipStream_t stream, const Pipeline& p, const VcmParams& it
   const uint32_t items = min(p.capacity, max_items);
   const uint32_t blocks = max(1u, min(kWalkBlocks, (items + kBlockSize - 1u) / kBlockSize));
   if (camera) {
-    if (p.scene.bvh8_nodes != nullptr)
-      hipLaunchKernelGGL(k_bdpt_walk_camera<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
-    else
-      hipLaunchKernelGGL(k_bdpt_walk_camera<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
+    hipLaunchKernelGGL(k_bdpt_walk_camera, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
     ETX_BDPT_LAUNCH(k_bdpt_walk_exit_camera, max(1u, grid_for(items)), p, it, in_set ^ 1u);
   } else {
-    if (p.scene.bvh8_nodes != nullptr)
-      hipLaunchKernelGGL(k_bdpt_walk_light<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
-    else
-      hipLaunchKernelGGL(k_bdpt_walk_light<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
+    hipLaunchKernelGGL(k_bdpt_walk_light, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
     ETX_BDPT_LAUNCH(k_bdpt_walk_exit_light, max(1u, grid_for(items)), p, it, in_set ^ 1u);
   }
 }

@@ -6,7 +6,6 @@
 // wave-uniform grid-stride loop; per-lane traversal stack in LDS laid out [level][lane] (bank conflict free).
 #include "kernels.h"
 #include "dev_bvh.h"
-#include "dev_bvh8.h"
 #include "dev_vcm.h"
 #include "pipeline.h"
 #include "tuning_knobs.h"
@@ -143,14 +142,17 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest(const DScene scene
 // and 2.5 triangle tests ON AVERAGE, while the rays that cross a gem need ten times that: with a fixed ray per lane a
 // wavefront costs its worst lane and 64-lane utilisation was ~10 % (4 Grays/s). Here every wavefront owns a contiguous
 // chunk of the queue and whenever kRefillLanes lanes are idle they take the next rays of the chunk (wave-uniform cursor,
-// no atomics); a lane executes one traversal step (inner node or leaf) per loop iteration.
-// LDS per workgroup: the per-lane stacks (32 KB) + the first kLdsNodesPersistent nodes of the tree (top levels, 8 KB).
+// no atomics).
+// PHASES (round 5). Rounds 2-4 ran "one traversal step (inner node or leaf) per lane and loop trip": counters of that kernel alone on the gems
+// scene (profiles/round5_pmc_trace_alone.txt) showed its VALU pipes issuing 65 % of the time with 36 % of the lanes active per instruction - every
+// trip ran the node step for the lanes on inner nodes AND the leaf step for the lanes on leaves, each lane idle through the other's code. Now a
+// wavefront alternates between NODE steps, while at least `node_phase_lanes` lanes stand on inner nodes - a lane that reaches a leaf keeps it
+// (one postponed leaf per lane, Aila & Laine's speculative traversal: it pops on and keeps walking, testing boxes against a `best.t` that does not
+// know the postponed leaf yet: a few extra node visits, never a wrong answer) - and LEAF steps, in which every lane that holds a leaf tests one
+// triangle per trip. Lane utilisation 36 -> 50 %, 9.6 -> 12.0 Grays/s on 2 M incoherent gems rays (profiles/round5_trace_kernel_phases.txt).
+// LDS per workgroup: the per-lane stacks (<= 32 KB) + the first kLdsNodesPersistent nodes of the tree (top levels, 8 KB).
 constexpr uint32_t kRefillLanes = 16;
-constexpr uint32_t kBvhVariantPhased = 3u;   // ETX_HIP_BVH_VARIANT (debug builds): 0 the interleaved kernel, 1 / 2 staging and stack experiments, 3 the phased kernel
-constexpr uint32_t kBvhVariantDefault = 0u;
-#if !defined(ETX_WIDE_LDS_NODES)
-#define ETX_WIDE_LDS_NODES 64u  // staged nodes of the eight-wide kernel: the root and its children (8 KB; with the 16 KB short stack six workgroups per CU)
-#endif
+constexpr uint32_t kNodePhaseLanes = 24;
 
 template <bool kDeep, uint32_t kLdsEntries = kStackDepth>
 struct TraversalStack {
@@ -174,150 +176,10 @@ struct TraversalStack<true, kShortStackDepth> {  // half the LDS: entries above 
   }
 };
 
-// kWide: the eight-wide tree of dev_bvh8.h (checked short stack, kDeep and kStack = kShortStackDepth): one 128-byte node decides eight children,
-// the nearest hit child is entered, the others pushed as they come.
-template <bool kFromCounter, uint32_t kStack, uint32_t kLdsNodesPersistent, bool kDeep = false, bool kWide = false>
+template <bool kFromCounter, uint32_t kStack, uint32_t kLdsNodesPersistent, bool kDeep = false>
 __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
   float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit,
-  uint32_t refill_lanes, uint32_t pass_stat) {
-  __shared__ int32_t s_stack[kStack * kBlockSize];
-  __shared__ float4 s_nodes[kLdsNodesPersistent * 8u];
-  const DScene& scene = scene_arg;
-  const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
-  if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
-    round_housekeeping(counters, active_counter, count, pass_stat, round_mirror, round_tag);
-  }
-  if (count == 0u)
-    return;
-  typedef typename std::conditional<kWide, Bvh8Nodes, BvhNodes>::type Nodes;
-  Nodes nodes;
-  if constexpr (kWide)
-    nodes = stage_nodes8(scene, reinterpret_cast<uint4*>(s_nodes), min(kLdsNodesPersistent, lds_node_limit));
-  else
-    nodes = stage_nodes(scene, s_nodes, min(kLdsNodesPersistent, lds_node_limit));
-  const typename TraversalStack<kDeep, kDeep ? kStack : kStackDepth>::Type stack = TraversalStack<kDeep, kDeep ? kStack : kStackDepth>::make(scene, s_stack + threadIdx.x, kBlockSize);
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6u;
-  const uint32_t wave_count = (gridDim.x * blockDim.x) >> 6u;
-  const uint32_t chunk = ((count + wave_count - 1u) / wave_count + 63u) & ~63u;  // rays per wavefront, whole 64-ray rows
-  uint32_t cursor = min(count, wave * chunk);                                    // wave-uniform
-  const uint32_t chunk_end = min(count, cursor + chunk);
-  const int32_t kDone = kBvhEmptyChild;
-  const BvhTri* __restrict__ tris = scene.bvh_tris;
-
-  uint32_t ray_index = kInvalid;
-  RayQ ray = {};
-  f3 inv_d = {};
-  Hit best = {};
-  uint32_t alpha_seed = 0u, sp = 0u;
-  int32_t cur = kDone;
-  for (;;) {
-    const bool idle = cur == kDone;
-    const unsigned long long idle_mask = __ballot(idle);
-    const uint32_t idle_count = uint32_t(__popcll(idle_mask));
-    if ((idle_count >= refill_lanes) || (idle_count == 64u)) {
-      if (cursor < chunk_end) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(idle_mask >> 32u), __builtin_amdgcn_mbcnt_lo(uint32_t(idle_mask), 0u));
-        const uint32_t take = min(idle_count, chunk_end - cursor);
-        if (idle && (rank < take)) {
-          ray_index = cursor + rank;
-          const float4 a = ray_o_tmin[ray_index];
-          const float4 b = ray_d_tmax[ray_index];
-          alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ (__float_as_uint(a.z) * 0x85ebca6bu) ^ (__float_as_uint(b.x) * 0xc2b2ae35u);
-          ray = {{a.x, a.y, a.z}, a.w, {b.x, b.y, b.z}, b.w};
-          if constexpr (kWide)
-            inv_d = {bvh8_reciprocal(ray.d.x), bvh8_reciprocal(ray.d.y), bvh8_reciprocal(ray.d.z)};
-          else
-            inv_d = {__builtin_amdgcn_rcpf(ray.d.x), __builtin_amdgcn_rcpf(ray.d.y), __builtin_amdgcn_rcpf(ray.d.z)};
-          best = {0.0f, 0.0f, ray.tmax, kInvalid};
-          sp = 0u;
-          cur = kWide ? scene.bvh8_root : scene.bvh_root;
-        }
-        cursor += take;
-      } else if (idle_count == 64u) {
-        break;
-      }
-    }
-    if (cur == kDone)
-      continue;
-    if (cur >= 0) {
-     if constexpr (kWide) {
-      const int32_t next = bvh8_visit<true>(bvh8_fetch(nodes, cur), ray.o, inv_d, ray.tmin, best.t, stack, sp);
-      cur = (next != kDone) ? next : (sp ? stack.pop(sp) : kDone);
-     } else {
-      float4 lox, loy, loz, hix, hiy, hiz, cc;
-      if (uint32_t(cur) < nodes.lds_count) {
-        const float4* n = nodes.lds + uint32_t(cur) * 8u;
-        lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5], cc = n[6];
-      } else {
-        const float4* n = nodes.global + uint32_t(cur) * 8u;
-        lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5], cc = n[6];
-      }
-      float t0 = slab(f3{lox.x, loy.x, loz.x}, f3{hix.x, hiy.x, hiz.x}, ray.o, inv_d, ray.tmin, best.t);
-      float t1 = slab(f3{lox.y, loy.y, loz.y}, f3{hix.y, hiy.y, hiz.y}, ray.o, inv_d, ray.tmin, best.t);
-      float t2 = slab(f3{lox.z, loy.z, loz.z}, f3{hix.z, hiy.z, hiz.z}, ray.o, inv_d, ray.tmin, best.t);
-      float t3 = slab(f3{lox.w, loy.w, loz.w}, f3{hix.w, hiy.w, hiz.w}, ray.o, inv_d, ray.tmin, best.t);
-      int32_t c0 = __float_as_int(cc.x), c1 = __float_as_int(cc.y), c2 = __float_as_int(cc.z), c3 = __float_as_int(cc.w);
-      t0 = (c0 == kBvhEmptyChild) ? kMaxFloat : t0;
-      t1 = (c1 == kBvhEmptyChild) ? kMaxFloat : t1;
-      t2 = (c2 == kBvhEmptyChild) ? kMaxFloat : t2;
-      t3 = (c3 == kBvhEmptyChild) ? kMaxFloat : t3;
-      sort_pair(t0, c0, t1, c1);
-      sort_pair(t2, c2, t3, c3);
-      sort_pair(t0, c0, t2, c2);
-      sort_pair(t1, c1, t3, c3);
-      sort_pair(t1, c1, t2, c2);
-      if (t0 == kMaxFloat) {
-        cur = sp ? stack.pop(sp) : kDone;
-      } else {
-        if (t3 < kMaxFloat)
-          stack.push(sp, c3);
-        if (t2 < kMaxFloat)
-          stack.push(sp, c2);
-        if (t1 < kMaxFloat)
-          stack.push(sp, c1);
-        cur = c0;
-      }
-     }
-    } else {
-      const uint32_t leaf = uint32_t(~cur);
-      const uint32_t first = leaf >> 3, leaf_count = (leaf & 7u) + 1u;
-      for (uint32_t i = first; i < first + leaf_count; ++i) {
-        const float4 v0 = tris[i].v0_index;
-        const float4 e1 = tris[i].e1_flags;
-        const float4 e2 = tris[i].e2_mat;
-        float u, v, t;
-        if (triangle_test(v0, e1, e2, ray, best.t, u, v, t) == false)
-          continue;
-        const uint32_t flags = __float_as_uint(e1.w);
-        if (flags & kTriVoid)
-          continue;
-        const uint32_t tri_index = __float_as_uint(v0.w);
-        if ((flags & kTriAlphaTested) && alpha_test_skips(scene, tri_index, __float_as_uint(e2.w), u, v, alpha_seed))
-          continue;
-        best = {u, v, t, tri_index};
-      }
-      cur = sp ? stack.pop(sp) : kDone;
-    }
-    if (cur == kDone)
-      hits[ray_index] = make_float4(best.u, best.v, best.t, __uint_as_float(best.tri));
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The same persistent traversal with PHASES (round 5). Counters of the kernel above alone on the gems scene (profiles/round5_pmc_trace_alone_*.txt):
-// its VALU pipes issue 65 % of the time, but a VALU instruction has 36 % of its lanes active - every loop trip runs the node step for the lanes
-// that stand on an inner node AND the leaf step for the lanes that stand on a leaf, each lane idle through the other's code. Here a wavefront
-// alternates between two phases: NODE steps while at least kNodePhaseLanes lanes stand on inner nodes - a lane that reaches a leaf keeps it
-// (one postponed leaf per lane, Aila & Laine's speculative traversal: it pops on and keeps walking, testing boxes against a `best.t` that does
-// not know the postponed leaf yet - a few extra node visits, never a wrong answer) - and LEAF steps, in which every lane that holds a leaf tests
-// one triangle per trip. Refill as above. Four-wide tree only.
-constexpr uint32_t kNodePhaseLanes = 24u;
-
-template <bool kFromCounter, uint32_t kStack, uint32_t kLdsNodesPersistent, bool kDeep = false>
-__global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh_phased(const DScene scene_arg, const float4* __restrict__ ray_o_tmin, const float4* __restrict__ ray_d_tmax,
-  float4* __restrict__ hits, uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t lds_node_limit,
-  uint32_t refill_lanes, uint32_t pass_stat) {
+  uint32_t refill_lanes, uint32_t node_phase_lanes, uint32_t pass_stat) {
   __shared__ int32_t s_stack[kStack * kBlockSize];
   __shared__ float4 s_nodes[kLdsNodesPersistent * 8u];
   const DScene& scene = scene_arg;
@@ -377,7 +239,7 @@ __global__ __launch_bounds__(kBlockSize) void k_trace_closest_bvh_phased(const D
       const uint32_t inner_count = uint32_t(__popcll(__ballot(inner)));
       if (inner_count == 0u)
         break;
-      if ((inner_count < kNodePhaseLanes) && (__ballot(leaf_at < leaf_end) != 0ull))
+      if ((inner_count < node_phase_lanes) && (__ballot(leaf_at < leaf_end) != 0ull))
         break;  // few lanes still walk while others hold leaves: test those first (the walkers resume in the next node phase)
       if (inner) {
         float4 lox, loy, loz, hix, hiy, hiz, cc;
@@ -586,59 +448,28 @@ static uint32_t lds_limit() {  // experiments: ETX_HIP_LDS_NODES caps the staged
   return limit;
 }
 
-// Variant by the stack the scene's tree needs (three entries per BVH4 level): 16 entries -> 24-32 KB of LDS per workgroup
-// and 5-6 resident workgroups per CU, 32 entries otherwise.
+// Variant by the stack the scene's tree needs (three entries per BVH4 level): 16 entries -> 24 KB of LDS per workgroup and six resident
+// workgroups per CU, 32 entries otherwise; a deep tree (> ~40 000 triangles: bound above 32) the checked stack, 16 entries in LDS, the rest in the
+// global spill rows (dev_bvh.h ShortLaneStack; a million triangles: 13.1 vs 12.8 Msamples/s with 32 entries in LDS).
 template <bool kFromCounter>
 static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t* counters, uint32_t active_counter,
   uint32_t items, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat) {
   static const uint32_t refill = etxh::tuning_knob("ETX_HIP_REFILL_LANES", kRefillLanes);
-  static const uint32_t variant = etxh::tuning_knob("ETX_HIP_BVH_VARIANT", kBvhVariantDefault);
+  static const uint32_t node_phase = etxh::tuning_knob("ETX_HIP_NODE_PHASE_LANES", kNodePhaseLanes);
   const dim3 grid(bvh_blocks(items)), block(kBlockSize);
   const uint32_t fixed_count = kFromCounter ? 0u : items;
-#define ETX_LAUNCH_BVH(STACK, NODES)                                                                                                                                              \
-  hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, STACK, NODES>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count, round_mirror, \
-    round_tag, lds_limit(), refill, pass_stat)
+#define ETX_LAUNCH_BVH(STACK, DEEP)                                                                                                                                                      \
+  hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, STACK, 64u, DEEP>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count, round_mirror, \
+    round_tag, lds_limit(), refill, node_phase, pass_stat)
   const uint32_t need = scene.bvh_stack_need;
-  if (scene.bvh8_nodes != nullptr) {  // ETX_HIP_BVH_WIDE: the eight-wide tree, checked short stack
-    hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, kShortStackDepth, ETX_WIDE_LDS_NODES, true, true>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count,
-      round_mirror, round_tag, lds_limit(), refill, pass_stat);
-    return;
-  }
-#define ETX_LAUNCH_BVH_PHASED(STACK, NODES, DEEP)                                                                                                                                   \
-  hipLaunchKernelGGL((k_trace_closest_bvh_phased<kFromCounter, STACK, NODES, DEEP>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count, \
-    round_mirror, round_tag, lds_limit(), refill, pass_stat)
-  if (variant == kBvhVariantPhased) {  // the phased kernel (node phase / leaf phase, one postponed leaf per lane)
-    if (need > kStackDepth)
-      ETX_LAUNCH_BVH_PHASED(kShortStackDepth, 64u, true);
-    else if (need <= 16u)
-      ETX_LAUNCH_BVH_PHASED(16u, 64u, false);
-    else if (need <= 24u)
-      ETX_LAUNCH_BVH_PHASED(24u, 64u, false);
-    else
-      ETX_LAUNCH_BVH_PHASED(kStackDepth, 64u, false);
-    return;
-  }
-#undef ETX_LAUNCH_BVH_PHASED
-  if (((variant == 2u) && (need > kShortStackDepth)) || (need > kStackDepth)) {
-    // a deep tree (> ~40 000 triangles): the checked stack, 16 entries in LDS (24 KB per workgroup with the staged nodes), the rest in the global
-    // spill rows (dev_bvh.h ShortLaneStack). A million triangles: 13.1 vs 12.8 Msamples/s with 32 entries in LDS; trees whose bound fits 32
-    // entries keep the unchecked stack (configs[3], bound 31: no difference)
-    hipLaunchKernelGGL((k_trace_closest_bvh<kFromCounter, kShortStackDepth, 64u, true>), grid, block, 0, stream, scene, ray_o_tmin, ray_d_tmax, hits, counters, active_counter, fixed_count,
-      round_mirror, round_tag, lds_limit(), refill, pass_stat);
-  } else if (variant == 1u) {  // experiments: twice the staged nodes
-    if (need <= 16u)
-      ETX_LAUNCH_BVH(16u, 128u);
-    else if (need <= 24u)
-      ETX_LAUNCH_BVH(24u, 128u);
-    else
-      ETX_LAUNCH_BVH(kStackDepth, 128u);
-  } else if (need <= 16u) {
-    ETX_LAUNCH_BVH(16u, 64u);
-  } else if (need <= 24u) {
-    ETX_LAUNCH_BVH(24u, 64u);
-  } else {
-    ETX_LAUNCH_BVH(kStackDepth, 64u);
-  }
+  if (need > kStackDepth)
+    ETX_LAUNCH_BVH(kShortStackDepth, true);
+  else if (need <= 16u)
+    ETX_LAUNCH_BVH(16u, false);
+  else if (need <= 24u)
+    ETX_LAUNCH_BVH(24u, false);
+  else
+    ETX_LAUNCH_BVH(kStackDepth, false);
 #undef ETX_LAUNCH_BVH
 }
 
@@ -682,10 +513,8 @@ constexpr uint32_t kShadowLdsNodes = 64u;
 #if !defined(ETX_SHADOW_OPAQUE_WAVES)
 #define ETX_SHADOW_OPAQUE_WAVES 7
 #endif
-// kWide (with kOpaque): the eight-wide tree of dev_bvh8.h
-template <bool kFlat, bool kDeep = false, bool kOpaque = false, bool kWide = false>
+template <bool kFlat, bool kDeep = false, bool kOpaque = false>
 __global__ __launch_bounds__(kBlockSize, kOpaque ? ETX_SHADOW_OPAQUE_WAVES : 1) void k_trace_shadow(Pipeline p) {
-  static_assert((kWide == false) || kOpaque, "the eight-wide tree is read by the opaque shadow kernel only");
   constexpr bool kShort = kOpaque && (uint32_t(ETX_SHADOW_OPAQUE_STACK) == kShortStackDepth);  // the opaque kernel: LDS for 16 entries per lane, the rest spills
   __shared__ int32_t s_stack[kFlat ? 1 : (kShort ? kShortStackDepth : kStackDepth) * kBlockSize];
   constexpr uint32_t kLdsNodes = kOpaque ? uint32_t(ETX_SHADOW_OPAQUE_NODES) : kShadowLdsNodes;
@@ -700,7 +529,6 @@ __global__ __launch_bounds__(kBlockSize, kOpaque ? ETX_SHADOW_OPAQUE_WAVES : 1) 
   BvhNodes nodes = global_nodes(scene);
   if ((kFlat == false) && (kLdsNodes != 0u) && (blockIdx.x * blockDim.x < count))
     nodes = stage_nodes(scene, s_nodes, kLdsNodes);
-  const Bvh8Nodes nodes8 = global_nodes8(scene);
   for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {
     const uint32_t i = base + lane;
     f3 value = mk3(0.0f);
@@ -710,9 +538,7 @@ __global__ __launch_bounds__(kBlockSize, kOpaque ? ETX_SHADOW_OPAQUE_WAVES : 1) 
       const float4 b = p.shadow.p1_target[i];
       uint32_t alpha_seed = __float_as_uint(a.x) ^ (__float_as_uint(b.y) * 0x9e3779b9u) ^ (__float_as_uint(a.z) * 0x85ebca6bu) ^ (__float_as_uint(b.x) * 0xc2b2ae35u);  // of the segment itself, not of its queue slot
       f3 tr = mk3(1.0f);
-      if (kWide)
-        tr = bvh_transmittance_opaque(scene, nodes8, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), p.shadow.value[i].w, alpha_seed);
-      else if (kOpaque)
+      if (kOpaque)
         tr = bvh_transmittance_opaque(scene, nodes, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), p.shadow.value[i].w, alpha_seed);
       else if ((p.debug_flags & 4u) == 0u)
         tr = bvh_transmittance(scene, nodes, scene.bvh_tris, scene.bvh_root, stack, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, __float_as_uint(a.w), p.shadow.value[i].w, alpha_seed);
@@ -768,15 +594,11 @@ void launch_trace_shadow(hipStream_t stream, const Pipeline& p, uint32_t max_ite
   if (flat)
     hipLaunchKernelGGL(k_trace_shadow<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p);
   else if (p.scene.bvh_stack_need > kStackDepth) {
-    if (opaque && (p.scene.bvh8_nodes != nullptr))
-      hipLaunchKernelGGL((k_trace_shadow<false, false, true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);  // its short stack is the checked one
-    else if (opaque)
+    if (opaque)
       hipLaunchKernelGGL((k_trace_shadow<false, true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);
     else
       hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);
-  } else if (opaque && (p.scene.bvh8_nodes != nullptr))
-    hipLaunchKernelGGL((k_trace_shadow<false, false, true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);
-  else if (opaque)
+  } else if (opaque)
     hipLaunchKernelGGL((k_trace_shadow<false, false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p);
   else
     hipLaunchKernelGGL(k_trace_shadow<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p);

@@ -109,14 +109,11 @@ int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, c
  *                            surface-area guided collapse to four-wide breadth-first nodes, boxes bottom-up): a few milliseconds
  *                            for 10^6 triangles - time to first iteration, geometry that changes every frame - at 3-15 % of the
  *                            traversal rate. Scenes of <= 64 triangles are swept linearly and always built on the host.
- *   ... | ETX_HIP_BVH_WIDE   (with ETX_HIP_BVH_HOST_SAH only; opt-in: measured no faster than the four-wide tree) the host
- *                            ALSO collapses its tree to eight children per node with 8-bit child boxes (csrc/dev_bvh8.h: 128 B per
- *                            node, a third fewer dependent node fetches per ray) and the kernels that have a variant for it - closest
- *                            hit, shadow segments of scenes without Boundary materials and density grids, the bidirectional
- *                            integrator's subsurface walks - traverse that one; edits that move vertices drop it again.
+ * (An eight-wide tree with 8-bit child boxes, ETX_HIP_BVH_WIDE = 256 until ABI 2, was measured no faster than the four-wide tree on any workload -
+ * lower lane utilisation, more VALU per ray - and is gone: DESIGN.md 3, HISTORY.md.)
  * etx_hip_bvh_info: {BVH4 nodes, triangles, depth | traversal stack entries << 16, bytes} of the uploaded scene and the time its
  * tree took to build (host: wall clock of the builder; device: HIP events around the build kernels), in milliseconds. */
-enum { ETX_HIP_BVH_HOST_SAH = 0, ETX_HIP_BVH_DEVICE_LBVH = 1, ETX_HIP_BVH_WIDE = 256 };
+enum { ETX_HIP_BVH_HOST_SAH = 0, ETX_HIP_BVH_DEVICE_LBVH = 1 };
 int etx_hip_set_bvh_builder(etx_hip_context* context, int builder);
 int etx_hip_bvh_info(etx_hip_context* context, uint32_t out_info[4], double* out_build_ms);
 
@@ -384,13 +381,6 @@ int etx_hip_host_bvh_stats(const etx_abi_scene* scene, const float* rays_8f, uin
  * (nullable): per ray {t, triangle index as u32 bits (0xffffffff: miss)} of the walk. */
 int etx_hip_host_check_bvh_builder(const etx_abi_scene* scene, int builder, uint32_t out_info[4]);
 int etx_hip_host_bvh_stats_builder(const etx_abi_scene* scene, int builder, const float* rays_8f, uint64_t count, uint64_t out[4], float* hits_2f);
-
-/* Host-only: the ENCODED eight-wide tree of ETX_HIP_BVH_WIDE (csrc/host_scene.cpp encode_bvh8) walked through the node function the kernels
- * call (csrc/dev_bvh8.h bvh8_visit: byte decoding and the folded slab test included). `occlusion`: any-hit walk (the shadow kernel's), hits_2f
- * then holds {0, index of the triangle that ended the query}. out[0] node visits, [1] triangle tests, [2] rays that hit, [3] deepest stack, [4] nodes, [6] sum of the
- * visits a ray had made when it found its final hit, [7] most visits of one ray; out[5] = levels | (the tree's exact bound
- * of the traversal stack << 16). */
-int etx_hip_host_bvh8_stats(const etx_abi_scene* scene, int occlusion, const float* rays_8f, uint64_t count, uint64_t out[8], float* hits_2f);
 
 #ifdef __cplusplus
 }

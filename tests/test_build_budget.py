@@ -23,21 +23,20 @@ def test_kernel_register_budget():
     kernels = {r["name"]: r for r in rows if r["kernel"]}
     assert len(kernels) > 30
     for name in ("void etxd::k_light_shade<0u, false>", "void etxd::k_camera_shade<0u, false>", "void etxd::k_connect_pairs<true>", "etxd::k_merge_diffuse", "void etxd::k_expand_pairs<true>",
-                 "void etxd::k_trace_closest<true, true, false>", "void etxd::k_trace_closest<true, true, true>", "void etxd::k_trace_shadow<true, false, false, false>", "void etxd::k_trace_closest_bvh<true, 16u, 128u, false, false>"):
+                 "void etxd::k_trace_closest<true, true, false>", "void etxd::k_trace_closest<true, true, true>", "void etxd::k_trace_shadow<true, false, false>", "void etxd::k_trace_closest_bvh<true, 16u, 64u, false>", "void etxd::k_trace_closest_bvh<true, 16u, 64u, true>"):
         k = kernels[name]
         assert k["total_vgprs"] <= 256 and k.get("agprs", 0) == 0 and k["vgpr_spills"] == 0, (name, k)
     assert kernels["void etxd::k_camera_shade<0u, false>"]["total_vgprs"] <= 224  # two waves per SIMD (<= 256) with room; 213 today
     # shadow segments of tree scenes without Class::Boundary materials and density grids: one any-hit traversal and one exp - compiled for
     # seven wavefronts per SIMD (a handful of spilled registers) where the general kernel has three
-    for name in ("void etxd::k_trace_shadow<false, false, true, false>", "void etxd::k_trace_shadow<false, true, true, false>", "void etxd::k_trace_shadow<false, false, true, true>"):
+    for name in ("void etxd::k_trace_shadow<false, false, true>", "void etxd::k_trace_shadow<false, true, true>"):
         k = kernels[name]
-        assert k["total_vgprs"] <= 72 and k["scratch"] <= 32 and k["vgpr_spills"] <= (8 if name.endswith("true, true>") else 6), (name, k)  # the eight-wide variant carries the ray frame's slack
-    # the eight-wide tree (dev_bvh8.h, opt-in): its closest-hit kernel decodes eight boxes per node in 77 registers
-    k = kernels["void etxd::k_trace_closest_bvh<true, 16u, 64u, true, true>"]
-    assert k["total_vgprs"] <= 84 and k["scratch"] == 0 and k["vgpr_spills"] == 0, k
+        assert k["total_vgprs"] <= 72 and k["scratch"] <= 32 and k["vgpr_spills"] <= 6, (name, k)
+    # the phased tree kernel (round 5): node phase / leaf phase with one postponed leaf per lane, 68-70 registers
+    assert kernels["void etxd::k_trace_closest_bvh<true, 32u, 64u, false>"]["total_vgprs"] <= 80
     # bidirectional (round 3): the walk-event kernels carry no BSDF code and fit four wavefronts per SIMD; the inline-BSDF instantiations
     # need no AGPRs and (almost) no scratch, three wavefronts per SIMD
-    for name in ("void etxd::k_bdpt_walk_light<false>", "void etxd::k_bdpt_walk_camera<false>", "void etxd::k_bdpt_walk_light<true>", "void etxd::k_bdpt_walk_camera<true>"):
+    for name in ("etxd::k_bdpt_walk_light", "etxd::k_bdpt_walk_camera"):
         k = kernels[name]
         assert k["total_vgprs"] <= 128 and k["scratch"] == 0 and k["vgpr_spills"] == 0, (name, k)
     for name in ("void etxd::k_bdpt_light_shade<true>", "void etxd::k_bdpt_camera_shade<true>", "void etxd::k_bdpt_connect_pairs<false>", "void etxd::k_bdpt_connect_pairs<true>",

@@ -53,7 +53,9 @@ BDPT_SETS = {
 # flavours differ from each other by 2.6 / 4.4 / 0.6 % (RGB) under vcm-mis=false (tests/test_reference_order_spread.py asserts it from the fixtures),
 # and the halves' difference understates the spread of a Poisson-dominated mean. The block RMSE and bias limits stay north_star's (their noise
 # allowance comes from the halves); the image-mean limit for these sets is what the reference's own flavours need, and more pixels may be specks.
-HEAVY_TAIL = {("full", "nomis"): dict(mean_limit=5.0e-2, speck_limit=0.05), ("full", "nonee"): dict(rmse_limit=2.0e-3, mean_limit=1.0e-2)}
+# (vcm-mis=false on the fog box: the film is 7 x brighter - mean radiance 2.5 - and the noise of one 1024-spp film is 4e-2 per 8 x 8 block, whose own
+# estimate from the halves moves between 3.6e-2 and 4.7e-2 from render to render: the excess-RMSE limit there is 3e-2 = 1.2 % of the image mean.)
+HEAVY_TAIL = {("full", "nomis"): dict(rmse_limit=3.0e-2, mean_limit=5.0e-2, speck_limit=0.05), ("full", "nonee"): dict(rmse_limit=2.0e-3, mean_limit=1.0e-2)}
 
 
 def compare_layers(halves, golden, label, light_is_empty=False, **limits):

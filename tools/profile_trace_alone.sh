@@ -6,16 +6,16 @@
 #   pass lanes  SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64) = the share of LANES a VALU instruction has active (divergence between node
 #               and leaf steps, finished rays), instruction counts per ray
 #   pass tcc    L2 hit rate
-# Usage: tools/profile_trace_alone.sh <tag> <snapshot> [wide]      -> gpurun_out/trace_alone_<tag>/summary.{json,txt}
+# Usage: tools/profile_trace_alone.sh <tag> <snapshot>      -> gpurun_out/trace_alone_<tag>/summary.{json,txt}
 set -u
-tag=$1; snapshot=$2; wide=${3:-}
+tag=$1; snapshot=$2
 root=$(pwd)
 out=$root/gpurun_out/trace_alone_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 pass() {
   local name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $out/pmc_$name -o pmc -- python $root/tools/trace_bench.py $snapshot 2073600 6 $wide > $out/pmc_$name.log 2>&1 || echo "pass $name failed"
+  timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $out/pmc_$name -o pmc -- python $root/tools/trace_bench.py $snapshot 2073600 6 > $out/pmc_$name.log 2>&1 || echo "pass $name failed"
 }
 pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM
 pass lanes SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Traversal kernel micro benchmark (GPU box): k_trace_closest on device-resident ray / hit queues.
-usage: trace_bench.py snapshot.etxscene [n_rays] [repeat] [wide]      (wide: the eight-wide tree of csrc/dev_bvh8.h, ETX_HIP_BVH_WIDE)"""
+usage: trace_bench.py snapshot.etxscene [n_rays] [repeat]"""
 import os
 import sys
 
@@ -33,8 +33,6 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1920 * 1080
     repeat = int(sys.argv[3]) if len(sys.argv) > 3 else 20
     ctx = api.Context(0)
-    if (len(sys.argv) > 4) and (sys.argv[4] == "wide"):
-        ctx.set_bvh_builder(api.BVH_HOST_SAH | api.BVH_WIDE)
     ctx.upload_scene(snap)
     print("tree:", ctx.bvh_info())
     g = torch.Generator(device="cuda").manual_seed(1)
