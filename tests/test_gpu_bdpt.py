@@ -25,8 +25,10 @@ def load(golden_dir, name):
 
 
 def render_halves(etx, golden_dir, flavour, spp, options, cie=None, debug_flags=0):
-    films = []
-    for first in (0, 1):
+    """The two interleaved halves of the iteration set, rendered concurrently by two contexts (as tests/test_gpu_parity_hi.py render_halves)."""
+    import concurrent.futures
+
+    def half(first):
         snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_%s_128.etxscene" % flavour))
         snap.samples = spp
         integ = etx.HIPBidirectional(snap, first_iteration=first, iteration_stride=2)
@@ -38,6 +40,12 @@ def render_halves(etx, golden_dir, flavour, spp, options, cie=None, debug_flags=
         cam, light = integ.film(etx.api.LAYER_CAMERA), integ.film(etx.api.LAYER_LIGHT)
         stats = integ.status()
         integ.context.close()
+        return cam, light, stats
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as pool:
+        results = list(pool.map(half, (0, 1)))
+    films = []
+    for cam, light, stats in results:
         assert stats.completed_iterations == spp // 2 and stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
         assert np.isfinite(cam).all() and np.isfinite(light).all()
         films.append((cam, light))

@@ -93,9 +93,12 @@ def compare(halves, reference, label, rmse_limit=1.0e-3, mean_limit=3.0e-3, bias
 
 
 def render_halves(etx, golden_dir, flavour, cie, integrator_class, options, debug_flags=0, bluenoise=None, spp=SPP, want_stats=None):
-    """Iterations 0, 2, 4, ... and 1, 3, 5, ... of the `spp`-iteration set: two contexts, etx_hip_begin(first, stride 2)."""
-    films = []
-    for first in (0, 1):
+    """Iterations 0, 2, 4, ... and 1, 3, 5, ... of the `spp`-iteration set: two contexts, etx_hip_begin(first, stride 2). The two halves render
+    CONCURRENTLY (two host threads, two contexts on the one device: a 128 x 128 frame leaves most of an MI355X idle, and the two contexts are
+    independent by construction - which this also exercises); the ctypes calls release the interpreter lock."""
+    import concurrent.futures
+
+    def half(first):
         snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_%s_128.etxscene" % flavour))
         snap.samples = spp
         snap.noise_threshold = 0.0  # the 4096-spp PT films were rendered with --noise-threshold 0 (every pixel gets every sample)
@@ -110,6 +113,12 @@ def render_halves(etx, golden_dir, flavour, cie, integrator_class, options, debu
         cam, light = integ.film(etx.api.LAYER_CAMERA), integ.film(etx.api.LAYER_LIGHT)
         stats = integ.status()
         integ.context.close()
+        return cam, light, stats
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as pool:
+        results = list(pool.map(half, (0, 1)))
+    films = []
+    for cam, light, stats in results:
         assert stats.completed_iterations == spp // 2 and stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
         assert np.isfinite(cam).all() and np.isfinite(light).all()
         films.append((cam, light))

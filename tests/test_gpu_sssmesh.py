@@ -23,8 +23,10 @@ def load(golden_dir, name):
 
 
 def render_halves(etx, golden_dir, cls, spp, options, christensen_burley=False):
-    films = []
-    for first in (0, 1):
+    """The two interleaved halves of the iteration set, rendered concurrently by two contexts (as tests/test_gpu_parity_hi.py render_halves)."""
+    import concurrent.futures
+
+    def half(first):
         snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_sssmesh_128.etxscene"))
         snap.samples = spp
         snap.noise_threshold = 0.0
@@ -39,6 +41,12 @@ def render_halves(etx, golden_dir, cls, spp, options, christensen_burley=False):
         stats = integ.status()
         info = integ.context.bvh_info()
         integ.context.close()
+        return cam, light, stats, info
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as pool:
+        results = list(pool.map(half, (0, 1)))
+    films = []
+    for cam, light, stats, info in results:
         assert info["triangles"] == 21772 and info["nodes"] > 1000  # the tree, not the flat sweep
         assert stats.completed_iterations == spp // 2 and stats.overflow_flags == 0 and stats.nonfinite_dropped == 0
         assert np.isfinite(cam).all() and np.isfinite(light).all()
