@@ -65,6 +65,15 @@ def cpu_baseline(snapshot_path, width, height, seconds_budget=25.0, integrator="
     }
 
 
+def flush_c_stdio():
+    """RCCL (and HIP) write diagnostics through C stdio, which is block-buffered when stdout is a pipe and flushed at exit - after Python's own output."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def library_sha16():
     import hashlib
     from etx_tracer_amd import api
@@ -160,6 +169,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
         multi_gpu.init_context_comm(ctx, rank, world)
     elif args.comm_single:
         ctx.comm_init(0, 1, api.comm_unique_id(ctx.library))
+    flush_c_stdio()  # the communicator's banner (every rank that printed one) goes out now, not behind the JSON line
 
     # VCMOptions::default_values(): blue noise on. The C++ host tabulates its BNSampler for the class of scene.samples
     # (64 -> set 6, include/etx_hip.h); here the same table comes from the committed fixture of the reference's sampler.
@@ -455,6 +465,9 @@ def main(argv=None, context_factory=None, backend="nccl"):
                                                 extra=(tuple(cpu_extra) + ("--opt", "bdpt-mode=3")) if bdpt_workload else ())
             if cpu_snapshot_path != snapshot_path:
                 os.remove(cpu_snapshot_path)
+        # RCCL prints its version banner on C stdio when the first communicator is created; C stdio is flushed at exit, i.e. AFTER Python's
+        # line - flush it now so that the JSON line is the last thing on stdout (the driver reads one JSON line)
+        flush_c_stdio()
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

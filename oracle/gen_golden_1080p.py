@@ -7,7 +7,7 @@ through the prebuilt oracle binary on the many-core host of the GPU box and keep
 
   cornell_full_1080p_vcm_64_blocks[_asis].npz        configs[1]: 64 VCM iterations, vcm-blue_noise=false
   cornell_full_1080p_vcm_64_blocks_bluenoise[_asis].npz   configs[1] with VCMOptions::default_values() (blue noise on): job full_bn
-  cornell_gems_1080p_vcm_32_blocks.npz               configs[2]: 32 VCM iterations (job gems32)
+  cornell_gems_1080p_vcm_32_blocks.npz               configs[2]: 32 VCM iterations (job gems32); ..._128_blocks.npz: 128 iterations (job gems128)
   cornell_sssdragon_1080p_bdpt3_16_blocks[_asis].npz configs[3]: 16 BDPTFull iterations of the scene tools/synthetic_scenes.py sss_dragon
                                                      assembles (written out with SceneSnapshot.save for the driver)
   cornell_cloud_2048_bdpt3_8_blocks[_asis].npz       configs[4]:  8 BDPTFull iterations, 256^3 density grid (--inject-density 256)
@@ -38,6 +38,7 @@ JOBS = {
     "full": ("full_1080p", "vcm", 64, ["--opt", "vcm-blue_noise=false"], "cornell_full_1080p_vcm_64_blocks"),
     "full_bn": ("full_1080p", "vcm", 64, [], "cornell_full_1080p_vcm_64_blocks_bluenoise"),  # VCMOptions defaults: what bench.py times
     "gems32": ("gems_1080p", "vcm", 32, ["--opt", "vcm-blue_noise=false"], "cornell_gems_1080p_vcm_32_blocks"),
+    "gems128": ("gems_1080p", "vcm", 128, ["--opt", "vcm-blue_noise=false"], "cornell_gems_1080p_vcm_128_blocks"),  # round 5: 23 min on the container's 8 cores
     "sssdragon": ("sssdragon", "bdpt", 16, ["--opt", "bdpt-blue_noise=false", "--opt", "bdpt-mode=3"], "cornell_sssdragon_1080p_bdpt3_16_blocks"),
     "cloud": ("cloud_2048", "bdpt", 8, ["--opt", "bdpt-blue_noise=false", "--opt", "bdpt-mode=3", "--inject-density", "256"], "cornell_cloud_2048_bdpt3_8_blocks"),
 }
