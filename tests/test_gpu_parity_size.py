@@ -88,7 +88,7 @@ def test_config2_gems_1080p_matches_reference_at_size(etx, golden_dir, cie_obser
     golden = np.load(os.path.join(golden_dir, "cornell_gems_1080p_vcm_128_blocks.npz"))
     assert int(golden["spp"]) == 128
     cam, light = render(etx, golden_dir, "gems", 128, cie_observer)
-    compare(cam + light, golden["camera"] + golden["light"], "gems 1080p camera+light", 5.0e-3, 0.01, 0.03)
+    compare(cam + light, golden["camera"] + golden["light"], "gems 1080p camera+light", 5.0e-3, 0.007, 0.025)  # measured (GPU call r5h): -0.03 / +0.19 / -0.03 %, 0.42 %, 1.6 %
 
 
 def test_config1_full_1080p_matches_unmodified_reference_at_size(etx, golden_dir):
