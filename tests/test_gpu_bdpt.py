@@ -25,9 +25,7 @@ def load(golden_dir, name):
 
 
 def render_halves(etx, golden_dir, flavour, spp, options, cie=None, debug_flags=0):
-    """The two interleaved halves of the iteration set, rendered concurrently by two contexts (as tests/test_gpu_parity_hi.py render_halves)."""
-    import concurrent.futures
-
+    """The two interleaved halves of the iteration set, two contexts one after the other (as tests/test_gpu_parity_hi.py render_halves)."""
     def half(first):
         snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_%s_128.etxscene" % flavour))
         snap.samples = spp
@@ -42,8 +40,10 @@ def render_halves(etx, golden_dir, flavour, spp, options, cie=None, debug_flags=
         integ.context.close()
         return cam, light, stats
 
-    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as pool:
-        results = list(pool.map(half, (0, 1)))
+    # one after the other: rendering the halves from two host threads at once made the suite 10 % shorter and crashed the interpreter in one of five
+    # full runs (GPU call r5k; not reproduced with the fault handler on) - two contexts driven CONCURRENTLY from one process are not something the
+    # product promises, so the tests do not do it
+    results = [half(0), half(1)]
     films = []
     for cam, light, stats in results:
         assert stats.completed_iterations == spp // 2 and stats.overflow_flags == 0 and stats.nonfinite_dropped == 0

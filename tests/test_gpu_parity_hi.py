@@ -93,11 +93,7 @@ def compare(halves, reference, label, rmse_limit=1.0e-3, mean_limit=3.0e-3, bias
 
 
 def render_halves(etx, golden_dir, flavour, cie, integrator_class, options, debug_flags=0, bluenoise=None, spp=SPP, want_stats=None):
-    """Iterations 0, 2, 4, ... and 1, 3, 5, ... of the `spp`-iteration set: two contexts, etx_hip_begin(first, stride 2). The two halves render
-    CONCURRENTLY (two host threads, two contexts on the one device: a 128 x 128 frame leaves most of an MI355X idle, and the two contexts are
-    independent by construction - which this also exercises); the ctypes calls release the interpreter lock."""
-    import concurrent.futures
-
+    """Iterations 0, 2, 4, ... and 1, 3, 5, ... of the `spp`-iteration set: two contexts, etx_hip_begin(first, stride 2), one after the other."""
     def half(first):
         snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_%s_128.etxscene" % flavour))
         snap.samples = spp
@@ -115,8 +111,10 @@ def render_halves(etx, golden_dir, flavour, cie, integrator_class, options, debu
         integ.context.close()
         return cam, light, stats
 
-    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as pool:
-        results = list(pool.map(half, (0, 1)))
+    # one after the other: rendering the halves from two host threads at once made the suite 10 % shorter and crashed the interpreter in one of five
+    # full runs (GPU call r5k; not reproduced with the fault handler on) - two contexts driven CONCURRENTLY from one process are not something the
+    # product promises, so the tests do not do it
+    results = [half(0), half(1)]
     films = []
     for cam, light, stats in results:
         assert stats.completed_iterations == spp // 2 and stats.overflow_flags == 0 and stats.nonfinite_dropped == 0

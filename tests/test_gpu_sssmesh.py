@@ -23,9 +23,7 @@ def load(golden_dir, name):
 
 
 def render_halves(etx, golden_dir, cls, spp, options, christensen_burley=False):
-    """The two interleaved halves of the iteration set, rendered concurrently by two contexts (as tests/test_gpu_parity_hi.py render_halves)."""
-    import concurrent.futures
-
+    """The two interleaved halves of the iteration set, two contexts one after the other (as tests/test_gpu_parity_hi.py render_halves)."""
     def half(first):
         snap = etx.SceneSnapshot(os.path.join(golden_dir, "cornell_sssmesh_128.etxscene"))
         snap.samples = spp
@@ -43,8 +41,10 @@ def render_halves(etx, golden_dir, cls, spp, options, christensen_burley=False):
         integ.context.close()
         return cam, light, stats, info
 
-    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as pool:
-        results = list(pool.map(half, (0, 1)))
+    # one after the other: rendering the halves from two host threads at once made the suite 10 % shorter and crashed the interpreter in one of five
+    # full runs (GPU call r5k; not reproduced with the fault handler on) - two contexts driven CONCURRENTLY from one process are not something the
+    # product promises, so the tests do not do it
+    results = [half(0), half(1)]
     films = []
     for cam, light, stats, info in results:
         assert info["triangles"] == 21772 and info["nodes"] > 1000  # the tree, not the flat sweep
