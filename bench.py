@@ -208,7 +208,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
             # stream; the lanes keep rendering. (The last one of the region is the blocking etx_hip_reduce_film below.)
             if (args.reduce_every > 0) and ((step + 1) % args.reduce_every == 0) and (step + 1 < count):
                 t_reduce = time.perf_counter()
-                ctx.reduce_film_begin()  # waits only if the previous reduce is still running
+                ctx.reduce_film_begin()  # never waits: any number of reduces may be in flight, the communication stream orders them
                 host_blocked += time.perf_counter() - t_reduce
         ctx.sync()
         s = ctx.stats()             # totals since begin

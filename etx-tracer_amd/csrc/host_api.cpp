@@ -4,6 +4,7 @@
 
 #include "host_scene.h"
 #include "host_reduce.h"
+#include "host_transfer.h"
 #include "kernels_bvh_build.h"
 #include "kernels.h"
 #include "dev_bvh.h"
@@ -148,6 +149,7 @@ struct etx_hip_context {
   size_t read_pixels = 0;
   bool read_pending = false;
   void* comm = nullptr;  // ncclComm_t (host_comm.cpp)
+  etxh::HostTransfer transfer;  // public context: every host <-> device copy of caller-owned memory goes through its pinned slots (host_transfer.h)
   int rank = 0, world = 1;
 
   // Asynchronous execution. A context is a set of LANES: the public context itself plus helper contexts, each with its
@@ -187,6 +189,14 @@ namespace {
       (ctx)->error = std::string(#call) + " failed: " + hipGetErrorString(e_);           \
       return ETX_HIP_ERROR_HIP;                                                           \
     }                                                                                     \
+  } while (0)
+
+#define TRANSFER_OK(ctx, call)                \
+  do {                                        \
+    if (int rc_ = (call)) {                   \
+      (void)(ctx);                            \
+      return rc_;                             \
+    }                                         \
   } while (0)
 
 template <class T>
@@ -1174,7 +1184,7 @@ int init_lane(etx_hip_context* lane, int device, std::string& error) {
   return ETX_HIP_OK;
 }
 
-void destroy_lane(etx_hip_context* lane) {
+void stop_lane_worker(etx_hip_context* lane) {
   if (lane->worker.joinable()) {
     {
       std::lock_guard<std::mutex> lock(lane->lane_mutex);
@@ -1183,6 +1193,10 @@ void destroy_lane(etx_hip_context* lane) {
     lane->lane_cv.notify_all();
     lane->worker.join();
   }
+}
+
+void destroy_lane(etx_hip_context* lane) {
+  stop_lane_worker(lane);
   if (lane->stream)
     (void)hipStreamSynchronize(lane->stream);
   release_pipeline(lane);
@@ -1246,6 +1260,7 @@ int etx_hip_create(int device, etx_hip_context** out_context) {
     return ETX_HIP_ERROR_HIP;
   }
   auto ctx = std::make_unique<etx_hip_context>();
+  ctx->scene.transfer = &ctx->transfer;
   int rc = init_lane(ctx.get(), device, g_create_error);
   // ETX_HIP_LANES: iterations in flight. Measured at 1080p (fog Cornell): 1 lane 55, 2 lanes 78, 3 lanes 89, 4 lanes 92,
   // 6 lanes 93 Msamples/s - the thin tails and small bounces of one iteration hide behind the wide bounces of the others.
@@ -1277,12 +1292,18 @@ void etx_hip_destroy(etx_hip_context* context) {
   if (context == nullptr)
     return;
   (void)hipSetDevice(context->device);
+  // iterations still in flight finish first: their commits use the reduce state (CommitSection) that etx_hip_comm_destroy_internal tears down,
+  // and every lane's worker - the public lane's too - is joined before that
+  (void)wait_idle(context);
+  for (etx_hip_context* helper : context->helpers)
+    stop_lane_worker(helper);
+  stop_lane_worker(context);
+  etx_hip_comm_destroy_internal(context);
   for (etx_hip_context* helper : context->helpers) {
     destroy_lane(helper);
     delete helper;
   }
   context->helpers.clear();
-  etx_hip_comm_destroy_internal(context);
   destroy_lane(context);
   for (uint8_t* table : context->bluenoise)
     if (table)
@@ -1299,6 +1320,7 @@ void etx_hip_destroy(etx_hip_context* context) {
     (void)hipEventDestroy(context->read_event);
   if (context->read_stream)
     (void)hipStreamDestroy(context->read_stream);
+  context->transfer.release();
   delete context;
 }
 
@@ -1314,6 +1336,10 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
     (void)hipEventSynchronize(context->read_event);
     context->read_pending = false;
   }
+  // a reduce in flight reads the film sums allocate_pipeline is about to free, and the reduced copy is the OLD scene's film:
+  // wait for it, forget it; the buffers follow the new film size below
+  if (int reset_rc = etx_hip_internal_reduce_reset(context))
+    return reset_rc;
   for (etx_hip_context* helper : context->helpers)
     release_pipeline(helper);
   int rc = etxh::build_device_scene(scene, camera, context->scene, context->error);
@@ -1327,6 +1353,10 @@ int etx_hip_upload_scene(etx_hip_context* context, const etx_abi_scene* scene, c
     return rc;
   HIP_OK(context, hipDeviceSynchronize());
   context->scene_ready = true;
+  if (context->comm != nullptr) {  // the reduce buffers at the new film size: a rank finds out here, not inside a collective, that it cannot take part
+    if ((rc = etx_hip_internal_reduce_allocate(context)))
+      return rc;
+  }
   return ETX_HIP_OK;
 }
 
@@ -1376,6 +1406,8 @@ int etx_hip_update_scene(etx_hip_context* context, const etx_abi_scene* scene, c
     (void)hipEventSynchronize(context->read_event);
     context->read_pending = false;
   }
+  if (int reset_rc = etx_hip_internal_reduce_reset(context))  // as etx_hip_upload_scene: the film sums are reallocated below
+    return reset_rc;
   // the tables (materials, spectra, emitters, media parameters, scene scalars, camera) are small and always rebuilt; vertices,
   // triangles, BVH, image pixels and density grids stay on the device
   int rc = etxh::build_device_scene(scene, camera, context->scene, context->error, /* keep geometry and images */ true);
@@ -1421,7 +1453,7 @@ int etx_hip_upload_bluenoise(etx_hip_context* context, uint32_t set_index, const
   HIP_OK(context, hipSetDevice(context->device));
   if (context->bluenoise[set_index] == nullptr)
     HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&context->bluenoise[set_index]), kTableBytes));
-  HIP_OK(context, hipMemcpy(context->bluenoise[set_index], values, kTableBytes, hipMemcpyHostToDevice));
+  TRANSFER_OK(context, context->transfer.to_device(context->bluenoise[set_index], values, kTableBytes, nullptr, context->error));
   return ETX_HIP_OK;
 }
 
@@ -1460,7 +1492,7 @@ int etx_hip_upload_cie_table(etx_hip_context* context, const float* xyz, uint32_
     (void)hipFree(context->cie_table);
   context->cie_table = nullptr;
   HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&context->cie_table), count * sizeof(float4)));
-  HIP_OK(context, hipMemcpy(context->cie_table, table.data(), count * sizeof(float4), hipMemcpyHostToDevice));
+  TRANSFER_OK(context, context->transfer.to_device(context->cie_table, table.data(), count * sizeof(float4), nullptr, context->error));
   context->cie_count = count;
   context->cie_first = first_wavelength;
   context->cie_y_scale = (y_sum > 0.0f) ? 1.0f / y_sum : 0.0f;
@@ -1480,7 +1512,7 @@ int etx_hip_upload_rgb_response(etx_hip_context* context, const float* rgb, uint
     (void)hipFree(context->rgb_response_table);
   context->rgb_response_table = nullptr;
   HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&context->rgb_response_table), count * sizeof(float4)));
-  HIP_OK(context, hipMemcpy(context->rgb_response_table, table.data(), count * sizeof(float4), hipMemcpyHostToDevice));
+  TRANSFER_OK(context, context->transfer.to_device(context->rgb_response_table, table.data(), count * sizeof(float4), nullptr, context->error));
   context->rgb_response_count = count;
   context->rgb_response_first = first_wavelength;
   return ETX_HIP_OK;
@@ -1822,13 +1854,12 @@ int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size
       if (rc < 0)
         return rc;
     }
-    if (context->reduce.valid) {
+    if (context->reduce.valid && (context->reduce.pixels == n)) {
       const EtxReduceState& r = context->reduce;
       const float4* source = (layer == ETX_HIP_LAYER_NORMAL) ? r.reduced + 2u * n : ((layer == ETX_HIP_LAYER_ALBEDO) ? r.reduced + 3u * n : r.reduced);
       const int mode = (layer == ETX_HIP_LAYER_NORMAL) ? 3 : ((layer == ETX_HIP_LAYER_ALBEDO) ? 0 : layer);
       launch_film_resolve(r.stream, source, r.reduced + n, context->resolve_buffer, uint32_t(n), 0.0f, mode, r.reduced);
-      HIP_OK(context, hipMemcpyAsync(dst_rgba, context->resolve_buffer, dst_bytes, hipMemcpyDeviceToHost, r.stream));
-      HIP_OK(context, hipStreamSynchronize(r.stream));
+      TRANSFER_OK(context, context->transfer.to_host(dst_rgba, context->resolve_buffer, dst_bytes, r.stream, context->error));
       return ETX_HIP_OK;
     }
   }
@@ -1845,8 +1876,7 @@ int etx_hip_read_film(etx_hip_context* context, int layer, float* dst_rgba, size
     launch_film_resolve(context->stream, context->pipe.albedo_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, 0, counts);
   else
     launch_film_resolve(context->stream, context->pipe.camera_sum, context->pipe.light_sum, context->resolve_buffer, uint32_t(n), scale, layer, counts);
-  HIP_OK(context, hipMemcpyAsync(dst_rgba, context->resolve_buffer, dst_bytes, hipMemcpyDeviceToHost, context->stream));
-  HIP_OK(context, hipStreamSynchronize(context->stream));
+  TRANSFER_OK(context, context->transfer.to_host(dst_rgba, context->resolve_buffer, dst_bytes, context->stream, context->error));
   return ETX_HIP_OK;
 }
 
@@ -1886,7 +1916,7 @@ int etx_hip_read_film_begin(etx_hip_context* context, int layer) {
     context->read_pixels = n;
   }
   const int mode = (layer == ETX_HIP_LAYER_NORMAL) ? 3 : ((layer == ETX_HIP_LAYER_ALBEDO) ? 0 : layer);
-  if ((context->comm != nullptr) && context->reduce.valid) {
+  if ((context->comm != nullptr) && context->reduce.valid && (context->reduce.pixels == n)) {
     // the reduced copy (whole job): behind the newest reduce on the communication stream - also one that is still in flight, whose result this
     // read-back then returns; the next reduce waits for this read (etx_hip_internal_reduce_prepare)
     const EtxReduceState& r = context->reduce;
@@ -2035,13 +2065,12 @@ int etx_hip_checkpoint_save(etx_hip_context* context, void* dst, size_t dst_byte
   uint8_t* out = static_cast<uint8_t*>(dst);
   memcpy(out, &header, sizeof(header));
   out += sizeof(header);
-  HIP_OK(context, hipMemcpyAsync(out, context->pipe.camera_sum, n * kFilmLayers * sizeof(float4), hipMemcpyDeviceToHost, context->stream));
+  TRANSFER_OK(context, context->transfer.to_host(out, context->pipe.camera_sum, n * kFilmLayers * sizeof(float4), context->stream, context->error));
   out += n * kFilmLayers * sizeof(float4);
   if (header.adaptive) {
-    HIP_OK(context, hipMemcpyAsync(out, context->pipe.adaptive_sum, n * sizeof(float4), hipMemcpyDeviceToHost, context->stream));
-    HIP_OK(context, hipMemcpyAsync(out + n * sizeof(float4), context->pipe.pixel_state, n * sizeof(uint32_t), hipMemcpyDeviceToHost, context->stream));
+    TRANSFER_OK(context, context->transfer.to_host(out, context->pipe.adaptive_sum, n * sizeof(float4), context->stream, context->error));
+    TRANSFER_OK(context, context->transfer.to_host(out + n * sizeof(float4), context->pipe.pixel_state, n * sizeof(uint32_t), context->stream, context->error));
   }
-  HIP_OK(context, hipStreamSynchronize(context->stream));
   return ETX_HIP_OK;
 }
 
@@ -2076,13 +2105,12 @@ int etx_hip_checkpoint_load(etx_hip_context* context, const void* src, size_t sr
   HIP_OK(context, hipSetDevice(context->device));
   const size_t n = context->pipe.capacity;
   const uint8_t* in = static_cast<const uint8_t*>(src) + sizeof(header);
-  HIP_OK(context, hipMemcpyAsync(context->pipe.camera_sum, in, n * kFilmLayers * sizeof(float4), hipMemcpyHostToDevice, context->stream));
+  TRANSFER_OK(context, context->transfer.to_device(context->pipe.camera_sum, in, n * kFilmLayers * sizeof(float4), context->stream, context->error));
   in += n * kFilmLayers * sizeof(float4);
   if (adaptive) {
-    HIP_OK(context, hipMemcpyAsync(context->pipe.adaptive_sum, in, n * sizeof(float4), hipMemcpyHostToDevice, context->stream));
-    HIP_OK(context, hipMemcpyAsync(context->pipe.pixel_state, in + n * sizeof(float4), n * sizeof(uint32_t), hipMemcpyHostToDevice, context->stream));
+    TRANSFER_OK(context, context->transfer.to_device(context->pipe.adaptive_sum, in, n * sizeof(float4), context->stream, context->error));
+    TRANSFER_OK(context, context->transfer.to_device(context->pipe.pixel_state, in + n * sizeof(float4), n * sizeof(uint32_t), context->stream, context->error));
   }
-  HIP_OK(context, hipStreamSynchronize(context->stream));
   context->next_iteration = header.next_iteration;
   context->local_iterations = header.local_iterations;
   context->reduce.valid = false;  // a reduced copy of the film before the load no longer describes this context's run
@@ -2162,15 +2190,14 @@ int etx_hip_trace_rays(etx_hip_context* context, const float* rays_8f, uint64_t 
   HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&d_h), count * sizeof(float4)));
   int rc = ETX_HIP_OK;
   do {
-    if ((hipMemcpyAsync(d_o, o.data(), count * sizeof(float4), hipMemcpyHostToDevice, context->stream) != hipSuccess) ||
-        (hipMemcpyAsync(d_d, d.data(), count * sizeof(float4), hipMemcpyHostToDevice, context->stream) != hipSuccess)) {
-      context->error = "ray upload failed";
+    if (context->transfer.to_device(d_o, o.data(), count * sizeof(float4), context->stream, context->error) ||
+        context->transfer.to_device(d_d, d.data(), count * sizeof(float4), context->stream, context->error)) {
       rc = ETX_HIP_ERROR_HIP;
       break;
     }
     launch_trace_rays(context->stream, context->pipe.scene, d_o, d_d, d_h, uint32_t(count), context->scene.host_copy.bvh_flat != 0u, context->debug_flags);
-    if ((hipMemcpyAsync(hits_4f, d_h, count * sizeof(float4), hipMemcpyDeviceToHost, context->stream) != hipSuccess) || (hipStreamSynchronize(context->stream) != hipSuccess)) {
-      context->error = std::string("trace kernel failed: ") + hipGetErrorString(hipGetLastError());
+    if (context->transfer.to_host(hits_4f, d_h, count * sizeof(float4), context->stream, context->error)) {
+      context->error = "trace kernel failed: " + context->error;
       rc = ETX_HIP_ERROR_HIP;
     }
   } while (false);
@@ -2224,11 +2251,12 @@ int etx_hip_selftest_stack(etx_hip_context* context, uint32_t depth, uint32_t* o
   }
   (void)hipMemsetAsync(errors, 0, sizeof(uint32_t), context->stream);
   launch_stack_selftest(context->stream, spill, lanes, blocks, depth, errors);
-  const hipError_t copied = hipMemcpyAsync(out_errors, errors, sizeof(uint32_t), hipMemcpyDeviceToHost, context->stream);
+  const int copied = context->transfer.to_host(out_errors, errors, sizeof(uint32_t), context->stream, context->error);
   const hipError_t synced = hipStreamSynchronize(context->stream);
   (void)hipFree(spill);
   (void)hipFree(errors);
-  HIP_OK(context, copied);
+  if (copied)
+    return copied;
   HIP_OK(context, synced);
   return ETX_HIP_OK;
 }
@@ -2257,16 +2285,13 @@ int etx_hip_kat(etx_hip_context* context, int which, const float* in, uint64_t c
   HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&d_in), count * in_width[which] * sizeof(float)));
   HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&d_out), count * out_width[which] * sizeof(float)));
   int rc = ETX_HIP_OK;
-  if (hipMemcpyAsync(d_in, in, count * in_width[which] * sizeof(float), hipMemcpyHostToDevice, context->stream) != hipSuccess)
-    rc = ETX_HIP_ERROR_HIP;
+  rc = context->transfer.to_device(d_in, in, count * in_width[which] * sizeof(float), context->stream, context->error);
   if (rc == ETX_HIP_OK) {
     launch_kat(context->stream, which, d_in, uint32_t(count), d_out, bluenoise);
-    if ((hipMemcpyAsync(out, d_out, count * out_width[which] * sizeof(float), hipMemcpyDeviceToHost, context->stream) != hipSuccess) ||
-        (hipStreamSynchronize(context->stream) != hipSuccess))
-      rc = ETX_HIP_ERROR_HIP;
+    rc = context->transfer.to_host(out, d_out, count * out_width[which] * sizeof(float), context->stream, context->error);
   }
   if (rc)
-    context->error = std::string("etx_hip_kat failed: ") + hipGetErrorString(hipGetLastError());
+    context->error = "etx_hip_kat failed: " + context->error;
   (void)hipFree(d_in);
   (void)hipFree(d_out);
   return rc;
@@ -2571,6 +2596,10 @@ int etx_hip_internal_reduce_allocate(etx_hip_context* c) {
 
 void etx_hip_internal_reduce_release(etx_hip_context* c) {
   EtxReduceState& r = c->reduce;
+  {
+    std::lock_guard<std::mutex> lock(r.mutex);  // CommitSection reads the flag on the lanes' threads: no commit waits for an event destroyed below
+    r.snapshot_recorded = false;
+  }
   if (r.stream)
     (void)hipStreamSynchronize(r.stream);
   free_reduce_buffers(r);
@@ -2587,7 +2616,7 @@ void etx_hip_internal_reduce_release(etx_hip_context* c) {
     (void)hipStreamDestroy(r.stream);
   r.stream = nullptr, r.d_counters = nullptr, r.h_counters = nullptr;
   r.pending = 0u;
-  r.valid = r.snapshot_recorded = false;
+  r.valid = false;
 }
 
 // etx_hip_begin: the reduced copy belongs to the run that produced it. A reduce still in flight is waited for (every rank begins the same
@@ -2664,6 +2693,22 @@ int etx_hip_internal_reduce_prepare(etx_hip_context* c, int local_rc, float4** o
   r.layer_mask = layer_mask;
   r.payload_bytes = uint64_t(__builtin_popcount(layer_mask)) * n * sizeof(float4);
   *out_snapshot = r.snapshot, *out_reduced = r.reduced, *out_pixels = n, *out_layer_mask = layer_mask;
+  return ETX_HIP_OK;
+}
+
+// etx_hip_internal_reduce_prepare failed on this rank although the communicator and the buffers exist (a HIP call inside it): the rank still joins the
+// collective the others are entering - with a zero snapshot and its failed flag set - so that every rank returns an error instead of waiting for the
+// RCCL timeout. Non-zero: there is nothing to join with (no scene, no buffers: the documented case of etx_hip.h).
+int etx_hip_internal_reduce_prepare_failed(etx_hip_context* c, float4** out_snapshot, float4** out_reduced, size_t* out_pixels, uint32_t* out_layer_mask) {
+  EtxReduceState& r = c->reduce;
+  if ((r.stream == nullptr) || (r.d_counters == nullptr) || (r.snapshot == nullptr) || (r.reduced == nullptr) || (r.pixels == 0u))
+    return ETX_HIP_ERROR_STATE;
+  const uint32_t layer_mask = (c->integrator == ETX_HIP_INTEGRATOR_VCM) ? 0x3u : ((c->integrator == ETX_HIP_INTEGRATOR_PT) ? 0xdu : 0xfu);
+  if (hipMemsetAsync(r.snapshot, 0, r.pixels * kFilmLayers * sizeof(float4), r.stream) != hipSuccess)
+    return ETX_HIP_ERROR_HIP;
+  launch_set_words(r.stream, r.d_counters, 0ull, 1ull);
+  r.layer_mask = layer_mask;
+  *out_snapshot = r.snapshot, *out_reduced = r.reduced, *out_pixels = r.pixels, *out_layer_mask = layer_mask;
   return ETX_HIP_OK;
 }
 

@@ -26,13 +26,14 @@ int etx_hip_internal_device(etx_hip_context* c);
 int etx_hip_internal_reduce_allocate(etx_hip_context* c);
 void etx_hip_internal_reduce_release(etx_hip_context* c);
 int etx_hip_internal_reduce_prepare(etx_hip_context* c, int local_rc, float4** out_snapshot, float4** out_reduced, size_t* out_pixels, uint32_t* out_layer_mask);
+int etx_hip_internal_reduce_prepare_failed(etx_hip_context* c, float4** out_snapshot, float4** out_reduced, size_t* out_pixels, uint32_t* out_layer_mask);
 int etx_hip_internal_reduce_finish(etx_hip_context* c);
 
 namespace {
 
 // One reduce, enqueued: snapshot, the collectives, the counter read-back. `local_rc`: this rank's own failure so far (travels INTO the collective
 // as its failed flag; reported by reduce_end after the collective, so no rank ever stays out of an all-reduce the others are already in).
-int reduce_begin(etx_hip_context* context, int local_rc, const std::string& local_error) {
+int reduce_begin(etx_hip_context* context, int local_rc, std::string local_error) {
   ncclComm_t comm = reinterpret_cast<ncclComm_t>(*etx_hip_internal_comm(context));
   EtxReduceState* r = etx_hip_internal_reduce(context);
   if (comm == nullptr)
@@ -40,8 +41,17 @@ int reduce_begin(etx_hip_context* context, int local_rc, const std::string& loca
   float4 *snapshot = nullptr, *reduced = nullptr;
   size_t pixels = 0;
   uint32_t layer_mask = 0;
-  if (int rc = etx_hip_internal_reduce_prepare(context, local_rc, &snapshot, &reduced, &pixels, &layer_mask))
-    return rc;  // before any collective call: nothing has been enqueued that another rank could wait for... except the collective itself (see etx_hip.h)
+  if (int rc = etx_hip_internal_reduce_prepare(context, local_rc, &snapshot, &reduced, &pixels, &layer_mask)) {
+    // the other ranks are entering the collective: this rank joins it with a zero snapshot and its failed flag, and reports its error from
+    // etx_hip_reduce_film_end like any other local failure - unless it has nothing to join with (no scene, no buffers: etx_hip.h)
+    const std::string why = etx_hip_last_error(context);
+    if (etx_hip_internal_reduce_prepare_failed(context, &snapshot, &reduced, &pixels, &layer_mask) != ETX_HIP_OK) {
+      etx_hip_internal_set_error(context, why);
+      return rc;
+    }
+    if (local_rc == 0)
+      local_rc = rc, local_error = why;
+  }
   // contiguous runs of layers become one all-reduce each (VCM: [camera, light]; path tracer: [camera], [normal, albedo]; bidirectional: all four)
   ncclResult_t res = ncclGroupStart();
   for (uint32_t layer = 0; (res == ncclSuccess) && (layer < 4u);) {

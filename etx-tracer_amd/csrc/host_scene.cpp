@@ -47,11 +47,13 @@ void DeviceScene::release_tables() {
 }
 
 int DeviceScene::sync_device_copy(std::string& error) {
-  if ((device != nullptr) && (hipMemcpy(device, &host_copy, sizeof(DScene), hipMemcpyHostToDevice) != hipSuccess)) {
-    error = "hipMemcpy of the scene header failed";
-    return ETX_HIP_ERROR_HIP;
+  if (device == nullptr)
+    return 0;
+  if (transfer == nullptr) {
+    error = "internal: the scene has no host transfer object";
+    return ETX_HIP_ERROR_STATE;
   }
-  return 0;
+  return transfer->to_device(device, &host_copy, sizeof(DScene), nullptr, error);
 }
 
 void DeviceScene::borrow(const DeviceScene& owner) {
@@ -260,9 +262,13 @@ int upload(DeviceScene& out, const T* src, size_t count, const T*& dst, std::str
     return ETX_HIP_ERROR_HIP;
   }
   ((out.alloc_group == 1) ? out.geometry_allocations : ((out.alloc_group == 2) ? out.image_allocations : out.allocations)).push_back(p);
-  if ((count > 0) && (hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)) {
-    error = "hipMemcpy failed";
-    return ETX_HIP_ERROR_HIP;
+  if (out.transfer == nullptr) {
+    error = "internal: the scene has no host transfer object";
+    return ETX_HIP_ERROR_STATE;
+  }
+  if (count > 0) {
+    if (int rc = out.transfer->to_device(p, src, count * sizeof(T), nullptr, error))
+      return rc;
   }
   dst = reinterpret_cast<const T*>(p);
   return 0;
@@ -1313,11 +1319,15 @@ int update_device_geometry(const etx_abi_scene* scene, DeviceScene& out, hipStre
     error = "etx_hip_update_scene: the geometry must keep its vertex and triangle counts; use etx_hip_upload_scene";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
-  if (positions_moved &&
-      ((hipMemcpyAsync(const_cast<etx_abi_vertex*>(d.vertices), scene->vertices.a, scene->vertices.count * sizeof(etx_abi_vertex), hipMemcpyHostToDevice, stream) != hipSuccess) ||
-       (hipMemcpyAsync(const_cast<etx_abi_triangle*>(d.triangles), scene->triangles.a, scene->triangles.count * sizeof(etx_abi_triangle), hipMemcpyHostToDevice, stream) != hipSuccess))) {
-    error = "hipMemcpy of the moved vertices failed";
-    return ETX_HIP_ERROR_HIP;
+  if (positions_moved) {
+    if (out.transfer == nullptr) {
+      error = "internal: the scene has no host transfer object";
+      return ETX_HIP_ERROR_STATE;
+    }
+    if (int rc = out.transfer->to_device(const_cast<etx_abi_vertex*>(d.vertices), scene->vertices.a, scene->vertices.count * sizeof(etx_abi_vertex), stream, error))
+      return rc;
+    if (int rc = out.transfer->to_device(const_cast<etx_abi_triangle*>(d.triangles), scene->triangles.a, scene->triangles.count * sizeof(etx_abi_triangle), stream, error))
+      return rc;
   }
   if (positions_moved)
     launch_build_tri_shade(stream, d, const_cast<float4*>(d.tri_shade), d.triangle_count);

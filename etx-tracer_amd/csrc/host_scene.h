@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "dev_scene.h"
+#include "host_transfer.h"
 
 namespace etxh {
 
@@ -41,6 +42,7 @@ struct DeviceScene {
   bool generic_materials = false;  // a connectible (non delta) surface material other than Diffuse is in use
   bool needs_rgb_response = false; // spectral scene with RGB images behind spectra: apply_rgb needs the host's table (etx_hip_upload_rgb_response)
   size_t bvh_bytes = 0;
+  HostTransfer* transfer = nullptr;  // the owning context's pinned transfer slots: every table of the host scene travels through them (host_transfer.h); set before build_device_scene
   uint32_t content_hash = 0;       // of the host tables the scene was built from (materials, emitters, media scalars, a sample of the vertices): etx_hip_checkpoint_*
 
   ~DeviceScene();

@@ -1,0 +1,124 @@
+// host_transfer.cpp - see host_transfer.h
+#include "host_transfer.h"
+
+#include "../../include/etx_hip.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace etxh {
+
+namespace {
+bool ok(hipError_t e, const char* what, std::string& error) {
+  if (e == hipSuccess)
+    return true;
+  error = std::string(what) + " failed: " + hipGetErrorString(e);
+  return false;
+}
+}  // namespace
+
+HostTransfer::~HostTransfer() {
+  release();
+}
+
+void HostTransfer::release() {
+  std::lock_guard<std::mutex> lock(mutex_);
+  if (own_stream_)
+    (void)hipStreamSynchronize(own_stream_);
+  for (int s = 0; s < 2; ++s) {
+    if (slot_free_[s]) {
+      (void)hipEventSynchronize(slot_free_[s]);
+      (void)hipEventDestroy(slot_free_[s]);
+    }
+    if (slots_[s])
+      (void)hipHostFree(slots_[s]);
+    slots_[s] = nullptr, slot_free_[s] = nullptr;
+  }
+  if (own_stream_)
+    (void)hipStreamDestroy(own_stream_);
+  own_stream_ = nullptr;
+}
+
+int HostTransfer::prepare(std::string& error) {
+  if (slots_[0] != nullptr)
+    return 0;
+  if (ok(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking), "hipStreamCreate (host transfer)", error) == false)
+    return ETX_HIP_ERROR_HIP;
+  for (int s = 0; s < 2; ++s) {
+    if ((ok(hipHostMalloc(reinterpret_cast<void**>(&slots_[s]), kSlotBytes, hipHostMallocDefault), "hipHostMalloc (host transfer)", error) == false) ||
+        (ok(hipEventCreateWithFlags(&slot_free_[s], hipEventDisableTiming), "hipEventCreate (host transfer)", error) == false))
+      return ETX_HIP_ERROR_HIP;
+  }
+  return 0;
+}
+
+int HostTransfer::to_device(void* dst_device, const void* src_host, size_t bytes, hipStream_t stream, std::string& error) {
+  if (bytes == 0u)
+    return 0;
+  std::lock_guard<std::mutex> lock(mutex_);
+  if (int rc = prepare(error))
+    return rc;
+  if (stream == nullptr)
+    stream = own_stream_;
+  const unsigned char* src = static_cast<const unsigned char*>(src_host);
+  unsigned char* dst = static_cast<unsigned char*>(dst_device);
+  bool used[2] = {false, false};
+  int slot = 0;
+  for (size_t offset = 0; offset < bytes; offset += kSlotBytes, slot ^= 1) {
+    const size_t n = std::min(kSlotBytes, bytes - offset);
+    if (used[slot] && (ok(hipEventSynchronize(slot_free_[slot]), "hipEventSynchronize (host transfer)", error) == false))
+      return ETX_HIP_ERROR_HIP;
+    memcpy(slots_[slot], src + offset, n);
+    if ((ok(hipMemcpyAsync(dst + offset, slots_[slot], n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync (host to device)", error) == false) ||
+        (ok(hipEventRecord(slot_free_[slot], stream), "hipEventRecord (host transfer)", error) == false))
+      return ETX_HIP_ERROR_HIP;
+    used[slot] = true;
+  }
+  // the slots are this object's, but the copy is synchronous for the caller as the hipMemcpy it replaces: errors surface here, and a later
+  // kernel on ANOTHER stream finds the data in place
+  for (int s = 0; s < 2; ++s) {
+    if (used[s] && (ok(hipEventSynchronize(slot_free_[s]), "hipEventSynchronize (host transfer)", error) == false))
+      return ETX_HIP_ERROR_HIP;
+  }
+  return 0;
+}
+
+int HostTransfer::to_host(void* dst_host, const void* src_device, size_t bytes, hipStream_t stream, std::string& error) {
+  if (bytes == 0u)
+    return 0;
+  std::lock_guard<std::mutex> lock(mutex_);
+  if (int rc = prepare(error))
+    return rc;
+  if (stream == nullptr)
+    stream = own_stream_;
+  const unsigned char* src = static_cast<const unsigned char*>(src_device);
+  unsigned char* dst = static_cast<unsigned char*>(dst_host);
+  // chunk i travels into slot i & 1 while chunk i - 1 is copied out of the other slot
+  size_t pending_offset[2] = {0, 0}, pending_bytes[2] = {0, 0};
+  auto drain = [&](int s) -> bool {
+    if (pending_bytes[s] == 0u)
+      return true;
+    if (ok(hipEventSynchronize(slot_free_[s]), "hipEventSynchronize (host transfer)", error) == false)
+      return false;
+    memcpy(dst + pending_offset[s], slots_[s], pending_bytes[s]);
+    pending_bytes[s] = 0u;
+    return true;
+  };
+  int slot = 0;
+  for (size_t offset = 0; offset < bytes; offset += kSlotBytes, slot ^= 1) {
+    const size_t n = std::min(kSlotBytes, bytes - offset);
+    if (drain(slot) == false)
+      return ETX_HIP_ERROR_HIP;
+    if ((ok(hipMemcpyAsync(slots_[slot], src + offset, n, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync (device to host)", error) == false) ||
+        (ok(hipEventRecord(slot_free_[slot], stream), "hipEventRecord (host transfer)", error) == false))
+      return ETX_HIP_ERROR_HIP;
+    pending_offset[slot] = offset, pending_bytes[slot] = n;
+    if (drain(slot ^ 1) == false)
+      return ETX_HIP_ERROR_HIP;
+  }
+  if ((drain(0) == false) || (drain(1) == false))
+    return ETX_HIP_ERROR_HIP;
+  return 0;
+}
+
+}  // namespace etxh

@@ -186,7 +186,12 @@ int lbvh_build_device(hipStream_t stream, DScene scene, f3 cube_min, float cube_
   void* sort_storage = nullptr;
   size_t sort_bytes = 0;
   hipEvent_t begin = nullptr, end = nullptr;
+  // what the host reads back during the build (one counter per level, the root node at the end) arrives in PINNED memory of the build's own:
+  // the library never hands HIP a pageable host pointer (host_transfer.h)
+  unsigned char* pinned = nullptr;
   auto cleanup = [&]() {
+    if (pinned != nullptr)
+      (void)hipHostFree(pinned);
     for (void* p : {static_cast<void*>(keys), static_cast<void*>(sorted_keys), static_cast<void*>(values), static_cast<void*>(sorted_values), static_cast<void*>(queue_a),
            static_cast<void*>(queue_b), static_cast<void*>(counter), static_cast<void*>(radix), static_cast<void*>(parent), static_cast<void*>(leaf_parent), static_cast<void*>(arrivals),
            static_cast<void*>(box_lo), static_cast<void*>(box_hi), sort_storage})
@@ -208,6 +213,8 @@ int lbvh_build_device(hipStream_t stream, DScene scene, f3 cube_min, float cube_
       (hipMalloc(&leaf_parent, n * sizeof(uint32_t)) != hipSuccess) || (hipMalloc(&arrivals, n * sizeof(uint32_t)) != hipSuccess) || (hipMalloc(&box_lo, n * sizeof(f3)) != hipSuccess) ||
       (hipMalloc(&box_hi, n * sizeof(f3)) != hipSuccess))
     return fail("hipMalloc of the temporaries");
+  if (hipHostMalloc(reinterpret_cast<void**>(&pinned), 256, hipHostMallocDefault) != hipSuccess)
+    return fail("hipHostMalloc of the read-back words");
   if (hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, sorted_keys, values, sorted_values, int(n), 0, 63, stream) != hipSuccess)
     return fail("sizing the radix sort");
   if (hipMalloc(&sort_storage, std::max<size_t>(sort_bytes, 16)) != hipSuccess)
@@ -230,9 +237,8 @@ int lbvh_build_device(hipStream_t stream, DScene scene, f3 cube_min, float cube_
   const LbvhBoxes boxes = {tris, box_lo, box_hi};
 
   // collapse, level by level; the host reads one counter per level (a build step, not the render loop)
-  const uint32_t root_source = 0u;  // radix node 0 covers every key
-  if (hipMemcpyAsync(queue_a, &root_source, sizeof(uint32_t), hipMemcpyHostToDevice, stream) != hipSuccess)
-    return fail("hipMemcpy of the root");
+  if (hipMemsetAsync(queue_a, 0, sizeof(uint32_t), stream) != hipSuccess)  // the first queue entry: radix node 0 covers every key
+    return fail("hipMemset of the root");
   uint32_t base = 0u, count = 1u;
   uint32_t *queue = queue_a, *next_queue = queue_b;
   while (count > 0u) {
@@ -245,9 +251,10 @@ int lbvh_build_device(hipStream_t stream, DScene scene, f3 cube_min, float cube_
     if (hipMemsetAsync(counter, 0, sizeof(uint32_t), stream) != hipSuccess)
       return fail("hipMemset of the level counter");
     hipLaunchKernelGGL(k_lbvh_collapse_level, dim3(blocks_for(count)), dim3(kBuildBlock), 0, stream, radix, boxes, queue, base, count, nodes, next_queue, counter);
-    uint32_t next = 0u;
-    if ((hipMemcpyAsync(&next, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) || (hipStreamSynchronize(stream) != hipSuccess))
+    if ((hipMemcpyAsync(pinned, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) || (hipStreamSynchronize(stream) != hipSuccess))
       return fail("reading the level counter");
+    uint32_t next = 0u;
+    memcpy(&next, pinned, sizeof(uint32_t));
     base += count;
     count = next;
     std::swap(queue, next_queue);
@@ -258,10 +265,12 @@ int lbvh_build_device(hipStream_t stream, DScene scene, f3 cube_min, float cube_
   result.root = 0;
   for (size_t level = result.level_offsets.size(); level-- > 1u;)
     launch_bvh_refit_level(stream, scene, nodes, result.level_offsets[level - 1u], result.level_offsets[level] - result.level_offsets[level - 1u]);
+  static_assert(sizeof(Bvh4Node) <= 256, "the pinned read-back area holds one node");
   Bvh4Node root_node;
   (void)hipEventRecord(end, stream);
-  if ((hipMemcpyAsync(&root_node, nodes, sizeof(Bvh4Node), hipMemcpyDeviceToHost, stream) != hipSuccess) || (hipStreamSynchronize(stream) != hipSuccess) || (hipGetLastError() != hipSuccess))
+  if ((hipMemcpyAsync(pinned, nodes, sizeof(Bvh4Node), hipMemcpyDeviceToHost, stream) != hipSuccess) || (hipStreamSynchronize(stream) != hipSuccess) || (hipGetLastError() != hipSuccess))
     return fail("the box pass");
+  memcpy(&root_node, pinned, sizeof(Bvh4Node));
   result.stack_need = root_node.pad[0];
   float ms = 0.0f;
   (void)hipEventElapsedTime(&ms, begin, end);

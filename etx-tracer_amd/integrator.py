@@ -247,6 +247,7 @@ class HIPVCM(HIPIntegrator):
     def _begin(self):
         if self.pixel_stride != 1:  # refused by the library with its reason (the photon map needs every pixel's light path)
             self.context.begin_ex(api.INTEGRATOR_VCM, vcm_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride, self.pixel_first, self.pixel_stride)
+            return
         self.context.begin_vcm(vcm_options_from_dict(self.integrator_options), self.first_iteration, self.iteration_stride)
 
 

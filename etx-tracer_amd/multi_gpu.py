@@ -10,8 +10,8 @@ Production path: RCCL inside libetx_hip.so (etx_hip_comm_init / etx_hip_reduce_f
 broadcast here through torch.distributed (init_context_comm). The CPU tests (gloo, world size 2) run this plumbing with a
 stub context and check the sharding / sum / normalisation arithmetic with a stand-in film (tests/film_accumulator.py).
 """
-import torch
-import torch.distributed as dist
+# torch is imported where a process group is used, never at module level: a process that only renders (tests -m gpu, a host application) keeps ONE ROCm
+# runtime - the one libetx_hip.so was built and linked against - instead of the older copy bundled with the torch wheel (DESIGN.md 7)
 
 
 def shard_iterations(total_iterations, rank, world_size):
@@ -25,6 +25,7 @@ def init_context_comm(context, rank, world_size, make_id=None):
     """Creates the RCCL communicator inside libetx_hip.so: rank 0 makes the ncclUniqueId (etx_hip_comm_unique_id), everyone
     receives its 128 bytes through the torch.distributed process group (any backend) and calls etx_hip_comm_init.
     `make_id`: replaces etx_hip_comm_unique_id where no GPU exists (the gloo tests)."""
+    import torch.distributed as dist
     from . import api
     make_id = make_id or getattr(context, "make_unique_id", None) or (lambda: api.comm_unique_id(context.library))
     payload = [make_id() if rank == 0 else None]
@@ -35,6 +36,8 @@ def init_context_comm(context, rank, world_size, make_id=None):
 
 def max_over_ranks(seconds, device=None):
     """bench.py: the timed region of the job is the slowest rank's."""
+    import torch
+    import torch.distributed as dist
     if (dist.is_initialized() is False) or (dist.get_world_size() == 1):
         return float(seconds)
     t = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")

@@ -319,8 +319,10 @@ int etx_hip_comm_init(etx_hip_context* context, int rank, int world_size, const 
  * itself are never modified: checkpoints, statistics and further iterations are unaffected. etx_hip_begin starts a new run (a reduce still in
  * flight is waited for, the reduced copy is cleared). Normal / albedo values of the path tracer and the bidirectional integrator are added by the
  * shade kernels of iterations in flight: a reduce taken while lanes render can hold part of those iterations' AOV values (a progressive display
- * issue only; etx_hip_reduce_film syncs first). Should a rank fail to ALLOCATE inside _begin (the buffers normally exist since etx_hip_comm_init /
- * etx_hip_begin), it returns the error without joining - the one case in which the other ranks are left to the RCCL timeout. */
+ * issue only; etx_hip_reduce_film syncs first). A rank whose _begin fails on its own side (a HIP call, a failed iteration) still joins the collective - zero
+ * snapshot, failed flag - and every rank gets an error from _end. The one case in which the other ranks are left to the RCCL timeout: a rank with
+ * nothing to join with (no scene uploaded, or the film-sized buffers could not be ALLOCATED; they normally exist since etx_hip_comm_init /
+ * etx_hip_upload_scene / etx_hip_begin). */
 int etx_hip_reduce_film_begin(etx_hip_context* context);
 int etx_hip_reduce_film_end(etx_hip_context* context, int wait);
 int etx_hip_reduce_film(etx_hip_context* context);

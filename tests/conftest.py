@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+if os.environ.get("ETX_TESTS_PRELOAD_TORCH"):
+    # Reproduction switch for the round-5 crash (tools/gpu_calls/gpu_r6c.sh): up to round 5 collecting tests/ imported torch - and with it
+    # the ROCm 7.0.2 runtime bundled in the wheel - before libetx_hip.so was loaded. Never set in a normal run.
+    import torch  # noqa: F401
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs an MI355X (gfx950) device; run with -m gpu on the GPU box")

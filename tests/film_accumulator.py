@@ -1,8 +1,7 @@
 """TEST DOUBLE (not product code): the arithmetic of the multi-GPU film reduce on torch tensors, any backend.
 etx_hip_reduce_film does the same with RCCL on the device film: per-rank SUMS of the camera / light layers and the
 iteration counter are all-reduced, the image is the sum divided by the total iteration count."""
-import torch
-import torch.distributed as dist
+from tests.lazy_torch import torch, dist
 
 
 class FilmAccumulator:

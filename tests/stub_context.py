@@ -4,8 +4,8 @@ runs line by line under gloo (tests/test_multi_gpu_gloo.py). An "iteration" is a
 a reduce all-reduces a COPY of the sums and of the iteration count like etx_hip_reduce_film* does over RCCL: out of place (the context's own
 sums stay its own), not terminal (rendering continues), any number of times per run - every rank the same number."""
 import numpy as np
-import torch
-import torch.distributed as dist
+
+from tests.lazy_torch import torch, dist
 
 from etx_tracer_amd import api
 

@@ -4,9 +4,8 @@ import os
 import socket
 
 import numpy as np
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
+
+from tests.lazy_torch import torch, dist, mp  # imported on first use: a -m gpu run collects this module and must not load torch's ROCm runtime
 
 
 def fake_iteration(iteration, h, w):
