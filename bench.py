@@ -8,8 +8,15 @@ end of every iteration (--reduce-every 1 = north_star; k: every k-th): asynchron
 communication stream of its own while the lanes keep rendering (csrc/host_reduce.h); the last reduce of the timed
 region is the blocking one (etx_hip_reduce_film) that leaves every rank with the whole-job film. All reduces are
 inside the timed region. Scene upload / BVH build happen before the timed region (inputs resident in HBM).
-The timed region is repeated --repeats times (each: exactly --steps steps between barrier + synchronize on both
-sides); `value` / `ms_per_step` are the median repeat's, `repeats` lists all of them.
+The timed region is repeated (each region: exactly --steps steps between barrier + synchronize on both sides) at least
+three times and until the regions add up to 2.5 s (--repeats 0, the default; a 20-step region of the headline workload
+lasts 0.4 s - too short for an outside observer to see the device busy); `value` / `ms_per_step` are the median
+region's, `repeats` lists all of them.
+
+No torch in this process: the collectives (film reduce, barrier, max over ranks) are RCCL inside libetx_hip.so, the 128-byte
+ncclUniqueId travels through a file on the node (etx_tracer_amd/multi_gpu.py). Importing the torch wheel would map the ROCm
+7.0.2 runtime it bundles next to (or, imported first, instead of) the one the library is built against; `config.runtime`
+records what the process runs on.
 
   python bench.py --gpus 1 --steps 8 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -29,7 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
-BYTES_PER_RAY = 48         # 32 B ray record in + 16 B hit record out (DESIGN.md "traversal kernel")
+BYTES_PER_RAY = 52         # 32 B ray record + 4 B path / queue index in, 16 B hit record out. (The queues here are index-aligned with the path state,
+                           # so the kernel moves 48 of them - the index is implicit; the contract's figure is the one priced.)
 
 
 def cpu_baseline(snapshot_path, width, height, seconds_budget=25.0, integrator="vcm", extra=()):
@@ -84,9 +92,9 @@ def library_sha16():
         return None
 
 
-def main(argv=None, context_factory=None, backend="nccl"):
-    """`context_factory` / `backend`: the CPU test of the N > 1 control flow (tests/test_multi_gpu_gloo.py) runs this function in two
-    gloo processes with a stand-in for api.Context; the driver's command line uses neither."""
+def main(argv=None, context_factory=None):
+    """`context_factory`: the CPU test of the N > 1 control flow (tests/test_multi_gpu_gloo.py) runs this function in two processes with a
+    stand-in for api.Context (whose collectives run over gloo); the driver's command line does not use it."""
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=32)
@@ -105,17 +113,15 @@ def main(argv=None, context_factory=None, backend="nccl"):
     parser.add_argument("--reduce-every", type=int, default=1,
                         help="film reduce cadence in iterations (N > 1, or N = 1 with --comm-single): 1 = at the end of every iteration (north_star), k = every k-th, "
                              "0 = only the final reduce of the timed region")
-    parser.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; value = the median one")
+    parser.add_argument("--repeats", type=int, default=0, help="timed regions of --steps steps each; value = the median one. 0 (default): at least 3, and until the regions add up to 2.5 s (at most 24)")
     parser.add_argument("--comm-single", action="store_true",
                         help="N = 1 only: create a one-rank RCCL communicator, so that the reduces of the timed region run (snapshot kernel + one-rank all-reduce) and their "
                              "device time can be read on one GPU (reduce.device_ms_avg); without it a single GPU has nothing to reduce")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-kernel-table", action="store_true", help="skip the extra pass that times every kernel group (profiling runs)")
     args = parser.parse_args(argv)
-    device = "cuda" if backend == "nccl" else "cpu"
 
     import numpy as np
-    import torch
     import etx_tracer_amd as etx
     from etx_tracer_amd import api, multi_gpu, integrator as integ_mod
 
@@ -126,14 +132,6 @@ def main(argv=None, context_factory=None, backend="nccl"):
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
     distributed = world > 1
-    if device == "cuda":
-        torch.cuda.set_device(local_rank)
-    if distributed:
-        import torch.distributed as dist
-        if device == "cuda":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
 
     spectral_workload = args.workload in ("gems", "gems1m")
     bdpt_workload = args.workload in ("sssdragon_bdpt", "cloud_bdpt")
@@ -230,22 +228,23 @@ def main(argv=None, context_factory=None, backend="nccl"):
         return acc
 
     def barrier():
-        if distributed:
-            dist.barrier()
-        if device == "cuda":
-            torch.cuda.synchronize()
-        ctx.sync()
+        ctx.sync()          # this rank's lanes are idle (hipStreamSynchronize of every launch stream: what torch.cuda.synchronize would wait for)
+        ctx.comm_barrier()  # every rank is here (an RCCL all-reduce on the communication stream; nothing to do on one rank)
 
     if args.warmup > 0:
         run_steps(args.warmup, 0)
     regions = []
-    for repeat in range(max(1, args.repeats)):
+    repeat = 0
+    while True:
         barrier()
         t0 = time.perf_counter()
         region_acc = run_steps(args.steps, args.warmup + repeat * args.steps)
         barrier()
-        region_elapsed = multi_gpu.max_over_ranks(time.perf_counter() - t0, device=device)  # the same number on every rank: all pick the same region
+        region_elapsed = multi_gpu.max_over_ranks(ctx, time.perf_counter() - t0)  # the same number on every rank: all pick the same region, all stop together
         regions.append((region_elapsed, repeat, region_acc))
+        repeat += 1
+        if (repeat >= args.repeats) if (args.repeats > 0) else ((repeat >= 3) and ((sum(r[0] for r in regions) >= 2.5) or (repeat >= 24))):
+            break
     # the headline is the MEDIAN region (its own steps, time and counters); min / max show the spread of this box
     elapsed, median_repeat, acc = sorted(regions, key=lambda r: r[0])[(len(regions) - 1) // 2]
 
@@ -257,19 +256,17 @@ def main(argv=None, context_factory=None, backend="nccl"):
     isolated = None
     if rank == 0:
         n_rays = width * height
-        g = torch.Generator(device=device).manual_seed(1)
-        o = torch.stack([torch.rand(n_rays, generator=g, device=device) * 1.9 - 0.95, torch.rand(n_rays, generator=g, device=device) * 1.85 + 0.05,
-                         torch.rand(n_rays, generator=g, device=device) * 1.9 - 0.95], dim=1)
-        d = torch.randn(n_rays, 3, generator=g, device=device)
-        d = d / d.norm(dim=1, keepdim=True)
-        ro = torch.cat([o, torch.full((n_rays, 1), 2.2889e-4, device=device)], dim=1).contiguous()
-        rd = torch.cat([d, torch.full((n_rays, 1), 3.0e38, device=device)], dim=1).contiguous()
-        hits = torch.empty((n_rays, 4), device=device)
-        if device == "cuda":
-            torch.cuda.synchronize()
-        ms = ctx.trace_rays_device(ro.data_ptr(), rd.data_ptr(), n_rays, hits.data_ptr(), 20)
-        if device == "cuda":
-            torch.cuda.synchronize()
+        g = np.random.default_rng(1)
+        rays = np.empty((n_rays, 8), dtype=np.float32)
+        rays[:, 0] = g.random(n_rays, dtype=np.float32) * 1.9 - 0.95
+        rays[:, 1] = g.random(n_rays, dtype=np.float32) * 1.85 + 0.05
+        rays[:, 2] = g.random(n_rays, dtype=np.float32) * 1.9 - 0.95
+        rays[:, 3] = 2.2889e-4
+        d = g.standard_normal((n_rays, 3), dtype=np.float32)
+        rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        rays[:, 7] = 3.0e38
+        ms = ctx.trace_rays_timed(rays, 20)  # uploaded once, then device-resident (etx_hip_trace_rays_timed)
+        del rays, d
         gbs = n_rays * BYTES_PER_RAY / ms / 1.0e6
         isolated = {"rays_per_launch": n_rays, "avg_launch_ms": round(ms, 6), "achieved": round(gbs, 3), "frac": round(gbs / HBM_PEAK_GBS, 6),
                     "note": "the same kernel alone on the device, 20 launches over one queue of incoherent rays"}
@@ -282,7 +279,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
         if bdpt_workload:
             # bidirectional state = 116 B (84 B + the previous vertex' position / normal), records of dev_bdpt.h
             units = {
-                "trace_closest": ("ray", s.rays_extension, 48.0 * s.rays_extension, s.ms_trace_closest, "k_trace_closest_bvh: 32 B ray in + 16 B hit out (+ the tree: not cache resident at this size)"),
+                "trace_closest": ("ray", s.rays_extension, float(BYTES_PER_RAY) * s.rays_extension, s.ms_trace_closest, "k_trace_closest_bvh: SURVEY 8(d) 52 B per ray (32 B ray + 4 B index in, 16 B hit out; + the tree: not cache resident at this size)"),
                 "trace_shadow": ("segment", s.rays_shadow, 48.0 * s.rays_shadow + 12.0 * s.splats, s.ms_trace_shadow, "k_trace_shadow: 48 B request in, 12 B of film atomics per visible light splat"),
                 "shade_light": ("path segment", s.rays_light, 248.0 * s.rays_light + 96.0 * s.light_vertices, s.ms_shade_light,
                                 "k_bdpt_light_shade + k_bdpt_walk + k_bdpt_connect_camera: 116 B state + 16 B hit in, 116 B state out, 96 B per stored light vertex (every event of a subsurface walk is one)"),
@@ -292,7 +289,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
             }
         else:
             units = {
-                "trace_closest": ("ray", s.rays_extension, 48.0 * s.rays_extension, s.ms_trace_closest, "k_trace_closest: 32 B ray in + 16 B hit out"),
+                "trace_closest": ("ray", s.rays_extension, float(BYTES_PER_RAY) * s.rays_extension, s.ms_trace_closest, "k_trace_closest: SURVEY 8(d) 52 B per ray (32 B ray + 4 B index in, 16 B hit out)"),
                 "trace_shadow": ("segment", s.rays_shadow, 48.0 * s.rays_shadow + 12.0 * s.splats, s.ms_trace_shadow, "k_trace_shadow: 48 B request in, 12 B of film atomics per visible light splat"),
                 "shade_light": ("path segment", s.rays_light, 184.0 * s.rays_light + 96.0 * s.light_vertices, s.ms_shade_light,
                                 "k_light_shade (+ tail): 84 B state + 16 B hit in, 84 B state out, 96 B per stored light vertex"),
@@ -401,6 +398,9 @@ def main(argv=None, context_factory=None, backend="nccl"):
                 "working_set_gb": round(ctx.device_bytes() / 1.0e9, 2),  # queues, pools, grid and film of all lanes (etx_hip_device_bytes)
                 "pool_grows": int(acc["stats"].pool_grows),  # iterations of the timed region that overflowed a pool and were rendered again (0 once the pools have their size)
                 "lanes": lanes, "workload_key": args.workload, "library_sha16": library_sha16(),
+                # the ROCm runtime this process ran on: versions (hipRuntimeGetVersion / the HIP_VERSION the library was compiled against, the same for RCCL)
+                # and the files they are mapped from - one of each in a healthy process
+                "runtime": api.runtime_info() if context_factory is None else None,
             },
             "roofline": {
                 "kernel": ("k_trace_closest_bvh (ray queue -> hit queue; BVH4, top levels staged in LDS, persistent workgroups)" if spectral_workload
@@ -412,7 +412,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": (round(trace_pmc["hbm_bytes_per_unit"] * acc["rays"] / max(acc["launches"], 1)) if trace_pmc and trace_pmc["hbm_bytes_per_unit"] else None),
                 "traffic_note": ("HBM bytes per average launch = PMC bytes per ray of the traversal kernel INSIDE a one-lane run of this pipeline (%s B: FETCH_SIZE x 2 + WRITE_SIZE of %s, %s) "
-                                 "x rays per launch of the timed region; algorithmic 48 B per ray. A query that crosses a medium boundary also rewrites its path's ray, medium and "
+                                 "x rays per launch of the timed region; algorithmic 52 B per ray (SURVEY 8d). A query that crosses a medium boundary also rewrites its path's ray, medium and "
                                  "path distance (about 112 B of state per crossing, counters.boundary_crossings_per_sample)" % (trace_pmc["hbm_bytes_per_unit"], ", ".join(trace_pmc["kernels"]), pmc_source))
                                 if trace_pmc and trace_pmc["hbm_bytes_per_unit"] else
                                 ("the committed PMC summary %s was collected on library %s, this run loaded %s: counters withheld (counters_stale)" % (pmc_source, profiled_sha, library_sha16())
@@ -421,7 +421,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
                 "rays": acc["rays"],
                 "launches": acc["launches"],
                 "avg_launch_ms": round(acc["trace_ms"] / max(acc["launches"], 1), 6),
-                "note": "algorithmic bytes = rays x 48 B summed over the timed region / summed HIP-event time of the trace launches (rank 0); rays include the "
+                "note": "algorithmic bytes = rays x 52 B (SURVEY 8d) summed over the timed region / summed HIP-event time of the trace launches (rank 0); rays include the "
                         "queries the kernel runs beyond medium boundaries it crosses itself (counters.boundary_crossings_per_sample). "
                         "The timed region overlaps several iterations on separate streams (ETX_HIP_LANES), so a launch shares the CUs with "
                         "other kernels; `isolated` is the same kernel alone",
@@ -470,8 +470,7 @@ def main(argv=None, context_factory=None, backend="nccl"):
         flush_c_stdio()
         print(json.dumps(line), flush=True)
     if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+        ctx.comm_barrier()
     ctx.close()
     return line if rank == 0 else None
 

@@ -21,6 +21,7 @@ VCM_ENABLE_MERGING = 1 << 6
 VCM_FULL_OPTIONS = 0x7F
 CHANGED_CAMERA, CHANGED_MATERIALS, CHANGED_POSITIONS, REBUILD_BVH = 1, 2, 4, 8  # etx_hip_update_scene
 BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1  # etx_hip_set_bvh_builder
+REDUCE_SUM, REDUCE_MAX, REDUCE_MIN = 0, 1, 2  # etx_hip_comm_all_reduce_f64
 
 EXPORTED_SYMBOLS = (
     "etx_hip_abi_version", "etx_hip_create", "etx_hip_destroy", "etx_hip_last_error", "etx_hip_upload_scene", "etx_hip_update_scene",
@@ -28,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "etx_hip_read_film", "etx_hip_read_film_begin", "etx_hip_read_film_end", "etx_hip_checkpoint_bytes", "etx_hip_checkpoint_save", "etx_hip_checkpoint_load", "etx_hip_stats", "etx_hip_set_timers", "etx_hip_set_debug_flags", "etx_hip_set_pool_policy", "etx_hip_lanes", "etx_hip_device_bytes", "etx_hip_comm_unique_id", "etx_hip_comm_init", "etx_hip_reduce_film", "etx_hip_reduce_film_begin", "etx_hip_reduce_film_end", "etx_hip_reduce_info",
     "etx_hip_trace_rays", "etx_hip_trace_rays_device", "etx_hip_kat", "etx_hip_host_check_bvh", "etx_hip_host_bvh_stats",
     "etx_hip_set_bvh_builder", "etx_hip_bvh_info", "etx_hip_selftest_stack", "etx_hip_host_check_bvh_builder", "etx_hip_host_bvh_stats_builder",
+    "etx_hip_runtime_info", "etx_hip_comm_all_reduce_f64", "etx_hip_comm_barrier", "etx_hip_trace_rays_timed",
 )
 
 
@@ -173,7 +175,11 @@ class Library:
                 "%s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(etx-tracer_amd has no CPU fallback)" % path)
         self.path = path
-        self.lib = ctypes.CDLL(path)
+        # RTLD_NOW: the library and the ROCm runtime it pulls in (/opt/rocm: libamdhip64, libhsa-runtime64, librccl - none of them linked -z now) bind
+        # every symbol HERE. With lazy binding a package imported later that maps a second ROCm stack into the global namespace (the torch wheel
+        # bundles 7.0.2 under torch/lib) would capture whichever calls had not happened yet - seen in round 6: hipRuntimeGetVersion answered by the
+        # wheel's runtime in a process whose libetx_hip.so had been loaded against /opt/rocm first.
+        self.lib = ctypes.CDLL(path, mode=os.RTLD_NOW | os.RTLD_LOCAL)
         L = self.lib
         vp, u32, u64, i32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_size_t
         L.etx_hip_abi_version.restype = i32
@@ -216,6 +222,10 @@ class Library:
         L.etx_hip_reduce_info.argtypes = [vp, vp, ctypes.c_size_t]
         L.etx_hip_trace_rays.argtypes = [vp, vp, u64, vp]
         L.etx_hip_trace_rays_device.argtypes = [vp, vp, vp, u64, vp, u32, ctypes.POINTER(ctypes.c_double)]
+        L.etx_hip_trace_rays_timed.argtypes = [vp, vp, u64, u32, ctypes.POINTER(ctypes.c_double), vp]
+        L.etx_hip_runtime_info.argtypes = [ctypes.POINTER(i32 * 4)]
+        L.etx_hip_comm_all_reduce_f64.argtypes = [vp, ctypes.POINTER(ctypes.c_double), u32, i32]
+        L.etx_hip_comm_barrier.argtypes = [vp]
         L.etx_hip_kat.argtypes = [vp, i32, vp, u64, vp]
         L.etx_hip_host_check_bvh.argtypes = [vp, ctypes.POINTER(u32 * 4)]
         L.etx_hip_host_bvh_stats.argtypes = [vp, vp, u64, ctypes.POINTER(u64 * 4)]
@@ -404,6 +414,15 @@ class Context:
         self._check(self.library.lib.etx_hip_trace_rays_device(self.handle, d_o_tmin, d_d_tmax, count, d_hits, repeat, ctypes.byref(ms)))
         return ms.value
 
+    def trace_rays_timed(self, rays, repeat, want_hits=False):
+        """etx_hip_trace_rays_timed: host rays [n, 8] uploaded once, one untimed + `repeat` timed launches of the production traversal kernel over the
+        device-resident queue -> average kernel time in ms (HIP events on the launch stream) [, hits of the last launch]."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        hits = np.empty((rays.shape[0], 4), dtype=np.float32) if want_hits else None
+        ms = ctypes.c_double()
+        self._check(self.library.lib.etx_hip_trace_rays_timed(self.handle, rays.ctypes.data, rays.shape[0], int(repeat), ctypes.byref(ms), hits.ctypes.data if want_hits else None))
+        return (ms.value, hits) if want_hits else ms.value
+
     def kat(self, which, values, out_width):
         values = np.ascontiguousarray(values, dtype=np.float32)
         count = values.shape[0]
@@ -414,6 +433,16 @@ class Context:
     def comm_init(self, rank, world, unique_id_bytes):
         buf = ctypes.create_string_buffer(bytes(unique_id_bytes), 128)
         self._check(self.library.lib.etx_hip_comm_init(self.handle, rank, world, buf))
+
+    def comm_all_reduce(self, values, op=REDUCE_SUM):
+        """etx_hip_comm_all_reduce_f64: up to 16 doubles reduced over the context's communicator (identity without one). -> list of floats"""
+        values = [float(v) for v in values]
+        words = (ctypes.c_double * len(values))(*values)
+        self._check(self.library.lib.etx_hip_comm_all_reduce_f64(self.handle, words, len(values), int(op)))
+        return [float(w) for w in words]
+
+    def comm_barrier(self):
+        self._check(self.library.lib.etx_hip_comm_barrier(self.handle))
 
     def reduce_film(self):
         """etx_hip_sync + one film reduce, blocking; rendering may continue afterwards."""
@@ -459,6 +488,24 @@ def host_bvh_stats(snapshot, rays, library=None, builder=BVH_HOST_SAH, with_hits
         triangle[triangle == 0xFFFFFFFF] = -1
         result["t"], result["triangle"] = hits[:, 0].copy(), triangle
     return rc, result
+
+
+def runtime_info(library=None):
+    """{hip_runtime, hip_built_against, rccl_runtime, rccl_built_against, mapped}: the ROCm runtime the loader bound libetx_hip.so to in THIS process
+    (etx_hip_runtime_info) and the files it is mapped from. One libamdhip64 / libhsa-runtime64 / librccl each is what a healthy process shows."""
+    library = library or Library.get()
+    versions = (ctypes.c_int * 4)()
+    library.lib.etx_hip_runtime_info(ctypes.byref(versions))
+    mapped = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.split()[-1] if "/" in line else ""
+                if any(k in path for k in ("libamdhip64", "libhsa-runtime64", "librccl")) and path not in mapped:
+                    mapped.append(path)
+    except OSError:
+        pass
+    return {"hip_runtime": versions[0], "hip_built_against": versions[1], "rccl_runtime": versions[2], "rccl_built_against": versions[3], "mapped": mapped}
 
 
 def comm_unique_id(library=None):

@@ -113,6 +113,7 @@ struct etx_hip_context {
   uint32_t cross_mode = 0;           // which path state the traversal kernel may advance across medium boundaries (kernels.h launch_trace_closest): set per iteration by the integrator
   size_t allocated_bytes = 0;        // of this lane's pipeline (etx_hip_device_bytes)
   uint32_t base_lanes = 1, active_lanes = 1;  // public context: lanes every integrator uses / lanes the armed integrator uses
+  uint32_t max_lanes = 1;                     // ... / lanes the bidirectional integrator uses: those beyond base_lanes (thread, stream, events, pools) are created by its first etx_hip_begin
   uint32_t debug_flags = 0;          // etx_hip_set_debug_flags: ablation switches of the kernels (Pipeline::debug_flags), 0 in production
   std::vector<hipEvent_t> event_pool;
   size_t events_used = 0;
@@ -437,8 +438,7 @@ bool lane_ready(const etx_hip_context* lane) {
 }
 
 uint32_t lanes_for_integrator(const etx_hip_context* context, int integrator) {
-  const uint32_t created = uint32_t(context->helpers.size()) + 1u;
-  return (integrator == ETX_HIP_INTEGRATOR_BDPT) ? created : std::min(created, context->base_lanes);
+  return (integrator == ETX_HIP_INTEGRATOR_BDPT) ? context->max_lanes : std::min(context->max_lanes, context->base_lanes);
 }
 
 // pools of the lanes every integrator uses, after the public context's own (etx_hip_upload_scene / etx_hip_update_scene)
@@ -1195,6 +1195,18 @@ void stop_lane_worker(etx_hip_context* lane) {
   }
 }
 
+// Helper lanes (thread, stream, events, pinned mirrors) up to `wanted` lanes in all; their pools follow in etx_hip_upload_scene / etx_hip_begin.
+int ensure_lanes(etx_hip_context* context, uint32_t wanted, std::string& error) {
+  while (context->helpers.size() + 1u < wanted) {
+    auto* helper = new etx_hip_context();
+    helper->owner = context;
+    context->helpers.push_back(helper);
+    if (int rc = init_lane(helper, context->device, error))
+      return rc;
+  }
+  return ETX_HIP_OK;
+}
+
 void destroy_lane(etx_hip_context* lane) {
   stop_lane_worker(lane);
   if (lane->stream)
@@ -1231,12 +1243,67 @@ const char* etx_hip_last_error(const etx_hip_context* context) {
   return context ? context->error.c_str() : g_create_error.c_str();
 }
 
+void etx_hip_internal_rccl_versions(int* mapped, int* built);
+
+int etx_hip_runtime_info(int out_versions[4]) {
+  if (out_versions == nullptr)
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  out_versions[0] = out_versions[2] = 0;
+  out_versions[1] = HIP_VERSION;
+  (void)hipRuntimeGetVersion(&out_versions[0]);
+  etx_hip_internal_rccl_versions(&out_versions[2], &out_versions[3]);
+  return ETX_HIP_OK;
+}
+
+namespace {
+// The runtime the dynamic loader bound this library to. A package that bundles its own ROCm under the same sonames (a PyTorch wheel: libamdhip64.so.7,
+// libhsa-runtime64.so.1, librccl.so.1 of ROCm 7.0.2 in torch/lib) and is imported BEFORE libetx_hip.so makes the loader resolve this library's
+// NEEDED entries to those copies: code objects and host stubs built by a newer hipcc then run on an older runtime. Round 5's GPU suite ran like
+// that and crashed in one of six processes; the library refuses the configuration instead of running on it.
+int check_runtime(std::string& error) {
+  int versions[4] = {};
+  (void)etx_hip_runtime_info(versions);
+  const bool verbose = getenv("ETX_HIP_VERBOSE") != nullptr;
+  std::string mapped;
+  if (FILE* maps = fopen("/proc/self/maps", "r")) {
+    char line[1024];
+    std::string last;
+    while (fgets(line, sizeof(line), maps)) {
+      const char* path = strchr(line, '/');
+      if ((path == nullptr) || ((strstr(path, "libamdhip64") == nullptr) && (strstr(path, "libhsa-runtime64") == nullptr) && (strstr(path, "librccl") == nullptr)))
+        continue;
+      std::string p(path);
+      while ((p.empty() == false) && ((p.back() == '\n') || (p.back() == ' ')))
+        p.pop_back();
+      if (p != last)
+        mapped += (mapped.empty() ? "" : ", ") + p;
+      last = p;
+    }
+    fclose(maps);
+  }
+  if (verbose)
+    fprintf(stderr, "[etx_hip] HIP runtime %d (built against %d), RCCL %d (built against %d); mapped: %s\n", versions[0], versions[1], versions[2], versions[3], mapped.c_str());
+  if ((versions[0] != 0) && (versions[0] / 100000 < versions[1] / 100000)) {
+    const char* allow = getenv("ETX_HIP_ALLOW_OLDER_RUNTIME");
+    if ((allow == nullptr) || (allow[0] == '0')) {
+      error = "the HIP runtime mapped into this process is version " + std::to_string(versions[0]) + ", older than the " + std::to_string(versions[1]) +
+              " libetx_hip.so was built against (mapped: " + mapped + "). Something that bundles its own ROCm runtime (a PyTorch wheel) was loaded first: load libetx_hip.so "
+              "before it, or set ETX_HIP_ALLOW_OLDER_RUNTIME=1 to run on the older runtime anyway";
+      return ETX_HIP_ERROR_HIP;
+    }
+  }
+  return ETX_HIP_OK;
+}
+}  // namespace
+
 int etx_hip_create(int device, etx_hip_context** out_context) {
   if (out_context == nullptr) {
     g_create_error = "out_context is null";
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   }
   *out_context = nullptr;
+  if (int rc = check_runtime(g_create_error))
+    return rc;
   int count = 0;
   if ((hipGetDeviceCount(&count) != hipSuccess) || (count == 0)) {
     g_create_error = "no HIP device available (this backend has no CPU path)";
@@ -1272,12 +1339,9 @@ int etx_hip_create(int device, etx_hip_context** out_context) {
   if (const char* e = getenv("ETX_HIP_LANES"))
     ctx->base_lanes = lanes = std::min(8, std::max(1, atoi(e)));
   ctx->active_lanes = ctx->base_lanes;
-  for (int l = 1; (rc == ETX_HIP_OK) && (l < lanes); ++l) {
-    auto* helper = new etx_hip_context();
-    helper->owner = ctx.get();
-    ctx->helpers.push_back(helper);
-    rc = init_lane(helper, device, g_create_error);
-  }
+  ctx->max_lanes = uint32_t(lanes);
+  if (rc == ETX_HIP_OK)
+    rc = ensure_lanes(ctx.get(), ctx->base_lanes, g_create_error);  // the bidirectional integrator's extra lanes: at its first etx_hip_begin
   if (rc != ETX_HIP_OK) {
     etx_hip_destroy(ctx.release());
     return rc;
@@ -1294,10 +1358,19 @@ void etx_hip_destroy(etx_hip_context* context) {
   (void)hipSetDevice(context->device);
   // iterations still in flight finish first: their commits use the reduce state (CommitSection) that etx_hip_comm_destroy_internal tears down,
   // and every lane's worker - the public lane's too - is joined before that
-  (void)wait_idle(context);
-  for (etx_hip_context* helper : context->helpers)
-    stop_lane_worker(helper);
-  stop_lane_worker(context);
+  const char* legacy = getenv("ETX_HIP_DEBUG_LEGACY");  // DIAGNOSTIC (round 6): bit 1 = the round-5 teardown order
+  if ((legacy != nullptr) && ((atoi(legacy) & 2) != 0)) {
+    for (etx_hip_context* helper : context->helpers) {
+      destroy_lane(helper);
+      delete helper;
+    }
+    context->helpers.clear();
+  } else {
+    (void)wait_idle(context);
+    for (etx_hip_context* helper : context->helpers)
+      stop_lane_worker(helper);
+    stop_lane_worker(context);
+  }
   etx_hip_comm_destroy_internal(context);
   for (etx_hip_context* helper : context->helpers) {
     destroy_lane(helper);
@@ -1669,8 +1742,10 @@ int etx_hip_begin_ex(etx_hip_context* context, int integrator, const void* optio
       return ETX_HIP_ERROR_OVERFLOW;
     }
   }
-  // the lanes this integrator uses beyond the base ones get their pools now - after every check above, so a refused begin leaves the
-  // working set as it was
+  // the lanes this integrator uses beyond the base ones are created and get their pools now - after every check above, so a refused begin
+  // leaves the working set as it was
+  if (int rc = ensure_lanes(context, lanes_wanted, context->error))
+    return rc;
   for (uint32_t i = 0; i + 1u < lanes_wanted; ++i) {
     etx_hip_context* helper = context->helpers[i];
     if (lane_ready(helper))
@@ -2165,13 +2240,15 @@ int etx_hip_stats(etx_hip_context* context, etx_hip_stats_t* out_stats, size_t s
   return ETX_HIP_OK;
 }
 
-int etx_hip_trace_rays(etx_hip_context* context, const float* rays_8f, uint64_t count, float* hits_4f) {
-  if ((context == nullptr) || ((count > 0) && ((rays_8f == nullptr) || (hits_4f == nullptr))))
+int etx_hip_trace_rays_timed(etx_hip_context* context, const float* rays_8f, uint64_t count, uint32_t repeat, double* out_avg_ms, float* hits_4f) {
+  if ((context == nullptr) || ((count > 0) && (rays_8f == nullptr)))
     return ETX_HIP_ERROR_INVALID_ARGUMENT;
   if (context->scene_ready == false) {
     context->error = "etx_hip_trace_rays: no scene uploaded";
     return ETX_HIP_ERROR_STATE;
   }
+  if (out_avg_ms)
+    *out_avg_ms = 0.0;
   if (count == 0)
     return ETX_HIP_OK;
   if (count > 0xffffffffull) {
@@ -2185,26 +2262,63 @@ int etx_hip_trace_rays(etx_hip_context* context, const float* rays_8f, uint64_t 
     d[i] = make_float4(rays_8f[8 * i + 4], rays_8f[8 * i + 5], rays_8f[8 * i + 6], rays_8f[8 * i + 7]);
   }
   float4 *d_o = nullptr, *d_d = nullptr, *d_h = nullptr;
-  HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&d_o), count * sizeof(float4)));
-  HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&d_d), count * sizeof(float4)));
-  HIP_OK(context, hipMalloc(reinterpret_cast<void**>(&d_h), count * sizeof(float4)));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = ETX_HIP_OK;
+  auto fail = [&](const std::string& what, hipError_t e) {
+    context->error = what + ": " + hipGetErrorString(e);
+    rc = ETX_HIP_ERROR_HIP;
+  };
   do {
-    if (context->transfer.to_device(d_o, o.data(), count * sizeof(float4), context->stream, context->error) ||
-        context->transfer.to_device(d_d, d.data(), count * sizeof(float4), context->stream, context->error)) {
-      rc = ETX_HIP_ERROR_HIP;
+    hipError_t e = hipSuccess;
+    if (((e = hipMalloc(reinterpret_cast<void**>(&d_o), count * sizeof(float4))) != hipSuccess) || ((e = hipMalloc(reinterpret_cast<void**>(&d_d), count * sizeof(float4))) != hipSuccess) ||
+        ((e = hipMalloc(reinterpret_cast<void**>(&d_h), count * sizeof(float4))) != hipSuccess)) {
+      fail("hipMalloc of the ray queues", e);
       break;
     }
-    launch_trace_rays(context->stream, context->pipe.scene, d_o, d_d, d_h, uint32_t(count), context->scene.host_copy.bvh_flat != 0u, context->debug_flags);
-    if (context->transfer.to_host(hits_4f, d_h, count * sizeof(float4), context->stream, context->error)) {
-      context->error = "trace kernel failed: " + context->error;
-      rc = ETX_HIP_ERROR_HIP;
+    if ((rc = context->transfer.to_device(d_o, o.data(), count * sizeof(float4), context->stream, context->error)) ||
+        (rc = context->transfer.to_device(d_d, d.data(), count * sizeof(float4), context->stream, context->error)))
+      break;
+    const bool flat = context->scene.host_copy.bvh_flat != 0u;
+    launch_trace_rays(context->stream, context->pipe.scene, d_o, d_d, d_h, uint32_t(count), flat, context->debug_flags);
+    if (repeat > 0u) {  // the first launch was the untimed one (code object load, caches)
+      if (((e = hipEventCreate(&e0)) != hipSuccess) || ((e = hipEventCreate(&e1)) != hipSuccess) || ((e = hipEventRecord(e0, context->stream)) != hipSuccess)) {
+        fail("hipEvent", e);
+        break;
+      }
+      for (uint32_t r = 0; r < repeat; ++r)
+        launch_trace_rays(context->stream, context->pipe.scene, d_o, d_d, d_h, uint32_t(count), flat, context->debug_flags);
+      float ms = 0.0f;
+      if (((e = hipEventRecord(e1, context->stream)) != hipSuccess) || ((e = hipEventSynchronize(e1)) != hipSuccess) || ((e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess)) {
+        fail("trace kernel failed", e);
+        break;
+      }
+      if (out_avg_ms)
+        *out_avg_ms = double(ms) / double(repeat);
+    }
+    if (hits_4f != nullptr) {
+      if ((rc = context->transfer.to_host(hits_4f, d_h, count * sizeof(float4), context->stream, context->error))) {
+        context->error = "trace kernel failed: " + context->error;
+        break;
+      }
+    } else if ((e = hipStreamSynchronize(context->stream)) != hipSuccess) {
+      fail("trace kernel failed", e);
     }
   } while (false);
+  if (e0)
+    (void)hipEventDestroy(e0);
+  if (e1)
+    (void)hipEventDestroy(e1);
+  (void)hipStreamSynchronize(context->stream);
   (void)hipFree(d_o);
   (void)hipFree(d_d);
   (void)hipFree(d_h);
   return rc;
+}
+
+int etx_hip_trace_rays(etx_hip_context* context, const float* rays_8f, uint64_t count, float* hits_4f) {
+  if ((count > 0) && (hits_4f == nullptr))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  return etx_hip_trace_rays_timed(context, rays_8f, count, 0u, nullptr, hits_4f);
 }
 
 int etx_hip_trace_rays_device(etx_hip_context* context, const void* d_rays_o_tmin, const void* d_rays_d_tmax, uint64_t count, void* d_hits, uint32_t repeat, double* out_avg_ms) {
@@ -2607,6 +2721,11 @@ void etx_hip_internal_reduce_release(etx_hip_context* c) {
     (void)hipFree(r.d_counters);
   if (r.h_counters)
     (void)hipHostFree(r.h_counters);
+  if (r.h_words)
+    (void)hipHostFree(r.h_words);
+  if (r.d_words)
+    (void)hipFree(r.d_words);
+  r.h_words = r.d_words = nullptr;
   for (hipEvent_t* e : {&r.snapshot_done, &r.done, &r.time_begin, &r.time_end}) {
     if (*e)
       (void)hipEventDestroy(*e);
@@ -2664,8 +2783,9 @@ int etx_hip_internal_reduce_prepare(etx_hip_context* c, int local_rc, float4** o
     return rc;
   const size_t n = r.pixels;
   const uint32_t layer_mask = (c->integrator == ETX_HIP_INTEGRATOR_VCM) ? 0x3u : ((c->integrator == ETX_HIP_INTEGRATOR_PT) ? 0xdu : 0xfu);
-  // the bidirectional integrator's commit counts every pixel of the frame on every pixel shard (k_vcm_commit): the count of shard 0 is the job's
-  const bool drop_counts = (c->integrator == ETX_HIP_INTEGRATOR_BDPT) && (c->pixel_first != 0u);
+  // the bidirectional integrator's commit counts every pixel of the frame on every pixel shard (k_vcm_commit): each shard contributes the counts of the
+  // pixels it owns (k_film_snapshot)
+  const uint32_t own_stride = (c->integrator == ETX_HIP_INTEGRATOR_BDPT) ? c->pixel_stride : 1u;
   uint32_t counted = 0;
   {
     std::lock_guard<std::mutex> lock(c->shared_mutex);
@@ -2685,7 +2805,7 @@ int etx_hip_internal_reduce_prepare(etx_hip_context* c, int local_rc, float4** o
     if (c->read_pending && (c->read_event != nullptr))
       HIP_OK(c, hipStreamWaitEvent(r.stream, c->read_event, 0));  // an asynchronous read-back of the reduced copy still in flight
     HIP_OK(c, hipEventRecord(r.time_begin, r.stream));
-    launch_film_snapshot(r.stream, c->pipe.camera_sum, r.snapshot, uint32_t(n), layer_mask, drop_counts);
+    launch_film_snapshot(r.stream, c->pipe.camera_sum, r.snapshot, uint32_t(n), layer_mask, c->pixel_first, own_stride, c->scene.film_w, c->scene.film_h);
     HIP_OK(c, hipEventRecord(r.snapshot_done, r.stream));
     r.snapshot_recorded = true;
   }

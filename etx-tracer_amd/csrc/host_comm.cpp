@@ -88,6 +88,12 @@ int reduce_begin(etx_hip_context* context, int local_rc, std::string local_error
 
 extern "C" {
 
+void etx_hip_internal_rccl_versions(int* mapped, int* built) {
+  *built = NCCL_VERSION_CODE;
+  *mapped = 0;
+  (void)ncclGetVersion(mapped);
+}
+
 void etx_hip_comm_destroy_internal(etx_hip_context* context) {
   EtxReduceState* r = etx_hip_internal_reduce(context);
   if (r->stream)
@@ -213,6 +219,50 @@ int etx_hip_reduce_film(etx_hip_context* context) {
     return begun;
   const int ended = etx_hip_reduce_film_end(context, 1);
   return (ended < 0) ? ended : ETX_HIP_OK;
+}
+
+// A handful of doubles all-reduced over the communicator (bench.py's barrier and max-over-ranks): pinned words -> device -> ncclAllReduce -> pinned, on
+// the communication stream, behind whatever reduces are in flight there.
+int etx_hip_comm_all_reduce_f64(etx_hip_context* context, double* values, uint32_t count, int op) {
+  if ((context == nullptr) || (values == nullptr) || (count == 0u) || (count > 16u) || (op < ETX_HIP_REDUCE_SUM) || (op > ETX_HIP_REDUCE_MIN))
+    return ETX_HIP_ERROR_INVALID_ARGUMENT;
+  ncclComm_t comm = reinterpret_cast<ncclComm_t>(*etx_hip_internal_comm(context));
+  if (comm == nullptr)
+    return ETX_HIP_OK;  // one rank: the values are the job's
+  EtxReduceState* r = etx_hip_internal_reduce(context);
+  if (hipSetDevice(etx_hip_internal_device(context)) != hipSuccess) {
+    etx_hip_internal_set_error(context, "hipSetDevice failed");
+    return ETX_HIP_ERROR_HIP;
+  }
+  if (r->h_words == nullptr) {
+    if ((hipHostMalloc(reinterpret_cast<void**>(&r->h_words), 32 * sizeof(double), hipHostMallocDefault) != hipSuccess) ||
+        (hipMalloc(reinterpret_cast<void**>(&r->d_words), 32 * sizeof(double)) != hipSuccess)) {
+      etx_hip_internal_set_error(context, "allocation of the collective's words failed");
+      return ETX_HIP_ERROR_HIP;
+    }
+  }
+  memcpy(r->h_words, values, count * sizeof(double));
+  const ncclRedOp_t red = (op == ETX_HIP_REDUCE_SUM) ? ncclSum : ((op == ETX_HIP_REDUCE_MAX) ? ncclMax : ncclMin);
+  if (hipMemcpyAsync(r->d_words, r->h_words, count * sizeof(double), hipMemcpyHostToDevice, r->stream) != hipSuccess) {
+    etx_hip_internal_set_error(context, "hipMemcpyAsync failed (collective words)");
+    return ETX_HIP_ERROR_HIP;
+  }
+  const ncclResult_t res = ncclAllReduce(r->d_words, r->d_words + 16, count, ncclDouble, red, comm, r->stream);
+  if (res != ncclSuccess) {
+    etx_hip_internal_set_error(context, std::string("ncclAllReduce: ") + ncclGetErrorString(res));
+    return ETX_HIP_ERROR_COMM;
+  }
+  if ((hipMemcpyAsync(r->h_words + 16, r->d_words + 16, count * sizeof(double), hipMemcpyDeviceToHost, r->stream) != hipSuccess) || (hipStreamSynchronize(r->stream) != hipSuccess)) {
+    etx_hip_internal_set_error(context, std::string("all-reduce of the collective's words failed: ") + hipGetErrorString(hipGetLastError()));
+    return ETX_HIP_ERROR_HIP;
+  }
+  memcpy(values, r->h_words + 16, count * sizeof(double));
+  return ETX_HIP_OK;
+}
+
+int etx_hip_comm_barrier(etx_hip_context* context) {
+  double word = 1.0;
+  return etx_hip_comm_all_reduce_f64(context, &word, 1u, ETX_HIP_REDUCE_SUM);
 }
 
 int etx_hip_reduce_info(etx_hip_context* context, etx_hip_reduce_info_t* out_info, size_t info_size) {

@@ -37,6 +37,8 @@ struct EtxReduceState {
   unsigned long long* d_counters = nullptr;  // device: [0..1] send {iterations counted by this rank, 1 if this rank failed} (written by a kernel: no host staging a later
                                              // reduce could overwrite), [2..3] receive
   unsigned long long* h_counters = nullptr;  // pinned: [2..3] the received sums of the newest reduce
+  double* h_words = nullptr;           // pinned [32] / device [32]: etx_hip_comm_all_reduce_f64 (send [0..16), receive [16..32))
+  double* d_words = nullptr;
   uint32_t pending = 0;                // reduces enqueued and not yet collected by etx_hip_reduce_film_end. Any number may be in flight: the communication stream
                                        // orders them (snapshot N+1 overwrites the send buffer behind all-reduce N), _begin never waits
   bool valid = false;                  // `reduced` holds a finished reduce of the current run (etx_hip_begin invalidates)

@@ -77,7 +77,7 @@ void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bo
 // film
 void launch_vcm_commit(hipStream_t stream, float4* iteration_camera, float4* iteration_light, float4* camera_sum, float4* light_sum, uint32_t pixels, const uint32_t* counters);
 void launch_set_words(hipStream_t stream, unsigned long long* dst, unsigned long long a, unsigned long long b);  // the counter words of a film reduce
-void launch_film_snapshot(hipStream_t stream, const float4* film, float4* snapshot, uint32_t pixels, uint32_t layer_mask, bool drop_counts);  // multi-GPU reduce, host_reduce.h
+void launch_film_snapshot(hipStream_t stream, const float4* film, float4* snapshot, uint32_t pixels, uint32_t layer_mask, uint32_t own_first, uint32_t own_stride, uint32_t film_w, uint32_t film_h);  // multi-GPU reduce, host_reduce.h
 void launch_film_resolve(hipStream_t stream, const float4* camera_sum, const float4* light_sum, float4* out, uint32_t pixel_count, float scale, int layer, const float4* counts = nullptr);
 
 // known-answer kernels

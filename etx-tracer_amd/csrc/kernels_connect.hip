@@ -274,8 +274,10 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_scan(Pipeline p) {
   o.z = running, running += v.z;
   o.w = running;
   *mine = o;
-  if ((blockIdx.x == 0) && (threadIdx.x == 0))
+  if ((blockIdx.x == 0) && (threadIdx.x == 0)) {
     p.counters[kCntMergeVertices] = all;
+    p.counters[kCntPairs] = 0u;  // the pair list is the merge's from here on (k_connect_pairs of this bounce is done): k_merge_filter_generic appends to it
+  }
 }
 
 __global__ __launch_bounds__(kBlockSize) void k_merge_scatter(Pipeline p) {
@@ -472,70 +474,53 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_diffuse(Pipeline p, VcmPar
   block_stat_add(p, kBlockStatMerged, merged_count, &s_stat);
 }
 
-// Every other connectible material: generic BSDF evaluation per accepted photon (stochastic for the Heitz models).
-// Same shape as k_merge_diffuse - 8 vertices x 8 cells per wave, ranges flattened, accepted photons through the LDS
-// ring, evaluated 64 at a time - with one LDS record per VERTEX (rebuilt intersection, BSDF inputs) written by the
-// first of its eight lanes. A lane-per-range loop left 1 lane in 30 busy inside the conductor random walk
-// (380 ms per iteration on the 1080p gems scene).
-struct MergeVertex {  // per camera vertex, in LDS
-  f3 pos, nrm, tan, btn, w_i, thr_film;
-  f2 tex;
-  float wavelength, w_camera_base, d_vm;
-  uint32_t medium, material, depth, seed;
-};
-
-__global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmParams it) {
-  __shared__ MergeVertex s_vertex[kBlockSize / 64][8];
-  __shared__ float s_acc[kBlockSize / 64][8][4];
-  __shared__ uint2 s_ring[kBlockSize / 64][128];  // (photon, distance^2 bits)
-  __shared__ uint32_t s_ring_range[kBlockSize / 64][128];
+// Every other connectible material: generic BSDF evaluation per accepted photon (stochastic for the Heitz models: a random walk of up to 16 steps).
+// Round 5 did filter and evaluation in ONE kernel shaped like k_merge_diffuse; on the configs[2] family it was 41.5 % of the step at 3 % occupancy and
+// 7 % VALU busy (profiles/round5_pmc_gems_1lane_summary.txt): the vertex list is sorted in space, the gems sit in one corner of it, so a handful of
+// workgroups evaluated every accepted photon while the rest of the grid found nothing to do. Now two kernels, like the connections
+// (k_expand_pairs -> k_connect_pairs):
+//   k_merge_filter_generic  the distance / path-length filter of VCMSpatialGridData::gather (vcm_shared.hxx:829-851) over the flattened ranges of the
+//       generic vertices - 16 bytes per photon examined, no BSDF code, 40 VGPRs; accepted (camera vertex, photon) pairs are appended to the PAIR LIST
+//       (free at this point of a bounce: k_connect_pairs has consumed it; k_merge_scan zeroes its counter), 64 at a time through the LDS ring with one
+//       reservation per 64 pairs;
+//   k_merge_eval_generic    one pair per lane over the dense list, whichever workgroup: bsdf::evaluate + reverse pdf + MIS (:852-884), contributions
+//       of a vertex folded across the wavefront (its pairs are neighbours in the list) before the film atomics.
+__global__ __launch_bounds__(kBlockSize) void k_merge_filter_generic(Pipeline p, VcmParams it) {
+  __shared__ float4 s_pos_depth[kBlockSize / 64][8];  // per camera vertex of the batch: position, total path depth bits
+  __shared__ uint32_t s_vertex[kBlockSize / 64][8];
+  __shared__ uint2 s_ring[kBlockSize / 64][128];      // (camera vertex, photon)
   __shared__ unsigned long long s_stat;
-  const DScene& scene = p.scene;
   const uint32_t count = min(p.counters[kCntMergeVertices], p.cv_capacity);
   const GridParams g = *p.grid_params;
   if ((g.valid == 0u) || (g.photon_count == 0u))
     return;
   const uint32_t items = count * 8u;
-  const bool use_mis = opt_enable_mis(it);
-  const bool use_epan = it.kernel == ETX_VCM_KERNEL_EPANECHNIKOV;
-  const uint32_t max_path_length = scene.max_path_length;
+  const uint32_t max_path_length = p.scene.max_path_length;
   const uint32_t wave = threadIdx.x >> 6u;
-  MergeVertex* verts = s_vertex[wave];
+  float4* pos_depth = s_pos_depth[wave];
+  uint32_t* vertex_of = s_vertex[wave];
   uint2* ring = s_ring[wave];
-  uint32_t* ring_range = s_ring_range[wave];
-  unsigned long long examined = 0, merged_count = 0;
+  unsigned long long examined = 0;
   ETX_XCD_RANGE_LOOP(items) {
     const uint32_t item = base_ + lane_;
     const uint32_t c = item & 7u;
-    uint32_t range_begin = 0, range_len = 0, pixel = 0;
-    bool generic = false;
+    uint32_t range_begin = 0, range_len = 0;
     if (item < seg_end_) {
       const uint32_t vertex = p.merge_order[item >> 3u];
       const float4 pi = p.cv.pos_info[vertex];
       const uint32_t info = __float_as_uint(pi.w);
       const uint32_t depth = info >> 8u;
-      generic = ((info & (kCvDiffuse | kCvMedium)) == 0u) && (depth + 1u <= max_path_length);
+      const bool generic = ((info & (kCvDiffuse | kCvMedium)) == 0u) && (depth + 1u <= max_path_length);
       uint32_t range_end = 0;
       if (generic && merge_cell_range(p, g, f3{pi.x, pi.y, pi.z}, c, range_begin, range_end) && (range_begin < range_end))
         range_len = range_end - range_begin;
-      if (c == 0u)
-        pixel = __float_as_uint(p.cv.mis_pixel[vertex].w);
-      if (generic && (c == 0u)) {  // one lane rebuilds the vertex for its eight ranges
-        CameraVertex cv = load_camera_vertex(p, scene, vertex);
-        MergeVertex& v = verts[lane_ >> 3u];
-        v.pos = cv.isect.pos, v.nrm = cv.isect.nrm, v.tan = cv.isect.tan, v.btn = cv.isect.btn, v.w_i = cv.isect.w_i, v.tex = cv.isect.tex;
-        // c_value = (func x throughput / sampling_pdf).to_rgb(), vcm_shared.hxx:869
-        v.thr_film = cv.st.throughput * spectral_film_weight(scene, cv.st.wavelength);
-        v.wavelength = cv.st.wavelength;
-        v.w_camera_base = cv.st.d_vcm * it.vc_weight;
-        v.d_vm = cv.st.d_vm;
-        v.medium = cv.st.medium, v.material = cv.isect.material, v.depth = cv.st.depth, v.seed = cv.st.sampler.seed;
+      if (generic && (c == 0u)) {
+        pos_depth[lane_ >> 3u] = make_float4(pi.x, pi.y, pi.z, __uint_as_float(depth));
+        vertex_of[lane_ >> 3u] = vertex;
       }
     }
     if (__ballot(range_len != 0u) == 0ull)
       continue;  // no generic vertex with photons in this batch (the common case: the list is sorted in space)
-    if (lane_ < 32u)
-      (&s_acc[wave][0][0])[lane_] = 0.0f;
     uint32_t incl = range_len;
 #pragma unroll
     for (uint32_t d = 1; d < 64; d <<= 1) {
@@ -548,38 +533,17 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
     __threadfence_block();
     if (lane_ == 0)
       examined += total;
-    uint32_t ring_head = 0, ring_tail = 0;
-    auto evaluate = [&](uint32_t entries) {
-      if (lane_ < entries) {
-        const uint2 en = ring[(ring_head + lane_) & 127u];
-        const uint32_t r = ring_range[(ring_head + lane_) & 127u], j = en.x;
-        const float distance_squared = __uint_as_float(en.y);
-        const MergeVertex& v = verts[r >> 3u];
-        const float4 nd = p.grid.nrm_dvcm(j);
-        if (dot(v.nrm, f3{nd.x, nd.y, nd.z}) > kEpsilon) {
-          const float4 wd = p.grid.win_dvm(j);
-          const f3 wi = {wd.x, wd.y, wd.z};
-          const etx_abi_material& mat = scene.materials[v.material];
-          const BsdfData camera_data = {v.nrm, v.tan, v.btn, v.tex, v.w_i, v.medium, kPathCamera, v.wavelength};
-          Sampler smp;  // the reference continues the path's stream through all photons; here one stream per (vertex, photon), keyed by the photon's
-          smp.seed = Sampler::random_seed(v.seed, __float_as_uint(wd.x) ^ (__float_as_uint(wd.w) * 0x9e3779b9u));  // own values, not by where the sort put it
-          smp.fixed_u = smp.fixed_v = smp.fixed_w = 0.0f;
-          const BsdfEval camera_bsdf = bsdf_evaluate_general(scene, camera_data, -wi, v.material, smp);
-          if (camera_bsdf.valid()) {
-            const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, camera_data, -wi, mat, smp);
-            const float w_light = nd.w * it.vc_weight + wd.w * camera_bsdf.pdf;
-            const float w_camera = v.w_camera_base + v.d_vm * rev_pdf;
-            const float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;
-            const float kernel_weight = use_epan ? fmaxf(2.0f * (1.0f - distance_squared * g.inv_radius_squared), 0.0f) : 1.0f;
-            const float4 lt = p.grid.thr(j);
-            const f3 value = camera_bsdf.func * v.thr_film * f3{lt.x, lt.y, lt.z} * (kernel_weight * weight);
-            float* acc = s_acc[wave][r >> 3u];
-            atomicAdd(acc + 0, value.x);
-            atomicAdd(acc + 1, value.y);
-            atomicAdd(acc + 2, value.z);
-            merged_count++;
-          }
-        }
+    uint32_t ring_head = 0, ring_tail = 0;  // wave-uniform
+    auto flush = [&](uint32_t entries) {
+      uint32_t base = 0;
+      if (lane_ == 0)
+        base = atomicAdd(p.counters + kCntPairs, entries);
+      base = __shfl(base, 0);
+      if (base + entries > p.pair_capacity) {
+        if (lane_ == 0)
+          atomicOr(p.counters + kCntOverflow, kOverflowPairs);  // the iteration is discarded, the pools grow, it is rendered again (host_api.cpp execute_iteration)
+      } else if (lane_ < entries) {
+        p.pairs[base + lane_] = ring[(ring_head + lane_) & 127u];
       }
       ring_head += entries;
     };
@@ -597,38 +561,105 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_generic(Pipeline p, VcmPar
       const uint32_t r_offset = __shfl(offset, r);
       bool accept = false;
       uint32_t j = 0;
-      float distance_squared = 0.0f;
       if (e < total) {
         j = r_begin + (e - r_offset);
         const float4 pl = p.grid.pos_len[j];
-        const MergeVertex& v = verts[r >> 3u];
-        const f3 d = f3{pl.x, pl.y, pl.z} - v.pos;
-        distance_squared = dot(d, d);
-        accept = (distance_squared <= g.radius_squared) && (__float_as_uint(pl.w) + v.depth + 1u <= max_path_length);
+        const float4 sp = pos_depth[r >> 3u];
+        const f3 d = f3{pl.x, pl.y, pl.z} - f3{sp.x, sp.y, sp.z};
+        accept = (dot(d, d) <= g.radius_squared) && (__float_as_uint(pl.w) + __float_as_uint(sp.w) + 1u <= max_path_length);
       }
       const unsigned long long mask = __ballot(accept);
       if (accept) {
         const uint32_t at = (ring_tail + __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32u), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u))) & 127u;
-        ring[at] = make_uint2(j, __float_as_uint(distance_squared));
-        ring_range[at] = r;
+        ring[at] = make_uint2(vertex_of[r >> 3u], j);
       }
       ring_tail += uint32_t(__popcll(mask));
       __threadfence_block();
       if (ring_tail - ring_head >= 64u)
-        evaluate(64u);
+        flush(64u);
     }
     if (ring_tail != ring_head)
-      evaluate(ring_tail - ring_head);
-    __threadfence_block();
-    if (((lane_ & 7u) == 0u) && (item < seg_end_)) {
-      const float* acc = s_acc[wave][lane_ >> 3u];
-      const f3 merged = {acc[0], acc[1], acc[2]};
-      if ((merged.x != 0.0f) || (merged.y != 0.0f) || (merged.z != 0.0f))
-        film_add(p, p.camera_sum + film_index(it, pixel), merged * it.vm_normalization);
-    }
-    __threadfence_block();
+      flush(ring_tail - ring_head);
+    __threadfence_block();  // the vertex slots are rewritten at the top of the next batch
   }
   block_stat_add(p, kBlockStatExamined, examined, &s_stat);
+}
+
+struct MergeVertex {  // what the evaluation reads of a camera vertex, per lane in LDS: the rebuilt intersection would otherwise sit in ~40 VGPRs across the BSDF code
+  f3 pos, nrm, tan, btn, w_i, thr_film;
+  f2 tex;
+  float wavelength, w_camera_base, d_vm;
+  uint32_t medium, material, seed;
+};
+
+__global__ __launch_bounds__(kBlockSize) void k_merge_eval_generic(Pipeline p, VcmParams it) {
+  __shared__ MergeVertex s_vertex[kBlockSize];
+  __shared__ unsigned long long s_stat;
+  const DScene& scene = p.scene;
+  const GridParams g = *p.grid_params;
+  const uint32_t count = ((g.valid == 0u) || (g.photon_count == 0u)) ? 0u : pair_list_count(p);
+  const bool use_mis = opt_enable_mis(it);
+  const bool use_epan = it.kernel == ETX_VCM_KERNEL_EPANECHNIKOV;
+  unsigned long long merged_count = 0;
+  MergeVertex& v = s_vertex[threadIdx.x];
+  ETX_WAVE_LOOP(count) {
+    const uint32_t i = base_ + lane_;
+    uint32_t vertex = kInvalid, pixel = 0, j = 0;
+    f3 value = mk3(0.0f);
+    if (i < count) {
+      const uint2 pair = p.pairs[i];
+      vertex = pair.x, j = pair.y;
+      const CameraVertex cv = load_camera_vertex(p, scene, vertex);
+      pixel = cv.st.id;
+      const float4 pi = p.cv.pos_info[vertex];  // the position the filter measured from
+      v.pos = {pi.x, pi.y, pi.z}, v.nrm = cv.isect.nrm, v.tan = cv.isect.tan, v.btn = cv.isect.btn, v.w_i = cv.isect.w_i, v.tex = cv.isect.tex;
+      // c_value = (func x throughput / sampling_pdf).to_rgb(), vcm_shared.hxx:869
+      v.thr_film = cv.st.throughput * spectral_film_weight(scene, cv.st.wavelength);
+      v.wavelength = cv.st.wavelength;
+      v.w_camera_base = cv.st.d_vcm * it.vc_weight;
+      v.d_vm = cv.st.d_vm;
+      v.medium = cv.st.medium, v.material = cv.isect.material, v.seed = cv.st.sampler.seed;
+    }
+    __threadfence_block();  // the record is read back from LDS where it is used, not carried in registers
+    if (i < count) {
+      const float4 nd = p.grid.nrm_dvcm(j);
+      if (dot(v.nrm, f3{nd.x, nd.y, nd.z}) > kEpsilon) {
+        const float4 wd = p.grid.win_dvm(j);
+        const f3 wi = {wd.x, wd.y, wd.z};
+        const etx_abi_material& mat = scene.materials[v.material];
+        const BsdfData camera_data = {v.nrm, v.tan, v.btn, v.tex, v.w_i, v.medium, kPathCamera, v.wavelength};
+        Sampler smp;  // the reference continues the path's stream through all photons; here one stream per (vertex, photon), keyed by the photon's
+        smp.seed = Sampler::random_seed(v.seed, __float_as_uint(wd.x) ^ (__float_as_uint(wd.w) * 0x9e3779b9u));  // own values, not by where the sort put it
+        smp.fixed_u = smp.fixed_v = smp.fixed_w = 0.0f;
+        const BsdfEval camera_bsdf = bsdf_evaluate_general(scene, camera_data, -wi, v.material, smp);
+        if (camera_bsdf.valid()) {
+          const float rev_pdf = bsdf_reverse_pdf_s<false>(scene, camera_data, -wi, mat, smp);
+          const float w_light = nd.w * it.vc_weight + wd.w * camera_bsdf.pdf;
+          const float w_camera = v.w_camera_base + v.d_vm * rev_pdf;
+          const float weight = use_mis ? (1.0f / (1.0f + w_light + w_camera)) : 1.0f;
+          const float4 pl = p.grid.pos_len[j];
+          const f3 d = f3{pl.x, pl.y, pl.z} - v.pos;
+          const float kernel_weight = use_epan ? fmaxf(2.0f * (1.0f - dot(d, d) * g.inv_radius_squared), 0.0f) : 1.0f;
+          const float4 lt = p.grid.thr(j);
+          value = camera_bsdf.func * v.thr_film * f3{lt.x, lt.y, lt.z} * (kernel_weight * weight);
+          merged_count++;
+        }
+      }
+    }
+    // the pairs of a vertex are neighbours in the list (one flush of the filter's ring holds a vertex' photons back to back): fold each run of
+    // equal vertices into its first lane, one set of film atomics per run
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint32_t other = __shfl_down(vertex, d);
+      const float ox = __shfl_down(value.x, d), oy = __shfl_down(value.y, d), oz = __shfl_down(value.z, d);
+      if ((lane_ + d < 64u) && (other == vertex))
+        value.x += ox, value.y += oy, value.z += oz;
+    }
+    const uint32_t before = __shfl_up(vertex, 1);
+    const bool head = (lane_ == 0u) || (before != vertex);
+    if (head && (vertex != kInvalid) && ((value.x != 0.0f) || (value.y != 0.0f) || (value.z != 0.0f)))
+      film_add(p, p.camera_sum + film_index(it, pixel), value * it.vm_normalization);
+  }
   block_stat_add(p, kBlockStatMerged, merged_count, &s_stat);
 }
 
@@ -645,8 +676,11 @@ void launch_merge(hipStream_t stream, const Pipeline& p, const VcmParams& it, bo
   // a multiple of 8 workgroups: one eighth of the sorted list per XCD
   const uint32_t blocks = max(8u, (grid_for(uint32_t(min(uint64_t(min(max_items, p.capacity)) * 8ull, 0xffffff00ull))) + 7u) & ~7u);
   hipLaunchKernelGGL(k_merge_diffuse, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
-  if (generic_materials)
-    hipLaunchKernelGGL(k_merge_generic, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
+  if (generic_materials) {
+    hipLaunchKernelGGL(k_merge_filter_generic, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
+    // the pair count is on the device: a persistent grid over the list, as large as the list can be
+    hipLaunchKernelGGL(k_merge_eval_generic, dim3(max(1u, grid_for(p.pair_capacity))), dim3(kBlockSize), 0, stream, p, it);
+  }
 }
 
 }  // namespace etxd

@@ -291,16 +291,24 @@ void launch_vcm_commit(hipStream_t stream, float4* iteration_camera, float4* ite
 // ---------------------------------------------------------------------------------------------------------------
 // Snapshot of the film sums for the multi-GPU reduce (host_reduce.h): the layers of `layer_mask` (bit = layer index in the film allocation) are
 // copied, the others are left as they are in `snapshot` (zero since allocation). HBM-bound: 32 B per pixel and layer, 16-byte lanes.
-// `drop_counts`: the w of the camera layer (iterations committed per pixel) is written as 0 - for the ranks of pixel shards other than the
-// first under the bidirectional integrator, whose commit counts every pixel of the frame on every pixel shard (the reduced count must be
-// the job's iterations, not shards x iterations; the path tracer counts only the pixels it sampled).
-__global__ __launch_bounds__(kBlockSize) void k_film_snapshot(const float4* __restrict__ film, float4* __restrict__ snapshot, uint32_t pixels, uint32_t layer_mask, uint32_t drop_counts) {
+// own_first / own_stride / film_w / film_h (own_stride > 1: a pixel-sharded bidirectional run): the commit of that integrator counts every pixel of the
+// frame on every shard, so each shard contributes the count of the pixels it OWNS (pixel id = first + k * stride, pipeline.h path_pixel; the film is
+// stored y-flipped) and zero for the others: the reduced count of a pixel is its owner's, whose camera values it normalises exactly whatever the
+// other shards had committed when their snapshots were taken (until then shard 0's count stood for everyone's).
+__global__ __launch_bounds__(kBlockSize) void k_film_snapshot(const float4* __restrict__ film, float4* __restrict__ snapshot, uint32_t pixels, uint32_t layer_mask, uint32_t own_first,
+  uint32_t own_stride, uint32_t film_w, uint32_t film_h) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += gridDim.x * blockDim.x) {
+    bool keep_count = true;
+    if (own_stride > 1u) {
+      const uint32_t fx = i % film_w, fy = i / film_w;
+      const uint32_t pixel_id = fx + (film_h - 1u - fy) * film_w;  // film_index, dev_vcm.h
+      keep_count = (pixel_id % own_stride) == own_first;
+    }
 #pragma unroll
     for (uint32_t layer = 0; layer < 4u; ++layer) {
       if ((layer_mask >> layer) & 1u) {
         float4 v = film[size_t(layer) * pixels + i];
-        if ((layer == 0u) && drop_counts)
+        if ((layer == 0u) && (keep_count == false))
           v.w = 0.0f;
         snapshot[size_t(layer) * pixels + i] = v;
       }
@@ -317,8 +325,8 @@ void launch_set_words(hipStream_t stream, unsigned long long* dst, unsigned long
   hipLaunchKernelGGL(k_set_words, dim3(1), dim3(64), 0, stream, dst, a, b);
 }
 
-void launch_film_snapshot(hipStream_t stream, const float4* film, float4* snapshot, uint32_t pixels, uint32_t layer_mask, bool drop_counts) {
-  hipLaunchKernelGGL(k_film_snapshot, dim3(grid_for(pixels)), dim3(kBlockSize), 0, stream, film, snapshot, pixels, layer_mask, drop_counts ? 1u : 0u);
+void launch_film_snapshot(hipStream_t stream, const float4* film, float4* snapshot, uint32_t pixels, uint32_t layer_mask, uint32_t own_first, uint32_t own_stride, uint32_t film_w, uint32_t film_h) {
+  hipLaunchKernelGGL(k_film_snapshot, dim3(grid_for(pixels)), dim3(kBlockSize), 0, stream, film, snapshot, pixels, layer_mask, own_first, own_stride, film_w, film_h);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

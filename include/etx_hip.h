@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define ETX_HIP_ABI_VERSION 3 /* 3: reference_seeding in the option structs, the asynchronous film reduce (etx_hip_reduce_film_begin / _end / _info) */
+#define ETX_HIP_ABI_VERSION 4 /* 3: reference_seeding in the option structs, the asynchronous film reduce (etx_hip_reduce_film_begin / _end / _info);
+                                 4: etx_hip_runtime_info, etx_hip_comm_all_reduce_f64 / _barrier, etx_hip_trace_rays_timed */
 
 typedef struct etx_hip_context etx_hip_context; /* opaque */
 
@@ -290,7 +291,7 @@ size_t etx_hip_device_bytes(const etx_hip_context* context);
 /* multi GPU: iterations (etx_hip_begin first / stride) or pixels (etx_hip_begin_ex) are sharded over ranks; the only exchange is an RCCL
  * sum-reduce of the float4 film layers the armed integrator writes - VCM: camera + light, 32 B per pixel (66 MB at 1080p); path tracer: camera +
  * normal + albedo; bidirectional: all four - plus two counter words. The 128-byte ncclUniqueId is created by rank 0 with
- * etx_hip_comm_unique_id and distributed by the host (bench.py: torch.distributed). */
+ * etx_hip_comm_unique_id and distributed by the host (etx_tracer_amd/multi_gpu.py: a file on the node, or the host's own process group). */
 #define ETX_HIP_UNIQUE_ID_BYTES 128
 int etx_hip_comm_unique_id(void* out_id_128_bytes);
 /* Joins the communicator and allocates what a reduce needs (communication stream, events, counters; the two film-sized buffers as soon as a scene
@@ -338,6 +339,23 @@ typedef struct etx_hip_reduce_info_t {
 } etx_hip_reduce_info_t;
 int etx_hip_reduce_info(etx_hip_context* context, etx_hip_reduce_info_t* out_info, size_t info_size);
 
+/* Two small collectives over the context's communicator for a host that has no process-group library of its own (bench.py: barrier and "the
+ * slowest rank's time" without loading a second ROCm runtime into the process). Every rank calls them in the same order; they are ordered
+ * behind the film reduces on the communication stream and return when the result is in `values`. op: 0 sum, 1 max, 2 min; count <= 16.
+ * A context without a communicator (one rank) returns at once with `values` unchanged. */
+#define ETX_HIP_REDUCE_SUM 0
+#define ETX_HIP_REDUCE_MAX 1
+#define ETX_HIP_REDUCE_MIN 2
+int etx_hip_comm_all_reduce_f64(etx_hip_context* context, double* values, uint32_t count, int op);
+int etx_hip_comm_barrier(etx_hip_context* context);
+
+/* The HIP runtime this process runs the library on: out_versions = {hipRuntimeGetVersion() of the runtime mapped into the process, HIP_VERSION
+ * the library was compiled against, RCCL version of the mapped librccl, RCCL version compiled against}. etx_hip_create refuses (ETX_HIP_ERROR_HIP)
+ * a runtime whose major.minor is OLDER than the one the library was built for - what happens when a package that bundles its own ROCm runtime
+ * under the same sonames (a PyTorch wheel) is imported before libetx_hip.so is loaded; load the library first, or set ETX_HIP_ALLOW_OLDER_RUNTIME=1
+ * to run anyway. No context needed. */
+int etx_hip_runtime_info(int out_versions[4]);
+
 /* ------------------------------------------------------------------------------------------------------------ */
 /* kernel-level entry points (used by tests/ and bench.py; the host integrator does not need them) */
 
@@ -349,6 +367,10 @@ int etx_hip_trace_rays(etx_hip_context* context, const float* rays_8f, uint64_t 
 /* Same kernel on device-resident buffers (device pointers), `repeat` launches back to back; returns the average
  * kernel time in ms measured with HIP events on the launch stream. Used by bench.py for the traversal roofline. */
 int etx_hip_trace_rays_device(etx_hip_context* context, const void* d_rays_o_tmin, const void* d_rays_d_tmax, uint64_t count, void* d_hits, uint32_t repeat, double* out_avg_ms);
+
+/* The same measurement for a host without device buffers of its own: rays as for etx_hip_trace_rays (host), uploaded once, one untimed launch,
+ * then `repeat` timed launches over the device-resident queue; hits_4f (nullable) receives the hits of the last launch. */
+int etx_hip_trace_rays_timed(etx_hip_context* context, const float* rays_8f, uint64_t count, uint32_t repeat, double* out_avg_ms, float* hits_4f);
 
 /* Runs a device-side known-answer kernel: `which` selects the function, in/out are host float arrays.
  *   0: Sampler        in: n*{a,b} as u32 bits           out: n*{seed bits, next(), next(), next()}   (sampler.hxx:54-77)

@@ -14,6 +14,9 @@ class LazyModule:
         self.__dict__["_module"] = None
 
     def __getattr__(self, attribute):
+        if attribute.startswith("_"):
+            # pytest's collector probes every module-level object of a test module (__test__, _pytestfixturefunction, ...): none of that may import torch
+            raise AttributeError(attribute)
         if self.__dict__["_module"] is None:
             self.__dict__["_module"] = importlib.import_module(self.__dict__["_name"])
         return getattr(self.__dict__["_module"], attribute)

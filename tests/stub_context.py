@@ -117,7 +117,7 @@ class StubContext:
 
     def _reduce(self):
         camera, light = self.camera_sum.clone(), self.light_sum.clone()  # the snapshot: the context's own sums are never modified
-        counted = self.count.clone() if self.pixel_first == 0 else torch.zeros_like(self.count)  # pixel shards hold the SAME iterations: shard 0 counts them
+        counted = self.count.clone() if self.pixel_first == 0 else torch.zeros_like(self.count)  # pixel shards hold the SAME iterations: the job's iteration counter is shard 0's (per pixel, the device reduces each owner's count)
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(camera, op=dist.ReduceOp.SUM)
             dist.all_reduce(light, op=dist.ReduceOp.SUM)
@@ -161,6 +161,22 @@ class StubContext:
 
     def trace_rays_device(self, d_o, d_d, count, d_hits, repeat):
         return 0.05
+
+    def trace_rays_timed(self, rays, repeat, want_hits=False):
+        return 0.05
+
+    def comm_all_reduce(self, values, op=api.REDUCE_SUM):
+        """etx_hip_comm_all_reduce_f64 over the test's gloo group"""
+        self.calls.append(("comm_all_reduce", int(op)))
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(t, op={api.REDUCE_SUM: dist.ReduceOp.SUM, api.REDUCE_MAX: dist.ReduceOp.MAX, api.REDUCE_MIN: dist.ReduceOp.MIN}[int(op)])
+        return [float(v) for v in t]
+
+    def comm_barrier(self):
+        self.calls.append(("comm_barrier",))
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.barrier()
 
     def close(self):
         self.calls.append(("close",))

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(etx):
     missing = [s for s in symbols if not lib.has_symbol(s)]
     assert missing == []
     assert set(etx.api.EXPORTED_SYMBOLS) == set(symbols)
-    assert lib.lib.etx_hip_abi_version() == 3  # 2: etx_hip_stats_t grew (pool_grows), etx_hip_set_pool_policy; 3: reference_seeding, asynchronous film reduce
+    assert lib.lib.etx_hip_abi_version() == 4  # 2: etx_hip_stats_t grew (pool_grows), etx_hip_set_pool_policy; 3: reference_seeding, asynchronous film reduce; 4: runtime info, small collectives, timed trace
 
 
 def test_missing_library_is_an_error(etx, tmp_path):
@@ -81,8 +81,7 @@ def test_options_mapping_follows_vcmoptions_load(etx):
 
 
 def test_create_without_gpu_fails_loudly(etx):
-    import torch
-    if torch.cuda.is_available():
+    if os.path.exists("/dev/kfd"):  # (not torch.cuda.is_available(): importing the torch wheel maps its own, older ROCm runtime into the process)
         pytest.skip("a GPU is present")
     from etx_tracer_amd import api
     with pytest.raises(api.EtxHipError) as e:
@@ -95,8 +94,7 @@ def test_cpp_binding_fails_loudly_without_a_device():
     fails, HIPVCM::run() logs the error and stays Stopped (the reference's convention), the driver exits with code 6 - it
     never falls back to the CPU integrator."""
     import subprocess
-    import torch
-    if torch.cuda.is_available():
+    if os.path.exists("/dev/kfd"):
         pytest.skip("a GPU is present: the binding is exercised by tests/test_gpu_binding.py")
     oracle = os.path.join(ROOT, "oracle", "_ref", "etx_oracle")
     if not os.path.exists(oracle):

@@ -46,9 +46,24 @@ def worker(rank, world, port, total, h, w, out_dir):
         def comm_init(self, r, w, unique_id):
             calls.append((r, w, bytes(unique_id)))
 
-    received = multi_gpu.init_context_comm(StubContext(), rank, world, make_id=lambda: bytes(range(128)))
+        def comm_barrier(self):
+            dist.barrier()
+
+        def comm_all_reduce(self, values, op):
+            t = torch.tensor(values, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return [float(v) for v in t]
+
+    # through the host's own process group ...
+    received = multi_gpu.init_context_comm(StubContext(), rank, world, make_id=lambda: bytes(range(128)), broadcast=lambda payload: multi_gpu.torch_broadcast(payload, rank))
     assert calls == [(rank, world, bytes(range(128)))] and bytes(received) == bytes(range(128))
-    assert multi_gpu.max_over_ranks(1.0 + rank) == float(world)  # the slowest rank's time
+    # ... and through the default exchange, a file on the node (what bench.py uses: no torch in a rendering process)
+    os.environ["ETX_HIP_RENDEZVOUS_DIR"] = out_dir
+    received = multi_gpu.init_context_comm(StubContext(), rank, world, make_id=lambda: bytes(range(64, 192)))
+    assert calls[1] == (rank, world, bytes(range(64, 192))) and bytes(received) == bytes(range(64, 192))
+    dist.barrier()
+    assert [f for f in os.listdir(out_dir) if f.startswith("etx_hip_rendezvous")] == []  # rank 0 removed it after the barrier
+    assert multi_gpu.max_over_ranks(StubContext(), 1.0 + rank) == float(world)  # the slowest rank's time
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), film.result().numpy())
     np.save(os.path.join(out_dir, "count%d.npy" % rank), film.iterations.numpy())
     dist.barrier()
@@ -91,12 +106,15 @@ def bench_worker(rank, world, port, out_dir):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
-    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "ETX_HIP_RENDEZVOUS_DIR": out_dir})
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # the stub context's collectives; bench.py itself never touches torch
     import bench
     from tests.stub_context import StubContext
     stdout = io.StringIO()
     with contextlib.redirect_stdout(stdout):
-        line = bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--workload", "classic"], context_factory=StubContext, backend="gloo")
+        line = bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--workload", "classic", "--repeats", "3"], context_factory=StubContext)
+    dist.barrier()
+    dist.destroy_process_group()
     ctx = StubContext.instances[-1]
     printed = [l for l in stdout.getvalue().splitlines() if l.startswith("{")]
     assert (len(printed) == 1) == (rank == 0)  # ONE JSON line, from rank 0
@@ -147,14 +165,17 @@ def pixel_bench_worker(rank, world, port, out_dir):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
-    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "ETX_HIP_RENDEZVOUS_DIR": out_dir})
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     import bench
     from tests.stub_context import StubContext
     stdout = io.StringIO()
     with contextlib.redirect_stdout(stdout):
         bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--workload", "cloud_bdpt", "--shard", "pixels", "--no-cpu-baseline", "--no-kernel-table", "--reduce-every", "2",
                     "--repeats", "2"],
-                   context_factory=StubContext, backend="gloo")
+                   context_factory=StubContext)
+    dist.barrier()
+    dist.destroy_process_group()
     ctx = StubContext.instances[-1]
     if rank == 0:
         with open(os.path.join(out_dir, "pixel_line.json"), "w") as f:
