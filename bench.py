@@ -117,6 +117,7 @@ def main(argv=None, context_factory=None):
     parser.add_argument("--comm-single", action="store_true",
                         help="N = 1 only: create a one-rank RCCL communicator, so that the reduces of the timed region run (snapshot kernel + one-rank all-reduce) and their "
                              "device time can be read on one GPU (reduce.device_ms_avg); without it a single GPU has nothing to reduce")
+    parser.add_argument("--debug-flags", type=int, default=0, help="etx_hip_set_debug_flags before the scene upload: kernel variants for A/B runs (64: two-ray packed sweep, 128: matrix-core sweep); 0 = the product")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-kernel-table", action="store_true", help="skip the extra pass that times every kernel group (profiling runs)")
     args = parser.parse_args(argv)
@@ -155,6 +156,8 @@ def main(argv=None, context_factory=None):
     width, height = snap.film_size
     ctx = (context_factory or api.Context)(local_rank)
     ctx.set_bvh_builder(api.BVH_DEVICE_LBVH if args.bvh == "device" else api.BVH_HOST_SAH)
+    if args.debug_flags:
+        ctx.set_debug_flags(args.debug_flags)  # kept by the pipelines etx_hip_upload_scene allocates
     lanes = ctx.lanes(api.INTEGRATOR_BDPT if bdpt_workload else api.INTEGRATOR_VCM)  # iterations in flight (etx_hip_lanes)
     upload_t0 = time.perf_counter()
     ctx.upload_scene(snap)
@@ -397,7 +400,7 @@ def main(argv=None, context_factory=None):
                                ("every %d iteration(s) + the final one" % args.reduce_every if args.reduce_every > 0 else "once at the end of the timed region"),
                 "working_set_gb": round(ctx.device_bytes() / 1.0e9, 2),  # queues, pools, grid and film of all lanes (etx_hip_device_bytes)
                 "pool_grows": int(acc["stats"].pool_grows),  # iterations of the timed region that overflowed a pool and were rendered again (0 once the pools have their size)
-                "lanes": lanes, "workload_key": args.workload, "library_sha16": library_sha16(),
+                "lanes": lanes, "workload_key": args.workload, "library_sha16": library_sha16(), "debug_flags": args.debug_flags,
                 # the ROCm runtime this process ran on: versions (hipRuntimeGetVersion / the HIP_VERSION the library was compiled against, the same for RCCL)
                 # and the files they are mapped from - one of each in a healthy process
                 "runtime": api.runtime_info() if context_factory is None else None,

@@ -179,7 +179,8 @@ class Library:
         # every symbol HERE. With lazy binding a package imported later that maps a second ROCm stack into the global namespace (the torch wheel
         # bundles 7.0.2 under torch/lib) would capture whichever calls had not happened yet - seen in round 6: hipRuntimeGetVersion answered by the
         # wheel's runtime in a process whose libetx_hip.so had been loaded against /opt/rocm first.
-        self.lib = ctypes.CDLL(path, mode=os.RTLD_NOW | os.RTLD_LOCAL)
+        # (ETX_HIP_DLOPEN_LAZY=1: the default lazy binding again - a diagnostic of round 6, tools/gpu_calls/gpu_r6g.sh)
+        self.lib = ctypes.CDLL(path) if os.environ.get("ETX_HIP_DLOPEN_LAZY") else ctypes.CDLL(path, mode=os.RTLD_NOW | os.RTLD_LOCAL)
         L = self.lib
         vp, u32, u64, i32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_size_t
         L.etx_hip_abi_version.restype = i32

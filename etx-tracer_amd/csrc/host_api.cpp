@@ -1203,6 +1203,9 @@ int ensure_lanes(etx_hip_context* context, uint32_t wanted, std::string& error) 
     context->helpers.push_back(helper);
     if (int rc = init_lane(helper, context->device, error))
       return rc;
+    // what etx_hip_set_timers / etx_hip_set_debug_flags told the lanes that existed then
+    helper->timer_mask = context->timer_mask;
+    helper->debug_flags = helper->pipe.debug_flags = context->debug_flags;
   }
   return ETX_HIP_OK;
 }

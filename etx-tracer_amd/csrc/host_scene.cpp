@@ -810,6 +810,14 @@ int build_traversal_tables(const etx_abi_scene* scene, DeviceScene& out, DScene&
   d.bvh_depth = bvh.depth4;
   d.bvh_stack_need = bvh.stack_need;
   d.bvh_flat = (bvh.tris.size() <= kFlatSweepMaxTriangles) ? 1u : 0u;
+  if (d.bvh_flat != 0u) {  // bit 1: a primitive is alpha tested (per-candidate random draws in sweep order: the matrix-core sweep does not take such scenes)
+    for (const BvhTri& t : bvh.tris) {
+      uint32_t flags = 0;
+      memcpy(&flags, &t.e1_flags.w, 4);
+      if (flags & kTriAlphaTested)
+        d.bvh_flat |= 2u;
+    }
+  }
   if (tuning_knob("ETX_HIP_FORCE_BVH", 0u) != 0u)
     d.bvh_flat = 0u;
   out.bvh_depth = bvh.depth4;

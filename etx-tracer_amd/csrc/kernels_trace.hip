@@ -451,6 +451,225 @@ static uint32_t lds_limit() {  // experiments: ETX_HIP_LDS_NODES caps the staged
 // Variant by the stack the scene's tree needs (three entries per BVH4 level): 16 entries -> 24 KB of LDS per workgroup and six resident
 // workgroups per CU, 32 entries otherwise; a deep tree (> ~40 000 triangles: bound above 32) the checked stack, 16 entries in LDS, the rest in the
 // global spill rows (dev_bvh.h ShortLaneStack; a million triangles: 13.1 vs 12.8 Msamples/s with 32 entries in LDS).
+// ---------------------------------------------------------------------------------------------------------------
+// Flat sweep with the affine part on the MATRIX cores (north_star: "MFMA ... for the per-vertex 3x3 frame transforms if rocprof shows it paying
+// off"). The sweep's test of primitive p against ray r is three affine forms of the hit point (plane distance and the two
+// parallelogram coordinates: FlatPrim rows `plane`, `row_a`, `row_b`, each [x y z w]) - and since the hit point is o + t d, each is
+// row.[o;1] + t (row.[d;0]): SIX dot products per (primitive, ray) that do not depend on one another. That is a small dense product: rows of four
+// primitives (16 rows, the fourth of each primitive zero) x the [o;1] and [d;0] columns of the 64 rays of a wavefront = 7 x
+// v_mfma_f32_16x16x1_4b_f32 (K = 1: one ray component per instruction, the zero w of d skipped), 224 matrix-pipe cycles for 256 (primitive, ray) tests.
+// What is left on the VALU per test: t = -num / den (v_rcp + v_mul), a = Ao + t Ad, b = Bo + t Bd (2 v_fma), the inside minimum (5), three compares and
+// four selects: 16 instructions where flat_prim_test + the best-hit update issue 29.
+// Layout (CDNA3/4 ISA, V_MFMA_F32_16X16X1_4B_F32: four independent 16x16 blocks; lane l feeds A[l % 16] and B[l % 16] of block l / 16 and receives,
+// in accumulator 4 b + r, D_b[4 (l / 16) + r][l % 16]): block b = rays 16 b .. 16 b + 15 of the wavefront, so a lane supplies ITS OWN ray as B and row
+// l % 16 of the current four primitives as A (read from LDS), and gets back the six forms of ONE primitive (slot g = l / 16 of the four) for FOUR rays
+// (l % 16 of every block). Every lane therefore tests one primitive against four rays per step and keeps four running best hits; after the last
+// step the four lanes that share a ray (l, l ^ 16, l ^ 32, l ^ 48) fold their bests (ties go to the higher primitive index, as the sequential `t <=
+// best` of bvh_flat_closest gives them) and lane l picks block l / 16: its own ray.
+// Scenes with alpha-tested primitives (per-candidate random draws in sweep order) keep the VALU sweep (DScene::bvh_flat bit 1).
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr uint32_t kMfmaSets = kFlatSweepMaxTriangles / 4u;  // steps of four primitives
+
+struct MfmaTables {  // LDS
+  float4 rows[kMfmaSets * 16u];   // [step][row]: plane / row_a / row_b / 0 of primitive 4 step + row / 4 (all zero: void, degenerate or padding - never hit)
+  float quad[kMfmaSets * 4u];     // per primitive: 1 = parallelogram, 0 = triangle
+  uint32_t flags[kMfmaSets * 4u];
+};
+
+ETX_DEV void mfma_stage_tables(const DScene& scene, MfmaTables& tables) {
+  const uint32_t prim_count = scene.flat_prim_count;
+  const float* source = reinterpret_cast<const float*>(scene.flat_prims);
+  for (uint32_t i = threadIdx.x; i < kMfmaSets * 16u; i += blockDim.x) {
+    const uint32_t prim = (i >> 4u) * 4u + ((i & 15u) >> 2u), which = i & 3u;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if ((prim < prim_count) && (which < 3u)) {
+      const float* t = source + size_t(prim) * 16u;
+      if ((__float_as_uint(t[12]) & kTriVoid) == 0u)
+        v = make_float4(t[which * 4u + 0u], t[which * 4u + 1u], t[which * 4u + 2u], t[which * 4u + 3u]);
+    }
+    tables.rows[i] = v;
+  }
+  for (uint32_t i = threadIdx.x; i < kMfmaSets * 4u; i += blockDim.x) {
+    const uint32_t flags = (i < prim_count) ? __float_as_uint(source[size_t(i) * 16u + 12u]) : 0u;
+    tables.flags[i] = flags;
+    tables.quad[i] = (flags & kTriQuad) ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+}
+
+// Closest primitive of the lane's own ray (origin / tmin in `a`, direction / tmax in `b`; a lane without a ray passes tmax < tmin). Must be called by
+// ALL 64 lanes of the wavefront (the matrix instructions take their operands from every lane).
+ETX_DEV void mfma_sweep(const MfmaTables& tables, uint32_t steps, const float4& a, const float4& b, float& out_t, float& out_a, float& out_b, int32_t& out_prim) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t col = lane & 15u, slot = lane >> 4u;
+  float tmin4[4], best_t[4], best_a[4], best_b[4];
+  int32_t best_p[4];
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) {
+    tmin4[k] = __shfl(a.w, int(16u * k + col));
+    best_t[k] = __shfl(b.w, int(16u * k + col));
+    best_a[k] = best_b[k] = 0.0f;
+    best_p[k] = -1;
+  }
+  // software pipeline: the seven matrix instructions of step s + 1 are issued before the VALU work on the results of step s, so the (separate)
+  // matrix pipe computes while this wavefront's own VALU instructions issue - not only those of the other wavefronts of the SIMD
+  const floatx16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  auto forms = [&](uint32_t step, floatx16& with_o, floatx16& with_d) {
+    const float4 row = tables.rows[step * 16u + col];
+    with_o = __builtin_amdgcn_mfma_f32_16x16x1f32(row.x, a.x, zero16, 0, 0, 0);
+    with_d = __builtin_amdgcn_mfma_f32_16x16x1f32(row.x, b.x, zero16, 0, 0, 0);
+    with_o = __builtin_amdgcn_mfma_f32_16x16x1f32(row.y, a.y, with_o, 0, 0, 0);
+    with_d = __builtin_amdgcn_mfma_f32_16x16x1f32(row.y, b.y, with_d, 0, 0, 0);
+    with_o = __builtin_amdgcn_mfma_f32_16x16x1f32(row.z, a.z, with_o, 0, 0, 0);
+    with_d = __builtin_amdgcn_mfma_f32_16x16x1f32(row.z, b.z, with_d, 0, 0, 0);
+    with_o = __builtin_amdgcn_mfma_f32_16x16x1f32(row.w, 1.0f, with_o, 0, 0, 0);
+  };
+  auto tests = [&](uint32_t step, const floatx16& with_o, const floatx16& with_d) {
+    const float quad = tables.quad[step * 4u + slot];
+    const float tri = 1.0f - quad;
+    const int32_t prim = int32_t(step * 4u + slot);
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+      const float num = with_o[4u * k + 0u], a_o = with_o[4u * k + 1u], b_o = with_o[4u * k + 2u];
+      const float den = with_d[4u * k + 0u], a_d = with_d[4u * k + 1u], b_d = with_d[4u * k + 2u];
+      const float t = -num * __builtin_amdgcn_rcpf(den);  // den = 0 (parallel, void, padding): inf / nan fail the comparisons below
+      const float ca = fmaf(t, a_d, a_o), cb = fmaf(t, b_d, b_o);
+      const float e = fmaf(-tri, ca, 1.0f - cb);
+      const float f = fmaf(-quad, ca, 1.0f);
+      const float inside = fminf(fminf(fminf(ca, cb), e), f);
+      const bool hit = bool(int(t >= tmin4[k]) & int(t <= best_t[k]) & int(inside >= 0.0f));  // no short circuit: four selects, no branch
+      best_t[k] = hit ? t : best_t[k];
+      best_a[k] = hit ? ca : best_a[k];
+      best_b[k] = hit ? cb : best_b[k];
+      best_p[k] = hit ? prim : best_p[k];
+    }
+  };
+  // two result sets, used alternately (a loop that handed `next` over to `current` copied 32 registers per step)
+  floatx16 o0, d0, o1 = zero16, d1 = zero16;
+  forms(0u, o0, d0);
+  for (uint32_t step = 0; step < steps; step += 2u) {  // trip counts and branches are wave-uniform
+    const bool second = step + 1u < steps;
+    if (second)
+      forms(step + 1u, o1, d1);
+    tests(step, o0, d0);
+    if (second) {
+      if (step + 2u < steps)
+        forms(step + 2u, o0, d0);
+      tests(step + 1u, o1, d1);
+    }
+  }
+  // the four lanes of a ray: nearer wins, equal distances go to the higher primitive index (-1 = none is the lowest)
+#pragma unroll
+  for (uint32_t distance = 16u; distance <= 32u; distance <<= 1u) {
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+      const float ot = __shfl_xor(best_t[k], int(distance)), oa = __shfl_xor(best_a[k], int(distance)), ob = __shfl_xor(best_b[k], int(distance));
+      const int32_t op = __shfl_xor(best_p[k], int(distance));
+      const bool take = bool(int(op >= 0) & (int(best_p[k] < 0) | int(ot < best_t[k]) | (int(ot == best_t[k]) & int(op > best_p[k]))));
+      best_t[k] = take ? ot : best_t[k], best_a[k] = take ? oa : best_a[k], best_b[k] = take ? ob : best_b[k], best_p[k] = take ? op : best_p[k];
+    }
+  }
+  out_t = (slot == 0u) ? best_t[0] : ((slot == 1u) ? best_t[1] : ((slot == 2u) ? best_t[2] : best_t[3]));
+  out_a = (slot == 0u) ? best_a[0] : ((slot == 1u) ? best_a[1] : ((slot == 2u) ? best_a[2] : best_a[3]));
+  out_b = (slot == 0u) ? best_b[0] : ((slot == 1u) ? best_b[1] : ((slot == 2u) ? best_b[2] : best_b[3]));
+  out_prim = (slot == 0u) ? best_p[0] : ((slot == 1u) ? best_p[1] : ((slot == 2u) ? best_p[2] : best_p[3]));
+}
+
+// (two workgroups per CU as the minimum occupancy = at most 256 registers per lane: with that bound the compiler keeps the matrix results in
+// ordinary VGPRs - "VGPR form" - instead of accumulation registers it would have to copy out one v_accvgpr_read at a time, 8 extra VALU per test)
+template <bool kFromCounter, bool kCross>
+__global__ __launch_bounds__(kBlockSize, 2) void k_trace_closest_mfma(const DScene scene_arg, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* __restrict__ hits,
+  uint32_t* __restrict__ counters, uint32_t active_counter, uint32_t fixed_count, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat, PathSet set = {},
+  uint32_t cross_mode = kCrossNone, unsigned long long* block_stats = nullptr) {
+  __shared__ MfmaTables s_tables;
+  const DScene& scene = scene_arg;
+  const uint32_t count = kFromCounter ? counters[active_counter] : fixed_count;
+  if (kFromCounter && (blockIdx.x == 0) && (threadIdx.x == 0)) {
+    round_housekeeping(counters, active_counter, count, pass_stat, round_mirror, round_tag);
+  }
+  mfma_stage_tables(scene, s_tables);
+  const uint32_t steps = (scene.flat_prim_count + 3u) / 4u;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  unsigned long long crossed_queries = 0ull;
+  for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x - lane; base < count; base += stride) {  // wave-uniform trip count: every lane runs every sweep
+    const uint32_t i = base + lane;
+    const bool live = i < count;
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = make_float4(0.0f, 0.0f, 1.0f, -1.0f);  // no ray: an empty interval
+    if (live)
+      a = ray_o_tmin[i], b = ray_d_tmax[i];
+    float t, ca, cb;
+    int32_t prim;
+    mfma_sweep(s_tables, steps, a, b, t, ca, cb, prim);
+    if (kCross) {
+      uint32_t crossings = 0u, medium = kInvalid;
+      float crossed = 0.0f;
+      f3 origin = {a.x, a.y, a.z};
+      const f3 direction = {b.x, b.y, b.z};
+      bool crossing = live && (prim >= 0) && ((s_tables.flags[prim >= 0 ? prim : 0] & kTriBoundary) != 0u);
+      if (crossing) {
+        medium = set.meta[i].z;
+        crossing = medium == kInvalid;
+      }
+      while (__any(crossing)) {  // wave-uniform: the matrix instructions need every lane; a lane that is not crossing sweeps an empty interval
+        float4 na = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nb = make_float4(0.0f, 0.0f, 1.0f, -1.0f);
+        if (crossing) {
+          const Hit h = flat_resolve(scene, uint32_t(prim), ca, cb, t);
+          const etx_abi_triangle& tri = scene.triangles[h.tri];
+          const etx_abi_material& mat = scene.materials[tri.material_index];
+          medium = (dot(ld3(tri.geo_n), direction) < 0.0f) ? mat.int_medium : mat.ext_medium;
+          crossed += t;
+          origin = shading_pos(scene, tri, barycentrics(h.u, h.v), direction);
+          crossings += 1u;
+          na = mk4(origin, kRayEpsilon), nb = mk4(direction, kMaxFloat);
+        }
+        float nt, nca, ncb;
+        int32_t nprim;
+        mfma_sweep(s_tables, steps, na, nb, nt, nca, ncb, nprim);
+        if (crossing) {
+          t = nt, ca = nca, cb = ncb, prim = nprim;
+          // the next boundary is crossed too only by a path that is (still) in no medium
+          crossing = (prim >= 0) && ((s_tables.flags[prim] & kTriBoundary) != 0u) && (medium == kInvalid) && (crossings < 8u);
+        }
+      }
+      crossed_queries += crossings;
+      if (crossings != 0u) {
+        const_cast<float4*>(ray_o_tmin)[i] = mk4(origin, kRayEpsilon);
+        const_cast<float4*>(ray_d_tmax)[i] = mk4(direction, kMaxFloat);
+        uint4 meta = set.meta[i];
+        meta.z = medium;
+        if (cross_mode == kCrossBdpt) {
+          Sampler stream;
+          stream.seed = meta.x;
+          for (uint32_t k = 0; k < crossings * 6u; ++k)
+            (void)stream.next();
+          meta.x = stream.seed;
+        }
+        set.meta[i] = meta;
+        if (cross_mode == kCrossVcm) {
+          float4 mis = set.mis[i];
+          mis.w += crossed;
+          set.mis[i] = mis;
+        }
+      }
+    }
+    if (live) {
+      if (prim < 0) {
+        hits[i] = make_float4(0.0f, 0.0f, t, __uint_as_float(kInvalid));  // t = the tmax of the (last) segment swept: mfma_sweep starts from it
+      } else {
+        const Hit h = flat_resolve(scene, uint32_t(prim), ca, cb, t);
+        hits[i] = make_float4(h.u, h.v, h.t, __uint_as_float(h.tri));
+      }
+    }
+  }
+  if (kCross) {
+    __shared__ unsigned long long s_stat;
+    Pipeline stats_only = {};
+    stats_only.block_stats = block_stats;
+    block_stat_add(stats_only, kBlockStatCrossings, crossed_queries, &s_stat);
+  }
+}
+
 template <bool kFromCounter>
 static void launch_bvh_kernel(hipStream_t stream, const DScene& scene, const float4* ray_o_tmin, const float4* ray_d_tmax, float4* hits, uint32_t* counters, uint32_t active_counter,
   uint32_t items, unsigned long long* round_mirror, uint32_t round_tag, uint32_t pass_stat) {
@@ -478,7 +697,15 @@ void launch_trace_closest(hipStream_t stream, const Pipeline& p, uint32_t set, u
   uint32_t blocks = max(1u, min(kPersistentBlocks, (min(p.capacity, max_items) + kBlockSize - 1) / kBlockSize));
   // opt-in (ETX_HIP_DEBUG_FLAGS bit 64): alone on the device the two-ray sweep is 10 % faster (39.3 vs 35.7 Grays/s on 2 M incoherent
   // rays), inside the 4-lane pipeline its fatter waves lose against the co-running kernels (51.5 vs 46.6 us per launch) - DESIGN.md 3
-  if (flat && (p.debug_flags & 64u))
+  // opt-in (debug flag 128): the sweep with its affine part on the matrix cores (k_trace_closest_mfma; measured in profiles/round6_ab_mfma_sweep.txt)
+  const bool mfma = flat && (p.debug_flags & 128u) && ((p.scene.bvh_flat & 2u) == 0u);
+  if (mfma && (cross_mode != kCrossNone) && (p.scene.boundary_materials != 0u))
+    hipLaunchKernelGGL((k_trace_closest_mfma<true, true>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror,
+      round_tag, pass_stat, p.paths[set], cross_mode, p.block_stats);
+  else if (mfma)
+    hipLaunchKernelGGL((k_trace_closest_mfma<true, false>), dim3(blocks), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits, p.counters, active_counter, 0u, round_mirror,
+      round_tag, pass_stat);
+  else if (flat && (p.debug_flags & 64u))
     hipLaunchKernelGGL((k_trace_closest_flat2<true>), dim3(flat2_blocks(min(p.capacity, max_items))), dim3(kBlockSize), 0, stream, p.scene, p.paths[set].ray_o_tmin, p.paths[set].ray_d_tmax, p.hits,
       p.counters, active_counter, 0u, round_mirror, round_tag, pass_stat);
   else if (flat && (cross_mode != kCrossNone) && (p.scene.boundary_materials != 0u))
@@ -613,7 +840,9 @@ void launch_trace_rays(hipStream_t stream, const DScene& scene, const float4* ra
   if ((prim_cap != 0u) && (prim_cap < limited.flat_prim_count))
     limited.flat_prim_count = prim_cap;
   const bool two_ray_sweep = (debug_flags & 64u) != 0u;  // etx_hip_set_debug_flags: the packed two-ray sweep (kept, measured, not the default)
-  if (flat && two_ray_sweep)
+  if (flat && (debug_flags & 128u) && ((limited.bvh_flat & 2u) == 0u))
+    hipLaunchKernelGGL((k_trace_closest_mfma<false, false>), dim3(blocks), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u, 0u);
+  else if (flat && two_ray_sweep)
     hipLaunchKernelGGL((k_trace_closest_flat2<false>), dim3(flat2_blocks(count)), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u, 0u);
   else if (flat)
     hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(blocks), dim3(kBlockSize), 0, stream, limited, ray_o_tmin, ray_d_tmax, hits, nullptr, 0u, count, nullptr, 0u, lds_limit(), 0u);

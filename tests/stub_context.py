@@ -52,6 +52,9 @@ class StubContext:
     def comm_init(self, rank, world, unique_id):
         self.calls.append(("comm_init", rank, world, bytes(unique_id)))
 
+    def set_debug_flags(self, flags):
+        self.calls.append(("set_debug_flags", flags))
+
     def set_bvh_builder(self, builder):
         self.calls.append(("set_bvh_builder", builder))
 
