@@ -223,10 +223,11 @@ class Library:
         L.etx_hip_reduce_info.argtypes = [vp, vp, ctypes.c_size_t]
         L.etx_hip_trace_rays.argtypes = [vp, vp, u64, vp]
         L.etx_hip_trace_rays_device.argtypes = [vp, vp, vp, u64, vp, u32, ctypes.POINTER(ctypes.c_double)]
-        L.etx_hip_trace_rays_timed.argtypes = [vp, vp, u64, u32, ctypes.POINTER(ctypes.c_double), vp]
-        L.etx_hip_runtime_info.argtypes = [ctypes.POINTER(i32 * 4)]
-        L.etx_hip_comm_all_reduce_f64.argtypes = [vp, ctypes.POINTER(ctypes.c_double), u32, i32]
-        L.etx_hip_comm_barrier.argtypes = [vp]
+        if hasattr(L, "etx_hip_runtime_info"):  # ABI 4. (A library of ABI 3 - tools/gpu_calls A/B runs against etx-tracer_amd/variants/libetx_hip_r5.so - still loads.)
+            L.etx_hip_trace_rays_timed.argtypes = [vp, vp, u64, u32, ctypes.POINTER(ctypes.c_double), vp]
+            L.etx_hip_runtime_info.argtypes = [ctypes.POINTER(i32 * 4)]
+            L.etx_hip_comm_all_reduce_f64.argtypes = [vp, ctypes.POINTER(ctypes.c_double), u32, i32]
+            L.etx_hip_comm_barrier.argtypes = [vp]
         L.etx_hip_kat.argtypes = [vp, i32, vp, u64, vp]
         L.etx_hip_host_check_bvh.argtypes = [vp, ctypes.POINTER(u32 * 4)]
         L.etx_hip_host_bvh_stats.argtypes = [vp, vp, u64, ctypes.POINTER(u64 * 4)]

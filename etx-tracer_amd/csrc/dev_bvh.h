@@ -14,7 +14,9 @@
 namespace etxd {
 
 constexpr uint32_t kStackDepth = 32;     // stack entries a lane keeps in LDS
-constexpr uint32_t kMaxStackDepth = 64;  // deepest stack a tree may need (host bound over the tree): the entries above kStackDepth spill
+constexpr uint32_t kMaxStackDepth = 512;  // deepest stack a tree may need (host bound over the tree: three pushes per BVH4 level = 170 levels); the entries above the LDS part
+                                          // spill to a per-lane global area that is sized by the uploaded tree's OWN bound (host_api.cpp allocate_pipeline). Until round 5 the
+                                          // limit was 64 and deeper trees were refused; Embree has no such limit (rt.cxx:66-88)
 constexpr uint32_t kFlatSweepMaxTriangles = 64;  // scenes up to this size are swept linearly (all lanes, same triangle)
 
 // The stack of the two traversal kernels when the tree's bound fits the LDS part (trees up to ~40 000 triangles): no checks.

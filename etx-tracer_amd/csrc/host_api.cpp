@@ -341,8 +341,9 @@ int allocate_pipeline(etx_hip_context* ctx) {
   p.scene.stack_spill = nullptr, p.scene.stack_spill_lanes = 0u;
   if ((p.scene.bvh_flat == 0u) && (p.scene.bvh_stack_need > kShortStackDepth)) {  // rows for the kernels with the short LDS stack, which cover the others'
     const uint32_t spill_lanes = 2u * kPersistentBlocks * kBlockSize;
-    // rows: what the deepest accepted tree can need beyond the short LDS stack
-    if (int rc = device_alloc(ctx, p.scene.stack_spill, size_t(spill_lanes) * (kMaxStackDepth - kShortStackDepth)))
+    // rows: what THIS tree can need beyond the short LDS stack (its exact bound from the host; at least the 48 rows every tree got until round 5)
+    const uint32_t spill_rows = std::max(p.scene.bvh_stack_need, 64u) - kShortStackDepth;
+    if (int rc = device_alloc(ctx, p.scene.stack_spill, size_t(spill_lanes) * spill_rows))
       return rc;
     p.scene.stack_spill_lanes = spill_lanes;
   }
@@ -2360,7 +2361,7 @@ int etx_hip_selftest_stack(etx_hip_context* context, uint32_t depth, uint32_t* o
   const uint32_t blocks = 1024u, lanes = blocks * kBlockSize;
   int32_t* spill = nullptr;
   uint32_t* errors = nullptr;
-  HIP_OK(context, hipMalloc(&spill, size_t(lanes) * (kMaxStackDepth - kShortStackDepth) * sizeof(int32_t)));  // rows of the short stack cover the other's
+  HIP_OK(context, hipMalloc(&spill, size_t(lanes) * (std::max(depth, 64u) - kShortStackDepth) * sizeof(int32_t)));  // rows of the short stack cover the other's
   if (hipMalloc(&errors, sizeof(uint32_t)) != hipSuccess) {
     (void)hipFree(spill);
     context->error = "hipMalloc failed";

@@ -385,7 +385,8 @@ int etx_hip_trace_rays_timed(etx_hip_context* context, const float* rays_8f, uin
 int etx_hip_kat(etx_hip_context* context, int which, const float* in, uint64_t count, float* out);
 
 /* Self test of the traversal stack: the kernels keep 32 entries per lane in LDS and spill the rest (trees of more than ~40 000
- * triangles can need up to 64 by their worst-case bound) to global memory. Every lane of a traversal-sized grid pushes `depth` (1..64)
+ * triangles can need more by their worst-case bound; accepted up to 512, the spill area is sized by the uploaded tree's own bound) to global memory.
+ * Every lane of a traversal-sized grid pushes `depth` (1..512)
  * values, pops half, pushes again, pops everything and compares; *out_errors = mismatches (0 expected). A real ray stays below 20
  * entries, so this is what exercises the spill. */
 int etx_hip_selftest_stack(etx_hip_context* context, uint32_t depth, uint32_t* out_errors);

@@ -126,7 +126,7 @@ def test_bidirectional_on_meshes_at_1024_spp(etx, golden_dir):
     compare((cam_a, cam_b), golden["camera"], "sssmesh bdpt camera (independent streams), 1024 spp")
 
 
-@pytest.mark.parametrize("depth", [1, 15, 16, 17, 31, 32, 33, 48, 64])
+@pytest.mark.parametrize("depth", [1, 15, 16, 17, 31, 32, 33, 48, 64, 65, 200, 512])  # beyond 64: the bound of round 5, now the spill rows follow the tree (kMaxStackDepth = 512)
 def test_traversal_stack_round_trip_through_the_spill(etx, depth):
     """etx_hip_selftest_stack: 262 144 lanes push / pop `depth` entries each through dev_bvh.h LaneStack (32 in LDS) and ShortLaneStack
     (16 in LDS: the closest-hit kernel of deep trees and the shadow kernel of opaque scenes), the rest in the global spill area a tree

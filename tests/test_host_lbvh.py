@@ -74,7 +74,7 @@ def test_small_scenes_keep_the_host_build(etx, golden_dir):
 
 def test_deep_trees_are_accepted_up_to_the_spill_bound(etx, golden_dir):
     """118 000 triangles: either builder's tree needs more traversal stack than a lane keeps in LDS (32 entries; the bound is three pushed
-    children on every level of the deepest path). Such trees are accepted up to kMaxStackDepth = 64 - the kernels spill the upper
+    children on every level of the deepest path). Such trees are accepted up to kMaxStackDepth = 512 (64 until round 5) - the kernels spill the upper
     part of the stack to global memory (dev_bvh.h LaneStack) - and the walk itself stays far below the bound."""
     from etx_tracer_amd import api
     from tests.test_gpu_scene_update import replicate_gems

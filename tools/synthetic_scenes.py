@@ -173,3 +173,4 @@ def sss_sheets(etx, snapshot_path, slabs=6, fill=0.6):
     area = emitters[:, 2] != 0xFFFFFFFF
     emitters[area, 2] = new_index[emitters[area, 2]].astype(np.uint32)
     return snap
+
