@@ -133,6 +133,10 @@ def main(argv=None, context_factory=None):
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
     distributed = world > 1
+    if distributed and (os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1")):
+        # one node, rendezvous on the loopback address (the launch contract): RCCL's bootstrap sockets stay on it as well instead of the first interface
+        # it finds (a container hostname that does not resolve must not matter); the film itself travels over xGMI / shared memory, not sockets
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 
     spectral_workload = args.workload in ("gems", "gems1m")
     bdpt_workload = args.workload in ("sssdragon_bdpt", "cloud_bdpt")

@@ -287,10 +287,11 @@ ETX_DEV void bdpt_store_light_vertex(const Pipeline& p, uint32_t idx, uint32_t p
   p.lv.nrm_tri(idx) = mk4(nrm, __uint_as_float(tri));
   p.lv.bc_len_med(idx) = make_float4(bc_u, bc_v, __uint_as_float((index_in_path << 16u) | (path_size & 0xffffu)), __uint_as_float(medium));
   p.lv.rec[idx * LightVertexPool::kLvStride + 5] = make_float4(__uint_as_float(prev), wavelength, __uint_as_float(seed), __uint_as_float(path));
-  if (index_in_path < p.path_table_entries)
-    reinterpret_cast<uint32_t*>(p.light_path_table)[size_t(path) * p.path_table_entries + index_in_path] = idx;
-  p.light_path_head[path] = idx;
-  p.light_path_len[path] = index_in_path + 1u;
+  uint32_t* row = reinterpret_cast<uint32_t*>(p.light_path_table) + size_t(path) * p.path_table_entries;  // head, length, first vertices: one cache line per path
+  if (index_in_path + kPathRowHeader < p.path_table_entries)
+    row[kPathRowHeader + index_in_path] = idx;
+  row[0] = idx;
+  row[1] = index_in_path + 1u;
 }
 
 struct BdptLightVertex {

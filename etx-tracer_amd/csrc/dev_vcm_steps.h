@@ -18,15 +18,16 @@ ETX_DEV void store_light_vertex(const Pipeline& p, uint32_t idx, const PathState
   p.lv.nrm_tri(idx) = mk4(nrm, __uint_as_float(tri));
   // vcm_connect_to_light_path (vcm_shared.hxx:773-778) derives the connection length from the vertex' INDEX in its
   // light path (delta bounces advance the depth without storing a vertex), the merge uses path_length: keep both.
-  const uint32_t prev = p.light_path_head[st.id];
+  uint32_t* row = reinterpret_cast<uint32_t*>(p.light_path_table) + size_t(st.id) * p.path_table_entries;  // head, length, first vertices: one cache line per path
+  const uint32_t prev = row[0];
   const uint32_t index_in_path = (prev == kInvalid) ? 0u : ((__float_as_uint(p.lv.bc_len_med(prev).z) >> 16u) + 1u);
   p.lv.bc_len_med(idx) = make_float4(bc_u, bc_v, __uint_as_float((index_in_path << 16u) | (st.depth & 0xffffu)), __uint_as_float(st.medium));
   p.lv.next(idx) = prev;
   p.lv.wavelength(idx) = st.wavelength;
-  if (index_in_path < p.path_table_entries)
-    reinterpret_cast<uint32_t*>(p.light_path_table)[size_t(st.id) * p.path_table_entries + index_in_path] = idx;
-  p.light_path_head[st.id] = idx;  // the photon bounding box is reduced by k_grid_bbox (kernels_grid.hip)
-  p.light_path_len[st.id] = index_in_path + 1u;
+  if (index_in_path + kPathRowHeader < p.path_table_entries)
+    row[kPathRowHeader + index_in_path] = idx;
+  row[0] = idx;  // the photon bounding box is reduced by k_grid_bbox (kernels_grid.hip)
+  row[1] = index_in_path + 1u;
 }
 
 

@@ -375,7 +375,7 @@ int allocate_pipeline(etx_hip_context* ctx) {
   // a light path that walks through a subsurface object under the bidirectional integrator stores a vertex per scattering event: a longer
   // table keeps k_expand_pairs off the per-lane list walk (configs[3]: 181 us per launch with eight entries)
   p.path_table_entries = etxh::tuning_knob("ETX_HIP_PATH_TABLE", ctx->scene.has_subsurface ? kPathTableEntriesWalk : kPathTableEntries) & ~3u;
-  if ((rc = device_alloc(ctx, p.light_path_head, n)) || (rc = device_alloc(ctx, p.light_path_len, n)) || (rc = device_alloc(ctx, p.light_path_table, size_t(n) * (p.path_table_entries / 4u))))
+  if ((rc = device_alloc(ctx, p.light_path_table, size_t(n) * (p.path_table_entries / 4u))))
     return rc;
   p.grid = {};
   if ((rc = device_alloc(ctx, p.grid_params, 1)))

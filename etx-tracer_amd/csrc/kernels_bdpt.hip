@@ -565,7 +565,7 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_camera(Pipeline p, 
                 const float curr_from_camera = bdpt_to_area(film_pdf, cs.position, y.self);
                 const float prev_from_curr = bdpt_pdf_area<kSimple>(scene, kPathCamera, cs.position, y.full, y_prev, y.wavelength, smp);
                 if (mode == kBdptFast) {
-                  const uint32_t* table = reinterpret_cast<const uint32_t*>(p.light_path_table) + size_t(y.path) * p.path_table_entries;
+                  const uint32_t* table = reinterpret_cast<const uint32_t*>(p.light_path_table) + size_t(y.path) * p.path_table_entries + kPathRowHeader;
                   const uint32_t e0 = table[0], e1 = table[1];
                   const float p_sample = p.lv.pos_dvcm(e0).w;  // e0.pdf.from_prev
                   const uint32_t e0_flags = __float_as_uint(p.lv.thr_dvm(e0).w), e1_flags = __float_as_uint(p.lv.thr_dvm(e1).w);

@@ -39,11 +39,14 @@ __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmPara
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6u;
   ETX_BLOCK_LOOP(count, i) {
     uint32_t head = kInvalid, k = 0, path = 0;
+    uint4 first = make_uint4(kInvalid, 0u, kInvalid, kInvalid);  // head, length and the path's first two vertices: one 16-byte load of its table row
     if (i < count) {
       path = __float_as_uint(p.cv.mis_pixel[i].w);
       const bool skip = kVcmRecords && (__float_as_uint(p.cv.pos_info[i].w) & kCvNoConnect);  // merge-only record of a Christensen-Burley vertex
-      head = skip ? kInvalid : p.light_path_head[path];
-      k = skip ? 0u : p.light_path_len[path];  // independent of the head load (the head record sits somewhere in a 0.8 GB pool)
+      if (skip == false)
+        first = p.light_path_table[size_t(path) * (p.path_table_entries >> 2u)];
+      head = first.x;
+      k = first.y;
     }
     // workgroup exclusive prefix sum of k: wave scan, then one reservation for all four waves
     uint32_t incl = k;
@@ -80,17 +83,21 @@ __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmPara
       continue;
     // the first path_table_entries vertices come from the path table (independent 16-byte loads), only longer
     // paths walk the list from the head down to that index
-    const uint32_t table_entries = p.path_table_entries;
-    const uint4* table = p.light_path_table + size_t(path) * (table_entries >> 2u);
-    for (uint32_t q = 0; (q << 2u) < min(k, table_entries); ++q) {
+    const uint32_t table_entries = p.path_table_entries - kPathRowHeader;  // vertices a row holds behind its two header words
+    const uint4* table = p.light_path_table + size_t(path) * (p.path_table_entries >> 2u);
+    const uint32_t from_table = min(k, table_entries);
+    p.pairs[base] = make_uint2(i, first.z);  // k >= 1 here
+    if (from_table > 1u)
+      p.pairs[base + 1u] = make_uint2(i, first.w);
+    for (uint32_t q = 1; (q << 2u) < from_table + kPathRowHeader; ++q) {  // word 4 q + c of the row = vertex 4 q + c - 2 of the path
       const uint4 t = table[q];
-      const uint32_t j = q << 2u;
+      const uint32_t j = (q << 2u) - kPathRowHeader;
       p.pairs[base + j] = make_uint2(i, t.x);
-      if (j + 1u < k)
+      if (j + 1u < from_table)
         p.pairs[base + j + 1u] = make_uint2(i, t.y);
-      if (j + 2u < k)
+      if (j + 2u < from_table)
         p.pairs[base + j + 2u] = make_uint2(i, t.z);
-      if (j + 3u < k)
+      if (j + 3u < from_table)
         p.pairs[base + j + 3u] = make_uint2(i, t.w);
     }
     uint32_t vi = head;

@@ -68,10 +68,8 @@ __global__ __launch_bounds__(kBlockSize) void k_iteration_reset(Pipeline p) {
   }
   if (tid < kBlockStatRows * kBlockStatCount)
     p.block_stats[tid] = 0ull;
-  for (uint32_t i = tid; i < p.capacity; i += stride) {
-    p.light_path_head[i] = kInvalid;
-    p.light_path_len[i] = 0u;
-  }
+  for (uint32_t i = tid; i < p.capacity; i += stride)  // head = none, length 0 (the first two words of every path's table row)
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(p.light_path_table) + size_t(i) * p.path_table_entries) = make_uint2(kInvalid, 0u);
 }
 
 void launch_iteration_reset(hipStream_t stream, const Pipeline& p) {
@@ -215,7 +213,7 @@ __global__ void k_debug_lists(Pipeline p) {
   if (i >= p.capacity)
     return;
   uint32_t len = 0;
-  for (uint32_t vi = p.light_path_head[i]; (vi != kInvalid) && (len < 100000u); vi = p.lv.next(vi))
+  for (uint32_t vi = reinterpret_cast<const uint32_t*>(p.light_path_table)[size_t(i) * p.path_table_entries]; (vi != kInvalid) && (len < 100000u); vi = p.lv.next(vi))
     len++;
   atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kDbgBase + 2), (unsigned long long)len);
   atomicMax(p.counters + kDbgBase + 4, len);

@@ -119,6 +119,7 @@ constexpr uint32_t kPathTableEntries = 32;         // Pipeline::path_table_entri
                                                    // table (16-byte loads) and WALKS the list beyond it, one dependent gather per vertex - a wavefront waits for its longest path. Fog box
                                                    // (3.8 vertices per path, long tail): 8 entries 101.7, 16 103.0, 32 103.9 Msamples/s (profiles/round4_ab_medium_rows_and_path_table.txt)
 constexpr uint32_t kPathTableEntriesWalk = 32;     // ... with: a light path that walked through an object has a vertex per scattering event
+constexpr uint32_t kPathRowHeader = 2;             // words 0 / 1 of a path's table row: head, length
 constexpr uint32_t kMergeBucketBits = 6;                                  // per axis
 constexpr uint32_t kMergeBuckets = 1u << (3u * kMergeBucketBits);         // 64^3 coarse buckets
 
@@ -225,12 +226,13 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   float4* walk_exit_hits;
   float4* hits;          // hit queue, aligned with the "in" path set
   LightVertexPool lv;
-  uint32_t* light_path_head;   // per path: last stored vertex (kInvalid = none)
-  uint32_t* light_path_len;    // per path: stored vertices so far (k_expand_pairs sizes a camera vertex' pair run with it: no dependent read of the head record)
   float* path_wavelength;      // spectral mode: wavelength of light path i, reused by camera path i (vcm_cpu.cxx:186)
-  uint4* light_path_table;     // per path: its first path_table_entries vertices by index in path (expand_pairs reads them
-                               // with independent 16-byte loads instead of walking the list from the head)
-  uint32_t path_table_entries; // kPathTableEntries or kPathTableEntriesWalk (a multiple of four)
+  uint4* light_path_table;     // per path: ONE ROW of path_table_entries words: [0] the last stored vertex (kInvalid = none), [1] the vertices stored so far, then the path's
+                               // first path_table_entries - 2 vertices by index in path (k_expand_pairs reads them with independent 16-byte loads instead of walking the list
+                               // from the head). Head and length lived in arrays of their own until round 5: storing a vertex then dirtied three cache lines in three
+                               // allocations with 4-byte writes (each a read-modify-write of its line in L2: PMC showed k_light_shade writing 1.6x and the bidirectional
+                               // light shading 2.2x its algorithmic bytes) and k_expand_pairs gathered from all three per camera vertex. One row = one line.
+  uint32_t path_table_entries; // words per row: kPathTableEntries or kPathTableEntriesWalk (a multiple of four; two of them are the header)
   PhotonGrid grid;
   GridParams* grid_params;
   CameraVertexPool cv;

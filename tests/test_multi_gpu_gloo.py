@@ -261,3 +261,30 @@ def test_reduce_cadence_progressive_and_not_terminal(tmp_path):
         expected = torch.clamp(sum(stub_iteration(i)[0] + stub_iteration(i)[1] for i in rendered) / len(rendered), min=0.0)
         expected[..., 3] = 1.0
         np.testing.assert_allclose(films[0][k], expected.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_bench_under_the_real_launcher(tmp_path):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P <script>`: the driver's own command line for
+    N > 1 (tests/bench_stub_launcher.py stands in for bench.py only in that it passes the stub context). The 128-byte id travels through the file
+    rendezvous keyed by what the launcher exports; both ranks receive rank 0's id, run the same sequence of collectives and exit cleanly."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("ETX_HIP_RENDEZVOUS_DIR", None)  # the default directory (the system's temporary directory), as on the GPU node
+    result = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+                             os.path.join(root, "tests", "bench_stub_launcher.py"), str(tmp_path)], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert result.returncode == 0, result.stdout[-3000:]
+    printed = [l for l in result.stdout.splitlines() if l.startswith("{")]
+    assert len(printed) == 1, result.stdout[-2000:]  # ONE JSON line, from rank 0
+    line = json.loads(printed[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["repeats"]["count"] == 2
+    ranks = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+    ids = {tuple(map(tuple, r["comm_init"])) for r in ranks}
+    assert [r["comm_init"][0][:2] for r in ranks] == [[0, 2], [1, 2]]
+    assert ranks[0]["comm_init"][0][2] == ranks[1]["comm_init"][0][2] == bytes(range(128)).hex()  # the stub's id, made by rank 0
+    assert [c for c in ranks[0]["sequence"] if c != "begin_vcm"] == [c for c in ranks[1]["sequence"] if c != "begin_vcm"]  # the same collectives in the same order
+    import glob
+    import tempfile
+    assert glob.glob(os.path.join(tempfile.gettempdir(), "etx_hip_rendezvous_127_0_0_1_*")) == []  # removed after the barrier
