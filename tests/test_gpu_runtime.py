@@ -27,12 +27,16 @@ def test_one_rocm_runtime_in_the_process(etx, gpu_context):
 
 @pytest.mark.gpu
 def test_an_older_runtime_loaded_first_is_refused():
-    """The round-5 configuration, on purpose, in a child process: torch first, then the library. etx_hip_create names the runtime it found and refuses;
-    ETX_HIP_ALLOW_OLDER_RUNTIME=1 is the documented way to run on it anyway."""
+    """The round-5 configuration, on purpose, in a child process: torch first, then the library - the loader binds libetx_hip.so to the ROCm runtime bundled
+    with the wheel. That is the configuration in which the round-5 suite died (heap corruption in one of six processes). etx_hip_create names
+    the runtime it found and refuses; ETX_HIP_ALLOW_OLDER_RUNTIME=1 is the documented way to run on it anyway. (The round-5 library has neither the
+    check nor etx_hip_runtime_info: this test fails on it.)"""
     code = (
         "import sys; sys.path.insert(0, %r)\n"
         "import torch\n"
         "import etx_tracer_amd as etx\n"
+        "info = etx.api.runtime_info()\n"
+        "print('INFO', info['hip_runtime'], info['hip_built_against'], ' '.join(info['mapped']))\n"
         "try:\n"
         "    etx.api.Context(0).close(); print('CREATED')\n"
         "except etx.EtxHipError as e:\n"
@@ -40,7 +44,12 @@ def test_an_older_runtime_loaded_first_is_refused():
     env = dict(os.environ)
     env.pop("ETX_HIP_ALLOW_OLDER_RUNTIME", None)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env).stdout
-    if "CREATED" in out:
+    info = [l for l in out.splitlines() if l.startswith("INFO ")]
+    assert info, out
+    runtime, built = int(info[0].split()[1]), int(info[0].split()[2])
+    assert "/torch/lib/libamdhip64" in info[0], info[0]  # torch first: its copy is the one the library was bound to
+    if runtime // 100000 >= built // 100000:
+        assert "CREATED" in out, out
         pytest.skip("the torch wheel of this image bundles a runtime at least as new as the library's")
     assert "REFUSED -3" in out and "older than" in out and "torch" in out, out
     env["ETX_HIP_ALLOW_OLDER_RUNTIME"] = "1"
