@@ -144,6 +144,9 @@ enum : uint32_t {
   kShadeGroupCount = 3,
 };
 
+constexpr uint32_t kSssMediumDynamic = 0xfffffffeu;          // DScene::material_sss_medium: the walk medium is derived per entry point (textured colour / distances)
+constexpr uint32_t kMediumStoredCoefficients = 0xfffffffeu;  // DMedium::derived_color of such a row: absorption / scattering hold the coefficients as they are, also in spectral mode
+
 struct DScene {
   const etx_abi_vertex* vertices;
   const etx_abi_triangle* triangles;
@@ -168,6 +171,7 @@ struct DScene {
   const DScene* self;              // device address of the device-resident copy of this struct (out-of-line BSDF calls, dev_bsdf_ool.h)
   const uint32_t* material_variants;  // per material: first of its three PrincipledBSDF variants (appended to `materials`), kInvalid otherwise
   const uint8_t* material_group;   // per material: shading group of a path that hits it (kShadeGroup*, kernels_shade.inl)
+  const uint8_t* material_general_bsdf;  // per material: != 0 = its BSDF calls need the out-of-line library (dev_bsdf_ool.h); the bidirectional kernels of mixed scenes split their items by it
   const uint32_t* material_sss_medium;  // per material: the medium its subsurface walk runs through (interior medium, or a derived entry appended to `mediums`; host_scene.cpp)
   uint32_t vertex_count, triangle_count, material_count, emitter_count, emitter_dist_count, spectrum_count, image_count, medium_count;
   uint32_t bvh_node_count, bvh_tri_count, flat_prim_count;
@@ -198,6 +202,14 @@ struct DScene {
   float cie_first, cie_y_scale;  // spectrum::kShortestWavelength, 1 / kYIntegral
   uint32_t rgb_response_count;
   float rgb_response_first;
+  // Subsurface materials WITHOUT an interior medium whose colour or scattering distances are TEXTURED, under the bidirectional integrator: the medium
+  // of a walk is then a property of the point where the path entered (subsurface_step, bidirectional.cxx:757-771: apply_image at intersection.tex).
+  // Such a walk appends a row of its own to the medium table when it starts - rows [dyn_medium_first, + dyn_medium_capacity) of `mediums`, which in
+  // that case is a per-lane copy of the table (host_api.cpp allocate_pools) - and names it by index like every other medium: the walk's free flights,
+  // the medium vertices it stores and the connections from them need nothing else. material_sss_medium holds kSssMediumDynamic for these materials.
+  uint32_t sss_dynamic_media;   // != 0: the scene holds such a material
+  uint32_t dyn_medium_first, dyn_medium_capacity;  // per lane (set in the lane's Pipeline::scene copy)
+  uint32_t* lane_counters;      // per lane: Pipeline::counters (the row counter kCntDynMedium, the overflow word)
   DCamera camera;
 };
 
@@ -280,7 +292,7 @@ ETX_DEV void sss_remap_channel(float color, float scattering_distance, float& al
 }
 
 ETX_DEV void medium_coefficients(const DScene& s, const DMedium& m, float wavelength, f3& absorption, f3& scattering) {
-  if (s.spectral == 0u) {
+  if ((s.spectral == 0u) || (m.derived_color == kMediumStoredCoefficients)) {  // ... a per-walk row (DScene::sss_dynamic_media) holds its coefficients at the walk's own wavelength
     absorption = m.absorption;
     scattering = m.scattering;
     return;

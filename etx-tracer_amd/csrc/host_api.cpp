@@ -241,6 +241,9 @@ void release_pools(etx_hip_context* ctx) {
   p.pairs = nullptr, p.pair_capacity = 0u;
   p.shadow = {};
   p.endpoints = {};
+  // the lane's own medium table (scenes whose walks append rows) went with the pools: back to the shared one
+  p.scene.mediums = ctx->scene.host_copy.mediums;
+  p.scene.dyn_medium_first = p.scene.dyn_medium_capacity = 0u;
 }
 
 void release_pipeline(etx_hip_context* ctx) {
@@ -327,6 +330,20 @@ int allocate_pools(etx_hip_context* ctx, const etx_hip_context::PoolSizes& sizes
   if ((rc = pool_alloc(ctx, p.endpoints.hit, epn)) || (rc = pool_alloc(ctx, p.endpoints.wi_medium, epn)) || (rc = pool_alloc(ctx, p.endpoints.thr_depth, epn)) ||
       (rc = pool_alloc(ctx, p.endpoints.mis_id, epn)) || (rc = pool_alloc(ctx, p.endpoints.rnd_seed, epn)) || (rc = pool_alloc(ctx, p.endpoints.wavelength, epn)))
     return rc;
+  // Textured subsurface materials under the bidirectional integrator (DScene::sss_dynamic_media): the lane's own copy of the medium table with room for
+  // one row per walk behind it - as many as the light vertex pool holds records (a walk stores at least its entry vertex there or in the camera pool,
+  // and an overflow of either grows all pools)
+  p.scene.lane_counters = p.counters;
+  if (ctx->scene.host_copy.sss_dynamic_media != 0u) {
+    const uint32_t rows = ctx->scene.medium_table_rows;
+    DMedium* table = nullptr;
+    if ((rc = pool_alloc(ctx, table, size_t(rows) + size_t(sizes.light_vertices))))
+      return rc;
+    HIP_OK(ctx, hipMemcpyAsync(table, ctx->scene.host_copy.mediums, size_t(rows) * sizeof(DMedium), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_OK(ctx, hipStreamSynchronize(ctx->stream));
+    p.scene.mediums = table;
+    p.scene.dyn_medium_first = rows, p.scene.dyn_medium_capacity = sizes.light_vertices;
+  }
   ctx->pool_sizes = sizes;
   return 0;
 }
@@ -407,6 +424,7 @@ int allocate_pipeline(etx_hip_context* ctx) {
   if ((rc = device_alloc(ctx, p.counters, kCounterCount)))
     return rc;
   HIP_OK(ctx, hipMemset(p.counters, 0, kCounterCount * sizeof(uint32_t)));
+  p.scene.lane_counters = p.counters;  // (allocate_pools ran before the counters existed)
   HIP_OK(ctx, hipMemset(p.grid_params, 0, sizeof(GridParams)));
   p.light_sum = p.camera_sum + n;
   p.normal_sum = p.camera_sum + 2u * size_t(n);
@@ -852,7 +870,9 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
   p.light_sum = ctx->pt_iteration_image + p.capacity;
   hipStream_t s = ctx->stream;
   const bool flat = ctx->scene.host_copy.bvh_flat != 0u;
-  const bool simple = ctx->scene.simple_materials;  // the BSDF instantiations of the bidirectional kernels (kernels_bdpt.hip)
+  // the BSDF instantiations of the bidirectional kernels (kernels_bdpt.hip ETX_BDPT_LAUNCH)
+  // (debug flag 0x10000: a mixed scene is not split by BSDF class - the general instantiations take every item, as until round 5; for A/B runs and tests/test_gpu_bdpt.py)
+  const uint32_t simple = ctx->scene.simple_materials ? kBdptKernelsSimple : ((ctx->scene.bdpt_binning && ((ctx->debug_flags & 0x10000u) == 0u)) ? kBdptKernelsBinned : kBdptKernelsGeneral);
   uint64_t rounds = 0;
   int rc = 0;
 
@@ -1672,8 +1692,8 @@ int etx_hip_begin_ex(etx_hip_context* context, int integrator, const void* optio
       return ETX_HIP_ERROR_INVALID_ARGUMENT;
     }
     if (context->scene.has_subsurface && (context->scene.sss_media_complete == false)) {
-      context->error = "bidirectional integrator: a subsurface material without an interior medium derives its walk medium from its colour and distances; the device path "
-                       "does that for untextured parameters only (a textured scattering colour / distance map makes the medium a property of the entry point: use VCM or path tracing)";
+      context->error = "bidirectional integrator: a subsurface material without an interior medium derives its walk medium from its colour and distances, and this one names a spectrum "
+                       "outside the scene's table (or the scene's subsurface SCATTER material is textured: the entry vertex' medium instance, bidirectional.cxx:629-633, is a table entry here)";
       return ETX_HIP_ERROR_UNSUPPORTED;
     }
     context->active_bluenoise = nullptr;

@@ -65,10 +65,12 @@ void DeviceScene::borrow(const DeviceScene& owner) {
   noise_threshold = owner.noise_threshold;
   bvh_depth = owner.bvh_depth;
   simple_materials = owner.simple_materials;
+  bdpt_binning = owner.bdpt_binning;
   group_general = owner.group_general, group_subsurface = owner.group_subsurface;
   has_subsurface = owner.has_subsurface;
   has_subsurface_cb = owner.has_subsurface_cb;
   sss_media_complete = owner.sss_media_complete;
+  medium_table_rows = owner.medium_table_rows;
   generic_materials = owner.generic_materials;
   needs_rgb_response = owner.needs_rgb_response;
   bvh_bytes = owner.bvh_bytes;
@@ -910,6 +912,10 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   const auto* mediums = reinterpret_cast<const etx_abi_medium*>(scene->mediums.a);
   const auto* triangles = reinterpret_cast<const etx_abi_triangle*>(scene->triangles.a);
 
+  if (scene->materials.count >= (1ull << 20u)) {  // the walk queue of the bidirectional integrator keeps (material | events << 20) in one word (kernels_bdpt.hip)
+    error = "more than 2^20 materials";
+    return ETX_HIP_ERROR_UNSUPPORTED;
+  }
   out.has_subsurface = false;
   // only materials that geometry references need a device implementation
   std::vector<bool> used(scene->materials.count, false);
@@ -943,11 +949,23 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   out.simple_materials = true;
   // Shading group per material (dev_scene.h kShadeGroup*): a path is shaded by the kernel of its hit material's group.
   std::vector<uint8_t> groups(scene->materials.count, uint8_t(kShadeGroupSimple));
+  // Bidirectional kernels of MIXED scenes (kernels_bdpt.hip kPartSimple / kPartGeneral): which materials' BSDF calls need the out-of-line library. A surface
+  // of a subsurface material is also shaded with the scatter material (the entry vertex, bidirectional.cxx:629-633), so it inherits that material's answer.
+  std::vector<uint8_t> general_bsdf(scene->materials.count, uint8_t(0));
+  auto simple_class = [](const etx_abi_material& m) {
+    const bool constant_roughness = m.roughness.image_index == ETX_ABI_INVALID;
+    const bool thin_film = m.thinfilm.max_thickness * m.thinfilm.min_thickness > 0.0f;
+    const bool lambert = (m.cls == ETX_MAT_DIFFUSE) && (m.diffuse_variation == 0u);
+    const bool mirror_conductor = (m.cls == ETX_MAT_CONDUCTOR) && constant_roughness && (m.roughness.value.x == 0.0f) && (m.roughness.value.y == 0.0f) && (thin_film == false);
+    return lambert || (m.cls == ETX_MAT_TRANSLUCENT) || (m.cls == ETX_MAT_MIRROR) || (m.cls == ETX_MAT_BOUNDARY) || (m.cls == ETX_MAT_VOID) || mirror_conductor;
+  };
+  const bool scatter_simple = (scene->subsurface_scatter_material >= scene->materials.count) || simple_class(materials[scene->subsurface_scatter_material]);
   for (uint64_t i = 0; i < scene->materials.count; ++i) {
     const etx_abi_material& m = materials[i];
     const bool constant_roughness = m.roughness.image_index == ETX_ABI_INVALID;
     const float max_roughness = std::max(m.roughness.value.x, m.roughness.value.y);
     const bool thin_film = m.thinfilm.max_thickness * m.thinfilm.min_thickness > 0.0f;
+    general_bsdf[i] = uint8_t(((simple_class(m) == false) || ((m.subsurface.cls != 0u) && (scatter_simple == false))) ? 1 : 0);
     // "generic" = a connectible (non delta) surface that is not a plain Lambert diffuse one: its connections and merges
     // go through the general BSDF kernels. Delta-only: Mirror, Thinfilm, Boundary, Void, roughness-0 Conductor / Dielectric.
     const bool lambert = (m.cls == ETX_MAT_DIFFUSE) && (m.diffuse_variation == 0u);
@@ -968,7 +986,13 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
     out.simple_materials = false;
     for (auto& g : groups)
       g = (g == kShadeGroupSimple) ? uint8_t(kShadeGroupGeneral) : g;
+    for (auto& g : general_bsdf)
+      g = 1;
   }
+  // a mixed scene: the bidirectional kernels run their inline instantiation over every item and the out-of-line one over the items of general classes only.
+  // Not when the scatter material itself is of a general class (every entry and exit vertex of a walk would be: nothing to split, and two listed vertices
+  // per path and round would not fit the lists). ETX_HIP_BDPT_BINNING=0: the round-5 behaviour, for A/B runs.
+  out.bdpt_binning = (out.simple_materials == false) && scatter_simple && (tuning_knob("ETX_HIP_BDPT_BINNING", 1u) != 0u);
   // PrincipledBSDF (bsdf_principled.hxx:24-114) evaluates Conductor / Dielectric / Plastic on a modified copy of the
   // material; the three copies are static, so they are appended to the table once (dev_bsdf_ool.h resolve_material)
   std::vector<etx_abi_material> material_table(materials, materials + scene->materials.count);
@@ -1043,7 +1067,7 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   if ((rc = upload(out, reinterpret_cast<const uint32_t*>(scene->triangle_to_emitter.a), scene->triangle_to_emitter.count, d.triangle_to_emitter, error)))
     return rc;
   if ((rc = upload(out, material_table.data(), material_table.size(), d.materials, error)) || (rc = upload(out, variants.data(), variants.size(), d.material_variants, error)) ||
-      (rc = upload(out, groups.data(), groups.size(), d.material_group, error)))
+      (rc = upload(out, groups.data(), groups.size(), d.material_group, error)) || (rc = upload(out, general_bsdf.data(), general_bsdf.size(), d.material_general_bsdf, error)))
     return rc;
   for (uint64_t i = 0; spectral && (i < scene->emitter_profiles.count); ++i)
     if (reinterpret_cast<const etx_abi_emitter_profile*>(scene->emitter_profiles.a)[i].emission.image_index != ETX_ABI_INVALID)
@@ -1173,15 +1197,23 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   // Subsurface materials under the bidirectional integrator (bidirectional.cxx:729-790): the walk runs through the material's
   // interior medium, or - without one - through a medium derived from its colour and scattering distances
   // (subsurface::remap_channel, scene_bssrdf_subsurface.hxx:17-44). The derived medium becomes a table entry of its own here, so that
-  // vertices inside the object name their medium by index like every other vertex. Untextured parameters (a textured colour would make
-  // the coefficients a property of the entry POINT, not of the material): such a material is left without an entry and etx_hip_begin
-  // refuses the scene for that integrator. Spectral scenes: the entry names the two spectra and the device remaps at the path's wavelength.
+  // vertices inside the object name their medium by index like every other vertex. A TEXTURED colour or distance map makes the coefficients a
+  // property of the entry POINT, not of the material: such a material gets kSssMediumDynamic and every walk through it appends a row of its own
+  // to (a per-lane copy of) this table at run time (round 6; until then etx_hip_begin refused such scenes for this integrator).
+  // Spectral scenes: the entry names the two spectra and the device remaps at the path's wavelength.
   std::vector<uint32_t> sss_medium(material_table.size(), kInvalid);
   out.sss_media_complete = true;
-  auto derive_medium = [&](const etx_abi_material& m) -> uint32_t {
+  bool dynamic_media = false;
+  auto derive_medium = [&](const etx_abi_material& m, bool allow_dynamic) -> uint32_t {
     const bool textured = (m.scattering.image_index != ETX_ABI_INVALID) || (m.subsurface.image_index != ETX_ABI_INVALID);
-    if (textured || (m.scattering.spectrum_index >= scene->spectrums.count) || (m.subsurface.spectrum_index >= scene->spectrums.count))
+    if ((m.scattering.spectrum_index >= scene->spectrums.count) || (m.subsurface.spectrum_index >= scene->spectrums.count))
       return kInvalid;
+    if (textured) {  // the coefficients are a property of the entry point: the walk appends its own row at run time (DScene::sss_dynamic_media)
+      if (allow_dynamic == false)
+        return kInvalid;
+      dynamic_media = true;
+      return kSssMediumDynamic;
+    }
     const f3 color = a3(spectrums[m.scattering.spectrum_index].integrated), distances = a3(spectrums[m.subsurface.spectrum_index].integrated);
     auto remap = [](float colour, float distance, float& extinction, float& scattering) {
       const float a = 1.826052378200f, b = 4.985111943850f + 0.12735595943800f, cc = 1.096861024240f;
@@ -1215,7 +1247,7 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
       sss_medium[i] = m.int_medium;
       continue;
     }
-    sss_medium[i] = derive_medium(m);
+    sss_medium[i] = derive_medium(m, true);
     any_derived = true;
     if (sss_medium[i] == kInvalid)
       out.sss_media_complete = false;
@@ -1225,12 +1257,15 @@ int build_device_scene(const etx_abi_scene* scene, const etx_abi_camera* camera,
   // with comes from the scatter material's parameters (white, and validate_materials' default distances {1, 0.2, 0.04},
   // scene_representation.cxx:270-272), not from the object's. The device keeps that: the scatter material gets an entry too.
   if (any_derived && (scene->subsurface_scatter_material < scene->materials.count)) {
-    sss_medium[scene->subsurface_scatter_material] = derive_medium(material_table[scene->subsurface_scatter_material]);
+    sss_medium[scene->subsurface_scatter_material] = derive_medium(material_table[scene->subsurface_scatter_material], false);  // the entry vertex' instance stays a table entry
     if (sss_medium[scene->subsurface_scatter_material] == kInvalid)
       out.sss_media_complete = false;
   }
   for (DMedium& dm : dmediums)
     dm.pack_rows();
+  d.sss_dynamic_media = dynamic_media ? 1u : 0u;
+  out.medium_table_rows = uint32_t(dmediums.size());
+  d.dyn_medium_first = d.dyn_medium_capacity = 0u, d.lane_counters = nullptr;  // per lane (host_api.cpp allocate_pools)
   if ((rc = upload(out, dmediums.data(), dmediums.size(), d.mediums, error)) || (rc = upload(out, sss_medium.data(), sss_medium.size(), d.material_sss_medium, error)))
     return rc;
 

@@ -34,10 +34,12 @@ struct DeviceScene {
   float noise_threshold = 0.0f;     // Scene::noise_threshold (adaptive sampling of the path tracer)
   uint32_t bvh_depth = 0;
   bool simple_materials = false;   // only Diffuse / Translucent / Mirror / Boundary / Void / roughness-0 Conductor in use (dev_bsdf.h)
+  bool bdpt_binning = false;       // bidirectional kernels: a mixed scene (simple_materials == false) whose items are split by BSDF class (kernels_bdpt.hip kPartSimple / kPartGeneral)
   bool group_general = false;      // a material of shading group kShadeGroupGeneral is in use (dev_scene.h)
   bool group_subsurface = false;   // ... of kShadeGroupSubsurface
   bool has_subsurface = false;     // a subsurface material is in use
-  bool sss_media_complete = true;  // every subsurface material has a medium table entry for its walk (bidirectional integrator)
+  bool sss_media_complete = true;  // every subsurface material has a medium table entry for its walk, or derives one per entry point (bidirectional integrator)
+  uint32_t medium_table_rows = 0;  // rows of the uploaded medium table (the scene's media + the entries derived from subsurface materials)
   bool has_subsurface_cb = false;  // ... of class Christensen-Burley (up to 24 exit points per vertex)
   bool generic_materials = false;  // a connectible (non delta) surface material other than Diffuse is in use
   bool needs_rgb_response = false; // spectral scene with RGB images behind spectra: apply_rgb needs the host's table (etx_hip_upload_rgb_response)

@@ -53,14 +53,16 @@ void launch_light_tail(hipStream_t stream, const Pipeline& p, const VcmParams& i
 void launch_camera_tail(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, const ShadeGroups& groups);
 
 // bidirectional path tracing (kernels_bdpt.hip)
+// which BSDF instantiations a pass launches: DeviceScene::simple_materials / ::bdpt_binning (kernels_bdpt.hip ETX_BDPT_LAUNCH)
+enum : uint32_t { kBdptKernelsGeneral = 0u, kBdptKernelsSimple = 1u, kBdptKernelsBinned = 2u };
 void launch_bdpt_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
-void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple);  // simple: DeviceScene::simple_materials
-void launch_bdpt_walk(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool camera, uint32_t in_set, uint32_t max_items, bool simple);  // subsurface walks of the round: walk queue in_set -> path set / walk queue in_set ^ 1
-void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, bool simple);
+void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, uint32_t variant);  // variant: kBdptKernels*
+void launch_bdpt_walk(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool camera, uint32_t in_set, uint32_t max_items, uint32_t variant);  // subsurface walks of the round: walk queue in_set -> path set / walk queue in_set ^ 1
+void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, uint32_t variant);
 void launch_bdpt_camera_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it);
-void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple);
-void launch_bdpt_connect_light(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, bool simple);
-void launch_bdpt_connect_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, bool simple);
+void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, uint32_t variant);
+void launch_bdpt_connect_light(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, uint32_t variant);
+void launch_bdpt_connect_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, uint32_t variant);
 void launch_expand_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items);  // kernels_connect.hip
 
 // photon grid

@@ -145,7 +145,51 @@ ETX_DEV bool bdpt_walk_flight(const DScene& scene, const Nodes& nodes, const Lan
 // instance the entry VERTEX keeps for the transmittance of its connections - the interior medium, or, without one, the instance
 // :632 derives from the SCATTER material (material_index was swapped at :630), an entry host_scene.cpp builds for that material;
 // and the path's medium index, which is the interior medium or none (:670 payload.medium_index = medium_instance.index).
-ETX_DEV bool bdpt_enter_subsurface(const DScene& scene, const etx_abi_material& mat, const Isect& isect, BsdfSample& bs, Sampler& smp, uint32_t& vertex_medium,
+// A slot for every lane that calls this (any subset of a wavefront: the callers sit in divergent shading code): one atomic per call site and wavefront.
+ETX_DEV uint32_t divergent_slot(uint32_t* counter) {
+  const unsigned long long mask = __ballot(true);
+  const uint32_t lane = __lane_id();
+  const uint32_t leader = uint32_t(__ffsll((long long)mask)) - 1u;
+  uint32_t base = 0u;
+  if (lane == leader)
+    base = atomicAdd(counter, uint32_t(__popcll(mask)));
+  base = __shfl(base, int(leader));
+  return base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+}
+
+// The walk medium of a subsurface material WITHOUT an interior medium whose colour or distances are textured (subsurface_step, bidirectional.cxx:757-765:
+// apply_image at the entry point's texture coordinate, subsurface::remap per channel): a row of its own behind the lane's copy of the medium table. RGB mode:
+// three channels; spectral mode: the path's wavelength, replicated (kMediumStoredCoefficients makes medium_coefficients take the row as it is).
+ETX_DEV uint32_t bdpt_derive_walk_medium(const DScene& scene, const etx_abi_material& mat, const Isect& isect, float wavelength, uint32_t fallback) {
+  const f3 color = apply_image(scene, mat.scattering, isect.tex, nullptr, wavelength);
+  const etx_abi_spectral_image distances_image = {mat.subsurface.spectrum_index, mat.subsurface.image_index};
+  const f3 distances = apply_image(scene, distances_image, isect.tex, nullptr, wavelength);
+  f3 albedo, extinction, scattering;
+  sss_remap_channel(color.x, distances.x, albedo.x, extinction.x, scattering.x);
+  sss_remap_channel(color.y, distances.y, albedo.y, extinction.y, scattering.y);
+  sss_remap_channel(color.z, distances.z, albedo.z, extinction.z, scattering.z);
+  const uint32_t slot = divergent_slot(scene.lane_counters + kCntDynMedium);
+  if (slot >= scene.dyn_medium_capacity) {  // the iteration is discarded, the pools (and this table with them) grow, it is rendered again
+    atomicOr(scene.lane_counters + kCntOverflow, kOverflowLightVertices);
+    return fallback;
+  }
+  const uint32_t index = scene.dyn_medium_first + slot;
+  float4* row = reinterpret_cast<float4*>(const_cast<DMedium*>(scene.mediums) + index);
+  const f3 absorption = extinction - scattering;
+  static_assert(sizeof(DMedium) == 8u * sizeof(float4), "a medium row is written as eight float4");
+  static_assert((offsetof(DMedium, density) == 48u) && (offsetof(DMedium, absorption_index) == 80u) && (offsetof(DMedium, derived_color) == 112u), "DMedium layout");
+  row[0] = mk4(absorption, 0.0f);                                    // absorption, g
+  row[1] = mk4(scattering, __uint_as_float(0u));                     // scattering, cls | explicit_connections << 16: homogeneous, no explicit connections (derive_medium, host_scene.cpp)
+  row[2] = mk4(extinction, __uint_as_float(0u));                     // extinction, cls
+  row[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                      // density (none), bounds_min.xy
+  row[4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                      // bounds_min.z, bounds_max
+  row[5] = make_float4(__uint_as_float(kInvalid), __uint_as_float(kInvalid), __uint_as_float(0u), __uint_as_float(0u));  // absorption_index, scattering_index, cls, explicit_connections
+  row[6] = make_float4(fmaxf(extinction.x, fmaxf(extinction.y, extinction.z)), 0.0f, 0.0f, 0.0f);                        // max_sigma, dims
+  row[7] = make_float4(__uint_as_float(kMediumStoredCoefficients), __uint_as_float(kInvalid), 0.0f, 0.0f);               // derived_color = "stored", derived_distances
+  return index;
+}
+
+ETX_DEV bool bdpt_enter_subsurface(const DScene& scene, const etx_abi_material& mat, const Isect& isect, BsdfSample& bs, Sampler& smp, float wavelength, uint32_t& vertex_medium,
   uint32_t& walk_medium, uint32_t& path_medium) {
   if ((mat.subsurface.cls == 0u) || ((bs.properties & kSampleReflection) == 0u) || ((bs.properties & kSampleDiffuse) == 0u))
     return false;
@@ -153,6 +197,8 @@ ETX_DEV bool bdpt_enter_subsurface(const DScene& scene, const etx_abi_material& 
   walk_medium = scene.material_sss_medium[isect.material];
   path_medium = (walk_medium == mat.int_medium) ? walk_medium : kInvalid;
   vertex_medium = (walk_medium == mat.int_medium) ? walk_medium : scene.material_sss_medium[scene.subsurface_scatter_material];
+  if (walk_medium == kSssMediumDynamic)
+    walk_medium = bdpt_derive_walk_medium(scene, mat, isect, wavelength, vertex_medium);
   bs.w_o = w_o;
   bs.weight = mk3(1.0f);
   bs.pdf = fabsf(dot(w_o, isect.nrm)) / kPi;
@@ -296,7 +342,7 @@ ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const Nodes& nodes, c
       st.sampler.pop_fixed();
       uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
       uint32_t walk_medium = kInvalid, path_medium = vertex_medium;
-      const bool enter = (kInWalk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, vertex_medium, walk_medium, path_medium);
+      const bool enter = (kInWalk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, st.wavelength, vertex_medium, walk_medium, path_medium);
       const uint32_t vertex_material = enter ? scene.subsurface_scatter_material : isect.material;
       st.path_size += 1u;
       const bool connectible = (bs.properties & kSampleDelta) == 0u;
@@ -308,7 +354,7 @@ ETX_DEV BdptLightStep bdpt_light_step(const DScene& scene, const Nodes& nodes, c
       r.v_pos = isect.pos, r.v_nrm = isect.nrm, r.v_wi = isect.w_i, r.v_throughput = st.throughput, r.v_flags = curr.flags, r.v_tri = isect.tri, r.v_bc_u = isect.bc.y, r.v_bc_v = isect.bc.z;
       if (enter || kInWalk)
         r.v_flags |= kBvScatterMaterial;
-      if (scene.material_group[vertex_material] != kShadeGroupSimple)
+      if (scene.material_general_bsdf[vertex_material] != 0u)
         r.v_flags |= kBvGeneralBsdf;
       r.v_medium = vertex_medium;
       st.medium = path_medium;
@@ -369,32 +415,64 @@ ETX_DEV void bdpt_walk_push(const Pipeline& p, uint32_t queue, uint32_t slot, co
   if (slot >= p.capacity)
     return;  // cannot happen: every path is in one place (path set, walk queue or exit queue)
   bdpt_store(p.walk[queue], slot, st, prev_w);
-  p.walk_info[queue][slot] = make_uint2(walk.material, walk.medium | (walk.events << 16u));
+  p.walk_info[queue][slot] = make_uint2(walk.material | (walk.events << 20u), walk.medium);  // material < 2^20 (host_scene.cpp), events <= 1024; the medium index needs all 32 bits (per-walk rows)
 }
 ETX_DEV BdptWalk bdpt_walk_info(const Pipeline& p, uint32_t queue, uint32_t entry) {
   const uint2 info = p.walk_info[queue][entry];
-  return {info.x, info.y & 0xffffu, info.y >> 16u};
+  return {info.x & 0xfffffu, info.y, info.x >> 20u};
+}
+
+// Mixed scenes (DeviceScene::bdpt_binning: most surfaces Lambert, some of a class that needs the out-of-line BSDF library - the plastic coat of a subsurface
+// object next to diffuse walls): until round 6 every kernel that evaluates a BSDF ran its general instantiation for EVERY item of such a scene (256 VGPRs + 110 AGPRs,
+// 784 B of call frames per lane, one wavefront per SIMD). Now a kernel exists in three parts: kPartAll (scenes of one kind: every item, the instantiation the
+// scene asks for), and for mixed scenes kPartSimple - the inline-Lambert instantiation over every item, which hands the items whose material needs the general
+// library (DScene::material_general_bsdf) to a list - followed by kPartGeneral, the general instantiation over that list, dense. As the VCM / PT shade kernels
+// bin by shading group (kernels_shade.inl); the lists and their counters are theirs (free under this integrator; cleared per round by round_housekeeping).
+enum : uint32_t { kPartAll = 0u, kPartSimple = 1u, kPartGeneral = 2u };
+
+ETX_DEV bool bdpt_hit_general(const DScene& scene, const float4& h) {
+  const uint32_t tri = __float_as_uint(h.w);
+  return (tri != kInvalid) && (scene.material_general_bsdf[scene.triangles[tri].material_index] != 0u);
+}
+
+// kPartSimple: true = the item stays with this kernel. Workgroup-uniform call (block compaction); `list` holds one entry per live path at most.
+ETX_DEV bool bdpt_bin_general(const Pipeline& p, uint32_t list, uint32_t item, bool valid, bool general, BlockScratch& scratch) {
+  const bool hand_over = valid && general;
+  const uint32_t at = block_compact_slot(hand_over, p.counters + (list == 0u ? kCntGroupGeneral : kCntGroupSubsurface), scratch);
+  if (hand_over) {
+    if (at < p.capacity)
+      p.group_list[list][at] = item;
+    else
+      atomicOr(p.counters + kCntOverflow, kOverflowLightVertices);  // cannot happen (see the callers); if it did, the iteration would be discarded, not rendered short
+  }
+  return valid && (general == false);
 }
 
 // One segment of an emitter path after the closest-hit query
-template <bool kSimple>
+template <bool kSimple, uint32_t kPart>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, VcmParams it, uint32_t in_set) {
+  static_assert((kPart == kPartAll) || (kSimple == (kPart == kPartSimple)), "kPartSimple runs the inline instantiation, kPartGeneral the out-of-line one");
   __shared__ BlockScratch s_scratch;
   const LaneStack no_stack = {};
   const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const PathSet& out = p.paths[in_set ^ 1u];
-  const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
+  const uint32_t count = (kPart == kPartGeneral) ? min(p.counters[kCntGroupGeneral], p.capacity) : p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
   uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
   const uint32_t mode = bdpt_mode(it);
-  ETX_BLOCK_LOOP(count, i) {
-    const bool valid = i < count;
+  ETX_BLOCK_LOOP(count, j) {
+    bool valid = j < count;
+    const uint32_t i = (kPart == kPartGeneral) ? (valid ? p.group_list[0][j] : 0u) : j;
+    float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
+    if (valid)
+      h = p.hits[i];
+    if (kPart == kPartSimple)
+      valid = bdpt_bin_general(p, 0u, i, valid, bdpt_hit_general(scene, h), s_scratch);
     BdptState st = {};
     BdptWalk walk = {kInvalid, kInvalid, 0u};
     BdptLightStep r = {};
     if (valid) {
       st = bdpt_load(in, i);
-      float4 h = p.hits[i];
       if (st.flags & kBpFirst) {
         st.prev.tri = st.prev_slot;  // see k_bdpt_light_generate
         st.prev_slot = kInvalid;
@@ -527,22 +605,32 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_exit_light(Pipeline p,
 }
 
 // connect_light_to_camera (:1380-1428) for the vertices the light pass stored in this bounce
-template <bool kSimple>
+// (kPartSimple hands the vertices flagged kBvGeneralBsdf to list 1: surface vertices only, one per path and round - the entry and the exit vertex of a walk carry
+// the scatter material, which is of a simple class whenever the host enables the binning)
+template <bool kSimple, uint32_t kPart>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_camera(Pipeline p, VcmParams it) {
+  static_assert((kPart == kPartAll) || (kSimple == (kPart == kPartSimple)), "part / instantiation");
   __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
   const uint32_t begin = p.counters[kCntLightBounceBegin];
   const uint32_t end = min(p.counters[kCntLightVertices], p.lv.capacity);
-  const uint32_t count = (end > begin) ? (end - begin) : 0u;
+  const uint32_t count = (kPart == kPartGeneral) ? min(p.counters[kCntGroupSubsurface], p.capacity) : ((end > begin) ? (end - begin) : 0u);
   const uint32_t mode = bdpt_mode(it);
   ETX_BLOCK_LOOP(count, j) {
     ShadowRequest request;
     bool queue = false;
-    if (j < count) {
-      const uint32_t vi = begin + j;
-      const uint32_t flags = __float_as_uint(p.lv.thr_dvm(vi).w);
+    bool valid = j < count;
+    const uint32_t vi = (kPart == kPartGeneral) ? (valid ? p.group_list[1][j] : 0u) : (begin + j);
+    uint32_t flags = 0u;
+    if (valid) {
+      flags = __float_as_uint(p.lv.thr_dvm(vi).w);
       const uint32_t index_in_path = __float_as_uint(p.lv.bc_len_med(vi).z) >> 16u;
-      if ((flags & kBvConnectible) && ((flags & kBvNoCameraConnection) == 0u) && (index_in_path >= 1u) && opt_connect_to_camera(it)) {
+      valid = (flags & kBvConnectible) && ((flags & kBvNoCameraConnection) == 0u) && (index_in_path >= 1u) && opt_connect_to_camera(it);
+    }
+    if (kPart == kPartSimple)
+      valid = bdpt_bin_general(p, 1u, vi, valid, (flags & kBvGeneralBsdf) != 0u, s_scratch);
+    if (valid) {
+      {
         BdptLightVertex y = bdpt_load_light_vertex(p, scene, vi);
         const uint32_t target_path_length = y.path_size;  // emitter_path_length() + 1
         if ((target_path_length <= scene.max_path_length) && (target_path_length >= scene.min_path_length)) {
@@ -747,7 +835,7 @@ ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, 
       st.sampler.pop_fixed();
       uint32_t vertex_medium = (bs.properties & kSampleMediumChanged) ? bs.medium_index : st.medium;
       uint32_t path_medium = vertex_medium;
-      r.enter = (kInWalk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, vertex_medium, r.enter_medium, path_medium);
+      r.enter = (kInWalk == false) && bdpt_enter_subsurface(scene, mat, isect, bs, st.sampler, st.wavelength, vertex_medium, r.enter_medium, path_medium);
       r.scatter_vertex = r.scatter_vertex || r.enter;
       r.enter_material = isect.material;
       const uint32_t vertex_material = r.enter ? scene.subsurface_scatter_material : isect.material;
@@ -807,7 +895,7 @@ ETX_DEV BdptCameraStep bdpt_camera_step(const Pipeline& p, const DScene& scene, 
       r.store_vertex = connectible && (mode != kBdptLightTracing);
       r.v_hit = h, r.v_wi = isect.w_i, r.v_throughput = vertex_throughput, r.v_medium = vertex_medium;
       r.v_rnd = {rnd_em.x, rnd_em.y, rnd_support.y};
-      r.general_bsdf = scene.material_group[vertex_material] != kShadeGroupSimple;
+      r.general_bsdf = scene.material_general_bsdf[vertex_material] != 0u;
     }
    }
   } else if ((kInWalk == false) && opt_direct_hit(it) && (mode != kBdptLightTracing)) {  // miss: direct_hit_environment_emitter, :1289-1340
@@ -880,26 +968,32 @@ ETX_DEV uint32_t bdpt_camera_finish(const Pipeline& p, const DScene& scene, Bdpt
   return goes_on ? 1u : 0u;
 }
 
-template <bool kSimple>
+template <bool kSimple, uint32_t kPart>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_camera_shade(Pipeline p, VcmParams it, uint32_t in_set) {
+  static_assert((kPart == kPartAll) || (kSimple == (kPart == kPartSimple)), "part / instantiation");
   __shared__ BlockScratch s_scratch;
   const LaneStack no_stack = {};
   const DScene& scene = p.scene;
   const PathSet& in = p.paths[in_set];
   const PathSet& out = p.paths[in_set ^ 1u];
-  const uint32_t count = p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
+  const uint32_t count = (kPart == kPartGeneral) ? min(p.counters[kCntGroupGeneral], p.capacity) : p.counters[in_set == 0 ? kCntActiveA : kCntActiveB];
   uint32_t* out_counter = p.counters + (in_set == 0 ? kCntActiveB : kCntActiveA);
   const uint32_t mode = bdpt_mode(it);
   const bool use_mis = opt_enable_mis(it);
-  ETX_BLOCK_LOOP(count, i) {
-    const bool valid = i < count;
+  ETX_BLOCK_LOOP(count, j) {
+    bool valid = j < count;
+    const uint32_t i = (kPart == kPartGeneral) ? (valid ? p.group_list[0][j] : 0u) : j;
+    float4 h = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kInvalid));
+    if (valid)
+      h = p.hits[i];
+    if (kPart == kPartSimple)
+      valid = bdpt_bin_general(p, 0u, i, valid, bdpt_hit_general(scene, h), s_scratch);
     BdptState st = {};
     BdptWalk walk = {kInvalid, kInvalid, 0u};
     BdptCameraStep r = {};
     if (valid) {
       st = bdpt_load(in, i);
       st.prev.tri = st.prev_slot;  // camera paths carry the previous vertex' triangle there
-      float4 h = p.hits[i];
       r = bdpt_camera_step<kStepSegment, kSimple>(p, scene, global_nodes(scene), no_stack, it, mode, use_mis, st, walk, h);
     }
     const uint32_t vertex_slot = block_compact_slot(r.store_vertex, p.counters + kCntCameraVertices, s_scratch);
@@ -992,16 +1086,21 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_walk_exit_camera(Pipeline p
 }
 
 // connect_camera_to_light (:1342-1378) with mis_weight_camera_to_light (:1079-1133) for the camera vertices of this bounce
-template <bool kSimple>
+template <bool kSimple, uint32_t kPart>
 __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_light(Pipeline p, VcmParams it) {
+  static_assert((kPart == kPartAll) || (kSimple == (kPart == kPartSimple)), "part / instantiation");
   __shared__ BlockScratch s_scratch;
   const DScene& scene = p.scene;
-  const uint32_t count = min(p.counters[kCntCameraVertices], p.cv_capacity);
+  const uint32_t count = (kPart == kPartGeneral) ? min(p.counters[kCntGroupSubsurface], p.capacity) : min(p.counters[kCntCameraVertices], p.cv_capacity);
   const uint32_t mode = bdpt_mode(it);
-  ETX_BLOCK_LOOP(count, i) {
+  ETX_BLOCK_LOOP(count, j) {
     ShadowRequest request;
     bool queue = false;
-    if ((i < count) && opt_connect_to_light(it)) {
+    bool valid = (j < count) && opt_connect_to_light(it);
+    const uint32_t i = (kPart == kPartGeneral) ? (valid ? p.group_list[1][j] : 0u) : j;
+    if (kPart == kPartSimple)  // (the class bit of a camera vertex record: bdpt_store_camera_vertex)
+      valid = bdpt_bin_general(p, 1u, i, valid, valid && ((__float_as_uint(p.cv.thr_depth[i].w) & kCvGeneralBsdfBit) != 0u), s_scratch);
+    if (valid) {
       BdptCameraVertex z = bdpt_load_camera_vertex(p, scene, i);
       const uint32_t connection_len = z.path_size;  // camera_path_length() + 1
       if ((connection_len <= scene.max_path_length) && (connection_len >= scene.min_path_length)) {
@@ -1182,49 +1281,62 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs_general(Pipel
 void launch_bdpt_light_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
   hipLaunchKernelGGL(k_bdpt_light_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
 }
-// `simple`: every material in use is of the simple shading group (DeviceScene::simple_materials) -> the instantiations with the inline
-// Lambert / delta BSDFs; otherwise every class through the out-of-line dispatch (dev_bsdf_ool.h)
-#define ETX_BDPT_LAUNCH(KERNEL, GRID, ...)                                                                  \
+// `variant` (kernels.h kBdptKernels*): Simple = every material in use is of a class the inline Lambert / delta BSDFs answer for (DeviceScene::simple_materials);
+// General = every class through the out-of-line dispatch (dev_bsdf_ool.h) for every item; Binned = a mixed scene whose subsurface scatter material is of a simple
+// class: the inline instantiation over every item, the out-of-line one over the items it handed over (kPartSimple / kPartGeneral above)
+#define ETX_BDPT_LAUNCH(KERNEL, GRID, ...)                                                                                    \
+  do {                                                                                                                        \
+    if (variant == kBdptKernelsSimple) {                                                                                      \
+      hipLaunchKernelGGL((KERNEL<true, kPartAll>), dim3(GRID), dim3(kBlockSize), 0, stream, __VA_ARGS__);                     \
+    } else if (variant == kBdptKernelsBinned) {                                                                               \
+      hipLaunchKernelGGL((KERNEL<true, kPartSimple>), dim3(GRID), dim3(kBlockSize), 0, stream, __VA_ARGS__);                  \
+      hipLaunchKernelGGL((KERNEL<false, kPartGeneral>), dim3(GRID), dim3(kBlockSize), 0, stream, __VA_ARGS__);                \
+    } else {                                                                                                                  \
+      hipLaunchKernelGGL((KERNEL<false, kPartAll>), dim3(GRID), dim3(kBlockSize), 0, stream, __VA_ARGS__);                    \
+    }                                                                                                                         \
+  } while (0)
+// the exit vertex of a walk carries the scatter material (build_path :858-861): of a simple class in a binned scene
+#define ETX_BDPT_LAUNCH_EXIT(KERNEL, GRID, ...)                                                             \
   do {                                                                                                      \
-    if (simple)                                                                                             \
+    if (variant != kBdptKernelsGeneral)                                                                     \
       hipLaunchKernelGGL(KERNEL<true>, dim3(GRID), dim3(kBlockSize), 0, stream, __VA_ARGS__);               \
     else                                                                                                    \
       hipLaunchKernelGGL(KERNEL<false>, dim3(GRID), dim3(kBlockSize), 0, stream, __VA_ARGS__);              \
   } while (0)
 
-void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple) {
+void launch_bdpt_light_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, uint32_t variant) {
   ETX_BDPT_LAUNCH(k_bdpt_light_shade, max(1u, grid_for(min(p.capacity, max_items))), p, it, in_set);
 }
 // the walks of the paths the shade kernel of this round put on the walk queue: the scattering events in persistent wavefronts (at most
 // kWalkBlocks workgroups: 32 KB of traversal stack each), then the exit vertices as a dense kernel
-void launch_bdpt_walk(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool camera, uint32_t in_set, uint32_t max_items, bool simple) {
+void launch_bdpt_walk(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool camera, uint32_t in_set, uint32_t max_items, uint32_t variant) {
   const uint32_t items = min(p.capacity, max_items);
   const uint32_t blocks = max(1u, min(kWalkBlocks, (items + kBlockSize - 1u) / kBlockSize));
   if (camera) {
     hipLaunchKernelGGL(k_bdpt_walk_camera, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
-    ETX_BDPT_LAUNCH(k_bdpt_walk_exit_camera, max(1u, grid_for(items)), p, it, in_set ^ 1u);
+    ETX_BDPT_LAUNCH_EXIT(k_bdpt_walk_exit_camera, max(1u, grid_for(items)), p, it, in_set ^ 1u);
   } else {
     hipLaunchKernelGGL(k_bdpt_walk_light, dim3(blocks), dim3(kBlockSize), 0, stream, p, it, in_set);
-    ETX_BDPT_LAUNCH(k_bdpt_walk_exit_light, max(1u, grid_for(items)), p, it, in_set ^ 1u);
+    ETX_BDPT_LAUNCH_EXIT(k_bdpt_walk_exit_light, max(1u, grid_for(items)), p, it, in_set ^ 1u);
   }
 }
-void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, bool simple) {
+void launch_bdpt_connect_camera(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, uint32_t variant) {
   ETX_BDPT_LAUNCH(k_bdpt_connect_camera, max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 2ull, uint64_t(p.lv.capacity))))), p, it);
 }
 void launch_bdpt_camera_generate(hipStream_t stream, const Pipeline& p, const VcmParams& it) {
   hipLaunchKernelGGL(k_bdpt_camera_generate, dim3(grid_for(p.capacity)), dim3(kBlockSize), 0, stream, p, it);
 }
-void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, bool simple) {
+void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, uint32_t variant) {
   ETX_BDPT_LAUNCH(k_bdpt_camera_shade, max(1u, grid_for(min(p.capacity, max_items))), p, it, in_set);
 }
-void launch_bdpt_connect_light(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, bool simple) {
+void launch_bdpt_connect_light(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, uint32_t variant) {
   ETX_BDPT_LAUNCH(k_bdpt_connect_light, max(1u, grid_for(min(p.capacity, max_items))), p, it);
 }
 // Vertex connections. A scene of simple materials: one kernel; otherwise the pairs of two simple vertices go through the inline
 // Lambert / phase-function kernel and only the others through the general one (both run over the pair list and take their class).
-void launch_bdpt_connect_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, bool simple) {
+void launch_bdpt_connect_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, uint32_t variant) {
   const uint32_t pair_blocks = max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 8ull, uint64_t(p.pair_capacity)))));
-  if (simple) {
+  if (variant == kBdptKernelsSimple) {
     hipLaunchKernelGGL(k_bdpt_connect_pairs<false>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
   } else {
     hipLaunchKernelGGL(k_bdpt_connect_pairs<true>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);

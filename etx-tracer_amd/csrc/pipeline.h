@@ -150,6 +150,7 @@ enum : uint32_t {
   kCntEndpoints = 608,       // endpoint connection requests of the current bounce, cleared per bounce
   kCntNonFinite = 640,
   kCntLightBounceBegin = 800, // BDPT: light vertex count when the current bounce began (k_bdpt_connect_camera covers [begin, count))
+  kCntDynMedium = 801,        // BDPT: per-walk medium rows appended in this iteration (DScene::sss_dynamic_media; one atomic per wavefront, shares a line with a word written once per bounce)
   kStatRaysLight = 672,      // u64 statistics: closest-hit rays of the light pass / camera pass, pair connections, endpoint connections
   kStatRaysCamera = 704,
   kStatPairs = 736,
@@ -221,7 +222,7 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
   PathSet paths[2];
   PathSet walk[2];       // BDPT walk queues (kCntWalk): the state of the paths that are inside a subsurface object (k_bdpt_walk_* take them from
                          // here; a path joins the "out" set again when it has left the object); null without such materials
-  uint2* walk_info[2];   // ... their object: (material, DScene::material_sss_medium of it | events of the walk so far << 16)
+  uint2* walk_info[2];   // ... their object: (material | events of the walk so far << 20, medium of the walk: DScene::material_sss_medium of the material, or the walk's own row)
   PathSet walk_exit;     // BDPT exit queue: walks whose free flight reached the surface of their object, with that hit
   float4* walk_exit_hits;
   float4* hits;          // hit queue, aligned with the "in" path set

@@ -263,7 +263,9 @@ int etx_hip_stats(etx_hip_context* context, etx_hip_stats_t* out_stats, size_t s
 
 /* Ablation switches of the kernels for timing experiments and kernel-level tests (0 = production, the default): bit 0 no film
  * atomics in the shadow kernel, bit 2 no transmittance traversal, bit 6 (64) the packed two-ray flat sweep in etx_hip_trace_rays*,
- * bits 8 / 9 no next event estimation / no camera vertex storage. (The reference's seeding of the camera path, bit 15 until ABI 2, is a product
+ * bit 7 (128) the matrix-core flat sweep, bits 8 / 9 no next event estimation / no camera vertex storage, bit 16 (0x10000) the bidirectional kernels of a
+ * scene that mixes Lambert surfaces with materials of the general BSDF classes run their general instantiation for every item instead of splitting the items
+ * by class. (The reference's seeding of the camera path, bit 15 until ABI 2, is a product
  * option now: etx_abi_vcm_options / etx_abi_bdpt_options::reference_seeding.) Waits for the iterations in flight. The library reads no
  * environment variable for these; builds with -DETX_HIP_DEBUG additionally read tuning knobs (csrc/tuning_knobs.h). */
 int etx_hip_set_debug_flags(etx_hip_context* context, uint32_t flags);

@@ -55,14 +55,14 @@ class Mesh:
         self.groups.append((mat, [(base + 1, ni), (base + 2, ni), (base + 3, ni)]))
         self.groups.append((mat, [(base + 1, ni), (base + 3, ni), (base + 4, ni)]))
 
-    def box(self, mat, top, height_y):
+    def box(self, mat, top, height_y, uv=False):
         """top: 4 points of the top face (counter-clockwise seen from above); sides go down to y=0."""
         bottom = [(p[0], 0.0, p[2]) for p in top]
         top = [(p[0], height_y, p[2]) for p in top]
-        self.quad(mat, top, (0, 1, 0))
+        self.quad(mat, top, (0, 1, 0), uv=uv)
         for i in range(4):
             j = (i + 1) % 4
-            self.quad(mat, [top[j], top[i], bottom[i], bottom[j]])
+            self.quad(mat, [top[j], top[i], bottom[i], bottom[j]], uv=uv)
 
     def aabb(self, mat, lo, hi):
         """closed axis aligned box with outward normals"""
@@ -133,7 +133,7 @@ class Mesh:
                 f.write("f " + " ".join(("%d/%d/%d" % (c[0], c[2], c[1])) if len(c) == 3 else ("%d//%d" % c) for c in idx) + "\n")
 
 
-def build_mesh(with_fog, spheres=False, sss_meshes=False):
+def build_mesh(with_fog, spheres=False, sss_meshes=False, box_uv=False):
     m = Mesh()
     # room, normals pointing inside
     m.quad("floor", [(-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1)], (0, 1, 0))
@@ -170,8 +170,8 @@ def build_mesh(with_fog, spheres=False, sss_meshes=False):
         m.icosphere("tallBox", (-0.40, 0.45, -0.30), 0.45, 3)
         m.icosphere("gem", (-0.45, 0.22, 0.55), 0.22, 2, flat=True)
     else:
-        m.box("shortBox", ccw_from_above(short_top), short_top[0][1])
-        m.box("tallBox", ccw_from_above(tall_top), tall_top[0][1])
+        m.box("shortBox", ccw_from_above(short_top), short_top[0][1], uv=box_uv)
+        m.box("tallBox", ccw_from_above(tall_top), tall_top[0][1], uv=box_uv)
     if with_fog:
         m.aabb("fog", (-0.99, 0.01, -0.99), (0.99, 1.99, 0.99))
     return m
@@ -568,6 +568,14 @@ two_sided 1
         f.write(text.replace("subsurface distances 0.30 0.15 0.08 scale 0.5", "subsurface distances 0.30 0.15 0.08 scale 0.5 class approximate")
                     .replace("subsurface path refracted distances 0.10 0.20 0.40 scale 0.5", "subsurface path refracted distances 0.10 0.20 0.40 scale 0.5 class approximate"))
     write_json("ssscb_test_128.json", "cornell_classic.obj", "cornell_ssscb.mtl", (128, 128), 64)
+    # the random-walk box with a TEXTURED scattering colour on the short box (checker albedo through map_Kd; every face of the boxes carries texture coordinates):
+    # without an interior medium the walk's coefficients are derived from the colour at the ENTRY POINT (subsurface_step, bidirectional.cxx:757-765) - under the
+    # bidirectional integrator every walk then runs through a medium of its own
+    build_extra_textures()
+    build_mesh(False, box_uv=True).write(os.path.join(OUT, "cornell_ssstex.obj"), "cornell_ssstex.mtl")
+    with open(os.path.join(OUT, "cornell_ssstex.mtl"), "w") as f:
+        f.write(text.replace("newmtl shortBox\nmaterial class diffuse\nKd 0.900 0.750 0.550", "newmtl shortBox\nmaterial class diffuse\nKd 1.000 0.900 0.700\nmap_Kd textures/checker.png"))
+    write_json("ssstex_test_128.json", "cornell_ssstex.obj", "cornell_ssstex.mtl", (128, 128), 64)
     write_json("spectral_test_128.json", "cornell_classic.obj", "cornell_classic.mtl", (128, 128), 64, spectral=True)
     write_json("diamond_test_128.json", "cornell_classic.obj", "cornell_diamond.mtl", (128, 128), 64, spectral=True)
 

@@ -111,9 +111,7 @@ def render_halves(etx, golden_dir, flavour, cie, integrator_class, options, debu
         integ.context.close()
         return cam, light, stats
 
-    # one after the other: rendering the halves from two host threads at once made the suite 10 % shorter and crashed the interpreter in one of five
-    # full runs (GPU call r5k; not reproduced with the fault handler on) - two contexts driven CONCURRENTLY from one process are not something the
-    # product promises, so the tests do not do it
+    # one after the other (contexts driven from several host threads at once are tests/test_gpu_contexts.py's subject)
     results = [half(0), half(1)]
     films = []
     for cam, light, stats in results:
