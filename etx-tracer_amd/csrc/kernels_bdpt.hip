@@ -496,13 +496,19 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
 
 // The subsurface walks of the paths that entered an object in this bounce (walk queue -> "out" path set). Persistent wavefronts:
 // a lane runs the sub-steps of ITS walk; whenever kWalkRefill lanes of a wavefront are idle they take the next entries of the queue.
-constexpr uint32_t kWalkRefill = 16u;
+#if !defined(ETX_WALK_REFILL)  // (experiment builds: tools/build_variant.sh ... "-DETX_WALK_REFILL=8 -DETX_WALK_BUDGET=64" kernels_bdpt.hip)
+#define ETX_WALK_REFILL 16u
+#endif
+#if !defined(ETX_WALK_BUDGET)
+#define ETX_WALK_BUDGET 32u
+#endif
+constexpr uint32_t kWalkRefill = ETX_WALK_REFILL;
 constexpr uint32_t kWalkBlocks = 1024u;
 // Scattering events a walk gets per round. Most walks leave their object after a few events, a few take hundreds (the reference
 // allows 1024, :776): a kernel that ran every walk of a bounce to its end lasted as long as its longest walk (measured 7 ms per
 // launch, 100 ms per iteration, with nearly all lanes idle). A walk that is still inside after its budget goes to the other walk
 // queue and continues in the next round, next to that round's new walks.
-constexpr uint32_t kWalkBudget = 32u;
+constexpr uint32_t kWalkBudget = ETX_WALK_BUDGET;
 // (Tried: letting the last <= 4096 walks of a pass run to their end in one launch - fewer rounds, 111 -> 91 per iteration, but the
 // launch then lasts as long as its longest walk with the stream idle behind it: 23.9 vs 25.3 Msamples/s. Not adopted.)
 constexpr uint32_t kWalkLdsNodes = 64u;  // 8 KB next to the 32 KB of stacks: four workgroups per CU
