@@ -292,7 +292,7 @@ def main(argv=None, context_factory=None):
                                 "k_bdpt_light_shade + k_bdpt_walk + k_bdpt_connect_camera: 116 B state + 16 B hit in, 116 B state out, 96 B per stored light vertex (every event of a subsurface walk is one)"),
                 "shade_camera": ("path segment", s.rays_camera, 248.0 * s.rays_camera + 164.0 * s.camera_vertices, s.ms_shade_camera,
                                  "k_bdpt_camera_shade + k_bdpt_walk + k_bdpt_connect_light: 116 B state + 16 B hit in, 116 B out, 116 B vertex record + 48 B request per connectible vertex"),
-                "connect": ("pair", s.pairs, 220.0 * s.pairs, s.ms_connect, "k_expand_pairs + k_bdpt_connect_pairs: 8 B pair + 96 B light vertex + 68 B camera vertex + 48 B shadow request"),
+                "connect": ("pair", s.pairs, 220.0 * s.pairs, s.ms_connect, "k_bdpt_expand_pairs + k_bdpt_connect_pairs: 8 B pair + 96 B light vertex + 68 B camera vertex + 48 B shadow request"),
             }
         else:
             units = {

@@ -287,11 +287,31 @@ ETX_DEV void bdpt_store_light_vertex(const Pipeline& p, uint32_t idx, uint32_t p
   p.lv.nrm_tri(idx) = mk4(nrm, __uint_as_float(tri));
   p.lv.bc_len_med(idx) = make_float4(bc_u, bc_v, __uint_as_float((index_in_path << 16u) | (path_size & 0xffffu)), __uint_as_float(medium));
   p.lv.rec[idx * LightVertexPool::kLvStride + 5] = make_float4(__uint_as_float(prev), wavelength, __uint_as_float(seed), __uint_as_float(path));
-  uint32_t* row = reinterpret_cast<uint32_t*>(p.light_path_table) + size_t(path) * p.path_table_entries;  // head, length, first vertices: one cache line per path
-  if (index_in_path + kPathRowHeader < p.path_table_entries)
-    row[kPathRowHeader + index_in_path] = idx;
-  row[0] = idx;
+  // the path's index list (pipeline.h kBdptRowHeader): one lane owns a path at any time, its vertices arrive in order
+  uint32_t* row = reinterpret_cast<uint32_t*>(p.light_path_table) + size_t(path) * p.path_table_entries;
+  const bool general = (flags & kBvGeneralBsdf) != 0u;
+  const uint32_t entry = idx | (general ? kPathEntryGeneralBit : 0u);
+  const uint32_t row_entries = p.path_table_entries - kBdptRowHeader;
+  if (index_in_path < row_entries) {
+    row[kBdptRowHeader + index_in_path] = entry;
+  } else {
+    const uint32_t position = (index_in_path - row_entries) % kPathChunkEntries;
+    uint32_t chunk = row[0];
+    if (position == 0u) {  // a new chunk, linked to the one before
+      const uint32_t fresh = atomicAdd(p.counters + kCntPathChunks, 1u);
+      if (fresh >= p.path_chunk_capacity) {  // cannot happen before the vertex pool itself overflows (host_api.cpp allocate_pools); the list stays as long as its chain
+        atomicOr(p.counters + kCntOverflow, kOverflowLightVertices);
+        return;
+      }
+      p.path_chunks[size_t(fresh) * kPathChunkWords] = chunk;
+      row[0] = chunk = fresh;
+    }
+    if (chunk < p.path_chunk_capacity)
+      p.path_chunks[size_t(chunk) * kPathChunkWords + 1u + position] = entry;
+  }
   row[1] = index_in_path + 1u;
+  if (general)
+    row[2] += 1u;
 }
 
 struct BdptLightVertex {

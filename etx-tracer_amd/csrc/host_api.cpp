@@ -239,6 +239,7 @@ void release_pools(etx_hip_context* ctx) {
   p.lv.rec = nullptr, p.lv.capacity = 0u;
   p.cv = {}, p.merge_order = nullptr, p.cv_capacity = 0u;
   p.pairs = nullptr, p.pair_capacity = 0u;
+  p.path_chunks = nullptr, p.path_chunk_capacity = 0u;
   p.shadow = {};
   p.endpoints = {};
   // the lane's own medium table (scenes whose walks append rows) went with the pools: back to the shared one
@@ -296,6 +297,7 @@ size_t pool_bytes_for(const etx_hip_context::PoolSizes& z, bool with_grid) {
     bytes += size_t(next_pow2(z.light_vertices)) * 4u + size_t(z.light_vertices) * (1u + PhotonGrid::kPhotonStride) * sizeof(float4);
   bytes += size_t(z.camera_vertices) * (7u * sizeof(float4) + 3u * 4u);
   bytes += size_t(z.pairs) * sizeof(uint2) + size_t(z.shadow) * 3u * sizeof(float4) + size_t(z.endpoints) * (5u * sizeof(float4) + 4u);
+  bytes += (size_t(z.light_vertices) / 15u + 1u) * kPathChunkWords * sizeof(uint32_t);  // path_chunks
   return bytes;
 }
 
@@ -321,6 +323,11 @@ int allocate_pools(etx_hip_context* ctx, const etx_hip_context::PoolSizes& sizes
     return rc;
   p.pair_capacity = sizes.pairs;
   if ((rc = pool_alloc(ctx, p.pairs, p.pair_capacity)))
+    return rc;
+  // overflow chunks of the bidirectional light paths' index lists (pipeline.h kBdptRowHeader): a path beyond its row takes one chunk per 31 vertices and leaves at most one
+  // partly filled - lv / 31 + lv / 30 chunks can never run out before the vertex pool does
+  p.path_chunk_capacity = p.lv.capacity / 15u + 1u;
+  if ((rc = pool_alloc(ctx, p.path_chunks, size_t(p.path_chunk_capacity) * kPathChunkWords)))
     return rc;
   p.shadow.capacity = sizes.shadow;
   if ((rc = pool_alloc(ctx, p.shadow.p0_medium, p.shadow.capacity)) || (rc = pool_alloc(ctx, p.shadow.p1_target, p.shadow.capacity)) || (rc = pool_alloc(ctx, p.shadow.value, p.shadow.capacity)))
@@ -925,7 +932,7 @@ int render_bdpt_iteration(etx_hip_context* ctx, uint32_t iteration) {
         }
         if (vertices) {
           ScopedTimer t(ctx, kTimerConnect);
-          launch_expand_pairs(s, p, it, max_items);
+          launch_bdpt_expand_pairs(s, p, it, max_items);
           launch_bdpt_connect_pairs(s, p, it, max_items, simple);
         }
         if (to_light || vertices) {

@@ -63,7 +63,7 @@ void launch_bdpt_camera_generate(hipStream_t stream, const Pipeline& p, const Vc
 void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t in_set, uint32_t max_items, uint32_t variant);
 void launch_bdpt_connect_light(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, uint32_t variant);
 void launch_bdpt_connect_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, uint32_t variant);
-void launch_expand_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items);  // kernels_connect.hip
+void launch_bdpt_expand_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items);
 
 // photon grid
 void launch_grid_build(hipStream_t stream, const Pipeline& p, const VcmParams& it);

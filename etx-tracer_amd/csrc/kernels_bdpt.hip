@@ -659,8 +659,8 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_camera(Pipeline p, 
                 const float curr_from_camera = bdpt_to_area(film_pdf, cs.position, y.self);
                 const float prev_from_curr = bdpt_pdf_area<kSimple>(scene, kPathCamera, cs.position, y.full, y_prev, y.wavelength, smp);
                 if (mode == kBdptFast) {
-                  const uint32_t* table = reinterpret_cast<const uint32_t*>(p.light_path_table) + size_t(y.path) * p.path_table_entries + kPathRowHeader;
-                  const uint32_t e0 = table[0], e1 = table[1];
+                  const uint32_t* table = reinterpret_cast<const uint32_t*>(p.light_path_table) + size_t(y.path) * p.path_table_entries + kBdptRowHeader;
+                  const uint32_t e0 = table[0] & ~kPathEntryGeneralBit, e1 = table[1] & ~kPathEntryGeneralBit;
                   const float p_sample = p.lv.pos_dvcm(e0).w;  // e0.pdf.from_prev
                   const uint32_t e0_flags = __float_as_uint(p.lv.thr_dvm(e0).w), e1_flags = __float_as_uint(p.lv.thr_dvm(e1).w);
                   float p_light = y_prev.from_prev * y.self.from_prev;
@@ -1159,18 +1159,14 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_light(Pipeline p, V
 
 // connect_camera_to_light_path (:438-497), one (camera vertex, light vertex) pair per lane, with
 // mis_weight_camera_to_light_path (:1184-1209)
-// The class of a pair (both instantiations read these words anyway) and whether it takes part at all
-struct BdptPairClass {
-  bool connects, general;
-};
-ETX_DEV BdptPairClass bdpt_pair_class(const Pipeline& p, const DScene& scene, const uint2 pair) {
+// Whether a listed pair takes part at all (k_bdpt_expand_pairs lists every vertex of the light path but the emitter's; the class of the pair is the list it is on)
+ETX_DEV bool bdpt_pair_connects(const Pipeline& p, const DScene& scene, const uint2 pair) {
   const uint32_t y_flags = __float_as_uint(p.lv.thr_dvm(pair.y).w);
   const uint32_t light_s = __float_as_uint(p.lv.bc_len_med(pair.y).z) >> 16u;
   const uint32_t z_word = __float_as_uint(p.cv.thr_depth[pair.x].w);
   const uint32_t camera_path_size = z_word & ~(kCvExitMaterialBit | kCvGeneralBsdfBit);
   const uint32_t target_path_length = (camera_path_size - 1u) + light_s + 1u;
-  return {(light_s >= 1u) && ((y_flags & kBvConnectible) != 0u) && (target_path_length >= scene.min_path_length) && (target_path_length <= scene.max_path_length),
-    ((y_flags & kBvGeneralBsdf) != 0u) || ((z_word & kCvGeneralBsdfBit) != 0u)};
+  return (light_s >= 1u) && ((y_flags & kBvConnectible) != 0u) && (target_path_length >= scene.min_path_length) && (target_path_length <= scene.max_path_length);
 }
 
 // connect_camera_to_light_path for one (camera vertex, light vertex) pair: the visibility request, or false
@@ -1208,79 +1204,143 @@ ETX_DEV bool bdpt_connect_pair(const Pipeline& p, const DScene& scene, const Vcm
   return true;
 }
 
-// The inline-BSDF kernel. kOnlySimple = false: every pair (a scene of simple materials); true: the pairs whose two vertices are of
-// the simple shading group, in a scene that also holds other materials (the rest: k_bdpt_connect_pairs_general).
-template <bool kOnlySimple>
-__global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs(Pipeline p, VcmParams it) {
-  __shared__ BlockScratch s_scratch;
-  const DScene& scene = p.scene;
-  const uint32_t count = pair_list_count(p);
+// (camera vertex, light path of its pixel) -> (camera vertex, light vertex) pairs: connect_camera_to_light_path (:438-497) flattened, as k_expand_pairs does for VCM
+// (kernels_connect.hip), with two differences. TWO dense lists in the one pair buffer: pairs of two vertices of simple BSDF classes from the front (kCntPairs), pairs
+// with a vertex of a general class from the BACK (kCntPairsGeneral; entry j at pair_capacity - 1 - j) - until round 6 both pair kernels streamed over one list and read
+// three words of the two records of EVERY pair to find their own (the general kernel: 9 ms per step of configs[3] for the few pairs it evaluates). The class of a light
+// vertex is a bit of its list entry, a path's count of them is in its row header, so the lists' sizes are known before anything is read. And the path's vertices come
+// from its row and its CHUNKS (pipeline.h kBdptRowHeader) with independent 16-byte loads - no walk along the vertices' links (9 ms per step: one lane chasing hundreds
+// of pointers while its workgroup waits). The emitter's vertex (entry 0) connects to nothing (light_s >= 1, :447) and is not listed.
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_expand_pairs(Pipeline p, VcmParams it) {
+  __shared__ uint32_t s_wave_total[2][kBlockSize / 64u];
+  __shared__ uint32_t s_base[2];
+  const uint32_t count = min(p.counters[kCntCameraVertices], p.cv_capacity);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6u;
+  const uint32_t row_entries = p.path_table_entries - kBdptRowHeader;
   ETX_BLOCK_LOOP(count, i) {
-    ShadowRequest request;
-    bool queue = false;
+    uint32_t length = 0u, general = 0u, path = 0u;
+    bool camera_general = false;
+    uint4 header = make_uint4(kInvalid, 0u, 0u, 0u);  // newest chunk, length, vertices of general classes, entry 0: one 16-byte load of the path's row
     if (i < count) {
-      const uint2 pair = p.pairs[i];
-      const BdptPairClass c = bdpt_pair_class(p, scene, pair);
-      if (c.connects && ((kOnlySimple == false) || (c.general == false)))
-        queue = bdpt_connect_pair<true>(p, scene, it, pair, request);
+      path = __float_as_uint(p.cv.mis_pixel[i].w);
+      camera_general = (__float_as_uint(p.cv.thr_depth[i].w) & kCvGeneralBsdfBit) != 0u;
+      header = p.light_path_table[size_t(path) * (p.path_table_entries >> 2u)];
+      length = header.y;
     }
-    const uint32_t slot = block_compact_slot(queue, p.counters + kCntShadow, s_scratch);
-    if (queue)
-      write_shadow(p, slot, request);
+    const uint32_t k = (length > 1u) ? (length - 1u) : 0u;  // without the emitter's vertex
+    const uint32_t kg = camera_general ? k : min(header.z, k);
+    const uint32_t ks = k - kg;
+    // workgroup exclusive prefix sums of the two counts: wave scans, then one reservation per list for all four waves
+    uint32_t incl_s = ks, incl_g = kg;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint32_t ts = __shfl_up(incl_s, d), tg = __shfl_up(incl_g, d);
+      if (lane >= d)
+        incl_s += ts, incl_g += tg;
+    }
+    if (lane == 63u)
+      s_wave_total[0][wave] = incl_s, s_wave_total[1][wave] = incl_g;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+      uint32_t total_s = 0u, total_g = 0u;
+#pragma unroll
+      for (uint32_t w = 0; w < kBlockSize / 64u; ++w)
+        total_s += s_wave_total[0][w], total_g += s_wave_total[1][w];
+      s_base[0] = total_s ? atomicAdd(p.counters + kCntPairs, total_s) : 0u;
+      s_base[1] = total_g ? atomicAdd(p.counters + kCntPairsGeneral, total_g) : 0u;
+      if (total_s + total_g)
+        atomicAdd(reinterpret_cast<unsigned long long*>(p.counters + kStatPairs), (unsigned long long)(total_s + total_g));
+    }
+    __syncthreads();
+    uint32_t base_s = s_base[0] + incl_s - ks, base_g = s_base[1] + incl_g - kg;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlockSize / 64u; ++w)
+      base_s += (w < wave) ? s_wave_total[0][w] : 0u, base_g += (w < wave) ? s_wave_total[1][w] : 0u;
+    __syncthreads();
+    if (k == 0u)
+      continue;
+    if ((base_s + ks > p.pair_capacity) || (base_g + kg > p.pair_capacity)) {  // the buffer's bounds; whether the two lists MET is the pair kernel's check (both counts are final there)
+      atomicOr(p.counters + kCntOverflow, kOverflowPairs);
+      continue;
+    }
+    uint32_t at_s = base_s, at_g = p.pair_capacity - 1u - base_g;
+    auto put = [&](uint32_t entry) {
+      const uint2 pair = make_uint2(i, entry & ~kPathEntryGeneralBit);
+      if (camera_general || ((entry & kPathEntryGeneralBit) != 0u)) {
+        if (at_g + kg > p.pair_capacity - 1u - base_g)  // (a row whose class count and entries disagree - an iteration that is being discarded - must not leave its range)
+          p.pairs[at_g--] = pair;
+      } else if (at_s < base_s + ks) {
+        p.pairs[at_s++] = pair;
+      }
+    };
+    // entries 1 .. of the row: word kBdptRowHeader + j of the row = entry j
+    const uint4* row = p.light_path_table + size_t(path) * (p.path_table_entries >> 2u);
+    const uint32_t from_row = min(length, row_entries);
+    for (uint32_t q = 1; (q << 2u) < from_row + kBdptRowHeader; ++q) {
+      const uint4 t = row[q];
+      const uint32_t j = (q << 2u) - kBdptRowHeader;  // 1, 5, 9, ...
+      put(t.x);
+      if (j + 1u < from_row)
+        put(t.y);
+      if (j + 2u < from_row)
+        put(t.z);
+      if (j + 3u < from_row)
+        put(t.w);
+    }
+    // ... and of the chunks, newest first: [0] the previous chunk, then kPathChunkEntries entries (all but the newest are full)
+    if (length > row_entries) {
+      uint32_t remaining = length - row_entries;
+      uint32_t in_chunk = ((remaining - 1u) % kPathChunkEntries) + 1u;
+      uint32_t chunk = header.x;
+      while ((remaining != 0u) && (chunk < p.path_chunk_capacity)) {
+        const uint4* c = reinterpret_cast<const uint4*>(p.path_chunks + size_t(chunk) * kPathChunkWords);
+        const uint4 t0 = c[0];
+        put(t0.y);
+        if (in_chunk > 1u)
+          put(t0.z);
+        if (in_chunk > 2u)
+          put(t0.w);
+        for (uint32_t q = 1; (q << 2u) - 1u < in_chunk; ++q) {
+          const uint4 t = c[q];
+          const uint32_t position = (q << 2u) - 1u;  // 3, 7, 11, ...
+          put(t.x);
+          if (position + 1u < in_chunk)
+            put(t.y);
+          if (position + 2u < in_chunk)
+            put(t.z);
+          if (position + 3u < in_chunk)
+            put(t.w);
+        }
+        remaining -= in_chunk;
+        in_chunk = kPathChunkEntries;
+        chunk = t0.x;
+      }
+    }
   }
 }
 
-// The pairs with a vertex of another shading group, through the out-of-line BSDF dispatch. They are few (the vertices on the
-// non-Lambert lobes of the scene) and scattered over the pair list; a kernel that took them where they stand paid a whole
-// wavefront of this register-heavy code for one or two live lanes. Each workgroup therefore collects the indices of its general
-// pairs in LDS while it streams over its part of the list and evaluates them 256 at a time, all lanes busy.
-__global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs_general(Pipeline p, VcmParams it) {
+// One pair per lane over one of the two lists: kGeneral = false the pairs of two vertices of simple classes (inline Lambert / phase-function code; every pair of a
+// scene of simple materials), true the pairs with a vertex of a general class (out-of-line BSDF library) - dense, so every lane of the register-heavy code has a pair.
+template <bool kGeneral>
+__global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_pairs(Pipeline p, VcmParams it) {
   __shared__ BlockScratch s_scratch;
-  __shared__ uint32_t s_queue[2u * kBlockSize];
-  __shared__ uint32_t s_queued;
   const DScene& scene = p.scene;
-  const uint32_t count = pair_list_count(p);
-  if (threadIdx.x == 0u)
-    s_queued = 0u;
-  __syncthreads();
-  auto evaluate = [&](bool live, uint32_t index) {  // workgroup-uniform call
+  const uint32_t front = p.counters[kCntPairs], back = p.counters[kCntPairsGeneral];
+  if ((kGeneral == false) && (blockIdx.x == 0u) && (threadIdx.x == 0u) && ((front > p.pair_capacity) || (back > p.pair_capacity) || (front + back > p.pair_capacity)))
+    atomicOr(p.counters + kCntOverflow, kOverflowPairs);  // the two lists met: the iteration is discarded, the pool grows, it is rendered again
+  const uint32_t count = min(kGeneral ? back : front, p.pair_capacity);
+  ETX_BLOCK_LOOP(count, i) {
     ShadowRequest request;
     bool queue = false;
-    if (live)
-      queue = bdpt_connect_pair<false>(p, scene, it, p.pairs[index], request);
+    if (i < count) {
+      const uint2 pair = p.pairs[kGeneral ? (p.pair_capacity - 1u - i) : i];
+      if (bdpt_pair_connects(p, scene, pair))
+        queue = bdpt_connect_pair<kGeneral == false>(p, scene, it, pair, request);
+    }
     const uint32_t slot = block_compact_slot(queue, p.counters + kCntShadow, s_scratch);
     if (queue)
       write_shadow(p, slot, request);
-  };
-  ETX_BLOCK_LOOP(count, i) {
-    bool mine = false;
-    if (i < count) {
-      const BdptPairClass c = bdpt_pair_class(p, scene, p.pairs[i]);
-      mine = c.connects && c.general;
-    }
-    const unsigned long long mask = __ballot(mine);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32u), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-    uint32_t base = 0u;
-    if (((threadIdx.x & 63u) == 0u) && (mask != 0ull))
-      base = atomicAdd(&s_queued, uint32_t(__popcll(mask)));
-    base = __shfl(base, 0);
-    if (mine)
-      s_queue[base + rank] = i;
-    __syncthreads();
-    const uint32_t queued = s_queued;  // < 2 x 256: at most 255 were left over, at most 256 came in
-    __syncthreads();
-    if (queued >= kBlockSize) {  // workgroup-uniform
-      const uint32_t index = s_queue[queued - kBlockSize + threadIdx.x];
-      __syncthreads();
-      if (threadIdx.x == 0u)
-        s_queued = queued - kBlockSize;
-      evaluate(true, index);  // ends with a barrier (block_compact_slot)
-    }
   }
-  __syncthreads();
-  const uint32_t rest = s_queued;
-  if (rest != 0u)  // workgroup-uniform
-    evaluate(threadIdx.x < rest, (threadIdx.x < rest) ? s_queue[threadIdx.x] : 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1338,17 +1398,15 @@ void launch_bdpt_camera_shade(hipStream_t stream, const Pipeline& p, const VcmPa
 void launch_bdpt_connect_light(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, uint32_t variant) {
   ETX_BDPT_LAUNCH(k_bdpt_connect_light, max(1u, grid_for(min(p.capacity, max_items))), p, it);
 }
-// Vertex connections. A scene of simple materials: one kernel; otherwise the pairs of two simple vertices go through the inline
-// Lambert / phase-function kernel and only the others through the general one (both run over the pair list and take their class).
+// Vertex connections: the expansion into the two pair lists, then one kernel per list (the general one only where a general class exists)
+void launch_bdpt_expand_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
+  hipLaunchKernelGGL(k_bdpt_expand_pairs, dim3(max(1u, grid_for(min(max_items, p.capacity)))), dim3(kBlockSize), 0, stream, p, it);
+}
 void launch_bdpt_connect_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items, uint32_t variant) {
   const uint32_t pair_blocks = max(1u, grid_for(uint32_t(min(uint64_t(max_items) * 8ull, uint64_t(p.pair_capacity)))));
-  if (variant == kBdptKernelsSimple) {
-    hipLaunchKernelGGL(k_bdpt_connect_pairs<false>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
-  } else {
+  hipLaunchKernelGGL(k_bdpt_connect_pairs<false>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
+  if (variant != kBdptKernelsSimple)
     hipLaunchKernelGGL(k_bdpt_connect_pairs<true>, dim3(pair_blocks), dim3(kBlockSize), 0, stream, p, it);
-    // fewer, fatter workgroups: each collects its general pairs over a long stretch of the list
-    hipLaunchKernelGGL(k_bdpt_connect_pairs_general, dim3(max(1u, min(pair_blocks, 512u))), dim3(kBlockSize), 0, stream, p, it);
-  }
 }
 
 }  // namespace etxd

@@ -29,8 +29,8 @@ ETX_DEV bool material_is_diffuse(const DScene& scene, uint32_t tri) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // (camera vertex, light path) -> pairs
-// kVcmRecords: the camera vertex records are VCM's (pos_info.w holds kCv* flags); the bidirectional kernels keep the previous
-// vertex' flags in that word (dev_bdpt.h)
+// kVcmRecords: the camera vertex records are VCM's (pos_info.w holds kCv* flags). (The bidirectional integrator has an expansion of its own since round 6:
+// k_bdpt_expand_pairs, kernels_bdpt.hip - two lists by BSDF class, chunked index lists instead of the `next` links.)
 template <bool kVcmRecords>
 __global__ __launch_bounds__(kBlockSize) void k_expand_pairs(Pipeline p, VcmParams it) {
   __shared__ uint32_t s_wave_total[kBlockSize / 64u];
@@ -181,10 +181,6 @@ void launch_connect_endpoints(hipStream_t stream, const Pipeline& p, const VcmPa
     hipLaunchKernelGGL(k_connect_endpoints<true>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
   else
     hipLaunchKernelGGL(k_connect_endpoints<false>, dim3(blocks), dim3(kBlockSize), 0, stream, p, it);
-}
-
-void launch_expand_pairs(hipStream_t stream, const Pipeline& p, const VcmParams& it, uint32_t max_items) {
-  hipLaunchKernelGGL(k_expand_pairs<false>, dim3(max(1u, grid_for(min(max_items, p.capacity)))), dim3(kBlockSize), 0, stream, p, it);  // bidirectional records
 }
 
 void launch_connect(hipStream_t stream, const Pipeline& p, const VcmParams& it, bool generic_materials, uint32_t max_items) {

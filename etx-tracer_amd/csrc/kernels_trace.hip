@@ -27,6 +27,7 @@ ETX_DEV void round_housekeeping(uint32_t* __restrict__ counters, uint32_t active
     atomicAdd(reinterpret_cast<unsigned long long*>(counters + kStatCameraVertices), (unsigned long long)counters[kCntCameraVertices]);
   counters[kCntCameraVertices] = 0u;
   counters[kCntPairs] = 0u;
+  counters[kCntPairsGeneral] = 0u;
   counters[kCntShadow] = 0u;
   counters[kCntMergeVertices] = 0u;
   counters[kCntEndpoints] = 0u;

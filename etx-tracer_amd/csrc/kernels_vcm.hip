@@ -68,8 +68,8 @@ __global__ __launch_bounds__(kBlockSize) void k_iteration_reset(Pipeline p) {
   }
   if (tid < kBlockStatRows * kBlockStatCount)
     p.block_stats[tid] = 0ull;
-  for (uint32_t i = tid; i < p.capacity; i += stride)  // head = none, length 0 (the first two words of every path's table row)
-    *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(p.light_path_table) + size_t(i) * p.path_table_entries) = make_uint2(kInvalid, 0u);
+  for (uint32_t i = tid; i < p.capacity; i += stride)  // head (bidirectional: newest chunk) = none, length 0, (bidirectional: vertices of general classes) 0: the header of every path's table row
+    p.light_path_table[size_t(i) * (p.path_table_entries >> 2u)] = make_uint4(kInvalid, 0u, 0u, 0u);
 }
 
 void launch_iteration_reset(hipStream_t stream, const Pipeline& p) {

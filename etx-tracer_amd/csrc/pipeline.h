@@ -119,7 +119,15 @@ constexpr uint32_t kPathTableEntries = 32;         // Pipeline::path_table_entri
                                                    // table (16-byte loads) and WALKS the list beyond it, one dependent gather per vertex - a wavefront waits for its longest path. Fog box
                                                    // (3.8 vertices per path, long tail): 8 entries 101.7, 16 103.0, 32 103.9 Msamples/s (profiles/round4_ab_medium_rows_and_path_table.txt)
 constexpr uint32_t kPathTableEntriesWalk = 32;     // ... with: a light path that walked through an object has a vertex per scattering event
-constexpr uint32_t kPathRowHeader = 2;             // words 0 / 1 of a path's table row: head, length
+constexpr uint32_t kPathRowHeader = 2;             // words 0 / 1 of a path's table row: head, length (VCM records)
+// The bidirectional integrator's rows: [0] the path's newest overflow chunk (kInvalid = none), [1] vertices stored so far, [2] how many of them are of a general BSDF class,
+// then the path's first path_table_entries - 3 vertices: pool index | kPathEntryGeneralBit. Vertices beyond the row go to CHUNKS of kPathChunkWords words (Pipeline::path_chunks:
+// [0] the previous chunk, then 31 entries) - k_bdpt_expand_pairs reads a path's vertices with independent 16-byte loads however long the path is (until round 5 it walked the
+// vertices' `prev` links beyond the row, one dependent gather per vertex: a light path that crossed a subsurface object has a vertex per scattering event, up to 1024 per walk).
+constexpr uint32_t kBdptRowHeader = 3;
+constexpr uint32_t kPathChunkWords = 32;
+constexpr uint32_t kPathChunkEntries = kPathChunkWords - 1u;
+constexpr uint32_t kPathEntryGeneralBit = 0x80000000u;
 constexpr uint32_t kMergeBucketBits = 6;                                  // per axis
 constexpr uint32_t kMergeBuckets = 1u << (3u * kMergeBucketBits);         // 64^3 coarse buckets
 
@@ -150,6 +158,8 @@ enum : uint32_t {
   kCntEndpoints = 608,       // endpoint connection requests of the current bounce, cleared per bounce
   kCntNonFinite = 640,
   kCntLightBounceBegin = 800, // BDPT: light vertex count when the current bounce began (k_bdpt_connect_camera covers [begin, count))
+  kCntPairsGeneral = 802,     // BDPT: pairs with a vertex of a general BSDF class, listed from the BACK of the pair buffer (kCntPairs counts the others, from the front); cleared per bounce
+  kCntPathChunks = 803,       // BDPT: chunks of the light paths' overflow index lists handed out in this iteration (Pipeline::path_chunks)
   kCntDynMedium = 801,        // BDPT: per-walk medium rows appended in this iteration (DScene::sss_dynamic_media; one atomic per wavefront, shares a line with a word written once per bounce)
   kStatRaysLight = 672,      // u64 statistics: closest-hit rays of the light pass / camera pass, pair connections, endpoint connections
   kStatRaysCamera = 704,
@@ -233,6 +243,8 @@ struct Pipeline {  // everything a kernel needs, passed by value (fits the kerna
                                // from the head). Head and length lived in arrays of their own until round 5: storing a vertex then dirtied three cache lines in three
                                // allocations with 4-byte writes (each a read-modify-write of its line in L2: PMC showed k_light_shade writing 1.6x and the bidirectional
                                // light shading 2.2x its algorithmic bytes) and k_expand_pairs gathered from all three per camera vertex. One row = one line.
+  uint32_t* path_chunks;        // BDPT: overflow chunks of the light paths' index lists (kPathChunkWords words each), one pool per lane
+  uint32_t path_chunk_capacity;
   uint32_t path_table_entries; // words per row: kPathTableEntries or kPathTableEntriesWalk (a multiple of four; two of them are the header)
   PhotonGrid grid;
   GridParams* grid_params;

@@ -41,12 +41,14 @@ def test_kernel_register_budget():
         assert k["total_vgprs"] <= 128 and k["scratch"] == 0 and k["vgpr_spills"] == 0, (name, k)
     # (<true, 0u>: scenes of simple classes, every item; <true, 1u>: the inline part of a mixed scene, which hands the items of general classes to a list - round 6)
     for name in ("void etxd::k_bdpt_light_shade<true, 0u>", "void etxd::k_bdpt_camera_shade<true, 0u>", "void etxd::k_bdpt_light_shade<true, 1u>", "void etxd::k_bdpt_camera_shade<true, 1u>",
-                 "void etxd::k_bdpt_connect_pairs<false>", "void etxd::k_bdpt_connect_pairs<true>", "void etxd::k_bdpt_connect_light<true, 0u>", "void etxd::k_bdpt_connect_camera<true, 0u>",
+                 "void etxd::k_bdpt_connect_pairs<false>", "void etxd::k_bdpt_connect_light<true, 0u>", "void etxd::k_bdpt_connect_camera<true, 0u>",
                  "void etxd::k_bdpt_connect_light<true, 1u>", "void etxd::k_bdpt_connect_camera<true, 1u>", "void etxd::k_bdpt_walk_exit_light<true>", "void etxd::k_bdpt_walk_exit_camera<true>"):
         k = kernels[name]
         assert k["total_vgprs"] <= 184 and k.get("agprs", 0) == 0 and k["vgpr_spills"] == 0 and k["scratch"] <= 32, (name, k)
     general = [k for name, k in kernels.items() if ("<1u" in name) or ("<2u" in name) or name.endswith("k_merge_eval_generic") or ("k_connect_endpoints" in name) or
-               name.endswith("k_connect_pairs<false>")]
+               name.endswith("etxd::k_connect_pairs<false>") or name.endswith("k_bdpt_connect_pairs<true>")]  # (k_bdpt_connect_pairs<kGeneral>: <true> = the dense list of general pairs, round 6)
+    k = kernels["etxd::k_bdpt_expand_pairs"]
+    assert k["total_vgprs"] <= 48 and k["scratch"] == 0, k
     assert len(general) >= 6
     # round 6: the filter half of the generic merge carries no BSDF code (it runs at full occupancy); the matrix-core sweep keeps its results in VGPRs
     k = kernels["etxd::k_merge_filter_generic"]

@@ -32,7 +32,7 @@ BDPT_GROUPS = {
     "trace_shadow": ("k_trace_shadow",),
     "shade_light": ("k_bdpt_light_shade", "k_bdpt_walk_light", "k_bdpt_walk_exit_light", "k_bdpt_connect_camera"),
     "shade_camera": ("k_bdpt_camera_shade", "k_bdpt_walk_camera", "k_bdpt_walk_exit_camera", "k_bdpt_connect_light"),
-    "connect": ("k_expand_pairs", "k_bdpt_connect_pairs"),
+    "connect": ("k_bdpt_expand_pairs", "k_expand_pairs", "k_bdpt_connect_pairs"),
 }
 # the unit of work of a group = which per-step count of the bench line (`counters.units_per_step`) it is divided by
 GROUP_UNITS = {"trace_closest": "rays_extension", "trace_shadow": "rays_shadow", "shade_light": "rays_light", "shade_camera": "rays_camera", "connect": "pairs",
