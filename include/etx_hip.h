@@ -243,7 +243,7 @@ typedef struct etx_hip_stats_t {
   /* more totals since etx_hip_begin (the units the per-kernel rooflines of bench.py are computed from) */
   uint64_t rays_light;           /* closest-hit rays of the light pass */
   uint64_t rays_camera;          /* closest-hit rays of the camera pass (PT: all rays) */
-  uint64_t pairs;                /* (camera vertex, light vertex) connections evaluated */
+  uint64_t pairs;                /* (camera vertex, light vertex) pairs listed for connection (bidirectional integrator, since round 6: without the emitter's own vertex, which connects to nothing) */
   uint64_t endpoints;            /* endpoint connections of the general / subsurface shading groups (k_connect_endpoints) */
   /* adaptive sampling (path tracing with Scene::noise_threshold > 0: Film::estimate_noise_levels / active_pixel) */
   uint64_t active_pixels;        /* pixels sampled, total since etx_hip_begin */
