@@ -292,6 +292,8 @@ ETX_DEV void bdpt_store_light_vertex(const Pipeline& p, uint32_t idx, uint32_t p
   const bool general = (flags & kBvGeneralBsdf) != 0u;
   const uint32_t entry = idx | (general ? kPathEntryGeneralBit : 0u);
   const uint32_t row_entries = p.path_table_entries - kBdptRowHeader;
+  if (row[1] != index_in_path)
+    return;  // the list was cut (a chunk could not be had: the iteration is being discarded); it stays as long as what it holds
   if (index_in_path < row_entries) {
     row[kBdptRowHeader + index_in_path] = entry;
   } else {

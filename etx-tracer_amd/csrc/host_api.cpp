@@ -297,7 +297,7 @@ size_t pool_bytes_for(const etx_hip_context::PoolSizes& z, bool with_grid) {
     bytes += size_t(next_pow2(z.light_vertices)) * 4u + size_t(z.light_vertices) * (1u + PhotonGrid::kPhotonStride) * sizeof(float4);
   bytes += size_t(z.camera_vertices) * (7u * sizeof(float4) + 3u * 4u);
   bytes += size_t(z.pairs) * sizeof(uint2) + size_t(z.shadow) * 3u * sizeof(float4) + size_t(z.endpoints) * (5u * sizeof(float4) + 4u);
-  bytes += (size_t(z.light_vertices) / 15u + 1u) * kPathChunkWords * sizeof(uint32_t);  // path_chunks
+  bytes += (size_t(z.light_vertices) / kPathChunkEntries + size_t(z.light_vertices) / (kPathTableEntries - kBdptRowHeader + 1u) + 1u) * kPathChunkWords * sizeof(uint32_t);  // path_chunks
   return bytes;
 }
 
@@ -325,8 +325,8 @@ int allocate_pools(etx_hip_context* ctx, const etx_hip_context::PoolSizes& sizes
   if ((rc = pool_alloc(ctx, p.pairs, p.pair_capacity)))
     return rc;
   // overflow chunks of the bidirectional light paths' index lists (pipeline.h kBdptRowHeader): a path beyond its row takes one chunk per 31 vertices and leaves at most one
-  // partly filled - lv / 31 + lv / 30 chunks can never run out before the vertex pool does
-  p.path_chunk_capacity = p.lv.capacity / 15u + 1u;
+  // partly filled, and only a path of more vertices than its row holds takes any - lv / 31 + lv / (row entries + 1) chunks can never run out before the vertex pool does
+  p.path_chunk_capacity = p.lv.capacity / kPathChunkEntries + p.lv.capacity / (p.path_table_entries - kBdptRowHeader + 1u) + 1u;
   if ((rc = pool_alloc(ctx, p.path_chunks, size_t(p.path_chunk_capacity) * kPathChunkWords)))
     return rc;
   p.shadow.capacity = sizes.shadow;
@@ -398,7 +398,7 @@ int allocate_pipeline(etx_hip_context* ctx) {
     return rc;
   // a light path that walks through a subsurface object under the bidirectional integrator stores a vertex per scattering event: a longer
   // table keeps k_expand_pairs off the per-lane list walk (configs[3]: 181 us per launch with eight entries)
-  p.path_table_entries = etxh::tuning_knob("ETX_HIP_PATH_TABLE", ctx->scene.has_subsurface ? kPathTableEntriesWalk : kPathTableEntries) & ~3u;
+  p.path_table_entries = std::max(8u, etxh::tuning_knob("ETX_HIP_PATH_TABLE", ctx->scene.has_subsurface ? kPathTableEntriesWalk : kPathTableEntries) & ~3u);  // (>= 8: the weights of BDPTFast read a path's first two entries from its row)
   if ((rc = device_alloc(ctx, p.light_path_table, size_t(n) * (p.path_table_entries / 4u))))
     return rc;
   p.grid = {};

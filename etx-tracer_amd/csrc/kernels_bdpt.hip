@@ -1161,6 +1161,8 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_connect_light(Pipeline p, V
 // mis_weight_camera_to_light_path (:1184-1209)
 // Whether a listed pair takes part at all (k_bdpt_expand_pairs lists every vertex of the light path but the emitter's; the class of the pair is the list it is on)
 ETX_DEV bool bdpt_pair_connects(const Pipeline& p, const DScene& scene, const uint2 pair) {
+  if ((pair.x >= p.cv_capacity) || (pair.y >= p.lv.capacity))
+    return false;  // a slot of an overflowed (discarded) iteration's lists that nobody wrote: whatever the freshly grown buffer held
   const uint32_t y_flags = __float_as_uint(p.lv.thr_dvm(pair.y).w);
   const uint32_t light_s = __float_as_uint(p.lv.bc_len_med(pair.y).z) >> 16u;
   const uint32_t z_word = __float_as_uint(p.cv.thr_depth[pair.x].w);
