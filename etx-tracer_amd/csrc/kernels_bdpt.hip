@@ -503,7 +503,10 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
 #define ETX_WALK_BUDGET 32u
 #endif
 constexpr uint32_t kWalkRefill = ETX_WALK_REFILL;
-constexpr uint32_t kWalkBlocks = 1024u;
+#if !defined(ETX_WALK_BLOCKS)
+#define ETX_WALK_BLOCKS 1024u
+#endif
+constexpr uint32_t kWalkBlocks = ETX_WALK_BLOCKS;
 // Scattering events a walk gets per round. Most walks leave their object after a few events, a few take hundreds (the reference
 // allows 1024, :776): a kernel that ran every walk of a bounce to its end lasted as long as its longest walk (measured 7 ms per
 // launch, 100 ms per iteration, with nearly all lanes idle). A walk that is still inside after its budget goes to the other walk
