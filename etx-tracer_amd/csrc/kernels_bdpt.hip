@@ -503,8 +503,10 @@ __global__ __launch_bounds__(kBlockSize) void k_bdpt_light_shade(Pipeline p, Vcm
 #define ETX_WALK_BUDGET 32u
 #endif
 constexpr uint32_t kWalkRefill = ETX_WALK_REFILL;
+// (256, one per CU: each workgroup holds 40 KB of LDS for its whole, persistent life; four per CU filled every CU's LDS and kept the other lanes' traversal kernels out -
+// configs[3], six lanes: 2048 workgroups 38.5, 1024 38.8, 512 39.4, 256 40.2 Msamples/s, profiles/round6_ab_walk_blocks.txt)
 #if !defined(ETX_WALK_BLOCKS)
-#define ETX_WALK_BLOCKS 1024u
+#define ETX_WALK_BLOCKS 256u
 #endif
 constexpr uint32_t kWalkBlocks = ETX_WALK_BLOCKS;
 // Scattering events a walk gets per round. Most walks leave their object after a few events, a few take hundreds (the reference

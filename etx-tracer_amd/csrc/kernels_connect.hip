@@ -649,17 +649,21 @@ __global__ __launch_bounds__(kBlockSize) void k_merge_eval_generic(Pipeline p, V
         }
       }
     }
-    // the pairs of a vertex are neighbours in the list (one flush of the filter's ring holds a vertex' photons back to back): fold each run of
-    // equal vertices into its first lane, one set of film atomics per run
-#pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-      const uint32_t other = __shfl_down(vertex, d);
-      const float ox = __shfl_down(value.x, d), oy = __shfl_down(value.y, d), oz = __shfl_down(value.z, d);
-      if ((lane_ + d < 64u) && (other == vertex))
-        value.x += ox, value.y += oy, value.z += oz;
-    }
+    // the pairs of a vertex are neighbours in the list (one flush of the filter's ring holds a vertex' photons back to back): fold each RUN of equal
+    // vertices into its first lane, one set of film atomics per run. Runs, not vertices: two flushes of one vertex may sit in one wavefront with another
+    // vertex' pairs between them (the first version compared vertex indices across the distance d and counted such a second run twice - once folded into
+    // the first run's head across the gap, once by its own head: one pixel in 25 000 off by one contribution, tests/test_gpu_pixel_sharding.py caught it)
     const uint32_t before = __shfl_up(vertex, 1);
     const bool head = (lane_ == 0u) || (before != vertex);
+    const unsigned long long heads = __ballot(head);
+    const uint32_t run = uint32_t(__popcll(heads & (~0ull >> (63u - lane_))));  // heads at or before this lane: equal only within one contiguous run
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint32_t other = __shfl_down(run, d);
+      const float ox = __shfl_down(value.x, d), oy = __shfl_down(value.y, d), oz = __shfl_down(value.z, d);
+      if ((lane_ + d < 64u) && (other == run))
+        value.x += ox, value.y += oy, value.z += oz;
+    }
     if (head && (vertex != kInvalid) && ((value.x != 0.0f) || (value.y != 0.0f) || (value.z != 0.0f)))
       film_add(p, p.camera_sum + film_index(it, pixel), value * it.vm_normalization);
   }
