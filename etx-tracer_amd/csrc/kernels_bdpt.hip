@@ -6,10 +6,10 @@
 //   k_bdpt_camera_generate                                  build_camera_path, start             (:900-953)
 //   loop: k_trace_closest ; k_bdpt_camera_shade ;           build_path, Camera mode + direct hits (:1235-1340)
 //         k_bdpt_connect_light ;                            connect_camera_to_light              (:1342-1378)
-//         k_expand_pairs ; k_bdpt_connect_pairs ;           connect_camera_to_light_path         (:438-497, MIS :1184-1209)
+//         k_bdpt_expand_pairs ; k_bdpt_connect_pairs ;      connect_camera_to_light_path         (:438-497, MIS :1184-1209)
 //         k_trace_shadow
 //   k_vcm_commit                                            Film::commit_light_iteration + the iteration's camera estimate
-// dev_bdpt.h explains the data layout. All BSDF classes go through the out-of-line dispatch (dev_bsdf_ool.h).
+// dev_bdpt.h explains the data layout. Scenes of simple BSDF classes run inline instantiations, mixed scenes split their items by class (kPartSimple / kPartGeneral).
 #include "kernels.h"
 #include "dev_bdpt.h"
 
