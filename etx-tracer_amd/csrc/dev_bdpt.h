@@ -12,7 +12,7 @@
 //   camera pass  the path state carries (previous vertex summary, mis_history, pdf_dir); direct emitter hits are resolved
 //                in the step (no visibility query involved); every connectible vertex goes to the camera vertex pool with
 //                its previous-vertex summary; next event estimation (connect_camera_to_light :1342-1378, k_bdpt_connect_light)
-//                and the vertex connections (connect_camera_to_light_path :438-497, k_expand_pairs + k_bdpt_connect_pairs)
+//                and the vertex connections (connect_camera_to_light_path :438-497, k_bdpt_expand_pairs + k_bdpt_connect_pairs)
 //                read it there; visibility goes through the shadow queue like every other connection.
 // Modes (CPUBidirectionalImpl::Mode :323-330): PathTracing, LightTracing, BDPTFast (the reference's default: no vertex
 // connections, product-form weights), BDPTFull. Random-walk subsurface materials: the reference threads the walk's medium vertices through
